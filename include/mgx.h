@@ -1,0 +1,153 @@
+/*
+ * mgx.h -- C ABI of the MI355X-native batched microgrid-step engine (libmgx.so).
+ *
+ * The reference (Total-RD/pymgrid v1.2.2) is pure Python and has NO FFI: its boundary for this hot path is
+ * the Gym surface  DiscreteMicrogridEnv.step / BaseMicrogridEnv.step / reset
+ * (src/pymgrid/envs/discrete/discrete.py:109-143, src/pymgrid/envs/base/base.py:165-209) over
+ * Microgrid.run / Microgrid.reset (src/pymgrid/microgrid/microgrid.py:227-325, :205-219).
+ * This header is what a binding for that path would bind (INTEGRATION.md shows the ctypes stub): every
+ * entry point below names the reference interface it replaces.  Plain C types only -- no torch, no HIP
+ * types in the signatures (a stream is passed as void*, it is a hipStream_t).
+ *
+ * Conventions
+ *  - N microgrids ("grids") advance in lock-step; all share the step counter t, the series length T and
+ *    the episode window [initial_step, final_step).
+ *  - Every pointer in mgx_columns and every data argument is a DEVICE pointer owned by the caller
+ *    (e.g. torch tensors); the library allocates only a small scratch buffer in mgx_create.
+ *  - All arithmetic is IEEE fp64, unfused (no FMA contraction), in the reference's operation order.
+ *  - Calls are asynchronous on the given stream and must be issued from one host thread per handle.
+ *  - Return value: MGX_OK or an error code; mgx_last_error() gives a thread-local message.
+ *
+ * Column layouts (struct-of-arrays, grid index fastest):
+ *    parameter / state columns   [N]
+ *    load_ts, pv_ts              [T, N]     sign as the reference STORES it: load <= 0, pv >= 0
+ *                                           (base_timeseries_module.py:68-79)
+ *    grid_ts                     [T, 4, N]  components import_price, export_price, co2_per_kwh, grid_status
+ *                                           (grid_module.py:70)
+ *    actions                     [N, A]     A = 2*has_genset + has_battery + has_grid, order
+ *                                           genset(goal_status, energy), battery, grid = the reference's
+ *                                           controllable sweep order (module_container.py:355-413)
+ *    obs                         [N, D]     D = mgx_obs_dim(); order load(1+H), pv(1+H), genset(4), battery(2),
+ *                                           grid(4*(1+H), component-minor)
+ *    log                         [L, N]     L = mgx_log_dim(); names from mgx_log_name()
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_ABI_VERSION 1
+
+enum mgx_status {
+    MGX_OK = 0,
+    MGX_ERR_INVALID = 1,      /* bad argument / inconsistent layout */
+    MGX_ERR_UNSUPPORTED = 2,  /* valid in the reference, not offered on device */
+    MGX_ERR_RANGE = 3,        /* step counter would leave the time series (IndexError in the reference) */
+    MGX_ERR_DEVICE = 4        /* HIP runtime error (message holds hipGetErrorString) */
+};
+
+typedef struct mgx_handle mgx_handle;
+typedef void *mgx_stream;     /* hipStream_t */
+
+/* Static shape of the batch.  Replaces the module list handed to Microgrid.__init__ (microgrid.py:100-128). */
+typedef struct mgx_layout {
+    int32_t struct_size;      /* = sizeof(mgx_layout), ABI guard */
+    int32_t n_grids;          /* N */
+    int32_t n_steps;          /* T, rows of every time series */
+    int32_t horizon;          /* forecast_horizon H of the (oracle) forecaster, 0 = no forecast */
+    int32_t initial_step;     /* base_module.py:40 */
+    int32_t final_step;       /* resolved as base_timeseries_module.py:317-330 does: <=0 means T */
+    int32_t has_genset;       /* 0/1 GensetModule  */
+    int32_t has_battery;      /* 0/1 BatteryModule */
+    int32_t has_grid;         /* 0/1 GridModule    */
+    int32_t n_load;           /* LoadModule count      (device path: 1) */
+    int32_t n_pv;             /* RenewableModule count (device path: 1) */
+} mgx_layout;
+
+/* Device columns.  Pointers for absent modules may be NULL. */
+typedef struct mgx_columns {
+    int32_t struct_size;      /* = sizeof(mgx_columns) */
+    int32_t reserved;
+    /* BatteryModule parameters (battery_module.py:66-93) */
+    const double *bat_min_capacity, *bat_max_capacity, *bat_max_charge, *bat_max_discharge;
+    const double *bat_efficiency, *bat_cost_cycle;
+    /* GensetModule parameters (genset_module.py:61-98) */
+    const double *gen_running_min, *gen_running_max, *gen_cost, *gen_co2_per_unit, *gen_cost_per_unit_co2;
+    const uint32_t *gen_times;            /* start_up_time | wind_down_time << 16 (each <= 255) */
+    /* GridModule parameters (grid_module.py:72-101) */
+    const double *grid_max_import, *grid_max_export, *grid_cost_per_unit_co2;
+    /* UnbalancedEnergyModule parameters (unbalanced_energy_module.py:11-26) */
+    const double *loss_load_cost, *overgeneration_cost;
+    /* time series */
+    const double *load_ts, *pv_ts, *grid_ts;
+    /* observation bounds (needed only when observations are requested):
+     * base_timeseries_module.py:81-88 (load/pv: min(ts.min(),0), max(ts.max(),0)), grid_module.py:125-132 */
+    const double *load_lo, *load_hi, *pv_lo, *pv_hi;      /* [N] */
+    const double *grid_lo, *grid_hi;                      /* [4, N] */
+    /* dynamic state, read and written by every step */
+    double *charge, *soc;                 /* BatteryModule._current_charge / _soc */
+    uint32_t *gen_status;                 /* current | goal<<8 | steps_until_up<<16 | steps_until_down<<24 */
+} mgx_columns;
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+int mgx_abi_version(void);
+/* thread-local text of the last error returned on this thread ("" if none) */
+const char *mgx_last_error(void);
+
+/* Microgrid.__init__ (microgrid.py:100-128): bind a layout + columns.  The step counter starts at
+ * layout->initial_step. */
+int mgx_create(const mgx_layout *layout, const mgx_columns *columns, mgx_handle **out);
+void mgx_destroy(mgx_handle *h);
+
+/* ---- shape queries -------------------------------------------------------------------------------- */
+int32_t mgx_action_dim(const mgx_handle *h);
+int32_t mgx_obs_dim(const mgx_handle *h);
+int32_t mgx_log_dim(const mgx_handle *h);
+const char *mgx_log_name(const mgx_handle *h, int32_t column);   /* NULL if out of range */
+int32_t mgx_current_step(const mgx_handle *h);                   /* BaseMicrogridModule.current_step */
+
+/* ---- the hot path --------------------------------------------------------------------------------- */
+/* Microgrid.reset (microgrid.py:205-219) -> BaseMicrogridModule.reset (base_module.py:65-77): the step counter
+ * returns to initial_step (or to `initial_step` if >= 0: the trajectory_func hook, microgrid.py:221-225);
+ * battery charge and genset status are NOT touched (the reference does not restore them).
+ * obs [N, D] may be NULL. */
+int mgx_reset(mgx_handle *h, int32_t initial_step, double *obs, mgx_stream stream);
+
+/* Normalised observation of the current state (BaseMicrogridModule.to_normalized(state), base_module.py:157;
+ * forecast window + end-of-series padding forecaster.py:120-149,215-217). */
+int mgx_observe(mgx_handle *h, double *obs, mgx_stream stream);
+
+/* ONE Microgrid.run(control, normalized) for all N grids (microgrid.py:227-325), as BaseMicrogridEnv.step
+ * returns it (base.py:169-209): reward [N], done [N] (0/1), optional post-step obs [N, D] and log [L, N].
+ * The step counter advances by one.  MGX_ERR_RANGE if the counter is already outside the series. */
+int mgx_step(mgx_handle *h, const double *actions, int normalized,
+             double *reward, uint8_t *done, double *obs, double *log, mgx_stream stream);
+
+/* K consecutive Microgrid.run calls in ONE launch: parameters and state stay in registers, actions
+ * [K, N, A] are streamed.  Outputs (each may be NULL): reward [K, N], done [K, N], soc_trace [K, N],
+ * status_trace [K, N] (post-step packed genset status), ret_acc [N] (+= sum of the K rewards per grid),
+ * log [K, L, N].  Replaces the user loop `for a in actions: env.step(a)` (README.md:109-111). */
+int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized,
+               double *reward, uint8_t *done, double *soc_trace, uint32_t *status_trace,
+               double *ret_acc, double *log, mgx_stream stream);
+
+/* DiscreteMicrogridEnv._get_action -> PriorityListAlgo._populate_action (discrete.py:82-88,
+ * priority_list.py:69-167): expand one priority-list id per grid into an UNNORMALISED control [N, A]
+ * (feed it to mgx_step(..., normalized=0)).  `table` is a HOST array [n_actions, 3, 2] of
+ * (module, action) pairs, module 0 genset / 1 battery / 2 grid, -1 = padding; n_actions <= 12. */
+int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions,
+                        double *control, mgx_stream stream);
+
+/* Column sums over the grids, sums[m] = sum_i values[m*N + i] (deterministic two-stage wavefront-shuffle +
+ * LDS reduction; the "metrics" vector that is all-reduced across GPUs).  M <= 64. */
+int mgx_metrics(mgx_handle *h, const double *values, int32_t M, double *sums, mgx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

@@ -1,0 +1,279 @@
+"""ctypes front-end of the CPU oracle (``oracle/mgx_oracle.c``).
+
+TEST INFRASTRUCTURE -- may be imported only by ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg.  The product package ``pymgrid_amd`` never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libmgx_oracle.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_u32_p = C.POINTER(C.c_uint32)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (no GPU needed)."""
+    src = [os.path.join(_HERE, f) for f in ("mgx_oracle.c", "mgx_oracle.h")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(s) for s in src)):
+        return _LIB_PATH
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return _LIB_PATH
+
+
+class Grid(C.Structure):
+    _fields_ = [
+        ("has_genset", C.c_int32), ("has_battery", C.c_int32), ("has_grid", C.c_int32),
+        ("n_load", C.c_int32), ("n_pv", C.c_int32), ("horizon", C.c_int32), ("T", C.c_int32),
+        ("final_step", C.c_int32),
+        ("bat_min_capacity", C.c_double), ("bat_max_capacity", C.c_double), ("bat_max_charge", C.c_double),
+        ("bat_max_discharge", C.c_double), ("bat_efficiency", C.c_double), ("bat_cost_cycle", C.c_double),
+        ("gen_running_min", C.c_double), ("gen_running_max", C.c_double), ("gen_cost", C.c_double),
+        ("gen_co2_per_unit", C.c_double), ("gen_cost_per_unit_co2", C.c_double),
+        ("gen_start_up_time", C.c_int32), ("gen_wind_down_time", C.c_int32),
+        ("grid_max_import", C.c_double), ("grid_max_export", C.c_double), ("grid_cost_per_unit_co2", C.c_double),
+        ("loss_load_cost", C.c_double), ("overgeneration_cost", C.c_double),
+        ("load_ts", c_double_p), ("load_t_stride", C.c_int64), ("load_m_stride", C.c_int64),
+        ("pv_ts", c_double_p), ("pv_t_stride", C.c_int64), ("pv_m_stride", C.c_int64),
+        ("grid_ts", c_double_p), ("grid_t_stride", C.c_int64), ("grid_c_stride", C.c_int64),
+        ("load_lo", c_double_p), ("load_hi", c_double_p), ("pv_lo", c_double_p), ("pv_hi", c_double_p),
+        ("grid_lo", C.c_double * 4), ("grid_hi", C.c_double * 4),
+    ]
+
+
+class State(C.Structure):
+    _fields_ = [("t", C.c_int32), ("charge", C.c_double), ("soc", C.c_double),
+                ("gen_cur", C.c_int32), ("gen_goal", C.c_int32), ("gen_up", C.c_int32), ("gen_down", C.c_int32)]
+
+
+class Action(C.Structure):
+    _fields_ = [("genset", C.c_double * 2), ("battery", C.c_double), ("grid", C.c_double)]
+
+
+class StepOut(C.Structure):
+    _fields_ = [
+        ("reward", C.c_double), ("done", C.c_int32),
+        ("fixed_provided", C.c_double), ("fixed_absorbed", C.c_double),
+        ("controllable_provided", C.c_double), ("controllable_absorbed", C.c_double),
+        ("overall_provided", C.c_double), ("overall_absorbed", C.c_double),
+        ("load_met", C.c_double), ("renewable_used", C.c_double), ("curtailment", C.c_double),
+        ("loss_load", C.c_double), ("overgeneration", C.c_double), ("unbalanced_reward", C.c_double),
+        ("genset_production", C.c_double), ("genset_co2_production", C.c_double), ("genset_reward", C.c_double),
+        ("gen_cur", C.c_int32), ("gen_goal", C.c_int32), ("gen_up", C.c_int32), ("gen_down", C.c_int32),
+        ("discharge_amount", C.c_double), ("charge_amount", C.c_double), ("battery_reward", C.c_double),
+        ("soc_pre", C.c_double), ("charge_pre", C.c_double),
+        ("grid_import", C.c_double), ("grid_export", C.c_double), ("grid_co2_production", C.c_double),
+        ("grid_reward", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class PLElement(C.Structure):
+    _fields_ = [("module", C.c_int32), ("action", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("T", C.c_int32), ("horizon", C.c_int32), ("final_step", C.c_int32),
+        ("has_genset", C.c_int32), ("has_battery", C.c_int32), ("has_grid", C.c_int32),
+        ("bat_min_capacity", c_double_p), ("bat_max_capacity", c_double_p), ("bat_max_charge", c_double_p),
+        ("bat_max_discharge", c_double_p), ("bat_efficiency", c_double_p), ("bat_cost_cycle", c_double_p),
+        ("gen_running_min", c_double_p), ("gen_running_max", c_double_p), ("gen_cost", c_double_p),
+        ("gen_co2_per_unit", c_double_p), ("gen_cost_per_unit_co2", c_double_p),
+        ("gen_times", c_u32_p),
+        ("grid_max_import", c_double_p), ("grid_max_export", c_double_p), ("grid_cost_per_unit_co2", c_double_p),
+        ("loss_load_cost", c_double_p), ("overgeneration_cost", c_double_p),
+        ("load_ts", c_double_p), ("pv_ts", c_double_p), ("grid_ts", c_double_p),
+        ("charge", c_double_p), ("soc", c_double_p), ("gen_status", c_u32_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_obs_dim.restype = C.c_int32
+        L.orc_obs_dim.argtypes = [C.POINTER(Grid)]
+        L.orc_genset_update_status.restype = None
+        L.orc_genset_update_status.argtypes = [C.POINTER(Grid), C.POINTER(State), C.c_double]
+        L.orc_genset_next_status.restype = C.c_int32
+        L.orc_genset_next_status.argtypes = [C.POINTER(State), C.c_int32]
+        L.orc_run.restype = C.c_int
+        L.orc_run.argtypes = [C.POINTER(Grid), C.POINTER(State), C.POINTER(Action), C.c_int, C.POINTER(StepOut)]
+        L.orc_observe.restype = None
+        L.orc_observe.argtypes = [C.POINTER(Grid), C.POINTER(State), c_double_p]
+        L.orc_populate_action.restype = None
+        L.orc_populate_action.argtypes = [C.POINTER(Grid), C.POINTER(State), C.POINTER(PLElement), C.c_int32,
+                                          C.POINTER(Action)]
+        L.orc_np_sum.restype = C.c_double
+        L.orc_np_sum.argtypes = [c_double_p, C.c_int32]
+        L.orc_run_batch.restype = C.c_int64
+        L.orc_run_batch.argtypes = [C.POINTER(Batch), C.c_int32, C.c_int32, c_double_p, C.c_int, c_double_p,
+                                    C.c_int32]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+MODULE_IDS = {"genset": 0, "battery": 1, "grid": 2}
+
+
+class OracleMicrogrid:
+    """One microgrid driven through the C oracle.
+
+    ``params`` is a plain dict (see ``tests/golden/make_goldens.py:extract_params``):
+    load_ts [T, n_load] (stored sign, <=0), pv_ts [T, n_pv], optional grid_ts [T, 4], optional
+    ``battery`` / ``genset`` / ``grid`` sub-dicts, ``unbalanced`` costs, ``horizon``, ``final_step``,
+    ``initial_step`` and the initial dynamic state.
+    """
+
+    def __init__(self, params):
+        p = params
+        self.p = p
+        g = Grid()
+        self._keep = []
+
+        def arr(x, ndim=None):
+            a = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+            self._keep.append(a)
+            return a
+
+        load = arr(p["load_ts"]); pv = arr(p["pv_ts"])
+        if load.ndim == 1: load = arr(load.reshape(-1, 1))
+        if pv.ndim == 1: pv = arr(pv.reshape(-1, 1))
+        g.T = load.shape[0] if load.size else pv.shape[0]
+        g.n_load, g.n_pv = load.shape[1], pv.shape[1]
+        g.horizon = int(p.get("horizon", 0))
+        g.final_step = int(p["final_step"])
+        g.load_ts, g.load_t_stride, g.load_m_stride = _dp(load), load.shape[1], 1
+        g.pv_ts, g.pv_t_stride, g.pv_m_stride = _dp(pv), pv.shape[1], 1
+
+        def bounds(ts):   # base_timeseries_module.py:81-88
+            lo = np.minimum(ts.min(axis=0), 0.0) if ts.size else np.zeros(ts.shape[1])
+            hi = np.maximum(ts.max(axis=0), 0.0) if ts.size else np.zeros(ts.shape[1])
+            return arr(lo), arr(hi)
+        ll, lh = bounds(load); pl, ph = bounds(pv)
+        g.load_lo, g.load_hi, g.pv_lo, g.pv_hi = _dp(ll), _dp(lh), _dp(pl), _dp(ph)
+
+        st = State()
+        st.t = int(p.get("initial_step", 0))
+        if p.get("battery") is not None:
+            b = p["battery"]; g.has_battery = 1
+            for k in ("min_capacity", "max_capacity", "max_charge", "max_discharge", "efficiency"):
+                setattr(g, "bat_" + k, float(b[k]))
+            g.bat_cost_cycle = float(b["battery_cost_cycle"])
+            st.charge, st.soc = float(b["charge"]), float(b["soc"])
+        if p.get("genset") is not None:
+            q = p["genset"]; g.has_genset = 1
+            g.gen_running_min, g.gen_running_max = float(q["running_min_production"]), float(q["running_max_production"])
+            g.gen_cost, g.gen_co2_per_unit = float(q["genset_cost"]), float(q["co2_per_unit"])
+            g.gen_cost_per_unit_co2 = float(q["cost_per_unit_co2"])
+            g.gen_start_up_time, g.gen_wind_down_time = int(q["start_up_time"]), int(q["wind_down_time"])
+            st.gen_cur, st.gen_goal, st.gen_up, st.gen_down = [int(v) for v in q["status"]]
+        if p.get("grid") is not None:
+            q = p["grid"]; g.has_grid = 1
+            g.grid_max_import, g.grid_max_export = float(q["max_import"]), float(q["max_export"])
+            g.grid_cost_per_unit_co2 = float(q["cost_per_unit_co2"])
+            gts = arr(p["grid_ts"])
+            g.grid_ts, g.grid_t_stride, g.grid_c_stride = _dp(gts), 4, 1
+            for c in range(4):   # grid_module.py:125-132
+                g.grid_lo[c], g.grid_hi[c] = gts[:, c].min(), gts[:, c].max()
+        g.loss_load_cost = float(p["unbalanced"]["loss_load_cost"])
+        g.overgeneration_cost = float(p["unbalanced"]["overgeneration_cost"])
+        self.g, self.s = g, st
+        self.obs_dim = lib().orc_obs_dim(C.byref(g))
+
+    # -- reference-like surface --------------------------------------------------------------
+    def run(self, action, normalized=True):
+        """action: dict(genset=[goal, e], battery=x, grid=x) (missing modules ignored)."""
+        a = Action()
+        if self.g.has_genset:
+            a.genset[0], a.genset[1] = float(action["genset"][0]), float(action["genset"][1])
+        if self.g.has_battery:
+            a.battery = float(action["battery"])
+        if self.g.has_grid:
+            a.grid = float(action["grid"])
+        out = StepOut()
+        rc = lib().orc_run(C.byref(self.g), C.byref(self.s), C.byref(a), int(normalized), C.byref(out))
+        if rc == -1:
+            raise RuntimeError("Microgrid modules unable to balance energy production with consumption.")
+        if rc != 0:
+            raise IndexError("step outside the time series")
+        return out
+
+    def observe(self):
+        obs = np.empty(self.obs_dim, dtype=np.float64)
+        lib().orc_observe(C.byref(self.g), C.byref(self.s), _dp(obs))
+        return obs
+
+    def reset(self, initial_step=None):
+        """BaseMicrogridModule.reset (base_module.py:65-77): only the step counter moves."""
+        self.s.t = int(self.p.get("initial_step", 0) if initial_step is None else initial_step)
+        return self.observe()
+
+    def populate_action(self, plist):
+        """plist: list of (module_name, action_id). Returns dict like DiscreteMicrogridEnv._get_action."""
+        arr_t = PLElement * len(plist)
+        els = arr_t(*[PLElement(MODULE_IDS[m], int(a)) for m, a in plist])
+        out = Action()
+        lib().orc_populate_action(C.byref(self.g), C.byref(self.s), els, len(plist), C.byref(out))
+        d = {}
+        if self.g.has_genset: d["genset"] = [out.genset[0], out.genset[1]]
+        if self.g.has_battery: d["battery"] = out.battery
+        if self.g.has_grid: d["grid"] = out.grid
+        return d
+
+    @property
+    def status(self):
+        return (self.s.gen_cur, self.s.gen_goal, self.s.gen_up, self.s.gen_down)
+
+
+def np_sum(values):
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    return lib().orc_np_sum(_dp(a), a.size)
+
+
+def run_batch(cols, state, t0, K, actions, normalized=True, want_reward=True, nthreads=1):
+    """Run K steps over an SoA batch (same column names / layouts as ``pymgrid_amd.batch``), in place on
+    ``state`` (dict of numpy arrays charge, soc, gen_status).  Returns reward [K, N] or None."""
+    b = Batch()
+    keep = []
+
+    def f64(x):
+        a = np.ascontiguousarray(x, dtype=np.float64); keep.append(a); return _dp(a)
+    lay = cols["layout"]
+    b.N, b.T, b.horizon, b.final_step = lay["N"], lay["T"], lay.get("horizon", 0), lay["final_step"]
+    b.has_genset, b.has_battery, b.has_grid = lay["has_genset"], lay["has_battery"], lay["has_grid"]
+    for name, _ in Batch._fields_:
+        if name in cols and name not in ("gen_times", "gen_status", "charge", "soc"):
+            setattr(b, name, f64(cols[name]))
+    if b.has_genset:
+        gt = np.ascontiguousarray(cols["gen_times"], dtype=np.uint32); keep.append(gt)
+        b.gen_times = gt.ctypes.data_as(c_u32_p)
+        assert state["gen_status"].dtype == np.uint32 and state["gen_status"].flags.c_contiguous
+        b.gen_status = state["gen_status"].ctypes.data_as(c_u32_p)
+    if b.has_battery:
+        for k in ("charge", "soc"):
+            assert state[k].dtype == np.float64 and state[k].flags.c_contiguous
+        b.charge, b.soc = _dp(state["charge"]), _dp(state["soc"])
+    actions = np.ascontiguousarray(actions, dtype=np.float64)
+    reward = np.empty((K, b.N), dtype=np.float64) if want_reward else None
+    n = lib().orc_run_batch(C.byref(b), int(t0), int(K), _dp(actions), int(normalized),
+                            _dp(reward) if want_reward else None, int(nthreads))
+    if n < 0:
+        raise RuntimeError(f"oracle batch run: {-n} step(s) failed the balance check")
+    return reward

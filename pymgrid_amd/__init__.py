@@ -1,0 +1,14 @@
+"""pymgrid_amd -- MI355X-native batched microgrid-step engine.
+
+One data-parallel hot path of Total-RD/pymgrid, rebuilt for gfx950: the per-instance ``Microgrid.run()`` /
+``module.step()`` loop becomes hand-written HIP kernels over a struct-of-arrays batch of N microgrids, behind a
+C ABI (``include/mgx.h``) and a ``pymgrid.envs``-style Gym surface (``pymgrid_amd.envs``).
+"""
+from .batch import BatchLayout, MicrogridBatch, pack_grids, pack_status, unpack_status  # noqa: F401
+from ._lib import MgxError, build, lib  # noqa: F401
+from .engine import StepEngine  # noqa: F401
+from .envs import (BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv, DiscreteMicrogridEnv,  # noqa: F401
+                   MicrogridEnv)
+from .priority_list import get_priority_lists  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,117 @@
+"""ctypes binding of ``libmgx.so`` (C ABI in ``include/mgx.h``).
+
+The HIP library is the only compute path: if it is missing or no GPU is visible the package raises -- there is
+no CPU fallback (the CPU oracle under ``oracle/`` is test infrastructure and is never imported from here).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libmgx.so")
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("mgx_kernels.hip", "mgx_core.hpp")] + \
+          [os.path.join(_ROOT, "include", "mgx.h")]
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+               "-fPIC", "-shared"]
+
+MGX_OK, MGX_ERR_INVALID, MGX_ERR_UNSUPPORTED, MGX_ERR_RANGE, MGX_ERR_DEVICE = range(5)
+ABI_VERSION = 1
+
+
+class MgxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[mgx error {code}] {message}")
+        self.code = code
+
+
+c_double_p = C.POINTER(C.c_double)
+c_u32_p = C.POINTER(C.c_uint32)
+c_u8_p = C.POINTER(C.c_uint8)
+c_i32_p = C.POINTER(C.c_int32)
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "n_grids", "n_steps", "horizon", "initial_step", "final_step",
+        "has_genset", "has_battery", "has_grid", "n_load", "n_pv")]
+
+
+_F64_COLS = ("bat_min_capacity", "bat_max_capacity", "bat_max_charge", "bat_max_discharge", "bat_efficiency",
+             "bat_cost_cycle", "gen_running_min", "gen_running_max", "gen_cost", "gen_co2_per_unit",
+             "gen_cost_per_unit_co2")
+_F64_COLS2 = ("grid_max_import", "grid_max_export", "grid_cost_per_unit_co2", "loss_load_cost", "overgeneration_cost",
+              "load_ts", "pv_ts", "grid_ts", "load_lo", "load_hi", "pv_lo", "pv_hi", "grid_lo", "grid_hi",
+              "charge", "soc")
+
+
+class Columns(C.Structure):
+    _fields_ = ([("struct_size", C.c_int32), ("reserved", C.c_int32)]
+                + [(n, C.c_void_p) for n in _F64_COLS]
+                + [("gen_times", C.c_void_p)]
+                + [(n, C.c_void_p) for n in _F64_COLS2]
+                + [("gen_status", C.c_void_p)])
+
+
+COLUMN_NAMES = tuple(n for n, _ in Columns._fields_[2:])
+
+# every symbol include/mgx.h declares: (restype, argtypes)
+SYMBOLS = {
+    "mgx_abi_version": (C.c_int, []),
+    "mgx_last_error": (C.c_char_p, []),
+    "mgx_create": (C.c_int, [C.POINTER(Layout), C.POINTER(Columns), C.POINTER(C.c_void_p)]),
+    "mgx_destroy": (None, [C.c_void_p]),
+    "mgx_action_dim": (C.c_int32, [C.c_void_p]),
+    "mgx_obs_dim": (C.c_int32, [C.c_void_p]),
+    "mgx_log_dim": (C.c_int32, [C.c_void_p]),
+    "mgx_log_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
+    "mgx_current_step": (C.c_int32, [C.c_void_p]),
+    "mgx_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgx_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.c_void_p]),
+    "mgx_step_k": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_expand_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgx_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+}
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into pymgrid_amd/libmgx.so (hipcc cross-compiles without a GPU)."""
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in SOURCES)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + [SOURCES[0], "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libmgx.so (must have been built: ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                              f"(pymgrid_amd has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)       # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if L.mgx_abi_version() != ABI_VERSION:
+            raise ImportError(f"libmgx.so ABI {L.mgx_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+        assert C.sizeof(Layout) == 44
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != MGX_OK:
+        raise MgxError(rc, lib().mgx_last_error().decode())

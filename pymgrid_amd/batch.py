@@ -1,0 +1,325 @@
+"""Struct-of-arrays batch of N microgrids in device memory.
+
+A *batch* is what ``Microgrid.__init__`` receives in the reference (a module list, microgrid.py:100-128) for N
+microgrids at once: every module parameter becomes an fp64 column ``[N]``, every time series a time-major
+``[T, N]`` array (one step reads one contiguous row), the battery charge / SoC and the packed genset status are the
+dynamic state columns.  Column names are exactly the fields of ``mgx_columns`` in ``include/mgx.h``.
+"""
+from dataclasses import dataclass, asdict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F64 = torch.float64
+
+
+@dataclass(frozen=True)
+class BatchLayout:
+    n_grids: int
+    n_steps: int                 # T
+    horizon: int = 0             # forecast horizon H (oracle forecaster), 0 = none
+    initial_step: int = 0
+    final_step: int = 0          # <= 0: n_steps (base_timeseries_module.py:321-326)
+    has_genset: bool = True
+    has_battery: bool = True
+    has_grid: bool = False
+    n_load: int = 1
+    n_pv: int = 1
+
+    def __post_init__(self):
+        if self.final_step <= 0:
+            object.__setattr__(self, "final_step", self.n_steps)
+
+    @property
+    def action_dim(self):
+        return 2 * int(self.has_genset) + int(self.has_battery) + int(self.has_grid)
+
+    @property
+    def obs_dim(self):
+        w = 1 + self.horizon
+        return (self.n_load + self.n_pv) * w + 4 * int(self.has_genset) + 2 * int(self.has_battery) \
+            + 4 * w * int(self.has_grid)
+
+    @property
+    def log_names(self):
+        names = ["reward", "fixed_provided", "fixed_absorbed", "controllable_provided", "controllable_absorbed",
+                 "overall_provided", "overall_absorbed", "load_met", "renewable_used", "curtailment", "loss_load",
+                 "overgeneration", "unbalanced_reward"]
+        if self.has_genset:
+            names += ["genset_production", "genset_co2_production", "genset_reward", "genset_status"]
+        if self.has_battery:
+            names += ["discharge_amount", "charge_amount", "battery_reward", "soc_pre", "charge_pre"]
+        if self.has_grid:
+            names += ["grid_import", "grid_export", "grid_co2_production", "grid_reward"]
+        return names
+
+    @property
+    def action_names(self):
+        names = []
+        if self.has_genset:
+            names += ["genset_goal_status", "genset_energy"]
+        if self.has_battery:
+            names += ["battery"]
+        if self.has_grid:
+            names += ["grid"]
+        return names
+
+    def obs_slices(self):
+        """name -> slice of the flat observation (order load, pv, genset, battery, grid)."""
+        w, k, out = 1 + self.horizon, 0, {}
+        for name, n in (("load", self.n_load * w), ("pv", self.n_pv * w), ("genset", 4 * int(self.has_genset)),
+                        ("battery", 2 * int(self.has_battery)), ("grid", 4 * w * int(self.has_grid))):
+            if n:
+                out[name] = slice(k, k + n)
+                k += n
+        return out
+
+    def bytes_per_step(self, log=False, obs=False):
+        """Algorithmic HBM bytes of one env-step of one grid for the single-step kernel:
+        B = 8*(A + P_f + C_ts + 2*S_f + 2) + 2*S_i + P_i + 1 [+ 8*L] [+ 8*D + 8*C_ts]."""
+        A = self.action_dim
+        P_f = 2 + 6 * int(self.has_battery) + 5 * int(self.has_genset) + 3 * int(self.has_grid)
+        C_ts = self.n_load + self.n_pv + 4 * int(self.has_grid)
+        S_f = int(self.has_battery)
+        S_i = 4 * int(self.has_genset)
+        P_i = 4 * int(self.has_genset)
+        B = 8 * (A + P_f + C_ts + 2 * S_f + 2) + 2 * S_i + P_i + 1
+        if log:
+            B += 8 * len(self.log_names) + 8 * S_f     # the log also reads the pre-step SoC
+        if obs:
+            B += 8 * self.obs_dim + 8 * C_ts
+        return B
+
+    def bytes_fused(self, K, reward=True, done=True, soc_trace=True, status_trace=False, log=False):
+        """Compulsory HBM bytes of ONE grid for a K-step fused launch: parameters and state move once, the
+        per-step streams (actions, series rows, requested outputs) K times."""
+        A = self.action_dim
+        P_f = 2 + 6 * int(self.has_battery) + 5 * int(self.has_genset) + 3 * int(self.has_grid)
+        C_ts = self.n_load + self.n_pv + 4 * int(self.has_grid)
+        once = 8 * P_f + 4 * int(self.has_genset) + (16 + 16) * int(self.has_battery) + 8 * int(self.has_genset)
+        per = 8 * (A + C_ts) + 8 * int(reward) + int(done) + 8 * int(soc_trace and self.has_battery) \
+            + 4 * int(status_trace and self.has_genset) + 8 * len(self.log_names) * int(log)
+        return once + K * per
+
+
+def pack_status(cur, goal, up, down):
+    """current | goal<<8 | steps_until_up<<16 | steps_until_down<<24 (genset_module.py:426-431 state keys)."""
+    cur, goal, up, down = (np.asarray(x, dtype=np.int64) for x in (cur, goal, up, down))
+    if np.any((up < 0) | (up > 255) | (down < 0) | (down > 255)):
+        raise ValueError("steps_until_up / steps_until_down must fit in 8 bits")
+    return (cur | (goal << 8) | (up << 16) | (down << 24)).astype(np.uint32)
+
+
+def unpack_status(word):
+    w = np.asarray(word).astype(np.int64)
+    return np.stack([w & 0xff, (w >> 8) & 0xff, (w >> 16) & 0xff, (w >> 24) & 0xff], axis=-1).astype(np.int32)
+
+
+def pack_times(start_up, wind_down):
+    su, wd = np.asarray(start_up, dtype=np.int64), np.asarray(wind_down, dtype=np.int64)
+    if np.any((su < 0) | (su > 255) | (wd < 0) | (wd > 255)):
+        raise ValueError("start_up_time / wind_down_time must be in [0, 255] on the device path")
+    return (su | (wd << 16)).astype(np.uint32)
+
+
+class MicrogridBatch:
+    """Device-resident SoA columns of N microgrids that share one layout."""
+
+    STATE_COLUMNS = ("charge", "soc", "gen_status")
+
+    def __init__(self, layout, cols):
+        self.layout = layout
+        self.cols = cols
+        self._validate()
+
+    # ------------------------------------------------------------------------------------------------
+    def _validate(self):
+        L, N, T = self.layout, self.layout.n_grids, self.layout.n_steps
+        need = ["load_ts", "pv_ts", "loss_load_cost", "overgeneration_cost"]
+        if L.has_battery:
+            need += ["bat_min_capacity", "bat_max_capacity", "bat_max_charge", "bat_max_discharge", "bat_efficiency",
+                     "bat_cost_cycle", "charge", "soc"]
+        if L.has_genset:
+            need += ["gen_running_min", "gen_running_max", "gen_cost", "gen_co2_per_unit", "gen_cost_per_unit_co2",
+                     "gen_times", "gen_status"]
+        if L.has_grid:
+            need += ["grid_max_import", "grid_max_export", "grid_cost_per_unit_co2", "grid_ts"]
+        shapes = {"load_ts": (T, N), "pv_ts": (T, N), "grid_ts": (T, 4, N), "grid_lo": (4, N), "grid_hi": (4, N)}
+        for name in need:
+            if name not in self.cols:
+                raise ValueError(f"column {name} is required by the layout")
+        dev = None
+        for name, t in self.cols.items():
+            if name not in _lib.COLUMN_NAMES:
+                raise ValueError(f"unknown column {name}")
+            want = torch.int32 if name in ("gen_times", "gen_status") else F64   # uint32 bit patterns
+            if t.dtype != want:
+                raise TypeError(f"column {name}: dtype {t.dtype}, expected {want}")
+            if tuple(t.shape) != shapes.get(name, (N,)):
+                raise ValueError(f"column {name}: shape {tuple(t.shape)}, expected {shapes.get(name, (N,))}")
+            if not t.is_contiguous():
+                raise ValueError(f"column {name} must be contiguous")
+            dev = dev or t.device
+            if t.device != dev:
+                raise ValueError("all columns must live on one device")
+        self.device = dev
+
+    # ------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_numpy(cls, layout, arrays, device):
+        cols = {}
+        for name, a in arrays.items():
+            a = np.ascontiguousarray(a)
+            if name in ("gen_times", "gen_status"):
+                t = torch.from_numpy(a.astype(np.uint32).view(np.int32).copy())
+            else:
+                t = torch.from_numpy(a.astype(np.float64, copy=False).copy())
+            cols[name] = t.to(device)
+        return cls(layout, cols)
+
+    @classmethod
+    def from_grids(cls, grids, device="cuda"):
+        """Pack a list of per-microgrid parameter dicts (the vocabulary of ``scenario.load_fixture`` /
+        ``tests/golden/make_goldens.py:extract_params``) that share a layout."""
+        arrays, layout = pack_grids(grids)
+        return cls.from_numpy(layout, arrays, device)
+
+    # ------------------------------------------------------------------------------------------------
+    def state(self):
+        """Copy of the dynamic state (BatteryModule charge/soc, GensetModule status)."""
+        return {k: self.cols[k].clone() for k in self.STATE_COLUMNS if k in self.cols}
+
+    def load_state(self, state):
+        for k, v in state.items():
+            self.cols[k].copy_(v)
+
+    def numpy_columns(self):
+        out = {}
+        for k, v in self.cols.items():
+            out[k] = v.cpu().numpy().view(np.uint32) if v.dtype == torch.int32 else v.cpu().numpy()
+        out["layout"] = dict(N=self.layout.n_grids, T=self.layout.n_steps, horizon=self.layout.horizon,
+                             final_step=self.layout.final_step, has_genset=int(self.layout.has_genset),
+                             has_battery=int(self.layout.has_battery), has_grid=int(self.layout.has_grid))
+        return out
+
+    def c_layout(self):
+        L = _lib.Layout()
+        d = asdict(self.layout)
+        for k, v in d.items():
+            setattr(L, k, int(v))
+        L.struct_size = _lib.C.sizeof(_lib.Layout)
+        return L
+
+    def c_columns(self):
+        c = _lib.Columns()
+        c.struct_size = _lib.C.sizeof(_lib.Columns)
+        for name in _lib.COLUMN_NAMES:
+            t = self.cols.get(name)
+            setattr(c, name, t.data_ptr() if t is not None else None)
+        return c
+
+
+def series_bounds(ts):
+    """Observation bounds of a load / renewable series: base_timeseries_module.py:81-88."""
+    lo, hi = ts.min(axis=0), ts.max(axis=0)
+    return np.minimum(lo, 0.0), np.maximum(hi, 0.0)
+
+
+def pack_grids(grids):
+    """list of parameter dicts -> (numpy column dict, BatchLayout)."""
+    if not grids:
+        raise ValueError("need at least one microgrid")
+    g0 = grids[0]
+    has = {k: g0.get(k) is not None for k in ("genset", "battery", "grid")}
+    T = np.asarray(g0["load_ts"]).shape[0]
+    N = len(grids)
+    for g in grids:
+        for k in has:
+            if (g.get(k) is not None) != has[k]:
+                raise ValueError("all microgrids of a batch must have the same module set (bucket them by layout)")
+        for k in ("load_ts", "pv_ts"):
+            a = np.asarray(g[k])
+            if a.shape[0] != T or (a.ndim == 2 and a.shape[1] != 1):
+                raise ValueError(f"{k}: every microgrid needs one series of the batch length {T}")
+        for k in ("horizon", "final_step", "initial_step"):
+            if g.get(k, g0.get(k)) != g0.get(k):
+                raise ValueError(f"all microgrids of a batch must share {k}")
+    layout = BatchLayout(n_grids=N, n_steps=T, horizon=int(g0.get("horizon", 0)),
+                         initial_step=int(g0.get("initial_step", 0)), final_step=int(g0.get("final_step", 0)),
+                         has_genset=has["genset"], has_battery=has["battery"], has_grid=has["grid"])
+
+    def col(fn):
+        return np.array([fn(g) for g in grids], dtype=np.float64)
+
+    A = {}
+    load = np.stack([np.asarray(g["load_ts"], dtype=np.float64).reshape(T) for g in grids], axis=1)
+    pv = np.stack([np.asarray(g["pv_ts"], dtype=np.float64).reshape(T) for g in grids], axis=1)
+    # sign convention of the stored series (base_timeseries_module.py:68-79)
+    A["load_ts"], A["pv_ts"] = -np.abs(load), np.abs(pv)
+    A["load_lo"], A["load_hi"] = series_bounds(A["load_ts"])
+    A["pv_lo"], A["pv_hi"] = series_bounds(A["pv_ts"])
+    A["loss_load_cost"] = col(lambda g: g["unbalanced"]["loss_load_cost"])
+    A["overgeneration_cost"] = col(lambda g: g["unbalanced"]["overgeneration_cost"])
+    if has["battery"]:
+        for k in ("min_capacity", "max_capacity", "max_charge", "max_discharge", "efficiency"):
+            A["bat_" + k] = col(lambda g, k=k: g["battery"][k])
+        A["bat_cost_cycle"] = col(lambda g: g["battery"]["battery_cost_cycle"])
+        if np.any((A["bat_efficiency"] <= 0) | (A["bat_efficiency"] > 1)):
+            raise ValueError("battery efficiency must be in (0, 1]")          # battery_module.py:78
+        charge, soc = [], []
+        for g in grids:            # BatteryModule._init_battery, battery_module.py:96-106
+            b = g["battery"]
+            if b.get("charge") is not None:
+                c = float(b["charge"])
+                s = float(b["soc"]) if b.get("soc") is not None else c / b["max_capacity"]
+            elif b.get("init_charge") is not None:
+                c = float(b["init_charge"]); s = c / b["max_capacity"]
+            elif b.get("init_soc") is not None:
+                s = float(b["init_soc"]); c = s * b["max_capacity"]
+            else:
+                raise ValueError("Must set one of init_charge and init_soc.")
+            charge.append(c); soc.append(s)
+        A["charge"], A["soc"] = np.array(charge), np.array(soc)
+    if has["genset"]:
+        A["gen_running_min"] = col(lambda g: g["genset"]["running_min_production"])
+        A["gen_running_max"] = col(lambda g: g["genset"]["running_max_production"])
+        if np.any(A["gen_running_min"] > A["gen_running_max"]):
+            raise ValueError("parameter min_production must not be greater than parameter max_production.")
+        A["gen_cost"] = col(lambda g: g["genset"]["genset_cost"])
+        A["gen_co2_per_unit"] = col(lambda g: g["genset"].get("co2_per_unit", 0.0))
+        A["gen_cost_per_unit_co2"] = col(lambda g: g["genset"].get("cost_per_unit_co2", 0.0))
+        su = [int(g["genset"].get("start_up_time", 0)) for g in grids]
+        wd = [int(g["genset"].get("wind_down_time", 0)) for g in grids]
+        A["gen_times"] = pack_times(su, wd)
+        st = []
+        for g, s_, w_ in zip(grids, su, wd):      # genset_module.py:91-92,216-227
+            q = g["genset"]
+            if q.get("status") is not None:
+                st.append([int(v) for v in q["status"]])
+            else:
+                on = int(bool(q.get("init_start_up", True)))
+                st.append([on, on, 0, w_] if on else [0, 0, s_, 0])
+        st = np.array(st)
+        A["gen_status"] = pack_status(st[:, 0], st[:, 1], st[:, 2], st[:, 3])
+    if has["grid"]:
+        A["grid_max_import"] = col(lambda g: g["grid"]["max_import"])
+        A["grid_max_export"] = col(lambda g: g["grid"]["max_export"])
+        A["grid_cost_per_unit_co2"] = col(lambda g: g["grid"].get("cost_per_unit_co2", 0.0))
+        gts = []
+        for g in grids:                           # GridModule._check_params, grid_module.py:103-123
+            ts = np.asarray(g["grid_ts"], dtype=np.float64)
+            if ts.ndim != 2 or ts.shape[1] not in (3, 4) or ts.shape[0] != T:
+                raise ValueError("Time series must be two dimensional with three or four columns.")
+            if ts.shape[1] == 3:
+                ts = np.concatenate([ts, np.ones((T, 1))], axis=1)
+            elif not np.all((ts[:, 3] == 0) | (ts[:, 3] == 1)):
+                raise ValueError("Last column (grid status) must contain binary values.")
+            if (ts < 0).any():
+                raise ValueError("Time series must be non-negative.")
+            gts.append(ts)
+        gts = np.stack(gts, axis=2)               # [T, 4, N]
+        A["grid_ts"] = gts
+        A["grid_lo"], A["grid_hi"] = gts.min(axis=0), gts.max(axis=0)
+    return A, layout

@@ -1,0 +1,366 @@
+// mgx_core.hpp -- per-microgrid device arithmetic of the batched step engine (gfx950 / CDNA4).
+//
+// One lane owns one microgrid.  Everything here is straight fp64 in the reference's operation order
+// (compile with -ffp-contract=off: the reference never fuses a multiply-add), so results are bit-identical
+// to the CPU loop of Total-RD/pymgrid v1.2.2 (paths below are relative to src/pymgrid/):
+//   Microgrid.run                     microgrid/microgrid.py:227-325
+//   MicrogridStep.append/balance      microgrid/utils/step.py:13-36
+//   BaseMicrogridModule.step & clips  modules/base/base_module.py:95-274
+//   BatteryModule                     modules/battery_module.py:108-147,244-291,332-338
+//   GensetModule                      modules/genset_module.py:100-149,188-346,465-517
+//   GridModule                        modules/grid_module.py:125-228,314-320
+//   LoadModule / RenewableModule      modules/load_module.py:86-111, modules/renewable_module.py:86-110
+//   UnbalancedEnergyModule            modules/unbalanced_energy_module.py:28-70
+//   ModuleSpace normalise/denormalise utils/space.py:184-231
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mgx.h"
+
+namespace mgx {
+
+// Layout flags: template parameter F of the kernels (one specialisation per module set).
+enum : int { F_GENSET = 1, F_BATTERY = 2, F_GRID = 4 };
+
+// Log columns, in output order.  Names are returned by mgx_log_name().
+enum LogCol : int {
+    LC_REWARD = 0, LC_FIXED_PROVIDED, LC_FIXED_ABSORBED, LC_CTRL_PROVIDED, LC_CTRL_ABSORBED,
+    LC_OVERALL_PROVIDED, LC_OVERALL_ABSORBED,
+    LC_LOAD_MET, LC_RENEWABLE_USED, LC_CURTAILMENT, LC_LOSS_LOAD, LC_OVERGENERATION, LC_UNBALANCED_REWARD,
+    LC_COMMON_END,
+    // genset block (4), battery block (5), grid block (4) follow, present modules only
+    LC_GENSET_N = 4, LC_BATTERY_N = 5, LC_GRID_N = 4
+};
+
+// Everything a launch needs; passed to kernels BY VALUE (kernarg segment, scalar loads).
+struct KArgs {
+    mgx_columns c;
+    int32_t N, T, H, final_step;
+    int32_t obs_dim, log_dim;
+};
+
+struct Params {
+    double bat_cmin, bat_cmax, bat_C, bat_D, bat_eta, bat_cost;
+    double gen_rmin, gen_rmax, gen_cost, gen_co2, gen_cco2;
+    uint32_t gen_times;
+    double grid_imp, grid_exp, grid_cco2;
+    double ll_cost, og_cost;
+};
+
+struct State {
+    double charge, soc;
+    uint32_t status;
+};
+
+struct Inputs {
+    double a_goal, a_gen, a_bat, a_grid;     // control (normalised or raw)
+    double load, pv;                         // series rows, stored sign
+    double g_pimp, g_pexp, g_co2, g_stat;    // grid_ts row
+};
+
+struct Outputs {
+    double reward;
+    double fixed_provided, fixed_absorbed, ctrl_provided, ctrl_absorbed, overall_provided, overall_absorbed;
+    double load_met, renewable_used, curtailment, loss_load, overgeneration, unbalanced_reward;
+    double genset_production, genset_co2, genset_reward;
+    double discharge_amount, charge_amount, battery_reward, soc_pre, charge_pre;
+    double grid_import, grid_export, grid_co2, grid_reward;
+};
+
+// ---- ModuleSpace (utils/space.py:204-205,213,224) -------------------------------------------------------
+__device__ __forceinline__ double space_spread(double lo, double hi)
+{
+    double s = hi - lo;
+    return s == 0.0 ? 1.0 : s;
+}
+__device__ __forceinline__ double space_denorm(double lo, double hi, double v) { return lo + space_spread(lo, hi) * v; }
+__device__ __forceinline__ double space_norm(double lo, double hi, double v) { return (v - lo) / space_spread(lo, hi); }
+
+// ---- loads ----------------------------------------------------------------------------------------------
+template <int F>
+__device__ __forceinline__ void load_params(const mgx_columns &c, int64_t i, Params &p)
+{
+    if constexpr (F & F_BATTERY) {
+        p.bat_cmin = c.bat_min_capacity[i]; p.bat_cmax = c.bat_max_capacity[i];
+        p.bat_C = c.bat_max_charge[i];      p.bat_D = c.bat_max_discharge[i];
+        p.bat_eta = c.bat_efficiency[i];    p.bat_cost = c.bat_cost_cycle[i];
+    }
+    if constexpr (F & F_GENSET) {
+        p.gen_rmin = c.gen_running_min[i];  p.gen_rmax = c.gen_running_max[i];
+        p.gen_cost = c.gen_cost[i];         p.gen_co2 = c.gen_co2_per_unit[i];
+        p.gen_cco2 = c.gen_cost_per_unit_co2[i];
+        p.gen_times = c.gen_times[i];
+    }
+    if constexpr (F & F_GRID) {
+        p.grid_imp = c.grid_max_import[i];  p.grid_exp = c.grid_max_export[i];
+        p.grid_cco2 = c.grid_cost_per_unit_co2[i];
+    }
+    p.ll_cost = c.loss_load_cost[i];
+    p.og_cost = c.overgeneration_cost[i];
+}
+
+template <int F>
+__device__ __forceinline__ void load_state(const mgx_columns &c, int64_t i, bool want_soc, State &s)
+{
+    s.charge = 0.0; s.soc = 0.0; s.status = 0u;
+    if constexpr (F & F_BATTERY) {
+        s.charge = c.charge[i];
+        if (want_soc) s.soc = c.soc[i];      // only the log reads the pre-step SoC
+    }
+    if constexpr (F & F_GENSET) s.status = c.gen_status[i];
+}
+
+template <int F>
+__device__ __forceinline__ void store_state(const mgx_columns &c, int64_t i, const State &s)
+{
+    if constexpr (F & F_BATTERY) { c.charge[i] = s.charge; c.soc[i] = s.soc; }
+    if constexpr (F & F_GENSET) c.gen_status[i] = s.status;
+}
+
+// actions row [A] of grid i at `act` (row-major [N, A]); series rows at time t
+template <int F>
+__device__ __forceinline__ void load_inputs(const mgx_columns &c, const double *__restrict__ act,
+                                            int64_t N, int64_t i, int64_t t, Inputs &in)
+{
+    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    const double *a = act + i * A;
+    int k = 0;
+    if constexpr (F & F_GENSET) { in.a_goal = a[k]; in.a_gen = a[k + 1]; k += 2; }
+    if constexpr (F & F_BATTERY) { in.a_bat = a[k]; k += 1; }
+    if constexpr (F & F_GRID) { in.a_grid = a[k]; k += 1; }
+    in.load = c.load_ts[t * N + i];
+    in.pv = c.pv_ts[t * N + i];
+    if constexpr (F & F_GRID) {
+        const double *g = c.grid_ts + (t * 4) * N + i;
+        in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
+    }
+}
+
+// ---- GensetModule.update_status (genset_module.py:235-346) on the packed status word ---------------------
+// status = current | goal<<8 | steps_until_up<<16 | steps_until_down<<24 ; times = start_up | wind_down<<16
+__device__ __forceinline__ uint32_t genset_update_status(uint32_t st, uint32_t times, double goal_f)
+{
+    int cur = st & 0xff, gs = (st >> 8) & 0xff, up = (st >> 16) & 0xff, down = st >> 24;
+    const int su = times & 0xffff, wd = times >> 16;
+    const int goal = goal_f > 0.5 ? 1 : 0;            // Python round(): half-to-even, 0.5 -> 0 (:281)
+    if (!(goal == cur && cur == gs)) {                // :284-287
+        if (goal != gs) gs = goal;                    // :289-292 (allow_abortion == True)
+        bool finished = false;                        // _finish_in_progress_change :302-311
+        if (up == 0 && gs == 1)        { cur = 1; up = 0;   down = wd; finished = true; }
+        else if (down == 0 && gs == 0) { cur = 0; down = 0; up = su;   finished = true; }
+        if (!finished) {                              // _non_instantaneous_update :327-346
+            if (goal == cur && cur != gs) {
+                gs = goal;
+                if (cur) { up = 0; down = wd; } else { down = 0; up = su; }
+            } else if (cur == gs && gs != goal) {
+                if (cur) { up = 0; down = wd; } else { down = 0; up = su; }
+                gs = goal;
+            }
+            if (gs != cur) { if (gs == 0) down -= 1; else up -= 1; }
+        }
+    }
+    return (uint32_t)cur | ((uint32_t)gs << 8) | ((uint32_t)(up & 0xff) << 16) | ((uint32_t)(down & 0xff) << 24);
+}
+
+// GensetModule.next_status (genset_module.py:360-390)
+__device__ __forceinline__ int genset_next_status(uint32_t st, int goal)
+{
+    const int cur = st & 0xff, up = (st >> 16) & 0xff, down = st >> 24;
+    if (goal) return (cur || up == 0) ? 1 : 0;
+    return (!cur || down == 0) ? 0 : 1;
+}
+
+// BatteryModule.max_production / max_consumption (battery_module.py:283-291); Python min(a,b) = b if b<a else a
+__device__ __forceinline__ double battery_max_production(const Params &p, double charge)
+{
+    const double b = charge - p.bat_cmin;
+    return (b < p.bat_D ? b : p.bat_D) * p.bat_eta;
+}
+__device__ __forceinline__ double battery_max_consumption(const Params &p, double charge)
+{
+    const double b = p.bat_cmax - charge;
+    return (b < p.bat_C ? b : p.bat_C) / p.bat_eta;
+}
+
+// ---- one Microgrid.run for one grid ---------------------------------------------------------------------
+// Sweep order load -> genset -> battery -> grid -> pv -> unbalanced (module_container.py:355-413,
+// microgrid.py:255-314).  np.sum over the provided/absorbed lists is a left-to-right running sum for the
+// list lengths that occur here (< 8 addends), so the running sums below reproduce MicrogridStep.balance.
+template <int F>
+__device__ __forceinline__ void step_core(const Params &p, State &s, const Inputs &in, bool normalized, Outputs &o)
+{
+    double prov = 0.0, absb = 0.0, reward = 0.0;
+
+    // fixed: LoadModule.update (load_module.py:86-111)
+    const double L = -1 * in.load;
+    o.load_met = L;
+    absb += L; reward += 0.0;
+    o.fixed_provided = prov; o.fixed_absorbed = absb;
+
+    if constexpr (F & F_GENSET) {
+        s.status = genset_update_status(s.status, p.gen_times, in.a_goal);      // GensetModule.step :146-149
+        double x = in.a_gen;
+        if (normalized) x = space_denorm(0.0, p.gen_rmax, in.a_gen);           // act space :511-517, _energy_pos=1
+        const double cur = (double)(s.status & 0xff);
+        const double mx = cur * p.gen_rmax, mn = cur * p.gen_rmin;             // max/min_production :465-501
+        double e;                                                              // as_source clip base_module.py:213-224
+        if (x > mx) e = mx; else if (x < mn) e = mn; else e = x;
+        const double co2 = p.gen_co2 * e;                                      // get_co2
+        const double cost = p.gen_cost * e + p.gen_cco2 * co2;                 // get_cost :188-205
+        o.genset_production = e; o.genset_co2 = co2; o.genset_reward = -1.0 * cost;
+        prov += e; reward += o.genset_reward;
+    }
+
+    if constexpr (F & F_BATTERY) {
+        double x = in.a_bat;
+        if (normalized) x = space_denorm(-p.bat_D / p.bat_eta, p.bat_C * p.bat_eta, in.a_bat);   // :332-338
+        o.soc_pre = s.soc; o.charge_pre = s.charge;
+        double internal;
+        if (x < 0) {                                                           // as_sink(-1.0*x)
+            const double ex = -1.0 * x, mc = battery_max_consumption(p, s.charge);
+            const double e = (ex > mc) ? mc : ex;
+            internal = (e < 0) ? e / p.bat_eta : e * p.bat_eta;                // default_transition_model :244-278
+            o.charge_amount = e; o.discharge_amount = 0.0;
+            absb += e;
+        } else {                                                               // as_source(x), incl. x == 0
+            const double mp = battery_max_production(p, s.charge);
+            double e;
+            if (x > mp) e = mp; else if (x < 0.0) e = 0.0; else e = x;
+            const double ext = -1.0 * e;
+            internal = (ext < 0) ? ext / p.bat_eta : ext * p.bat_eta;
+            o.discharge_amount = e; o.charge_amount = 0.0;
+            prov += e;
+        }
+        s.charge += internal;                                                  // _update_state :125-130
+        if (s.charge < p.bat_cmin) s.charge = p.bat_cmin;
+        s.soc = s.charge / p.bat_cmax;
+        o.battery_reward = -1.0 * (fabs(internal) * p.bat_cost);               // get_cost :132-147
+        reward += o.battery_reward;
+    }
+
+    if constexpr (F & F_GRID) {
+        double x = in.a_grid;
+        if (normalized) x = space_denorm(-1 * p.grid_exp, p.grid_imp, in.a_grid);   // _get_bounds :125-132
+        if (x < 0) {                                                           // export
+            const double ex = -1.0 * x, mc = p.grid_exp * in.g_stat;           // max_consumption :318-320
+            const double e = (ex > mc) ? mc : ex;
+            o.grid_export = e; o.grid_import = 0.0; o.grid_co2 = 0.0;
+            o.grid_reward = in.g_pexp * e + (-1.0 * p.grid_cco2 * 0.0);        // get_cost :169-171
+            absb += e;
+        } else {                                                               // import
+            const double mp = p.grid_imp * in.g_stat;                          // max_production :314-316
+            double e;
+            if (x > mp) e = mp; else if (x < 0.0) e = 0.0; else e = x;
+            const double co2 = e * in.g_co2;                                   // get_co2_production :221-224
+            o.grid_import = e; o.grid_export = 0.0; o.grid_co2 = co2;
+            o.grid_reward = -1 * in.g_pimp * e + (-1.0 * p.grid_cco2 * co2);   // :166-168, :176-197
+            prov += e;
+        }
+        reward += o.grid_reward;
+    }
+
+    const double difference = prov - absb;                                     // microgrid.py:277-278
+    o.ctrl_provided = prov - o.fixed_provided;                                 // :281
+    o.ctrl_absorbed = absb - o.fixed_absorbed;
+
+    if (difference > 0) {                                                      // :286-299
+        o.renewable_used = 0.0; o.curtailment = in.pv - 0.0;                   // renewable_module.py:86-93
+        prov += 0.0; reward += 0.0;
+        const double e = -1.0 * (-1.0 * difference);
+        o.overgeneration = e; o.loss_load = 0.0;
+        o.unbalanced_reward = -1.0 * (p.og_cost * e);                          // unbalanced_energy_module.py:38-70
+        absb += e;
+    } else {                                                                   // :301-314
+        double need = -difference;
+        const double used = (in.pv < need) ? in.pv : need;
+        o.renewable_used = used; o.curtailment = in.pv - used;
+        prov += used; reward += 0.0;
+        need -= used;
+        o.loss_load = need; o.overgeneration = 0.0;
+        o.unbalanced_reward = -1.0 * (p.ll_cost * need);
+        prov += need;
+    }
+    reward += o.unbalanced_reward;
+    o.overall_provided = prov; o.overall_absorbed = absb;
+    o.reward = reward;
+}
+
+// ---- log row ------------------------------------------------------------------------------------------
+// log points at column 0 of grid i; consecutive columns are N apart.
+template <int F>
+__device__ __forceinline__ void store_log(double *__restrict__ log, int64_t N, const Outputs &o, uint32_t status)
+{
+    int k = 0;
+    log[(k++) * N] = o.reward;
+    log[(k++) * N] = o.fixed_provided;   log[(k++) * N] = o.fixed_absorbed;
+    log[(k++) * N] = o.ctrl_provided;    log[(k++) * N] = o.ctrl_absorbed;
+    log[(k++) * N] = o.overall_provided; log[(k++) * N] = o.overall_absorbed;
+    log[(k++) * N] = o.load_met;         log[(k++) * N] = o.renewable_used;
+    log[(k++) * N] = o.curtailment;      log[(k++) * N] = o.loss_load;
+    log[(k++) * N] = o.overgeneration;   log[(k++) * N] = o.unbalanced_reward;
+    if constexpr (F & F_GENSET) {
+        log[(k++) * N] = o.genset_production; log[(k++) * N] = o.genset_co2;
+        log[(k++) * N] = o.genset_reward;     log[(k++) * N] = (double)status;   // packed word, exact in fp64
+    }
+    if constexpr (F & F_BATTERY) {
+        log[(k++) * N] = o.discharge_amount;  log[(k++) * N] = o.charge_amount;
+        log[(k++) * N] = o.battery_reward;    log[(k++) * N] = o.soc_pre;
+        log[(k++) * N] = o.charge_pre;
+    }
+    if constexpr (F & F_GRID) {
+        log[(k++) * N] = o.grid_import;       log[(k++) * N] = o.grid_export;
+        log[(k++) * N] = o.grid_co2;          log[(k++) * N] = o.grid_reward;
+    }
+}
+
+// ---- observation (post-step state, series index t = current step) --------------------------------------
+// One component of a time-series module: [cur, forecast_0..H-1] (base_timeseries_module.py:103-140,332-338);
+// rows beyond the series = (lo+hi)/2 (forecaster.py:95,120-137); forecasts clipped to the bounds (:139-149).
+__device__ __forceinline__ void observe_series(const double *__restrict__ ts, int64_t row_stride, int32_t T, int32_t t,
+                                               int32_t H, double lo, double hi, double *__restrict__ obs, int obs_stride)
+{
+    const double fill = (hi + lo) / 2;
+    const double sp = space_spread(lo, hi);
+    for (int h = 0; h <= H; h++) {
+        double v = fill;
+        if (t < T && t + h < T) {
+            v = ts[(int64_t)(t + h) * row_stride];
+            if (h > 0) { if (v < lo) v = lo; if (v > hi) v = hi; }
+        }
+        obs[h * obs_stride] = (v - lo) / sp;
+    }
+}
+
+template <int F>
+__device__ __forceinline__ void observe_core(const KArgs &a, int64_t i, int32_t t, const Params &p, const State &s,
+                                             double *__restrict__ obs)
+{
+    const mgx_columns &c = a.c;
+    const int64_t N = a.N;
+    const int w = 1 + a.H;
+    int k = 0;
+    observe_series(c.load_ts + i, N, a.T, t, a.H, c.load_lo[i], c.load_hi[i], obs + k, 1); k += w;
+    observe_series(c.pv_ts + i, N, a.T, t, a.H, c.pv_lo[i], c.pv_hi[i], obs + k, 1);       k += w;
+    if constexpr (F & F_GENSET) {                      // genset_module.py:503-509
+        const double su = (double)(p.gen_times & 0xffff), wd = (double)(p.gen_times >> 16);
+        obs[k++] = space_norm(0.0, 1.0, (double)(s.status & 0xff));
+        obs[k++] = space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
+        obs[k++] = space_norm(0.0, su, (double)((s.status >> 16) & 0xff));
+        obs[k++] = space_norm(0.0, wd, (double)(s.status >> 24));
+    }
+    if constexpr (F & F_BATTERY) {                     // battery_module.py:87,323-330
+        const double min_soc = p.bat_cmin / p.bat_cmax;
+        obs[k++] = space_norm(min_soc, 1.0, s.soc);
+        obs[k++] = space_norm(p.bat_cmin, p.bat_cmax, s.charge);
+    }
+    if constexpr (F & F_GRID) {                        // component-minor: [c0..c3]_cur, [c0..c3]_+1, ...
+        for (int cc = 0; cc < 4; cc++)
+            observe_series(c.grid_ts + cc * N + i, 4 * N, a.T, t, a.H, c.grid_lo[cc * N + i], c.grid_hi[cc * N + i],
+                           obs + k + cc, 4);
+        k += 4 * w;
+    }
+}
+
+}  // namespace mgx

@@ -1,0 +1,500 @@
+// mgx_kernels.hip -- HIP kernels of the batched microgrid-step engine, written for gfx950 (MI355X, CDNA4).
+//
+// Execution shape: one lane per microgrid, 64-lane wavefronts, 256-thread workgroups, SoA columns so every
+// global access of a wave is one contiguous 512-byte segment.  The path is element-wise and HBM-bound
+// (~40 useful flops vs 189 B per env-step): no MFMA, no LDS tiling of the physics.
+// LDS + wavefront shuffles are used where data actually crosses lanes: the [N, D] observation tile
+// transpose and the metrics column sums.
+//
+// Block b runs on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch"): because block b always owns grids
+// [256 b, 256 b + 256), the parameter and state columns of a grid stay in the SAME XCD's 4 MiB L2 across
+// the per-step launches -- the blockIdx -> data mapping is deliberately launch-invariant.
+#include "mgx_core.hpp"
+
+namespace mgx {
+
+constexpr int BLOCK = 256;
+
+// ------------------------------------------------------------------------------------------------------
+// Single step: Microgrid.run for N grids (microgrid.py:227-325) + optional obs (base.py:205-209) + log.
+// ------------------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double *__restrict__ actions, int32_t t,
+                                                     int normalized, double *__restrict__ reward,
+                                                     uint8_t *__restrict__ done, double *__restrict__ obs,
+                                                     double *__restrict__ log)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    // all loads first (independent, one latency round), then the arithmetic
+    Params p; State s; Inputs in; Outputs o;
+    load_inputs<F>(a.c, actions, a.N, i, t, in);
+    load_state<F>(a.c, i, log != nullptr, s);
+    load_params<F>(a.c, i, p);
+
+    step_core<F>(p, s, in, normalized != 0, o);
+
+    store_state<F>(a.c, i, s);
+    reward[i] = o.reward;
+    // _done(): t >= final_step - 1, evaluated before the counter moves (base_timeseries_module.py:124-125)
+    if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
+    if (log) store_log<F>(log + i, a.N, o, s.status);
+    if (obs) observe_core<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K fused steps: parameters + state live in registers, actions / series rows are streamed with a
+// U-deep software pipeline (loads of chunk c+1 are in flight while chunk c is computed).
+// ------------------------------------------------------------------------------------------------------
+template <int F, int U>
+__global__ __launch_bounds__(BLOCK) void step_k_kernel(const KArgs a, const double *__restrict__ actions, int32_t t0,
+                                                       int32_t K, int normalized, double *__restrict__ reward,
+                                                       uint8_t *__restrict__ done, double *__restrict__ soc_trace,
+                                                       uint32_t *__restrict__ status_trace,
+                                                       double *__restrict__ ret_acc, double *__restrict__ log)
+{
+    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    const int64_t N = a.N;
+    Params p; State s;
+    load_state<F>(a.c, i, true, s);
+    load_params<F>(a.c, i, p);
+    double ret = 0.0;
+
+    Inputs cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        if (u < K) load_inputs<F>(a.c, actions + (int64_t)u * N * A, N, i, t0 + u, cur[u]);
+
+    for (int32_t k0 = 0; k0 < K; k0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {           // prefetch the next chunk
+            const int32_t k = k0 + U + u;
+            if (k < K) load_inputs<F>(a.c, actions + (int64_t)k * N * A, N, i, t0 + k, nxt[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int32_t k = k0 + u;
+            if (k < K) {
+                Outputs o;
+                step_core<F>(p, s, cur[u], normalized != 0, o);
+                const int64_t off = (int64_t)k * N + i;
+                if (reward) reward[off] = o.reward;
+                if (done) done[off] = (uint8_t)(t0 + k >= a.final_step - 1);
+                if constexpr (F & F_BATTERY) { if (soc_trace) soc_trace[off] = s.soc; }
+                if constexpr (F & F_GENSET) { if (status_trace) status_trace[off] = s.status; }
+                if (log) store_log<F>(log + (int64_t)k * a.log_dim * N + i, N, o, s.status);
+                ret += o.reward;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) cur[u] = nxt[u];
+    }
+    store_state<F>(a.c, i, s);
+    if (ret_acc) ret_acc[i] += ret;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Observation of the current state (reset(), or after step_k).
+// ------------------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t, double *__restrict__ obs)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    Params p; State s;
+    load_state<F>(a.c, i, true, s);
+    load_params<F>(a.c, i, p);
+    observe_core<F>(a, i, t, p, s, obs + i * a.obs_dim);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Discrete action expansion: PriorityListAlgo._populate_action (priority_list.py:69-167).
+// ------------------------------------------------------------------------------------------------------
+struct PLTable {
+    int8_t module[12][3];      // 0 genset, 1 battery, 2 grid, -1 padding
+    int8_t action[12][3];
+    int32_t n_actions;
+};
+
+template <int F>
+__global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLTable tab, const int32_t *__restrict__ action_id,
+                                                       int32_t t, double *__restrict__ control)
+{
+    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    const int64_t N = a.N;
+    Params p; State s;
+    load_state<F>(a.c, i, false, s);
+    load_params<F>(a.c, i, p);
+    int32_t id = action_id[i];
+    if (id < 0 || id >= tab.n_actions) id = 0;         // the reference raises ValueError (discrete.py:83-84)
+    const double total_load = 0.0 + -1 * a.c.load_ts[(int64_t)t * N + i];    // _get_load :157-164
+    const double renewable = a.c.pv_ts[(int64_t)t * N + i];                  // _get_renewable :166-167
+    double g_stat = 1.0;
+    if constexpr (F & F_GRID) g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
+    double remaining = total_load - renewable;                                // :74
+
+    double c_goal = 0.0, c_gen = 0.0, c_bat = 0.0, c_grid = 0.0;
+    bool set_gen = false, set_bat = false, set_grid = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int mod = tab.module[id][k], act = tab.action[id][k];
+        if (mod < 0) continue;
+        if (mod == 0) { if (set_gen) continue; set_gen = true; c_goal = (double)act; }     // :82-88
+        else if (mod == 1) { if (set_bat) continue; set_bat = true; }
+        else { if (set_grid) continue; set_grid = true; }
+        double energy;
+        if (fabs(remaining - 0.0) <= 1e-4 + 1e-5 * fabs(0.0)) {           // np.isclose(remaining, 0, atol=1e-4) :90
+            energy = 0.0;
+        } else if (remaining > 0) {                                       // _produce_from_module :138-155
+            double mx = 0.0, mn = 0.0;
+            if (mod == 0) {
+                if constexpr (F & F_GENSET) {
+                    const double ns = (double)genset_next_status(s.status, act);   // genset_module.py:392-424
+                    mx = ns * p.gen_rmax; mn = ns * p.gen_rmin;
+                }
+            } else if (mod == 1) {
+                if constexpr (F & F_BATTERY) mx = battery_max_production(p, s.charge);
+            } else {
+                if constexpr (F & F_GRID) mx = p.grid_imp * g_stat;
+            }
+            if (mn <= remaining && remaining <= mx) energy = remaining;
+            else if (remaining < mn) energy = mn;
+            else energy = mx;
+        } else {                                                          // _consume_in_module :118-136
+            if (mod == 0) energy = 0.0;
+            else {
+                double mc = 0.0;
+                if (mod == 1) { if constexpr (F & F_BATTERY) mc = battery_max_consumption(p, s.charge); }
+                else          { if constexpr (F & F_GRID) mc = p.grid_exp * g_stat; }
+                energy = (-1 * remaining > mc) ? -1.0 * mc : remaining;
+            }
+        }
+        if (mod == 0) c_gen = energy; else if (mod == 1) c_bat = energy; else c_grid = energy;
+        remaining -= energy;                                              // :105
+    }
+    double *c = control + i * A;
+    int k = 0;
+    if constexpr (F & F_GENSET) { c[k] = c_goal; c[k + 1] = c_gen; k += 2; }
+    if constexpr (F & F_BATTERY) { c[k++] = c_bat; }
+    if constexpr (F & F_GRID) { c[k++] = c_grid; }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Metrics: deterministic column sums  sums[m] = sum_i values[m, i].
+// Stage 1: every block folds a fixed slice of column m (lane-strided running sums, then a 64-lane
+// wavefront shuffle tree, then the 4 wave results through LDS).  Stage 2: one block per column folds the
+// per-block partials the same way.  No atomics: the order is fixed by (N, grid size) alone.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *lds)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) r += lds[w];
+    }
+    __syncthreads();
+    return r;      // valid in thread 0
+}
+
+__global__ __launch_bounds__(BLOCK) void colsum_stage1(const double *__restrict__ values, int64_t N, int32_t per_block,
+                                                       double *__restrict__ partial)
+{
+    __shared__ double lds[BLOCK / 64];
+    const int m = blockIdx.y;
+    const int64_t begin = (int64_t)blockIdx.x * per_block;
+    int64_t end = begin + per_block; if (end > N) end = N;
+    const double *col = values + (int64_t)m * N;
+    double acc = 0.0;
+    for (int64_t i = begin + threadIdx.x; i < end; i += BLOCK) acc += col[i];
+    const double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partial[(int64_t)m * gridDim.x + blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(BLOCK) void colsum_stage2(const double *__restrict__ partial, int32_t n_partial,
+                                                       double *__restrict__ sums)
+{
+    __shared__ double lds[BLOCK / 64];
+    const int m = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_partial; i += BLOCK) acc += partial[(int64_t)m * n_partial + i];
+    const double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) sums[m] = r;
+}
+
+}  // namespace mgx
+
+// ======================================================================================================
+// Host side: the C ABI (include/mgx.h)
+// ======================================================================================================
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+using namespace mgx;
+
+struct mgx_handle {
+    KArgs k;
+    mgx_layout layout;
+    int32_t flags;          // F
+    int32_t t;              // current step
+    int32_t action_dim;
+    int device;
+    double *scratch;        // [64 * MAX_PARTIAL] column-sum partials
+};
+
+namespace {
+
+constexpr int MAX_PARTIAL = 1024;
+constexpr int MAX_METRICS = 64;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    return fail(MGX_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+}
+
+const char *const kCommonNames[] = {
+    "reward", "fixed_provided", "fixed_absorbed", "controllable_provided", "controllable_absorbed",
+    "overall_provided", "overall_absorbed", "load_met", "renewable_used", "curtailment", "loss_load",
+    "overgeneration", "unbalanced_reward"};
+const char *const kGensetNames[] = {"genset_production", "genset_co2_production", "genset_reward", "genset_status"};
+const char *const kBatteryNames[] = {"discharge_amount", "charge_amount", "battery_reward", "soc_pre", "charge_pre"};
+const char *const kGridNames[] = {"grid_import", "grid_export", "grid_co2_production", "grid_reward"};
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+// dispatch a kernel template on the runtime layout flags
+#define MGX_DISPATCH_F(flags, CALL)                     \
+    switch (flags) {                                    \
+        case 0: { constexpr int F = 0; CALL; } break;   \
+        case 1: { constexpr int F = 1; CALL; } break;   \
+        case 2: { constexpr int F = 2; CALL; } break;   \
+        case 3: { constexpr int F = 3; CALL; } break;   \
+        case 4: { constexpr int F = 4; CALL; } break;   \
+        case 5: { constexpr int F = 5; CALL; } break;   \
+        case 6: { constexpr int F = 6; CALL; } break;   \
+        default: { constexpr int F = 7; CALL; } break;  \
+    }
+
+}  // namespace
+
+extern "C" {
+
+int mgx_abi_version(void) { return MGX_ABI_VERSION; }
+
+const char *mgx_last_error(void) { return g_err; }
+
+int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
+{
+    g_err[0] = 0;
+    if (!L || !C || !out) return fail(MGX_ERR_INVALID, "mgx_create: NULL argument");
+    *out = nullptr;
+    if (L->struct_size != (int32_t)sizeof(mgx_layout) || C->struct_size != (int32_t)sizeof(mgx_columns))
+        return fail(MGX_ERR_INVALID, "mgx_create: struct_size mismatch (ABI %d): layout %d vs %zu, columns %d vs %zu",
+                    MGX_ABI_VERSION, L->struct_size, sizeof(mgx_layout), C->struct_size, sizeof(mgx_columns));
+    if (L->n_grids <= 0 || L->n_steps <= 0 || L->horizon < 0)
+        return fail(MGX_ERR_INVALID, "mgx_create: need n_grids > 0, n_steps > 0, horizon >= 0");
+    if ((L->has_genset | L->has_battery | L->has_grid) & ~1)
+        return fail(MGX_ERR_INVALID, "mgx_create: has_genset / has_battery / has_grid must be 0 or 1");
+    if (L->n_load != 1 || L->n_pv != 1)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_create: the device path takes exactly one load and one pv module per grid "
+                                         "(got n_load=%d n_pv=%d)", L->n_load, L->n_pv);
+    const int32_t final_step = L->final_step <= 0 ? L->n_steps : L->final_step;   // base_timeseries_module.py:321-326
+    if (final_step > L->n_steps) return fail(MGX_ERR_INVALID, "mgx_create: final_step %d > n_steps %d", final_step, L->n_steps);
+    if (L->initial_step < 0 || L->initial_step >= final_step)
+        return fail(MGX_ERR_INVALID, "mgx_create: final_step value must be greater than initial_step");
+#define NEED(cond, ptr) if ((cond) && !(C->ptr)) return fail(MGX_ERR_INVALID, "mgx_create: column " #ptr " is NULL")
+    NEED(true, load_ts); NEED(true, pv_ts); NEED(true, loss_load_cost); NEED(true, overgeneration_cost);
+    NEED(L->has_battery, bat_min_capacity); NEED(L->has_battery, bat_max_capacity); NEED(L->has_battery, bat_max_charge);
+    NEED(L->has_battery, bat_max_discharge); NEED(L->has_battery, bat_efficiency); NEED(L->has_battery, bat_cost_cycle);
+    NEED(L->has_battery, charge); NEED(L->has_battery, soc);
+    NEED(L->has_genset, gen_running_min); NEED(L->has_genset, gen_running_max); NEED(L->has_genset, gen_cost);
+    NEED(L->has_genset, gen_co2_per_unit); NEED(L->has_genset, gen_cost_per_unit_co2); NEED(L->has_genset, gen_times);
+    NEED(L->has_genset, gen_status);
+    NEED(L->has_grid, grid_max_import); NEED(L->has_grid, grid_max_export); NEED(L->has_grid, grid_cost_per_unit_co2);
+    NEED(L->has_grid, grid_ts);
+#undef NEED
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(MGX_ERR_DEVICE, "mgx_create: no HIP device available (%s) -- this engine has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    mgx_handle *h = new (std::nothrow) mgx_handle();
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_create: out of host memory");
+    if ((e = hipGetDevice(&h->device)) != hipSuccess) { delete h; return hip_fail(e, "hipGetDevice"); }
+    h->layout = *L;
+    h->layout.final_step = final_step;
+    h->k.c = *C;
+    h->k.N = L->n_grids; h->k.T = L->n_steps; h->k.H = L->horizon; h->k.final_step = final_step;
+    h->flags = (L->has_genset ? F_GENSET : 0) | (L->has_battery ? F_BATTERY : 0) | (L->has_grid ? F_GRID : 0);
+    h->action_dim = 2 * L->has_genset + L->has_battery + L->has_grid;
+    const int w = 1 + L->horizon;
+    h->k.obs_dim = 2 * w + 4 * L->has_genset + 2 * L->has_battery + 4 * w * L->has_grid;
+    h->k.log_dim = LC_COMMON_END + LC_GENSET_N * L->has_genset + LC_BATTERY_N * L->has_battery + LC_GRID_N * L->has_grid;
+    h->t = L->initial_step;
+    if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
+        delete h;
+        return hip_fail(e, "hipMalloc(scratch)");
+    }
+    *out = h;
+    return MGX_OK;
+}
+
+void mgx_destroy(mgx_handle *h)
+{
+    if (!h) return;
+    if (h->scratch) (void)hipFree(h->scratch);
+    delete h;
+}
+
+int32_t mgx_action_dim(const mgx_handle *h) { return h ? h->action_dim : -1; }
+int32_t mgx_obs_dim(const mgx_handle *h) { return h ? h->k.obs_dim : -1; }
+int32_t mgx_log_dim(const mgx_handle *h) { return h ? h->k.log_dim : -1; }
+int32_t mgx_current_step(const mgx_handle *h) { return h ? h->t : -1; }
+
+const char *mgx_log_name(const mgx_handle *h, int32_t col)
+{
+    if (!h || col < 0 || col >= h->k.log_dim) return nullptr;
+    if (col < LC_COMMON_END) return kCommonNames[col];
+    col -= LC_COMMON_END;
+    if (h->layout.has_genset) { if (col < LC_GENSET_N) return kGensetNames[col]; col -= LC_GENSET_N; }
+    if (h->layout.has_battery) { if (col < LC_BATTERY_N) return kBatteryNames[col]; col -= LC_BATTERY_N; }
+    if (h->layout.has_grid) { if (col < LC_GRID_N) return kGridNames[col]; }
+    return nullptr;
+}
+
+static int need_obs_bounds(const mgx_handle *h, const char *who)
+{
+    const mgx_columns &c = h->k.c;
+    if (!c.load_lo || !c.load_hi || !c.pv_lo || !c.pv_hi || (h->layout.has_grid && (!c.grid_lo || !c.grid_hi)))
+        return fail(MGX_ERR_INVALID, "%s: observations requested but the *_lo / *_hi bound columns are NULL", who);
+    return MGX_OK;
+}
+
+int mgx_observe(mgx_handle *h, double *obs, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !obs) return fail(MGX_ERR_INVALID, "mgx_observe: NULL argument");
+    if (int rc = need_obs_bounds(h, "mgx_observe")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    MGX_DISPATCH_F(h->flags, (observe_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, h->t, obs)));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "observe_kernel launch");
+}
+
+int mgx_reset(mgx_handle *h, int32_t initial_step, double *obs, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_reset: NULL handle");
+    const int32_t t0 = initial_step >= 0 ? initial_step : h->layout.initial_step;
+    if (t0 >= h->layout.final_step)
+        return fail(MGX_ERR_INVALID, "mgx_reset: initial_step %d must be below final_step %d", t0, h->layout.final_step);
+    h->t = t0;                       // base_module.py:292-296 -- nothing else is restored
+    return obs ? mgx_observe(h, obs, stream) : MGX_OK;
+}
+
+int mgx_step(mgx_handle *h, const double *actions, int normalized, double *reward, uint8_t *done, double *obs,
+             double *log, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !reward || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_step: NULL argument");
+    if (h->t < 0 || h->t >= h->k.T)
+        return fail(MGX_ERR_RANGE, "mgx_step: step %d is outside the time series (length %d)", h->t, h->k.T);
+    if (obs) { if (int rc = need_obs_bounds(h, "mgx_step")) return rc; }
+    hipStream_t st = (hipStream_t)stream;
+    MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, h->t, normalized, reward,
+                                                                                    done, obs, log)));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "step_kernel launch");
+    h->t += 1;
+    return MGX_OK;
+}
+
+int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized, double *reward, uint8_t *done,
+               double *soc_trace, uint32_t *status_trace, double *ret_acc, double *log, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_step_k: NULL argument");
+    if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_step_k: K must be positive");
+    if (h->t < 0 || (int64_t)h->t + K > h->k.T)
+        return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
+    hipStream_t st = (hipStream_t)stream;
+    MGX_DISPATCH_F(h->flags, (step_k_kernel<F, 4><<<blocks_for(h->k.N), BLOCK, 0, st>>>(
+                                  h->k, actions, h->t, K, normalized, reward, done, soc_trace, status_trace, ret_acc, log)));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "step_k_kernel launch");
+    h->t += K;
+    return MGX_OK;
+}
+
+int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions,
+                        double *control, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !action_id || !table || !control) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: NULL argument");
+    if (n_actions <= 0 || n_actions > 12) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: n_actions must be in [1, 12]");
+    if (h->t < 0 || h->t >= h->k.T)
+        return fail(MGX_ERR_RANGE, "mgx_expand_discrete: step %d is outside the time series (length %d)", h->t, h->k.T);
+    PLTable tab;
+    memset(&tab, 0xff, sizeof(tab));
+    tab.n_actions = n_actions;
+    for (int i = 0; i < n_actions; i++)
+        for (int k = 0; k < 3; k++) {
+            const int32_t mod = table[(i * 3 + k) * 2], act = table[(i * 3 + k) * 2 + 1];
+            if (mod < -1 || mod > 2) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: bad module id %d", mod);
+            if (mod == 0 && !h->layout.has_genset) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: table names a genset, layout has none");
+            if (mod == 1 && !h->layout.has_battery) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: table names a battery, layout has none");
+            if (mod == 2 && !h->layout.has_grid) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: table names a grid, layout has none");
+            tab.module[i][k] = (int8_t)mod;
+            tab.action[i][k] = (int8_t)act;
+        }
+    hipStream_t st = (hipStream_t)stream;
+    MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, h->t, control)));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "expand_kernel launch");
+}
+
+int mgx_metrics(mgx_handle *h, const double *values, int32_t M, double *sums, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !values || !sums) return fail(MGX_ERR_INVALID, "mgx_metrics: NULL argument");
+    if (M <= 0 || M > MAX_METRICS) return fail(MGX_ERR_INVALID, "mgx_metrics: M must be in [1, %d]", MAX_METRICS);
+    const int64_t N = h->k.N;
+    // fixed slice per block: >= 2048 grids, at most MAX_PARTIAL blocks
+    int64_t per_block = 2048;
+    while ((N + per_block - 1) / per_block > MAX_PARTIAL) per_block *= 2;
+    const unsigned nb = (unsigned)((N + per_block - 1) / per_block);
+    hipStream_t st = (hipStream_t)stream;
+    colsum_stage1<<<dim3(nb, (unsigned)M), BLOCK, 0, st>>>(values, N, (int32_t)per_block, h->scratch);
+    colsum_stage2<<<(unsigned)M, BLOCK, 0, st>>>(h->scratch, (int32_t)nb, sums);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "colsum launch");
+}
+
+}  // extern "C"

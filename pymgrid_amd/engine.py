@@ -1,0 +1,152 @@
+"""Thin Python driver of the C ABI (``include/mgx.h``): device pointers of torch tensors in, kernels out.
+
+``StepEngine`` is the batched counterpart of the reference's ``Microgrid`` object as far as stepping goes:
+``run``/``step`` (microgrid.py:227-325), ``reset`` (microgrid.py:205-219), the discrete action expansion
+(priority_list.py:69-167) and the log/observation outputs.  torch is used for memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class StepEngine:
+    def __init__(self, batch):
+        if batch.device.type != "cuda":
+            raise _lib.MgxError(_lib.MGX_ERR_DEVICE,
+                                "StepEngine needs the batch on a GPU (cuda/HIP device); there is no CPU path")
+        self.batch = batch
+        self.layout = batch.layout
+        self.device = batch.device
+        self._lib = _lib.lib()
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L, cols = batch.c_layout(), batch.c_columns()
+            check(self._lib.mgx_create(C.byref(L), C.byref(cols), C.byref(self._h)))
+        self.N = self.layout.n_grids
+        self.action_dim = self._lib.mgx_action_dim(self._h)
+        self.obs_dim = self._lib.mgx_obs_dim(self._h)
+        self.log_dim = self._lib.mgx_log_dim(self._h)
+        self.log_names = [self._lib.mgx_log_name(self._h, j).decode() for j in range(self.log_dim)]
+        assert self.action_dim == self.layout.action_dim and self.obs_dim == self.layout.obs_dim
+        assert self.log_names == self.layout.log_names
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mgx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _empty(self, *shape, dtype=torch.float64):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _check_actions(self, actions, lead):
+        want = (*lead, self.N, self.action_dim)
+        if actions is None:
+            if self.action_dim:
+                raise ValueError("actions are required")
+            return None
+        if tuple(actions.shape) != want or actions.dtype != torch.float64 or not actions.is_contiguous() \
+                or actions.device != self.device:
+            raise ValueError(f"actions must be a contiguous float64 tensor of shape {want} on {self.device}")
+        return actions
+
+    @property
+    def current_step(self):
+        return self._lib.mgx_current_step(self._h)
+
+    # ------------------------------------------------------------------------------------------------
+    def reset(self, initial_step=None, want_obs=True, out=None):
+        obs = (out if out is not None else self._empty(self.N, self.obs_dim)) if want_obs else None
+        with torch.cuda.device(self.device):
+            check(self._lib.mgx_reset(self._h, -1 if initial_step is None else int(initial_step), _ptr(obs),
+                                      self._stream()))
+        return obs
+
+    def observe(self, out=None):
+        obs = out if out is not None else self._empty(self.N, self.obs_dim)
+        with torch.cuda.device(self.device):
+            check(self._lib.mgx_observe(self._h, _ptr(obs), self._stream()))
+        return obs
+
+    def step(self, actions, normalized=True, want_obs=True, want_log=False, out=None):
+        """One Microgrid.run for every grid.  Returns (obs|None, reward, done, log|None); ``out`` may hold
+        preallocated ``obs`` / ``reward`` / ``done`` / ``log`` tensors."""
+        out = out or {}
+        actions = self._check_actions(actions, ())
+        reward = out.get("reward") if out.get("reward") is not None else self._empty(self.N)
+        done = out.get("done") if out.get("done") is not None else self._empty(self.N, dtype=torch.uint8)
+        obs = (out.get("obs") if out.get("obs") is not None else self._empty(self.N, self.obs_dim)) if want_obs else None
+        log = (out.get("log") if out.get("log") is not None else self._empty(self.log_dim, self.N)) if want_log else None
+        with torch.cuda.device(self.device):
+            check(self._lib.mgx_step(self._h, _ptr(actions), int(bool(normalized)), _ptr(reward), _ptr(done),
+                                     _ptr(obs), _ptr(log), self._stream()))
+        return obs, reward, done, log
+
+    def step_k(self, actions, normalized=True, reward=True, done=False, soc_trace=False, status_trace=False,
+               ret_acc=None, log=False, out=None):
+        """K fused steps (actions [K, N, A]).  Returns a dict of the requested [K, N] outputs."""
+        out = out or {}
+        K = int(actions.shape[0]) if actions is not None else int(out["K"])
+        actions = self._check_actions(actions, (K,))
+        res = {}
+
+        def buf(name, want, *shape, dtype=torch.float64):
+            if not want:
+                return None
+            t = out.get(name)
+            if t is None:
+                t = self._empty(*shape, dtype=dtype)
+            res[name] = t
+            return t
+        r = buf("reward", reward, K, self.N)
+        d = buf("done", done, K, self.N, dtype=torch.uint8)
+        s = buf("soc_trace", soc_trace and self.layout.has_battery, K, self.N)
+        g = buf("status_trace", status_trace and self.layout.has_genset, K, self.N, dtype=torch.int32)
+        lg = buf("log", log, K, self.log_dim, self.N)
+        if ret_acc is not None:
+            res["ret_acc"] = ret_acc
+        with torch.cuda.device(self.device):
+            check(self._lib.mgx_step_k(self._h, _ptr(actions), K, int(bool(normalized)), _ptr(r), _ptr(d), _ptr(s),
+                                       _ptr(g), _ptr(ret_acc), _ptr(lg), self._stream()))
+        return res
+
+    def expand_discrete(self, action_id, table, out=None):
+        """priority-list ids [N] (int32) -> unnormalised control [N, A]; ``table`` int32 [n_actions, 3, 2]."""
+        if action_id.dtype != torch.int32 or tuple(action_id.shape) != (self.N,) or action_id.device != self.device:
+            raise ValueError(f"action_id must be an int32 tensor of shape ({self.N},) on {self.device}")
+        table = np.ascontiguousarray(table, dtype=np.int32)
+        if table.ndim != 3 or table.shape[1:] != (3, 2):
+            raise ValueError("table must have shape [n_actions, 3, 2]")
+        control = out if out is not None else self._empty(self.N, self.action_dim)
+        with torch.cuda.device(self.device):
+            check(self._lib.mgx_expand_discrete(self._h, _ptr(action_id), table.ctypes.data_as(_lib.c_i32_p),
+                                                table.shape[0], _ptr(control), self._stream()))
+        return control
+
+    def metrics(self, values, out=None):
+        """Column sums over the grids: values [M, N] -> [M] (deterministic LDS + wavefront-shuffle reduction)."""
+        if values.dim() == 1:
+            values = values.unsqueeze(0)
+        if values.dtype != torch.float64 or values.shape[1] != self.N or not values.is_contiguous():
+            raise ValueError(f"values must be contiguous float64 [M, {self.N}]")
+        sums = out if out is not None else self._empty(values.shape[0])
+        with torch.cuda.device(self.device):
+            check(self._lib.mgx_metrics(self._h, _ptr(values), values.shape[0], _ptr(sums), self._stream()))
+        return sums

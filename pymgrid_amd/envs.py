@@ -1,0 +1,247 @@
+"""Gym-style environments over the batched step engine -- the drop-in boundary for the reference's ``pymgrid.envs``.
+
+Reference surface being mirrored (paths relative to src/pymgrid/):
+  BaseMicrogridEnv.step / reset / action_space / observation_space    envs/base/base.py:85-224
+  DiscreteMicrogridEnv.step / actions_list / action_space              envs/discrete/discrete.py:38-152
+  Microgrid.run / reset / sample_action / get_log                      microgrid/microgrid.py:205-475
+
+Batched classes take and return torch tensors with a leading grid dimension N.  ``MicrogridEnv`` /
+``DiscreteMicrogridEnv`` below are N = 1 adaptors that return exactly the reference's Python shapes
+(float reward, bool done, flat ``np.ndarray`` or nested ``dict`` observation), so parity tests read like the
+reference's own tests.
+
+Differences that are deliberate:
+  * ``raise_errors=True`` (ValueError instead of clipping, base_module.py:79-93) is not offered on device;
+    requests are always clipped, as with the reference default ``raise_errors=False``.
+  * the flat observation order is fixed: load, pv, genset, battery, grid (the reference leaves it to gym's
+    ``Dict`` ordering); ``info`` holds batched log columns instead of per-module dict lists.
+"""
+import numpy as np
+import torch
+
+from .batch import MicrogridBatch, unpack_status
+from .engine import StepEngine
+from .priority_list import MODULE_NAMES, get_priority_lists, table_array
+from .spaces import Box, Discrete
+
+
+class BatchedMicrogridEnv:
+    """``BaseMicrogridEnv`` for N microgrids advancing in lock-step (continuous control surface =
+    ``Microgrid.run(control, normalized)``; the reference's own ContinuousMicrogridEnv is non-functional in
+    v1.2.2)."""
+
+    def __init__(self, batch, log=False, observations=True):
+        if not isinstance(batch, MicrogridBatch):
+            raise TypeError("batch must be a MicrogridBatch")
+        self.batch = batch
+        self.layout = batch.layout
+        self.engine = StepEngine(batch)
+        self.n_grids = self.layout.n_grids
+        self._keep_log = bool(log)
+        self._observations = bool(observations)
+        self._log_rows = []
+        A = self.layout.action_dim
+        self.action_space = Box(0.0, 1.0, shape=(A,))                       # normalised control
+        self.observation_space = Box(0.0, 1.0, shape=(self.layout.obs_dim,))  # normalised observation
+        self._out = {}
+
+    # ---- reference-like properties ------------------------------------------------------------------
+    @property
+    def current_step(self):
+        return self.engine.current_step
+
+    @property
+    def initial_step(self):
+        return self.layout.initial_step
+
+    @property
+    def final_step(self):
+        return self.layout.final_step
+
+    def __len__(self):
+        return self.n_grids
+
+    # ---- Gym API --------------------------------------------------------------------------------------
+    def reset(self, initial_step=None):
+        """Microgrid.reset: step counter back to ``initial_step``, logs flushed, state NOT restored."""
+        self._log_rows = []
+        return self.engine.reset(initial_step, want_obs=self._observations)
+
+    def step(self, action, normalized=True):
+        """action: float64 tensor [N, A] (columns ``layout.action_names``) or a control dict as taken by
+        ``Microgrid.run``.  Returns (obs [N, D], reward [N], done [N] bool, info)."""
+        if isinstance(action, dict):
+            action = self.control_to_tensor(action)
+        obs, reward, done, log = self.engine.step(action, normalized=normalized, want_obs=self._observations,
+                                                  want_log=self._keep_log)
+        info = {}
+        if log is not None:
+            self._log_rows.append(log)
+            info["log"] = log
+        return obs, reward, done.bool(), info
+
+    run = step      # Microgrid.run has the same signature and return value (microgrid.py:227-325)
+
+    def sample_action(self, generator=None):
+        """Microgrid.sample_action(strict_bound=False): uniform normalised control (microgrid.py:337-362)."""
+        return torch.rand(self.n_grids, self.layout.action_dim, dtype=torch.float64, device=self.batch.device,
+                          generator=generator)
+
+    def control_to_tensor(self, control):
+        """{'genset': [[goal, energy]], 'battery': [x], 'grid': [x]} (values scalars or [N] tensors) -> [N, A]."""
+        cols = []
+        dev = self.batch.device
+
+        def as_col(v):
+            v = torch.as_tensor(v, dtype=torch.float64, device=dev)
+            return v.expand(self.n_grids) if v.dim() == 0 else v
+        if self.layout.has_genset:
+            g = control["genset"][0] if isinstance(control["genset"], (list, tuple)) and len(control["genset"]) == 1 \
+                else control["genset"]
+            cols += [as_col(g[0]), as_col(g[1])]
+        for name, has in (("battery", self.layout.has_battery), ("grid", self.layout.has_grid)):
+            if has:
+                v = control[name]
+                v = v[0] if isinstance(v, (list, tuple)) else v
+                cols.append(as_col(v))
+        return torch.stack(cols, dim=1).contiguous() if cols else torch.empty(self.n_grids, 0, dtype=torch.float64,
+                                                                              device=dev)
+
+    # ---- log --------------------------------------------------------------------------------------------
+    def get_log(self, as_numpy=True):
+        """Microgrid.get_log (microgrid.py:434-475) as {column: [steps, N]}; needs ``log=True``."""
+        if not self._keep_log:
+            raise RuntimeError("environment was created with log=False")
+        if not self._log_rows:
+            return {}
+        stack = torch.stack(self._log_rows)                     # [steps, L, N]
+        out = {name: stack[:, j] for j, name in enumerate(self.engine.log_names)}
+        if "genset_status" in out:
+            st = unpack_status(out.pop("genset_status").cpu().numpy())
+            for j, name in enumerate(("current_status", "goal_status", "steps_until_up", "steps_until_down")):
+                out["genset_" + name] = st[..., j]
+        return {k: (v.cpu().numpy() if as_numpy and torch.is_tensor(v) else v) for k, v in out.items()}
+
+    def state_dict(self):
+        """Microgrid.state_dict-like view of the dynamic state (microgrid.py:699-729)."""
+        out = {"current_step": self.current_step}
+        c = self.batch.cols
+        if self.layout.has_battery:
+            out["soc"], out["current_charge"] = c["soc"], c["charge"]
+        if self.layout.has_genset:
+            out["genset_status"] = c["gen_status"]
+        return out
+
+    def close(self):
+        self.engine.close()
+
+
+class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
+    """``DiscreteMicrogridEnv`` for N microgrids: an action is the index of a priority list, expanded on device
+    into an unnormalised control and stepped with ``normalized=False`` (discrete.py:109-143)."""
+
+    def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True):
+        super().__init__(batch, log=log, observations=observations)
+        L = self.layout
+        redundant = False
+        if remove_redundant_gensets and L.has_genset:
+            rmin = batch.cols["gen_running_min"]
+            n_zero = int((rmin == 0).sum().item())
+            if 0 < n_zero < L.n_grids:
+                raise ValueError("remove_redundant_gensets: the batch mixes gensets with running_min_production == 0 "
+                                 "and > 0, which have different action spaces in the reference "
+                                 "(priority_list.py:53-67); bucket them or pass remove_redundant_gensets=False")
+            redundant = n_zero == L.n_grids
+        self.actions_list = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, redundant)
+        self._table = table_array(self.actions_list)
+        self.action_space = Discrete(len(self.actions_list))
+
+    def get_action(self, action_id):
+        """DiscreteMicrogridEnv._get_action: ids [N] -> unnormalised control [N, A]."""
+        if not torch.is_tensor(action_id):
+            action_id = torch.as_tensor(np.asarray(action_id), device=self.batch.device)
+        action_id = action_id.to(device=self.batch.device, dtype=torch.int32).contiguous()
+        return self.engine.expand_discrete(action_id, self._table)
+
+    def step(self, action_id):
+        control = self.get_action(action_id)
+        return super().step(control, normalized=False)
+
+    def sample_action(self, generator=None):
+        return torch.randint(0, self.action_space.n, (self.n_grids,), dtype=torch.int32, device=self.batch.device,
+                             generator=generator)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N = 1 adaptors with the reference's exact Python return shapes
+# ---------------------------------------------------------------------------------------------------------
+class _SingleMixin:
+    flat_spaces = True
+
+    def _nested(self, obs_row):
+        """flat row -> {'load': [arr], 'pv': [arr], 'genset': [arr], 'battery': [arr], 'grid': [arr]}."""
+        return {name: [obs_row[sl].copy()] for name, sl in self.layout.obs_slices().items()}
+
+    def _obs_out(self, obs):
+        row = obs[0].cpu().numpy()
+        return row if self.flat_spaces else self._nested(row)
+
+    def _info_out(self, info):
+        if "log" not in info:
+            return {}
+        col = info["log"][:, 0].cpu().numpy()
+        return {name: float(col[j]) for j, name in enumerate(self.engine.log_names)}
+
+
+class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
+    """One microgrid behind ``BaseMicrogridEnv``'s API: ``step(control_dict, normalized=True)`` returns
+    ``(obs, float, bool, dict)`` exactly like envs/base/base.py:169-209."""
+
+    def __init__(self, params, device="cuda", flat_spaces=True, log=True):
+        super().__init__(MicrogridBatch.from_grids([params], device=device), log=log)
+        self.flat_spaces = flat_spaces
+
+    def reset(self, initial_step=None):
+        return self._obs_out(super().reset(initial_step))
+
+    def step(self, action, normalized=True):
+        obs, reward, done, info = super().step(action, normalized=normalized)
+        return self._obs_out(obs), float(reward.item()), bool(done.item()), self._info_out(info)
+
+    run = step
+
+
+class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
+    """One microgrid behind ``DiscreteMicrogridEnv``'s API (envs/discrete/discrete.py:10-152):
+    ``step(action: int) -> (obs, reward: float, done: bool, info: dict)``."""
+
+    def __init__(self, params, device="cuda", flat_spaces=True, log=True, remove_redundant_gensets=True):
+        super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
+                         remove_redundant_gensets=remove_redundant_gensets)
+        self.flat_spaces = flat_spaces
+
+    def reset(self, initial_step=None):
+        return self._obs_out(super().reset(initial_step))
+
+    def get_action_dict(self, action):
+        """The control dict the reference's ``_get_action`` returns (discrete.py:82-88)."""
+        if action not in self.action_space:
+            raise ValueError(f" Action {action} not in action space {self.action_space}")
+        c = self.get_action(np.array([action]))[0].cpu().numpy()
+        out, k = {}, 0
+        if self.layout.has_genset:
+            out["genset"] = [np.array([c[k], c[k + 1]])]; k += 2
+        if self.layout.has_battery:
+            out["battery"] = [float(c[k])]; k += 1
+        if self.layout.has_grid:
+            out["grid"] = [float(c[k])]; k += 1
+        return out
+
+    def step(self, action):
+        if action not in self.action_space:
+            raise ValueError(f" Action {action} not in action space {self.action_space}")
+        obs, reward, done, info = super().step(np.array([int(action)]))
+        return self._obs_out(obs), float(reward.item()), bool(done.item()), self._info_out(info)
+
+    def priority_list_names(self, action):
+        return [(MODULE_NAMES[m], a) for m, a in self.actions_list[action]]

@@ -1,0 +1,49 @@
+"""Priority lists of the discrete environment: host-side mirror of ``PriorityListAlgo.get_priority_lists``
+(algos/priority_list/priority_list.py:15-67) and ``PriorityListElement`` (priority_list_element.py:8-80).
+
+An element is ``(module, action)`` with module 0 genset / 1 battery / 2 grid.  A genset contributes two elements
+(its action space has two entries: goal status 0 or 1), battery and grid one each.
+"""
+from itertools import permutations
+
+import numpy as np
+
+GENSET, BATTERY, GRID = 0, 1, 2
+MODULE_NAMES = {GENSET: "genset", BATTERY: "battery", GRID: "grid"}
+
+
+def get_priority_lists(has_genset, has_battery, has_grid, remove_redundant_gensets=False):
+    """All priority lists in the reference's order.
+
+    controllable sources first (genset), then source_and_sinks (battery, grid) -- priority_list.py:26-33;
+    every permutation, later repeats of a module dropped (:40-47), duplicates removed keeping first
+    occurrence (:48); with ``remove_redundant_gensets`` (gensets whose running_min_production == 0) lists that
+    hold the genset "off" element are dropped (:53-67)."""
+    elements = []
+    if has_genset:
+        elements += [(GENSET, 0), (GENSET, 1)]
+    if has_battery:
+        elements += [(BATTERY, 0)]
+    if has_grid:
+        elements += [(GRID, 0)]
+    pls = []
+    for perm in permutations(elements):
+        seen, pl = set(), []
+        for mod, act in perm:
+            if mod not in seen:
+                seen.add(mod)
+                pl.append((mod, act))
+        pls.append(tuple(pl))
+    unique = list(dict.fromkeys(pls))
+    if remove_redundant_gensets:
+        unique = [pl for pl in unique if (GENSET, 0) not in pl]
+    return unique
+
+
+def table_array(priority_lists):
+    """-> int32 [n_actions, 3, 2] (module, action), -1 padded: the layout ``mgx_expand_discrete`` takes."""
+    tab = -np.ones((len(priority_lists), 3, 2), dtype=np.int32)
+    for i, pl in enumerate(priority_lists):
+        for j, (mod, act) in enumerate(pl):
+            tab[i, j] = (mod, act)
+    return tab

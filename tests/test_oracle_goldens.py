@@ -1,0 +1,194 @@
+"""The CPU oracle (oracle/mgx_oracle.c) against golden vectors produced by the REAL reference
+(tests/golden/make_goldens.py).  Bit-exact fp64 equality everywhere: the restatement must be the reference."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import action_dim, actions_for, golden
+
+
+def _check_log_row(out, names, row, where):
+    d = out.as_dict()
+    for j, name in enumerate(names):
+        ref = row[j]
+        if np.isnan(ref):
+            continue
+        assert d[name] == ref, f"{where}: {name}: oracle {d[name]!r} != reference {ref!r}"
+
+
+@pytest.mark.parametrize("n", range(25))
+def test_pymgrid25_full_year(n, pymgrid25, oracle):
+    """G1/G2: every scenario, 8759 steps, seeded random normalised actions: per-step reward, SoC, genset status,
+    sub-sampled full log rows and column sums."""
+    z = golden("pymgrid25_run.npz")
+    names = [str(s) for s in z["log_names"]]
+    p = pymgrid25[n]
+    om = oracle.OracleMicrogrid(p)
+    K = p["final_step"] - p["initial_step"]
+    acts = np.random.RandomState(int(z[f"s{n}_seed"])).rand(K, action_dim(p))
+    reward, soc, status = np.zeros(K), np.zeros(K), np.zeros((K, 4), np.int8)
+    idx = set(z[f"s{n}_log_idx"].tolist())
+    sub = {int(k): r for k, r in zip(z[f"s{n}_log_idx"], z[f"s{n}_log_sub"])}
+    charge_sub = dict(zip(z[f"s{n}_log_idx"].tolist(), z[f"s{n}_charge_sub"]))
+    colsum = np.zeros(len(names))
+    for k in range(K):
+        out = om.run(actions_for(p, acts[k]), True)
+        reward[k], soc[k], status[k] = out.reward, om.s.soc, om.status
+        d = out.as_dict()
+        colsum += np.array([d[nm] for nm in names])
+        if k in idx:
+            _check_log_row(out, names, sub[k], f"scenario {n} step {k}")
+            assert om.s.charge == charge_sub[k]
+        assert out.done == int(k == K - 1)
+    assert np.array_equal(reward, z[f"s{n}_reward"])
+    assert np.array_equal(soc, z[f"s{n}_soc"])
+    if p.get("genset") is not None:
+        assert np.array_equal(status, z[f"s{n}_status"])
+    ref_sum = z[f"s{n}_log_colsum"]
+    present = ~np.isnan(sub[0])
+    np.testing.assert_allclose(colsum[present], ref_sum[present], rtol=1e-9)
+
+
+@pytest.mark.parametrize("n", range(25))
+def test_discrete_expansion(n, pymgrid25, oracle):
+    """G3: priority-list tables and the expanded controls of DiscreteMicrogridEnv, 400 random ids/scenario."""
+    from pymgrid_amd.priority_list import MODULE_NAMES
+    z = golden("discrete.npz")
+    p = pymgrid25[n]
+    om = oracle.OracleMicrogrid(p)
+    table = z[f"s{n}_table"]
+    ids, control, reward, soc = z[f"s{n}_ids"], z[f"s{n}_control"], z[f"s{n}_reward"], z[f"s{n}_soc"]
+    for k in range(len(ids)):
+        plist = [(MODULE_NAMES[int(m)], int(a)) for m, a in table[ids[k]] if m >= 0]
+        act = om.populate_action(plist)
+        flat = []
+        for name in ("genset", "battery", "grid"):
+            if name in act:
+                flat += list(np.atleast_1d(act[name]))
+        assert np.array_equal(np.array(flat), control[k]), f"scenario {n} step {k}"
+        out = om.run(act, normalized=False)
+        assert out.reward == reward[k]
+        if p.get("battery") is not None:
+            assert om.s.soc == soc[k]
+
+
+def test_genset_fsm_table(oracle):
+    """G4: every (start_up, wind_down, pre-state, goal) -> post-state transition the reference produces."""
+    import ctypes as C
+    z = golden("genset_fsm.npz")
+    L = oracle.lib()
+    for su, wd, goal, c0, g0, u0, d0, c1, g1, u1, d1, nxt in z["transitions"]:
+        g = oracle.Grid(); g.gen_start_up_time, g.gen_wind_down_time = int(su), int(wd)
+        s = oracle.State(); s.gen_cur, s.gen_goal, s.gen_up, s.gen_down = int(c0), int(g0), int(u0), int(d0)
+        assert L.orc_genset_next_status(C.byref(s), int(goal)) == nxt
+        L.orc_genset_update_status(C.byref(g), C.byref(s), float(goal))
+        assert (s.gen_cur, s.gen_goal, s.gen_up, s.gen_down) == (c1, g1, u1, d1)
+        assert s.gen_cur == nxt
+    for v, cur in z["fractional"]:          # round-half-to-even on the goal (genset_module.py:281)
+        g = oracle.Grid(); s = oracle.State()
+        L.orc_genset_update_status(C.byref(g), C.byref(s), float(v))
+        assert s.gen_cur == int(cur), v
+
+
+def test_observations_head(pymgrid25, oracle):
+    """reset() observation + 40 post-step observations of every scenario (H = 23, 4-component grid windows)."""
+    z = golden("obs.npz")
+    for n, p in enumerate(pymgrid25):
+        om = oracle.OracleMicrogrid(p)
+        assert np.array_equal(om.reset(), z[f"head{n}_obs0"])
+        acts = np.random.RandomState(3100 + n).rand(40, action_dim(p))
+        for k in range(40):
+            om.run(actions_for(p, acts[k]), True)
+            assert np.array_equal(om.observe(), z[f"head{n}_obs"][k]), (n, k)
+
+
+@pytest.mark.parametrize("n", [1, 0, 2])
+def test_observations_end_of_series_padding(n, pymgrid25, oracle):
+    """G5: start late, run to done and one step beyond: forecast rows past the series are (lo+hi)/2."""
+    z = golden("obs.npz")
+    p = dict(pymgrid25[n]); p["initial_step"] = int(z[f"tail{n}_start"])
+    om = oracle.OracleMicrogrid(p)
+    assert np.array_equal(om.reset(), z[f"tail{n}_obs0"])
+    K = p["final_step"] - p["initial_step"]
+    acts = np.random.RandomState(3000 + n).rand(K, action_dim(p))
+    for k in range(K):
+        out = om.run(actions_for(p, acts[k]), True)
+        assert out.reward == z[f"tail{n}_reward"][k] and out.done == z[f"tail{n}_done"][k]
+        assert np.array_equal(om.observe(), z[f"tail{n}_obs"][k]), k
+    om.run(actions_for(p, np.full(action_dim(p), 0.5)), True)     # one step past `done`: still inside the series
+    assert np.array_equal(om.observe(), z[f"tail{n}_obs_extra"][0])
+    with pytest.raises(IndexError):                              # the series is exhausted now
+        om.run(actions_for(p, np.full(action_dim(p), 0.5)), True)
+
+
+def test_reset_keeps_dynamic_state(pymgrid25, oracle):
+    """G8: reset() rewinds the step counter only; SoC and genset status persist."""
+    z = golden("obs.npz")
+    p = pymgrid25[1]
+    om = oracle.OracleMicrogrid(p)
+    acts = np.random.RandomState(3200).rand(30, action_dim(p))
+    r1 = [om.run(actions_for(p, a), True).reward for a in acts[:15]]
+    obs = om.reset()
+    assert np.array_equal(obs, z["reset_obs"])
+    assert np.array_equal(np.array([om.s.charge, om.s.soc, *om.status]), z["reset_state"])
+    r2, soc2 = [], []
+    for a in acts[15:]:
+        r2.append(om.run(actions_for(p, a), True).reward); soc2.append(om.s.soc)
+    assert np.array_equal(r1, z["reset_reward1"]) and np.array_equal(r2, z["reset_reward2"])
+    assert np.array_equal(soc2, z["reset_soc2"])
+
+
+def test_generated_grids(oracle):
+    """G6/G7: 48 generator-style grids built as real reference modules: genset timers 0..3, weak grids,
+    normalised and raw (out-of-range, exact-zero) controls, H = 0 and 24."""
+    z = golden("generated.npz")
+    names = [str(s) for s in z["log_names"]]
+    meta = json.loads(str(z["meta"]))
+    for i, m in enumerate(meta):
+        p = dict(m)
+        for k in ("load_ts", "pv_ts", "grid_ts"):
+            if f"g{i}_{k}" in z.files:
+                p[k] = z[f"g{i}_{k}"]
+        om = oracle.OracleMicrogrid(p)
+        assert np.array_equal(om.reset(), z[f"g{i}_obs0"])
+        acts = z[f"g{i}_actions"]
+        has_obs = f"g{i}_obs" in z.files
+        for k in range(acts.shape[0]):
+            out = om.run(actions_for(p, acts[k]), m["normalized"])
+            _check_log_row(out, names, z[f"g{i}_log"][k], f"grid {i} step {k}")
+            assert om.s.charge == z[f"g{i}_charge"][k] and om.s.soc == z[f"g{i}_soc"][k]
+            if p.get("genset") is not None:
+                assert tuple(z[f"g{i}_status"][k]) == om.status
+            if has_obs and k % 5 == 0:
+                assert np.array_equal(om.observe(), z[f"g{i}_obs"][k // 5]), (i, k)
+
+
+def test_loadpv_multi_module(oracle):
+    """Load/PV-only grids with up to 9 modules each (reference tests/microgrid/test_microgrid.py:188-427):
+    reward, balance columns and the numpy pairwise-sum order for >= 8 addends."""
+    z = golden("loadpv.npz")
+    names = [str(s) for s in z["log_names"]]
+    for c in range(int(z["n_cases"])):
+        p = dict(load_ts=z[f"c{c}_load_ts"], pv_ts=z[f"c{c}_pv_ts"], final_step=100, horizon=0,
+                 unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0))
+        om = oracle.OracleMicrogrid(p)
+        for k in range(99):
+            out = om.run({}, True)
+            assert out.reward == z[f"c{c}_reward"][k] and out.done == z[f"c{c}_done"][k]
+            row = z[f"c{c}_log"][k]
+            d = out.as_dict()
+            for j, name in enumerate(names):
+                if np.isnan(row[j]):
+                    continue
+                if name in ("load_met", "renewable_used", "curtailment"):     # per-module columns summed
+                    assert d[name] == pytest.approx(row[j], rel=1e-13)
+                else:
+                    assert d[name] == row[j], (c, k, name)
+
+
+def test_np_sum_matches_numpy(oracle):
+    rs = np.random.RandomState(0)
+    for n in list(range(0, 20)) + [31, 64, 100, 128]:
+        a = rs.randn(n) * 10.0 ** rs.randint(-3, 6, size=n)
+        assert oracle.np_sum(a) == np.sum(a)
