@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- microgrid env-steps/s of the batched step engine (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2]): N = 100 000 generated Template-4 grids (genset + battery + load + pv) per GPU,
+T = 8760 hourly rows, synthetic data drawn with the MicrogridGenerator sizing rules (pymgrid_amd/generator.py),
+normalised U[0,1) actions.  A "step" is ONE env-step of all N grids of a rank (one pass of the hot path over the
+batch).  Everything the timed region reads (columns, series, actions) is resident in HBM before timing starts.
+
+Modes
+  fused (default)  K steps are issued as ceil(K / chunk) launches of the K-step kernel (mgx_step_k): parameters and
+                   state stay in registers, actions / series rows / per-step outputs (reward, done, SoC) stream.
+  step             one launch of the single-step kernel (mgx_step) per env-step -- the Gym cadence.
+Both are timed in every run; --mode picks which one is the headline `value`; the other is reported under "other".
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]          (N>1: torchrun, one rank per GPU, RCCL only
+                                                                    for the final metrics all-reduce)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pymgrid_amd import _lib  # noqa: E402
+from pymgrid_amd import distributed as mdist  # noqa: E402
+from pymgrid_amd.engine import StepEngine  # noqa: E402
+from pymgrid_amd.generator import generate  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--grids", type=int, default=100_000, help="microgrids PER GPU (weak scaling)")
+    ap.add_argument("--rows", type=int, default=8760, help="time-series rows T")
+    ap.add_argument("--mode", choices=["fused", "step"], default="fused")
+    ap.add_argument("--chunk", type=int, default=64, help="env-steps per fused launch")
+    ap.add_argument("--arch", default="genset+battery")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+class Runner:
+    """Issues env-steps on the current stream; wraps around the series with reset() (a host counter)."""
+
+    def __init__(self, eng, chunk, pool):
+        self.eng, self.chunk, self.pool = eng, chunk, pool          # pool: [P, chunk, N, A] actions
+        L = eng.layout
+        N = L.n_grids
+        dev = eng.device
+        self.reward_k = torch.empty(chunk, N, dtype=torch.float64, device=dev)
+        self.done_k = torch.empty(chunk, N, dtype=torch.uint8, device=dev)
+        self.soc_k = torch.empty(chunk, N, dtype=torch.float64, device=dev)
+        self.out1 = dict(reward=torch.empty(N, dtype=torch.float64, device=dev),
+                         done=torch.empty(N, dtype=torch.uint8, device=dev))
+        self.launches = 0
+        self.i = 0
+
+    def _room(self, k):
+        if self.eng.current_step + k > self.eng.layout.final_step:
+            self.eng.reset(want_obs=False)
+
+    def fused(self, steps):
+        done = 0
+        while done < steps:
+            k = min(self.chunk, steps - done)
+            self._room(k)
+            a = self.pool[self.i % self.pool.shape[0]]
+            self.eng.step_k(a[:k], normalized=True,
+                            out=dict(reward=self.reward_k[:k], done=self.done_k[:k], soc_trace=self.soc_k[:k]),
+                            reward=True, done=True, soc_trace=True)
+            self.i += 1; self.launches += 1; done += k
+
+    def single(self, steps):
+        for s in range(steps):
+            self._room(1)
+            a = self.pool[self.i % self.pool.shape[0]][s % self.chunk]
+            self.eng.step(a, normalized=True, want_obs=False, want_log=False, out=self.out1)
+            self.launches += 1
+        self.i += 1
+
+
+def timed(fn, steps, device):
+    """barrier + sync | K steps | sync + barrier; returns (wall seconds, GPU-event seconds)."""
+    mdist.barrier()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    fn(steps)
+    e1.record()
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    mdist.barrier()
+    return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def cpu_baseline(eng, pool, seconds):
+    """The CPU oracle (C restatement of the reference loop, oracle/mgx_oracle.c) timed on this host: a bounded
+    sample of the SAME workload (first n grids, their real columns / series / actions)."""
+    from oracle import oracle as orc
+    orc.build()
+    L = eng.layout
+    cores = os.cpu_count() or 1
+    n = min(L.n_grids, 4096)
+    K = min(pool.shape[1], L.final_step)
+    cols = {}
+    for k, v in eng.batch.cols.items():
+        if k in ("load_ts", "pv_ts"):
+            cols[k] = v[:K + 1, :n].contiguous().cpu().numpy()
+        elif k == "grid_ts":
+            cols[k] = v[:K + 1, :, :n].contiguous().cpu().numpy()
+        elif v.dim() == 1:
+            a = v[:n].cpu().numpy()
+            cols[k] = a.view(np.uint32) if v.dtype == torch.int32 else a
+    cols["layout"] = dict(N=n, T=K + 1, horizon=0, final_step=K + 1, has_genset=int(L.has_genset),
+                          has_battery=int(L.has_battery), has_grid=int(L.has_grid))
+    acts = pool[0][:K, :n].contiguous().cpu().numpy()
+
+    def run(nthreads, budget):
+        st = {k: cols[k].copy() for k in ("charge", "soc", "gen_status") if k in cols}
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            orc.run_batch(cols, st, 0, K, acts, normalized=True, want_reward=False, nthreads=nthreads)
+            done += n * K
+        return done / (time.perf_counter() - t0), done
+    v1, n1 = run(1, seconds * 0.4)
+    vall, nall = run(cores, seconds * 0.6)
+    return {"value": vall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "value_1thread": v1,
+            "sample": f"first {n} grids x {K} steps of the benchmark batch, repeated for ~{seconds:.0f} s "
+                      f"({n1 + nall} env-steps): oracle/mgx_oracle.c (scalar C restatement of the reference loop), "
+                      f"{cores} OpenMP threads; the Python reference itself runs ~2e3 env-steps/s/core (BASELINE.md)"}
+
+
+def main():
+    args = parse()
+    rank, world, local = mdist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    _lib.build()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    N, chunk = args.grids, args.chunk
+    n_total = N * world
+
+    batch = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world)
+    eng = StepEngine(batch)
+    L = eng.layout
+    gen = torch.Generator(device=dev); gen.manual_seed(7 + rank)
+    pool = torch.rand(4, chunk, N, L.action_dim, dtype=torch.float64, device=dev, generator=gen)
+    run = Runner(eng, chunk, pool)
+
+    results = {}
+    for mode in ("fused", "step"):
+        fn = run.fused if mode == "fused" else run.single
+        steps = args.steps if mode == args.mode else min(args.steps, 512)
+        eng.reset(want_obs=False)
+        fn(args.warmup if mode == args.mode else min(args.warmup, 64))
+        run.launches = 0
+        wall, gpu = timed(fn, steps, dev)
+        wall = mdist.max_over_ranks(wall, dev)
+        gpu = mdist.max_over_ranks(gpu, dev)
+        launches = run.launches
+        if mode == "fused":
+            per_launch = sum(L.bytes_fused(min(chunk, steps - k0)) for k0 in range(0, steps, chunk)) / launches
+            unit_bytes = L.bytes_fused(chunk) / chunk
+        else:
+            unit_bytes = L.bytes_per_step()
+            per_launch = unit_bytes
+        per_launch_bytes = per_launch * N
+        avg_launch_s = gpu / launches
+        achieved = per_launch_bytes / avg_launch_s / 1e9
+        results[mode] = {
+            "value": n_total * steps / wall, "steps": steps, "ms_per_step": wall / steps * 1e3,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "step_k_kernel<3,4>" if mode == "fused" else "step_kernel<3>",
+                         "bytes_per_env_step": unit_bytes, "launches": launches,
+                         "avg_launch_us": avg_launch_s * 1e6},
+        }
+
+    # metrics vector: episode-return sum + mean SoC, all-reduced over ranks (the ONLY collective; RCCL over xGMI)
+    sums = eng.metrics(torch.stack([run.reward_k[-1], batch.cols["soc"]]))
+    mdist.all_reduce_metrics(sums)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(eng, pool, args.cpu_seconds)
+
+    if rank == 0:
+        main_r, other = results[args.mode], results["step" if args.mode == "fused" else "fused"]
+        line = {
+            "metric": "microgrid env-steps/sec", "value": main_r["value"], "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_r["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{N} generated 4-module grids (genset+battery+load+pv) per GPU, T={args.rows}, "
+                                   f"H=0, normalised random actions (BASELINE configs[2])",
+                       "grids_per_gpu": N, "grids_total": n_total, "mode": args.mode,
+                       "steps_per_launch": chunk if args.mode == "fused" else 1,
+                       "outputs": "reward+done+soc per step" + ("" if args.mode == "step" else " (streamed [K,N])"),
+                       "parallelism": f"grids sharded x{world}, no data-path collective"},
+            "roofline": main_r["roofline"],
+            "cpu_baseline": cpu,
+            "other": {("single_step_launches" if args.mode == "fused" else "fused_launches"):
+                      {"value": other["value"], "steps": other["steps"], "ms_per_step": other["ms_per_step"],
+                       "roofline": other["roofline"]}},
+            "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total},
+        }
+        print(json.dumps(line))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

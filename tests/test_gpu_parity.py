@@ -1,0 +1,351 @@
+"""GPU parity: the HIP engine (through the C ABI in include/mgx.h) against
+  (a) golden vectors produced by the real reference (tests/golden/*.npz), and
+  (b) the CPU oracle on seeded inputs,
+bit-exact (==) on every fp64 output: reward, SoC / charge, genset status, log columns, observations, expanded
+controls.  (BASELINE.json asks for 1e-6 relative; the engine keeps the reference's operation order and disables
+FMA contraction, so equality is the bar here.)"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import action_dim, golden
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------------
+def _buckets(grids):
+    from pymgrid_amd.scenario import bucket_by_layout
+    return list(bucket_by_layout(grids).values())
+
+
+def _batch(grids, device):
+    from pymgrid_amd import MicrogridBatch
+    return MicrogridBatch.from_grids(grids, device=device)
+
+
+def _status4(word_tensor):
+    from pymgrid_amd import unpack_status
+    return unpack_status(word_tensor.cpu().numpy().view(np.uint32))
+
+
+def _t(a, device, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=device)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_pymgrid25_full_year_vs_reference(pymgrid25, device):
+    """BASELINE config 2: all 25 pymgrid25 scenarios batched (one SoA batch per module set), 8759 steps with the
+    goldens' seeded random actions, fused launches of 512 steps: per-step reward, SoC and genset status must equal
+    what the REFERENCE produced, for every step of the year."""
+    from pymgrid_amd import StepEngine
+    z = golden("pymgrid25_run.npz")
+    for idx in _buckets(pymgrid25):
+        grids = [pymgrid25[n] for n in idx]
+        batch = _batch(grids, device)
+        eng = StepEngine(batch)
+        K = grids[0]["final_step"] - grids[0]["initial_step"]
+        A = action_dim(grids[0])
+        acts = np.stack([np.random.RandomState(int(z[f"s{n}_seed"])).rand(K, A) for n in idx], axis=1)   # [K, Nb, A]
+        reward, soc, status, done = [], [], [], []
+        for k0 in range(0, K, 512):
+            out = eng.step_k(_t(acts[k0:k0 + 512], device), normalized=True, reward=True, done=True, soc_trace=True,
+                             status_trace=True)
+            reward.append(out["reward"]); soc.append(out["soc_trace"]); done.append(out["done"])
+            if "status_trace" in out:
+                status.append(out["status_trace"])
+        reward, soc, done = torch.cat(reward).cpu().numpy(), torch.cat(soc).cpu().numpy(), torch.cat(done).cpu().numpy()
+        assert eng.current_step == grids[0]["final_step"]
+        for j, n in enumerate(idx):
+            assert np.array_equal(reward[:, j], z[f"s{n}_reward"]), f"scenario {n}: reward"
+            assert np.array_equal(soc[:, j], z[f"s{n}_soc"]), f"scenario {n}: soc"
+            assert done[:-1, j].sum() == 0 and done[-1, j] == 1
+        if status:
+            st = _status4(torch.cat(status))
+            for j, n in enumerate(idx):
+                assert np.array_equal(st[:, j], z[f"s{n}_status"].astype(np.int32)), f"scenario {n}: genset status"
+        eng.close()
+
+
+def test_pymgrid25_log_columns_vs_reference(pymgrid25, device):
+    """Single-step path with the log enabled: first 128 steps of every scenario, every log column the reference
+    writes (balance log + per-module energies/rewards + pre-step SoC) equals the golden row."""
+    from pymgrid_amd import StepEngine
+    z = golden("pymgrid25_run.npz")
+    names = [str(s) for s in z["log_names"]]
+    for idx in _buckets(pymgrid25):
+        grids = [pymgrid25[n] for n in idx]
+        eng = StepEngine(_batch(grids, device))
+        A = action_dim(grids[0])
+        K = grids[0]["final_step"] - grids[0]["initial_step"]
+        acts = np.stack([np.random.RandomState(int(z[f"s{n}_seed"])).rand(K, A)[:128] for n in idx], axis=1)
+        for k in range(128):
+            _, reward, done, log = eng.step(_t(acts[k], device), normalized=True, want_obs=False, want_log=True)
+            log = log.cpu().numpy()
+            for j, n in enumerate(idx):
+                assert int(z[f"s{n}_log_idx"][k]) == k
+                row = z[f"s{n}_log_sub"][k]
+                dev = dict(zip(eng.log_names, log[:, j]))
+                if "genset_status" in dev:
+                    w = int(dev.pop("genset_status"))
+                    dev.update(gen_cur=w & 0xff, gen_goal=(w >> 8) & 0xff, gen_up=(w >> 16) & 0xff, gen_down=w >> 24)
+                for c, name in enumerate(names):
+                    if not np.isnan(row[c]):
+                        assert dev[name] == row[c], f"scenario {n} step {k} column {name}: {dev[name]!r} vs {row[c]!r}"
+        eng.close()
+
+
+def test_generated_grids_vs_reference(device):
+    """48 generator-style grids built as real reference modules (genset timers 0..3, weak grids, normalised and
+    raw / out-of-range / exact-zero controls, H = 0 and 24): every log column, state and observation."""
+    from pymgrid_amd import StepEngine
+    z = golden("generated.npz")
+    names = [str(s) for s in z["log_names"]]
+    meta = json.loads(str(z["meta"]))
+    grids = []
+    for i, m in enumerate(meta):
+        p = dict(m)
+        for k in ("load_ts", "pv_ts", "grid_ts"):
+            if f"g{i}_{k}" in z.files:
+                p[k] = z[f"g{i}_{k}"]
+        grids.append(p)
+    keyed = {}
+    for i, p in enumerate(grids):
+        from pymgrid_amd.scenario import architecture
+        keyed.setdefault((architecture(p), p["horizon"], p["normalized"]), []).append(i)
+    for (arch, horizon, normalized), idx in keyed.items():
+        eng = StepEngine(_batch([grids[i] for i in idx], device))
+        obs0 = eng.reset().cpu().numpy()
+        for j, i in enumerate(idx):
+            assert np.array_equal(obs0[j], z[f"g{i}_obs0"]), f"grid {i}: reset obs"
+        K = z[f"g{idx[0]}_actions"].shape[0]
+        acts = np.stack([z[f"g{i}_actions"] for i in idx], axis=1)
+        for k in range(K):
+            obs, reward, done, log = eng.step(_t(acts[k], device), normalized=normalized, want_obs=True, want_log=True)
+            log, obs = log.cpu().numpy(), obs.cpu().numpy()
+            charge = eng.batch.cols["charge"].cpu().numpy()
+            for j, i in enumerate(idx):
+                row = z[f"g{i}_log"][k]
+                dev = dict(zip(eng.log_names, log[:, j]))
+                if "genset_status" in dev:
+                    w = int(dev.pop("genset_status"))
+                    dev.update(gen_cur=w & 0xff, gen_goal=(w >> 8) & 0xff, gen_up=(w >> 16) & 0xff, gen_down=w >> 24)
+                for c, name in enumerate(names):
+                    if not np.isnan(row[c]):
+                        assert dev[name] == row[c], f"grid {i} step {k} {name}: {dev[name]!r} vs {row[c]!r}"
+                assert charge[j] == z[f"g{i}_charge"][k]
+                if f"g{i}_obs" in z.files and k % 5 == 0:
+                    assert np.array_equal(obs[j], z[f"g{i}_obs"][k // 5]), f"grid {i} step {k}: obs"
+        eng.close()
+
+
+def test_discrete_env_vs_reference(pymgrid25, device):
+    """G3: DiscreteBatchedMicrogridEnv -- the priority-list table, the expanded (unnormalised) controls and the
+    rewards of 400 random action ids per scenario equal DiscreteMicrogridEnv's."""
+    from pymgrid_amd import DiscreteBatchedMicrogridEnv
+    from pymgrid_amd.priority_list import table_array
+    z = golden("discrete.npz")
+    for idx in _buckets(pymgrid25):
+        grids = [pymgrid25[n] for n in idx]
+        env = DiscreteBatchedMicrogridEnv(_batch(grids, device), log=False, observations=True)
+        for n in idx:
+            assert np.array_equal(table_array(env.actions_list), z[f"s{n}_table"][:, :3])
+            assert env.action_space.n == z[f"s{n}_table"].shape[0]
+        ids = np.stack([z[f"s{n}_ids"] for n in idx], axis=1)          # [400, Nb]
+        for k in range(ids.shape[0]):
+            a = _t(ids[k], device, torch.int32)
+            control = env.get_action(a).cpu().numpy()
+            obs, reward, done, _ = env.step(a)
+            reward = reward.cpu().numpy()
+            soc = env.batch.cols["soc"].cpu().numpy()
+            for j, n in enumerate(idx):
+                assert np.array_equal(control[j], z[f"s{n}_control"][k]), f"scenario {n} step {k}: control"
+                assert reward[j] == z[f"s{n}_reward"][k], f"scenario {n} step {k}: reward"
+                assert soc[j] == z[f"s{n}_soc"][k]
+        env.close()
+
+
+def test_observations_vs_reference(pymgrid25, device):
+    """reset + 40 post-step observations (H = 23; 4-component grid windows) and the end-of-series padding."""
+    from pymgrid_amd import StepEngine
+    z = golden("obs.npz")
+    for idx in _buckets(pymgrid25):
+        grids = [pymgrid25[n] for n in idx]
+        eng = StepEngine(_batch(grids, device))
+        obs0 = eng.reset().cpu().numpy()
+        A = action_dim(grids[0])
+        acts = np.stack([np.random.RandomState(3100 + n).rand(40, A) for n in idx], axis=1)
+        for j, n in enumerate(idx):
+            assert np.array_equal(obs0[j], z[f"head{n}_obs0"])
+        for k in range(40):
+            obs = eng.step(_t(acts[k], device))[0].cpu().numpy()
+            for j, n in enumerate(idx):
+                assert np.array_equal(obs[j], z[f"head{n}_obs"][k]), (n, k)
+        eng.close()
+    for n in (1, 0, 2):                                               # G5: run into the end of the series
+        p = dict(pymgrid25[n]); p["initial_step"] = int(z[f"tail{n}_start"])
+        eng = StepEngine(_batch([p], device))
+        assert np.array_equal(eng.reset().cpu().numpy()[0], z[f"tail{n}_obs0"])
+        K = p["final_step"] - p["initial_step"]
+        acts = np.random.RandomState(3000 + n).rand(K, action_dim(p))
+        for k in range(K):
+            obs, reward, done, _ = eng.step(_t(acts[k:k + 1], device))
+            assert reward.item() == z[f"tail{n}_reward"][k] and int(done.item()) == z[f"tail{n}_done"][k]
+            assert np.array_equal(obs.cpu().numpy()[0], z[f"tail{n}_obs"][k]), k
+        obs = eng.step(_t(np.full((1, action_dim(p)), 0.5), device))[0]
+        assert np.array_equal(obs.cpu().numpy()[0], z[f"tail{n}_obs_extra"][0])
+        from pymgrid_amd import MgxError
+        with pytest.raises(MgxError) as e:                            # IndexError in the reference
+            eng.step(_t(np.full((1, action_dim(p)), 0.5), device))
+        assert e.value.code == 3
+        eng.close()
+
+
+def test_reset_keeps_dynamic_state(pymgrid25, device):
+    from pymgrid_amd import StepEngine
+    z = golden("obs.npz")
+    p = pymgrid25[1]
+    eng = StepEngine(_batch([p], device))
+    acts = np.random.RandomState(3200).rand(30, action_dim(p))
+    r1 = [eng.step(_t(acts[k:k + 1], device))[1].item() for k in range(15)]
+    obs = eng.reset().cpu().numpy()[0]
+    assert eng.current_step == 0
+    assert np.array_equal(obs, z["reset_obs"])
+    c = eng.batch.cols
+    st = _status4(c["gen_status"])[0]
+    assert np.array_equal(np.array([c["charge"].item(), c["soc"].item(), *st]), z["reset_state"])
+    r2, soc2 = [], []
+    for k in range(15, 30):
+        r2.append(eng.step(_t(acts[k:k + 1], device))[1].item()); soc2.append(c["soc"].item())
+    assert np.array_equal(r1, z["reset_reward1"]) and np.array_equal(r2, z["reset_reward2"])
+    assert np.array_equal(soc2, z["reset_soc2"])
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arch", ["genset+battery", "battery+grid", "genset+battery+grid", "loadpv"])
+def test_fused_equals_single_step_equals_oracle(arch, device, oracle):
+    """Seeded generated batch: K fused steps == K single steps == CPU oracle, bit for bit (state + rewards)."""
+    from pymgrid_amd import StepEngine
+    from pymgrid_amd.generator import generate
+    N, T, K = 5000, 80, 67            # ragged: N not a multiple of 256, K not a multiple of the pipeline depth
+    gen = torch.Generator(device=device); gen.manual_seed(5)
+    b1 = generate(N, n_steps=T, seed=9, arch=arch, device=device, mixed_timers=True)
+    b2 = generate(N, n_steps=T, seed=9, arch=arch, device=device, mixed_timers=True)
+    A = b1.layout.action_dim
+    acts = torch.rand(K, N, A, dtype=torch.float64, device=device, generator=gen)
+    acts[::7] = acts[::7].round()      # exact 0 / 1 controls: x == 0 routing, goal exactly 0/1
+    cols = b1.numpy_columns()
+    st = {k: cols[k].copy() for k in ("charge", "soc", "gen_status") if k in cols}
+    e1, e2 = StepEngine(b1), StepEngine(b2)
+    fused = e1.step_k(acts, reward=True, done=True, soc_trace=True, status_trace=True, log=True)
+    single_r, single_log = [], []
+    for k in range(K):
+        _, r, d, lg = e2.step(acts[k], want_obs=False, want_log=True)
+        single_r.append(r.clone()); single_log.append(lg.clone())
+    single_r, single_log = torch.stack(single_r), torch.stack(single_log)
+    assert torch.equal(fused["reward"], single_r)
+    assert torch.equal(fused["log"], single_log)
+    for k in ("charge", "soc", "gen_status"):
+        if k in b1.cols:
+            assert torch.equal(b1.cols[k], b2.cols[k])
+    ref = oracle.run_batch(cols, st, 0, K, acts.cpu().numpy(), normalized=True, nthreads=8)
+    assert np.array_equal(fused["reward"].cpu().numpy(), ref)
+    for k in st:
+        got = b1.cols[k].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32) if k == "gen_status" else got, st[k]), k
+    if "soc_trace" in fused:
+        assert torch.equal(fused["soc_trace"][-1], b1.cols["soc"])
+    e1.close(); e2.close()
+
+
+def test_full_size_batch_properties(device, oracle):
+    """BASELINE config 3 size (N = 100 000 Template-4 grids): oracle equality on a fused chunk, energy balance,
+    reward decomposition, metrics reduction."""
+    from pymgrid_amd import StepEngine
+    from pymgrid_amd.generator import generate
+    N, T, K = 100_000, 72, 64
+    b = generate(N, n_steps=T, seed=42, arch="genset+battery", device=device)
+    cols = b.numpy_columns()
+    st = {k: cols[k].copy() for k in ("charge", "soc", "gen_status")}
+    eng = StepEngine(b)
+    gen = torch.Generator(device=device); gen.manual_seed(7)
+    acts = torch.rand(K, N, 3, dtype=torch.float64, device=device, generator=gen)
+    ret = torch.zeros(N, dtype=torch.float64, device=device)
+    out = eng.step_k(acts, reward=True, ret_acc=ret, log=True)
+    ref = oracle.run_batch(cols, st, 0, K, acts.cpu().numpy(), normalized=True, nthreads=8)
+    assert np.array_equal(out["reward"].cpu().numpy(), ref)
+    assert np.array_equal(b.cols["charge"].cpu().numpy(), st["charge"])
+    log = out["log"]
+    ix = {n: j for j, n in enumerate(eng.log_names)}
+    prov, absb = log[:, ix["overall_provided"]], log[:, ix["overall_absorbed"]]
+    assert torch.allclose(prov, absb, rtol=1e-9, atol=1e-9)                  # microgrid.py:321-323
+    total = log[:, ix["genset_reward"]] + log[:, ix["battery_reward"]] + log[:, ix["unbalanced_reward"]]
+    assert torch.allclose(total, out["reward"], rtol=1e-12, atol=1e-9)
+    assert torch.allclose(ret, out["reward"].sum(0), rtol=1e-12, atol=1e-6)
+    soc = b.cols["soc"]
+    assert (soc >= 0.2 - 1e-12).all() and (soc <= 1 + 1e-9).all()
+    sums = eng.metrics(log[-1])
+    assert torch.equal(sums, eng.metrics(log[-1]))                           # deterministic
+    assert torch.allclose(sums, log[-1].sum(1), rtol=1e-11, atol=1e-5)
+    eng.close()
+
+
+def test_gym_adaptors_shapes(pymgrid25, device):
+    """Reference tests/envs/test_discrete.py:12-95: flat obs shape, nested obs keys, action_space.n, float / bool
+    return types, 10 random steps, reset."""
+    from pymgrid_amd import DiscreteMicrogridEnv, MicrogridEnv
+    for n in (0, 1, 2):
+        p = pymgrid25[n]
+        env = DiscreteMicrogridEnv(p, device=device)
+        n_ctrl = (p.get("genset") is not None) + (p.get("battery") is not None) + (p.get("grid") is not None)
+        n_expected = {1: 1, 2: 2 if p.get("genset") is None else 4, 3: 12}[n_ctrl]
+        assert env.action_space.n == n_expected          # n_modules! * 2^n_gensets (test_discrete.py:73-80)
+        obs = env.reset()
+        assert obs.shape == env.observation_space.shape == (env.layout.obs_dim,)
+        for _ in range(10):
+            a = env.action_space.sample()
+            ctrl = env.get_action_dict(a)
+            assert set(ctrl) == {k for k in ("genset", "battery", "grid") if p.get(k) is not None}
+            obs, reward, done, info = env.step(a)
+            assert obs.shape == (env.layout.obs_dim,) and isinstance(reward, float) and isinstance(done, bool)
+            assert info["reward"] == reward
+        assert len(env.get_log()["reward"]) == 10
+        env.reset(); assert env.current_step == 0 and env.get_log() == {}
+        with pytest.raises(ValueError):
+            env.step(env.action_space.n)
+        env.close()
+        env = MicrogridEnv(p, device=device, flat_spaces=False)
+        obs = env.reset()
+        assert set(obs) == set(env.layout.obs_slices())
+        ctrl = {"battery": [0.5]}
+        if p.get("genset") is not None: ctrl["genset"] = [np.array([1.0, 0.5])]
+        if p.get("grid") is not None: ctrl["grid"] = [0.5]
+        obs, reward, done, info = env.step(ctrl, normalized=True)
+        assert isinstance(reward, float) and len(obs["load"][0]) == 24
+        env.close()
+
+
+def test_error_paths(pymgrid25, device):
+    from pymgrid_amd import BatchLayout, MgxError, MicrogridBatch, StepEngine
+    p = pymgrid25[2]
+    b = _batch([p], device)
+    eng = StepEngine(b)
+    with pytest.raises(ValueError):
+        eng.step(torch.zeros(1, 2, dtype=torch.float64, device=device))          # wrong action width
+    with pytest.raises(ValueError):
+        eng.step(torch.zeros(1, 3, dtype=torch.float32, device=device))          # wrong dtype
+    with pytest.raises(MgxError) as e:
+        eng.step_k(torch.zeros(9000, 1, 3, dtype=torch.float64, device=device))  # leaves the series
+    assert e.value.code == 3 and eng.current_step == 0
+    with pytest.raises(MgxError):
+        eng.reset(initial_step=8759)
+    eng.close()
+    bad = BatchLayout(n_grids=1, n_steps=8760, has_genset=True, has_battery=True, n_load=2)
+    with pytest.raises(MgxError) as e:
+        StepEngine(MicrogridBatch(bad, b.cols))
+    assert e.value.code == 2
+    with pytest.raises(MgxError):
+        StepEngine(_batch([p], "cpu"))                                           # no CPU path
