@@ -111,8 +111,8 @@ def cpu_baseline(eng, pool, seconds):
     from oracle import oracle as orc
     orc.build()
     L = eng.layout
-    cores = os.cpu_count() or 1
-    n = min(L.n_grids, 4096)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = min(L.n_grids, 65536)
     K = min(pool.shape[1], L.final_step)
     cols = {}
     for k, v in eng.batch.cols.items():

@@ -100,8 +100,8 @@ static void battery_update_state(const orc_grid *g, orc_state *s, double energy_
 }
 /* BaseMicrogridModule.step for the battery: base_module.py:138-171 + as_source/as_sink :210-274
  * + BatteryModule.update :108-123 */
-static void battery_step(const orc_grid *g, orc_state *s, double action, int normalized,
-                         mstep *m, orc_step_out *out)
+static int battery_step(const orc_grid *g, orc_state *s, double action, int normalized,
+                        mstep *m, orc_step_out *out)
 {
     double x = action;
     if (normalized) {
@@ -117,6 +117,7 @@ static void battery_step(const orc_grid *g, orc_state *s, double action, int nor
     if (x < 0) {                          /* as_sink(-1.0*x), base_module.py:164-165, :262-274 */
         double ex = -1.0 * x, mc = battery_max_consumption(g, s);
         e = (ex > mc) ? mc : ex;
+        if (!(e >= 0)) return -3;         /* `assert absorbed_energy >= 0`, base_module.py:272 */
         internal = battery_transition(g, e);
         battery_update_state(g, s, internal);
         out->charge_amount = e;
@@ -133,6 +134,7 @@ static void battery_step(const orc_grid *g, orc_state *s, double action, int nor
         out->battery_reward = -1.0 * (fabs(internal) * g->bat_cost_cycle);
         mstep_append(m, out->battery_reward, 0, 1, e);
     }
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -263,7 +265,7 @@ int orc_run(const orc_grid *g, orc_state *s, const orc_action *a, int normalized
     /* controllable modules in container order: sources (genset) then source_and_sinks
      * (battery, grid)  -- module_container.py:355-413, microgrid.py:262-275 */
     if (g->has_genset)  genset_step(g, s, a->genset, normalized, &m, out);
-    if (g->has_battery) battery_step(g, s, a->battery, normalized, &m, out);
+    if (g->has_battery && battery_step(g, s, a->battery, normalized, &m, out) != 0) return -3;
     if (g->has_grid)    grid_step(g, s, a->grid, normalized, &m, out);
 
     double provided = orc_np_sum(m.provided, m.n_provided);          /* microgrid.py:277 */
@@ -426,11 +428,48 @@ void orc_populate_action(const orc_grid *g, const orc_state *s,
 }
 
 /* ------------------------------------------------------------------------------------------- */
+#define ORC_TILE 64
+
+static void batch_init_grid(const orc_batch *b, int32_t i, int32_t t0, orc_grid *g, orc_state *s)
+{
+    const int32_t N = b->N;
+    memset(g, 0, sizeof(*g)); memset(s, 0, sizeof(*s));
+    g->has_genset = b->has_genset; g->has_battery = b->has_battery; g->has_grid = b->has_grid;
+    g->n_load = 1; g->n_pv = 1; g->horizon = b->horizon; g->T = b->T; g->final_step = b->final_step;
+    s->t = t0;
+    if (b->has_battery) {
+        g->bat_min_capacity = b->bat_min_capacity[i]; g->bat_max_capacity = b->bat_max_capacity[i];
+        g->bat_max_charge = b->bat_max_charge[i]; g->bat_max_discharge = b->bat_max_discharge[i];
+        g->bat_efficiency = b->bat_efficiency[i]; g->bat_cost_cycle = b->bat_cost_cycle[i];
+        s->charge = b->charge[i]; s->soc = b->soc[i];
+    }
+    if (b->has_genset) {
+        g->gen_running_min = b->gen_running_min[i]; g->gen_running_max = b->gen_running_max[i];
+        g->gen_cost = b->gen_cost[i]; g->gen_co2_per_unit = b->gen_co2_per_unit[i];
+        g->gen_cost_per_unit_co2 = b->gen_cost_per_unit_co2[i];
+        g->gen_start_up_time = (int32_t)(b->gen_times[i] & 0xffffu);
+        g->gen_wind_down_time = (int32_t)(b->gen_times[i] >> 16);
+        uint32_t st = b->gen_status[i];
+        s->gen_cur = st & 0xff; s->gen_goal = (st >> 8) & 0xff; s->gen_up = (st >> 16) & 0xff; s->gen_down = st >> 24;
+    }
+    if (b->has_grid) {
+        g->grid_max_import = b->grid_max_import[i]; g->grid_max_export = b->grid_max_export[i];
+        g->grid_cost_per_unit_co2 = b->grid_cost_per_unit_co2[i];
+        g->grid_ts = b->grid_ts + i; g->grid_t_stride = 4 * (int64_t)N; g->grid_c_stride = N;
+    }
+    g->loss_load_cost = b->loss_load_cost[i]; g->overgeneration_cost = b->overgeneration_cost[i];
+    g->load_ts = b->load_ts + i; g->load_t_stride = N; g->load_m_stride = 0;
+    g->pv_ts = b->pv_ts + i;     g->pv_t_stride = N;   g->pv_m_stride = 0;
+}
+
+/* Tiles of ORC_TILE grids are walked step-major so that the [T,N] series rows and the [K,N,A] action rows are
+ * read along their contiguous axis; each grid still goes through the scalar orc_run() above. */
 int64_t orc_run_batch(const orc_batch *b, int32_t t0, int32_t K, const double *actions, int normalized,
                       double *reward, int32_t nthreads)
 {
     const int32_t N = b->N;
     const int32_t A = 2 * b->has_genset + b->has_battery + b->has_grid;
+    const int32_t n_tiles = (N + ORC_TILE - 1) / ORC_TILE;
     int64_t failures = 0;
 #ifdef _OPENMP
     if (nthreads < 1) nthreads = 1;
@@ -438,50 +477,32 @@ int64_t orc_run_batch(const orc_batch *b, int32_t t0, int32_t K, const double *a
 #else
     (void)nthreads;
 #endif
-    for (int32_t i = 0; i < N; i++) {
-        orc_grid g; memset(&g, 0, sizeof(g));
-        g.has_genset = b->has_genset; g.has_battery = b->has_battery; g.has_grid = b->has_grid;
-        g.n_load = 1; g.n_pv = 1; g.horizon = b->horizon; g.T = b->T; g.final_step = b->final_step;
-        orc_state s; memset(&s, 0, sizeof(s));
-        s.t = t0;
-        if (b->has_battery) {
-            g.bat_min_capacity = b->bat_min_capacity[i]; g.bat_max_capacity = b->bat_max_capacity[i];
-            g.bat_max_charge = b->bat_max_charge[i]; g.bat_max_discharge = b->bat_max_discharge[i];
-            g.bat_efficiency = b->bat_efficiency[i]; g.bat_cost_cycle = b->bat_cost_cycle[i];
-            s.charge = b->charge[i]; s.soc = b->soc[i];
-        }
-        if (b->has_genset) {
-            g.gen_running_min = b->gen_running_min[i]; g.gen_running_max = b->gen_running_max[i];
-            g.gen_cost = b->gen_cost[i]; g.gen_co2_per_unit = b->gen_co2_per_unit[i];
-            g.gen_cost_per_unit_co2 = b->gen_cost_per_unit_co2[i];
-            g.gen_start_up_time = (int32_t)(b->gen_times[i] & 0xffffu);
-            g.gen_wind_down_time = (int32_t)(b->gen_times[i] >> 16);
-            uint32_t st = b->gen_status[i];
-            s.gen_cur = st & 0xff; s.gen_goal = (st >> 8) & 0xff; s.gen_up = (st >> 16) & 0xff; s.gen_down = st >> 24;
-        }
-        if (b->has_grid) {
-            g.grid_max_import = b->grid_max_import[i]; g.grid_max_export = b->grid_max_export[i];
-            g.grid_cost_per_unit_co2 = b->grid_cost_per_unit_co2[i];
-            g.grid_ts = b->grid_ts + i; g.grid_t_stride = 4 * (int64_t)N; g.grid_c_stride = N;
-        }
-        g.loss_load_cost = b->loss_load_cost[i]; g.overgeneration_cost = b->overgeneration_cost[i];
-        g.load_ts = b->load_ts + i; g.load_t_stride = N; g.load_m_stride = 0;
-        g.pv_ts = b->pv_ts + i;     g.pv_t_stride = N;   g.pv_m_stride = 0;
+    for (int32_t tile = 0; tile < n_tiles; tile++) {
+        orc_grid g[ORC_TILE]; orc_state s[ORC_TILE];
+        const int32_t i0 = tile * ORC_TILE;
+        const int32_t n = (N - i0 < ORC_TILE) ? N - i0 : ORC_TILE;
+        for (int32_t j = 0; j < n; j++) batch_init_grid(b, i0 + j, t0, &g[j], &s[j]);
         orc_step_out o;
         for (int32_t k = 0; k < K; k++) {
-            const double *ap = actions + ((int64_t)k * N + i) * A;
-            orc_action a; memset(&a, 0, sizeof(a));
-            int32_t c = 0;
-            if (b->has_genset)  { a.genset[0] = ap[c]; a.genset[1] = ap[c + 1]; c += 2; }
-            if (b->has_battery) { a.battery = ap[c++]; }
-            if (b->has_grid)    { a.grid = ap[c++]; }
-            if (orc_run(&g, &s, &a, normalized, &o) != 0) failures++;
-            if (reward) reward[(int64_t)k * N + i] = o.reward;
+            for (int32_t j = 0; j < n; j++) {
+                const int32_t i = i0 + j;
+                const double *ap = actions + ((int64_t)k * N + i) * A;
+                orc_action a; memset(&a, 0, sizeof(a));
+                int32_t c = 0;
+                if (b->has_genset)  { a.genset[0] = ap[c]; a.genset[1] = ap[c + 1]; c += 2; }
+                if (b->has_battery) { a.battery = ap[c++]; }
+                if (b->has_grid)    { a.grid = ap[c++]; }
+                if (orc_run(&g[j], &s[j], &a, normalized, &o) != 0) failures++;
+                if (reward) reward[(int64_t)k * N + i] = o.reward;
+            }
         }
-        if (b->has_battery) { b->charge[i] = s.charge; b->soc[i] = s.soc; }
-        if (b->has_genset)
-            b->gen_status[i] = (uint32_t)s.gen_cur | ((uint32_t)s.gen_goal << 8) |
-                               ((uint32_t)s.gen_up << 16) | ((uint32_t)s.gen_down << 24);
+        for (int32_t j = 0; j < n; j++) {
+            const int32_t i = i0 + j;
+            if (b->has_battery) { b->charge[i] = s[j].charge; b->soc[i] = s[j].soc; }
+            if (b->has_genset)
+                b->gen_status[i] = (uint32_t)s[j].gen_cur | ((uint32_t)s[j].gen_goal << 8) |
+                                   ((uint32_t)s[j].gen_up << 16) | ((uint32_t)s[j].gen_down << 24);
+        }
     }
     return failures ? -failures : (int64_t)N * K;
 }

@@ -108,7 +108,8 @@ void orc_genset_update_status(const orc_grid *g, orc_state *s, double goal_statu
 int32_t orc_genset_next_status(const orc_state *s, int32_t goal_status);
 
 /* One Microgrid.run(control, normalized).  Advances *s (including s->t).  Returns 0, or -1 if the
- * energy balance check (microgrid.py:321-323) fails, -2 if s->t is outside the series. */
+ * energy balance check (microgrid.py:321-323) fails, -2 if s->t is outside the series, -3 where the reference
+ * raises AssertionError (a battery asked to charge while its charge already exceeds max_capacity, base_module.py:272). */
 int orc_run(const orc_grid *g, orc_state *s, const orc_action *a, int normalized, orc_step_out *out);
 
 /* Normalised observation of the CURRENT state (module.to_normalized(module.state), i.e. what reset()

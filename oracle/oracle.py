@@ -211,6 +211,8 @@ class OracleMicrogrid:
         rc = lib().orc_run(C.byref(self.g), C.byref(self.s), C.byref(a), int(normalized), C.byref(out))
         if rc == -1:
             raise RuntimeError("Microgrid modules unable to balance energy production with consumption.")
+        if rc == -3:
+            raise AssertionError("absorbed_energy >= 0 (base_module.py:272)")
         if rc != 0:
             raise IndexError("step outside the time series")
         return out

@@ -54,6 +54,14 @@ struct State {
     uint32_t status;
 };
 
+// Step-invariant values derived from the parameters (hoisted out of the K-step loop; same operations, same
+// operands, hence the same bits as recomputing them every step like the reference does).
+struct Derived {
+    double bat_lo, bat_sp;     // battery action space: low = -max_discharge/eta, spread (battery_module.py:332-338)
+    double gen_sp;             // genset energy action: low 0, spread running_max (genset_module.py:511-517)
+    double grid_lo, grid_sp;   // grid action space: low = -max_export, spread (grid_module.py:125-132)
+};
+
 struct Inputs {
     double a_goal, a_gen, a_bat, a_grid;     // control (normalised or raw)
     double load, pv;                         // series rows, stored sign
@@ -77,6 +85,20 @@ __device__ __forceinline__ double space_spread(double lo, double hi)
 }
 __device__ __forceinline__ double space_denorm(double lo, double hi, double v) { return lo + space_spread(lo, hi) * v; }
 __device__ __forceinline__ double space_norm(double lo, double hi, double v) { return (v - lo) / space_spread(lo, hi); }
+
+template <int F>
+__device__ __forceinline__ void derive(const Params &p, Derived &d)
+{
+    if constexpr (F & F_BATTERY) {
+        d.bat_lo = -p.bat_D / p.bat_eta;
+        d.bat_sp = space_spread(d.bat_lo, p.bat_C * p.bat_eta);
+    }
+    if constexpr (F & F_GENSET) d.gen_sp = space_spread(0.0, p.gen_rmax);
+    if constexpr (F & F_GRID) {
+        d.grid_lo = -1 * p.grid_exp;
+        d.grid_sp = space_spread(d.grid_lo, p.grid_imp);
+    }
+}
 
 // ---- loads ----------------------------------------------------------------------------------------------
 template <int F>
@@ -188,8 +210,11 @@ __device__ __forceinline__ double battery_max_consumption(const Params &p, doubl
 // Sweep order load -> genset -> battery -> grid -> pv -> unbalanced (module_container.py:355-413,
 // microgrid.py:255-314).  np.sum over the provided/absorbed lists is a left-to-right running sum for the
 // list lengths that occur here (< 8 addends), so the running sums below reproduce MicrogridStep.balance.
+// want_soc (wave-uniform): compute soc = charge / max_capacity this step (a division); the fused kernel skips it on
+// steps whose SoC nobody reads and derives it once at the end (same value: it depends on the final charge only).
 template <int F>
-__device__ __forceinline__ void step_core(const Params &p, State &s, const Inputs &in, bool normalized, Outputs &o)
+__device__ __forceinline__ void step_core(const Params &p, const Derived &d, State &s, const Inputs &in, bool normalized,
+                                          bool want_soc, Outputs &o)
 {
     double prov = 0.0, absb = 0.0, reward = 0.0;
 
@@ -202,7 +227,7 @@ __device__ __forceinline__ void step_core(const Params &p, State &s, const Input
     if constexpr (F & F_GENSET) {
         s.status = genset_update_status(s.status, p.gen_times, in.a_goal);      // GensetModule.step :146-149
         double x = in.a_gen;
-        if (normalized) x = space_denorm(0.0, p.gen_rmax, in.a_gen);           // act space :511-517, _energy_pos=1
+        if (normalized) x = 0.0 + d.gen_sp * in.a_gen;                         // act space :511-517, _energy_pos=1
         const double cur = (double)(s.status & 0xff);
         const double mx = cur * p.gen_rmax, mn = cur * p.gen_rmin;             // max/min_production :465-501
         double e;                                                              // as_source clip base_module.py:213-224
@@ -215,34 +240,45 @@ __device__ __forceinline__ void step_core(const Params &p, State &s, const Input
 
     if constexpr (F & F_BATTERY) {
         double x = in.a_bat;
-        if (normalized) x = space_denorm(-p.bat_D / p.bat_eta, p.bat_C * p.bat_eta, in.a_bat);   // :332-338
+        if (normalized) x = d.bat_lo + d.bat_sp * in.a_bat;                    // space.py:224, bounds :332-338
         o.soc_pre = s.soc; o.charge_pre = s.charge;
-        double internal;
-        if (x < 0) {                                                           // as_sink(-1.0*x)
-            const double ex = -1.0 * x, mc = battery_max_consumption(p, s.charge);
-            const double e = (ex > mc) ? mc : ex;
-            internal = (e < 0) ? e / p.bat_eta : e * p.bat_eta;                // default_transition_model :244-278
-            o.charge_amount = e; o.discharge_amount = 0.0;
-            absb += e;
+        // Each lane needs ONE division by eta: charging -> max_consumption = min(C, cmax - c) / eta (:288-291),
+        // discharging -> internal = (-e) / eta (default_transition_model :244-278).  Select the numerator, divide once.
+        const bool sink = x < 0;
+        double e, internal, num;
+        if (sink) {                                                            // as_sink(-1.0*x)
+            const double b = p.bat_cmax - s.charge;
+            num = (b < p.bat_C ? b : p.bat_C);
+            e = 0.0;
         } else {                                                               // as_source(x), incl. x == 0
             const double mp = battery_max_production(p, s.charge);
-            double e;
-            if (x > mp) e = mp; else if (x < 0.0) e = 0.0; else e = x;
-            const double ext = -1.0 * e;
-            internal = (ext < 0) ? ext / p.bat_eta : ext * p.bat_eta;
+            if (x > mp) e = mp; else if (x < 0.0) e = 0.0; else e = x;        // base_module.py:213-224, min_production 0
+            num = -1.0 * e;
+        }
+        const double q = num / p.bat_eta;
+        if (sink) {
+            const double ex = -1.0 * x;
+            e = (ex > q) ? q : ex;                                             // base_module.py:265-270
+            // e < 0 (charge above max_capacity) is an AssertionError in the reference (base_module.py:272) and
+            // unspecified here; every valid run has e >= 0 and internal = e * eta (default_transition_model).
+            internal = e * p.bat_eta;
+            o.charge_amount = e; o.discharge_amount = 0.0;
+            absb += e;
+        } else {
+            internal = (num < 0) ? q : num * p.bat_eta;
             o.discharge_amount = e; o.charge_amount = 0.0;
             prov += e;
         }
         s.charge += internal;                                                  // _update_state :125-130
         if (s.charge < p.bat_cmin) s.charge = p.bat_cmin;
-        s.soc = s.charge / p.bat_cmax;
+        if (want_soc) s.soc = s.charge / p.bat_cmax;
         o.battery_reward = -1.0 * (fabs(internal) * p.bat_cost);               // get_cost :132-147
         reward += o.battery_reward;
     }
 
     if constexpr (F & F_GRID) {
         double x = in.a_grid;
-        if (normalized) x = space_denorm(-1 * p.grid_exp, p.grid_imp, in.a_grid);   // _get_bounds :125-132
+        if (normalized) x = d.grid_lo + d.grid_sp * in.a_grid;                 // _get_bounds :125-132
         if (x < 0) {                                                           // export
             const double ex = -1.0 * x, mc = p.grid_exp * in.g_stat;           // max_consumption :318-320
             const double e = (ex > mc) ? mc : ex;

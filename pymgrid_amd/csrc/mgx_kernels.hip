@@ -14,6 +14,13 @@
 namespace mgx {
 
 constexpr int BLOCK = 256;
+#ifndef MGX_RING
+#define MGX_RING 4          // register-ring depth of the fused kernel (steps of loads in flight)
+#endif
+#ifndef MGX_BLOCK_K
+#define MGX_BLOCK_K 256     // workgroup size of the fused kernel
+#endif
+constexpr int BLOCK_K = MGX_BLOCK_K;
 
 // ------------------------------------------------------------------------------------------------------
 // Single step: Microgrid.run for N grids (microgrid.py:227-325) + optional obs (base.py:205-209) + log.
@@ -27,12 +34,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.N) return;
     // all loads first (independent, one latency round), then the arithmetic
-    Params p; State s; Inputs in; Outputs o;
+    Params p; State s; Inputs in; Outputs o; Derived d;
     load_inputs<F>(a.c, actions, a.N, i, t, in);
     load_state<F>(a.c, i, log != nullptr, s);
     load_params<F>(a.c, i, p);
+    derive<F>(p, d);
 
-    step_core<F>(p, s, in, normalized != 0, o);
+    step_core<F>(p, d, s, in, normalized != 0, true, o);
 
     store_state<F>(a.c, i, s);
     reward[i] = o.reward;
@@ -43,56 +51,86 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K fused steps: parameters + state live in registers, actions / series rows are streamed with a
-// U-deep software pipeline (loads of chunk c+1 are in flight while chunk c is computed).
+// K fused steps: parameters + state live in registers; actions / series rows stream through a U-slot register
+// ring (slot u is refilled with step k+U as soon as step k has been consumed, so U steps of loads are always in
+// flight).  Every [K, N] stream is addressed as base + (k*N + i): one shared 64-bit lane offset, SGPR bases.
 // ------------------------------------------------------------------------------------------------------
-template <int F, int U>
-__global__ __launch_bounds__(BLOCK) void step_k_kernel(const KArgs a, const double *__restrict__ actions, int32_t t0,
-                                                       int32_t K, int normalized, double *__restrict__ reward,
-                                                       uint8_t *__restrict__ done, double *__restrict__ soc_trace,
-                                                       uint32_t *__restrict__ status_trace,
-                                                       double *__restrict__ ret_acc, double *__restrict__ log)
+struct FusedOut {
+    double *reward;
+    uint8_t *done;
+    double *soc_trace;
+    uint32_t *status_trace;
+    double *ret_acc;
+    double *log;
+};
+
+template <int F>
+__device__ __forceinline__ void load_inputs_at(const double *__restrict__ act, const double *__restrict__ lts,
+                                               const double *__restrict__ pts, const double *__restrict__ gts,
+                                               int64_t N, int64_t i, int64_t off, Inputs &in)
 {
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const double *a = act + off * A;
+    int k = 0;
+    if constexpr (F & F_GENSET) { in.a_goal = a[k]; in.a_gen = a[k + 1]; k += 2; }
+    if constexpr (F & F_BATTERY) { in.a_bat = a[k]; k += 1; }
+    if constexpr (F & F_GRID) { in.a_grid = a[k]; k += 1; }
+    in.load = lts[off];
+    in.pv = pts[off];
+    if constexpr (F & F_GRID) {
+        const double *g = gts + (4 * off - 3 * i);                       // off = k*N + i  ->  (k*4)*N + i
+        in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
+    }
+}
+
+template <int F, int U>
+__global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const double *__restrict__ actions, int32_t t0,
+                                                         int32_t K, int normalized, const FusedOut out)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK_K + threadIdx.x;
     if (i >= a.N) return;
     const int64_t N = a.N;
-    Params p; State s;
-    load_state<F>(a.c, i, true, s);
+    Params p; State s; Derived d;
+    load_state<F>(a.c, i, out.log != nullptr, s);
     load_params<F>(a.c, i, p);
+    derive<F>(p, d);
+    // series bases moved to row t0 once (scalar), so row k of this launch is base + k*N
+    const double *__restrict__ lts = a.c.load_ts + (int64_t)t0 * N;
+    const double *__restrict__ pts = a.c.pv_ts + (int64_t)t0 * N;
+    const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
+    const bool norm = normalized != 0;
+    const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
+    const int32_t k_done = a.final_step - 1 - t0;            // done <=> k >= k_done
     double ret = 0.0;
 
-    Inputs cur[U], nxt[U];
+    Inputs ring[U];
 #pragma unroll
     for (int u = 0; u < U; u++)
-        if (u < K) load_inputs<F>(a.c, actions + (int64_t)u * N * A, N, i, t0 + u, cur[u]);
+        if (u < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
 
+    int64_t off = i;                                         // k*N + i
     for (int32_t k0 = 0; k0 < K; k0 += U) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {           // prefetch the next chunk
-            const int32_t k = k0 + U + u;
-            if (k < K) load_inputs<F>(a.c, actions + (int64_t)k * N * A, N, i, t0 + k, nxt[u]);
-        }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int32_t k = k0 + u;
             if (k < K) {
+                const Inputs in = ring[u];
+                if (k + U < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
                 Outputs o;
-                step_core<F>(p, s, cur[u], normalized != 0, o);
-                const int64_t off = (int64_t)k * N + i;
-                if (reward) reward[off] = o.reward;
-                if (done) done[off] = (uint8_t)(t0 + k >= a.final_step - 1);
-                if constexpr (F & F_BATTERY) { if (soc_trace) soc_trace[off] = s.soc; }
-                if constexpr (F & F_GENSET) { if (status_trace) status_trace[off] = s.status; }
-                if (log) store_log<F>(log + (int64_t)k * a.log_dim * N + i, N, o, s.status);
+                step_core<F>(p, d, s, in, norm, want_soc, o);
+                if (out.reward) out.reward[off] = o.reward;
+                if (out.done) out.done[off] = (uint8_t)(k >= k_done);
+                if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
+                if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
+                if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
                 ret += o.reward;
+                off += N;
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) cur[u] = nxt[u];
     }
+    if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
     store_state<F>(a.c, i, s);
-    if (ret_acc) ret_acc[i] += ret;
+    if (out.ret_acc) out.ret_acc[i] += ret;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -445,8 +483,9 @@ int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized, 
     if (h->t < 0 || (int64_t)h->t + K > h->k.T)
         return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
     hipStream_t st = (hipStream_t)stream;
-    MGX_DISPATCH_F(h->flags, (step_k_kernel<F, 4><<<blocks_for(h->k.N), BLOCK, 0, st>>>(
-                                  h->k, actions, h->t, K, normalized, reward, done, soc_trace, status_trace, ret_acc, log)));
+    const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
+    MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING><<<(unsigned)((h->k.N + BLOCK_K - 1) / BLOCK_K), BLOCK_K, 0, st>>>(
+                                  h->k, actions, h->t, K, normalized, fo)));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_k_kernel launch");
     h->t += K;

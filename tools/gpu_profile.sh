@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + stats and the HBM PMC passes for bench.py.
+# Usage: tools/gpu_profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/*
+# PMC passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950: TCC has 4 slots,
+# FETCH_SIZE takes 3, WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots"), kernel-trace only.
+set -u
+TAG=${1:-run}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+ARGS="--steps 512 --warmup 64 --no-cpu-baseline $*"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/stats.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
+cd "$REPO"
+python tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
+# keep the merged-back payload small: drop the raw per-dispatch traces, keep stats + summary
+find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
+find "$OUT" -name "*counter_collection.csv" -size +2M -delete
