@@ -194,6 +194,16 @@ __device__ __forceinline__ int genset_next_status(uint32_t st, int goal)
     return (!cur || down == 0) ? 0 : 1;
 }
 
+// Wave-uniform test for the genset fast path: no start-up / wind-down delay anywhere in the wave and every status in
+// equilibrium with zero counters.  With zero delays update_status keeps the status inside {off = 0, on = 0x0101}.
+template <int F>
+__device__ __forceinline__ bool genset_wave_is_instant(const Params &p, const State &s)
+{
+    if constexpr (F & F_GENSET)
+        return __all((p.gen_times == 0u) && (s.status == 0u || s.status == 0x0101u)) != 0;
+    return false;
+}
+
 // BatteryModule.max_production / max_consumption (battery_module.py:283-291); Python min(a,b) = b if b<a else a
 __device__ __forceinline__ double battery_max_production(const Params &p, double charge)
 {
@@ -210,11 +220,18 @@ __device__ __forceinline__ double battery_max_consumption(const Params &p, doubl
 // Sweep order load -> genset -> battery -> grid -> pv -> unbalanced (module_container.py:355-413,
 // microgrid.py:255-314).  np.sum over the provided/absorbed lists is a left-to-right running sum for the
 // list lengths that occur here (< 8 addends), so the running sums below reproduce MicrogridStep.balance.
+//
+// The reference's if/else ladders are written as selects (both arms are cheap, lanes of a wave disagree on every
+// one of them with random controls): same operations on the taken arm, hence the same bits.  Adding +0.0 where the
+// reference appends nothing to a list leaves the running sum's value unchanged.
+//
 // want_soc (wave-uniform): compute soc = charge / max_capacity this step (a division); the fused kernel skips it on
 // steps whose SoC nobody reads and derives it once at the end (same value: it depends on the final charge only).
+// gen_instant (wave-uniform): every genset of the wave has start_up_time == wind_down_time == 0 and an equilibrium
+// status, so update_status collapses to "status follows the goal" (instant_up / instant_down, :289-311).
 template <int F>
 __device__ __forceinline__ void step_core(const Params &p, const Derived &d, State &s, const Inputs &in, bool normalized,
-                                          bool want_soc, Outputs &o)
+                                          bool want_soc, bool gen_instant, Outputs &o)
 {
     double prov = 0.0, absb = 0.0, reward = 0.0;
 
@@ -225,75 +242,64 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
     o.fixed_provided = prov; o.fixed_absorbed = absb;
 
     if constexpr (F & F_GENSET) {
-        s.status = genset_update_status(s.status, p.gen_times, in.a_goal);      // GensetModule.step :146-149
-        double x = in.a_gen;
-        if (normalized) x = 0.0 + d.gen_sp * in.a_gen;                         // act space :511-517, _energy_pos=1
+        if (gen_instant) {
+            const uint32_t g = in.a_goal > 0.5 ? 1u : 0u;                       // round(): half-to-even (:281)
+            s.status = g | (g << 8);
+        } else {
+            s.status = genset_update_status(s.status, p.gen_times, in.a_goal);  // GensetModule.step :146-149
+        }
+        const double x = normalized ? 0.0 + d.gen_sp * in.a_gen : in.a_gen;     // act space :511-517, _energy_pos=1
         const double cur = (double)(s.status & 0xff);
-        const double mx = cur * p.gen_rmax, mn = cur * p.gen_rmin;             // max/min_production :465-501
-        double e;                                                              // as_source clip base_module.py:213-224
-        if (x > mx) e = mx; else if (x < mn) e = mn; else e = x;
-        const double co2 = p.gen_co2 * e;                                      // get_co2
-        const double cost = p.gen_cost * e + p.gen_cco2 * co2;                 // get_cost :188-205
+        const double mx = cur * p.gen_rmax, mn = cur * p.gen_rmin;              // max/min_production :465-501
+        const double e = (x > mx) ? mx : ((x < mn) ? mn : x);                   // as_source clip base_module.py:213-224
+        const double co2 = p.gen_co2 * e;                                       // get_co2
+        const double cost = p.gen_cost * e + p.gen_cco2 * co2;                  // get_cost :188-205
         o.genset_production = e; o.genset_co2 = co2; o.genset_reward = -1.0 * cost;
         prov += e; reward += o.genset_reward;
     }
 
     if constexpr (F & F_BATTERY) {
-        double x = in.a_bat;
-        if (normalized) x = d.bat_lo + d.bat_sp * in.a_bat;                    // space.py:224, bounds :332-338
+        const double x = normalized ? d.bat_lo + d.bat_sp * in.a_bat : in.a_bat;   // space.py:224, bounds :332-338
         o.soc_pre = s.soc; o.charge_pre = s.charge;
         // Each lane needs ONE division by eta: charging -> max_consumption = min(C, cmax - c) / eta (:288-291),
         // discharging -> internal = (-e) / eta (default_transition_model :244-278).  Select the numerator, divide once.
-        const bool sink = x < 0;
-        double e, internal, num;
-        if (sink) {                                                            // as_sink(-1.0*x)
-            const double b = p.bat_cmax - s.charge;
-            num = (b < p.bat_C ? b : p.bat_C);
-            e = 0.0;
-        } else {                                                               // as_source(x), incl. x == 0
-            const double mp = battery_max_production(p, s.charge);
-            if (x > mp) e = mp; else if (x < 0.0) e = 0.0; else e = x;        // base_module.py:213-224, min_production 0
-            num = -1.0 * e;
-        }
+        const bool sink = x < 0;                                                // as_sink(-1.0*x) vs as_source(x)
+        const double room = p.bat_cmax - s.charge;
+        const double num_sink = (room < p.bat_C) ? room : p.bat_C;              // Python min(a, b) = b if b < a else a
+        const double mp = battery_max_production(p, s.charge);                  // :283-286
+        const double e_src = (x > mp) ? mp : ((x < 0.0) ? 0.0 : x);            // base_module.py:213-224, min_production 0
+        const double num = sink ? num_sink : -1.0 * e_src;
         const double q = num / p.bat_eta;
-        if (sink) {
-            const double ex = -1.0 * x;
-            e = (ex > q) ? q : ex;                                             // base_module.py:265-270
-            // e < 0 (charge above max_capacity) is an AssertionError in the reference (base_module.py:272) and
-            // unspecified here; every valid run has e >= 0 and internal = e * eta (default_transition_model).
-            internal = e * p.bat_eta;
-            o.charge_amount = e; o.discharge_amount = 0.0;
-            absb += e;
-        } else {
-            internal = (num < 0) ? q : num * p.bat_eta;
-            o.discharge_amount = e; o.charge_amount = 0.0;
-            prov += e;
-        }
-        s.charge += internal;                                                  // _update_state :125-130
+        const double ex = -1.0 * x;
+        const double e_sink = (ex > q) ? q : ex;                                // base_module.py:265-270
+        // (e_sink < 0, i.e. charge above max_capacity, is an AssertionError in the reference, base_module.py:272,
+        //  and unspecified here; every valid run has e >= 0 and internal = e * eta.)
+        const double e = sink ? e_sink : e_src;
+        const double internal = sink ? e * p.bat_eta : ((num < 0) ? q : num * p.bat_eta);
+        o.charge_amount = sink ? e : 0.0;
+        o.discharge_amount = sink ? 0.0 : e;
+        absb += o.charge_amount; prov += o.discharge_amount;
+        s.charge += internal;                                                   // _update_state :125-130
         if (s.charge < p.bat_cmin) s.charge = p.bat_cmin;
         if (want_soc) s.soc = s.charge / p.bat_cmax;
-        o.battery_reward = -1.0 * (fabs(internal) * p.bat_cost);               // get_cost :132-147
+        o.battery_reward = -1.0 * (fabs(internal) * p.bat_cost);                // get_cost :132-147
         reward += o.battery_reward;
     }
 
     if constexpr (F & F_GRID) {
-        double x = in.a_grid;
-        if (normalized) x = d.grid_lo + d.grid_sp * in.a_grid;                 // _get_bounds :125-132
-        if (x < 0) {                                                           // export
-            const double ex = -1.0 * x, mc = p.grid_exp * in.g_stat;           // max_consumption :318-320
-            const double e = (ex > mc) ? mc : ex;
-            o.grid_export = e; o.grid_import = 0.0; o.grid_co2 = 0.0;
-            o.grid_reward = in.g_pexp * e + (-1.0 * p.grid_cco2 * 0.0);        // get_cost :169-171
-            absb += e;
-        } else {                                                               // import
-            const double mp = p.grid_imp * in.g_stat;                          // max_production :314-316
-            double e;
-            if (x > mp) e = mp; else if (x < 0.0) e = 0.0; else e = x;
-            const double co2 = e * in.g_co2;                                   // get_co2_production :221-224
-            o.grid_import = e; o.grid_export = 0.0; o.grid_co2 = co2;
-            o.grid_reward = -1 * in.g_pimp * e + (-1.0 * p.grid_cco2 * co2);   // :166-168, :176-197
-            prov += e;
-        }
+        const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;   // _get_bounds :125-132
+        const bool sink = x < 0;
+        const double ex = -1.0 * x, mc = p.grid_exp * in.g_stat;               // max_consumption :318-320
+        const double e_exp = (ex > mc) ? mc : ex;
+        const double mp = p.grid_imp * in.g_stat;                              // max_production :314-316
+        const double e_imp = (x > mp) ? mp : ((x < 0.0) ? 0.0 : x);
+        const double co2 = sink ? 0.0 : e_imp * in.g_co2;                      // get_co2_production :199-228
+        const double cco2 = -1.0 * p.grid_cco2 * co2;                          // get_co2_cost :176-197
+        o.grid_export = sink ? e_exp : 0.0;
+        o.grid_import = sink ? 0.0 : e_imp;
+        o.grid_co2 = co2;
+        o.grid_reward = sink ? in.g_pexp * e_exp + cco2 : -1 * in.g_pimp * e_imp + cco2;   // get_cost :143-174
+        absb += o.grid_export; prov += o.grid_import;
         reward += o.grid_reward;
     }
 
@@ -301,23 +307,18 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
     o.ctrl_provided = prov - o.fixed_provided;                                 // :281
     o.ctrl_absorbed = absb - o.fixed_absorbed;
 
-    if (difference > 0) {                                                      // :286-299
-        o.renewable_used = 0.0; o.curtailment = in.pv - 0.0;                   // renewable_module.py:86-93
-        prov += 0.0; reward += 0.0;
-        const double e = -1.0 * (-1.0 * difference);
-        o.overgeneration = e; o.loss_load = 0.0;
-        o.unbalanced_reward = -1.0 * (p.og_cost * e);                          // unbalanced_energy_module.py:38-70
-        absb += e;
-    } else {                                                                   // :301-314
-        double need = -difference;
-        const double used = (in.pv < need) ? in.pv : need;
-        o.renewable_used = used; o.curtailment = in.pv - used;
-        prov += used; reward += 0.0;
-        need -= used;
-        o.loss_load = need; o.overgeneration = 0.0;
-        o.unbalanced_reward = -1.0 * (p.ll_cost * need);
-        prov += need;
-    }
+    // flex modules (:286-314): renewable first, unbalanced energy last
+    const bool excess = difference > 0;
+    const double need = -difference;
+    const double used = excess ? 0.0 : ((in.pv < need) ? in.pv : need);        // renewable_module.py:86-93
+    o.renewable_used = used; o.curtailment = in.pv - used;
+    const double loss = excess ? 0.0 : need - used;
+    const double over = excess ? difference : 0.0;
+    o.loss_load = loss; o.overgeneration = over;
+    o.unbalanced_reward = -1.0 * (excess ? p.og_cost * over : p.ll_cost * loss);   // unbalanced_energy_module.py:38-70
+    prov += used; reward += 0.0;
+    prov += loss;
+    absb += over;
     reward += o.unbalanced_reward;
     o.overall_provided = prov; o.overall_absorbed = absb;
     o.reward = reward;

@@ -39,8 +39,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
     load_state<F>(a.c, i, log != nullptr, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
+    const bool gen_instant = genset_wave_is_instant<F>(p, s);
 
-    step_core<F>(p, d, s, in, normalized != 0, true, o);
+    step_core<F>(p, d, s, in, normalized != 0, true, gen_instant, o);
 
     store_state<F>(a.c, i, s);
     reward[i] = o.reward;
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const do
     const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
     const bool norm = normalized != 0;
     const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
+    const bool gen_instant = genset_wave_is_instant<F>(p, s);
     const int32_t k_done = a.final_step - 1 - t0;            // done <=> k >= k_done
     double ret = 0.0;
 
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const do
                 const Inputs in = ring[u];
                 if (k + U < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
                 Outputs o;
-                step_core<F>(p, d, s, in, norm, want_soc, o);
+                step_core<F>(p, d, s, in, norm, want_soc, gen_instant, o);
                 if (out.reward) out.reward[off] = o.reward;
                 if (out.done) out.done[off] = (uint8_t)(k >= k_done);
                 if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
