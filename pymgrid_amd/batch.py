@@ -98,7 +98,9 @@ class BatchLayout:
         A = self.action_dim
         P_f = 2 + 6 * int(self.has_battery) + 5 * int(self.has_genset) + 3 * int(self.has_grid)
         C_ts = self.n_load + self.n_pv + 4 * int(self.has_grid)
-        once = 8 * P_f + 4 * int(self.has_genset) + (16 + 16) * int(self.has_battery) + 8 * int(self.has_genset)
+        # once: float params, packed genset times, charge read + charge/soc write, genset status read + write
+        once = 8 * P_f + 4 * int(self.has_genset) + (8 + 16) * int(self.has_battery) + 8 * int(self.has_genset) \
+            + 8 * int(log and self.has_battery)      # the log also reads the pre-launch SoC
         per = 8 * (A + C_ts) + 8 * int(reward) + int(done) + 8 * int(soc_trace and self.has_battery) \
             + 4 * int(status_trace and self.has_genset) + 8 * len(self.log_names) * int(log)
         return once + K * per

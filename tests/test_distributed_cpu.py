@@ -1,0 +1,65 @@
+"""Multi-process (world_size 2, gloo, CPU) coverage of the N>1 path: contiguous sharding with no data-path
+collective, and the single metrics all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from pymgrid_amd import distributed as mdist
+    from pymgrid_amd.generator import generate
+    r, w, _ = mdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    lo, hi = mdist.shard_bounds(n_total, r, w)
+    shard = generate(n_total, n_steps=16, seed=3, device="cpu", rank=r, world=w)
+    assert shard.layout.n_grids == hi - lo
+    # "metrics": per-shard sums of two state columns, then ONE all-reduce
+    local = torch.stack([shard.cols["charge"].sum(), shard.cols["soc"].sum(),
+                         torch.tensor(float(hi - lo), dtype=torch.float64)])
+    total = mdist.all_reduce_metrics(local.clone())
+    tmax = mdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    mdist.barrier()
+    if rank == 0:
+        torch.save(dict(total=total, tmax=tmax), out)
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_and_allreduce_world2(tmp_path):
+    from pymgrid_amd.generator import generate
+    n_total = 128
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), n_total, out), nprocs=2, join=True)
+    res = torch.load(out)
+    full = generate(n_total, n_steps=16, seed=3, device="cpu")
+    ref = torch.stack([full.cols["charge"][:64].sum() + full.cols["charge"][64:].sum(),
+                       full.cols["soc"][:64].sum() + full.cols["soc"][64:].sum(),
+                       torch.tensor(float(n_total), dtype=torch.float64)])
+    assert torch.allclose(res["total"], ref, rtol=1e-14)
+    assert res["tmax"] == 2.0
+
+
+def test_shard_bounds():
+    from pymgrid_amd.distributed import shard_bounds
+    assert [shard_bounds(1_000_000, r, 8) for r in (0, 7)] == [(0, 125_000), (875_000, 1_000_000)]
+    with pytest.raises(ValueError):
+        shard_bounds(10, 0, 3)
+
+
+def test_single_process_is_a_noop():
+    from pymgrid_amd import distributed as mdist
+    v = torch.tensor([1.0, 2.0], dtype=torch.float64)
+    assert torch.equal(mdist.all_reduce_metrics(v.clone()), v)
+    assert mdist.max_over_ranks(3.5, torch.device("cpu")) == 3.5
+    mdist.barrier()
