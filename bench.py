@@ -10,7 +10,9 @@ Modes
   fused (default)  K steps are issued as ceil(K / chunk) launches of the K-step kernel (mgx_step_k): parameters and
                    state stay in registers, actions / series rows / per-step outputs (reward, done, SoC) stream.
   step             one launch of the single-step kernel (mgx_step) per env-step -- the Gym cadence.
-Both are timed in every run; --mode picks which one is the headline `value`; the other is reported under "other".
+  rbc              rule-based control rolled out on device (mgx_rollout_discrete, one fixed priority list per grid):
+                   the control is expanded in-kernel, so there is no action stream at all.
+All are timed in every run; --mode picks which one is the headline `value`; the others are reported under "other".
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]          (N>1: torchrun, one rank per GPU, RCCL only
                                                                     for the final metrics all-reduce)
@@ -42,7 +44,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--grids", type=int, default=100_000, help="microgrids PER GPU (weak scaling)")
     ap.add_argument("--rows", type=int, default=8760, help="time-series rows T")
-    ap.add_argument("--mode", choices=["fused", "step"], default="fused")
+    ap.add_argument("--mode", choices=["fused", "step", "rbc"], default="fused")
     ap.add_argument("--chunk", type=int, default=64, help="env-steps per fused launch")
     ap.add_argument("--arch", default="genset+battery")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,6 +82,15 @@ class Runner:
                             out=dict(reward=self.reward_k[:k], done=self.done_k[:k], soc_trace=self.soc_k[:k]),
                             reward=True, done=True, soc_trace=True)
             self.i += 1; self.launches += 1; done += k
+
+    def rbc(self, steps):
+        done = 0
+        while done < steps:
+            k = min(self.chunk, steps - done)
+            self._room(k)
+            self.eng.rollout_discrete(self.rbc_ids, self.rbc_table, k, reward=True, done=True, soc_trace=True,
+                                      out=dict(reward=self.reward_k[:k], done=self.done_k[:k], soc_trace=self.soc_k[:k]))
+            self.launches += 1; done += k
 
     def single(self, steps):
         for s in range(steps):
@@ -169,10 +180,15 @@ def main():
     gen = torch.Generator(device=dev); gen.manual_seed(7 + rank)
     pool = torch.rand(4, chunk, N, L.action_dim, dtype=torch.float64, device=dev, generator=gen)
     run = Runner(eng, chunk, pool)
+    from pymgrid_amd.priority_list import get_priority_lists, table_array
+    from pymgrid_amd.rbc import default_priority_ids
+    lists = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, False)
+    run.rbc_table = table_array(lists)
+    run.rbc_ids = torch.from_numpy(default_priority_ids(batch, lists, remove_redundant_gensets=False)).to(dev)
 
     results = {}
-    for mode in ("fused", "step"):
-        fn = run.fused if mode == "fused" else run.single
+    for mode in ("fused", "step", "rbc"):
+        fn = {"fused": run.fused, "step": run.single, "rbc": run.rbc}[mode]
         steps = args.steps if mode == args.mode else min(args.steps, 512)
         eng.reset(want_obs=False)
         fn(args.warmup if mode == args.mode else min(args.warmup, 64))
@@ -181,9 +197,12 @@ def main():
         wall = mdist.max_over_ranks(wall, dev)
         gpu = mdist.max_over_ranks(gpu, dev)
         launches = run.launches
-        if mode == "fused":
-            per_launch = sum(L.bytes_fused(min(chunk, steps - k0)) for k0 in range(0, steps, chunk)) / launches
-            unit_bytes = L.bytes_fused(chunk) / chunk
+        if mode in ("fused", "rbc"):
+            A8 = 8 * L.action_dim if mode == "rbc" else 0        # rbc: no action stream; + 1 id byte per grid, once
+            once = 1 if mode == "rbc" else 0
+            per_launch = sum(L.bytes_fused(min(chunk, steps - k0)) - A8 * min(chunk, steps - k0) + once
+                             for k0 in range(0, steps, chunk)) / launches
+            unit_bytes = (L.bytes_fused(chunk) - A8 * chunk + once) / chunk
         else:
             unit_bytes = L.bytes_per_step()
             per_launch = unit_bytes
@@ -194,7 +213,8 @@ def main():
             "value": n_total * steps / wall, "steps": steps, "ms_per_step": wall / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "step_k_kernel<3,4>" if mode == "fused" else "step_kernel<3>",
+                         "kernel": {"fused": "step_k_kernel<3,4>", "step": "step_kernel<3>",
+                                    "rbc": "rollout_kernel<3,4>"}[mode],
                          "bytes_per_env_step": unit_bytes, "launches": launches,
                          "avg_launch_us": avg_launch_s * 1e6},
         }
@@ -208,7 +228,8 @@ def main():
         cpu = cpu_baseline(eng, pool, args.cpu_seconds)
 
     if rank == 0:
-        main_r, other = results[args.mode], results["step" if args.mode == "fused" else "fused"]
+        main_r = results[args.mode]
+        names = {"fused": "fused_launches", "step": "single_step_launches", "rbc": "rbc_rollout_on_device"}
         line = {
             "metric": "microgrid env-steps/sec", "value": main_r["value"], "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_r["ms_per_step"],
@@ -216,14 +237,13 @@ def main():
             "config": {"workload": f"{N} generated 4-module grids (genset+battery+load+pv) per GPU, T={args.rows}, "
                                    f"H=0, normalised random actions (BASELINE configs[2])",
                        "grids_per_gpu": N, "grids_total": n_total, "mode": args.mode,
-                       "steps_per_launch": chunk if args.mode == "fused" else 1,
+                       "steps_per_launch": 1 if args.mode == "step" else chunk,
                        "outputs": "reward+done+soc per step" + ("" if args.mode == "step" else " (streamed [K,N])"),
                        "parallelism": f"grids sharded x{world}, no data-path collective"},
             "roofline": main_r["roofline"],
             "cpu_baseline": cpu,
-            "other": {("single_step_launches" if args.mode == "fused" else "fused_launches"):
-                      {"value": other["value"], "steps": other["steps"], "ms_per_step": other["ms_per_step"],
-                       "roofline": other["roofline"]}},
+            "other": {names[m]: {"value": r["value"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
+                                 "roofline": r["roofline"]} for m, r in results.items() if m != args.mode},
             "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total},
         }
         print(json.dumps(line))

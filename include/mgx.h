@@ -143,6 +143,14 @@ int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized,
 int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions,
                         double *control, mgx_stream stream);
 
+/* K fused DiscreteMicrogridEnv steps with the control expanded ON DEVICE: action_id holds priority-list ids as
+ * bytes, either [K, N] (per_step != 0: `for a in ids: env.step(a)`, discrete.py:109-143) or [N] (per_step == 0: one
+ * fixed list per grid for the whole call = RuleBasedControl.run, algos/rbc/rbc.py:64-93).  `table` as in
+ * mgx_expand_discrete; outputs as in mgx_step_k.  No action stream is read at all. */
+int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, const int32_t *table,
+                         int32_t n_actions, int32_t K, double *reward, uint8_t *done, double *soc_trace,
+                         uint32_t *status_trace, double *ret_acc, double *log, mgx_stream stream);
+
 /* Column sums over the grids, sums[m] = sum_i values[m*N + i] (deterministic two-stage wavefront-shuffle +
  * LDS reduction; the "metrics" vector that is all-reduced across GPUs).  M <= 64. */
 int mgx_metrics(mgx_handle *h, const double *values, int32_t M, double *sums, mgx_stream stream);

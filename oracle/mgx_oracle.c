@@ -506,3 +506,51 @@ int64_t orc_run_batch(const orc_batch *b, int32_t t0, int32_t K, const double *a
     }
     return failures ? -failures : (int64_t)N * K;
 }
+
+/* K steps of `action = _populate_action(priority_list); microgrid.run(action, normalized=False)` per grid:
+ * DiscreteMicrogridEnv.step (envs/discrete/discrete.py:109-143) with per-step ids [K,N], or
+ * RuleBasedControl.run (algos/rbc/rbc.py:64-93) with one fixed list per grid (ids [N]). */
+int64_t orc_rollout_batch(const orc_batch *b, int32_t t0, int32_t K, const uint8_t *ids, int per_step,
+                          const int32_t *table, int32_t n_actions, double *reward, int32_t nthreads)
+{
+    const int32_t N = b->N;
+    const int32_t n_tiles = (N + ORC_TILE - 1) / ORC_TILE;
+    int64_t failures = 0;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+    #pragma omp parallel for num_threads(nthreads) schedule(static) reduction(+:failures)
+#else
+    (void)nthreads;
+#endif
+    for (int32_t tile = 0; tile < n_tiles; tile++) {
+        orc_grid g[ORC_TILE]; orc_state s[ORC_TILE];
+        const int32_t i0 = tile * ORC_TILE;
+        const int32_t n = (N - i0 < ORC_TILE) ? N - i0 : ORC_TILE;
+        for (int32_t j = 0; j < n; j++) batch_init_grid(b, i0 + j, t0, &g[j], &s[j]);
+        orc_step_out o;
+        for (int32_t k = 0; k < K; k++) {
+            for (int32_t j = 0; j < n; j++) {
+                const int32_t i = i0 + j;
+                int32_t id = per_step ? ids[(int64_t)k * N + i] : ids[i];
+                if (id < 0 || id >= n_actions) { failures++; id = 0; }
+                orc_pl_element pl[3]; int32_t n_el = 0;
+                for (int32_t e = 0; e < 3; e++) {
+                    const int32_t mod = table[(id * 3 + e) * 2], act = table[(id * 3 + e) * 2 + 1];
+                    if (mod >= 0) { pl[n_el].module = mod; pl[n_el].action = act; n_el++; }
+                }
+                orc_action a;
+                orc_populate_action(&g[j], &s[j], pl, n_el, &a);
+                if (orc_run(&g[j], &s[j], &a, 0, &o) != 0) failures++;
+                if (reward) reward[(int64_t)k * N + i] = o.reward;
+            }
+        }
+        for (int32_t j = 0; j < n; j++) {
+            const int32_t i = i0 + j;
+            if (b->has_battery) { b->charge[i] = s[j].charge; b->soc[i] = s[j].soc; }
+            if (b->has_genset)
+                b->gen_status[i] = (uint32_t)s[j].gen_cur | ((uint32_t)s[j].gen_goal << 8) |
+                                   ((uint32_t)s[j].gen_up << 16) | ((uint32_t)s[j].gen_down << 24);
+        }
+    }
+    return failures ? -failures : (int64_t)N * K;
+}

@@ -147,6 +147,12 @@ typedef struct orc_batch {
 int64_t orc_run_batch(const orc_batch *b, int32_t t0, int32_t K, const double *actions, int normalized,
                       double *reward, int32_t nthreads);
 
+/* Discrete rollout over the same SoA batch: control = _populate_action(table[id]) then run(normalized=False);
+ * ids are bytes, [K,N] (per_step) or [N] (one fixed list per grid = RuleBasedControl.run, rbc.py:64-93);
+ * table int32 [n_actions,3,2] of (module, action), -1 padded. */
+int64_t orc_rollout_batch(const orc_batch *b, int32_t t0, int32_t K, const uint8_t *ids, int per_step,
+                          const int32_t *table, int32_t n_actions, double *reward, int32_t nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,6 +121,9 @@ def lib():
         L.orc_run_batch.restype = C.c_int64
         L.orc_run_batch.argtypes = [C.POINTER(Batch), C.c_int32, C.c_int32, c_double_p, C.c_int, c_double_p,
                                     C.c_int32]
+        L.orc_rollout_batch.restype = C.c_int64
+        L.orc_rollout_batch.argtypes = [C.POINTER(Batch), C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_int,
+                                        C.POINTER(C.c_int32), C.c_int32, c_double_p, C.c_int32]
         _lib = L
     return _lib
 
@@ -249,11 +252,8 @@ def np_sum(values):
     return lib().orc_np_sum(_dp(a), a.size)
 
 
-def run_batch(cols, state, t0, K, actions, normalized=True, want_reward=True, nthreads=1):
-    """Run K steps over an SoA batch (same column names / layouts as ``pymgrid_amd.batch``), in place on
-    ``state`` (dict of numpy arrays charge, soc, gen_status).  Returns reward [K, N] or None."""
+def _make_batch(cols, state, keep):
     b = Batch()
-    keep = []
 
     def f64(x):
         a = np.ascontiguousarray(x, dtype=np.float64); keep.append(a); return _dp(a)
@@ -272,10 +272,35 @@ def run_batch(cols, state, t0, K, actions, normalized=True, want_reward=True, nt
         for k in ("charge", "soc"):
             assert state[k].dtype == np.float64 and state[k].flags.c_contiguous
         b.charge, b.soc = _dp(state["charge"]), _dp(state["soc"])
+    return b
+
+
+def run_batch(cols, state, t0, K, actions, normalized=True, want_reward=True, nthreads=1):
+    """Run K steps over an SoA batch (same column names / layouts as ``pymgrid_amd.batch``), in place on
+    ``state`` (dict of numpy arrays charge, soc, gen_status).  Returns reward [K, N] or None."""
+    keep = []
+    b = _make_batch(cols, state, keep)
     actions = np.ascontiguousarray(actions, dtype=np.float64)
     reward = np.empty((K, b.N), dtype=np.float64) if want_reward else None
     n = lib().orc_run_batch(C.byref(b), int(t0), int(K), _dp(actions), int(normalized),
                             _dp(reward) if want_reward else None, int(nthreads))
     if n < 0:
         raise RuntimeError(f"oracle batch run: {-n} step(s) failed the balance check")
+    return reward
+
+
+def rollout_batch(cols, state, t0, K, ids, table, want_reward=True, nthreads=1):
+    """K discrete steps (priority-list ids uint8, [K, N] per step or [N] fixed per grid) over an SoA batch."""
+    keep = []
+    b = _make_batch(cols, state, keep)
+    ids = np.ascontiguousarray(ids, dtype=np.uint8)
+    per_step = int(ids.ndim == 2)
+    assert ids.shape == ((K, b.N) if per_step else (b.N,))
+    table = np.ascontiguousarray(table, dtype=np.int32)
+    reward = np.empty((K, b.N), dtype=np.float64) if want_reward else None
+    n = lib().orc_rollout_batch(C.byref(b), int(t0), int(K), ids.ctypes.data_as(C.POINTER(C.c_uint8)), per_step,
+                                table.ctypes.data_as(C.POINTER(C.c_int32)), table.shape[0],
+                                _dp(reward) if want_reward else None, int(nthreads))
+    if n < 0:
+        raise RuntimeError(f"oracle rollout: {-n} step(s) failed")
     return reward

@@ -10,5 +10,6 @@ from .engine import StepEngine  # noqa: F401
 from .envs import (BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv, DiscreteMicrogridEnv,  # noqa: F401
                    MicrogridEnv)
 from .priority_list import get_priority_lists  # noqa: F401
+from .rbc import RuleBasedControl  # noqa: F401
 
 __version__ = "0.1.0"

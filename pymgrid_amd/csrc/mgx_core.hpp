@@ -324,6 +324,72 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
     o.reward = reward;
 }
 
+// ---- discrete action expansion -------------------------------------------------------------------------
+// PriorityListAlgo._populate_action (algos/priority_list/priority_list.py:69-167).  A priority list is packed in
+// one word: element k in bits [4k, 4k+3] = module (0 genset, 1 battery, 2 grid) | action << 2 | valid << 3.
+struct PLWords {
+    uint32_t w[12];
+    int32_t n_actions;
+};
+
+__device__ __forceinline__ uint32_t pl_select(const PLWords &tab, int32_t id)
+{
+    // per-lane table lookup out of the kernarg (SGPR) copy: a select chain, no memory access
+    uint32_t w = tab.w[0];                 // ids outside [0, n) fall back to list 0 (the reference raises ValueError)
+#pragma unroll
+    for (int j = 1; j < 12; j++) w = (id == j && j < tab.n_actions) ? tab.w[j] : w;
+    return w;
+}
+
+template <int F>
+__device__ __forceinline__ void populate_core(const Params &p, const State &s, uint32_t word, Inputs &in)
+{
+    const double total_load = 0.0 + -1 * in.load;                  // _get_load :157-164
+    const double renewable = in.pv;                                // _get_renewable :166-167
+    double remaining = total_load - renewable;                     // :74
+    double c_goal = 0.0, c_gen = 0.0, c_bat = 0.0, c_grid = 0.0;
+    bool set_gen = false, set_bat = false, set_grid = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t el = (word >> (4 * k)) & 0xfu;
+        if (!(el & 8u)) continue;
+        const int mod = el & 3u, act = (el >> 2) & 1u;
+        if (mod == 0) { if (set_gen) continue; set_gen = true; c_goal = (double)act; }     // :82-88
+        else if (mod == 1) { if (set_bat) continue; set_bat = true; }
+        else { if (set_grid) continue; set_grid = true; }
+        double energy;
+        if (fabs(remaining - 0.0) <= 1e-4 + 1e-5 * fabs(0.0)) {   // np.isclose(remaining, 0, atol=1e-4) :90
+            energy = 0.0;
+        } else if (remaining > 0) {                               // _produce_from_module :138-155
+            double mx = 0.0, mn = 0.0;
+            if (mod == 0) {
+                if constexpr (F & F_GENSET) {
+                    const double ns = (double)genset_next_status(s.status, act);   // genset_module.py:392-424
+                    mx = ns * p.gen_rmax; mn = ns * p.gen_rmin;
+                }
+            } else if (mod == 1) {
+                if constexpr (F & F_BATTERY) mx = battery_max_production(p, s.charge);
+            } else {
+                if constexpr (F & F_GRID) mx = p.grid_imp * in.g_stat;
+            }
+            if (mn <= remaining && remaining <= mx) energy = remaining;
+            else if (remaining < mn) energy = mn;
+            else energy = mx;
+        } else {                                                  // _consume_in_module :118-136
+            if (mod == 0) energy = 0.0;
+            else {
+                double mc = 0.0;
+                if (mod == 1) { if constexpr (F & F_BATTERY) mc = battery_max_consumption(p, s.charge); }
+                else          { if constexpr (F & F_GRID) mc = p.grid_exp * in.g_stat; }
+                energy = (-1 * remaining > mc) ? -1.0 * mc : remaining;
+            }
+        }
+        if (mod == 0) c_gen = energy; else if (mod == 1) c_bat = energy; else c_grid = energy;
+        remaining -= energy;                                      // :105
+    }
+    in.a_goal = c_goal; in.a_gen = c_gen; in.a_bat = c_bat; in.a_grid = c_grid;
+}
+
 // ---- log row ------------------------------------------------------------------------------------------
 // log points at column 0 of grid i; consecutive columns are N apart.
 template <int F>

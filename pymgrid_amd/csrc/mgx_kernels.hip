@@ -152,75 +152,105 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t
 // ------------------------------------------------------------------------------------------------------
 // Discrete action expansion: PriorityListAlgo._populate_action (priority_list.py:69-167).
 // ------------------------------------------------------------------------------------------------------
-struct PLTable {
-    int8_t module[12][3];      // 0 genset, 1 battery, 2 grid, -1 padding
-    int8_t action[12][3];
-    int32_t n_actions;
-};
-
 template <int F>
-__global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLTable tab, const int32_t *__restrict__ action_id,
+__global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWords tab, const int32_t *__restrict__ action_id,
                                                        int32_t t, double *__restrict__ control)
 {
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.N) return;
     const int64_t N = a.N;
-    Params p; State s;
+    Params p; State s; Inputs in;
     load_state<F>(a.c, i, false, s);
     load_params<F>(a.c, i, p);
-    int32_t id = action_id[i];
-    if (id < 0 || id >= tab.n_actions) id = 0;         // the reference raises ValueError (discrete.py:83-84)
-    const double total_load = 0.0 + -1 * a.c.load_ts[(int64_t)t * N + i];    // _get_load :157-164
-    const double renewable = a.c.pv_ts[(int64_t)t * N + i];                  // _get_renewable :166-167
-    double g_stat = 1.0;
-    if constexpr (F & F_GRID) g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
-    double remaining = total_load - renewable;                                // :74
-
-    double c_goal = 0.0, c_gen = 0.0, c_bat = 0.0, c_grid = 0.0;
-    bool set_gen = false, set_bat = false, set_grid = false;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int mod = tab.module[id][k], act = tab.action[id][k];
-        if (mod < 0) continue;
-        if (mod == 0) { if (set_gen) continue; set_gen = true; c_goal = (double)act; }     // :82-88
-        else if (mod == 1) { if (set_bat) continue; set_bat = true; }
-        else { if (set_grid) continue; set_grid = true; }
-        double energy;
-        if (fabs(remaining - 0.0) <= 1e-4 + 1e-5 * fabs(0.0)) {           // np.isclose(remaining, 0, atol=1e-4) :90
-            energy = 0.0;
-        } else if (remaining > 0) {                                       // _produce_from_module :138-155
-            double mx = 0.0, mn = 0.0;
-            if (mod == 0) {
-                if constexpr (F & F_GENSET) {
-                    const double ns = (double)genset_next_status(s.status, act);   // genset_module.py:392-424
-                    mx = ns * p.gen_rmax; mn = ns * p.gen_rmin;
-                }
-            } else if (mod == 1) {
-                if constexpr (F & F_BATTERY) mx = battery_max_production(p, s.charge);
-            } else {
-                if constexpr (F & F_GRID) mx = p.grid_imp * g_stat;
-            }
-            if (mn <= remaining && remaining <= mx) energy = remaining;
-            else if (remaining < mn) energy = mn;
-            else energy = mx;
-        } else {                                                          // _consume_in_module :118-136
-            if (mod == 0) energy = 0.0;
-            else {
-                double mc = 0.0;
-                if (mod == 1) { if constexpr (F & F_BATTERY) mc = battery_max_consumption(p, s.charge); }
-                else          { if constexpr (F & F_GRID) mc = p.grid_exp * g_stat; }
-                energy = (-1 * remaining > mc) ? -1.0 * mc : remaining;
-            }
-        }
-        if (mod == 0) c_gen = energy; else if (mod == 1) c_bat = energy; else c_grid = energy;
-        remaining -= energy;                                              // :105
-    }
+    in.load = a.c.load_ts[(int64_t)t * N + i];
+    in.pv = a.c.pv_ts[(int64_t)t * N + i];
+    in.g_stat = 1.0;
+    if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
+    populate_core<F>(p, s, pl_select(tab, action_id[i]), in);
     double *c = control + i * A;
     int k = 0;
-    if constexpr (F & F_GENSET) { c[k] = c_goal; c[k + 1] = c_gen; k += 2; }
-    if constexpr (F & F_BATTERY) { c[k++] = c_bat; }
-    if constexpr (F & F_GRID) { c[k++] = c_grid; }
+    if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
+    if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
+    if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Discrete rollout: K fused steps whose control is expanded ON DEVICE from a priority-list id -- per step
+// (ids [K, N], one byte each: a DiscreteMicrogridEnv roll-out) or constant per grid (ids [N]: RuleBasedControl.run,
+// algos/rbc/rbc.py:64-93).  No action stream at all: per step only the series rows are read.
+// ------------------------------------------------------------------------------------------------------
+template <int F>
+__device__ __forceinline__ void load_series_at(const double *__restrict__ lts, const double *__restrict__ pts,
+                                               const double *__restrict__ gts, int64_t N, int64_t i, int64_t off,
+                                               Inputs &in)
+{
+    in.load = lts[off];
+    in.pv = pts[off];
+    in.g_stat = 1.0;
+    if constexpr (F & F_GRID) {
+        const double *g = gts + (4 * off - 3 * i);
+        in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
+    }
+}
+
+template <int F, int U>
+__global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const PLWords tab, const uint8_t *__restrict__ ids,
+                                                          int per_step, int32_t t0, int32_t K, const FusedOut out)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK_K + threadIdx.x;
+    if (i >= a.N) return;
+    const int64_t N = a.N;
+    Params p; State s; Derived d;
+    load_state<F>(a.c, i, out.log != nullptr, s);
+    load_params<F>(a.c, i, p);
+    derive<F>(p, d);
+    const double *__restrict__ lts = a.c.load_ts + (int64_t)t0 * N;
+    const double *__restrict__ pts = a.c.pv_ts + (int64_t)t0 * N;
+    const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
+    const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
+    const bool gen_instant = genset_wave_is_instant<F>(p, s);
+    const int32_t k_done = a.final_step - 1 - t0;
+    uint32_t word = per_step ? 0u : pl_select(tab, ids[i]);
+    double ret = 0.0;
+
+    Inputs ring[U];
+    uint8_t idr[U];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        if (u < K) {
+            load_series_at<F>(lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
+            if (per_step) idr[u] = ids[(int64_t)u * N + i];
+        }
+
+    int64_t off = i;
+    for (int32_t k0 = 0; k0 < K; k0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int32_t k = k0 + u;
+            if (k < K) {
+                Inputs in = ring[u];
+                if (per_step) word = pl_select(tab, idr[u]);
+                if (k + U < K) {
+                    load_series_at<F>(lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
+                    if (per_step) idr[u] = ids[off + (int64_t)U * N];
+                }
+                populate_core<F>(p, s, word, in);
+                Outputs o;
+                step_core<F>(p, d, s, in, false, want_soc, gen_instant, o);
+                if (out.reward) out.reward[off] = o.reward;
+                if (out.done) out.done[off] = (uint8_t)(k >= k_done);
+                if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
+                if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
+                if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
+                ret += o.reward;
+                off += N;
+            }
+        }
+    }
+    if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
+    store_state<F>(a.c, i, s);
+    if (out.ret_acc) out.ret_acc[i] += ret;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -494,31 +524,58 @@ int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized, 
     return MGX_OK;
 }
 
+static int encode_table(const mgx_handle *h, const int32_t *table, int32_t n_actions, PLWords *tab, const char *who)
+{
+    if (n_actions <= 0 || n_actions > 12) return fail(MGX_ERR_INVALID, "%s: n_actions must be in [1, 12]", who);
+    memset(tab, 0, sizeof(*tab));
+    tab->n_actions = n_actions;
+    for (int i = 0; i < n_actions; i++)
+        for (int k = 0; k < 3; k++) {
+            const int32_t mod = table[(i * 3 + k) * 2], act = table[(i * 3 + k) * 2 + 1];
+            if (mod == -1) continue;
+            if (mod < 0 || mod > 2 || act < 0 || act > 1) return fail(MGX_ERR_INVALID, "%s: bad table entry (%d, %d)", who, mod, act);
+            if (mod == 0 && !h->layout.has_genset) return fail(MGX_ERR_INVALID, "%s: table names a genset, layout has none", who);
+            if (mod == 1 && !h->layout.has_battery) return fail(MGX_ERR_INVALID, "%s: table names a battery, layout has none", who);
+            if (mod == 2 && !h->layout.has_grid) return fail(MGX_ERR_INVALID, "%s: table names a grid, layout has none", who);
+            tab->w[i] |= ((uint32_t)mod | ((uint32_t)act << 2) | 8u) << (4 * k);
+        }
+    return MGX_OK;
+}
+
 int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions,
                         double *control, mgx_stream stream)
 {
     g_err[0] = 0;
     if (!h || !action_id || !table || !control) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: NULL argument");
-    if (n_actions <= 0 || n_actions > 12) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: n_actions must be in [1, 12]");
     if (h->t < 0 || h->t >= h->k.T)
         return fail(MGX_ERR_RANGE, "mgx_expand_discrete: step %d is outside the time series (length %d)", h->t, h->k.T);
-    PLTable tab;
-    memset(&tab, 0xff, sizeof(tab));
-    tab.n_actions = n_actions;
-    for (int i = 0; i < n_actions; i++)
-        for (int k = 0; k < 3; k++) {
-            const int32_t mod = table[(i * 3 + k) * 2], act = table[(i * 3 + k) * 2 + 1];
-            if (mod < -1 || mod > 2) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: bad module id %d", mod);
-            if (mod == 0 && !h->layout.has_genset) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: table names a genset, layout has none");
-            if (mod == 1 && !h->layout.has_battery) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: table names a battery, layout has none");
-            if (mod == 2 && !h->layout.has_grid) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: table names a grid, layout has none");
-            tab.module[i][k] = (int8_t)mod;
-            tab.action[i][k] = (int8_t)act;
-        }
+    PLWords tab;
+    if (int rc = encode_table(h, table, n_actions, &tab, "mgx_expand_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
     MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, h->t, control)));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "expand_kernel launch");
+}
+
+int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, const int32_t *table, int32_t n_actions,
+                         int32_t K, double *reward, uint8_t *done, double *soc_trace, uint32_t *status_trace,
+                         double *ret_acc, double *log, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !action_id || !table) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: NULL argument");
+    if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: K must be positive");
+    if (h->t < 0 || (int64_t)h->t + K > h->k.T)
+        return fail(MGX_ERR_RANGE, "mgx_rollout_discrete: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
+    PLWords tab;
+    if (int rc = encode_table(h, table, n_actions, &tab, "mgx_rollout_discrete")) return rc;
+    const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
+    hipStream_t st = (hipStream_t)stream;
+    MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING><<<(unsigned)((h->k.N + BLOCK_K - 1) / BLOCK_K), BLOCK_K, 0, st>>>(
+                                  h->k, tab, action_id, per_step, h->t, K, fo)));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rollout_kernel launch");
+    h->t += K;
+    return MGX_OK;
 }
 
 int mgx_metrics(mgx_handle *h, const double *values, int32_t M, double *sums, mgx_stream stream)

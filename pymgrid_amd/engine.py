@@ -127,6 +127,42 @@ class StepEngine:
                                        _ptr(g), _ptr(ret_acc), _ptr(lg), self._stream()))
         return res
 
+    def rollout_discrete(self, action_id, table, K, reward=True, done=False, soc_trace=False, status_trace=False,
+                         ret_acc=None, log=False, out=None):
+        """K fused discrete steps with on-device action expansion.  ``action_id`` uint8: [K, N] (an id per step) or
+        [N] (one fixed priority list per grid: rule-based control).  Returns the requested [K, N] outputs."""
+        out = out or {}
+        K = int(K)
+        if action_id.dtype != torch.uint8 or action_id.device != self.device or not action_id.is_contiguous() \
+                or tuple(action_id.shape) not in ((K, self.N), (self.N,)):
+            raise ValueError(f"action_id must be a contiguous uint8 tensor [{K}, {self.N}] or [{self.N}] on {self.device}")
+        per_step = int(action_id.dim() == 2)
+        table = np.ascontiguousarray(table, dtype=np.int32)
+        if table.ndim != 3 or table.shape[1:] != (3, 2):
+            raise ValueError("table must have shape [n_actions, 3, 2]")
+        res = {}
+
+        def buf(name, want, *shape, dtype=torch.float64):
+            if not want:
+                return None
+            t = out.get(name)
+            if t is None:
+                t = self._empty(*shape, dtype=dtype)
+            res[name] = t
+            return t
+        r = buf("reward", reward, K, self.N)
+        d = buf("done", done, K, self.N, dtype=torch.uint8)
+        s = buf("soc_trace", soc_trace and self.layout.has_battery, K, self.N)
+        g = buf("status_trace", status_trace and self.layout.has_genset, K, self.N, dtype=torch.int32)
+        lg = buf("log", log, K, self.log_dim, self.N)
+        if ret_acc is not None:
+            res["ret_acc"] = ret_acc
+        with torch.cuda.device(self.device):
+            check(self._lib.mgx_rollout_discrete(self._h, _ptr(action_id), per_step,
+                                                 table.ctypes.data_as(_lib.c_i32_p), table.shape[0], K, _ptr(r),
+                                                 _ptr(d), _ptr(s), _ptr(g), _ptr(ret_acc), _ptr(lg), self._stream()))
+        return res
+
     def expand_discrete(self, action_id, table, out=None):
         """priority-list ids [N] (int32) -> unnormalised control [N, A]; ``table`` int32 [n_actions, 3, 2]."""
         if action_id.dtype != torch.int32 or tuple(action_id.shape) != (self.N,) or action_id.device != self.device:

@@ -487,7 +487,46 @@ def make_loadpv():
     save("loadpv.npz", **out)
 
 
+# --------------------------------------------------------------------------------------------- #
+def make_rbc():
+    """RuleBasedControl.run (algos/rbc/rbc.py:64-93) on every pymgrid25 scenario for a full year, plus on the
+    generator-style grids (shorter): the sorted priority list, per-step reward, final state."""
+    from pymgrid.algos import RuleBasedControl
+    out = {}
+    mod_id = {GensetModule: 0, BatteryModule: 1, GridModule: 2}
+
+    def plist(rbc):
+        arr = -np.ones((3, 2), np.int32)
+        for j, el in enumerate(rbc.priority_list):
+            arr[j] = (mod_id[type(rbc.microgrid.modules[el.module[0]][el.module[1]])], el.action)
+        return arr
+    for n in range(25):
+        m = Microgrid.from_scenario(n)
+        rbc = RuleBasedControl(m)
+        log = rbc.run()
+        mg = rbc.microgrid
+        out[f"s{n}_plist"] = plist(rbc)
+        out[f"s{n}_reward"] = log[("balance", 0, "reward")].values.astype(np.float64)
+        ch, soc, st = post_state(mg)
+        out[f"s{n}_final"] = np.array([ch, soc, *st])
+        out[f"s{n}_logsum"] = np.nansum(log_matrix(mg), axis=0)
+        print(f"rbc {n}: steps={len(log)} cost={-out[f's{n}_reward'].sum():.2f} plist={out[f's{n}_plist'].tolist()}")
+    # generator-style grids (timers, weak grids): same draw as make_generated
+    T, n_grids = 400, 48
+    grids = draw_generated(np.random.RandomState(4000), n_grids, T)
+    for i, g in enumerate(grids):
+        m = build_reference_grid(g, 0)
+        rbc = RuleBasedControl(m)
+        log = rbc.run()
+        out[f"g{i}_plist"] = plist(rbc)
+        out[f"g{i}_reward"] = log[("balance", 0, "reward")].values.astype(np.float64)
+        ch, soc, st = post_state(rbc.microgrid)
+        out[f"g{i}_final"] = np.array([ch, soc, *st])
+    out["log_names"] = np.array(LOG_NAMES)
+    save("rbc.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pymgrid25", "discrete", "genset_fsm", "obs", "generated", "loadpv"]
+    which = sys.argv[1:] or ["pymgrid25", "discrete", "genset_fsm", "obs", "generated", "loadpv", "rbc"]
     for w in which:
         globals()["make_" + w]()
