@@ -161,6 +161,20 @@ def cpu_baseline(eng, pool, seconds):
                       f"env-steps/s/core (BASELINE.md)"}
 
 
+def measured_traffic(kernel, grids, chunk):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
+    (tools/gpu_profile.sh -> profiles/<round>/traffic.json); None when no matching profile is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("grids") == grids and d.get("chunk") == chunk and kernel in d.get("kernels", {}):
+            return d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def main():
     args = parse()
     rank, world, local = mdist.init_from_env()
@@ -209,10 +223,13 @@ def main():
         per_launch_bytes = per_launch * N
         avg_launch_s = gpu / launches
         achieved = per_launch_bytes / avg_launch_s / 1e9
+        kname = {"fused": "step_k_kernel", "step": "step_kernel", "rbc": "rollout_kernel"}[mode]
+        traffic, traffic_src = measured_traffic(kname, N, chunk)
         results[mode] = {
             "value": n_total * steps / wall, "steps": steps, "ms_per_step": wall / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": per_launch_bytes,
                          "kernel": {"fused": "step_k_kernel<3,4>", "step": "step_kernel<3>",
                                     "rbc": "rollout_kernel<3,4>"}[mode],
                          "bytes_per_env_step": unit_bytes, "launches": launches,

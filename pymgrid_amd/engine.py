@@ -17,6 +17,16 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+try:                                   # raw hipStream_t of torch's current stream, without building a Stream object
+    _get_raw = torch._C._cuda_getCurrentRawStream
+
+    def _raw_stream(idx):
+        return _get_raw(idx)
+except AttributeError:                 # pragma: no cover
+    def _raw_stream(idx):
+        return torch.cuda.current_stream(idx).cuda_stream
+
+
 class StepEngine:
     def __init__(self, batch):
         if batch.device.type != "cuda":
@@ -30,6 +40,7 @@ class StepEngine:
         with torch.cuda.device(self.device):
             L, cols = batch.c_layout(), batch.c_columns()
             check(self._lib.mgx_create(C.byref(L), C.byref(cols), C.byref(self._h)))
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.N = self.layout.n_grids
         self.action_dim = self._lib.mgx_action_dim(self._h)
         self.obs_dim = self._lib.mgx_obs_dim(self._h)
@@ -50,8 +61,17 @@ class StepEngine:
             pass
 
     # ------------------------------------------------------------------------------------------------
-    def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+    def _call(self, fn, *args):
+        """fn(handle, *args, stream) on torch's current stream of the engine's device.  Kept lean: at N = 100k a
+        single-step kernel takes ~5 us, so every microsecond of Python here shows up in env-steps/s."""
+        idx = self._dev_index
+        if torch.cuda.current_device() == idx:
+            rc = fn(self._h, *args, _raw_stream(idx))
+        else:
+            with torch.cuda.device(idx):
+                rc = fn(self._h, *args, _raw_stream(idx))
+        if rc:
+            check(rc)
 
     def _empty(self, *shape, dtype=torch.float64):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -74,29 +94,35 @@ class StepEngine:
     # ------------------------------------------------------------------------------------------------
     def reset(self, initial_step=None, want_obs=True, out=None):
         obs = (out if out is not None else self._empty(self.N, self.obs_dim)) if want_obs else None
-        with torch.cuda.device(self.device):
-            check(self._lib.mgx_reset(self._h, -1 if initial_step is None else int(initial_step), _ptr(obs),
-                                      self._stream()))
+        self._call(self._lib.mgx_reset, -1 if initial_step is None else int(initial_step), _ptr(obs))
         return obs
 
     def observe(self, out=None):
         obs = out if out is not None else self._empty(self.N, self.obs_dim)
-        with torch.cuda.device(self.device):
-            check(self._lib.mgx_observe(self._h, _ptr(obs), self._stream()))
+        self._call(self._lib.mgx_observe, _ptr(obs))
         return obs
 
     def step(self, actions, normalized=True, want_obs=True, want_log=False, out=None):
         """One Microgrid.run for every grid.  Returns (obs|None, reward, done, log|None); ``out`` may hold
         preallocated ``obs`` / ``reward`` / ``done`` / ``log`` tensors."""
-        out = out or {}
         actions = self._check_actions(actions, ())
-        reward = out.get("reward") if out.get("reward") is not None else self._empty(self.N)
-        done = out.get("done") if out.get("done") is not None else self._empty(self.N, dtype=torch.uint8)
-        obs = (out.get("obs") if out.get("obs") is not None else self._empty(self.N, self.obs_dim)) if want_obs else None
-        log = (out.get("log") if out.get("log") is not None else self._empty(self.log_dim, self.N)) if want_log else None
-        with torch.cuda.device(self.device):
-            check(self._lib.mgx_step(self._h, _ptr(actions), int(bool(normalized)), _ptr(reward), _ptr(done),
-                                     _ptr(obs), _ptr(log), self._stream()))
+        reward = done = obs = log = None
+        if out:
+            reward, done, obs, log = out.get("reward"), out.get("done"), out.get("obs"), out.get("log")
+        if reward is None:
+            reward = self._empty(self.N)
+        if done is None:
+            done = self._empty(self.N, dtype=torch.uint8)
+        if not want_obs:
+            obs = None
+        elif obs is None:
+            obs = self._empty(self.N, self.obs_dim)
+        if not want_log:
+            log = None
+        elif log is None:
+            log = self._empty(self.log_dim, self.N)
+        self._call(self._lib.mgx_step, _ptr(actions), 1 if normalized else 0, reward.data_ptr(), done.data_ptr(),
+                   _ptr(obs), _ptr(log))
         return obs, reward, done, log
 
     def step_k(self, actions, normalized=True, reward=True, done=False, soc_trace=False, status_trace=False,
@@ -122,9 +148,8 @@ class StepEngine:
         lg = buf("log", log, K, self.log_dim, self.N)
         if ret_acc is not None:
             res["ret_acc"] = ret_acc
-        with torch.cuda.device(self.device):
-            check(self._lib.mgx_step_k(self._h, _ptr(actions), K, int(bool(normalized)), _ptr(r), _ptr(d), _ptr(s),
-                                       _ptr(g), _ptr(ret_acc), _ptr(lg), self._stream()))
+        self._call(self._lib.mgx_step_k, _ptr(actions), K, 1 if normalized else 0, _ptr(r), _ptr(d), _ptr(s), _ptr(g),
+                   _ptr(ret_acc), _ptr(lg))
         return res
 
     def rollout_discrete(self, action_id, table, K, reward=True, done=False, soc_trace=False, status_trace=False,
@@ -157,10 +182,8 @@ class StepEngine:
         lg = buf("log", log, K, self.log_dim, self.N)
         if ret_acc is not None:
             res["ret_acc"] = ret_acc
-        with torch.cuda.device(self.device):
-            check(self._lib.mgx_rollout_discrete(self._h, _ptr(action_id), per_step,
-                                                 table.ctypes.data_as(_lib.c_i32_p), table.shape[0], K, _ptr(r),
-                                                 _ptr(d), _ptr(s), _ptr(g), _ptr(ret_acc), _ptr(lg), self._stream()))
+        self._call(self._lib.mgx_rollout_discrete, _ptr(action_id), per_step, table.ctypes.data_as(_lib.c_i32_p),
+                   table.shape[0], K, _ptr(r), _ptr(d), _ptr(s), _ptr(g), _ptr(ret_acc), _ptr(lg))
         return res
 
     def expand_discrete(self, action_id, table, out=None):
@@ -171,9 +194,8 @@ class StepEngine:
         if table.ndim != 3 or table.shape[1:] != (3, 2):
             raise ValueError("table must have shape [n_actions, 3, 2]")
         control = out if out is not None else self._empty(self.N, self.action_dim)
-        with torch.cuda.device(self.device):
-            check(self._lib.mgx_expand_discrete(self._h, _ptr(action_id), table.ctypes.data_as(_lib.c_i32_p),
-                                                table.shape[0], _ptr(control), self._stream()))
+        self._call(self._lib.mgx_expand_discrete, _ptr(action_id), table.ctypes.data_as(_lib.c_i32_p), table.shape[0],
+                   _ptr(control))
         return control
 
     def metrics(self, values, out=None):
@@ -183,6 +205,5 @@ class StepEngine:
         if values.dtype != torch.float64 or values.shape[1] != self.N or not values.is_contiguous():
             raise ValueError(f"values must be contiguous float64 [M, {self.N}]")
         sums = out if out is not None else self._empty(values.shape[0])
-        with torch.cuda.device(self.device):
-            check(self._lib.mgx_metrics(self._h, _ptr(values), values.shape[0], _ptr(sums), self._stream()))
+        self._call(self._lib.mgx_metrics, _ptr(values), values.shape[0], _ptr(sums))
         return sums

@@ -16,6 +16,15 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o ben
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
 cd "$REPO"
 python tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
+# stamp the workload the counters belong to (bench.py only reports `traffic` for a matching config)
+python - "$OUT/traffic.json" $ARGS <<'PY'
+import json, sys
+f, a = sys.argv[1], sys.argv[2:]
+def arg(name, default):
+    return int(a[a.index(name) + 1]) if name in a else default
+d = json.load(open(f)); d["grids"] = arg("--grids", 100000); d["chunk"] = arg("--chunk", 64); d["bench_args"] = " ".join(a)
+json.dump(d, open(f, "w"), indent=1)
+PY
 cat "$OUT/summary.txt"
 # keep the merged-back payload small: drop the raw per-dispatch traces, keep stats + summary
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
