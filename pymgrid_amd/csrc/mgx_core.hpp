@@ -419,51 +419,113 @@ __device__ __forceinline__ void store_log(double *__restrict__ log, int64_t N, c
 }
 
 // ---- observation (post-step state, series index t = current step) --------------------------------------
-// One component of a time-series module: [cur, forecast_0..H-1] (base_timeseries_module.py:103-140,332-338);
-// rows beyond the series = (lo+hi)/2 (forecaster.py:95,120-137); forecasts clipped to the bounds (:139-149).
-__device__ __forceinline__ void observe_series(const double *__restrict__ ts, int64_t row_stride, int32_t T, int32_t t,
-                                               int32_t H, double lo, double hi, double *__restrict__ obs, int obs_stride)
+// obs row of a grid: [load window (1+H) | pv window (1+H) | genset 4 | battery 2 | grid window 4*(1+H)].
+// The windows depend on the series only, the 6 state columns on the post-step state only, so they are produced
+// separately: state columns by the lane that owns the grid, windows by wave-sized (64 grids x <=32 columns) work
+// items (observe_window_item) that transpose through LDS -- one lane per grid would leave the chip at ~1.5 waves
+// per SIMD with D fp64 divisions each in a row.
+
+// normalised value of one series element: rows beyond the series = (lo+hi)/2 (forecaster.py:95,120-137); forecasts
+// clipped to the bounds (:139-149); (v - lo) / spread (space.py:213)
+__device__ __forceinline__ double obs_series_value(double v, bool in_series, bool is_forecast, double lo, double hi,
+                                                   double fill, double sp)
 {
-    const double fill = (hi + lo) / 2;
-    const double sp = space_spread(lo, hi);
-    for (int h = 0; h <= H; h++) {
-        double v = fill;
-        if (t < T && t + h < T) {
-            v = ts[(int64_t)(t + h) * row_stride];
-            if (h > 0) { if (v < lo) v = lo; if (v > hi) v = hi; }
-        }
-        obs[h * obs_stride] = (v - lo) / sp;
+    double x = in_series ? v : fill;
+    if (in_series && is_forecast) { if (x < lo) x = lo; if (x > hi) x = hi; }
+    return (x - lo) / sp;
+}
+
+// the 6 state columns (genset_module.py:503-509, battery_module.py:87,323-330), written by the owning lane
+template <int F>
+__device__ __forceinline__ void observe_state_cols(const KArgs &a, const Params &p, const State &s,
+                                                   double *__restrict__ obs_row)
+{
+    int k = 2 * (1 + a.H);
+    if constexpr (F & F_GENSET) {
+        const double su = (double)(p.gen_times & 0xffff), wd = (double)(p.gen_times >> 16);
+        obs_row[k++] = space_norm(0.0, 1.0, (double)(s.status & 0xff));
+        obs_row[k++] = space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
+        obs_row[k++] = space_norm(0.0, su, (double)((s.status >> 16) & 0xff));
+        obs_row[k++] = space_norm(0.0, wd, (double)(s.status >> 24));
+    }
+    if constexpr (F & F_BATTERY) {
+        const double min_soc = p.bat_cmin / p.bat_cmax;
+        obs_row[k++] = space_norm(min_soc, 1.0, s.soc);
+        obs_row[k++] = space_norm(p.bat_cmin, p.bat_cmax, s.charge);
     }
 }
 
+// H == 0 (no forecaster): the whole row is 2 + 6 (+4) values -- the owning lane stores them directly
 template <int F>
-__device__ __forceinline__ void observe_core(const KArgs &a, int64_t i, int32_t t, const Params &p, const State &s,
-                                             double *__restrict__ obs)
+__device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_t t, const Params &p, const State &s,
+                                               double *__restrict__ obs_row)
 {
     const mgx_columns &c = a.c;
     const int64_t N = a.N;
-    const int w = 1 + a.H;
-    int k = 0;
-    observe_series(c.load_ts + i, N, a.T, t, a.H, c.load_lo[i], c.load_hi[i], obs + k, 1); k += w;
-    observe_series(c.pv_ts + i, N, a.T, t, a.H, c.pv_lo[i], c.pv_hi[i], obs + k, 1);       k += w;
-    if constexpr (F & F_GENSET) {                      // genset_module.py:503-509
-        const double su = (double)(p.gen_times & 0xffff), wd = (double)(p.gen_times >> 16);
-        obs[k++] = space_norm(0.0, 1.0, (double)(s.status & 0xff));
-        obs[k++] = space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
-        obs[k++] = space_norm(0.0, su, (double)((s.status >> 16) & 0xff));
-        obs[k++] = space_norm(0.0, wd, (double)(s.status >> 24));
+    const bool in = t < a.T;
+    {
+        const double lo = c.load_lo[i], hi = c.load_hi[i];
+        const double v = in ? c.load_ts[(int64_t)t * N + i] : 0.0;
+        obs_row[0] = obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
-    if constexpr (F & F_BATTERY) {                     // battery_module.py:87,323-330
-        const double min_soc = p.bat_cmin / p.bat_cmax;
-        obs[k++] = space_norm(min_soc, 1.0, s.soc);
-        obs[k++] = space_norm(p.bat_cmin, p.bat_cmax, s.charge);
+    {
+        const double lo = c.pv_lo[i], hi = c.pv_hi[i];
+        const double v = in ? c.pv_ts[(int64_t)t * N + i] : 0.0;
+        obs_row[1] = obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
-    if constexpr (F & F_GRID) {                        // component-minor: [c0..c3]_cur, [c0..c3]_+1, ...
-        for (int cc = 0; cc < 4; cc++)
-            observe_series(c.grid_ts + cc * N + i, 4 * N, a.T, t, a.H, c.grid_lo[cc * N + i], c.grid_hi[cc * N + i],
-                           obs + k + cc, 4);
-        k += 4 * w;
+    observe_state_cols<F>(a, p, s, obs_row);
+    if constexpr (F & F_GRID) {
+        const int k = 2 + 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+            const double lo = c.grid_lo[cc * N + i], hi = c.grid_hi[cc * N + i];
+            const double v = in ? c.grid_ts[((int64_t)t * 4 + cc) * N + i] : 0.0;
+            obs_row[k + cc] = obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
+        }
     }
+}
+
+// One wave-sized window work item: 64 grids [g0, g0+64) x horizon steps [h0, h0+nh) of one time-series module with
+// NC interleaved components (1: load / pv, 4: grid) -> columns [col, col + nh*NC) of the group's LDS row tile.
+// Loads are coalesced along the grids and issued as one unconditional batch (one latency round).
+constexpr int OBS_CH = 32;                   // columns per work item
+
+template <int NC>
+__device__ __forceinline__ void observe_window_item(const double *__restrict__ ts, int64_t N, int64_t row_stride,
+                                                    const double *__restrict__ lo_col, const double *__restrict__ hi_col,
+                                                    int32_t T, int32_t t, int64_t g0, int32_t h0, int32_t nh,
+                                                    double *row /* tile + lane*LD + first column of this item */)
+{
+    constexpr int HB = OBS_CH / NC;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = g0 + lane;
+    const int64_t ic = i < N ? i : g0;
+    double lo[NC], hi[NC], fill[NC], sp[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        lo[c] = lo_col[c * N + ic]; hi[c] = hi_col[c * N + ic];
+        fill[c] = (hi[c] + lo[c]) / 2; sp[c] = space_spread(lo[c], hi[c]);
+    }
+    // Unconditional, clamped loads: every row index is forced into [0, T-1] and the value of a row that is not
+    // wanted (beyond the series, or beyond this chunk) is discarded afterwards -- a predicated load would put each
+    // access in its own exec-masked block with an s_waitcnt behind it and serialise HB memory round trips.
+    double v[HB][NC];
+    bool in[HB];
+#pragma unroll
+    for (int hh = 0; hh < HB; hh++) {
+        const int32_t r = t + h0 + hh;
+        in[hh] = hh < nh && r < T;
+        const int32_t rc = r < T ? r : T - 1;
+#pragma unroll
+        for (int c = 0; c < NC; c++) v[hh][c] = ts[(int64_t)rc * row_stride + c * N + ic];
+    }
+#pragma unroll
+    for (int hh = 0; hh < HB; hh++)
+        if (hh < nh) {
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                row[hh * NC + c] = obs_series_value(v[hh][c], in[hh], h0 + hh > 0, lo[c], hi[c], fill[c], sp[c]);
+        }
 }
 
 }  // namespace mgx

@@ -48,7 +48,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
     // _done(): t >= final_step - 1, evaluated before the counter moves (base_timeseries_module.py:124-125)
     if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
     if (log) store_log<F>(log + i, a.N, o, s.status);
-    if (obs) observe_core<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
+    // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
+    // one (H > 0) the host launches obs_rows_kernel behind this kernel and passes obs == nullptr
+    if (obs) observe_row_h0<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -146,7 +148,63 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t
     Params p; State s;
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
-    observe_core<F>(a, i, t, p, s, obs + i * a.obs_dim);
+    observe_row_h0<F>(a, i, t, p, s, obs + i * a.obs_dim);          // H == 0 only (host dispatches)
+}
+
+// Observation rows for H > 0: one workgroup per 64-grid group builds the group's complete [64, D] row block in LDS
+// (window chunks are dealt round-robin to the 4 waves, one wave adds the state columns) and then streams it out
+// with lanes running along each row: the block is one contiguous 64*D*8-byte region of obs, every cache line is
+// written whole by one workgroup (partial-line writes from different waves/XCDs cost read-modify-write at the
+// memory side; measured 3x slower).
+struct WindowPlan {
+    int32_t chunks_ts;       // chunks per load / pv window: ceil((1+H) / 32)
+    int32_t chunks_grid;     // chunks of the 4-component grid window: ceil((1+H) / 8), 0 without a grid
+    int32_t hpc_ts, hpc_grid;   // horizon steps per chunk (balanced: ceil((1+H) / chunks))
+    int32_t grid_col_base;   // first obs column of the grid window
+    int32_t ld;              // LDS row pitch in doubles (odd: conflict-free column writes)
+};
+
+template <int F>
+__global__ __launch_bounds__(BLOCK) void obs_rows_kernel(const KArgs a, const WindowPlan plan, int32_t t,
+                                                         double *__restrict__ obs)
+{
+    extern __shared__ double tile[];                    // [64][plan.ld]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t g0 = (int64_t)blockIdx.x * 64;
+    const int64_t N = a.N;
+    const int32_t W = 1 + a.H, D = a.obs_dim, LD = plan.ld;
+    const int32_t n_chunks = 2 * plan.chunks_ts + plan.chunks_grid;
+    double *row = tile + lane * LD;
+    for (int32_t chunk = wave; chunk < n_chunks; chunk += BLOCK / 64) {
+        if (chunk < 2 * plan.chunks_ts) {
+            const bool is_pv = chunk >= plan.chunks_ts;
+            const int32_t h0 = (is_pv ? chunk - plan.chunks_ts : chunk) * plan.hpc_ts;
+            const int32_t nh = (W - h0 < plan.hpc_ts) ? W - h0 : plan.hpc_ts;
+            observe_window_item<1>(is_pv ? a.c.pv_ts : a.c.load_ts, N, N, is_pv ? a.c.pv_lo : a.c.load_lo,
+                                   is_pv ? a.c.pv_hi : a.c.load_hi, a.T, t, g0, h0, nh, row + (is_pv ? W : 0) + h0);
+        } else {
+            if constexpr (F & F_GRID) {
+                const int32_t h0 = (chunk - 2 * plan.chunks_ts) * plan.hpc_grid;
+                const int32_t nh = (W - h0 < plan.hpc_grid) ? W - h0 : plan.hpc_grid;
+                observe_window_item<4>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, g0, h0, nh,
+                                       row + plan.grid_col_base + 4 * h0);
+            }
+        }
+    }
+    if (wave == n_chunks % (BLOCK / 64)) {               // the least loaded wave adds the 6 state columns
+        const int64_t i = g0 + lane;
+        if (i < N) {
+            Params p; State s;
+            load_state<F>(a.c, i, true, s);
+            load_params<F>(a.c, i, p);
+            observe_state_cols<F>(a, p, s, row);
+        }
+    }
+    __syncthreads();
+    const int32_t n_valid = (N - g0 < 64) ? (int32_t)(N - g0) : 64;
+    double *out = obs + g0 * D;
+    for (int32_t g = wave; g < n_valid; g += BLOCK / 64)
+        for (int32_t j = lane; j < D; j += 64) out[(int64_t)g * D + j] = tile[g * LD + j];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -374,6 +432,38 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOC
 
 }  // namespace
 
+template <int F>
+static void launch_obs_rows(const KArgs &k, const WindowPlan &plan, int32_t t, double *obs, unsigned blocks, size_t lds,
+                            hipStream_t st)
+{
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)obs_rows_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    obs_rows_kernel<F><<<blocks, BLOCK, lds, st>>>(k, plan, t, obs);
+}
+
+// observation of the state at series index t into obs [N, D]
+static int launch_observe(const mgx_handle *h, int32_t t, double *obs, hipStream_t st)
+{
+    if (h->k.H == 0) {
+        MGX_DISPATCH_F(h->flags, (observe_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, t, obs)));
+        return MGX_OK;
+    }
+    const int32_t W = 1 + h->k.H, D = h->k.obs_dim;
+    WindowPlan plan;
+    plan.chunks_ts = (W + OBS_CH - 1) / OBS_CH;
+    plan.chunks_grid = h->layout.has_grid ? (W + OBS_CH / 4 - 1) / (OBS_CH / 4) : 0;
+    plan.hpc_ts = (W + plan.chunks_ts - 1) / plan.chunks_ts;
+    plan.hpc_grid = plan.chunks_grid ? (W + plan.chunks_grid - 1) / plan.chunks_grid : 0;
+    plan.grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
+    plan.ld = D | 1;
+    const size_t lds = (size_t)64 * plan.ld * sizeof(double);
+    if (lds > 160 * 1024)
+        return fail(MGX_ERR_UNSUPPORTED, "observation rows of %d values do not fit the 160 KiB LDS tile (horizon too large)", D);
+    const unsigned blocks = (unsigned)(((int64_t)h->k.N + 63) / 64);
+    MGX_DISPATCH_F(h->flags, (launch_obs_rows<F>(h->k, plan, t, obs, blocks, lds, st)));
+    return MGX_OK;
+}
+
 extern "C" {
 
 int mgx_abi_version(void) { return MGX_ABI_VERSION; }
@@ -472,10 +562,9 @@ int mgx_observe(mgx_handle *h, double *obs, mgx_stream stream)
     g_err[0] = 0;
     if (!h || !obs) return fail(MGX_ERR_INVALID, "mgx_observe: NULL argument");
     if (int rc = need_obs_bounds(h, "mgx_observe")) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    MGX_DISPATCH_F(h->flags, (observe_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, h->t, obs)));
+    if (int rc = launch_observe(h, h->t, obs, (hipStream_t)stream)) return rc;
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? MGX_OK : hip_fail(e, "observe_kernel launch");
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "observe launch");
 }
 
 int mgx_reset(mgx_handle *h, int32_t initial_step, double *obs, mgx_stream stream)
@@ -498,8 +587,10 @@ int mgx_step(mgx_handle *h, const double *actions, int normalized, double *rewar
         return fail(MGX_ERR_RANGE, "mgx_step: step %d is outside the time series (length %d)", h->t, h->k.T);
     if (obs) { if (int rc = need_obs_bounds(h, "mgx_step")) return rc; }
     hipStream_t st = (hipStream_t)stream;
+    double *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
     MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, h->t, normalized, reward,
-                                                                                    done, obs, log)));
+                                                                                    done, obs_inline, log)));
+    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, h->t + 1, obs, st)) return rc; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_kernel launch");
     h->t += 1;
