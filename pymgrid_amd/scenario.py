@@ -39,3 +39,145 @@ def bucket_by_layout(grids):
                int(p.get("initial_step", 0)), int(p.get("final_step", 0)))
         buckets.setdefault(key, []).append(i)
     return buckets
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Scenario files of the reference: `!Microgrid` YAML + csv.gz arrays
+#   Microgrid.from_scenario / load      microgrid/microgrid.py:847-893,958-980
+#   BaseMicrogridModule.from_yaml       modules/base/base_module.py:771-799  (cls_params -> __init__, then state)
+#   !NDArray constructor                utils/serialize.py:91-112            (pd.read_csv(path, index_col=0).values)
+# ---------------------------------------------------------------------------------------------------------
+_MODULE_TAGS = ("!LoadModule", "!RenewableModule", "!UnbalancedEnergyModule", "!Genset", "!BatteryModule",
+                "!GridModule")
+
+
+def _make_loader(base_dir):
+    import os
+
+    import pandas as pd
+    import yaml
+
+    class Loader(yaml.SafeLoader):
+        pass
+
+    def ndarray(loader, node):
+        if isinstance(node, yaml.SequenceNode):
+            return np.array(loader.construct_sequence(node, deep=True))
+        path = loader.construct_scalar(node)
+        if not os.path.isabs(path):
+            path = os.path.join(base_dir, path)
+        return pd.read_csv(path, index_col=0).values
+
+    def tagged(tag):
+        def construct(loader, node):
+            d = loader.construct_mapping(node, deep=True)
+            d["__tag__"] = tag
+            return d
+        return construct
+
+    Loader.add_constructor("!NDArray", ndarray)
+    for tag in _MODULE_TAGS + ("!Microgrid", "!DiscreteMicrogridEnv"):
+        Loader.add_constructor(tag, tagged(tag))
+    return Loader
+
+
+def load_scenario_yaml(path):
+    """Read one serialised microgrid (``Microgrid.dump`` format, e.g. data/scenario/pymgrid25/microgrid_3/
+    microgrid_3.yaml) into a parameter dict, applying the reference's deserialisation rules: constructor arguments
+    from ``cls_params``, then the state attributes (battery: ``soc`` then ``current_charge`` setters,
+    battery_module.py:356-362 -> charge = current_charge, soc = charge / max_capacity; genset: the four private
+    status fields, genset_module.py:426-427)."""
+    import os
+
+    import yaml
+    with open(path) as fh:
+        doc = yaml.load(fh, Loader=_make_loader(os.path.dirname(os.path.abspath(path))))
+    if doc.get("__tag__") not in ("!Microgrid", "!DiscreteMicrogridEnv"):
+        raise ValueError(f"{path}: not a !Microgrid document")
+    if doc.get("trajectory_func") is not None or doc.get("reward_shaping_func") is not None:
+        raise NotImplementedError("trajectory_func / reward_shaping_func in scenario files are not supported yet")
+    p, seen = {}, set()
+    ts_meta = []
+    for name, mod in doc["modules"]:
+        tag, cp, state = mod["__tag__"], mod["cls_params"], mod.get("state", {})
+        if tag in seen:
+            raise NotImplementedError(f"more than one {tag} per microgrid is not supported on the device path")
+        seen.add(tag)
+        if cp.get("raise_errors"):
+            raise NotImplementedError("raise_errors=True is not offered (requests are always clipped)")
+        if tag in ("!LoadModule", "!RenewableModule", "!GridModule"):
+            fc = cp.get("forecaster")
+            if fc not in (None, "oracle"):
+                raise NotImplementedError(f"forecaster {fc!r}: only None and 'oracle' are supported")
+            horizon = int(cp.get("forecast_horizon", 0)) if fc is not None else 0   # base_timeseries_module.py:40
+            ts = np.asarray(cp["time_series"], dtype=np.float64)
+            final = int(cp.get("final_step", -1))
+            final = ts.shape[0] if final <= 0 else final
+            ts_meta.append((horizon, final, int(state.get("_current_step", cp.get("initial_step", 0)))))
+            if tag == "!LoadModule":
+                p["load_ts"] = -np.abs(ts.reshape(ts.shape[0], -1)[:, 0])
+            elif tag == "!RenewableModule":
+                p["pv_ts"] = np.abs(ts.reshape(ts.shape[0], -1)[:, 0])
+            else:
+                p["grid_ts"] = ts
+                p["grid"] = dict(max_import=float(cp["max_import"]), max_export=float(cp["max_export"]),
+                                 cost_per_unit_co2=float(cp.get("cost_per_unit_co2", 0.0)))
+        elif tag == "!UnbalancedEnergyModule":
+            p["unbalanced"] = dict(loss_load_cost=float(cp["loss_load_cost"]),
+                                   overgeneration_cost=float(cp["overgeneration_cost"]))
+        elif tag == "!Genset":
+            if not cp.get("allow_abortion", True):
+                raise NotImplementedError("allow_abortion=False is not supported")
+            su, wd = int(cp.get("start_up_time", 0)), int(cp.get("wind_down_time", 0))
+            on = int(bool(cp.get("init_start_up", True)))
+            status = [on, on, 0, wd] if on else [0, 0, su, 0]                   # genset_module.py:91-92,216-227
+            if "_current_status" in state:
+                status = [int(state["_current_status"]), int(state["_goal_status"]),
+                          int(state["_steps_until_up"]), int(state["_steps_until_down"])]
+            p["genset"] = dict(running_min_production=float(cp["running_min_production"]),
+                               running_max_production=float(cp["running_max_production"]),
+                               genset_cost=float(cp["genset_cost"]), co2_per_unit=float(cp.get("co2_per_unit", 0.0)),
+                               cost_per_unit_co2=float(cp.get("cost_per_unit_co2", 0.0)),
+                               start_up_time=su, wind_down_time=wd, status=status)
+        elif tag == "!BatteryModule":
+            if cp.get("battery_transition_model") is not None:
+                raise NotImplementedError("custom battery_transition_model is not supported")
+            cap = float(cp["max_capacity"])
+            if "current_charge" in state:
+                charge = float(state["current_charge"])
+            elif cp.get("init_charge") is not None:
+                charge = float(cp["init_charge"])
+            else:
+                charge = float(cp["init_soc"]) * cap
+            p["battery"] = dict(min_capacity=float(cp["min_capacity"]), max_capacity=cap,
+                                max_charge=float(cp["max_charge"]), max_discharge=float(cp["max_discharge"]),
+                                efficiency=float(cp["efficiency"]),
+                                battery_cost_cycle=float(cp.get("battery_cost_cycle", 0.0)),
+                                charge=charge, soc=charge / cap)
+    if "unbalanced" not in p:
+        raise ValueError("scenario has no UnbalancedEnergyModule")
+    if len(set(ts_meta)) != 1:
+        raise NotImplementedError("time-series modules with different horizon / final_step / current step")
+    p["horizon"], p["final_step"], p["initial_step"] = ts_meta[0]
+    return p
+
+
+def from_scenario(microgrid_number, root):
+    """``Microgrid.from_scenario(n)`` (microgrid.py:958-980) given the directory that holds ``pymgrid25/``."""
+    import os
+    n = int(microgrid_number)
+    return load_scenario_yaml(os.path.join(root, "pymgrid25", f"microgrid_{n}", f"microgrid_{n}.yaml"))
+
+
+def save_state(batch, step, path):
+    """Checkpoint of the dynamic state (the YAML ``state`` blocks of the reference, base_module.py:826-850)."""
+    arrays = {k: v.cpu().numpy() for k, v in batch.state().items()}
+    np.savez_compressed(path, current_step=np.int64(step), **arrays)
+
+
+def load_state(batch, path):
+    """Restore a ``save_state`` checkpoint into the batch; returns the saved step counter."""
+    import torch
+    z = np.load(path)
+    batch.load_state({k: torch.from_numpy(z[k]).to(batch.device) for k in z.files if k != "current_step"})
+    return int(z["current_step"])
