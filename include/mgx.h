@@ -51,6 +51,14 @@ enum mgx_status {
     MGX_ERR_DEVICE = 4        /* HIP runtime error (message holds hipGetErrorString) */
 };
 
+/* Reward shaping functions of the reference (microgrid/reward_shaping/): what step() RETURNS as reward.
+ * The log's "reward" column always keeps the unshaped sum (the balance log's `reward` vs `shaped_reward`). */
+enum mgx_reward_shaper {
+    MGX_SHAPER_NONE = 0,
+    MGX_SHAPER_PV_CURTAILMENT = 1,     /* PVCurtailmentShaper:    -curtailment                       */
+    MGX_SHAPER_BATTERY_DISCHARGE = 2   /* BatteryDischargeShaper: (discharge - loss_load) / load     */
+};
+
 typedef struct mgx_handle mgx_handle;
 typedef void *mgx_stream;     /* hipStream_t */
 
@@ -117,6 +125,14 @@ int32_t mgx_current_step(const mgx_handle *h);                   /* BaseMicrogri
  * battery charge and genset status are NOT touched (the reference does not restore them).
  * obs [N, D] may be NULL. */
 int mgx_reset(mgx_handle *h, int32_t initial_step, double *obs, mgx_stream stream);
+
+/* Episode window [initial_step, final_step) for the next reset -- what a trajectory_func returns
+ * (microgrid.py:221-225, microgrid/trajectory/ classes; validated like _check_trajectory_func, microgrid.py:181-203:
+ * inside the window given at create, initial < final).  Does not move the step counter; call mgx_reset next. */
+int mgx_set_window(mgx_handle *h, int32_t initial_step, int32_t final_step);
+
+/* Microgrid.reward_shaping_func (microgrid.py:105,130): one of enum mgx_reward_shaper. */
+int mgx_set_reward_shaper(mgx_handle *h, int32_t shaper);
 
 /* Normalised observation of the current state (BaseMicrogridModule.to_normalized(state), base_module.py:157;
  * forecast window + end-of-series padding forecaster.py:120-149,215-217). */

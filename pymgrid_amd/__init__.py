@@ -11,5 +11,7 @@ from .envs import (BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv, DiscreteMic
                    MicrogridEnv)
 from .priority_list import get_priority_lists  # noqa: F401
 from .rbc import RuleBasedControl  # noqa: F401
+from .trajectory import (BatteryDischargeShaper, DeterministicTrajectory,  # noqa: F401
+                         FixedLengthStochasticTrajectory, PVCurtailmentShaper, StochasticTrajectory)
 
 __version__ = "0.1.0"

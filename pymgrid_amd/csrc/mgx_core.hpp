@@ -39,6 +39,7 @@ struct KArgs {
     mgx_columns c;
     int32_t N, T, H, final_step;
     int32_t obs_dim, log_dim;
+    int32_t shaper;          // mgx_reward_shaper
 };
 
 struct Params {
@@ -388,6 +389,22 @@ __device__ __forceinline__ void populate_core(const Params &p, const State &s, u
         remaining -= energy;                                      // :105
     }
     in.a_goal = c_goal; in.a_gen = c_gen; in.a_bat = c_bat; in.a_grid = c_grid;
+}
+
+// ---- reward shaping (microgrid/reward_shaping/*.py; MicrogridStep.shaped_reward, utils/step.py:41-46) ----------
+// The value RETURNED by step(); the log's "reward" column always holds the unshaped sum.
+template <int F>
+__device__ __forceinline__ double shaped_reward(int32_t shaper, const Outputs &o)
+{
+    if (shaper == MGX_SHAPER_PV_CURTAILMENT)            // pv_curtailment_shaper.py:15-17
+        return -1.0 * o.curtailment;
+    if (shaper == MGX_SHAPER_BATTERY_DISCHARGE) {       // battery_discharge_shaper.py:23-34
+        double discharge = 0.0;
+        if constexpr (F & F_BATTERY) discharge = o.discharge_amount;
+        const double load = o.load_met;
+        return load == 0.0 ? 0.0 : (discharge - o.loss_load) / load;   // ZeroDivisionError -> 0.0
+    }
+    return o.reward;
 }
 
 // ---- log row ------------------------------------------------------------------------------------------

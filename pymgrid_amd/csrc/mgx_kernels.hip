@@ -44,7 +44,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
     step_core<F>(p, d, s, in, normalized != 0, true, gen_instant, o);
 
     store_state<F>(a.c, i, s);
-    reward[i] = o.reward;
+    reward[i] = shaped_reward<F>(a.shaper, o);
     // _done(): t >= final_step - 1, evaluated before the counter moves (base_timeseries_module.py:124-125)
     if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
     if (log) store_log<F>(log + i, a.N, o, s.status);
@@ -122,12 +122,13 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const do
                 if (k + U < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
                 Outputs o;
                 step_core<F>(p, d, s, in, norm, want_soc, gen_instant, o);
-                if (out.reward) out.reward[off] = o.reward;
+                const double r = shaped_reward<F>(a.shaper, o);
+                if (out.reward) out.reward[off] = r;
                 if (out.done) out.done[off] = (uint8_t)(k >= k_done);
                 if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
                 if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
                 if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
-                ret += o.reward;
+                ret += r;
                 off += N;
             }
         }
@@ -296,12 +297,13 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
                 populate_core<F>(p, s, word, in);
                 Outputs o;
                 step_core<F>(p, d, s, in, false, want_soc, gen_instant, o);
-                if (out.reward) out.reward[off] = o.reward;
+                const double r = shaped_reward<F>(a.shaper, o);
+                if (out.reward) out.reward[off] = r;
                 if (out.done) out.done[off] = (uint8_t)(k >= k_done);
                 if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
                 if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
                 if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
-                ret += o.reward;
+                ret += r;
                 off += N;
             }
         }
@@ -379,6 +381,7 @@ using namespace mgx;
 struct mgx_handle {
     KArgs k;
     mgx_layout layout;
+    int32_t window_lo, window_hi;   // episode window given at create: trajectories must stay inside it
     int32_t flags;          // F
     int32_t t;              // current step
     int32_t action_dim;
@@ -518,6 +521,8 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->k.obs_dim = 2 * w + 4 * L->has_genset + 2 * L->has_battery + 4 * w * L->has_grid;
     h->k.log_dim = LC_COMMON_END + LC_GENSET_N * L->has_genset + LC_BATTERY_N * L->has_battery + LC_GRID_N * L->has_grid;
     h->t = L->initial_step;
+    h->k.shaper = MGX_SHAPER_NONE;
+    h->window_lo = L->initial_step; h->window_hi = final_step;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
         return hip_fail(e, "hipMalloc(scratch)");
@@ -565,6 +570,35 @@ int mgx_observe(mgx_handle *h, double *obs, mgx_stream stream)
     if (int rc = launch_observe(h, h->t, obs, (hipStream_t)stream)) return rc;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "observe launch");
+}
+
+int mgx_set_window(mgx_handle *h, int32_t initial_step, int32_t final_step)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_window: NULL handle");
+    if (initial_step < h->window_lo)
+        return fail(MGX_ERR_INVALID, "trajectory_func returned initial_step value (%d) less than env's initial step: (%d)",
+                    initial_step, h->window_lo);
+    if (final_step > h->window_hi)
+        return fail(MGX_ERR_INVALID, "trajectory_func returned final_step value (%d) greater than env's final step: (%d)",
+                    final_step, h->window_hi);
+    if (initial_step >= final_step)
+        return fail(MGX_ERR_INVALID, "trajectory_func returned values (%d, %d) such that initial_step was greater than "
+                                     "or equal to final_step.", initial_step, final_step);
+    h->layout.initial_step = initial_step;
+    h->layout.final_step = final_step;
+    h->k.final_step = final_step;
+    return MGX_OK;
+}
+
+int mgx_set_reward_shaper(mgx_handle *h, int32_t shaper)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_reward_shaper: NULL handle");
+    if (shaper < MGX_SHAPER_NONE || shaper > MGX_SHAPER_BATTERY_DISCHARGE)
+        return fail(MGX_ERR_INVALID, "mgx_set_reward_shaper: unknown shaper %d", shaper);
+    h->k.shaper = shaper;
+    return MGX_OK;
 }
 
 int mgx_reset(mgx_handle *h, int32_t initial_step, double *obs, mgx_stream stream)

@@ -40,6 +40,7 @@ class StepEngine:
         with torch.cuda.device(self.device):
             L, cols = batch.c_layout(), batch.c_columns()
             check(self._lib.mgx_create(C.byref(L), C.byref(cols), C.byref(self._h)))
+        self.window = (self.layout.initial_step, self.layout.final_step)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.N = self.layout.n_grids
         self.action_dim = self._lib.mgx_action_dim(self._h)
@@ -90,6 +91,14 @@ class StepEngine:
     @property
     def current_step(self):
         return self._lib.mgx_current_step(self._h)
+
+    def set_window(self, initial_step, final_step):
+        """Episode window of the next reset (what a trajectory_func returns, microgrid.py:221-225)."""
+        check(self._lib.mgx_set_window(self._h, int(initial_step), int(final_step)))
+        self.window = (int(initial_step), int(final_step))
+
+    def set_reward_shaper(self, kind):
+        check(self._lib.mgx_set_reward_shaper(self._h, int(kind)))
 
     # ------------------------------------------------------------------------------------------------
     def reset(self, initial_step=None, want_obs=True, out=None):

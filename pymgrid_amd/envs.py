@@ -23,6 +23,7 @@ from .batch import MicrogridBatch, unpack_status
 from .engine import StepEngine
 from .priority_list import MODULE_NAMES, get_priority_lists, table_array
 from .spaces import Box, Discrete
+from .trajectory import check_trajectory_output, shaper_kind
 
 
 class BatchedMicrogridEnv:
@@ -30,12 +31,19 @@ class BatchedMicrogridEnv:
     ``Microgrid.run(control, normalized)``; the reference's own ContinuousMicrogridEnv is non-functional in
     v1.2.2)."""
 
-    def __init__(self, batch, log=False, observations=True):
+    def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
         self.batch = batch
         self.layout = batch.layout
         self.engine = StepEngine(batch)
+        self.reward_shaping_func = reward_shaping_func
+        self.engine.set_reward_shaper(shaper_kind(reward_shaping_func))
+        self.trajectory_func = trajectory_func
+        if trajectory_func is not None:                    # Microgrid._check_trajectory_func, microgrid.py:181-203
+            if not callable(trajectory_func):
+                raise TypeError('trajectory_func must be callable.')
+            self._draw_window(apply=False)
         self.n_grids = self.layout.n_grids
         self._keep_log = bool(log)
         self._observations = bool(observations)
@@ -52,11 +60,26 @@ class BatchedMicrogridEnv:
 
     @property
     def initial_step(self):
-        return self.layout.initial_step
+        return self.engine.window[0]
 
     @property
     def final_step(self):
-        return self.layout.final_step
+        return self.engine.window[1]
+
+    def _draw_window(self, apply=True):
+        """Microgrid._set_trajectory (microgrid.py:221-225): one window for the whole batch."""
+        lo, hi = check_trajectory_output(self.trajectory_func(self.layout.initial_step, self.layout.final_step))
+        if lo < self.layout.initial_step:
+            raise ValueError(f'trajectory_func returned initial_step value ({lo}) less than env\'s initial '
+                             f'step: ({self.layout.initial_step})')
+        if hi > self.layout.final_step:
+            raise ValueError(f'trajectory_func returned final_step value ({hi}) greater than env\'s final step:'
+                             f' ({self.layout.final_step})')
+        if lo >= hi:
+            raise ValueError(f'trajectory_func returned values ({lo}, {hi}) such that initial_step'
+                             f'was greater than or equal to final_step.')
+        if apply:
+            self.engine.set_window(lo, hi)
 
     def __len__(self):
         return self.n_grids
@@ -65,6 +88,8 @@ class BatchedMicrogridEnv:
     def reset(self, initial_step=None):
         """Microgrid.reset: step counter back to ``initial_step``, logs flushed, state NOT restored."""
         self._log_rows = []
+        if self.trajectory_func is not None and initial_step is None:
+            self._draw_window()
         return self.engine.reset(initial_step, want_obs=self._observations)
 
     def step(self, action, normalized=True):
@@ -140,8 +165,10 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
     """``DiscreteMicrogridEnv`` for N microgrids: an action is the index of a priority list, expanded on device
     into an unnormalised control and stepped with ``normalized=False`` (discrete.py:109-143)."""
 
-    def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True):
-        super().__init__(batch, log=log, observations=observations)
+    def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
+                 trajectory_func=None):
+        super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
+                         trajectory_func=trajectory_func)
         L = self.layout
         redundant = False
         if remove_redundant_gensets and L.has_genset:
@@ -197,8 +224,10 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
     """One microgrid behind ``BaseMicrogridEnv``'s API: ``step(control_dict, normalized=True)`` returns
     ``(obs, float, bool, dict)`` exactly like envs/base/base.py:169-209."""
 
-    def __init__(self, params, device="cuda", flat_spaces=True, log=True):
-        super().__init__(MicrogridBatch.from_grids([params], device=device), log=log)
+    def __init__(self, params, device="cuda", flat_spaces=True, log=True, reward_shaping_func=None,
+                 trajectory_func=None):
+        super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
+                         reward_shaping_func=reward_shaping_func, trajectory_func=trajectory_func)
         self.flat_spaces = flat_spaces
 
     def reset(self, initial_step=None):
@@ -215,9 +244,11 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
     """One microgrid behind ``DiscreteMicrogridEnv``'s API (envs/discrete/discrete.py:10-152):
     ``step(action: int) -> (obs, reward: float, done: bool, info: dict)``."""
 
-    def __init__(self, params, device="cuda", flat_spaces=True, log=True, remove_redundant_gensets=True):
+    def __init__(self, params, device="cuda", flat_spaces=True, log=True, remove_redundant_gensets=True,
+                 reward_shaping_func=None, trajectory_func=None):
         super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
-                         remove_redundant_gensets=remove_redundant_gensets)
+                         remove_redundant_gensets=remove_redundant_gensets, reward_shaping_func=reward_shaping_func,
+                         trajectory_func=trajectory_func)
         self.flat_spaces = flat_spaces
 
     def reset(self, initial_step=None):

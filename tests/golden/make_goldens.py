@@ -526,7 +526,70 @@ def make_rbc():
     save("rbc.npz", **out)
 
 
+# --------------------------------------------------------------------------------------------- #
+def make_shaping():
+    """Reward shapers (microgrid/reward_shaping/*.py) and trajectory functions (microgrid/trajectory/*.py)."""
+    from pymgrid.microgrid.reward_shaping import BatteryDischargeShaper, PVCurtailmentShaper
+    from pymgrid.microgrid.trajectory import (DeterministicTrajectory, FixedLengthStochasticTrajectory,
+                                              StochasticTrajectory)
+    out = {}
+    K = 300
+    for n in (1, 2, 0):
+        # PV curtailment shaper under random normalised controls
+        m = Microgrid.from_scenario(n)
+        m.reward_shaping_func = PVCurtailmentShaper()
+        p = extract_params(m)
+        a = np.random.RandomState(6000 + n).rand(K, action_dims(p))
+        a[::11] = np.round(a[::11])
+        shaped = np.zeros(K)
+        for k in range(K):
+            _, shaped[k], _, _ = m.run(control_from_row(m, p, a[k]))
+        log = m.get_log()
+        out[f"shape_pv_{n}_shaped"] = shaped
+        out[f"shape_pv_{n}_raw"] = log[("balance", 0, "reward")].values.astype(np.float64)
+        assert np.array_equal(shaped, log[("balance", 0, "shaped_reward")].values)
+        # Battery discharge shaper: it asserts a value in [-1, 1] (battery_discharge_shaper.py:33), which random
+        # controls violate, so it is driven through the discrete env (priority-list controls never over-produce)
+        env = DiscreteMicrogridEnv.from_scenario(n)
+        env.reward_shaping_func = BatteryDischargeShaper()
+        ids = np.random.RandomState(6050 + n).randint(0, env.action_space.n, size=K)
+        shaped = np.zeros(K)
+        for k in range(K):
+            _, shaped[k], _, _ = env.step(int(ids[k]))
+        log = env.get_log()
+        out[f"shape_bat_{n}_ids"] = ids.astype(np.int32)
+        out[f"shape_bat_{n}_shaped"] = shaped
+        out[f"shape_bat_{n}_raw"] = log[("balance", 0, "reward")].values.astype(np.float64)
+    # trajectories: windows drawn from numpy's global RNG at every reset (microgrid.py:221-225)
+    for tag, func in (("det", DeterministicTrajectory(100, 160)), ("stoch", StochasticTrajectory()),
+                      ("fixed", FixedLengthStochasticTrajectory(48))):
+        m = Microgrid.from_scenario(2)
+        m.trajectory_func = func
+        p = extract_params(m)
+        np.random.seed(777)
+        windows, rewards, obs0 = [], [], []
+        for ep in range(3):
+            o = m.reset()
+            lo = find(m, LoadModule)[0]
+            windows.append((lo.initial_step, lo.final_step))
+            obs0.append(flat_obs(m, o))
+            rs = np.random.RandomState(6100 + ep)
+            ep_r = []
+            for k in range(400):
+                _, r, d, _ = m.run(control_from_row(m, p, rs.rand(action_dims(p))))
+                ep_r.append(r)
+                if d:
+                    break
+            rewards.append(np.array(ep_r))
+        out[f"traj_{tag}_windows"] = np.array(windows)
+        for ep in range(3):
+            out[f"traj_{tag}_reward{ep}"] = rewards[ep]
+            out[f"traj_{tag}_obs0_{ep}"] = obs0[ep]
+        print(tag, windows, [len(r) for r in rewards])
+    save("shaping.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pymgrid25", "discrete", "genset_fsm", "obs", "generated", "loadpv", "rbc"]
+    which = sys.argv[1:] or ["pymgrid25", "discrete", "genset_fsm", "obs", "generated", "loadpv", "rbc", "shaping"]
     for w in which:
         globals()["make_" + w]()
