@@ -97,6 +97,9 @@ typedef struct mgx_columns {
      * base_timeseries_module.py:81-88 (load/pv: min(ts.min(),0), max(ts.max(),0)), grid_module.py:125-132 */
     const double *load_lo, *load_hi, *pv_lo, *pv_hi;      /* [N] */
     const double *grid_lo, *grid_hi;                      /* [4, N] */
+    /* GaussianNoiseForecaster (forecast/forecaster.py:220-275): per-grid noise standard deviation of each module's
+     * forecast, already scaled by |mean(series)| when relative_noise is set; NULL = OracleForecaster */
+    const double *load_noise_std, *pv_noise_std, *grid_noise_std;   /* [N] */
     /* dynamic state, read and written by every step */
     double *charge, *soc;                 /* BatteryModule._current_charge / _soc */
     uint32_t *gen_status;                 /* current | goal<<8 | steps_until_up<<16 | steps_until_down<<24 */
@@ -133,6 +136,11 @@ int mgx_set_window(mgx_handle *h, int32_t initial_step, int32_t final_step);
 
 /* Microgrid.reward_shaping_func (microgrid.py:105,130): one of enum mgx_reward_shaper. */
 int mgx_set_reward_shaper(mgx_handle *h, int32_t shaper);
+
+/* GaussianNoiseForecaster switches: Philox seed of the forecast noise and `increase_uncertainty`
+ * (std_j = std * (1 + log(1 + j)) for forecast_j, forecaster.py:243-249).  Noise is drawn per (grid, module
+ * component, step, horizon index); statistical -- not bit -- parity with the reference's np.random.normal. */
+int mgx_set_forecast_noise(mgx_handle *h, uint64_t seed, int increase_uncertainty);
 
 /* Normalised observation of the current state (BaseMicrogridModule.to_normalized(state), base_module.py:157;
  * forecast window + end-of-series padding forecaster.py:120-149,215-217). */

@@ -43,7 +43,7 @@ _F64_COLS = ("bat_min_capacity", "bat_max_capacity", "bat_max_charge", "bat_max_
              "gen_cost_per_unit_co2")
 _F64_COLS2 = ("grid_max_import", "grid_max_export", "grid_cost_per_unit_co2", "loss_load_cost", "overgeneration_cost",
               "load_ts", "pv_ts", "grid_ts", "load_lo", "load_hi", "pv_lo", "pv_hi", "grid_lo", "grid_hi",
-              "charge", "soc")
+              "load_noise_std", "pv_noise_std", "grid_noise_std", "charge", "soc")
 
 
 class Columns(C.Structure):
@@ -69,6 +69,7 @@ SYMBOLS = {
     "mgx_current_step": (C.c_int32, [C.c_void_p]),
     "mgx_set_window": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "mgx_set_reward_shaper": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mgx_set_forecast_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
     "mgx_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgx_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -131,9 +131,11 @@ class MicrogridBatch:
 
     STATE_COLUMNS = ("charge", "soc", "gen_status")
 
-    def __init__(self, layout, cols):
+    def __init__(self, layout, cols, forecast_noise=None):
         self.layout = layout
         self.cols = cols
+        # GaussianNoiseForecaster switches: dict(seed=int, increase_uncertainty=bool) or None (oracle forecaster)
+        self.forecast_noise = forecast_noise
         self._validate()
 
     # ------------------------------------------------------------------------------------------------
@@ -172,6 +174,8 @@ class MicrogridBatch:
     @classmethod
     def from_numpy(cls, layout, arrays, device):
         cols = {}
+        arrays = dict(arrays)
+        noise = arrays.pop("__forecast_noise__", None)
         for name, a in arrays.items():
             a = np.ascontiguousarray(a)
             if name in ("gen_times", "gen_status"):
@@ -179,7 +183,7 @@ class MicrogridBatch:
             else:
                 t = torch.from_numpy(a.astype(np.float64, copy=False).copy())
             cols[name] = t.to(device)
-        return cls(layout, cols)
+        return cls(layout, cols, forecast_noise=noise)
 
     @classmethod
     def from_grids(cls, grids, device="cuda"):
@@ -324,4 +328,33 @@ def pack_grids(grids):
         gts = np.stack(gts, axis=2)               # [T, 4, N]
         A["grid_ts"] = gts
         A["grid_lo"], A["grid_hi"] = gts.min(axis=0), gts.max(axis=0)
+    # GaussianNoiseForecaster (forecast/forecaster.py:220-275): p["forecast_noise"] = dict(std=, relative_noise=,
+    # increase_uncertainty=, seed=) -> per-grid, per-module noise standard deviation columns
+    fn0 = g0.get("forecast_noise")
+    if any((g.get("forecast_noise") is None) != (fn0 is None) for g in grids):
+        raise ValueError("all microgrids of a batch must agree on having a noisy forecaster")
+    if fn0 is not None:
+        if layout.horizon == 0:
+            raise ValueError("forecast_noise needs a forecast horizon > 0")
+        lo_, hi_ = layout.initial_step, layout.final_step
+        for g in grids:
+            f = g["forecast_noise"]
+            if bool(f.get("increase_uncertainty", False)) != bool(fn0.get("increase_uncertainty", False)):
+                raise ValueError("all microgrids of a batch must share increase_uncertainty")
+
+        def stds(series_of):          # _get_noise_std :236-249: std * |mean(time_series[initial:final])| if relative
+            out = []
+            for j, g in enumerate(grids):
+                f = g["forecast_noise"]
+                sd = float(f["std"])
+                if f.get("relative_noise", False):
+                    sd *= abs(float(series_of(j)[lo_:hi_].mean()))
+                out.append(sd)
+            return np.array(out)
+        A["load_noise_std"] = stds(lambda j: A["load_ts"][:, j])
+        A["pv_noise_std"] = stds(lambda j: A["pv_ts"][:, j])
+        if has["grid"]:
+            A["grid_noise_std"] = stds(lambda j: A["grid_ts"][:, :, j])
+        A["__forecast_noise__"] = dict(seed=int(fn0.get("seed", 0)),
+                                       increase_uncertainty=bool(fn0.get("increase_uncertainty", False)))
     return A, layout

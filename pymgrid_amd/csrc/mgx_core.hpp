@@ -40,6 +40,8 @@ struct KArgs {
     int32_t N, T, H, final_step;
     int32_t obs_dim, log_dim;
     int32_t shaper;          // mgx_reward_shaper
+    int32_t noise_increase;  // GaussianNoiseForecaster.increase_uncertainty
+    uint64_t noise_seed;
 };
 
 struct Params {
@@ -502,16 +504,47 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
     }
 }
 
+// ---- forecast noise: Philox4x32-10 counter-based generator + Box-Muller ------------------------------------
+// GaussianNoiseForecaster._forecast (forecaster.py:262-263): forecast = true future values + N(0, std).  The
+// reference draws from numpy's global stream; here every (grid, series component, step, horizon index) owns a
+// counter, so the noise is reproducible and independent of batch size / sharding.  Statistical parity only.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// one standard normal for (grid, component id, absolute series row, seed)
+__device__ __forceinline__ double forecast_normal(uint64_t seed, int64_t grid, uint32_t comp, int32_t t, int32_t h)
+{
+    uint32_t r[4];
+    philox4x32_10((uint32_t)grid, (uint32_t)((uint64_t)grid >> 32) ^ (comp << 24), (uint32_t)t, (uint32_t)h,
+                  (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    // 53-bit uniform in (0, 1] and a 32-bit angle
+    const double u1 = ((double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) + 1.0) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)r[2] + 0.5) * (1.0 / 4294967296.0);
+    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);     // cospi: no large-argument reduction (no scratch)
+}
+
 // One wave-sized window work item: 64 grids [g0, g0+64) x horizon steps [h0, h0+nh) of one time-series module with
 // NC interleaved components (1: load / pv, 4: grid) -> columns [col, col + nh*NC) of the group's LDS row tile.
 // Loads are coalesced along the grids and issued as one unconditional batch (one latency round).
 constexpr int OBS_CH = 32;                   // columns per work item
 
-template <int NC>
+template <int NC, bool NOISE>
 __device__ __forceinline__ void observe_window_item(const double *__restrict__ ts, int64_t N, int64_t row_stride,
                                                     const double *__restrict__ lo_col, const double *__restrict__ hi_col,
                                                     int32_t T, int32_t t, int64_t g0, int32_t h0, int32_t nh,
-                                                    double *row /* tile + lane*LD + first column of this item */)
+                                                    double *row /* tile + lane*LD + first column of this item */,
+                                                    const double *__restrict__ noise_std, uint32_t comp_base,
+                                                    uint64_t noise_seed, int noise_increase)
 {
     constexpr int HB = OBS_CH / NC;
     const int lane = threadIdx.x & 63;
@@ -535,6 +568,18 @@ __device__ __forceinline__ void observe_window_item(const double *__restrict__ t
         const int32_t rc = r < T ? r : T - 1;
 #pragma unroll
         for (int c = 0; c < NC; c++) v[hh][c] = ts[(int64_t)rc * row_stride + c * N + ic];
+    }
+    if constexpr (NOISE) if (noise_std != nullptr) {        // GaussianNoiseForecaster
+        const double std0 = noise_std[ic];
+#pragma unroll
+        for (int hh = 0; hh < HB; hh++) {
+            const int32_t h = h0 + hh;                      // h >= 1 is forecast_{h-1}; the current value carries no noise
+            if (hh < nh && h > 0 && in[hh]) {
+                const double sd = noise_increase ? std0 * (1.0 + log(1.0 + (double)(h - 1))) : std0;   // :243-249
+#pragma unroll
+                for (int c = 0; c < NC; c++) v[hh][c] += sd * forecast_normal(noise_seed, i, comp_base + c, t, h);
+            }
+        }
     }
 #pragma unroll
     for (int hh = 0; hh < HB; hh++)

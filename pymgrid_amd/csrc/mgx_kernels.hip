@@ -165,7 +165,7 @@ struct WindowPlan {
     int32_t ld;              // LDS row pitch in doubles (odd: conflict-free column writes)
 };
 
-template <int F>
+template <int F, bool NOISE>
 __global__ __launch_bounds__(BLOCK) void obs_rows_kernel(const KArgs a, const WindowPlan plan, int32_t t,
                                                          double *__restrict__ obs)
 {
@@ -181,14 +181,17 @@ __global__ __launch_bounds__(BLOCK) void obs_rows_kernel(const KArgs a, const Wi
             const bool is_pv = chunk >= plan.chunks_ts;
             const int32_t h0 = (is_pv ? chunk - plan.chunks_ts : chunk) * plan.hpc_ts;
             const int32_t nh = (W - h0 < plan.hpc_ts) ? W - h0 : plan.hpc_ts;
-            observe_window_item<1>(is_pv ? a.c.pv_ts : a.c.load_ts, N, N, is_pv ? a.c.pv_lo : a.c.load_lo,
-                                   is_pv ? a.c.pv_hi : a.c.load_hi, a.T, t, g0, h0, nh, row + (is_pv ? W : 0) + h0);
+            observe_window_item<1, NOISE>(is_pv ? a.c.pv_ts : a.c.load_ts, N, N, is_pv ? a.c.pv_lo : a.c.load_lo,
+                                   is_pv ? a.c.pv_hi : a.c.load_hi, a.T, t, g0, h0, nh, row + (is_pv ? W : 0) + h0,
+                                   is_pv ? a.c.pv_noise_std : a.c.load_noise_std, is_pv ? 1u : 0u, a.noise_seed,
+                                   a.noise_increase);
         } else {
             if constexpr (F & F_GRID) {
                 const int32_t h0 = (chunk - 2 * plan.chunks_ts) * plan.hpc_grid;
                 const int32_t nh = (W - h0 < plan.hpc_grid) ? W - h0 : plan.hpc_grid;
-                observe_window_item<4>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, g0, h0, nh,
-                                       row + plan.grid_col_base + 4 * h0);
+                observe_window_item<4, NOISE>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, g0, h0, nh,
+                                       row + plan.grid_col_base + 4 * h0, a.c.grid_noise_std, 2u, a.noise_seed,
+                                       a.noise_increase);
             }
         }
     }
@@ -439,9 +442,16 @@ template <int F>
 static void launch_obs_rows(const KArgs &k, const WindowPlan &plan, int32_t t, double *obs, unsigned blocks, size_t lds,
                             hipStream_t st)
 {
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)obs_rows_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    obs_rows_kernel<F><<<blocks, BLOCK, lds, st>>>(k, plan, t, obs);
+    const bool noise = k.c.load_noise_std || k.c.pv_noise_std || k.c.grid_noise_std;
+    if (noise) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)obs_rows_kernel<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        obs_rows_kernel<F, true><<<blocks, BLOCK, lds, st>>>(k, plan, t, obs);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)obs_rows_kernel<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        obs_rows_kernel<F, false><<<blocks, BLOCK, lds, st>>>(k, plan, t, obs);
+    }
 }
 
 // observation of the state at series index t into obs [N, D]
@@ -522,6 +532,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->k.log_dim = LC_COMMON_END + LC_GENSET_N * L->has_genset + LC_BATTERY_N * L->has_battery + LC_GRID_N * L->has_grid;
     h->t = L->initial_step;
     h->k.shaper = MGX_SHAPER_NONE;
+    h->k.noise_seed = 0; h->k.noise_increase = 0;
     h->window_lo = L->initial_step; h->window_hi = final_step;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
@@ -598,6 +609,15 @@ int mgx_set_reward_shaper(mgx_handle *h, int32_t shaper)
     if (shaper < MGX_SHAPER_NONE || shaper > MGX_SHAPER_BATTERY_DISCHARGE)
         return fail(MGX_ERR_INVALID, "mgx_set_reward_shaper: unknown shaper %d", shaper);
     h->k.shaper = shaper;
+    return MGX_OK;
+}
+
+int mgx_set_forecast_noise(mgx_handle *h, uint64_t seed, int increase_uncertainty)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_forecast_noise: NULL handle");
+    h->k.noise_seed = seed;
+    h->k.noise_increase = increase_uncertainty ? 1 : 0;
     return MGX_OK;
 }
 

@@ -41,6 +41,8 @@ class StepEngine:
             L, cols = batch.c_layout(), batch.c_columns()
             check(self._lib.mgx_create(C.byref(L), C.byref(cols), C.byref(self._h)))
         self.window = (self.layout.initial_step, self.layout.final_step)
+        if batch.forecast_noise is not None:
+            self.set_forecast_noise(**batch.forecast_noise)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.N = self.layout.n_grids
         self.action_dim = self._lib.mgx_action_dim(self._h)
@@ -96,6 +98,10 @@ class StepEngine:
         """Episode window of the next reset (what a trajectory_func returns, microgrid.py:221-225)."""
         check(self._lib.mgx_set_window(self._h, int(initial_step), int(final_step)))
         self.window = (int(initial_step), int(final_step))
+
+    def set_forecast_noise(self, seed=0, increase_uncertainty=False):
+        """GaussianNoiseForecaster switches (needs the *_noise_std columns in the batch)."""
+        check(self._lib.mgx_set_forecast_noise(self._h, int(seed) & (2 ** 64 - 1), int(bool(increase_uncertainty))))
 
     def set_reward_shaper(self, kind):
         check(self._lib.mgx_set_reward_shaper(self._h, int(kind)))

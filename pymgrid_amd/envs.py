@@ -48,6 +48,7 @@ class BatchedMicrogridEnv:
         self._keep_log = bool(log)
         self._observations = bool(observations)
         self._log_rows = []
+        self._shaped_rows = []
         A = self.layout.action_dim
         self.action_space = Box(0.0, 1.0, shape=(A,))                       # normalised control
         self.observation_space = Box(0.0, 1.0, shape=(self.layout.obs_dim,))  # normalised observation
@@ -88,6 +89,7 @@ class BatchedMicrogridEnv:
     def reset(self, initial_step=None):
         """Microgrid.reset: step counter back to ``initial_step``, logs flushed, state NOT restored."""
         self._log_rows = []
+        self._shaped_rows = []
         if self.trajectory_func is not None and initial_step is None:
             self._draw_window()
         return self.engine.reset(initial_step, want_obs=self._observations)
@@ -102,6 +104,7 @@ class BatchedMicrogridEnv:
         info = {}
         if log is not None:
             self._log_rows.append(log)
+            self._shaped_rows.append(reward.clone())
             info["log"] = log
         return obs, reward, done.bool(), info
 
@@ -146,6 +149,46 @@ class BatchedMicrogridEnv:
             for j, name in enumerate(("current_status", "goal_status", "steps_until_up", "steps_until_down")):
                 out["genset_" + name] = st[..., j]
         return {k: (v.cpu().numpy() if as_numpy and torch.is_tensor(v) else v) for k, v in out.items()}
+
+    def get_log_frame(self, grid=0):
+        """``Microgrid.get_log(as_frame=True)`` for one grid of the batch: a DataFrame with the reference's 3-level
+        columns (module_name, module_number, field) (microgrid.py:434-475).  Columns that are verbatim copies of the
+        input series (``*_current``, ``*_forecast_j``) are not materialised."""
+        import pandas as pd
+        log = self.get_log()
+        if not log:
+            return pd.DataFrame()
+        col = {k: np.asarray(v)[:, grid] for k, v in log.items()}
+        shaped = torch.stack(self._shaped_rows)[:, grid].cpu().numpy()
+        zeros = np.zeros(len(shaped))
+        data = {("load", 0, "reward"): zeros, ("load", 0, "load_met"): col["load_met"],
+                ("pv", 0, "reward"): zeros, ("pv", 0, "curtailment"): col["curtailment"],
+                ("pv", 0, "renewable_used"): col["renewable_used"],
+                ("unbalanced_energy", 0, "reward"): col["unbalanced_reward"],
+                ("unbalanced_energy", 0, "loss_load"): col["loss_load"],
+                ("unbalanced_energy", 0, "overgeneration"): col["overgeneration"]}
+        if self.layout.has_genset:
+            data.update({("genset", 0, "reward"): col["genset_reward"],
+                         ("genset", 0, "co2_production"): col["genset_co2_production"],
+                         ("genset", 0, "genset_production"): col["genset_production"]})
+            for name in ("current_status", "goal_status", "steps_until_up", "steps_until_down"):
+                data[("genset", 0, name)] = col["genset_" + name]
+        if self.layout.has_battery:
+            data.update({("battery", 0, "reward"): col["battery_reward"],
+                         ("battery", 0, "discharge_amount"): col["discharge_amount"],
+                         ("battery", 0, "charge_amount"): col["charge_amount"],
+                         ("battery", 0, "soc"): col["soc_pre"], ("battery", 0, "current_charge"): col["charge_pre"]})
+        if self.layout.has_grid:
+            data.update({("grid", 0, "reward"): col["grid_reward"],
+                         ("grid", 0, "co2_production"): col["grid_co2_production"],
+                         ("grid", 0, "grid_import"): col["grid_import"], ("grid", 0, "grid_export"): col["grid_export"]})
+        data.update({("balance", 0, "reward"): col["reward"], ("balance", 0, "shaped_reward"): shaped})
+        for a in ("overall", "controllable", "fixed"):
+            data[("balance", 0, f"{a}_provided_to_microgrid")] = col[f"{a}_provided"]
+            data[("balance", 0, f"{a}_absorbed_from_microgrid")] = col[f"{a}_absorbed"]
+        df = pd.DataFrame(data)
+        df.columns = pd.MultiIndex.from_tuples(df.columns, names=["module_name", "module_number", "field"])
+        return df
 
     def state_dict(self):
         """Microgrid.state_dict-like view of the dynamic state (microgrid.py:699-729)."""

@@ -107,8 +107,13 @@ def load_scenario_yaml(path):
             raise NotImplementedError("raise_errors=True is not offered (requests are always clipped)")
         if tag in ("!LoadModule", "!RenewableModule", "!GridModule"):
             fc = cp.get("forecaster")
-            if fc not in (None, "oracle"):
-                raise NotImplementedError(f"forecaster {fc!r}: only None and 'oracle' are supported")
+            if isinstance(fc, (int, float)) and not isinstance(fc, bool):         # GaussianNoiseForecaster
+                noise = dict(std=float(fc), relative_noise=bool(cp.get("forecaster_relative_noise", False)),
+                             increase_uncertainty=bool(cp.get("forecaster_increase_uncertainty", False)))
+                if p.setdefault("forecast_noise", noise) != noise:
+                    raise NotImplementedError("different noisy forecasters per module are not supported")
+            elif fc not in (None, "oracle"):
+                raise NotImplementedError(f"forecaster {fc!r}: only None, 'oracle' and a noise std are supported")
             horizon = int(cp.get("forecast_horizon", 0)) if fc is not None else 0   # base_timeseries_module.py:40
             ts = np.asarray(cp["time_series"], dtype=np.float64)
             final = int(cp.get("final_step", -1))

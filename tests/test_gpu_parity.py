@@ -313,6 +313,10 @@ def test_gym_adaptors_shapes(pymgrid25, device):
             assert obs.shape == (env.layout.obs_dim,) and isinstance(reward, float) and isinstance(done, bool)
             assert info["reward"] == reward
         assert len(env.get_log()["reward"]) == 10
+        df = env.get_log_frame()                          # Microgrid.get_log(as_frame=True) shape
+        assert len(df) == 10 and df.columns.nlevels == 3
+        assert np.array_equal(df[("balance", 0, "reward")].values, env.get_log()["reward"][:, 0])
+        assert ("battery", 0, "soc") in df.columns and ("unbalanced_energy", 0, "loss_load") in df.columns
         env.reset(); assert env.current_step == 0 and env.get_log() == {}
         with pytest.raises(ValueError):
             env.step(env.action_space.n)

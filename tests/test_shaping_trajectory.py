@@ -70,3 +70,64 @@ def test_trajectory_windows_vs_reference(pymgrid25, device):
         env.close()
     with pytest.raises(ValueError):
         MicrogridEnv(p, device=device, trajectory_func=DeterministicTrajectory(50, 9000))
+
+
+def test_forecast_noise_columns_follow_the_reference_rule(pymgrid25):
+    """_get_noise_std (forecaster.py:236-249): std, or std * |mean(series[initial:final])| with relative_noise."""
+    from pymgrid_amd import pack_grids
+    p = dict(pymgrid25[1], forecast_noise=dict(std=0.1, relative_noise=True, increase_uncertainty=True, seed=5))
+    A, L = pack_grids([p])
+    assert A["load_noise_std"][0] == 0.1 * abs(p["load_ts"][:8759].mean())
+    assert A["grid_noise_std"][0] == 0.1 * abs(p["grid_ts"][:8759].mean())
+    assert A["__forecast_noise__"] == dict(seed=5, increase_uncertainty=True)
+    q = dict(pymgrid25[1], forecast_noise=dict(std=0.3))
+    assert pack_grids([q])[0]["pv_noise_std"][0] == 0.3
+
+
+@pytest.mark.gpu
+def test_gaussian_noise_forecaster_statistics(device):
+    """GaussianNoiseForecaster on device: current values untouched, forecast_j = truth + N(0, std_j) (then clipped to
+    the observation bounds), std_j = std * (1 + log(1 + j)) with increase_uncertainty; reproducible per seed, fresh
+    noise every step.  Statistical parity (the reference draws from numpy's global stream)."""
+    from pymgrid_amd import MicrogridBatch, StepEngine
+    from pymgrid_amd.generator import generate
+    N, H = 16384, 24
+    base = generate(N, n_steps=80, seed=2, arch="genset+battery+grid", horizon=H, device=device)
+    cols = dict(base.cols)
+    rel = 0.02
+    cols["load_noise_std"] = rel * base.cols["load_ts"].mean(0).abs()
+    cols["pv_noise_std"] = rel * base.cols["pv_ts"].mean(0).abs()
+    cols["grid_noise_std"] = torch.full((N,), 0.01, dtype=torch.float64, device=device)
+    oracle_eng = StepEngine(MicrogridBatch(base.layout, dict(base.cols)))
+    noisy = StepEngine(MicrogridBatch(base.layout, cols, forecast_noise=dict(seed=9, increase_uncertainty=True)))
+    oracle_eng.reset(initial_step=10, want_obs=False); noisy.reset(initial_step=10, want_obs=False)
+    o0, o1 = oracle_eng.observe(), noisy.observe()
+    assert torch.equal(noisy.observe(), o1)                        # same seed, same step -> same noise
+    W = H + 1
+    sl = base.layout.obs_slices()
+    spread = (base.cols["load_hi"] - base.cols["load_lo"])
+    d = ((o1 - o0)[:, sl["load"]] * spread[:, None])               # back to energy units, [N, W]
+    assert torch.equal(d[:, 0], torch.zeros(N, dtype=torch.float64, device=device))       # current value: no noise
+    z = d[:, 1:] / cols["load_noise_std"][:, None]
+    inside = (o0[:, sl["load"]][:, 1:] > 0.1) & (o0[:, sl["load"]][:, 1:] < 0.9)      # away from the clip bounds
+    for j in (0, 3, 23):
+        zz = z[:, j][inside[:, j]]
+        expect = 1.0 + np.log(1.0 + j)
+        assert abs(zz.mean().item()) < 5 * expect / np.sqrt(zz.numel())
+        assert abs(zz.std().item() / expect - 1.0) < 0.03, (j, zz.std().item(), expect)
+    # grid window: component-minor columns, absolute std 0.01 on every component
+    g = (o1 - o0)[:, sl["grid"]].reshape(N, W, 4)
+    assert torch.equal(g[:, 0], torch.zeros(N, 4, dtype=torch.float64, device=device))
+    price_spread = (base.cols["grid_hi"][0] - base.cols["grid_lo"][0])
+    gz = g[:, 1, 0] * price_spread / 0.01
+    ok = (o0[:, sl["grid"]].reshape(N, W, 4)[:, 1, 0] > 0.2) & (o0[:, sl["grid"]].reshape(N, W, 4)[:, 1, 0] < 0.8)
+    if ok.sum() > 1000:
+        assert abs(gz[ok].std().item() - 1.0) < 0.05
+    for name in ("load", "pv", "grid"):                            # forecasts are clipped to the observation space
+        assert (o1[:, sl[name]] >= 0).all() and (o1[:, sl[name]] <= 1).all()
+    # a step later the noise is redrawn
+    a = torch.rand(N, 4, dtype=torch.float64, device=device)
+    n1 = noisy.step(a)[0]; o_next = oracle_eng.step(a)[0]
+    d2 = (n1 - o_next)[:, sl["load"]][:, 1] * spread
+    assert not torch.equal(d2, d[:, 1]) and abs((d2 / cols["load_noise_std"]).std().item() - 1.0) < 0.05
+    oracle_eng.close(); noisy.close()
