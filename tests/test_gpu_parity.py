@@ -353,3 +353,24 @@ def test_error_paths(pymgrid25, device):
     assert e.value.code == 2
     with pytest.raises(MgxError):
         StepEngine(_batch([p], "cpu"))                                           # no CPU path
+
+
+def test_bucketed_fleet_of_mixed_layouts(pymgrid25, device):
+    """BASELINE config 5 shape: the 25 scenarios (3 module sets) as ONE fleet; per-grid rewards / SoC of 200 steps
+    equal the per-scenario goldens, buckets stepped on separate streams."""
+    from pymgrid_amd.hetero import BucketedFleet
+    z = golden("pymgrid25_run.npz")
+    fleet = BucketedFleet(pymgrid25, device=device, observations=True)
+    assert len(fleet.envs) == 3 and len(fleet) == 25
+    obs = fleet.reset()
+    assert [o.shape[1] for o in obs] == [env.layout.obs_dim for env in fleet.envs]
+    K = 200
+    acts = {n: np.random.RandomState(int(z[f"s{n}_seed"])).rand(8759, action_dim(p))[:K] for n, p in enumerate(pymgrid25)}
+    for k in range(K):
+        a = [_t(np.stack([acts[n][k] for n in idx]), device) for _, idx in fleet.buckets]
+        obs, reward, done, _ = fleet.step(a)
+        r = fleet.scatter(reward).cpu().numpy()
+        soc = fleet.scatter([env.batch.cols["soc"] for env in fleet.envs]).cpu().numpy()
+        for n in range(25):
+            assert r[n] == z[f"s{n}_reward"][k] and soc[n] == z[f"s{n}_soc"][k], (n, k)
+    fleet.close()
