@@ -232,9 +232,10 @@ __device__ __forceinline__ double battery_max_consumption(const Params &p, doubl
 // steps whose SoC nobody reads and derives it once at the end (same value: it depends on the final charge only).
 // gen_instant (wave-uniform): every genset of the wave has start_up_time == wind_down_time == 0 and an equilibrium
 // status, so update_status collapses to "status follows the goal" (instant_up / instant_down, :289-311).
-template <int F>
+// HAVE_Q: the battery's one quotient by eta was already formed by populate_core on the same pre-step state (bat_q).
+template <int F, bool HAVE_Q = false>
 __device__ __forceinline__ void step_core(const Params &p, const Derived &d, State &s, const Inputs &in, bool normalized,
-                                          bool want_soc, bool gen_instant, Outputs &o)
+                                          bool want_soc, bool gen_instant, Outputs &o, double bat_q = 0.0)
 {
     double prov = 0.0, absb = 0.0, reward = 0.0;
 
@@ -272,7 +273,8 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         const double mp = battery_max_production(p, s.charge);                  // :283-286
         const double e_src = (x > mp) ? mp : ((x < 0.0) ? 0.0 : x);            // base_module.py:213-224, min_production 0
         const double num = sink ? num_sink : -1.0 * e_src;
-        const double q = num / p.bat_eta;
+        double q;
+        if constexpr (HAVE_Q) q = bat_q; else q = num / p.bat_eta;
         const double ex = -1.0 * x;
         const double e_sink = (ex > q) ? q : ex;                                // base_module.py:265-270
         // (e_sink < 0, i.e. charge above max_capacity, is an AssertionError in the reference, base_module.py:272,
@@ -344,53 +346,107 @@ __device__ __forceinline__ uint32_t pl_select(const PLWords &tab, int32_t id)
     return w;
 }
 
+// Branch-free form.  Lanes of a wave hold different lists, so the reference's per-element if/else ladder would
+// diverge on every slot; instead every slot evaluates the (cheap) genset / grid candidates and selects.  The battery
+// is the only module whose answer needs a division (max_consumption = min(C, cmax - c) / eta), and exactly ONE
+// division per step is ever needed per lane: when the battery is reached with remaining < 0 it is that one, when it
+// is reached with remaining > 0 the battery will act as a source and the step itself needs (-e) / eta
+// (default_transition_model).  Pass A finds `remaining` at the battery's slot, the division happens once, pass B
+// replays the list with the battery's energy known.  bat_q returns that quotient for step_core<F, true>.
+__device__ __forceinline__ bool pl_isclose0(double rem)
+{
+    return fabs(rem - 0.0) <= 1e-4 + 1e-5 * fabs(0.0);            // np.isclose(remaining_load, 0.0, atol=1e-4) :90
+}
+
+// _produce_from_module :138-155 / _consume_in_module :118-136 for a module without a division
+__device__ __forceinline__ double pl_energy(double rem, double mn, double mx, double mc, bool is_sink)
+{
+    const double produce = (mn <= rem && rem <= mx) ? rem : ((rem < mn) ? mn : mx);
+    const double consume = is_sink ? ((-1 * rem > mc) ? -1.0 * mc : rem) : 0.0;
+    return pl_isclose0(rem) ? 0.0 : ((rem > 0) ? produce : consume);
+}
+
 template <int F>
-__device__ __forceinline__ void populate_core(const Params &p, const State &s, uint32_t word, Inputs &in)
+__device__ __forceinline__ void populate_core(const Params &p, const State &s, uint32_t word, Inputs &in, double &bat_q)
 {
     const double total_load = 0.0 + -1 * in.load;                  // _get_load :157-164
     const double renewable = in.pv;                                // _get_renewable :166-167
-    double remaining = total_load - renewable;                     // :74
-    double c_goal = 0.0, c_gen = 0.0, c_bat = 0.0, c_grid = 0.0;
-    bool set_gen = false, set_bat = false, set_grid = false;
+    const double rem0 = total_load - renewable;                    // :74
+    // per-module limits at the pre-step state
+    double g_mx[2] = {0.0, 0.0}, g_mn[2] = {0.0, 0.0};             // next_max/min_production(goal) genset_module.py:392-424
+    if constexpr (F & F_GENSET) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const uint32_t el = (word >> (4 * k)) & 0xfu;
-        if (!(el & 8u)) continue;
-        const int mod = el & 3u, act = (el >> 2) & 1u;
-        if (mod == 0) { if (set_gen) continue; set_gen = true; c_goal = (double)act; }     // :82-88
-        else if (mod == 1) { if (set_bat) continue; set_bat = true; }
-        else { if (set_grid) continue; set_grid = true; }
-        double energy;
-        if (fabs(remaining - 0.0) <= 1e-4 + 1e-5 * fabs(0.0)) {   // np.isclose(remaining, 0, atol=1e-4) :90
-            energy = 0.0;
-        } else if (remaining > 0) {                               // _produce_from_module :138-155
-            double mx = 0.0, mn = 0.0;
-            if (mod == 0) {
-                if constexpr (F & F_GENSET) {
-                    const double ns = (double)genset_next_status(s.status, act);   // genset_module.py:392-424
-                    mx = ns * p.gen_rmax; mn = ns * p.gen_rmin;
-                }
-            } else if (mod == 1) {
-                if constexpr (F & F_BATTERY) mx = battery_max_production(p, s.charge);
-            } else {
-                if constexpr (F & F_GRID) mx = p.grid_imp * in.g_stat;
-            }
-            if (mn <= remaining && remaining <= mx) energy = remaining;
-            else if (remaining < mn) energy = mn;
-            else energy = mx;
-        } else {                                                  // _consume_in_module :118-136
-            if (mod == 0) energy = 0.0;
-            else {
-                double mc = 0.0;
-                if (mod == 1) { if constexpr (F & F_BATTERY) mc = battery_max_consumption(p, s.charge); }
-                else          { if constexpr (F & F_GRID) mc = p.grid_exp * in.g_stat; }
-                energy = (-1 * remaining > mc) ? -1.0 * mc : remaining;
-            }
+        for (int act = 0; act < 2; act++) {
+            const double ns = (double)genset_next_status(s.status, act);
+            g_mx[act] = ns * p.gen_rmax; g_mn[act] = ns * p.gen_rmin;
         }
-        if (mod == 0) c_gen = energy; else if (mod == 1) c_bat = energy; else c_grid = energy;
-        remaining -= energy;                                      // :105
     }
-    in.a_goal = c_goal; in.a_gen = c_gen; in.a_bat = c_bat; in.a_grid = c_grid;
+    double r_mx = 0.0, r_mc = 0.0;
+    if constexpr (F & F_GRID) { r_mx = p.grid_imp * in.g_stat; r_mc = p.grid_exp * in.g_stat; }
+
+    // a list holds every controllable module of the layout at most once: NSLOT slots are enough
+    constexpr int NSLOT = ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    constexpr int NS = NSLOT > 0 ? NSLOT : 1;
+    uint32_t el[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) el[k] = (k < NSLOT) ? (word >> (4 * k)) & 0xfu : 0u;
+    // candidate energy of the division-free modules at `rem` (genset and / or grid, whichever the layout has)
+    auto cheap = [&](int mod, int act, double rem) -> double {
+        double e = 0.0;
+        if constexpr ((F & F_GENSET) && (F & F_GRID))
+            e = (mod == 0) ? pl_energy(rem, g_mn[act], g_mx[act], 0.0, false) : pl_energy(rem, 0.0, r_mx, r_mc, true);
+        else if constexpr (F & F_GENSET)
+            e = pl_energy(rem, g_mn[act], g_mx[act], 0.0, false);
+        else if constexpr (F & F_GRID)
+            e = pl_energy(rem, 0.0, r_mx, r_mc, true);
+        return e;
+    };
+
+    // pass A: remaining load when the battery's element is reached
+    double remB = rem0;
+    if constexpr (F & F_BATTERY) {
+        double rem = rem0;
+        bool seen = false;
+#pragma unroll
+        for (int k = 0; k < NSLOT - 1; k++) {              // the last slot cannot precede the battery
+            const bool valid = (el[k] & 8u) != 0;
+            const int mod = el[k] & 3u, act = (el[k] >> 2) & 1u;
+            const bool isB = valid && mod == 1;
+            seen = seen || isB;
+            rem -= (valid && !seen) ? cheap(mod, act, rem) : 0.0;
+            remB = seen ? remB : rem;                      // still before the battery: remaining after this slot
+        }
+    }
+    // the battery's energy, one division
+    double eB = 0.0;
+    bat_q = 0.0;
+    if constexpr (F & F_BATTERY) {
+        const bool close = pl_isclose0(remB);
+        const bool produce = !close && remB > 0;
+        const double mp = battery_max_production(p, s.charge);                  // battery_module.py:283-286
+        const double room = p.bat_cmax - s.charge;
+        const double num_sink = (room < p.bat_C) ? room : p.bat_C;              // numerator of max_consumption :288-291
+        const double e_src = (0.0 <= remB && remB <= mp) ? remB : ((remB < 0.0) ? 0.0 : mp);
+        const double num = (close || produce) ? -1.0 * (produce ? e_src : 0.0) : num_sink;
+        const double q = num / p.bat_eta;
+        const double e_snk = (-1 * remB > q) ? -1.0 * q : remB;
+        eB = close ? 0.0 : (produce ? e_src : e_snk);
+        bat_q = q;
+    }
+    // pass B: replay the list with the battery's energy known
+    double rem = rem0, c_goal = 0.0, c_gen = 0.0, c_grid = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+        const bool valid = (el[k] & 8u) != 0;
+        const int mod = el[k] & 3u, act = (el[k] >> 2) & 1u;
+        const double e = (mod == 1) ? eB : cheap(mod, act, rem);
+        const bool isG = valid && mod == 0, isR = valid && mod == 2;
+        c_goal = isG ? (double)act : c_goal;                                    // :82-88
+        c_gen = isG ? e : c_gen;
+        c_grid = isR ? e : c_grid;
+        rem -= valid ? e : 0.0;                                                 // :105
+    }
+    in.a_goal = c_goal; in.a_gen = c_gen; in.a_bat = eB; in.a_grid = c_grid;
 }
 
 // ---- reward shaping (microgrid/reward_shaping/*.py; MicrogridStep.shaped_reward, utils/step.py:41-46) ----------

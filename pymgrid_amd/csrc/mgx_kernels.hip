@@ -229,7 +229,8 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
     in.pv = a.c.pv_ts[(int64_t)t * N + i];
     in.g_stat = 1.0;
     if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
-    populate_core<F>(p, s, pl_select(tab, action_id[i]), in);
+    double q_unused;
+    populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused);
     double *c = control + i * A;
     int k = 0;
     if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
@@ -297,9 +298,10 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
                     load_series_at<F>(lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
                     if (per_step) idr[u] = ids[off + (int64_t)U * N];
                 }
-                populate_core<F>(p, s, word, in);
+                double bat_q;
+                populate_core<F>(p, s, word, in, bat_q);
                 Outputs o;
-                step_core<F>(p, d, s, in, false, want_soc, gen_instant, o);
+                step_core<F, true>(p, d, s, in, false, want_soc, gen_instant, o, bat_q);
                 const double r = shaped_reward<F>(a.shaper, o);
                 if (out.reward) out.reward[off] = r;
                 if (out.done) out.done[off] = (uint8_t)(k >= k_done);
@@ -682,6 +684,10 @@ static int encode_table(const mgx_handle *h, const int32_t *table, int32_t n_act
             if (mod == 0 && !h->layout.has_genset) return fail(MGX_ERR_INVALID, "%s: table names a genset, layout has none", who);
             if (mod == 1 && !h->layout.has_battery) return fail(MGX_ERR_INVALID, "%s: table names a battery, layout has none", who);
             if (mod == 2 && !h->layout.has_grid) return fail(MGX_ERR_INVALID, "%s: table names a grid, layout has none", who);
+            for (int k2 = 0; k2 < k; k2++)
+                if (table[(i * 3 + k2) * 2] == mod)
+                    return fail(MGX_ERR_INVALID, "%s: list %d names module %d twice (priority lists hold each module once, "
+                                                 "priority_list.py:40-48)", who, i, mod);
             tab->w[i] |= ((uint32_t)mod | ((uint32_t)act << 2) | 8u) << (4 * k);
         }
     return MGX_OK;
