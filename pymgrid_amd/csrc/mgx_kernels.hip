@@ -13,7 +13,10 @@
 
 namespace mgx {
 
-constexpr int BLOCK = 256;
+#ifndef MGX_BLOCK
+#define MGX_BLOCK 256
+#endif
+constexpr int BLOCK = MGX_BLOCK;
 #ifndef MGX_RING
 #define MGX_RING 4          // register-ring depth of the fused kernel (steps of loads in flight)
 #endif
