@@ -155,7 +155,9 @@ class OracleMicrogrid:
             self._keep.append(a)
             return a
 
-        load = arr(p["load_ts"]); pv = arr(p["pv_ts"])
+        # sign convention of the stored series: sinks <= 0, sources >= 0 (base_timeseries_module.py:68-79)
+        load = arr(-np.abs(np.asarray(p["load_ts"], dtype=np.float64)))
+        pv = arr(np.abs(np.asarray(p["pv_ts"], dtype=np.float64)))
         if load.ndim == 1: load = arr(load.reshape(-1, 1))
         if pv.ndim == 1: pv = arr(pv.reshape(-1, 1))
         g.T = load.shape[0] if load.size else pv.shape[0]
@@ -179,14 +181,25 @@ class OracleMicrogrid:
             for k in ("min_capacity", "max_capacity", "max_charge", "max_discharge", "efficiency"):
                 setattr(g, "bat_" + k, float(b[k]))
             g.bat_cost_cycle = float(b["battery_cost_cycle"])
-            st.charge, st.soc = float(b["charge"]), float(b["soc"])
+            if b.get("charge") is not None:        # BatteryModule._init_battery, battery_module.py:96-106
+                st.charge = float(b["charge"])
+                st.soc = float(b["soc"]) if b.get("soc") is not None else st.charge / g.bat_max_capacity
+            elif b.get("init_charge") is not None:
+                st.charge = float(b["init_charge"]); st.soc = st.charge / g.bat_max_capacity
+            else:
+                st.soc = float(b["init_soc"]); st.charge = st.soc * g.bat_max_capacity
         if p.get("genset") is not None:
             q = p["genset"]; g.has_genset = 1
             g.gen_running_min, g.gen_running_max = float(q["running_min_production"]), float(q["running_max_production"])
             g.gen_cost, g.gen_co2_per_unit = float(q["genset_cost"]), float(q["co2_per_unit"])
             g.gen_cost_per_unit_co2 = float(q["cost_per_unit_co2"])
             g.gen_start_up_time, g.gen_wind_down_time = int(q["start_up_time"]), int(q["wind_down_time"])
-            st.gen_cur, st.gen_goal, st.gen_up, st.gen_down = [int(v) for v in q["status"]]
+            if q.get("status") is not None:
+                status = [int(v) for v in q["status"]]
+            else:                                    # genset_module.py:91-92,216-227
+                on = int(bool(q.get("init_start_up", True)))
+                status = [on, on, 0, g.gen_wind_down_time] if on else [0, 0, g.gen_start_up_time, 0]
+            st.gen_cur, st.gen_goal, st.gen_up, st.gen_down = status
         if p.get("grid") is not None:
             q = p["grid"]; g.has_grid = 1
             g.grid_max_import, g.grid_max_export = float(q["max_import"]), float(q["max_export"])
