@@ -53,6 +53,7 @@ class BatchLayout:
             names += ["discharge_amount", "charge_amount", "battery_reward", "soc_pre", "charge_pre"]
         if self.has_grid:
             names += ["grid_import", "grid_export", "grid_co2_production", "grid_reward"]
+        names += ["violations"]      # bit mask of requests the reference refuses with raise_errors=True
         return names
 
     @property

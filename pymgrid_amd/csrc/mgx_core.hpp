@@ -78,6 +78,11 @@ struct Outputs {
     double genset_production, genset_co2, genset_reward;
     double discharge_amount, charge_amount, battery_reward, soc_pre, charge_pre;
     double grid_import, grid_export, grid_co2, grid_reward;
+    // requests the reference would have refused with raise_errors=True (base_module.py:79-93,213-224,265-270) or
+    // always refuses: bit 0 genset request outside [min, max] production, bit 1 battery request above its limit,
+    // bit 2 grid request above its limit, bit 3 genset goal outside [0, 1] (AssertionError, genset_module.py:147),
+    // bit 4 negative genset energy (a pure source asked to absorb)
+    uint32_t violations;
 };
 
 // ---- ModuleSpace (utils/space.py:204-205,213,224) -------------------------------------------------------
@@ -238,6 +243,7 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
                                           bool want_soc, bool gen_instant, Outputs &o, double bat_q = 0.0)
 {
     double prov = 0.0, absb = 0.0, reward = 0.0;
+    uint32_t viol = 0u;
 
     // fixed: LoadModule.update (load_module.py:86-111)
     const double L = -1 * in.load;
@@ -256,6 +262,7 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         const double cur = (double)(s.status & 0xff);
         const double mx = cur * p.gen_rmax, mn = cur * p.gen_rmin;              // max/min_production :465-501
         const double e = (x > mx) ? mx : ((x < mn) ? mn : x);                   // as_source clip base_module.py:213-224
+        viol |= ((x > mx) || (x < mn) ? 1u : 0u) | (!(in.a_goal >= 0.0 && in.a_goal <= 1.0) ? 8u : 0u) | (x < 0.0 ? 16u : 0u);
         const double co2 = p.gen_co2 * e;                                       // get_co2
         const double cost = p.gen_cost * e + p.gen_cco2 * co2;                  // get_cost :188-205
         o.genset_production = e; o.genset_co2 = co2; o.genset_reward = -1.0 * cost;
@@ -280,6 +287,7 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         // (e_sink < 0, i.e. charge above max_capacity, is an AssertionError in the reference, base_module.py:272,
         //  and unspecified here; every valid run has e >= 0 and internal = e * eta.)
         const double e = sink ? e_sink : e_src;
+        viol |= (sink ? (ex > q) : (x > mp)) ? 2u : 0u;
         const double internal = sink ? e * p.bat_eta : ((num < 0) ? q : num * p.bat_eta);
         o.charge_amount = sink ? e : 0.0;
         o.discharge_amount = sink ? 0.0 : e;
@@ -298,6 +306,7 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         const double e_exp = (ex > mc) ? mc : ex;
         const double mp = p.grid_imp * in.g_stat;                              // max_production :314-316
         const double e_imp = (x > mp) ? mp : ((x < 0.0) ? 0.0 : x);
+        viol |= (sink ? (ex > mc) : (x > mp)) ? 4u : 0u;
         const double co2 = sink ? 0.0 : e_imp * in.g_co2;                      // get_co2_production :199-228
         const double cco2 = -1.0 * p.grid_cco2 * co2;                          // get_co2_cost :176-197
         o.grid_export = sink ? e_exp : 0.0;
@@ -327,6 +336,7 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
     reward += o.unbalanced_reward;
     o.overall_provided = prov; o.overall_absorbed = absb;
     o.reward = reward;
+    o.violations = viol;
 }
 
 // ---- discrete action expansion -------------------------------------------------------------------------
@@ -491,6 +501,7 @@ __device__ __forceinline__ void store_log(double *__restrict__ log, int64_t N, c
         log[(k++) * N] = o.grid_import;       log[(k++) * N] = o.grid_export;
         log[(k++) * N] = o.grid_co2;          log[(k++) * N] = o.grid_reward;
     }
+    log[(k++) * N] = (double)o.violations;
 }
 
 // ---- observation (post-step state, series index t = current step) --------------------------------------

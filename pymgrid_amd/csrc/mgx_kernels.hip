@@ -534,7 +534,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->action_dim = 2 * L->has_genset + L->has_battery + L->has_grid;
     const int w = 1 + L->horizon;
     h->k.obs_dim = 2 * w + 4 * L->has_genset + 2 * L->has_battery + 4 * w * L->has_grid;
-    h->k.log_dim = LC_COMMON_END + LC_GENSET_N * L->has_genset + LC_BATTERY_N * L->has_battery + LC_GRID_N * L->has_grid;
+    h->k.log_dim = LC_COMMON_END + LC_GENSET_N * L->has_genset + LC_BATTERY_N * L->has_battery + LC_GRID_N * L->has_grid + 1;
     h->t = L->initial_step;
     h->k.shaper = MGX_SHAPER_NONE;
     h->k.noise_seed = 0; h->k.noise_increase = 0;
@@ -566,8 +566,8 @@ const char *mgx_log_name(const mgx_handle *h, int32_t col)
     col -= LC_COMMON_END;
     if (h->layout.has_genset) { if (col < LC_GENSET_N) return kGensetNames[col]; col -= LC_GENSET_N; }
     if (h->layout.has_battery) { if (col < LC_BATTERY_N) return kBatteryNames[col]; col -= LC_BATTERY_N; }
-    if (h->layout.has_grid) { if (col < LC_GRID_N) return kGridNames[col]; }
-    return nullptr;
+    if (h->layout.has_grid) { if (col < LC_GRID_N) return kGridNames[col]; col -= LC_GRID_N; }
+    return col == 0 ? "violations" : nullptr;
 }
 
 static int need_obs_bounds(const mgx_handle *h, const char *who)

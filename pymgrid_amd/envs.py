@@ -11,8 +11,9 @@ Batched classes take and return torch tensors with a leading grid dimension N.  
 reference's own tests.
 
 Differences that are deliberate:
-  * ``raise_errors=True`` (ValueError instead of clipping, base_module.py:79-93) is not offered on device;
-    requests are always clipped, as with the reference default ``raise_errors=False``.
+  * the device always clips requests (the reference default ``raise_errors=False``); ``raise_errors=True``
+    (ValueError instead of clipping, base_module.py:79-93) is emulated from the step's ``violations`` mask AFTER the
+    (clipped) step has been applied.
   * the flat observation order is fixed: load, pv, genset, battery, grid (the reference leaves it to gym's
     ``Dict`` ordering); ``info`` holds batched log columns instead of per-module dict lists.
 """
@@ -31,9 +32,14 @@ class BatchedMicrogridEnv:
     ``Microgrid.run(control, normalized)``; the reference's own ContinuousMicrogridEnv is non-functional in
     v1.2.2)."""
 
-    def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None):
+    def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
+                 raise_errors=False):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
+        # raise_errors=True (base_module.py:79-93): the device always clips; the step's `violations` log column
+        # is inspected afterwards (one device->host sync per step) and a ValueError is raised like the reference's.
+        self.raise_errors = bool(raise_errors)
+        log = log or self.raise_errors
         self.batch = batch
         self.layout = batch.layout
         self.engine = StepEngine(batch)
@@ -106,7 +112,22 @@ class BatchedMicrogridEnv:
             self._log_rows.append(log)
             self._shaped_rows.append(reward.clone())
             info["log"] = log
+            if self.raise_errors:
+                self._raise_on_violations(log[-1])
         return obs, reward, done.bool(), info
+
+    _VIOLATIONS = ((1, "Genset", "supply requested value as a source (outside [min_production, max_production])"),
+                   (2, "BatteryModule", "supply / absorb requested value (above max_production / max_consumption)"),
+                   (4, "GridModule", "supply / absorb requested value (above max import / export)"),
+                   (8, "Genset", "goal_status outside [0, 1]"), (16, "Genset", "negative energy request"))
+
+    def _raise_on_violations(self, mask_col):
+        mask = mask_col.to(torch.int64)
+        if bool((mask != 0).any()):
+            bad = int((mask != 0).nonzero()[0])
+            m = int(mask[bad])
+            what = "; ".join(f"Module {mod} unable to {msg}" for bit, mod, msg in self._VIOLATIONS if m & bit)
+            raise ValueError(f"{what} [microgrid {bad}; the step has been applied with the request clipped]")
 
     run = step      # Microgrid.run has the same signature and return value (microgrid.py:227-325)
 
@@ -209,9 +230,9 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
     into an unnormalised control and stepped with ``normalized=False`` (discrete.py:109-143)."""
 
     def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
-                 trajectory_func=None):
+                 trajectory_func=None, raise_errors=False):
         super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
-                         trajectory_func=trajectory_func)
+                         trajectory_func=trajectory_func, raise_errors=raise_errors)
         L = self.layout
         redundant = False
         if remove_redundant_gensets and L.has_genset:
@@ -268,9 +289,10 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
     ``(obs, float, bool, dict)`` exactly like envs/base/base.py:169-209."""
 
     def __init__(self, params, device="cuda", flat_spaces=True, log=True, reward_shaping_func=None,
-                 trajectory_func=None):
+                 trajectory_func=None, raise_errors=False):
         super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
-                         reward_shaping_func=reward_shaping_func, trajectory_func=trajectory_func)
+                         reward_shaping_func=reward_shaping_func, trajectory_func=trajectory_func,
+                         raise_errors=raise_errors)
         self.flat_spaces = flat_spaces
 
     def reset(self, initial_step=None):
@@ -288,10 +310,10 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
     ``step(action: int) -> (obs, reward: float, done: bool, info: dict)``."""
 
     def __init__(self, params, device="cuda", flat_spaces=True, log=True, remove_redundant_gensets=True,
-                 reward_shaping_func=None, trajectory_func=None):
+                 reward_shaping_func=None, trajectory_func=None, raise_errors=False):
         super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
                          remove_redundant_gensets=remove_redundant_gensets, reward_shaping_func=reward_shaping_func,
-                         trajectory_func=trajectory_func)
+                         trajectory_func=trajectory_func, raise_errors=raise_errors)
         self.flat_spaces = flat_spaces
 
     def reset(self, initial_step=None):

@@ -67,7 +67,7 @@ def test_pack_grids_and_layout(pymgrid25):
     tmpl4 = [pymgrid25[n] for n in (2, 3, 5, 7, 15, 17, 19, 20, 21, 23)]
     A, L = pack_grids(tmpl4)
     assert (L.n_grids, L.n_steps, L.horizon, L.final_step) == (10, 8760, 23, 8759)
-    assert L.action_dim == 3 and L.obs_dim == 24 + 24 + 4 + 2 and len(L.log_names) == 22
+    assert L.action_dim == 3 and L.obs_dim == 24 + 24 + 4 + 2 and len(L.log_names) == 23
     assert A["load_ts"].shape == (8760, 10) and (A["load_ts"] <= 0).all() and (A["pv_ts"] >= 0).all()
     assert np.array_equal(A["load_lo"], A["load_ts"].min(0)) and (A["load_hi"] == 0).all()
     assert np.array_equal(unpack_status(A["gen_status"]), np.tile([1, 1, 0, 0], (10, 1)))
@@ -76,7 +76,7 @@ def test_pack_grids_and_layout(pymgrid25):
     from pymgrid_amd import BatchLayout
     t4 = BatchLayout(n_grids=1, n_steps=10, has_genset=True, has_battery=True, has_grid=False)
     assert t4.bytes_per_step() == 189
-    assert t4.bytes_per_step(log=True, obs=True) == 189 + 8 * 22 + 8 + 8 * 8 + 16
+    assert t4.bytes_per_step(log=True, obs=True) == 189 + 8 * 23 + 8 + 8 * 8 + 16
     assert t4.bytes_fused(64) == 140 + 64 * 57                        # params 108 + state 12 r / 20 w; 57 B streamed per step
     full = BatchLayout(n_grids=1, n_steps=10, horizon=24, has_genset=True, has_battery=True, has_grid=True)
     assert full.action_dim == 4 and full.obs_dim == 156                  # D = 156 with grid, H = 24

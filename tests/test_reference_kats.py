@@ -96,6 +96,26 @@ def test_step_production_request_out_of_range_is_clipped(backend):   # :138-163
         assert o["genset_production"] == possible
 
 
+@pytest.mark.gpu
+def test_raise_errors_true_raises_value_error(device):               # :110-122 (raise_errors=True -> ValueError)
+    """Genset turned off (wind_down_time 0) and asked for 50: the reference raises ValueError with raise_errors=True;
+    an out-of-range goal_status is an AssertionError there (:146-147) -- both surface as ValueError here."""
+    from pymgrid_amd import MicrogridEnv
+    env = MicrogridEnv(genset_grid(), device=device, raise_errors=True)
+    env.reset()
+    env.step({"genset": [np.array([1.0, 0.5])]})                     # in range: fine
+    with pytest.raises(ValueError, match="Genset"):
+        env.step({"genset": [np.array([0.0, 0.5])]})
+    with pytest.raises(ValueError, match="goal_status"):
+        env.step({"genset": [np.array([-0.5, 0.0])]})
+    env.close()
+    quiet = MicrogridEnv(genset_grid(), device=device)               # raise_errors=False: silently clipped
+    quiet.reset()
+    _, _, _, info = quiet.step({"genset": [np.array([0.0, 0.5])]})
+    assert info["violations"] == 1.0 and info["genset_production"] == 0
+    quiet.close()
+
+
 # ---- test_genset_long_status_changes.py: start_up_time 2, wind_down_time 3, on at start ------------------------
 def long_genset(backend):
     return backend(genset_grid(start_up_time=2, wind_down_time=3))
