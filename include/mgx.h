@@ -21,7 +21,8 @@
  * Column layouts (struct-of-arrays, grid index fastest):
  *    parameter / state columns   [N]
  *    load_ts, pv_ts              [T, N]     sign as the reference STORES it: load <= 0, pv >= 0
- *                                           (base_timeseries_module.py:68-79)
+ *                                           (base_timeseries_module.py:68-79); with several load / renewable
+ *                                           modules per grid: [T, n_load, N] / [T, n_pv, N], bounds [n, N]
  *    grid_ts                     [T, 4, N]  components import_price, export_price, co2_per_kwh, grid_status
  *                                           (grid_module.py:70)
  *    actions                     [N, A]     A = 2*has_genset + has_battery + has_grid, order
@@ -73,8 +74,8 @@ typedef struct mgx_layout {
     int32_t has_genset;       /* 0/1 GensetModule  */
     int32_t has_battery;      /* 0/1 BatteryModule */
     int32_t has_grid;         /* 0/1 GridModule    */
-    int32_t n_load;           /* LoadModule count      (device path: 1) */
-    int32_t n_pv;             /* RenewableModule count (device path: 1) */
+    int32_t n_load;           /* LoadModule count      (1 on the fast path; 0..16 via the general kernels) */
+    int32_t n_pv;             /* RenewableModule count (1 on the fast path; 0..16 via the general kernels) */
 } mgx_layout;
 
 /* Device columns.  Pointers for absent modules may be NULL. */

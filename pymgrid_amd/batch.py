@@ -142,7 +142,8 @@ class MicrogridBatch:
     # ------------------------------------------------------------------------------------------------
     def _validate(self):
         L, N, T = self.layout, self.layout.n_grids, self.layout.n_steps
-        need = ["load_ts", "pv_ts", "loss_load_cost", "overgeneration_cost"]
+        need = ["loss_load_cost", "overgeneration_cost"] + (["load_ts"] if L.n_load else []) + \
+            (["pv_ts"] if L.n_pv else [])
         if L.has_battery:
             need += ["bat_min_capacity", "bat_max_capacity", "bat_max_charge", "bat_max_discharge", "bat_efficiency",
                      "bat_cost_cycle", "charge", "soc"]
@@ -152,6 +153,10 @@ class MicrogridBatch:
         if L.has_grid:
             need += ["grid_max_import", "grid_max_export", "grid_cost_per_unit_co2", "grid_ts"]
         shapes = {"load_ts": (T, N), "pv_ts": (T, N), "grid_ts": (T, 4, N), "grid_lo": (4, N), "grid_hi": (4, N)}
+        if L.n_load != 1:            # several (or no) load modules per grid: [T, n_load, N], bounds [n_load, N]
+            shapes.update(load_ts=(T, L.n_load, N), load_lo=(L.n_load, N), load_hi=(L.n_load, N))
+        if L.n_pv != 1:
+            shapes.update(pv_ts=(T, L.n_pv, N), pv_lo=(L.n_pv, N), pv_hi=(L.n_pv, N))
         for name in need:
             if name not in self.cols:
                 raise ValueError(f"column {name} is required by the layout")
@@ -242,31 +247,44 @@ def pack_grids(grids):
     has = {k: g0.get(k) is not None for k in ("genset", "battery", "grid")}
     T = np.asarray(g0["load_ts"]).shape[0]
     N = len(grids)
+
+    def n_modules(a):
+        a = np.asarray(a)
+        return 1 if a.ndim == 1 else a.shape[1]
+    n_load, n_pv = n_modules(g0["load_ts"]), n_modules(g0["pv_ts"])
     for g in grids:
         for k in has:
             if (g.get(k) is not None) != has[k]:
                 raise ValueError("all microgrids of a batch must have the same module set (bucket them by layout)")
-        for k in ("load_ts", "pv_ts"):
+        for k, n in (("load_ts", n_load), ("pv_ts", n_pv)):
             a = np.asarray(g[k])
-            if a.shape[0] != T or (a.ndim == 2 and a.shape[1] != 1):
-                raise ValueError(f"{k}: every microgrid needs one series of the batch length {T}")
+            if a.shape[0] != T or n_modules(a) != n:
+                raise ValueError(f"{k}: every microgrid of a batch needs {n} series of length {T}")
         for k in ("horizon", "final_step", "initial_step"):
             if g.get(k, g0.get(k)) != g0.get(k):
                 raise ValueError(f"all microgrids of a batch must share {k}")
     layout = BatchLayout(n_grids=N, n_steps=T, horizon=int(g0.get("horizon", 0)),
                          initial_step=int(g0.get("initial_step", 0)), final_step=int(g0.get("final_step", 0)),
-                         has_genset=has["genset"], has_battery=has["battery"], has_grid=has["grid"])
+                         has_genset=has["genset"], has_battery=has["battery"], has_grid=has["grid"],
+                         n_load=n_load, n_pv=n_pv)
 
     def col(fn):
         return np.array([fn(g) for g in grids], dtype=np.float64)
 
     A = {}
-    load = np.stack([np.asarray(g["load_ts"], dtype=np.float64).reshape(T) for g in grids], axis=1)
-    pv = np.stack([np.asarray(g["pv_ts"], dtype=np.float64).reshape(T) for g in grids], axis=1)
+    def stack(key, n):           # -> [T, N] for one module per grid, else [T, n, N]
+        a = np.stack([np.asarray(g[key], dtype=np.float64).reshape(T, n) for g in grids], axis=2)
+        return a[:, 0, :] if n == 1 else a
     # sign convention of the stored series (base_timeseries_module.py:68-79)
-    A["load_ts"], A["pv_ts"] = -np.abs(load), np.abs(pv)
-    A["load_lo"], A["load_hi"] = series_bounds(A["load_ts"])
-    A["pv_lo"], A["pv_hi"] = series_bounds(A["pv_ts"])
+    A["load_ts"], A["pv_ts"] = -np.abs(stack("load_ts", n_load)), np.abs(stack("pv_ts", n_pv))
+    if n_load:
+        A["load_lo"], A["load_hi"] = series_bounds(A["load_ts"])
+    else:
+        del A["load_ts"]
+    if n_pv:
+        A["pv_lo"], A["pv_hi"] = series_bounds(A["pv_ts"])
+    else:
+        del A["pv_ts"]
     A["loss_load_cost"] = col(lambda g: g["unbalanced"]["loss_load_cost"])
     A["overgeneration_cost"] = col(lambda g: g["unbalanced"]["overgeneration_cost"])
     if has["battery"]:

@@ -39,6 +39,7 @@ struct KArgs {
     mgx_columns c;
     int32_t N, T, H, final_step;
     int32_t obs_dim, log_dim;
+    int32_t n_load, n_pv;    // load / renewable modules per grid (1 on the fast path, <= MGX_MAX_MODULES otherwise)
     int32_t shaper;          // mgx_reward_shaper
     int32_t noise_increase;  // GaussianNoiseForecaster.increase_uncertainty
     uint64_t noise_seed;
@@ -377,10 +378,11 @@ __device__ __forceinline__ double pl_energy(double rem, double mn, double mx, do
 }
 
 template <int F>
-__device__ __forceinline__ void populate_core(const Params &p, const State &s, uint32_t word, Inputs &in, double &bat_q)
+__device__ __forceinline__ void populate_core(const Params &p, const State &s, uint32_t word, Inputs &in, double &bat_q,
+                                              double total_load, double renewable)
 {
-    const double total_load = 0.0 + -1 * in.load;                  // _get_load :157-164
-    const double renewable = in.pv;                                // _get_renewable :166-167
+    // total_load: sum of the fixed sinks' max_consumption (_get_load :157-164); renewable: np.sum of the flex
+    // sources' max_production (_get_renewable :166-167)
     const double rem0 = total_load - renewable;                    // :74
     // per-module limits at the pre-step state
     double g_mx[2] = {0.0, 0.0}, g_mn[2] = {0.0, 0.0};             // next_max/min_production(goal) genset_module.py:392-424
@@ -655,6 +657,101 @@ __device__ __forceinline__ void observe_window_item(const double *__restrict__ t
             for (int c = 0; c < NC; c++)
                 row[hh * NC + c] = obs_series_value(v[hh][c], in[hh], h0 + hh > 0, lo[c], hi[c], fill[c], sp[c]);
         }
+}
+
+// =========================================================================================================
+// General path: several load / renewable modules per microgrid (the reference's TestMicrogridLoadPV family,
+// tests/microgrid/test_microgrid.py:188-427).  Not the hot path: one lane per grid, the provided / absorbed lists of
+// MicrogridStep are materialised in private memory and summed exactly as numpy's float64 add.reduce does
+// (pairwise_sum: running sum below 8 addends, eight interleaved partial sums above).
+// =========================================================================================================
+constexpr int MGX_MAX_MODULES = 16;                       // per kind
+constexpr int MGX_MAX_ADDENDS = MGX_MAX_MODULES + 4;
+
+__device__ inline double np_sum_dev(const double *a, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    double r[8];
+    int i;
+    for (i = 0; i < 8; i++) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+// One Microgrid.run with n_load fixed sinks and n_pv flex sources (microgrid.py:227-325).  `in` carries the control
+// and the grid row; load[] / pv[] hold the modules' series values at the step (stored sign).
+template <int F>
+__device__ inline void step_multi_core(const Params &p, const Derived &d, State &s, const Inputs &in, bool normalized,
+                                       const double *load, int n_load, const double *pv, int n_pv, Outputs &o)
+{
+    double prov[MGX_MAX_ADDENDS], absb[MGX_MAX_ADDENDS];
+    int n_prov = 0, n_absb = 0;
+    double reward = 0.0;
+    o.load_met = 0.0;
+    for (int j = 0; j < n_load; j++) {                    // fixed modules, module order (microgrid.py:255-257)
+        const double L = -1 * load[j];
+        o.load_met += L;
+        absb[n_absb++] = L; reward += 0.0;
+    }
+    o.fixed_provided = np_sum_dev(prov, n_prov); o.fixed_absorbed = np_sum_dev(absb, n_absb);   // :259-260
+
+    // controllable modules: reuse the single-module arithmetic through a one-step core on zero load / pv and read
+    // back what each module did (same operations, same order: genset -> battery -> grid)
+    Inputs c = in; c.load = 0.0; c.pv = 0.0;
+    Outputs oc;
+    step_core<F>(p, d, s, c, normalized, true, false, oc);
+    o.violations = oc.violations;
+    if constexpr (F & F_GENSET) {
+        o.genset_production = oc.genset_production; o.genset_co2 = oc.genset_co2; o.genset_reward = oc.genset_reward;
+        prov[n_prov++] = oc.genset_production; reward += oc.genset_reward;
+    }
+    if constexpr (F & F_BATTERY) {
+        o.discharge_amount = oc.discharge_amount; o.charge_amount = oc.charge_amount; o.battery_reward = oc.battery_reward;
+        o.soc_pre = oc.soc_pre; o.charge_pre = oc.charge_pre;
+        // as_source iff the unnormalised request is >= 0 (base_module.py:161-171); a sink logs charge_amount
+        const double x = normalized ? d.bat_lo + d.bat_sp * in.a_bat : in.a_bat;
+        if (x < 0) absb[n_absb++] = oc.charge_amount; else prov[n_prov++] = oc.discharge_amount;
+        reward += oc.battery_reward;
+    }
+    if constexpr (F & F_GRID) {
+        o.grid_import = oc.grid_import; o.grid_export = oc.grid_export; o.grid_co2 = oc.grid_co2; o.grid_reward = oc.grid_reward;
+        const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;
+        if (x < 0) absb[n_absb++] = oc.grid_export; else prov[n_prov++] = oc.grid_import;
+        reward += oc.grid_reward;
+    }
+    const double provided = np_sum_dev(prov, n_prov), consumed = np_sum_dev(absb, n_absb);      // :277
+    const double difference = provided - consumed;
+    o.ctrl_provided = provided - o.fixed_provided; o.ctrl_absorbed = consumed - o.fixed_absorbed;
+
+    o.renewable_used = 0.0; o.curtailment = 0.0;
+    if (difference > 0) {                                 // :286-299: renewables idle, the excess is overgeneration
+        for (int j = 0; j < n_pv; j++) { o.curtailment += pv[j] - 0.0; prov[n_prov++] = 0.0; reward += 0.0; }
+        const double e = -1.0 * (-1.0 * difference);
+        o.overgeneration = e; o.loss_load = 0.0;
+        o.unbalanced_reward = -1.0 * (p.og_cost * e);
+        absb[n_absb++] = e;
+    } else {                                              // :301-314: renewables in module order, then loss load
+        double need = -difference;
+        for (int j = 0; j < n_pv; j++) {
+            const double amt = (pv[j] < need) ? pv[j] : need;
+            o.renewable_used += amt; o.curtailment += pv[j] - amt;
+            prov[n_prov++] = amt; reward += 0.0;
+            need -= amt;
+        }
+        o.loss_load = need; o.overgeneration = 0.0;
+        o.unbalanced_reward = -1.0 * (p.ll_cost * need);
+        prov[n_prov++] = need;
+    }
+    reward += o.unbalanced_reward;
+    o.overall_provided = np_sum_dev(prov, n_prov); o.overall_absorbed = np_sum_dev(absb, n_absb);   // :316-317
+    o.reward = reward;
 }
 
 }  // namespace mgx

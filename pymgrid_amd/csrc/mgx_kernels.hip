@@ -233,7 +233,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
     in.g_stat = 1.0;
     if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
     double q_unused;
-    populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused);
+    populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused, 0.0 + -1 * in.load, in.pv);
     double *c = control + i * A;
     int k = 0;
     if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
                     if (per_step) idr[u] = ids[off + (int64_t)U * N];
                 }
                 double bat_q;
-                populate_core<F>(p, s, word, in, bat_q);
+                populate_core<F>(p, s, word, in, bat_q, 0.0 + -1 * in.load, in.pv);
                 Outputs o;
                 step_core<F, true>(p, d, s, in, false, want_soc, gen_instant, o, bat_q);
                 const double r = shaped_reward<F>(a.shaper, o);
@@ -319,6 +319,133 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
     if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
     store_state<F>(a.c, i, s);
     if (out.ret_acc) out.ret_acc[i] += ret;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// General path: n_load / n_pv != 1 (series [T, n_load, N] and [T, n_pv, N], bounds [n_load, N] / [n_pv, N]).
+// Straightforward one-lane-per-grid kernels; parity with the reference's multi-module grids, not speed.
+// ------------------------------------------------------------------------------------------------------
+template <int F>
+__device__ inline void load_controls_multi(const KArgs &a, const double *__restrict__ actions, int64_t i, int32_t t, Inputs &in)
+{
+    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    const double *ap = actions + i * A;
+    int k = 0;
+    if constexpr (F & F_GENSET) { in.a_goal = ap[k]; in.a_gen = ap[k + 1]; k += 2; }
+    if constexpr (F & F_BATTERY) { in.a_bat = ap[k]; k += 1; }
+    if constexpr (F & F_GRID) {
+        in.a_grid = ap[k];
+        const double *g = a.c.grid_ts + ((int64_t)t * 4) * a.N + i;
+        in.g_pimp = g[0]; in.g_pexp = g[a.N]; in.g_co2 = g[2 * (int64_t)a.N]; in.g_stat = g[3 * (int64_t)a.N];
+    }
+}
+
+__device__ inline void observe_series_multi(const double *__restrict__ ts, int64_t row_stride, int32_t T, int32_t t, int32_t H,
+                                            double lo, double hi, double *__restrict__ obs)
+{
+    const double fill = (hi + lo) / 2, sp = space_spread(lo, hi);
+    for (int h = 0; h <= H; h++) {
+        const bool in = t < T && t + h < T;
+        const double v = in ? ts[(int64_t)(t + h) * row_stride] : 0.0;
+        obs[h] = obs_series_value(v, in, h > 0, lo, hi, fill, sp);
+    }
+}
+
+template <int F>
+__device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, const Params &p, const State &s,
+                                         double *__restrict__ obs_row)
+{
+    const int64_t N = a.N;
+    const int W = 1 + a.H;
+    int k = 0;
+    for (int j = 0; j < a.n_load; j++, k += W)
+        observe_series_multi(a.c.load_ts + (int64_t)j * N + i, (int64_t)a.n_load * N, a.T, t, a.H, a.c.load_lo[(int64_t)j * N + i],
+                             a.c.load_hi[(int64_t)j * N + i], obs_row + k);
+    for (int j = 0; j < a.n_pv; j++, k += W)
+        observe_series_multi(a.c.pv_ts + (int64_t)j * N + i, (int64_t)a.n_pv * N, a.T, t, a.H, a.c.pv_lo[(int64_t)j * N + i],
+                             a.c.pv_hi[(int64_t)j * N + i], obs_row + k);
+    if constexpr (F & F_GENSET) {
+        const double su = (double)(p.gen_times & 0xffff), wd = (double)(p.gen_times >> 16);
+        obs_row[k++] = space_norm(0.0, 1.0, (double)(s.status & 0xff));
+        obs_row[k++] = space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
+        obs_row[k++] = space_norm(0.0, su, (double)((s.status >> 16) & 0xff));
+        obs_row[k++] = space_norm(0.0, wd, (double)(s.status >> 24));
+    }
+    if constexpr (F & F_BATTERY) {
+        const double min_soc = p.bat_cmin / p.bat_cmax;
+        obs_row[k++] = space_norm(min_soc, 1.0, s.soc);
+        obs_row[k++] = space_norm(p.bat_cmin, p.bat_cmax, s.charge);
+    }
+    if constexpr (F & F_GRID) {
+        for (int h = 0; h <= a.H; h++)
+            for (int cc = 0; cc < 4; cc++) {
+                const double lo = a.c.grid_lo[cc * N + i], hi = a.c.grid_hi[cc * N + i];
+                const bool in = t < a.T && t + h < a.T;
+                const double v = in ? a.c.grid_ts[((int64_t)(t + h) * 4 + cc) * N + i] : 0.0;
+                obs_row[k + h * 4 + cc] = obs_series_value(v, in, h > 0, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
+            }
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const double *__restrict__ actions, int32_t t,
+                                                           int normalized, double *__restrict__ reward,
+                                                           uint8_t *__restrict__ done, double *__restrict__ obs,
+                                                           double *__restrict__ log)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    const int64_t N = a.N;
+    Params p; State s; Inputs in; Outputs o; Derived d;
+    load_controls_multi<F>(a, actions, i, t, in);
+    load_state<F>(a.c, i, true, s);
+    load_params<F>(a.c, i, p);
+    derive<F>(p, d);
+    double load[MGX_MAX_MODULES], pv[MGX_MAX_MODULES];
+    for (int j = 0; j < a.n_load; j++) load[j] = a.c.load_ts[((int64_t)t * a.n_load + j) * N + i];
+    for (int j = 0; j < a.n_pv; j++) pv[j] = a.c.pv_ts[((int64_t)t * a.n_pv + j) * N + i];
+    step_multi_core<F>(p, d, s, in, normalized != 0, load, a.n_load, pv, a.n_pv, o);
+    store_state<F>(a.c, i, s);
+    reward[i] = shaped_reward<F>(a.shaper, o);
+    if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
+    if (log) store_log<F>(log + i, N, o, s.status);
+    if (obs) observe_row_multi<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
+}
+
+template <int F>
+__global__ __launch_bounds__(BLOCK) void observe_multi_kernel(const KArgs a, int32_t t, double *__restrict__ obs)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    Params p; State s;
+    load_state<F>(a.c, i, true, s);
+    load_params<F>(a.c, i, p);
+    observe_row_multi<F>(a, i, t, p, s, obs + i * a.obs_dim);
+}
+
+template <int F>
+__global__ __launch_bounds__(BLOCK) void expand_multi_kernel(const KArgs a, const PLWords tab, const int32_t *__restrict__ action_id,
+                                                             int32_t t, double *__restrict__ control)
+{
+    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    const int64_t N = a.N;
+    Params p; State s; Inputs in;
+    load_state<F>(a.c, i, false, s);
+    load_params<F>(a.c, i, p);
+    double total_load = 0.0, pv[MGX_MAX_MODULES];                     // _get_load: running sum; _get_renewable: np.sum
+    for (int j = 0; j < a.n_load; j++) total_load += -1 * a.c.load_ts[((int64_t)t * a.n_load + j) * N + i];
+    for (int j = 0; j < a.n_pv; j++) pv[j] = a.c.pv_ts[((int64_t)t * a.n_pv + j) * N + i];
+    in.g_stat = 1.0;
+    if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
+    double q_unused;
+    populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused, total_load, np_sum_dev(pv, a.n_pv));
+    double *c = control + i * A;
+    int k = 0;
+    if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
+    if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
+    if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -390,6 +517,7 @@ struct mgx_handle {
     KArgs k;
     mgx_layout layout;
     int32_t window_lo, window_hi;   // episode window given at create: trajectories must stay inside it
+    bool multi;             // n_load != 1 or n_pv != 1: general (slow) kernels
     int32_t flags;          // F
     int32_t t;              // current step
     int32_t action_dim;
@@ -462,6 +590,10 @@ static void launch_obs_rows(const KArgs &k, const WindowPlan &plan, int32_t t, d
 // observation of the state at series index t into obs [N, D]
 static int launch_observe(const mgx_handle *h, int32_t t, double *obs, hipStream_t st)
 {
+    if (h->multi) {
+        MGX_DISPATCH_F(h->flags, (observe_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, t, obs)));
+        return MGX_OK;
+    }
     if (h->k.H == 0) {
         MGX_DISPATCH_F(h->flags, (observe_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, t, obs)));
         return MGX_OK;
@@ -500,15 +632,15 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
         return fail(MGX_ERR_INVALID, "mgx_create: need n_grids > 0, n_steps > 0, horizon >= 0");
     if ((L->has_genset | L->has_battery | L->has_grid) & ~1)
         return fail(MGX_ERR_INVALID, "mgx_create: has_genset / has_battery / has_grid must be 0 or 1");
-    if (L->n_load != 1 || L->n_pv != 1)
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_create: the device path takes exactly one load and one pv module per grid "
-                                         "(got n_load=%d n_pv=%d)", L->n_load, L->n_pv);
+    if (L->n_load < 0 || L->n_pv < 0 || L->n_load > MGX_MAX_MODULES || L->n_pv > MGX_MAX_MODULES)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_create: at most %d load and %d renewable modules per grid (got n_load=%d "
+                                         "n_pv=%d)", MGX_MAX_MODULES, MGX_MAX_MODULES, L->n_load, L->n_pv);
     const int32_t final_step = L->final_step <= 0 ? L->n_steps : L->final_step;   // base_timeseries_module.py:321-326
     if (final_step > L->n_steps) return fail(MGX_ERR_INVALID, "mgx_create: final_step %d > n_steps %d", final_step, L->n_steps);
     if (L->initial_step < 0 || L->initial_step >= final_step)
         return fail(MGX_ERR_INVALID, "mgx_create: final_step value must be greater than initial_step");
 #define NEED(cond, ptr) if ((cond) && !(C->ptr)) return fail(MGX_ERR_INVALID, "mgx_create: column " #ptr " is NULL")
-    NEED(true, load_ts); NEED(true, pv_ts); NEED(true, loss_load_cost); NEED(true, overgeneration_cost);
+    NEED(L->n_load > 0, load_ts); NEED(L->n_pv > 0, pv_ts); NEED(true, loss_load_cost); NEED(true, overgeneration_cost);
     NEED(L->has_battery, bat_min_capacity); NEED(L->has_battery, bat_max_capacity); NEED(L->has_battery, bat_max_charge);
     NEED(L->has_battery, bat_max_discharge); NEED(L->has_battery, bat_efficiency); NEED(L->has_battery, bat_cost_cycle);
     NEED(L->has_battery, charge); NEED(L->has_battery, soc);
@@ -533,7 +665,9 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->flags = (L->has_genset ? F_GENSET : 0) | (L->has_battery ? F_BATTERY : 0) | (L->has_grid ? F_GRID : 0);
     h->action_dim = 2 * L->has_genset + L->has_battery + L->has_grid;
     const int w = 1 + L->horizon;
-    h->k.obs_dim = 2 * w + 4 * L->has_genset + 2 * L->has_battery + 4 * w * L->has_grid;
+    h->k.obs_dim = (L->n_load + L->n_pv) * w + 4 * L->has_genset + 2 * L->has_battery + 4 * w * L->has_grid;
+    h->k.n_load = L->n_load; h->k.n_pv = L->n_pv;
+    h->multi = (L->n_load != 1 || L->n_pv != 1);
     h->k.log_dim = LC_COMMON_END + LC_GENSET_N * L->has_genset + LC_BATTERY_N * L->has_battery + LC_GRID_N * L->has_grid + 1;
     h->t = L->initial_step;
     h->k.shaper = MGX_SHAPER_NONE;
@@ -573,7 +707,8 @@ const char *mgx_log_name(const mgx_handle *h, int32_t col)
 static int need_obs_bounds(const mgx_handle *h, const char *who)
 {
     const mgx_columns &c = h->k.c;
-    if (!c.load_lo || !c.load_hi || !c.pv_lo || !c.pv_hi || (h->layout.has_grid && (!c.grid_lo || !c.grid_hi)))
+    if ((h->layout.n_load > 0 && (!c.load_lo || !c.load_hi)) || (h->layout.n_pv > 0 && (!c.pv_lo || !c.pv_hi)) ||
+        (h->layout.has_grid && (!c.grid_lo || !c.grid_hi)))
         return fail(MGX_ERR_INVALID, "%s: observations requested but the *_lo / *_hi bound columns are NULL", who);
     return MGX_OK;
 }
@@ -646,6 +781,14 @@ int mgx_step(mgx_handle *h, const double *actions, int normalized, double *rewar
         return fail(MGX_ERR_RANGE, "mgx_step: step %d is outside the time series (length %d)", h->t, h->k.T);
     if (obs) { if (int rc = need_obs_bounds(h, "mgx_step")) return rc; }
     hipStream_t st = (hipStream_t)stream;
+    if (h->multi) {
+        MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, h->t, normalized,
+                                                                                              reward, done, obs, log)));
+        hipError_t em = hipGetLastError();
+        if (em != hipSuccess) return hip_fail(em, "step_multi_kernel launch");
+        h->t += 1;
+        return MGX_OK;
+    }
     double *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
     MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, h->t, normalized, reward,
                                                                                     done, obs_inline, log)));
@@ -662,6 +805,8 @@ int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized, 
     g_err[0] = 0;
     if (!h || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_step_k: NULL argument");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_step_k: K must be positive");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: fused steps need exactly one load and one renewable module "
+                                                    "per grid; use mgx_step");
     if (h->t < 0 || (int64_t)h->t + K > h->k.T)
         return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
     hipStream_t st = (hipStream_t)stream;
@@ -706,7 +851,11 @@ int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_expand_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, h->t, control)));
+    if (h->multi) {
+        MGX_DISPATCH_F(h->flags, (expand_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, h->t, control)));
+    } else {
+        MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, h->t, control)));
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "expand_kernel launch");
 }
@@ -718,6 +867,8 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     g_err[0] = 0;
     if (!h || !action_id || !table) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: NULL argument");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: K must be positive");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: needs exactly one load and one renewable module "
+                                                    "per grid; use mgx_expand_discrete + mgx_step");
     if (h->t < 0 || (int64_t)h->t + K > h->k.T)
         return fail(MGX_ERR_RANGE, "mgx_rollout_discrete: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
     PLWords tab;

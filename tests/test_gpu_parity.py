@@ -347,10 +347,16 @@ def test_error_paths(pymgrid25, device):
     with pytest.raises(MgxError):
         eng.reset(initial_step=8759)
     eng.close()
-    bad = BatchLayout(n_grids=1, n_steps=8760, has_genset=True, has_battery=True, n_load=2)
-    with pytest.raises(MgxError) as e:
-        StepEngine(MicrogridBatch(bad, b.cols))
+    z = golden("loadpv.npz")                                                       # 2 loads + 1 pv: general kernels
+    multi = dict(load_ts=z["c1_load_ts"], pv_ts=z["c1_pv_ts"], final_step=100, horizon=0,
+                 unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0))
+    eng = StepEngine(_batch([multi], device))
+    with pytest.raises(MgxError) as e:                                             # fused path: one load + one pv only
+        eng.step_k(torch.zeros(4, 1, 0, dtype=torch.float64, device=device))
     assert e.value.code == 2
+    eng.close()
+    with pytest.raises(ValueError):
+        MicrogridBatch(BatchLayout(n_grids=1, n_steps=8760, has_genset=True, has_battery=True, n_load=2), b.cols)
     with pytest.raises(MgxError):
         StepEngine(_batch([p], "cpu"))                                           # no CPU path
 

@@ -1,0 +1,90 @@
+"""Several load / renewable modules per microgrid (general kernels): the reference's TestMicrogridLoadPV family
+(tests/microgrid/test_microgrid.py:188-427) via goldens, and mixed grids against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_loadpv_multi_module_vs_reference(device):
+    """1..9 load and pv modules, no controllable module: reward, done and every log column of 99 steps, including
+    numpy's pairwise summation order once a list reaches 8 addends (9 loads, 9 pvs)."""
+    from pymgrid_amd import MicrogridBatch, StepEngine
+    z = golden("loadpv.npz")
+    names = [str(s) for s in z["log_names"]]
+    for c in range(int(z["n_cases"])):
+        p = dict(load_ts=z[f"c{c}_load_ts"], pv_ts=z[f"c{c}_pv_ts"], final_step=100, horizon=0,
+                 unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0))
+        eng = StepEngine(MicrogridBatch.from_grids([p, p], device=device))
+        assert eng.layout.n_load == p["load_ts"].shape[1] and eng.action_dim == 0
+        a = torch.empty(2, 0, dtype=torch.float64, device=device)
+        for k in range(99):
+            _, reward, done, log = eng.step(a, want_obs=False, want_log=True)
+            assert reward[0].item() == z[f"c{c}_reward"][k] == reward[1].item(), (c, k)
+            assert int(done[0]) == z[f"c{c}_done"][k]
+            dev = dict(zip(eng.log_names, log[:, 0].cpu().numpy()))
+            for j, name in enumerate(names):
+                ref = z[f"c{c}_log"][k][j]
+                if not np.isnan(ref):
+                    assert dev[name] == ref, (c, k, name, dev[name], ref)
+        eng.close()
+
+
+def test_multi_module_with_controllables_vs_oracle(device, oracle):
+    """3 loads + 2 pvs + genset + battery + grid, H = 2: step (log, obs, state) and discrete expansion vs oracle."""
+    from pymgrid_amd import DiscreteBatchedMicrogridEnv, MicrogridBatch
+    from pymgrid_amd.priority_list import MODULE_NAMES
+    rs = np.random.RandomState(12)
+    T, N, K = 60, 6, 40
+    grids = []
+    for i in range(N):
+        price = 0.1 + 0.4 * rs.rand(T)
+        status = (rs.rand(T) > 0.15).astype(float)
+        grids.append(dict(
+            load_ts=40 * rs.rand(T, 3), pv_ts=30 * rs.rand(T, 2) * (rs.rand(T, 2) > 0.3), horizon=2, final_step=T,
+            initial_step=0, unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0),
+            genset=dict(running_min_production=5.0, running_max_production=60.0, genset_cost=0.4, co2_per_unit=2.0,
+                        cost_per_unit_co2=0.1, start_up_time=int(rs.randint(0, 3)), wind_down_time=int(rs.randint(0, 3)),
+                        init_start_up=bool(rs.randint(0, 2))),
+            battery=dict(min_capacity=20.0, max_capacity=100.0, max_charge=25.0, max_discharge=25.0, efficiency=0.9,
+                         battery_cost_cycle=0.02, init_soc=0.5),
+            grid=dict(max_import=50.0, max_export=30.0, cost_per_unit_co2=0.1),
+            grid_ts=np.stack([price, 0.5 * price, 0.3 * rs.rand(T), status], axis=1)))
+    env = DiscreteBatchedMicrogridEnv(MicrogridBatch.from_grids(grids, device=device), log=True,
+                                      remove_redundant_gensets=False)
+    oms = [oracle.OracleMicrogrid(g) for g in grids]
+    obs0 = env.reset().cpu().numpy()
+    for j, om in enumerate(oms):
+        assert np.array_equal(obs0[j], om.reset()), j
+    names = env.engine.log_names
+    for k in range(K):
+        if k % 2 == 0:                       # continuous normalised control
+            a = rs.rand(N, 4)
+            if k % 6 == 0:
+                a = np.round(a)
+            obs, reward, done, info = super(DiscreteBatchedMicrogridEnv, env).step(
+                torch.as_tensor(a, dtype=torch.float64, device=device), normalized=True)
+            outs = [om.run(dict(genset=a[j, :2], battery=a[j, 2], grid=a[j, 3]), True) for j, om in enumerate(oms)]
+        else:                                # discrete priority-list action
+            ids = rs.randint(0, env.action_space.n, size=N)
+            control = env.get_action(ids).cpu().numpy()
+            acts = []
+            for j, om in enumerate(oms):
+                act = om.populate_action([(MODULE_NAMES[m], a_) for m, a_ in env.actions_list[ids[j]]])
+                assert np.array_equal(control[j], [*act["genset"], act["battery"], act["grid"]]), (k, j)
+                acts.append(act)
+            obs, reward, done, info = env.step(ids)
+            outs = [om.run(acts[j], False) for j, om in enumerate(oms)]
+        log, obs = info["log"].cpu().numpy(), obs.cpu().numpy()
+        for j, (om, o) in enumerate(zip(oms, outs)):
+            d = o.as_dict()
+            for c, name in enumerate(names):
+                if name in d:
+                    assert log[c, j] == d[name], (k, j, name, log[c, j], d[name])
+            assert reward[j].item() == o.reward
+            assert np.array_equal(obs[j], om.observe()), (k, j)
+            assert env.batch.cols["charge"][j].item() == om.s.charge
+    env.close()
