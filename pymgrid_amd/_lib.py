@@ -88,11 +88,24 @@ def build(force=False, verbose=False):
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in SOURCES)):
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + [SOURCES[0], "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    # several ranks may get here at once (torchrun): serialise on a lock file, compile to a temporary name and
+    # rename atomically so that nobody ever dlopens a half-written library
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if (not force and os.path.exists(LIB_PATH)
+                    and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in SOURCES)):
+                return LIB_PATH                      # another process built it while we waited
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+            cmd = [hipcc] + HIPCC_FLAGS + [SOURCES[0], "-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
