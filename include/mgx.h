@@ -168,6 +168,12 @@ int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized,
 int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions,
                         double *control, mgx_stream stream);
 
+/* DiscreteMicrogridEnv.step (discrete.py:109-143) in ONE launch: mgx_expand_discrete + mgx_step(normalized=0) with the
+ * control kept in registers.  control [N, A] (optional, may be NULL) receives the expanded control; the other
+ * outputs are those of mgx_step. */
+int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions, double *control,
+                      double *reward, uint8_t *done, double *obs, double *log, mgx_stream stream);
+
 /* K fused DiscreteMicrogridEnv steps with the control expanded ON DEVICE: action_id holds priority-list ids as
  * bytes, either [K, N] (per_step != 0: `for a in ids: env.step(a)`, discrete.py:109-143) or [N] (per_step == 0: one
  * fixed list per grid for the whole call = RuleBasedControl.run, algos/rbc/rbc.py:64-93).  `table` as in

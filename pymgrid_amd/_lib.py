@@ -77,6 +77,8 @@ SYMBOLS = {
     "mgx_step_k": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_expand_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgx_step_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_rollout_discrete": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_i32_p, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

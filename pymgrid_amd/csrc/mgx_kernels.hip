@@ -241,11 +241,6 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
     if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Discrete rollout: K fused steps whose control is expanded ON DEVICE from a priority-list id -- per step
-// (ids [K, N], one byte each: a DiscreteMicrogridEnv roll-out) or constant per grid (ids [N]: RuleBasedControl.run,
-// algos/rbc/rbc.py:64-93).  No action stream at all: per step only the series rows are read.
-// ------------------------------------------------------------------------------------------------------
 template <int F>
 __device__ __forceinline__ void load_series_at(const double *__restrict__ lts, const double *__restrict__ pts,
                                                const double *__restrict__ gts, int64_t N, int64_t i, int64_t off,
@@ -260,6 +255,49 @@ __device__ __forceinline__ void load_series_at(const double *__restrict__ lts, c
     }
 }
 
+// DiscreteMicrogridEnv.step in ONE launch (discrete.py:109-143): expand the priority list of every grid into its
+// control and run Microgrid.run(control, normalized=False) on it, without the control ever leaving registers.
+template <int F>
+__global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, const PLWords tab,
+                                                              const int32_t *__restrict__ action_id, int32_t t,
+                                                              double *__restrict__ control, double *__restrict__ reward,
+                                                              uint8_t *__restrict__ done, double *__restrict__ obs,
+                                                              double *__restrict__ log)
+{
+    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+    const int64_t N = a.N;
+    Params p; State s; Inputs in; Outputs o; Derived d;
+    const int32_t id = action_id[i];
+    load_series_at<F>(a.c.load_ts + (int64_t)t * N, a.c.pv_ts + (int64_t)t * N,
+                      (F & F_GRID) ? a.c.grid_ts + (int64_t)t * 4 * N : nullptr, N, i, i, in);
+    load_state<F>(a.c, i, log != nullptr, s);
+    load_params<F>(a.c, i, p);
+    derive<F>(p, d);
+    const bool gen_instant = genset_wave_is_instant<F>(p, s);
+    double bat_q;
+    populate_core<F>(p, s, pl_select(tab, id), in, bat_q, 0.0 + -1 * in.load, in.pv);
+    if (control) {                                   // optional copy of the expanded control (_get_action's value)
+        double *c = control + i * A;
+        int k = 0;
+        if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
+        if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
+        if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
+    }
+    step_core<F, true>(p, d, s, in, false, true, gen_instant, o, bat_q);
+    store_state<F>(a.c, i, s);
+    reward[i] = shaped_reward<F>(a.shaper, o);
+    if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
+    if (log) store_log<F>(log + i, N, o, s.status);
+    if (obs) observe_row_h0<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Discrete rollout: K fused steps whose control is expanded ON DEVICE from a priority-list id -- per step
+// (ids [K, N], one byte each: a DiscreteMicrogridEnv roll-out) or constant per grid (ids [N]: RuleBasedControl.run,
+// algos/rbc/rbc.py:64-93).  No action stream at all: per step only the series rows are read.
+// ------------------------------------------------------------------------------------------------------
 template <int F, int U>
 __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const PLWords tab, const uint8_t *__restrict__ ids,
                                                           int per_step, int32_t t0, int32_t K, const FusedOut out)
@@ -858,6 +896,29 @@ int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "expand_kernel launch");
+}
+
+int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions, double *control,
+                      double *reward, uint8_t *done, double *obs, double *log, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !action_id || !table || !reward) return fail(MGX_ERR_INVALID, "mgx_step_discrete: NULL argument");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_discrete: needs exactly one load and one renewable module per "
+                                                    "grid; use mgx_expand_discrete + mgx_step");
+    if (h->t < 0 || h->t >= h->k.T)
+        return fail(MGX_ERR_RANGE, "mgx_step_discrete: step %d is outside the time series (length %d)", h->t, h->k.T);
+    if (obs) { if (int rc = need_obs_bounds(h, "mgx_step_discrete")) return rc; }
+    PLWords tab;
+    if (int rc = encode_table(h, table, n_actions, &tab, "mgx_step_discrete")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    double *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
+    MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, h->t, control,
+                                                                                             reward, done, obs_inline, log)));
+    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, h->t + 1, obs, st)) return rc; }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "step_discrete_kernel launch");
+    h->t += 1;
+    return MGX_OK;
 }
 
 int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, const int32_t *table, int32_t n_actions,

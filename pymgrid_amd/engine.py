@@ -167,6 +167,23 @@ class StepEngine:
                    _ptr(ret_acc), _ptr(lg))
         return res
 
+    def step_discrete(self, action_id, table, want_obs=True, want_log=False, want_control=False, out=None):
+        """DiscreteMicrogridEnv.step for every grid in one launch: priority-list ids [N] (int32) are expanded and
+        stepped in-kernel.  Returns (obs|None, reward, done, log|None, control|None)."""
+        if action_id.dtype != torch.int32 or tuple(action_id.shape) != (self.N,) or action_id.device != self.device:
+            raise ValueError(f"action_id must be an int32 tensor of shape ({self.N},) on {self.device}")
+        table = np.ascontiguousarray(table, dtype=np.int32)
+        out = out or {}
+        reward = out.get("reward") if out.get("reward") is not None else self._empty(self.N)
+        done = out.get("done") if out.get("done") is not None else self._empty(self.N, dtype=torch.uint8)
+        obs = (out.get("obs") if out.get("obs") is not None else self._empty(self.N, self.obs_dim)) if want_obs else None
+        log = (out.get("log") if out.get("log") is not None else self._empty(self.log_dim, self.N)) if want_log else None
+        control = (out.get("control") if out.get("control") is not None
+                   else self._empty(self.N, self.action_dim)) if want_control else None
+        self._call(self._lib.mgx_step_discrete, _ptr(action_id), table.ctypes.data_as(_lib.c_i32_p), table.shape[0],
+                   _ptr(control), reward.data_ptr(), done.data_ptr(), _ptr(obs), _ptr(log))
+        return obs, reward, done, log, control
+
     def rollout_discrete(self, action_id, table, K, reward=True, done=False, soc_trace=False, status_trace=False,
                          ret_acc=None, log=False, out=None):
         """K fused discrete steps with on-device action expansion.  ``action_id`` uint8: [K, N] (an id per step) or

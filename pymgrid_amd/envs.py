@@ -114,7 +114,7 @@ class BatchedMicrogridEnv:
             info["log"] = log
             if self.raise_errors:
                 self._raise_on_violations(log[-1])
-        return obs, reward, done.bool(), info
+        return obs, reward, done.view(torch.bool), info       # 0/1 bytes reinterpreted, no conversion kernel
 
     _VIOLATIONS = ((1, "Genset", "supply requested value as a source (outside [min_production, max_production])"),
                    (2, "BatteryModule", "supply / absorb requested value (above max_production / max_consumption)"),
@@ -255,8 +255,22 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
         return self.engine.expand_discrete(action_id, self._table)
 
     def step(self, action_id):
-        control = self.get_action(action_id)
-        return super().step(control, normalized=False)
+        """One fused launch (expand + step); grids with several load / pv modules go through expand + step."""
+        if self.layout.n_load != 1 or self.layout.n_pv != 1:
+            return super().step(self.get_action(action_id), normalized=False)
+        if not torch.is_tensor(action_id):
+            action_id = torch.as_tensor(np.asarray(action_id), device=self.batch.device)
+        action_id = action_id.to(device=self.batch.device, dtype=torch.int32).contiguous()
+        obs, reward, done, log, _ = self.engine.step_discrete(action_id, self._table, want_obs=self._observations,
+                                                              want_log=self._keep_log)
+        info = {}
+        if log is not None:
+            self._log_rows.append(log)
+            self._shaped_rows.append(reward.clone())
+            info["log"] = log
+            if self.raise_errors:
+                self._raise_on_violations(log[-1])
+        return obs, reward, done.view(torch.bool), info
 
     def sample_action(self, generator=None):
         return torch.randint(0, self.action_space.n, (self.n_grids,), dtype=torch.int32, device=self.batch.device,
