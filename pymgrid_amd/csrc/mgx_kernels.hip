@@ -91,10 +91,12 @@ __device__ __forceinline__ void load_inputs_at(const double *__restrict__ act, c
 
 template <int F, int U>
 __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const double *__restrict__ actions, int32_t t0,
-                                                         int32_t K, int normalized, const FusedOut out)
+                                                         int32_t K, int normalized, const FusedOut out, int32_t gpb)
 {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK_K + threadIdx.x;
-    if (i >= a.N) return;
+    // gpb = grids per workgroup (<= BLOCK_K, multiple of 16 = one 128-B line of doubles): chosen by the host so that
+    // the busiest CU streams as few grids as possible (fused_grids_per_block)
+    const int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x;
+    if ((int32_t)threadIdx.x >= gpb || i >= a.N) return;
     const int64_t N = a.N;
     Params p; State s; Derived d;
     load_state<F>(a.c, i, out.log != nullptr, s);
@@ -300,10 +302,10 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
 // ------------------------------------------------------------------------------------------------------
 template <int F, int U>
 __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const PLWords tab, const uint8_t *__restrict__ ids,
-                                                          int per_step, int32_t t0, int32_t K, const FusedOut out)
+                                                          int per_step, int32_t t0, int32_t K, const FusedOut out, int32_t gpb)
 {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK_K + threadIdx.x;
-    if (i >= a.N) return;
+    const int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x;
+    if ((int32_t)threadIdx.x >= gpb || i >= a.N) return;
     const int64_t N = a.N;
     Params p; State s; Derived d;
     load_state<F>(a.c, i, out.log != nullptr, s);
@@ -556,6 +558,7 @@ struct mgx_handle {
     mgx_layout layout;
     int32_t window_lo, window_hi;   // episode window given at create: trajectories must stay inside it
     bool multi;             // n_load != 1 or n_pv != 1: general (slow) kernels
+    int32_t n_cu;           // compute units of the device (workgroup balancing of the fused kernels)
     int32_t flags;          // F
     int32_t t;              // current step
     int32_t action_dim;
@@ -608,6 +611,25 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOC
     }
 
 }  // namespace
+
+// Grids per workgroup of the fused kernels.  Those kernels are bound by what the BUSIEST compute unit has to stream
+// (measured: N = 100 000 in 391 workgroups of 256 leaves 135 CUs with two workgroups and 121 with one: 0.60 of peak;
+// 131 072 grids = exactly two per CU: 0.64).  Pick the multiple of 16 grids (one 128-byte line of doubles, so every
+// workgroup's rows stay line-aligned) in [192, 256] that minimises  ceil(workgroups / CUs) * grids_per_workgroup
+// (smaller workgroups measured slower at equal cost: more, emptier waves).
+static int32_t fused_grids_per_block(const mgx_handle *h)
+{
+    const int64_t N = h->k.N;
+    const int cus = h->n_cu > 0 ? h->n_cu : 256;
+    int32_t best = BLOCK_K;
+    int64_t best_cost = -1;
+    for (int32_t g = BLOCK_K; g >= 192 && g >= BLOCK_K - 64; g -= 16) {
+        const int64_t blocks = (N + g - 1) / g;
+        const int64_t cost = ((blocks + cus - 1) / cus) * g;          // grids streamed by the busiest CU
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = g; }
+    }
+    return best;
+}
 
 template <int F>
 static void launch_obs_rows(const KArgs &k, const WindowPlan &plan, int32_t t, double *obs, unsigned blocks, size_t lds,
@@ -696,6 +718,8 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     mgx_handle *h = new (std::nothrow) mgx_handle();
     if (!h) return fail(MGX_ERR_INVALID, "mgx_create: out of host memory");
     if ((e = hipGetDevice(&h->device)) != hipSuccess) { delete h; return hip_fail(e, "hipGetDevice"); }
+    h->n_cu = 0;
+    (void)hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
     h->layout = *L;
     h->layout.final_step = final_step;
     h->k.c = *C;
@@ -849,8 +873,9 @@ int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized, 
         return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
     hipStream_t st = (hipStream_t)stream;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
-    MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING><<<(unsigned)((h->k.N + BLOCK_K - 1) / BLOCK_K), BLOCK_K, 0, st>>>(
-                                  h->k, actions, h->t, K, normalized, fo)));
+    const int32_t gpb = fused_grids_per_block(h);
+    MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING><<<(unsigned)((h->k.N + gpb - 1) / gpb), BLOCK_K, 0, st>>>(
+                                  h->k, actions, h->t, K, normalized, fo, gpb)));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_k_kernel launch");
     h->t += K;
@@ -936,8 +961,9 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_rollout_discrete")) return rc;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     hipStream_t st = (hipStream_t)stream;
-    MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING><<<(unsigned)((h->k.N + BLOCK_K - 1) / BLOCK_K), BLOCK_K, 0, st>>>(
-                                  h->k, tab, action_id, per_step, h->t, K, fo)));
+    const int32_t gpb = fused_grids_per_block(h);
+    MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING><<<(unsigned)((h->k.N + gpb - 1) / gpb), BLOCK_K, 0, st>>>(
+                                  h->k, tab, action_id, per_step, h->t, K, fo, gpb)));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rollout_kernel launch");
     h->t += K;
