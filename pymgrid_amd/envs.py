@@ -58,7 +58,6 @@ class BatchedMicrogridEnv:
         A = self.layout.action_dim
         self.action_space = Box(0.0, 1.0, shape=(A,))                       # normalised control
         self.observation_space = Box(0.0, 1.0, shape=(self.layout.obs_dim,))  # normalised observation
-        self._out = {}
 
     # ---- reference-like properties ------------------------------------------------------------------
     @property

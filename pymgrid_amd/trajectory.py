@@ -8,8 +8,6 @@ the step counter).
 """
 import numpy as np
 
-from . import _lib
-
 
 class DeterministicTrajectory:
     """trajectory/deterministic.py:4-12"""

@@ -3,7 +3,6 @@ collective, and the single metrics all-reduce."""
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
