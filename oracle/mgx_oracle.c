@@ -464,6 +464,9 @@ static void batch_init_grid(const orc_batch *b, int32_t i, int32_t t0, orc_grid 
 
 /* Tiles of ORC_TILE grids are walked step-major so that the [T,N] series rows and the [K,N,A] action rows are
  * read along their contiguous axis; each grid still goes through the scalar orc_run() above. */
+static uint8_t *g_failed = NULL;      /* optional [N] flags: grid hit a state where the reference raises */
+void orc_set_failure_flags(uint8_t *flags) { g_failed = flags; }
+
 int64_t orc_run_batch(const orc_batch *b, int32_t t0, int32_t K, const double *actions, int normalized,
                       double *reward, int32_t nthreads)
 {
@@ -492,7 +495,10 @@ int64_t orc_run_batch(const orc_batch *b, int32_t t0, int32_t K, const double *a
                 if (b->has_genset)  { a.genset[0] = ap[c]; a.genset[1] = ap[c + 1]; c += 2; }
                 if (b->has_battery) { a.battery = ap[c++]; }
                 if (b->has_grid)    { a.grid = ap[c++]; }
-                if (orc_run(&g[j], &s[j], &a, normalized, &o) != 0) failures++;
+                if (orc_run(&g[j], &s[j], &a, normalized, &o) != 0) {
+                    if (g_failed) g_failed[i] = 1; else failures++;
+                    s[j].t = t0 + k + 1;              /* keep walking the series; this grid is flagged */
+                }
                 if (reward) reward[(int64_t)k * N + i] = o.reward;
             }
         }

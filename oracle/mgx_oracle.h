@@ -146,6 +146,9 @@ typedef struct orc_batch {
 } orc_batch;
 int64_t orc_run_batch(const orc_batch *b, int32_t t0, int32_t K, const double *actions, int normalized,
                       double *reward, int32_t nthreads);
+/* Optional [N] byte flags for orc_run_batch: instead of counting a failed step as an error, flag the grid (the
+ * reference would have raised there: balance check, AssertionError) and keep going.  NULL switches it off. */
+void orc_set_failure_flags(uint8_t *flags);
 
 /* Discrete rollout over the same SoA batch: control = _populate_action(table[id]) then run(normalized=False);
  * ids are bytes, [K,N] (per_step) or [N] (one fixed list per grid = RuleBasedControl.run, rbc.py:64-93);

@@ -288,15 +288,25 @@ def _make_batch(cols, state, keep):
     return b
 
 
-def run_batch(cols, state, t0, K, actions, normalized=True, want_reward=True, nthreads=1):
+def run_batch(cols, state, t0, K, actions, normalized=True, want_reward=True, nthreads=1, failed=None):
     """Run K steps over an SoA batch (same column names / layouts as ``pymgrid_amd.batch``), in place on
-    ``state`` (dict of numpy arrays charge, soc, gen_status).  Returns reward [K, N] or None."""
+    ``state`` (dict of numpy arrays charge, soc, gen_status).  Returns reward [K, N] or None.
+    ``failed``: optional uint8 [N] array that receives 1 for grids on which the reference would have raised."""
     keep = []
     b = _make_batch(cols, state, keep)
     actions = np.ascontiguousarray(actions, dtype=np.float64)
     reward = np.empty((K, b.N), dtype=np.float64) if want_reward else None
-    n = lib().orc_run_batch(C.byref(b), int(t0), int(K), _dp(actions), int(normalized),
+    L = lib()
+    L.orc_set_failure_flags.restype = None
+    L.orc_set_failure_flags.argtypes = [C.POINTER(C.c_uint8)]
+    if failed is not None:
+        assert failed.dtype == np.uint8 and failed.shape == (b.N,) and failed.flags.c_contiguous
+        L.orc_set_failure_flags(failed.ctypes.data_as(C.POINTER(C.c_uint8)))
+    try:
+        n = L.orc_run_batch(C.byref(b), int(t0), int(K), _dp(actions), int(normalized),
                             _dp(reward) if want_reward else None, int(nthreads))
+    finally:
+        L.orc_set_failure_flags(None)
     if n < 0:
         raise RuntimeError(f"oracle batch run: {-n} step(s) failed the balance check")
     return reward

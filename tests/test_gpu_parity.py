@@ -380,3 +380,72 @@ def test_bucketed_fleet_of_mixed_layouts(pymgrid25, device):
         for n in range(25):
             assert r[n] == z[f"s{n}_reward"][k] and soc[n] == z[f"s{n}_soc"][k], (n, k)
     fleet.close()
+
+
+@pytest.mark.parametrize("arch", ["genset+battery", "genset+battery+grid"])
+def test_randomized_differential_degenerate_parameters(arch, device, oracle):
+    """Differential test over wild / degenerate parameters (zero-width action spaces, eta = 1, zero capacities and
+    costs, min == max production, huge and tiny magnitudes, raw controls far outside the limits): 20 000 grids x 48
+    steps, device == oracle bit for bit."""
+    from pymgrid_amd import BatchLayout, MicrogridBatch, StepEngine, pack_status
+    from pymgrid_amd.batch import pack_times
+    rs = np.random.RandomState(99)
+    N, T, K = 20_000, 50, 48
+    has_grid = "grid" in arch
+
+    def pick(*choices):
+        return rs.choice(np.array(choices, dtype=np.float64), size=N)
+    scale = 10.0 ** rs.randint(-2, 7, size=N)
+    cap = scale * pick(0.0, 1.0, 3.0, 100.0)
+    cmin = cap * pick(0.0, 0.2, 0.5, 1.0)
+    A = dict(
+        load_ts=-np.abs(scale * rs.rand(T, N) * (rs.rand(T, N) > 0.1)),
+        pv_ts=np.abs(scale * rs.rand(T, N) * (rs.rand(T, N) > 0.4)),
+        loss_load_cost=pick(0.0, 10.0, 1e3), overgeneration_cost=pick(0.0, 1.0, 2.5),
+        bat_min_capacity=cmin, bat_max_capacity=np.maximum(cap, 1e-300),
+        bat_max_charge=cap * pick(0.0, 0.25, 1.0, 5.0), bat_max_discharge=cap * pick(0.0, 0.25, 1.0, 5.0),
+        bat_efficiency=pick(1.0, 0.9, 0.5, 0.123), bat_cost_cycle=pick(0.0, 0.02, 7.0),
+        gen_running_max=scale * pick(0.0, 1.0, 2.0),
+        gen_cost=pick(0.0, 0.4, 3.0), gen_co2_per_unit=pick(0.0, 2.0), gen_cost_per_unit_co2=pick(0.0, 0.1),
+    )
+    A["gen_running_min"] = A["gen_running_max"] * pick(0.0, 0.05, 1.0)
+    su, wd = rs.randint(0, 5, N), rs.randint(0, 5, N)
+    on = rs.randint(0, 2, N)
+    A["gen_times"] = pack_times(su, wd)
+    A["gen_status"] = pack_status(on, on, np.where(on, 0, su), np.where(on, wd, 0))
+    soc0 = np.clip(rs.rand(N), A["bat_min_capacity"] / A["bat_max_capacity"], 1.0)
+    A["charge"] = np.maximum(soc0 * A["bat_max_capacity"], A["bat_min_capacity"])
+    A["soc"] = A["charge"] / A["bat_max_capacity"]
+    if has_grid:
+        A["grid_max_import"] = scale * pick(0.0, 1.0, 4.0)
+        A["grid_max_export"] = scale * pick(0.0, 1.0, 4.0)
+        A["grid_cost_per_unit_co2"] = pick(0.0, 0.1)
+        g = np.stack([rs.rand(T, N), rs.rand(T, N) * (rs.rand(T, N) > 0.5), rs.rand(T, N),
+                      (rs.rand(T, N) > 0.2).astype(np.float64)], axis=1)
+        A["grid_ts"] = g
+    layout = BatchLayout(n_grids=N, n_steps=T, has_genset=True, has_battery=True, has_grid=has_grid)
+    batch = MicrogridBatch.from_numpy(layout, A, device)
+    cols = batch.numpy_columns()
+    st = {k: cols[k].copy() for k in ("charge", "soc", "gen_status")}
+    eng = StepEngine(batch)
+    failed = np.zeros(N, dtype=np.uint8)        # grids on which the REFERENCE would raise (e.g. charge above
+    for normalized in (True, False):            # max_capacity by a rounding when max_charge >= capacity / 2)
+        a = rs.rand(K // 2, N, layout.action_dim)
+        if not normalized:                                  # raw requests, up to 3x beyond any limit, both signs
+            a[..., 1] = a[..., 1] * 3 * A["gen_running_max"]
+            a[..., 2] = (a[..., 2] * 2 - 1) * 3 * np.maximum(A["bat_max_charge"], A["bat_max_discharge"])
+            if has_grid:
+                a[..., 3] = (a[..., 3] * 2 - 1) * 3 * np.maximum(A["grid_max_import"], A["grid_max_export"])
+        a[::5] = np.round(a[::5])
+        t0 = eng.current_step
+        out = eng.step_k(_t(a, device), normalized=normalized, reward=True, soc_trace=True)
+        ref = oracle.run_batch(cols, st, t0, K // 2, a, normalized=normalized, nthreads=8, failed=failed)
+        ok = failed == 0
+        got = out["reward"].cpu().numpy()
+        assert np.array_equal(got[:, ok], ref[:, ok]), f"normalized={normalized}: {np.sum(got[:, ok] != ref[:, ok])} differ"
+        for k in st:
+            dev = batch.cols[k].cpu().numpy()
+            dev = dev.view(np.uint32) if k == "gen_status" else dev
+            assert np.array_equal(dev[ok], st[k][ok]), k
+    assert failed.mean() < 0.02, failed.mean()
+    eng.close()
