@@ -66,3 +66,63 @@ class BucketedFleet:
     def close(self):
         for env in self.envs:
             env.close()
+
+
+class PerGridWindowEnv:
+    """Per-grid random episode windows (the per-microgrid ``FixedLengthStochasticTrajectory`` of the reference,
+    microgrid/trajectory/stochastic.py:15-30, for a batch): every grid gets its OWN start row, all episodes have the
+    same length, so the batch still advances in lock-step and the hot path is unchanged.
+
+    How: at ``reset()`` the rows ``[start_i, start_i + length + H]`` of every grid's series are gathered ONCE into a
+    short window buffer ``[length + H + 1, N]`` (a few MB) and the engine steps over that buffer from row 0.  The
+    observation bounds stay those of the full series, as in the reference.
+    """
+
+    def __init__(self, full_batch, trajectory_length, discrete=False, generator=None, **env_kwargs):
+        L = full_batch.layout
+        if L.n_load != 1 or L.n_pv != 1:
+            raise NotImplementedError("per-grid windows need one load and one renewable module per grid")
+        self.full = full_batch
+        self.length = int(trajectory_length)
+        self.rows = self.length + L.horizon + 1
+        if self.rows > L.final_step - L.initial_step:
+            raise ValueError(f'Cannot create a trajectory of length {self.length}'
+                             f'between initial_step ({L.initial_step}) and final_step ({L.final_step})')
+        self.generator = generator
+        dev = full_batch.device
+        N = L.n_grids
+        cols = dict(full_batch.cols)                   # parameters / state / bounds are shared with the full batch
+        cols["load_ts"] = torch.empty(self.rows, N, dtype=torch.float64, device=dev)
+        cols["pv_ts"] = torch.empty(self.rows, N, dtype=torch.float64, device=dev)
+        if L.has_grid:
+            cols["grid_ts"] = torch.empty(self.rows, 4, N, dtype=torch.float64, device=dev)
+        from dataclasses import replace
+        wl = replace(L, n_steps=self.rows, initial_step=0, final_step=self.length)
+        self.window = MicrogridBatch(wl, cols, forecast_noise=full_batch.forecast_noise)
+        cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
+        self.env = cls(self.window, **env_kwargs)
+        self.starts = None
+        self._k = torch.arange(self.rows, device=dev).unsqueeze(1)            # [rows, 1]
+
+    def draw_starts(self):
+        """initial_i ~ U{initial_step, ..., final_step - length - H - 1} (so that the forecast window of the last
+        step still lies inside the series)."""
+        L = self.full.layout
+        hi = L.final_step - self.rows + 1
+        return torch.randint(L.initial_step, hi, (L.n_grids,), device=self.full.device, generator=self.generator)
+
+    def reset(self, starts=None):
+        self.starts = self.draw_starts() if starts is None else torch.as_tensor(starts, device=self.full.device)
+        idx = self._k + self.starts.unsqueeze(0)                               # [rows, N] absolute rows
+        self.window.cols["load_ts"].copy_(torch.gather(self.full.cols["load_ts"], 0, idx))
+        self.window.cols["pv_ts"].copy_(torch.gather(self.full.cols["pv_ts"], 0, idx))
+        if self.full.layout.has_grid:
+            idx4 = idx.unsqueeze(1).expand(-1, 4, -1)
+            self.window.cols["grid_ts"].copy_(torch.gather(self.full.cols["grid_ts"], 0, idx4))
+        return self.env.reset()
+
+    def step(self, action, **kw):
+        return self.env.step(action, **kw)
+
+    def __getattr__(self, name):              # everything else (engine, action_space, sample_action, ...) as the env
+        return getattr(self.env, name)
