@@ -123,6 +123,13 @@ int32_t mgx_log_dim(const mgx_handle *h);
 const char *mgx_log_name(const mgx_handle *h, int32_t column);   /* NULL if out of range */
 int32_t mgx_current_step(const mgx_handle *h);                   /* BaseMicrogridModule.current_step */
 
+/* Keep the step counter in DEVICE memory (enable != 0) so that a sequence of mgx_step / mgx_step_discrete / mgx_step_k /
+ * mgx_rollout_discrete / mgx_observe calls can be captured in a hipGraph (stream capture) and replayed: kernels read
+ * the counter, a one-thread kernel advances it after every step call.  While enabled, launch-time range checks are
+ * replaced by an in-kernel clamp + sticky overrun flag (reported as MGX_ERR_RANGE when the mode is switched off), and
+ * mgx_current_step() performs a blocking device read.  Disabling copies the counter back to the host. */
+int mgx_use_device_counter(mgx_handle *h, int enable, mgx_stream stream);
+
 /* ---- the hot path --------------------------------------------------------------------------------- */
 /* Microgrid.reset (microgrid.py:205-219) -> BaseMicrogridModule.reset (base_module.py:65-77): the step counter
  * returns to initial_step (or to `initial_step` if >= 0: the trajectory_func hook, microgrid.py:221-225);

@@ -67,6 +67,7 @@ SYMBOLS = {
     "mgx_log_dim": (C.c_int32, [C.c_void_p]),
     "mgx_log_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
     "mgx_current_step": (C.c_int32, [C.c_void_p]),
+    "mgx_use_device_counter": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mgx_set_window": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "mgx_set_reward_shaper": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_set_forecast_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),

@@ -43,7 +43,31 @@ struct KArgs {
     int32_t shaper;          // mgx_reward_shaper
     int32_t noise_increase;  // GaussianNoiseForecaster.increase_uncertainty
     uint64_t noise_seed;
+    // Device-resident step counter (NULL = the host passes t).  With it a sequence of steps can be captured in a
+    // hipGraph and replayed: kernels read the counter, `advance_counter` moves it, the kernel argument t is then an
+    // offset relative to it.  A replay that would run past the series is clamped to the last row and flagged.
+    int32_t *t_dev;
 };
+
+__device__ __forceinline__ int32_t resolve_t(const KArgs &a, int32_t t)
+{
+    if (a.t_dev) {
+        const int32_t td = a.t_dev[0] + t;
+        if (td >= a.T) { a.t_dev[1] = 1; return a.T - 1; }     // sticky overrun flag (all lanes write the same value)
+        return td;
+    }
+    return t;
+}
+
+// observation kernels: no clamp (t >= T is legal there: the row is end-of-series padding)
+__device__ __forceinline__ int32_t resolve_t_obs(const KArgs &a, int32_t t) { return a.t_dev ? a.t_dev[0] + t : t; }
+
+// K-step kernels in device-counter mode: never walk past the series (steps beyond it are dropped and flagged)
+__device__ __forceinline__ int32_t resolve_k(const KArgs &a, int32_t t0, int32_t K)
+{
+    if (a.t_dev && t0 + K > a.T) { a.t_dev[1] = 1; return a.T - t0; }
+    return K;
+}
 
 struct Params {
     double bat_cmin, bat_cmax, bat_C, bat_D, bat_eta, bat_cost;

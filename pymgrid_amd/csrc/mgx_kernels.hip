@@ -34,6 +34,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
                                                      uint8_t *__restrict__ done, double *__restrict__ obs,
                                                      double *__restrict__ log)
 {
+    t = resolve_t(a, t);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.N) return;
     // all loads first (independent, one latency round), then the arithmetic
@@ -93,6 +94,8 @@ template <int F, int U>
 __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const double *__restrict__ actions, int32_t t0,
                                                          int32_t K, int normalized, const FusedOut out, int32_t gpb)
 {
+    t0 = resolve_t(a, t0);
+    K = resolve_k(a, t0, K);
     // gpb = grids per workgroup (<= BLOCK_K, multiple of 16 = one 128-B line of doubles): chosen by the host so that
     // the busiest CU streams as few grids as possible (fused_grids_per_block)
     const int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x;
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const do
 template <int F>
 __global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t, double *__restrict__ obs)
 {
+    t = resolve_t_obs(a, t);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.N) return;
     Params p; State s;
@@ -174,6 +178,7 @@ template <int F, bool NOISE>
 __global__ __launch_bounds__(BLOCK) void obs_rows_kernel(const KArgs a, const WindowPlan plan, int32_t t,
                                                          double *__restrict__ obs)
 {
+    t = resolve_t_obs(a, t);
     extern __shared__ double tile[];                    // [64][plan.ld]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t g0 = (int64_t)blockIdx.x * 64;
@@ -223,6 +228,7 @@ template <int F>
 __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWords tab, const int32_t *__restrict__ action_id,
                                                        int32_t t, double *__restrict__ control)
 {
+    t = resolve_t(a, t);
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.N) return;
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
                                                               uint8_t *__restrict__ done, double *__restrict__ obs,
                                                               double *__restrict__ log)
 {
+    t = resolve_t(a, t);
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.N) return;
@@ -304,6 +311,8 @@ template <int F, int U>
 __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const PLWords tab, const uint8_t *__restrict__ ids,
                                                           int per_step, int32_t t0, int32_t K, const FusedOut out, int32_t gpb)
 {
+    t0 = resolve_t(a, t0);
+    K = resolve_k(a, t0, K);
     const int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x;
     if ((int32_t)threadIdx.x >= gpb || i >= a.N) return;
     const int64_t N = a.N;
@@ -433,6 +442,7 @@ __global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const 
                                                            uint8_t *__restrict__ done, double *__restrict__ obs,
                                                            double *__restrict__ log)
 {
+    t = resolve_t(a, t);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.N) return;
     const int64_t N = a.N;
@@ -455,6 +465,7 @@ __global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const 
 template <int F>
 __global__ __launch_bounds__(BLOCK) void observe_multi_kernel(const KArgs a, int32_t t, double *__restrict__ obs)
 {
+    t = resolve_t_obs(a, t);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.N) return;
     Params p; State s;
@@ -467,6 +478,7 @@ template <int F>
 __global__ __launch_bounds__(BLOCK) void expand_multi_kernel(const KArgs a, const PLWords tab, const int32_t *__restrict__ action_id,
                                                              int32_t t, double *__restrict__ control)
 {
+    t = resolve_t(a, t);
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.N) return;
@@ -487,6 +499,10 @@ __global__ __launch_bounds__(BLOCK) void expand_multi_kernel(const KArgs a, cons
     if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
     if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
 }
+
+// device-resident step counter (hipGraph-replayable stepping): counter[0] = t, counter[1] = overrun flag
+__global__ void set_counter_kernel(int32_t *counter, int32_t t) { counter[0] = t; counter[1] = 0; }
+__global__ void advance_counter_kernel(int32_t *counter, int32_t k) { counter[0] += k; }
 
 // ------------------------------------------------------------------------------------------------------
 // Metrics: deterministic column sums  sums[m] = sum_i values[m, i].
@@ -558,6 +574,7 @@ struct mgx_handle {
     mgx_layout layout;
     int32_t window_lo, window_hi;   // episode window given at create: trajectories must stay inside it
     bool multi;             // n_load != 1 or n_pv != 1: general (slow) kernels
+    int32_t *d_counter;     // device step counter + overrun flag (used when k.t_dev != NULL)
     int32_t n_cu;           // compute units of the device (workgroup balancing of the fused kernels)
     int32_t flags;          // F
     int32_t t;              // current step
@@ -596,6 +613,15 @@ const char *const kBatteryNames[] = {"discharge_amount", "charge_amount", "batte
 const char *const kGridNames[] = {"grid_import", "grid_export", "grid_co2_production", "grid_reward"};
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+// kernel argument for "the current step": the host's counter, or 0 (= offset to the device counter)
+inline int32_t t_arg(const mgx_handle *h) { return h->k.t_dev ? 0 : h->t; }
+inline bool dev_counter(const mgx_handle *h) { return h->k.t_dev != nullptr; }
+inline void advance(mgx_handle *h, int32_t k, hipStream_t st)
+{
+    if (h->k.t_dev) advance_counter_kernel<<<1, 1, 0, st>>>(h->d_counter, k);
+    h->t += k;
+}
 
 // dispatch a kernel template on the runtime layout flags
 #define MGX_DISPATCH_F(flags, CALL)                     \
@@ -739,6 +765,12 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
         delete h;
         return hip_fail(e, "hipMalloc(scratch)");
     }
+    h->d_counter = nullptr;
+    h->k.t_dev = nullptr;
+    if ((e = hipMalloc((void **)&h->d_counter, 2 * sizeof(int32_t))) != hipSuccess) {
+        (void)hipFree(h->scratch); delete h;
+        return hip_fail(e, "hipMalloc(counter)");
+    }
     *out = h;
     return MGX_OK;
 }
@@ -747,13 +779,44 @@ void mgx_destroy(mgx_handle *h)
 {
     if (!h) return;
     if (h->scratch) (void)hipFree(h->scratch);
+    if (h->d_counter) (void)hipFree(h->d_counter);
     delete h;
 }
 
 int32_t mgx_action_dim(const mgx_handle *h) { return h ? h->action_dim : -1; }
 int32_t mgx_obs_dim(const mgx_handle *h) { return h ? h->k.obs_dim : -1; }
 int32_t mgx_log_dim(const mgx_handle *h) { return h ? h->k.log_dim : -1; }
-int32_t mgx_current_step(const mgx_handle *h) { return h ? h->t : -1; }
+int32_t mgx_current_step(const mgx_handle *h)
+{
+    if (!h) return -1;
+    if (h->k.t_dev) {                    // device-counter mode: the truth lives on the device (blocking read)
+        int32_t c[2] = {0, 0};
+        if (hipMemcpy(c, h->d_counter, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return c[0];
+    }
+    return h->t;
+}
+
+int mgx_use_device_counter(mgx_handle *h, int enable, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_use_device_counter: NULL handle");
+    hipStream_t st = (hipStream_t)stream;
+    if (enable) {
+        set_counter_kernel<<<1, 1, 0, st>>>(h->d_counter, h->t);
+        h->k.t_dev = h->d_counter;
+    } else if (h->k.t_dev) {
+        int32_t c[2] = {0, 0};
+        hipError_t e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipMemcpy(c, h->d_counter, sizeof(c), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "mgx_use_device_counter: reading the counter back");
+        h->t = c[0];
+        h->k.t_dev = nullptr;
+        if (c[1]) return fail(MGX_ERR_RANGE, "a replayed step ran past the end of the time series (length %d)", h->k.T);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "mgx_use_device_counter");
+}
 
 const char *mgx_log_name(const mgx_handle *h, int32_t col)
 {
@@ -780,7 +843,7 @@ int mgx_observe(mgx_handle *h, double *obs, mgx_stream stream)
     g_err[0] = 0;
     if (!h || !obs) return fail(MGX_ERR_INVALID, "mgx_observe: NULL argument");
     if (int rc = need_obs_bounds(h, "mgx_observe")) return rc;
-    if (int rc = launch_observe(h, h->t, obs, (hipStream_t)stream)) return rc;
+    if (int rc = launch_observe(h, t_arg(h), obs, (hipStream_t)stream)) return rc;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "observe launch");
 }
@@ -831,6 +894,7 @@ int mgx_reset(mgx_handle *h, int32_t initial_step, double *obs, mgx_stream strea
     if (t0 >= h->layout.final_step)
         return fail(MGX_ERR_INVALID, "mgx_reset: initial_step %d must be below final_step %d", t0, h->layout.final_step);
     h->t = t0;                       // base_module.py:292-296 -- nothing else is restored
+    if (h->k.t_dev) set_counter_kernel<<<1, 1, 0, (hipStream_t)stream>>>(h->d_counter, t0);
     return obs ? mgx_observe(h, obs, stream) : MGX_OK;
 }
 
@@ -839,25 +903,25 @@ int mgx_step(mgx_handle *h, const double *actions, int normalized, double *rewar
 {
     g_err[0] = 0;
     if (!h || !reward || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_step: NULL argument");
-    if (h->t < 0 || h->t >= h->k.T)
+    if (!dev_counter(h) && (h->t < 0 || h->t >= h->k.T))
         return fail(MGX_ERR_RANGE, "mgx_step: step %d is outside the time series (length %d)", h->t, h->k.T);
     if (obs) { if (int rc = need_obs_bounds(h, "mgx_step")) return rc; }
     hipStream_t st = (hipStream_t)stream;
     if (h->multi) {
-        MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, h->t, normalized,
+        MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, t_arg(h), normalized,
                                                                                               reward, done, obs, log)));
         hipError_t em = hipGetLastError();
         if (em != hipSuccess) return hip_fail(em, "step_multi_kernel launch");
-        h->t += 1;
+        advance(h, 1, st);
         return MGX_OK;
     }
     double *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
-    MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, h->t, normalized, reward,
+    MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, t_arg(h), normalized, reward,
                                                                                     done, obs_inline, log)));
-    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, h->t + 1, obs, st)) return rc; }
+    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, t_arg(h) + 1, obs, st)) return rc; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_kernel launch");
-    h->t += 1;
+    advance(h, 1, st);
     return MGX_OK;
 }
 
@@ -869,16 +933,16 @@ int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized, 
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_step_k: K must be positive");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: fused steps need exactly one load and one renewable module "
                                                     "per grid; use mgx_step");
-    if (h->t < 0 || (int64_t)h->t + K > h->k.T)
+    if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > h->k.T))
         return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
     hipStream_t st = (hipStream_t)stream;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     const int32_t gpb = fused_grids_per_block(h);
     MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING><<<(unsigned)((h->k.N + gpb - 1) / gpb), BLOCK_K, 0, st>>>(
-                                  h->k, actions, h->t, K, normalized, fo, gpb)));
+                                  h->k, actions, t_arg(h), K, normalized, fo, gpb)));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_k_kernel launch");
-    h->t += K;
+    advance(h, K, st);
     return MGX_OK;
 }
 
@@ -909,15 +973,15 @@ int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *
 {
     g_err[0] = 0;
     if (!h || !action_id || !table || !control) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: NULL argument");
-    if (h->t < 0 || h->t >= h->k.T)
+    if (!dev_counter(h) && (h->t < 0 || h->t >= h->k.T))
         return fail(MGX_ERR_RANGE, "mgx_expand_discrete: step %d is outside the time series (length %d)", h->t, h->k.T);
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_expand_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->multi) {
-        MGX_DISPATCH_F(h->flags, (expand_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, h->t, control)));
+        MGX_DISPATCH_F(h->flags, (expand_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, t_arg(h), control)));
     } else {
-        MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, h->t, control)));
+        MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, t_arg(h), control)));
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "expand_kernel launch");
@@ -930,19 +994,19 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
     if (!h || !action_id || !table || !reward) return fail(MGX_ERR_INVALID, "mgx_step_discrete: NULL argument");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_discrete: needs exactly one load and one renewable module per "
                                                     "grid; use mgx_expand_discrete + mgx_step");
-    if (h->t < 0 || h->t >= h->k.T)
+    if (!dev_counter(h) && (h->t < 0 || h->t >= h->k.T))
         return fail(MGX_ERR_RANGE, "mgx_step_discrete: step %d is outside the time series (length %d)", h->t, h->k.T);
     if (obs) { if (int rc = need_obs_bounds(h, "mgx_step_discrete")) return rc; }
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_step_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
     double *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
-    MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, h->t, control,
+    MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, t_arg(h), control,
                                                                                              reward, done, obs_inline, log)));
-    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, h->t + 1, obs, st)) return rc; }
+    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, t_arg(h) + 1, obs, st)) return rc; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_discrete_kernel launch");
-    h->t += 1;
+    advance(h, 1, st);
     return MGX_OK;
 }
 
@@ -955,7 +1019,7 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: K must be positive");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: needs exactly one load and one renewable module "
                                                     "per grid; use mgx_expand_discrete + mgx_step");
-    if (h->t < 0 || (int64_t)h->t + K > h->k.T)
+    if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > h->k.T))
         return fail(MGX_ERR_RANGE, "mgx_rollout_discrete: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_rollout_discrete")) return rc;
@@ -963,10 +1027,10 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     hipStream_t st = (hipStream_t)stream;
     const int32_t gpb = fused_grids_per_block(h);
     MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING><<<(unsigned)((h->k.N + gpb - 1) / gpb), BLOCK_K, 0, st>>>(
-                                  h->k, tab, action_id, per_step, h->t, K, fo, gpb)));
+                                  h->k, tab, action_id, per_step, t_arg(h), K, fo, gpb)));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rollout_kernel launch");
-    h->t += K;
+    advance(h, K, st);
     return MGX_OK;
 }
 

@@ -94,6 +94,11 @@ class StepEngine:
     def current_step(self):
         return self._lib.mgx_current_step(self._h)
 
+    def use_device_counter(self, enable=True):
+        """Keep the step counter on the device so that step calls can be captured in a HIP graph
+        (``torch.cuda.graph``) and replayed; see ``mgx_use_device_counter`` in include/mgx.h."""
+        self._call(self._lib.mgx_use_device_counter, 1 if enable else 0)
+
     def set_window(self, initial_step, final_step):
         """Episode window of the next reset (what a trajectory_func returns, microgrid.py:221-225)."""
         check(self._lib.mgx_set_window(self._h, int(initial_step), int(final_step)))

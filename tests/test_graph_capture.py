@@ -1,0 +1,67 @@
+"""HIP-graph capture of env steps (device-resident step counter): a graph of 8 single steps, replayed, must equal the
+same steps issued eagerly -- rewards, observations, state and the step counter."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_captured_steps_replay_like_eager(device):
+    from pymgrid_amd import StepEngine
+    from pymgrid_amd.generator import generate
+    N, T, S, R = 5000, 200, 8, 5                 # graph of S steps, replayed R times
+    gen = torch.Generator(device=device); gen.manual_seed(1)
+    acts = torch.rand(R * S, N, 3, dtype=torch.float64, device=device, generator=gen)
+    eager = StepEngine(generate(N, n_steps=T, seed=4, device=device, mixed_timers=True))
+    ref_r, ref_o = [], []
+    for k in range(R * S):
+        o, r, d, _ = eager.step(acts[k])
+        ref_r.append(r.clone()); ref_o.append(o.clone())
+
+    eng = StepEngine(generate(N, n_steps=T, seed=4, device=device, mixed_timers=True))
+    eng.use_device_counter(True)
+    static_a = torch.zeros(S, N, 3, dtype=torch.float64, device=device)
+    bufs = [dict(reward=torch.empty(N, dtype=torch.float64, device=device),
+                 done=torch.empty(N, dtype=torch.uint8, device=device),
+                 obs=torch.empty(N, eng.obs_dim, dtype=torch.float64, device=device)) for _ in range(S)]
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for k in range(S):
+                eng.step(static_a[k], want_obs=True, out=bufs[k])
+    torch.cuda.current_stream(device).wait_stream(side)
+    # capturing does not execute: the counter is still at 0
+    assert eng.current_step == 0
+    for rep in range(R):
+        static_a.copy_(acts[rep * S:(rep + 1) * S])
+        graph.replay()
+        torch.cuda.synchronize(device)
+        for k in range(S):
+            assert torch.equal(bufs[k]["reward"], ref_r[rep * S + k]), (rep, k)
+            assert torch.equal(bufs[k]["obs"], ref_o[rep * S + k]), (rep, k)
+    assert eng.current_step == R * S == eager.current_step
+    for name in ("charge", "soc", "gen_status"):
+        assert torch.equal(eng.batch.cols[name], eager.batch.cols[name])
+    eng.use_device_counter(False)                 # counter copied back to the host, eager stepping continues
+    assert eng.current_step == R * S
+    o1, r1, _, _ = eng.step(acts[0]); o2, r2, _, _ = eager.step(acts[0])
+    assert torch.equal(r1, r2) and torch.equal(o1, o2)
+    eng.close(); eager.close()
+
+
+def test_replay_past_the_series_is_flagged(device):
+    from pymgrid_amd import MgxError, StepEngine
+    from pymgrid_amd.generator import generate
+    N, T = 1000, 12
+    eng = StepEngine(generate(N, n_steps=T, seed=4, device=device))
+    eng.use_device_counter(True)
+    a = torch.rand(N, 3, dtype=torch.float64, device=device)
+    for _ in range(T + 3):                        # no launch-time range check in this mode: clamped + flagged in-kernel
+        eng.step(a, want_obs=False)
+    with pytest.raises(MgxError) as e:
+        eng.use_device_counter(False)
+    assert e.value.code == 3
+    eng.close()
