@@ -59,6 +59,17 @@ __device__ __forceinline__ int32_t resolve_t(const KArgs &a, int32_t t)
     return t;
 }
 
+// Device-counter mode: the LAST workgroup of a stepping kernel to finish moves the counter by `k` steps
+// (counter[2] counts finished workgroups).  Every workgroup read the counter at its very start, i.e. before its own
+// arrival here, so nobody can observe the new value inside this launch; the next launch sees it (kernel boundary).
+__device__ __forceinline__ void advance_counter_in_kernel(const KArgs &a, int32_t k)
+{
+    if (a.t_dev && threadIdx.x == 0) {
+        const unsigned prev = atomicAdd((unsigned *)&a.t_dev[2], 1u);
+        if (prev == gridDim.x - 1) { a.t_dev[2] = 0; a.t_dev[0] += k; }
+    }
+}
+
 // observation kernels: no clamp (t >= T is legal there: the row is end-of-series padding)
 __device__ __forceinline__ int32_t resolve_t_obs(const KArgs &a, int32_t t) { return a.t_dev ? a.t_dev[0] + t : t; }
 

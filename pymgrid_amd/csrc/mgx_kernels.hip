@@ -55,6 +55,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
     // one (H > 0) the host launches obs_rows_kernel behind this kernel and passes obs == nullptr
     if (obs) observe_row_h0<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
+    advance_counter_in_kernel(a, 1);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -94,6 +95,7 @@ template <int F, int U>
 __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const double *__restrict__ actions, int32_t t0,
                                                          int32_t K, int normalized, const FusedOut out, int32_t gpb)
 {
+    const int32_t K_launch = K;          // what the host asked for (the counter always moves by this much)
     t0 = resolve_t(a, t0);
     K = resolve_k(a, t0, K);
     // gpb = grids per workgroup (<= BLOCK_K, multiple of 16 = one 128-B line of doubles): chosen by the host so that
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const do
     if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
     store_state<F>(a.c, i, s);
     if (out.ret_acc) out.ret_acc[i] += ret;
+    advance_counter_in_kernel(a, K_launch);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
     if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
     if (log) store_log<F>(log + i, N, o, s.status);
     if (obs) observe_row_h0<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
+    advance_counter_in_kernel(a, 1);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -311,6 +315,7 @@ template <int F, int U>
 __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const PLWords tab, const uint8_t *__restrict__ ids,
                                                           int per_step, int32_t t0, int32_t K, const FusedOut out, int32_t gpb)
 {
+    const int32_t K_launch = K;          // what the host asked for (the counter always moves by this much)
     t0 = resolve_t(a, t0);
     K = resolve_k(a, t0, K);
     const int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x;
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
     if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
     store_state<F>(a.c, i, s);
     if (out.ret_acc) out.ret_acc[i] += ret;
+    advance_counter_in_kernel(a, K_launch);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -460,6 +466,7 @@ __global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const 
     if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
     if (log) store_log<F>(log + i, N, o, s.status);
     if (obs) observe_row_multi<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
+    advance_counter_in_kernel(a, 1);
 }
 
 template <int F>
@@ -501,8 +508,7 @@ __global__ __launch_bounds__(BLOCK) void expand_multi_kernel(const KArgs a, cons
 }
 
 // device-resident step counter (hipGraph-replayable stepping): counter[0] = t, counter[1] = overrun flag
-__global__ void set_counter_kernel(int32_t *counter, int32_t t) { counter[0] = t; counter[1] = 0; }
-__global__ void advance_counter_kernel(int32_t *counter, int32_t k) { counter[0] += k; }
+__global__ void set_counter_kernel(int32_t *counter, int32_t t) { counter[0] = t; counter[1] = 0; counter[2] = 0; }
 
 // ------------------------------------------------------------------------------------------------------
 // Metrics: deterministic column sums  sums[m] = sum_i values[m, i].
@@ -619,7 +625,7 @@ inline int32_t t_arg(const mgx_handle *h) { return h->k.t_dev ? 0 : h->t; }
 inline bool dev_counter(const mgx_handle *h) { return h->k.t_dev != nullptr; }
 inline void advance(mgx_handle *h, int32_t k, hipStream_t st)
 {
-    if (h->k.t_dev) advance_counter_kernel<<<1, 1, 0, st>>>(h->d_counter, k);
+    (void)st;                    // device-counter mode: the stepping kernel itself advanced the counter
     h->t += k;
 }
 
@@ -767,7 +773,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     }
     h->d_counter = nullptr;
     h->k.t_dev = nullptr;
-    if ((e = hipMalloc((void **)&h->d_counter, 2 * sizeof(int32_t))) != hipSuccess) {
+    if ((e = hipMalloc((void **)&h->d_counter, 4 * sizeof(int32_t))) != hipSuccess) {
         (void)hipFree(h->scratch); delete h;
         return hip_fail(e, "hipMalloc(counter)");
     }
@@ -918,7 +924,7 @@ int mgx_step(mgx_handle *h, const double *actions, int normalized, double *rewar
     double *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
     MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, t_arg(h), normalized, reward,
                                                                                     done, obs_inline, log)));
-    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, t_arg(h) + 1, obs, st)) return rc; }
+    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_kernel launch");
     advance(h, 1, st);
@@ -1003,7 +1009,7 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
     double *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
     MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, t_arg(h), control,
                                                                                              reward, done, obs_inline, log)));
-    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, t_arg(h) + 1, obs, st)) return rc; }
+    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_discrete_kernel launch");
     advance(h, 1, st);
