@@ -263,8 +263,12 @@ def main():
                                  "roofline": r["roofline"]} for m, r in results.items() if m != args.mode},
             "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total},
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
