@@ -67,6 +67,31 @@ class BatchLayout:
             names += ["grid"]
         return names
 
+    @property
+    def obs_names(self):
+        """State-key name of every flat observation column, as the reference's ``state_dict`` spells them
+        (base_timeseries_module.py:90-97 ``<component>_current`` / ``<component>_forecast_<j>``; genset_module.py:426-431;
+        battery_module.py:280-281; grid_module.py:70)."""
+        H = self.horizon
+
+        def window(components):
+            names = [f"{c}_current" for c in components]
+            for j in range(H):
+                names += [f"{c}_forecast_{j}" for c in components]
+            return names
+        names = []
+        for _ in range(self.n_load):
+            names += window(["load"])
+        for _ in range(self.n_pv):
+            names += window(["renewable"])
+        if self.has_genset:
+            names += ["current_status", "goal_status", "steps_until_up", "steps_until_down"]
+        if self.has_battery:
+            names += ["soc", "current_charge"]
+        if self.has_grid:
+            names += window(["import_price", "export_price", "co2_per_kwh", "grid_status"])
+        return names
+
     def obs_slices(self):
         """name -> slice of the flat observation (order load, pv, genset, battery, grid)."""
         w, k, out = 1 + self.horizon, 0, {}

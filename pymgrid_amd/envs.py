@@ -33,7 +33,7 @@ class BatchedMicrogridEnv:
     v1.2.2)."""
 
     def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
-                 raise_errors=False):
+                 raise_errors=False, observation_keys=None):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
         # raise_errors=True (base_module.py:79-93): the device always clips; the step's `violations` log column
@@ -57,7 +57,19 @@ class BatchedMicrogridEnv:
         self._shaped_rows = []
         A = self.layout.action_dim
         self.action_space = Box(0.0, 1.0, shape=(A,))                       # normalised control
-        self.observation_space = Box(0.0, 1.0, shape=(self.layout.obs_dim,))  # normalised observation
+        # observation_keys (envs/base/base.py:109-163,211-223): the observation is the listed state keys, in the
+        # order of the list; unknown keys are a NameError as in _validate_observation_keys
+        self.observation_keys = list(observation_keys) if observation_keys else None
+        self._obs_index = None
+        if self.observation_keys:
+            names = self.layout.obs_names
+            bad = [k for k in self.observation_keys if k not in names]
+            if bad:
+                raise NameError(f'Keys {bad} not found in state.')
+            idx = [j for k in self.observation_keys for j, n in enumerate(names) if n == k]
+            self._obs_index = torch.as_tensor(idx, dtype=torch.long, device=batch.device)
+        D = len(self._obs_index) if self._obs_index is not None else self.layout.obs_dim
+        self.observation_space = Box(0.0, 1.0, shape=(D,))                  # normalised observation
 
     # ---- reference-like properties ------------------------------------------------------------------
     @property
@@ -97,7 +109,12 @@ class BatchedMicrogridEnv:
         self._shaped_rows = []
         if self.trajectory_func is not None and initial_step is None:
             self._draw_window()
-        return self.engine.reset(initial_step, want_obs=self._observations)
+        return self._select_obs(self.engine.reset(initial_step, want_obs=self._observations))
+
+    def _select_obs(self, obs):
+        if obs is None or self._obs_index is None:
+            return obs
+        return obs.index_select(1, self._obs_index)
 
     def step(self, action, normalized=True):
         """action: float64 tensor [N, A] (columns ``layout.action_names``) or a control dict as taken by
@@ -113,7 +130,7 @@ class BatchedMicrogridEnv:
             info["log"] = log
             if self.raise_errors:
                 self._raise_on_violations(log[-1])
-        return obs, reward, done.view(torch.bool), info       # 0/1 bytes reinterpreted, no conversion kernel
+        return self._select_obs(obs), reward, done.view(torch.bool), info   # 0/1 bytes reinterpreted, no conversion kernel
 
     _VIOLATIONS = ((1, "Genset", "supply requested value as a source (outside [min_production, max_production])"),
                    (2, "BatteryModule", "supply / absorb requested value (above max_production / max_consumption)"),
@@ -229,9 +246,9 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
     into an unnormalised control and stepped with ``normalized=False`` (discrete.py:109-143)."""
 
     def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
-                 trajectory_func=None, raise_errors=False):
+                 trajectory_func=None, raise_errors=False, observation_keys=None):
         super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
-                         trajectory_func=trajectory_func, raise_errors=raise_errors)
+                         trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys)
         L = self.layout
         redundant = False
         if remove_redundant_gensets and L.has_genset:
@@ -269,7 +286,7 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
             info["log"] = log
             if self.raise_errors:
                 self._raise_on_violations(log[-1])
-        return obs, reward, done.view(torch.bool), info
+        return self._select_obs(obs), reward, done.view(torch.bool), info
 
     def sample_action(self, generator=None):
         return torch.randint(0, self.action_space.n, (self.n_grids,), dtype=torch.int32, device=self.batch.device,
@@ -288,7 +305,7 @@ class _SingleMixin:
 
     def _obs_out(self, obs):
         row = obs[0].cpu().numpy()
-        return row if self.flat_spaces else self._nested(row)
+        return row if (self.flat_spaces or self._obs_index is not None) else self._nested(row)
 
     def _info_out(self, info):
         if "log" not in info:
@@ -302,10 +319,10 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
     ``(obs, float, bool, dict)`` exactly like envs/base/base.py:169-209."""
 
     def __init__(self, params, device="cuda", flat_spaces=True, log=True, reward_shaping_func=None,
-                 trajectory_func=None, raise_errors=False):
+                 trajectory_func=None, raise_errors=False, observation_keys=None):
         super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
                          reward_shaping_func=reward_shaping_func, trajectory_func=trajectory_func,
-                         raise_errors=raise_errors)
+                         raise_errors=raise_errors, observation_keys=observation_keys)
         self.flat_spaces = flat_spaces
 
     def reset(self, initial_step=None):
@@ -323,10 +340,10 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
     ``step(action: int) -> (obs, reward: float, done: bool, info: dict)``."""
 
     def __init__(self, params, device="cuda", flat_spaces=True, log=True, remove_redundant_gensets=True,
-                 reward_shaping_func=None, trajectory_func=None, raise_errors=False):
+                 reward_shaping_func=None, trajectory_func=None, raise_errors=False, observation_keys=None):
         super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
                          remove_redundant_gensets=remove_redundant_gensets, reward_shaping_func=reward_shaping_func,
-                         trajectory_func=trajectory_func, raise_errors=raise_errors)
+                         trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys)
         self.flat_spaces = flat_spaces
 
     def reset(self, initial_step=None):

@@ -589,7 +589,37 @@ def make_shaping():
     save("shaping.npz", **out)
 
 
+# --------------------------------------------------------------------------------------------- #
+def make_obskeys():
+    """BaseMicrogridEnv(observation_keys=...) (envs/base/base.py:109-163,211-223; tests/envs/test_discrete.py:82-95)."""
+    out = {}
+    keys = ["soc", "load_current", "import_price_current", "current_status", "renewable_forecast_3",
+            "grid_status_forecast_0", "steps_until_down"]
+    all_keys = keys
+    for n in (1, 0, 2):
+        m0 = Microgrid.from_scenario(n)
+        have = set(m0.state_series().index.get_level_values(-1))
+        keys = [k for k in all_keys if k in have]                  # a key absent from the state is a NameError
+        out[f"s{n}_keys"] = np.array(keys)
+        env = DiscreteMicrogridEnv.from_scenario(n, observation_keys=keys)
+        obs0 = np.asarray(env.reset(), dtype=np.float64)
+        ids = np.random.RandomState(7000 + n).randint(0, env.action_space.n, size=30)
+        rows = []
+        for a in ids:
+            o, r, d, _ = env.step(int(a))
+            rows.append(np.asarray(o, dtype=np.float64))
+        out[f"s{n}_obs0"] = obs0
+        out[f"s{n}_obs"] = np.stack(rows)
+        out[f"s{n}_ids"] = ids.astype(np.int32)
+        ss = env.state_series(normalized=True)
+        import pandas as pd
+        sel = ss.loc[pd.IndexSlice[:, :, keys]]
+        out[f"s{n}_key_order"] = np.array([k[2] for k in sel.index])
+        print(n, obs0.shape, list(out[f"s{n}_key_order"]))
+    save("obskeys.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pymgrid25", "discrete", "genset_fsm", "obs", "generated", "loadpv", "rbc", "shaping"]
+    which = sys.argv[1:] or ["pymgrid25", "discrete", "genset_fsm", "obs", "generated", "loadpv", "rbc", "shaping", "obskeys"]
     for w in which:
         globals()["make_" + w]()

@@ -478,3 +478,21 @@ def test_per_grid_episode_windows(pymgrid25, device, oracle):
     drawn = env.reset()                       # random starts: inside the admissible range
     assert int(env.starts.min()) >= 0 and int(env.starts.max()) + 48 + 23 < 8759
     env.close()
+
+
+def test_observation_keys_vs_reference(pymgrid25, device):
+    """BaseMicrogridEnv(observation_keys=...) (reference tests/envs/test_discrete.py:82-95): the observation is the
+    listed state keys in list order; unknown keys raise NameError."""
+    from pymgrid_amd import DiscreteMicrogridEnv
+    z = golden("obskeys.npz")
+    for n in (1, 0, 2):
+        keys = [str(k) for k in z[f"s{n}_keys"]]
+        env = DiscreteMicrogridEnv(pymgrid25[n], device=device, observation_keys=keys)
+        assert env.observation_space.shape == (len(keys),)
+        assert np.array_equal(env.reset(), z[f"s{n}_obs0"])
+        for k, a in enumerate(z[f"s{n}_ids"]):
+            obs, _, _, _ = env.step(int(a))
+            assert np.array_equal(obs, z[f"s{n}_obs"][k]), (n, k)
+        env.close()
+    with pytest.raises(NameError):
+        DiscreteMicrogridEnv(pymgrid25[0], device=device, observation_keys=["current_status"])
