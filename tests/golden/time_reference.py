@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build-container only: time the REAL reference (pymgrid 1.2.2 imported from /root/reference) on Template-4 grids
 drawn with the benchmark's generator (same sizing rules), next to this repo's C oracle on the same grids.
-Usage: python tools/time_reference.py [n_grids] [steps]   -> prints env-steps/s on one core."""
+Usage: python tests/golden/time_reference.py [n_grids] [steps]   -> prints env-steps/s on one core."""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ import warnings
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 warnings.simplefilter("ignore")
 import _refenv  # noqa: E402
