@@ -24,6 +24,9 @@ constexpr int BLOCK = MGX_BLOCK;
 #define MGX_BLOCK_K 256     // workgroup size of the fused kernel
 #endif
 constexpr int BLOCK_K = MGX_BLOCK_K;
+#ifndef MGX_RING_ROLLOUT
+#define MGX_RING_ROLLOUT 4  // ring depth of the discrete rollout kernel (its slots are small: 2..6 doubles + an id byte)
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // Single step: Microgrid.run for N grids (microgrid.py:227-325) + optional obs (base.py:205-209) + log.
@@ -1032,7 +1035,7 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     hipStream_t st = (hipStream_t)stream;
     const int32_t gpb = fused_grids_per_block(h);
-    MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING><<<(unsigned)((h->k.N + gpb - 1) / gpb), BLOCK_K, 0, st>>>(
+    MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT><<<(unsigned)((h->k.N + gpb - 1) / gpb), BLOCK_K, 0, st>>>(
                                   h->k, tab, action_id, per_step, t_arg(h), K, fo, gpb)));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rollout_kernel launch");
