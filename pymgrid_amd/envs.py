@@ -299,6 +299,28 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
 class _SingleMixin:
     flat_spaces = True
 
+    @classmethod
+    def from_scenario(cls, microgrid_number=0, root=None, **kwargs):
+        """``Env.from_scenario(n)`` (envs/base/base.py:290-296).  ``root`` is the directory that holds ``pymgrid25/``
+        (``<pymgrid>/data/scenario``); with ``root=None`` the scenario is read from an installed ``pymgrid`` package's
+        data directory if there is one."""
+        from .scenario import from_scenario
+        if root is None:
+            import importlib.util
+            import os
+            spec = importlib.util.find_spec("pymgrid")
+            if spec is None or not spec.submodule_search_locations:
+                raise FileNotFoundError("pass root=<.../data/scenario>: no pymgrid installation to take the scenario "
+                                        "files from")
+            root = os.path.join(list(spec.submodule_search_locations)[0], "data", "scenario")
+        return cls(from_scenario(microgrid_number, root), **kwargs)
+
+    @classmethod
+    def load(cls, path, **kwargs):
+        """``Env.load(stream)`` (microgrid.py:847-864): a serialised ``!Microgrid`` YAML file."""
+        from .scenario import load_scenario_yaml
+        return cls(load_scenario_yaml(path), **kwargs)
+
     def _nested(self, obs_row):
         """flat row -> {'load': [arr], 'pv': [arr], 'genset': [arr], 'battery': [arr], 'grid': [arr]}."""
         return {name: [obs_row[sl].copy()] for name, sl in self.layout.obs_slices().items()}
@@ -368,6 +390,10 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
             raise ValueError(f" Action {action} not in action space {self.action_space}")
         obs, reward, done, info = super().step(np.array([int(action)]))
         return self._obs_out(obs), float(reward.item()), bool(done.item()), self._info_out(info)
+
+    def sample_action(self, strict_bound=False, sample_flex_modules=False):
+        """DiscreteMicrogridEnv.sample_action (discrete.py:145-146): a random priority-list index."""
+        return self.action_space.sample()
 
     def priority_list_names(self, action):
         return [(MODULE_NAMES[m], a) for m, a in self.actions_list[action]]
