@@ -648,12 +648,12 @@ __device__ __forceinline__ void observe_window_item(const double *__restrict__ t
                                                     int32_t T, int32_t t, int64_t g0, int32_t h0, int32_t nh,
                                                     double *row /* tile + lane*LD + first column of this item */,
                                                     const double *__restrict__ noise_std, uint32_t comp_base,
-                                                    uint64_t noise_seed, int noise_increase)
+                                                    uint64_t noise_seed, int noise_increase, int32_t G)
 {
     constexpr int HB = OBS_CH / NC;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;          // lanes >= G (group smaller than a wave: very wide rows) only idle
     const int64_t i = g0 + lane;
-    const int64_t ic = i < N ? i : g0;
+    const int64_t ic = (lane < G && i < N) ? i : g0;
     double lo[NC], hi[NC], fill[NC], sp[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
@@ -685,6 +685,7 @@ __device__ __forceinline__ void observe_window_item(const double *__restrict__ t
             }
         }
     }
+    if (lane >= G) return;
 #pragma unroll
     for (int hh = 0; hh < HB; hh++)
         if (hh < nh) {

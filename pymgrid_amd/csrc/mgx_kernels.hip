@@ -178,6 +178,7 @@ struct WindowPlan {
     int32_t hpc_ts, hpc_grid;   // horizon steps per chunk (balanced: ceil((1+H) / chunks))
     int32_t grid_col_base;   // first obs column of the grid window
     int32_t ld;              // LDS row pitch in doubles (odd: conflict-free column writes)
+    int32_t group;           // grids per workgroup: 64, or 32 / 16 / 8 when a 64-row tile would not fit the LDS
 };
 
 template <int F, bool NOISE>
@@ -185,9 +186,10 @@ __global__ __launch_bounds__(BLOCK) void obs_rows_kernel(const KArgs a, const Wi
                                                          double *__restrict__ obs)
 {
     t = resolve_t_obs(a, t);
-    extern __shared__ double tile[];                    // [64][plan.ld]
+    extern __shared__ double tile[];                    // [plan.group][plan.ld]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t g0 = (int64_t)blockIdx.x * 64;
+    const int32_t G = plan.group;
+    const int64_t g0 = (int64_t)blockIdx.x * G;
     const int64_t N = a.N;
     const int32_t W = 1 + a.H, D = a.obs_dim, LD = plan.ld;
     const int32_t n_chunks = 2 * plan.chunks_ts + plan.chunks_grid;
@@ -200,20 +202,20 @@ __global__ __launch_bounds__(BLOCK) void obs_rows_kernel(const KArgs a, const Wi
             observe_window_item<1, NOISE>(is_pv ? a.c.pv_ts : a.c.load_ts, N, N, is_pv ? a.c.pv_lo : a.c.load_lo,
                                    is_pv ? a.c.pv_hi : a.c.load_hi, a.T, t, g0, h0, nh, row + (is_pv ? W : 0) + h0,
                                    is_pv ? a.c.pv_noise_std : a.c.load_noise_std, is_pv ? 1u : 0u, a.noise_seed,
-                                   a.noise_increase);
+                                   a.noise_increase, G);
         } else {
             if constexpr (F & F_GRID) {
                 const int32_t h0 = (chunk - 2 * plan.chunks_ts) * plan.hpc_grid;
                 const int32_t nh = (W - h0 < plan.hpc_grid) ? W - h0 : plan.hpc_grid;
                 observe_window_item<4, NOISE>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, g0, h0, nh,
                                        row + plan.grid_col_base + 4 * h0, a.c.grid_noise_std, 2u, a.noise_seed,
-                                       a.noise_increase);
+                                       a.noise_increase, G);
             }
         }
     }
     if (wave == n_chunks % (BLOCK / 64)) {               // the least loaded wave adds the 6 state columns
         const int64_t i = g0 + lane;
-        if (i < N) {
+        if (lane < G && i < N) {
             Params p; State s;
             load_state<F>(a.c, i, true, s);
             load_params<F>(a.c, i, p);
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(BLOCK) void obs_rows_kernel(const KArgs a, const Wi
         }
     }
     __syncthreads();
-    const int32_t n_valid = (N - g0 < 64) ? (int32_t)(N - g0) : 64;
+    const int32_t n_valid = (N - g0 < G) ? (int32_t)(N - g0) : G;
     double *out = obs + g0 * D;
     for (int32_t g = wave; g < n_valid; g += BLOCK / 64)
         for (int32_t j = lane; j < D; j += 64) out[(int64_t)g * D + j] = tile[g * LD + j];
@@ -701,10 +703,12 @@ static int launch_observe(const mgx_handle *h, int32_t t, double *obs, hipStream
     plan.hpc_grid = plan.chunks_grid ? (W + plan.chunks_grid - 1) / plan.chunks_grid : 0;
     plan.grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
     plan.ld = D | 1;
-    const size_t lds = (size_t)64 * plan.ld * sizeof(double);
+    plan.group = 64;                                   // rows of the LDS tile; halve until it fits 80 KiB (two workgroups per CU)
+    while (plan.group > 8 && (size_t)plan.group * plan.ld * sizeof(double) > 80 * 1024) plan.group /= 2;
+    const size_t lds = (size_t)plan.group * plan.ld * sizeof(double);
     if (lds > 160 * 1024)
         return fail(MGX_ERR_UNSUPPORTED, "observation rows of %d values do not fit the 160 KiB LDS tile (horizon too large)", D);
-    const unsigned blocks = (unsigned)(((int64_t)h->k.N + 63) / 64);
+    const unsigned blocks = (unsigned)(((int64_t)h->k.N + plan.group - 1) / plan.group);
     MGX_DISPATCH_F(h->flags, (launch_obs_rows<F>(h->k, plan, t, obs, blocks, lds, st)));
     return MGX_OK;
 }

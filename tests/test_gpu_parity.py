@@ -496,3 +496,40 @@ def test_observation_keys_vs_reference(pymgrid25, device):
         env.close()
     with pytest.raises(NameError):
         DiscreteMicrogridEnv(pymgrid25[0], device=device, observation_keys=["current_status"])
+
+
+@pytest.mark.parametrize("H", [1, 7, 8, 9, 30, 31, 32, 33, 40, 63, 64, 70])
+def test_observation_window_chunk_boundaries(H, device, oracle):
+    """Forecast horizons around the window-chunk sizes (32 columns for load / pv, 8 horizon steps for the 4-component
+    grid window), ragged N, steps that run into the end-of-series padding: device observation == oracle."""
+    from pymgrid_amd import StepEngine
+    rs = np.random.RandomState(H)
+    T, N = 90, 130
+    grids = []
+    for i in range(N):
+        g = dict(load_ts=50 * rs.rand(T), pv_ts=40 * rs.rand(T) * (rs.rand(T) > 0.3), horizon=H, final_step=T,
+                 initial_step=0, unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0),
+                 battery=dict(min_capacity=20.0, max_capacity=100.0, max_charge=25.0, max_discharge=25.0,
+                              efficiency=0.9, battery_cost_cycle=0.02, init_soc=0.5),
+                 grid=dict(max_import=60.0, max_export=30.0, cost_per_unit_co2=0.1),
+                 grid_ts=np.stack([0.1 + rs.rand(T), 0.5 * rs.rand(T), 0.3 * rs.rand(T),
+                                   (rs.rand(T) > 0.2).astype(float)], axis=1))
+        if i % 2:
+            g["genset"] = None
+        grids.append(g)
+    for sub in ([g for g in grids if g.get("genset", 1) is None],):
+        for g in sub:
+            g.pop("genset")
+        eng = StepEngine(_batch(sub, device))
+        oms = [oracle.OracleMicrogrid(g) for g in sub[:12]]
+        for start in (0, T - H - 3 if T - H - 3 > 0 else 0, T - 4):
+            obs = eng.reset(initial_step=start).cpu().numpy()
+            for j, om in enumerate(oms):
+                assert np.array_equal(obs[j], om.reset(initial_step=start)), (H, start, j)
+            a = rs.rand(len(sub), 2)
+            for k in range(3):
+                obs = eng.step(_t(a, device))[0].cpu().numpy()
+                for j, om in enumerate(oms):
+                    om.run(dict(battery=a[j, 0], grid=a[j, 1]), True)
+                    assert np.array_equal(obs[j], om.observe()), (H, start, k, j)
+        eng.close()
