@@ -533,3 +533,31 @@ def test_observation_window_chunk_boundaries(H, device, oracle):
                     om.run(dict(battery=a[j, 0], grid=a[j, 1]), True)
                     assert np.array_equal(obs[j], om.observe()), (H, start, k, j)
         eng.close()
+
+
+def test_small_and_ragged_shapes(device, oracle):
+    """N around the wave / workgroup / balanced-workgroup sizes and K around the ring depth: fused steps, discrete
+    rollout and single steps == oracle (empty tails, partially filled waves, K < ring depth)."""
+    from pymgrid_amd import DiscreteBatchedMicrogridEnv
+    from pymgrid_amd.generator import generate
+    rs = np.random.RandomState(0)
+    for N in (1, 2, 63, 64, 65, 207, 208, 209, 255, 256, 257, 1000):
+        for K in (1, 2, 3, 4, 5, 9):
+            env = DiscreteBatchedMicrogridEnv(generate(N, n_steps=K + 12, seed=N, device=device, mixed_timers=True),
+                                              observations=False, remove_redundant_gensets=False)
+            cols = env.batch.numpy_columns()
+            st = {k: cols[k].copy() for k in ("charge", "soc", "gen_status")}
+            a = rs.rand(K, N, 3)
+            out = env.engine.step_k(_t(a, device), reward=True)
+            ref = oracle.run_batch(cols, st, 0, K, a)
+            assert np.array_equal(out["reward"].cpu().numpy(), ref), (N, K)
+            ids = rs.randint(0, env.action_space.n, size=(K, N)).astype(np.uint8)
+            t0 = env.engine.current_step
+            out = env.engine.rollout_discrete(_t(ids, device, torch.uint8), env._table, K)
+            ref = oracle.rollout_batch(cols, st, t0, K, ids, env._table)
+            assert np.array_equal(out["reward"].cpu().numpy(), ref), (N, K)
+            _, r, _, _ = env.step(_t(ids[0], device, torch.int32))
+            ref = oracle.rollout_batch(cols, st, t0 + K, 1, ids[:1], env._table)
+            assert np.array_equal(r.cpu().numpy(), ref[0]), (N, K)
+            assert np.array_equal(env.batch.cols["charge"].cpu().numpy(), st["charge"])
+            env.close()
