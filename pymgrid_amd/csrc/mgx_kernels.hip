@@ -2,7 +2,7 @@
 //
 // Execution shape: one lane per microgrid, 64-lane wavefronts, 256-thread workgroups, SoA columns so every
 // global access of a wave is one contiguous 512-byte segment.  The path is element-wise and HBM-bound
-// (~40 useful flops vs 189 B per env-step, DESIGN.md section 4): no MFMA, no LDS tiling of the physics.
+// (~40 useful flops vs 189 B per env-step, DESIGN.md section 2): no MFMA, no LDS tiling of the physics.
 // LDS + wavefront shuffles are used where data actually crosses lanes: the [N, D] observation tile
 // transpose and the metrics column sums.
 //
