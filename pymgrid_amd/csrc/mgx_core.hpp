@@ -637,62 +637,142 @@ __device__ __forceinline__ double forecast_normal(uint64_t seed, int64_t grid, u
     return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);     // cospi: no large-argument reduction (no scratch)
 }
 
-// One wave-sized window work item: 64 grids [g0, g0+64) x horizon steps [h0, h0+nh) of one time-series module with
-// NC interleaved components (1: load / pv, 4: grid) -> columns [col, col + nh*NC) of the group's LDS row tile.
-// Loads are coalesced along the grids and issued as one unconditional batch (one latency round).
-constexpr int OBS_CH = 32;                   // columns per work item
+// Window work of a wave: it owns G (= 16) grids and the whole window of one time-series module.  Lane = (g, q):
+// g = grid within the group, q = horizon phase; lane (g, q) takes horizon steps q, q + Q, q + 2Q, ... (Q = 64 / G),
+// JB of them per latency round (7 * 4 = 28 slots cover the usual 24 / 25-step windows in one round), all NC components
+// of each.  Loads are 8*G-byte segments along the grids.
+constexpr int OBS_JB = 7;
 
+// General form (any horizon, any t): clamped rows, padding beyond the series.
 template <int NC, bool NOISE>
-__device__ __forceinline__ void observe_window_item(const double *__restrict__ ts, int64_t N, int64_t row_stride,
+__device__ __forceinline__ void observe_window_cols(const double *__restrict__ ts, int64_t N, int64_t row_stride,
                                                     const double *__restrict__ lo_col, const double *__restrict__ hi_col,
-                                                    int32_t T, int32_t t, int64_t g0, int32_t h0, int32_t nh,
-                                                    double *row /* tile + lane*LD + first column of this item */,
+                                                    int32_t T, int32_t t, int32_t W, int64_t i, int64_t ic, int32_t q, int32_t Q,
+                                                    double *row /* tile + g*LD + first column of this module */,
                                                     const double *__restrict__ noise_std, uint32_t comp_base,
-                                                    uint64_t noise_seed, int noise_increase, int32_t G)
+                                                    uint64_t noise_seed, int noise_increase)
 {
-    constexpr int HB = OBS_CH / NC;
-    const int lane = threadIdx.x & 63;          // lanes >= G (group smaller than a wave: very wide rows) only idle
-    const int64_t i = g0 + lane;
-    const int64_t ic = (lane < G && i < N) ? i : g0;
     double lo[NC], hi[NC], fill[NC], sp[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         lo[c] = lo_col[c * N + ic]; hi[c] = hi_col[c * N + ic];
         fill[c] = (hi[c] + lo[c]) / 2; sp[c] = space_spread(lo[c], hi[c]);
     }
-    // Unconditional, clamped loads: every row index is forced into [0, T-1] and the value of a row that is not
-    // wanted (beyond the series, or beyond this chunk) is discarded afterwards -- a predicated load would put each
-    // access in its own exec-masked block with an s_waitcnt behind it and serialise HB memory round trips.
-    double v[HB][NC];
-    bool in[HB];
+    double std0 = 0.0;
+    if constexpr (NOISE) if (noise_std != nullptr) std0 = noise_std[ic];
+    for (int32_t hb = 0; hb < W; hb += OBS_JB * Q) {                 // wave-uniform trip count
+        double v[OBS_JB][NC];
 #pragma unroll
-    for (int hh = 0; hh < HB; hh++) {
-        const int32_t r = t + h0 + hh;
-        in[hh] = hh < nh && r < T;
-        const int32_t rc = r < T ? r : T - 1;
+        for (int jj = 0; jj < OBS_JB; jj++) {                         // unconditional, clamped loads (one latency round)
+            const int32_t r = t + hb + q + Q * jj;
+            const int32_t rc = r < T ? r : T - 1;
 #pragma unroll
-        for (int c = 0; c < NC; c++) v[hh][c] = ts[(int64_t)rc * row_stride + c * N + ic];
-    }
-    if constexpr (NOISE) if (noise_std != nullptr) {        // GaussianNoiseForecaster
-        const double std0 = noise_std[ic];
+            for (int c = 0; c < NC; c++) v[jj][c] = ts[(int64_t)rc * row_stride + c * N + ic];
+        }
 #pragma unroll
-        for (int hh = 0; hh < HB; hh++) {
-            const int32_t h = h0 + hh;                      // h >= 1 is forecast_{h-1}; the current value carries no noise
-            if (hh < nh && h > 0 && in[hh]) {
-                const double sd = noise_increase ? std0 * (1.0 + log(1.0 + (double)(h - 1))) : std0;   // :243-249
+        for (int jj = 0; jj < OBS_JB; jj++) {
+            const int32_t h = hb + q + Q * jj;
+            const bool in = t + h < T;
+            if (h < W) {
+                if constexpr (NOISE) if (noise_std != nullptr && h > 0 && in) {     // GaussianNoiseForecaster (:243-263)
+                    const double sd = noise_increase ? std0 * (1.0 + log(1.0 + (double)(h - 1))) : std0;
 #pragma unroll
-                for (int c = 0; c < NC; c++) v[hh][c] += sd * forecast_normal(noise_seed, i, comp_base + c, t, h);
+                    for (int c = 0; c < NC; c++) v[jj][c] += sd * forecast_normal(noise_seed, i, comp_base + c, t, h);
+                }
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    row[h * NC + c] = obs_series_value(v[jj][c], in, h > 0, lo[c], hi[c], fill[c], sp[c]);
             }
         }
     }
-    if (lane >= G) return;
+}
+
+// ---- fast form: every slot of every round of OBS_JB * Q slots lies inside the series -------------------------
+// Split in three so that the caller can put the loads of ALL modules in flight before the first value is consumed.
+template <int NC>
+struct WinBounds {
+    double lo[NC], hi[NC], sp[NC], rsp[NC];
+    bool sp_ok[NC];
+};
+
+// a / b with b > 0 fixed per column and y = RN(1 / b) computed once: q0 = RN(a y); one FMA correction makes it
+// faithful, a second one is then the correctly rounded quotient (Markstein 1990; Muller et al., Handbook of
+// Floating-Point Arithmetic, "division with a correctly rounded reciprocal") -- identical bits to a / b -- as long as
+// nothing under- / overflows on the way, which the exponent guard ensures (2^-500 <= |a|, b < 2^500, or a == 0);
+// everything else takes the hardware division.  5 full-rate FMAs instead of the ~15-instruction v_div_* sequence.
+__device__ __forceinline__ bool exponent_is_moderate(double x)
+{
+    const uint32_t e = ((uint32_t)__double2hiint(x) >> 20) & 0x7ffu;            // biased exponent
+    return e - 523u < 1000u;                                                    // 2^-500 <= |x| < 2^500
+}
+
+__device__ __forceinline__ double div_cached_reciprocal(double a, double b, double y, bool b_ok)
+{
+    const double q0 = a * y;
+    const double r0 = fma(-b, q0, a);
+    const double q1 = fma(r0, y, q0);
+    const double r1 = fma(-b, q1, a);
+    double q = fma(r1, y, q1);
+    if (!(b_ok && (a == 0.0 || exponent_is_moderate(a)))) q = a / b;            // rare: wave skips it when no lane needs it
+    return q;
+}
+
+template <int NC>
+__device__ __forceinline__ void window_bounds(const double *__restrict__ lo_col, const double *__restrict__ hi_col, int64_t N,
+                                              int64_t ic, WinBounds<NC> &b)
+{
 #pragma unroll
-    for (int hh = 0; hh < HB; hh++)
-        if (hh < nh) {
+    for (int c = 0; c < NC; c++) { b.lo[c] = lo_col[c * N + ic]; b.hi[c] = hi_col[c * N + ic]; }
+}
+
+template <int NC>
+__device__ __forceinline__ void window_bounds_finish(WinBounds<NC> &b)
+{
 #pragma unroll
-            for (int c = 0; c < NC; c++)
-                row[hh * NC + c] = obs_series_value(v[hh][c], in[hh], h0 + hh > 0, lo[c], hi[c], fill[c], sp[c]);
+    for (int c = 0; c < NC; c++) {
+        b.sp[c] = space_spread(b.lo[c], b.hi[c]);
+        b.rsp[c] = 1.0 / b.sp[c];
+        b.sp_ok[c] = b.sp[c] > 0.0 && exponent_is_moderate(b.sp[c]);
+    }
+}
+
+// loads of slot jj: row t + Q jj (+ q through lane_off): the row base is wave-uniform (SGPR base + 32-bit lane offset)
+template <int NC>
+__device__ __forceinline__ void window_issue(const double *__restrict__ ts, int64_t N, int64_t row_stride, int32_t t, int32_t hb,
+                                             int32_t Q, uint32_t lane_off, double (&v)[OBS_JB][NC])
+{
+#pragma unroll
+    for (int jj = 0; jj < OBS_JB; jj++) {
+        const double *rp = ts + (int64_t)(t + hb + Q * jj) * row_stride;
+#pragma unroll
+        for (int c = 0; c < NC; c++) v[jj][c] = (rp + c * N)[lane_off];
+    }
+}
+
+template <int NC, bool NOISE>
+__device__ __forceinline__ void window_finish(double (&v)[OBS_JB][NC], const WinBounds<NC> &b, int32_t W, int32_t t, int32_t hb,
+                                              int64_t i, int64_t ic, int32_t q, int32_t Q, double *row,
+                                              const double *__restrict__ noise_std, uint32_t comp_base, uint64_t noise_seed,
+                                              int noise_increase)
+{
+    double std0 = 0.0;
+    if constexpr (NOISE) if (noise_std != nullptr) std0 = noise_std[ic];
+#pragma unroll
+    for (int jj = 0; jj < OBS_JB; jj++) {
+        const int32_t h = hb + q + Q * jj;
+        if constexpr (NOISE) if (noise_std != nullptr && h > 0 && h < W) {
+            const double sd = noise_increase ? std0 * (1.0 + log(1.0 + (double)(h - 1))) : std0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) v[jj][c] += sd * forecast_normal(noise_seed, i, comp_base + c, t, h);
         }
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            double x = v[jj][c];
+            if (h > 0) { if (x < b.lo[c]) x = b.lo[c]; if (x > b.hi[c]) x = b.hi[c]; }   // forecasts are clipped (:139-149)
+            const double val = div_cached_reciprocal(x - b.lo[c], b.sp[c], b.rsp[c], b.sp_ok[c]);
+            if (h < W) row[h * NC + c] = val;
+        }
+    }
 }
 
 // =========================================================================================================

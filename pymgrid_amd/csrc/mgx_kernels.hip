@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
     if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
     if (log) store_log<F>(log + i, a.N, o, s.status);
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
-    // one (H > 0) the host launches obs_rows_kernel behind this kernel and passes obs == nullptr
+    // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
     if (obs) observe_row_h0<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
     advance_counter_in_kernel(a, 1);
 }
@@ -167,66 +167,97 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t
     observe_row_h0<F>(a, i, t, p, s, obs + i * a.obs_dim);          // H == 0 only (host dispatches)
 }
 
-// Observation rows for H > 0: one workgroup per 64-grid group builds the group's complete [64, D] row block in LDS
-// (window chunks are dealt round-robin to the 4 waves, one wave adds the state columns) and then streams it out
-// with lanes running along each row: the block is one contiguous 64*D*8-byte region of obs, every cache line is
-// written whole by one workgroup (partial-line writes from different waves/XCDs cost read-modify-write at the
-// memory side; measured 3x slower).
+// Observation rows for H > 0 (obs_rows_wave_kernel below).  Every cache line of obs is written whole by one wave
+// (partial-line writes from different waves / XCDs cost read-modify-write at the memory side; measured 3x slower).
 struct WindowPlan {
-    int32_t chunks_ts;       // chunks per load / pv window: ceil((1+H) / 32)
-    int32_t chunks_grid;     // chunks of the 4-component grid window: ceil((1+H) / 8), 0 without a grid
-    int32_t hpc_ts, hpc_grid;   // horizon steps per chunk (balanced: ceil((1+H) / chunks))
     int32_t grid_col_base;   // first obs column of the grid window
     int32_t ld;              // LDS row pitch in doubles (odd: conflict-free column writes)
-    int32_t group;           // grids per workgroup: 64, or 32 / 16 / 8 when a 64-row tile would not fit the LDS
+    int32_t group;           // grids per wave tile: 16, or 8 / 4 / 2 / 1 when a 16-row tile would not fit the LDS
 };
 
+// Wave-private row tiles: one 64-lane workgroup per G = plan.group (16) grids.  The wave gathers the windows of its
+// grids into an LDS tile [G][LD] (lane = grid x horizon phase), then writes the G rows -- G*D consecutive doubles of
+// obs -- with full-wave 16-byte non-temporal stores (the rows are write-once; keeping them out of the caches leaves
+// the window rows, which the next 24 steps read again, resident in the 256 MB MALL: measured 65 -> 53 us at D = 156).
+// No workgroup is ever waiting for another wave's phase, so load, arithmetic and store phases of different waves
+// overlap on a CU (8 tiles of 20 KB per CU at D = 156).
 template <int F, bool NOISE>
-__global__ __launch_bounds__(BLOCK) void obs_rows_kernel(const KArgs a, const WindowPlan plan, int32_t t,
-                                                         double *__restrict__ obs)
+__global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const WindowPlan plan, int32_t t,
+                                                           double *__restrict__ obs)
 {
     t = resolve_t_obs(a, t);
     extern __shared__ double tile[];                    // [plan.group][plan.ld]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int32_t G = plan.group;
+    const int lane = threadIdx.x;
+    const int32_t G = plan.group, Q = 64 / G;
+    const int32_t g = lane & (G - 1), q = lane / G;
     const int64_t g0 = (int64_t)blockIdx.x * G;
     const int64_t N = a.N;
     const int32_t W = 1 + a.H, D = a.obs_dim, LD = plan.ld;
-    const int32_t n_chunks = 2 * plan.chunks_ts + plan.chunks_grid;
-    double *row = tile + lane * LD;
-    for (int32_t chunk = wave; chunk < n_chunks; chunk += BLOCK / 64) {
-        if (chunk < 2 * plan.chunks_ts) {
-            const bool is_pv = chunk >= plan.chunks_ts;
-            const int32_t h0 = (is_pv ? chunk - plan.chunks_ts : chunk) * plan.hpc_ts;
-            const int32_t nh = (W - h0 < plan.hpc_ts) ? W - h0 : plan.hpc_ts;
-            observe_window_item<1, NOISE>(is_pv ? a.c.pv_ts : a.c.load_ts, N, N, is_pv ? a.c.pv_lo : a.c.load_lo,
-                                   is_pv ? a.c.pv_hi : a.c.load_hi, a.T, t, g0, h0, nh, row + (is_pv ? W : 0) + h0,
-                                   is_pv ? a.c.pv_noise_std : a.c.load_noise_std, is_pv ? 1u : 0u, a.noise_seed,
-                                   a.noise_increase, G);
-        } else {
+    const int64_t i = g0 + g, ic = i < N ? i : g0;
+    double *row = tile + g * LD;
+    const int32_t slots = OBS_JB * Q;
+    const int32_t W_pad = (W + slots - 1) / slots * slots;
+    // wave-uniform: every slot's row exists, lane offsets fit 32-bit byte offsets
+    const bool fast = t >= 0 && (int64_t)t + W_pad <= a.T && (int64_t)(4 * Q + 4) * N < (int64_t(1) << 28);
+    if (fast) {
+        WinBounds<1> bl, bp;
+        WinBounds<(F & F_GRID) ? 4 : 1> bg;
+        window_bounds<1>(a.c.load_lo, a.c.load_hi, N, ic, bl);
+        window_bounds<1>(a.c.pv_lo, a.c.pv_hi, N, ic, bp);
+        if constexpr (F & F_GRID) window_bounds<4>(a.c.grid_lo, a.c.grid_hi, N, ic, bg);
+        for (int32_t hb = 0; hb < W; hb += slots) {      // one round for the usual 24 / 25-step windows
+            double vl[OBS_JB][1], vp[OBS_JB][1], vg[OBS_JB][(F & F_GRID) ? 4 : 1];
+            window_issue<1>(a.c.load_ts, N, N, t, hb, Q, (uint32_t)(q * N + ic), vl);     // all loads of the round in flight
+            window_issue<1>(a.c.pv_ts, N, N, t, hb, Q, (uint32_t)(q * N + ic), vp);
+            if constexpr (F & F_GRID) window_issue<4>(a.c.grid_ts, N, 4 * N, t, hb, Q, (uint32_t)(q * 4 * N + ic), vg);
+            if (hb == 0) window_bounds_finish<1>(bl);
+            window_finish<1, NOISE>(vl, bl, W, t, hb, i, ic, q, Q, row, a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
+            if (hb == 0) window_bounds_finish<1>(bp);
+            window_finish<1, NOISE>(vp, bp, W, t, hb, i, ic, q, Q, row + W, a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase);
             if constexpr (F & F_GRID) {
-                const int32_t h0 = (chunk - 2 * plan.chunks_ts) * plan.hpc_grid;
-                const int32_t nh = (W - h0 < plan.hpc_grid) ? W - h0 : plan.hpc_grid;
-                observe_window_item<4, NOISE>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, g0, h0, nh,
-                                       row + plan.grid_col_base + 4 * h0, a.c.grid_noise_std, 2u, a.noise_seed,
-                                       a.noise_increase, G);
+                if (hb == 0) window_bounds_finish<4>(bg);
+                window_finish<4, NOISE>(vg, bg, W, t, hb, i, ic, q, Q, row + plan.grid_col_base, a.c.grid_noise_std, 2u,
+                                        a.noise_seed, a.noise_increase);
             }
         }
+    } else {
+        observe_window_cols<1, NOISE>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row,
+                                      a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
+        observe_window_cols<1, NOISE>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + W,
+                                      a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase);
+        if constexpr (F & F_GRID)
+            observe_window_cols<4, NOISE>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q,
+                                          row + plan.grid_col_base, a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase);
     }
-    if (wave == n_chunks % (BLOCK / 64)) {               // the least loaded wave adds the 6 state columns
-        const int64_t i = g0 + lane;
-        if (lane < G && i < N) {
-            Params p; State s;
-            load_state<F>(a.c, i, true, s);
-            load_params<F>(a.c, i, p);
-            observe_state_cols<F>(a, p, s, row);
-        }
+    if (q == 0) {                                        // the 6 state columns, by the first lane of each grid
+        Params p; State s;
+        load_state<F>(a.c, ic, true, s);
+        load_params<F>(a.c, ic, p);
+        observe_state_cols<F>(a, p, s, row);
     }
     __syncthreads();
     const int32_t n_valid = (N - g0 < G) ? (int32_t)(N - g0) : G;
+    const int32_t total = n_valid * D;                   // D is even here (one load, one renewable module)
     double *out = obs + g0 * D;
-    for (int32_t g = wave; g < n_valid; g += BLOCK / 64)
-        for (int32_t j = lane; j < D; j += 64) out[(int64_t)g * D + j] = tile[g * LD + j];
+    if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {  // flat element pair f, f + 1 = 2 lane + 128 j  ->  (row, column)
+        int32_t r = 2 * lane / D, c = 2 * lane - r * D;
+        for (int32_t f = 2 * lane; f < total; f += 128) {
+            typedef double vec2d __attribute__((ext_vector_type(2)));
+            vec2d v2;
+            v2.x = tile[r * LD + c];
+            v2.y = tile[r * LD + c + 1];                 // D even, c even: the pair never straddles two rows
+            __builtin_nontemporal_store(v2, reinterpret_cast<vec2d *>(out + f));
+            c += 128;
+            while (c >= D) { c -= D; r++; }
+        }
+    } else {
+        int32_t r = lane / D, c = lane - r * D;
+        for (int32_t f = lane; f < total; f += 64) {
+            __builtin_nontemporal_store(tile[r * LD + c], out + f);
+            c += 64;
+            while (c >= D) { c -= D; r++; }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -675,12 +706,12 @@ static void launch_obs_rows(const KArgs &k, const WindowPlan &plan, int32_t t, d
     const bool noise = k.c.load_noise_std || k.c.pv_noise_std || k.c.grid_noise_std;
     if (noise) {
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)obs_rows_kernel<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        obs_rows_kernel<F, true><<<blocks, BLOCK, lds, st>>>(k, plan, t, obs);
+            (void)hipFuncSetAttribute((const void *)obs_rows_wave_kernel<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        obs_rows_wave_kernel<F, true><<<blocks, 64, lds, st>>>(k, plan, t, obs);
     } else {
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)obs_rows_kernel<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        obs_rows_kernel<F, false><<<blocks, BLOCK, lds, st>>>(k, plan, t, obs);
+            (void)hipFuncSetAttribute((const void *)obs_rows_wave_kernel<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        obs_rows_wave_kernel<F, false><<<blocks, 64, lds, st>>>(k, plan, t, obs);
     }
 }
 
@@ -697,14 +728,10 @@ static int launch_observe(const mgx_handle *h, int32_t t, double *obs, hipStream
     }
     const int32_t W = 1 + h->k.H, D = h->k.obs_dim;
     WindowPlan plan;
-    plan.chunks_ts = (W + OBS_CH - 1) / OBS_CH;
-    plan.chunks_grid = h->layout.has_grid ? (W + OBS_CH / 4 - 1) / (OBS_CH / 4) : 0;
-    plan.hpc_ts = (W + plan.chunks_ts - 1) / plan.chunks_ts;
-    plan.hpc_grid = plan.chunks_grid ? (W + plan.chunks_grid - 1) / plan.chunks_grid : 0;
     plan.grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
     plan.ld = D | 1;
-    plan.group = 64;                                   // rows of the LDS tile; halve until it fits 80 KiB (two workgroups per CU)
-    while (plan.group > 8 && (size_t)plan.group * plan.ld * sizeof(double) > 80 * 1024) plan.group /= 2;
+    plan.group = 16;                                   // grids per wave tile; halve while a tile would not fit the LDS
+    while (plan.group > 1 && (size_t)plan.group * plan.ld * sizeof(double) > 160 * 1024) plan.group /= 2;
     const size_t lds = (size_t)plan.group * plan.ld * sizeof(double);
     if (lds > 160 * 1024)
         return fail(MGX_ERR_UNSUPPORTED, "observation rows of %d values do not fit the 160 KiB LDS tile (horizon too large)", D);

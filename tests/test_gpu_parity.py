@@ -498,10 +498,11 @@ def test_observation_keys_vs_reference(pymgrid25, device):
         DiscreteMicrogridEnv(pymgrid25[0], device=device, observation_keys=["current_status"])
 
 
-@pytest.mark.parametrize("H", [1, 7, 8, 9, 30, 31, 32, 33, 40, 63, 64, 70])
+@pytest.mark.parametrize("H", [1, 7, 8, 9, 26, 27, 28, 30, 31, 32, 33, 40, 55, 56, 63, 64, 70])
 def test_observation_window_chunk_boundaries(H, device, oracle):
-    """Forecast horizons around the window-chunk sizes (32 columns for load / pv, 8 horizon steps for the 4-component
-    grid window), ragged N, steps that run into the end-of-series padding: device observation == oracle."""
+    """Forecast horizons around the window-round size (28 slots per round: 7 per lane x 4 horizon phases), ragged N
+    (65 grids: a partly filled 16-grid tile), starts inside the series (fast path: cached-reciprocal division, SGPR-base
+    loads) and steps that run into the end-of-series padding (general path): device observation == oracle."""
     from pymgrid_amd import StepEngine
     rs = np.random.RandomState(H)
     T, N = 90, 130
@@ -561,3 +562,39 @@ def test_small_and_ragged_shapes(device, oracle):
             assert np.array_equal(r.cpu().numpy(), ref[0]), (N, K)
             assert np.array_equal(env.batch.cols["charge"].cpu().numpy(), st["charge"])
             env.close()
+
+
+def test_observation_division_is_exact_for_extreme_magnitudes(device, oracle):
+    """The window kernel divides by the per-column spread through a cached correctly-rounded reciprocal and two FMA
+    corrections (exact when nothing under- / overflows) and falls back to the hardware division otherwise.  Series
+    scaled by 2^k for k from deep in the subnormal range to near overflow, constant columns (spread 0 -> 1), and an
+    output buffer that is only 8-byte aligned (scalar store path): device observation == oracle, bit for bit."""
+    from pymgrid_amd import StepEngine
+    rs = np.random.RandomState(11)
+    T, H = 64, 24
+    grids = []
+    for k in (-1060, -1030, -1022, -600, -523, -500, -499, -250, -52, -1, 0, 1, 53, 250, 499, 500, 523, 600, 900):
+        for rep in range(3):
+            scale = np.ldexp(1.0, k)
+            load = (1.0 + rs.rand(T)) * scale * (50 if rep else 1)
+            pv = rs.rand(T) * scale * (rs.rand(T) > 0.3)
+            if rep == 2:
+                pv = np.full(T, 3.0 * scale)                      # constant column: spread 0 -> 1
+            grids.append(dict(load_ts=load, pv_ts=pv, horizon=H, final_step=T, initial_step=0,
+                              unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0),
+                              battery=dict(min_capacity=20.0, max_capacity=100.0, max_charge=25.0, max_discharge=25.0,
+                                           efficiency=0.9, battery_cost_cycle=0.02, init_soc=0.5),
+                              grid=dict(max_import=60.0, max_export=30.0, cost_per_unit_co2=0.1),
+                              grid_ts=np.stack([(0.1 + rs.rand(T)) * np.ldexp(1.0, k // 2), 0.5 * rs.rand(T),
+                                                rs.rand(T) * np.ldexp(1.0, -k // 3), (rs.rand(T) > 0.2).astype(float)], axis=1)))
+    eng = StepEngine(_batch(grids, device))
+    N, D = len(grids), eng.layout.obs_dim
+    oms = [oracle.OracleMicrogrid(g) for g in grids]
+    flat = torch.empty(N * D + 1, dtype=torch.float64, device=device)
+    for out in (None, flat[1:].view(N, D)):
+        for start in (0, 5, T - H - 5, T - 3):
+            eng.reset(initial_step=start, want_obs=False)
+            obs = eng.observe(out=out).cpu().numpy()
+            for j, om in enumerate(oms):
+                assert np.array_equal(obs[j], om.reset(initial_step=start)), (start, j)
+    eng.close()
