@@ -691,31 +691,8 @@ __device__ __forceinline__ void observe_window_cols(const double *__restrict__ t
 // Split in three so that the caller can put the loads of ALL modules in flight before the first value is consumed.
 template <int NC>
 struct WinBounds {
-    double lo[NC], hi[NC], sp[NC], rsp[NC];
-    bool sp_ok[NC];
+    double lo[NC], hi[NC], sp[NC];
 };
-
-// a / b with b > 0 fixed per column and y = RN(1 / b) computed once: q0 = RN(a y); one FMA correction makes it
-// faithful, a second one is then the correctly rounded quotient (Markstein 1990; Muller et al., Handbook of
-// Floating-Point Arithmetic, "division with a correctly rounded reciprocal") -- identical bits to a / b -- as long as
-// nothing under- / overflows on the way, which the exponent guard ensures (2^-500 <= |a|, b < 2^500, or a == 0);
-// everything else takes the hardware division.  5 full-rate FMAs instead of the ~15-instruction v_div_* sequence.
-__device__ __forceinline__ bool exponent_is_moderate(double x)
-{
-    const uint32_t e = ((uint32_t)__double2hiint(x) >> 20) & 0x7ffu;            // biased exponent
-    return e - 523u < 1000u;                                                    // 2^-500 <= |x| < 2^500
-}
-
-__device__ __forceinline__ double div_cached_reciprocal(double a, double b, double y, bool b_ok)
-{
-    const double q0 = a * y;
-    const double r0 = fma(-b, q0, a);
-    const double q1 = fma(r0, y, q0);
-    const double r1 = fma(-b, q1, a);
-    double q = fma(r1, y, q1);
-    if (!(b_ok && (a == 0.0 || exponent_is_moderate(a)))) q = a / b;            // rare: wave skips it when no lane needs it
-    return q;
-}
 
 template <int NC>
 __device__ __forceinline__ void window_bounds(const double *__restrict__ lo_col, const double *__restrict__ hi_col, int64_t N,
@@ -729,11 +706,7 @@ template <int NC>
 __device__ __forceinline__ void window_bounds_finish(WinBounds<NC> &b)
 {
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-        b.sp[c] = space_spread(b.lo[c], b.hi[c]);
-        b.rsp[c] = 1.0 / b.sp[c];
-        b.sp_ok[c] = b.sp[c] > 0.0 && exponent_is_moderate(b.sp[c]);
-    }
+    for (int c = 0; c < NC; c++) b.sp[c] = space_spread(b.lo[c], b.hi[c]);
 }
 
 // loads of slot jj: row t + Q jj (+ q through lane_off): the row base is wave-uniform (SGPR base + 32-bit lane offset)
@@ -769,7 +742,7 @@ __device__ __forceinline__ void window_finish(double (&v)[OBS_JB][NC], const Win
         for (int c = 0; c < NC; c++) {
             double x = v[jj][c];
             if (h > 0) { if (x < b.lo[c]) x = b.lo[c]; if (x > b.hi[c]) x = b.hi[c]; }   // forecasts are clipped (:139-149)
-            const double val = div_cached_reciprocal(x - b.lo[c], b.sp[c], b.rsp[c], b.sp_ok[c]);
+            const double val = (x - b.lo[c]) / b.sp[c];                                  // space.py:213
             if (h < W) row[h * NC + c] = val;
         }
     }

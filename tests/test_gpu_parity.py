@@ -501,7 +501,7 @@ def test_observation_keys_vs_reference(pymgrid25, device):
 @pytest.mark.parametrize("H", [1, 7, 8, 9, 26, 27, 28, 30, 31, 32, 33, 40, 55, 56, 63, 64, 70])
 def test_observation_window_chunk_boundaries(H, device, oracle):
     """Forecast horizons around the window-round size (28 slots per round: 7 per lane x 4 horizon phases), ragged N
-    (65 grids: a partly filled 16-grid tile), starts inside the series (fast path: cached-reciprocal division, SGPR-base
+    (65 grids: a partly filled 16-grid tile), starts inside the series (fast path: SGPR-base
     loads) and steps that run into the end-of-series padding (general path): device observation == oracle."""
     from pymgrid_amd import StepEngine
     rs = np.random.RandomState(H)
@@ -564,11 +564,10 @@ def test_small_and_ragged_shapes(device, oracle):
             env.close()
 
 
-def test_observation_division_is_exact_for_extreme_magnitudes(device, oracle):
-    """The window kernel divides by the per-column spread through a cached correctly-rounded reciprocal and two FMA
-    corrections (exact when nothing under- / overflows) and falls back to the hardware division otherwise.  Series
-    scaled by 2^k for k from deep in the subnormal range to near overflow, constant columns (spread 0 -> 1), and an
-    output buffer that is only 8-byte aligned (scalar store path): device observation == oracle, bit for bit."""
+def test_observation_extreme_magnitudes_and_unaligned_output(device, oracle):
+    """Normalisation (v - lo) / spread at extreme magnitudes: series scaled by 2^k for k from deep in the subnormal
+    range to near overflow, constant columns (spread 0 -> 1), and an output buffer that is only 8-byte aligned (scalar
+    store path of the row writer): device observation == oracle, bit for bit."""
     from pymgrid_amd import StepEngine
     rs = np.random.RandomState(11)
     T, H = 64, 24
