@@ -52,6 +52,9 @@ enum mgx_status {
     MGX_ERR_DEVICE = 4        /* HIP runtime error (message holds hipGetErrorString) */
 };
 
+/* element type of the observation rows (mgx_set_obs_format) */
+enum mgx_obs_format { MGX_OBS_F64 = 0, MGX_OBS_F32 = 1 };
+
 /* Reward shaping functions of the reference (microgrid/reward_shaping/): what step() RETURNS as reward.
  * The log's "reward" column always keeps the unshaped sum (the balance log's `reward` vs `shaped_reward`). */
 enum mgx_reward_shaper {
@@ -135,7 +138,7 @@ int mgx_use_device_counter(mgx_handle *h, int enable, mgx_stream stream);
  * returns to initial_step (or to `initial_step` if >= 0: the trajectory_func hook, microgrid.py:221-225);
  * battery charge and genset status are NOT touched (the reference does not restore them).
  * obs [N, D] may be NULL. */
-int mgx_reset(mgx_handle *h, int32_t initial_step, double *obs, mgx_stream stream);
+int mgx_reset(mgx_handle *h, int32_t initial_step, void *obs, mgx_stream stream);
 
 /* Episode window [initial_step, final_step) for the next reset -- what a trajectory_func returns
  * (microgrid.py:221-225, microgrid/trajectory/ classes; validated like _check_trajectory_func, microgrid.py:181-203:
@@ -150,15 +153,21 @@ int mgx_set_reward_shaper(mgx_handle *h, int32_t shaper);
  * component, step, horizon index); statistical -- not bit -- parity with the reference's np.random.normal. */
 int mgx_set_forecast_noise(mgx_handle *h, uint64_t seed, int increase_uncertainty);
 
+/* Element type of every `obs` argument below: MGX_OBS_F64 (default; the reference's float64 arrays) or MGX_OBS_F32
+ * = the same value rounded to nearest float on the way out (what an RL policy consumes after gym's / torch's cast,
+ * envs/base/base.py:211-223: half the bytes of the largest output of the step).  The pointers are `void *` for that
+ * reason: [N, D] doubles or [N, D] floats. */
+int mgx_set_obs_format(mgx_handle *h, int32_t format);
+
 /* Normalised observation of the current state (BaseMicrogridModule.to_normalized(state), base_module.py:157;
  * forecast window + end-of-series padding forecaster.py:120-149,215-217). */
-int mgx_observe(mgx_handle *h, double *obs, mgx_stream stream);
+int mgx_observe(mgx_handle *h, void *obs, mgx_stream stream);
 
 /* ONE Microgrid.run(control, normalized) for all N grids (microgrid.py:227-325), as BaseMicrogridEnv.step
  * returns it (base.py:169-209): reward [N], done [N] (0/1), optional post-step obs [N, D] and log [L, N].
  * The step counter advances by one.  MGX_ERR_RANGE if the counter is already outside the series. */
 int mgx_step(mgx_handle *h, const double *actions, int normalized,
-             double *reward, uint8_t *done, double *obs, double *log, mgx_stream stream);
+             double *reward, uint8_t *done, void *obs, double *log, mgx_stream stream);
 
 /* K consecutive Microgrid.run calls in ONE launch: parameters and state stay in registers, actions
  * [K, N, A] are streamed.  Outputs (each may be NULL): reward [K, N], done [K, N], soc_trace [K, N],
@@ -179,7 +188,7 @@ int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *
  * control kept in registers.  control [N, A] (optional, may be NULL) receives the expanded control; the other
  * outputs are those of mgx_step. */
 int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions, double *control,
-                      double *reward, uint8_t *done, double *obs, double *log, mgx_stream stream);
+                      double *reward, uint8_t *done, void *obs, double *log, mgx_stream stream);
 
 /* K fused DiscreteMicrogridEnv steps with the control expanded ON DEVICE: action_id holds priority-list ids as
  * bytes, either [K, N] (per_step != 0: `for a in ids: env.step(a)`, discrete.py:109-143) or [N] (per_step == 0: one

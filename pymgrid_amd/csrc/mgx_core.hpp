@@ -40,6 +40,7 @@ struct KArgs {
     int32_t N, T, H, final_step;
     int32_t obs_dim, log_dim;
     int32_t n_load, n_pv;    // load / renewable modules per grid (1 on the fast path, <= MGX_MAX_MODULES otherwise)
+    int32_t obs_f32;         // observation rows are written as float (RN of the fp64 value) instead of double
     int32_t shaper;          // mgx_reward_shaper
     int32_t noise_increase;  // GaussianNoiseForecaster.increase_uncertainty
     uint64_t noise_seed;
@@ -559,29 +560,29 @@ __device__ __forceinline__ double obs_series_value(double v, bool in_series, boo
 }
 
 // the 6 state columns (genset_module.py:503-509, battery_module.py:87,323-330), written by the owning lane
-template <int F>
+template <int F, typename OT>
 __device__ __forceinline__ void observe_state_cols(const KArgs &a, const Params &p, const State &s,
-                                                   double *__restrict__ obs_row)
+                                                   OT *__restrict__ obs_row)
 {
     int k = 2 * (1 + a.H);
     if constexpr (F & F_GENSET) {
         const double su = (double)(p.gen_times & 0xffff), wd = (double)(p.gen_times >> 16);
-        obs_row[k++] = space_norm(0.0, 1.0, (double)(s.status & 0xff));
-        obs_row[k++] = space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
-        obs_row[k++] = space_norm(0.0, su, (double)((s.status >> 16) & 0xff));
-        obs_row[k++] = space_norm(0.0, wd, (double)(s.status >> 24));
+        obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)(s.status & 0xff));
+        obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
+        obs_row[k++] = (OT)space_norm(0.0, su, (double)((s.status >> 16) & 0xff));
+        obs_row[k++] = (OT)space_norm(0.0, wd, (double)(s.status >> 24));
     }
     if constexpr (F & F_BATTERY) {
         const double min_soc = p.bat_cmin / p.bat_cmax;
-        obs_row[k++] = space_norm(min_soc, 1.0, s.soc);
-        obs_row[k++] = space_norm(p.bat_cmin, p.bat_cmax, s.charge);
+        obs_row[k++] = (OT)space_norm(min_soc, 1.0, s.soc);
+        obs_row[k++] = (OT)space_norm(p.bat_cmin, p.bat_cmax, s.charge);
     }
 }
 
 // H == 0 (no forecaster): the whole row is 2 + 6 (+4) values -- the owning lane stores them directly
-template <int F>
+template <int F, typename OT>
 __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_t t, const Params &p, const State &s,
-                                               double *__restrict__ obs_row)
+                                               OT *__restrict__ obs_row)
 {
     const mgx_columns &c = a.c;
     const int64_t N = a.N;
@@ -589,21 +590,21 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
     {
         const double lo = c.load_lo[i], hi = c.load_hi[i];
         const double v = in ? c.load_ts[(int64_t)t * N + i] : 0.0;
-        obs_row[0] = obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
+        obs_row[0] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     {
         const double lo = c.pv_lo[i], hi = c.pv_hi[i];
         const double v = in ? c.pv_ts[(int64_t)t * N + i] : 0.0;
-        obs_row[1] = obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
+        obs_row[1] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
-    observe_state_cols<F>(a, p, s, obs_row);
+    observe_state_cols<F, OT>(a, p, s, obs_row);
     if constexpr (F & F_GRID) {
         const int k = 2 + 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
             const double lo = c.grid_lo[cc * N + i], hi = c.grid_hi[cc * N + i];
             const double v = in ? c.grid_ts[((int64_t)t * 4 + cc) * N + i] : 0.0;
-            obs_row[k + cc] = obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
+            obs_row[k + cc] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
         }
     }
 }
@@ -644,11 +645,11 @@ __device__ __forceinline__ double forecast_normal(uint64_t seed, int64_t grid, u
 constexpr int OBS_JB = 7;
 
 // General form (any horizon, any t): clamped rows, padding beyond the series.
-template <int NC, bool NOISE>
+template <int NC, bool NOISE, typename OT>
 __device__ __forceinline__ void observe_window_cols(const double *__restrict__ ts, int64_t N, int64_t row_stride,
                                                     const double *__restrict__ lo_col, const double *__restrict__ hi_col,
                                                     int32_t T, int32_t t, int32_t W, int64_t i, int64_t ic, int32_t q, int32_t Q,
-                                                    double *row /* tile + g*LD + first column of this module */,
+                                                    OT *row /* tile + g*LD + first column of this module */,
                                                     const double *__restrict__ noise_std, uint32_t comp_base,
                                                     uint64_t noise_seed, int noise_increase)
 {
@@ -681,7 +682,7 @@ __device__ __forceinline__ void observe_window_cols(const double *__restrict__ t
                 }
 #pragma unroll
                 for (int c = 0; c < NC; c++)
-                    row[h * NC + c] = obs_series_value(v[jj][c], in, h > 0, lo[c], hi[c], fill[c], sp[c]);
+                    row[h * NC + c] = (OT)obs_series_value(v[jj][c], in, h > 0, lo[c], hi[c], fill[c], sp[c]);
             }
         }
     }
@@ -722,9 +723,9 @@ __device__ __forceinline__ void window_issue(const double *__restrict__ ts, int6
     }
 }
 
-template <int NC, bool NOISE>
+template <int NC, bool NOISE, typename OT>
 __device__ __forceinline__ void window_finish(double (&v)[OBS_JB][NC], const WinBounds<NC> &b, int32_t W, int32_t t, int32_t hb,
-                                              int64_t i, int64_t ic, int32_t q, int32_t Q, double *row,
+                                              int64_t i, int64_t ic, int32_t q, int32_t Q, OT *row,
                                               const double *__restrict__ noise_std, uint32_t comp_base, uint64_t noise_seed,
                                               int noise_increase)
 {
@@ -743,7 +744,7 @@ __device__ __forceinline__ void window_finish(double (&v)[OBS_JB][NC], const Win
             double x = v[jj][c];
             if (h > 0) { if (x < b.lo[c]) x = b.lo[c]; if (x > b.hi[c]) x = b.hi[c]; }   // forecasts are clipped (:139-149)
             const double val = (x - b.lo[c]) / b.sp[c];                                  // space.py:213
-            if (h < W) row[h * NC + c] = val;
+            if (h < W) row[h * NC + c] = (OT)val;
         }
     }
 }

@@ -34,7 +34,7 @@ constexpr int BLOCK_K = MGX_BLOCK_K;
 template <int F>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double *__restrict__ actions, int32_t t,
                                                      int normalized, double *__restrict__ reward,
-                                                     uint8_t *__restrict__ done, double *__restrict__ obs,
+                                                     uint8_t *__restrict__ done, void *__restrict__ obs,
                                                      double *__restrict__ log)
 {
     t = resolve_t(a, t);
@@ -57,7 +57,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
     if (log) store_log<F>(log + i, a.N, o, s.status);
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
     // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
-    if (obs) observe_row_h0<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
+    if (obs) {
+        if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
+        else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
+    }
     advance_counter_in_kernel(a, 1);
 }
 
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const do
 // Observation of the current state (reset(), or after step_k).
 // ------------------------------------------------------------------------------------------------------
 template <int F>
-__global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t, double *__restrict__ obs)
+__global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t, void *__restrict__ obs)
 {
     t = resolve_t_obs(a, t);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -164,7 +167,8 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t
     Params p; State s;
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
-    observe_row_h0<F>(a, i, t, p, s, obs + i * a.obs_dim);          // H == 0 only (host dispatches)
+    if (a.obs_f32) observe_row_h0<F>(a, i, t, p, s, (float *)obs + i * a.obs_dim);     // H == 0 only (host dispatches)
+    else observe_row_h0<F>(a, i, t, p, s, (double *)obs + i * a.obs_dim);
 }
 
 // Observation rows for H > 0 (obs_rows_wave_kernel below).  Every cache line of obs is written whole by one wave
@@ -181,12 +185,13 @@ struct WindowPlan {
 // the window rows, which the next 24 steps read again, resident in the 256 MB MALL: measured 65 -> 53 us at D = 156).
 // No workgroup is ever waiting for another wave's phase, so load, arithmetic and store phases of different waves
 // overlap on a CU (8 tiles of 20 KB per CU at D = 156).
-template <int F, bool NOISE>
+template <int F, bool NOISE, typename OT>
 __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const WindowPlan plan, int32_t t,
-                                                           double *__restrict__ obs)
+                                                           OT *__restrict__ obs)
 {
     t = resolve_t_obs(a, t);
-    extern __shared__ double tile[];                    // [plan.group][plan.ld]
+    extern __shared__ double tile_raw[];                // [plan.group][plan.ld] of OT
+    OT *tile = reinterpret_cast<OT *>(tile_raw);
     const int lane = threadIdx.x;
     const int32_t G = plan.group, Q = 64 / G;
     const int32_t g = lane & (G - 1), q = lane / G;
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
     const int64_t N = a.N;
     const int32_t W = 1 + a.H, D = a.obs_dim, LD = plan.ld;
     const int64_t i = g0 + g, ic = i < N ? i : g0;
-    double *row = tile + g * LD;
+    OT *row = tile + g * LD;
     const int32_t slots = OBS_JB * Q;
     const int32_t W_pad = (W + slots - 1) / slots * slots;
     // wave-uniform: every slot's row exists, lane offsets fit 32-bit byte offsets
@@ -211,42 +216,42 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
             window_issue<1>(a.c.pv_ts, N, N, t, hb, Q, (uint32_t)(q * N + ic), vp);
             if constexpr (F & F_GRID) window_issue<4>(a.c.grid_ts, N, 4 * N, t, hb, Q, (uint32_t)(q * 4 * N + ic), vg);
             if (hb == 0) window_bounds_finish<1>(bl);
-            window_finish<1, NOISE>(vl, bl, W, t, hb, i, ic, q, Q, row, a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
+            window_finish<1, NOISE, OT>(vl, bl, W, t, hb, i, ic, q, Q, row, a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
             if (hb == 0) window_bounds_finish<1>(bp);
-            window_finish<1, NOISE>(vp, bp, W, t, hb, i, ic, q, Q, row + W, a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase);
+            window_finish<1, NOISE, OT>(vp, bp, W, t, hb, i, ic, q, Q, row + W, a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase);
             if constexpr (F & F_GRID) {
                 if (hb == 0) window_bounds_finish<4>(bg);
-                window_finish<4, NOISE>(vg, bg, W, t, hb, i, ic, q, Q, row + plan.grid_col_base, a.c.grid_noise_std, 2u,
+                window_finish<4, NOISE, OT>(vg, bg, W, t, hb, i, ic, q, Q, row + plan.grid_col_base, a.c.grid_noise_std, 2u,
                                         a.noise_seed, a.noise_increase);
             }
         }
     } else {
-        observe_window_cols<1, NOISE>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row,
+        observe_window_cols<1, NOISE, OT>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row,
                                       a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
-        observe_window_cols<1, NOISE>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + W,
+        observe_window_cols<1, NOISE, OT>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + W,
                                       a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase);
         if constexpr (F & F_GRID)
-            observe_window_cols<4, NOISE>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q,
+            observe_window_cols<4, NOISE, OT>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q,
                                           row + plan.grid_col_base, a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase);
     }
     if (q == 0) {                                        // the 6 state columns, by the first lane of each grid
         Params p; State s;
         load_state<F>(a.c, ic, true, s);
         load_params<F>(a.c, ic, p);
-        observe_state_cols<F>(a, p, s, row);
+        observe_state_cols<F, OT>(a, p, s, row);
     }
     __syncthreads();
     const int32_t n_valid = (N - g0 < G) ? (int32_t)(N - g0) : G;
     const int32_t total = n_valid * D;                   // D is even here (one load, one renewable module)
-    double *out = obs + g0 * D;
-    if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {  // flat element pair f, f + 1 = 2 lane + 128 j  ->  (row, column)
+    OT *out = obs + g0 * D;
+    typedef OT vec2 __attribute__((ext_vector_type(2)));
+    if ((reinterpret_cast<uintptr_t>(out) & (sizeof(vec2) - 1)) == 0) {   // element pair f, f + 1 = 2 lane + 128 j -> (row, column)
         int32_t r = 2 * lane / D, c = 2 * lane - r * D;
         for (int32_t f = 2 * lane; f < total; f += 128) {
-            typedef double vec2d __attribute__((ext_vector_type(2)));
-            vec2d v2;
+            vec2 v2;
             v2.x = tile[r * LD + c];
             v2.y = tile[r * LD + c + 1];                 // D even, c even: the pair never straddles two rows
-            __builtin_nontemporal_store(v2, reinterpret_cast<vec2d *>(out + f));
+            __builtin_nontemporal_store(v2, reinterpret_cast<vec2 *>(out + f));
             c += 128;
             while (c >= D) { c -= D; r++; }
         }
@@ -308,7 +313,7 @@ template <int F>
 __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, const PLWords tab,
                                                               const int32_t *__restrict__ action_id, int32_t t,
                                                               double *__restrict__ control, double *__restrict__ reward,
-                                                              uint8_t *__restrict__ done, double *__restrict__ obs,
+                                                              uint8_t *__restrict__ done, void *__restrict__ obs,
                                                               double *__restrict__ log)
 {
     t = resolve_t(a, t);
@@ -338,7 +343,10 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
     reward[i] = shaped_reward<F>(a.shaper, o);
     if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
     if (log) store_log<F>(log + i, N, o, s.status);
-    if (obs) observe_row_h0<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
+    if (obs) {
+        if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
+        else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
+    }
     advance_counter_in_kernel(a, 1);
 }
 
@@ -431,20 +439,21 @@ __device__ inline void load_controls_multi(const KArgs &a, const double *__restr
     }
 }
 
+template <typename OT>
 __device__ inline void observe_series_multi(const double *__restrict__ ts, int64_t row_stride, int32_t T, int32_t t, int32_t H,
-                                            double lo, double hi, double *__restrict__ obs)
+                                            double lo, double hi, OT *__restrict__ obs)
 {
     const double fill = (hi + lo) / 2, sp = space_spread(lo, hi);
     for (int h = 0; h <= H; h++) {
         const bool in = t < T && t + h < T;
         const double v = in ? ts[(int64_t)(t + h) * row_stride] : 0.0;
-        obs[h] = obs_series_value(v, in, h > 0, lo, hi, fill, sp);
+        obs[h] = (OT)obs_series_value(v, in, h > 0, lo, hi, fill, sp);
     }
 }
 
-template <int F>
+template <int F, typename OT>
 __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, const Params &p, const State &s,
-                                         double *__restrict__ obs_row)
+                                         OT *__restrict__ obs_row)
 {
     const int64_t N = a.N;
     const int W = 1 + a.H;
@@ -457,15 +466,15 @@ __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, c
                              a.c.pv_hi[(int64_t)j * N + i], obs_row + k);
     if constexpr (F & F_GENSET) {
         const double su = (double)(p.gen_times & 0xffff), wd = (double)(p.gen_times >> 16);
-        obs_row[k++] = space_norm(0.0, 1.0, (double)(s.status & 0xff));
-        obs_row[k++] = space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
-        obs_row[k++] = space_norm(0.0, su, (double)((s.status >> 16) & 0xff));
-        obs_row[k++] = space_norm(0.0, wd, (double)(s.status >> 24));
+        obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)(s.status & 0xff));
+        obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
+        obs_row[k++] = (OT)space_norm(0.0, su, (double)((s.status >> 16) & 0xff));
+        obs_row[k++] = (OT)space_norm(0.0, wd, (double)(s.status >> 24));
     }
     if constexpr (F & F_BATTERY) {
         const double min_soc = p.bat_cmin / p.bat_cmax;
-        obs_row[k++] = space_norm(min_soc, 1.0, s.soc);
-        obs_row[k++] = space_norm(p.bat_cmin, p.bat_cmax, s.charge);
+        obs_row[k++] = (OT)space_norm(min_soc, 1.0, s.soc);
+        obs_row[k++] = (OT)space_norm(p.bat_cmin, p.bat_cmax, s.charge);
     }
     if constexpr (F & F_GRID) {
         for (int h = 0; h <= a.H; h++)
@@ -473,7 +482,7 @@ __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, c
                 const double lo = a.c.grid_lo[cc * N + i], hi = a.c.grid_hi[cc * N + i];
                 const bool in = t < a.T && t + h < a.T;
                 const double v = in ? a.c.grid_ts[((int64_t)(t + h) * 4 + cc) * N + i] : 0.0;
-                obs_row[k + h * 4 + cc] = obs_series_value(v, in, h > 0, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
+                obs_row[k + h * 4 + cc] = (OT)obs_series_value(v, in, h > 0, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
             }
     }
 }
@@ -481,7 +490,7 @@ __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, c
 template <int F>
 __global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const double *__restrict__ actions, int32_t t,
                                                            int normalized, double *__restrict__ reward,
-                                                           uint8_t *__restrict__ done, double *__restrict__ obs,
+                                                           uint8_t *__restrict__ done, void *__restrict__ obs,
                                                            double *__restrict__ log)
 {
     t = resolve_t(a, t);
@@ -501,12 +510,15 @@ __global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const 
     reward[i] = shaped_reward<F>(a.shaper, o);
     if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
     if (log) store_log<F>(log + i, N, o, s.status);
-    if (obs) observe_row_multi<F>(a, i, t + 1, p, s, obs + i * a.obs_dim);
+    if (obs) {
+        if (a.obs_f32) observe_row_multi<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
+        else observe_row_multi<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
+    }
     advance_counter_in_kernel(a, 1);
 }
 
 template <int F>
-__global__ __launch_bounds__(BLOCK) void observe_multi_kernel(const KArgs a, int32_t t, double *__restrict__ obs)
+__global__ __launch_bounds__(BLOCK) void observe_multi_kernel(const KArgs a, int32_t t, void *__restrict__ obs)
 {
     t = resolve_t_obs(a, t);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -514,7 +526,8 @@ __global__ __launch_bounds__(BLOCK) void observe_multi_kernel(const KArgs a, int
     Params p; State s;
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
-    observe_row_multi<F>(a, i, t, p, s, obs + i * a.obs_dim);
+    if (a.obs_f32) observe_row_multi<F>(a, i, t, p, s, (float *)obs + i * a.obs_dim);
+    else observe_row_multi<F>(a, i, t, p, s, (double *)obs + i * a.obs_dim);
 }
 
 template <int F>
@@ -699,24 +712,30 @@ static int32_t fused_grids_per_block(const mgx_handle *h)
     return best;
 }
 
+template <int F, bool NOISE, typename OT>
+static void launch_obs_rows_as(const KArgs &k, const WindowPlan &plan, int32_t t, void *obs, unsigned blocks, size_t lds, hipStream_t st)
+{
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)obs_rows_wave_kernel<F, NOISE, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    obs_rows_wave_kernel<F, NOISE, OT><<<blocks, 64, lds, st>>>(k, plan, t, (OT *)obs);
+}
+
 template <int F>
-static void launch_obs_rows(const KArgs &k, const WindowPlan &plan, int32_t t, double *obs, unsigned blocks, size_t lds,
+static void launch_obs_rows(const KArgs &k, const WindowPlan &plan, int32_t t, void *obs, unsigned blocks, size_t lds,
                             hipStream_t st)
 {
     const bool noise = k.c.load_noise_std || k.c.pv_noise_std || k.c.grid_noise_std;
     if (noise) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)obs_rows_wave_kernel<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        obs_rows_wave_kernel<F, true><<<blocks, 64, lds, st>>>(k, plan, t, obs);
+        if (k.obs_f32) launch_obs_rows_as<F, true, float>(k, plan, t, obs, blocks, lds, st);
+        else launch_obs_rows_as<F, true, double>(k, plan, t, obs, blocks, lds, st);
     } else {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)obs_rows_wave_kernel<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        obs_rows_wave_kernel<F, false><<<blocks, 64, lds, st>>>(k, plan, t, obs);
+        if (k.obs_f32) launch_obs_rows_as<F, false, float>(k, plan, t, obs, blocks, lds, st);
+        else launch_obs_rows_as<F, false, double>(k, plan, t, obs, blocks, lds, st);
     }
 }
 
 // observation of the state at series index t into obs [N, D]
-static int launch_observe(const mgx_handle *h, int32_t t, double *obs, hipStream_t st)
+static int launch_observe(const mgx_handle *h, int32_t t, void *obs, hipStream_t st)
 {
     if (h->multi) {
         MGX_DISPATCH_F(h->flags, (observe_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, t, obs)));
@@ -731,8 +750,9 @@ static int launch_observe(const mgx_handle *h, int32_t t, double *obs, hipStream
     plan.grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
     plan.ld = D | 1;
     plan.group = 16;                                   // grids per wave tile; halve while a tile would not fit the LDS
-    while (plan.group > 1 && (size_t)plan.group * plan.ld * sizeof(double) > 160 * 1024) plan.group /= 2;
-    const size_t lds = (size_t)plan.group * plan.ld * sizeof(double);
+    const size_t esz = h->k.obs_f32 ? sizeof(float) : sizeof(double);
+    while (plan.group > 1 && (size_t)plan.group * plan.ld * esz > 160 * 1024) plan.group /= 2;
+    const size_t lds = ((size_t)plan.group * plan.ld * esz + 7) & ~(size_t)7;
     if (lds > 160 * 1024)
         return fail(MGX_ERR_UNSUPPORTED, "observation rows of %d values do not fit the 160 KiB LDS tile (horizon too large)", D);
     const unsigned blocks = (unsigned)(((int64_t)h->k.N + plan.group - 1) / plan.group);
@@ -799,7 +819,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->k.log_dim = LC_COMMON_END + LC_GENSET_N * L->has_genset + LC_BATTERY_N * L->has_battery + LC_GRID_N * L->has_grid + 1;
     h->t = L->initial_step;
     h->k.shaper = MGX_SHAPER_NONE;
-    h->k.noise_seed = 0; h->k.noise_increase = 0;
+    h->k.noise_seed = 0; h->k.noise_increase = 0; h->k.obs_f32 = 0;
     h->window_lo = L->initial_step; h->window_hi = final_step;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
@@ -878,7 +898,17 @@ static int need_obs_bounds(const mgx_handle *h, const char *who)
     return MGX_OK;
 }
 
-int mgx_observe(mgx_handle *h, double *obs, mgx_stream stream)
+int mgx_set_obs_format(mgx_handle *h, int32_t format)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_obs_format: NULL handle");
+    if (format != MGX_OBS_F64 && format != MGX_OBS_F32)
+        return fail(MGX_ERR_INVALID, "mgx_set_obs_format: unknown format %d", format);
+    h->k.obs_f32 = format == MGX_OBS_F32;
+    return MGX_OK;
+}
+
+int mgx_observe(mgx_handle *h, void *obs, mgx_stream stream)
 {
     g_err[0] = 0;
     if (!h || !obs) return fail(MGX_ERR_INVALID, "mgx_observe: NULL argument");
@@ -926,7 +956,7 @@ int mgx_set_forecast_noise(mgx_handle *h, uint64_t seed, int increase_uncertaint
     return MGX_OK;
 }
 
-int mgx_reset(mgx_handle *h, int32_t initial_step, double *obs, mgx_stream stream)
+int mgx_reset(mgx_handle *h, int32_t initial_step, void *obs, mgx_stream stream)
 {
     g_err[0] = 0;
     if (!h) return fail(MGX_ERR_INVALID, "mgx_reset: NULL handle");
@@ -938,7 +968,7 @@ int mgx_reset(mgx_handle *h, int32_t initial_step, double *obs, mgx_stream strea
     return obs ? mgx_observe(h, obs, stream) : MGX_OK;
 }
 
-int mgx_step(mgx_handle *h, const double *actions, int normalized, double *reward, uint8_t *done, double *obs,
+int mgx_step(mgx_handle *h, const double *actions, int normalized, double *reward, uint8_t *done, void *obs,
              double *log, mgx_stream stream)
 {
     g_err[0] = 0;
@@ -955,7 +985,7 @@ int mgx_step(mgx_handle *h, const double *actions, int normalized, double *rewar
         advance(h, 1, st);
         return MGX_OK;
     }
-    double *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
+    void *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
     MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, t_arg(h), normalized, reward,
                                                                                     done, obs_inline, log)));
     if (obs && h->k.H > 0) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
@@ -1028,7 +1058,7 @@ int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *
 }
 
 int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions, double *control,
-                      double *reward, uint8_t *done, double *obs, double *log, mgx_stream stream)
+                      double *reward, uint8_t *done, void *obs, double *log, mgx_stream stream)
 {
     g_err[0] = 0;
     if (!h || !action_id || !table || !reward) return fail(MGX_ERR_INVALID, "mgx_step_discrete: NULL argument");
@@ -1040,7 +1070,7 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_step_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    double *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
+    void *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
     MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, t_arg(h), control,
                                                                                              reward, done, obs_inline, log)));
     if (obs && h->k.H > 0) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }

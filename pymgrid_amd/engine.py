@@ -28,7 +28,7 @@ except AttributeError:                 # pragma: no cover
 
 
 class StepEngine:
-    def __init__(self, batch):
+    def __init__(self, batch, obs_dtype=torch.float64):
         if batch.device.type != "cuda":
             raise _lib.MgxError(_lib.MGX_ERR_DEVICE,
                                 "StepEngine needs the batch on a GPU (cuda/HIP device); there is no CPU path")
@@ -51,6 +51,9 @@ class StepEngine:
         self.log_names = [self._lib.mgx_log_name(self._h, j).decode() for j in range(self.log_dim)]
         assert self.action_dim == self.layout.action_dim and self.obs_dim == self.layout.obs_dim
         assert self.log_names == self.layout.log_names
+        self.obs_dtype = torch.float64
+        if obs_dtype != torch.float64:
+            self.set_obs_dtype(obs_dtype)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -78,6 +81,23 @@ class StepEngine:
 
     def _empty(self, *shape, dtype=torch.float64):
         return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def set_obs_dtype(self, dtype):
+        """Element type of the observation rows: torch.float64 (the reference's arrays) or torch.float32 (the same
+        values rounded to nearest on the way out -- half the bytes of the largest output of a step)."""
+        if dtype not in (torch.float64, torch.float32):
+            raise ValueError("obs_dtype must be torch.float64 or torch.float32")
+        check(self._lib.mgx_set_obs_format(self._h, 1 if dtype == torch.float32 else 0))
+        self.obs_dtype = dtype
+
+    def _obs_buf(self, out):
+        if out is None:
+            return torch.empty((self.N, self.obs_dim), dtype=self.obs_dtype, device=self.device)
+        if tuple(out.shape) != (self.N, self.obs_dim) or out.dtype != self.obs_dtype or not out.is_contiguous() \
+                or out.device != self.device:
+            raise ValueError(f"obs must be a contiguous {self.obs_dtype} tensor of shape ({self.N}, {self.obs_dim}) "
+                             f"on {self.device}")
+        return out
 
     def _check_actions(self, actions, lead):
         want = (*lead, self.N, self.action_dim)
@@ -113,12 +133,12 @@ class StepEngine:
 
     # ------------------------------------------------------------------------------------------------
     def reset(self, initial_step=None, want_obs=True, out=None):
-        obs = (out if out is not None else self._empty(self.N, self.obs_dim)) if want_obs else None
+        obs = self._obs_buf(out) if want_obs else None
         self._call(self._lib.mgx_reset, -1 if initial_step is None else int(initial_step), _ptr(obs))
         return obs
 
     def observe(self, out=None):
-        obs = out if out is not None else self._empty(self.N, self.obs_dim)
+        obs = self._obs_buf(out)
         self._call(self._lib.mgx_observe, _ptr(obs))
         return obs
 
@@ -133,10 +153,7 @@ class StepEngine:
             reward = self._empty(self.N)
         if done is None:
             done = self._empty(self.N, dtype=torch.uint8)
-        if not want_obs:
-            obs = None
-        elif obs is None:
-            obs = self._empty(self.N, self.obs_dim)
+        obs = self._obs_buf(obs) if want_obs else None
         if not want_log:
             log = None
         elif log is None:
@@ -181,7 +198,7 @@ class StepEngine:
         out = out or {}
         reward = out.get("reward") if out.get("reward") is not None else self._empty(self.N)
         done = out.get("done") if out.get("done") is not None else self._empty(self.N, dtype=torch.uint8)
-        obs = (out.get("obs") if out.get("obs") is not None else self._empty(self.N, self.obs_dim)) if want_obs else None
+        obs = self._obs_buf(out.get("obs")) if want_obs else None
         log = (out.get("log") if out.get("log") is not None else self._empty(self.log_dim, self.N)) if want_log else None
         control = (out.get("control") if out.get("control") is not None
                    else self._empty(self.N, self.action_dim)) if want_control else None

@@ -33,7 +33,7 @@ class BatchedMicrogridEnv:
     v1.2.2)."""
 
     def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
-                 raise_errors=False, observation_keys=None):
+                 raise_errors=False, observation_keys=None, obs_dtype=torch.float64):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
         # raise_errors=True (base_module.py:79-93): the device always clips; the step's `violations` log column
@@ -42,7 +42,8 @@ class BatchedMicrogridEnv:
         log = log or self.raise_errors
         self.batch = batch
         self.layout = batch.layout
-        self.engine = StepEngine(batch)
+        # obs_dtype=torch.float32: rows leave the device as floats (RN of the float64 value): what a policy consumes
+        self.engine = StepEngine(batch, obs_dtype=obs_dtype)
         self.reward_shaping_func = reward_shaping_func
         self.engine.set_reward_shaper(shaper_kind(reward_shaping_func))
         self.trajectory_func = trajectory_func
@@ -246,9 +247,10 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
     into an unnormalised control and stepped with ``normalized=False`` (discrete.py:109-143)."""
 
     def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
-                 trajectory_func=None, raise_errors=False, observation_keys=None):
+                 trajectory_func=None, raise_errors=False, observation_keys=None, obs_dtype=torch.float64):
         super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
-                         trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys)
+                         trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
+                         obs_dtype=obs_dtype)
         L = self.layout
         redundant = False
         if remove_redundant_gensets and L.has_genset:

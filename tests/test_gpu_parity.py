@@ -597,3 +597,57 @@ def test_observation_extreme_magnitudes_and_unaligned_output(device, oracle):
             for j, om in enumerate(oms):
                 assert np.array_equal(obs[j], om.reset(initial_step=start)), (start, j)
     eng.close()
+
+
+@pytest.mark.parametrize("arch,H,noise", [("genset+battery", 0, False), ("genset+battery+grid", 0, False),
+                                          ("genset+battery", 24, False), ("genset+battery+grid", 24, True),
+                                          ("battery+grid", 30, False), ("loadpv", 5, False)])
+def test_float32_observations_are_the_rounded_float64_rows(arch, H, noise, device):
+    """obs_dtype=float32 (mgx_set_obs_format): every observation entry point returns exactly the float64 row rounded
+    to nearest float -- reset, observe, step, discrete step, through the inline (H = 0), window (H > 0, incl. forecast
+    noise, end-of-series padding) and general multi-module kernels; ragged N, unaligned output buffer."""
+    from pymgrid_amd import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv, StepEngine
+    from pymgrid_amd.generator import generate
+    N, T = 1003, 80
+
+    def make():
+        if arch == "loadpv":
+            rs = np.random.RandomState(3)
+            grids = [dict(load_ts=rs.rand(T, 2) * [20, 5], pv_ts=rs.rand(T, 3) * [10, 4, 1],
+                          horizon=H, final_step=T, initial_step=0, unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0),
+                          battery=dict(min_capacity=20.0, max_capacity=100.0, max_charge=25.0, max_discharge=25.0,
+                                       efficiency=0.9, battery_cost_cycle=0.02, init_soc=0.5)) for _ in range(37)]
+            return _batch(grids, device)
+        b = generate(N, n_steps=T, seed=5, arch=arch, horizon=H, device=device)
+        if noise:
+            b.cols["load_noise_std"] = torch.full((N,), 3.0, dtype=torch.float64, device=device)
+            b.cols["grid_noise_std"] = torch.full((N,), 0.05, dtype=torch.float64, device=device)
+            b.forecast_noise = dict(seed=9, increase_uncertainty=True)
+        return b
+    e64, e32 = StepEngine(make()), StepEngine(make(), obs_dtype=torch.float32)
+    n, D = e64.N, e64.obs_dim
+    rs = np.random.RandomState(1)
+    flat = torch.empty(n * D + 1, dtype=torch.float32, device=device)
+    for start in (0, 3, T - 6):
+        o64, o32 = e64.reset(initial_step=start), e32.reset(initial_step=start)
+        assert o32.dtype == torch.float32 and torch.equal(o32, o64.to(torch.float32)), (start, "reset")
+        assert torch.equal(e32.observe(out=flat[1:].view(n, D)), e64.observe().to(torch.float32)), (start, "observe")
+        for k in range(4):
+            a = _t(rs.rand(n, e64.action_dim), device)
+            r64, r32 = e64.step(a), e32.step(a)
+            assert torch.equal(r32[0], r64[0].to(torch.float32)), (start, k)
+            assert torch.equal(r32[1], r64[1])                      # rewards stay float64
+    with pytest.raises(ValueError):
+        e32.observe(out=torch.empty(n, D, dtype=torch.float64, device=device))
+    e64.close(); e32.close()
+    if arch != "loadpv":
+        d64 = DiscreteBatchedMicrogridEnv(make())
+        d32 = DiscreteBatchedMicrogridEnv(make(), obs_dtype=torch.float32)
+        assert torch.equal(d32.reset(), d64.reset().to(torch.float32))
+        for k in range(3):
+            ids = torch.from_numpy(rs.randint(0, d64.action_space.n, size=n).astype(np.int32)).to(device)
+            assert torch.equal(d32.step(ids)[0], d64.step(ids)[0].to(torch.float32)), k
+        d64.close(); d32.close()
+        c32 = BatchedMicrogridEnv(make(), obs_dtype=torch.float32)
+        assert c32.reset().dtype == torch.float32
+        c32.close()
