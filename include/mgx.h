@@ -54,6 +54,8 @@ enum mgx_status {
 
 /* element type of the observation rows (mgx_set_obs_format) */
 enum mgx_obs_format { MGX_OBS_F64 = 0, MGX_OBS_F32 = 1 };
+/* what the `obs` argument of mgx_step / mgx_step_discrete / mgx_observe / mgx_reset receives (mgx_set_obs_mode) */
+enum mgx_obs_rows { MGX_OBS_ROWS_FULL = 0, MGX_OBS_ROWS_STATE_ONLY = 1 };
 
 /* Reward shaping functions of the reference (microgrid/reward_shaping/): what step() RETURNS as reward.
  * The log's "reward" column always keeps the unshaped sum (the balance log's `reward` vs `shaped_reward`). */
@@ -158,6 +160,18 @@ int mgx_set_forecast_noise(mgx_handle *h, uint64_t seed, int increase_uncertaint
  * envs/base/base.py:211-223: half the bytes of the largest output of the step).  The pointers are `void *` for that
  * reason: [N, D] doubles or [N, D] floats. */
 int mgx_set_obs_format(mgx_handle *h, int32_t format);
+
+/* Window prefetch.  The time-series windows of an observation (load / pv / grid: current value + forecast, the bulk of
+ * the row; base_timeseries_module.py:103-140, forecaster.py:120-149) depend on the series only, never on the actions, and
+ * consecutive steps share all but one of their rows.  mgx_observe_windows writes the observation rows of the NEXT K
+ * steps -- ring [K, N, D], block k = the row the reference returns at step counter t + k -- reading and normalising
+ * every series value once instead of 1 + horizon times.  Block 0 is complete (state columns of the current state); in
+ * blocks 1..K-1 the genset / battery state columns are zero: with mgx_set_obs_mode(MGX_OBS_ROWS_STATE_ONLY) the `obs`
+ * argument of mgx_step / mgx_step_discrete (pass ring + k*N*D for the step that reaches counter t + k) receives just
+ * those columns.  Values are identical to mgx_observe's.  MGX_ERR_UNSUPPORTED with forecast noise (it depends on the
+ * (step, horizon index) pair) or several load / renewable modules. */
+int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream);
+int mgx_set_obs_mode(mgx_handle *h, int32_t mode);
 
 /* Normalised observation of the current state (BaseMicrogridModule.to_normalized(state), base_module.py:157;
  * forecast window + end-of-series padding forecaster.py:120-149,215-217). */

@@ -41,6 +41,7 @@ struct KArgs {
     int32_t obs_dim, log_dim;
     int32_t n_load, n_pv;    // load / renewable modules per grid (1 on the fast path, <= MGX_MAX_MODULES otherwise)
     int32_t obs_f32;         // observation rows are written as float (RN of the fp64 value) instead of double
+    int32_t obs_state_only;  // obs arguments of step / observe receive ONLY the state columns (windows were prefetched)
     int32_t shaper;          // mgx_reward_shaper
     int32_t noise_increase;  // GaussianNoiseForecaster.increase_uncertainty
     uint64_t noise_seed;
@@ -562,9 +563,9 @@ __device__ __forceinline__ double obs_series_value(double v, bool in_series, boo
 // the 6 state columns (genset_module.py:503-509, battery_module.py:87,323-330), written by the owning lane
 template <int F, typename OT>
 __device__ __forceinline__ void observe_state_cols(const KArgs &a, const Params &p, const State &s,
-                                                   OT *__restrict__ obs_row)
+                                                   OT *__restrict__ obs_row, int first = -1)
 {
-    int k = 2 * (1 + a.H);
+    int k = first < 0 ? 2 * (1 + a.H) : first;        // the state columns follow the load and pv windows
     if constexpr (F & F_GENSET) {
         const double su = (double)(p.gen_times & 0xffff), wd = (double)(p.gen_times >> 16);
         obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)(s.status & 0xff));

@@ -58,7 +58,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
     // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
     if (obs) {
-        if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
+        if (a.obs_state_only) {                 // the window columns of this row were prefetched (obs_windows_k_kernel)
+            if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
+            else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
+        } else if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
         else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
     }
     advance_counter_in_kernel(a, 1);
@@ -167,7 +170,10 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t
     Params p; State s;
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
-    if (a.obs_f32) observe_row_h0<F>(a, i, t, p, s, (float *)obs + i * a.obs_dim);     // H == 0 only (host dispatches)
+    if (a.obs_state_only) {
+        if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
+        else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
+    } else if (a.obs_f32) observe_row_h0<F>(a, i, t, p, s, (float *)obs + i * a.obs_dim);   // H == 0 only (host dispatches)
     else observe_row_h0<F>(a, i, t, p, s, (double *)obs + i * a.obs_dim);
 }
 
@@ -266,6 +272,150 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Window prefetch: the observation rows of the NEXT K steps in one launch (mgx_observe_windows).
+// The window columns of an observation depend on the series only -- never on the actions -- and the windows of
+// consecutive steps overlap in H of their 1 + H rows.  A per-step kernel therefore re-reads (and re-normalises) every
+// series value 1 + H times, and those reads miss the 4 MiB L2s (per-XCD window working set 15 MB at N = 100k): they are
+// the bound of obs_rows_wave_kernel.  Here a wave reads rows t .. t+K-1+H of its 16 grids ONCE, normalises each value
+// ONCE into LDS (clipped / padded form for forecast positions, unclipped form for the "current value" position), and
+// writes K row blocks ring[k] (k = 0..K-1) as shifted copies -- with 288 GB of HBM the K*N*D ring is cheap (1 GB at
+// K = 8, N = 100k, D = 156).  Block 0 is complete (state columns of the current state); in blocks 1..K-1 the state
+// columns are zero and are filled in by the step that reaches them (obs_state_only mode of the step kernels).
+// Not offered with forecast noise (noise depends on (t, h), not on t + h: nothing to share).
+// ------------------------------------------------------------------------------------------------------
+// Workgroup = 4 waves around ONE LDS image of 16 grids: per grid a block of BP doubles
+//   [NCOMP][RP]  normalised rows t .. t+R-1 in forecast form (clipped to the bounds, padded beyond the series)
+//   [NCOMP][K]   rows t .. t+K-1 in "current value" form (unclipped)
+//   [6][K]       state columns: entry 0 = the current state, entries 1..K-1 = 0
+// so that output element (block k, grid r, column c) = image[r*BP + map[c] + k] for EVERY kind of column (map[c] =
+// offset of the column's k = 0 entry).  Thread (g, q) of the 256 loads rows q, q+16, ... of grid g; wave w then writes
+// blocks w, w+4, ... (each 16*D consecutive elements) with 16-byte non-temporal stores.
+constexpr int OBS_KJ = 2;                               // rows per thread and latency round (x 16 phases = 32 rows)
+constexpr int OBS_K_THREADS = 256;
+
+template <int NC>
+__device__ __forceinline__ void windows_k_module(const double *__restrict__ ts, int64_t N, int64_t row_stride,
+                                                 const double *__restrict__ lo_col, const double *__restrict__ hi_col,
+                                                 int32_t T, int32_t t, int32_t R, int32_t K, int64_t ic, int32_t q, int32_t Q,
+                                                 double *nc /* [NC][RP] of this grid */, double *nu /* [NC][K] */, int32_t RP)
+{
+    double lo[NC], hi[NC], sp[NC], z_lo[NC], z_hi[NC], z_fill[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        lo[c] = lo_col[c * N + ic]; hi[c] = hi_col[c * N + ic];
+        sp[c] = space_spread(lo[c], hi[c]);
+        z_lo[c] = (lo[c] - lo[c]) / sp[c];                               // a forecast clipped to the lower bound
+        z_hi[c] = (hi[c] - lo[c]) / sp[c];                               // ... to the upper bound
+        z_fill[c] = ((hi[c] + lo[c]) / 2 - lo[c]) / sp[c];               // a row beyond the series (forecaster.py:95,120-137)
+    }
+    for (int32_t rb = 0; rb < R; rb += OBS_KJ * Q) {                     // workgroup-uniform trip count
+        double v[OBS_KJ][NC];
+#pragma unroll
+        for (int jj = 0; jj < OBS_KJ; jj++) {                            // unconditional, clamped loads: one latency round
+            const int32_t r = t + rb + q + Q * jj;
+            const int32_t rc = r < T ? (r < 0 ? 0 : r) : T - 1;
+#pragma unroll
+            for (int c = 0; c < NC; c++) v[jj][c] = ts[(int64_t)rc * row_stride + c * N + ic];
+        }
+#pragma unroll
+        for (int jj = 0; jj < OBS_KJ; jj++) {
+            const int32_t rr = rb + q + Q * jj;                          // row relative to t
+            if (rr < R) {
+                const bool in = t + rr < T;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const double x = v[jj][c];
+                    const double n_u = in ? (x - lo[c]) / sp[c] : z_fill[c];                 // unclipped (current value)
+                    const double n_c = in ? (x < lo[c] ? z_lo[c] : (x > hi[c] ? z_hi[c] : n_u)) : z_fill[c];
+                    nc[c * RP + rr] = n_c;
+                    if (rr < K) nu[c * K + rr] = n_u;
+                }
+            }
+        }
+    }
+}
+
+struct WindowsKPlan {
+    int32_t grid_col_base;   // first obs column of the grid window
+    int32_t group;           // grids per workgroup (16)
+    int32_t K;               // steps per launch
+    int32_t rp;              // pitch of one component's rows in the image
+    int32_t bp;              // pitch of one grid's block in the image (odd)
+};
+
+template <int F, typename OT>
+__global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArgs a, const WindowsKPlan plan, int32_t t,
+                                                                      OT *__restrict__ ring)
+{
+    t = resolve_t_obs(a, t);
+    constexpr int NCOMP = 2 + ((F & F_GRID) ? 4 : 0);
+    constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
+    extern __shared__ double image[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t G = plan.group, Q = OBS_K_THREADS / G, K = plan.K, RP = plan.rp, BP = plan.bp;
+    const int32_t g = tid & (G - 1), q = tid / G;
+    const int64_t g0 = (int64_t)blockIdx.x * G;
+    const int64_t N = a.N;
+    const int32_t W = 1 + a.H, D = a.obs_dim, R = K + a.H;
+    const int64_t i = g0 + g, ic = i < N ? i : g0;
+    const int32_t NU0 = NCOMP * RP, S0 = NU0 + NCOMP * K;
+    double *blk = image + g * BP;
+    uint32_t *map = reinterpret_cast<uint32_t *>(image + G * BP);       // [D]
+
+    windows_k_module<1>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, R, K, ic, q, Q, blk, blk + NU0, RP);
+    windows_k_module<1>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP);
+    if constexpr (F & F_GRID)
+        windows_k_module<4>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, R, K, ic, q, Q, blk + 2 * RP,
+                            blk + NU0 + 2 * K, RP);
+    if (q == 0) {                                        // state columns: the current state for block 0, zeros ahead
+        Params p; State s;
+        load_state<F>(a.c, ic, true, s);
+        load_params<F>(a.c, ic, p);
+        double now[8];
+        observe_state_cols<F>(a, p, s, now, 0);
+        for (int j = 0; j < NSTATE; j++) {
+            blk[S0 + j * K] = now[j];
+            for (int32_t k = 1; k < K; k++) blk[S0 + j * K + k] = 0.0;
+        }
+    }
+    for (int32_t col = tid; col < D; col += OBS_K_THREADS) {            // column -> offset of its k = 0 entry in a block
+        uint32_t comp, h;
+        if (col < W) { comp = 0; h = col; }
+        else if (col < 2 * W) { comp = 1; h = col - W; }
+        else if (col < plan.grid_col_base) { comp = 0xffffu; h = col - 2 * W; }
+        else { comp = 2u + ((col - plan.grid_col_base) & 3); h = (col - plan.grid_col_base) >> 2; }
+        map[col] = comp == 0xffffu ? S0 + h * K : (h == 0 ? NU0 + comp * K : comp * RP + h);
+    }
+    __syncthreads();
+    const int32_t n_valid = (N - g0 < G) ? (int32_t)(N - g0) : G;
+    const int32_t total = n_valid * D;                   // D is even (one load, one renewable module)
+    typedef OT vec2 __attribute__((ext_vector_type(2)));
+    const bool wide = (reinterpret_cast<uintptr_t>(ring) & (sizeof(vec2) - 1)) == 0;
+    for (int32_t k = wave; k < K; k += OBS_K_THREADS / 64) {
+        OT *out = ring + ((int64_t)k * N + g0) * D;
+        const double *src = image + k;
+        if (wide) {                                      // element pair f, f + 1 = 2 lane + 128 j -> (row, column)
+            int32_t r = 2 * lane / D, c = 2 * lane - r * D;
+            for (int32_t f = 2 * lane; f < total; f += 128) {
+                vec2 v2;
+                v2.x = (OT)src[r * BP + map[c]];
+                v2.y = (OT)src[r * BP + map[c + 1]];     // D even, c even: the pair never straddles two rows
+                __builtin_nontemporal_store(v2, reinterpret_cast<vec2 *>(out + f));
+                c += 128;
+                while (c >= D) { c -= D; r++; }
+            }
+        } else {
+            int32_t r = lane / D, c = lane - r * D;
+            for (int32_t f = lane; f < total; f += 64) {
+                __builtin_nontemporal_store((OT)src[r * BP + map[c]], out + f);
+                c += 64;
+                while (c >= D) { c -= D; r++; }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Discrete action expansion: PriorityListAlgo._populate_action (priority_list.py:69-167).
 // ------------------------------------------------------------------------------------------------------
 template <int F>
@@ -344,7 +494,10 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
     if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
     if (log) store_log<F>(log + i, N, o, s.status);
     if (obs) {
-        if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
+        if (a.obs_state_only) {                 // the window columns of this row were prefetched (obs_windows_k_kernel)
+            if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
+            else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
+        } else if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
         else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
     }
     advance_counter_in_kernel(a, 1);
@@ -741,7 +894,7 @@ static int launch_observe(const mgx_handle *h, int32_t t, void *obs, hipStream_t
         MGX_DISPATCH_F(h->flags, (observe_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, t, obs)));
         return MGX_OK;
     }
-    if (h->k.H == 0) {
+    if (h->k.H == 0 || h->k.obs_state_only) {
         MGX_DISPATCH_F(h->flags, (observe_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, t, obs)));
         return MGX_OK;
     }
@@ -819,7 +972,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->k.log_dim = LC_COMMON_END + LC_GENSET_N * L->has_genset + LC_BATTERY_N * L->has_battery + LC_GRID_N * L->has_grid + 1;
     h->t = L->initial_step;
     h->k.shaper = MGX_SHAPER_NONE;
-    h->k.noise_seed = 0; h->k.noise_increase = 0; h->k.obs_f32 = 0;
+    h->k.noise_seed = 0; h->k.noise_increase = 0; h->k.obs_f32 = 0; h->k.obs_state_only = 0;
     h->window_lo = L->initial_step; h->window_hi = final_step;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
@@ -908,6 +1061,55 @@ int mgx_set_obs_format(mgx_handle *h, int32_t format)
     return MGX_OK;
 }
 
+int mgx_set_obs_mode(mgx_handle *h, int32_t mode)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_obs_mode: NULL handle");
+    if (mode != MGX_OBS_ROWS_FULL && mode != MGX_OBS_ROWS_STATE_ONLY)
+        return fail(MGX_ERR_INVALID, "mgx_set_obs_mode: unknown mode %d", mode);
+    if (mode == MGX_OBS_ROWS_STATE_ONLY && h->multi)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_set_obs_mode: state-only rows need exactly one load and one renewable module per grid");
+    h->k.obs_state_only = mode == MGX_OBS_ROWS_STATE_ONLY;
+    return MGX_OK;
+}
+
+int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !ring) return fail(MGX_ERR_INVALID, "mgx_observe_windows: NULL argument");
+    if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "mgx_observe_windows: K = %d outside [1, 4096]", K);
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_observe_windows: needs exactly one load and one renewable module per grid");
+    if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_observe_windows: forecast noise depends on (step, horizon index), windows cannot be shared");
+    if (int rc = need_obs_bounds(h, "mgx_observe_windows")) return rc;
+    if (!dev_counter(h) && h->t > h->k.T)
+        return fail(MGX_ERR_RANGE, "mgx_observe_windows: step %d is outside the time series (length %d)", h->t, h->k.T);
+    const int32_t W = 1 + h->k.H, R = K + h->k.H, ncomp = 2 + 4 * h->layout.has_grid;
+    WindowsKPlan plan;
+    plan.grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
+    plan.K = K;
+    plan.rp = R;
+    plan.bp = (ncomp * (R + K) + 6 * K) | 1;
+    plan.group = 16;
+    auto lds_of = [&](int32_t g) { return (size_t)g * plan.bp * sizeof(double) + (size_t)h->k.obs_dim * sizeof(uint32_t); };
+    while (plan.group > 1 && lds_of(plan.group) > 160 * 1024) plan.group /= 2;
+    const size_t lds = (lds_of(plan.group) + 7) & ~(size_t)7;
+    if (lds > 160 * 1024)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_observe_windows: K + horizon = %d rows do not fit the 160 KiB LDS", R);
+    const unsigned blocks = (unsigned)(((int64_t)h->k.N + plan.group - 1) / plan.group);
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t t = t_arg(h);
+    if (h->k.obs_f32) {
+        MGX_DISPATCH_F(h->flags, ((lds > 64 * 1024 ? (void)hipFuncSetAttribute((const void *)obs_windows_k_kernel<F, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : (void)0),
+                                  obs_windows_k_kernel<F, float><<<blocks, OBS_K_THREADS, lds, st>>>(h->k, plan, t, (float *)ring)));
+    } else {
+        MGX_DISPATCH_F(h->flags, ((lds > 64 * 1024 ? (void)hipFuncSetAttribute((const void *)obs_windows_k_kernel<F, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : (void)0),
+                                  obs_windows_k_kernel<F, double><<<blocks, OBS_K_THREADS, lds, st>>>(h->k, plan, t, (double *)ring)));
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "obs_windows_k_kernel launch");
+}
+
 int mgx_observe(mgx_handle *h, void *obs, mgx_stream stream)
 {
     g_err[0] = 0;
@@ -985,10 +1187,10 @@ int mgx_step(mgx_handle *h, const double *actions, int normalized, double *rewar
         advance(h, 1, st);
         return MGX_OK;
     }
-    void *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
+    void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
     MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, t_arg(h), normalized, reward,
                                                                                     done, obs_inline, log)));
-    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
+    if (obs && h->k.H > 0 && !h->k.obs_state_only) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_kernel launch");
     advance(h, 1, st);
@@ -1070,10 +1272,10 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_step_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    void *obs_inline = (obs && h->k.H == 0) ? obs : nullptr;
+    void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
     MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, t_arg(h), control,
                                                                                              reward, done, obs_inline, log)));
-    if (obs && h->k.H > 0) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
+    if (obs && h->k.H > 0 && !h->k.obs_state_only) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_discrete_kernel launch");
     advance(h, 1, st);

@@ -90,6 +90,22 @@ class StepEngine:
         check(self._lib.mgx_set_obs_format(self._h, 1 if dtype == torch.float32 else 0))
         self.obs_dtype = dtype
 
+    def set_obs_state_only(self, flag):
+        """True: the ``obs`` output of step / step_discrete / observe / reset receives only the genset / battery state
+        columns -- the window columns of that row were written ahead of time by ``observe_windows``."""
+        check(self._lib.mgx_set_obs_mode(self._h, 1 if flag else 0))
+
+    def observe_windows(self, K=None, out=None):
+        """Observation rows of the next K steps, ``ring[k]`` = the row of step counter t + k (block 0 complete, blocks
+        1..K-1 without the state columns): every series value is read and normalised once instead of 1 + horizon times."""
+        if out is None:
+            out = torch.empty((int(K), self.N, self.obs_dim), dtype=self.obs_dtype, device=self.device)
+        if out.dim() != 3 or tuple(out.shape[1:]) != (self.N, self.obs_dim) or out.dtype != self.obs_dtype \
+                or not out.is_contiguous() or out.device != self.device:
+            raise ValueError(f"ring must be a contiguous {self.obs_dtype} tensor [K, {self.N}, {self.obs_dim}] on {self.device}")
+        self._call(self._lib.mgx_observe_windows, int(out.shape[0]), out.data_ptr())
+        return out
+
     def _obs_buf(self, out):
         if out is None:
             return torch.empty((self.N, self.obs_dim), dtype=self.obs_dtype, device=self.device)

@@ -33,7 +33,7 @@ class BatchedMicrogridEnv:
     v1.2.2)."""
 
     def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
-                 raise_errors=False, observation_keys=None, obs_dtype=torch.float64):
+                 raise_errors=False, observation_keys=None, obs_dtype=torch.float64, obs_prefetch=0):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
         # raise_errors=True (base_module.py:79-93): the device always clips; the step's `violations` log column
@@ -44,6 +44,21 @@ class BatchedMicrogridEnv:
         self.layout = batch.layout
         # obs_dtype=torch.float32: rows leave the device as floats (RN of the float64 value): what a policy consumes
         self.engine = StepEngine(batch, obs_dtype=obs_dtype)
+        # obs_prefetch=K (> 1): the forecast windows of the next K steps are written in one launch every K steps
+        # (engine.observe_windows: each series value read and normalised once instead of 1 + horizon times) and a step
+        # only adds the genset / battery state columns.  Same values; the returned obs is a view into a [K, N, D] ring
+        # and stays valid for K - 1 further steps.  Ignored (per-step rows) where there is nothing to share: no
+        # forecast horizon, forecast noise, several load / renewable modules, observations off.
+        L = self.layout
+        noisy = batch.forecast_noise is not None or any(batch.cols.get(k) is not None
+                                                        for k in ("load_noise_std", "pv_noise_std", "grid_noise_std"))
+        self.obs_prefetch = int(obs_prefetch) if (obs_prefetch and int(obs_prefetch) > 1 and observations and L.horizon > 0
+                                                   and L.n_load == 1 and L.n_pv == 1 and not noisy) else 0
+        self._ring = None
+        if self.obs_prefetch:
+            self._ring = torch.empty(self.obs_prefetch, L.n_grids, L.obs_dim, dtype=obs_dtype, device=batch.device)
+            self._ring_pos = 0
+            self.engine.set_obs_state_only(True)
         self.reward_shaping_func = reward_shaping_func
         self.engine.set_reward_shaper(shaper_kind(reward_shaping_func))
         self.trajectory_func = trajectory_func
@@ -110,7 +125,32 @@ class BatchedMicrogridEnv:
         self._shaped_rows = []
         if self.trajectory_func is not None and initial_step is None:
             self._draw_window()
+        if self._ring is not None:
+            self.engine.reset(initial_step, want_obs=False)
+            return self._select_obs(self._refill())
         return self._select_obs(self.engine.reset(initial_step, want_obs=self._observations))
+
+    def _refill(self):
+        self.engine.observe_windows(out=self._ring)
+        self._ring_pos = 0
+        return self._ring[0]
+
+    def _obs_target(self):
+        """Where the coming step's observation goes: the next ring block (state columns only), or nowhere when the
+        ring is used up (the windows are then refilled after the step)."""
+        if self._ring is None:
+            return self._observations, None
+        if self._ring_pos + 1 < self.obs_prefetch:
+            return True, dict(obs=self._ring[self._ring_pos + 1])
+        return False, None
+
+    def _obs_after(self, obs):
+        if self._ring is None:
+            return obs
+        if obs is None:
+            return self._refill()
+        self._ring_pos += 1
+        return obs
 
     def _select_obs(self, obs):
         if obs is None or self._obs_index is None:
@@ -122,8 +162,10 @@ class BatchedMicrogridEnv:
         ``Microgrid.run``.  Returns (obs [N, D], reward [N], done [N] bool, info)."""
         if isinstance(action, dict):
             action = self.control_to_tensor(action)
-        obs, reward, done, log = self.engine.step(action, normalized=normalized, want_obs=self._observations,
-                                                  want_log=self._keep_log)
+        want_obs, out = self._obs_target()
+        obs, reward, done, log = self.engine.step(action, normalized=normalized, want_obs=want_obs,
+                                                  want_log=self._keep_log, out=out)
+        obs = self._obs_after(obs)
         info = {}
         if log is not None:
             self._log_rows.append(log)
@@ -247,10 +289,11 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
     into an unnormalised control and stepped with ``normalized=False`` (discrete.py:109-143)."""
 
     def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
-                 trajectory_func=None, raise_errors=False, observation_keys=None, obs_dtype=torch.float64):
+                 trajectory_func=None, raise_errors=False, observation_keys=None, obs_dtype=torch.float64,
+                 obs_prefetch=0):
         super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
                          trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
-                         obs_dtype=obs_dtype)
+                         obs_dtype=obs_dtype, obs_prefetch=obs_prefetch)
         L = self.layout
         redundant = False
         if remove_redundant_gensets and L.has_genset:
@@ -279,8 +322,10 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
         if not torch.is_tensor(action_id):
             action_id = torch.as_tensor(np.asarray(action_id), device=self.batch.device)
         action_id = action_id.to(device=self.batch.device, dtype=torch.int32).contiguous()
-        obs, reward, done, log, _ = self.engine.step_discrete(action_id, self._table, want_obs=self._observations,
-                                                              want_log=self._keep_log)
+        want_obs, out = self._obs_target()
+        obs, reward, done, log, _ = self.engine.step_discrete(action_id, self._table, want_obs=want_obs,
+                                                              want_log=self._keep_log, out=out)
+        obs = self._obs_after(obs)
         info = {}
         if log is not None:
             self._log_rows.append(log)

@@ -651,3 +651,52 @@ def test_float32_observations_are_the_rounded_float64_rows(arch, H, noise, devic
         c32 = BatchedMicrogridEnv(make(), obs_dtype=torch.float32)
         assert c32.reset().dtype == torch.float32
         c32.close()
+
+
+@pytest.mark.parametrize("arch,H,K,dtype", [("genset+battery", 24, 8, torch.float64), ("genset+battery+grid", 24, 8, torch.float64),
+                                            ("genset+battery+grid", 23, 3, torch.float32), ("battery+grid", 5, 2, torch.float64),
+                                            ("genset+battery+grid", 40, 30, torch.float64), ("genset+battery", 1, 64, torch.float32)])
+def test_window_prefetch_equals_per_step_observations(arch, H, K, dtype, device):
+    """obs_prefetch=K (mgx_observe_windows + state-only rows): the observation returned by every reset / step is
+    identical to the per-step kernel's, across ring refills, into the end-of-series padding, ragged N, float32 rows;
+    ring blocks ahead of the current step hold the right windows and zero state columns."""
+    from pymgrid_amd import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv, StepEngine
+    from pymgrid_amd.generator import generate
+    N, T = 1003, 150
+    rs = np.random.RandomState(K)
+
+    def make():
+        return generate(N, n_steps=T, seed=5, arch=arch, horizon=H, device=device, mixed_timers=True)
+    ref, pre = BatchedMicrogridEnv(make(), obs_dtype=dtype), BatchedMicrogridEnv(make(), obs_dtype=dtype, obs_prefetch=K)
+    assert pre.obs_prefetch == K
+    for start, n_steps in ((0, 2 * K + 3), (T - H - 7, H + 6)):
+        o_ref, o_pre = ref.reset(start), pre.reset(start)
+        assert torch.equal(o_ref, o_pre), (start, "reset")
+        for k in range(min(n_steps, T - start - 1)):
+            a = _t(rs.rand(N, ref.layout.action_dim), device)
+            s_ref, s_pre = ref.step(a), pre.step(a)
+            assert torch.equal(s_ref[0], s_pre[0]), (start, k)
+            assert torch.equal(s_ref[1], s_pre[1]) and torch.equal(s_ref[2], s_pre[2])
+    ref.close(); pre.close()
+    # the ring itself: block k = observation of step t + k, state columns zero for k > 0
+    e = StepEngine(make(), obs_dtype=dtype)
+    W, D = 1 + H, e.obs_dim
+    n_state = 4 * e.layout.has_genset + 2 * e.layout.has_battery
+    e.reset(initial_step=7, want_obs=False)
+    ring = e.observe_windows(K)
+    for k in range(K):
+        if 7 + k >= T:
+            break
+        e.reset(initial_step=7 + k, want_obs=False)
+        row = e.observe()
+        if k:
+            row[:, 2 * W:2 * W + n_state] = 0
+        assert torch.equal(ring[k], row), k
+    e.close()
+    d_ref = DiscreteBatchedMicrogridEnv(make(), obs_dtype=dtype)
+    d_pre = DiscreteBatchedMicrogridEnv(make(), obs_dtype=dtype, obs_prefetch=K)
+    assert torch.equal(d_ref.reset(), d_pre.reset())
+    for k in range(K + 2):
+        ids = torch.from_numpy(rs.randint(0, d_ref.action_space.n, size=N).astype(np.int32)).to(device)
+        assert torch.equal(d_ref.step(ids)[0], d_pre.step(ids)[0]), k
+    d_ref.close(); d_pre.close()
