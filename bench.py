@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--mode", choices=["fused", "step", "rbc"], default="fused")
     ap.add_argument("--chunk", type=int, default=64, help="env-steps per fused launch")
     ap.add_argument("--arch", default="genset+battery")
+    ap.add_argument("--hetero-steps", type=int, default=256, help="timed Gym steps of the heterogeneous H=24 fleet (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -114,6 +115,39 @@ def timed(fn, steps, device):
     t1 = time.perf_counter()
     mdist.barrier()
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def hetero_gym_steps(N, dev, rank, world, steps):
+    from pymgrid_amd.hetero import BucketedFleet
+    per = N // 3
+    out = {}
+    for name, dt in (("float64_rows", torch.float64), ("float32_rows", torch.float32)):
+        batches = [generate(per * world, n_steps=steps + 1100, seed=43 + k, arch=arch, horizon=24, device=dev, rank=rank,
+                            world=world) for k, arch in enumerate(("genset+battery", "battery+grid", "genset+battery+grid"))]
+        fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=8)
+        gen = torch.Generator(device=dev); gen.manual_seed(11 + rank)
+        acts = [torch.rand(per, e.layout.action_dim, dtype=torch.float64, device=dev, generator=gen) for e in fleet.envs]
+        # warm-up by wall time: the fleet is built on the host while the GPU idles and clocks down, and under this
+        # host-paced load the clocks take ~0.2 s to come back (first leg measured 5x slow with a 512-step warm-up)
+        t_end = time.perf_counter() + 0.6
+        while time.perf_counter() < t_end:
+            fleet.reset()
+            for _ in range(1000):
+                fleet.step(acts)
+            torch.cuda.synchronize(dev)
+        fleet.reset()
+        for _ in range(64):
+            fleet.step(acts)
+        wall, _ = timed(lambda k: [fleet.step(acts) for _ in range(k)], steps, dev)
+        wall = mdist.max_over_ranks(wall, dev)
+        out[name] = {"value": 3 * per * world * steps / wall, "us_per_step": wall / steps * 1e6}
+        fleet.close()
+        del fleet, batches
+        torch.cuda.empty_cache()
+    out.update({"grids_per_gpu": 3 * per, "obs_dims": [56, 106, 156], "horizon": 24, "obs_prefetch": 8, "steps": steps,
+                "workload": "BASELINE configs[4] mix per GPU: 1/3 genset+battery, 1/3 battery+grid, 1/3 genset+battery+grid; "
+                            "Gym step() with observation rows"})
+    return out
 
 
 def cpu_baseline(eng, pool, seconds):
@@ -236,6 +270,13 @@ def main():
                          "avg_launch_us": avg_launch_s * 1e6},
         }
 
+    # BASELINE configs[4] in miniature, reported under "other": a heterogeneous fleet (1/3 genset+battery, 1/3
+    # battery+grid, 1/3 genset+battery+grid; forecast_horizon = 24) stepped through the Gym surface WITH observations
+    # (window prefetch K = 8), one bucket per HIP stream.
+    hetero = None
+    if args.hetero_steps > 0:
+        hetero = hetero_gym_steps(N, dev, rank, world, args.hetero_steps)
+
     # metrics vector: episode-return sum + mean SoC, all-reduced over ranks (the ONLY collective; RCCL over xGMI)
     sums = eng.metrics(torch.stack([run.reward_k[-1], batch.cols["soc"]]))
     mdist.all_reduce_metrics(sums)
@@ -262,6 +303,7 @@ def main():
             "other": {names[m]: {"value": r["value"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
                                  "roofline": r["roofline"]} for m, r in results.items() if m != args.mode},
             "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total},
+            "hetero_h24_gym_steps": hetero,
         }
         print(json.dumps(line), flush=True)
     eng.close()

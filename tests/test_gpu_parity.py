@@ -361,12 +361,13 @@ def test_error_paths(pymgrid25, device):
         StepEngine(_batch([p], "cpu"))                                           # no CPU path
 
 
-def test_bucketed_fleet_of_mixed_layouts(pymgrid25, device):
+@pytest.mark.parametrize("streams,prefetch", [(False, 0), (True, 0), (False, 8)])
+def test_bucketed_fleet_of_mixed_layouts(streams, prefetch, pymgrid25, device):
     """BASELINE config 5 shape: the 25 scenarios (3 module sets) as ONE fleet; per-grid rewards / SoC of 200 steps
-    equal the per-scenario goldens, buckets stepped on separate streams."""
+    equal the per-scenario goldens; buckets back to back, on separate streams, and with window prefetch."""
     from pymgrid_amd.hetero import BucketedFleet
     z = golden("pymgrid25_run.npz")
-    fleet = BucketedFleet(pymgrid25, device=device, observations=True)
+    fleet = BucketedFleet(pymgrid25, device=device, observations=True, streams=streams, obs_prefetch=prefetch)
     assert len(fleet.envs) == 3 and len(fleet) == 25
     obs = fleet.reset()
     assert [o.shape[1] for o in obs] == [env.layout.obs_dim for env in fleet.envs]
