@@ -54,6 +54,8 @@ enum mgx_status {
 
 /* element type of the observation rows (mgx_set_obs_format) */
 enum mgx_obs_format { MGX_OBS_F64 = 0, MGX_OBS_F32 = 1 };
+/* element type of the continuous `actions` of mgx_step / mgx_step_k (mgx_set_action_format) */
+enum mgx_action_format { MGX_ACT_F64 = 0, MGX_ACT_F32 = 1 };
 /* what the `obs` argument of mgx_step / mgx_step_discrete / mgx_observe / mgx_reset receives (mgx_set_obs_mode) */
 enum mgx_obs_rows { MGX_OBS_ROWS_FULL = 0, MGX_OBS_ROWS_STATE_ONLY = 1 };
 
@@ -161,6 +163,11 @@ int mgx_set_forecast_noise(mgx_handle *h, uint64_t seed, int increase_uncertaint
  * reason: [N, D] doubles or [N, D] floats. */
 int mgx_set_obs_format(mgx_handle *h, int32_t format);
 
+/* Element type of the continuous controls passed to mgx_step / mgx_step_k: MGX_ACT_F64 (default) or MGX_ACT_F32 -- a
+ * policy network emits floats; they are widened to double exactly and every operation after that is the float64 one
+ * (= the reference fed `actions.astype(float64)`).  Halves the action stream of the fused kernel (24 -> 12 of 57 B). */
+int mgx_set_action_format(mgx_handle *h, int32_t format);
+
 /* Window prefetch.  The time-series windows of an observation (load / pv / grid: current value + forecast, the bulk of
  * the row; base_timeseries_module.py:103-140, forecaster.py:120-149) depend on the series only, never on the actions, and
  * consecutive steps share all but one of their rows.  mgx_observe_windows writes the observation rows of the NEXT K
@@ -180,14 +187,14 @@ int mgx_observe(mgx_handle *h, void *obs, mgx_stream stream);
 /* ONE Microgrid.run(control, normalized) for all N grids (microgrid.py:227-325), as BaseMicrogridEnv.step
  * returns it (base.py:169-209): reward [N], done [N] (0/1), optional post-step obs [N, D] and log [L, N].
  * The step counter advances by one.  MGX_ERR_RANGE if the counter is already outside the series. */
-int mgx_step(mgx_handle *h, const double *actions, int normalized,
+int mgx_step(mgx_handle *h, const void *actions, int normalized,
              double *reward, uint8_t *done, void *obs, double *log, mgx_stream stream);
 
 /* K consecutive Microgrid.run calls in ONE launch: parameters and state stay in registers, actions
  * [K, N, A] are streamed.  Outputs (each may be NULL): reward [K, N], done [K, N], soc_trace [K, N],
  * status_trace [K, N] (post-step packed genset status), ret_acc [N] (+= sum of the K rewards per grid),
  * log [K, L, N].  Replaces the user loop `for a in actions: env.step(a)` (README.md:109-111). */
-int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized,
+int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized,
                double *reward, uint8_t *done, double *soc_trace, uint32_t *status_trace,
                double *ret_acc, double *log, mgx_stream stream);
 

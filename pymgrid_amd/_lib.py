@@ -73,6 +73,7 @@ SYMBOLS = {
     "mgx_set_forecast_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
     "mgx_set_obs_format": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_set_obs_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mgx_set_action_format": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_observe_windows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgx_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgx_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

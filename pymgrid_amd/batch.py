@@ -118,7 +118,7 @@ class BatchLayout:
             B += 8 * self.obs_dim + 8 * C_ts
         return B
 
-    def bytes_fused(self, K, reward=True, done=True, soc_trace=True, status_trace=False, log=False):
+    def bytes_fused(self, K, reward=True, done=True, soc_trace=True, status_trace=False, log=False, action_bytes=8):
         """Compulsory HBM bytes of ONE grid for a K-step fused launch: parameters and state move once, the
         per-step streams (actions, series rows, requested outputs) K times."""
         A = self.action_dim
@@ -127,7 +127,7 @@ class BatchLayout:
         # once: float params, packed genset times, charge read + charge/soc write, genset status read + write
         once = 8 * P_f + 4 * int(self.has_genset) + (8 + 16) * int(self.has_battery) + 8 * int(self.has_genset) \
             + 8 * int(log and self.has_battery)      # the log also reads the pre-launch SoC
-        per = 8 * (A + C_ts) + 8 * int(reward) + int(done) + 8 * int(soc_trace and self.has_battery) \
+        per = action_bytes * A + 8 * C_ts + 8 * int(reward) + int(done) + 8 * int(soc_trace and self.has_battery) \
             + 4 * int(status_trace and self.has_genset) + 8 * len(self.log_names) * int(log)
         return once + K * per
 

@@ -41,6 +41,7 @@ struct KArgs {
     int32_t obs_dim, log_dim;
     int32_t n_load, n_pv;    // load / renewable modules per grid (1 on the fast path, <= MGX_MAX_MODULES otherwise)
     int32_t obs_f32;         // observation rows are written as float (RN of the fp64 value) instead of double
+    int32_t act_f32;         // continuous actions arrive as float (widened to double exactly) instead of double
     int32_t obs_state_only;  // obs arguments of step / observe receive ONLY the state columns (windows were prefetched)
     int32_t shaper;          // mgx_reward_shaper
     int32_t noise_increase;  // GaussianNoiseForecaster.increase_uncertainty
@@ -188,12 +189,12 @@ __device__ __forceinline__ void store_state(const mgx_columns &c, int64_t i, con
 }
 
 // actions row [A] of grid i at `act` (row-major [N, A]); series rows at time t
-template <int F>
-__device__ __forceinline__ void load_inputs(const mgx_columns &c, const double *__restrict__ act,
+template <int F, typename AT>
+__device__ __forceinline__ void load_inputs(const mgx_columns &c, const AT *__restrict__ act,
                                             int64_t N, int64_t i, int64_t t, Inputs &in)
 {
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const double *a = act + i * A;
+    const AT *a = act + i * A;
     int k = 0;
     if constexpr (F & F_GENSET) { in.a_goal = a[k]; in.a_gen = a[k + 1]; k += 2; }
     if constexpr (F & F_BATTERY) { in.a_bat = a[k]; k += 1; }

@@ -32,7 +32,7 @@ constexpr int BLOCK_K = MGX_BLOCK_K;
 // Single step: Microgrid.run for N grids (microgrid.py:227-325) + optional obs (base.py:205-209) + log.
 // ------------------------------------------------------------------------------------------------------
 template <int F>
-__global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double *__restrict__ actions, int32_t t,
+__global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
                                                      int normalized, double *__restrict__ reward,
                                                      uint8_t *__restrict__ done, void *__restrict__ obs,
                                                      double *__restrict__ log)
@@ -42,7 +42,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const double
     if (i >= a.N) return;
     // all loads first (independent, one latency round), then the arithmetic
     Params p; State s; Inputs in; Outputs o; Derived d;
-    load_inputs<F>(a.c, actions, a.N, i, t, in);
+    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t, in);
+    else load_inputs<F>(a.c, (const double *)actions, a.N, i, t, in);
     load_state<F>(a.c, i, log != nullptr, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
@@ -81,13 +82,35 @@ struct FusedOut {
     double *log;
 };
 
-template <int F>
-__device__ __forceinline__ void load_inputs_at(const double *__restrict__ act, const double *__restrict__ lts,
+// One ring slot: the controls stay in their storage type until the step consumes them (widening a float at load time
+// makes the prefetch wait for its own data: measured 86 instead of 77 us per launch).
+template <typename AT>
+struct RawInputs {
+    AT a_goal, a_gen, a_bat, a_grid;
+    double load, pv, g_pimp, g_pexp, g_co2, g_stat;
+};
+
+template <int F, typename AT>
+__device__ __forceinline__ Inputs widen(const RawInputs<AT> &r)
+{
+    Inputs in;
+    if constexpr (F & F_GENSET) { in.a_goal = (double)r.a_goal; in.a_gen = (double)r.a_gen; }
+    if constexpr (F & F_BATTERY) in.a_bat = (double)r.a_bat;
+    if constexpr (F & F_GRID) {
+        in.a_grid = (double)r.a_grid;
+        in.g_pimp = r.g_pimp; in.g_pexp = r.g_pexp; in.g_co2 = r.g_co2; in.g_stat = r.g_stat;
+    }
+    in.load = r.load; in.pv = r.pv;
+    return in;
+}
+
+template <int F, typename AT>
+__device__ __forceinline__ void load_inputs_at(const AT *__restrict__ act, const double *__restrict__ lts,
                                                const double *__restrict__ pts, const double *__restrict__ gts,
-                                               int64_t N, int64_t i, int64_t off, Inputs &in)
+                                               int64_t N, int64_t i, int64_t off, RawInputs<AT> &in)
 {
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const double *a = act + off * A;
+    const AT *a = act + off * A;
     int k = 0;
     if constexpr (F & F_GENSET) { in.a_goal = a[k]; in.a_gen = a[k + 1]; k += 2; }
     if constexpr (F & F_BATTERY) { in.a_bat = a[k]; k += 1; }
@@ -100,8 +123,8 @@ __device__ __forceinline__ void load_inputs_at(const double *__restrict__ act, c
     }
 }
 
-template <int F, int U>
-__global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const double *__restrict__ actions, int32_t t0,
+template <int F, int U, typename AT>
+__global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT *__restrict__ actions, int32_t t0,
                                                          int32_t K, int normalized, const FusedOut out, int32_t gpb)
 {
     const int32_t K_launch = K;          // what the host asked for (the counter always moves by this much)
@@ -126,7 +149,7 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const do
     const int32_t k_done = a.final_step - 1 - t0;            // done <=> k >= k_done
     double ret = 0.0;
 
-    Inputs ring[U];
+    RawInputs<AT> ring[U];
 #pragma unroll
     for (int u = 0; u < U; u++)
         if (u < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
@@ -137,7 +160,7 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const do
         for (int u = 0; u < U; u++) {
             const int32_t k = k0 + u;
             if (k < K) {
-                const Inputs in = ring[u];
+                const Inputs in = widen<F>(ring[u]);
                 if (k + U < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
                 Outputs o;
                 step_core<F>(p, d, s, in, norm, want_soc, gen_instant, o);
@@ -577,11 +600,11 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
 // General path: n_load / n_pv != 1 (series [T, n_load, N] and [T, n_pv, N], bounds [n_load, N] / [n_pv, N]).
 // Straightforward one-lane-per-grid kernels; parity with the reference's multi-module grids, not speed.
 // ------------------------------------------------------------------------------------------------------
-template <int F>
-__device__ inline void load_controls_multi(const KArgs &a, const double *__restrict__ actions, int64_t i, int32_t t, Inputs &in)
+template <int F, typename AT>
+__device__ inline void load_controls_multi(const KArgs &a, const AT *__restrict__ actions, int64_t i, int32_t t, Inputs &in)
 {
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const double *ap = actions + i * A;
+    const AT *ap = actions + i * A;
     int k = 0;
     if constexpr (F & F_GENSET) { in.a_goal = ap[k]; in.a_gen = ap[k + 1]; k += 2; }
     if constexpr (F & F_BATTERY) { in.a_bat = ap[k]; k += 1; }
@@ -641,7 +664,7 @@ __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, c
 }
 
 template <int F>
-__global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const double *__restrict__ actions, int32_t t,
+__global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
                                                            int normalized, double *__restrict__ reward,
                                                            uint8_t *__restrict__ done, void *__restrict__ obs,
                                                            double *__restrict__ log)
@@ -651,7 +674,8 @@ __global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const 
     if (i >= a.N) return;
     const int64_t N = a.N;
     Params p; State s; Inputs in; Outputs o; Derived d;
-    load_controls_multi<F>(a, actions, i, t, in);
+    if (a.act_f32) load_controls_multi<F>(a, (const float *)actions, i, t, in);
+    else load_controls_multi<F>(a, (const double *)actions, i, t, in);
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
@@ -972,7 +996,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->k.log_dim = LC_COMMON_END + LC_GENSET_N * L->has_genset + LC_BATTERY_N * L->has_battery + LC_GRID_N * L->has_grid + 1;
     h->t = L->initial_step;
     h->k.shaper = MGX_SHAPER_NONE;
-    h->k.noise_seed = 0; h->k.noise_increase = 0; h->k.obs_f32 = 0; h->k.obs_state_only = 0;
+    h->k.noise_seed = 0; h->k.noise_increase = 0; h->k.obs_f32 = 0; h->k.obs_state_only = 0; h->k.act_f32 = 0;
     h->window_lo = L->initial_step; h->window_hi = final_step;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
@@ -1058,6 +1082,16 @@ int mgx_set_obs_format(mgx_handle *h, int32_t format)
     if (format != MGX_OBS_F64 && format != MGX_OBS_F32)
         return fail(MGX_ERR_INVALID, "mgx_set_obs_format: unknown format %d", format);
     h->k.obs_f32 = format == MGX_OBS_F32;
+    return MGX_OK;
+}
+
+int mgx_set_action_format(mgx_handle *h, int32_t format)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_action_format: NULL handle");
+    if (format != MGX_ACT_F64 && format != MGX_ACT_F32)
+        return fail(MGX_ERR_INVALID, "mgx_set_action_format: unknown format %d", format);
+    h->k.act_f32 = format == MGX_ACT_F32;
     return MGX_OK;
 }
 
@@ -1170,7 +1204,7 @@ int mgx_reset(mgx_handle *h, int32_t initial_step, void *obs, mgx_stream stream)
     return obs ? mgx_observe(h, obs, stream) : MGX_OK;
 }
 
-int mgx_step(mgx_handle *h, const double *actions, int normalized, double *reward, uint8_t *done, void *obs,
+int mgx_step(mgx_handle *h, const void *actions, int normalized, double *reward, uint8_t *done, void *obs,
              double *log, mgx_stream stream)
 {
     g_err[0] = 0;
@@ -1197,7 +1231,7 @@ int mgx_step(mgx_handle *h, const double *actions, int normalized, double *rewar
     return MGX_OK;
 }
 
-int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized, double *reward, uint8_t *done,
+int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, double *reward, uint8_t *done,
                double *soc_trace, uint32_t *status_trace, double *ret_acc, double *log, mgx_stream stream)
 {
     g_err[0] = 0;
@@ -1210,8 +1244,14 @@ int mgx_step_k(mgx_handle *h, const double *actions, int32_t K, int normalized, 
     hipStream_t st = (hipStream_t)stream;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     const int32_t gpb = fused_grids_per_block(h);
-    MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING><<<(unsigned)((h->k.N + gpb - 1) / gpb), BLOCK_K, 0, st>>>(
-                                  h->k, actions, t_arg(h), K, normalized, fo, gpb)));
+    const unsigned blocks = (unsigned)((h->k.N + gpb - 1) / gpb);
+    if (h->k.act_f32) {
+        MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, float><<<blocks, BLOCK_K, 0, st>>>(
+                                      h->k, (const float *)actions, t_arg(h), K, normalized, fo, gpb)));
+    } else {
+        MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, double><<<blocks, BLOCK_K, 0, st>>>(
+                                      h->k, (const double *)actions, t_arg(h), K, normalized, fo, gpb)));
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_k_kernel launch");
     advance(h, K, st);

@@ -28,7 +28,7 @@ except AttributeError:                 # pragma: no cover
 
 
 class StepEngine:
-    def __init__(self, batch, obs_dtype=torch.float64):
+    def __init__(self, batch, obs_dtype=torch.float64, action_dtype=torch.float64):
         if batch.device.type != "cuda":
             raise _lib.MgxError(_lib.MGX_ERR_DEVICE,
                                 "StepEngine needs the batch on a GPU (cuda/HIP device); there is no CPU path")
@@ -54,6 +54,9 @@ class StepEngine:
         self.obs_dtype = torch.float64
         if obs_dtype != torch.float64:
             self.set_obs_dtype(obs_dtype)
+        self.action_dtype = torch.float64
+        if action_dtype != torch.float64:
+            self.set_action_dtype(action_dtype)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -90,6 +93,14 @@ class StepEngine:
         check(self._lib.mgx_set_obs_format(self._h, 1 if dtype == torch.float32 else 0))
         self.obs_dtype = dtype
 
+    def set_action_dtype(self, dtype):
+        """Element type of the continuous controls of step / step_k: torch.float64, or torch.float32 (what a policy emits;
+        widened exactly on device -- the results are those of the float64 path fed ``actions.double()``)."""
+        if dtype not in (torch.float64, torch.float32):
+            raise ValueError("action_dtype must be torch.float64 or torch.float32")
+        check(self._lib.mgx_set_action_format(self._h, 1 if dtype == torch.float32 else 0))
+        self.action_dtype = dtype
+
     def set_obs_state_only(self, flag):
         """True: the ``obs`` output of step / step_discrete / observe / reset receives only the genset / battery state
         columns -- the window columns of that row were written ahead of time by ``observe_windows``."""
@@ -121,9 +132,9 @@ class StepEngine:
             if self.action_dim:
                 raise ValueError("actions are required")
             return None
-        if tuple(actions.shape) != want or actions.dtype != torch.float64 or not actions.is_contiguous() \
+        if tuple(actions.shape) != want or actions.dtype != self.action_dtype or not actions.is_contiguous() \
                 or actions.device != self.device:
-            raise ValueError(f"actions must be a contiguous float64 tensor of shape {want} on {self.device}")
+            raise ValueError(f"actions must be a contiguous {self.action_dtype} tensor of shape {want} on {self.device}")
         return actions
 
     @property

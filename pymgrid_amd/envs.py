@@ -33,7 +33,8 @@ class BatchedMicrogridEnv:
     v1.2.2)."""
 
     def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
-                 raise_errors=False, observation_keys=None, obs_dtype=torch.float64, obs_prefetch=0):
+                 raise_errors=False, observation_keys=None, obs_dtype=torch.float64, obs_prefetch=0,
+                 action_dtype=torch.float64):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
         # raise_errors=True (base_module.py:79-93): the device always clips; the step's `violations` log column
@@ -43,7 +44,7 @@ class BatchedMicrogridEnv:
         self.batch = batch
         self.layout = batch.layout
         # obs_dtype=torch.float32: rows leave the device as floats (RN of the float64 value): what a policy consumes
-        self.engine = StepEngine(batch, obs_dtype=obs_dtype)
+        self.engine = StepEngine(batch, obs_dtype=obs_dtype, action_dtype=action_dtype)
         # obs_prefetch=K (> 1): the forecast windows of the next K steps are written in one launch every K steps
         # (engine.observe_windows: each series value read and normalised once instead of 1 + horizon times) and a step
         # only adds the genset / battery state columns.  Same values; the returned obs is a view into a [K, N, D] ring
@@ -158,10 +159,10 @@ class BatchedMicrogridEnv:
         return obs.index_select(1, self._obs_index)
 
     def step(self, action, normalized=True):
-        """action: float64 tensor [N, A] (columns ``layout.action_names``) or a control dict as taken by
-        ``Microgrid.run``.  Returns (obs [N, D], reward [N], done [N] bool, info)."""
+        """action: tensor [N, A] of the env's ``action_dtype`` (float64 by default; columns ``layout.action_names``) or
+        a control dict as taken by ``Microgrid.run``.  Returns (obs [N, D], reward [N], done [N] bool, info)."""
         if isinstance(action, dict):
-            action = self.control_to_tensor(action)
+            action = self.control_to_tensor(action).to(self.engine.action_dtype)
         want_obs, out = self._obs_target()
         obs, reward, done, log = self.engine.step(action, normalized=normalized, want_obs=want_obs,
                                                   want_log=self._keep_log, out=out)
@@ -192,7 +193,7 @@ class BatchedMicrogridEnv:
 
     def sample_action(self, generator=None):
         """Microgrid.sample_action(strict_bound=False): uniform normalised control (microgrid.py:337-362)."""
-        return torch.rand(self.n_grids, self.layout.action_dim, dtype=torch.float64, device=self.batch.device,
+        return torch.rand(self.n_grids, self.layout.action_dim, dtype=self.engine.action_dtype, device=self.batch.device,
                           generator=generator)
 
     def control_to_tensor(self, control):

@@ -701,3 +701,49 @@ def test_window_prefetch_equals_per_step_observations(arch, H, K, dtype, device)
         ids = torch.from_numpy(rs.randint(0, d_ref.action_space.n, size=N).astype(np.int32)).to(device)
         assert torch.equal(d_ref.step(ids)[0], d_pre.step(ids)[0]), k
     d_ref.close(); d_pre.close()
+
+
+@pytest.mark.parametrize("arch", ["genset+battery", "battery+grid", "genset+battery+grid"])
+def test_float32_actions_equal_widened_float64_actions(arch, device):
+    """action_dtype=float32 (mgx_set_action_format): single steps, fused K-step launches and the general multi-module
+    kernel give bit-identical rewards / state / logs to the float64 path fed ``actions.double()``."""
+    from pymgrid_amd import BatchedMicrogridEnv, StepEngine
+    from pymgrid_amd.generator import generate
+    N, T, K = 777, 64, 9
+    g = torch.Generator(device=device); g.manual_seed(3)
+
+    def make():
+        return generate(N, n_steps=T, seed=8, arch=arch, device=device, mixed_timers=True)
+    e64, e32 = StepEngine(make()), StepEngine(make(), action_dtype=torch.float32)
+    A = e64.action_dim
+    for k in range(5):
+        a = torch.rand(N, A, dtype=torch.float32, device=device, generator=g)
+        r64, r32 = e64.step(a.double(), want_log=True), e32.step(a, want_log=True)
+        assert all(torch.equal(x, y) for x, y in zip(r64, r32)), k
+    a = torch.rand(K, N, A, dtype=torch.float32, device=device, generator=g) * 1.2 - 0.1       # some out of range
+    o64 = e64.step_k(a.double(), reward=True, soc_trace=True, status_trace=True, log=True)
+    o32 = e32.step_k(a, reward=True, soc_trace=True, status_trace=True, log=True)
+    assert o64.keys() == o32.keys() and all(torch.equal(o64[k], o32[k]) for k in o64)
+    for name in ("charge", "soc", "gen_status"):
+        if name in e64.batch.cols and e64.batch.cols[name] is not None:
+            assert torch.equal(e64.batch.cols[name], e32.batch.cols[name]), name
+    with pytest.raises(ValueError):
+        e32.step(torch.rand(N, A, dtype=torch.float64, device=device))
+    e64.close(); e32.close()
+    env = BatchedMicrogridEnv(make(), action_dtype=torch.float32)
+    env.reset()
+    assert env.sample_action().dtype == torch.float32
+    env.step(env.sample_action())
+    env.step({"genset": [[1.0, 0.5]], "battery": [0.5], "grid": [0.5]})
+    env.close()
+    # general path: two loads, three renewables
+    rs = np.random.RandomState(3)
+    grids = [dict(load_ts=rs.rand(T, 2) * [20, 5], pv_ts=rs.rand(T, 3) * [10, 4, 1], horizon=2, final_step=T,
+                  initial_step=0, unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0),
+                  battery=dict(min_capacity=20.0, max_capacity=100.0, max_charge=25.0, max_discharge=25.0,
+                               efficiency=0.9, battery_cost_cycle=0.02, init_soc=0.5)) for _ in range(37)]
+    m64, m32 = StepEngine(_batch(grids, device)), StepEngine(_batch(grids, device), action_dtype=torch.float32)
+    for k in range(4):
+        a = torch.rand(37, 1, dtype=torch.float32, device=device, generator=g)
+        assert all(torch.equal(x, y) for x, y in zip(m64.step(a.double())[:3], m32.step(a)[:3])), k
+    m64.close(); m32.close()
