@@ -301,7 +301,12 @@ def pack_grids(grids):
         a = np.stack([np.asarray(g[key], dtype=np.float64).reshape(T, n) for g in grids], axis=2)
         return a[:, 0, :] if n == 1 else a
     # sign convention of the stored series (base_timeseries_module.py:68-79)
-    A["load_ts"], A["pv_ts"] = -np.abs(stack("load_ts", n_load)), np.abs(stack("pv_ts", n_pv))
+    raw_load, raw_pv = stack("load_ts", n_load), stack("pv_ts", n_pv)
+    for ts in (raw_load, raw_pv):                       # _sign_check: a pure sink / source has one sign
+        if not ((np.sign(ts) <= 0).all(axis=0) | (np.sign(ts) >= 0).all(axis=0)).all():
+            raise ValueError('time_series cannot contain both positive and negative values unless it is both '
+                             'a source and a sink.')
+    A["load_ts"], A["pv_ts"] = -np.abs(raw_load), np.abs(raw_pv)
     if n_load:
         A["load_lo"], A["load_hi"] = series_bounds(A["load_ts"])
     else:

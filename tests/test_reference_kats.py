@@ -7,6 +7,8 @@ oracle and (on a GPU) through the HIP engine.
   tests/microgrid/modules/module_tests/test_genset_module_start_up_1_wind_down_1.py
   tests/microgrid/test_microgrid.py:263-320 (check_step, load/pv-only grids)
   tests/envs/test_discrete.py:73-80 (action_space.n)
+  tests/microgrid/modules/module_tests/timeseries_modules.py:31-90, test_load_module.py:26-56,
+  test_renewable_module.py:19-58 (observation bounds, first step, forecasts, negative-valued input series)
 """
 import numpy as np
 import pytest
@@ -196,3 +198,48 @@ def test_discrete_action_space_size():
     for has in ((1, 1, 1), (1, 1, 0), (0, 1, 1), (0, 1, 0), (1, 0, 0)):
         n_modules, n_gensets = sum(has), has[0]
         assert len(get_priority_lists(*map(bool, has))) == factorial(n_modules) * 2 ** n_gensets
+
+
+# ---- timeseries_modules.py / test_load_module.py / test_renewable_module.py --------------------------------------
+# The reference tests one module at a time; here the same series drive a load + renewable microgrid (no controllable
+# module), where the load module behaves as in its own test and the renewable module is the flex source.
+SERIES = 2 - np.cos(np.pi * np.arange(100) / 2)                       # timeseries_modules.py:24-26  (1, 2, 3, 2, ...)
+
+
+@pytest.mark.parametrize("H", [0, 24])                                # NoForecasting / Forecasting
+@pytest.mark.parametrize("flip", [1, -1])                             # ...NegativeVals: the module is handed -series
+def test_timeseries_modules_first_step_and_bounds(backend, H, flip):
+    from pymgrid_amd.batch import pack_grids
+    p = dict(load_ts=flip * SERIES, pv_ts=flip * 0.5 * SERIES, horizon=H, final_step=100, initial_step=0,
+             unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0))
+    A, layout = pack_grids([p])
+    # test_observation_space: Box(min(0, ts.min()), max(0, ts.max())) with ts in the module's sign convention
+    assert A["load_lo"][0] == -3.0 and A["load_hi"][0] == 0.0 and A["pv_lo"][0] == 0.0 and A["pv_hi"][0] == 1.5
+    assert layout.obs_dim == 2 * (1 + H)
+    b = backend(p)
+    o = b.step({}, True)
+    assert o["done"] == 0 and o["load_met"] == SERIES[0]               # info["absorbed_energy"] == -1 * time_series[0]
+    assert o["renewable_used"] == 0.5 * SERIES[0] and o["curtailment"] == 0   # the flex source covers what it can
+    assert o["reward"] == -10.0 * (SERIES[0] - 0.5 * SERIES[0])        # the load module itself contributes reward 0
+    obs = np.asarray(o["obs"], dtype=np.float64)
+    W = 1 + H
+    # from_normalized(obs, obs=True) == time_series[1 : forecast_horizon + 2]   (test_step; the reference's assertEqual
+    # falls back to allclose(rtol=1e-7, atol=1e-10) for arrays, tests/helpers/test_case.py)
+    np.testing.assert_allclose(-3.0 + 3.0 * obs[:W], -SERIES[1:H + 2], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(0.0 + 1.5 * obs[W:2 * W], 0.5 * SERIES[1:H + 2], rtol=1e-7, atol=1e-10)
+    # test_observations_in_observation_space: every observation of the episode lies in [0, 1]; done on the last row
+    k = 1
+    while not o["done"]:
+        o = b.step({}, True)
+        k += 1
+        obs = np.asarray(o["obs"], dtype=np.float64)
+        assert ((obs >= 0) & (obs <= 1)).all(), k
+    assert k == 100                                                    # done on the step taken at t = final_step - 1
+
+
+def test_mixed_sign_series_is_rejected():                              # base_timeseries_module.py:68-79 (_sign_check)
+    from pymgrid_amd.batch import pack_grids
+    p = dict(load_ts=np.array([1.0, -1.0, 2.0]), pv_ts=np.zeros(3), horizon=0, final_step=3, initial_step=0,
+             unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0))
+    with pytest.raises(ValueError, match="both positive and negative"):
+        pack_grids([p])
