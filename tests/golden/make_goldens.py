@@ -16,6 +16,7 @@ Fixture families:
   generated.npz          G6/G7: generator-style grids built as real pymgrid modules (genset FSM timers,
                          grid module with outages, normalised and raw actions)
   loadpv.npz             multi-module load/pv-only grids (the reference's TestMicrogridLoadPV family)
+  helper_microgrid.npz   the fixture microgrid of the reference's own tests: random actions, RBC, discrete env
 """
 import itertools
 import json
@@ -619,7 +620,54 @@ def make_obskeys():
     save("obskeys.npz", **out)
 
 
+def make_helper():
+    """The fixture microgrid of the reference's OWN test suite (tests/helpers/modular_microgrid.py:14-37: genset 10..50
+    at cost 0.5, lossless 100-unit battery at SoC 0.5, renewable 50, load 60, import-only grid with unit prices) --
+    rebuilt here through the public module constructors with the same arguments -- run (a) with 60 seeded random
+    normalised actions, observations included, (b) by RuleBasedControl for 10 steps (tests/control/test_rbc.py:28-38),
+    (c) through DiscreteMicrogridEnv with 40 random priority-list ids."""
+    from pymgrid.algos import RuleBasedControl
+
+    def build(T=100):
+        return Microgrid([GensetModule(running_min_production=10, running_max_production=50, genset_cost=0.5),
+                          BatteryModule(min_capacity=0, max_capacity=100, max_charge=50, max_discharge=50, efficiency=1.0,
+                                        init_soc=0.5),
+                          RenewableModule(time_series=50 * np.ones(T)),
+                          LoadModule(time_series=60 * np.ones(T)),
+                          GridModule(max_import=100, max_export=0, time_series=np.ones((T, 3)), raise_errors=True)])
+    m = build()
+    p = extract_params(m)
+    scalars, arrays = split_params(p)
+    out = {"meta": np.array(json.dumps(scalars))}
+    out.update({f"in_{k}": v for k, v in arrays.items()})
+    rs = np.random.RandomState(77)
+    acts = rs.rand(60, action_dims(p))
+    m.reset()
+    res = run_episode(m, p, acts, normalized=True, want_obs=True)
+    out["rand_actions"] = acts
+    for k in ("reward", "done", "charge", "soc", "status", "obs", "log"):
+        out[f"rand_{k}"] = res[k]
+    rbc = RuleBasedControl(build())
+    mod_id = {GensetModule: 0, BatteryModule: 1, GridModule: 2}
+    out["rbc_plist"] = np.array([(mod_id[type(rbc.microgrid.modules[el.module[0]][el.module[1]])], el.action)
+                                 for el in rbc.priority_list], np.int32)
+    out["rbc_marginal_cost"] = np.array([el.marginal_cost for el in rbc.priority_list], np.float64)
+    log = rbc.run(10)
+    out["rbc_reward"] = log[("balance", 0, "reward")].values.astype(np.float64)
+    out["rbc_final"] = np.array(post_state(rbc.microgrid)[:2])
+    env = DiscreteMicrogridEnv.from_microgrid(build())
+    ids = rs.randint(0, env.action_space.n, size=40)
+    env.reset()
+    r = []
+    for a in ids:
+        r.append(env.step(int(a))[1])
+    out["disc_ids"], out["disc_reward"], out["disc_n"] = ids.astype(np.int32), np.array(r, np.float64), np.array(env.action_space.n)
+    out["log_names"] = np.array(LOG_NAMES)
+    save("helper_microgrid.npz", **out)
+    print("helper: rand reward sum", res["reward"].sum(), "rbc", out["rbc_reward"], "plist", out["rbc_plist"].tolist())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pymgrid25", "discrete", "genset_fsm", "obs", "generated", "loadpv", "rbc", "shaping", "obskeys"]
+    which = sys.argv[1:] or ["pymgrid25", "discrete", "genset_fsm", "obs", "generated", "loadpv", "rbc", "shaping", "obskeys", "helper"]
     for w in which:
         globals()["make_" + w]()
