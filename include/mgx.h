@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 1
+#define MGX_ABI_VERSION 2
 
 enum mgx_status {
     MGX_OK = 0,
@@ -83,6 +83,10 @@ typedef struct mgx_layout {
     int32_t has_grid;         /* 0/1 GridModule    */
     int32_t n_load;           /* LoadModule count      (1 on the fast path; 0..16 via the general kernels) */
     int32_t n_pv;             /* RenewableModule count (1 on the fast path; 0..16 via the general kernels) */
+    int32_t grid_before_battery;   /* 0/1: the GridModule precedes the BatteryModule in the microgrid's module list and is
+                                    * therefore stepped / summed first (module_container.py:355-413; the controllable
+                                    * sweep is pure sources, then sources-and-sinks in list order).  Changes the last
+                                    * bit of the balance sums, not the action / log / observation column order. */
 } mgx_layout;
 
 /* Device columns.  Pointers for absent modules may be NULL. */

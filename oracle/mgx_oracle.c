@@ -265,8 +265,9 @@ int orc_run(const orc_grid *g, orc_state *s, const orc_action *a, int normalized
     /* controllable modules in container order: sources (genset) then source_and_sinks
      * (battery, grid)  -- module_container.py:355-413, microgrid.py:262-275 */
     if (g->has_genset)  genset_step(g, s, a->genset, normalized, &m, out);
+    if (g->grid_before_battery && g->has_grid) grid_step(g, s, a->grid, normalized, &m, out);
     if (g->has_battery && battery_step(g, s, a->battery, normalized, &m, out) != 0) return -3;
-    if (g->has_grid)    grid_step(g, s, a->grid, normalized, &m, out);
+    if (!g->grid_before_battery && g->has_grid) grid_step(g, s, a->grid, normalized, &m, out);
 
     double provided = orc_np_sum(m.provided, m.n_provided);          /* microgrid.py:277 */
     double consumed = orc_np_sum(m.absorbed, m.n_absorbed);
@@ -435,6 +436,7 @@ static void batch_init_grid(const orc_batch *b, int32_t i, int32_t t0, orc_grid 
     const int32_t N = b->N;
     memset(g, 0, sizeof(*g)); memset(s, 0, sizeof(*s));
     g->has_genset = b->has_genset; g->has_battery = b->has_battery; g->has_grid = b->has_grid;
+    g->grid_before_battery = b->grid_before_battery;
     g->n_load = 1; g->n_pv = 1; g->horizon = b->horizon; g->T = b->T; g->final_step = b->final_step;
     s->t = t0;
     if (b->has_battery) {

@@ -60,6 +60,9 @@ typedef struct orc_grid {
     const double *load_lo, *load_hi;   /* [n_load] */
     const double *pv_lo, *pv_hi;       /* [n_pv]   */
     double grid_lo[4], grid_hi[4];
+    /* the GridModule precedes the BatteryModule in the microgrid's module list: source-and-sink modules are swept in
+     * list order (module_container.py:355-413), so it is stepped and appended to the MicrogridStep lists first */
+    int32_t grid_before_battery;
 } orc_grid;
 
 /* Dynamic state of ONE microgrid. */
@@ -143,6 +146,7 @@ typedef struct orc_batch {
     const double *grid_ts;              /* [T,4,N] */
     double *charge, *soc;               /* [N] state */
     uint32_t *gen_status;               /* [N] cur | goal<<8 | up<<16 | down<<24 */
+    int32_t grid_before_battery;        /* as in orc_grid */
 } orc_batch;
 int64_t orc_run_batch(const orc_batch *b, int32_t t0, int32_t K, const double *actions, int normalized,
                       double *reward, int32_t nthreads);

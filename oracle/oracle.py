@@ -43,6 +43,7 @@ class Grid(C.Structure):
         ("grid_ts", c_double_p), ("grid_t_stride", C.c_int64), ("grid_c_stride", C.c_int64),
         ("load_lo", c_double_p), ("load_hi", c_double_p), ("pv_lo", c_double_p), ("pv_hi", c_double_p),
         ("grid_lo", C.c_double * 4), ("grid_hi", C.c_double * 4),
+        ("grid_before_battery", C.c_int32),
     ]
 
 
@@ -92,6 +93,7 @@ class Batch(C.Structure):
         ("loss_load_cost", c_double_p), ("overgeneration_cost", c_double_p),
         ("load_ts", c_double_p), ("pv_ts", c_double_p), ("grid_ts", c_double_p),
         ("charge", c_double_p), ("soc", c_double_p), ("gen_status", c_u32_p),
+        ("grid_before_battery", C.c_int32),
     ]
 
 
@@ -210,6 +212,9 @@ class OracleMicrogrid:
                 g.grid_lo[c], g.grid_hi[c] = gts[:, c].min(), gts[:, c].max()
         g.loss_load_cost = float(p["unbalanced"]["loss_load_cost"])
         g.overgeneration_cost = float(p["unbalanced"]["overgeneration_cost"])
+        order = [str(x) for x in (p.get("controllable_order") or [])]
+        g.grid_before_battery = int(g.has_grid and g.has_battery and "grid" in order and "battery" in order
+                                    and order.index("grid") < order.index("battery"))
         self.g, self.s = g, st
         self.obs_dim = lib().orc_obs_dim(C.byref(g))
 
@@ -273,6 +278,7 @@ def _make_batch(cols, state, keep):
     lay = cols["layout"]
     b.N, b.T, b.horizon, b.final_step = lay["N"], lay["T"], lay.get("horizon", 0), lay["final_step"]
     b.has_genset, b.has_battery, b.has_grid = lay["has_genset"], lay["has_battery"], lay["has_grid"]
+    b.grid_before_battery = int(lay.get("grid_before_battery", 0))
     for name, _ in Batch._fields_:
         if name in cols and name not in ("gen_times", "gen_status", "charge", "soc"):
             setattr(b, name, f64(cols[name]))

@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-fPIC", "-shared"]
 
 MGX_OK, MGX_ERR_INVALID, MGX_ERR_UNSUPPORTED, MGX_ERR_RANGE, MGX_ERR_DEVICE = range(5)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MgxError(RuntimeError):
@@ -35,7 +35,7 @@ c_i32_p = C.POINTER(C.c_int32)
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "n_grids", "n_steps", "horizon", "initial_step", "final_step",
-        "has_genset", "has_battery", "has_grid", "n_load", "n_pv")]
+        "has_genset", "has_battery", "has_grid", "n_load", "n_pv", "grid_before_battery")]
 
 
 _F64_COLS = ("bat_min_capacity", "bat_max_capacity", "bat_max_charge", "bat_max_discharge", "bat_efficiency",
@@ -132,7 +132,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.mgx_abi_version() != ABI_VERSION:
             raise ImportError(f"libmgx.so ABI {L.mgx_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
-        assert C.sizeof(Layout) == 44
+        assert C.sizeof(Layout) == 48
         _lib = L
     return _lib
 

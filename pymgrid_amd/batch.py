@@ -27,10 +27,15 @@ class BatchLayout:
     has_grid: bool = False
     n_load: int = 1
     n_pv: int = 1
+    # the GridModule precedes the BatteryModule in the microgrid's module list: it is stepped and summed first
+    # (module_container.py:355-413).  Column orders (actions, log, observation) do not depend on it.
+    grid_before_battery: bool = False
 
     def __post_init__(self):
         if self.final_step <= 0:
             object.__setattr__(self, "final_step", self.n_steps)
+        if self.grid_before_battery and not (self.has_grid and self.has_battery):
+            object.__setattr__(self, "grid_before_battery", False)
 
     @property
     def action_dim(self):
@@ -238,7 +243,8 @@ class MicrogridBatch:
             out[k] = v.cpu().numpy().view(np.uint32) if v.dtype == torch.int32 else v.cpu().numpy()
         out["layout"] = dict(N=self.layout.n_grids, T=self.layout.n_steps, horizon=self.layout.horizon,
                              final_step=self.layout.final_step, has_genset=int(self.layout.has_genset),
-                             has_battery=int(self.layout.has_battery), has_grid=int(self.layout.has_grid))
+                             has_battery=int(self.layout.has_battery), has_grid=int(self.layout.has_grid),
+                             grid_before_battery=int(self.layout.grid_before_battery))
         return out
 
     def c_layout(self):
@@ -262,6 +268,16 @@ def series_bounds(ts):
     """Observation bounds of a load / renewable series: base_timeseries_module.py:81-88."""
     lo, hi = ts.min(axis=0), ts.max(axis=0)
     return np.minimum(lo, 0.0), np.maximum(hi, 0.0)
+
+
+def grid_first(p):
+    """True when the parameter dict says the GridModule comes before the BatteryModule in the module list
+    (``controllable_order``: names of the controllable modules in list order, e.g. ("grid", "battery", "genset"))."""
+    order = p.get("controllable_order")
+    if not order or p.get("grid") is None or p.get("battery") is None:
+        return False
+    order = [str(x) for x in order]
+    return "grid" in order and "battery" in order and order.index("grid") < order.index("battery")
 
 
 def pack_grids(grids):
@@ -291,7 +307,9 @@ def pack_grids(grids):
     layout = BatchLayout(n_grids=N, n_steps=T, horizon=int(g0.get("horizon", 0)),
                          initial_step=int(g0.get("initial_step", 0)), final_step=int(g0.get("final_step", 0)),
                          has_genset=has["genset"], has_battery=has["battery"], has_grid=has["grid"],
-                         n_load=n_load, n_pv=n_pv)
+                         n_load=n_load, n_pv=n_pv, grid_before_battery=grid_first(g0))
+    if any(grid_first(g) != layout.grid_before_battery for g in grids if has["grid"] and has["battery"]):
+        raise ValueError("all microgrids of a batch must step battery and grid in the same order (bucket them by layout)")
 
     def col(fn):
         return np.array([fn(g) for g in grids], dtype=np.float64)

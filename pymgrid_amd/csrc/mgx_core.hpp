@@ -22,7 +22,10 @@
 namespace mgx {
 
 // Layout flags: template parameter F of the kernels (one specialisation per module set).
-enum : int { F_GENSET = 1, F_BATTERY = 2, F_GRID = 4 };
+// F_GRID_FIRST (only with battery AND grid): the GridModule precedes the BatteryModule in the microgrid's module list,
+// so it is stepped -- and its energies / reward are added to the running sums -- before the battery
+// (module_container.py:355-413: controllable = pure sources first, then sources-and-sinks in list order).
+enum : int { F_GENSET = 1, F_BATTERY = 2, F_GRID = 4, F_GRID_FIRST = 8 };
 
 // Log columns, in output order.  Names are returned by mgx_log_name().
 enum LogCol : int {
@@ -308,7 +311,7 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         prov += e; reward += o.genset_reward;
     }
 
-    if constexpr (F & F_BATTERY) {
+    auto step_battery = [&]() __attribute__((always_inline)) {
         const double x = normalized ? d.bat_lo + d.bat_sp * in.a_bat : in.a_bat;   // space.py:224, bounds :332-338
         o.soc_pre = s.soc; o.charge_pre = s.charge;
         // Each lane needs ONE division by eta: charging -> max_consumption = min(C, cmax - c) / eta (:288-291),
@@ -336,9 +339,8 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         if (want_soc) s.soc = s.charge / p.bat_cmax;
         o.battery_reward = -1.0 * (fabs(internal) * p.bat_cost);                // get_cost :132-147
         reward += o.battery_reward;
-    }
-
-    if constexpr (F & F_GRID) {
+    };
+    auto step_grid = [&]() __attribute__((always_inline)) {
         const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;   // _get_bounds :125-132
         const bool sink = x < 0;
         const double ex = -1.0 * x, mc = p.grid_exp * in.g_stat;               // max_consumption :318-320
@@ -354,6 +356,13 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         o.grid_reward = sink ? in.g_pexp * e_exp + cco2 : -1 * in.g_pimp * e_imp + cco2;   // get_cost :143-174
         absb += o.grid_export; prov += o.grid_import;
         reward += o.grid_reward;
+    };
+    if constexpr ((F & F_GRID_FIRST) != 0) {
+        if constexpr (F & F_GRID) step_grid();
+        if constexpr (F & F_BATTERY) step_battery();
+    } else {
+        if constexpr (F & F_BATTERY) step_battery();
+        if constexpr (F & F_GRID) step_grid();
     }
 
     const double difference = prov - absb;                                     // microgrid.py:277-278
@@ -804,19 +813,26 @@ __device__ inline void step_multi_core(const Params &p, const Derived &d, State 
         o.genset_production = oc.genset_production; o.genset_co2 = oc.genset_co2; o.genset_reward = oc.genset_reward;
         prov[n_prov++] = oc.genset_production; reward += oc.genset_reward;
     }
-    if constexpr (F & F_BATTERY) {
+    auto add_battery = [&]() __attribute__((always_inline)) {
         o.discharge_amount = oc.discharge_amount; o.charge_amount = oc.charge_amount; o.battery_reward = oc.battery_reward;
         o.soc_pre = oc.soc_pre; o.charge_pre = oc.charge_pre;
         // as_source iff the unnormalised request is >= 0 (base_module.py:161-171); a sink logs charge_amount
         const double x = normalized ? d.bat_lo + d.bat_sp * in.a_bat : in.a_bat;
         if (x < 0) absb[n_absb++] = oc.charge_amount; else prov[n_prov++] = oc.discharge_amount;
         reward += oc.battery_reward;
-    }
-    if constexpr (F & F_GRID) {
+    };
+    auto add_grid = [&]() __attribute__((always_inline)) {
         o.grid_import = oc.grid_import; o.grid_export = oc.grid_export; o.grid_co2 = oc.grid_co2; o.grid_reward = oc.grid_reward;
         const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;
         if (x < 0) absb[n_absb++] = oc.grid_export; else prov[n_prov++] = oc.grid_import;
         reward += oc.grid_reward;
+    };
+    if constexpr ((F & F_GRID_FIRST) != 0) {
+        if constexpr (F & F_GRID) add_grid();
+        if constexpr (F & F_BATTERY) add_battery();
+    } else {
+        if constexpr (F & F_BATTERY) add_battery();
+        if constexpr (F & F_GRID) add_grid();
     }
     const double provided = np_sum_dev(prov, n_prov), consumed = np_sum_dev(absb, n_absb);      // :277
     const double difference = provided - consumed;

@@ -865,7 +865,9 @@ inline void advance(mgx_handle *h, int32_t k, hipStream_t st)
         case 4: { constexpr int F = 4; CALL; } break;   \
         case 5: { constexpr int F = 5; CALL; } break;   \
         case 6: { constexpr int F = 6; CALL; } break;   \
-        default: { constexpr int F = 7; CALL; } break;  \
+        case 7: { constexpr int F = 7; CALL; } break;   \
+        case 14: { constexpr int F = 14; CALL; } break; \
+        default: { constexpr int F = 15; CALL; } break; \
     }
 
 }  // namespace
@@ -953,8 +955,8 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
                     MGX_ABI_VERSION, L->struct_size, sizeof(mgx_layout), C->struct_size, sizeof(mgx_columns));
     if (L->n_grids <= 0 || L->n_steps <= 0 || L->horizon < 0)
         return fail(MGX_ERR_INVALID, "mgx_create: need n_grids > 0, n_steps > 0, horizon >= 0");
-    if ((L->has_genset | L->has_battery | L->has_grid) & ~1)
-        return fail(MGX_ERR_INVALID, "mgx_create: has_genset / has_battery / has_grid must be 0 or 1");
+    if ((L->has_genset | L->has_battery | L->has_grid | L->grid_before_battery) & ~1)
+        return fail(MGX_ERR_INVALID, "mgx_create: has_genset / has_battery / has_grid / grid_before_battery must be 0 or 1");
     if (L->n_load < 0 || L->n_pv < 0 || L->n_load > MGX_MAX_MODULES || L->n_pv > MGX_MAX_MODULES)
         return fail(MGX_ERR_UNSUPPORTED, "mgx_create: at most %d load and %d renewable modules per grid (got n_load=%d "
                                          "n_pv=%d)", MGX_MAX_MODULES, MGX_MAX_MODULES, L->n_load, L->n_pv);
@@ -987,7 +989,8 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->layout.final_step = final_step;
     h->k.c = *C;
     h->k.N = L->n_grids; h->k.T = L->n_steps; h->k.H = L->horizon; h->k.final_step = final_step;
-    h->flags = (L->has_genset ? F_GENSET : 0) | (L->has_battery ? F_BATTERY : 0) | (L->has_grid ? F_GRID : 0);
+    h->flags = (L->has_genset ? F_GENSET : 0) | (L->has_battery ? F_BATTERY : 0) | (L->has_grid ? F_GRID : 0) |
+               ((L->grid_before_battery && L->has_battery && L->has_grid) ? F_GRID_FIRST : 0);
     h->action_dim = 2 * L->has_genset + L->has_battery + L->has_grid;
     const int w = 1 + L->horizon;
     h->k.obs_dim = (L->n_load + L->n_pv) * w + 4 * L->has_genset + 2 * L->has_battery + 4 * w * L->has_grid;

@@ -305,7 +305,7 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
                                  "and > 0, which have different action spaces in the reference "
                                  "(priority_list.py:53-67); bucket them or pass remove_redundant_gensets=False")
             redundant = n_zero == L.n_grids
-        self.actions_list = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, redundant)
+        self.actions_list = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, redundant, L.grid_before_battery)
         self._table = table_array(self.actions_list)
         self.action_space = Discrete(len(self.actions_list))
 

@@ -12,8 +12,9 @@ GENSET, BATTERY, GRID = 0, 1, 2
 MODULE_NAMES = {GENSET: "genset", BATTERY: "battery", GRID: "grid"}
 
 
-def get_priority_lists(has_genset, has_battery, has_grid, remove_redundant_gensets=False):
-    """All priority lists in the reference's order.
+def get_priority_lists(has_genset, has_battery, has_grid, remove_redundant_gensets=False, grid_before_battery=False):
+    """All priority lists in the reference's order (``grid_before_battery``: the source-and-sink modules in the order of
+    the microgrid's module list, BatchLayout.grid_before_battery).
 
     controllable sources first (genset), then source_and_sinks (battery, grid) -- priority_list.py:26-33;
     every permutation, later repeats of a module dropped (:40-47), duplicates removed keeping first
@@ -22,10 +23,8 @@ def get_priority_lists(has_genset, has_battery, has_grid, remove_redundant_gense
     elements = []
     if has_genset:
         elements += [(GENSET, 0), (GENSET, 1)]
-    if has_battery:
-        elements += [(BATTERY, 0)]
-    if has_grid:
-        elements += [(GRID, 0)]
+    sas = ([(BATTERY, 0)] if has_battery else []) + ([(GRID, 0)] if has_grid else [])
+    elements += sas[::-1] if (grid_before_battery and has_battery and has_grid) else sas
     pls = []
     for perm in permutations(elements):
         seen, pl = set(), []

@@ -39,7 +39,7 @@ def default_priority_ids(batch, actions_list, remove_redundant_gensets=True, t=N
         redundant = bool(zero.all())
     else:
         redundant = False
-    first = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, redundant)[0]
+    first = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, redundant, L.grid_before_battery)[0]
     costs = marginal_costs(batch.cols, L, t)
     # stable sort of the elements of `first` by (marginal cost ascending, action descending)
     cost = np.stack([costs[m] for m, _ in first], axis=1)                  # [N, n_el]
@@ -76,7 +76,7 @@ class RuleBasedControl:
         redundant = False
         if remove_redundant_gensets and L.has_genset:
             redundant = bool((self.batch.cols["gen_running_min"] == 0).all().item())
-        self.actions_list = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, redundant)
+        self.actions_list = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, redundant, L.grid_before_battery)
         self._table = table_array(self.actions_list)
         if priority_list is None:
             ids = default_priority_ids(self.batch, self.actions_list, remove_redundant_gensets)

@@ -35,8 +35,9 @@ def bucket_by_layout(grids):
     Returns {key: [indices]} in first-seen order."""
     buckets = {}
     for i, p in enumerate(grids):
+        from .batch import grid_first
         key = (architecture(p), np.asarray(p["load_ts"]).shape[0], int(p.get("horizon", 0)),
-               int(p.get("initial_step", 0)), int(p.get("final_step", 0)))
+               int(p.get("initial_step", 0)), int(p.get("final_step", 0)), grid_first(p))
         buckets.setdefault(key, []).append(i)
     return buckets
 
@@ -98,8 +99,11 @@ def load_scenario_yaml(path):
         raise NotImplementedError("trajectory_func / reward_shaping_func in scenario files are not supported yet")
     p, seen = {}, set()
     ts_meta = []
+    order = []                                          # controllable modules in list order (module_container.py:355-413)
     for name, mod in doc["modules"]:
         tag, cp, state = mod["__tag__"], mod["cls_params"], mod.get("state", {})
+        if tag in ("!Genset", "!BatteryModule", "!GridModule"):
+            order.append({"!Genset": "genset", "!BatteryModule": "battery", "!GridModule": "grid"}[tag])
         if tag in seen:
             raise NotImplementedError(f"more than one {tag} per microgrid is not supported on the device path")
         seen.add(tag)
@@ -164,6 +168,7 @@ def load_scenario_yaml(path):
     if len(set(ts_meta)) != 1:
         raise NotImplementedError("time-series modules with different horizon / final_step / current step")
     p["horizon"], p["final_step"], p["initial_step"] = ts_meta[0]
+    p["controllable_order"] = order
     return p
 
 

@@ -16,6 +16,7 @@ Fixture families:
   generated.npz          G6/G7: generator-style grids built as real pymgrid modules (genset FSM timers,
                          grid module with outages, normalised and raw actions)
   loadpv.npz             multi-module load/pv-only grids (the reference's TestMicrogridLoadPV family)
+  order.npz              grids whose module list names the GridModule before the BatteryModule (sweep order)
   helper_microgrid.npz   the fixture microgrid of the reference's own tests: random actions, RBC, discrete env
 """
 import itertools
@@ -620,6 +621,61 @@ def make_obskeys():
     save("obskeys.npz", **out)
 
 
+def make_order():
+    """Module-list ORDER: the controllable sweep is pure sources first, then sources-and-sinks in the order of the
+    module list (module_container.py:355-413).  Generator-style grids whose GridModule is listed BEFORE the
+    BatteryModule: random normalised + raw actions (rewards, state, log rows) and DiscreteMicrogridEnv (priority-list
+    table in the reference's enumeration order, expanded controls, rewards)."""
+    T, n_grids = 300, 8
+    grids = [g for g in draw_generated(np.random.RandomState(9100), 40, T) if "grid" in g][:n_grids]
+    assert len(grids) == n_grids and any("genset" in g for g in grids) and any("genset" not in g for g in grids)
+    mod_id = {GensetModule: 0, BatteryModule: 1, GridModule: 2}
+    kind = {GensetModule: "genset", BatteryModule: "battery", GridModule: "grid"}
+    out, meta = {}, []
+
+    def build(g):
+        q, b = g["grid"], g["battery"]
+        mods = [("load", LoadModule(time_series=g["load"])), ("pv", RenewableModule(time_series=g["pv"])),
+                ("grid", GridModule(max_import=q["max_import"], max_export=q["max_export"], time_series=q["ts"],
+                                    cost_per_unit_co2=q["cost_per_unit_co2"])),
+                ("battery", BatteryModule(**b))]
+        if "genset" in g:
+            mods.append(("genset", GensetModule(**g["genset"])))
+        return Microgrid(mods, loss_load_cost=g["loss_load_cost"], overgeneration_cost=g["overgeneration_cost"])
+    for i, g in enumerate(grids):
+        m = build(g)
+        p = extract_params(m)
+        p["controllable_order"] = [kind[type(lst[0])] for _, lst in m.controllable.iterdict()]
+        assert p["controllable_order"].index("grid") < p["controllable_order"].index("battery")
+        scalars, arrays = split_params(p)
+        meta.append(scalars)
+        out.update({f"g{i}_{k}": v for k, v in arrays.items()})
+        rs = np.random.RandomState(9200 + i)
+        K = T - 1
+        acts = rs.rand(K, action_dims(p)) * 1.3 - 0.15          # some requests outside [0, 1]: clipped by the modules
+        if "genset" in p:
+            acts[:, 0] = rs.rand(K)                              # goal status must stay inside [0, 1]
+            acts[:, 1] = np.clip(acts[:, 1], 0, None)
+        m.reset()
+        res = run_episode(m, p, acts, normalized=True)
+        out[f"g{i}_actions"] = acts
+        for k in ("reward", "charge", "soc", "status", "log"):
+            out[f"g{i}_{k}"] = res[k]
+        env = DiscreteMicrogridEnv.from_microgrid(build(g))
+        table = -np.ones((len(env.actions_list), 4, 2), np.int32)
+        for a, pl in enumerate(env.actions_list):
+            for j, el in enumerate(pl):
+                table[a, j] = (mod_id[type(env.modules[el.module[0]][el.module[1]])], el.action)
+        ids = rs.randint(0, env.action_space.n, size=200)
+        env.reset()
+        out[f"g{i}_table"], out[f"g{i}_ids"] = table, ids.astype(np.int32)
+        out[f"g{i}_disc_reward"] = np.array([env.step(int(a))[1] for a in ids], np.float64)
+        print(f"order {i}: {p['controllable_order']} n_actions={env.action_space.n} reward sum {res['reward'].sum():.3f}")
+    out["meta"] = np.array(json.dumps(meta))
+    out["log_names"] = np.array(LOG_NAMES)
+    save("order.npz", **out)
+
+
 def make_helper():
     """The fixture microgrid of the reference's OWN test suite (tests/helpers/modular_microgrid.py:14-37: genset 10..50
     at cost 0.5, lossless 100-unit battery at SoC 0.5, renewable 50, load 60, import-only grid with unit prices) --
@@ -668,6 +724,6 @@ def make_helper():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pymgrid25", "discrete", "genset_fsm", "obs", "generated", "loadpv", "rbc", "shaping", "obskeys", "helper"]
+    which = sys.argv[1:] or ["pymgrid25", "discrete", "genset_fsm", "obs", "generated", "loadpv", "rbc", "shaping", "obskeys", "helper", "order"]
     for w in which:
         globals()["make_" + w]()
