@@ -15,6 +15,8 @@ def test_yaml_loader_equals_reference_loader(pymgrid25):
     from pymgrid_amd.scenario import from_scenario
     for n, ref in enumerate(pymgrid25):
         p = from_scenario(n, REF_SCENARIOS)
+        order = p.pop("controllable_order")               # module-list order of the YAML: never grid before battery here
+        assert not ("grid" in order and "battery" in order and order.index("grid") < order.index("battery")), n
         assert set(p) == set(ref), (n, set(p) ^ set(ref))
         for k, v in ref.items():
             if isinstance(v, np.ndarray):
