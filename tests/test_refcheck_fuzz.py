@@ -29,6 +29,11 @@ def _draw(rs):
     load = peak * rs.rand(T) * (rs.rand(T) > 0.05)
     pv = peak * rs.uniform(0.2, 1.5) * rs.rand(T) * (rs.rand(T) > 0.4)
     mods = [("load", LoadModule(time_series=load, **fc)), ("pv", RenewableModule(time_series=pv, **fc))]
+    if rs.rand() < 0.3:                                  # several load / renewable modules (np.sum pairwise order at >= 8)
+        for j in range(int(rs.randint(1, 9))):
+            mods.append(("load", LoadModule(time_series=peak * 0.2 * rs.rand(T), **fc)))
+        for j in range(int(rs.randint(0, 9))):
+            mods.append(("pv", RenewableModule(time_series=peak * 0.2 * rs.rand(T) * (rs.rand(T) > 0.3), **fc)))
     arch = rs.randint(0, 8) or 3                        # bit 0 genset, bit 1 battery, bit 2 grid
     ctrl = []
     if arch & 1:
