@@ -31,13 +31,16 @@ def architecture(p):
 
 
 def bucket_by_layout(grids):
-    """Group microgrids that can share one SoA batch (same module set, series length, horizon, window).
+    """Group microgrids that can share one SoA batch (same module set and multiplicities, sweep order, series length,
+    horizon, window).
     Returns {key: [indices]} in first-seen order."""
     buckets = {}
     for i, p in enumerate(grids):
         from .batch import grid_first
-        key = (architecture(p), np.asarray(p["load_ts"]).shape[0], int(p.get("horizon", 0)),
-               int(p.get("initial_step", 0)), int(p.get("final_step", 0)), grid_first(p))
+        load, pv = np.asarray(p["load_ts"]), np.asarray(p["pv_ts"])
+        key = (architecture(p), load.shape[0], int(p.get("horizon", 0)),
+               int(p.get("initial_step", 0)), int(p.get("final_step", 0)), grid_first(p),
+               1 if load.ndim == 1 else load.shape[1], 1 if pv.ndim == 1 else pv.shape[1])
         buckets.setdefault(key, []).append(i)
     return buckets
 
