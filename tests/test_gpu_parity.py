@@ -832,6 +832,29 @@ def test_random_fleet_every_module_set_vs_oracle(seed, device, oracle):
                 for cidx, name in enumerate(eng.log_names):
                     if name in dd:
                         assert log[cidx, j] == dd[name], (where, name)
+        if L.n_load == 1 and L.n_pv == 1 and L.action_dim:   # the fused kernels of this specialisation: K steps, ids
+            from pymgrid_amd.priority_list import MODULE_NAMES, get_priority_lists, table_array
+            K = 6
+            a = rs.rand(K, len(sub), L.action_dim)
+            out = eng.step_k(_t(a, device), normalized=True, reward=True)
+            rk = out["reward"].cpu().numpy()
+            lists = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, False, L.grid_before_battery)
+            ids = rs.randint(0, len(lists), size=(K, len(sub))).astype(np.uint8)
+            out = eng.rollout_discrete(_t(ids, device, torch.uint8), table_array(lists), K, reward=True)
+            rd = out["reward"].cpu().numpy()
+            for j, (om, g) in enumerate(zip(oms, sub)):
+                if om is None:
+                    continue
+                try:
+                    for k in range(K):
+                        assert rk[k, j] == om.run(actions_for(g, a[k, j]), True).reward, (idx[j], "step_k", k)
+                    for k in range(K):
+                        act = om.populate_action([(MODULE_NAMES[m], a_) for m, a_ in lists[ids[k, j]]])
+                        assert rd[k, j] == om.run(act, normalized=False).reward, (idx[j], "rollout", k)
+                except AssertionError as e:
+                    if "absorbed_energy" not in str(e):
+                        raise
+                    oms[j] = None
         cols = eng.batch.cols
         for j, om in enumerate(oms):
             if om is None:
