@@ -531,9 +531,9 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
 // (ids [K, N], one byte each: a DiscreteMicrogridEnv roll-out) or constant per grid (ids [N]: RuleBasedControl.run,
 // algos/rbc/rbc.py:64-93).  No action stream at all: per step only the series rows are read.
 // ------------------------------------------------------------------------------------------------------
-template <int F, int U>
+template <int F, int U, bool PER_STEP>
 __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const PLWords tab, const uint8_t *__restrict__ ids,
-                                                          int per_step, int32_t t0, int32_t K, const FusedOut out, int32_t gpb)
+                                                          int32_t t0, int32_t K, const FusedOut out, int32_t gpb)
 {
     const int32_t K_launch = K;          // what the host asked for (the counter always moves by this much)
     t0 = resolve_t(a, t0);
@@ -551,7 +551,9 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
     const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
     const bool gen_instant = genset_wave_is_instant<F>(p, s);
     const int32_t k_done = a.final_step - 1 - t0;
-    uint32_t word = per_step ? 0u : pl_select(tab, ids[i]);
+    // PER_STEP = false (one fixed list per grid: RuleBasedControl): `word` is loop-invariant and the list decoding of
+    // populate_core is hoisted out of the step loop by the compiler
+    uint32_t word = PER_STEP ? 0u : pl_select(tab, ids[i]);
     double ret = 0.0;
 
     Inputs ring[U];
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
     for (int u = 0; u < U; u++)
         if (u < K) {
             load_series_at<F>(lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
-            if (per_step) idr[u] = ids[(int64_t)u * N + i];
+            if constexpr (PER_STEP) idr[u] = ids[(int64_t)u * N + i];
         }
 
     int64_t off = i;
@@ -570,10 +572,10 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
             const int32_t k = k0 + u;
             if (k < K) {
                 Inputs in = ring[u];
-                if (per_step) word = pl_select(tab, idr[u]);
+                if constexpr (PER_STEP) word = pl_select(tab, idr[u]);
                 if (k + U < K) {
                     load_series_at<F>(lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
-                    if (per_step) idr[u] = ids[off + (int64_t)U * N];
+                    if constexpr (PER_STEP) idr[u] = ids[off + (int64_t)U * N];
                 }
                 double bat_q;
                 populate_core<F>(p, s, word, in, bat_q, 0.0 + -1 * in.load, in.pv);
@@ -1341,8 +1343,14 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     hipStream_t st = (hipStream_t)stream;
     const int32_t gpb = fused_grids_per_block(h);
-    MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT><<<(unsigned)((h->k.N + gpb - 1) / gpb), BLOCK_K, 0, st>>>(
-                                  h->k, tab, action_id, per_step, t_arg(h), K, fo, gpb)));
+    const unsigned blocks = (unsigned)((h->k.N + gpb - 1) / gpb);
+    if (per_step) {
+        MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT, true><<<blocks, BLOCK_K, 0, st>>>(
+                                      h->k, tab, action_id, t_arg(h), K, fo, gpb)));
+    } else {
+        MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT, false><<<blocks, BLOCK_K, 0, st>>>(
+                                      h->k, tab, action_id, t_arg(h), K, fo, gpb)));
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rollout_kernel launch");
     advance(h, K, st);
