@@ -320,9 +320,11 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
         """One fused launch (expand + step); grids with several load / pv modules go through expand + step."""
         if self.layout.n_load != 1 or self.layout.n_pv != 1:
             return super().step(self.get_action(action_id), normalized=False)
-        if not torch.is_tensor(action_id):
-            action_id = torch.as_tensor(np.asarray(action_id), device=self.batch.device)
-        action_id = action_id.to(device=self.batch.device, dtype=torch.int32).contiguous()
+        if not (torch.is_tensor(action_id) and action_id.dtype == torch.int32 and action_id.is_contiguous()
+                and action_id.device == self.batch.device):
+            if not torch.is_tensor(action_id):
+                action_id = torch.as_tensor(np.asarray(action_id), device=self.batch.device)
+            action_id = action_id.to(device=self.batch.device, dtype=torch.int32).contiguous()
         want_obs, out = self._obs_target()
         obs, reward, done, log, _ = self.engine.step_discrete(action_id, self._table, want_obs=want_obs,
                                                               want_log=self._keep_log, out=out)
