@@ -9,6 +9,7 @@ from ._lib import MgxError, build, lib  # noqa: F401
 from .engine import StepEngine  # noqa: F401
 from .envs import (BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv, DiscreteMicrogridEnv,  # noqa: F401
                    MicrogridEnv)
+from .graph import GraphedRollout  # noqa: F401
 from .priority_list import get_priority_lists  # noqa: F401
 from .rbc import RuleBasedControl  # noqa: F401
 from .trajectory import (BatteryDischargeShaper, DeterministicTrajectory,  # noqa: F401

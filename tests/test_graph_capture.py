@@ -65,3 +65,51 @@ def test_replay_past_the_series_is_flagged(device):
         eng.use_device_counter(False)
     assert e.value.code == 3
     eng.close()
+
+
+@pytest.mark.parametrize("discrete", [False, True])
+def test_graphed_rollout_equals_the_eager_loop(discrete, device):
+    """GraphedRollout: n_steps iterations of policy -> env.step captured as ONE graph (a small fp64 network as policy),
+    replayed three times in a row, then reset and replayed again == the same loop issued eagerly on a twin env."""
+    from pymgrid_amd import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv, GraphedRollout
+    from pymgrid_amd.generator import generate
+    N, T, S = 3000, 120, 8
+    cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
+
+    def make():
+        return cls(generate(N, n_steps=T, seed=6, arch="genset+battery+grid", horizon=5, device=device, mixed_timers=True))
+    env, twin = make(), make()
+    g = torch.Generator(device=device); g.manual_seed(2)
+    D = env.layout.obs_dim
+    W1 = torch.randn(D, 16, dtype=torch.float64, device=device, generator=g) * 0.3
+    if discrete:
+        n = env.action_space.n
+        W2 = torch.randn(16, n, dtype=torch.float64, device=device, generator=g)
+
+        def policy(obs):
+            return torch.argmax(torch.tanh(obs @ W1) @ W2, dim=1).to(torch.int32)
+    else:
+        W2 = torch.randn(16, env.layout.action_dim, dtype=torch.float64, device=device, generator=g)
+
+        def policy(obs):
+            return torch.sigmoid(torch.tanh(obs @ W1) @ W2)
+    roll = GraphedRollout(env, policy, S)
+    obs = twin.reset()
+    for rep in range(3):
+        r, d, o = roll.run()
+        for k in range(S):
+            obs, rr, dd, _ = twin.step(policy(obs))
+            assert torch.equal(r[k], rr) and torch.equal(d[k], dd), (rep, k)
+        assert torch.equal(o, obs), rep
+    for name in ("charge", "soc", "gen_status"):
+        assert torch.equal(env.batch.cols[name], twin.batch.cols[name]), name
+    o0 = roll.reset()                                  # counter back to the start, state untouched (like env.reset)
+    obs = twin.reset()
+    assert torch.equal(o0, obs)
+    r, d, o = roll.run()
+    for k in range(S):
+        obs, rr, dd, _ = twin.step(policy(obs))
+        assert torch.equal(r[k], rr), k
+    roll.close()
+    assert env.current_step == twin.current_step == S
+    env.close(); twin.close()
