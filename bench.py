@@ -128,13 +128,19 @@ def hetero_gym_steps(N, dev, rank, world, steps):
         gen = torch.Generator(device=dev); gen.manual_seed(11 + rank)
         acts = [torch.rand(per, e.layout.action_dim, dtype=torch.float64, device=dev, generator=gen) for e in fleet.envs]
         # warm-up by wall time: the fleet is built on the host while the GPU idles and clocks down, and under this
-        # host-paced load the clocks take ~0.2 s to come back (first leg measured 5x slow with a 512-step warm-up)
-        t_end = time.perf_counter() + 0.6
-        while time.perf_counter() < t_end:
+        # host-paced load the clocks take a few tenths of a second to come back (first leg measured 5x slow with a
+        # 512-step warm-up, 1.6x slow with 0.6 s)
+        prev, t_end = None, time.perf_counter() + 4.0
+        while time.perf_counter() < t_end:                # until two consecutive 1000-step blocks agree within 3 %
             fleet.reset()
+            t0 = time.perf_counter()
             for _ in range(1000):
                 fleet.step(acts)
             torch.cuda.synchronize(dev)
+            cur = time.perf_counter() - t0
+            if prev is not None and abs(cur - prev) < 0.03 * prev:
+                break
+            prev = cur
         fleet.reset()
         for _ in range(64):
             fleet.step(acts)
