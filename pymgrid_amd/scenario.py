@@ -175,6 +175,102 @@ def load_scenario_yaml(path):
     return p
 
 
+def dump_scenario_yaml(p, path):
+    """Write a parameter dict as a serialised microgrid in the reference's format (``Microgrid.dump``: microgrid.py:820-846,
+    ``!Microgrid`` YAML + ``data/cls_params/<Module>/time_series.csv.gz`` next to it, utils/serialize.py:24-83) so that
+    ``pymgrid.Microgrid.load(open(path))`` -- and ``load_scenario_yaml(path)`` -- give the same microgrid back: constructor
+    arguments under ``cls_params``, the dynamic state (battery charge / SoC, the four genset status fields, the step
+    counter) under ``state``.  One module of each kind; the controllable modules are listed in ``controllable_order``."""
+    import os
+
+    import pandas as pd
+    import yaml
+    load, pv = np.asarray(p["load_ts"], dtype=np.float64), np.asarray(p["pv_ts"], dtype=np.float64)
+    if (load.ndim == 2 and load.shape[1] != 1) or (pv.ndim == 2 and pv.shape[1] != 1):
+        raise NotImplementedError("more than one load / renewable module per microgrid is not supported by the file format here")
+    base = os.path.dirname(os.path.abspath(path))
+    H, t0, final = int(p.get("horizon", 0)), int(p.get("initial_step", 0)), int(p.get("final_step", 0)) or load.shape[0]
+    noise = p.get("forecast_noise")
+
+    def series(tag, arr):
+        rel = os.path.join("data", "cls_params", tag, "time_series.csv.gz")
+        os.makedirs(os.path.dirname(os.path.join(base, rel)), exist_ok=True)
+        pd.DataFrame(np.asarray(arr, dtype=np.float64).reshape(arr.shape[0], -1)).to_csv(os.path.join(base, rel))
+        return _Tagged("!NDArray", rel)
+
+    def ts_params(tag, arr, extra=None):
+        fc = (float(noise["std"]) if noise else "oracle") if H > 0 else None
+        d = dict(final_step=final, forecast_horizon=H, forecaster=fc,
+                 forecaster_increase_uncertainty=bool(noise and noise.get("increase_uncertainty", False)),
+                 forecaster_relative_noise=bool(noise and noise.get("relative_noise", False)),
+                 initial_step=t0, raise_errors=False, time_series=series(tag, arr))
+        d.update(extra or {})
+        return d
+
+    def module(name, tag, cls_params, state):
+        return [name, _Tagged(tag, dict(cls_params=cls_params, name=[name, 0], state=dict(state, _current_step=t0)))]
+    mods = [module("load", "!LoadModule", ts_params("LoadModule", np.abs(load)), {}),
+            module("pv", "!RenewableModule", ts_params("RenewableModule", np.abs(pv), dict(provided_energy_name="renewable_used")), {}),
+            module("unbalanced_energy", "!UnbalancedEnergyModule",
+                   dict(initial_step=t0, loss_load_cost=float(p["unbalanced"]["loss_load_cost"]),
+                        overgeneration_cost=float(p["unbalanced"]["overgeneration_cost"]), raise_errors=False), {})]
+    order = [k for k in (p.get("controllable_order") or []) if p.get(k) is not None]
+    order += [k for k in ("genset", "battery", "grid") if p.get(k) is not None and k not in order]
+    for kind in order:
+        q = p[kind]
+        if kind == "genset":
+            su, wd = int(q.get("start_up_time", 0)), int(q.get("wind_down_time", 0))
+            if q.get("status") is not None:
+                st = [int(v) for v in q["status"]]
+            else:
+                on = int(bool(q.get("init_start_up", True)))
+                st = [on, on, 0, wd] if on else [0, 0, su, 0]
+            mods.append(module("genset", "!Genset", dict(
+                allow_abortion=True, co2_per_unit=float(q.get("co2_per_unit", 0.0)),
+                cost_per_unit_co2=float(q.get("cost_per_unit_co2", 0.0)), genset_cost=float(q["genset_cost"]),
+                init_start_up=bool(st[0]), initial_step=t0, provided_energy_name="genset_production", raise_errors=False,
+                running_max_production=float(q["running_max_production"]),
+                running_min_production=float(q["running_min_production"]), start_up_time=su, wind_down_time=wd),
+                dict(_current_status=st[0], _goal_status=st[1], _steps_until_up=st[2], _steps_until_down=st[3])))
+        elif kind == "battery":
+            cap = float(q["max_capacity"])
+            if q.get("charge") is not None:
+                charge = float(q["charge"])
+            elif q.get("init_charge") is not None:
+                charge = float(q["init_charge"])
+            else:
+                charge = float(q["init_soc"]) * cap
+            mods.append(module("battery", "!BatteryModule", dict(
+                battery_cost_cycle=float(q.get("battery_cost_cycle", 0.0)), battery_transition_model=None,
+                efficiency=float(q["efficiency"]), init_charge=None, init_soc=charge / cap, initial_step=t0,
+                max_capacity=cap, max_charge=float(q["max_charge"]), max_discharge=float(q["max_discharge"]),
+                min_capacity=float(q["min_capacity"]), raise_errors=False), dict(current_charge=charge, soc=charge / cap)))
+        else:
+            mods.append(module("grid", "!GridModule", ts_params("GridModule", np.asarray(p["grid_ts"], dtype=np.float64), dict(
+                cost_per_unit_co2=float(q.get("cost_per_unit_co2", 0.0)), max_export=float(q["max_export"]),
+                max_import=float(q["max_import"]))), {}))
+    doc = _Tagged("!Microgrid", dict(final_step=final, initial_step=t0, modules=mods, trajectory_func=None))
+
+    class Dumper(yaml.SafeDumper):
+        pass
+
+    def represent(dumper, obj):
+        if isinstance(obj.value, dict):
+            return dumper.represent_mapping(obj.tag, obj.value)
+        return dumper.represent_scalar(obj.tag, obj.value)
+    Dumper.add_representer(_Tagged, represent)
+    with open(path, "w") as fh:
+        yaml.dump(doc, fh, Dumper=Dumper, default_flow_style=False, sort_keys=True)
+    return path
+
+
+class _Tagged:
+    """A YAML node with an application tag (``!Microgrid``, ``!LoadModule``, ``!NDArray`` ...)."""
+
+    def __init__(self, tag, value):
+        self.tag, self.value = tag, value
+
+
 def from_scenario(microgrid_number, root):
     """``Microgrid.from_scenario(n)`` (microgrid.py:958-980) given the directory that holds ``pymgrid25/``."""
     import os

@@ -39,3 +39,56 @@ def test_state_checkpoint_roundtrip(tmp_path, pymgrid25):
     for k in ("charge", "soc", "gen_status"):
         assert torch.equal(b.cols[k], b2.cols[k])
 
+
+
+def test_dump_and_load_round_trip(pymgrid25, tmp_path):
+    """dump_scenario_yaml -> load_scenario_yaml gives the parameter dict back, bit for bit (all 25 scenarios; one with the
+    grid listed before the battery and a stepped state)."""
+    from pymgrid_amd.scenario import dump_scenario_yaml, load_scenario_yaml
+    cases = list(enumerate(pymgrid25))
+    with_grid = next(q for q in pymgrid25 if q.get("grid") is not None and q.get("genset") is not None)
+    odd = dict(with_grid); odd["controllable_order"] = ["grid", "battery"]; odd["initial_step"] = 5
+    odd["battery"] = dict(odd["battery"], charge=odd["battery"]["max_capacity"] * 0.61803, soc=0.61803)
+    cases.append(("odd", odd))
+    for n, ref in cases:
+        os.makedirs(tmp_path / f"mg_{n}", exist_ok=True)
+        path = dump_scenario_yaml(ref, str(tmp_path / f"mg_{n}" / "microgrid.yaml"))
+        p = load_scenario_yaml(path)
+        order = p.pop("controllable_order")
+        if n == "odd":
+            assert order.index("grid") < order.index("battery")
+        for k, v in ref.items():
+            if k == "controllable_order":
+                continue
+            if isinstance(v, np.ndarray):
+                assert np.array_equal(np.asarray(p[k]).reshape(v.shape), v), (n, k)
+            elif k == "battery":
+                assert p[k]["charge"] == v["charge"] and abs(p[k]["soc"] - v["soc"]) < 1e-15, (n, k)
+                assert {kk: vv for kk, vv in p[k].items() if kk not in ("charge", "soc")} == \
+                    {kk: vv for kk, vv in v.items() if kk not in ("charge", "soc", "init_soc")}, (n, k)
+            else:
+                assert p[k] == v, (n, k, p[k], v)
+
+
+def test_the_reference_loads_what_we_dump(pymgrid25, tmp_path):
+    """Microgrid.load(<file written by dump_scenario_yaml>) in the real reference == the scenario it came from."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import _refenv
+    _refenv.import_reference()
+    import make_goldens as mg
+    from pymgrid import Microgrid
+    from pymgrid_amd.scenario import dump_scenario_yaml
+    for n in (0, 3, 7, 24):
+        ref = pymgrid25[n]
+        os.makedirs(tmp_path / f"mg_{n}", exist_ok=True)
+        path = dump_scenario_yaml(ref, str(tmp_path / f"mg_{n}" / "microgrid.yaml"))
+        with open(path) as fh:
+            m = Microgrid.load(fh)
+        back = mg.extract_params(m)
+        assert set(back) == set(ref), (n, set(back) ^ set(ref))
+        for k, v in ref.items():
+            if isinstance(v, np.ndarray):
+                assert np.array_equal(np.asarray(back[k]).reshape(v.shape), v), (n, k)
+            else:
+                assert back[k] == v, (n, k, back[k], v)
