@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=8760, help="time-series rows T")
     ap.add_argument("--mode", choices=["fused", "step", "rbc"], default="fused")
     ap.add_argument("--chunk", type=int, default=64, help="env-steps per fused launch")
+    ap.add_argument("--shards", type=int, default=2,
+                    help="independent shards per GPU, each on its own HIP stream (fused / rbc modes; 1 = one launch sequence)")
     ap.add_argument("--arch", default="genset+battery")
     ap.add_argument("--hetero-steps", type=int, default=256, help="timed Gym steps of the heterogeneous H=24 fleet (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,6 +102,75 @@ class Runner:
             self.eng.step(a, normalized=True, want_obs=False, want_log=False, out=self.out1)
             self.launches += 1
         self.i += 1
+
+
+class ShardRunner:
+    """The fused modes over S independent shards of the rank's grids (pymgrid_amd.hetero.StreamShards): every shard has
+    its own engine, action pool, output buffers and HIP stream; the launch sequences are not joined between launches."""
+
+    def __init__(self, shards, chunk, seed):
+        from pymgrid_amd.priority_list import get_priority_lists, table_array
+        from pymgrid_amd.rbc import default_priority_ids
+        self.shards, self.chunk = shards, chunk
+        dev = shards.device
+        self.pools, self.outs, self.rbc_ids, self.rbc_tables = [], [], [], []
+        for j, eng in enumerate(shards.engines):
+            L, n = eng.layout, eng.N
+            gen = torch.Generator(device=dev); gen.manual_seed(seed + j)
+            self.pools.append(torch.rand(4, chunk, n, L.action_dim, dtype=torch.float64, device=dev, generator=gen))
+            self.outs.append(dict(reward=torch.empty(chunk, n, dtype=torch.float64, device=dev),
+                                  done=torch.empty(chunk, n, dtype=torch.uint8, device=dev),
+                                  soc_trace=torch.empty(chunk, n, dtype=torch.float64, device=dev)))
+            lists = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, False)
+            self.rbc_tables.append(table_array(lists))
+            self.rbc_ids.append(torch.from_numpy(default_priority_ids(eng.batch, lists, remove_redundant_gensets=False)).to(dev))
+        self.launches = 0            # per stream
+        self.i = 0
+
+    def _room(self, k):
+        e = self.shards.engines[0]
+        if e.current_step + k > e.layout.final_step:
+            self.shards.reset()
+
+    def fused(self, steps):
+        done = 0
+        while done < steps:
+            k = min(self.chunk, steps - done)
+            self._room(k)
+            self.shards.step_k([p[self.i % 4][:k] for p in self.pools],
+                               outs=[{name: t[:k] for name, t in o.items()} for o in self.outs],
+                               normalized=True, reward=True, done=True, soc_trace=True)
+            self.i += 1; self.launches += 1; done += k
+
+    def rbc(self, steps):
+        done = 0
+        while done < steps:
+            k = min(self.chunk, steps - done)
+            self._room(k)
+            self.shards.rollout_discrete(self.rbc_ids, self.rbc_tables, k,
+                                         outs=[{name: t[:k] for name, t in o.items()} for o in self.outs],
+                                         reward=True, done=True, soc_trace=True)
+            self.launches += 1; done += k
+
+
+def timed_shards(fn, steps, shards, device):
+    """barrier + sync | K steps on every shard stream | join + sync + barrier; returns (wall seconds, GPU seconds =
+    the longest shard stream's elapsed time between its own start and stop events)."""
+    mdist.barrier()
+    torch.cuda.synchronize(device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in shards.streams]
+    t0 = time.perf_counter()
+    shards.fork()
+    for (e0, _), st in zip(ev, shards.streams):
+        e0.record(st)
+    fn(steps)
+    for (_, e1), st in zip(ev, shards.streams):
+        e1.record(st)
+    shards.join()
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    mdist.barrier()
+    return t1 - t0, max(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3
 
 
 def timed(fn, steps, device):
@@ -210,7 +281,13 @@ def measured_traffic(kernel, grids, chunk):
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("grids") == grids and d.get("chunk") == chunk and kernel in d.get("kernels", {}):
+        if d.get("chunk") != chunk:
+            continue
+        # launches are recorded by size (threads = workgroups * 256; a workgroup owns 192..256 grids)
+        for threads, e in sorted(d.get("by_launch_threads", {}).get(kernel, {}).items(), key=lambda kv: int(kv[0])):
+            if grids <= int(threads) < 1.45 * grids:
+                return e["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+        if d.get("grids") == grids and kernel in d.get("kernels", {}):
             return d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
     return None, None
 
@@ -240,17 +317,29 @@ def main():
     run.rbc_table = table_array(lists)
     run.rbc_ids = torch.from_numpy(default_priority_ids(batch, lists, remove_redundant_gensets=False)).to(dev)
 
-    results = {}
-    for mode in ("fused", "step", "rbc"):
-        fn = {"fused": run.fused, "step": run.single, "rbc": run.rbc}[mode]
-        steps = args.steps if mode == args.mode else min(args.steps, 512)
-        eng.reset(want_obs=False)
-        fn(args.warmup if mode == args.mode else min(args.warmup, 64))
-        run.launches = 0
-        wall, gpu = timed(fn, steps, dev)
+    # fused / rbc modes: S independent shards of the rank's grids, one HIP stream each (the launch sequences of shards
+    # owe each other nothing and fill each other's ramp-up / tail gaps); S = 1: one launch sequence over all N grids
+    S = max(1, args.shards)
+    if N % S:
+        raise SystemExit(f"--grids {N} is not divisible by --shards {S}")
+    shards = srun = None
+    if S > 1:
+        from pymgrid_amd.hetero import StreamShards
+        shards = StreamShards([generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev,
+                                        rank=rank * S + j, world=world * S) for j in range(S)])
+        srun = ShardRunner(shards, chunk, 7 + 1000 * rank)
+
+    def measure(mode, sharded, steps, warmup):
+        n_launch = N // S if sharded else N                      # grids per kernel launch
+        r = srun if sharded else run
+        fn = {"fused": r.fused, "step": getattr(r, "single", None), "rbc": r.rbc}[mode]
+        (shards.reset() if sharded else eng.reset(want_obs=False))
+        fn(warmup)
+        r.launches = 0
+        wall, gpu = timed_shards(fn, steps, shards, dev) if sharded else timed(fn, steps, dev)
         wall = mdist.max_over_ranks(wall, dev)
         gpu = mdist.max_over_ranks(gpu, dev)
-        launches = run.launches
+        launches = r.launches                                    # per stream
         if mode in ("fused", "rbc"):
             A8 = 8 * L.action_dim if mode == "rbc" else 0        # rbc: no action stream; + 1 id byte per grid, once
             once = 1 if mode == "rbc" else 0
@@ -260,21 +349,31 @@ def main():
         else:
             unit_bytes = L.bytes_per_step()
             per_launch = unit_bytes
-        per_launch_bytes = per_launch * N
-        avg_launch_s = gpu / launches
-        achieved = per_launch_bytes / avg_launch_s / 1e9
+        per_launch_bytes = per_launch * n_launch
+        avg_launch_s = gpu / launches                            # of ONE stream's launches; S streams run concurrently
+        achieved = (S if sharded else 1) * per_launch_bytes / avg_launch_s / 1e9
         kname = {"fused": "step_k_kernel", "step": "step_kernel", "rbc": "rollout_kernel"}[mode]
-        traffic, traffic_src = measured_traffic(kname, N, chunk)
-        results[mode] = {
+        traffic, traffic_src = measured_traffic(kname, n_launch, chunk)
+        return {
             "value": n_total * steps / wall, "steps": steps, "ms_per_step": wall / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "kernel": {"fused": "step_k_kernel<3,4>", "step": "step_kernel<3>",
-                                    "rbc": "rollout_kernel<3,4>"}[mode],
-                         "bytes_per_env_step": unit_bytes, "launches": launches,
+                         "kernel": {"fused": "step_k_kernel<3,4,double>", "step": "step_kernel<3>",
+                                    "rbc": "rollout_kernel<3,4,false>"}[mode],
+                         "grids_per_launch": n_launch, "concurrent_streams": S if sharded else 1,
+                         "bytes_per_env_step": unit_bytes, "launches_per_stream": launches,
                          "avg_launch_us": avg_launch_s * 1e6},
         }
+
+    results = {}
+    for mode in ("fused", "step", "rbc"):
+        main_mode = mode == args.mode
+        results[mode] = measure(mode, sharded=(S > 1 and mode != "step"),
+                                steps=args.steps if main_mode else min(args.steps, 512),
+                                warmup=args.warmup if main_mode else min(args.warmup, 64))
+    if S > 1:                                                    # the same fused kernel as ONE launch sequence over all N
+        results["fused_one_stream"] = measure("fused", sharded=False, steps=min(args.steps, 512), warmup=64)
 
     # BASELINE configs[4] in miniature, reported under "other": a heterogeneous fleet (1/3 genset+battery, 1/3
     # battery+grid, 1/3 genset+battery+grid; forecast_horizon = 24) stepped through the Gym surface WITH observations
@@ -293,7 +392,8 @@ def main():
 
     if rank == 0:
         main_r = results[args.mode]
-        names = {"fused": "fused_launches", "step": "single_step_launches", "rbc": "rbc_rollout_on_device"}
+        names = {"fused": "fused_launches", "step": "single_step_launches", "rbc": "rbc_rollout_on_device",
+                 "fused_one_stream": "fused_launches_one_stream"}
         line = {
             "metric": "microgrid env-steps/sec", "value": main_r["value"], "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_r["ms_per_step"],
@@ -303,7 +403,8 @@ def main():
                        "grids_per_gpu": N, "grids_total": n_total, "mode": args.mode,
                        "steps_per_launch": 1 if args.mode == "step" else chunk,
                        "outputs": "reward+done+soc per step" + ("" if args.mode == "step" else " (streamed [K,N])"),
-                       "parallelism": f"grids sharded x{world}, no data-path collective"},
+                       "parallelism": f"grids sharded x{world} ranks, no data-path collective"
+                                      + (f"; {S} independent shards per GPU on {S} HIP streams" if S > 1 and args.mode != "step" else "")},
             "roofline": main_r["roofline"],
             "cpu_baseline": cpu,
             "other": {names[m]: {"value": r["value"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
@@ -313,6 +414,8 @@ def main():
         }
         print(json.dumps(line), flush=True)
     eng.close()
+    if shards is not None:
+        shards.close()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

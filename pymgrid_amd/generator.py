@@ -61,6 +61,18 @@ def draw_scalars(n_total, seed=42, arch="genset+battery", mixed_timers=False):
     return d
 
 
+def _hash_uniform(rows, gidx, seed):
+    """U[0, 1) per (series row, GLOBAL grid index): a counter-based hash (splitmix64-style mixing in wrapping int64
+    arithmetic), so a shard's draw does not depend on how many ranks / shards the batch is split over."""
+    def lsr(v, k):                                     # logical shift right of the two's-complement bit pattern
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    x = rows * -7046029254386353131 + gidx * -4658895280553007687 + (int(seed) * 1000003 + 12345)
+    x = (x ^ lsr(x, 30)) * -4658895280553007687
+    x = (x ^ lsr(x, 27)) * -7723592293110705685
+    x = x ^ lsr(x, 31)
+    return lsr(x, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+
+
 def generate(n_grids, n_steps=8760, seed=42, arch="genset+battery", horizon=0, device="cuda", rank=0, world=1,
              mixed_timers=False, final_step=0, row_block=256):
     """Build the [rank]-th shard of a global batch of ``n_grids`` microgrids on ``device``."""
@@ -122,14 +134,15 @@ def generate(n_grids, n_steps=8760, seed=42, arch="genset+battery", horizon=0, d
         cid = torch.as_tensor(d["co2_pid"], device=dev)
         bc = up(base_co2)
         weak = torch.as_tensor(d["weak"], device=dev)
-        gen = torch.Generator(device=dev); gen.manual_seed(seed * 1000003 + rank)
+        gidx = torch.arange(lo, hi, dtype=torch.int64, device=dev).unsqueeze(0)          # GLOBAL grid index
         grid_ts = torch.empty(T, 4, N, **f64)
         for r0 in range(0, T, row_block):
             r1 = min(T, r0 + row_block)
             grid_ts[r0:r1, 0] = tariffs[r0:r1][:, tid]
             grid_ts[r0:r1, 1] = 0.0
             grid_ts[r0:r1, 2] = bc[r0:r1][:, cid]
-            outage = (torch.rand(r1 - r0, N, device=dev, generator=gen) < 0.02) & weak   # weak-grid outages (:321-340)
+            rows = torch.arange(r0, r1, dtype=torch.int64, device=dev).unsqueeze(1)
+            outage = (_hash_uniform(rows, gidx, seed) < 0.02) & weak              # weak-grid outages (:321-340)
             grid_ts[r0:r1, 3] = (~outage).to(torch.float64)
         cols["grid_ts"] = grid_ts
         cols["grid_lo"] = grid_ts.amin(dim=0).contiguous(); cols["grid_hi"] = grid_ts.amax(dim=0).contiguous()

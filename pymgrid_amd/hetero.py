@@ -152,3 +152,74 @@ class PerGridWindowEnv:
 
     def __getattr__(self, name):              # everything else (engine, action_space, sample_action, ...) as the env
         return getattr(self.env, name)
+
+
+class StreamShards:
+    """Independent shards of a fleet -- each a ``MicrogridBatch`` with its own engine -- driven on one HIP stream each and
+    NOT joined between calls.
+
+    Why: grids never interact, so the launch sequence of one shard owes nothing to another's.  On one stream every
+    fused launch has a ramp-up (parameters, ring fill) and a tail (the last waves) during which the chip is not full;
+    two shard sequences on two streams run out of phase and fill each other's gaps: measured 70-74 us instead of
+    76-78 us per 64-step round of 100 000 grids (2 x 50 000; three shards 73 us, four 76 us:
+    ``profiles/r01/exp_two_streams.txt``).  Outputs are valid on the caller's stream after ``join()``.
+    """
+
+    def __init__(self, batches, **engine_kwargs):
+        from .engine import StepEngine
+        self.engines = [StepEngine(b, **engine_kwargs) for b in batches]
+        self.device = self.engines[0].device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.engines]
+        self.n_grids = sum(e.N for e in self.engines)
+
+    def __len__(self):
+        return len(self.engines)
+
+    def fork(self):
+        """Shard streams wait for the caller's stream (inputs produced there are then safe to read)."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            st.wait_stream(cur)
+
+    def join(self):
+        """The caller's stream waits for every shard stream (outputs are then safe to read there)."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def each(self, fn):
+        """fn(engine, shard_index) on every shard's stream; returns the results, does not join."""
+        out = []
+        for k, (eng, st) in enumerate(zip(self.engines, self.streams)):
+            with torch.cuda.stream(st):
+                out.append(fn(eng, k))
+        return out
+
+    def _guard(self, k, *tensors):
+        """Tell the caching allocator that shard k's stream uses these tensors (they were allocated on another stream and
+        must not be recycled while a launch that reads / writes them is still queued here)."""
+        for t in tensors:
+            if isinstance(t, dict):
+                self._guard(k, *t.values())
+            elif torch.is_tensor(t):
+                t.record_stream(self.streams[k])
+
+    def step_k(self, actions, outs=None, **kw):
+        """``StepEngine.step_k`` per shard: actions / outs are lists with one entry per shard."""
+        def one(eng, k):
+            self._guard(k, actions[k], None if outs is None else outs[k])
+            return eng.step_k(actions[k], out=None if outs is None else outs[k], **kw)
+        return self.each(one)
+
+    def rollout_discrete(self, ids, tables, K, outs=None, **kw):
+        def one(eng, k):
+            self._guard(k, ids[k], None if outs is None else outs[k])
+            return eng.rollout_discrete(ids[k], tables[k], K, out=None if outs is None else outs[k], **kw)
+        return self.each(one)
+
+    def reset(self, initial_step=None):
+        self.each(lambda eng, k: eng.reset(initial_step, want_obs=False))
+
+    def close(self):
+        for eng in self.engines:
+            eng.close()

@@ -864,3 +864,38 @@ def test_random_fleet_every_module_set_vs_oracle(seed, device, oracle):
             if L.has_genset:
                 assert unpack_status(cols["gen_status"][j:j + 1].cpu().numpy().view(np.uint32))[0].tolist() == list(om.status), idx[j]
         eng.close()
+
+
+def test_stream_shards_equal_one_engine(device):
+    """StreamShards (independent shards on their own HIP streams, joined once at the end) == the same grids in one engine:
+    fused K-step launches and on-device rule-based rollouts, several rounds without joining in between."""
+    from pymgrid_amd import MicrogridBatch, StepEngine
+    from pymgrid_amd.generator import generate
+    from pymgrid_amd.hetero import StreamShards
+    from pymgrid_amd.priority_list import get_priority_lists, table_array
+    N, T, K, S = 6000, 200, 16, 3
+    whole = StepEngine(generate(N, n_steps=T, seed=12, arch="genset+battery+grid", device=device, mixed_timers=True))
+    shards = StreamShards([generate(N, n_steps=T, seed=12, arch="genset+battery+grid", device=device, mixed_timers=True,
+                                    rank=j, world=S) for j in range(S)])
+    n = N // S
+    g = torch.Generator(device=device); g.manual_seed(4)
+    tab = table_array(get_priority_lists(True, True, True))
+    rw, rs = [], []
+    shards.fork()
+    for rnd in range(4):
+        a = torch.rand(K, N, 4, dtype=torch.float64, device=device, generator=g)
+        parts = [a[:, j * n:(j + 1) * n].contiguous() for j in range(S)]
+        torch.cuda.current_stream(device).synchronize()          # the slices were made on the caller's stream
+        rw.append(whole.step_k(a, reward=True)["reward"])
+        rs.append(shards.step_k(parts, reward=True))
+    ids = torch.randint(0, len(tab), (N,), device=device, generator=g).to(torch.uint8)
+    parts = [ids[j * n:(j + 1) * n].contiguous() for j in range(S)]
+    torch.cuda.current_stream(device).synchronize()
+    rw.append(whole.rollout_discrete(ids, tab, K, reward=True)["reward"])
+    rs.append(shards.rollout_discrete(parts, [tab] * S, K, reward=True))
+    shards.join()
+    for x, ys in zip(rw, rs):
+        assert torch.equal(x, torch.cat([y["reward"] for y in ys], dim=1))
+    for name in ("charge", "soc", "gen_status"):
+        assert torch.equal(whole.batch.cols[name], torch.cat([e.batch.cols[name] for e in shards.engines]))
+    whole.close(); shards.close()

@@ -137,13 +137,15 @@ def test_spaces():
 def test_generator_is_shard_invariant():
     """Rank r of W draws exactly columns [r*N/W, (r+1)*N/W) of the global batch."""
     from pymgrid_amd.generator import generate
+    for arch in ("genset+battery", "genset+battery+grid", "battery+grid"):    # incl. the weak-grid outage draws
+        full = generate(96, n_steps=300, seed=5, arch=arch, device="cpu", mixed_timers=True)
+        parts = [generate(96, n_steps=300, seed=5, arch=arch, device="cpu", mixed_timers=True, rank=r, world=3)
+                 for r in range(3)]
+        for name, t in full.cols.items():
+            cat = torch.cat([p.cols[name] for p in parts], dim=-1)
+            assert torch.equal(cat, t), (arch, name)
+        assert parts[0].layout.n_grids == 32
     full = generate(96, n_steps=30, seed=5, arch="genset+battery", device="cpu", mixed_timers=True)
-    parts = [generate(96, n_steps=30, seed=5, arch="genset+battery", device="cpu", mixed_timers=True, rank=r, world=3)
-             for r in range(3)]
-    for name, t in full.cols.items():
-        cat = torch.cat([p.cols[name] for p in parts], dim=-1)
-        assert torch.equal(cat, t), name
-    assert parts[0].layout.n_grids == 32
     # sizing rules (MicrogridGenerator.py:214-386, SURVEY App. B)
     c = full.cols
     assert torch.equal(c["bat_min_capacity"], 0.2 * c["bat_max_capacity"])
