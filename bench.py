@@ -9,6 +9,12 @@ batch).  Everything the timed region reads (columns, series, actions) is residen
 Modes
   fused (default)  K steps are issued as ceil(K / chunk) launches of the K-step kernel (mgx_step_k): parameters and
                    state stay in registers, actions / series rows / per-step outputs (reward, done, SoC) stream.
+                   The rank's N grids are stepped as --shards (2) independent shards of N / 2 grids, each with its own
+                   engine and HIP stream and never joined between launches (pymgrid_amd.hetero.StreamShards): grids do
+                   not interact, and two launch sequences out of phase fill each other's ramp-up / tail gaps (+5..10 %).
+                   A roofline "launch" is then one ROUND = one kernel launch per shard stream (all N grids, 64 steps);
+                   its duration is a shard stream's cadence (HIP events on that stream over the region / launches).
+                   The same kernel as ONE launch sequence over all N grids is reported under "other".
   step             one launch of the single-step kernel (mgx_step) per env-step -- the Gym cadence.
   rbc              rule-based control rolled out on device (mgx_rollout_discrete, one fixed priority list per grid):
                    the control is expanded in-kernel, so there is no action stream at all.
@@ -47,7 +53,7 @@ def parse():
     ap.add_argument("--mode", choices=["fused", "step", "rbc"], default="fused")
     ap.add_argument("--chunk", type=int, default=64, help="env-steps per fused launch")
     ap.add_argument("--shards", type=int, default=2,
-                    help="independent shards per GPU, each on its own HIP stream (fused / rbc modes; 1 = one launch sequence)")
+                    help="fused mode: independent shards per GPU, one HIP stream each (1: one launch sequence over all grids)")
     ap.add_argument("--arch", default="genset+battery")
     ap.add_argument("--hetero-steps", type=int, default=256, help="timed Gym steps of the heterogeneous H=24 fleet (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,6 +157,32 @@ class ShardRunner:
                                          outs=[{name: t[:k] for name, t in o.items()} for o in self.outs],
                                          reward=True, done=True, soc_trace=True)
             self.launches += 1; done += k
+
+
+def _kernel_durations_us(self, rounds):
+    """Mean start-to-end time of the shard kernels themselves (HIP events around every launch, a short extra pass after the
+    timed region): what rocprofv3 reports as the kernel's duration.  Shorter than the cadence of a round because the S
+    concurrent kernels overlap only partly."""
+    ev = []
+    self.shards.fork()
+    for _ in range(rounds):
+        k = self.chunk
+        self._room(k)
+        for j, (eng, st) in enumerate(zip(self.shards.engines, self.shards.streams)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(st):
+                e0.record(st)
+                eng.step_k(self.pools[j][self.i % 4][:k], out=self.outs[j], normalized=True, reward=True, done=True,
+                           soc_trace=True)
+                e1.record(st)
+            ev.append((e0, e1))
+        self.i += 1
+    self.shards.join()
+    torch.cuda.synchronize(self.shards.device)
+    return sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev) * 1e3
+
+
+ShardRunner.kernel_durations_us = _kernel_durations_us
 
 
 def timed_shards(fn, steps, shards, device):
@@ -317,8 +349,8 @@ def main():
     run.rbc_table = table_array(lists)
     run.rbc_ids = torch.from_numpy(default_priority_ids(batch, lists, remove_redundant_gensets=False)).to(dev)
 
-    # fused / rbc modes: S independent shards of the rank's grids, one HIP stream each (the launch sequences of shards
-    # owe each other nothing and fill each other's ramp-up / tail gaps); S = 1: one launch sequence over all N grids
+    # extra measurement: S independent shards of the rank's grids, one HIP stream each (the launch sequences of shards
+    # owe each other nothing and fill each other's ramp-up / tail gaps)
     S = max(1, args.shards)
     if N % S:
         raise SystemExit(f"--grids {N} is not divisible by --shards {S}")
@@ -349,31 +381,35 @@ def main():
         else:
             unit_bytes = L.bytes_per_step()
             per_launch = unit_bytes
-        per_launch_bytes = per_launch * n_launch
-        avg_launch_s = gpu / launches                            # of ONE stream's launches; S streams run concurrently
-        achieved = (S if sharded else 1) * per_launch_bytes / avg_launch_s / 1e9
+        # sharded: a "launch" is one ROUND = S kernel launches issued together, one per shard stream, covering all N grids;
+        # its duration is the cadence of a shard stream (HIP events on that stream over the region / its launches)
+        per_launch_bytes = per_launch * N
+        avg_launch_s = gpu / launches
+        achieved = per_launch_bytes / avg_launch_s / 1e9
         kname = {"fused": "step_k_kernel", "step": "step_kernel", "rbc": "rollout_kernel"}[mode]
         traffic, traffic_src = measured_traffic(kname, n_launch, chunk)
-        return {
-            "value": n_total * steps / wall, "steps": steps, "ms_per_step": wall / steps * 1e3,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "kernel": {"fused": "step_k_kernel<3,4,double>", "step": "step_kernel<3>",
-                                    "rbc": "rollout_kernel<3,4,false>"}[mode],
-                         "grids_per_launch": n_launch, "concurrent_streams": S if sharded else 1,
-                         "bytes_per_env_step": unit_bytes, "launches_per_stream": launches,
-                         "avg_launch_us": avg_launch_s * 1e6},
-        }
+        if traffic is not None and sharded:
+            traffic *= S
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": per_launch_bytes,
+                "kernel": {"fused": "step_k_kernel<3,4,double>", "step": "step_kernel<3>",
+                           "rbc": "rollout_kernel<3,4,false>"}[mode],
+                "bytes_per_env_step": unit_bytes, "launches": launches, "avg_launch_us": avg_launch_s * 1e6}
+        if sharded:
+            roof.update({"launch": f"one round = {S} concurrent kernel launches, one per shard stream, {n_launch} grids each",
+                         "concurrent_streams": S, "grids_per_kernel_launch": n_launch,
+                         "kernel_avg_duration_us": r.kernel_durations_us(16)})
+        return {"value": n_total * steps / wall, "steps": steps, "ms_per_step": wall / steps * 1e3, "roofline": roof}
 
     results = {}
     for mode in ("fused", "step", "rbc"):
         main_mode = mode == args.mode
-        results[mode] = measure(mode, sharded=(S > 1 and mode != "step"),
+        results[mode] = measure(mode, sharded=(S > 1 and mode == "fused"),
                                 steps=args.steps if main_mode else min(args.steps, 512),
                                 warmup=args.warmup if main_mode else min(args.warmup, 64))
-    if S > 1:                                                    # the same fused kernel as ONE launch sequence over all N
-        results["fused_one_stream"] = measure("fused", sharded=False, steps=min(args.steps, 512), warmup=64)
+    if S > 1:        # the same fused kernel as ONE launch sequence over all N grids (reported under "other")
+        results["fused_one_stream"] = measure("fused", sharded=False, steps=min(args.steps, 2048), warmup=min(args.warmup, 256))
 
     # BASELINE configs[4] in miniature, reported under "other": a heterogeneous fleet (1/3 genset+battery, 1/3
     # battery+grid, 1/3 genset+battery+grid; forecast_horizon = 24) stepped through the Gym surface WITH observations
@@ -404,7 +440,7 @@ def main():
                        "steps_per_launch": 1 if args.mode == "step" else chunk,
                        "outputs": "reward+done+soc per step" + ("" if args.mode == "step" else " (streamed [K,N])"),
                        "parallelism": f"grids sharded x{world} ranks, no data-path collective"
-                                      + (f"; {S} independent shards per GPU on {S} HIP streams" if S > 1 and args.mode != "step" else "")},
+                                      + (f"; fused mode: {S} independent shards per GPU on {S} HIP streams" if S > 1 else "")},
             "roofline": main_r["roofline"],
             "cpu_baseline": cpu,
             "other": {names[m]: {"value": r["value"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],

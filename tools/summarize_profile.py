@@ -34,6 +34,32 @@ for f in find("*kernel_trace.csv"):
         print(f"{k[:90]:90s} calls={len(v)} avg_us={sum(v)/len(v)/1e3:.2f} med_us={v2[len(v2)//2]/1e3:.2f} "
               f"min_us={v2[0]/1e3:.2f} max_us={v2[-1]/1e3:.2f}")
 
+# the fused kernel per HIP queue (bench.py steps two independent shards on two streams): kernel durations AND the cadence
+# of each queue = what bench.py's HIP events on that stream measure as "duration of a round"
+for f in find("*kernel_trace.csv"):
+    if os.sep + "stats" + os.sep not in f:
+        continue
+    per_q = defaultdict(list)
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            if "mgx::step_k_kernel<" in r["Kernel_Name"]:
+                per_q[(r.get("Queue_Id"), r.get("Grid_Size_X") or r.get("Grid_Size"))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    print("== step_k_kernel per queue / launch size (threads): kernel duration vs queue cadence ==")
+    for (q, size), v in sorted(per_q.items()):
+        v.sort()
+        # the longest burst of back-to-back launches (bench.py's timed region): a new burst starts after an idle gap
+        bursts, cur = [], [v[0]]
+        for a, b in zip(v, v[1:]):
+            if b[0] - a[1] > 40_000:
+                bursts.append(cur); cur = []
+            cur.append(b)
+        bursts.append(cur)
+        body = max(bursts, key=len)
+        dur = [(e - s) / 1e3 for s, e in body]
+        cad = (body[-1][1] - body[0][0]) / 1e3 / len(body)
+        print(f"queue {q} threads {size}: launches={len(body)} kernel avg_us={sum(dur) / len(dur):.2f} min_us={min(dur):.2f} "
+              f"max_us={max(dur):.2f}  cadence_us={cad:.2f}")
+
 traffic = defaultdict(dict)
 sized = defaultdict(dict)
 for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
