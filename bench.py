@@ -288,6 +288,33 @@ def cpu_baseline(eng, pool, seconds):
             orc.run_batch(cols, st, 0, K, acts, normalized=True, want_reward=False, nthreads=nthreads)
             done += n * K
         return done / (time.perf_counter() - t0), done
+    # per-instance cadence: ONE microgrid object stepped from a Python loop, as a reference user would
+    # step `env.step(a)` -- the C restatement does the arithmetic, Python only the call: ~1 s
+    one = {k: (v[:, 0] if v.ndim == 2 else (v[:, :, 0] if v.ndim == 3 else v[0])) for k, v in cols.items()
+           if isinstance(v, np.ndarray)}
+    p1 = dict(load_ts=-one["load_ts"], pv_ts=one["pv_ts"], horizon=0, final_step=K + 1, initial_step=0,
+              unbalanced=dict(loss_load_cost=float(one["loss_load_cost"]), overgeneration_cost=float(one["overgeneration_cost"])))
+    if L.has_battery:
+        p1["battery"] = dict(min_capacity=float(one["bat_min_capacity"]), max_capacity=float(one["bat_max_capacity"]),
+                             max_charge=float(one["bat_max_charge"]), max_discharge=float(one["bat_max_discharge"]),
+                             efficiency=float(one["bat_efficiency"]), battery_cost_cycle=float(one["bat_cost_cycle"]),
+                             init_soc=float(one["soc"]))
+    if L.has_genset:
+        p1["genset"] = dict(running_min_production=float(one["gen_running_min"]), running_max_production=float(one["gen_running_max"]),
+                            genset_cost=float(one["gen_cost"]), co2_per_unit=float(one["gen_co2_per_unit"]),
+                            cost_per_unit_co2=float(one["gen_cost_per_unit_co2"]), start_up_time=0, wind_down_time=0)
+    per_instance = None
+    if not L.has_grid:
+        om = orc.OracleMicrogrid(p1)
+        a1 = acts[:, 0]
+        n_py, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 1.0:
+            om.reset()
+            for k in range(K - 1):
+                om.run(dict(genset=a1[k, :2], battery=a1[k, 2]) if L.has_genset and L.has_battery else
+                       (dict(genset=a1[k, :2]) if L.has_genset else dict(battery=a1[k, 0])), True)
+            n_py += K - 1
+        per_instance = n_py / (time.perf_counter() - t0)
     v1, n1 = run(1, seconds * 0.3)
     # pick the OpenMP thread count that is fastest on this host (containers often expose more logical CPUs
     # than they may use), then spend the rest of the budget on it
@@ -297,6 +324,7 @@ def cpu_baseline(eng, pool, seconds):
     vall, nall = run(best, seconds * 0.4)
     return {"value": vall, "unit": "env-steps/s", "cores": best, "kind": "port",
             "value_1thread": v1, "host_logical_cpus": cores,
+            "per_instance_python_loop_1core": per_instance,
             "thread_probe": {str(c): round(v) for c, v in probe.items()},
             "sample": f"first {n} grids x {K} steps of the benchmark batch, repeated for ~{seconds:.0f} s "
                       f"({n1 + nall} env-steps on 1 and {best} threads): oracle/mgx_oracle.c (scalar C restatement of "
