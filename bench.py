@@ -360,6 +360,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     _lib.build()
+    local = int(os.environ.get("MGX_FORCE_LOCAL_RANK", local))     # tests: several ranks on one GPU (with a gloo backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     N, chunk = args.grids, args.chunk
