@@ -46,8 +46,11 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8192)
-    ap.add_argument("--warmup", type=int, default=1024)
+    # defaults: the GPU needs ~10-20 ms of this load before the time per launch settles (81 -> 75 us over the first ~160
+    # launches of one stream, 77 -> 67.7 us over ~250 rounds of two shards: profiles/r01/exp_time_dependence.txt), so the
+    # default warm-up is 384 launches (~27 ms) and the timed region 1024 launches (~70 ms)
+    ap.add_argument("--steps", type=int, default=65536)
+    ap.add_argument("--warmup", type=int, default=24576)
     ap.add_argument("--grids", type=int, default=100_000, help="microgrids PER GPU (weak scaling)")
     ap.add_argument("--rows", type=int, default=8760, help="time-series rows T")
     ap.add_argument("--mode", choices=["fused", "step", "rbc"], default="fused")
@@ -432,13 +435,15 @@ def main():
         return {"value": n_total * steps / wall, "steps": steps, "ms_per_step": wall / steps * 1e3, "roofline": roof}
 
     results = {}
+    side = {"fused": (32768, 16384), "step": (8192, 2048), "rbc": (16384, 8192)}     # (steps, warm-up) when not the headline
     for mode in ("fused", "step", "rbc"):
         main_mode = mode == args.mode
         results[mode] = measure(mode, sharded=(S > 1 and mode == "fused"),
-                                steps=args.steps if main_mode else min(args.steps, 512),
-                                warmup=args.warmup if main_mode else min(args.warmup, 64))
+                                steps=args.steps if main_mode else min(args.steps, side[mode][0]),
+                                warmup=args.warmup if main_mode else min(args.warmup, side[mode][1]))
     if S > 1:        # the same fused kernel as ONE launch sequence over all N grids (reported under "other")
-        results["fused_one_stream"] = measure("fused", sharded=False, steps=min(args.steps, 2048), warmup=min(args.warmup, 256))
+        results["fused_one_stream"] = measure("fused", sharded=False, steps=min(args.steps, side["fused"][0]),
+                                              warmup=min(args.warmup, side["fused"][1]))
 
     # BASELINE configs[4] in miniature, reported under "other": a heterogeneous fleet (1/3 genset+battery, 1/3
     # battery+grid, 1/3 genset+battery+grid; forecast_horizon = 24) stepped through the Gym surface WITH observations
