@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 4096 --warmup 4096 --no-cpu-baseline --hetero-steps 0 $*"
+ARGS="--steps 8192 --warmup 24576 --no-cpu-baseline --hetero-steps 0 $*"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
