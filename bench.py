@@ -20,6 +20,9 @@ Modes
                    the control is expanded in-kernel, so there is no action stream at all.
 All are timed in every run; --mode picks which one is the headline `value`; the others are reported under "other".
 
+Every mode is preceded by PREWARM_S = 0.1 s of its own launches (untimed set-up: code-object load and the ~15 ms the clocks
+need to settle under this load), then the W warm-up steps, then EXACTLY K timed steps between barrier + synchronize.
+
 Launch:  python bench.py [--gpus N --steps K --warmup W]          (N>1: torchrun, one rank per GPU, RCCL only
                                                                     for the final metrics all-reduce)
 """
@@ -40,6 +43,7 @@ from pymgrid_amd import distributed as mdist  # noqa: E402
 from pymgrid_amd.engine import StepEngine  # noqa: E402
 from pymgrid_amd.generator import generate  # noqa: E402
 
+PREWARM_S = 0.1            # seconds of untimed device pre-warm before each mode's W warm-up steps (see measure())
 OUT_SETS = 4               # sets of output buffers each runner cycles through (see Runner)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
@@ -404,6 +408,14 @@ def main():
         r = srun if sharded else run
         fn = {"fused": r.fused, "step": getattr(r, "single", None), "rbc": r.rbc}[mode]
         (shards.reset() if sharded else eng.reset(want_obs=False))
+        # device pre-warm (untimed, part of set-up like the data generation): the first launches after start-up or after
+        # an idle phase run on a cold device -- code-object load, and ~15 ms until the clocks settle under this load
+        # (profiles/r01/exp_transient_cause.txt) -- so PREWARM_S seconds of the same launches precede the W warm-up steps
+        t_end = time.perf_counter() + PREWARM_S
+        while time.perf_counter() < t_end:
+            fn(chunk if mode != "step" else 64)
+            torch.cuda.synchronize(dev)
+        (shards.reset() if sharded else eng.reset(want_obs=False))
         fn(warmup)
         r.launches = 0
         wall, gpu = timed_shards(fn, steps, shards, dev) if sharded else timed(fn, steps, dev)
@@ -487,6 +499,7 @@ def main():
                                  "roofline": r["roofline"]} for m, r in results.items() if m != args.mode},
             "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total},
             "hetero_h24_gym_steps": hetero,
+            "prewarm_seconds_per_mode": PREWARM_S,
         }
         print(json.dumps(line), flush=True)
     eng.close()
