@@ -109,6 +109,23 @@ class RuleBasedControl:
         ret = torch.zeros(L.n_grids, dtype=torch.float64, device=self.batch.device)
         parts = {}
         done = 0
+        if L.n_load != 1 or L.n_pv != 1:
+            # several load / renewable modules per grid: no fused kernel for that layout -- one expand + step per env-step
+            ids = self._ids_dev.to(torch.int32)
+            rows = {"reward": [], "soc_trace": [], "log": []}
+            for _ in range(total):
+                control = self.engine.expand_discrete(ids, self._table)
+                _, r, _, lg = self.engine.step(control, normalized=False, want_obs=False, want_log=log)
+                ret += r
+                if reward:
+                    rows["reward"].append(r)
+                if soc_trace and L.has_battery:
+                    rows["soc_trace"].append(self.batch.cols["soc"].clone())
+                if log:
+                    rows["log"].append(lg)
+            res = {name: torch.stack(v) for name, v in rows.items() if v}
+            res["episode_return"] = ret
+            return res
         while done < total:
             k = min(chunk, total - done)
             out = self.engine.rollout_discrete(self._ids_dev, self._table, k, reward=reward, soc_trace=soc_trace,

@@ -88,3 +88,33 @@ def test_multi_module_with_controllables_vs_oracle(device, oracle):
             assert np.array_equal(obs[j], om.observe()), (k, j)
             assert env.batch.cols["charge"][j].item() == om.s.charge
     env.close()
+
+
+@pytest.mark.gpu
+def test_rule_based_control_on_multi_module_grids(device, oracle):
+    """RuleBasedControl.run on grids with several load / renewable modules (no fused kernel for that layout: one
+    expand + step per env-step) == the oracle's populate_action + run loop."""
+    import torch
+    from pymgrid_amd import DiscreteBatchedMicrogridEnv, MicrogridBatch, RuleBasedControl
+    from pymgrid_amd.priority_list import MODULE_NAMES
+    rs = np.random.RandomState(5)
+    T, n = 40, 9
+    grids = [dict(load_ts=40 * rs.rand(T, 3), pv_ts=30 * rs.rand(T, 2) * (rs.rand(T, 2) > 0.3), horizon=0, final_step=T,
+                  initial_step=0, unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0),
+                  genset=dict(running_min_production=5.0, running_max_production=60.0, genset_cost=0.4 + 0.1 * rs.rand(),
+                              co2_per_unit=2.0, cost_per_unit_co2=0.1, start_up_time=int(rs.randint(0, 3)),
+                              wind_down_time=int(rs.randint(0, 3))),
+                  battery=dict(min_capacity=20.0, max_capacity=100.0, max_charge=25.0, max_discharge=25.0, efficiency=0.9,
+                               battery_cost_cycle=0.02, init_soc=0.5)) for _ in range(n)]
+    env = DiscreteBatchedMicrogridEnv(MicrogridBatch.from_grids(grids, device=device), remove_redundant_gensets=False)
+    rbc = RuleBasedControl(env, remove_redundant_gensets=False)
+    res = rbc.run(soc_trace=True)
+    r = res["reward"].cpu().numpy()
+    assert r.shape == (T, n)
+    for j, g in enumerate(grids):
+        om = oracle.OracleMicrogrid(g)
+        plist = [(MODULE_NAMES[m], a) for m, a in rbc.priority_list[j]]
+        for k in range(T):
+            assert r[k, j] == om.run(om.populate_action(plist), normalized=False).reward, (j, k)
+        assert res["soc_trace"][-1, j].item() == om.s.soc
+    env.close()
