@@ -44,6 +44,7 @@ class StepEngine:
         if batch.forecast_noise is not None:
             self.set_forecast_noise(**batch.forecast_noise)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._only_device = torch.cuda.device_count() == 1
         self.N = self.layout.n_grids
         self.action_dim = self._lib.mgx_action_dim(self._h)
         self.obs_dim = self._lib.mgx_obs_dim(self._h)
@@ -74,7 +75,7 @@ class StepEngine:
         """fn(handle, *args, stream) on torch's current stream of the engine's device.  Kept lean: at N = 100k a
         single-step kernel takes ~5 us, so every microsecond of Python here shows up in env-steps/s."""
         idx = self._dev_index
-        if torch.cuda.current_device() == idx:
+        if self._only_device or torch.cuda.current_device() == idx:      # one visible GPU: nothing to check (~1 us saved)
             rc = fn(self._h, *args, _raw_stream(idx))
         else:
             with torch.cuda.device(idx):
@@ -127,13 +128,15 @@ class StepEngine:
         return out
 
     def _check_actions(self, actions, lead):
-        want = (*lead, self.N, self.action_dim)
         if actions is None:
             if self.action_dim:
                 raise ValueError("actions are required")
             return None
-        if tuple(actions.shape) != want or actions.dtype != self.action_dtype or not actions.is_contiguous() \
-                or actions.device != self.device:
+        shape = actions.shape
+        if (len(shape) != len(lead) + 2 or shape[-1] != self.action_dim or shape[-2] != self.N
+                or (lead and shape[0] != lead[0]) or actions.dtype != self.action_dtype or not actions.is_contiguous()
+                or actions.device != self.device):
+            want = (*lead, self.N, self.action_dim)
             raise ValueError(f"actions must be a contiguous {self.action_dtype} tensor of shape {want} on {self.device}")
         return actions
 
