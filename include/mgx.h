@@ -98,7 +98,7 @@ typedef struct mgx_columns {
     const double *bat_efficiency, *bat_cost_cycle;
     /* GensetModule parameters (genset_module.py:61-98) */
     const double *gen_running_min, *gen_running_max, *gen_cost, *gen_co2_per_unit, *gen_cost_per_unit_co2;
-    const uint32_t *gen_times;            /* start_up_time | wind_down_time << 16 (each <= 255) */
+    const uint32_t *gen_times;            /* start_up_time | (!allow_abortion) << 8 | wind_down_time << 16 (times <= 255) */
     /* GridModule parameters (grid_module.py:72-101) */
     const double *grid_max_import, *grid_max_export, *grid_cost_per_unit_co2;
     /* UnbalancedEnergyModule parameters (unbalanced_energy_module.py:11-26) */

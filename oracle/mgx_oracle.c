@@ -151,8 +151,8 @@ static int genset_finish_in_progress_change(const orc_grid *g, orc_state *s)
     return 0;
 }
 static void genset_non_instantaneous_update(const orc_grid *g, orc_state *s, int32_t goal)
-{   /* :327-346, allow_abortion == True (False is "not fully tested" upstream, :78-80; unsupported) */
-    if (goal == s->gen_cur && s->gen_cur != s->gen_goal) {
+{   /* :327-346 */
+    if (goal == s->gen_cur && s->gen_cur != s->gen_goal && !g->gen_no_abortion) {   /* abort: only if allow_abortion */
         s->gen_goal = goal;
         genset_reset_up_down_times(g, s);
     } else if (s->gen_cur == s->gen_goal && s->gen_goal != goal) {
@@ -177,8 +177,10 @@ void orc_genset_update_status(const orc_grid *g, orc_state *s, double goal_statu
 {   /* update_status :235-300 */
     int32_t goal = (goal_status > 0.5) ? 1 : 0;     /* Python round(): half-to-even, 0.5 -> 0 (:281) */
     if (goal == s->gen_cur && s->gen_cur == s->gen_goal) return;          /* :284-287 */
-    /* :289-292 -- allow_abortion is True, so the goal is always taken */
-    if (goal != s->gen_goal) s->gen_goal = goal;
+    /* :289-292 -- the new goal is taken if abortion is allowed or the change is instantaneous */
+    int instant_up = g->gen_start_up_time == 0 && goal == 1;
+    int instant_down = g->gen_wind_down_time == 0 && goal == 0;
+    if (goal != s->gen_goal && (!g->gen_no_abortion || instant_up || instant_down)) s->gen_goal = goal;
     if (!genset_finish_in_progress_change(g, s))                            /* :294 */
         genset_non_instantaneous_update(g, s, goal);                       /* :296-297 */
 }
@@ -449,8 +451,9 @@ static void batch_init_grid(const orc_batch *b, int32_t i, int32_t t0, orc_grid 
         g->gen_running_min = b->gen_running_min[i]; g->gen_running_max = b->gen_running_max[i];
         g->gen_cost = b->gen_cost[i]; g->gen_co2_per_unit = b->gen_co2_per_unit[i];
         g->gen_cost_per_unit_co2 = b->gen_cost_per_unit_co2[i];
-        g->gen_start_up_time = (int32_t)(b->gen_times[i] & 0xffffu);
-        g->gen_wind_down_time = (int32_t)(b->gen_times[i] >> 16);
+        g->gen_start_up_time = (int32_t)(b->gen_times[i] & 0xffu);
+        g->gen_no_abortion = (int32_t)((b->gen_times[i] >> 8) & 1u);
+        g->gen_wind_down_time = (int32_t)((b->gen_times[i] >> 16) & 0xffu);
         uint32_t st = b->gen_status[i];
         s->gen_cur = st & 0xff; s->gen_goal = (st >> 8) & 0xff; s->gen_up = (st >> 16) & 0xff; s->gen_down = st >> 24;
     }

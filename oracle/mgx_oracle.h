@@ -63,6 +63,8 @@ typedef struct orc_grid {
     /* the GridModule precedes the BatteryModule in the microgrid's module list: source-and-sink modules are swept in
      * list order (module_container.py:355-413), so it is stepped and appended to the MicrogridStep lists first */
     int32_t grid_before_battery;
+    /* GensetModule(allow_abortion=False), genset_module.py:78-88: an in-progress status change cannot be called off */
+    int32_t gen_no_abortion;
 } orc_grid;
 
 /* Dynamic state of ONE microgrid. */
@@ -139,7 +141,7 @@ typedef struct orc_batch {
     const double *bat_min_capacity, *bat_max_capacity, *bat_max_charge, *bat_max_discharge,
                  *bat_efficiency, *bat_cost_cycle;
     const double *gen_running_min, *gen_running_max, *gen_cost, *gen_co2_per_unit, *gen_cost_per_unit_co2;
-    const uint32_t *gen_times;          /* start_up | wind_down << 16 */
+    const uint32_t *gen_times;          /* start_up | no_abortion << 8 | wind_down << 16 */
     const double *grid_max_import, *grid_max_export, *grid_cost_per_unit_co2;
     const double *loss_load_cost, *overgeneration_cost;
     const double *load_ts, *pv_ts;      /* [T,N] */

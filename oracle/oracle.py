@@ -44,6 +44,7 @@ class Grid(C.Structure):
         ("load_lo", c_double_p), ("load_hi", c_double_p), ("pv_lo", c_double_p), ("pv_hi", c_double_p),
         ("grid_lo", C.c_double * 4), ("grid_hi", C.c_double * 4),
         ("grid_before_battery", C.c_int32),
+        ("gen_no_abortion", C.c_int32),
     ]
 
 
@@ -196,6 +197,7 @@ class OracleMicrogrid:
             g.gen_cost, g.gen_co2_per_unit = float(q["genset_cost"]), float(q["co2_per_unit"])
             g.gen_cost_per_unit_co2 = float(q["cost_per_unit_co2"])
             g.gen_start_up_time, g.gen_wind_down_time = int(q["start_up_time"]), int(q["wind_down_time"])
+            g.gen_no_abortion = int(not q.get("allow_abortion", True))
             if q.get("status") is not None:
                 status = [int(v) for v in q["status"]]
             else:                                    # genset_module.py:91-92,216-227

@@ -150,11 +150,13 @@ def unpack_status(word):
     return np.stack([w & 0xff, (w >> 8) & 0xff, (w >> 16) & 0xff, (w >> 24) & 0xff], axis=-1).astype(np.int32)
 
 
-def pack_times(start_up, wind_down):
+def pack_times(start_up, wind_down, allow_abortion=True):
+    """start_up_time | (not allow_abortion) << 8 | wind_down_time << 16 (GensetModule arguments, genset_module.py:61-98)."""
     su, wd = np.asarray(start_up, dtype=np.int64), np.asarray(wind_down, dtype=np.int64)
     if np.any((su < 0) | (su > 255) | (wd < 0) | (wd > 255)):
         raise ValueError("start_up_time / wind_down_time must be in [0, 255] on the device path")
-    return (su | (wd << 16)).astype(np.uint32)
+    no_abort = (~np.asarray(allow_abortion, dtype=bool)).astype(np.int64)
+    return (su | (no_abort << 8) | (wd << 16)).astype(np.uint32)
 
 
 class MicrogridBatch:
@@ -365,7 +367,7 @@ def pack_grids(grids):
         A["gen_cost_per_unit_co2"] = col(lambda g: g["genset"].get("cost_per_unit_co2", 0.0))
         su = [int(g["genset"].get("start_up_time", 0)) for g in grids]
         wd = [int(g["genset"].get("wind_down_time", 0)) for g in grids]
-        A["gen_times"] = pack_times(su, wd)
+        A["gen_times"] = pack_times(su, wd, [bool(g["genset"].get("allow_abortion", True)) for g in grids])
         st = []
         for g, s_, w_ in zip(grids, su, wd):      # genset_module.py:91-92,216-227
             q = g["genset"]

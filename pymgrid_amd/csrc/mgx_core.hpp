@@ -211,19 +211,21 @@ __device__ __forceinline__ void load_inputs(const mgx_columns &c, const AT *__re
 }
 
 // ---- GensetModule.update_status (genset_module.py:235-346) on the packed status word ---------------------
-// status = current | goal<<8 | steps_until_up<<16 | steps_until_down<<24 ; times = start_up | wind_down<<16
+// status = current | goal<<8 | steps_until_up<<16 | steps_until_down<<24 ; times = start_up | no_abortion<<8 | wind_down<<16
 __device__ __forceinline__ uint32_t genset_update_status(uint32_t st, uint32_t times, double goal_f)
 {
     int cur = st & 0xff, gs = (st >> 8) & 0xff, up = (st >> 16) & 0xff, down = st >> 24;
-    const int su = times & 0xffff, wd = times >> 16;
+    const int su = times & 0xff, wd = (times >> 16) & 0xff;
+    const bool allow = ((times >> 8) & 1u) == 0;      // allow_abortion (genset_module.py:78-88)
     const int goal = goal_f > 0.5 ? 1 : 0;            // Python round(): half-to-even, 0.5 -> 0 (:281)
     if (!(goal == cur && cur == gs)) {                // :284-287
-        if (goal != gs) gs = goal;                    // :289-292 (allow_abortion == True)
+        const bool instant = (su == 0 && goal == 1) || (wd == 0 && goal == 0);
+        if (goal != gs && (allow || instant)) gs = goal;   // :289-292
         bool finished = false;                        // _finish_in_progress_change :302-311
         if (up == 0 && gs == 1)        { cur = 1; up = 0;   down = wd; finished = true; }
         else if (down == 0 && gs == 0) { cur = 0; down = 0; up = su;   finished = true; }
         if (!finished) {                              // _non_instantaneous_update :327-346
-            if (goal == cur && cur != gs) {
+            if (goal == cur && cur != gs && allow) {  // calling off an in-progress change
                 gs = goal;
                 if (cur) { up = 0; down = wd; } else { down = 0; up = su; }
             } else if (cur == gs && gs != goal) {
@@ -577,7 +579,7 @@ __device__ __forceinline__ void observe_state_cols(const KArgs &a, const Params 
 {
     int k = first < 0 ? 2 * (1 + a.H) : first;        // the state columns follow the load and pv windows
     if constexpr (F & F_GENSET) {
-        const double su = (double)(p.gen_times & 0xffff), wd = (double)(p.gen_times >> 16);
+        const double su = (double)(p.gen_times & 0xff), wd = (double)((p.gen_times >> 16) & 0xff);
         obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)(s.status & 0xff));
         obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
         obs_row[k++] = (OT)space_norm(0.0, su, (double)((s.status >> 16) & 0xff));

@@ -643,7 +643,7 @@ __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, c
         observe_series_multi(a.c.pv_ts + (int64_t)j * N + i, (int64_t)a.n_pv * N, a.T, t, a.H, a.c.pv_lo[(int64_t)j * N + i],
                              a.c.pv_hi[(int64_t)j * N + i], obs_row + k);
     if constexpr (F & F_GENSET) {
-        const double su = (double)(p.gen_times & 0xffff), wd = (double)(p.gen_times >> 16);
+        const double su = (double)(p.gen_times & 0xff), wd = (double)((p.gen_times >> 16) & 0xff);
         obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)(s.status & 0xff));
         obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
         obs_row[k++] = (OT)space_norm(0.0, su, (double)((s.status >> 16) & 0xff));

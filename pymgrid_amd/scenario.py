@@ -138,8 +138,6 @@ def load_scenario_yaml(path):
             p["unbalanced"] = dict(loss_load_cost=float(cp["loss_load_cost"]),
                                    overgeneration_cost=float(cp["overgeneration_cost"]))
         elif tag == "!Genset":
-            if not cp.get("allow_abortion", True):
-                raise NotImplementedError("allow_abortion=False is not supported")
             su, wd = int(cp.get("start_up_time", 0)), int(cp.get("wind_down_time", 0))
             on = int(bool(cp.get("init_start_up", True)))
             status = [on, on, 0, wd] if on else [0, 0, su, 0]                   # genset_module.py:91-92,216-227
@@ -151,6 +149,8 @@ def load_scenario_yaml(path):
                                genset_cost=float(cp["genset_cost"]), co2_per_unit=float(cp.get("co2_per_unit", 0.0)),
                                cost_per_unit_co2=float(cp.get("cost_per_unit_co2", 0.0)),
                                start_up_time=su, wind_down_time=wd, status=status)
+            if not cp.get("allow_abortion", True):
+                p["genset"]["allow_abortion"] = False
         elif tag == "!BatteryModule":
             if cp.get("battery_transition_model") is not None:
                 raise NotImplementedError("custom battery_transition_model is not supported")
@@ -226,7 +226,7 @@ def dump_scenario_yaml(p, path):
                 on = int(bool(q.get("init_start_up", True)))
                 st = [on, on, 0, wd] if on else [0, 0, su, 0]
             mods.append(module("genset", "!Genset", dict(
-                allow_abortion=True, co2_per_unit=float(q.get("co2_per_unit", 0.0)),
+                allow_abortion=bool(q.get("allow_abortion", True)), co2_per_unit=float(q.get("co2_per_unit", 0.0)),
                 cost_per_unit_co2=float(q.get("cost_per_unit_co2", 0.0)), genset_cost=float(q["genset_cost"]),
                 init_start_up=bool(st[0]), initial_step=t0, provided_energy_name="genset_production", raise_errors=False,
                 running_max_production=float(q["running_max_production"]),

@@ -71,7 +71,7 @@ def extract_params(m):
                             charge=float(b.current_charge), soc=float(b.soc))
     if gens:
         g = gens[0]
-        assert g.allow_abortion and not callable(g.genset_cost)
+        assert not callable(g.genset_cost)
         p["genset"] = dict(running_min_production=float(g.running_min_production),
                            running_max_production=float(g.running_max_production),
                            genset_cost=float(g.genset_cost), co2_per_unit=float(g.co2_per_unit),
@@ -79,6 +79,8 @@ def extract_params(m):
                            start_up_time=int(g.start_up_time), wind_down_time=int(g.wind_down_time),
                            status=[int(g._current_status), int(g._goal_status),
                                    int(g._steps_until_up), int(g._steps_until_down)])
+        if not g.allow_abortion:
+            p["genset"]["allow_abortion"] = False
     if grids:
         g = grids[0]
         p["grid"] = dict(max_import=float(g.max_import), max_export=float(g.max_export),
@@ -302,14 +304,27 @@ def make_genset_fsm():
                 post = (g._current_status, g._goal_status, g._steps_until_up, g._steps_until_down)
                 rows.append((su, wd, goal, *map(int, pre), *map(int, post), int(nxt)))
     tab = np.unique(np.array(rows, dtype=np.int16), axis=0)
+    # the same table for GensetModule(allow_abortion=False) (genset_module.py:78-88,291,328)
+    rows = []
+    for su, wd, init in itertools.product(range(5), range(5), (0, 1)):
+        for seq in itertools.product((0, 1), repeat=7):
+            g = GensetModule(running_min_production=10, running_max_production=100, genset_cost=1.0, start_up_time=su,
+                             wind_down_time=wd, init_start_up=bool(init), allow_abortion=False)
+            for goal in seq:
+                pre = (g._current_status, g._goal_status, g._steps_until_up, g._steps_until_down)
+                nxt = g.next_status(goal)
+                g.update_status(goal)
+                post = (g._current_status, g._goal_status, g._steps_until_up, g._steps_until_down)
+                rows.append((su, wd, goal, *map(int, pre), *map(int, post), int(nxt)))
+    tab_noabort = np.unique(np.array(rows, dtype=np.int16), axis=0)
     # fractional goal values: round-half-even (genset_module.py:281)
     fr = []
     for v in (0.0, 0.25, 0.5, 0.5000000001, 0.4999999999, 0.75, 1.0):
         g = GensetModule(10, 100, 1.0, start_up_time=0, wind_down_time=0, init_start_up=False)
         g.update_status(v)
         fr.append((v, int(g._current_status)))
-    save("genset_fsm.npz", transitions=tab, fractional=np.array(fr))
-    print("genset transitions:", tab.shape)
+    save("genset_fsm.npz", transitions=tab, transitions_no_abortion=tab_noabort, fractional=np.array(fr))
+    print("genset transitions:", tab.shape, "without abortion:", tab_noabort.shape)
 
 
 # --------------------------------------------------------------------------------------------- #

@@ -775,7 +775,8 @@ def test_random_fleet_every_module_set_vs_oracle(seed, device, oracle):
             p["genset"] = dict(running_min_production=rmax * float(rs.choice([0.05, 0.3])), running_max_production=rmax,
                                genset_cost=rs.uniform(0, 1), co2_per_unit=float(rs.choice([0.0, 2.0])),
                                cost_per_unit_co2=float(rs.choice([0.0, 0.1])), start_up_time=int(rs.randint(0, 4)),
-                               wind_down_time=int(rs.randint(0, 4)), init_start_up=bool(rs.randint(0, 2)))
+                               wind_down_time=int(rs.randint(0, 4)), init_start_up=bool(rs.randint(0, 2)),
+                               allow_abortion=bool(rs.rand() < 0.7))
         if arch & 2:
             cap = peak * rs.uniform(0.5, 5)
             cmin = cap * float(rs.choice([0.0, 0.2, 0.5]))
@@ -899,3 +900,25 @@ def test_stream_shards_equal_one_engine(device):
     for name in ("charge", "soc", "gen_status"):
         assert torch.equal(whole.batch.cols[name], torch.cat([e.batch.cols[name] for e in shards.engines]))
     whole.close(); shards.close()
+
+
+def test_genset_fsm_tables_on_device(device):
+    """G4 on the device: every distinct GensetModule.update_status transition of the reference, with and without
+    allow_abortion (genset_module.py:235-346), as ONE batch -- a grid per transition, preset status, one step."""
+    from pymgrid_amd import MicrogridBatch, StepEngine, unpack_status
+    z = golden("genset_fsm.npz")
+    rows = [(r, True) for r in z["transitions"]] + [(r, False) for r in z["transitions_no_abortion"]]
+    T = 4
+    grids = [dict(load_ts=np.zeros(T), pv_ts=np.zeros(T), horizon=0, final_step=T, initial_step=0,
+                  unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0),
+                  genset=dict(running_min_production=10.0, running_max_production=100.0, genset_cost=1.0, co2_per_unit=0.0,
+                              cost_per_unit_co2=0.0, start_up_time=int(r[1 - 1]), wind_down_time=int(r[1]), allow_abortion=allow,
+                              status=[int(r[3]), int(r[4]), int(r[5]), int(r[6])])) for r, allow in rows]
+    eng = StepEngine(MicrogridBatch.from_grids(grids, device=device))
+    a = np.zeros((len(rows), 2))
+    a[:, 0] = [float(r[2]) for r, _ in rows]
+    eng.step(_t(a, device), want_obs=False)
+    post = unpack_status(eng.batch.cols["gen_status"].cpu().numpy().view(np.uint32))
+    for j, (r, allow) in enumerate(rows):
+        assert post[j].tolist() == [int(v) for v in r[7:11]], (allow, r.tolist())
+    eng.close()

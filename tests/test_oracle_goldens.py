@@ -78,13 +78,14 @@ def test_genset_fsm_table(oracle):
     import ctypes as C
     z = golden("genset_fsm.npz")
     L = oracle.lib()
-    for su, wd, goal, c0, g0, u0, d0, c1, g1, u1, d1, nxt in z["transitions"]:
-        g = oracle.Grid(); g.gen_start_up_time, g.gen_wind_down_time = int(su), int(wd)
-        s = oracle.State(); s.gen_cur, s.gen_goal, s.gen_up, s.gen_down = int(c0), int(g0), int(u0), int(d0)
-        assert L.orc_genset_next_status(C.byref(s), int(goal)) == nxt
-        L.orc_genset_update_status(C.byref(g), C.byref(s), float(goal))
-        assert (s.gen_cur, s.gen_goal, s.gen_up, s.gen_down) == (c1, g1, u1, d1)
-        assert s.gen_cur == nxt
+    for key, no_abort in (("transitions", 0), ("transitions_no_abortion", 1)):     # allow_abortion True / False
+        for su, wd, goal, c0, g0, u0, d0, c1, g1, u1, d1, nxt in z[key]:
+            g = oracle.Grid(); g.gen_start_up_time, g.gen_wind_down_time, g.gen_no_abortion = int(su), int(wd), no_abort
+            s = oracle.State(); s.gen_cur, s.gen_goal, s.gen_up, s.gen_down = int(c0), int(g0), int(u0), int(d0)
+            assert L.orc_genset_next_status(C.byref(s), int(goal)) == nxt
+            L.orc_genset_update_status(C.byref(g), C.byref(s), float(goal))
+            assert (s.gen_cur, s.gen_goal, s.gen_up, s.gen_down) == (c1, g1, u1, d1), (key, su, wd, goal, c0, g0, u0, d0)
+            assert s.gen_cur == nxt
     for v, cur in z["fractional"]:          # round-half-to-even on the goal (genset_module.py:281)
         g = oracle.Grid(); s = oracle.State()
         L.orc_genset_update_status(C.byref(g), C.byref(s), float(v))

@@ -42,7 +42,7 @@ def _draw(rs):
                                             running_max_production=rmax, genset_cost=rs.uniform(0, 1),
                                             co2_per_unit=rs.choice([0.0, 2.0]), cost_per_unit_co2=rs.choice([0.0, 0.1]),
                                             start_up_time=int(rs.randint(0, 4)), wind_down_time=int(rs.randint(0, 4)),
-                                            init_start_up=bool(rs.randint(0, 2)))))
+                                            init_start_up=bool(rs.randint(0, 2)), allow_abortion=bool(rs.rand() < 0.7))))
     if arch & 2:
         cap = peak * rs.uniform(0.5, 5)
         cmin = cap * rs.choice([0.0, 0.2, 0.5])
