@@ -11,7 +11,8 @@
  *
  * Conventions
  *  - N microgrids ("grids") advance in lock-step; all share the step counter t, the series length T and
- *    the episode window [initial_step, final_step).
+ *    the episode window [initial_step, final_step) -- unless the episode was started with mgx_reset_windows, which
+ *    gives every grid its own start row and episode length (its own trajectory) behind the shared counter.
  *  - Every pointer in mgx_columns and every data argument is a DEVICE pointer owned by the caller
  *    (e.g. torch tensors); the library allocates only a small scratch buffer in mgx_create.
  *  - All arithmetic is IEEE fp64, unfused (no FMA contraction), in the reference's operation order.
@@ -42,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 2
+#define MGX_ABI_VERSION 3
 
 enum mgx_status {
     MGX_OK = 0,
@@ -136,9 +137,10 @@ int32_t mgx_current_step(const mgx_handle *h);                   /* BaseMicrogri
 
 /* Keep the step counter in DEVICE memory (enable != 0) so that a sequence of mgx_step / mgx_step_discrete / mgx_step_k /
  * mgx_rollout_discrete / mgx_observe calls can be captured in a hipGraph (stream capture) and replayed: kernels read
- * the counter, a one-thread kernel advances it after every step call.  While enabled, launch-time range checks are
+ * the counter, the last workgroup of every stepping kernel to finish advances it.  While enabled, launch-time range checks are
  * replaced by an in-kernel clamp + sticky overrun flag (reported as MGX_ERR_RANGE when the mode is switched off), and
- * mgx_current_step() performs a blocking device read.  Disabling copies the counter back to the host. */
+ * mgx_current_step() performs a blocking device read (after synchronising the stream of the last call that moved the
+ * counter).  Disabling copies the counter back to the host. */
 int mgx_use_device_counter(mgx_handle *h, int enable, mgx_stream stream);
 
 /* ---- the hot path --------------------------------------------------------------------------------- */
@@ -152,6 +154,24 @@ int mgx_reset(mgx_handle *h, int32_t initial_step, void *obs, mgx_stream stream)
  * (microgrid.py:221-225, microgrid/trajectory/ classes; validated like _check_trajectory_func, microgrid.py:181-203:
  * inside the window given at create, initial < final).  Does not move the step counter; call mgx_reset next. */
 int mgx_set_window(mgx_handle *h, int32_t initial_step, int32_t final_step);
+
+/* Per-grid episodes.  In the reference every Microgrid owns its step counter and draws its own trajectory at reset
+ * (Microgrid.reset -> _set_trajectory, microgrid.py:205-225; BaseMicrogridModule.reset, base_module.py:65-77,292-296;
+ * FixedLengthStochasticTrajectory / StochasticTrajectory, microgrid/trajectory/stochastic.py:9-30).  Batched form:
+ * grid i starts at series row start[i] and its episode lasts length[i] steps (NULL: max_length for every grid), i.e.
+ * it reports done from counter value length[i] - 1 on (base_timeseries_module.py:124-125 with its own final_step =
+ * start[i] + length[i]).  A HIP kernel gathers rows [start[i], start[i] + max_length + horizon] of every grid's series
+ * into the caller's window buffers load_w / pv_w [R, N], grid_w [R, 4, N] (R = max_length + horizon + 1; rows beyond
+ * the end of a series hold the forecaster's padding value (lo + hi) / 2, forecaster.py:95,120-137), and the handle then
+ * steps over those buffers from counter 0: mgx_current_step() = steps since the reset, grid i's own current_step =
+ * start[i] + mgx_current_step().  start / length are DEVICE arrays [N]; a start outside the window given at create is
+ * clamped into it and a length is cut at the env's final step (the reference raises ValueError in
+ * _check_trajectory_func, microgrid.py:181-203: validate on the host if the arrays come from outside).  final_rel [N]
+ * (device, int32; required with `length`) receives the episode lengths actually used and must stay alive until the
+ * next reset.  Observation bounds stay those of the full series.  mgx_reset() returns to the full series.
+ * MGX_ERR_UNSUPPORTED with several load / renewable modules, in device-counter mode or while stepping in shards. */
+int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length,
+                      double *load_w, double *pv_w, double *grid_w, int32_t *final_rel, void *obs, mgx_stream stream);
 
 /* Microgrid.reward_shaping_func (microgrid.py:105,130): one of enum mgx_reward_shaper. */
 int mgx_set_reward_shaper(mgx_handle *h, int32_t shaper);
@@ -222,6 +242,79 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
 int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, const int32_t *table,
                          int32_t n_actions, int32_t K, double *reward, uint8_t *done, double *soc_trace,
                          uint32_t *status_trace, double *ret_acc, double *log, mgx_stream stream);
+
+/* K consecutive mgx_step calls issued by ONE call: the Gym cadence (`for a in actions: env.step(a)`, one kernel launch
+ * per env-step, envs/base/base.py:169-209) without a host round trip per step -- from Python a per-step call costs
+ * more than the 5 us the kernel takes at N = 100 000.  actions [K, N, A]; reward [K, N]; done [K, N], obs [K, N, D]
+ * (block k = the observation after step k) and log [K, L, N] may be NULL. */
+int mgx_step_many(mgx_handle *h, const void *actions, int32_t K, int normalized,
+                  double *reward, uint8_t *done, void *obs, double *log, mgx_stream stream);
+
+/* Shards.  Grids never interact (no cross-grid term anywhere in Microgrid.run), so the launch sequence of one range of
+ * grids owes nothing to another's.  mgx_set_shards(h, S > 1) splits every stepping call (mgx_step, mgx_step_many,
+ * mgx_step_k, mgx_step_discrete, mgx_expand_discrete, mgx_rollout_discrete) into S launches over contiguous grid ranges,
+ * each on its own internal HIP stream, and the ranges are NOT joined between calls: while one range is in the ramp-up or
+ * the tail of a launch another is in full flight (measured: 66-68 instead of 74-76 us per 64-step round of 100 000
+ * grids with S = 2).  In this mode the `stream` argument of those calls is ignored; ordering
+ * against other streams is explicit:
+ *   mgx_fork(h, s)  the shard streams wait for everything queued on s so far  (inputs produced on s are then safe)
+ *   mgx_join(h, s)  s waits for everything issued to the shard streams so far (outputs are then safe to read on s)
+ * Every other entry point still runs on the stream it is given: bracket it with mgx_join / mgx_fork.  Buffers handed to
+ * a stepping call must stay alive until the next mgx_join.  mgx_shard_stream returns the hipStream_t of a shard (for
+ * timing events), NULL when shards are off.  Not offered in device-counter mode. */
+int mgx_set_shards(mgx_handle *h, int32_t n_shards);
+int mgx_fork(mgx_handle *h, mgx_stream stream);
+int mgx_join(mgx_handle *h, mgx_stream stream);
+void *mgx_shard_stream(mgx_handle *h, int32_t shard);
+
+/* Heterogeneous fleets (a population of microgrids with different module sets: one handle per layout).  One call steps
+ * every batch of the fleet once -- `for m in microgrids: m.run(control)` over the whole population -- and, for the
+ * batches whose observation ring is used up, issues the window prefetch of the next refill_K steps
+ * (mgx_observe_windows) behind the steps; no host work between the launches.  An item is a continuous step
+ * (actions; `normalized` applies) or, when action_id != NULL, a discrete one (mgx_step_discrete with table / n_actions).
+ * All items are validated before the first launch. */
+typedef struct mgx_fleet_item {
+    int32_t struct_size;          /* = sizeof(mgx_fleet_item) */
+    int32_t n_actions;            /* discrete: rows of `table` */
+    mgx_handle *handle;
+    const void *actions;          /* [N, A] continuous control, or NULL */
+    const int32_t *action_id;     /* [N] priority-list ids (device), or NULL */
+    const int32_t *table;         /* host [n_actions, 3, 2], discrete only */
+    double *reward;               /* [N] */
+    uint8_t *done;                /* [N] or NULL */
+    void *obs;                    /* [N, D] (or the state-only target inside a ring block) or NULL */
+    double *log;                  /* [L, N] or NULL */
+    void *refill_ring;            /* [refill_K, N, D] or NULL: mgx_observe_windows(handle, refill_K, refill_ring) after the step */
+    int32_t refill_K;
+    int32_t reserved;
+} mgx_fleet_item;
+int mgx_fleet_step(const mgx_fleet_item *items, int32_t n_items, int normalized, mgx_stream stream);
+
+/* MicrogridGenerator's time series on device (MicrogridGenerator.py): load / pv = base profile x size / max(profile)
+ * (_scale_ts, :137-147; stored with the modules' sign, base_timeseries_module.py:68-79), import price = tariff pattern
+ * 1 / 2 by hour of day (_get_electricity_tariff, :253-285), export price 0, co2 = base co2 profile (:205-212), grid
+ * status = 1 except weak-grid outages (_generate_weak_grid_profile, :321-340: a uniform draw per row below
+ * outage_per_day / 24 starts an outage whose back-fill covers the duration - 1 rows before it, never row 0; T + 1
+ * draws).  Uniforms come from Philox4x32-10(seed; global grid index, row), so rank r of W writes exactly columns
+ * [grid_index0, grid_index0 + n_grids) of the same global batch.  Everything is a device pointer; grid_ts (and the
+ * arrays only it needs) may be NULL.  No handle: this runs before mgx_create. */
+typedef struct mgx_synth {
+    int32_t struct_size;          /* = sizeof(mgx_synth) */
+    int32_t n_grids, n_steps;
+    int32_t n_load_profiles, n_pv_profiles, n_co2_profiles;
+    const double *base_load, *base_pv, *base_co2;          /* [T, n_*_profiles], values as in the reference's csv files */
+    const int32_t *load_profile, *pv_profile, *co2_profile; /* [N] column of the base arrays */
+    const double *load_ratio, *pv_ratio;                    /* [N] size / max(profile) */
+    const int32_t *tariff;                                  /* [N] 1 or 2 */
+    const int32_t *weak;                                    /* [N] 0 / 1 (rand_weak_grid, :535) */
+    const double *outage_per_day;                           /* [N] randn * 3/4 + 0.25 (:291) */
+    const int32_t *outage_duration;                         /* [N] randint(1, 8) (:292) */
+    uint64_t seed;
+    int64_t grid_index0;
+    double *load_ts, *pv_ts;                                /* out [T, N] */
+    double *grid_ts;                                        /* out [T, 4, N] or NULL */
+} mgx_synth;
+int mgx_synthesize_series(const mgx_synth *args, mgx_stream stream);
 
 /* Column sums over the grids, sums[m] = sum_i values[m*N + i] (deterministic two-stage wavefront-shuffle +
  * LDS reduction; the "metrics" vector that is all-reduced across GPUs).  M <= 64. */

@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-fPIC", "-shared"]
 
 MGX_OK, MGX_ERR_INVALID, MGX_ERR_UNSUPPORTED, MGX_ERR_RANGE, MGX_ERR_DEVICE = range(5)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MgxError(RuntimeError):
@@ -56,6 +56,25 @@ class Columns(C.Structure):
 
 COLUMN_NAMES = tuple(n for n, _ in Columns._fields_[2:])
 
+
+class FleetItem(C.Structure):
+    """mgx_fleet_item (include/mgx.h): one batch of a heterogeneous fleet inside ``mgx_fleet_step``."""
+    _fields_ = [("struct_size", C.c_int32), ("n_actions", C.c_int32), ("handle", C.c_void_p), ("actions", C.c_void_p),
+                ("action_id", C.c_void_p), ("table", c_i32_p), ("reward", C.c_void_p), ("done", C.c_void_p),
+                ("obs", C.c_void_p), ("log", C.c_void_p), ("refill_ring", C.c_void_p), ("refill_K", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class Synth(C.Structure):
+    """mgx_synth (include/mgx.h): arguments of ``mgx_synthesize_series``."""
+    _fields_ = ([("struct_size", C.c_int32), ("n_grids", C.c_int32), ("n_steps", C.c_int32),
+                 ("n_load_profiles", C.c_int32), ("n_pv_profiles", C.c_int32), ("n_co2_profiles", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("base_load", "base_pv", "base_co2", "load_profile", "pv_profile", "co2_profile",
+                                             "load_ratio", "pv_ratio", "tariff", "weak", "outage_per_day",
+                                             "outage_duration")]
+                + [("seed", C.c_uint64), ("grid_index0", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("load_ts", "pv_ts", "grid_ts")])
+
 # every symbol include/mgx.h declares: (restype, argtypes)
 SYMBOLS = {
     "mgx_abi_version": (C.c_int, []),
@@ -87,6 +106,16 @@ SYMBOLS = {
     "mgx_rollout_discrete": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_i32_p, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgx_reset_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_step_many": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p]),
+    "mgx_set_shards": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mgx_fork": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgx_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgx_shard_stream": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "mgx_fleet_step": (C.c_int, [C.POINTER(FleetItem), C.c_int32, C.c_int, C.c_void_p]),
+    "mgx_synthesize_series": (C.c_int, [C.POINTER(Synth), C.c_void_p]),
 }
 
 

@@ -53,7 +53,19 @@ struct KArgs {
     // hipGraph and replayed: kernels read the counter, `advance_counter` moves it, the kernel argument t is then an
     // offset relative to it.  A replay that would run past the series is clamped to the last row and flagged.
     int32_t *t_dev;
+    // Sub-range [g0, g1) of the grids a stepping launch owns (0, N unless the handle steps in shards: every shard is a
+    // launch of its own, on its own HIP stream; column pointers and row strides stay those of the whole batch).
+    int32_t g0, g1;
+    // Per-grid episode ends (mgx_reset_windows): done_i = t >= grid_final[i] - 1 instead of the batch-wide final_step.
+    const int32_t *grid_final;
 };
+
+// done flag of grid i at step counter t: _done(), base_timeseries_module.py:124-125 (evaluated before the counter moves)
+__device__ __forceinline__ uint8_t done_at(const KArgs &a, int64_t i, int32_t t)
+{
+    const int32_t fin = a.grid_final ? a.grid_final[i] : a.final_step;
+    return (uint8_t)(t >= fin - 1);
+}
 
 __device__ __forceinline__ int32_t resolve_t(const KArgs &a, int32_t t)
 {
@@ -68,11 +80,21 @@ __device__ __forceinline__ int32_t resolve_t(const KArgs &a, int32_t t)
 // Device-counter mode: the LAST workgroup of a stepping kernel to finish moves the counter by `k` steps
 // (counter[2] counts finished workgroups).  Every workgroup read the counter at its very start, i.e. before its own
 // arrival here, so nobody can observe the new value inside this launch; the next launch sees it (kernel boundary).
+// Inside a workgroup the waves are NOT ordered by themselves, hence the barrier: every wave of the arriving workgroup has
+// read the counter (resolve_t at its start; waves that left through the range check do not hold the barrier back on
+// AMD hardware) before thread 0 signs the workgroup off.  The counter words are written with agent-scope atomics so the
+// next launch -- possibly on another XCD's L2 -- reads the new value.
 __device__ __forceinline__ void advance_counter_in_kernel(const KArgs &a, int32_t k)
 {
-    if (a.t_dev && threadIdx.x == 0) {
+    if (a.t_dev == nullptr) return;              // kernel argument: uniform over the whole launch
+    __syncthreads();
+    if (threadIdx.x == 0) {
         const unsigned prev = atomicAdd((unsigned *)&a.t_dev[2], 1u);
-        if (prev == gridDim.x - 1) { a.t_dev[2] = 0; a.t_dev[0] += k; }
+        if (prev == gridDim.x - 1) {
+            const int32_t t = __hip_atomic_load(&a.t_dev[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.t_dev[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.t_dev[0], t + k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

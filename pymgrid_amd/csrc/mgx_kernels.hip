@@ -38,8 +38,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *
                                                      double *__restrict__ log)
 {
     t = resolve_t(a, t);
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.N) return;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.g1) return;
     // all loads first (independent, one latency round), then the arithmetic
     Params p; State s; Inputs in; Outputs o; Derived d;
     if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t, in);
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *
     store_state<F>(a.c, i, s);
     reward[i] = shaped_reward<F>(a.shaper, o);
     // _done(): t >= final_step - 1, evaluated before the counter moves (base_timeseries_module.py:124-125)
-    if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
+    if (done) done[i] = done_at(a, i, t);
     if (log) store_log<F>(log + i, a.N, o, s.status);
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
     // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT
     K = resolve_k(a, t0, K);
     // gpb = grids per workgroup (<= BLOCK_K, multiple of 16 = one 128-B line of doubles): chosen by the host so that
     // the busiest CU streams as few grids as possible (fused_grids_per_block)
-    const int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x;
-    if ((int32_t)threadIdx.x >= gpb || i >= a.N) return;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * gpb + threadIdx.x;
+    if ((int32_t)threadIdx.x >= gpb || i >= a.g1) return;
     const int64_t N = a.N;
     Params p; State s; Derived d;
     load_state<F>(a.c, i, out.log != nullptr, s);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT
     const bool norm = normalized != 0;
     const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
     const bool gen_instant = genset_wave_is_instant<F>(p, s);
-    const int32_t k_done = a.final_step - 1 - t0;            // done <=> k >= k_done
+    const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;      // done <=> k >= k_done
     double ret = 0.0;
 
     RawInputs<AT> ring[U];
@@ -188,8 +188,8 @@ template <int F>
 __global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t, void *__restrict__ obs)
 {
     t = resolve_t_obs(a, t);
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.N) return;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.g1) return;
     Params p; State s;
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
@@ -447,8 +447,8 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
 {
     t = resolve_t(a, t);
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.N) return;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.g1) return;
     const int64_t N = a.N;
     Params p; State s; Inputs in;
     load_state<F>(a.c, i, false, s);
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
 {
     t = resolve_t(a, t);
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.N) return;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.g1) return;
     const int64_t N = a.N;
     Params p; State s; Inputs in; Outputs o; Derived d;
     const int32_t id = action_id[i];
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
     step_core<F, true>(p, d, s, in, false, true, gen_instant, o, bat_q);
     store_state<F>(a.c, i, s);
     reward[i] = shaped_reward<F>(a.shaper, o);
-    if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
+    if (done) done[i] = done_at(a, i, t);
     if (log) store_log<F>(log + i, N, o, s.status);
     if (obs) {
         if (a.obs_state_only) {                 // the window columns of this row were prefetched (obs_windows_k_kernel)
@@ -538,8 +538,8 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
     const int32_t K_launch = K;          // what the host asked for (the counter always moves by this much)
     t0 = resolve_t(a, t0);
     K = resolve_k(a, t0, K);
-    const int64_t i = (int64_t)blockIdx.x * gpb + threadIdx.x;
-    if ((int32_t)threadIdx.x >= gpb || i >= a.N) return;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * gpb + threadIdx.x;
+    if ((int32_t)threadIdx.x >= gpb || i >= a.g1) return;
     const int64_t N = a.N;
     Params p; State s; Derived d;
     load_state<F>(a.c, i, out.log != nullptr, s);
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
     const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
     const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
     const bool gen_instant = genset_wave_is_instant<F>(p, s);
-    const int32_t k_done = a.final_step - 1 - t0;
+    const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
     // PER_STEP = false (one fixed list per grid: RuleBasedControl): `word` is loop-invariant and the list decoding of
     // populate_core is hoisted out of the step loop by the compiler
     uint32_t word = PER_STEP ? 0u : pl_select(tab, ids[i]);
@@ -672,8 +672,8 @@ __global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const 
                                                            double *__restrict__ log)
 {
     t = resolve_t(a, t);
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.N) return;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.g1) return;
     const int64_t N = a.N;
     Params p; State s; Inputs in; Outputs o; Derived d;
     if (a.act_f32) load_controls_multi<F>(a, (const float *)actions, i, t, in);
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const 
     step_multi_core<F>(p, d, s, in, normalized != 0, load, a.n_load, pv, a.n_pv, o);
     store_state<F>(a.c, i, s);
     reward[i] = shaped_reward<F>(a.shaper, o);
-    if (done) done[i] = (uint8_t)(t >= a.final_step - 1);
+    if (done) done[i] = done_at(a, i, t);
     if (log) store_log<F>(log + i, N, o, s.status);
     if (obs) {
         if (a.obs_f32) observe_row_multi<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
@@ -700,8 +700,8 @@ template <int F>
 __global__ __launch_bounds__(BLOCK) void observe_multi_kernel(const KArgs a, int32_t t, void *__restrict__ obs)
 {
     t = resolve_t_obs(a, t);
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.N) return;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.g1) return;
     Params p; State s;
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
@@ -715,8 +715,8 @@ __global__ __launch_bounds__(BLOCK) void expand_multi_kernel(const KArgs a, cons
 {
     t = resolve_t(a, t);
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.N) return;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.g1) return;
     const int64_t N = a.N;
     Params p; State s; Inputs in;
     load_state<F>(a.c, i, false, s);
@@ -791,6 +791,128 @@ __global__ __launch_bounds__(BLOCK) void colsum_stage2(const double *__restrict_
     if (threadIdx.x == 0) sums[m] = r;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Per-grid episode windows (mgx_reset_windows).  Every reference Microgrid owns its step counter and draws its own
+// trajectory at reset (microgrid.py:205-225, base_module.py:65-77,292-296, trajectory/stochastic.py:15-30).  The batch
+// keeps ONE counter: at reset the rows [start_i, start_i + R) of every grid's series are gathered into window buffers
+// [R, N] that the step kernels then walk from row 0 -- coalesced, like the full series.  Rows beyond the end of the
+// series receive the forecaster's padding value (lo + hi) / 2 (forecaster.py:95,120-137), so the observation kernels
+// need no per-grid series length.  One lane per grid: its reads are one line per row (once per episode), the writes
+// are coalesced.
+// ------------------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const double *load_ts, *pv_ts, *grid_ts;
+    const double *load_lo, *load_hi, *pv_lo, *pv_hi, *grid_lo, *grid_hi;
+    double *load_w, *pv_w, *grid_w;
+    const int32_t *start, *length;
+    int32_t *final_rel;
+    int32_t N, T, rows, max_length, lo, hi;
+};
+
+__global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs g)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= g.N) return;
+    const int64_t N = g.N;
+    int32_t s = g.start[i];
+    s = s < g.lo ? g.lo : (s > g.hi - 1 ? g.hi - 1 : s);            // a start outside the env's window is clamped into it
+    int32_t len = g.length ? g.length[i] : g.max_length;
+    const int32_t room = g.hi - s;
+    len = len < 1 ? 1 : len;
+    len = len > g.max_length ? g.max_length : len;
+    len = len > room ? room : len;                                     // the episode ends at the env's final step at the latest
+    if (g.final_rel) g.final_rel[i] = len;
+    const double fl = (g.load_lo && g.load_hi) ? (g.load_hi[i] + g.load_lo[i]) / 2 : 0.0;
+    const double fp = (g.pv_lo && g.pv_hi) ? (g.pv_hi[i] + g.pv_lo[i]) / 2 : 0.0;
+    double fg[4] = {0.0, 0.0, 0.0, 0.0};
+    if (g.grid_ts && g.grid_lo && g.grid_hi) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) fg[c] = (g.grid_hi[c * N + i] + g.grid_lo[c * N + i]) / 2;
+    }
+    for (int32_t r = 0; r < g.rows; r++) {
+        const int64_t row = (int64_t)s + r;
+        const bool in = row < g.T;
+        const int64_t src = (in ? row : (int64_t)g.T - 1) * N + i;
+        const double vl = g.load_ts[src], vp = g.pv_ts[src];
+        g.load_w[(int64_t)r * N + i] = in ? vl : fl;
+        g.pv_w[(int64_t)r * N + i] = in ? vp : fp;
+        if (g.grid_ts) {
+            const int64_t sg = (in ? row : (int64_t)g.T - 1) * 4 * N + i;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const double v = g.grid_ts[sg + c * N];
+                g.grid_w[((int64_t)r * 4 + c) * N + i] = in ? v : fg[c];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Series synthesis (mgx_synthesize_series): MicrogridGenerator's time series for N grids, written at HBM speed.
+//   load / pv     base profile x ratio, ratio = size / max(profile)      (_scale_ts 'max', MicrogridGenerator.py:137-147)
+//   import price  tariff pattern 1 / 2 by hour of day                    (_get_electricity_tariff, :253-285)
+//   co2           base co2 profile, verbatim                             (_get_co2_ts, :205-212)
+//   grid status   weak-grid outages: 0 where a uniform draw of rows t .. t+duration-1 falls below outage_per_day / 24;
+//                 the back-fill never reaches row 0                      (_generate_weak_grid_profile, :321-340)
+// One lane per grid walks the rows from the last to the first (the outage back-fill looks forward in time); every row
+// of every output is one coalesced store per wave.  Uniforms: Philox4x32-10 keyed by the seed, counter = (GLOBAL grid
+// index, row), so a shard's draw does not depend on how the batch is split over ranks.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double synth_uniform(uint64_t seed, int64_t grid, int32_t row)
+{
+    uint32_t r[4];
+    philox4x32_10((uint32_t)grid, (uint32_t)((uint64_t)grid >> 32), (uint32_t)row, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return (double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) * (1.0 / 9007199254740992.0);      // 53 bits, [0, 1)
+}
+
+// MicrogridGenerator._get_electricity_tariff (:253-285)
+__device__ __forceinline__ double tariff_price(int32_t pattern, int32_t row)
+{
+    const int32_t h = row % 24;
+    if (pattern == 1) return (h >= 12 && h < 18) ? 0.59 : ((h < 8 || h >= 21) ? 0.22 : 0.29);
+    if (pattern == 2) return ((h >= 0 && h < 5) || (h >= 14 && h < 17)) ? 0.08 : 0.11;
+    return 0.0;
+}
+
+__global__ __launch_bounds__(BLOCK) void synthesize_series_kernel(const mgx_synth a)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.n_grids) return;
+    const int64_t N = a.n_grids;
+    const int32_t T = a.n_steps;
+    const int32_t lp = a.load_profile[i], pp = a.pv_profile[i];
+    const double lr = a.load_ratio[i], pr = a.pv_ratio[i];
+    const bool grid = a.grid_ts != nullptr;
+    int32_t cp = 0, pat = 0, dur = 1;
+    double prob = 0.0;
+    if (grid) {
+        cp = a.co2_profile[i]; pat = a.tariff[i];
+        prob = a.outage_per_day ? a.outage_per_day[i] / 24 : 0.0;           // weak_grid_timeseries[i] < outage_per_day/24 (:332)
+        dur = a.outage_duration ? a.outage_duration[i] : 1;
+    }
+    const bool weak = grid && a.outage_per_day != nullptr && a.weak[i] != 0;
+    // rows still covered by an outage that starts later: the extra draw of row T (the reference draws T + 1 values) first
+    int32_t cover = 0;
+    if (weak && synth_uniform(a.seed, a.grid_index0 + i, T) < prob) cover = dur - 1;
+    for (int32_t t = T - 1; t >= 0; t--) {
+        a.load_ts[(int64_t)t * N + i] = -1.0 * fabs(a.base_load[(int64_t)t * a.n_load_profiles + lp] * lr);   // stored sign
+        a.pv_ts[(int64_t)t * N + i] = fabs(a.base_pv[(int64_t)t * a.n_pv_profiles + pp] * pr);
+        if (grid) {
+            double status = 1.0;
+            if (weak) {
+                const bool own = synth_uniform(a.seed, a.grid_index0 + i, t) < prob;
+                status = (own || (cover > 0 && t > 0)) ? 0.0 : 1.0;             // "if i-j > 0": the back-fill spares row 0
+                cover = own ? dur - 1 : (cover > 0 ? cover - 1 : 0);
+            }
+            double *g = a.grid_ts + (int64_t)t * 4 * N + i;
+            g[0] = tariff_price(pat, t);
+            g[N] = 0.0;                                                       // price_export = zeros (:264)
+            g[2 * N] = a.base_co2[(int64_t)t * a.n_co2_profiles + cp];
+            g[3 * N] = status;
+        }
+    }
+}
+
 }  // namespace mgx
 
 // ======================================================================================================
@@ -802,6 +924,8 @@ __global__ __launch_bounds__(BLOCK) void colsum_stage2(const double *__restrict_
 #include <new>
 
 using namespace mgx;
+
+#define MGX_MAX_SHARDS 8
 
 struct mgx_handle {
     KArgs k;
@@ -815,6 +939,18 @@ struct mgx_handle {
     int32_t action_dim;
     int device;
     double *scratch;        // [64 * MAX_PARTIAL] column-sum partials
+    // shards (mgx_set_shards): stepping launches are split into n_shards contiguous grid ranges, one internal stream each
+    int32_t n_shards;                        // 1 = off
+    int32_t shard_lo[MGX_MAX_SHARDS + 1];    // range j = [shard_lo[j], shard_lo[j + 1])
+    hipStream_t shard_stream[MGX_MAX_SHARDS];
+    hipEvent_t shard_event[MGX_MAX_SHARDS];
+    hipEvent_t fork_event;
+    hipStream_t counter_stream;              // device-counter mode: the stream of the last call that touched the counter
+    // per-grid episode windows (mgx_reset_windows): the full series are remembered here while the handle steps over the
+    // caller's window buffers
+    bool windowed;
+    const double *full_load_ts, *full_pv_ts, *full_grid_ts;
+    int32_t full_T, full_final, full_initial, full_window_lo, full_window_hi;
 };
 
 namespace {
@@ -853,8 +989,20 @@ inline int32_t t_arg(const mgx_handle *h) { return h->k.t_dev ? 0 : h->t; }
 inline bool dev_counter(const mgx_handle *h) { return h->k.t_dev != nullptr; }
 inline void advance(mgx_handle *h, int32_t k, hipStream_t st)
 {
-    (void)st;                    // device-counter mode: the stepping kernel itself advanced the counter
+    h->counter_stream = st;      // device-counter mode: the stepping kernel itself advanced the counter (on this stream)
     h->t += k;
+}
+
+// One stepping call = one launch per shard.  fn(kargs with [g0, g1) set, stream of that shard).
+template <class Fn>
+inline void for_each_shard(const mgx_handle *h, hipStream_t user, Fn fn)
+{
+    KArgs k = h->k;
+    if (h->n_shards <= 1) { k.g0 = 0; k.g1 = k.N; fn(k, user); return; }
+    for (int j = 0; j < h->n_shards; j++) {
+        k.g0 = h->shard_lo[j]; k.g1 = h->shard_lo[j + 1];
+        if (k.g1 > k.g0) fn(k, h->shard_stream[j]);
+    }
 }
 
 // dispatch a kernel template on the runtime layout flags
@@ -879,9 +1027,8 @@ inline void advance(mgx_handle *h, int32_t k, hipStream_t st)
 // 131 072 grids = exactly two per CU: 0.64).  Pick the multiple of 16 grids (one 128-byte line of doubles, so every
 // workgroup's rows stay line-aligned) in [192, 256] that minimises  ceil(workgroups / CUs) * grids_per_workgroup
 // (smaller workgroups measured slower at equal cost: more, emptier waves).
-static int32_t fused_grids_per_block(const mgx_handle *h)
+static int32_t fused_grids_per_block(const mgx_handle *h, int64_t N)
 {
-    const int64_t N = h->k.N;
     const int cus = h->n_cu > 0 ? h->n_cu : 256;
     int32_t best = BLOCK_K;
     int64_t best_cost = -1;
@@ -1003,6 +1150,11 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->k.shaper = MGX_SHAPER_NONE;
     h->k.noise_seed = 0; h->k.noise_increase = 0; h->k.obs_f32 = 0; h->k.obs_state_only = 0; h->k.act_f32 = 0;
     h->window_lo = L->initial_step; h->window_hi = final_step;
+    h->k.g0 = 0; h->k.g1 = L->n_grids; h->k.grid_final = nullptr;
+    h->n_shards = 1; h->shard_lo[0] = 0; h->shard_lo[1] = L->n_grids;
+    for (int j = 0; j < MGX_MAX_SHARDS; j++) { h->shard_stream[j] = nullptr; h->shard_event[j] = nullptr; }
+    h->fork_event = nullptr; h->counter_stream = nullptr;
+    h->windowed = false;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
         return hip_fail(e, "hipMalloc(scratch)");
@@ -1020,6 +1172,11 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
 void mgx_destroy(mgx_handle *h)
 {
     if (!h) return;
+    for (int j = 0; j < MGX_MAX_SHARDS; j++) {
+        if (h->shard_stream[j]) { (void)hipStreamSynchronize(h->shard_stream[j]); (void)hipStreamDestroy(h->shard_stream[j]); }
+        if (h->shard_event[j]) (void)hipEventDestroy(h->shard_event[j]);
+    }
+    if (h->fork_event) (void)hipEventDestroy(h->fork_event);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->d_counter) (void)hipFree(h->d_counter);
     delete h;
@@ -1033,6 +1190,9 @@ int32_t mgx_current_step(const mgx_handle *h)
     if (!h) return -1;
     if (h->k.t_dev) {                    // device-counter mode: the truth lives on the device (blocking read)
         int32_t c[2] = {0, 0};
+        // the stream of the last call that touched the counter may be a non-blocking side stream (torch streams are):
+        // the null-stream copy below would not wait for it
+        if (hipStreamSynchronize(h->counter_stream) != hipSuccess) return -1;
         if (hipMemcpy(c, h->d_counter, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         return c[0];
     }
@@ -1044,6 +1204,9 @@ int mgx_use_device_counter(mgx_handle *h, int enable, mgx_stream stream)
     g_err[0] = 0;
     if (!h) return fail(MGX_ERR_INVALID, "mgx_use_device_counter: NULL handle");
     hipStream_t st = (hipStream_t)stream;
+    if (enable && h->n_shards > 1)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_use_device_counter: not offered while the handle steps in shards (mgx_set_shards)");
+    h->counter_stream = st;
     if (enable) {
         set_counter_kernel<<<1, 1, 0, st>>>(h->d_counter, h->t);
         h->k.t_dev = h->d_counter;
@@ -1197,42 +1360,192 @@ int mgx_set_forecast_noise(mgx_handle *h, uint64_t seed, int increase_uncertaint
     return MGX_OK;
 }
 
+// back to the full series after a per-grid-window episode
+static void leave_windows(mgx_handle *h)
+{
+    if (!h->windowed) return;
+    h->k.c.load_ts = h->full_load_ts; h->k.c.pv_ts = h->full_pv_ts; h->k.c.grid_ts = h->full_grid_ts;
+    h->k.T = h->full_T; h->k.final_step = h->full_final; h->k.grid_final = nullptr;
+    h->layout.n_steps = h->full_T; h->layout.final_step = h->full_final; h->layout.initial_step = h->full_initial;
+    h->window_lo = h->full_window_lo; h->window_hi = h->full_window_hi;
+    h->windowed = false;
+}
+
 int mgx_reset(mgx_handle *h, int32_t initial_step, void *obs, mgx_stream stream)
 {
     g_err[0] = 0;
     if (!h) return fail(MGX_ERR_INVALID, "mgx_reset: NULL handle");
+    leave_windows(h);
     const int32_t t0 = initial_step >= 0 ? initial_step : h->layout.initial_step;
     if (t0 >= h->layout.final_step)
         return fail(MGX_ERR_INVALID, "mgx_reset: initial_step %d must be below final_step %d", t0, h->layout.final_step);
     h->t = t0;                       // base_module.py:292-296 -- nothing else is restored
-    if (h->k.t_dev) set_counter_kernel<<<1, 1, 0, (hipStream_t)stream>>>(h->d_counter, t0);
+    if (h->k.t_dev) { set_counter_kernel<<<1, 1, 0, (hipStream_t)stream>>>(h->d_counter, t0); h->counter_stream = (hipStream_t)stream; }
     return obs ? mgx_observe(h, obs, stream) : MGX_OK;
 }
 
-int mgx_step(mgx_handle *h, const void *actions, int normalized, double *reward, uint8_t *done, void *obs,
-             double *log, mgx_stream stream)
+int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length, double *load_w,
+                      double *pv_w, double *grid_w, int32_t *final_rel, void *obs, mgx_stream stream)
 {
     g_err[0] = 0;
-    if (!h || !reward || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_step: NULL argument");
-    if (!dev_counter(h) && (h->t < 0 || h->t >= h->k.T))
-        return fail(MGX_ERR_RANGE, "mgx_step: step %d is outside the time series (length %d)", h->t, h->k.T);
-    if (obs) { if (int rc = need_obs_bounds(h, "mgx_step")) return rc; }
+    if (!h || !start || !load_w || !pv_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows: NULL argument");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: needs exactly one load and one renewable module per grid");
+    if (h->layout.has_grid && !grid_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows: grid_w is NULL but the layout has a GridModule");
+    if (length && !final_rel) return fail(MGX_ERR_INVALID, "mgx_reset_windows: per-grid lengths need the final_rel buffer");
+    if (h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: not offered in device-counter mode");
+    if (h->n_shards > 1) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: not offered while the handle steps in shards");
+    if (!h->windowed) {
+        h->full_load_ts = h->k.c.load_ts; h->full_pv_ts = h->k.c.pv_ts; h->full_grid_ts = h->k.c.grid_ts;
+        h->full_T = h->k.T; h->full_final = h->layout.final_step; h->full_initial = h->layout.initial_step;
+        h->full_window_lo = h->window_lo; h->full_window_hi = h->window_hi;
+    }
+    if (max_length < 1 || max_length > h->full_window_hi - h->full_window_lo)
+        return fail(MGX_ERR_INVALID, "Cannot create a trajectory of length %d between initial_step (%d) and final_step (%d)",
+                    max_length, h->full_window_lo, h->full_window_hi);
+    const int32_t rows = max_length + h->k.H + 1;
     hipStream_t st = (hipStream_t)stream;
+    GatherArgs g;
+    g.load_ts = h->full_load_ts; g.pv_ts = h->full_pv_ts; g.grid_ts = h->layout.has_grid ? h->full_grid_ts : nullptr;
+    g.load_lo = h->k.c.load_lo; g.load_hi = h->k.c.load_hi; g.pv_lo = h->k.c.pv_lo; g.pv_hi = h->k.c.pv_hi;
+    g.grid_lo = h->k.c.grid_lo; g.grid_hi = h->k.c.grid_hi;
+    g.load_w = load_w; g.pv_w = pv_w; g.grid_w = grid_w;
+    g.start = start; g.length = length; g.final_rel = final_rel;
+    g.N = h->k.N; g.T = h->full_T; g.rows = rows; g.max_length = max_length;
+    g.lo = h->full_window_lo; g.hi = h->full_window_hi;
+    gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gather_windows_kernel launch");
+    h->k.c.load_ts = load_w; h->k.c.pv_ts = pv_w; if (h->layout.has_grid) h->k.c.grid_ts = grid_w;
+    h->k.T = rows; h->k.final_step = max_length; h->k.grid_final = length ? final_rel : nullptr;
+    h->layout.n_steps = rows; h->layout.final_step = max_length; h->layout.initial_step = 0;
+    h->window_lo = 0; h->window_hi = max_length;
+    h->windowed = true;
+    h->t = 0;
+    return obs ? mgx_observe(h, obs, stream) : MGX_OK;
+}
+
+// ---- shards -------------------------------------------------------------------------------------------------
+int mgx_set_shards(mgx_handle *h, int32_t n_shards)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_shards: NULL handle");
+    if (n_shards < 1 || n_shards > MGX_MAX_SHARDS) return fail(MGX_ERR_INVALID, "mgx_set_shards: n_shards must be in [1, %d]", MGX_MAX_SHARDS);
+    if (n_shards > 1 && h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_set_shards: not offered in device-counter mode");
+    if (n_shards > 1 && h->windowed) return fail(MGX_ERR_UNSUPPORTED, "mgx_set_shards: not offered during a per-grid-window episode");
+    for (int j = 0; j < h->n_shards && h->n_shards > 1; j++)          // work still queued on the old shard streams
+        if (h->shard_stream[j]) (void)hipStreamSynchronize(h->shard_stream[j]);
+    hipError_t e = hipSuccess;
+    if (n_shards > 1) {
+        if (!h->fork_event) e = hipEventCreateWithFlags(&h->fork_event, hipEventDisableTiming);
+        for (int j = 0; j < n_shards && e == hipSuccess; j++) {
+            if (!h->shard_stream[j]) e = hipStreamCreateWithFlags(&h->shard_stream[j], hipStreamNonBlocking);
+            if (e == hipSuccess && !h->shard_event[j]) e = hipEventCreateWithFlags(&h->shard_event[j], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return hip_fail(e, "mgx_set_shards: creating streams / events");
+    }
+    // contiguous ranges whose bounds are multiples of 256 grids (rows of every stream stay line-aligned per shard)
+    const int64_t N = h->k.N;
+    int64_t per = ((N + n_shards - 1) / n_shards + 255) / 256 * 256;
+    for (int j = 0; j <= n_shards; j++) { const int64_t b = (int64_t)j * per; h->shard_lo[j] = (int32_t)(b < N ? b : N); }
+    h->shard_lo[n_shards] = (int32_t)N;
+    h->n_shards = n_shards;
+    return MGX_OK;
+}
+
+int mgx_fork(mgx_handle *h, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_fork: NULL handle");
+    if (h->n_shards <= 1) return MGX_OK;
+    hipError_t e = hipEventRecord(h->fork_event, (hipStream_t)stream);
+    for (int j = 0; j < h->n_shards && e == hipSuccess; j++) e = hipStreamWaitEvent(h->shard_stream[j], h->fork_event, 0);
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "mgx_fork");
+}
+
+int mgx_join(mgx_handle *h, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_join: NULL handle");
+    if (h->n_shards <= 1) return MGX_OK;
+    hipError_t e = hipSuccess;
+    for (int j = 0; j < h->n_shards && e == hipSuccess; j++) {
+        e = hipEventRecord(h->shard_event[j], h->shard_stream[j]);
+        if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, h->shard_event[j], 0);
+    }
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "mgx_join");
+}
+
+void *mgx_shard_stream(mgx_handle *h, int32_t shard)
+{
+    if (!h || shard < 0 || shard >= h->n_shards || h->n_shards <= 1) return nullptr;
+    return (void *)h->shard_stream[shard];
+}
+
+// ---- single steps ----------------------------------------------------------------------------------------------
+// one Microgrid.run of every grid: the launches of mgx_step without its argument checks
+static int step_once(mgx_handle *h, const void *actions, int normalized, double *reward, uint8_t *done, void *obs, double *log,
+                     hipStream_t st)
+{
     if (h->multi) {
-        MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, t_arg(h), normalized,
-                                                                                              reward, done, obs, log)));
+        for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+            MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, actions, t_arg(h), normalized,
+                                                                                                 reward, done, obs, log)));
+        });
         hipError_t em = hipGetLastError();
         if (em != hipSuccess) return hip_fail(em, "step_multi_kernel launch");
         advance(h, 1, st);
         return MGX_OK;
     }
     void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
-    MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, actions, t_arg(h), normalized, reward,
-                                                                                    done, obs_inline, log)));
-    if (obs && h->k.H > 0 && !h->k.obs_state_only) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
+    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+        MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, actions, t_arg(h), normalized, reward,
+                                                                                       done, obs_inline, log)));
+    });
+    if (obs && !obs_inline) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_kernel launch");
     advance(h, 1, st);
+    return MGX_OK;
+}
+
+static int check_step_args(const mgx_handle *h, const void *actions, const double *reward, const void *obs, int32_t K, const char *who)
+{
+    if (!h || !reward || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "%s: NULL argument", who);
+    if (K <= 0) return fail(MGX_ERR_INVALID, "%s: K must be positive", who);
+    if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > h->k.T))
+        return K == 1 ? fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, h->k.T)
+                      : fail(MGX_ERR_RANGE, "%s: steps [%d, %d) leave the time series (length %d)", who, h->t, h->t + K, h->k.T);
+    if (obs) {
+        if (int rc = need_obs_bounds(h, who)) return rc;
+        if (h->n_shards > 1 && !h->multi && h->k.H > 0 && !h->k.obs_state_only)
+            return fail(MGX_ERR_UNSUPPORTED, "%s: observation rows with a forecast horizon are not written per shard; "
+                                             "mgx_join, mgx_observe on your stream, mgx_fork", who);
+    }
+    return MGX_OK;
+}
+
+int mgx_step(mgx_handle *h, const void *actions, int normalized, double *reward, uint8_t *done, void *obs,
+             double *log, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (int rc = check_step_args(h, actions, reward, obs, 1, "mgx_step")) return rc;
+    return step_once(h, actions, normalized, reward, done, obs, log, (hipStream_t)stream);
+}
+
+int mgx_step_many(mgx_handle *h, const void *actions, int32_t K, int normalized, double *reward, uint8_t *done, void *obs,
+                  double *log, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (int rc = check_step_args(h, actions, reward, obs, K, "mgx_step_many")) return rc;
+    const int64_t N = h->k.N;
+    const size_t act_row = (size_t)N * h->action_dim * (h->k.act_f32 ? sizeof(float) : sizeof(double));
+    const size_t obs_row = (size_t)N * h->k.obs_dim * (h->k.obs_f32 ? sizeof(float) : sizeof(double));
+    for (int32_t k = 0; k < K; k++) {
+        if (int rc = step_once(h, actions ? (const char *)actions + k * act_row : nullptr, normalized, reward + k * N,
+                               done ? done + k * N : nullptr, obs ? (char *)obs + k * obs_row : nullptr,
+                               log ? log + (int64_t)k * h->k.log_dim * N : nullptr, (hipStream_t)stream))
+            return rc;
+    }
     return MGX_OK;
 }
 
@@ -1248,15 +1561,17 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
         return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
     hipStream_t st = (hipStream_t)stream;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
-    const int32_t gpb = fused_grids_per_block(h);
-    const unsigned blocks = (unsigned)((h->k.N + gpb - 1) / gpb);
-    if (h->k.act_f32) {
-        MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, float><<<blocks, BLOCK_K, 0, st>>>(
-                                      h->k, (const float *)actions, t_arg(h), K, normalized, fo, gpb)));
-    } else {
-        MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, double><<<blocks, BLOCK_K, 0, st>>>(
-                                      h->k, (const double *)actions, t_arg(h), K, normalized, fo, gpb)));
-    }
+    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+        const int32_t gpb = fused_grids_per_block(h, k.g1 - k.g0);
+        const unsigned blocks = (unsigned)((k.g1 - k.g0 + gpb - 1) / gpb);
+        if (k.act_f32) {
+            MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, float><<<blocks, BLOCK_K, 0, s>>>(
+                                          k, (const float *)actions, t_arg(h), K, normalized, fo, gpb)));
+        } else {
+            MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, double><<<blocks, BLOCK_K, 0, s>>>(
+                                          k, (const double *)actions, t_arg(h), K, normalized, fo, gpb)));
+        }
+    });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_k_kernel launch");
     advance(h, K, st);
@@ -1295,11 +1610,13 @@ int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_expand_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (h->multi) {
-        MGX_DISPATCH_F(h->flags, (expand_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, t_arg(h), control)));
-    } else {
-        MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, t_arg(h), control)));
-    }
+    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+        if (h->multi) {
+            MGX_DISPATCH_F(h->flags, (expand_multi_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control)));
+        } else {
+            MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control)));
+        }
+    });
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "expand_kernel launch");
 }
@@ -1311,16 +1628,16 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
     if (!h || !action_id || !table || !reward) return fail(MGX_ERR_INVALID, "mgx_step_discrete: NULL argument");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_discrete: needs exactly one load and one renewable module per "
                                                     "grid; use mgx_expand_discrete + mgx_step");
-    if (!dev_counter(h) && (h->t < 0 || h->t >= h->k.T))
-        return fail(MGX_ERR_RANGE, "mgx_step_discrete: step %d is outside the time series (length %d)", h->t, h->k.T);
-    if (obs) { if (int rc = need_obs_bounds(h, "mgx_step_discrete")) return rc; }
+    if (int rc = check_step_args(h, action_id, reward, obs, 1, "mgx_step_discrete")) return rc;
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_step_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
     void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
-    MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, tab, action_id, t_arg(h), control,
-                                                                                             reward, done, obs_inline, log)));
-    if (obs && h->k.H > 0 && !h->k.obs_state_only) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
+    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+        MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control,
+                                                                                                reward, done, obs_inline, log)));
+    });
+    if (obs && !obs_inline) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_discrete_kernel launch");
     advance(h, 1, st);
@@ -1342,19 +1659,75 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_rollout_discrete")) return rc;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     hipStream_t st = (hipStream_t)stream;
-    const int32_t gpb = fused_grids_per_block(h);
-    const unsigned blocks = (unsigned)((h->k.N + gpb - 1) / gpb);
-    if (per_step) {
-        MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT, true><<<blocks, BLOCK_K, 0, st>>>(
-                                      h->k, tab, action_id, t_arg(h), K, fo, gpb)));
-    } else {
-        MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT, false><<<blocks, BLOCK_K, 0, st>>>(
-                                      h->k, tab, action_id, t_arg(h), K, fo, gpb)));
-    }
+    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+        const int32_t gpb = fused_grids_per_block(h, k.g1 - k.g0);
+        const unsigned blocks = (unsigned)((k.g1 - k.g0 + gpb - 1) / gpb);
+        if (per_step) {
+            MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT, true><<<blocks, BLOCK_K, 0, s>>>(
+                                          k, tab, action_id, t_arg(h), K, fo, gpb)));
+        } else {
+            MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT, false><<<blocks, BLOCK_K, 0, s>>>(
+                                          k, tab, action_id, t_arg(h), K, fo, gpb)));
+        }
+    });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rollout_kernel launch");
     advance(h, K, st);
     return MGX_OK;
+}
+
+// ---- fleets: several batches (one per layout) stepped by ONE call ---------------------------------------------------
+int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!items || n <= 0) return fail(MGX_ERR_INVALID, "mgx_fleet_step: no items");
+    for (int32_t j = 0; j < n; j++) {                       // all checks first: a fleet step is all or nothing
+        const mgx_fleet_item &it = items[j];
+        if (it.struct_size != (int32_t)sizeof(mgx_fleet_item))
+            return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d struct_size %d vs %zu", j, it.struct_size, sizeof(mgx_fleet_item));
+        if (!it.handle) return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d has no handle", j);
+        if (it.action_id) {
+            if (!it.table || !it.reward) return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d: NULL table / reward", j);
+        } else if (int rc = check_step_args(it.handle, it.actions, it.reward, it.obs, 1, "mgx_fleet_step")) return rc;
+        if (it.refill_ring && it.refill_K < 1) return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d: refill_K < 1", j);
+    }
+    for (int32_t j = 0; j < n; j++) {
+        const mgx_fleet_item &it = items[j];
+        int rc;
+        if (it.action_id)
+            rc = mgx_step_discrete(it.handle, it.action_id, it.table, it.n_actions, nullptr, it.reward, it.done, it.obs, it.log, stream);
+        else
+            rc = step_once(it.handle, it.actions, normalized, it.reward, it.done, it.obs, it.log, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    for (int32_t j = 0; j < n; j++)                         // window prefetch of the buckets whose ring is used up
+        if (items[j].refill_ring)
+            if (int rc = mgx_observe_windows(items[j].handle, items[j].refill_K, items[j].refill_ring, stream)) return rc;
+    return MGX_OK;
+}
+
+
+int mgx_synthesize_series(const mgx_synth *a, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!a) return fail(MGX_ERR_INVALID, "mgx_synthesize_series: NULL argument");
+    if (a->struct_size != (int32_t)sizeof(mgx_synth))
+        return fail(MGX_ERR_INVALID, "mgx_synthesize_series: struct_size %d vs %zu (ABI %d)", a->struct_size, sizeof(mgx_synth), MGX_ABI_VERSION);
+    if (a->n_grids <= 0 || a->n_steps <= 0 || a->n_load_profiles <= 0 || a->n_pv_profiles <= 0)
+        return fail(MGX_ERR_INVALID, "mgx_synthesize_series: need n_grids, n_steps, n_load_profiles, n_pv_profiles > 0");
+    if (!a->base_load || !a->base_pv || !a->load_profile || !a->pv_profile || !a->load_ratio || !a->pv_ratio || !a->load_ts || !a->pv_ts)
+        return fail(MGX_ERR_INVALID, "mgx_synthesize_series: NULL load / pv argument");
+    if (a->grid_ts && (!a->base_co2 || !a->co2_profile || !a->tariff || a->n_co2_profiles <= 0))
+        return fail(MGX_ERR_INVALID, "mgx_synthesize_series: grid_ts requested without base_co2 / co2_profile / tariff");
+    if (a->grid_ts && a->outage_per_day && (!a->weak || !a->outage_duration))
+        return fail(MGX_ERR_INVALID, "mgx_synthesize_series: outage_per_day given without weak / outage_duration");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(MGX_ERR_DEVICE, "mgx_synthesize_series: no HIP device available -- this engine has no CPU path");
+    synthesize_series_kernel<<<blocks_for(a->n_grids), BLOCK, 0, (hipStream_t)stream>>>(*a);
+    e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "synthesize_series_kernel launch");
 }
 
 int mgx_metrics(mgx_handle *h, const double *values, int32_t M, double *sums, mgx_stream stream)

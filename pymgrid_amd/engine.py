@@ -41,6 +41,9 @@ class StepEngine:
             L, cols = batch.c_layout(), batch.c_columns()
             check(self._lib.mgx_create(C.byref(L), C.byref(cols), C.byref(self._h)))
         self.window = (self.layout.initial_step, self.layout.final_step)
+        self._full_window = self.window
+        self._window_start = None
+        self.n_shards = 1
         if batch.forecast_noise is not None:
             self.set_forecast_noise(**batch.forecast_noise)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -153,6 +156,7 @@ class StepEngine:
         """Episode window of the next reset (what a trajectory_func returns, microgrid.py:221-225)."""
         check(self._lib.mgx_set_window(self._h, int(initial_step), int(final_step)))
         self.window = (int(initial_step), int(final_step))
+        self._full_window = self.window
 
     def set_forecast_noise(self, seed=0, increase_uncertainty=False):
         """GaussianNoiseForecaster switches (needs the *_noise_std columns in the batch)."""
@@ -165,7 +169,74 @@ class StepEngine:
     def reset(self, initial_step=None, want_obs=True, out=None):
         obs = self._obs_buf(out) if want_obs else None
         self._call(self._lib.mgx_reset, -1 if initial_step is None else int(initial_step), _ptr(obs))
+        if getattr(self, "_window_start", None) is not None:       # a per-grid-window episode ends with a plain reset
+            self._window_start = None
+            self.window = self._full_window
         return obs
+
+    def reset_windows(self, start, length=None, max_length=None, want_obs=True, out=None):
+        """Per-grid episodes (``mgx_reset_windows``): grid i starts at series row ``start[i]`` and reports ``done`` after
+        ``length[i]`` steps (``length=None``: ``max_length`` for every grid).  ``start`` / ``length`` are int32 device
+        tensors [N].  The window buffers live in the engine and are re-used by the next reset of the same shape."""
+        L = self.layout
+        if start.dtype != torch.int32 or tuple(start.shape) != (self.N,) or start.device != self.device:
+            raise ValueError(f"start must be an int32 tensor of shape ({self.N},) on {self.device}")
+        if length is not None:
+            if length.dtype != torch.int32 or tuple(length.shape) != (self.N,) or length.device != self.device:
+                raise ValueError(f"length must be an int32 tensor of shape ({self.N},) on {self.device}")
+            if max_length is None:
+                max_length = int(length.max().item())
+        if max_length is None:
+            raise ValueError("max_length is required when length is None")
+        rows = int(max_length) + L.horizon + 1
+        w = getattr(self, "_windows", None)
+        if w is None or w["rows"] != rows:
+            w = dict(rows=rows, load=self._empty(rows, self.N), pv=self._empty(rows, self.N),
+                     grid=self._empty(rows, 4, self.N) if L.has_grid else None,
+                     final=self._empty(self.N, dtype=torch.int32))
+            self._windows = w
+        obs = self._obs_buf(out) if want_obs else None
+        self._call(self._lib.mgx_reset_windows, start.data_ptr(), _ptr(length), int(max_length), w["load"].data_ptr(),
+                   w["pv"].data_ptr(), _ptr(w["grid"]), w["final"].data_ptr() if length is not None else None, _ptr(obs))
+        self._window_start = start
+        self.window = (0, int(max_length))
+        return obs
+
+    def set_shards(self, n_shards):
+        """Step in ``n_shards`` independent grid ranges, one internal HIP stream each (``mgx_set_shards``).  While
+        n_shards > 1 the stepping calls ignore torch's current stream: bracket them with ``fork()`` / ``join()``."""
+        check(self._lib.mgx_set_shards(self._h, int(n_shards)))
+        self.n_shards = int(n_shards)
+
+    def fork(self):
+        """The shard streams wait for everything queued on torch's current stream (inputs produced there)."""
+        self._call(self._lib.mgx_fork)
+
+    def join(self):
+        """Torch's current stream waits for everything issued to the shard streams (outputs are then safe to read)."""
+        self._call(self._lib.mgx_join)
+
+    def shard_streams(self):
+        """``torch.cuda.ExternalStream`` views of the internal shard streams (for timing events)."""
+        n = getattr(self, "n_shards", 1)
+        if n <= 1:
+            return []
+        return [torch.cuda.ExternalStream(self._lib.mgx_shard_stream(self._h, j), device=self.device) for j in range(n)]
+
+    def step_many(self, actions, normalized=True, want_obs=False, want_log=False, done=True, out=None):
+        """K single-step launches issued by one call (``mgx_step_many``): actions [K, N, A] -> reward [K, N], done [K, N],
+        optionally obs [K, N, D] and log [K, L, N]."""
+        K = int(actions.shape[0])
+        actions = self._check_actions(actions, (K,))
+        out = out or {}
+        reward = out.get("reward") if out.get("reward") is not None else self._empty(K, self.N)
+        d = (out.get("done") if out.get("done") is not None else self._empty(K, self.N, dtype=torch.uint8)) if done else None
+        obs = (out.get("obs") if out.get("obs") is not None
+               else torch.empty((K, self.N, self.obs_dim), dtype=self.obs_dtype, device=self.device)) if want_obs else None
+        log = (out.get("log") if out.get("log") is not None else self._empty(K, self.log_dim, self.N)) if want_log else None
+        self._call(self._lib.mgx_step_many, _ptr(actions), K, 1 if normalized else 0, reward.data_ptr(), _ptr(d), _ptr(obs),
+                   _ptr(log))
+        return obs, reward, d, log
 
     def observe(self, out=None):
         obs = self._obs_buf(out)

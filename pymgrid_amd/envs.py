@@ -131,6 +131,35 @@ class BatchedMicrogridEnv:
             return self._select_obs(self._refill())
         return self._select_obs(self.engine.reset(initial_step, want_obs=self._observations))
 
+    def reset_windows(self, start, length=None, max_length=None):
+        """Per-grid episodes (``mgx_reset_windows``; the reference's per-microgrid trajectories, microgrid.py:205-225,
+        trajectory/stochastic.py:9-30): grid i starts at series row ``start[i]`` and is ``done`` after ``length[i]`` steps
+        (``length=None``: ``max_length`` steps for every grid).  The batch still advances in lock-step; ``current_steps``
+        gives every grid's own step counter.  A plain ``reset()`` returns to the shared window."""
+        dev = self.batch.device
+
+        def as_i32(v):
+            if v is None or (torch.is_tensor(v) and v.dtype == torch.int32 and v.device == dev and v.is_contiguous()):
+                return v
+            return torch.as_tensor(np.asarray(v.cpu() if torch.is_tensor(v) else v), device=dev).to(torch.int32).contiguous()
+        start, length = as_i32(start), as_i32(length)
+        self._log_rows = []
+        self._shaped_rows = []
+        if self._ring is not None:
+            self.engine.reset_windows(start, length, max_length, want_obs=False)
+            return self._select_obs(self._refill())
+        return self._select_obs(self.engine.reset_windows(start, length, max_length, want_obs=self._observations))
+
+    @property
+    def current_steps(self):
+        """Per-grid step counters [N]: start_i + steps since the reset during a per-grid-window episode, else the shared
+        counter for every grid (BaseMicrogridModule.current_step of each microgrid)."""
+        t = self.engine.current_step
+        st = self.engine._window_start
+        if st is None:
+            return torch.full((self.n_grids,), t, dtype=torch.int32, device=self.batch.device)
+        return st + t
+
     def _refill(self):
         self.engine.observe_windows(out=self._ring)
         self._ring_pos = 0

@@ -14,6 +14,10 @@ from .envs import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv
 from .scenario import bucket_by_layout
 
 
+def L_multi(layout):
+    return layout.n_load != 1 or layout.n_pv != 1
+
+
 class BucketedFleet:
     """N microgrids of mixed layouts behind one step()/reset() surface.
 
@@ -74,9 +78,74 @@ class BucketedFleet:
         return self._each(lambda env, k: env.reset())
 
     def step(self, actions, **kw):
-        """actions: list with one tensor per bucket.  Returns (obs_list, reward_list, done_list, info_list)."""
-        res = self._each(lambda env, k: env.step(actions[k], **kw))
-        return tuple(list(x) for x in zip(*res))
+        """actions: list with one tensor per bucket.  Returns (obs_list, reward_list, done_list, info_list).
+
+        Buckets on the caller's stream go through ONE call of the C ABI (``mgx_fleet_step``): every bucket's step launch
+        and, where a bucket's observation ring is used up, its window prefetch are issued from C back to back -- three
+        Python-level ``env.step`` calls cost ~30 us, more than the kernels of a 100 000-grid fleet step take."""
+        if self.streams or any(env.raise_errors for env in self.envs) or any(isinstance(a, dict) for a in actions) \
+                or any(isinstance(env, DiscreteBatchedMicrogridEnv) and L_multi(env.layout) for env in self.envs):
+            res = self._each(lambda env, k: env.step(actions[k], **kw))
+            return tuple(list(x) for x in zip(*res))
+        return self._step_fused(actions, **kw)
+
+    def _step_fused(self, actions, normalized=True):
+        import ctypes as C
+        from . import _lib
+        from .engine import _raw_stream
+        items = getattr(self, "_items", None)
+        if items is None:
+            items = self._items = (_lib.FleetItem * len(self.envs))()
+            for it, env in zip(items, self.envs):
+                it.struct_size = C.sizeof(_lib.FleetItem)
+                it.handle = env.engine._h.value
+                if isinstance(env, DiscreteBatchedMicrogridEnv):
+                    it.table, it.n_actions = env.engine._table_ptr(env._table)
+        obs_l, reward_l, done_l, info_l, refills = [], [], [], [], []
+        for it, env, a in zip(items, self.envs, actions):
+            e = env.engine
+            discrete = isinstance(env, DiscreteBatchedMicrogridEnv)
+            if discrete:
+                if not (torch.is_tensor(a) and a.dtype == torch.int32 and a.is_contiguous() and a.device == e.device
+                        and tuple(a.shape) == (e.N,)):
+                    a = torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a), device=e.device).to(torch.int32).contiguous()
+                it.action_id = a.data_ptr()
+            else:
+                a = e._check_actions(a, ())
+                it.actions = None if a is None else a.data_ptr()
+            want_obs, out = env._obs_target()
+            reward = e._empty(e.N)
+            done = e._empty(e.N, dtype=torch.uint8)
+            obs = (out["obs"] if out else e._obs_buf(None)) if want_obs else None
+            log = e._empty(e.log_dim, e.N) if env._keep_log else None
+            refill = env._ring is not None and not want_obs
+            it.reward, it.done = reward.data_ptr(), done.data_ptr()
+            it.obs = None if obs is None else obs.data_ptr()
+            it.log = None if log is None else log.data_ptr()
+            it.refill_ring = env._ring.data_ptr() if refill else None
+            it.refill_K = env.obs_prefetch if refill else 0
+            refills.append(refill)
+            obs_l.append(obs); reward_l.append(reward); done_l.append(done.view(torch.bool)); info_l.append({} if log is None else {"log": log})
+        e0 = self.envs[0].engine
+        idx = e0._dev_index
+        if e0._only_device or torch.cuda.current_device() == idx:
+            rc = e0._lib.mgx_fleet_step(items, len(self.envs), 1 if normalized else 0, _raw_stream(idx))
+        else:
+            with torch.cuda.device(idx):
+                rc = e0._lib.mgx_fleet_step(items, len(self.envs), 1 if normalized else 0, _raw_stream(idx))
+        _lib.check(rc)
+        for k, (env, refill) in enumerate(zip(self.envs, refills)):
+            if env._ring is not None:
+                if refill:
+                    env._ring_pos = 0
+                    obs_l[k] = env._ring[0]
+                else:
+                    env._ring_pos += 1
+            obs_l[k] = env._select_obs(obs_l[k])
+            if info_l[k]:
+                env._log_rows.append(info_l[k]["log"])
+                env._shaped_rows.append(reward_l[k].clone())
+        return obs_l, reward_l, done_l, info_l
 
     def sample_action(self, generator=None):
         return [env.sample_action(generator=generator) for env in self.envs]
@@ -95,57 +164,61 @@ class BucketedFleet:
 
 
 class PerGridWindowEnv:
-    """Per-grid random episode windows (the per-microgrid ``FixedLengthStochasticTrajectory`` of the reference,
-    microgrid/trajectory/stochastic.py:15-30, for a batch): every grid gets its OWN start row, all episodes have the
-    same length, so the batch still advances in lock-step and the hot path is unchanged.
+    """Per-grid random episodes: what a population of reference microgrids does when each has its own
+    ``trajectory_func`` (microgrid.py:205-225) -- ``FixedLengthStochasticTrajectory(trajectory_length)`` per grid
+    (trajectory/stochastic.py:15-30: own start row, common length) or, with ``trajectory_length=None``,
+    ``StochasticTrajectory`` per grid (trajectory/stochastic.py:9-12: own start row AND own final step, so the grids
+    report ``done`` at different steps).
 
-    How: at ``reset()`` the rows ``[start_i, start_i + length + H]`` of every grid's series are gathered ONCE into a
-    short window buffer ``[length + H + 1, N]`` (a few MB) and the engine steps over that buffer from row 0.  The
-    observation bounds stay those of the full series, as in the reference.
+    The batch keeps one step counter: at ``reset()`` a HIP kernel (``mgx_reset_windows``) gathers every grid's rows
+    ``[start_i, start_i + max length + H]`` of the full series into window buffers the step kernels walk from row 0, and
+    ``done`` is per grid.  Observation bounds stay those of the full series, as in the reference.  Draws come from a
+    torch generator on the device (the reference draws from numpy's global stream, one microgrid at a time).
     """
 
-    def __init__(self, full_batch, trajectory_length, discrete=False, generator=None, **env_kwargs):
+    def __init__(self, full_batch, trajectory_length=None, discrete=False, generator=None, **env_kwargs):
         L = full_batch.layout
         if L.n_load != 1 or L.n_pv != 1:
             raise NotImplementedError("per-grid windows need one load and one renewable module per grid")
         self.full = full_batch
-        self.length = int(trajectory_length)
-        self.rows = self.length + L.horizon + 1
-        if self.rows > L.final_step - L.initial_step:
+        self.length = None if trajectory_length is None else int(trajectory_length)
+        if self.length is not None and L.final_step - L.initial_step < self.length:
             raise ValueError(f'Cannot create a trajectory of length {self.length}'
                              f'between initial_step ({L.initial_step}) and final_step ({L.final_step})')
         self.generator = generator
-        dev = full_batch.device
-        N = L.n_grids
-        cols = dict(full_batch.cols)                   # parameters / state / bounds are shared with the full batch
-        cols["load_ts"] = torch.empty(self.rows, N, dtype=torch.float64, device=dev)
-        cols["pv_ts"] = torch.empty(self.rows, N, dtype=torch.float64, device=dev)
-        if L.has_grid:
-            cols["grid_ts"] = torch.empty(self.rows, 4, N, dtype=torch.float64, device=dev)
-        from dataclasses import replace
-        wl = replace(L, n_steps=self.rows, initial_step=0, final_step=self.length)
-        self.window = MicrogridBatch(wl, cols, forecast_noise=full_batch.forecast_noise)
         cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
-        self.env = cls(self.window, **env_kwargs)
-        self.starts = None
-        self._k = torch.arange(self.rows, device=dev).unsqueeze(1)            # [rows, 1]
+        self.env = cls(full_batch, **env_kwargs)
+        self.starts = self.lengths = None
 
-    def draw_starts(self):
-        """initial_i ~ U{initial_step, ..., final_step - length - H - 1} (so that the forecast window of the last
-        step still lies inside the series)."""
-        L = self.full.layout
-        hi = L.final_step - self.rows + 1
-        return torch.randint(L.initial_step, hi, (L.n_grids,), device=self.full.device, generator=self.generator)
+    def draw(self):
+        """(starts, lengths): FixedLengthStochasticTrajectory / StochasticTrajectory draws, one per grid."""
+        L, dev, N = self.full.layout, self.full.device, self.full.layout.n_grids
+        lo, hi = L.initial_step, L.final_step
 
-    def reset(self, starts=None):
-        self.starts = self.draw_starts() if starts is None else torch.as_tensor(starts, device=self.full.device)
-        idx = self._k + self.starts.unsqueeze(0)                               # [rows, N] absolute rows
-        self.window.cols["load_ts"].copy_(torch.gather(self.full.cols["load_ts"], 0, idx))
-        self.window.cols["pv_ts"].copy_(torch.gather(self.full.cols["pv_ts"], 0, idx))
-        if self.full.layout.has_grid:
-            idx4 = idx.unsqueeze(1).expand(-1, 4, -1)
-            self.window.cols["grid_ts"].copy_(torch.gather(self.full.cols["grid_ts"], 0, idx4))
-        return self.env.reset()
+        def randint(low, high):              # elementwise np.random.randint(low, high): high exclusive, tensors allowed
+            u = torch.rand(N, device=dev, generator=self.generator, dtype=torch.float64)
+            span = torch.as_tensor(high, device=dev) - torch.as_tensor(low, device=dev)
+            return (torch.as_tensor(low, device=dev) + torch.clamp((u * span).floor().long(), max=span - 1)).to(torch.int32)
+        if self.length is not None:
+            if hi - self.length <= lo:       # np.random.randint(initial, final - length) needs a non-empty range
+                return torch.full((N,), lo, dtype=torch.int32, device=dev), None
+            return randint(lo, hi - self.length), None
+        starts = randint(lo, hi - 2)
+        finals = randint(starts.long(), hi)
+        lengths = torch.clamp(finals - starts, min=1).to(torch.int32)       # a zero-length draw steps once (done at once)
+        return starts, lengths
+
+    def reset(self, starts=None, lengths=None):
+        if starts is None:
+            starts, lengths = self.draw()
+        dev = self.full.device
+        self.starts = torch.as_tensor(np.asarray(starts.cpu() if torch.is_tensor(starts) else starts), device=dev).to(torch.int32)
+        self.lengths = None if lengths is None else \
+            torch.as_tensor(np.asarray(lengths.cpu() if torch.is_tensor(lengths) else lengths), device=dev).to(torch.int32)
+        max_len = self.length if self.lengths is None else int(self.lengths.max().item())
+        if max_len is None:
+            raise ValueError("lengths are required when the env was built without a trajectory_length")
+        return self.env.reset_windows(self.starts, self.lengths, max_len)
 
     def step(self, action, **kw):
         return self.env.step(action, **kw)
