@@ -2,33 +2,37 @@
 """bench.py -- microgrid env-steps/s of the batched step engine (BASELINE.json metric).
 
 Workload (BASELINE.json configs[2]): N = 100 000 generated Template-4 grids (genset + battery + load + pv) per GPU,
-T = 8760 hourly rows, synthetic data drawn with the MicrogridGenerator sizing rules (pymgrid_amd/generator.py),
-normalised U[0,1) actions.  A "step" is ONE env-step of all N grids of a rank (one pass of the hot path over the
-batch).  Everything the timed region reads (columns, series, actions) is resident in HBM before timing starts.
+T = 8760 hourly rows, series built on device from the reference's base profiles with the MicrogridGenerator sizing rules
+(pymgrid_amd/generator.py), normalised U[0,1) actions.  Everything the timed region reads (columns, series, actions) is
+resident in HBM before timing starts.
 
-Modes
-  fused (default)  K steps are issued as ceil(K / chunk) launches of the K-step kernel (mgx_step_k): parameters and
-                   state stay in registers, actions / series rows / per-step outputs (reward, done, SoC) stream.
-                   The rank's N grids are stepped as --shards (2) independent shards of N / 2 grids, each with its own
-                   engine and HIP stream and never joined between launches (pymgrid_amd.hetero.StreamShards): grids do
-                   not interact, and two launch sequences out of phase fill each other's ramp-up / tail gaps (+5..10 %).
-                   A roofline "launch" is then one ROUND = one kernel launch per shard stream (all N grids, 64 steps);
-                   its duration is a shard stream's cadence (HIP events on that stream over the region / launches).
-                   The same kernel as ONE launch sequence over all N grids is reported under "other".
-  step             one launch of the single-step kernel (mgx_step) per env-step -- the Gym cadence.
-  rbc              rule-based control rolled out on device (mgx_rollout_discrete, one fixed priority list per grid):
-                   the control is expanded in-kernel, so there is no action stream at all.
-All are timed in every run; --mode picks which one is the headline `value`; the others are reported under "other".
+A bench STEP is one fused ROUND: `--chunk` (64) consecutive env-steps of ALL grids of the rank -- one pass of the hot path
+over one [64, N, A] batch of actions, issued as one K-step kernel launch (mgx_step_k) per shard.  `--steps K --warmup W`
+therefore time exactly K rounds after W untimed ones; `value` = grids x K x chunk / wall time (env-steps/s, whole job),
+`ms_per_step` = wall time per round.
 
-Every mode is preceded by PREWARM_S = 0.1 s of its own launches (untimed set-up: code-object load and the ~15 ms the clocks
-need to settle under this load), then the W warm-up steps, then EXACTLY K timed steps between barrier + synchronize.
+Modes (all are timed in every run; --mode picks the headline `value`, the others are reported under "other")
+  fused (default)  parameters and state stay in registers for the 64 steps of a round, actions / series rows / per-step
+                   outputs (reward, done, SoC) stream.  The rank's grids are stepped as --shards (2) contiguous ranges on
+                   the engine's internal HIP streams (mgx_set_shards): ranges are not joined between rounds, so one range's
+                   launch ramp-up / tail overlaps the other's steady state.  A roofline "launch" is one round (one kernel per
+                   shard stream, all N grids); its duration is the cadence of a shard stream (HIP events on that stream over
+                   the timed region / rounds).  The same kernel as ONE launch sequence is reported under "other".
+  step             the Gym cadence: one launch of the single-step kernel per env-step, 64 of them per round issued by ONE
+                   call (mgx_step_many); the same from a Python loop around env.step is reported beside it.
+  rbc              rule-based control rolled out on device (mgx_rollout_discrete, one fixed priority list per grid).
 
-Launch:  python bench.py [--gpus N --steps K --warmup W]          (N>1: torchrun, one rank per GPU, RCCL only
-                                                                    for the final metrics all-reduce)
+Every mode is preceded by PREWARM_S seconds of its own rounds (untimed set-up: code-object load and the ~15 ms the clocks need
+to settle under this load; it runs straight into the W warm-up rounds), then EXACTLY K timed rounds between barrier + synchronize.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]      N > 1 without WORLD_SIZE in the environment: the script
+         re-launches itself under torch.distributed.run, one rank per GPU (RCCL only for the final metrics all-reduce).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,214 +42,167 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pymgrid_amd import _lib  # noqa: E402
-from pymgrid_amd import distributed as mdist  # noqa: E402
-from pymgrid_amd.engine import StepEngine  # noqa: E402
-from pymgrid_amd.generator import generate  # noqa: E402
-
-PREWARM_S = 0.1            # seconds of untimed device pre-warm before each mode's W warm-up steps (see measure())
-OUT_SETS = 4               # sets of output buffers each runner cycles through (see Runner)
+PREWARM_S = 0.3            # seconds of untimed device pre-warm before each mode's W warm-up rounds
+OUT_SETS = 4               # sets of output buffers each runner cycles through (no Infinity-Cache absorption of rewrites)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+SIDE_ROUNDS = (192, 64)    # (timed, warm-up) rounds of the modes that are not the headline
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: the GPU needs ~10-20 ms of this load before the time per launch settles (81 -> 75 us over the first ~160
-    # launches of one stream, 77 -> 67.7 us over ~250 rounds of two shards: profiles/r01/exp_time_dependence.txt), so the
-    # default warm-up is 384 launches (~27 ms) and the timed region 1024 launches (~70 ms)
-    ap.add_argument("--steps", type=int, default=65536)
-    ap.add_argument("--warmup", type=int, default=24576)
+    ap.add_argument("--steps", type=int, default=1024, help="timed ROUNDS (one round = --chunk env-steps of all grids)")
+    ap.add_argument("--warmup", type=int, default=256, help="untimed rounds before the timed ones")
     ap.add_argument("--grids", type=int, default=100_000, help="microgrids PER GPU (weak scaling)")
     ap.add_argument("--rows", type=int, default=8760, help="time-series rows T")
     ap.add_argument("--mode", choices=["fused", "step", "rbc"], default="fused")
-    ap.add_argument("--chunk", type=int, default=64, help="env-steps per fused launch")
+    ap.add_argument("--chunk", type=int, default=64, help="env-steps per round (= per fused launch)")
     ap.add_argument("--shards", type=int, default=2,
-                    help="fused mode: independent shards per GPU, one HIP stream each (1: one launch sequence over all grids)")
+                    help="grid ranges stepped on internal HIP streams (mgx_set_shards); 1: one launch sequence")
     ap.add_argument("--arch", default="genset+battery")
     ap.add_argument("--hetero-steps", type=int, default=256, help="timed Gym steps of the heterogeneous H=24 fleet (0: skip)")
+    ap.add_argument("--no-side-modes", action="store_true", help="time the headline mode only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
-    return ap.parse_args()
+    ap.add_argument("--prewarm", type=float, default=PREWARM_S)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring the N ranks up, check the process group and print {n_gpus: N} (no GPU work)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) under torch.distributed.run and relay the
+    result.  Returns the exit code, or None when this process is already a rank / a single-GPU run."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.run(cmd, env=env).returncode
 
 
 class Runner:
-    """Issues env-steps on the current stream; wraps around the series with reset() (a host counter)."""
+    """Issues rounds on one engine.  Sharded: the engine steps in S grid ranges on its internal streams."""
 
-    def __init__(self, eng, chunk, pool):
-        self.eng, self.chunk, self.pool = eng, chunk, pool          # pool: [P, chunk, N, A] actions
-        L = eng.layout
-        N = L.n_grids
-        dev = eng.device
-        # OUT_SETS sets of [chunk, N] output buffers, cycled: a launch never rewrites what the previous three wrote, so no
-        # output line can still sit in the 256 MB Infinity Cache when it is written again (re-using ONE set makes 48-step
-        # launches look 9 % faster than they are from HBM: profiles/r01/exp_chunk_outputs.txt)
-        self.out_sets = [dict(reward=torch.empty(chunk, N, dtype=torch.float64, device=dev),
-                              done=torch.empty(chunk, N, dtype=torch.uint8, device=dev),
-                              soc_trace=torch.empty(chunk, N, dtype=torch.float64, device=dev)) for _ in range(OUT_SETS)]
-        self.reward_k = self.out_sets[0]["reward"]
-        self.out1 = dict(reward=torch.empty(N, dtype=torch.float64, device=dev),
-                         done=torch.empty(N, dtype=torch.uint8, device=dev))
-        self.launches = 0
-        self.i = 0
-
-    def _room(self, k):
-        if self.eng.current_step + k > self.eng.layout.final_step:
-            self.eng.reset(want_obs=False)
-
-    def fused(self, steps):
-        done = 0
-        while done < steps:
-            k = min(self.chunk, steps - done)
-            self._room(k)
-            a = self.pool[self.i % self.pool.shape[0]]
-            o = self.out_sets[self.launches % OUT_SETS]
-            self.eng.step_k(a[:k], normalized=True, out={name: t[:k] for name, t in o.items()},
-                            reward=True, done=True, soc_trace=True)
-            self.i += 1; self.launches += 1; done += k
-
-    def rbc(self, steps):
-        done = 0
-        while done < steps:
-            k = min(self.chunk, steps - done)
-            self._room(k)
-            o = self.out_sets[self.launches % OUT_SETS]
-            self.eng.rollout_discrete(self.rbc_ids, self.rbc_table, k, reward=True, done=True, soc_trace=True,
-                                      out={name: t[:k] for name, t in o.items()})
-            self.launches += 1; done += k
-
-    def single(self, steps):
-        for s in range(steps):
-            self._room(1)
-            a = self.pool[self.i % self.pool.shape[0]][s % self.chunk]
-            self.eng.step(a, normalized=True, want_obs=False, want_log=False, out=self.out1)
-            self.launches += 1
-        self.i += 1
-
-
-class ShardRunner:
-    """The fused modes over S independent shards of the rank's grids (pymgrid_amd.hetero.StreamShards): every shard has
-    its own engine, action pool, output buffers and HIP stream; the launch sequences are not joined between launches."""
-
-    def __init__(self, shards, chunk, seed):
+    def __init__(self, eng, chunk, seed, shards):
         from pymgrid_amd.priority_list import get_priority_lists, table_array
         from pymgrid_amd.rbc import default_priority_ids
-        self.shards, self.chunk = shards, chunk
-        dev = shards.device
-        self.pools, self.outs, self.rbc_ids, self.rbc_tables = [], [], [], []
-        for j, eng in enumerate(shards.engines):
-            L, n = eng.layout, eng.N
-            gen = torch.Generator(device=dev); gen.manual_seed(seed + j)
-            self.pools.append(torch.rand(4, chunk, n, L.action_dim, dtype=torch.float64, device=dev, generator=gen))
-            self.outs.append([dict(reward=torch.empty(chunk, n, dtype=torch.float64, device=dev),
-                                   done=torch.empty(chunk, n, dtype=torch.uint8, device=dev),
-                                   soc_trace=torch.empty(chunk, n, dtype=torch.float64, device=dev)) for _ in range(OUT_SETS)])
-            lists = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, False)
-            self.rbc_tables.append(table_array(lists))
-            self.rbc_ids.append(torch.from_numpy(default_priority_ids(eng.batch, lists, remove_redundant_gensets=False)).to(dev))
-        self.launches = 0            # per stream
-        self.i = 0
+        self.eng, self.chunk, self.S = eng, chunk, shards
+        L, N, dev = eng.layout, eng.N, eng.device
+        gen = torch.Generator(device=dev); gen.manual_seed(seed)
+        self.pool = torch.rand(4, chunk, N, L.action_dim, dtype=torch.float64, device=dev, generator=gen)
+        # OUT_SETS sets of [chunk, N] output buffers, cycled: a launch never rewrites what the previous three wrote, so no
+        # output line can still sit in the 256 MB Infinity Cache when it is written again
+        self.outs = [dict(reward=torch.empty(chunk, N, dtype=torch.float64, device=dev),
+                          done=torch.empty(chunk, N, dtype=torch.uint8, device=dev),
+                          soc_trace=torch.empty(chunk, N, dtype=torch.float64, device=dev)) for _ in range(OUT_SETS)]
+        lists = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, False)
+        self.rbc_table = table_array(lists)
+        self.rbc_ids = torch.from_numpy(default_priority_ids(eng.batch, lists, remove_redundant_gensets=False)).to(dev)
+        self.rounds = 0            # rounds issued since the process started (per mode runner)
+        self.streams = []
 
-    def _room(self, k):
-        e = self.shards.engines[0]
-        if e.current_step + k > e.layout.final_step:
-            self.shards.reset()
+    def shard(self, on):
+        self.eng.set_shards(self.S if on else 1)
+        self.streams = self.eng.shard_streams() if on and self.S > 1 else []
 
-    def fused(self, steps):
-        done = 0
-        while done < steps:
-            k = min(self.chunk, steps - done)
-            self._room(k)
-            self.shards.step_k([p[self.i % 4][:k] for p in self.pools],
-                               outs=[{name: t[:k] for name, t in o[self.launches % OUT_SETS].items()} for o in self.outs],
-                               normalized=True, reward=True, done=True, soc_trace=True)
-            self.i += 1; self.launches += 1; done += k
+    def _room(self):
+        if self.eng.current_step + self.chunk > self.eng.layout.final_step:
+            self.eng.reset(want_obs=False)
 
-    def rbc(self, steps):
-        done = 0
-        while done < steps:
-            k = min(self.chunk, steps - done)
-            self._room(k)
-            self.shards.rollout_discrete(self.rbc_ids, self.rbc_tables, k,
-                                         outs=[{name: t[:k] for name, t in o[self.launches % OUT_SETS].items()} for o in self.outs],
-                                         reward=True, done=True, soc_trace=True)
-            self.launches += 1; done += k
+    def fused(self, rounds):
+        for _ in range(rounds):
+            self._room()
+            self.eng.step_k(self.pool[self.rounds % 4], normalized=True, out=self.outs[self.rounds % OUT_SETS],
+                            reward=True, done=True, soc_trace=True)
+            self.rounds += 1
 
+    def rbc(self, rounds):
+        for _ in range(rounds):
+            self._room()
+            self.eng.rollout_discrete(self.rbc_ids, self.rbc_table, self.chunk, reward=True, done=True, soc_trace=True,
+                                      out=self.outs[self.rounds % OUT_SETS])
+            self.rounds += 1
 
-def _kernel_durations_us(self, rounds):
-    """Mean start-to-end time of the shard kernels themselves (HIP events around every launch, a short extra pass after the
-    timed region): what rocprofv3 reports as the kernel's duration.  Shorter than the cadence of a round because the S
-    concurrent kernels overlap only partly."""
-    ev = []
-    self.shards.fork()
-    for _ in range(rounds):
-        k = self.chunk
-        self._room(k)
-        for j, (eng, st) in enumerate(zip(self.shards.engines, self.shards.streams)):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(st):
+    def step(self, rounds):
+        """Gym cadence: `chunk` single-step launches per round, issued by one call of the C ABI."""
+        for _ in range(rounds):
+            self._room()
+            o = self.outs[self.rounds % OUT_SETS]
+            self.eng.step_many(self.pool[self.rounds % 4], normalized=True, out=dict(reward=o["reward"], done=o["done"]))
+            self.rounds += 1
+
+    def step_python(self, rounds):
+        """The same launches from a Python loop around engine.step (what `for a in actions: env.step(a)` costs)."""
+        o = self.outs[0]
+        out1 = dict(reward=o["reward"][0], done=o["done"][0])
+        for _ in range(rounds):
+            self._room()
+            a = self.pool[self.rounds % 4]
+            for k in range(self.chunk):
+                self.eng.step(a[k], normalized=True, want_obs=False, want_log=False, out=out1)
+            self.rounds += 1
+
+    def kernel_durations_us(self, fn, rounds=16):
+        """Mean start-to-end time of the kernels of a round (HIP events around every launch on its own stream, a short
+        extra pass after the timed region): what rocprofv3 reports as the kernel's duration."""
+        dev = self.eng.device
+        streams = self.streams or [torch.cuda.current_stream(dev)]
+        ev = []
+        self.eng.fork()
+        for _ in range(rounds):
+            pair = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
+            for (e0, _), st in zip(pair, streams):
                 e0.record(st)
-                eng.step_k(self.pools[j][self.i % 4][:k], out=self.outs[j][self.i % OUT_SETS], normalized=True, reward=True,
-                           done=True, soc_trace=True)
+            fn(1)
+            for (_, e1), st in zip(pair, streams):
                 e1.record(st)
-            ev.append((e0, e1))
-        self.i += 1
-    self.shards.join()
-    torch.cuda.synchronize(self.shards.device)
-    return sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev) * 1e3
+            ev += pair
+        self.eng.join()
+        torch.cuda.synchronize(dev)
+        return sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev) * 1e3
 
 
-ShardRunner.kernel_durations_us = _kernel_durations_us
-
-
-def timed_shards(fn, steps, shards, device):
-    """barrier + sync | K steps on every shard stream | join + sync + barrier; returns (wall seconds, GPU seconds =
-    the longest shard stream's elapsed time between its own start and stop events)."""
+def timed(run, fn, rounds, device, mdist):
+    """barrier + sync | K rounds | sync + barrier; returns (wall seconds, GPU seconds = the longest launch stream's elapsed
+    time between its own start and stop events)."""
+    streams = run.streams or [torch.cuda.current_stream(device)]
     mdist.barrier()
     torch.cuda.synchronize(device)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in shards.streams]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
     t0 = time.perf_counter()
-    shards.fork()
-    for (e0, _), st in zip(ev, shards.streams):
+    run.eng.fork()
+    for (e0, _), st in zip(ev, streams):
         e0.record(st)
-    fn(steps)
-    for (_, e1), st in zip(ev, shards.streams):
+    fn(rounds)
+    for (_, e1), st in zip(ev, streams):
         e1.record(st)
-    shards.join()
+    run.eng.join()
     torch.cuda.synchronize(device)
     t1 = time.perf_counter()
     mdist.barrier()
     return t1 - t0, max(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3
 
 
-def timed(fn, steps, device):
-    """barrier + sync | K steps | sync + barrier; returns (wall seconds, GPU-event seconds)."""
-    mdist.barrier()
-    torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    fn(steps)
-    e1.record()
-    torch.cuda.synchronize(device)
-    t1 = time.perf_counter()
-    mdist.barrier()
-    return t1 - t0, e0.elapsed_time(e1) * 1e-3
-
-
-def hetero_gym_steps(N, dev, rank, world, steps):
+def hetero_gym_steps(N, dev, rank, world, steps, mdist):
+    """BASELINE configs[4] in miniature: a heterogeneous fleet (1/3 genset+battery, 1/3 battery+grid, 1/3
+    genset+battery+grid; forecast_horizon = 24) stepped through the Gym surface WITH observation rows."""
+    from pymgrid_amd.generator import generate
     from pymgrid_amd.hetero import BucketedFleet
     per = N // 3
+    K_ring = 8
     out = {}
     for name, dt in (("float64_rows", torch.float64), ("float32_rows", torch.float32)):
         batches = [generate(per * world, n_steps=steps + 1100, seed=43 + k, arch=arch, horizon=24, device=dev, rank=rank,
                             world=world) for k, arch in enumerate(("genset+battery", "battery+grid", "genset+battery+grid"))]
-        fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=8)
+        fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K_ring)
         gen = torch.Generator(device=dev); gen.manual_seed(11 + rank)
         acts = [torch.rand(per, e.layout.action_dim, dtype=torch.float64, device=dev, generator=gen) for e in fleet.envs]
-        # warm-up by wall time: the fleet is built on the host while the GPU idles and clocks down, and under this
-        # host-paced load the clocks take a few tenths of a second to come back (first leg measured 5x slow with a
-        # 512-step warm-up, 1.6x slow with 0.6 s)
+        # warm-up by wall time: the fleet is built on the host while the GPU idles and clocks down
         prev, t_end = None, time.perf_counter() + 4.0
         while time.perf_counter() < t_end:                # until two consecutive 1000-step blocks agree within 3 %
             fleet.reset()
@@ -260,13 +217,37 @@ def hetero_gym_steps(N, dev, rank, world, steps):
         fleet.reset()
         for _ in range(64):
             fleet.step(acts)
-        wall, _ = timed(lambda k: [fleet.step(acts) for _ in range(k)], steps, dev)
-        wall = mdist.max_over_ranks(wall, dev)
-        out[name] = {"value": 3 * per * world * steps / wall, "us_per_step": wall / steps * 1e6}
+        mdist.barrier()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            fleet.step(acts)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+        gpu = mdist.max_over_ranks(e0.elapsed_time(e1) * 1e-3, dev)
+        mdist.barrier()
+        esz = 8 if dt == torch.float64 else 4
+        # algorithmic bytes of one fleet step (SURVEY 8(d) formula): the core step of every bucket + the observation row
+        # written (esz * D) + the window rows read once per ring refill (8 * C_ts * (K + H) / K per step)
+        alg = 0
+        for e in fleet.envs:
+            L = e.layout
+            c_ts = L.n_load + L.n_pv + 4 * int(L.has_grid)
+            alg += L.n_grids * (L.bytes_per_step() + esz * L.obs_dim + 8 * c_ts * (K_ring + L.horizon) / K_ring)
+        ach = alg / (gpu / steps) / 1e9
+        out[name] = {"value": 3 * per * world * steps / wall, "us_per_step": wall / steps * 1e6,
+                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                  "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_us": gpu / steps * 1e6,
+                                  "launch": "one fleet step = one mgx_fleet_step call: a step kernel per bucket + every "
+                                            f"{K_ring}th step the window prefetch (obs_windows_k_kernel) of each bucket",
+                                  "kernel": "step_kernel<F> x3 + obs_windows_k_kernel<F> x3 / 8"}}
         fleet.close()
         del fleet, batches
         torch.cuda.empty_cache()
-    out.update({"grids_per_gpu": 3 * per, "obs_dims": [56, 106, 156], "horizon": 24, "obs_prefetch": 8, "steps": steps,
+    out.update({"grids_per_gpu": 3 * per, "obs_dims": [56, 106, 156], "horizon": 24, "obs_prefetch": K_ring, "steps": steps,
                 "workload": "BASELINE configs[4] mix per GPU: 1/3 genset+battery, 1/3 battery+grid, 1/3 genset+battery+grid; "
                             "Gym step() with observation rows"})
     return out
@@ -329,14 +310,21 @@ def cpu_baseline(eng, pool, seconds):
             n_py += K - 1
         per_instance = n_py / (time.perf_counter() - t0)
     v1, n1 = run(1, seconds * 0.3)
-    # pick the OpenMP thread count that is fastest on this host (containers often expose more logical CPUs
-    # than they may use), then spend the rest of the budget on it
+    # pick the OpenMP thread count that is fastest on this host (the container exposes every logical CPU of the box, but
+    # its cgroup quota is smaller: above the quota the threads time-share and the rate collapses), then spend the rest of
+    # the budget on it
     cands = sorted({c for c in (4, 8, 16, 32, 64, 128, cores) if c <= cores})
     probe = {c: run(c, seconds * 0.05)[0] for c in cands}
     best = max(probe, key=probe.get)
     vall, nall = run(best, seconds * 0.4)
+    quota = None
+    try:                                                       # cgroup v2 CPU quota of this container ("max" = none)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
     return {"value": vall, "unit": "env-steps/s", "cores": best, "kind": "port",
-            "value_1thread": v1, "host_logical_cpus": cores,
+            "value_1thread": v1, "host_logical_cpus": cores, "cgroup_cpu_quota": quota,
             "per_instance_python_loop_1core": per_instance,
             "thread_probe": {str(c): round(v) for c, v in probe.items()},
             "sample": f"first {n} grids x {K} steps of the benchmark batch, repeated for ~{seconds:.0f} s "
@@ -346,8 +334,9 @@ def cpu_baseline(eng, pool, seconds):
 
 
 def measured_traffic(kernel, grids, chunk):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
-    (tools/gpu_profile.sh -> profiles/<round>/traffic.json); None when no matching profile is committed."""
+    """HBM bytes per launch of `kernel` (a launch over `grids` grids and `chunk` steps) from the committed rocprofv3 PMC
+    passes of THIS command (tools/gpu_profile.sh -> profiles/<round>/traffic.json); None when no profile of that launch
+    shape is committed."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
         try:
@@ -360,151 +349,164 @@ def measured_traffic(kernel, grids, chunk):
         for threads, e in sorted(d.get("by_launch_threads", {}).get(kernel, {}).items(), key=lambda kv: int(kv[0])):
             if grids <= int(threads) < 1.45 * grids:
                 return e["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
-        if d.get("grids") == grids and kernel in d.get("kernels", {}):
-            return d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
     return None, None
 
 
 def main():
     args = parse()
+    rc = self_launch(args)
+    if rc is not None:
+        raise SystemExit(rc)
+    from pymgrid_amd import _lib
+    from pymgrid_amd import distributed as mdist
+    from pymgrid_amd.engine import StepEngine
+    from pymgrid_amd.generator import generate
     rank, world, local = mdist.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the job has {world} rank(s): launch with `python bench.py --gpus N` "
+                         f"(self-launching) or torch.distributed.run --nproc-per-node N")
+    if args.launch_check:          # the N-rank launch path alone (runs on a CPU box with MGX_DIST_BACKEND=gloo)
+        if world > 1:
+            import torch.distributed as dist
+            assert dist.get_world_size() == args.gpus
+            ranks = mdist.gather_over_ranks(rank, torch.device("cpu") if dist.get_backend() == "gloo" else torch.device("cuda", local))
+            assert ranks == list(range(world)), ranks
+            if rank == 0:
+                print(json.dumps({"launch_check": True, "n_gpus": world, "backend": dist.get_backend(), "ranks": ranks}), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            print(json.dumps({"launch_check": True, "n_gpus": 1, "backend": None, "ranks": [0]}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     _lib.build()
     local = int(os.environ.get("MGX_FORCE_LOCAL_RANK", local))     # tests: several ranks on one GPU (with a gloo backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    N, chunk = args.grids, args.chunk
+    if world > 1:
+        import torch.distributed as dist
+        assert dist.get_world_size() == args.gpus
+        want = os.environ.get("MGX_DIST_BACKEND", "nccl")
+        if dist.get_backend() != want:
+            raise SystemExit(f"backend {dist.get_backend()} != {want}")
+    N, chunk, S = args.grids, args.chunk, max(1, args.shards)
     n_total = N * world
 
     batch = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world)
     eng = StepEngine(batch)
     L = eng.layout
-    gen = torch.Generator(device=dev); gen.manual_seed(7 + rank)
-    pool = torch.rand(4, chunk, N, L.action_dim, dtype=torch.float64, device=dev, generator=gen)
-    run = Runner(eng, chunk, pool)
-    from pymgrid_amd.priority_list import get_priority_lists, table_array
-    from pymgrid_amd.rbc import default_priority_ids
-    lists = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, False)
-    run.rbc_table = table_array(lists)
-    run.rbc_ids = torch.from_numpy(default_priority_ids(batch, lists, remove_redundant_gensets=False)).to(dev)
+    run = Runner(eng, chunk, 7 + rank, S)
 
-    # extra measurement: S independent shards of the rank's grids, one HIP stream each (the launch sequences of shards
-    # owe each other nothing and fill each other's ramp-up / tail gaps)
-    S = max(1, args.shards)
-    if N % S:
-        raise SystemExit(f"--grids {N} is not divisible by --shards {S}")
-    shards = srun = None
-    if S > 1:
-        from pymgrid_amd.hetero import StreamShards
-        shards = StreamShards([generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev,
-                                        rank=rank * S + j, world=world * S) for j in range(S)])
-        srun = ShardRunner(shards, chunk, 7 + 1000 * rank)
-
-    def measure(mode, sharded, steps, warmup):
-        n_launch = N // S if sharded else N                      # grids per kernel launch
-        r = srun if sharded else run
-        fn = {"fused": r.fused, "step": getattr(r, "single", None), "rbc": r.rbc}[mode]
-        (shards.reset() if sharded else eng.reset(want_obs=False))
+    def measure(mode, sharded, rounds, warmup):
+        run.shard(sharded)
+        fn = getattr(run, mode)
+        eng.reset(want_obs=False)
         # device pre-warm (untimed, part of set-up like the data generation): the first launches after start-up or after
         # an idle phase run on a cold device -- code-object load, and ~15 ms until the clocks settle under this load
-        # (profiles/r01/exp_transient_cause.txt) -- so PREWARM_S seconds of the same launches precede the W warm-up steps
-        t_end = time.perf_counter() + PREWARM_S
+        # (profiles/r01/exp_transient_cause.txt) -- so PREWARM_S seconds of the same rounds precede the W warm-up rounds,
+        # with no idle gap between them
+        r0 = run.rounds
+        run.eng.fork()
+        t_end = time.perf_counter() + args.prewarm
         while time.perf_counter() < t_end:
-            fn(chunk if mode != "step" else 64)
-            torch.cuda.synchronize(dev)
-        (shards.reset() if sharded else eng.reset(want_obs=False))
+            fn(8)
+            if run.rounds - r0 > 64:                             # keep the launch queues short: ~64 rounds ahead at most
+                run.eng.join(); torch.cuda.synchronize(dev); run.eng.fork(); r0 = run.rounds
         fn(warmup)
-        r.launches = 0
-        wall, gpu = timed_shards(fn, steps, shards, dev) if sharded else timed(fn, steps, dev)
-        wall = mdist.max_over_ranks(wall, dev)
-        gpu = mdist.max_over_ranks(gpu, dev)
-        launches = r.launches                                    # per stream
+        first = run.rounds
+        wall, gpu = timed(run, fn, rounds, dev, mdist)
+        walls = mdist.gather_over_ranks(wall, dev)
+        wall, gpu = max(walls), mdist.max_over_ranks(gpu, dev)
+        n_launch = (N + S - 1) // S if sharded and S > 1 else N   # grids per kernel launch
         if mode in ("fused", "rbc"):
-            A8 = 8 * L.action_dim if mode == "rbc" else 0        # rbc: no action stream; + 1 id byte per grid, once
-            once = 1 if mode == "rbc" else 0
-            per_launch = sum(L.bytes_fused(min(chunk, steps - k0)) - A8 * min(chunk, steps - k0) + once
-                             for k0 in range(0, steps, chunk)) / launches
-            unit_bytes = (L.bytes_fused(chunk) - A8 * chunk + once) / chunk
-        else:
-            unit_bytes = L.bytes_per_step()
-            per_launch = unit_bytes
-        # sharded: a "launch" is one ROUND = S kernel launches issued together, one per shard stream, covering all N grids;
-        # its duration is the cadence of a shard stream (HIP events on that stream over the region / its launches)
-        per_launch_bytes = per_launch * N
+            A8 = 8 * L.action_dim * chunk if mode == "rbc" else 0  # rbc: no action stream; + 1 id byte per grid, once
+            per_launch = L.bytes_fused(chunk) - A8 + (1 if mode == "rbc" else 0)
+            launches_per_round = 1
+        else:                                                      # `chunk` single-step launches per round
+            per_launch = L.bytes_per_step()
+            launches_per_round = chunk
+        launches = rounds * launches_per_round                     # per stream
+        per_launch_bytes = per_launch * N                          # one launch on every shard stream = all N grids
         avg_launch_s = gpu / launches
         achieved = per_launch_bytes / avg_launch_s / 1e9
-        kname = {"fused": "step_k_kernel", "step": "step_kernel", "rbc": "rollout_kernel"}[mode]
+        kname = {"fused": "step_k_kernel", "step": "step_kernel", "step_python": "step_kernel", "rbc": "rollout_kernel"}[mode]
         traffic, traffic_src = measured_traffic(kname, n_launch, chunk)
-        if traffic is not None and sharded:
+        if traffic is not None and sharded and S > 1:
             traffic *= S
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": per_launch_bytes,
-                "kernel": {"fused": "step_k_kernel<3,4,double>", "step": "step_kernel<3>",
+                "kernel": {"fused": "step_k_kernel<3,4,double>", "step": "step_kernel<3>", "step_python": "step_kernel<3>",
                            "rbc": "rollout_kernel<3,4,false>"}[mode],
-                "bytes_per_env_step": unit_bytes, "launches": launches, "avg_launch_us": avg_launch_s * 1e6}
-        if sharded:
-            roof.update({"launch": f"one round = {S} concurrent kernel launches, one per shard stream, {n_launch} grids each",
-                         "concurrent_streams": S, "grids_per_kernel_launch": n_launch,
-                         "kernel_avg_duration_us": r.kernel_durations_us(16)})
-        return {"value": n_total * steps / wall, "steps": steps, "ms_per_step": wall / steps * 1e3, "roofline": roof}
+                "bytes_per_env_step": per_launch / (chunk if mode in ("fused", "rbc") else 1),
+                "launches": launches, "avg_launch_us": avg_launch_s * 1e6,
+                "timed_rounds": [first, first + rounds]}
+        if sharded and S > 1:
+            roof.update({"launch": f"one round = {S} concurrent kernel launches, one per internal shard stream "
+                                   f"(mgx_set_shards), {n_launch} grids each, never joined between rounds",
+                         "concurrent_streams": S, "grids_per_kernel_launch": n_launch})
+        if mode in ("fused", "rbc"):
+            roof["kernel_avg_duration_us"] = run.kernel_durations_us(fn)
+        run.shard(False)
+        return {"value": n_total * rounds * chunk / wall, "steps": rounds, "warmup": warmup, "ms_per_step": wall / rounds * 1e3,
+                "roofline": roof, "per_rank_env_steps_per_s": [N * rounds * chunk / w for w in walls]}
 
-    results = {}
-    side = {"fused": (32768, 16384), "step": (8192, 2048), "rbc": (16384, 8192)}     # (steps, warm-up) when not the headline
-    for mode in ("fused", "step", "rbc"):
-        main_mode = mode == args.mode
-        results[mode] = measure(mode, sharded=(S > 1 and mode == "fused"),
-                                steps=args.steps if main_mode else min(args.steps, side[mode][0]),
-                                warmup=args.warmup if main_mode else min(args.warmup, side[mode][1]))
-    if S > 1:        # the same fused kernel as ONE launch sequence over all N grids (reported under "other")
-        results["fused_one_stream"] = measure("fused", sharded=False, steps=min(args.steps, side["fused"][0]),
-                                              warmup=min(args.warmup, side["fused"][1]))
+    # the headline first (its launch indices in a rocprofv3 trace are then [prewarm + W, prewarm + W + K) per queue)
+    results = {args.mode: measure(args.mode, sharded=(S > 1 and args.mode in ("fused", "rbc")), rounds=args.steps,
+                                  warmup=args.warmup)}
+    if not args.no_side_modes:
+        side = (min(args.steps, SIDE_ROUNDS[0]), min(args.warmup, SIDE_ROUNDS[1]))
+        for mode in ("fused", "step", "rbc"):
+            if mode != args.mode:
+                results[mode] = measure(mode, sharded=(S > 1 and mode == "fused"), rounds=side[0], warmup=side[1])
+        if S > 1:    # single-step launches over the shard streams: a range's kernel boundary overlaps the other's kernel
+            results["step_sharded"] = measure("step", sharded=True, rounds=side[0], warmup=side[1])
+        if S > 1:    # the same fused kernel as ONE launch sequence over all N grids
+            results["fused_one_stream"] = measure("fused", sharded=False, rounds=side[0], warmup=side[1])
+        results["step_python"] = measure("step_python", sharded=False, rounds=min(side[0], 32), warmup=min(side[1], 8))
 
-    # BASELINE configs[4] in miniature, reported under "other": a heterogeneous fleet (1/3 genset+battery, 1/3
-    # battery+grid, 1/3 genset+battery+grid; forecast_horizon = 24) stepped through the Gym surface WITH observations
-    # (window prefetch K = 8), one bucket per HIP stream.
     hetero = None
     if args.hetero_steps > 0:
-        hetero = hetero_gym_steps(N, dev, rank, world, args.hetero_steps)
+        hetero = hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist)
 
     # metrics vector: episode-return sum + mean SoC, all-reduced over ranks (the ONLY collective; RCCL over xGMI)
-    sums = eng.metrics(torch.stack([run.reward_k[-1], batch.cols["soc"]]))
+    sums = eng.metrics(torch.stack([run.outs[0]["reward"][-1], batch.cols["soc"]]))
     mdist.all_reduce_metrics(sums)
+    mdist.barrier()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(eng, pool, args.cpu_seconds)
+    if rank == 0 and not args.no_cpu_baseline:      # rank 0 only; for N > 1 a shorter sample while the other ranks wait
+        cpu = cpu_baseline(eng, run.pool, args.cpu_seconds if world == 1 else min(args.cpu_seconds, 4.0))
 
     if rank == 0:
         main_r = results[args.mode]
-        names = {"fused": "fused_launches", "step": "single_step_launches", "rbc": "rbc_rollout_on_device",
-                 "fused_one_stream": "fused_launches_one_stream"}
+        names = {"fused": "fused_launches", "step": "single_step_launches_one_call", "rbc": "rbc_rollout_on_device",
+                 "fused_one_stream": "fused_launches_one_stream", "step_python": "single_step_launches_python_loop",
+                 "step_sharded": "single_step_launches_one_call_sharded"}
         line = {
             "metric": "microgrid env-steps/sec", "value": main_r["value"], "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{N} generated 4-module grids (genset+battery+load+pv) per GPU, T={args.rows}, "
                                    f"H=0, normalised random actions (BASELINE configs[2])",
-                       "grids_per_gpu": N, "grids_total": n_total, "mode": args.mode,
+                       "step": f"one round = {chunk} consecutive env-steps of all grids of a rank",
+                       "env_steps_per_step": chunk, "grids_per_gpu": N, "grids_total": n_total, "mode": args.mode,
                        "steps_per_launch": 1 if args.mode == "step" else chunk,
                        "outputs": "reward+done+soc per step" + ("" if args.mode == "step" else " (streamed [K,N])"),
                        "parallelism": f"grids sharded x{world} ranks, no data-path collective"
-                                      + (f"; fused mode: {S} independent shards per GPU on {S} HIP streams" if S > 1 else "")},
+                                      + (f"; {S} grid ranges per GPU on {S} internal HIP streams" if S > 1 else "")},
             "roofline": main_r["roofline"],
             "cpu_baseline": cpu,
-            "other": {names[m]: {"value": r["value"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
-                                 "roofline": r["roofline"]} for m, r in results.items() if m != args.mode},
+            "per_rank_env_steps_per_s": main_r["per_rank_env_steps_per_s"],
+            "other": {names[m]: {k: r[k] for k in ("value", "steps", "warmup", "ms_per_step", "roofline")}
+                      for m, r in results.items() if m != args.mode},
             "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total},
             "hetero_h24_gym_steps": hetero,
-            "prewarm_seconds_per_mode": PREWARM_S,
+            "prewarm_seconds_per_mode": args.prewarm,
         }
         print(json.dumps(line), flush=True)
     eng.close()
-    if shards is not None:
-        shards.close()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -45,6 +45,16 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def gather_over_ranks(value, device):
+    """[value of rank 0, ..., value of rank W-1] on every rank (one small all-gather; a one-element list for one process)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+        return [float(x.item()) for x in out]
+    return [float(value)]
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

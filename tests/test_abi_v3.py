@@ -1,0 +1,253 @@
+"""GPU tests of the ABI v3 entry points (include/mgx.h): shards on internal streams, mgx_step_many, per-grid episode windows
+(mgx_reset_windows), mgx_fleet_step.  Everything is compared bit for bit (==) with the unsharded / per-step / per-env path
+or with the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import action_dim, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, device, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=device)
+
+
+def _batch(grids, device):
+    from pymgrid_amd import MicrogridBatch
+    return MicrogridBatch.from_grids(grids, device=device)
+
+
+@pytest.mark.parametrize("S", [2, 3, 8])
+def test_internal_shards_equal_one_launch_sequence(S, device):
+    """mgx_set_shards: the same handle stepped as S grid ranges on S internal streams (never joined between calls) ==
+    stepped as one launch sequence: fused steps, single steps, step_many, discrete steps and rule-based rollouts."""
+    from pymgrid_amd import StepEngine
+    from pymgrid_amd.generator import generate
+    from pymgrid_amd.priority_list import get_priority_lists, table_array
+    N, T, K = 6001, 260, 16                     # ragged: the last shard is short, shard bounds are multiples of 256
+    mk = lambda: StepEngine(generate(N, n_steps=T, seed=12, arch="genset+battery+grid", device=device, mixed_timers=True))
+    whole, sh = mk(), mk()
+    sh.set_shards(S)
+    g = torch.Generator(device=device); g.manual_seed(4)
+    tab = table_array(get_priority_lists(True, True, True))
+    res_w, res_s = [], []
+    sh.fork()
+    for rnd in range(4):
+        a = torch.rand(K, N, 4, dtype=torch.float64, device=device, generator=g)
+        torch.cuda.current_stream(device).synchronize()          # `a` was made on the caller's stream
+        res_w.append(whole.step_k(a, reward=True, done=True, soc_trace=True, status_trace=True, log=(rnd == 0)))
+        res_s.append(sh.step_k(a, reward=True, done=True, soc_trace=True, status_trace=True, log=(rnd == 0)))
+    a1 = torch.rand(5, N, 4, dtype=torch.float64, device=device, generator=g)
+    ids = torch.randint(0, len(tab), (N,), device=device, generator=g)
+    torch.cuda.current_stream(device).synchronize()
+    for eng, res in ((whole, res_w), (sh, res_s)):
+        for k in range(2):
+            _, r, d, lg = eng.step(a1[k], want_obs=False, want_log=True)
+            res.append(dict(reward=r, done=d, log=lg))
+        _, r, d, lg = eng.step_many(a1[2:], want_log=True)
+        res.append(dict(reward=r, done=d, log=lg))
+        _, r, d, lg, c = eng.step_discrete(ids.to(torch.int32), tab, want_obs=False, want_log=True, want_control=True)
+        res.append(dict(reward=r, done=d, log=lg, control=c))
+        res.append(dict(control=eng.expand_discrete(ids.to(torch.int32), tab)))
+        res.append(eng.rollout_discrete(ids.to(torch.uint8), tab, K, reward=True, soc_trace=True))
+    assert whole.current_step == sh.current_step == 4 * K + 2 + 3 + 1 + K
+    sh.join()
+    torch.cuda.synchronize(device)
+    for x, y in zip(res_w, res_s):
+        assert set(x) == set(y)
+        for name in x:
+            assert torch.equal(x[name], y[name]), name
+    for name in ("charge", "soc", "gen_status"):
+        assert torch.equal(whole.batch.cols[name], sh.batch.cols[name])
+    # switching shards off again: back on the caller's stream
+    sh.set_shards(1)
+    a = torch.rand(K, N, 4, dtype=torch.float64, device=device, generator=g)
+    assert torch.equal(whole.step_k(a, reward=True)["reward"], sh.step_k(a, reward=True)["reward"])
+    whole.close(); sh.close()
+
+
+def test_shards_refuse_what_they_cannot_order(device):
+    from pymgrid_amd import StepEngine
+    from pymgrid_amd._lib import MGX_ERR_INVALID, MGX_ERR_UNSUPPORTED, MgxError
+    from pymgrid_amd.generator import generate
+    eng = StepEngine(generate(512, n_steps=40, seed=1, arch="genset+battery", horizon=4, device=device))
+    with pytest.raises(MgxError) as e:
+        eng.set_shards(9)
+    assert e.value.code == MGX_ERR_INVALID
+    eng.set_shards(2)
+    with pytest.raises(MgxError) as e:
+        eng.use_device_counter(True)
+    assert e.value.code == MGX_ERR_UNSUPPORTED
+    a = torch.rand(512, 3, dtype=torch.float64, device=device)
+    with pytest.raises(MgxError) as e:                     # H > 0 observation rows are not written per shard
+        eng.step(a, want_obs=True)
+    assert e.value.code == MGX_ERR_UNSUPPORTED
+    eng.fork(); eng.step(a, want_obs=False); eng.join()
+    eng.set_shards(1)
+    eng.use_device_counter(True)
+    with pytest.raises(MgxError) as e:
+        eng.set_shards(2)
+    assert e.value.code == MGX_ERR_UNSUPPORTED
+    eng.use_device_counter(False)
+    eng.close()
+
+
+@pytest.mark.parametrize("arch,H", [("genset+battery", 0), ("genset+battery+grid", 3), ("loadpv2", 0)])
+def test_step_many_equals_a_loop_of_steps(arch, H, device):
+    """mgx_step_many == K calls of mgx_step: rewards, done flags, observation rows, log rows, final state."""
+    from pymgrid_amd import MicrogridBatch, StepEngine
+    from pymgrid_amd.generator import generate
+    N, T, K = 777, 50, 46
+    if arch == "loadpv2":                                        # two load and two renewable modules per grid (general kernels)
+        rs = np.random.RandomState(3)
+        grids = [dict(load_ts=40 * rs.rand(T, 2), pv_ts=30 * rs.rand(T, 2), horizon=2, final_step=T, initial_step=0,
+                      unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0),
+                      battery=dict(min_capacity=20.0, max_capacity=100.0, max_charge=25.0, max_discharge=25.0,
+                                   efficiency=0.9, battery_cost_cycle=0.02, init_soc=0.5)) for _ in range(100)]
+        mk = lambda: StepEngine(MicrogridBatch.from_grids(grids, device=device))
+        N = 100
+    else:
+        mk = lambda: StepEngine(generate(N, n_steps=T, seed=2, arch=arch, horizon=H, device=device, mixed_timers=True))
+    e1, e2 = mk(), mk()
+    A = e1.action_dim
+    g = torch.Generator(device=device); g.manual_seed(1)
+    acts = torch.rand(K, N, A, dtype=torch.float64, device=device, generator=g)
+    e1.reset(want_obs=False); e2.reset(want_obs=False)
+    obs, reward, done, log = e1.step_many(acts, want_obs=True, want_log=True)
+    for k in range(K):
+        o, r, d, lg = e2.step(acts[k], want_obs=True, want_log=True)
+        assert torch.equal(obs[k], o) and torch.equal(reward[k], r) and torch.equal(done[k], d) and torch.equal(log[k], lg), k
+    assert e1.current_step == e2.current_step == K
+    assert bool(done[-1].all()) == (K >= T - 1) and not bool(done[K - 5].any())
+    for name in ("charge", "soc", "gen_status"):
+        if name in e1.batch.cols:
+            assert torch.equal(e1.batch.cols[name], e2.batch.cols[name])
+    from pymgrid_amd._lib import MGX_ERR_RANGE, MgxError
+    with pytest.raises(MgxError) as e:                           # would leave the series: nothing is launched
+        e1.step_many(acts[:8])
+    assert e.value.code == MGX_ERR_RANGE and e1.current_step == K
+    e1.close(); e2.close()
+
+
+def test_per_grid_windows_with_unequal_lengths_vs_oracle(pymgrid25, device, oracle):
+    """mgx_reset_windows: every grid has its own start row AND its own episode length (StochasticTrajectory per
+    microgrid, trajectory/stochastic.py:9-12); windows may reach the end of the series (forecast padding).  Rewards,
+    observations and the per-grid done flags equal per-grid oracle runs on the full series."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    sel = (1, 8, 9, 10, 13, 18, 22, 24)                          # genset + battery + grid, four of them weak grids; H = 23
+    grids = [pymgrid25[n] for n in sel]
+    env = BatchedMicrogridEnv(_batch(grids, device), observations=True)
+    starts = np.array([0, 100, 4000, 8700, 8735, 37, 8758 - 30, 5555])
+    lengths = np.array([30, 12, 24, 59, 24, 1, 30, 17])          # 8700 + 59 = 8759 = final_step: runs to the very end
+    obs = env.reset_windows(starts, lengths).cpu().numpy()
+    assert env.final_step == 59 and env.current_step == 0
+    oms = []
+    for p, s, n in zip(grids, starts, lengths):
+        q = dict(p); q["initial_step"], q["final_step"] = int(s), int(s) + int(n)
+        oms.append(oracle.OracleMicrogrid(q))
+    for j, om in enumerate(oms):
+        assert np.array_equal(obs[j], om.reset()), j
+    rs = np.random.RandomState(4)
+    for k in range(int(lengths.max())):
+        a = rs.rand(len(grids), 4)
+        obs, reward, done, _ = env.step(_t(a, device))
+        obs, cur = obs.cpu().numpy(), env.current_steps.cpu().numpy()
+        for j, om in enumerate(oms):
+            if k >= lengths[j]:                                   # this grid's episode is over: its microgrid would be reset
+                assert bool(done[j])
+                continue
+            out = om.run(dict(genset=a[j, :2], battery=a[j, 2], grid=a[j, 3]), True)
+            assert reward[j].item() == out.reward, (k, j)
+            assert bool(done[j]) == bool(out.done) == (k == lengths[j] - 1), (k, j)
+            assert np.array_equal(obs[j], om.observe()), (k, j)
+            assert cur[j] == starts[j] + k + 1
+    # fused launches over the windows: same rewards / per-grid done as the single steps
+    env2, env3 = (BatchedMicrogridEnv(_batch(grids, device), observations=False) for _ in range(2))
+    env2.reset_windows(starts, lengths)
+    env3.reset_windows(starts, lengths)
+    acts = torch.rand(40, len(grids), 4, dtype=torch.float64, device=device)
+    out = env2.engine.step_k(acts, reward=True, done=True)
+    for k in range(40):
+        _, r, d, _ = env3.step(acts[k])
+        assert torch.equal(out["reward"][k], r) and torch.equal(out["done"][k].view(torch.bool), d), k
+    env3.close()
+    # a plain reset returns to the shared window over the full series (the dynamic state is untouched by either reset)
+    env4 = BatchedMicrogridEnv(_batch(grids, device), observations=True)
+    env4.reset_windows(starts, lengths)
+    assert np.array_equal(env4.reset().cpu().numpy(), np.stack([oracle.OracleMicrogrid(p).reset() for p in grids]))
+    assert env4.final_step == 8759 and int(env4.current_steps[0]) == 0
+    env.close(); env2.close(); env4.close()
+
+
+def test_per_grid_window_env_draws(pymgrid25, device, oracle):
+    """hetero.PerGridWindowEnv: FixedLengthStochasticTrajectory / StochasticTrajectory draws per grid stay inside the env's
+    window; explicit starts reproduce per-grid oracle runs (equal lengths, H = 23 forecasts)."""
+    from pymgrid_amd.hetero import PerGridWindowEnv
+    tmpl4 = [pymgrid25[n] for n in (2, 3, 5, 7, 15, 17)]
+    env = PerGridWindowEnv(_batch(tmpl4, device), trajectory_length=48, observations=True, obs_prefetch=8)
+    starts = np.array([0, 100, 4000, 8600, 8711, 37])            # 8711 + 48 = 8759: the forecasts run into the padding
+    obs = env.reset(starts=starts).cpu().numpy()
+    oms = []
+    for p, s in zip(tmpl4, starts):
+        q = dict(p); q["initial_step"], q["final_step"] = int(s), int(s) + 48
+        oms.append(oracle.OracleMicrogrid(q))
+    for j, om in enumerate(oms):
+        assert np.array_equal(obs[j], om.reset()), j
+    rs = np.random.RandomState(4)
+    for k in range(48):
+        a = rs.rand(6, 3)
+        obs, reward, done, _ = env.step(_t(a, device))
+        obs = obs.cpu().numpy()
+        for j, om in enumerate(oms):
+            out = om.run(dict(genset=a[j, :2], battery=a[j, 2]), True)
+            assert reward[j].item() == out.reward and bool(done[j]) == bool(out.done) == (k == 47)
+            assert np.array_equal(obs[j], om.observe()), (k, j)
+    env.reset()
+    assert int(env.starts.min()) >= 0 and int(env.starts.max()) + 48 <= 8759 and env.lengths is None
+    env.close()
+    gen = torch.Generator(device=device); gen.manual_seed(5)
+    env = PerGridWindowEnv(_batch(tmpl4 * 50, device), observations=False, generator=gen)    # random start and end per grid
+    env.reset()
+    s, n = env.starts.cpu().numpy(), env.lengths.cpu().numpy()
+    assert s.min() >= 0 and (n >= 1).all() and (s + n <= 8759).all() and len(set(n.tolist())) > 10
+    k_done = np.full(len(s), -1)
+    for k in range(int(n.max())):
+        _, _, done, _ = env.step(env.sample_action())
+        d = done.cpu().numpy()
+        k_done[(k_done < 0) & d] = k
+        if k > 40:
+            break
+    seen = k_done >= 0
+    assert seen.any() and np.array_equal(k_done[seen], n[seen] - 1)
+    env.close()
+
+
+@pytest.mark.parametrize("prefetch,discrete", [(0, False), (8, False), (4, True)])
+def test_fleet_step_in_one_call_equals_per_env_steps(prefetch, discrete, pymgrid25, device):
+    """mgx_fleet_step (BucketedFleet.step: every bucket's launch and ring refill from ONE C call) == one env.step per bucket:
+    observations (incl. ring refills), rewards, done, log rows, state."""
+    from pymgrid_amd.hetero import BucketedFleet
+    kw = dict(device=device, observations=True, obs_prefetch=prefetch, log=True, discrete=discrete)
+    if discrete:
+        kw["remove_redundant_gensets"] = False
+    fused, plain = BucketedFleet(pymgrid25, **kw), BucketedFleet(pymgrid25, **kw)
+    o1, o2 = fused.reset(), plain.reset()
+    g = torch.Generator(device=device); g.manual_seed(0)
+    for k in range(21):
+        acts = fused.sample_action(generator=g)
+        r1 = fused.step(acts)
+        r2 = [env.step(a) for env, a in zip(plain.envs, acts)]
+        for b in range(len(fused.envs)):
+            assert torch.equal(r1[0][b], r2[b][0]), (k, b)
+            assert torch.equal(r1[1][b], r2[b][1]) and torch.equal(r1[2][b], r2[b][2]), (k, b)
+            assert torch.equal(r1[3][b]["log"], r2[b][3]["log"]), (k, b)
+    for e1, e2 in zip(fused.envs, plain.envs):
+        assert e1.current_step == e2.current_step == 21
+        for name in ("charge", "soc", "gen_status"):
+            if name in e1.batch.cols:
+                assert torch.equal(e1.batch.cols[name], e2.batch.cols[name])
+        la, lb = e1.get_log(), e2.get_log()
+        assert all(np.array_equal(la[c], lb[c]) for c in la)
+    fused.close(); plain.close()

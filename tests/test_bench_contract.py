@@ -1,6 +1,7 @@
-"""bench.py contract on a GPU box: the one-rank JSON line, and the N > 1 launch path (torchrun, one rank per GPU) exercised
-with two ranks on the single GPU through the gloo backend (MGX_DIST_BACKEND / MGX_FORCE_LOCAL_RANK test overrides) -- the
-real multi-GPU runs over RCCL are the driver's."""
+"""bench.py contract: the one-rank JSON line on a GPU box, and the N > 1 path -- `python bench.py --gpus N` launches its own N
+ranks (torch.distributed.run, one rank per GPU) -- exercised here with two ranks through the gloo backend (MGX_DIST_BACKEND /
+MGX_FORCE_LOCAL_RANK test overrides: on CPU for the launch path alone, on the single GPU for the whole bench).  The real
+multi-GPU runs over RCCL are the driver's."""
 import json
 import os
 import subprocess
@@ -9,7 +10,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--grids", "20000", "--rows", "700", "--steps", "192", "--warmup", "64", "--hetero-steps", "16", "--cpu-seconds", "1"]
+SMALL = ["--grids", "20000", "--rows", "700", "--steps", "6", "--warmup", "2", "--chunk", "32", "--hetero-steps", "16",
+         "--cpu-seconds", "1", "--prewarm", "0.05"]
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
         "dtype", "data", "config", "roofline", "cpu_baseline"}
 
@@ -20,23 +22,60 @@ def _line(out):
     return json.loads(lines[0])
 
 
+def test_gpus_n_launches_its_own_ranks_cpu():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts two ranks itself and they form one process
+    group of size 2 (gloo here; nccl = RCCL on a GPU node)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MGX_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert d == {"launch_check": True, "n_gpus": 2, "backend": "gloo", "ranks": [0, 1]}
+
+
+def test_gpus_mismatch_fails_loudly():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "--gpus 2" in (r.stdout + r.stderr)
+
+
 @pytest.mark.gpu
 def test_bench_one_rank_json_line(device):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
-    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 192 and d["value"] > 0
-    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "hbm"
-    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0
+    rf = d["roofline"]
+    assert set(rf) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and rf["bound"] == "hbm"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["launches"] == 6 and rf["concurrent_streams"] == 2            # every timed round is one full-K launch per shard stream
+    assert abs(d["value"] - 20000 * 6 * 32 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert set(d["hetero_h24_gym_steps"]["float64_rows"]["roofline"]) >= {"bound", "achieved", "peak", "frac"}
+    assert {"fused_launches_one_stream", "single_step_launches_one_call", "rbc_rollout_on_device",
+            "single_step_launches_python_loop"} <= set(d["other"])
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_launch_path(device):
+def test_bench_two_ranks_self_launched(device):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MGX_DIST_BACKEND="gloo", MGX_FORCE_LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-side-modes"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["grids_total"] == 40000 and d["value"] > 0
+    assert len(d["per_rank_env_steps_per_s"]) == 2 and d["cpu_baseline"]["kind"] == "port"
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_under_torchrun(device):
     env = dict(os.environ, MGX_DIST_BACKEND="gloo", MGX_FORCE_LOCAL_RANK="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-side-modes", "--no-cpu-baseline"] + SMALL
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _line(r.stdout)

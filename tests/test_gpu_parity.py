@@ -452,35 +452,6 @@ def test_randomized_differential_degenerate_parameters(arch, device, oracle):
     eng.close()
 
 
-def test_per_grid_episode_windows(pymgrid25, device, oracle):
-    """Every grid runs its own window [start_i, start_i + 48) of its series (H = 23 forecasts reach past the window
-    into the real series): rewards, observations and the done flag equal a per-grid oracle run on the full series."""
-    from pymgrid_amd.hetero import PerGridWindowEnv
-    tmpl4 = [pymgrid25[n] for n in (2, 3, 5, 7, 15, 17)]
-    full = _batch(tmpl4, device)
-    env = PerGridWindowEnv(full, trajectory_length=48, observations=True)
-    starts = np.array([0, 100, 4000, 8600, 8687, 37])
-    obs = env.reset(starts=starts).cpu().numpy()
-    oms = []
-    for p, s in zip(tmpl4, starts):
-        q = dict(p); q["initial_step"], q["final_step"] = int(s), int(s) + 48
-        oms.append(oracle.OracleMicrogrid(q))
-    for j, om in enumerate(oms):
-        assert np.array_equal(obs[j], om.reset()), j
-    rs = np.random.RandomState(4)
-    for k in range(48):
-        a = rs.rand(6, 3)
-        obs, reward, done, _ = env.step(_t(a, device))
-        obs = obs.cpu().numpy()
-        for j, om in enumerate(oms):
-            out = om.run(dict(genset=a[j, :2], battery=a[j, 2]), True)
-            assert reward[j].item() == out.reward and bool(done[j]) == bool(out.done) == (k == 47)
-            assert np.array_equal(obs[j], om.observe()), (k, j)
-    drawn = env.reset()                       # random starts: inside the admissible range
-    assert int(env.starts.min()) >= 0 and int(env.starts.max()) + 48 + 23 < 8759
-    env.close()
-
-
 def test_observation_keys_vs_reference(pymgrid25, device):
     """BaseMicrogridEnv(observation_keys=...) (reference tests/envs/test_discrete.py:82-95): the observation is the
     listed state keys in list order; unknown keys raise NameError."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + stats and the HBM PMC passes for bench.py.
-# Usage: tools/gpu_profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/*
+# Usage: tools/gpu_profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/*      (default args: the driver's command)
 # PMC passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950: TCC has 4 slots,
 # FETCH_SIZE takes 3, WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots"), kernel-trace only.
 set -u
@@ -10,13 +10,14 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 8192 --warmup 24576 --no-cpu-baseline --hetero-steps 0 $*"
-timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/stats.log" 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
+ARGS="${*:---gpus 1 --steps 20 --warmup 5}"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/stats.log" 2> "$OUT/stats.err"
+PMCARGS="$ARGS --no-cpu-baseline --hetero-steps 0"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o bench --output-format csv -- python "$REPO/bench.py" $PMCARGS > "$OUT/pmc_fetch.log" 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o bench --output-format csv -- python "$REPO/bench.py" $PMCARGS > "$OUT/pmc_write.log" 2>&1
 cd "$REPO"
 python tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
-# stamp the workload the counters belong to (bench.py only reports `traffic` for a matching config)
+# stamp the workload the counters belong to (bench.py only reports `traffic` for a matching launch shape)
 python - "$OUT/traffic.json" $ARGS <<'PY'
 import json, sys
 f, a = sys.argv[1], sys.argv[2:]

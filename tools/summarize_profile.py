@@ -34,31 +34,53 @@ for f in find("*kernel_trace.csv"):
         print(f"{k[:90]:90s} calls={len(v)} avg_us={sum(v)/len(v)/1e3:.2f} med_us={v2[len(v2)//2]/1e3:.2f} "
               f"min_us={v2[0]/1e3:.2f} max_us={v2[-1]/1e3:.2f}")
 
-# the fused kernel per HIP queue (bench.py steps two independent shards on two streams): kernel durations AND the cadence
-# of each queue = what bench.py's HIP events on that stream measure as "duration of a round"
+# The headline of bench.py in this trace.  The bench line (stats.log) says which launches of the headline kernel were the
+# timed ones: roofline.timed_rounds = [first, last) counts the rounds the runner had issued, and the headline mode runs
+# first, so on every queue that carries its launches the timed ones are launches [first, last) of that kernel in time order.
+import json
+bench = None
+for name in ("stats.log",):
+    try:
+        for ln in open(os.path.join(out, name)):
+            if ln.startswith("{"):
+                bench = json.loads(ln)
+    except OSError:
+        pass
 for f in find("*kernel_trace.csv"):
-    if os.sep + "stats" + os.sep not in f:
+    if os.sep + "stats" + os.sep not in f or bench is None:
         continue
+    rf = bench["roofline"]
+    kshort = rf["kernel"].split("<")[0]
+    first, last = rf.get("timed_rounds", [0, 0])
+    lpr = rf["launches"] // max(1, last - first)                      # launches per round and stream
+    grids = rf.get("grids_per_kernel_launch", bench["config"]["grids_per_gpu"])
     per_q = defaultdict(list)
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            if "mgx::step_k_kernel<" in r["Kernel_Name"]:
-                per_q[(r.get("Queue_Id"), r.get("Grid_Size_X") or r.get("Grid_Size"))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-    print("== step_k_kernel per queue / launch size (threads): kernel duration vs queue cadence ==")
-    for (q, size), v in sorted(per_q.items()):
+            if f"mgx::{kshort}<" in r["Kernel_Name"]:
+                threads = int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)
+                if grids <= threads < 1.45 * grids:
+                    per_q[r.get("Queue_Id")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    print(f"== headline: {rf['kernel']} launches of the timed region (rounds [{first}, {last}) of the bench line) per queue ==")
+    lo, hi, n = None, None, 0
+    for q, v in sorted(per_q.items()):
         v.sort()
-        # the longest burst of back-to-back launches (bench.py's timed region): a new burst starts after an idle gap
-        bursts, cur = [], [v[0]]
-        for a, b in zip(v, v[1:]):
-            if b[0] - a[1] > 40_000:
-                bursts.append(cur); cur = []
-            cur.append(b)
-        bursts.append(cur)
-        body = max(bursts, key=len)
+        body = v[first * lpr: last * lpr]
+        if len(body) != (last - first) * lpr:
+            print(f"queue {q}: {len(v)} launches of that size, not the headline's queue")
+            continue
         dur = [(e - s) / 1e3 for s, e in body]
         cad = (body[-1][1] - body[0][0]) / 1e3 / len(body)
-        print(f"queue {q} threads {size}: launches={len(body)} kernel avg_us={sum(dur) / len(dur):.2f} min_us={min(dur):.2f} "
-              f"max_us={max(dur):.2f}  cadence_us={cad:.2f}")
+        lo = body[0][0] if lo is None else min(lo, body[0][0]); hi = body[-1][1] if hi is None else max(hi, body[-1][1]); n = len(body)
+        print(f"queue {q}: launches={len(body)} kernel avg_us={sum(dur) / len(dur):.2f} min_us={min(dur):.2f} "
+              f"max_us={max(dur):.2f}  queue cadence_us={cad:.2f}")
+    if n:
+        cad = (hi - lo) / 1e3 / n
+        alg = rf["algorithmic_bytes_per_launch"]
+        frac = alg / (cad * 1e-6) / 1e9 / rf["peak"]
+        print(f"timed region: {n} rounds in {(hi - lo) / 1e3:.1f} us -> {cad:.2f} us per round (one launch per queue); "
+              f"algorithmic {alg / 1e6:.1f} MB per round -> {alg / (cad * 1e-6) / 1e9:.0f} GB/s = frac {frac:.3f} of {rf['peak']:.0f} GB/s"
+              f"   [bench line: avg_launch_us {rf['avg_launch_us']:.2f}, frac {rf['frac']:.3f}]")
 
 traffic = defaultdict(dict)
 sized = defaultdict(dict)
@@ -77,12 +99,12 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:8]:
             print(f"{k[:90]:90s} dispatches={len(v)} avg={sum(v)/len(v):.1f} total={sum(v):.1f}")
         for k, v in acc.items():
-            for short in ("step_k_kernel", "step_kernel", "rollout_kernel", "observe_kernel", "expand_kernel"):
+            for short in ("step_k_kernel", "step_kernel", "rollout_kernel", "observe_kernel", "expand_kernel", "obs_windows_k_kernel"):
                 if f"mgx::{short}<" in k:
                     v2 = sorted(v)[len(v) // 4: max(len(v) // 4 + 1, 3 * len(v) // 4)]     # inter-quartile mean
                     traffic[short][counter] = sum(v2) / len(v2)
         for (k, threads), v in by_size.items():        # the same per launch size (sharded runs launch half-size grids)
-            for short in ("step_k_kernel", "step_kernel", "rollout_kernel"):
+            for short in ("step_k_kernel", "step_kernel", "rollout_kernel", "obs_windows_k_kernel"):
                 if f"mgx::{short}<" in k and len(v) >= 4:
                     v2 = sorted(v)[len(v) // 4: max(len(v) // 4 + 1, 3 * len(v) // 4)]
                     sized[short].setdefault(str(threads), {})[counter] = sum(v2) / len(v2)
