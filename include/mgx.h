@@ -204,6 +204,16 @@ int mgx_set_action_format(mgx_handle *h, int32_t format);
 int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream);
 int mgx_set_obs_mode(mgx_handle *h, int32_t mode);
 
+/* The same prefetch AHEAD of the counter, overlapped with the steps: block k of `ring` = the window columns of counter
+ * value t + ahead + k (ahead >= 1; the state columns of every block are zero and are filled in by the steps that reach
+ * them).  The kernel runs on the handle's own prefetch stream, behind everything queued on `stream` so far (the readers
+ * of the ring's previous contents); mgx_prefetch_wait(h, s) makes stream s wait for the last prefetch.  Typical use:
+ * three rings of K blocks -- while the steps walk ring r, ring r + 1 is being written and ring r - 1 is still readable by
+ * the policy (pymgrid_amd/envs.py).  The series rows do not depend on the state, so the overlap needs no other ordering.
+ * MGX_ERR_UNSUPPORTED in device-counter mode. */
+int mgx_observe_windows_ahead(mgx_handle *h, int32_t ahead, int32_t K, void *ring, mgx_stream stream);
+int mgx_prefetch_wait(mgx_handle *h, mgx_stream stream);
+
 /* Normalised observation of the current state (BaseMicrogridModule.to_normalized(state), base_module.py:157;
  * forecast window + end-of-series padding forecaster.py:120-149,215-217). */
 int mgx_observe(mgx_handle *h, void *obs, mgx_stream stream);
@@ -284,8 +294,20 @@ typedef struct mgx_fleet_item {
     uint8_t *done;                /* [N] or NULL */
     void *obs;                    /* [N, D] (or the state-only target inside a ring block) or NULL */
     double *log;                  /* [L, N] or NULL */
-    void *refill_ring;            /* [refill_K, N, D] or NULL: mgx_observe_windows(handle, refill_K, refill_ring) after the step */
+    void *refill_ring;            /* [refill_K, N, D] or NULL: window prefetch issued with this step.  Block k = the window columns of
+                                   * counter value (counter after this step) + refill_ahead + k.
+                                   *   refill_chunks == 0: the whole batch -- mgx_observe_windows (refill_ahead == 0, after the step)
+                                   *     or mgx_observe_windows_ahead (refill_ahead >= 1, on the handle's prefetch stream);
+                                   *   refill_chunks >= 1 (refill_ahead >= 1): only chunk refill_chunk of refill_chunks of the
+                                   *     batch's 16-grid groups, on `stream`, as extra workgroups of the step's own launch: a ring
+                                   *     spread over the K - 1 steps before it is needed moves at a constant rate instead of
+                                   *     one burst per K steps (state columns zero, as in mgx_observe_windows_ahead). */
     int32_t refill_K;
+    int32_t refill_ahead;
+    int32_t refill_chunk;
+    int32_t refill_chunks;
+    int32_t wait_prefetch;        /* != 0: mgx_prefetch_wait(handle, stream) before the step (its obs target lies in a ring that
+                                   * mgx_observe_windows_ahead wrote) */
     int32_t reserved;
 } mgx_fleet_item;
 int mgx_fleet_step(const mgx_fleet_item *items, int32_t n_items, int normalized, mgx_stream stream);

@@ -62,7 +62,8 @@ class FleetItem(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("n_actions", C.c_int32), ("handle", C.c_void_p), ("actions", C.c_void_p),
                 ("action_id", C.c_void_p), ("table", c_i32_p), ("reward", C.c_void_p), ("done", C.c_void_p),
                 ("obs", C.c_void_p), ("log", C.c_void_p), ("refill_ring", C.c_void_p), ("refill_K", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("refill_ahead", C.c_int32), ("refill_chunk", C.c_int32), ("refill_chunks", C.c_int32),
+                ("wait_prefetch", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Synth(C.Structure):
@@ -94,6 +95,8 @@ SYMBOLS = {
     "mgx_set_obs_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_set_action_format": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_observe_windows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgx_observe_windows_ahead": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgx_prefetch_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgx_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgx_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -31,15 +31,12 @@ constexpr int BLOCK_K = MGX_BLOCK_K;
 // ------------------------------------------------------------------------------------------------------
 // Single step: Microgrid.run for N grids (microgrid.py:227-325) + optional obs (base.py:205-209) + log.
 // ------------------------------------------------------------------------------------------------------
+// body of one step of grid i (shared by step_kernel and fleet_step_kernel)
 template <int F>
-__global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
-                                                     int normalized, double *__restrict__ reward,
-                                                     uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                     double *__restrict__ log)
+__device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict__ actions, int32_t t, int normalized,
+                                          double *__restrict__ reward, uint8_t *__restrict__ done, void *__restrict__ obs,
+                                          double *__restrict__ log, int64_t i)
 {
-    t = resolve_t(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.g1) return;
     // all loads first (independent, one latency round), then the arithmetic
     Params p; State s; Inputs in; Outputs o; Derived d;
     if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t, in);
@@ -65,6 +62,17 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *
         } else if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
         else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
     }
+}
+
+template <int F>
+__global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
+                                                     int normalized, double *__restrict__ reward,
+                                                     uint8_t *__restrict__ done, void *__restrict__ obs,
+                                                     double *__restrict__ log)
+{
+    t = resolve_t(a, t);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < a.g1) step_body<F>(a, actions, t, normalized, reward, done, obs, log, i);
     advance_counter_in_kernel(a, 1);
 }
 
@@ -364,20 +372,27 @@ struct WindowsKPlan {
     int32_t K;               // steps per launch
     int32_t rp;              // pitch of one component's rows in the image
     int32_t bp;              // pitch of one grid's block in the image (odd)
+    int32_t with_state;      // block 0 receives the state columns of the current state (0: a prefetch AHEAD of the counter)
+    int32_t group0;          // first group of this launch (a launch may cover a chunk of the batch's groups)
 };
 
-template <int F, typename OT>
-__global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArgs a, const WindowsKPlan plan, int32_t t,
-                                                                      OT *__restrict__ ring)
+#ifdef MGX_WIN_PLAIN_STORES
+#define MGX_WIN_STORE(v, p) (*(p) = (v))
+#else
+#define MGX_WIN_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+// Body shared by obs_windows_k_kernel and the window part of fleet_step_kernel: workgroup `group` (16 grids) of the batch.
+// GRID: the layout has a GridModule (6 instead of 2 series components).  `now` (meaningful in the q == 0 lanes): the state
+// columns of the current state for block 0, or nullptr (a prefetch ahead of the counter: every state column is zero).
+template <bool GRID, typename OT>
+__device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan &plan, int32_t t, OT *__restrict__ ring,
+                                             int64_t group, int32_t nstate, const double *now, double *image)
 {
-    t = resolve_t_obs(a, t);
-    constexpr int NCOMP = 2 + ((F & F_GRID) ? 4 : 0);
-    constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
-    extern __shared__ double image[];
+    constexpr int NCOMP = 2 + (GRID ? 4 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t G = plan.group, Q = OBS_K_THREADS / G, K = plan.K, RP = plan.rp, BP = plan.bp;
     const int32_t g = tid & (G - 1), q = tid / G;
-    const int64_t g0 = (int64_t)blockIdx.x * G;
+    const int64_t g0 = group * G;
     const int64_t N = a.N;
     const int32_t W = 1 + a.H, D = a.obs_dim, R = K + a.H;
     const int64_t i = g0 + g, ic = i < N ? i : g0;
@@ -387,17 +402,12 @@ __global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArg
 
     windows_k_module<1>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, R, K, ic, q, Q, blk, blk + NU0, RP);
     windows_k_module<1>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP);
-    if constexpr (F & F_GRID)
+    if constexpr (GRID)
         windows_k_module<4>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, R, K, ic, q, Q, blk + 2 * RP,
                             blk + NU0 + 2 * K, RP);
     if (q == 0) {                                        // state columns: the current state for block 0, zeros ahead
-        Params p; State s;
-        load_state<F>(a.c, ic, true, s);
-        load_params<F>(a.c, ic, p);
-        double now[8];
-        observe_state_cols<F>(a, p, s, now, 0);
-        for (int j = 0; j < NSTATE; j++) {
-            blk[S0 + j * K] = now[j];
+        for (int j = 0; j < nstate; j++) {
+            blk[S0 + j * K] = now ? now[j] : 0.0;
             for (int32_t k = 1; k < K; k++) blk[S0 + j * K + k] = 0.0;
         }
     }
@@ -423,19 +433,127 @@ __global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArg
                 vec2 v2;
                 v2.x = (OT)src[r * BP + map[c]];
                 v2.y = (OT)src[r * BP + map[c + 1]];     // D even, c even: the pair never straddles two rows
-                __builtin_nontemporal_store(v2, reinterpret_cast<vec2 *>(out + f));
+                MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out + f));
                 c += 128;
                 while (c >= D) { c -= D; r++; }
             }
         } else {
             int32_t r = lane / D, c = lane - r * D;
             for (int32_t f = lane; f < total; f += 64) {
-                __builtin_nontemporal_store((OT)src[r * BP + map[c]], out + f);
+                MGX_WIN_STORE((OT)src[r * BP + map[c]], out + f);
                 c += 64;
                 while (c >= D) { c -= D; r++; }
             }
         }
     }
+}
+
+template <int F, typename OT>
+__global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArgs a, const WindowsKPlan plan, int32_t t,
+                                                                      OT *__restrict__ ring)
+{
+    t = resolve_t_obs(a, t);
+    constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
+    extern __shared__ double image[];
+    const int64_t group = (int64_t)plan.group0 + blockIdx.x;
+    double now[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (plan.with_state && (int)threadIdx.x < plan.group) {           // the q == 0 lanes: one per grid of the group
+        const int64_t i = group * plan.group + threadIdx.x, ic = i < a.N ? i : group * plan.group;
+        Params p; State s;
+        load_state<F>(a.c, ic, true, s);
+        load_params<F>(a.c, ic, p);
+        observe_state_cols<F>(a, p, s, now, 0);
+    }
+    windows_body<(F & F_GRID) != 0, OT>(a, plan, t, ring, group, NSTATE, plan.with_state ? now : nullptr, image);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// A heterogeneous fleet in ONE launch (mgx_fleet_step): up to MGX_FLEET_MAX batches of different layouts, each with its own
+// columns / actions / outputs / step counter, laid end to end over the workgroups.  The table travels in the kernarg
+// segment (scalar loads); a workgroup finds its batch with a few scalar compares and jumps -- wave-uniformly -- to that
+// layout's specialisation of the step.  Three 33 000-grid batches cost one ~6 us launch instead of three ~5 us ones.
+// ------------------------------------------------------------------------------------------------------
+constexpr int MGX_FLEET_MAX = 6;
+// What changes from step to step travels by value (small: one scalar-load round at kernel start); the big, rarely changing
+// KArgs of every batch are read from DEVICE memory (the handle's own copy, refreshed by the host when it changes).  A table
+// of whole KArgs in the kernarg segment measured 57 us per launch: the kernarg buffer lives in host memory and the chain
+// of dependent scalar loads (which batch? -> its layout -> its columns) paid a host round trip per link.
+struct FleetArgs {
+    const KArgs *k[MGX_FLEET_MAX];               // device copies (mgx_handle::d_kargs)
+    const void *actions[MGX_FLEET_MAX];
+    double *reward[MGX_FLEET_MAX];
+    uint8_t *done[MGX_FLEET_MAX];
+    void *obs[MGX_FLEET_MAX];
+    double *log[MGX_FLEET_MAX];
+    int32_t t[MGX_FLEET_MAX], flags[MGX_FLEET_MAX], block0[MGX_FLEET_MAX];   // block0: first workgroup of the batch
+    int32_t n, normalized;
+};
+
+// Window chunks riding along with a fleet step: workgroups behind the step's own.  While the steps walk an observation
+// ring of K blocks, the ring of the NEXT K counter values is due (obs_windows_k_kernel's job); as one launch per K steps it
+// is a 150 us burst of pure writes between latency-bound step kernels.  Cut into K - 1 chunks of the batch's 16-grid
+// groups, one chunk per step, the same bytes move at a constant rate in the shadow of the step kernels' latency.
+struct FleetWin {
+    const KArgs *k[MGX_FLEET_MAX];
+    void *ring[MGX_FLEET_MAX];
+    WindowsKPlan plan[MGX_FLEET_MAX];            // plan.group0 = first group of the chunk
+    int32_t t[MGX_FLEET_MAX], block0[MGX_FLEET_MAX], kind[MGX_FLEET_MAX], nstate[MGX_FLEET_MAX];   // kind: bit 0 grid, bit 1 float rows
+    int32_t n, first_block;                      // first_block = workgroups of the step part
+};
+
+__global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArgs fa, const FleetWin fw)
+{
+    extern __shared__ double image[];
+    if (fw.n > 0 && (int)blockIdx.x >= fw.first_block) {               // ---- window chunk workgroups
+        const int b = (int)blockIdx.x - fw.first_block;
+        const KArgs *kp = fw.k[0];
+        void *ring = fw.ring[0];
+        WindowsKPlan plan = fw.plan[0];
+        int32_t t = fw.t[0], block0 = 0, kind = fw.kind[0], nstate = fw.nstate[0];
+#pragma unroll
+        for (int q = 1; q < MGX_FLEET_MAX; q++) {
+            const bool mine = q < fw.n && b >= fw.block0[q];
+            kp = mine ? fw.k[q] : kp; ring = mine ? fw.ring[q] : ring;
+            plan.grid_col_base = mine ? fw.plan[q].grid_col_base : plan.grid_col_base;
+            plan.group = mine ? fw.plan[q].group : plan.group; plan.K = mine ? fw.plan[q].K : plan.K;
+            plan.rp = mine ? fw.plan[q].rp : plan.rp; plan.bp = mine ? fw.plan[q].bp : plan.bp;
+            plan.group0 = mine ? fw.plan[q].group0 : plan.group0;
+            t = mine ? fw.t[q] : t; block0 = mine ? fw.block0[q] : block0; kind = mine ? fw.kind[q] : kind;
+            nstate = mine ? fw.nstate[q] : nstate;
+        }
+        const KArgs &a = *kp;
+        const int64_t group = (int64_t)plan.group0 + (b - block0);
+        switch (kind) {
+            case 0: windows_body<false, double>(a, plan, t, (double *)ring, group, nstate, nullptr, image); break;
+            case 1: windows_body<true, double>(a, plan, t, (double *)ring, group, nstate, nullptr, image); break;
+            case 2: windows_body<false, float>(a, plan, t, (float *)ring, group, nstate, nullptr, image); break;
+            default: windows_body<true, float>(a, plan, t, (float *)ring, group, nstate, nullptr, image); break;
+        }
+        return;
+    }
+    // which batch owns this workgroup: selects over the (<= 6) kernarg entries, no run-time indexing (that would send the
+    // struct to scratch)
+    const KArgs *kp = fa.k[0];
+    const void *actions = fa.actions[0];
+    double *reward = fa.reward[0]; uint8_t *done = fa.done[0]; void *obs = fa.obs[0]; double *log = fa.log[0];
+    int32_t t = fa.t[0], flags = fa.flags[0], block0 = 0;
+#pragma unroll
+    for (int q = 1; q < MGX_FLEET_MAX; q++) {
+        const bool mine = q < fa.n && (int)blockIdx.x >= fa.block0[q];
+        kp = mine ? fa.k[q] : kp; actions = mine ? fa.actions[q] : actions; reward = mine ? fa.reward[q] : reward;
+        done = mine ? fa.done[q] : done; obs = mine ? fa.obs[q] : obs; log = mine ? fa.log[q] : log;
+        t = mine ? fa.t[q] : t; flags = mine ? fa.flags[q] : flags; block0 = mine ? fa.block0[q] : block0;
+    }
+    const KArgs &a = *kp;                         // uniform address, read-only: scalar loads from HBM / L2
+    const int64_t i = (int64_t)((int)blockIdx.x - block0) * BLOCK + threadIdx.x;
+    if (i >= a.N) return;
+#define MGX_FLEET_CASE(FV) case FV: step_body<FV>(a, actions, t, fa.normalized, reward, done, obs, log, i); break;
+    switch (flags) {
+        MGX_FLEET_CASE(0) MGX_FLEET_CASE(1) MGX_FLEET_CASE(2) MGX_FLEET_CASE(3) MGX_FLEET_CASE(4)
+        MGX_FLEET_CASE(5) MGX_FLEET_CASE(6) MGX_FLEET_CASE(7) MGX_FLEET_CASE(14)
+        default: step_body<15>(a, actions, t, fa.normalized, reward, done, obs, log, i); break;
+    }
+#undef MGX_FLEET_CASE
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -735,6 +853,13 @@ __global__ __launch_bounds__(BLOCK) void expand_multi_kernel(const KArgs a, cons
     if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
 }
 
+// one wave that idles for `ticks` of the 100 MHz real-time counter: mgx_fork staggers the shard streams with it
+__global__ void stagger_kernel(int64_t ticks)
+{
+    const int64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // device-resident step counter (hipGraph-replayable stepping): counter[0] = t, counter[1] = overrun flag
 __global__ void set_counter_kernel(int32_t *counter, int32_t t) { counter[0] = t; counter[1] = 0; counter[2] = 0; }
 
@@ -920,6 +1045,7 @@ __global__ __launch_bounds__(BLOCK) void synthesize_series_kernel(const mgx_synt
 // ======================================================================================================
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -945,7 +1071,14 @@ struct mgx_handle {
     hipStream_t shard_stream[MGX_MAX_SHARDS];
     hipEvent_t shard_event[MGX_MAX_SHARDS];
     hipEvent_t fork_event;
+    double stagger_us;                       // mgx_fork delays shard j by j / S of this (0: off)
     hipStream_t counter_stream;              // device-counter mode: the stream of the last call that touched the counter
+    KArgs *d_kargs;                          // device copy of `k` for fleet_step_kernel, refreshed when `k` changed
+    KArgs k_uploaded;
+    bool k_uploaded_valid;
+    hipStream_t prefetch_stream;             // mgx_observe_windows_ahead: the window prefetch overlaps the steps
+    hipEvent_t prefetch_gate, prefetch_done;
+    bool prefetch_pending;
     // per-grid episode windows (mgx_reset_windows): the full series are remembered here while the handle steps over the
     // caller's window buffers
     bool windowed;
@@ -1154,6 +1287,9 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->n_shards = 1; h->shard_lo[0] = 0; h->shard_lo[1] = L->n_grids;
     for (int j = 0; j < MGX_MAX_SHARDS; j++) { h->shard_stream[j] = nullptr; h->shard_event[j] = nullptr; }
     h->fork_event = nullptr; h->counter_stream = nullptr;
+    { const char *e = getenv("MGX_FORK_STAGGER_US"); h->stagger_us = e ? atof(e) : 0.0; }
+    h->d_kargs = nullptr; h->k_uploaded_valid = false;
+    h->prefetch_stream = nullptr; h->prefetch_gate = nullptr; h->prefetch_done = nullptr; h->prefetch_pending = false;
     h->windowed = false;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
@@ -1177,6 +1313,10 @@ void mgx_destroy(mgx_handle *h)
         if (h->shard_event[j]) (void)hipEventDestroy(h->shard_event[j]);
     }
     if (h->fork_event) (void)hipEventDestroy(h->fork_event);
+    if (h->prefetch_stream) { (void)hipStreamSynchronize(h->prefetch_stream); (void)hipStreamDestroy(h->prefetch_stream); }
+    if (h->d_kargs) (void)hipFree(h->d_kargs);
+    if (h->prefetch_gate) (void)hipEventDestroy(h->prefetch_gate);
+    if (h->prefetch_done) (void)hipEventDestroy(h->prefetch_done);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->d_counter) (void)hipFree(h->d_counter);
     delete h;
@@ -1275,32 +1415,60 @@ int mgx_set_obs_mode(mgx_handle *h, int32_t mode)
     return MGX_OK;
 }
 
-int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream)
+// shape of a window prefetch: LDS image plan + bytes; n_groups = 16-grid groups of the batch
+static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const void *ring, const char *who, WindowsKPlan *plan,
+                        size_t *lds_out, int32_t *n_groups)
 {
-    g_err[0] = 0;
-    if (!h || !ring) return fail(MGX_ERR_INVALID, "mgx_observe_windows: NULL argument");
-    if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "mgx_observe_windows: K = %d outside [1, 4096]", K);
-    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_observe_windows: needs exactly one load and one renewable module per grid");
+    if (!h || !ring) return fail(MGX_ERR_INVALID, "%s: NULL argument", who);
+    if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "%s: K = %d outside [1, 4096]", who, K);
+    if (ahead < 0) return fail(MGX_ERR_INVALID, "%s: ahead = %d is negative", who, ahead);
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "%s: needs exactly one load and one renewable module per grid", who);
     if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_observe_windows: forecast noise depends on (step, horizon index), windows cannot be shared");
-    if (int rc = need_obs_bounds(h, "mgx_observe_windows")) return rc;
-    if (!dev_counter(h) && h->t > h->k.T)
-        return fail(MGX_ERR_RANGE, "mgx_observe_windows: step %d is outside the time series (length %d)", h->t, h->k.T);
+        return fail(MGX_ERR_UNSUPPORTED, "%s: forecast noise depends on (step, horizon index), windows cannot be shared", who);
+    if (int rc = need_obs_bounds(h, who)) return rc;
+    if (!dev_counter(h) && ahead == 0 && h->t > h->k.T)
+        return fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, h->k.T);
     const int32_t W = 1 + h->k.H, R = K + h->k.H, ncomp = 2 + 4 * h->layout.has_grid;
-    WindowsKPlan plan;
-    plan.grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
-    plan.K = K;
-    plan.rp = R;
-    plan.bp = (ncomp * (R + K) + 6 * K) | 1;
-    plan.group = 16;
-    auto lds_of = [&](int32_t g) { return (size_t)g * plan.bp * sizeof(double) + (size_t)h->k.obs_dim * sizeof(uint32_t); };
-    while (plan.group > 1 && lds_of(plan.group) > 160 * 1024) plan.group /= 2;
-    const size_t lds = (lds_of(plan.group) + 7) & ~(size_t)7;
+    plan->grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
+    plan->K = K;
+    plan->rp = R;
+    plan->bp = (ncomp * (R + K) + 6 * K) | 1;
+    static const int group_env = [] { const char *e = getenv("MGX_WIN_GROUP"); return e ? atoi(e) : 0; }();   // experiment knob
+    plan->group = (group_env == 8 || group_env == 4 || group_env == 16) ? group_env : 16;
+    plan->with_state = ahead == 0;
+    plan->group0 = 0;
+    auto lds_of = [&](int32_t g) { return (size_t)g * plan->bp * sizeof(double) + (size_t)h->k.obs_dim * sizeof(uint32_t); };
+    while (plan->group > 1 && lds_of(plan->group) > 160 * 1024) plan->group /= 2;
+    const size_t lds = (lds_of(plan->group) + 7) & ~(size_t)7;
     if (lds > 160 * 1024)
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_observe_windows: K + horizon = %d rows do not fit the 160 KiB LDS", R);
-    const unsigned blocks = (unsigned)(((int64_t)h->k.N + plan.group - 1) / plan.group);
-    hipStream_t st = (hipStream_t)stream;
-    const int32_t t = t_arg(h);
+        return fail(MGX_ERR_UNSUPPORTED, "%s: K + horizon = %d rows do not fit the 160 KiB LDS", who, R);
+    *lds_out = lds;
+    *n_groups = (int32_t)(((int64_t)h->k.N + plan->group - 1) / plan->group);
+    return MGX_OK;
+}
+
+// groups [chunk * per, (chunk + 1) * per) of n_groups, per = ceil(n_groups / n_chunks)
+static void chunk_range(int32_t n_groups, int32_t chunk, int32_t n_chunks, int32_t *first, int32_t *count)
+{
+    if (n_chunks <= 1) { *first = 0; *count = n_groups; return; }
+    const int32_t per = (n_groups + n_chunks - 1) / n_chunks;
+    const int64_t lo = (int64_t)chunk * per, hi = lo + per;
+    *first = (int32_t)(lo < n_groups ? lo : n_groups);
+    *count = (int32_t)((hi < n_groups ? hi : n_groups) - *first);
+}
+
+static int launch_windows(mgx_handle *h, int32_t ahead, int32_t K, void *ring, hipStream_t st, const char *who,
+                          int32_t chunk = 0, int32_t n_chunks = 1)
+{
+    WindowsKPlan plan;
+    size_t lds;
+    int32_t n_groups, first, count;
+    if (int rc = windows_plan(h, ahead, K, ring, who, &plan, &lds, &n_groups)) return rc;
+    chunk_range(n_groups, chunk, n_chunks, &first, &count);
+    if (count <= 0) return MGX_OK;
+    plan.group0 = first;
+    const unsigned blocks = (unsigned)count;
+    const int32_t t = t_arg(h) + ahead;
     if (h->k.obs_f32) {
         MGX_DISPATCH_F(h->flags, ((lds > 64 * 1024 ? (void)hipFuncSetAttribute((const void *)obs_windows_k_kernel<F, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : (void)0),
                                   obs_windows_k_kernel<F, float><<<blocks, OBS_K_THREADS, lds, st>>>(h->k, plan, t, (float *)ring)));
@@ -1310,6 +1478,45 @@ int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream)
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "obs_windows_k_kernel launch");
+}
+
+int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream)
+{
+    g_err[0] = 0;
+    return launch_windows(h, 0, K, ring, (hipStream_t)stream, "mgx_observe_windows");
+}
+
+int mgx_observe_windows_ahead(mgx_handle *h, int32_t ahead, int32_t K, void *ring, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_observe_windows_ahead: NULL handle");
+    if (ahead < 1) return fail(MGX_ERR_INVALID, "mgx_observe_windows_ahead: ahead must be >= 1 (mgx_observe_windows is the ahead = 0 form)");
+    if (dev_counter(h)) return fail(MGX_ERR_UNSUPPORTED, "mgx_observe_windows_ahead: not offered in device-counter mode (the prefetch "
+                                                         "stream would race with the kernels that move the counter)");
+    hipError_t e = hipSuccess;
+    if (!h->prefetch_stream) {
+        e = hipStreamCreateWithFlags(&h->prefetch_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prefetch_gate, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prefetch_done, hipEventDisableTiming);
+        if (e != hipSuccess) return hip_fail(e, "mgx_observe_windows_ahead: creating the prefetch stream");
+    }
+    // readers of the ring's previous contents were queued on `stream`: the prefetch starts behind them
+    e = hipEventRecord(h->prefetch_gate, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->prefetch_stream, h->prefetch_gate, 0);
+    if (e != hipSuccess) return hip_fail(e, "mgx_observe_windows_ahead: ordering behind the caller's stream");
+    if (int rc = launch_windows(h, ahead, K, ring, h->prefetch_stream, "mgx_observe_windows_ahead")) return rc;
+    e = hipEventRecord(h->prefetch_done, h->prefetch_stream);
+    h->prefetch_pending = true;
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "mgx_observe_windows_ahead: recording the completion event");
+}
+
+int mgx_prefetch_wait(mgx_handle *h, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_prefetch_wait: NULL handle");
+    if (!h->prefetch_pending) return MGX_OK;
+    hipError_t e = hipStreamWaitEvent((hipStream_t)stream, h->prefetch_done, 0);
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "mgx_prefetch_wait");
 }
 
 int mgx_observe(mgx_handle *h, void *obs, mgx_stream stream)
@@ -1459,6 +1666,14 @@ int mgx_fork(mgx_handle *h, mgx_stream stream)
     if (h->n_shards <= 1) return MGX_OK;
     hipError_t e = hipEventRecord(h->fork_event, (hipStream_t)stream);
     for (int j = 0; j < h->n_shards && e == hipSuccess; j++) e = hipStreamWaitEvent(h->shard_stream[j], h->fork_event, 0);
+    // Stagger: shard j starts j / S of `stagger_us` late, so that the launch boundaries of the shards -- which otherwise
+    // all start together after a fork and, their kernels being equally long, STAY together -- interleave: one range's
+    // ramp-up / tail then always falls into the others' steady state (mgx_set_shard_stagger; 0 = off).
+    if (h->stagger_us > 0)
+        for (int j = 1; j < h->n_shards && e == hipSuccess; j++) {
+            stagger_kernel<<<1, 64, 0, h->shard_stream[j]>>>((int64_t)(h->stagger_us * 100.0 * j / h->n_shards));
+            e = hipGetLastError();
+        }
     return e == hipSuccess ? MGX_OK : hip_fail(e, "mgx_fork");
 }
 
@@ -1681,6 +1896,7 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
 {
     g_err[0] = 0;
     if (!items || n <= 0) return fail(MGX_ERR_INVALID, "mgx_fleet_step: no items");
+    hipStream_t st = (hipStream_t)stream;
     for (int32_t j = 0; j < n; j++) {                       // all checks first: a fleet step is all or nothing
         const mgx_fleet_item &it = items[j];
         if (it.struct_size != (int32_t)sizeof(mgx_fleet_item))
@@ -1689,23 +1905,101 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
         if (it.action_id) {
             if (!it.table || !it.reward) return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d: NULL table / reward", j);
         } else if (int rc = check_step_args(it.handle, it.actions, it.reward, it.obs, 1, "mgx_fleet_step")) return rc;
-        if (it.refill_ring && it.refill_K < 1) return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d: refill_K < 1", j);
+        if (it.refill_ring) {
+            if (it.refill_K < 1 || it.refill_ahead < 0 || it.refill_chunks < 0 || it.refill_chunk < 0 ||
+                (it.refill_chunks > 0 && (it.refill_chunk >= it.refill_chunks || it.refill_ahead < 1)))
+                return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d: bad refill_K / refill_ahead / refill_chunk(s)", j);
+            WindowsKPlan plan; size_t lds; int32_t ng;
+            if (int rc = windows_plan(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, "mgx_fleet_step", &plan, &lds, &ng)) return rc;
+        }
     }
-    for (int32_t j = 0; j < n; j++) {
+    // one launch for all batches when every item is a plain continuous step (the common fleet)
+    bool fusable = true;
+    for (int32_t j = 0; j < n && fusable; j++) {
+        const mgx_fleet_item &it = items[j];
+        const mgx_handle *h = it.handle;
+        fusable = !it.action_id && !h->multi && !dev_counter(h) && h->n_shards <= 1 &&
+                  !(it.obs && h->k.H > 0 && !h->k.obs_state_only);
+        for (int32_t q = 0; q < j && fusable; q++) fusable = items[q].handle != it.handle;      // a batch steps once per call
+    }
+    bool chunk_done[64];                                    // window chunks that rode along with the step launch
+    for (int32_t j = 0; j < n && j < 64; j++) chunk_done[j] = false;
+    for (int32_t j = 0; j < n; j++)
+        if (items[j].wait_prefetch) { if (int rc = mgx_prefetch_wait(items[j].handle, stream)) return rc; }
+    if (fusable) {
+        for (int32_t j = 0; j < n; j++) {                 // device copies of the batches' KArgs: uploaded when they changed
+            mgx_handle *h = items[j].handle;
+            if (h->k_uploaded_valid && memcmp(&h->k, &h->k_uploaded, sizeof(KArgs)) == 0) continue;
+            hipError_t e = hipSuccess;
+            if (!h->d_kargs) e = hipMalloc((void **)&h->d_kargs, sizeof(KArgs));
+            if (e == hipSuccess) e = hipMemcpyAsync(h->d_kargs, &h->k, sizeof(KArgs), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return hip_fail(e, "mgx_fleet_step: uploading the layout table");
+            memcpy(&h->k_uploaded, &h->k, sizeof(KArgs));
+            h->k_uploaded_valid = true;
+        }
+        for (int32_t j0 = 0; j0 < n; j0 += MGX_FLEET_MAX) {
+            FleetArgs fa;
+            FleetWin fw;
+            memset(&fa, 0, sizeof(fa));
+            memset(&fw, 0, sizeof(fw));
+            fa.n = n - j0 < MGX_FLEET_MAX ? n - j0 : MGX_FLEET_MAX;
+            fa.normalized = normalized;
+            int32_t blocks = 0, wblocks = 0;
+            size_t lds_max = 0;
+            for (int32_t q = 0; q < fa.n; q++) {
+                const mgx_fleet_item &it = items[j0 + q];
+                mgx_handle *h = it.handle;
+                fa.k[q] = h->d_kargs;
+                fa.actions[q] = it.actions; fa.reward[q] = it.reward; fa.done[q] = it.done; fa.obs[q] = it.obs; fa.log[q] = it.log;
+                fa.t[q] = h->t; fa.flags[q] = h->flags; fa.block0[q] = blocks;
+                blocks += (int32_t)blocks_for(h->k.N);
+                if (it.refill_ring && it.refill_chunks > 0 && j0 + q < 64) {        // this step's share of the next ring
+                    WindowsKPlan plan; size_t lds; int32_t ng, first, count;
+                    (void)windows_plan(h, it.refill_ahead, it.refill_K, it.refill_ring, "mgx_fleet_step", &plan, &lds, &ng);
+                    if (lds > 64 * 1024) continue;                                   // launched on its own below
+                    chunk_range(ng, it.refill_chunk, it.refill_chunks, &first, &count);
+                    chunk_done[j0 + q] = true;
+                    if (count <= 0) continue;
+                    const int w = fw.n++;
+                    plan.group0 = first;
+                    fw.k[w] = h->d_kargs; fw.ring[w] = it.refill_ring; fw.plan[w] = plan;
+                    fw.t[w] = h->t + 1 + it.refill_ahead;
+                    fw.block0[w] = wblocks;
+                    fw.kind[w] = (h->layout.has_grid ? 1 : 0) | (h->k.obs_f32 ? 2 : 0);
+                    fw.nstate[w] = 4 * h->layout.has_genset + 2 * h->layout.has_battery;
+                    wblocks += count;
+                    if (lds > lds_max) lds_max = lds;
+                }
+            }
+            fw.first_block = blocks;
+            fleet_step_kernel<<<(unsigned)(blocks + wblocks), BLOCK, lds_max, st>>>(fa, fw);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "fleet_step_kernel launch");
+        }
+        for (int32_t j = 0; j < n; j++) advance(items[j].handle, 1, st);
+    }
+    for (int32_t j = 0; j < n && !fusable; j++) {
         const mgx_fleet_item &it = items[j];
         int rc;
         if (it.action_id)
             rc = mgx_step_discrete(it.handle, it.action_id, it.table, it.n_actions, nullptr, it.reward, it.done, it.obs, it.log, stream);
         else
-            rc = step_once(it.handle, it.actions, normalized, it.reward, it.done, it.obs, it.log, (hipStream_t)stream);
+            rc = step_once(it.handle, it.actions, normalized, it.reward, it.done, it.obs, it.log, st);
         if (rc) return rc;
     }
-    for (int32_t j = 0; j < n; j++)                         // window prefetch of the buckets whose ring is used up
-        if (items[j].refill_ring)
-            if (int rc = mgx_observe_windows(items[j].handle, items[j].refill_K, items[j].refill_ring, stream)) return rc;
+    for (int32_t j = 0; j < n; j++) {                       // window prefetch that did not ride along with the step launch
+        const mgx_fleet_item &it = items[j];
+        if (!it.refill_ring || (j < 64 && chunk_done[j])) continue;
+        int rc;
+        if (it.refill_chunks > 0)                           // a chunk, on the caller's stream (the counter has advanced: ahead as given)
+            rc = launch_windows(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, st, "mgx_fleet_step", it.refill_chunk, it.refill_chunks);
+        else
+            rc = it.refill_ahead > 0 ? mgx_observe_windows_ahead(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, stream)
+                                     : mgx_observe_windows(it.handle, it.refill_K, it.refill_ring, stream);
+        if (rc) return rc;
+    }
     return MGX_OK;
 }
-
 
 int mgx_synthesize_series(const mgx_synth *a, mgx_stream stream)
 {

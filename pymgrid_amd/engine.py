@@ -121,6 +121,19 @@ class StepEngine:
         self._call(self._lib.mgx_observe_windows, int(out.shape[0]), out.data_ptr())
         return out
 
+    def observe_windows_ahead(self, ahead, out):
+        """``mgx_observe_windows_ahead``: the window columns of counter values t + ahead .. t + ahead + K - 1 into ``out``
+        [K, N, D], written on the engine's prefetch stream behind everything queued on torch's current stream."""
+        if out.dim() != 3 or tuple(out.shape[1:]) != (self.N, self.obs_dim) or out.dtype != self.obs_dtype \
+                or not out.is_contiguous() or out.device != self.device:
+            raise ValueError(f"ring must be a contiguous {self.obs_dtype} tensor [K, {self.N}, {self.obs_dim}] on {self.device}")
+        self._call(self._lib.mgx_observe_windows_ahead, int(ahead), int(out.shape[0]), out.data_ptr())
+        return out
+
+    def prefetch_wait(self):
+        """Torch's current stream waits for the last ``observe_windows_ahead``."""
+        self._call(self._lib.mgx_prefetch_wait)
+
     def _obs_buf(self, out):
         if out is None:
             return torch.empty((self.N, self.obs_dim), dtype=self.obs_dtype, device=self.device)

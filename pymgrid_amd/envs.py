@@ -47,19 +47,26 @@ class BatchedMicrogridEnv:
         self.engine = StepEngine(batch, obs_dtype=obs_dtype, action_dtype=action_dtype)
         # obs_prefetch=K (> 1): the forecast windows of the next K steps are written in one launch every K steps
         # (engine.observe_windows: each series value read and normalised once instead of 1 + horizon times) and a step
-        # only adds the genset / battery state columns.  Same values; the returned obs is a view into a [K, N, D] ring
-        # and stays valid for K - 1 further steps.  Ignored (per-step rows) where there is nothing to share: no
+        # only adds the genset / battery state columns.  Same values; the returned obs is a view into a ring of K blocks
+        # and stays valid for at least K further steps.  Ignored (per-step rows) where there is nothing to share: no
         # forecast horizon, forecast noise, several load / renewable modules, observations off.
         L = self.layout
         noisy = batch.forecast_noise is not None or any(batch.cols.get(k) is not None
                                                         for k in ("load_noise_std", "pv_noise_std", "grid_noise_std"))
         self.obs_prefetch = int(obs_prefetch) if (obs_prefetch and int(obs_prefetch) > 1 and observations and L.horizon > 0
                                                    and L.n_load == 1 and L.n_pv == 1 and not noisy) else 0
-        self._ring = None
+        # Three rings of K blocks: while the steps walk ring r, the windows of ring r + 1 (the NEXT K counter values) are
+        # being written on the engine's prefetch stream (mgx_observe_windows_ahead -- the series rows do not depend on the
+        # state, so this overlaps the step kernels), and ring r - 1 is still intact for whoever holds observations from it.
+        self._ring = self._rings = None
         if self.obs_prefetch:
-            self._ring = torch.empty(self.obs_prefetch, L.n_grids, L.obs_dim, dtype=obs_dtype, device=batch.device)
-            self._ring_pos = 0
+            self._rings = torch.empty(3, self.obs_prefetch, L.n_grids, L.obs_dim, dtype=obs_dtype, device=batch.device)
+            self._ring_idx, self._ring_pos = 0, 0
+            self._ring = self._rings[0]
             self.engine.set_obs_state_only(True)
+        # True inside a fused BucketedFleet: the next ring is written in K - 1 chunks that ride along with the fleet's step
+        # launches (mgx_fleet_item.refill_chunk), not by this env's prefetch stream; such an env is stepped by its fleet only
+        self._chunked = False
         self.reward_shaping_func = reward_shaping_func
         self.engine.set_reward_shaper(shaper_kind(reward_shaping_func))
         self.trajectory_func = trajectory_func
@@ -161,25 +168,59 @@ class BatchedMicrogridEnv:
         return st + t
 
     def _refill(self):
+        """Fill ring 0 for the counter values t .. t + K - 1 (block 0 complete: current state) and start the prefetch of
+        the next K behind it."""
+        self._ring_idx, self._ring_pos = 0, 0
+        self._ring = self._rings[0]
         self.engine.observe_windows(out=self._ring)
-        self._ring_pos = 0
+        if not self._chunked:
+            self.engine.observe_windows_ahead(self.obs_prefetch, out=self._rings[1])
         return self._ring[0]
 
-    def _obs_target(self):
-        """Where the coming step's observation goes: the next ring block (state columns only), or nowhere when the
-        ring is used up (the windows are then refilled after the step)."""
+    def _obs_plan(self):
+        """Where the coming step's observation goes: (want_obs, target tensor or None, wait for the prefetch first).  With a
+        ring the target is the next block (the step adds the state columns): of the current ring, or block 0 of the
+        prefetched one."""
         if self._ring is None:
-            return self._observations, None
+            return self._observations, None, False
         if self._ring_pos + 1 < self.obs_prefetch:
-            return True, dict(obs=self._ring[self._ring_pos + 1])
-        return False, None
+            return True, self._ring[self._ring_pos + 1], False
+        return True, self._rings[(self._ring_idx + 1) % 3][0], not self._chunked
+
+    def _obs_commit(self):
+        """After the step: advance inside the ring, or move on to the prefetched ring -- then the ring after it is due:
+        returns (ring tensor, ahead) for ``observe_windows_ahead``, else None."""
+        if self._ring is None:
+            return None
+        if self._ring_pos + 1 < self.obs_prefetch:
+            self._ring_pos += 1
+            return None
+        self._ring_idx = (self._ring_idx + 1) % 3
+        self._ring = self._rings[self._ring_idx]
+        self._ring_pos = 0
+        return None if self._chunked else (self._rings[(self._ring_idx + 1) % 3], self.obs_prefetch)
+
+    def _chunk_plan(self):
+        """Chunked mode: this step's share of the NEXT ring, as (ring tensor, ahead, chunk, n_chunks) -- ahead counted from the
+        counter value after the step -- or None on the last position of a ring (the next ring is complete by then)."""
+        K = self.obs_prefetch
+        if self._ring is None or not self._chunked or self._ring_pos > K - 2:
+            return None
+        return self._rings[(self._ring_idx + 1) % 3], K - self._ring_pos - 1, self._ring_pos, K - 1
+
+    def _obs_target(self):
+        if self._chunked and self._ring is not None:
+            raise RuntimeError("this env belongs to a fused BucketedFleet (its observation rings are refilled by the fleet's "
+                               "step launches): step it through fleet.step(), or build the fleet with fused=False")
+        want, target, wait = self._obs_plan()
+        if wait:
+            self.engine.prefetch_wait()
+        return want, (None if target is None else dict(obs=target))
 
     def _obs_after(self, obs):
-        if self._ring is None:
-            return obs
-        if obs is None:
-            return self._refill()
-        self._ring_pos += 1
+        refill = self._obs_commit()
+        if refill is not None:
+            self.engine.observe_windows_ahead(refill[1], out=refill[0])
         return obs
 
     def _select_obs(self, obs):

@@ -25,7 +25,8 @@ class BucketedFleet:
     per-grid quantity (reward, done, ...) back into fleet order.
     """
 
-    def __init__(self, grids, device="cuda", discrete=False, streams=False, **env_kwargs):
+    def __init__(self, grids, device="cuda", discrete=False, streams=False, reuse_outputs=0, fused=True, **env_kwargs):
+        self._init_fused(reuse_outputs, fused)
         self.n_grids = len(grids)
         self.device = torch.device(device)
         self.buckets = list(bucket_by_layout(grids).items())          # [(key, [indices])]
@@ -36,12 +37,29 @@ class BucketedFleet:
             self.index.append(torch.as_tensor(np.asarray(idx), device=self.device))
         self.streams = [torch.cuda.Stream(device=self.device) for _ in self.envs] \
             if (streams and self.device.type == "cuda") else []
+        self._decide_fused()
+
+    def _decide_fused(self):
+        """Fused mode (one ``mgx_fleet_step`` call per fleet step, ring refills in chunks inside the step launches) unless
+        the fleet was asked for per-bucket streams / per-env steps or holds envs that need host work per step."""
+        self.fused = bool(self._want_fused and not self.streams and not any(env.raise_errors for env in self.envs)
+                          and not any(isinstance(env, DiscreteBatchedMicrogridEnv) and L_multi(env.layout) for env in self.envs))
+        for env in self.envs:
+            env._chunked = self.fused and not isinstance(env, DiscreteBatchedMicrogridEnv) and not L_multi(env.layout)
+
+    def _init_fused(self, reuse_outputs, fused=True):
+        # reuse_outputs = R > 0: step() returns reward / done as views into R rotating buffers per bucket (valid for R - 1
+        # further steps) instead of fresh tensors -- no allocation on the hot path
+        self.reuse_outputs = int(reuse_outputs)
+        self._want_fused = bool(fused)
+        self._plans, self._n_steps, self._out_reward, self._out_done = {}, 0, None, None
 
     @classmethod
-    def from_batches(cls, batches, discrete=False, streams=False, **env_kwargs):
+    def from_batches(cls, batches, discrete=False, streams=False, reuse_outputs=0, fused=True, **env_kwargs):
         """Fleet over ready-made ``MicrogridBatch`` objects (e.g. ``generator.generate`` per architecture): bucket k owns
         fleet positions [sum(n_0..n_{k-1}), ... + n_k)."""
         self = cls.__new__(cls)
+        self._init_fused(reuse_outputs, fused)
         self.device = batches[0].device
         env_cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
         self.envs, self.index, self.buckets, start = [], [], [], 0
@@ -54,6 +72,7 @@ class BucketedFleet:
         self.n_grids = start
         self.streams = [torch.cuda.Stream(device=self.device) for _ in self.envs] \
             if (streams and self.device.type == "cuda") else []
+        self._decide_fused()
         return self
 
     def __len__(self):
@@ -83,66 +102,113 @@ class BucketedFleet:
         Buckets on the caller's stream go through ONE call of the C ABI (``mgx_fleet_step``): every bucket's step launch
         and, where a bucket's observation ring is used up, its window prefetch are issued from C back to back -- three
         Python-level ``env.step`` calls cost ~30 us, more than the kernels of a 100 000-grid fleet step take."""
-        if self.streams or any(env.raise_errors for env in self.envs) or any(isinstance(a, dict) for a in actions) \
-                or any(isinstance(env, DiscreteBatchedMicrogridEnv) and L_multi(env.layout) for env in self.envs):
+        if not self.fused:
             res = self._each(lambda env, k: env.step(actions[k], **kw))
             return tuple(list(x) for x in zip(*res))
+        actions = [env.control_to_tensor(a).to(env.engine.action_dtype) if isinstance(a, dict) else a
+                   for env, a in zip(self.envs, actions)]
         return self._step_fused(actions, **kw)
 
-    def _step_fused(self, actions, normalized=True):
+    def _plan(self, key):
+        """Everything about a fleet step that depends only on where the envs stand in their observation rings (and, with
+        ``reuse_outputs``, on the output slot): the filled-in ``mgx_fleet_item`` array (all but the action pointers), the
+        observation views the step returns and the ring state after it.  A fleet that walks its rings in lock-step meets
+        3 K such situations, so after the first lap a step costs a dictionary look-up instead of ~25 us of bookkeeping."""
         import ctypes as C
         from . import _lib
-        from .engine import _raw_stream
-        items = getattr(self, "_items", None)
-        if items is None:
-            items = self._items = (_lib.FleetItem * len(self.envs))()
-            for it, env in zip(items, self.envs):
-                it.struct_size = C.sizeof(_lib.FleetItem)
-                it.handle = env.engine._h.value
-                if isinstance(env, DiscreteBatchedMicrogridEnv):
-                    it.table, it.n_actions = env.engine._table_ptr(env._table)
-        obs_l, reward_l, done_l, info_l, refills = [], [], [], [], []
-        for it, env, a in zip(items, self.envs, actions):
+        states, slot = key
+        n = len(self.envs)
+        items = (_lib.FleetItem * n)()
+        obs_l, next_states, fixed_out = [], [], []
+        for k, (it, env, st) in enumerate(zip(items, self.envs, states)):
             e = env.engine
-            discrete = isinstance(env, DiscreteBatchedMicrogridEnv)
-            if discrete:
+            it.struct_size = C.sizeof(_lib.FleetItem)
+            it.handle = e._h.value
+            if isinstance(env, DiscreteBatchedMicrogridEnv):
+                it.table, it.n_actions = e._table_ptr(env._table)
+            if st is not None:
+                env._ring_idx, env._ring_pos = st
+                env._ring = env._rings[st[0]]
+            want_obs, target, wait = env._obs_plan()
+            chunk = env._chunk_plan()             # chunked envs: this step's share of the next ring
+            refill = env._obs_commit()            # other envs: (ring, ahead) when this step moves on to the prefetched ring
+            next_states.append((env._ring_idx, env._ring_pos) if st is not None else None)
+            obs = target if want_obs else None
+            it.obs = None if obs is None else obs.data_ptr()
+            it.wait_prefetch = int(wait)
+            if chunk:
+                it.refill_ring, it.refill_K = chunk[0].data_ptr(), env.obs_prefetch
+                it.refill_ahead, it.refill_chunk, it.refill_chunks = chunk[1], chunk[2], chunk[3]
+            else:
+                it.refill_ring = refill[0].data_ptr() if refill else None
+                it.refill_K, it.refill_ahead = (env.obs_prefetch, refill[1]) if refill else (0, 0)
+            obs_l.append((obs, want_obs and obs is None))          # (ring view, needs a fresh row buffer per step)
+            if slot is not None:                                     # rotating output buffers: pointers are part of the plan
+                r, d = self._out_reward[k][slot], self._out_done[k][slot]
+                it.reward, it.done = r.data_ptr(), d.data_ptr()
+                fixed_out.append((r, d.view(torch.bool)))
+        return items, obs_l, next_states, fixed_out
+
+    def _step_fused(self, actions, normalized=True):
+        from . import _lib
+        from .engine import _raw_stream
+        envs = self.envs
+        R = self.reuse_outputs
+        if R and self._out_reward is None:
+            self._out_reward = [e.engine._empty(R, e.engine.N) for e in envs]
+            self._out_done = [e.engine._empty(R, e.engine.N, dtype=torch.uint8) for e in envs]
+        slot = (self._n_steps % R) if R else None
+        key = (tuple((e._ring_idx, e._ring_pos) if e._ring is not None else None for e in envs), slot)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._plan(key)
+        items, obs_plan, next_states, fixed_out = plan
+        obs_l, reward_l, done_l, info_l = [], [], [], []
+        for k, (it, env, a) in enumerate(zip(items, envs, actions)):
+            e = env.engine
+            if it.table:                          # discrete bucket: priority-list ids
                 if not (torch.is_tensor(a) and a.dtype == torch.int32 and a.is_contiguous() and a.device == e.device
-                        and tuple(a.shape) == (e.N,)):
+                        and a.shape == (e.N,)):
                     a = torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a), device=e.device).to(torch.int32).contiguous()
                 it.action_id = a.data_ptr()
             else:
                 a = e._check_actions(a, ())
                 it.actions = None if a is None else a.data_ptr()
-            want_obs, out = env._obs_target()
-            reward = e._empty(e.N)
-            done = e._empty(e.N, dtype=torch.uint8)
-            obs = (out["obs"] if out else e._obs_buf(None)) if want_obs else None
-            log = e._empty(e.log_dim, e.N) if env._keep_log else None
-            refill = env._ring is not None and not want_obs
-            it.reward, it.done = reward.data_ptr(), done.data_ptr()
-            it.obs = None if obs is None else obs.data_ptr()
-            it.log = None if log is None else log.data_ptr()
-            it.refill_ring = env._ring.data_ptr() if refill else None
-            it.refill_K = env.obs_prefetch if refill else 0
-            refills.append(refill)
-            obs_l.append(obs); reward_l.append(reward); done_l.append(done.view(torch.bool)); info_l.append({} if log is None else {"log": log})
-        e0 = self.envs[0].engine
+            obs, fresh = obs_plan[k]
+            if fresh:
+                obs = e._obs_buf(None)
+                it.obs = obs.data_ptr()
+            if R:
+                reward, done = fixed_out[k]
+            else:
+                reward, d8 = e._empty(e.N), e._empty(e.N, dtype=torch.uint8)
+                it.reward, it.done = reward.data_ptr(), d8.data_ptr()
+                done = d8.view(torch.bool)
+            if env._keep_log:
+                log = e._empty(e.log_dim, e.N)
+                it.log = log.data_ptr()
+                info_l.append({"log": log})
+            else:
+                info_l.append({})
+            obs_l.append(obs); reward_l.append(reward); done_l.append(done)
+        e0 = envs[0].engine
         idx = e0._dev_index
         if e0._only_device or torch.cuda.current_device() == idx:
-            rc = e0._lib.mgx_fleet_step(items, len(self.envs), 1 if normalized else 0, _raw_stream(idx))
+            rc = e0._lib.mgx_fleet_step(items, len(envs), 1 if normalized else 0, _raw_stream(idx))
         else:
             with torch.cuda.device(idx):
-                rc = e0._lib.mgx_fleet_step(items, len(self.envs), 1 if normalized else 0, _raw_stream(idx))
-        _lib.check(rc)
-        for k, (env, refill) in enumerate(zip(self.envs, refills)):
-            if env._ring is not None:
-                if refill:
-                    env._ring_pos = 0
-                    obs_l[k] = env._ring[0]
-                else:
-                    env._ring_pos += 1
-            obs_l[k] = env._select_obs(obs_l[k])
-            if info_l[k]:
+                rc = e0._lib.mgx_fleet_step(items, len(envs), 1 if normalized else 0, _raw_stream(idx))
+        if rc:
+            _lib.check(rc)
+        self._n_steps += 1
+        for k, env in enumerate(envs):
+            st = next_states[k]
+            if st is not None:
+                env._ring_idx, env._ring_pos = st
+                env._ring = env._rings[st[0]]
+            if env._obs_index is not None:
+                obs_l[k] = env._select_obs(obs_l[k])
+            if env._keep_log:
                 env._log_rows.append(info_l[k]["log"])
                 env._shaped_rows.append(reward_l[k].clone())
         return obs_l, reward_l, done_l, info_l

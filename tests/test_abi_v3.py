@@ -232,10 +232,11 @@ def test_fleet_step_in_one_call_equals_per_env_steps(prefetch, discrete, pymgrid
     kw = dict(device=device, observations=True, obs_prefetch=prefetch, log=True, discrete=discrete)
     if discrete:
         kw["remove_redundant_gensets"] = False
-    fused, plain = BucketedFleet(pymgrid25, **kw), BucketedFleet(pymgrid25, **kw)
+    fused, plain = BucketedFleet(pymgrid25, **kw), BucketedFleet(pymgrid25, fused=False, **kw)
+    assert fused.fused and not plain.fused
     o1, o2 = fused.reset(), plain.reset()
     g = torch.Generator(device=device); g.manual_seed(0)
-    for k in range(21):
+    for k in range(29):
         acts = fused.sample_action(generator=g)
         r1 = fused.step(acts)
         r2 = [env.step(a) for env, a in zip(plain.envs, acts)]
@@ -244,10 +245,40 @@ def test_fleet_step_in_one_call_equals_per_env_steps(prefetch, discrete, pymgrid
             assert torch.equal(r1[1][b], r2[b][1]) and torch.equal(r1[2][b], r2[b][2]), (k, b)
             assert torch.equal(r1[3][b]["log"], r2[b][3]["log"]), (k, b)
     for e1, e2 in zip(fused.envs, plain.envs):
-        assert e1.current_step == e2.current_step == 21
+        assert e1.current_step == e2.current_step == 29
         for name in ("charge", "soc", "gen_status"):
             if name in e1.batch.cols:
                 assert torch.equal(e1.batch.cols[name], e2.batch.cols[name])
         la, lb = e1.get_log(), e2.get_log()
         assert all(np.array_equal(la[c], lb[c]) for c in la)
     fused.close(); plain.close()
+
+
+def test_prefetched_observations_stay_valid_for_k_steps(device):
+    """obs_prefetch=K with the windows written AHEAD on the prefetch stream (mgx_observe_windows_ahead, three rings): every
+    observation equals the per-step kernel's, and the view returned by a step is still intact K steps later (the ring it
+    lives in is only refilled after that)."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    from pymgrid_amd.generator import generate
+    N, T, H, K = 3001, 120, 24, 4
+    make = lambda: generate(N, n_steps=T, seed=5, arch="genset+battery+grid", horizon=H, device=device, mixed_timers=True)
+    ref, pre = BatchedMicrogridEnv(make()), BatchedMicrogridEnv(make(), obs_prefetch=K)
+    g = torch.Generator(device=device); g.manual_seed(2)
+    held = []
+    o_ref, o_pre = ref.reset(), pre.reset()
+    assert torch.equal(o_ref, o_pre)
+    held.append((o_pre, o_pre.clone()))
+    for k in range(5 * K + 2):
+        a = torch.rand(N, 4, dtype=torch.float64, device=device, generator=g)
+        o_ref, o_pre = ref.step(a)[0], pre.step(a)[0]
+        assert torch.equal(o_ref, o_pre), k
+        held.append((o_pre, o_pre.clone()))
+        if len(held) > K:
+            view, snap = held[-1 - K]
+            assert torch.equal(view, snap), k
+    # a reset in the middle of a ring (a prefetch is in flight) starts over cleanly
+    assert torch.equal(ref.reset(30), pre.reset(30))
+    for k in range(K + 1):
+        a = torch.rand(N, 4, dtype=torch.float64, device=device, generator=g)
+        assert torch.equal(ref.step(a)[0], pre.step(a)[0]), k
+    ref.close(); pre.close()
