@@ -462,8 +462,6 @@ def main():
         for mode in ("fused", "step", "rbc"):
             if mode != args.mode:
                 results[mode] = measure(mode, sharded=(S > 1 and mode == "fused"), rounds=side[0], warmup=side[1])
-        if S > 1:    # single-step launches over the shard streams: a range's kernel boundary overlaps the other's kernel
-            results["step_sharded"] = measure("step", sharded=True, rounds=side[0], warmup=side[1])
         if S > 1:    # the same fused kernel as ONE launch sequence over all N grids
             results["fused_one_stream"] = measure("fused", sharded=False, rounds=side[0], warmup=side[1])
         results["step_python"] = measure("step_python", sharded=False, rounds=min(side[0], 32), warmup=min(side[1], 8))
@@ -484,8 +482,7 @@ def main():
     if rank == 0:
         main_r = results[args.mode]
         names = {"fused": "fused_launches", "step": "single_step_launches_one_call", "rbc": "rbc_rollout_on_device",
-                 "fused_one_stream": "fused_launches_one_stream", "step_python": "single_step_launches_python_loop",
-                 "step_sharded": "single_step_launches_one_call_sharded"}
+                 "fused_one_stream": "fused_launches_one_stream", "step_python": "single_step_launches_python_loop"}
         line = {
             "metric": "microgrid env-steps/sec", "value": main_r["value"], "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_r["ms_per_step"],

@@ -332,7 +332,8 @@ typedef struct mgx_synth {
     const double *outage_per_day;                           /* [N] randn * 3/4 + 0.25 (:291) */
     const int32_t *outage_duration;                         /* [N] randint(1, 8) (:292) */
     uint64_t seed;
-    int64_t grid_index0;
+    int64_t grid_index0;                                    /* global index of grid 0 ... */
+    const int64_t *grid_index;                              /* ... or [N] global indices (a scattered selection); NULL: grid_index0 + i */
     double *load_ts, *pv_ts;                                /* out [T, N] */
     double *grid_ts;                                        /* out [T, 4, N] or NULL */
 } mgx_synth;

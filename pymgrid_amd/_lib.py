@@ -73,7 +73,7 @@ class Synth(C.Structure):
                 + [(n, C.c_void_p) for n in ("base_load", "base_pv", "base_co2", "load_profile", "pv_profile", "co2_profile",
                                              "load_ratio", "pv_ratio", "tariff", "weak", "outage_per_day",
                                              "outage_duration")]
-                + [("seed", C.c_uint64), ("grid_index0", C.c_int64)]
+                + [("seed", C.c_uint64), ("grid_index0", C.c_int64), ("grid_index", C.c_void_p)]
                 + [(n, C.c_void_p) for n in ("load_ts", "pv_ts", "grid_ts")])
 
 # every symbol include/mgx.h declares: (restype, argtypes)

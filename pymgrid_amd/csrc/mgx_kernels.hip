@@ -1016,16 +1016,17 @@ __global__ __launch_bounds__(BLOCK) void synthesize_series_kernel(const mgx_synt
         dur = a.outage_duration ? a.outage_duration[i] : 1;
     }
     const bool weak = grid && a.outage_per_day != nullptr && a.weak[i] != 0;
+    const int64_t gi = a.grid_index ? a.grid_index[i] : a.grid_index0 + i;      // the Philox counter: GLOBAL grid index
     // rows still covered by an outage that starts later: the extra draw of row T (the reference draws T + 1 values) first
     int32_t cover = 0;
-    if (weak && synth_uniform(a.seed, a.grid_index0 + i, T) < prob) cover = dur - 1;
+    if (weak && synth_uniform(a.seed, gi, T) < prob) cover = dur - 1;
     for (int32_t t = T - 1; t >= 0; t--) {
         a.load_ts[(int64_t)t * N + i] = -1.0 * fabs(a.base_load[(int64_t)t * a.n_load_profiles + lp] * lr);   // stored sign
         a.pv_ts[(int64_t)t * N + i] = fabs(a.base_pv[(int64_t)t * a.n_pv_profiles + pp] * pr);
         if (grid) {
             double status = 1.0;
             if (weak) {
-                const bool own = synth_uniform(a.seed, a.grid_index0 + i, t) < prob;
+                const bool own = synth_uniform(a.seed, gi, t) < prob;
                 status = (own || (cover > 0 && t > 0)) ? 0.0 : 1.0;             // "if i-j > 0": the back-fill spares row 0
                 cover = own ? dur - 1 : (cover > 0 ? cover - 1 : 0);
             }

@@ -167,6 +167,12 @@ class BatchedMicrogridEnv:
             return torch.full((self.n_grids,), t, dtype=torch.int32, device=self.batch.device)
         return st + t
 
+    def _after_external_steps(self):
+        """The engine was stepped behind the env's back (fused rollouts: ``RuleBasedControl.run``, ``engine.step_k``): the
+        observation rings no longer match the counter -- refill them at the current step."""
+        if self._ring is not None and self.engine.current_step <= self.layout.n_steps:
+            self._refill()
+
     def _refill(self):
         """Fill ring 0 for the counter values t .. t + K - 1 (block 0 complete: current state) and start the prefetch of
         the next K behind it."""
@@ -439,7 +445,14 @@ class _SingleMixin:
     def load(cls, path, **kwargs):
         """``Env.load(stream)`` (microgrid.py:847-864): a serialised ``!Microgrid`` YAML file."""
         from .scenario import load_scenario_yaml
-        return cls(load_scenario_yaml(path), **kwargs)
+        params = load_scenario_yaml(path)
+        env = cls(params, **kwargs)
+        cur = params.get("current_step")
+        if cur is not None and cur != env.layout.initial_step:      # a microgrid saved mid-episode resumes at its counter;
+            env.engine.reset(int(cur), want_obs=False)              # reset() still returns to the constructor's initial_step
+            if env._ring is not None:
+                env._refill()
+        return env
 
     def _nested(self, obs_row):
         """flat row -> {'load': [arr], 'pv': [arr], 'genset': [arr], 'battery': [arr], 'grid': [arr]}."""

@@ -1,10 +1,23 @@
-"""Synthetic microgrid batches drawn with the sizing rules of the reference's ``MicrogridGenerator``
-(MicrogridGenerator.py:214-603) -- used by bench.py and the large parity tests.
+"""Microgrid batches drawn with the rules of the reference's ``MicrogridGenerator`` (MicrogridGenerator.py:137-147,214-441,
+535-538; the conversion to modules, convert/get_module.py:39-97) -- used by bench.py and the large parity tests.
 
-Per-grid scalars come from a counter-based Philox stream over the GLOBAL grid index, so rank r of W draws exactly
-rows [r*N/W, (r+1)*N/W) of the same global batch whatever W is.  Series are base profile x per-grid scale, built
-on the device row-block by row-block (the [T, N] arrays never exist on the host).
+What is reproduced exactly (pinned by ``tests/golden/generator_rules.npz``, 96 microgrids the real generator produced,
+``tests/test_generator_rules.py``): given the same random draws, every derived number -- the scaled load / pv series
+(base profile x size / max(profile)), PV size (penetration of the scaled load's peak), battery capacity (ceil(hours x mean
+load)) and power (ceil(capacity / 4)), initial SoC (clipped normal), genset rating (ceil(peak / 0.9)) and its 5 % / 90 %
+running limits, grid power (2 x peak), the two import tariffs by hour of day, the co2 series and the weak-grid outage series.
+The base profiles are the reference's own 12 data files (``pymgrid_amd/data/base_profiles.npz``).
+
+What differs by design: where the draws come from.  The reference consumes numpy's global stream one microgrid at a time;
+here every per-grid scalar comes from a counter-based Philox stream over the GLOBAL grid index, so rank r of W draws exactly
+rows [r N / W, (r + 1) N / W) of the same global batch whatever W is, and the [T, N] series are written on the device by a
+HIP kernel (``mgx_synthesize_series``; outage uniforms = Philox(seed; global grid index, row)) -- they never exist on the
+host.  On a CPU device (the gloo tests) the same rule functions build the series with numpy.
 """
+import ctypes as C
+import json
+import os
+
 import numpy as np
 import torch
 
@@ -12,140 +25,278 @@ from .batch import BatchLayout, MicrogridBatch, pack_status, pack_times
 
 ARCHS = {"genset+battery": (True, True, False), "battery+grid": (False, True, True),
          "genset+battery+grid": (True, True, True), "loadpv": (False, False, False)}
+YEAR = 8760
+
+_profiles = None
 
 
-def _base_profiles(T, seed):
-    """5 load shapes, 5 pv shapes, 2 co2 shapes (hourly, peak-normalised) -- stand-ins for data/load, data/pv,
-    data/co2 of the reference, which are not available on the GPU box."""
-    rs = np.random.Generator(np.random.Philox(key=seed + 0x5eed))
-    t = np.arange(T)
-    hour, day = t % 24, t // 24
-    load, pv, co2 = [], [], []
-    for k in range(5):
-        daily = 0.55 + 0.3 * np.sin(2 * np.pi * (hour - 7 - k) / 24) + 0.1 * np.sin(4 * np.pi * (hour + k) / 24)
-        season = 1.0 + 0.15 * np.cos(2 * np.pi * (day - 30 * k) / 365.0)
-        x = np.clip(daily * season * (1 + 0.05 * rs.standard_normal(T)), 0.05, None)
-        load.append(x / x.max())
-        sun = np.clip(np.sin(np.pi * (hour - 6) / 12.0), 0, None) ** (1.0 + 0.1 * k)
-        cloud = np.clip(0.75 + 0.25 * np.cos(2 * np.pi * (day + 20 * k) / 365.0) - 0.3 * rs.random(T), 0, 1)
-        y = sun * cloud
-        pv.append(y / max(y.max(), 1e-12))
-    for k in range(2):
-        co2.append(0.25 + 0.1 * k + 0.1 * np.sin(2 * np.pi * (hour - 15) / 24) + 0.02 * rs.random(T))
-    return np.stack(load, 1), np.stack(pv, 1), np.stack(co2, 1)
+def base_profiles():
+    """{'load': [8760, 5], 'pv': [8760, 5], 'co2': [8760, 2]}: the reference's data/load, data/pv, data/co2 files."""
+    global _profiles
+    if _profiles is None:
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "base_profiles.npz"))
+        _profiles = {k: np.ascontiguousarray(z[k], dtype=np.float64) for k in ("load", "pv", "co2")}
+        _profiles["names"] = json.loads(str(z["names"]))
+    return _profiles
 
 
-def _tariff(T, pattern):
-    """MicrogridGenerator._get_electricity_tariff (:253-285): pattern 1 {0.22, 0.29, 0.59}, pattern 2 {0.08, 0.11}."""
-    hour = np.arange(T) % 24
-    if pattern == 1:
-        return np.where((hour >= 17) & (hour < 21), 0.59, np.where((hour >= 8) & (hour < 23), 0.29, 0.22))
-    return np.where((hour >= 8) & (hour < 22), 0.11, 0.08)
+# ---------------------------------------------------------------------------------------------------------------------
+# The rules, as functions of the draws (numpy, the reference's operation order)
+# ---------------------------------------------------------------------------------------------------------------------
+def scale_ratio(size, profile):
+    """_scale_ts(..., 'max') (:137-147): the series is profile * (size / profile.max())."""
+    return np.asarray(size, dtype=np.float64) / profile.max(axis=0)
 
 
-def draw_scalars(n_total, seed=42, arch="genset+battery", mixed_timers=False):
-    """Per-grid scalar draws for the GLOBAL batch (cheap: a few doubles per grid)."""
+def electricity_tariff(pattern, n=YEAR):
+    """_get_electricity_tariff (:253-285): import price by hour of day; the export price is 0."""
+    h = np.arange(n) % 24
+    if pattern == 1:                                    # PG&E A-6 TOU
+        return np.where((h >= 12) & (h < 18), 0.59, np.where((h < 8) | (h >= 21), 0.22, 0.29))
+    if pattern == 2:                                    # France, commercial TOU
+        return np.where(((h >= 0) & (h < 5)) | ((h >= 14) & (h < 17)), 0.08, 0.11)
+    raise ValueError("tariff pattern must be 1 or 2")
+
+
+def weak_grid_profile(uniforms, outage_per_day, duration):
+    """_generate_weak_grid_profile (:321-340) on given uniform draws (len n + 1): status 0 where the draw is below
+    outage_per_day / 24, and on the duration - 1 rows before each such row -- but never on row 0 ("if i - j > 0");
+    the first n rows are kept (:304)."""
+    u = np.asarray(uniforms, dtype=np.float64)
+    zero = u < outage_per_day / 24
+    out = zero.copy()
+    for j in range(1, int(duration)):
+        out[1:len(u) - j] |= zero[1 + j:]               # row t > 0 is covered by an outage starting at t + j
+    return (~out[:len(u) - 1]).astype(np.float64)
+
+
+def mean_of_scaled(profile, ratio, chunk=2048):
+    """np.mean(profile * ratio) per grid with the summation order pandas / numpy use for one series (pairwise along the
+    contiguous axis): the battery sizing rule rounds this mean up, so it is computed exactly, chunk by chunk."""
+    ratio = np.atleast_1d(np.asarray(ratio, dtype=np.float64))
+    out = np.empty(ratio.shape[0])
+    for a in range(0, ratio.shape[0], chunk):
+        r = ratio[a:a + chunk]
+        out[a:a + chunk] = (profile[None, :] * r[:, None]).sum(axis=1) / profile.shape[0]
+    return out
+
+
+def derive(draws, profiles=None):
+    """Everything MicrogridGenerator._create_microgrid / to_modular derive from the draws, as arrays over the grids.
+    draws: dict of arrays -- size_load, load_file, pv_pen, bat_hours, pv_file, soc0_randn (+ weak, tariff, outage_randn,
+    outage_dur, co2_file for grids with a GridModule)."""
+    P = profiles or base_profiles()
+    d = {k: np.asarray(v) for k, v in draws.items()}
+    lf, pf = d["load_file"].astype(np.int64), d["pv_file"].astype(np.int64)
+    load_max, pv_max = P["load"].max(axis=0), P["pv"].max(axis=0)
+    out = {}
+    out["load_ratio"] = d["size_load"].astype(np.float64) / load_max[lf]                   # _scale_ts 'max' (:137-147)
+    load_peak = load_max[lf] * out["load_ratio"]                                            # max of the scaled series
+    out["load_peak"] = load_peak
+    out["pv_size"] = load_peak * (d["pv_pen"].astype(np.float64) / 100)                     # _size_mg (:357)
+    out["pv_ratio"] = out["pv_size"] / pv_max[pf]
+    mean_load = np.empty(len(lf))
+    for p in range(P["load"].shape[1]):
+        sel = lf == p
+        if sel.any():
+            mean_load[sel] = mean_of_scaled(P["load"][:, p], out["load_ratio"][sel])
+    out["mean_load"] = mean_load
+    cap = np.ceil(d["bat_hours"].astype(np.float64) * mean_load)                            # _size_battery (:382-386)
+    out["bat_max_capacity"] = cap
+    out["bat_power"] = np.ceil(cap / 4)                                                     # _get_battery (:230-243), duration 4
+    out["bat_min_capacity"] = cap * 0.2                                                     # get_battery_module: capacity * soc_min
+    out["soc0"] = np.minimum(np.maximum(d["soc0_randn"].astype(np.float64), 0.2), 1.0)     # min(max(randn, soc_min), soc_max)
+    rated = np.ceil(load_peak / 0.9)                                                        # _size_genset (:372-379)
+    out["gen_rated"] = rated
+    out["gen_running_min"] = 0.05 * rated                                                   # get_genset_module: p_min * rated_power
+    out["gen_running_max"] = 0.9 * rated
+    out["grid_power"] = np.floor(load_peak * 2)                                             # int(max(load.values) * 2) (:364)
+    if "outage_randn" in d:
+        out["outage_per_day"] = d["outage_randn"].astype(np.float64) * 3 / 4 + 0.25         # _get_grid (:291)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Draws: counter-based over the global grid index
+# ---------------------------------------------------------------------------------------------------------------------
+def draw_scalars(n_total, seed=42, mixed_timers=False):
+    """The per-grid random draws of MicrogridGenerator._create_microgrid for the GLOBAL batch (cheap: a few numbers per
+    grid), from one Philox stream per quantity -- not the reference's interleaved global stream."""
     rs = np.random.Generator(np.random.Philox(key=seed))
     d = {}
-    d["peak"] = rs.integers(100, 100001, n_total).astype(np.float64)          # load size U{100..100000} (:437-441)
-    d["load_pid"] = rs.integers(0, 5, n_total)
-    d["pv_pid"] = rs.integers(0, 5, n_total)
-    d["pv_pen"] = rs.integers(30, 151, n_total) / 100.0                       # PV penetration 30..150 % (:357)
-    d["bat_hours"] = rs.integers(3, 6, n_total).astype(np.float64)            # battery 3..5 h of mean load (:385)
-    d["soc0"] = np.clip(rs.standard_normal(n_total), 0.2, 1.0)                # (:239)
+    d["bin_rand"] = rs.random(n_total)                                         # _bin_genset_grid (:417-435)
+    d["size_load"] = rs.integers(100, 100001, n_total)                         # _size_load (:437-441)
+    d["load_file"] = rs.integers(0, 5, n_total)
+    d["pv_pen"] = rs.integers(30, 151, n_total)                                # _size_mg (:357)
+    d["bat_hours"] = rs.integers(3, 6, n_total)                                # _size_battery (:385)
+    d["pv_file"] = rs.integers(0, 5, n_total)
+    d["soc0_randn"] = rs.standard_normal(n_total)                              # _get_battery (:239)
+    d["weak"] = rs.integers(0, 2, n_total)                                     # rand_weak_grid (:535)
+    d["tariff"] = rs.integers(1, 3, n_total)                                   # price_scenario (:536)
+    d["outage_randn"] = rs.standard_normal(n_total)                            # _get_grid (:291)
+    d["outage_dur"] = rs.integers(1, 8, n_total)                               # (:292)
+    d["co2_file"] = rs.integers(0, 2, n_total)
     d["su"] = rs.integers(0, 4, n_total) if mixed_timers else np.zeros(n_total, np.int64)
     d["wd"] = rs.integers(0, 4, n_total) if mixed_timers else np.zeros(n_total, np.int64)
-    d["weak"] = rs.random(n_total) < 0.5
-    d["tariff"] = rs.integers(1, 3, n_total)
-    d["co2_pid"] = rs.integers(0, 2, n_total)
     return d
 
 
-def _hash_uniform(rows, gidx, seed):
-    """U[0, 1) per (series row, GLOBAL grid index): a counter-based hash (splitmix64-style mixing in wrapping int64
-    arithmetic), so a shard's draw does not depend on how many ranks / shards the batch is split over."""
-    def lsr(v, k):                                     # logical shift right of the two's-complement bit pattern
-        return (v >> k) & ((1 << (64 - k)) - 1)
-    x = rows * -7046029254386353131 + gidx * -4658895280553007687 + (int(seed) * 1000003 + 12345)
-    x = (x ^ lsr(x, 30)) * -4658895280553007687
-    x = (x ^ lsr(x, 27)) * -7723592293110705685
-    x = x ^ lsr(x, 31)
-    return lsr(x, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+def architecture_of(d):
+    """MicrogridGenerator's architecture draw per grid (:417-435,535-538): rand < 0.33 genset only, < 0.66 grid only, else
+    both; a weak grid forces a genset.  Returns an array of ARCHS keys."""
+    r, weak = d["bin_rand"], d["weak"].astype(bool)
+    genset = (r < 0.33) | (r >= 0.66)
+    grid = r >= 0.33
+    genset = genset | (grid & weak)
+    return np.where(genset & grid, "genset+battery+grid", np.where(grid, "battery+grid", "genset+battery"))
 
 
-def generate(n_grids, n_steps=8760, seed=42, arch="genset+battery", horizon=0, device="cuda", rank=0, world=1,
-             mixed_timers=False, final_step=0, row_block=256):
-    """Build the [rank]-th shard of a global batch of ``n_grids`` microgrids on ``device``."""
-    has_genset, has_battery, has_grid = ARCHS[arch]
-    if n_grids % world:
-        raise ValueError("n_grids must be divisible by the number of ranks")
-    per = n_grids // world
-    lo, hi = rank * per, (rank + 1) * per
-    d = {k: v[lo:hi] for k, v in draw_scalars(n_grids, seed, arch, mixed_timers).items()}
-    T, N = n_steps, per
-    base_load, base_pv, base_co2 = _base_profiles(T, seed)
-    dev = torch.device(device)
+# ---------------------------------------------------------------------------------------------------------------------
+# Philox4x32-10 on the host: the uniforms the synthesis kernel draws (mgx_kernels.hip: synth_uniform)
+# ---------------------------------------------------------------------------------------------------------------------
+def synth_uniform_host(seed, grid, row):
+    """U[0, 1) of (seed; GLOBAL grid index, row), bit-identical to the device's synth_uniform (vectorised over arrays)."""
+    grid = np.asarray(grid, dtype=np.uint64)
+    row = np.asarray(row, dtype=np.uint64)
+    grid, row = np.broadcast_arrays(grid, row)
+    m32 = np.uint64(0xFFFFFFFF)
+    c0, c1 = grid & m32, (grid >> np.uint64(32)) & m32
+    c2, c3 = row & m32, np.full(grid.shape, 0x5eed, dtype=np.uint64)
+    k0, k1 = np.uint64(int(seed) & 0xFFFFFFFF), np.uint64((int(seed) >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & m32
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & m32
+        c1, c3, c0, c2 = p1 & m32, p0 & m32, n0, n2
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    return (((c0 << np.uint64(21)) ^ (c1 >> np.uint64(11))).astype(np.float64)) * (1.0 / 9007199254740992.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _tile_rows(profile, T):
+    """First T rows of a yearly profile (tiled when T > 8760)."""
+    if T <= profile.shape[0]:
+        return profile[:T]
+    reps = -(-T // profile.shape[0])
+    return np.concatenate([profile] * reps, axis=0)[:T]
+
+
+def _synthesize(dev, T, N, gidx, seed, d, r, P, has_grid):
+    """load_ts [T, N], pv_ts [T, N], grid_ts [T, 4, N] (or None) for the grids with GLOBAL indices gidx [N]."""
     f64 = dict(dtype=torch.float64, device=dev)
-
-    load_scale = d["peak"]                                   # profiles are peak-normalised
-    pv_scale = d["peak"] * d["pv_pen"]
-    mean_load = base_load.mean(0)[d["load_pid"]] * load_scale
-    cols = {}
-
-    def up(a):
-        return torch.as_tensor(np.ascontiguousarray(a), **f64)
-
-    bl, bp = up(base_load), up(base_pv)
-    lpid, ppid = torch.as_tensor(d["load_pid"], device=dev), torch.as_tensor(d["pv_pid"], device=dev)
-    ls, ps = up(load_scale), up(pv_scale)
+    bl, bp, bc = (_tile_rows(P[k], T) for k in ("load", "pv", "co2"))
+    if dev.type != "cuda":                                  # host synthesis (CPU tests): the same rules in numpy
+        load_ts = -np.abs(bl[:, d["load_file"]] * r["load_ratio"][None, :])
+        pv_ts = np.abs(bp[:, d["pv_file"]] * r["pv_ratio"][None, :])
+        grid_ts = None
+        if has_grid:
+            grid_ts = np.empty((T, 4, N))
+            t1, t2 = electricity_tariff(1, T), electricity_tariff(2, T)
+            grid_ts[:, 0] = np.where(d["tariff"][None, :] == 1, t1[:, None], t2[:, None])
+            grid_ts[:, 1] = 0.0
+            grid_ts[:, 2] = bc[:, d["co2_file"]]
+            grid_ts[:, 3] = 1.0
+            rows = np.arange(T + 1)
+            for j in np.nonzero(d["weak"])[0]:
+                u = synth_uniform_host(seed, gidx[j], rows)
+                grid_ts[:, 3, j] = weak_grid_profile(u, r["outage_per_day"][j], d["outage_dur"][j])
+        as_t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), **f64)
+        return as_t(load_ts), as_t(pv_ts), as_t(grid_ts)
+    from . import _lib
+    lib = _lib.lib()
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=dev)
+    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+    keep = dict(base_load=up(bl), base_pv=up(bp), load_profile=i32(d["load_file"]), pv_profile=i32(d["pv_file"]),
+                load_ratio=up(r["load_ratio"]), pv_ratio=up(r["pv_ratio"]))
     load_ts, pv_ts = torch.empty(T, N, **f64), torch.empty(T, N, **f64)
-    for r0 in range(0, T, row_block):
-        r1 = min(T, r0 + row_block)
-        load_ts[r0:r1] = -(bl[r0:r1][:, lpid] * ls)          # stored sign: load <= 0
-        pv_ts[r0:r1] = bp[r0:r1][:, ppid] * ps
-    cols["load_ts"], cols["pv_ts"] = load_ts, pv_ts
-    cols["load_lo"] = -(up(base_load.max(0))[lpid] * ls); cols["load_hi"] = torch.zeros(N, **f64)
-    cols["pv_lo"] = torch.zeros(N, **f64);               cols["pv_hi"] = up(base_pv.max(0))[ppid] * ps
-    cols["loss_load_cost"] = torch.full((N,), 10.0, **f64)
-    cols["overgeneration_cost"] = torch.full((N,), 1.0, **f64)
+    grid_ts = torch.empty(T, 4, N, **f64) if has_grid else None
+    if has_grid:
+        keep.update(base_co2=up(bc), co2_profile=i32(d["co2_file"]), tariff=i32(d["tariff"]), weak=i32(d["weak"]),
+                    outage_per_day=up(r["outage_per_day"]), outage_duration=i32(d["outage_dur"]))
+    a = _lib.Synth()
+    a.struct_size = C.sizeof(_lib.Synth)
+    a.n_grids, a.n_steps = N, T
+    a.n_load_profiles, a.n_pv_profiles, a.n_co2_profiles = bl.shape[1], bp.shape[1], bc.shape[1]
+    for k, t in keep.items():
+        setattr(a, k, t.data_ptr())
+    contiguous = N == 0 or bool((np.diff(gidx) == 1).all())
+    gi = None if contiguous else torch.as_tensor(np.ascontiguousarray(gidx, dtype=np.int64), device=dev)
+    a.seed, a.grid_index0 = int(seed) & (2 ** 64 - 1), int(gidx[0]) if N else 0
+    a.grid_index = None if gi is None else gi.data_ptr()
+    a.load_ts, a.pv_ts = load_ts.data_ptr(), pv_ts.data_ptr()
+    a.grid_ts = grid_ts.data_ptr() if has_grid else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.mgx_synthesize_series(C.byref(a), torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.current_stream(dev).synchronize()        # `keep` may go once the kernel has read it
+    return load_ts, pv_ts, grid_ts
 
-    if has_battery:                                           # _get_battery / _size_battery (:230-243,:382-386)
-        cap = np.ceil(d["bat_hours"] * mean_load)
-        cols["bat_max_capacity"] = up(cap)
-        cols["bat_min_capacity"] = up(0.2 * cap)
-        cols["bat_max_charge"] = up(np.ceil(cap / 4)); cols["bat_max_discharge"] = up(np.ceil(cap / 4))
+
+def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, device="cuda", rank=0, world=1,
+             mixed_timers=False, final_step=0, select=None):
+    """Build the [rank]-th shard of a global batch of ``n_grids`` microgrids of architecture ``arch`` on ``device``.
+    ``select``: optional global indices (numpy int array, ascending) -- the grids of the global draw to build instead of
+    the rank's contiguous block (``generate_fleet`` uses it to split one draw by architecture)."""
+    has_genset, has_battery, has_grid = ARCHS[arch]
+    dev = torch.device(device)
+    D = draw_scalars(n_grids, seed, mixed_timers)
+    if select is None:
+        if n_grids % world:
+            raise ValueError("n_grids must be divisible by the number of ranks")
+        per = n_grids // world
+        idx = np.arange(rank * per, (rank + 1) * per)
+    else:
+        idx = np.asarray(select, dtype=np.int64)
+    d = {k: v[idx] for k, v in D.items()}
+    N, T = len(idx), int(n_steps)
+    P = base_profiles()
+    r = derive(d, P)
+    f64 = dict(dtype=torch.float64, device=dev)
+    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), **f64)
+
+    load_ts, pv_ts, grid_ts = _synthesize(dev, T, N, idx, seed, d, r, P, has_grid)
+
+    cols = {"load_ts": load_ts, "pv_ts": pv_ts}
+    # observation bounds (base_timeseries_module.py:81-88): min / max of the series actually held, with 0
+    bl, bp = _tile_rows(P["load"], T), _tile_rows(P["pv"], T)
+    cols["load_lo"] = up(-(bl.max(axis=0)[d["load_file"]] * r["load_ratio"])); cols["load_hi"] = torch.zeros(N, **f64)
+    cols["pv_lo"] = torch.zeros(N, **f64); cols["pv_hi"] = up(bp.max(axis=0)[d["pv_file"]] * r["pv_ratio"])
+    cols["loss_load_cost"] = torch.full((N,), 10.0, **f64)              # df_parameters['cost_loss_load'] (:472)
+    cols["overgeneration_cost"] = torch.full((N,), 1.0, **f64)
+    if has_battery:                                                     # get_battery_module (convert/get_module.py:39-57)
+        cols["bat_max_capacity"] = up(r["bat_max_capacity"]); cols["bat_min_capacity"] = up(r["bat_min_capacity"])
+        cols["bat_max_charge"] = up(r["bat_power"]); cols["bat_max_discharge"] = up(r["bat_power"])
         cols["bat_efficiency"] = torch.full((N,), 0.9, **f64)
         cols["bat_cost_cycle"] = torch.full((N,), 0.02, **f64)
-        cols["soc"] = up(d["soc0"]); cols["charge"] = up(d["soc0"] * cap)     # battery_module.py:96-106
-    if has_genset:                                            # _get_genset / _size_genset (:214-228,:372-379)
-        rated = np.ceil(d["peak"] / 0.9)
-        cols["gen_running_min"] = up(0.05 * rated); cols["gen_running_max"] = up(0.9 * rated)
+        cols["soc"] = up(r["soc0"]); cols["charge"] = up(r["soc0"] * r["bat_max_capacity"])   # battery_module.py:96-106
+    if has_genset:                                                      # get_genset_module (:60-76)
+        cols["gen_running_min"] = up(r["gen_running_min"]); cols["gen_running_max"] = up(r["gen_running_max"])
         cols["gen_cost"] = torch.full((N,), 0.4, **f64)
         cols["gen_co2_per_unit"] = torch.full((N,), 2.0, **f64)
         cols["gen_cost_per_unit_co2"] = torch.full((N,), 0.1, **f64)
         cols["gen_times"] = torch.from_numpy(pack_times(d["su"], d["wd"]).view(np.int32).copy()).to(dev)
         st = pack_status(np.ones(N, np.int64), np.ones(N, np.int64), np.zeros(N, np.int64), d["wd"])   # init on
         cols["gen_status"] = torch.from_numpy(st.view(np.int32).copy()).to(dev)
-    if has_grid:                                              # _get_grid (:288-319)
-        cols["grid_max_import"] = up(2 * d["peak"]); cols["grid_max_export"] = up(2 * d["peak"])
+    if has_grid:                                                        # get_grid_module (:79-97)
+        cols["grid_max_import"] = up(r["grid_power"]); cols["grid_max_export"] = up(r["grid_power"])
         cols["grid_cost_per_unit_co2"] = torch.full((N,), 0.1, **f64)
-        tariffs = up(np.stack([_tariff(T, 1), _tariff(T, 2)], 1))
-        tid = torch.as_tensor(d["tariff"] - 1, device=dev)
-        cid = torch.as_tensor(d["co2_pid"], device=dev)
-        bc = up(base_co2)
-        weak = torch.as_tensor(d["weak"], device=dev)
-        gidx = torch.arange(lo, hi, dtype=torch.int64, device=dev).unsqueeze(0)          # GLOBAL grid index
-        grid_ts = torch.empty(T, 4, N, **f64)
-        for r0 in range(0, T, row_block):
-            r1 = min(T, r0 + row_block)
-            grid_ts[r0:r1, 0] = tariffs[r0:r1][:, tid]
-            grid_ts[r0:r1, 1] = 0.0
-            grid_ts[r0:r1, 2] = bc[r0:r1][:, cid]
-            rows = torch.arange(r0, r1, dtype=torch.int64, device=dev).unsqueeze(1)
-            outage = (_hash_uniform(rows, gidx, seed) < 0.02) & weak              # weak-grid outages (:321-340)
-            grid_ts[r0:r1, 3] = (~outage).to(torch.float64)
         cols["grid_ts"] = grid_ts
         cols["grid_lo"] = grid_ts.amin(dim=0).contiguous(); cols["grid_hi"] = grid_ts.amax(dim=0).contiguous()
     layout = BatchLayout(n_grids=N, n_steps=T, horizon=horizon, initial_step=0, final_step=final_step,
                          has_genset=has_genset, has_battery=has_battery, has_grid=has_grid)
     return MicrogridBatch(layout, {k: v.contiguous() for k, v in cols.items()})
+
+
+def generate_fleet(n_grids, n_steps=YEAR, seed=42, horizon=0, device="cuda", rank=0, world=1, mixed_timers=False):
+    """A heterogeneous population with MicrogridGenerator's own architecture mix (BASELINE config 5): the rank's block of
+    the global draw, split by the architecture each grid drew.  Returns {arch: (MicrogridBatch, global indices)}."""
+    if n_grids % world:
+        raise ValueError("n_grids must be divisible by the number of ranks")
+    per = n_grids // world
+    D = draw_scalars(n_grids, seed, mixed_timers)
+    arch = architecture_of(D)
+    out = {}
+    for name in ("genset+battery", "battery+grid", "genset+battery+grid"):
+        idx = np.nonzero(arch[rank * per:(rank + 1) * per] == name)[0] + rank * per
+        if len(idx):
+            out[name] = (generate(n_grids, n_steps, seed, name, horizon, device, mixed_timers=mixed_timers, select=idx), idx)
+    return out

@@ -91,6 +91,17 @@ class BucketedFleet:
                 out.append(fn(env, k))
         for st in self.streams:
             cur.wait_stream(st)
+
+        def guard(x):          # allocated on a bucket stream, read on the caller's: the caching allocator must know (else
+            if torch.is_tensor(x):                          # it may recycle the block while the caller's reads are pending)
+                x.record_stream(cur)
+            elif isinstance(x, dict):
+                for v in x.values():
+                    guard(v)
+            elif isinstance(x, (list, tuple)):
+                for v in x:
+                    guard(v)
+        guard(out)
         return out
 
     def reset(self):

@@ -100,12 +100,28 @@ class RuleBasedControl:
     def reset(self):
         return self.env.reset()
 
-    def run(self, max_steps=None, chunk=512, log=False, soc_trace=False, reward=True):
+    def run(self, max_steps=None, chunk=512, log=False, soc_trace=False, reward=True, restore_state=False):
+        """``RuleBasedControl.run`` (rbc.py:64-93): reset the microgrids -- through the env, so a ``trajectory_func``
+        redraws the episode window as ``Microgrid.reset`` does (microgrid.py:205-225) -- then deploy the priority lists
+        until ``done`` (the end of the CURRENT episode window) or for ``max_steps`` steps.  The reference works on a deep
+        copy of the microgrid; here the batch itself is stepped unless ``restore_state=True`` puts battery charge / SoC and
+        genset status back afterwards."""
         L = self.layout
-        self.engine.reset(want_obs=False)
-        total = L.final_step - L.initial_step
+        self.env.reset()
+        lo, hi = self.engine.window                       # the window the reset has just installed
+        total = hi - lo                                   # done fires at counter hi - 1: hi - lo steps in all
         if max_steps is not None:
             total = min(total, int(max_steps))
+        saved = self.batch.state() if restore_state else None
+        try:
+            return self._run(total, chunk, log, soc_trace, reward)
+        finally:
+            if saved is not None:
+                self.batch.load_state(saved)
+            self.env._after_external_steps()              # the env's observation rings follow the counter again
+
+    def _run(self, total, chunk, log, soc_trace, reward):
+        L = self.layout
         ret = torch.zeros(L.n_grids, dtype=torch.float64, device=self.batch.device)
         parts = {}
         done = 0

@@ -125,7 +125,10 @@ def load_scenario_yaml(path):
             ts = np.asarray(cp["time_series"], dtype=np.float64)
             final = int(cp.get("final_step", -1))
             final = ts.shape[0] if final <= 0 else final
-            ts_meta.append((horizon, final, int(state.get("_current_step", cp.get("initial_step", 0)))))
+            # the constructor's initial_step and the saved step counter are two things (Microgrid.from_yaml builds the module
+            # from cls_params and only then restores _current_step, base_module.py:771-957): reset() goes back to the former
+            init = int(cp.get("initial_step", 0))
+            ts_meta.append((horizon, final, init, int(state.get("_current_step", init))))
             if tag == "!LoadModule":
                 p["load_ts"] = -np.abs(ts.reshape(ts.shape[0], -1)[:, 0])
             elif tag == "!RenewableModule":
@@ -170,7 +173,7 @@ def load_scenario_yaml(path):
         raise ValueError("scenario has no UnbalancedEnergyModule")
     if len(set(ts_meta)) != 1:
         raise NotImplementedError("time-series modules with different horizon / final_step / current step")
-    p["horizon"], p["final_step"], p["initial_step"] = ts_meta[0]
+    p["horizon"], p["final_step"], p["initial_step"], p["current_step"] = ts_meta[0]
     p["controllable_order"] = order
     return p
 
@@ -190,6 +193,7 @@ def dump_scenario_yaml(p, path):
         raise NotImplementedError("more than one load / renewable module per microgrid is not supported by the file format here")
     base = os.path.dirname(os.path.abspath(path))
     H, t0, final = int(p.get("horizon", 0)), int(p.get("initial_step", 0)), int(p.get("final_step", 0)) or load.shape[0]
+    cur = int(p.get("current_step", t0))               # the saved step counter (state), not the constructor's initial_step
     noise = p.get("forecast_noise")
 
     def series(tag, arr):
@@ -208,7 +212,7 @@ def dump_scenario_yaml(p, path):
         return d
 
     def module(name, tag, cls_params, state):
-        return [name, _Tagged(tag, dict(cls_params=cls_params, name=[name, 0], state=dict(state, _current_step=t0)))]
+        return [name, _Tagged(tag, dict(cls_params=cls_params, name=[name, 0], state=dict(state, _current_step=cur)))]
     mods = [module("load", "!LoadModule", ts_params("LoadModule", np.abs(load)), {}),
             module("pv", "!RenewableModule", ts_params("RenewableModule", np.abs(pv), dict(provided_energy_name="renewable_used")), {}),
             module("unbalanced_energy", "!UnbalancedEnergyModule",

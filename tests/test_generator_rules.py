@@ -1,0 +1,157 @@
+"""Generator rules pinned against the REAL MicrogridGenerator: tests/golden/generator_rules.npz holds, for 96
+microgrids the reference generated (seeds 42 and 7), the random draws its code made and everything it derived from them
+(tests/golden/make_generator_goldens.py).  Fed the same draws, pymgrid_amd.generator's rule functions must give the same
+numbers, bit for bit: sizes, converted module parameters, scaled series, tariffs, co2 series, weak-grid outage series."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+
+@pytest.fixture(scope="module")
+def cases():
+    z = golden("generator_rules.npz")
+    return z, json.loads(str(z["meta"]))
+
+
+def _draws(metas):
+    keys = ("size_load", "load_file", "pv_pen", "bat_hours", "pv_file", "soc0_randn", "weak", "tariff", "outage_randn",
+            "outage_dur", "co2_file")
+    return {k: np.array([d[k] for _, d in metas]) for k in keys}
+
+
+def test_sizing_rules_equal_the_reference(cases):
+    from pymgrid_amd import generator as gen
+    z, metas = cases
+    r = gen.derive(_draws(metas))
+    n_gen = n_grid = n_weak = 0
+    for j, (key, d) in enumerate(metas):
+        p = d["params"]
+        assert np.around(r["pv_size"][j], 2) == d["pv_rated"], key                       # df_parameters['PV_rated_power']
+        assert r["bat_max_capacity"][j] == d["battery_capacity"] == p["battery"]["max_capacity"], key
+        assert r["bat_power"][j] == d["battery_power"] == p["battery"]["max_charge"] == p["battery"]["max_discharge"], key
+        assert r["bat_min_capacity"][j] == p["battery"]["min_capacity"], key
+        assert r["soc0"][j] == d["battery_soc_0"] == p["battery"]["soc"], key
+        assert r["soc0"][j] * r["bat_max_capacity"][j] == p["battery"]["charge"], key
+        assert p["battery"]["efficiency"] == 0.9 and p["battery"]["battery_cost_cycle"] == 0.02
+        assert p["unbalanced"] == dict(loss_load_cost=10.0, overgeneration_cost=1.0)
+        assert (p["horizon"], p["initial_step"], p["final_step"]) == (23, 0, 8760)      # a fresh microgrid runs to the end of its series
+        if d["genset"]:
+            n_gen += 1
+            g = p["genset"]
+            assert r["gen_rated"][j] == d["genset_rated"], key
+            assert r["gen_running_min"][j] == g["running_min_production"] and r["gen_running_max"][j] == g["running_max_production"], key
+            assert (g["genset_cost"], g["co2_per_unit"], g["cost_per_unit_co2"], g["start_up_time"], g["wind_down_time"]) == \
+                (0.4, 2.0, 0.1, 0, 0) and g["status"] == [1, 1, 0, 0]
+        if d["grid"]:
+            n_grid += 1
+            assert r["grid_power"][j] == d["grid_power"] == p["grid"]["max_import"] == p["grid"]["max_export"], key
+            assert p["grid"]["cost_per_unit_co2"] == 0.1
+            n_weak += d["weak"]
+    assert n_gen > 30 and n_grid > 30 and n_weak > 10
+
+
+def test_architecture_rule_equals_the_reference(cases):
+    from pymgrid_amd import generator as gen
+    _, metas = cases
+    arch = gen.architecture_of(dict(bin_rand=np.array([d["bin_rand"] for _, d in metas]),
+                                    weak=np.array([d["weak"] for _, d in metas])))
+    for a, (key, d) in zip(arch, metas):
+        want = "genset+battery+grid" if d["genset"] and d["grid"] else ("battery+grid" if d["grid"] else "genset+battery")
+        assert a == want, key
+
+
+def test_series_rules_equal_the_reference(cases):
+    from pymgrid_amd import generator as gen
+    z, metas = cases
+    P = gen.base_profiles()
+    r = gen.derive(_draws(metas), P)
+    rows = z["sample_rows"]
+    checked = 0
+    for j, (key, d) in enumerate(metas):
+        load = P["load"][:, d["load_file"]] * r["load_ratio"][j]
+        pv = P["pv"][:, d["pv_file"]] * r["pv_ratio"][j]
+        assert np.array_equal(-np.abs(load)[rows], z[f"{key}_load_sample"]) and -np.abs(load).sum() == z[f"{key}_load_sum"], key
+        assert np.array_equal(np.abs(pv)[rows], z[f"{key}_pv_sample"]) and np.abs(pv).sum() == z[f"{key}_pv_sum"], key
+        if d["grid"]:
+            assert np.array_equal(gen.electricity_tariff(d["tariff"])[:48], z[f"{key}_price_day0"]), key
+            assert np.array_equal(P["co2"][rows, d["co2_file"]], z[f"{key}_co2_sample"]), key
+            status = np.unpackbits(z[f"{key}_status"])[:8760].astype(np.float64)
+            if not d["weak"]:
+                assert status.all(), key
+            elif f"{key}_outage_uniforms" in z.files:                    # the reference's own uniform draws as input
+                mine = gen.weak_grid_profile(z[f"{key}_outage_uniforms"], r["outage_per_day"][j], d["outage_dur"])
+                assert np.array_equal(mine, status), key
+                checked += 1
+    assert checked == 8
+
+
+def test_weak_grid_rule_edge_cases():
+    from pymgrid_amd.generator import weak_grid_profile
+    u = np.full(21, 0.9)
+    u[[0, 5, 20]] = 0.0                                   # outages drawn at rows 0, 5 and at the extra row 20
+    s = weak_grid_profile(u, 24 * 0.5, 3)                 # threshold 0.5, duration 3: back-fill covers 2 rows before each
+    assert s.tolist() == [0, 1, 1, 0, 0, 0] + [1] * 12 + [0, 0]          # row 0 only by its own draw; rows 18, 19 from row 20
+    assert weak_grid_profile(np.full(11, 0.9), -1.0, 7).all()           # a negative outage rate (randn * 3/4 + 0.25 < 0): none
+    u = np.full(11, 0.9); u[2] = 0.0
+    assert weak_grid_profile(u, 24 * 0.5, 7).tolist() == [1, 0, 0] + [1] * 7      # "if i - j > 0": row 0 is never back-filled
+    assert weak_grid_profile(u, 24 * 0.5, 1).tolist() == [1, 1, 0] + [1] * 7      # duration 1: no back-fill at all
+
+
+def test_host_philox_stream_is_a_uniform_stream():
+    from pymgrid_amd.generator import synth_uniform_host
+    u = synth_uniform_host(42, np.arange(2000)[:, None], np.arange(500)[None, :])
+    assert u.shape == (2000, 500) and 0.0 <= u.min() and u.max() < 1.0
+    assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 1e-3
+    assert len(np.unique(u)) == u.size                                    # counter-based: no repeats across (grid, row)
+    assert not np.array_equal(u, synth_uniform_host(43, np.arange(2000)[:, None], np.arange(500)[None, :]))
+
+
+def test_generate_on_cpu_follows_the_rules_and_is_shard_invariant():
+    from pymgrid_amd import generator as gen
+    full = gen.generate(96, n_steps=300, seed=11, arch="genset+battery+grid", device="cpu")
+    halves = [gen.generate(96, n_steps=300, seed=11, arch="genset+battery+grid", device="cpu", rank=r, world=2) for r in (0, 1)]
+    for k, v in full.cols.items():
+        assert torch.equal(v, torch.cat([h.cols[k] for h in halves], dim=-1)), k
+    D = gen.draw_scalars(96, 11)
+    r = gen.derive(D)
+    P = gen.base_profiles()
+    c = full.cols
+    assert np.array_equal(c["bat_max_capacity"].numpy(), r["bat_max_capacity"]) and np.array_equal(c["gen_running_max"].numpy(), r["gen_running_max"])
+    assert np.array_equal(c["load_ts"].numpy(), -np.abs(P["load"][:300, D["load_file"]] * r["load_ratio"][None, :]))
+    assert np.array_equal(c["grid_ts"][:, 0].numpy(), np.where(D["tariff"][None, :] == 1, gen.electricity_tariff(1, 300)[:, None],
+                                                              gen.electricity_tariff(2, 300)[:, None]))
+    status = c["grid_ts"][:, 3].numpy()
+    weak = D["weak"].astype(bool)
+    assert status[:, ~weak].all() and ((status == 0) | (status == 1)).all()
+    # fleet split: MicrogridGenerator's architecture mix, every grid exactly once
+    fleet = gen.generate_fleet(300, n_steps=48, seed=5, device="cpu")
+    idx = np.sort(np.concatenate([i for _, i in fleet.values()]))
+    assert np.array_equal(idx, np.arange(300)) and set(fleet) == {"genset+battery", "battery+grid", "genset+battery+grid"}
+    arch = gen.architecture_of(gen.draw_scalars(300, 5))
+    for name, (b, i) in fleet.items():
+        assert (arch[i] == name).all() and b.layout.n_grids == len(i)
+
+
+@pytest.mark.gpu
+def test_device_synthesis_equals_the_host_rules(device):
+    """mgx_synthesize_series (HIP: base profile x ratio, tariffs, co2, Philox outage uniforms + back-fill) == the numpy rule
+    functions on the same draws, bit for bit; contiguous shards and scattered selections."""
+    from pymgrid_amd import generator as gen
+    for arch in ("genset+battery", "genset+battery+grid"):
+        dev_b = gen.generate(1030, n_steps=400, seed=3, arch=arch, device=device, rank=1, world=2, mixed_timers=True)
+        cpu_b = gen.generate(1030, n_steps=400, seed=3, arch=arch, device="cpu", rank=1, world=2, mixed_timers=True)
+        assert set(dev_b.cols) == set(cpu_b.cols)
+        for k, v in cpu_b.cols.items():
+            assert torch.equal(dev_b.cols[k].cpu(), v), (arch, k)
+    sel = np.sort(np.random.RandomState(0).choice(5000, 700, replace=False))
+    a = gen.generate(5000, n_steps=8760, seed=9, arch="genset+battery+grid", device=device, select=sel)
+    b = gen.generate(5000, n_steps=8760, seed=9, arch="genset+battery+grid", device="cpu", select=sel)
+    for k, v in b.cols.items():
+        assert torch.equal(a.cols[k].cpu(), v), k
+    st = a.cols["grid_ts"][:, 3]
+    weak = gen.draw_scalars(5000, 9)["weak"][sel].astype(bool)
+    assert bool(st[:, torch.as_tensor(~weak, device=device)].all()) and float(st[:, torch.as_tensor(weak, device=device)].mean()) < 1.0

@@ -16,6 +16,7 @@ def test_yaml_loader_equals_reference_loader(pymgrid25):
     for n, ref in enumerate(pymgrid25):
         p = from_scenario(n, REF_SCENARIOS)
         order = p.pop("controllable_order")               # module-list order of the YAML: never grid before battery here
+        assert p.pop("current_step") == p["initial_step"] == 0       # saved counter: kept apart from the constructor's initial_step
         assert not ("grid" in order and "battery" in order and order.index("grid") < order.index("battery")), n
         assert set(p) == set(ref), (n, set(p) ^ set(ref))
         for k, v in ref.items():
@@ -48,6 +49,7 @@ def test_dump_and_load_round_trip(pymgrid25, tmp_path):
     cases = list(enumerate(pymgrid25))
     with_grid = next(q for q in pymgrid25 if q.get("grid") is not None and q.get("genset") is not None)
     odd = dict(with_grid); odd["controllable_order"] = ["grid", "battery"]; odd["initial_step"] = 5
+    odd["current_step"] = 9                                # saved mid-episode: the counter is NOT the constructor's initial_step
     odd["battery"] = dict(odd["battery"], charge=odd["battery"]["max_capacity"] * 0.61803, soc=0.61803)
     cases.append(("odd", odd))
     for n, ref in cases:
@@ -57,6 +59,9 @@ def test_dump_and_load_round_trip(pymgrid25, tmp_path):
         order = p.pop("controllable_order")
         if n == "odd":
             assert order.index("grid") < order.index("battery")
+            assert p["initial_step"] == 5 and p["current_step"] == 9
+        else:
+            assert p.pop("current_step") == p["initial_step"]
         for k, v in ref.items():
             if k == "controllable_order":
                 continue
@@ -79,6 +84,14 @@ def test_the_reference_loads_what_we_dump(pymgrid25, tmp_path):
     import make_goldens as mg
     from pymgrid import Microgrid
     from pymgrid_amd.scenario import dump_scenario_yaml
+    mid = dict(pymgrid25[3], initial_step=4, current_step=11)      # saved mid-episode
+    os.makedirs(tmp_path / "mg_mid", exist_ok=True)
+    with open(dump_scenario_yaml(mid, str(tmp_path / "mg_mid" / "microgrid.yaml"))) as fh:
+        m = Microgrid.load(fh)
+    load = mg.find(m, mg.LoadModule)[0]
+    assert load.initial_step == 4 and load.current_step == 11       # the reference keeps the two apart the same way
+    m.reset()
+    assert load.current_step == 4
     for n in (0, 3, 7, 24):
         ref = pymgrid25[n]
         os.makedirs(tmp_path / f"mg_{n}", exist_ok=True)
