@@ -1,0 +1,148 @@
+"""BASELINE configs at their TRUE shape on one GPU (the bench workloads, checked instead of timed):
+  configs[2]  100 000 generated Template-4 grids x 8 760 rows (14 GB of series)
+  configs[3]  the per-GPU shard of the 1 M-grid batch: 125 000 grids, rank 3 of 8
+  configs[4]  a 99 999-grid heterogeneous fleet with GridModules and forecast_horizon = 24, stepped through the Gym surface
+Sampled grids are compared with the CPU oracle bit for bit; the rest through size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sub_columns(batch, idx, rows):
+    """Oracle columns of the sampled grids `idx` over the series rows `rows` (a slice): [len(rows), len(idx)] arrays."""
+    ii = torch.as_tensor(idx, device=batch.device)
+    cols = {}
+    for k, v in batch.cols.items():
+        if k in ("load_ts", "pv_ts"):
+            cols[k] = v[rows][:, ii].contiguous().cpu().numpy()
+        elif k == "grid_ts":
+            cols[k] = v[rows][:, :, ii].contiguous().cpu().numpy()
+        elif k in ("grid_lo", "grid_hi"):
+            cols[k] = v[:, ii].contiguous().cpu().numpy()
+        else:
+            a = v[ii].cpu().numpy()
+            cols[k] = a.view(np.uint32) if v.dtype == torch.int32 else a
+    L = batch.layout
+    T = cols["load_ts"].shape[0]
+    cols["layout"] = dict(N=len(idx), T=T, horizon=0, final_step=T, has_genset=int(L.has_genset), has_battery=int(L.has_battery),
+                          has_grid=int(L.has_grid), grid_before_battery=int(L.grid_before_battery))
+    return cols
+
+
+@pytest.mark.parametrize("n_total,rank,world", [(100_000, 0, 1), (1_000_000, 3, 8)])
+def test_full_year_batch_end_of_series_and_wrap_around(n_total, rank, world, device, oracle):
+    """The real bench batch (and the config-4 shard): the last 64 rows of the year -- `done` exactly at step 8 759, stepping
+    past the series refused, reset() wraps to row 0 -- with 1 024 sampled grids equal to the oracle (rewards, SoC, state)."""
+    from pymgrid_amd import StepEngine
+    from pymgrid_amd._lib import MGX_ERR_RANGE, MgxError
+    from pymgrid_amd.generator import generate
+    T, K = 8760, 64
+    b = generate(n_total, n_steps=T, seed=42, arch="genset+battery", device=device, rank=rank, world=world)
+    N = b.layout.n_grids
+    assert N == n_total // world and b.cols["load_ts"].shape == (T, N) and b.layout.final_step == T
+    eng = StepEngine(b)
+    eng.set_shards(2)                                           # as bench.py steps it
+    rs = np.random.RandomState(1)
+    idx = np.sort(rs.choice(N, 1024, replace=False))
+    gen = torch.Generator(device=device); gen.manual_seed(7)
+    acts = torch.rand(K, N, 3, dtype=torch.float64, device=device, generator=gen)
+    eng.reset(initial_step=T - K, want_obs=False)
+    cols = _sub_columns(b, idx, slice(T - K, T))
+    st = {k: cols[k].copy() for k in ("charge", "soc", "gen_status")}
+    eng.fork()
+    out = eng.step_k(acts, reward=True, done=True, soc_trace=True)
+    eng.join()
+    torch.cuda.synchronize(device)
+    assert eng.current_step == T
+    done = out["done"]
+    assert not bool(done[:K - 1].any()) and bool(done[K - 1].all())            # _done(): t >= final_step - 1 = 8 759
+    ii = torch.as_tensor(idx, device=device)
+    ref = oracle.run_batch(cols, st, 0, K, acts[:, ii].contiguous().cpu().numpy(), normalized=True, nthreads=8)
+    assert np.array_equal(out["reward"][:, ii].cpu().numpy(), ref)
+    assert np.array_equal(b.cols["charge"][ii].cpu().numpy(), st["charge"]) and np.array_equal(b.cols["soc"][ii].cpu().numpy(), st["soc"])
+    assert np.array_equal(b.cols["gen_status"][ii].cpu().numpy().view(np.uint32), st["gen_status"])
+    assert torch.equal(out["soc_trace"][-1], b.cols["soc"])
+    soc = out["soc_trace"]
+    assert float(soc.min()) >= 0.2 - 1e-12 and float(soc.max()) <= 1.0 + 1e-12 and bool(torch.isfinite(out["reward"]).all())
+    with pytest.raises(MgxError) as e:                                          # IndexError in the reference: the series is over
+        eng.step_k(acts[:1], reward=True)
+    assert e.value.code == MGX_ERR_RANGE
+    eng.reset(want_obs=False)                                                   # wrap-around: back to row 0, state kept
+    assert eng.current_step == 0
+    cols0 = _sub_columns(b, idx, slice(0, K))
+    st0 = {k: cols0[k].copy() for k in ("charge", "soc", "gen_status")}
+    assert np.array_equal(st0["charge"], st["charge"])                          # reset restores the counter only
+    eng.fork()
+    out = eng.step_k(acts, reward=True, done=True)
+    eng.join()
+    ref = oracle.run_batch(cols0, st0, 0, K, acts[:, ii].contiguous().cpu().numpy(), normalized=True, nthreads=8)
+    assert np.array_equal(out["reward"][:, ii].cpu().numpy(), ref) and not bool(out["done"].any())
+    eng.close()
+
+
+def _grid_params(batch, j):
+    """Parameter dict (scenario vocabulary) of grid j of a batch, for oracle.OracleMicrogrid."""
+    c, L = batch.cols, batch.layout
+    f = lambda k: float(c[k][j])
+    p = dict(load_ts=-c["load_ts"][:, j].cpu().numpy(), pv_ts=c["pv_ts"][:, j].cpu().numpy(), horizon=L.horizon,
+             initial_step=L.initial_step, final_step=L.final_step,
+             unbalanced=dict(loss_load_cost=f("loss_load_cost"), overgeneration_cost=f("overgeneration_cost")))
+    if L.has_battery:
+        p["battery"] = dict(min_capacity=f("bat_min_capacity"), max_capacity=f("bat_max_capacity"), max_charge=f("bat_max_charge"),
+                            max_discharge=f("bat_max_discharge"), efficiency=f("bat_efficiency"),
+                            battery_cost_cycle=f("bat_cost_cycle"), charge=f("charge"), soc=f("soc"))
+    if L.has_genset:
+        from pymgrid_amd import unpack_status
+        tm = int(c["gen_times"][j].item()) & 0xffffffff
+        p["genset"] = dict(running_min_production=f("gen_running_min"), running_max_production=f("gen_running_max"),
+                           genset_cost=f("gen_cost"), co2_per_unit=f("gen_co2_per_unit"), cost_per_unit_co2=f("gen_cost_per_unit_co2"),
+                           start_up_time=tm & 0xff, wind_down_time=(tm >> 16) & 0xff,
+                           status=[int(x) for x in unpack_status(np.array([c["gen_status"][j].item()]).astype(np.int64) & 0xffffffff)[0]])
+    if L.has_grid:
+        p["grid"] = dict(max_import=f("grid_max_import"), max_export=f("grid_max_export"), cost_per_unit_co2=f("grid_cost_per_unit_co2"))
+        p["grid_ts"] = c["grid_ts"][:, :, j].cpu().numpy()
+    return p
+
+
+def test_heterogeneous_fleet_of_100k_grids_with_forecasts_vs_oracle(device, oracle):
+    """configs[4] shape on one GPU: 99 999 grids in MicrogridGenerator's architecture mix (half of the grid-connected ones
+    weak), forecast_horizon = 24, genset timers 0..3, stepped through BucketedFleet.step with observation rows (one
+    fleet_step_kernel launch per step, ring refills in chunks).  A sample of every bucket == per-grid oracle microgrids:
+    observation rows (forecast windows included), rewards, done."""
+    from pymgrid_amd.generator import generate_fleet
+    from pymgrid_amd.hetero import BucketedFleet
+    n, T, H, steps = 99_999, 120, 24, 21
+    parts = generate_fleet(n, n_steps=T, seed=17, horizon=H, device=device, mixed_timers=True)
+    names = list(parts)
+    assert set(names) == {"genset+battery", "battery+grid", "genset+battery+grid"} and sum(len(i) for _, i in parts.values()) == n
+    fleet = BucketedFleet.from_batches([parts[k][0] for k in names], obs_prefetch=8)
+    assert fleet.fused
+    rs = np.random.RandomState(0)
+    sample = [np.sort(rs.choice(e.n_grids, 6, replace=False)) for e in fleet.envs]
+    oms = [[oracle.OracleMicrogrid(_grid_params(e.batch, int(j))) for j in s] for e, s in zip(fleet.envs, sample)]
+    obs = fleet.reset()
+    for b, (s, ms) in enumerate(zip(sample, oms)):
+        assert [e.layout.obs_dim for e in fleet.envs][b] == obs[b].shape[1]
+        for j, om in zip(s, ms):
+            assert np.array_equal(obs[b][j].cpu().numpy(), om.reset()), (names[b], j)
+    g = torch.Generator(device=device); g.manual_seed(3)
+    for k in range(steps):
+        acts = fleet.sample_action(generator=g)
+        obs, reward, done, _ = fleet.step(acts)
+        for b, (env, s, ms) in enumerate(zip(fleet.envs, sample, oms)):
+            a = acts[b][torch.as_tensor(s, device=device)].cpu().numpy()
+            L = env.layout
+            for q, (j, om) in enumerate(zip(s, ms)):
+                ad, c = {}, 0
+                if L.has_genset:
+                    ad["genset"] = a[q, c:c + 2]; c += 2
+                if L.has_battery:
+                    ad["battery"] = a[q, c]; c += 1
+                if L.has_grid:
+                    ad["grid"] = a[q, c]
+                out = om.run(ad, True)
+                assert reward[b][j].item() == out.reward and bool(done[b][j]) == bool(out.done), (names[b], k, j)
+                assert np.array_equal(obs[b][j].cpu().numpy(), om.observe()), (names[b], k, j)
+    fleet.close()
