@@ -131,10 +131,14 @@ __device__ __forceinline__ void load_inputs_at(const AT *__restrict__ act, const
     }
 }
 
-template <int F, int U, typename AT>
+// RICH = false: the launch writes neither log rows nor the status trace -- compiled out, together with every value only
+// they consume (balance sums, co2, the violations mask): the lean form is the hot one (reward / done / SoC streams).
+template <int F, int U, typename AT, bool RICH>
 __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT *__restrict__ actions, int32_t t0,
-                                                         int32_t K, int normalized, const FusedOut out, int32_t gpb)
+                                                         int32_t K, int normalized, const FusedOut out_rt, int32_t gpb)
 {
+    FusedOut out = out_rt;
+    if constexpr (!RICH) { out.log = nullptr; out.status_trace = nullptr; }
     const int32_t K_launch = K;          // what the host asked for (the counter always moves by this much)
     t0 = resolve_t(a, t0);
     K = resolve_k(a, t0, K);
@@ -649,10 +653,12 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
 // (ids [K, N], one byte each: a DiscreteMicrogridEnv roll-out) or constant per grid (ids [N]: RuleBasedControl.run,
 // algos/rbc/rbc.py:64-93).  No action stream at all: per step only the series rows are read.
 // ------------------------------------------------------------------------------------------------------
-template <int F, int U, bool PER_STEP>
+template <int F, int U, bool PER_STEP, bool RICH>
 __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const PLWords tab, const uint8_t *__restrict__ ids,
-                                                          int32_t t0, int32_t K, const FusedOut out, int32_t gpb)
+                                                          int32_t t0, int32_t K, const FusedOut out_rt, int32_t gpb)
 {
+    FusedOut out = out_rt;
+    if constexpr (!RICH) { out.log = nullptr; out.status_trace = nullptr; }
     const int32_t K_launch = K;          // what the host asked for (the counter always moves by this much)
     t0 = resolve_t(a, t0);
     K = resolve_k(a, t0, K);
@@ -1780,12 +1786,17 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
         const int32_t gpb = fused_grids_per_block(h, k.g1 - k.g0);
         const unsigned blocks = (unsigned)((k.g1 - k.g0 + gpb - 1) / gpb);
+        const bool rich = log != nullptr || status_trace != nullptr;
         if (k.act_f32) {
-            MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, float><<<blocks, BLOCK_K, 0, s>>>(
-                                          k, (const float *)actions, t_arg(h), K, normalized, fo, gpb)));
+            if (rich) { MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, float, true><<<blocks, BLOCK_K, 0, s>>>(
+                                                      k, (const float *)actions, t_arg(h), K, normalized, fo, gpb))); }
+            else { MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, float, false><<<blocks, BLOCK_K, 0, s>>>(
+                                                 k, (const float *)actions, t_arg(h), K, normalized, fo, gpb))); }
         } else {
-            MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, double><<<blocks, BLOCK_K, 0, s>>>(
-                                          k, (const double *)actions, t_arg(h), K, normalized, fo, gpb)));
+            if (rich) { MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, double, true><<<blocks, BLOCK_K, 0, s>>>(
+                                                      k, (const double *)actions, t_arg(h), K, normalized, fo, gpb))); }
+            else { MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, double, false><<<blocks, BLOCK_K, 0, s>>>(
+                                                 k, (const double *)actions, t_arg(h), K, normalized, fo, gpb))); }
         }
     });
     hipError_t e = hipGetLastError();
@@ -1878,13 +1889,12 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
         const int32_t gpb = fused_grids_per_block(h, k.g1 - k.g0);
         const unsigned blocks = (unsigned)((k.g1 - k.g0 + gpb - 1) / gpb);
-        if (per_step) {
-            MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT, true><<<blocks, BLOCK_K, 0, s>>>(
-                                          k, tab, action_id, t_arg(h), K, fo, gpb)));
-        } else {
-            MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT, false><<<blocks, BLOCK_K, 0, s>>>(
-                                          k, tab, action_id, t_arg(h), K, fo, gpb)));
-        }
+        const bool rich = log != nullptr || status_trace != nullptr;
+#define MGX_ROLLOUT(PS, RC) MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT, PS, RC><<<blocks, BLOCK_K, 0, s>>>( \
+                                                          k, tab, action_id, t_arg(h), K, fo, gpb)))
+        if (per_step) { if (rich) { MGX_ROLLOUT(true, true); } else { MGX_ROLLOUT(true, false); } }
+        else { if (rich) { MGX_ROLLOUT(false, true); } else { MGX_ROLLOUT(false, false); } }
+#undef MGX_ROLLOUT
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rollout_kernel launch");
