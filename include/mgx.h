@@ -253,6 +253,16 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
                          int32_t n_actions, int32_t K, double *reward, uint8_t *done, double *soc_trace,
                          uint32_t *status_trace, double *ret_acc, double *log, mgx_stream stream);
 
+/* raise_errors=True (BaseMicrogridModule.__init__, base_module.py:40; as_source / as_sink, :213-224,265-270; _raise_error,
+ * :79-93): the reference refuses a request a module cannot meet with a ValueError instead of clipping it.  mgx_step always
+ * clips; mgx_check_step is its DRY RUN -- the same arithmetic on a register copy of the state, nothing stored, the counter
+ * untouched -- and writes per grid the mask of requests the reference would refuse: bit 0 genset request outside
+ * [min, max] production, bit 1 battery request above max_production / max_consumption, bit 2 grid request above its
+ * limit, bit 3 genset goal outside [0, 1], bit 4 negative genset energy.  A caller that wants raise_errors semantics
+ * checks first and steps only when every mask is 0 (the reference has by then already stepped the modules that come
+ * before the refusing one in its sweep; here nothing is applied).  violations [N] uint32 (device). */
+int mgx_check_step(mgx_handle *h, const void *actions, int normalized, uint32_t *violations, mgx_stream stream);
+
 /* K consecutive mgx_step calls issued by ONE call: the Gym cadence (`for a in actions: env.step(a)`, one kernel launch
  * per env-step, envs/base/base.py:169-209) without a host round trip per step -- from Python a per-step call costs
  * more than the 5 us the kernel takes at N = 100 000.  actions [K, N, A]; reward [K, N]; done [K, N], obs [K, N, D]

@@ -76,6 +76,39 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *
     advance_counter_in_kernel(a, 1);
 }
 
+// Dry run of one step: which requests would the reference refuse with raise_errors=True (base_module.py:79-93,213-224,
+// 265-270)?  The step arithmetic runs on a register copy of the state; only the violations mask leaves the kernel.
+template <int F>
+__global__ __launch_bounds__(BLOCK) void check_kernel(const KArgs a, const void *__restrict__ actions, int32_t t, int normalized,
+                                                      uint32_t *__restrict__ violations)
+{
+    t = resolve_t(a, t);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.g1) return;
+    Params p; State s; Inputs in; Outputs o; Derived d;
+    load_state<F>(a.c, i, true, s);
+    load_params<F>(a.c, i, p);
+    derive<F>(p, d);
+    if (a.n_load == 1 && a.n_pv == 1) {
+        if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t, in);
+        else load_inputs<F>(a.c, (const double *)actions, a.N, i, t, in);
+    } else {                                               // several load / renewable modules: the controllable modules' limits
+        constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);   // do not depend on them
+        int k = 0;
+        auto ld = [&](int j) { return a.act_f32 ? (double)((const float *)actions)[i * A + j] : ((const double *)actions)[i * A + j]; };
+        if constexpr (F & F_GENSET) { in.a_goal = ld(k); in.a_gen = ld(k + 1); k += 2; }
+        if constexpr (F & F_BATTERY) { in.a_bat = ld(k); k += 1; }
+        if constexpr (F & F_GRID) {
+            in.a_grid = ld(k);
+            const double *g = a.c.grid_ts + ((int64_t)t * 4) * a.N + i;
+            in.g_pimp = g[0]; in.g_pexp = g[a.N]; in.g_co2 = g[2 * (int64_t)a.N]; in.g_stat = g[3 * (int64_t)a.N];
+        }
+        in.load = 0.0; in.pv = 0.0;
+    }
+    step_core<F>(p, d, s, in, normalized != 0, false, false, o);
+    violations[i] = o.violations;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // K fused steps: parameters + state live in registers; actions / series rows stream through a U-slot register
 // ring (slot u is refilled with step k+U as soon as step k has been consumed, so U steps of loads are always in
@@ -1752,6 +1785,19 @@ int mgx_step(mgx_handle *h, const void *actions, int normalized, double *reward,
     g_err[0] = 0;
     if (int rc = check_step_args(h, actions, reward, obs, 1, "mgx_step")) return rc;
     return step_once(h, actions, normalized, reward, done, obs, log, (hipStream_t)stream);
+}
+
+int mgx_check_step(mgx_handle *h, const void *actions, int normalized, uint32_t *violations, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !violations || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_check_step: NULL argument");
+    if (!dev_counter(h) && (h->t < 0 || h->t >= h->k.T))
+        return fail(MGX_ERR_RANGE, "mgx_check_step: step %d is outside the time series (length %d)", h->t, h->k.T);
+    for_each_shard(h, (hipStream_t)stream, [&](const KArgs &k, hipStream_t s) {
+        MGX_DISPATCH_F(h->flags, (check_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, actions, t_arg(h), normalized, violations)));
+    });
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "check_kernel launch");
 }
 
 int mgx_step_many(mgx_handle *h, const void *actions, int32_t K, int normalized, double *reward, uint8_t *done, void *obs,

@@ -236,6 +236,14 @@ class StepEngine:
             return []
         return [torch.cuda.ExternalStream(self._lib.mgx_shard_stream(self._h, j), device=self.device) for j in range(n)]
 
+    def check_step(self, actions, normalized=True, out=None):
+        """Dry run of ``step`` (``mgx_check_step``): int32 mask [N] of the requests the reference would refuse with
+        ``raise_errors=True``; state and step counter are not touched."""
+        actions = self._check_actions(actions, ())
+        mask = out if out is not None else self._empty(self.N, dtype=torch.int32)
+        self._call(self._lib.mgx_check_step, _ptr(actions), 1 if normalized else 0, mask.data_ptr())
+        return mask
+
     def step_many(self, actions, normalized=True, want_obs=False, want_log=False, done=True, out=None):
         """K single-step launches issued by one call (``mgx_step_many``): actions [K, N, A] -> reward [K, N], done [K, N],
         optionally obs [K, N, D] and log [K, L, N]."""

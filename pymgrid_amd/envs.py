@@ -11,9 +11,10 @@ Batched classes take and return torch tensors with a leading grid dimension N.  
 reference's own tests.
 
 Differences that are deliberate:
-  * the device always clips requests (the reference default ``raise_errors=False``); ``raise_errors=True``
-    (ValueError instead of clipping, base_module.py:79-93) is emulated from the step's ``violations`` mask AFTER the
-    (clipped) step has been applied.
+  * the device always clips requests (the reference default ``raise_errors=False``); with ``raise_errors=True``
+    (ValueError instead of clipping, base_module.py:79-93) every step is preceded by a dry run on device
+    (``mgx_check_step``) and a refused request raises before ANY module has been stepped (the reference has by then
+    stepped the modules that precede the refusing one in its sweep).
   * the flat observation order is fixed: load, pv, genset, battery, grid (the reference leaves it to gym's
     ``Dict`` ordering); ``info`` holds batched log columns instead of per-module dict lists.
 """
@@ -37,10 +38,10 @@ class BatchedMicrogridEnv:
                  action_dtype=torch.float64):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
-        # raise_errors=True (base_module.py:79-93): the device always clips; the step's `violations` log column
-        # is inspected afterwards (one device->host sync per step) and a ValueError is raised like the reference's.
+        # raise_errors=True (base_module.py:79-93): every step is preceded by its dry run (mgx_check_step: the violations
+        # mask, nothing stored; one device->host sync per step) and a refused request raises ValueError like the
+        # reference's -- before any state changes.
         self.raise_errors = bool(raise_errors)
-        log = log or self.raise_errors
         self.batch = batch
         self.layout = batch.layout
         # obs_dtype=torch.float32: rows leave the device as floats (RN of the float64 value): what a policy consumes
@@ -239,6 +240,8 @@ class BatchedMicrogridEnv:
         a control dict as taken by ``Microgrid.run``.  Returns (obs [N, D], reward [N], done [N] bool, info)."""
         if isinstance(action, dict):
             action = self.control_to_tensor(action).to(self.engine.action_dtype)
+        if self.raise_errors:             # dry run first (mgx_check_step): a refused request raises BEFORE anything is applied
+            self._raise_on_violations(self.engine.check_step(action, normalized=normalized))
         want_obs, out = self._obs_target()
         obs, reward, done, log = self.engine.step(action, normalized=normalized, want_obs=want_obs,
                                                   want_log=self._keep_log, out=out)
@@ -248,8 +251,6 @@ class BatchedMicrogridEnv:
             self._log_rows.append(log)
             self._shaped_rows.append(reward.clone())
             info["log"] = log
-            if self.raise_errors:
-                self._raise_on_violations(log[-1])
         return self._select_obs(obs), reward, done.view(torch.bool), info   # 0/1 bytes reinterpreted, no conversion kernel
 
     _VIOLATIONS = ((1, "Genset", "supply requested value as a source (outside [min_production, max_production])"),
@@ -263,7 +264,7 @@ class BatchedMicrogridEnv:
             bad = int((mask != 0).nonzero()[0])
             m = int(mask[bad])
             what = "; ".join(f"Module {mod} unable to {msg}" for bit, mod, msg in self._VIOLATIONS if m & bit)
-            raise ValueError(f"{what} [microgrid {bad}; the step has been applied with the request clipped]")
+            raise ValueError(f"{what} [microgrid {bad}; nothing has been applied]")
 
     run = step      # Microgrid.run has the same signature and return value (microgrid.py:227-325)
 
@@ -409,9 +410,7 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
         if log is not None:
             self._log_rows.append(log)
             self._shaped_rows.append(reward.clone())
-            info["log"] = log
-            if self.raise_errors:
-                self._raise_on_violations(log[-1])
+            info["log"] = log           # (an expanded priority list never asks a module for more than it can do: nothing to refuse)
         return self._select_obs(obs), reward, done.view(torch.bool), info
 
     def sample_action(self, generator=None):

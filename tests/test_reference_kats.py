@@ -11,6 +11,7 @@ oracle and (on a GPU) through the HIP engine.
   test_renewable_module.py:19-58 (observation bounds, first step, forecasts, negative-valued input series)
 """
 import numpy as np
+import torch
 import pytest
 
 T = 100
@@ -110,7 +111,26 @@ def test_raise_errors_true_raises_value_error(device):               # :110-122 
         env.step({"genset": [np.array([0.0, 0.5])]})
     with pytest.raises(ValueError, match="goal_status"):
         env.step({"genset": [np.array([-0.5, 0.0])]})
+    # the refusals came from the dry run (mgx_check_step): nothing was applied -- counter and genset status as before
+    assert env.current_step == 1 and env.batch.cols["gen_status"].cpu().numpy().view(np.uint32)[0] & 0xffff == 0x0101
+    _, _, _, info = env.step({"genset": [np.array([1.0, 0.25])]})
+    assert env.current_step == 2 and info["violations"] == 0.0
     env.close()
+    from pymgrid_amd import BatchedMicrogridEnv, MicrogridBatch
+    bat = dict(load_ts=np.full(6, 10.0), pv_ts=np.zeros(6), horizon=0, final_step=6, initial_step=0,
+               unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=1.0),
+               battery=dict(min_capacity=0.0, max_capacity=100.0, max_charge=20.0, max_discharge=20.0, efficiency=1.0,
+                            battery_cost_cycle=0.0, init_soc=0.5))
+    benv = BatchedMicrogridEnv(MicrogridBatch.from_grids([bat, bat], device=device), raise_errors=True, observations=False)
+    benv.reset()
+    ok = torch.tensor([[10.0], [-10.0]], dtype=torch.float64, device=device)
+    bad = torch.tensor([[10.0], [-30.0]], dtype=torch.float64, device=device)      # grid 1: charge 30 > max_charge 20
+    benv.step(ok, normalized=False)
+    charge = benv.batch.cols["charge"].clone()
+    with pytest.raises(ValueError, match=r"BatteryModule.*microgrid 1"):
+        benv.step(bad, normalized=False)
+    assert torch.equal(benv.batch.cols["charge"], charge) and benv.current_step == 1
+    benv.close()
     quiet = MicrogridEnv(genset_grid(), device=device)               # raise_errors=False: silently clipped
     quiet.reset()
     _, _, _, info = quiet.step({"genset": [np.array([0.0, 0.5])]})
