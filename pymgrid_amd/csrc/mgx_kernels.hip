@@ -1607,6 +1607,19 @@ int mgx_set_forecast_noise(mgx_handle *h, uint64_t seed, int increase_uncertaint
     return MGX_OK;
 }
 
+// device copy of the handle's KArgs (fleet_step_kernel, step_dk_kernel): uploaded on `st` when it changed
+static int sync_device_kargs(mgx_handle *h, hipStream_t st, const char *who)
+{
+    if (h->k_uploaded_valid && memcmp(&h->k, &h->k_uploaded, sizeof(KArgs)) == 0) return MGX_OK;
+    hipError_t e = hipSuccess;
+    if (!h->d_kargs) e = hipMalloc((void **)&h->d_kargs, sizeof(KArgs));
+    if (e == hipSuccess) e = hipMemcpyAsync(h->d_kargs, &h->k, sizeof(KArgs), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return hip_fail(e, who);
+    memcpy(&h->k_uploaded, &h->k, sizeof(KArgs));
+    h->k_uploaded_valid = true;
+    return MGX_OK;
+}
+
 // back to the full series after a per-grid-window episode
 static void leave_windows(mgx_handle *h)
 {
@@ -1984,16 +1997,8 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
     for (int32_t j = 0; j < n; j++)
         if (items[j].wait_prefetch) { if (int rc = mgx_prefetch_wait(items[j].handle, stream)) return rc; }
     if (fusable) {
-        for (int32_t j = 0; j < n; j++) {                 // device copies of the batches' KArgs: uploaded when they changed
-            mgx_handle *h = items[j].handle;
-            if (h->k_uploaded_valid && memcmp(&h->k, &h->k_uploaded, sizeof(KArgs)) == 0) continue;
-            hipError_t e = hipSuccess;
-            if (!h->d_kargs) e = hipMalloc((void **)&h->d_kargs, sizeof(KArgs));
-            if (e == hipSuccess) e = hipMemcpyAsync(h->d_kargs, &h->k, sizeof(KArgs), hipMemcpyHostToDevice, st);
-            if (e != hipSuccess) return hip_fail(e, "mgx_fleet_step: uploading the layout table");
-            memcpy(&h->k_uploaded, &h->k, sizeof(KArgs));
-            h->k_uploaded_valid = true;
-        }
+        for (int32_t j = 0; j < n; j++)                   // device copies of the batches' KArgs: uploaded when they changed
+            if (int rc = sync_device_kargs(items[j].handle, st, "mgx_fleet_step: uploading the layout table")) return rc;
         for (int32_t j0 = 0; j0 < n; j0 += MGX_FLEET_MAX) {
             FleetArgs fa;
             FleetWin fw;
