@@ -33,8 +33,10 @@ class BatchedMicrogridEnv:
     ``Microgrid.run(control, normalized)``; the reference's own ContinuousMicrogridEnv is non-functional in
     v1.2.2)."""
 
+    DEFAULT_OBS_PREFETCH = 8
+
     def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
-                 raise_errors=False, observation_keys=None, obs_dtype=torch.float64, obs_prefetch=0,
+                 raise_errors=False, observation_keys=None, obs_dtype=torch.float64, obs_prefetch=None,
                  action_dtype=torch.float64):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
@@ -46,7 +48,7 @@ class BatchedMicrogridEnv:
         self.layout = batch.layout
         # obs_dtype=torch.float32: rows leave the device as floats (RN of the float64 value): what a policy consumes
         self.engine = StepEngine(batch, obs_dtype=obs_dtype, action_dtype=action_dtype)
-        # obs_prefetch=K (> 1): the forecast windows of the next K steps are written in one launch every K steps
+        # obs_prefetch=K (> 1; default 8, 0 = off): the forecast windows of the next K steps are written in one launch every K steps
         # (engine.observe_windows: each series value read and normalised once instead of 1 + horizon times) and a step
         # only adds the genset / battery state columns.  Same values; the returned obs is a view into a ring of K blocks
         # and stays valid for at least K further steps.  Ignored (per-step rows) where there is nothing to share: no
@@ -54,8 +56,11 @@ class BatchedMicrogridEnv:
         L = self.layout
         noisy = batch.forecast_noise is not None or any(batch.cols.get(k) is not None
                                                         for k in ("load_noise_std", "pv_noise_std", "grid_noise_std"))
-        self.obs_prefetch = int(obs_prefetch) if (obs_prefetch and int(obs_prefetch) > 1 and observations and L.horizon > 0
-                                                   and L.n_load == 1 and L.n_pv == 1 and not noisy) else 0
+        if obs_prefetch is None:      # default: on (K = 8) wherever there are forecast windows to share; 0 switches it off
+            obs_prefetch = self.DEFAULT_OBS_PREFETCH
+        self._prefetch_ok = bool(observations and L.horizon > 0 and L.n_load == 1 and L.n_pv == 1 and not noisy)
+        self._obs_dtype = obs_dtype
+        self.obs_prefetch = int(obs_prefetch) if (obs_prefetch and int(obs_prefetch) > 1 and self._prefetch_ok) else 0
         # Three rings of K blocks: while the steps walk ring r, the windows of ring r + 1 (the NEXT K counter values) are
         # being written on the engine's prefetch stream (mgx_observe_windows_ahead -- the series rows do not depend on the
         # state, so this overlaps the step kernels), and ring r - 1 is still intact for whoever holds observations from it.
@@ -167,6 +172,22 @@ class BatchedMicrogridEnv:
         if st is None:
             return torch.full((self.n_grids,), t, dtype=torch.int32, device=self.batch.device)
         return st + t
+
+    def set_obs_prefetch(self, K):
+        """Switch the window prefetch on (K > 1 blocks per ring) or off (0) after construction; the next observation comes
+        from the new mode (rings are refilled at the current step)."""
+        K = int(K) if (K and int(K) > 1 and self._prefetch_ok) else 0
+        if K == self.obs_prefetch:
+            return
+        if self._chunked and K != self.obs_prefetch:
+            raise RuntimeError("this env belongs to a fused BucketedFleet: its ring depth is fixed")
+        self.obs_prefetch = K
+        L = self.layout
+        self._ring = self._rings = None
+        self.engine.set_obs_state_only(bool(K))
+        if K:
+            self._rings = torch.empty(3, K, L.n_grids, L.obs_dim, dtype=self._obs_dtype, device=self.batch.device)
+            self._refill()
 
     def _after_external_steps(self):
         """The engine was stepped behind the env's back (fused rollouts: ``RuleBasedControl.run``, ``engine.step_k``): the
@@ -368,7 +389,7 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
 
     def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
                  trajectory_func=None, raise_errors=False, observation_keys=None, obs_dtype=torch.float64,
-                 obs_prefetch=0):
+                 obs_prefetch=None):
         super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
                          trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
                          obs_dtype=obs_dtype, obs_prefetch=obs_prefetch)
@@ -476,7 +497,7 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
                  trajectory_func=None, raise_errors=False, observation_keys=None):
         super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
                          reward_shaping_func=reward_shaping_func, trajectory_func=trajectory_func,
-                         raise_errors=raise_errors, observation_keys=observation_keys)
+                         raise_errors=raise_errors, observation_keys=observation_keys, obs_prefetch=0)
         self.flat_spaces = flat_spaces
 
     def reset(self, initial_step=None):
@@ -497,7 +518,8 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
                  reward_shaping_func=None, trajectory_func=None, raise_errors=False, observation_keys=None):
         super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
                          remove_redundant_gensets=remove_redundant_gensets, reward_shaping_func=reward_shaping_func,
-                         trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys)
+                         trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
+                         obs_prefetch=0)
         self.flat_spaces = flat_spaces
 
     def reset(self, initial_step=None):

@@ -26,9 +26,9 @@ class GraphedRollout:
     def __init__(self, env, policy, n_steps, warmup=2):
         if not isinstance(env, BatchedMicrogridEnv):
             raise TypeError("env must be a (Discrete)BatchedMicrogridEnv")
-        if env.obs_prefetch or env.raise_errors or env._keep_log:
-            raise ValueError("GraphedRollout needs an env with obs_prefetch=0, raise_errors=False, log=False "
-                             "(their bookkeeping lives on the host)")
+        if env.raise_errors or env._keep_log:
+            raise ValueError("GraphedRollout needs an env with raise_errors=False, log=False (their bookkeeping lives on the host)")
+        env.set_obs_prefetch(0)        # the ring bookkeeping lives on the host too: captured steps write whole rows
         if not env._observations:
             raise ValueError("the policy consumes observations: build the env with observations=True")
         self.env, self.policy, self.n_steps = env, policy, int(n_steps)

@@ -16,7 +16,7 @@ for N in (1_000, 10_000, 100_000):
     for H in (0, 24):
         def make():
             return BatchedMicrogridEnv(generate(N, n_steps=4000, seed=6, arch="genset+battery", horizon=H, device=dev),
-                                       obs_dtype=torch.float32, action_dtype=torch.float32)
+                                       obs_dtype=torch.float32, action_dtype=torch.float32, obs_prefetch=0)
         env = make()
         D, A = env.layout.obs_dim, env.layout.action_dim
         W1 = torch.randn(D, 64, device=dev) * 0.2
