@@ -461,7 +461,7 @@ def main():
         side = (min(args.steps, SIDE_ROUNDS[0]), min(args.warmup, SIDE_ROUNDS[1]))
         for mode in ("fused", "step", "rbc"):
             if mode != args.mode:
-                results[mode] = measure(mode, sharded=(S > 1 and mode == "fused"), rounds=side[0], warmup=side[1])
+                results[mode] = measure(mode, sharded=(S > 1 and mode in ("fused", "rbc")), rounds=side[0], warmup=side[1])
         if S > 1:    # the same fused kernel as ONE launch sequence over all N grids
             results["fused_one_stream"] = measure("fused", sharded=False, rounds=side[0], warmup=side[1])
         results["step_python"] = measure("step_python", sharded=False, rounds=min(side[0], 32), warmup=min(side[1], 8))

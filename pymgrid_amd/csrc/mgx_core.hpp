@@ -448,9 +448,11 @@ __device__ __forceinline__ double pl_energy(double rem, double mn, double mx, do
     return pl_isclose0(rem) ? 0.0 : ((rem > 0) ? produce : consume);
 }
 
+// gen_instant (wave-uniform, see step_core): next_status(goal) == goal, so the genset's limits under a list element are
+// act * running_{min,max} -- loop-invariant for a fixed list, which lets the compiler hoist them out of a K-step loop.
 template <int F>
 __device__ __forceinline__ void populate_core(const Params &p, const State &s, uint32_t word, Inputs &in, double &bat_q,
-                                              double total_load, double renewable)
+                                              double total_load, double renewable, bool gen_instant = false)
 {
     // total_load: sum of the fixed sinks' max_consumption (_get_load :157-164); renewable: np.sum of the flex
     // sources' max_production (_get_renewable :166-167)
@@ -460,7 +462,7 @@ __device__ __forceinline__ void populate_core(const Params &p, const State &s, u
     if constexpr (F & F_GENSET) {
 #pragma unroll
         for (int act = 0; act < 2; act++) {
-            const double ns = (double)genset_next_status(s.status, act);
+            const double ns = gen_instant ? (double)act : (double)genset_next_status(s.status, act);
             g_mx[act] = ns * p.gen_rmax; g_mn[act] = ns * p.gen_rmin;
         }
     }

@@ -11,6 +11,8 @@
 // the per-step launches -- the blockIdx -> data mapping is deliberately launch-invariant.
 #include "mgx_core.hpp"
 
+#include <type_traits>
+
 namespace mgx {
 
 #ifndef MGX_BLOCK
@@ -25,8 +27,9 @@ constexpr int BLOCK = MGX_BLOCK;
 #endif
 constexpr int BLOCK_K = MGX_BLOCK_K;
 #ifndef MGX_RING_ROLLOUT
-#define MGX_RING_ROLLOUT 4  // ring depth of the discrete rollout kernel (its slots are small: 2..6 doubles + an id byte)
-#endif
+#define MGX_RING_ROLLOUT 8  // ring depth of the discrete rollout kernel for layouts without a GridModule (a slot is two series
+#endif                      // values + an id byte; 58.2 vs 61.3 us per 64 steps against depth 4 once the loop was specialised:
+                            // profiles/r02/exp_rollout_gpb_ring.txt); with a GridModule (six values per slot) the depth stays 4
 
 // ------------------------------------------------------------------------------------------------------
 // Single step: Microgrid.run for N grids (microgrid.py:227-325) + optional obs (base.py:205-209) + log.
@@ -713,41 +716,51 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
     uint32_t word = PER_STEP ? 0u : pl_select(tab, ids[i]);
     double ret = 0.0;
 
-    Inputs ring[U];
-    uint8_t idr[U];
+    // The step loop exists twice, specialised at COMPILE time on the wave-uniform `gen_instant`: in the instant form the
+    // genset's status is its goal, its limits under a fixed list are loop-invariant (hoisted), and the FSM is gone.
+    auto run = [&](auto gi_tag) __attribute__((always_inline)) {
+        constexpr bool GI = decltype(gi_tag)::value;
+        Inputs ring[U];
+        uint8_t idr[U];
 #pragma unroll
-    for (int u = 0; u < U; u++)
-        if (u < K) {
-            load_series_at<F>(lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
-            if constexpr (PER_STEP) idr[u] = ids[(int64_t)u * N + i];
-        }
+        for (int u = 0; u < U; u++)
+            if (u < K) {
+                load_series_at<F>(lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
+                if constexpr (PER_STEP) idr[u] = ids[(int64_t)u * N + i];
+            }
 
-    int64_t off = i;
-    for (int32_t k0 = 0; k0 < K; k0 += U) {
+        int64_t off = i;
+        for (int32_t k0 = 0; k0 < K; k0 += U) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int32_t k = k0 + u;
-            if (k < K) {
-                Inputs in = ring[u];
-                if constexpr (PER_STEP) word = pl_select(tab, idr[u]);
-                if (k + U < K) {
-                    load_series_at<F>(lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
-                    if constexpr (PER_STEP) idr[u] = ids[off + (int64_t)U * N];
+            for (int u = 0; u < U; u++) {
+                const int32_t k = k0 + u;
+                if (k < K) {
+                    Inputs in = ring[u];
+                    if constexpr (PER_STEP) word = pl_select(tab, idr[u]);
+                    if (k + U < K) {
+                        load_series_at<F>(lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
+                        if constexpr (PER_STEP) idr[u] = ids[off + (int64_t)U * N];
+                    }
+                    double bat_q;
+                    populate_core<F>(p, s, word, in, bat_q, 0.0 + -1 * in.load, in.pv, GI);
+                    Outputs o;
+                    step_core<F, true>(p, d, s, in, false, want_soc, GI, o, bat_q);
+                    const double r = shaped_reward<F>(a.shaper, o);
+                    if (out.reward) out.reward[off] = r;
+                    if (out.done) out.done[off] = (uint8_t)(k >= k_done);
+                    if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
+                    if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
+                    if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
+                    ret += r;
+                    off += N;
                 }
-                double bat_q;
-                populate_core<F>(p, s, word, in, bat_q, 0.0 + -1 * in.load, in.pv);
-                Outputs o;
-                step_core<F, true>(p, d, s, in, false, want_soc, gen_instant, o, bat_q);
-                const double r = shaped_reward<F>(a.shaper, o);
-                if (out.reward) out.reward[off] = r;
-                if (out.done) out.done[off] = (uint8_t)(k >= k_done);
-                if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
-                if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
-                if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
-                ret += r;
-                off += N;
             }
         }
+    };
+    if constexpr ((F & F_GENSET) != 0) {
+        if (gen_instant) run(std::true_type{}); else run(std::false_type{});
+    } else {
+        run(std::false_type{});
     }
     if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
     store_state<F>(a.c, i, s);
@@ -1945,11 +1958,12 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_rollout_discrete")) return rc;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     hipStream_t st = (hipStream_t)stream;
+    static const int gpb_env = [] { const char *e = getenv("MGX_GPB_ROLLOUT"); return e ? atoi(e) : 0; }();   // experiment knob
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
-        const int32_t gpb = fused_grids_per_block(h, k.g1 - k.g0);
+        const int32_t gpb = gpb_env > 0 ? gpb_env : fused_grids_per_block(h, k.g1 - k.g0);
         const unsigned blocks = (unsigned)((k.g1 - k.g0 + gpb - 1) / gpb);
         const bool rich = log != nullptr || status_trace != nullptr;
-#define MGX_ROLLOUT(PS, RC) MGX_DISPATCH_F(h->flags, (rollout_kernel<F, MGX_RING_ROLLOUT, PS, RC><<<blocks, BLOCK_K, 0, s>>>( \
+#define MGX_ROLLOUT(PS, RC) MGX_DISPATCH_F(h->flags, (rollout_kernel<F, (F & F_GRID) ? 4 : MGX_RING_ROLLOUT, PS, RC><<<blocks, BLOCK_K, 0, s>>>( \
                                                           k, tab, action_id, t_arg(h), K, fo, gpb)))
         if (per_step) { if (rich) { MGX_ROLLOUT(true, true); } else { MGX_ROLLOUT(true, false); } }
         else { if (rich) { MGX_ROLLOUT(false, true); } else { MGX_ROLLOUT(false, false); } }
