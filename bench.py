@@ -238,9 +238,16 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist):
             c_ts = L.n_load + L.n_pv + 4 * int(L.has_grid)
             alg += L.n_grids * (L.bytes_per_step() + esz * L.obs_dim + 8 * c_ts * (K_ring + L.horizon) / K_ring)
         ach = alg / (gpu / steps) / 1e9
+        traffic = None
+        try:                                              # PMC bytes of the same fleet shape, if a profile of it is committed
+            tf = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic_fleet.json")))
+            if (tf["grids_per_gpu"], tf["obs_prefetch"], tf["rows"]) == (3 * per, K_ring, "float64" if dt == torch.float64 else "float32"):
+                traffic = tf["hbm_bytes_per_fleet_step"]
+        except (OSError, ValueError, KeyError):
+            pass
         out[name] = {"value": 3 * per * world * steps / wall, "us_per_step": wall / steps * 1e6,
                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                  "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_us": gpu / steps * 1e6,
+                                  "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_us": gpu / steps * 1e6,
                                   "launch": "one fleet step = one mgx_fleet_step call: ONE fleet_step_kernel launch over the three "
                                             f"buckets + every {K_ring}th step the window prefetch of the next {K_ring} steps "
                                             "(obs_windows_k_kernel per bucket, on the prefetch streams, overlapping the steps)",
