@@ -168,7 +168,8 @@ int mgx_set_window(mgx_handle *h, int32_t initial_step, int32_t final_step);
  * clamped into it and a length is cut at the env's final step (the reference raises ValueError in
  * _check_trajectory_func, microgrid.py:181-203: validate on the host if the arrays come from outside).  final_rel [N]
  * (device, int32; required with `length`) receives the episode lengths actually used and must stay alive until the
- * next reset.  Observation bounds stay those of the full series.  mgx_reset() returns to the full series.
+ * next reset.  Observation bounds stay those of the full series.  Stepping past the longest episode (counter >= max_length)
+ * is MGX_ERR_RANGE, like stepping past the end of a series.  mgx_reset() returns to the full series.
  * MGX_ERR_UNSUPPORTED with several load / renewable modules, in device-counter mode or while stepping in shards. */
 int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length,
                       double *load_w, double *pv_w, double *grid_w, int32_t *final_rel, void *obs, mgx_stream stream);

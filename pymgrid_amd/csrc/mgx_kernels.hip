@@ -1173,6 +1173,9 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOC
 // kernel argument for "the current step": the host's counter, or 0 (= offset to the device counter)
 inline int32_t t_arg(const mgx_handle *h) { return h->k.t_dev ? 0 : h->t; }
 inline bool dev_counter(const mgx_handle *h) { return h->k.t_dev != nullptr; }
+// rows a stepping call may consume: the series -- or, during a per-grid-window episode, the longest episode (the window
+// buffers hold horizon + 1 further rows, but those are forecast rows: stepping into them is stepping past the end)
+inline int32_t step_limit(const mgx_handle *h) { return h->windowed ? h->layout.final_step : h->k.T; }
 inline void advance(mgx_handle *h, int32_t k, hipStream_t st)
 {
     h->counter_stream = st;      // device-counter mode: the stepping kernel itself advanced the counter (on this stream)
@@ -1793,9 +1796,9 @@ static int check_step_args(const mgx_handle *h, const void *actions, const doubl
 {
     if (!h || !reward || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "%s: NULL argument", who);
     if (K <= 0) return fail(MGX_ERR_INVALID, "%s: K must be positive", who);
-    if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > h->k.T))
-        return K == 1 ? fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, h->k.T)
-                      : fail(MGX_ERR_RANGE, "%s: steps [%d, %d) leave the time series (length %d)", who, h->t, h->t + K, h->k.T);
+    if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
+        return K == 1 ? fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, step_limit(h))
+                      : fail(MGX_ERR_RANGE, "%s: steps [%d, %d) leave the time series (length %d)", who, h->t, h->t + K, step_limit(h));
     if (obs) {
         if (int rc = need_obs_bounds(h, who)) return rc;
         if (h->n_shards > 1 && !h->multi && h->k.H > 0 && !h->k.obs_state_only)
@@ -1817,8 +1820,8 @@ int mgx_check_step(mgx_handle *h, const void *actions, int normalized, uint32_t 
 {
     g_err[0] = 0;
     if (!h || !violations || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_check_step: NULL argument");
-    if (!dev_counter(h) && (h->t < 0 || h->t >= h->k.T))
-        return fail(MGX_ERR_RANGE, "mgx_check_step: step %d is outside the time series (length %d)", h->t, h->k.T);
+    if (!dev_counter(h) && (h->t < 0 || h->t >= step_limit(h)))
+        return fail(MGX_ERR_RANGE, "mgx_check_step: step %d is outside the time series (length %d)", h->t, step_limit(h));
     for_each_shard(h, (hipStream_t)stream, [&](const KArgs &k, hipStream_t s) {
         MGX_DISPATCH_F(h->flags, (check_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, actions, t_arg(h), normalized, violations)));
     });
@@ -1851,8 +1854,8 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_step_k: K must be positive");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: fused steps need exactly one load and one renewable module "
                                                     "per grid; use mgx_step");
-    if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > h->k.T))
-        return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
+    if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
+        return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, step_limit(h));
     hipStream_t st = (hipStream_t)stream;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
@@ -1904,8 +1907,8 @@ int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *
 {
     g_err[0] = 0;
     if (!h || !action_id || !table || !control) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: NULL argument");
-    if (!dev_counter(h) && (h->t < 0 || h->t >= h->k.T))
-        return fail(MGX_ERR_RANGE, "mgx_expand_discrete: step %d is outside the time series (length %d)", h->t, h->k.T);
+    if (!dev_counter(h) && (h->t < 0 || h->t >= step_limit(h)))
+        return fail(MGX_ERR_RANGE, "mgx_expand_discrete: step %d is outside the time series (length %d)", h->t, step_limit(h));
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_expand_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1952,8 +1955,8 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: K must be positive");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: needs exactly one load and one renewable module "
                                                     "per grid; use mgx_expand_discrete + mgx_step");
-    if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > h->k.T))
-        return fail(MGX_ERR_RANGE, "mgx_rollout_discrete: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, h->k.T);
+    if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
+        return fail(MGX_ERR_RANGE, "mgx_rollout_discrete: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, step_limit(h));
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_rollout_discrete")) return rc;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};

@@ -282,3 +282,113 @@ def test_prefetched_observations_stay_valid_for_k_steps(device):
         a = torch.rand(N, 4, dtype=torch.float64, device=device, generator=g)
         assert torch.equal(ref.step(a)[0], pre.step(a)[0]), k
     ref.close(); pre.close()
+
+
+def _toy_grid(rs, T, genset, battery, grid, horizon=0):
+    g = dict(load_ts=50 * rs.rand(T) + 1, pv_ts=40 * rs.rand(T) * (rs.rand(T) > 0.3), horizon=horizon, final_step=T, initial_step=0,
+             unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0))
+    if battery:
+        g["battery"] = dict(min_capacity=20.0, max_capacity=100.0 + 50 * rs.rand(), max_charge=25.0, max_discharge=25.0,
+                            efficiency=0.9, battery_cost_cycle=0.02, init_soc=0.3 + 0.5 * rs.rand())
+    if genset:
+        g["genset"] = dict(running_min_production=5.0, running_max_production=60.0, genset_cost=0.4, co2_per_unit=2.0,
+                           cost_per_unit_co2=0.1, start_up_time=int(rs.randint(0, 3)), wind_down_time=int(rs.randint(0, 3)))
+    if grid:
+        g["grid"] = dict(max_import=60.0, max_export=30.0, cost_per_unit_co2=0.1)
+        g["grid_ts"] = np.stack([0.1 + rs.rand(T), 0.5 * rs.rand(T), 0.3 * rs.rand(T), (rs.rand(T) > 0.2).astype(float)], axis=1)
+    return g
+
+
+def test_fleet_of_all_eight_module_sets_needs_two_launches(device, oracle):
+    """A fleet with every module set (8 buckets > the 6 entries of one fleet_step_kernel launch: two launches per step),
+    ragged bucket sizes, H = 3 with ring refills in chunks: every grid == its oracle microgrid (rewards, observations)."""
+    from pymgrid_amd.hetero import BucketedFleet
+    rs = np.random.RandomState(7)
+    T, H = 40, 3
+    grids = []
+    for f in range(8):
+        for _ in range(5 + 37 * f):                               # 5 .. 264 grids per module set
+            grids.append(_toy_grid(rs, T, bool(f & 1), bool(f & 2), bool(f & 4), horizon=H))
+    order = rs.permutation(len(grids))
+    grids = [grids[j] for j in order]
+    fleet = BucketedFleet(grids, device=device, observations=True, obs_prefetch=4)
+    assert len(fleet.envs) == 8 and fleet.fused
+    oms = [oracle.OracleMicrogrid(g) for g in grids]
+    obs = fleet.reset()
+    for b, (_, idx) in enumerate(fleet.buckets):
+        for q, j in enumerate(idx[:3]):
+            assert np.array_equal(obs[b][q].cpu().numpy(), oms[j].reset()), (b, j)
+    g = torch.Generator(device=device); g.manual_seed(1)
+    for k in range(13):                                            # three ring roll-overs at K = 4
+        acts = fleet.sample_action(generator=g)
+        obs, reward, done, _ = fleet.step(acts)
+        for b, ((_, idx), env) in enumerate(zip(fleet.buckets, fleet.envs)):
+            a = acts[b].cpu().numpy()
+            L = env.layout
+            for q, j in enumerate(idx[:3]):
+                ad, c = {}, 0
+                if L.has_genset:
+                    ad["genset"] = a[q, c:c + 2]; c += 2
+                if L.has_battery:
+                    ad["battery"] = a[q, c]; c += 1
+                if L.has_grid:
+                    ad["grid"] = a[q, c]
+                out = oms[j].run(ad, True)
+                assert reward[b][q].item() == out.reward, (k, b, j)
+                assert np.array_equal(obs[b][q].cpu().numpy(), oms[j].observe()), (k, b, j)
+    fleet.close()
+
+
+def test_edge_shapes_of_the_new_entry_points(device, oracle):
+    """Tiny and ragged shapes: more shards than 256-grid ranges (empty shards), one grid, K = 1 step_many, a per-grid window
+    that spans the whole series and windows of length 1."""
+    from pymgrid_amd import BatchedMicrogridEnv, MicrogridBatch, StepEngine
+    rs = np.random.RandomState(3)
+    T = 30
+    for n in (1, 300):
+        grids = [_toy_grid(rs, T, True, True, False) for _ in range(n)]
+        mk = lambda: StepEngine(MicrogridBatch.from_grids(grids, device=device))
+        e1, e2 = mk(), mk()
+        e2.set_shards(8)                                           # 300 grids -> ranges [0, 256), [256, 300), six empty ones
+        a = torch.rand(7, n, 3, dtype=torch.float64, device=device)
+        torch.cuda.synchronize(device)
+        e2.fork()
+        r1 = e1.step_k(a, reward=True, done=True)["reward"]
+        r2 = e2.step_k(a, reward=True, done=True)["reward"]
+        _, s1, _, _ = e1.step_many(a[:1])
+        _, s2, _, _ = e2.step_many(a[:1])
+        m2 = e2.check_step(a[1])                                    # dry run of the next step: == the violations column it logs
+        _, _, _, lg = e1.step(a[1], want_obs=False, want_log=True)
+        e2.join()
+        torch.cuda.synchronize(device)
+        assert torch.equal(r1, r2) and torch.equal(s1, s2) and s1.shape == (1, n)
+        assert torch.equal(m2.to(torch.float64), lg[-1]) and e2.current_step == 8
+        e1.close(); e2.close()
+    grids = [_toy_grid(rs, T, True, True, True, horizon=2) for _ in range(5)]
+    env = BatchedMicrogridEnv(MicrogridBatch.from_grids(grids, device=device), observations=True)
+    starts, lengths = np.array([0, 29, 5, 28, 0]), np.array([30, 1, 25, 1, 1])       # the whole series; single-step episodes
+    obs = env.reset_windows(starts, lengths).cpu().numpy()
+    oms = []
+    for p, s, n in zip(grids, starts, lengths):
+        q = dict(p); q["initial_step"], q["final_step"] = int(s), int(s) + int(n)
+        oms.append(oracle.OracleMicrogrid(q))
+    for j, om in enumerate(oms):
+        assert np.array_equal(obs[j], om.reset()), j
+    for k in range(30):
+        a = rs.rand(5, 4)
+        obs, reward, done, _ = env.step(_t(a, device))
+        for j, om in enumerate(oms):
+            if k < lengths[j]:
+                out = om.run(dict(genset=a[j, :2], battery=a[j, 2], grid=a[j, 3]), True)
+                assert reward[j].item() == out.reward and bool(done[j]) == bool(out.done) == (k == lengths[j] - 1), (k, j)
+                assert np.array_equal(obs[j].cpu().numpy(), om.observe()), (k, j)
+            else:
+                assert bool(done[j])
+    from pymgrid_amd._lib import MGX_ERR_INVALID, MGX_ERR_RANGE, MgxError
+    with pytest.raises(MgxError) as e:                              # the window buffer is exhausted: like the end of a series
+        env.step(_t(rs.rand(5, 4), device))
+    assert e.value.code == MGX_ERR_RANGE
+    with pytest.raises(MgxError) as e:
+        env.engine.reset_windows(torch.zeros(5, dtype=torch.int32, device=device), None, 31)     # longer than the env's window
+    assert e.value.code == MGX_ERR_INVALID
+    env.close()
