@@ -508,6 +508,103 @@ __global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArg
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Discrete action expansion: PriorityListAlgo._populate_action (priority_list.py:69-167).
+// ------------------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWords tab, const int32_t *__restrict__ action_id,
+                                                       int32_t t, double *__restrict__ control)
+{
+    t = resolve_t(a, t);
+    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.g1) return;
+    const int64_t N = a.N;
+    Params p; State s; Inputs in;
+    load_state<F>(a.c, i, false, s);
+    load_params<F>(a.c, i, p);
+    in.load = a.c.load_ts[(int64_t)t * N + i];
+    in.pv = a.c.pv_ts[(int64_t)t * N + i];
+    in.g_stat = 1.0;
+    if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
+    double q_unused;
+    populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused, 0.0 + -1 * in.load, in.pv);
+    double *c = control + i * A;
+    int k = 0;
+    if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
+    if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
+    if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
+}
+
+template <int F>
+__device__ __forceinline__ void load_series_at(const double *__restrict__ lts, const double *__restrict__ pts,
+                                               const double *__restrict__ gts, int64_t N, int64_t i, int64_t off,
+                                               Inputs &in)
+{
+    in.load = lts[off];
+    in.pv = pts[off];
+    in.g_stat = 1.0;
+    if constexpr (F & F_GRID) {
+        const double *g = gts + (4 * off - 3 * i);
+        in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
+    }
+}
+
+// DiscreteMicrogridEnv.step in ONE launch (discrete.py:109-143): expand the priority list of every grid into its
+// control and run Microgrid.run(control, normalized=False) on it, without the control ever leaving registers.
+// (body shared by step_discrete_kernel and fleet_step_kernel)
+template <int F>
+__device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords &tab, const int32_t *__restrict__ action_id,
+                                                   int32_t t, double *__restrict__ control, double *__restrict__ reward,
+                                                   uint8_t *__restrict__ done, void *__restrict__ obs,
+                                                   double *__restrict__ log, int64_t i)
+{
+    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    const int64_t N = a.N;
+    Params p; State s; Inputs in; Outputs o; Derived d;
+    const int32_t id = action_id[i];
+    load_series_at<F>(a.c.load_ts + (int64_t)t * N, a.c.pv_ts + (int64_t)t * N,
+                      (F & F_GRID) ? a.c.grid_ts + (int64_t)t * 4 * N : nullptr, N, i, i, in);
+    load_state<F>(a.c, i, log != nullptr, s);
+    load_params<F>(a.c, i, p);
+    derive<F>(p, d);
+    const bool gen_instant = genset_wave_is_instant<F>(p, s);
+    double bat_q;
+    populate_core<F>(p, s, pl_select(tab, id), in, bat_q, 0.0 + -1 * in.load, in.pv);
+    if (control) {                                   // optional copy of the expanded control (_get_action's value)
+        double *c = control + i * A;
+        int k = 0;
+        if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
+        if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
+        if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
+    }
+    step_core<F, true>(p, d, s, in, false, true, gen_instant, o, bat_q);
+    store_state<F>(a.c, i, s);
+    reward[i] = shaped_reward<F>(a.shaper, o);
+    if (done) done[i] = done_at(a, i, t);
+    if (log) store_log<F>(log + i, N, o, s.status);
+    if (obs) {
+        if (a.obs_state_only) {                 // the window columns of this row were prefetched (obs_windows_k_kernel)
+            if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
+            else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
+        } else if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
+        else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, const PLWords tab,
+                                                              const int32_t *__restrict__ action_id, int32_t t,
+                                                              double *__restrict__ control, double *__restrict__ reward,
+                                                              uint8_t *__restrict__ done, void *__restrict__ obs,
+                                                              double *__restrict__ log)
+{
+    t = resolve_t(a, t);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < a.g1) step_discrete_body<F>(a, tab, action_id, t, control, reward, done, obs, log, i);
+    advance_counter_in_kernel(a, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // A heterogeneous fleet in ONE launch (mgx_fleet_step): up to MGX_FLEET_MAX batches of different layouts, each with its own
 // columns / actions / outputs / step counter, laid end to end over the workgroups.  The table travels in the kernarg
 // segment (scalar loads); a workgroup finds its batch with a few scalar compares and jumps -- wave-uniformly -- to that
@@ -520,7 +617,8 @@ constexpr int MGX_FLEET_MAX = 6;
 // of dependent scalar loads (which batch? -> its layout -> its columns) paid a host round trip per link.
 struct FleetArgs {
     const KArgs *k[MGX_FLEET_MAX];               // device copies (mgx_handle::d_kargs)
-    const void *actions[MGX_FLEET_MAX];
+    const PLWords *tab[MGX_FLEET_MAX];           // discrete items: the priority-list table (device copy), else NULL
+    const void *actions[MGX_FLEET_MAX];          // continuous control [N, A] -- or the int32 priority-list ids [N] of a discrete item
     double *reward[MGX_FLEET_MAX];
     uint8_t *done[MGX_FLEET_MAX];
     void *obs[MGX_FLEET_MAX];
@@ -574,19 +672,32 @@ __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArgs fa, c
     // which batch owns this workgroup: selects over the (<= 6) kernarg entries, no run-time indexing (that would send the
     // struct to scratch)
     const KArgs *kp = fa.k[0];
+    const PLWords *tp = fa.tab[0];
     const void *actions = fa.actions[0];
     double *reward = fa.reward[0]; uint8_t *done = fa.done[0]; void *obs = fa.obs[0]; double *log = fa.log[0];
     int32_t t = fa.t[0], flags = fa.flags[0], block0 = 0;
 #pragma unroll
     for (int q = 1; q < MGX_FLEET_MAX; q++) {
         const bool mine = q < fa.n && (int)blockIdx.x >= fa.block0[q];
-        kp = mine ? fa.k[q] : kp; actions = mine ? fa.actions[q] : actions; reward = mine ? fa.reward[q] : reward;
+        kp = mine ? fa.k[q] : kp; tp = mine ? fa.tab[q] : tp;
+        actions = mine ? fa.actions[q] : actions; reward = mine ? fa.reward[q] : reward;
         done = mine ? fa.done[q] : done; obs = mine ? fa.obs[q] : obs; log = mine ? fa.log[q] : log;
         t = mine ? fa.t[q] : t; flags = mine ? fa.flags[q] : flags; block0 = mine ? fa.block0[q] : block0;
     }
     const KArgs &a = *kp;                         // uniform address, read-only: scalar loads from HBM / L2
     const int64_t i = (int64_t)((int)blockIdx.x - block0) * BLOCK + threadIdx.x;
     if (i >= a.N) return;
+    if (tp != nullptr) {                          // a DiscreteMicrogridEnv batch: ids -> control -> run, in registers
+        const PLWords &tab = *tp;
+#define MGX_FLEET_CASE(FV) case FV: step_discrete_body<FV>(a, tab, (const int32_t *)actions, t, nullptr, reward, done, obs, log, i); break;
+        switch (flags) {
+            MGX_FLEET_CASE(0) MGX_FLEET_CASE(1) MGX_FLEET_CASE(2) MGX_FLEET_CASE(3) MGX_FLEET_CASE(4)
+            MGX_FLEET_CASE(5) MGX_FLEET_CASE(6) MGX_FLEET_CASE(7) MGX_FLEET_CASE(14)
+            default: step_discrete_body<15>(a, tab, (const int32_t *)actions, t, nullptr, reward, done, obs, log, i); break;
+        }
+#undef MGX_FLEET_CASE
+        return;
+    }
 #define MGX_FLEET_CASE(FV) case FV: step_body<FV>(a, actions, t, fa.normalized, reward, done, obs, log, i); break;
     switch (flags) {
         MGX_FLEET_CASE(0) MGX_FLEET_CASE(1) MGX_FLEET_CASE(2) MGX_FLEET_CASE(3) MGX_FLEET_CASE(4)
@@ -594,94 +705,6 @@ __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArgs fa, c
         default: step_body<15>(a, actions, t, fa.normalized, reward, done, obs, log, i); break;
     }
 #undef MGX_FLEET_CASE
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Discrete action expansion: PriorityListAlgo._populate_action (priority_list.py:69-167).
-// ------------------------------------------------------------------------------------------------------
-template <int F>
-__global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWords tab, const int32_t *__restrict__ action_id,
-                                                       int32_t t, double *__restrict__ control)
-{
-    t = resolve_t(a, t);
-    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.g1) return;
-    const int64_t N = a.N;
-    Params p; State s; Inputs in;
-    load_state<F>(a.c, i, false, s);
-    load_params<F>(a.c, i, p);
-    in.load = a.c.load_ts[(int64_t)t * N + i];
-    in.pv = a.c.pv_ts[(int64_t)t * N + i];
-    in.g_stat = 1.0;
-    if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
-    double q_unused;
-    populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused, 0.0 + -1 * in.load, in.pv);
-    double *c = control + i * A;
-    int k = 0;
-    if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
-    if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
-    if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
-}
-
-template <int F>
-__device__ __forceinline__ void load_series_at(const double *__restrict__ lts, const double *__restrict__ pts,
-                                               const double *__restrict__ gts, int64_t N, int64_t i, int64_t off,
-                                               Inputs &in)
-{
-    in.load = lts[off];
-    in.pv = pts[off];
-    in.g_stat = 1.0;
-    if constexpr (F & F_GRID) {
-        const double *g = gts + (4 * off - 3 * i);
-        in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
-    }
-}
-
-// DiscreteMicrogridEnv.step in ONE launch (discrete.py:109-143): expand the priority list of every grid into its
-// control and run Microgrid.run(control, normalized=False) on it, without the control ever leaving registers.
-template <int F>
-__global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, const PLWords tab,
-                                                              const int32_t *__restrict__ action_id, int32_t t,
-                                                              double *__restrict__ control, double *__restrict__ reward,
-                                                              uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                              double *__restrict__ log)
-{
-    t = resolve_t(a, t);
-    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.g1) return;
-    const int64_t N = a.N;
-    Params p; State s; Inputs in; Outputs o; Derived d;
-    const int32_t id = action_id[i];
-    load_series_at<F>(a.c.load_ts + (int64_t)t * N, a.c.pv_ts + (int64_t)t * N,
-                      (F & F_GRID) ? a.c.grid_ts + (int64_t)t * 4 * N : nullptr, N, i, i, in);
-    load_state<F>(a.c, i, log != nullptr, s);
-    load_params<F>(a.c, i, p);
-    derive<F>(p, d);
-    const bool gen_instant = genset_wave_is_instant<F>(p, s);
-    double bat_q;
-    populate_core<F>(p, s, pl_select(tab, id), in, bat_q, 0.0 + -1 * in.load, in.pv);
-    if (control) {                                   // optional copy of the expanded control (_get_action's value)
-        double *c = control + i * A;
-        int k = 0;
-        if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
-        if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
-        if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
-    }
-    step_core<F, true>(p, d, s, in, false, true, gen_instant, o, bat_q);
-    store_state<F>(a.c, i, s);
-    reward[i] = shaped_reward<F>(a.shaper, o);
-    if (done) done[i] = done_at(a, i, t);
-    if (log) store_log<F>(log + i, N, o, s.status);
-    if (obs) {
-        if (a.obs_state_only) {                 // the window columns of this row were prefetched (obs_windows_k_kernel)
-            if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
-            else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
-        } else if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
-        else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
-    }
-    advance_counter_in_kernel(a, 1);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1129,6 +1152,9 @@ struct mgx_handle {
     KArgs *d_kargs;                          // device copy of `k` for fleet_step_kernel, refreshed when `k` changed
     KArgs k_uploaded;
     bool k_uploaded_valid;
+    PLWords *d_table;                        // device copy of the priority-list table of a discrete fleet item
+    PLWords table_uploaded;
+    bool table_uploaded_valid;
     hipStream_t prefetch_stream;             // mgx_observe_windows_ahead: the window prefetch overlaps the steps
     hipEvent_t prefetch_gate, prefetch_done;
     bool prefetch_pending;
@@ -1345,6 +1371,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->fork_event = nullptr; h->counter_stream = nullptr;
     { const char *e = getenv("MGX_FORK_STAGGER_US"); h->stagger_us = e ? atof(e) : 0.0; }
     h->d_kargs = nullptr; h->k_uploaded_valid = false;
+    h->d_table = nullptr; h->table_uploaded_valid = false;
     h->prefetch_stream = nullptr; h->prefetch_gate = nullptr; h->prefetch_done = nullptr; h->prefetch_pending = false;
     h->windowed = false;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
@@ -1371,6 +1398,7 @@ void mgx_destroy(mgx_handle *h)
     if (h->fork_event) (void)hipEventDestroy(h->fork_event);
     if (h->prefetch_stream) { (void)hipStreamSynchronize(h->prefetch_stream); (void)hipStreamDestroy(h->prefetch_stream); }
     if (h->d_kargs) (void)hipFree(h->d_kargs);
+    if (h->d_table) (void)hipFree(h->d_table);
     if (h->prefetch_gate) (void)hipEventDestroy(h->prefetch_gate);
     if (h->prefetch_done) (void)hipEventDestroy(h->prefetch_done);
     if (h->scratch) (void)hipFree(h->scratch);
@@ -1989,9 +2017,9 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
         if (it.struct_size != (int32_t)sizeof(mgx_fleet_item))
             return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d struct_size %d vs %zu", j, it.struct_size, sizeof(mgx_fleet_item));
         if (!it.handle) return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d has no handle", j);
-        if (it.action_id) {
-            if (!it.table || !it.reward) return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d: NULL table / reward", j);
-        } else if (int rc = check_step_args(it.handle, it.actions, it.reward, it.obs, 1, "mgx_fleet_step")) return rc;
+        if (it.action_id && !it.table) return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d: NULL table", j);
+        if (int rc = check_step_args(it.handle, it.action_id ? (const void *)it.action_id : it.actions, it.reward, it.obs, 1,
+                                     "mgx_fleet_step")) return rc;
         if (it.refill_ring) {
             if (it.refill_K < 1 || it.refill_ahead < 0 || it.refill_chunks < 0 || it.refill_chunk < 0 ||
                 (it.refill_chunks > 0 && (it.refill_chunk >= it.refill_chunks || it.refill_ahead < 1)))
@@ -2000,13 +2028,12 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
             if (int rc = windows_plan(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, "mgx_fleet_step", &plan, &lds, &ng)) return rc;
         }
     }
-    // one launch for all batches when every item is a plain continuous step (the common fleet)
+    // one launch for all batches (continuous and discrete items alike) unless an item needs a kernel of its own
     bool fusable = true;
     for (int32_t j = 0; j < n && fusable; j++) {
         const mgx_fleet_item &it = items[j];
         const mgx_handle *h = it.handle;
-        fusable = !it.action_id && !h->multi && !dev_counter(h) && h->n_shards <= 1 &&
-                  !(it.obs && h->k.H > 0 && !h->k.obs_state_only);
+        fusable = !h->multi && !dev_counter(h) && h->n_shards <= 1 && !(it.obs && h->k.H > 0 && !h->k.obs_state_only);
         for (int32_t q = 0; q < j && fusable; q++) fusable = items[q].handle != it.handle;      // a batch steps once per call
     }
     bool chunk_done[64];                                    // window chunks that rode along with the step launch
@@ -2014,8 +2041,20 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
     for (int32_t j = 0; j < n; j++)
         if (items[j].wait_prefetch) { if (int rc = mgx_prefetch_wait(items[j].handle, stream)) return rc; }
     if (fusable) {
-        for (int32_t j = 0; j < n; j++)                   // device copies of the batches' KArgs: uploaded when they changed
+        for (int32_t j = 0; j < n; j++) {                 // device copies of the batches' KArgs: uploaded when they changed
             if (int rc = sync_device_kargs(items[j].handle, st, "mgx_fleet_step: uploading the layout table")) return rc;
+            if (!items[j].action_id) continue;            // discrete item: its priority-list table, too
+            mgx_handle *h = items[j].handle;
+            PLWords tab;
+            if (int rc = encode_table(h, items[j].table, items[j].n_actions, &tab, "mgx_fleet_step")) return rc;
+            if (h->table_uploaded_valid && memcmp(&tab, &h->table_uploaded, sizeof(PLWords)) == 0) continue;
+            hipError_t e = hipSuccess;
+            if (!h->d_table) e = hipMalloc((void **)&h->d_table, sizeof(PLWords));
+            if (e == hipSuccess) e = hipMemcpyAsync(h->d_table, &tab, sizeof(PLWords), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return hip_fail(e, "mgx_fleet_step: uploading the priority-list table");
+            memcpy(&h->table_uploaded, &tab, sizeof(PLWords));
+            h->table_uploaded_valid = true;
+        }
         for (int32_t j0 = 0; j0 < n; j0 += MGX_FLEET_MAX) {
             FleetArgs fa;
             FleetWin fw;
@@ -2029,7 +2068,8 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
                 const mgx_fleet_item &it = items[j0 + q];
                 mgx_handle *h = it.handle;
                 fa.k[q] = h->d_kargs;
-                fa.actions[q] = it.actions; fa.reward[q] = it.reward; fa.done[q] = it.done; fa.obs[q] = it.obs; fa.log[q] = it.log;
+                fa.tab[q] = it.action_id ? h->d_table : nullptr;
+                fa.actions[q] = it.action_id ? (const void *)it.action_id : it.actions; fa.reward[q] = it.reward; fa.done[q] = it.done; fa.obs[q] = it.obs; fa.log[q] = it.log;
                 fa.t[q] = h->t; fa.flags[q] = h->flags; fa.block0[q] = blocks;
                 blocks += (int32_t)blocks_for(h->k.N);
                 if (it.refill_ring && it.refill_chunks > 0 && j0 + q < 64) {        // this step's share of the next ring

@@ -45,7 +45,7 @@ class BucketedFleet:
         self.fused = bool(self._want_fused and not self.streams and not any(env.raise_errors for env in self.envs)
                           and not any(isinstance(env, DiscreteBatchedMicrogridEnv) and L_multi(env.layout) for env in self.envs))
         for env in self.envs:
-            env._chunked = self.fused and not isinstance(env, DiscreteBatchedMicrogridEnv) and not L_multi(env.layout)
+            env._chunked = self.fused and not L_multi(env.layout)
 
     def _init_fused(self, reuse_outputs, fused=True):
         # reuse_outputs = R > 0: step() returns reward / done as views into R rotating buffers per bucket (valid for R - 1
