@@ -158,6 +158,30 @@ __device__ __forceinline__ double space_spread(double lo, double hi)
 __device__ __forceinline__ double space_denorm(double lo, double hi, double v) { return lo + space_spread(lo, hi) * v; }
 __device__ __forceinline__ double space_norm(double lo, double hi, double v) { return (v - lo) / space_spread(lo, hi); }
 
+// ---- min / max / clip ---------------------------------------------------------------------------------------------
+// The reference's `min(a, b)` (= b if b < a else a), `max`, and its clip ladders (base_module.py:213-224,265-270) are
+// one v_min_f64 / v_max_f64 each instead of a compare and two 32-bit selects -- a third of the VALU instructions of the
+// rule-based rollout were such selects.  For every non-NaN input the VALUE is the one the ladder picks; only the sign of
+// a zero result may differ (v_min_f64 orders -0 < +0, `b < a` does not), and no operation downstream can tell +0 from -0
+// (no division by a possibly-zero result, no copysign): every comparison with the reference is `==` on values.
+// The clip forms assume lo <= hi (min_production <= max_production etc.: what the reference's constructors enforce).
+// (Inline asm rather than __builtin_fmin / fmax: for those hipcc canonicalises every operand that is not provably the
+// result of an arithmetic instruction -- a `v_max_f64 x, x, x` per loaded parameter and per select result, in every loop
+// iteration, which gave back most of the saving.  The asm is not volatile: the compiler may still hoist and CSE it.)
+__device__ __forceinline__ double py_min(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double py_max(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double py_clip(double x, double lo, double hi) { return py_min(py_max(x, lo), hi); }
+
 template <int F>
 __device__ __forceinline__ void derive(const Params &p, Derived &d)
 {
@@ -282,12 +306,12 @@ __device__ __forceinline__ bool genset_wave_is_instant(const Params &p, const St
 __device__ __forceinline__ double battery_max_production(const Params &p, double charge)
 {
     const double b = charge - p.bat_cmin;
-    return (b < p.bat_D ? b : p.bat_D) * p.bat_eta;
+    return py_min(p.bat_D, b) * p.bat_eta;
 }
 __device__ __forceinline__ double battery_max_consumption(const Params &p, double charge)
 {
     const double b = p.bat_cmax - charge;
-    return (b < p.bat_C ? b : p.bat_C) / p.bat_eta;
+    return py_min(p.bat_C, b) / p.bat_eta;
 }
 
 // ---- one Microgrid.run for one grid ---------------------------------------------------------------------
@@ -296,8 +320,9 @@ __device__ __forceinline__ double battery_max_consumption(const Params &p, doubl
 // list lengths that occur here (< 8 addends), so the running sums below reproduce MicrogridStep.balance.
 //
 // The reference's if/else ladders are written as selects (both arms are cheap, lanes of a wave disagree on every
-// one of them with random controls): same operations on the taken arm, hence the same bits.  Adding +0.0 where the
-// reference appends nothing to a list leaves the running sum's value unchanged.
+// one of them with random controls): same operations on the taken arm, hence the same values; its min / max / clip
+// ladders are v_min_f64 / v_max_f64 (py_min / py_max / py_clip above: same value, the sign of a zero may differ).
+// Adding +0.0 where the reference appends nothing to a list leaves the running sum's value unchanged.
 //
 // want_soc (wave-uniform): compute soc = charge / max_capacity this step (a division); the fused kernel skips it on
 // steps whose SoC nobody reads and derives it once at the end (same value: it depends on the final charge only).
@@ -327,7 +352,7 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         const double x = normalized ? 0.0 + d.gen_sp * in.a_gen : in.a_gen;     // act space :511-517, _energy_pos=1
         const double cur = (double)(s.status & 0xff);
         const double mx = cur * p.gen_rmax, mn = cur * p.gen_rmin;              // max/min_production :465-501
-        const double e = (x > mx) ? mx : ((x < mn) ? mn : x);                   // as_source clip base_module.py:213-224
+        const double e = py_clip(x, mn, mx);                                    // as_source clip base_module.py:213-224
         viol |= ((x > mx) || (x < mn) ? 1u : 0u) | (!(in.a_goal >= 0.0 && in.a_goal <= 1.0) ? 8u : 0u) | (x < 0.0 ? 16u : 0u);
         const double co2 = p.gen_co2 * e;                                       // get_co2
         const double cost = p.gen_cost * e + p.gen_cco2 * co2;                  // get_cost :188-205
@@ -342,14 +367,14 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         // discharging -> internal = (-e) / eta (default_transition_model :244-278).  Select the numerator, divide once.
         const bool sink = x < 0;                                                // as_sink(-1.0*x) vs as_source(x)
         const double room = p.bat_cmax - s.charge;
-        const double num_sink = (room < p.bat_C) ? room : p.bat_C;              // Python min(a, b) = b if b < a else a
+        const double num_sink = py_min(p.bat_C, room);                          // Python min(a, b) = b if b < a else a
         const double mp = battery_max_production(p, s.charge);                  // :283-286
-        const double e_src = (x > mp) ? mp : ((x < 0.0) ? 0.0 : x);            // base_module.py:213-224, min_production 0
+        const double e_src = py_clip(x, 0.0, mp);                               // base_module.py:213-224, min_production 0
         const double num = sink ? num_sink : -1.0 * e_src;
         double q;
         if constexpr (HAVE_Q) q = bat_q; else q = num / p.bat_eta;
         const double ex = -1.0 * x;
-        const double e_sink = (ex > q) ? q : ex;                                // base_module.py:265-270
+        const double e_sink = py_min(ex, q);                                    // base_module.py:265-270
         // (e_sink < 0, i.e. charge above max_capacity, is an AssertionError in the reference, base_module.py:272,
         //  and unspecified here; every valid run has e >= 0 and internal = e * eta.)
         const double e = sink ? e_sink : e_src;
@@ -358,8 +383,7 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         o.charge_amount = sink ? e : 0.0;
         o.discharge_amount = sink ? 0.0 : e;
         absb += o.charge_amount; prov += o.discharge_amount;
-        s.charge += internal;                                                   // _update_state :125-130
-        if (s.charge < p.bat_cmin) s.charge = p.bat_cmin;
+        s.charge = py_max(s.charge + internal, p.bat_cmin);                     // _update_state :125-130
         if (want_soc) s.soc = s.charge / p.bat_cmax;
         o.battery_reward = -1.0 * (fabs(internal) * p.bat_cost);                // get_cost :132-147
         reward += o.battery_reward;
@@ -368,9 +392,9 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;   // _get_bounds :125-132
         const bool sink = x < 0;
         const double ex = -1.0 * x, mc = p.grid_exp * in.g_stat;               // max_consumption :318-320
-        const double e_exp = (ex > mc) ? mc : ex;
+        const double e_exp = py_min(ex, mc);
         const double mp = p.grid_imp * in.g_stat;                              // max_production :314-316
-        const double e_imp = (x > mp) ? mp : ((x < 0.0) ? 0.0 : x);
+        const double e_imp = py_clip(x, 0.0, mp);
         viol |= (sink ? (ex > mc) : (x > mp)) ? 4u : 0u;
         const double co2 = sink ? 0.0 : e_imp * in.g_co2;                      // get_co2_production :199-228
         const double cco2 = -1.0 * p.grid_cco2 * co2;                          // get_co2_cost :176-197
@@ -396,7 +420,7 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
     // flex modules (:286-314): renewable first, unbalanced energy last
     const bool excess = difference > 0;
     const double need = -difference;
-    const double used = excess ? 0.0 : ((in.pv < need) ? in.pv : need);        // renewable_module.py:86-93
+    const double used = excess ? 0.0 : py_min(need, in.pv);                    // renewable_module.py:86-93
     o.renewable_used = used; o.curtailment = in.pv - used;
     const double loss = excess ? 0.0 : need - used;
     const double over = excess ? difference : 0.0;
@@ -443,8 +467,8 @@ __device__ __forceinline__ bool pl_isclose0(double rem)
 // _produce_from_module :138-155 / _consume_in_module :118-136 for a module without a division
 __device__ __forceinline__ double pl_energy(double rem, double mn, double mx, double mc, bool is_sink)
 {
-    const double produce = (mn <= rem && rem <= mx) ? rem : ((rem < mn) ? mn : mx);
-    const double consume = is_sink ? ((-1 * rem > mc) ? -1.0 * mc : rem) : 0.0;
+    const double produce = py_clip(rem, mn, mx);
+    const double consume = is_sink ? py_max(rem, -1.0 * mc) : 0.0;
     return pl_isclose0(rem) ? 0.0 : ((rem > 0) ? produce : consume);
 }
 
@@ -510,11 +534,11 @@ __device__ __forceinline__ void populate_core(const Params &p, const State &s, u
         const bool produce = !close && remB > 0;
         const double mp = battery_max_production(p, s.charge);                  // battery_module.py:283-286
         const double room = p.bat_cmax - s.charge;
-        const double num_sink = (room < p.bat_C) ? room : p.bat_C;              // numerator of max_consumption :288-291
-        const double e_src = (0.0 <= remB && remB <= mp) ? remB : ((remB < 0.0) ? 0.0 : mp);
+        const double num_sink = py_min(p.bat_C, room);                          // numerator of max_consumption :288-291
+        const double e_src = py_clip(remB, 0.0, mp);
         const double num = (close || produce) ? -1.0 * (produce ? e_src : 0.0) : num_sink;
         const double q = num / p.bat_eta;
-        const double e_snk = (-1 * remB > q) ? -1.0 * q : remB;
+        const double e_snk = py_max(remB, -1.0 * q);
         eB = close ? 0.0 : (produce ? e_src : e_snk);
         bat_q = q;
     }
