@@ -1208,6 +1208,18 @@ inline void advance(mgx_handle *h, int32_t k, hipStream_t st)
     h->t += k;
 }
 
+// The handle's device for the duration of a scope: streams, events and buffers the library creates lazily must live on
+// the device the batch is on, whatever the caller's current device happens to be.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
 // One stepping call = one launch per shard.  fn(kargs with [g0, g1) set, stream of that shard).
 template <class Fn>
 inline void for_each_shard(const mgx_handle *h, hipStream_t user, Fn fn)
@@ -1578,6 +1590,7 @@ int mgx_observe_windows_ahead(mgx_handle *h, int32_t ahead, int32_t K, void *rin
     if (dev_counter(h)) return fail(MGX_ERR_UNSUPPORTED, "mgx_observe_windows_ahead: not offered in device-counter mode (the prefetch "
                                                          "stream would race with the kernels that move the counter)");
     hipError_t e = hipSuccess;
+    DeviceGuard on_device(h->device);
     if (!h->prefetch_stream) {
         e = hipStreamCreateWithFlags(&h->prefetch_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prefetch_gate, hipEventDisableTiming);
@@ -1655,6 +1668,7 @@ int mgx_set_forecast_noise(mgx_handle *h, uint64_t seed, int increase_uncertaint
 static int sync_device_kargs(mgx_handle *h, hipStream_t st, const char *who)
 {
     if (h->k_uploaded_valid && memcmp(&h->k, &h->k_uploaded, sizeof(KArgs)) == 0) return MGX_OK;
+    DeviceGuard on_device(h->device);
     hipError_t e = hipSuccess;
     if (!h->d_kargs) e = hipMalloc((void **)&h->d_kargs, sizeof(KArgs));
     if (e == hipSuccess) e = hipMemcpyAsync(h->d_kargs, &h->k, sizeof(KArgs), hipMemcpyHostToDevice, st);
@@ -1736,6 +1750,7 @@ int mgx_set_shards(mgx_handle *h, int32_t n_shards)
     if (n_shards < 1 || n_shards > MGX_MAX_SHARDS) return fail(MGX_ERR_INVALID, "mgx_set_shards: n_shards must be in [1, %d]", MGX_MAX_SHARDS);
     if (n_shards > 1 && h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_set_shards: not offered in device-counter mode");
     if (n_shards > 1 && h->windowed) return fail(MGX_ERR_UNSUPPORTED, "mgx_set_shards: not offered during a per-grid-window episode");
+    DeviceGuard on_device(h->device);
     for (int j = 0; j < h->n_shards && h->n_shards > 1; j++)          // work still queued on the old shard streams
         if (h->shard_stream[j]) (void)hipStreamSynchronize(h->shard_stream[j]);
     hipError_t e = hipSuccess;
@@ -2049,6 +2064,7 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
             if (int rc = encode_table(h, items[j].table, items[j].n_actions, &tab, "mgx_fleet_step")) return rc;
             if (h->table_uploaded_valid && memcmp(&tab, &h->table_uploaded, sizeof(PLWords)) == 0) continue;
             hipError_t e = hipSuccess;
+            DeviceGuard on_device(h->device);
             if (!h->d_table) e = hipMalloc((void **)&h->d_table, sizeof(PLWords));
             if (e == hipSuccess) e = hipMemcpyAsync(h->d_table, &tab, sizeof(PLWords), hipMemcpyHostToDevice, st);
             if (e != hipSuccess) return hip_fail(e, "mgx_fleet_step: uploading the priority-list table");
