@@ -447,7 +447,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": per_launch_bytes,
                 "kernel": {"fused": "step_k_kernel<3,4,double,false>", "step": "step_kernel<3>", "step_python": "step_kernel<3>",
-                           "rbc": "rollout_kernel<3,4,false,false>"}[mode],
+                           "rbc": "rollout_kernel<3,8,false,false>"}[mode],
                 "bytes_per_env_step": per_launch / (chunk if mode in ("fused", "rbc") else 1),
                 "launches": launches, "avg_launch_us": avg_launch_s * 1e6,
                 "timed_rounds": [first, first + rounds]}
