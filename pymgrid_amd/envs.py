@@ -462,6 +462,30 @@ class _SingleMixin:
         return cls(from_scenario(microgrid_number, root), **kwargs)
 
     @classmethod
+    def from_microgrid(cls, microgrid, **kwargs):
+        """``Env.from_microgrid(microgrid)`` (envs/base/base.py:253-283): wrap an existing microgrid with the environment
+        API.  ``microgrid`` is a parameter dict or one of this module's N = 1 envs -- its parameters WITH its current
+        dynamic state (battery charge / SoC, genset status; logs are not carried over, as in the reference), its reward
+        shaper and trajectory function unless overridden."""
+        if isinstance(microgrid, dict):
+            return cls(microgrid, **kwargs)
+        if not isinstance(microgrid, BatchedMicrogridEnv) or microgrid.n_grids != 1:
+            raise TypeError("microgrid must be a parameter dict or an N = 1 env of this module")
+        params = dict(microgrid._params)
+        c = microgrid.batch.cols
+        if microgrid.layout.has_battery:
+            params["battery"] = dict(params["battery"], charge=float(c["charge"][0]), soc=float(c["soc"][0]))
+            params["battery"].pop("init_soc", None); params["battery"].pop("init_charge", None)
+        if microgrid.layout.has_genset:
+            st = unpack_status(c["gen_status"].cpu().numpy().view(np.uint32))[0]
+            params["genset"] = dict(params["genset"], status=[int(v) for v in st])
+        kwargs = dict(kwargs)
+        kwargs.setdefault("reward_shaping_func", microgrid.reward_shaping_func)
+        kwargs.setdefault("trajectory_func", microgrid.trajectory_func)
+        kwargs.setdefault("device", str(microgrid.batch.device))
+        return cls(params, **kwargs)
+
+    @classmethod
     def load(cls, path, **kwargs):
         """``Env.load(stream)`` (microgrid.py:847-864): a serialised ``!Microgrid`` YAML file."""
         from .scenario import load_scenario_yaml
@@ -499,6 +523,7 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
                          reward_shaping_func=reward_shaping_func, trajectory_func=trajectory_func,
                          raise_errors=raise_errors, observation_keys=observation_keys, obs_prefetch=0)
         self.flat_spaces = flat_spaces
+        self._params = params
 
     def reset(self, initial_step=None):
         return self._obs_out(super().reset(initial_step))
@@ -521,6 +546,7 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
                          trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
                          obs_prefetch=0)
         self.flat_spaces = flat_spaces
+        self._params = params
 
     def reset(self, initial_step=None):
         return self._obs_out(super().reset(initial_step))

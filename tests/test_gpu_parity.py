@@ -329,7 +329,13 @@ def test_gym_adaptors_shapes(pymgrid25, device):
         if p.get("grid") is not None: ctrl["grid"] = [0.5]
         obs, reward, done, info = env.step(ctrl, normalized=True)
         assert isinstance(reward, float) and len(obs["load"][0]) == 24
-        env.close()
+        # Env.from_microgrid (envs/base/base.py:253-283): wrap a stepped microgrid -- parameters AND current state carry over
+        twin = DiscreteMicrogridEnv.from_microgrid(env)
+        for name in ("charge", "soc", "gen_status"):
+            if name in env.batch.cols:
+                assert torch.equal(twin.batch.cols[name], env.batch.cols[name]), name
+        assert twin.action_space.n == n_expected and twin.current_step == 0
+        twin.close(); env.close()
 
 
 def test_error_paths(pymgrid25, device):
