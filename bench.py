@@ -194,7 +194,7 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist):
     from pymgrid_amd.generator import generate
     from pymgrid_amd.hetero import BucketedFleet
     per = N // 3
-    K_ring = 8
+    K_ring = 16
     out = {}
     for name, dt in (("float64_rows", torch.float64), ("float32_rows", torch.float32)):
         batches = [generate(per * world, n_steps=steps + 1100, seed=43 + k, arch=arch, horizon=24, device=dev, rank=rank,
@@ -241,7 +241,8 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist):
         traffic = None
         try:                                              # PMC bytes of the same fleet shape, if a profile of it is committed
             tf = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic_fleet.json")))
-            if (tf["grids_per_gpu"], tf["obs_prefetch"], tf["rows"]) == (3 * per, K_ring, "float64" if dt == torch.float64 else "float32"):
+            if (tf["grids_per_gpu"], tf["obs_prefetch"], tf["rows"], tf.get("refill")) == \
+                    (3 * per, K_ring, "float64" if dt == torch.float64 else "float32", fleet.refill):
                 traffic = tf["hbm_bytes_per_fleet_step"]
         except (OSError, ValueError, KeyError):
             pass
@@ -249,9 +250,10 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist):
                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                   "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_us": gpu / steps * 1e6,
                                   "launch": "one fleet step = one mgx_fleet_step call: ONE fleet_step_kernel launch over the three "
-                                            f"buckets + every {K_ring}th step the window prefetch of the next {K_ring} steps "
-                                            "(obs_windows_k_kernel per bucket, on the prefetch streams, overlapping the steps)",
-                                  "kernel": "fleet_step_kernel + obs_windows_k_kernel<F> x3 / 8"}}
+                                            f"buckets + every {K_ring}th step the observation ring after next ({K_ring} row blocks: "
+                                            "obs_windows_k_kernel per bucket on the engines' prefetch streams, running beside "
+                                            f"the following step launches); bytes and time are per fleet step, refills included",
+                                  "kernel": f"fleet_step_kernel + obs_windows_k_kernel<F> x3 / {K_ring}", "refill": fleet.refill}}
         obs_dims = [e.layout.obs_dim for e in fleet.envs]
         fleet.close()
         del fleet, batches

@@ -224,16 +224,18 @@ def test_per_grid_window_env_draws(pymgrid25, device, oracle):
     env.close()
 
 
-@pytest.mark.parametrize("prefetch,discrete", [(0, False), (8, False), (4, True)])
-def test_fleet_step_in_one_call_equals_per_env_steps(prefetch, discrete, pymgrid25, device):
+@pytest.mark.parametrize("prefetch,discrete,refill", [(0, False, "ahead"), (8, False, "chunks"), (4, True, "chunks"),
+                                                      (8, False, "ahead"), (4, True, "ahead"), (16, False, "ahead")])
+def test_fleet_step_in_one_call_equals_per_env_steps(prefetch, discrete, refill, pymgrid25, device):
     """mgx_fleet_step (BucketedFleet.step: every bucket's launch and ring refill from ONE C call) == one env.step per bucket:
     observations (incl. ring refills), rewards, done, log rows, state."""
     from pymgrid_amd.hetero import BucketedFleet
     kw = dict(device=device, observations=True, obs_prefetch=prefetch, log=True, discrete=discrete)
     if discrete:
         kw["remove_redundant_gensets"] = False
-    fused, plain = BucketedFleet(pymgrid25, **kw), BucketedFleet(pymgrid25, fused=False, **kw)
-    assert fused.fused and not plain.fused
+    fused, plain = BucketedFleet(pymgrid25, refill=refill, **kw), BucketedFleet(pymgrid25, fused=False, **kw)
+    assert fused.fused and not plain.fused and fused.refill == refill
+    assert all(e._chunked == (refill == "chunks") for e in fused.envs)
     o1, o2 = fused.reset(), plain.reset()
     g = torch.Generator(device=device); g.manual_seed(0)
     for k in range(29):

@@ -1,38 +1,43 @@
 #!/bin/bash
-# Run ON THE GPU BOX: HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the config-5 fleet step, per fleet_step_kernel launch.
+# Run ON THE GPU BOX: HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of config-5 fleet stepping, per fleet step:
+# every mgx kernel dispatched from the first of the last STEPS fleet_step_kernel launches on (step launches + ring refills).
+# usage: gpu_pmc_fleet.sh [K] [chunks|ahead] [float64|float32]
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+K=${1:-16}; MODE=${2:-ahead}; ROWS=${3:-float64}; STEPS=256
 OUT=$REPO/gpurun_out/pmc_fleet
 mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace -d "$OUT/$c" -o b --output-format csv -- python "$REPO/tools/exp_hetero_trace.py" 256 8 > "$OUT/$c.log" 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace -d "$OUT/$c" -o b --output-format csv -- python "$REPO/tools/exp_hetero_trace.py" $STEPS $K $ROWS $MODE > "$OUT/$c.log" 2>&1
 done
 cd "$REPO"
-python - "$OUT" <<'PY' | tee "$OUT/summary.txt"
-import csv, glob, os, sys
-out = sys.argv[1]
-res = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    vals = []
-    for f in glob.glob(os.path.join(out, c, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "fleet_step_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
-                vals.append((int(r.get("Grid_Size") or 0), float(r["Counter_Value"])))
-    res[c] = vals
-# launches with a window chunk have more workgroups than the chunk-less 8th step
-sizes = sorted({s for s, _ in res["FETCH_SIZE"]})
-print("launch sizes (threads):", sizes)
+python - "$OUT" $STEPS $K $MODE $ROWS <<'PY' | tee "$OUT/summary.txt"
+import csv, glob, json, os, sys
+out, steps, K, mode, rows_t = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
 tot = {}
-for c, vals in res.items():
-    for s in sizes:
-        v = [x for sz, x in vals if sz == s]
-        if v:
-            v.sort(); v = v[len(v) // 4: max(len(v) // 4 + 1, 3 * len(v) // 4)]
-            tot[(c, s)] = sum(v) / len(v)
-            print(f"{c} threads={s}: {tot[(c, s)]:.0f} KiB per launch")
-small, big = sizes[0], sizes[-1]
-b = lambda s: (2 * tot[("FETCH_SIZE", s)] + tot[("WRITE_SIZE", s)]) * 1024      # gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads
-per8 = 7 * b(big) + b(small)
-print(f"HBM bytes per launch: with chunk {b(big) / 1e6:.1f} MB, without {b(small) / 1e6:.1f} MB -> per fleet step (7 + 1 of 8): {per8 / 8 / 1e6:.1f} MB")
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    rows = []
+    for f in glob.glob(os.path.join(out, c, "**", "*counter_collection.csv"), recursive=True):
+        rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c and "mgx::" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    step_idx = [j for j, r in enumerate(rows) if "fleet_step_kernel" in r["Kernel_Name"]]
+    tail = rows[step_idx[-steps]:]
+    by = {}
+    for r in tail:
+        name = r["Kernel_Name"].split("mgx::")[1].split("(")[0]
+        n, v = by.get(name, (0, 0.0))
+        by[name] = (n + 1, v + float(r["Counter_Value"]))
+    for name, (n, v) in sorted(by.items()):
+        print(f"{c:11s} {name:40s} {n:5d} launches  {v / n:12.0f} KiB per launch")
+    tot[c] = sum(v for _, v in by.values())
+# gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads (MI355X_MICROARCH.md)
+per_step = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / steps
+print(f"HBM bytes per fleet step (K = {K}, refill = {mode}, {rows_t} rows): {per_step / 1e6:.1f} MB "
+      f"(read {2 * tot['FETCH_SIZE'] * 1024 / steps / 1e6:.1f} + written {tot['WRITE_SIZE'] * 1024 / steps / 1e6:.1f})")
+json.dump({"kernel": "fleet_step_kernel + obs_windows_k_kernel", "grids_per_gpu": 99999, "obs_prefetch": K, "refill": mode,
+           "rows": rows_t, "hbm_bytes_per_fleet_step": per_step,
+           "source": "tools/gpu_pmc_fleet.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + "
+                     f"WRITE_SIZE)*1024 summed over every kernel of the last {steps} fleet steps (step launches + ring refills) / {steps}"},
+          open(os.path.join(out, "traffic_fleet.json"), "w"), indent=1)
 PY
 rm -rf "$OUT/FETCH_SIZE" "$OUT/WRITE_SIZE"
