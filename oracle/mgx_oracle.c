@@ -431,6 +431,196 @@ void orc_populate_action(const orc_grid *g, const orc_state *s,
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* Several gensets / batteries / grids per microgrid: the same sweep with a loop per module list
+ * (microgrid.py:262-275: `for name, modules in self.controllable.iterdict(): ... for module, _control in _zip`). */
+static void mstate_view(const orc_mstate *s, const orc_state *inst, orc_state *v)
+{
+    *v = *inst; v->t = s->t;
+}
+
+int orc_mrun(const orc_mgrid *mg, orc_mstate *s, const double *actions, int normalized, orc_mstep_out *out)
+{
+    const orc_grid *g = &mg->base;
+    int32_t t = s->t;
+    if (t < 0 || t >= g->T) return -2;
+    if (mg->n_genset > ORC_MAX_INST || mg->n_battery > ORC_MAX_INST || mg->n_grid > ORC_MAX_INST) return -2;
+    if (g->n_load + g->n_pv + mg->n_genset + mg->n_battery + mg->n_grid + 2 > ORC_MAX_ADDENDS) return -2;
+    memset(out, 0, sizeof(*out));
+    orc_step_out *oc = &out->common;
+    mstep m; m.n_provided = 0; m.n_absorbed = 0; m.reward = 0.0; m.done = 0;
+    int done_ts = ts_done(g, t);
+
+    for (int32_t j = 0; j < g->n_load; j++) {                         /* fixed modules, microgrid.py:255-257 */
+        double cur = -1 * g->load_ts[(int64_t)t * g->load_t_stride + (int64_t)j * g->load_m_stride];
+        oc->load_met += cur;
+        mstep_append(&m, 0.0, done_ts, 0, cur);
+    }
+    double fixed_provided = orc_np_sum(m.provided, m.n_provided);
+    double fixed_consumed = orc_np_sum(m.absorbed, m.n_absorbed);
+    oc->fixed_provided = fixed_provided; oc->fixed_absorbed = fixed_consumed;
+
+    /* controllable: pure sources (gensets), then the source-and-sink names in list order, each name's modules in order */
+    const double *a_gen = actions, *a_bat = actions + 2 * mg->n_genset, *a_grid = a_bat + mg->n_battery;
+    for (int32_t j = 0; j < mg->n_genset; j++) {
+        orc_state v; mstate_view(s, &s->genset[j], &v);
+        genset_step(&mg->genset[j], &v, a_gen + 2 * j, normalized, &m, &out->genset[j]);
+        s->genset[j] = v;
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        int grids_now = (pass == 0) == (g->grid_before_battery != 0);
+        if (grids_now) {
+            for (int32_t j = 0; j < mg->n_grid; j++) {
+                orc_state v; memset(&v, 0, sizeof(v)); v.t = s->t;
+                grid_step(&mg->grid[j], &v, a_grid[j], normalized, &m, &out->grid[j]);
+            }
+        } else {
+            for (int32_t j = 0; j < mg->n_battery; j++) {
+                orc_state v; mstate_view(s, &s->battery[j], &v);
+                if (battery_step(&mg->battery[j], &v, a_bat[j], normalized, &m, &out->battery[j]) != 0) return -3;
+                s->battery[j] = v;
+            }
+        }
+    }
+    double provided = orc_np_sum(m.provided, m.n_provided);          /* microgrid.py:277 */
+    double consumed = orc_np_sum(m.absorbed, m.n_absorbed);
+    double difference = provided - consumed;
+    oc->controllable_provided = provided - fixed_provided;
+    oc->controllable_absorbed = consumed - fixed_consumed;
+
+    if (difference > 0) {                                            /* :286-299 */
+        double energy_excess = difference;
+        for (int32_t j = 0; j < g->n_pv; j++) {
+            double pv = g->pv_ts[(int64_t)t * g->pv_t_stride + (int64_t)j * g->pv_m_stride];
+            oc->curtailment += pv - 0.0;
+            mstep_append(&m, 0.0, done_ts, 1, 0.0);
+            energy_excess += 0.0;
+        }
+        double sink_amt = -1.0 * energy_excess;
+        double e = -1.0 * sink_amt;
+        oc->overgeneration = e; oc->loss_load = 0.0;
+        oc->unbalanced_reward = -1.0 * (g->overgeneration_cost * e);
+        mstep_append(&m, oc->unbalanced_reward, 0, 0, e);
+    } else {                                                         /* :301-314 */
+        double energy_needed = -difference;
+        for (int32_t j = 0; j < g->n_pv; j++) {
+            double pv = g->pv_ts[(int64_t)t * g->pv_t_stride + (int64_t)j * g->pv_m_stride];
+            double amt = (pv < energy_needed) ? pv : energy_needed;
+            oc->renewable_used += amt;
+            oc->curtailment += pv - amt;
+            mstep_append(&m, 0.0, done_ts, 1, amt);
+            energy_needed -= amt;
+        }
+        double e = energy_needed;
+        oc->loss_load = e; oc->overgeneration = 0.0;
+        oc->unbalanced_reward = -1.0 * (g->loss_load_cost * e);
+        mstep_append(&m, oc->unbalanced_reward, 0, 1, e);
+    }
+    oc->overall_provided = orc_np_sum(m.provided, m.n_provided);
+    oc->overall_absorbed = orc_np_sum(m.absorbed, m.n_absorbed);
+    oc->reward = m.reward;
+    oc->done = m.done;
+    s->t = t + 1;
+    if (!(fabs(oc->overall_provided - oc->overall_absorbed) <= 1e-8 + 1e-5 * fabs(oc->overall_absorbed)))
+        return -1;
+    return 0;
+}
+
+int32_t orc_mobs_dim(const orc_mgrid *mg)
+{
+    int32_t w = 1 + mg->base.horizon;
+    return (mg->base.n_load + mg->base.n_pv) * w + 4 * mg->n_genset + 2 * mg->n_battery + 4 * w * mg->n_grid;
+}
+
+void orc_mobserve(const orc_mgrid *mg, const orc_mstate *s, double *obs)
+{
+    const orc_grid *g = &mg->base;
+    int32_t H = g->horizon, w = 1 + H, k = 0;
+    for (int32_t j = 0; j < g->n_load; j++, k += w)
+        ts_window(g->load_ts + (int64_t)j * g->load_m_stride, g->load_t_stride, g->T, s->t, H,
+                  g->load_lo[j], g->load_hi[j], obs + k, 1);
+    for (int32_t j = 0; j < g->n_pv; j++, k += w)
+        ts_window(g->pv_ts + (int64_t)j * g->pv_m_stride, g->pv_t_stride, g->T, s->t, H,
+                  g->pv_lo[j], g->pv_hi[j], obs + k, 1);
+    for (int32_t j = 0; j < mg->n_genset; j++) {
+        const orc_grid *q = &mg->genset[j]; const orc_state *v = &s->genset[j];
+        obs[k++] = space_normalize(0.0, 1.0, (double)v->gen_cur);
+        obs[k++] = space_normalize(0.0, 1.0, (double)v->gen_goal);
+        obs[k++] = space_normalize(0.0, (double)q->gen_start_up_time, (double)v->gen_up);
+        obs[k++] = space_normalize(0.0, (double)q->gen_wind_down_time, (double)v->gen_down);
+    }
+    for (int32_t j = 0; j < mg->n_battery; j++) {
+        const orc_grid *q = &mg->battery[j]; const orc_state *v = &s->battery[j];
+        double min_soc = q->bat_min_capacity / q->bat_max_capacity;
+        obs[k++] = space_normalize(min_soc, 1.0, v->soc);
+        obs[k++] = space_normalize(q->bat_min_capacity, q->bat_max_capacity, v->charge);
+    }
+    for (int32_t j = 0; j < mg->n_grid; j++) {
+        const orc_grid *q = &mg->grid[j];
+        for (int c = 0; c < 4; c++)
+            ts_window(q->grid_ts + (int64_t)c * q->grid_c_stride, q->grid_t_stride, g->T, s->t, H,
+                      q->grid_lo[c], q->grid_hi[c], obs + k + c, 4);
+        k += 4 * w;
+    }
+}
+
+/* PriorityListAlgo._populate_action over module instances, priority_list.py:69-116 */
+void orc_mpopulate_action(const orc_mgrid *mg, const orc_mstate *s, const orc_mpl_element *plist, int32_t n_elements,
+                          double *actions)
+{
+    const orc_grid *g = &mg->base;
+    int32_t t = s->t;
+    double total_load = 0.0;
+    for (int32_t j = 0; j < g->n_load; j++)
+        total_load += -1 * g->load_ts[(int64_t)t * g->load_t_stride + (int64_t)j * g->load_m_stride];
+    double pvs[ORC_MAX_ADDENDS];
+    for (int32_t j = 0; j < g->n_pv; j++)
+        pvs[j] = g->pv_ts[(int64_t)t * g->pv_t_stride + (int64_t)j * g->pv_m_stride];
+    double remaining = total_load - orc_np_sum(pvs, g->n_pv);
+    int set[3][ORC_MAX_INST];
+    memset(set, 0, sizeof(set));
+    double *a_gen = actions, *a_bat = actions + 2 * mg->n_genset, *a_grid = a_bat + mg->n_battery;
+    for (int32_t j = 0; j < 2 * mg->n_genset + mg->n_battery + mg->n_grid; j++) actions[j] = 0.0;
+    for (int32_t k = 0; k < n_elements; k++) {
+        int32_t kind = plist[k].kind, j = plist[k].inst, act = plist[k].action;
+        if (set[kind][j]) continue;                                   /* :82-88 */
+        set[kind][j] = 1;
+        if (kind == 0) a_gen[2 * j] = (double)act;
+        orc_state v;
+        const orc_grid *q;
+        if (kind == 0) { q = &mg->genset[j]; mstate_view(s, &s->genset[j], &v); }
+        else if (kind == 1) { q = &mg->battery[j]; mstate_view(s, &s->battery[j], &v); }
+        else { q = &mg->grid[j]; memset(&v, 0, sizeof(v)); v.t = t; }
+        double energy;
+        if (fabs(remaining - 0.0) <= 1e-4 + 1e-5 * fabs(0.0)) {
+            energy = 0.0;
+        } else if (remaining > 0) {
+            double mx, mn;
+            if (kind == 0) {
+                int32_t ns = orc_genset_next_status(&v, act);
+                mx = ns * q->gen_running_max; mn = ns * q->gen_running_min;
+            } else if (kind == 1) {
+                mx = battery_max_production(q, &v); mn = 0.0;
+            } else {
+                mx = q->grid_max_import * grid_comp(q, t, 3); mn = 0.0;
+            }
+            if (mn <= remaining && remaining <= mx) energy = remaining;
+            else if (remaining < mn) energy = mn;
+            else energy = mx;
+        } else {
+            if (kind == 0) energy = 0.0;
+            else {
+                double mc = (kind == 1) ? battery_max_consumption(q, &v) : q->grid_max_export * grid_comp(q, t, 3);
+                energy = (-1 * remaining > mc) ? -1.0 * mc : remaining;
+            }
+        }
+        if (kind == 0) a_gen[2 * j + 1] = energy;
+        else if (kind == 1) a_bat[j] = energy;
+        else a_grid[j] = energy;
+        remaining -= energy;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
 #define ORC_TILE 64
 
 static void batch_init_grid(const orc_batch *b, int32_t i, int32_t t0, orc_grid *g, orc_state *s)

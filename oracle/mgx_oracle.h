@@ -127,6 +127,40 @@ typedef struct orc_pl_element { int32_t module; int32_t action; } orc_pl_element
 void orc_populate_action(const orc_grid *g, const orc_state *s,
                          const orc_pl_element *plist, int32_t n_elements, orc_action *out);
 
+/* ---- microgrids with SEVERAL gensets / batteries / grids -------------------------------------------------------------
+ * The reference's container holds a list of modules per name (module_container.py:355-413); Microgrid.run sweeps every
+ * list in order (microgrid.py:255-314) and the priority lists range over module INSTANCES (priority_list.py:15-67).
+ * An orc_mgrid is an orc_grid (`base`: layout, load / pv series, unbalanced costs) plus one orc_grid per controllable
+ * module instance that carries that instance's parameters (every other field copied from `base`); the per-module
+ * arithmetic is the single-instance code above, called once per instance in the reference's order. */
+#define ORC_MAX_INST 8
+typedef struct orc_mgrid {
+    orc_grid base;
+    int32_t n_genset, n_battery, n_grid;
+    orc_grid genset[ORC_MAX_INST];      /* gen_* fields of genset j */
+    orc_grid battery[ORC_MAX_INST];     /* bat_* fields of battery j */
+    orc_grid grid[ORC_MAX_INST];        /* grid_* fields, grid_ts pointer / strides, grid_lo / grid_hi of grid j */
+} orc_mgrid;
+typedef struct orc_mstate {
+    int32_t t;
+    orc_state genset[ORC_MAX_INST];     /* gen_* fields */
+    orc_state battery[ORC_MAX_INST];    /* charge, soc */
+} orc_mstate;
+typedef struct orc_mstep_out {
+    orc_step_out common;                /* reward, done, balance columns, load / pv / unbalanced columns */
+    orc_step_out genset[ORC_MAX_INST], battery[ORC_MAX_INST], grid[ORC_MAX_INST];   /* that instance's columns */
+} orc_mstep_out;
+/* actions: [2 * n_genset + n_battery + n_grid] = (goal, energy) per genset, then the batteries, then the grids.
+ * Return codes as orc_run. */
+int orc_mrun(const orc_mgrid *g, orc_mstate *s, const double *actions, int normalized, orc_mstep_out *out);
+int32_t orc_mobs_dim(const orc_mgrid *g);
+/* flat order: load windows, pv windows, gensets (4 each), batteries (2 each), grid windows */
+void orc_mobserve(const orc_mgrid *g, const orc_mstate *s, double *obs);
+/* kind: 0 genset, 1 battery, 2 grid */
+typedef struct orc_mpl_element { int32_t kind, inst, action; } orc_mpl_element;
+void orc_mpopulate_action(const orc_mgrid *g, const orc_mstate *s, const orc_mpl_element *plist, int32_t n_elements,
+                          double *actions);
+
 /* numpy's float64 add.reduce over a contiguous 1-D array (pairwise_sum, n<=128 path), used by
  * MicrogridStep.balance (step.py:33-36). */
 double orc_np_sum(const double *a, int32_t n);

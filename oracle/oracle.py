@@ -81,6 +81,27 @@ class PLElement(C.Structure):
     _fields_ = [("module", C.c_int32), ("action", C.c_int32)]
 
 
+MAX_INST = 8
+
+
+class MGrid(C.Structure):
+    _fields_ = [("base", Grid), ("n_genset", C.c_int32), ("n_battery", C.c_int32), ("n_grid", C.c_int32),
+                ("genset", Grid * MAX_INST), ("battery", Grid * MAX_INST), ("grid", Grid * MAX_INST)]
+
+
+class MState(C.Structure):
+    _fields_ = [("t", C.c_int32), ("genset", State * MAX_INST), ("battery", State * MAX_INST)]
+
+
+class MStepOut(C.Structure):
+    _fields_ = [("common", StepOut), ("genset", StepOut * MAX_INST), ("battery", StepOut * MAX_INST),
+                ("grid", StepOut * MAX_INST)]
+
+
+class MPLElement(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("inst", C.c_int32), ("action", C.c_int32)]
+
+
 class Batch(C.Structure):
     _fields_ = [
         ("N", C.c_int32), ("T", C.c_int32), ("horizon", C.c_int32), ("final_step", C.c_int32),
@@ -127,6 +148,14 @@ def lib():
         L.orc_rollout_batch.restype = C.c_int64
         L.orc_rollout_batch.argtypes = [C.POINTER(Batch), C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_int,
                                         C.POINTER(C.c_int32), C.c_int32, c_double_p, C.c_int32]
+        L.orc_mrun.restype = C.c_int
+        L.orc_mrun.argtypes = [C.POINTER(MGrid), C.POINTER(MState), c_double_p, C.c_int, C.POINTER(MStepOut)]
+        L.orc_mobs_dim.restype = C.c_int32
+        L.orc_mobs_dim.argtypes = [C.POINTER(MGrid)]
+        L.orc_mobserve.restype = None
+        L.orc_mobserve.argtypes = [C.POINTER(MGrid), C.POINTER(MState), c_double_p]
+        L.orc_mpopulate_action.restype = None
+        L.orc_mpopulate_action.argtypes = [C.POINTER(MGrid), C.POINTER(MState), C.POINTER(MPLElement), C.c_int32, c_double_p]
         _lib = L
     return _lib
 
@@ -265,6 +294,94 @@ class OracleMicrogrid:
     @property
     def status(self):
         return (self.s.gen_cur, self.s.gen_goal, self.s.gen_up, self.s.gen_down)
+
+
+def module_list(v):
+    """A parameter dict's ``battery`` / ``genset`` / ``grid`` entry -> list of per-instance dicts."""
+    if v is None:
+        return []
+    return list(v) if isinstance(v, (list, tuple)) else [v]
+
+
+class OracleMultiMicrogrid:
+    """One microgrid with any number of gensets / batteries / grids (``orc_mrun``).  ``params`` as for
+    ``OracleMicrogrid`` with ``genset`` / ``battery`` / ``grid`` lists of dicts and ``grid_ts`` a list of [T, 4] arrays
+    (a single dict / array = one instance).  Actions are flat: (goal, energy) per genset, the batteries, the grids."""
+
+    def __init__(self, params):
+        p = dict(params)
+        gens, bats, grids = module_list(p.get("genset")), module_list(p.get("battery")), module_list(p.get("grid"))
+        gts = p.get("grid_ts")
+        gts = [] if gts is None else (list(gts) if isinstance(gts, (list, tuple)) else [gts])
+        base_p = {k: v for k, v in p.items() if k not in ("genset", "battery", "grid", "grid_ts")}
+        self._parts = [OracleMicrogrid(base_p)]          # keeps the series arrays alive
+        mg, ms = MGrid(), MState()
+        mg.base = self._parts[0].g
+        mg.n_genset, mg.n_battery, mg.n_grid = len(gens), len(bats), len(grids)
+        ms.t = self._parts[0].s.t
+        for kind, lst in (("genset", gens), ("battery", bats), ("grid", grids)):
+            for j, q in enumerate(lst):
+                extra = {"grid_ts": gts[j]} if kind == "grid" else {}
+                om = OracleMicrogrid({**base_p, kind: q, **extra})
+                self._parts.append(om)
+                getattr(mg, kind)[j] = om.g
+                if kind != "grid":
+                    getattr(ms, kind)[j] = om.s
+        order = [str(x) for x in (p.get("controllable_order") or [])]
+        mg.base.grid_before_battery = int(bool(grids) and bool(bats) and "grid" in order and "battery" in order
+                                          and order.index("grid") < order.index("battery"))
+        self.g, self.s, self.p = mg, ms, p
+        self.counts = dict(genset=len(gens), battery=len(bats), grid=len(grids))
+        self.action_dim = 2 * len(gens) + len(bats) + len(grids)
+        self.obs_dim = lib().orc_mobs_dim(C.byref(mg))
+
+    def run(self, actions, normalized=True):
+        a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(-1))
+        assert a.size == self.action_dim
+        out = MStepOut()
+        rc = lib().orc_mrun(C.byref(self.g), C.byref(self.s), _dp(a), int(normalized), C.byref(out))
+        if rc == -1:
+            raise RuntimeError("Microgrid modules unable to balance energy production with consumption.")
+        if rc == -3:
+            raise AssertionError("absorbed_energy >= 0 (base_module.py:272)")
+        if rc != 0:
+            raise IndexError("step outside the time series")
+        return out
+
+    def observe(self):
+        obs = np.empty(self.obs_dim, dtype=np.float64)
+        lib().orc_mobserve(C.byref(self.g), C.byref(self.s), _dp(obs))
+        return obs
+
+    def reset(self, initial_step=None):
+        self.s.t = int(self.p.get("initial_step", 0) if initial_step is None else initial_step)
+        return self.observe()
+
+    def populate_action(self, plist):
+        """plist: list of (kind id 0/1/2, instance, action id) -> flat unnormalised control."""
+        els = (MPLElement * len(plist))(*[MPLElement(int(k), int(j), int(a)) for k, j, a in plist])
+        out = np.zeros(self.action_dim, dtype=np.float64)
+        lib().orc_mpopulate_action(C.byref(self.g), C.byref(self.s), els, len(plist), _dp(out))
+        return out
+
+    def log_row(self, out, names):
+        """The step's log columns in the order of ``names`` (BatchLayout.log_names spelling: ``name`` / ``name[j]``);
+        names the oracle does not produce (``genset_status``, ``violations``) give None."""
+        common = out.common.as_dict()
+        row = []
+        for n in names:
+            base, j = (n[:n.index("[")], int(n[n.index("[") + 1:-1])) if n.endswith("]") else (n, 0)
+            if base in ("genset_production", "genset_co2_production", "genset_reward"):
+                row.append(getattr(out.genset[j], base))
+            elif base in ("discharge_amount", "charge_amount", "battery_reward", "soc_pre", "charge_pre"):
+                row.append(getattr(out.battery[j], base))
+            elif base in ("grid_import", "grid_export", "grid_co2_production", "grid_reward"):
+                row.append(getattr(out.grid[j], base))
+            elif base in ("gen_cur", "gen_goal", "gen_up", "gen_down"):
+                row.append(float(getattr(out.genset[j], base)))
+            else:
+                row.append(common.get(base))
+        return row
 
 
 def np_sum(values):

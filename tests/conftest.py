@@ -58,3 +58,19 @@ def actions_for(p, row):
 
 def action_dim(p):
     return 2 * (p.get("genset") is not None) + (p.get("battery") is not None) + (p.get("grid") is not None)
+
+
+def multi_cases():
+    """The reference-made fixtures for microgrids with several gensets / batteries / grids (tests/golden/multi.npz,
+    make_multi_goldens.py): yields (case index, parameter dict in this repo's vocabulary, meta, npz)."""
+    import json
+    z = golden("multi.npz")
+    for ci, mt in enumerate(json.loads(str(z["meta"]))):
+        p = dict(load_ts=np.stack([z[f"c{ci}_load_{j}"] for j in range(mt["n_load"])], axis=1),
+                 pv_ts=np.stack([z[f"c{ci}_pv_{j}"] for j in range(mt["n_pv"])], axis=1),
+                 horizon=mt["horizon"], final_step=mt["T"], initial_step=0,
+                 unbalanced=dict(loss_load_cost=mt["loss_load_cost"], overgeneration_cost=mt["overgeneration_cost"]),
+                 genset=mt["genset"], battery=mt["battery"], grid=mt["grid"],
+                 grid_ts=[z[f"c{ci}_grid_ts_{j}"] for j in range(len(mt["grid"]))],
+                 controllable_order=[k for k in mt["order"] if k in ("genset", "battery", "grid")])
+        yield ci, p, mt, z
