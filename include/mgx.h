@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 3
+#define MGX_ABI_VERSION 4
 
 enum mgx_status {
     MGX_OK = 0,
@@ -88,7 +88,16 @@ typedef struct mgx_layout {
                                     * therefore stepped / summed first (module_container.py:355-413; the controllable
                                     * sweep is pure sources, then sources-and-sinks in list order).  Changes the last
                                     * bit of the balance sums, not the action / log / observation column order. */
+    /* Module multiplicities (the container holds a LIST of modules per name, module_container.py:355-413, and
+     * Microgrid.run sweeps every list in order, microgrid.py:262-275): 0 = "as has_*" (0 or 1).  With n > 1 every
+     * column of that module kind is [n, N] (instance-major), grid_ts is [T, n_grid, 4, N], grid_lo / grid_hi
+     * [n_grid, 4, N]; actions are (goal, energy) per genset, then the batteries, then the grids; the log carries one
+     * block per instance; observations one group of state columns / one grid window per instance.  Such layouts run on
+     * the general kernels (as do n_load / n_pv != 1): single steps, observations, priority lists (mgx_expand_lists). */
+    int32_t n_genset, n_battery, n_grid;      /* <= MGX_MAX_INSTANCES */
 } mgx_layout;
+
+#define MGX_MAX_INSTANCES 8
 
 /* Device columns.  Pointers for absent modules may be NULL. */
 typedef struct mgx_columns {
@@ -239,6 +248,13 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized,
  * (module, action) pairs, module 0 genset / 1 battery / 2 grid, -1 = padding; n_actions <= 12. */
 int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions,
                         double *control, mgx_stream stream);
+
+/* The same for priority lists over module INSTANCES (microgrids with several gensets / batteries / grids:
+ * get_priority_lists enumerates (module name, module number, action) elements, priority_list.py:15-67, and there can
+ * be hundreds of lists): `lists` is a DEVICE array int32 [n_lists, list_len, 3] of (kind, instance, action), kind
+ * 0 genset / 1 battery / 2 grid, kind -1 = padding.  Works for every layout. */
+int mgx_expand_lists(mgx_handle *h, const int32_t *action_id, const int32_t *lists, int32_t n_lists, int32_t list_len,
+                     double *control, mgx_stream stream);
 
 /* DiscreteMicrogridEnv.step (discrete.py:109-143) in ONE launch: mgx_expand_discrete + mgx_step(normalized=0) with the
  * control kept in registers.  control [N, A] (optional, may be NULL) receives the expanded control; the other

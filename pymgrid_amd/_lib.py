@@ -17,7 +17,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-fPIC", "-shared"]
 
 MGX_OK, MGX_ERR_INVALID, MGX_ERR_UNSUPPORTED, MGX_ERR_RANGE, MGX_ERR_DEVICE = range(5)
-ABI_VERSION = 3
+ABI_VERSION = 4
+MAX_INSTANCES = 8          # MGX_MAX_INSTANCES: gensets / batteries / grids per microgrid
 
 
 class MgxError(RuntimeError):
@@ -35,7 +36,7 @@ c_i32_p = C.POINTER(C.c_int32)
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "n_grids", "n_steps", "horizon", "initial_step", "final_step",
-        "has_genset", "has_battery", "has_grid", "n_load", "n_pv", "grid_before_battery")]
+        "has_genset", "has_battery", "has_grid", "n_load", "n_pv", "grid_before_battery", "n_genset", "n_battery", "n_grid")]
 
 
 _F64_COLS = ("bat_min_capacity", "bat_max_capacity", "bat_max_charge", "bat_max_discharge", "bat_efficiency",
@@ -104,6 +105,7 @@ SYMBOLS = {
     "mgx_step_k": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_expand_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgx_expand_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgx_step_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_rollout_discrete": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_i32_p, C.c_int32, C.c_int32, C.c_void_p,
@@ -165,7 +167,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.mgx_abi_version() != ABI_VERSION:
             raise ImportError(f"libmgx.so ABI {L.mgx_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
-        assert C.sizeof(Layout) == 48
+        assert C.sizeof(Layout) == 60
         _lib = L
     return _lib
 

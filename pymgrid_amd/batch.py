@@ -30,47 +30,58 @@ class BatchLayout:
     # the GridModule precedes the BatteryModule in the microgrid's module list: it is stepped and summed first
     # (module_container.py:355-413).  Column orders (actions, log, observation) do not depend on it.
     grid_before_battery: bool = False
+    # module multiplicities (the reference's container holds a list of modules per name, module_container.py:355-413):
+    # -1 = as has_* says (0 or 1).  With n > 1 the columns of that kind are [n, N], grid_ts [T, n_grid, 4, N], and the
+    # batch runs on the general kernels.
+    n_genset: int = -1
+    n_battery: int = -1
+    n_grid: int = -1
 
     def __post_init__(self):
         if self.final_step <= 0:
             object.__setattr__(self, "final_step", self.n_steps)
+        for kind in ("genset", "battery", "grid"):
+            n = getattr(self, "n_" + kind)
+            if n < 0:
+                object.__setattr__(self, "n_" + kind, int(getattr(self, "has_" + kind)))
+            else:
+                object.__setattr__(self, "has_" + kind, n > 0)
         if self.grid_before_battery and not (self.has_grid and self.has_battery):
             object.__setattr__(self, "grid_before_battery", False)
 
     @property
+    def multi(self):
+        """True when the batch runs on the general kernels: not exactly one module of every present kind."""
+        return self.n_load != 1 or self.n_pv != 1 or self.n_genset > 1 or self.n_battery > 1 or self.n_grid > 1
+
+    @property
     def action_dim(self):
-        return 2 * int(self.has_genset) + int(self.has_battery) + int(self.has_grid)
+        return 2 * self.n_genset + self.n_battery + self.n_grid
 
     @property
     def obs_dim(self):
         w = 1 + self.horizon
-        return (self.n_load + self.n_pv) * w + 4 * int(self.has_genset) + 2 * int(self.has_battery) \
-            + 4 * w * int(self.has_grid)
+        return (self.n_load + self.n_pv) * w + 4 * self.n_genset + 2 * self.n_battery + 4 * w * self.n_grid
 
     @property
     def log_names(self):
         names = ["reward", "fixed_provided", "fixed_absorbed", "controllable_provided", "controllable_absorbed",
                  "overall_provided", "overall_absorbed", "load_met", "renewable_used", "curtailment", "loss_load",
                  "overgeneration", "unbalanced_reward"]
-        if self.has_genset:
-            names += ["genset_production", "genset_co2_production", "genset_reward", "genset_status"]
-        if self.has_battery:
-            names += ["discharge_amount", "charge_amount", "battery_reward", "soc_pre", "charge_pre"]
-        if self.has_grid:
-            names += ["grid_import", "grid_export", "grid_co2_production", "grid_reward"]
+        def block(cols, n):          # instance 0 keeps the plain names, instance j > 0 is "name[j]"
+            return [c if j == 0 else f"{c}[{j}]" for j in range(n) for c in cols]
+        names += block(["genset_production", "genset_co2_production", "genset_reward", "genset_status"], self.n_genset)
+        names += block(["discharge_amount", "charge_amount", "battery_reward", "soc_pre", "charge_pre"], self.n_battery)
+        names += block(["grid_import", "grid_export", "grid_co2_production", "grid_reward"], self.n_grid)
         names += ["violations"]      # bit mask of requests the reference refuses with raise_errors=True
         return names
 
     @property
     def action_names(self):
-        names = []
-        if self.has_genset:
-            names += ["genset_goal_status", "genset_energy"]
-        if self.has_battery:
-            names += ["battery"]
-        if self.has_grid:
-            names += ["grid"]
-        return names
+        def block(cols, n):
+            return [c if j == 0 else f"{c}[{j}]" for j in range(n) for c in cols]
+        return block(["genset_goal_status", "genset_energy"], self.n_genset) + block(["battery"], self.n_battery) \
+            + block(["grid"], self.n_grid)
 
     @property
     def obs_names(self):
@@ -89,22 +100,33 @@ class BatchLayout:
             names += window(["load"])
         for _ in range(self.n_pv):
             names += window(["renewable"])
-        if self.has_genset:
+        for _ in range(self.n_genset):
             names += ["current_status", "goal_status", "steps_until_up", "steps_until_down"]
-        if self.has_battery:
+        for _ in range(self.n_battery):
             names += ["soc", "current_charge"]
-        if self.has_grid:
+        for _ in range(self.n_grid):
             names += window(["import_price", "export_price", "co2_per_kwh", "grid_status"])
         return names
 
     def obs_slices(self):
         """name -> slice of the flat observation (order load, pv, genset, battery, grid)."""
         w, k, out = 1 + self.horizon, 0, {}
-        for name, n in (("load", self.n_load * w), ("pv", self.n_pv * w), ("genset", 4 * int(self.has_genset)),
-                        ("battery", 2 * int(self.has_battery)), ("grid", 4 * w * int(self.has_grid))):
+        for name, n in (("load", self.n_load * w), ("pv", self.n_pv * w), ("genset", 4 * self.n_genset),
+                        ("battery", 2 * self.n_battery), ("grid", 4 * w * self.n_grid)):
             if n:
                 out[name] = slice(k, k + n)
                 k += n
+        return out
+
+    def obs_instances(self):
+        """module name -> list of slices of the flat observation, one per module instance (the reference's nested
+        observation: {name: [array per module]}, microgrid.py:316-319)."""
+        w, k, out = 1 + self.horizon, 0, {}
+        for name, n, width in (("load", self.n_load, w), ("pv", self.n_pv, w), ("genset", self.n_genset, 4),
+                               ("battery", self.n_battery, 2), ("grid", self.n_grid, 4 * w)):
+            if n:
+                out[name] = [slice(k + j * width, k + (j + 1) * width) for j in range(n)]
+                k += n * width
         return out
 
     def bytes_per_step(self, log=False, obs=False):
@@ -189,6 +211,17 @@ class MicrogridBatch:
             shapes.update(load_ts=(T, L.n_load, N), load_lo=(L.n_load, N), load_hi=(L.n_load, N))
         if L.n_pv != 1:
             shapes.update(pv_ts=(T, L.n_pv, N), pv_lo=(L.n_pv, N), pv_hi=(L.n_pv, N))
+        # several modules of a controllable kind: instance-major columns
+        per_kind = {"bat_": L.n_battery, "gen_": L.n_genset, "grid_m": L.n_grid, "grid_c": L.n_grid}
+        for name in _lib.COLUMN_NAMES:
+            for prefix, n in per_kind.items():
+                if name.startswith(prefix) and n > 1:
+                    shapes[name] = (n, N)
+        if L.n_battery > 1:
+            shapes.update(charge=(L.n_battery, N), soc=(L.n_battery, N))
+        if L.n_grid > 1:
+            shapes.update(grid_ts=(T, L.n_grid, 4, N), grid_lo=(L.n_grid, 4, N), grid_hi=(L.n_grid, 4, N),
+                          grid_noise_std=(L.n_grid, N))
         for name in need:
             if name not in self.cols:
                 raise ValueError(f"column {name} is required by the layout")
@@ -282,12 +315,29 @@ def grid_first(p):
     return "grid" in order and "battery" in order and order.index("grid") < order.index("battery")
 
 
+def module_list(v):
+    """A parameter dict's ``genset`` / ``battery`` / ``grid`` entry -> list of per-instance dicts (a single dict = one
+    instance, None = none)."""
+    if v is None:
+        return []
+    return list(v) if isinstance(v, (list, tuple)) else [v]
+
+
+def grid_series_list(g):
+    ts = g.get("grid_ts")
+    if ts is None:
+        return []
+    return list(ts) if isinstance(ts, (list, tuple)) else [ts]
+
+
 def pack_grids(grids):
-    """list of parameter dicts -> (numpy column dict, BatchLayout)."""
+    """list of parameter dicts -> (numpy column dict, BatchLayout).  ``genset`` / ``battery`` / ``grid`` may be lists of
+    dicts (several modules of a kind, ``grid_ts`` then a list of [T, 4] arrays): columns [n, N], instance-major."""
     if not grids:
         raise ValueError("need at least one microgrid")
     g0 = grids[0]
-    has = {k: g0.get(k) is not None for k in ("genset", "battery", "grid")}
+    count = {k: len(module_list(g0.get(k))) for k in ("genset", "battery", "grid")}
+    has = {k: n > 0 for k, n in count.items()}
     T = np.asarray(g0["load_ts"]).shape[0]
     N = len(grids)
 
@@ -296,9 +346,11 @@ def pack_grids(grids):
         return 1 if a.ndim == 1 else a.shape[1]
     n_load, n_pv = n_modules(g0["load_ts"]), n_modules(g0["pv_ts"])
     for g in grids:
-        for k in has:
-            if (g.get(k) is not None) != has[k]:
+        for k in count:
+            if len(module_list(g.get(k))) != count[k]:
                 raise ValueError("all microgrids of a batch must have the same module set (bucket them by layout)")
+        if len(grid_series_list(g)) != count["grid"]:
+            raise ValueError("grid_ts: one [T, 4] series per GridModule")
         for k, n in (("load_ts", n_load), ("pv_ts", n_pv)):
             a = np.asarray(g[k])
             if a.shape[0] != T or n_modules(a) != n:
@@ -306,15 +358,22 @@ def pack_grids(grids):
         for k in ("horizon", "final_step", "initial_step"):
             if g.get(k, g0.get(k)) != g0.get(k):
                 raise ValueError(f"all microgrids of a batch must share {k}")
+    if max(count.values()) > _lib.MAX_INSTANCES:
+        raise ValueError(f"at most {_lib.MAX_INSTANCES} gensets, batteries and grids per microgrid on the device path")
     layout = BatchLayout(n_grids=N, n_steps=T, horizon=int(g0.get("horizon", 0)),
                          initial_step=int(g0.get("initial_step", 0)), final_step=int(g0.get("final_step", 0)),
                          has_genset=has["genset"], has_battery=has["battery"], has_grid=has["grid"],
-                         n_load=n_load, n_pv=n_pv, grid_before_battery=grid_first(g0))
+                         n_load=n_load, n_pv=n_pv, grid_before_battery=grid_first(g0),
+                         n_genset=count["genset"], n_battery=count["battery"], n_grid=count["grid"])
     if any(grid_first(g) != layout.grid_before_battery for g in grids if has["grid"] and has["battery"]):
         raise ValueError("all microgrids of a batch must step battery and grid in the same order (bucket them by layout)")
 
     def col(fn):
         return np.array([fn(g) for g in grids], dtype=np.float64)
+
+    def inst_col(kind, fn, dtype=np.float64):          # -> [N] for one instance per grid, else [n, N]
+        a = np.array([[fn(q) for q in module_list(g.get(kind))] for g in grids], dtype=dtype).T
+        return a[0] if count[kind] == 1 else np.ascontiguousarray(a)
 
     A = {}
     def stack(key, n):           # -> [T, N] for one module per grid, else [T, n, N]
@@ -339,64 +398,68 @@ def pack_grids(grids):
     A["overgeneration_cost"] = col(lambda g: g["unbalanced"]["overgeneration_cost"])
     if has["battery"]:
         for k in ("min_capacity", "max_capacity", "max_charge", "max_discharge", "efficiency"):
-            A["bat_" + k] = col(lambda g, k=k: g["battery"][k])
-        A["bat_cost_cycle"] = col(lambda g: g["battery"]["battery_cost_cycle"])
+            A["bat_" + k] = inst_col("battery", lambda b, k=k: b[k])
+        A["bat_cost_cycle"] = inst_col("battery", lambda b: b["battery_cost_cycle"])
         if np.any((A["bat_efficiency"] <= 0) | (A["bat_efficiency"] > 1)):
             raise ValueError("battery efficiency must be in (0, 1]")          # battery_module.py:78
-        charge, soc = [], []
-        for g in grids:            # BatteryModule._init_battery, battery_module.py:96-106
-            b = g["battery"]
+
+        def init_battery(b):       # BatteryModule._init_battery, battery_module.py:96-106 -> (charge, soc)
             if b.get("charge") is not None:
                 c = float(b["charge"])
-                s = float(b["soc"]) if b.get("soc") is not None else c / b["max_capacity"]
-            elif b.get("init_charge") is not None:
-                c = float(b["init_charge"]); s = c / b["max_capacity"]
-            elif b.get("init_soc") is not None:
-                s = float(b["init_soc"]); c = s * b["max_capacity"]
-            else:
-                raise ValueError("Must set one of init_charge and init_soc.")
-            charge.append(c); soc.append(s)
-        A["charge"], A["soc"] = np.array(charge), np.array(soc)
+                return c, (float(b["soc"]) if b.get("soc") is not None else c / b["max_capacity"])
+            if b.get("init_charge") is not None:
+                c = float(b["init_charge"])
+                return c, c / b["max_capacity"]
+            if b.get("init_soc") is not None:
+                s = float(b["init_soc"])
+                return s * b["max_capacity"], s
+            raise ValueError("Must set one of init_charge and init_soc.")
+        A["charge"] = inst_col("battery", lambda b: init_battery(b)[0])
+        A["soc"] = inst_col("battery", lambda b: init_battery(b)[1])
     if has["genset"]:
-        A["gen_running_min"] = col(lambda g: g["genset"]["running_min_production"])
-        A["gen_running_max"] = col(lambda g: g["genset"]["running_max_production"])
+        A["gen_running_min"] = inst_col("genset", lambda q: q["running_min_production"])
+        A["gen_running_max"] = inst_col("genset", lambda q: q["running_max_production"])
         if np.any(A["gen_running_min"] > A["gen_running_max"]):
             raise ValueError("parameter min_production must not be greater than parameter max_production.")
-        A["gen_cost"] = col(lambda g: g["genset"]["genset_cost"])
-        A["gen_co2_per_unit"] = col(lambda g: g["genset"].get("co2_per_unit", 0.0))
-        A["gen_cost_per_unit_co2"] = col(lambda g: g["genset"].get("cost_per_unit_co2", 0.0))
-        su = [int(g["genset"].get("start_up_time", 0)) for g in grids]
-        wd = [int(g["genset"].get("wind_down_time", 0)) for g in grids]
-        A["gen_times"] = pack_times(su, wd, [bool(g["genset"].get("allow_abortion", True)) for g in grids])
-        st = []
-        for g, s_, w_ in zip(grids, su, wd):      # genset_module.py:91-92,216-227
-            q = g["genset"]
+        A["gen_cost"] = inst_col("genset", lambda q: q["genset_cost"])
+        A["gen_co2_per_unit"] = inst_col("genset", lambda q: q.get("co2_per_unit", 0.0))
+        A["gen_cost_per_unit_co2"] = inst_col("genset", lambda q: q.get("cost_per_unit_co2", 0.0))
+        su = inst_col("genset", lambda q: int(q.get("start_up_time", 0)), np.int64)
+        wd = inst_col("genset", lambda q: int(q.get("wind_down_time", 0)), np.int64)
+        A["gen_times"] = pack_times(su, wd, inst_col("genset", lambda q: bool(q.get("allow_abortion", True)), bool))
+
+        def init_status(q):        # genset_module.py:91-92,216-227
             if q.get("status") is not None:
-                st.append([int(v) for v in q["status"]])
-            else:
-                on = int(bool(q.get("init_start_up", True)))
-                st.append([on, on, 0, w_] if on else [0, 0, s_, 0])
-        st = np.array(st)
-        A["gen_status"] = pack_status(st[:, 0], st[:, 1], st[:, 2], st[:, 3])
+                return [int(v) for v in q["status"]]
+            on = int(bool(q.get("init_start_up", True)))
+            return [on, on, 0, int(q.get("wind_down_time", 0))] if on else [0, 0, int(q.get("start_up_time", 0)), 0]
+        st = [inst_col("genset", lambda q, c=c: init_status(q)[c], np.int64) for c in range(4)]
+        A["gen_status"] = pack_status(*st)
     if has["grid"]:
-        A["grid_max_import"] = col(lambda g: g["grid"]["max_import"])
-        A["grid_max_export"] = col(lambda g: g["grid"]["max_export"])
-        A["grid_cost_per_unit_co2"] = col(lambda g: g["grid"].get("cost_per_unit_co2", 0.0))
+        A["grid_max_import"] = inst_col("grid", lambda q: q["max_import"])
+        A["grid_max_export"] = inst_col("grid", lambda q: q["max_export"])
+        A["grid_cost_per_unit_co2"] = inst_col("grid", lambda q: q.get("cost_per_unit_co2", 0.0))
         gts = []
         for g in grids:                           # GridModule._check_params, grid_module.py:103-123
-            ts = np.asarray(g["grid_ts"], dtype=np.float64)
-            if ts.ndim != 2 or ts.shape[1] not in (3, 4) or ts.shape[0] != T:
-                raise ValueError("Time series must be two dimensional with three or four columns.")
-            if ts.shape[1] == 3:
-                ts = np.concatenate([ts, np.ones((T, 1))], axis=1)
-            elif not np.all((ts[:, 3] == 0) | (ts[:, 3] == 1)):
-                raise ValueError("Last column (grid status) must contain binary values.")
-            if (ts < 0).any():
-                raise ValueError("Time series must be non-negative.")
-            gts.append(ts)
-        gts = np.stack(gts, axis=2)               # [T, 4, N]
-        A["grid_ts"] = gts
-        A["grid_lo"], A["grid_hi"] = gts.min(axis=0), gts.max(axis=0)
+            per = []
+            for ts in grid_series_list(g):
+                ts = np.asarray(ts, dtype=np.float64)
+                if ts.ndim != 2 or ts.shape[1] not in (3, 4) or ts.shape[0] != T:
+                    raise ValueError("Time series must be two dimensional with three or four columns.")
+                if ts.shape[1] == 3:
+                    ts = np.concatenate([ts, np.ones((T, 1))], axis=1)
+                elif not np.all((ts[:, 3] == 0) | (ts[:, 3] == 1)):
+                    raise ValueError("Last column (grid status) must contain binary values.")
+                if (ts < 0).any():
+                    raise ValueError("Time series must be non-negative.")
+                per.append(ts)
+            gts.append(np.stack(per, axis=1))     # [T, n_grid, 4]
+        gts = np.stack(gts, axis=3)               # [T, n_grid, 4, N]
+        lo, hi = gts.min(axis=0), gts.max(axis=0)
+        if count["grid"] == 1:
+            gts, lo, hi = gts[:, 0], lo[0], hi[0]  # [T, 4, N]
+        A["grid_ts"] = np.ascontiguousarray(gts)
+        A["grid_lo"], A["grid_hi"] = lo, hi
     # GaussianNoiseForecaster (forecast/forecaster.py:220-275): p["forecast_noise"] = dict(std=, relative_noise=,
     # increase_uncertainty=, seed=) -> per-grid, per-module noise standard deviation columns
     fn0 = g0.get("forecast_noise")
@@ -405,6 +468,8 @@ def pack_grids(grids):
     if fn0 is not None:
         if layout.horizon == 0:
             raise ValueError("forecast_noise needs a forecast horizon > 0")
+        if layout.multi:
+            raise ValueError("forecast_noise is offered for microgrids with one module of every kind only")
         lo_, hi_ = layout.initial_step, layout.final_step
         for g in grids:
             f = g["forecast_noise"]

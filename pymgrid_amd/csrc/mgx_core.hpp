@@ -43,6 +43,7 @@ struct KArgs {
     int32_t N, T, H, final_step;
     int32_t obs_dim, log_dim;
     int32_t n_load, n_pv;    // load / renewable modules per grid (1 on the fast path, <= MGX_MAX_MODULES otherwise)
+    int32_t n_genset, n_battery, n_grid;   // controllable module instances per grid (0 / 1 on the fast path, <= MGX_MAX_INSTANCES)
     int32_t obs_f32;         // observation rows are written as float (RN of the fp64 value) instead of double
     int32_t act_f32;         // continuous actions arrive as float (widened to double exactly) instead of double
     int32_t obs_state_only;  // obs arguments of step / observe receive ONLY the state columns (windows were prefetched)
@@ -197,8 +198,9 @@ __device__ __forceinline__ void derive(const Params &p, Derived &d)
 }
 
 // ---- loads ----------------------------------------------------------------------------------------------
+// parameters of the controllable modules at column index i (= instance * N + grid for layouts with several instances)
 template <int F>
-__device__ __forceinline__ void load_params(const mgx_columns &c, int64_t i, Params &p)
+__device__ __forceinline__ void load_module_params(const mgx_columns &c, int64_t i, Params &p)
 {
     if constexpr (F & F_BATTERY) {
         p.bat_cmin = c.bat_min_capacity[i]; p.bat_cmax = c.bat_max_capacity[i];
@@ -215,6 +217,12 @@ __device__ __forceinline__ void load_params(const mgx_columns &c, int64_t i, Par
         p.grid_imp = c.grid_max_import[i];  p.grid_exp = c.grid_max_export[i];
         p.grid_cco2 = c.grid_cost_per_unit_co2[i];
     }
+}
+
+template <int F>
+__device__ __forceinline__ void load_params(const mgx_columns &c, int64_t i, Params &p)
+{
+    load_module_params<F>(c, i, p);
     p.ll_cost = c.loss_load_cost[i];
     p.og_cost = c.overgeneration_cost[i];
 }
@@ -816,100 +824,242 @@ __device__ __forceinline__ void window_finish(double (&v)[OBS_JB][NC], const Win
 // MicrogridStep are materialised in private memory and summed exactly as numpy's float64 add.reduce does
 // (pairwise_sum: running sum below 8 addends, eight interleaved partial sums above).
 // =========================================================================================================
-constexpr int MGX_MAX_MODULES = 16;                       // per kind
-constexpr int MGX_MAX_ADDENDS = MGX_MAX_MODULES + 4;
+constexpr int MGX_MAX_MODULES = 16;                       // load / renewable modules per grid
 
-__device__ inline double np_sum_dev(const double *a, int n)
+// ---- general path: any number of modules per kind ----------------------------------------------------------------------
+// MicrogridStep keeps a list of provided and a list of absorbed energies and np.sum()s them three times per step
+// (utils/step.py:24-36, microgrid.py:259,277,316).  Which list a battery / grid entry joins depends on the sign of its
+// request, so the list lengths differ from grid to grid.  The lists live in LDS, one column per lane (element k of a lane's
+// list at list[k * stride]: lanes of a wave hit distinct banks); numpy's summation order depends on the length:
+// n < 8 a running sum, n >= 8 eight partial sums combined pairwise, then the tail (DOUBLE_pairwise_sum, n <= 128).
+struct StepLists {
+    double *prov, *absb;
+    int stride, n_prov, n_absb;
+    __device__ __forceinline__ void provided(double v) { prov[(n_prov++) * stride] = v; }
+    __device__ __forceinline__ void absorbed(double v) { absb[(n_absb++) * stride] = v; }
+};
+
+__device__ inline double np_sum_strided(const double *a, int stride, int n)
 {
     if (n < 8) {
         double res = 0.0;
-        for (int i = 0; i < n; i++) res += a[i];
+        for (int i = 0; i < n; i++) res += a[i * stride];
         return res;
     }
     double r[8];
     int i;
-    for (i = 0; i < 8; i++) r[i] = a[i];
+#pragma unroll
+    for (i = 0; i < 8; i++) r[i] = a[i * stride];
     for (i = 8; i < n - (n % 8); i += 8)
-        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] += a[(i + j) * stride];
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res += a[i];
+    for (; i < n; i++) res += a[i * stride];
     return res;
 }
 
-// One Microgrid.run with n_load fixed sinks and n_pv flex sources (microgrid.py:227-325).  `in` carries the control
-// and the grid row; load[] / pv[] hold the modules' series values at the step (stored sign).
-template <int F>
-__device__ inline void step_multi_core(const Params &p, const Derived &d, State &s, const Inputs &in, bool normalized,
-                                       const double *load, int n_load, const double *pv, int n_pv, Outputs &o)
+// addends a lane's lists can hold: provided <= gensets + batteries + grids + renewables + loss load, absorbed <= loads +
+// batteries + grids + overgeneration
+__host__ __device__ inline int multi_list_capacity(int n_load, int n_pv, int n_genset, int n_battery, int n_grid)
 {
-    double prov[MGX_MAX_ADDENDS], absb[MGX_MAX_ADDENDS];
-    int n_prov = 0, n_absb = 0;
-    double reward = 0.0;
-    o.load_met = 0.0;
-    for (int j = 0; j < n_load; j++) {                    // fixed modules, module order (microgrid.py:255-257)
-        const double L = -1 * load[j];
-        o.load_met += L;
-        absb[n_absb++] = L; reward += 0.0;
-    }
-    o.fixed_provided = np_sum_dev(prov, n_prov); o.fixed_absorbed = np_sum_dev(absb, n_absb);   // :259-260
+    const int a = n_genset + n_battery + n_grid + n_pv + 1, b = n_load + n_battery + n_grid + 1;
+    return a > b ? a : b;
+}
 
-    // controllable modules: reuse the single-module arithmetic through a one-step core on zero load / pv and read
-    // back what each module did (same operations, same order: genset -> battery -> grid)
-    Inputs c = in; c.load = 0.0; c.pv = 0.0;
-    Outputs oc;
-    step_core<F>(p, d, s, c, normalized, true, false, oc);
-    o.violations = oc.violations;
-    if constexpr (F & F_GENSET) {
-        o.genset_production = oc.genset_production; o.genset_co2 = oc.genset_co2; o.genset_reward = oc.genset_reward;
-        prov[n_prov++] = oc.genset_production; reward += oc.genset_reward;
+// One Microgrid.run of grid i with every module list swept in the reference's order (microgrid.py:255-314): fixed modules,
+// gensets (pure sources), the source-and-sink names in list order (batteries and grids, every instance of a name in
+// order), renewables, unbalanced energy.  Each controllable instance runs the SAME arithmetic as the single-instance
+// kernels: step_core<that module only> on zero load / pv, of which only that module's part is kept.  State columns and
+// the instance's log block are written as the sweep goes.  `o` receives the microgrid-level outputs (balance columns,
+// load / pv / unbalanced columns, reward, violations; discharge_amount / charge_amount = what BatteryDischargeShaper sums).
+template <int F, typename AT>
+__device__ inline void step_multi_core(const KArgs &a, const AT *__restrict__ act, int64_t i, int32_t t, bool normalized,
+                                       StepLists &L, double *__restrict__ log, Outputs &o)
+{
+    const int64_t N = a.N;
+    const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
+    double reward = 0.0;
+    uint32_t viol = 0u;
+    L.n_prov = 0; L.n_absb = 0;
+    o.load_met = 0.0;
+    for (int j = 0; j < a.n_load; j++) {                  // fixed modules, module order (microgrid.py:255-257)
+        const double Lv = -1 * a.c.load_ts[((int64_t)t * a.n_load + j) * N + i];
+        o.load_met += Lv;
+        L.absorbed(Lv); reward += 0.0;
     }
-    auto add_battery = [&]() __attribute__((always_inline)) {
-        o.discharge_amount = oc.discharge_amount; o.charge_amount = oc.charge_amount; o.battery_reward = oc.battery_reward;
-        o.soc_pre = oc.soc_pre; o.charge_pre = oc.charge_pre;
-        // as_source iff the unnormalised request is >= 0 (base_module.py:161-171); a sink logs charge_amount
-        const double x = normalized ? d.bat_lo + d.bat_sp * in.a_bat : in.a_bat;
-        if (x < 0) absb[n_absb++] = oc.charge_amount; else prov[n_prov++] = oc.discharge_amount;
-        reward += oc.battery_reward;
+    o.fixed_provided = np_sum_strided(L.prov, L.stride, L.n_prov);          // :259-260
+    o.fixed_absorbed = np_sum_strided(L.absb, L.stride, L.n_absb);
+
+    const int kg = LC_COMMON_END, kb = kg + LC_GENSET_N * NG, kr = kb + LC_BATTERY_N * NB;    // log blocks
+    Inputs in; in.load = 0.0; in.pv = 0.0;
+    Outputs oc;
+    if constexpr (F & F_GENSET) {
+        for (int j = 0; j < NG; j++) {
+            const int64_t c = (int64_t)j * N + i;
+            Params p; Derived d; State s;
+            load_module_params<F_GENSET>(a.c, c, p); derive<F_GENSET>(p, d);
+            s.status = a.c.gen_status[c];
+            in.a_goal = (double)act[2 * j]; in.a_gen = (double)act[2 * j + 1];
+            step_core<F_GENSET>(p, d, s, in, normalized, false, false, oc);
+            a.c.gen_status[c] = s.status;
+            L.provided(oc.genset_production); reward += oc.genset_reward; viol |= oc.violations;
+            if (log) {
+                double *q = log + (int64_t)(kg + LC_GENSET_N * j) * N;
+                q[0] = oc.genset_production; q[N] = oc.genset_co2; q[2 * N] = oc.genset_reward; q[3 * N] = (double)s.status;
+            }
+        }
+    }
+    // BatteryDischargeShaper sums info['battery'][*]['provided_energy'] with a KeyError -> 0.0 fallback for the WHOLE sum
+    // (reward_shaping/base.py:10-16): one battery acting as a sink zeroes it
+    double discharge_sum = 0.0; bool any_sink = false;
+    auto step_batteries = [&]() __attribute__((always_inline)) {
+        for (int j = 0; j < NB; j++) {
+            const int64_t c = (int64_t)j * N + i;
+            Params p; Derived d; State s;
+            load_module_params<F_BATTERY>(a.c, c, p); derive<F_BATTERY>(p, d);
+            s.charge = a.c.charge[c]; s.soc = a.c.soc[c]; s.status = 0u;
+            in.a_bat = (double)act[2 * NG + j];
+            step_core<F_BATTERY>(p, d, s, in, normalized, true, false, oc);
+            a.c.charge[c] = s.charge; a.c.soc[c] = s.soc;
+            // as_source iff the unnormalised request is >= 0 (base_module.py:161-171); a sink logs charge_amount
+            const double x = normalized ? d.bat_lo + d.bat_sp * in.a_bat : in.a_bat;
+            if (x < 0) { L.absorbed(oc.charge_amount); any_sink = true; }
+            else { L.provided(oc.discharge_amount); discharge_sum += oc.discharge_amount; }
+            reward += oc.battery_reward; viol |= oc.violations;
+            if (log) {
+                double *q = log + (int64_t)(kb + LC_BATTERY_N * j) * N;
+                q[0] = oc.discharge_amount; q[N] = oc.charge_amount; q[2 * N] = oc.battery_reward;
+                q[3 * N] = oc.soc_pre; q[4 * N] = oc.charge_pre;
+            }
+        }
     };
-    auto add_grid = [&]() __attribute__((always_inline)) {
-        o.grid_import = oc.grid_import; o.grid_export = oc.grid_export; o.grid_co2 = oc.grid_co2; o.grid_reward = oc.grid_reward;
-        const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;
-        if (x < 0) absb[n_absb++] = oc.grid_export; else prov[n_prov++] = oc.grid_import;
-        reward += oc.grid_reward;
+    auto step_grids = [&]() __attribute__((always_inline)) {
+        for (int j = 0; j < NR; j++) {
+            const int64_t c = (int64_t)j * N + i;
+            Params p; Derived d; State s;
+            load_module_params<F_GRID>(a.c, c, p); derive<F_GRID>(p, d);
+            s.charge = 0.0; s.soc = 0.0; s.status = 0u;
+            const double *g = a.c.grid_ts + (((int64_t)t * NR + j) * 4) * N + i;
+            in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
+            in.a_grid = (double)act[2 * NG + NB + j];
+            step_core<F_GRID>(p, d, s, in, normalized, false, false, oc);
+            const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;
+            if (x < 0) L.absorbed(oc.grid_export); else L.provided(oc.grid_import);
+            reward += oc.grid_reward; viol |= oc.violations;
+            if (log) {
+                double *q = log + (int64_t)(kr + LC_GRID_N * j) * N;
+                q[0] = oc.grid_import; q[N] = oc.grid_export; q[2 * N] = oc.grid_co2; q[3 * N] = oc.grid_reward;
+            }
+        }
     };
     if constexpr ((F & F_GRID_FIRST) != 0) {
-        if constexpr (F & F_GRID) add_grid();
-        if constexpr (F & F_BATTERY) add_battery();
+        if constexpr (F & F_GRID) step_grids();
+        if constexpr (F & F_BATTERY) step_batteries();
     } else {
-        if constexpr (F & F_BATTERY) add_battery();
-        if constexpr (F & F_GRID) add_grid();
+        if constexpr (F & F_BATTERY) step_batteries();
+        if constexpr (F & F_GRID) step_grids();
     }
-    const double provided = np_sum_dev(prov, n_prov), consumed = np_sum_dev(absb, n_absb);      // :277
+    o.discharge_amount = any_sink ? 0.0 : discharge_sum;
+    o.charge_amount = 0.0;
+    const double provided = np_sum_strided(L.prov, L.stride, L.n_prov);      // :277
+    const double consumed = np_sum_strided(L.absb, L.stride, L.n_absb);
     const double difference = provided - consumed;
     o.ctrl_provided = provided - o.fixed_provided; o.ctrl_absorbed = consumed - o.fixed_absorbed;
 
+    const double ll_cost = a.c.loss_load_cost[i], og_cost = a.c.overgeneration_cost[i];
     o.renewable_used = 0.0; o.curtailment = 0.0;
     if (difference > 0) {                                 // :286-299: renewables idle, the excess is overgeneration
-        for (int j = 0; j < n_pv; j++) { o.curtailment += pv[j] - 0.0; prov[n_prov++] = 0.0; reward += 0.0; }
+        for (int j = 0; j < a.n_pv; j++) {
+            o.curtailment += a.c.pv_ts[((int64_t)t * a.n_pv + j) * N + i] - 0.0;
+            L.provided(0.0); reward += 0.0;
+        }
         const double e = -1.0 * (-1.0 * difference);
         o.overgeneration = e; o.loss_load = 0.0;
-        o.unbalanced_reward = -1.0 * (p.og_cost * e);
-        absb[n_absb++] = e;
+        o.unbalanced_reward = -1.0 * (og_cost * e);
+        L.absorbed(e);
     } else {                                              // :301-314: renewables in module order, then loss load
         double need = -difference;
-        for (int j = 0; j < n_pv; j++) {
-            const double amt = (pv[j] < need) ? pv[j] : need;
-            o.renewable_used += amt; o.curtailment += pv[j] - amt;
-            prov[n_prov++] = amt; reward += 0.0;
+        for (int j = 0; j < a.n_pv; j++) {
+            const double pv = a.c.pv_ts[((int64_t)t * a.n_pv + j) * N + i];
+            const double amt = (pv < need) ? pv : need;
+            o.renewable_used += amt; o.curtailment += pv - amt;
+            L.provided(amt); reward += 0.0;
             need -= amt;
         }
         o.loss_load = need; o.overgeneration = 0.0;
-        o.unbalanced_reward = -1.0 * (p.ll_cost * need);
-        prov[n_prov++] = need;
+        o.unbalanced_reward = -1.0 * (ll_cost * need);
+        L.provided(need);
     }
     reward += o.unbalanced_reward;
-    o.overall_provided = np_sum_dev(prov, n_prov); o.overall_absorbed = np_sum_dev(absb, n_absb);   // :316-317
+    o.overall_provided = np_sum_strided(L.prov, L.stride, L.n_prov);         // :316-317
+    o.overall_absorbed = np_sum_strided(L.absb, L.stride, L.n_absb);
     o.reward = reward;
+    o.violations = viol;
+    if (log) {
+        log[0] = o.reward;
+        log[N] = o.fixed_provided;        log[2 * N] = o.fixed_absorbed;
+        log[3 * N] = o.ctrl_provided;     log[4 * N] = o.ctrl_absorbed;
+        log[5 * N] = o.overall_provided;  log[6 * N] = o.overall_absorbed;
+        log[7 * N] = o.load_met;          log[8 * N] = o.renewable_used;
+        log[9 * N] = o.curtailment;       log[10 * N] = o.loss_load;
+        log[11 * N] = o.overgeneration;   log[12 * N] = o.unbalanced_reward;
+        log[(int64_t)(kr + LC_GRID_N * NR) * N] = (double)viol;
+    }
+}
+
+// PriorityListAlgo._populate_action over module instances (priority_list.py:69-116): `list` holds list_len elements
+// (kind, instance, action), kind < 0 = padding.  Every element runs the single-module form of populate_core on the load
+// that remains when it is reached; control [A] = (goal, energy) per genset, batteries, grids.
+template <int F>
+__device__ inline void populate_multi(const KArgs &a, const int32_t *__restrict__ list, int32_t list_len, int64_t i, int32_t t,
+                                      double *__restrict__ control)
+{
+    const int64_t N = a.N;
+    const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
+    const int A = 2 * NG + NB + NR;
+    for (int k = 0; k < A; k++) control[k] = 0.0;
+    double total_load = 0.0;                                           // _get_load: running sum (:157-164)
+    for (int j = 0; j < a.n_load; j++) total_load += -1 * a.c.load_ts[((int64_t)t * a.n_load + j) * N + i];
+    double renewable;                                                  // _get_renewable: np.sum (:166-167)
+    {
+        const double *pv = a.c.pv_ts + ((int64_t)t * a.n_pv) * N + i;
+        renewable = np_sum_strided(pv, (int)N, a.n_pv);
+    }
+    double remaining = total_load - renewable;                         // :74
+    uint32_t seen = 0u;
+    for (int k = 0; k < list_len; k++) {
+        const int kind = list[3 * k], j = list[3 * k + 1], act = list[3 * k + 2];
+        if (kind < 0) continue;
+        const uint32_t bit = 1u << (kind * MGX_MAX_INSTANCES + j);
+        if (seen & bit) continue;                                      // :82-88: a module met again is skipped
+        seen |= bit;
+        const int64_t c = (int64_t)j * N + i;
+        const uint32_t word = (uint32_t)kind | ((uint32_t)act << 2) | 8u;
+        Params p; State s; Inputs in; double q_unused;
+        s.charge = 0.0; s.soc = 0.0; s.status = 0u; in.g_stat = 1.0;
+        double e = 0.0;
+        if (kind == 0) {
+            if constexpr (F & F_GENSET) {
+                load_module_params<F_GENSET>(a.c, c, p); s.status = a.c.gen_status[c];
+                populate_core<F_GENSET>(p, s, word, in, q_unused, remaining, 0.0);
+                control[2 * j] = in.a_goal; control[2 * j + 1] = in.a_gen; e = in.a_gen;
+            }
+        } else if (kind == 1) {
+            if constexpr (F & F_BATTERY) {
+                load_module_params<F_BATTERY>(a.c, c, p); s.charge = a.c.charge[c];
+                populate_core<F_BATTERY>(p, s, word, in, q_unused, remaining, 0.0);
+                control[2 * NG + j] = in.a_bat; e = in.a_bat;
+            }
+        } else {
+            if constexpr (F & F_GRID) {
+                load_module_params<F_GRID>(a.c, c, p);
+                in.g_stat = a.c.grid_ts[(((int64_t)t * NR + j) * 4 + 3) * N + i];
+                populate_core<F_GRID>(p, s, word, in, q_unused, remaining, 0.0);
+                control[2 * NG + NB + j] = in.a_grid; e = in.a_grid;
+            }
+        }
+        remaining -= e;                                                // :105
+    }
 }
 
 }  // namespace mgx

@@ -92,22 +92,8 @@ __global__ __launch_bounds__(BLOCK) void check_kernel(const KArgs a, const void 
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
-    if (a.n_load == 1 && a.n_pv == 1) {
-        if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t, in);
-        else load_inputs<F>(a.c, (const double *)actions, a.N, i, t, in);
-    } else {                                               // several load / renewable modules: the controllable modules' limits
-        constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);   // do not depend on them
-        int k = 0;
-        auto ld = [&](int j) { return a.act_f32 ? (double)((const float *)actions)[i * A + j] : ((const double *)actions)[i * A + j]; };
-        if constexpr (F & F_GENSET) { in.a_goal = ld(k); in.a_gen = ld(k + 1); k += 2; }
-        if constexpr (F & F_BATTERY) { in.a_bat = ld(k); k += 1; }
-        if constexpr (F & F_GRID) {
-            in.a_grid = ld(k);
-            const double *g = a.c.grid_ts + ((int64_t)t * 4) * a.N + i;
-            in.g_pimp = g[0]; in.g_pexp = g[a.N]; in.g_co2 = g[2 * (int64_t)a.N]; in.g_stat = g[3 * (int64_t)a.N];
-        }
-        in.load = 0.0; in.pv = 0.0;
-    }
+    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t, in);
+    else load_inputs<F>(a.c, (const double *)actions, a.N, i, t, in);
     step_core<F>(p, d, s, in, normalized != 0, false, false, o);
     violations[i] = o.violations;
 }
@@ -793,39 +779,37 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
 }
 
 // ------------------------------------------------------------------------------------------------------
-// General path: n_load / n_pv != 1 (series [T, n_load, N] and [T, n_pv, N], bounds [n_load, N] / [n_pv, N]).
-// Straightforward one-lane-per-grid kernels; parity with the reference's multi-module grids, not speed.
+// General path: any number of modules per kind (n_load / n_pv != 1, or several gensets / batteries / grids: columns
+// [n, N] instance-major, load / pv series [T, n, N], grid series [T, n_grid, 4, N]).  One lane per grid; the lists
+// MicrogridStep sums live in LDS (StepLists).  Parity with the reference's multi-module microgrids, not speed.
 // ------------------------------------------------------------------------------------------------------
-template <int F, typename AT>
-__device__ inline void load_controls_multi(const KArgs &a, const AT *__restrict__ actions, int64_t i, int32_t t, Inputs &in)
+constexpr int BLOCK_MULTI = 64;
+
+__device__ __forceinline__ StepLists multi_lists(const KArgs &a, double *lds)
 {
-    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const AT *ap = actions + i * A;
-    int k = 0;
-    if constexpr (F & F_GENSET) { in.a_goal = ap[k]; in.a_gen = ap[k + 1]; k += 2; }
-    if constexpr (F & F_BATTERY) { in.a_bat = ap[k]; k += 1; }
-    if constexpr (F & F_GRID) {
-        in.a_grid = ap[k];
-        const double *g = a.c.grid_ts + ((int64_t)t * 4) * a.N + i;
-        in.g_pimp = g[0]; in.g_pexp = g[a.N]; in.g_co2 = g[2 * (int64_t)a.N]; in.g_stat = g[3 * (int64_t)a.N];
-    }
+    const int cap = multi_list_capacity(a.n_load, a.n_pv, a.n_genset, a.n_battery, a.n_grid);
+    StepLists L;
+    L.stride = BLOCK_MULTI; L.n_prov = 0; L.n_absb = 0;
+    L.prov = lds + threadIdx.x;
+    L.absb = lds + (size_t)cap * BLOCK_MULTI + threadIdx.x;
+    return L;
 }
 
 template <typename OT>
 __device__ inline void observe_series_multi(const double *__restrict__ ts, int64_t row_stride, int32_t T, int32_t t, int32_t H,
-                                            double lo, double hi, OT *__restrict__ obs)
+                                            double lo, double hi, OT *__restrict__ obs, int obs_stride = 1)
 {
     const double fill = (hi + lo) / 2, sp = space_spread(lo, hi);
     for (int h = 0; h <= H; h++) {
         const bool in = t < T && t + h < T;
         const double v = in ? ts[(int64_t)(t + h) * row_stride] : 0.0;
-        obs[h] = (OT)obs_series_value(v, in, h > 0, lo, hi, fill, sp);
+        obs[h * obs_stride] = (OT)obs_series_value(v, in, h > 0, lo, hi, fill, sp);
     }
 }
 
+// flat order: load windows, pv windows, gensets (4 columns each), batteries (2 each), grid windows (4 (1 + H) each)
 template <int F, typename OT>
-__device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, const Params &p, const State &s,
-                                         OT *__restrict__ obs_row)
+__device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, OT *__restrict__ obs_row)
 {
     const int64_t N = a.N;
     const int W = 1 + a.H;
@@ -837,96 +821,129 @@ __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, c
         observe_series_multi(a.c.pv_ts + (int64_t)j * N + i, (int64_t)a.n_pv * N, a.T, t, a.H, a.c.pv_lo[(int64_t)j * N + i],
                              a.c.pv_hi[(int64_t)j * N + i], obs_row + k);
     if constexpr (F & F_GENSET) {
-        const double su = (double)(p.gen_times & 0xff), wd = (double)((p.gen_times >> 16) & 0xff);
-        obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)(s.status & 0xff));
-        obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)((s.status >> 8) & 0xff));
-        obs_row[k++] = (OT)space_norm(0.0, su, (double)((s.status >> 16) & 0xff));
-        obs_row[k++] = (OT)space_norm(0.0, wd, (double)(s.status >> 24));
+        for (int j = 0; j < a.n_genset; j++) {
+            const int64_t c = (int64_t)j * N + i;
+            const uint32_t times = a.c.gen_times[c], st = a.c.gen_status[c];
+            const double su = (double)(times & 0xff), wd = (double)((times >> 16) & 0xff);
+            obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)(st & 0xff));
+            obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)((st >> 8) & 0xff));
+            obs_row[k++] = (OT)space_norm(0.0, su, (double)((st >> 16) & 0xff));
+            obs_row[k++] = (OT)space_norm(0.0, wd, (double)(st >> 24));
+        }
     }
     if constexpr (F & F_BATTERY) {
-        const double min_soc = p.bat_cmin / p.bat_cmax;
-        obs_row[k++] = (OT)space_norm(min_soc, 1.0, s.soc);
-        obs_row[k++] = (OT)space_norm(p.bat_cmin, p.bat_cmax, s.charge);
+        for (int j = 0; j < a.n_battery; j++) {
+            const int64_t c = (int64_t)j * N + i;
+            const double cmin = a.c.bat_min_capacity[c], cmax = a.c.bat_max_capacity[c];
+            obs_row[k++] = (OT)space_norm(cmin / cmax, 1.0, a.c.soc[c]);
+            obs_row[k++] = (OT)space_norm(cmin, cmax, a.c.charge[c]);
+        }
     }
     if constexpr (F & F_GRID) {
-        for (int h = 0; h <= a.H; h++)
+        for (int j = 0; j < a.n_grid; j++, k += 4 * W)
             for (int cc = 0; cc < 4; cc++) {
-                const double lo = a.c.grid_lo[cc * N + i], hi = a.c.grid_hi[cc * N + i];
-                const bool in = t < a.T && t + h < a.T;
-                const double v = in ? a.c.grid_ts[((int64_t)(t + h) * 4 + cc) * N + i] : 0.0;
-                obs_row[k + h * 4 + cc] = (OT)obs_series_value(v, in, h > 0, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
+                const int64_t c = ((int64_t)j * 4 + cc) * N + i;
+                observe_series_multi(a.c.grid_ts + c, (int64_t)a.n_grid * 4 * N, a.T, t, a.H, a.c.grid_lo[c], a.c.grid_hi[c],
+                                     obs_row + k + cc, 4);
             }
     }
 }
 
 template <int F>
-__global__ __launch_bounds__(BLOCK) void step_multi_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
-                                                           int normalized, double *__restrict__ reward,
-                                                           uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                           double *__restrict__ log)
+__global__ __launch_bounds__(BLOCK_MULTI) void step_multi_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
+                                                                 int normalized, double *__restrict__ reward,
+                                                                 uint8_t *__restrict__ done, void *__restrict__ obs,
+                                                                 double *__restrict__ log)
 {
+    extern __shared__ double multi_lds[];
     t = resolve_t(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.g1) return;
-    const int64_t N = a.N;
-    Params p; State s; Inputs in; Outputs o; Derived d;
-    if (a.act_f32) load_controls_multi<F>(a, (const float *)actions, i, t, in);
-    else load_controls_multi<F>(a, (const double *)actions, i, t, in);
-    load_state<F>(a.c, i, true, s);
-    load_params<F>(a.c, i, p);
-    derive<F>(p, d);
-    double load[MGX_MAX_MODULES], pv[MGX_MAX_MODULES];
-    for (int j = 0; j < a.n_load; j++) load[j] = a.c.load_ts[((int64_t)t * a.n_load + j) * N + i];
-    for (int j = 0; j < a.n_pv; j++) pv[j] = a.c.pv_ts[((int64_t)t * a.n_pv + j) * N + i];
-    step_multi_core<F>(p, d, s, in, normalized != 0, load, a.n_load, pv, a.n_pv, o);
-    store_state<F>(a.c, i, s);
-    reward[i] = shaped_reward<F>(a.shaper, o);
-    if (done) done[i] = done_at(a, i, t);
-    if (log) store_log<F>(log + i, N, o, s.status);
-    if (obs) {
-        if (a.obs_f32) observe_row_multi<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
-        else observe_row_multi<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
+    if (i < a.g1) {
+        const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
+        StepLists L = multi_lists(a, multi_lds);
+        Outputs o;
+        if (a.act_f32) step_multi_core<F>(a, (const float *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
+        else step_multi_core<F>(a, (const double *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
+        reward[i] = shaped_reward<F>(a.shaper, o);
+        if (done) done[i] = done_at(a, i, t);
+        if (obs) {
+            if (a.obs_f32) observe_row_multi<F>(a, i, t + 1, (float *)obs + i * a.obs_dim);
+            else observe_row_multi<F>(a, i, t + 1, (double *)obs + i * a.obs_dim);
+        }
     }
     advance_counter_in_kernel(a, 1);
 }
 
 template <int F>
-__global__ __launch_bounds__(BLOCK) void observe_multi_kernel(const KArgs a, int32_t t, void *__restrict__ obs)
+__global__ __launch_bounds__(BLOCK_MULTI) void observe_multi_kernel(const KArgs a, int32_t t, void *__restrict__ obs)
 {
     t = resolve_t_obs(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
     if (i >= a.g1) return;
-    Params p; State s;
-    load_state<F>(a.c, i, true, s);
-    load_params<F>(a.c, i, p);
-    if (a.obs_f32) observe_row_multi<F>(a, i, t, p, s, (float *)obs + i * a.obs_dim);
-    else observe_row_multi<F>(a, i, t, p, s, (double *)obs + i * a.obs_dim);
+    if (a.obs_f32) observe_row_multi<F>(a, i, t, (float *)obs + i * a.obs_dim);
+    else observe_row_multi<F>(a, i, t, (double *)obs + i * a.obs_dim);
 }
 
+// dry run (mgx_check_step) on the general path: the violations of the controllable instances depend on their own
+// state and request only, never on the other modules
 template <int F>
-__global__ __launch_bounds__(BLOCK) void expand_multi_kernel(const KArgs a, const PLWords tab, const int32_t *__restrict__ action_id,
-                                                             int32_t t, double *__restrict__ control)
+__global__ __launch_bounds__(BLOCK_MULTI) void check_multi_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
+                                                                  int normalized, uint32_t *__restrict__ violations)
 {
     t = resolve_t(a, t);
-    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
     if (i >= a.g1) return;
     const int64_t N = a.N;
-    Params p; State s; Inputs in;
-    load_state<F>(a.c, i, false, s);
-    load_params<F>(a.c, i, p);
-    double total_load = 0.0, pv[MGX_MAX_MODULES];                     // _get_load: running sum; _get_renewable: np.sum
-    for (int j = 0; j < a.n_load; j++) total_load += -1 * a.c.load_ts[((int64_t)t * a.n_load + j) * N + i];
-    for (int j = 0; j < a.n_pv; j++) pv[j] = a.c.pv_ts[((int64_t)t * a.n_pv + j) * N + i];
-    in.g_stat = 1.0;
-    if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
-    double q_unused;
-    populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused, total_load, np_sum_dev(pv, a.n_pv));
-    double *c = control + i * A;
-    int k = 0;
-    if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
-    if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
-    if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
+    const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid, A = 2 * NG + NB + NR;
+    auto ld = [&](int j) { return a.act_f32 ? (double)((const float *)actions)[i * A + j] : ((const double *)actions)[i * A + j]; };
+    uint32_t viol = 0u;
+    Inputs in; in.load = 0.0; in.pv = 0.0;
+    Outputs oc;
+    if constexpr (F & F_GENSET)
+        for (int j = 0; j < NG; j++) {
+            Params p; Derived d; State s;
+            load_module_params<F_GENSET>(a.c, (int64_t)j * N + i, p); derive<F_GENSET>(p, d);
+            s.status = a.c.gen_status[(int64_t)j * N + i];
+            in.a_goal = ld(2 * j); in.a_gen = ld(2 * j + 1);
+            step_core<F_GENSET>(p, d, s, in, normalized != 0, false, false, oc);
+            viol |= oc.violations;
+        }
+    if constexpr (F & F_BATTERY)
+        for (int j = 0; j < NB; j++) {
+            Params p; Derived d; State s;
+            load_module_params<F_BATTERY>(a.c, (int64_t)j * N + i, p); derive<F_BATTERY>(p, d);
+            s.charge = a.c.charge[(int64_t)j * N + i]; s.soc = 0.0; s.status = 0u;
+            in.a_bat = ld(2 * NG + j);
+            step_core<F_BATTERY>(p, d, s, in, normalized != 0, false, false, oc);
+            viol |= oc.violations;
+        }
+    if constexpr (F & F_GRID)
+        for (int j = 0; j < NR; j++) {
+            Params p; Derived d; State s;
+            load_module_params<F_GRID>(a.c, (int64_t)j * N + i, p); derive<F_GRID>(p, d);
+            s.charge = 0.0; s.soc = 0.0; s.status = 0u;
+            in.g_pimp = 0.0; in.g_pexp = 0.0; in.g_co2 = 0.0;
+            in.g_stat = a.c.grid_ts[(((int64_t)t * NR + j) * 4 + 3) * N + i];
+            in.a_grid = ld(2 * NG + NB + j);
+            step_core<F_GRID>(p, d, s, in, normalized != 0, false, false, oc);
+            viol |= oc.violations;
+        }
+    violations[i] = viol;
+}
+
+// mgx_expand_lists / mgx_expand_discrete on the general path: lists [n_lists, list_len, 3] in device memory
+template <int F>
+__global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a, const int32_t *__restrict__ lists, int32_t n_lists,
+                                                                   int32_t list_len, const int32_t *__restrict__ action_id,
+                                                                   int32_t t, double *__restrict__ control)
+{
+    t = resolve_t(a, t);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
+    if (i >= a.g1) return;
+    const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
+    int32_t id = action_id[i];
+    id = (id >= 0 && id < n_lists) ? id : 0;              // ids outside [0, n) fall back to list 0 (the reference raises)
+    populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t, control + i * A);
 }
 
 // one wave that idles for `ticks` of the 100 MHz real-time counter: mgx_fork staggers the shard streams with it
@@ -1125,6 +1142,8 @@ __global__ __launch_bounds__(BLOCK) void synthesize_series_kernel(const mgx_synt
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <vector>
 
 using namespace mgx;
 
@@ -1134,7 +1153,11 @@ struct mgx_handle {
     KArgs k;
     mgx_layout layout;
     int32_t window_lo, window_hi;   // episode window given at create: trajectories must stay inside it
-    bool multi;             // n_load != 1 or n_pv != 1: general (slow) kernels
+    bool multi;             // n_load != 1, n_pv != 1 or several gensets / batteries / grids: general (slow) kernels
+    size_t multi_lds;       // LDS bytes of a general-kernel workgroup (the MicrogridStep lists)
+    std::vector<std::string> log_names;
+    int32_t *d_lists;       // general path: device copy of the priority lists handed to mgx_expand_discrete as a host table
+    std::vector<int32_t> lists_uploaded;
     int32_t *d_counter;     // device step counter + overrun flag (used when k.t_dev != NULL)
     int32_t n_cu;           // compute units of the device (workgroup balancing of the fused kernels)
     int32_t flags;          // F
@@ -1290,11 +1313,13 @@ static void launch_obs_rows(const KArgs &k, const WindowPlan &plan, int32_t t, v
     }
 }
 
+static inline unsigned multi_blocks(int64_t n) { return (unsigned)((n + BLOCK_MULTI - 1) / BLOCK_MULTI); }
+
 // observation of the state at series index t into obs [N, D]
 static int launch_observe(const mgx_handle *h, int32_t t, void *obs, hipStream_t st)
 {
     if (h->multi) {
-        MGX_DISPATCH_F(h->flags, (observe_multi_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, t, obs)));
+        MGX_DISPATCH_F(h->flags, (observe_multi_kernel<F><<<multi_blocks(h->k.N), BLOCK_MULTI, 0, st>>>(h->k, t, obs)));
         return MGX_OK;
     }
     if (h->k.H == 0 || h->k.obs_state_only) {
@@ -1337,6 +1362,14 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     if (L->n_load < 0 || L->n_pv < 0 || L->n_load > MGX_MAX_MODULES || L->n_pv > MGX_MAX_MODULES)
         return fail(MGX_ERR_UNSUPPORTED, "mgx_create: at most %d load and %d renewable modules per grid (got n_load=%d "
                                          "n_pv=%d)", MGX_MAX_MODULES, MGX_MAX_MODULES, L->n_load, L->n_pv);
+    const int32_t n_genset = L->n_genset > 0 ? L->n_genset : L->has_genset, n_battery = L->n_battery > 0 ? L->n_battery : L->has_battery,
+                  n_grid = L->n_grid > 0 ? L->n_grid : L->has_grid;
+    if (L->n_genset < 0 || L->n_battery < 0 || L->n_grid < 0 || n_genset > MGX_MAX_INSTANCES || n_battery > MGX_MAX_INSTANCES ||
+        n_grid > MGX_MAX_INSTANCES)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_create: at most %d gensets, batteries and grids per microgrid (got %d, %d, %d)",
+                    MGX_MAX_INSTANCES, L->n_genset, L->n_battery, L->n_grid);
+    if ((n_genset > 0) != (L->has_genset != 0) || (n_battery > 0) != (L->has_battery != 0) || (n_grid > 0) != (L->has_grid != 0))
+        return fail(MGX_ERR_INVALID, "mgx_create: n_genset / n_battery / n_grid contradict has_genset / has_battery / has_grid");
     const int32_t final_step = L->final_step <= 0 ? L->n_steps : L->final_step;   // base_timeseries_module.py:321-326
     if (final_step > L->n_steps) return fail(MGX_ERR_INVALID, "mgx_create: final_step %d > n_steps %d", final_step, L->n_steps);
     if (L->initial_step < 0 || L->initial_step >= final_step)
@@ -1368,12 +1401,25 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->k.N = L->n_grids; h->k.T = L->n_steps; h->k.H = L->horizon; h->k.final_step = final_step;
     h->flags = (L->has_genset ? F_GENSET : 0) | (L->has_battery ? F_BATTERY : 0) | (L->has_grid ? F_GRID : 0) |
                ((L->grid_before_battery && L->has_battery && L->has_grid) ? F_GRID_FIRST : 0);
-    h->action_dim = 2 * L->has_genset + L->has_battery + L->has_grid;
+    h->layout.n_genset = n_genset; h->layout.n_battery = n_battery; h->layout.n_grid = n_grid;
+    h->action_dim = 2 * n_genset + n_battery + n_grid;
     const int w = 1 + L->horizon;
-    h->k.obs_dim = (L->n_load + L->n_pv) * w + 4 * L->has_genset + 2 * L->has_battery + 4 * w * L->has_grid;
+    h->k.obs_dim = (L->n_load + L->n_pv) * w + 4 * n_genset + 2 * n_battery + 4 * w * n_grid;
     h->k.n_load = L->n_load; h->k.n_pv = L->n_pv;
-    h->multi = (L->n_load != 1 || L->n_pv != 1);
-    h->k.log_dim = LC_COMMON_END + LC_GENSET_N * L->has_genset + LC_BATTERY_N * L->has_battery + LC_GRID_N * L->has_grid + 1;
+    h->k.n_genset = n_genset; h->k.n_battery = n_battery; h->k.n_grid = n_grid;
+    h->multi = (L->n_load != 1 || L->n_pv != 1 || n_genset > 1 || n_battery > 1 || n_grid > 1);
+    h->multi_lds = 2 * (size_t)multi_list_capacity(L->n_load, L->n_pv, n_genset, n_battery, n_grid) * BLOCK_MULTI * sizeof(double);
+    h->k.log_dim = LC_COMMON_END + LC_GENSET_N * n_genset + LC_BATTERY_N * n_battery + LC_GRID_N * n_grid + 1;
+    for (int c = 0; c < LC_COMMON_END; c++) h->log_names.push_back(kCommonNames[c]);
+    auto add_block = [&](const char *const *names, int n_cols, int n_inst) {       // instance 0: plain names, j > 0: name[j]
+        for (int j = 0; j < n_inst; j++)
+            for (int c = 0; c < n_cols; c++)
+                h->log_names.push_back(j == 0 ? std::string(names[c]) : std::string(names[c]) + "[" + std::to_string(j) + "]");
+    };
+    add_block(kGensetNames, LC_GENSET_N, n_genset); add_block(kBatteryNames, LC_BATTERY_N, n_battery);
+    add_block(kGridNames, LC_GRID_N, n_grid);
+    h->log_names.push_back("violations");
+    h->d_lists = nullptr;
     h->t = L->initial_step;
     h->k.shaper = MGX_SHAPER_NONE;
     h->k.noise_seed = 0; h->k.noise_increase = 0; h->k.obs_f32 = 0; h->k.obs_state_only = 0; h->k.act_f32 = 0;
@@ -1412,6 +1458,7 @@ void mgx_destroy(mgx_handle *h)
     if (h->prefetch_stream) { (void)hipStreamSynchronize(h->prefetch_stream); (void)hipStreamDestroy(h->prefetch_stream); }
     if (h->d_kargs) (void)hipFree(h->d_kargs);
     if (h->d_table) (void)hipFree(h->d_table);
+    if (h->d_lists) (void)hipFree(h->d_lists);
     if (h->prefetch_gate) (void)hipEventDestroy(h->prefetch_gate);
     if (h->prefetch_done) (void)hipEventDestroy(h->prefetch_done);
     if (h->scratch) (void)hipFree(h->scratch);
@@ -1463,12 +1510,7 @@ int mgx_use_device_counter(mgx_handle *h, int enable, mgx_stream stream)
 const char *mgx_log_name(const mgx_handle *h, int32_t col)
 {
     if (!h || col < 0 || col >= h->k.log_dim) return nullptr;
-    if (col < LC_COMMON_END) return kCommonNames[col];
-    col -= LC_COMMON_END;
-    if (h->layout.has_genset) { if (col < LC_GENSET_N) return kGensetNames[col]; col -= LC_GENSET_N; }
-    if (h->layout.has_battery) { if (col < LC_BATTERY_N) return kBatteryNames[col]; col -= LC_BATTERY_N; }
-    if (h->layout.has_grid) { if (col < LC_GRID_N) return kGridNames[col]; col -= LC_GRID_N; }
-    return col == 0 ? "violations" : nullptr;
+    return h->log_names[col].c_str();
 }
 
 static int need_obs_bounds(const mgx_handle *h, const char *who)
@@ -1519,7 +1561,7 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (!h || !ring) return fail(MGX_ERR_INVALID, "%s: NULL argument", who);
     if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "%s: K = %d outside [1, 4096]", who, K);
     if (ahead < 0) return fail(MGX_ERR_INVALID, "%s: ahead = %d is negative", who, ahead);
-    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "%s: needs exactly one load and one renewable module per grid", who);
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "%s: needs exactly one module of every kind per grid", who);
     if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
         return fail(MGX_ERR_UNSUPPORTED, "%s: forecast noise depends on (step, horizon index), windows cannot be shared", who);
     if (int rc = need_obs_bounds(h, who)) return rc;
@@ -1709,7 +1751,7 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
 {
     g_err[0] = 0;
     if (!h || !start || !load_w || !pv_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows: NULL argument");
-    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: needs exactly one load and one renewable module per grid");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: needs exactly one module of every kind per grid");
     if (h->layout.has_grid && !grid_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows: grid_w is NULL but the layout has a GridModule");
     if (length && !final_rel) return fail(MGX_ERR_INVALID, "mgx_reset_windows: per-grid lengths need the final_rel buffer");
     if (h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: not offered in device-counter mode");
@@ -1817,8 +1859,8 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
 {
     if (h->multi) {
         for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
-            MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, actions, t_arg(h), normalized,
-                                                                                                 reward, done, obs, log)));
+            MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
+                                          k, actions, t_arg(h), normalized, reward, done, obs, log)));
         });
         hipError_t em = hipGetLastError();
         if (em != hipSuccess) return hip_fail(em, "step_multi_kernel launch");
@@ -1868,7 +1910,11 @@ int mgx_check_step(mgx_handle *h, const void *actions, int normalized, uint32_t 
     if (!dev_counter(h) && (h->t < 0 || h->t >= step_limit(h)))
         return fail(MGX_ERR_RANGE, "mgx_check_step: step %d is outside the time series (length %d)", h->t, step_limit(h));
     for_each_shard(h, (hipStream_t)stream, [&](const KArgs &k, hipStream_t s) {
-        MGX_DISPATCH_F(h->flags, (check_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, actions, t_arg(h), normalized, violations)));
+        if (h->multi) {
+            MGX_DISPATCH_F(h->flags, (check_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, 0, s>>>(k, actions, t_arg(h), normalized, violations)));
+        } else {
+            MGX_DISPATCH_F(h->flags, (check_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, actions, t_arg(h), normalized, violations)));
+        }
     });
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "check_kernel launch");
@@ -1897,7 +1943,7 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
     g_err[0] = 0;
     if (!h || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_step_k: NULL argument");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_step_k: K must be positive");
-    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: fused steps need exactly one load and one renewable module "
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: fused steps need exactly one module of every kind "
                                                     "per grid; use mgx_step");
     if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
         return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, step_limit(h));
@@ -1947,6 +1993,17 @@ static int encode_table(const mgx_handle *h, const int32_t *table, int32_t n_act
     return MGX_OK;
 }
 
+static int launch_expand_lists(mgx_handle *h, const int32_t *action_id, const int32_t *d_lists, int32_t n_lists, int32_t list_len,
+                               double *control, hipStream_t st)
+{
+    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+        MGX_DISPATCH_F(h->flags, (expand_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, 0, s>>>(k, d_lists, n_lists, list_len,
+                                                                                                       action_id, t_arg(h), control)));
+    });
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "expand_multi_kernel launch");
+}
+
 int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions,
                         double *control, mgx_stream stream)
 {
@@ -1957,15 +2014,44 @@ int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_expand_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
-        if (h->multi) {
-            MGX_DISPATCH_F(h->flags, (expand_multi_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control)));
-        } else {
-            MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control)));
+    if (h->multi) {                                       // general path: the table as device lists of (kind, instance 0, action)
+        if (h->layout.n_genset > 1 || h->layout.n_battery > 1 || h->layout.n_grid > 1)
+            return fail(MGX_ERR_UNSUPPORTED, "mgx_expand_discrete: the layout has several gensets / batteries / grids, its priority "
+                                             "lists name module instances: use mgx_expand_lists");
+        std::vector<int32_t> lists((size_t)n_actions * 9);
+        for (int i = 0; i < n_actions * 3; i++) {
+            lists[3 * i] = table[2 * i]; lists[3 * i + 1] = 0; lists[3 * i + 2] = table[2 * i + 1];
         }
+        if (lists != h->lists_uploaded) {
+            DeviceGuard on_device(h->device);
+            hipError_t e = hipSuccess;
+            if (!h->d_lists) e = hipMalloc((void **)&h->d_lists, 12 * 9 * sizeof(int32_t));
+            // the previous table may still be read by a launch in flight on another stream: settle before overwriting
+            if (e == hipSuccess && !h->lists_uploaded.empty()) e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpyAsync(h->d_lists, lists.data(), lists.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);     // `lists` is a host temporary
+            if (e != hipSuccess) return hip_fail(e, "mgx_expand_discrete: uploading the priority lists");
+            h->lists_uploaded = lists;
+        }
+        return launch_expand_lists(h, action_id, h->d_lists, n_actions, 3, control, st);
+    }
+    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+        MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control)));
     });
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "expand_kernel launch");
+}
+
+int mgx_expand_lists(mgx_handle *h, const int32_t *action_id, const int32_t *lists, int32_t n_lists, int32_t list_len,
+                     double *control, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !action_id || !lists || !control) return fail(MGX_ERR_INVALID, "mgx_expand_lists: NULL argument");
+    if (n_lists <= 0 || list_len <= 0 || list_len > 3 * MGX_MAX_INSTANCES)
+        return fail(MGX_ERR_INVALID, "mgx_expand_lists: need n_lists > 0 and list_len in [1, %d]", 3 * MGX_MAX_INSTANCES);
+    if (!dev_counter(h) && (h->t < 0 || h->t >= step_limit(h)))
+        return fail(MGX_ERR_RANGE, "mgx_expand_lists: step %d is outside the time series (length %d)", h->t, step_limit(h));
+    return launch_expand_lists(h, action_id, lists, n_lists, list_len, control, (hipStream_t)stream);
 }
 
 int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions, double *control,
@@ -1973,8 +2059,8 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
 {
     g_err[0] = 0;
     if (!h || !action_id || !table || !reward) return fail(MGX_ERR_INVALID, "mgx_step_discrete: NULL argument");
-    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_discrete: needs exactly one load and one renewable module per "
-                                                    "grid; use mgx_expand_discrete + mgx_step");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_discrete: needs exactly one module of every kind per "
+                                                    "grid; use mgx_expand_discrete / mgx_expand_lists + mgx_step");
     if (int rc = check_step_args(h, action_id, reward, obs, 1, "mgx_step_discrete")) return rc;
     PLWords tab;
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_step_discrete")) return rc;
@@ -1998,8 +2084,8 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     g_err[0] = 0;
     if (!h || !action_id || !table) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: NULL argument");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: K must be positive");
-    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: needs exactly one load and one renewable module "
-                                                    "per grid; use mgx_expand_discrete + mgx_step");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: needs exactly one module of every kind "
+                                                    "per grid; use mgx_expand_discrete / mgx_expand_lists + mgx_step");
     if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
         return fail(MGX_ERR_RANGE, "mgx_rollout_discrete: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, step_limit(h));
     PLWords tab;

@@ -381,6 +381,19 @@ class StepEngine:
         self._call(self._lib.mgx_expand_discrete, _ptr(action_id), tptr, n_lists, _ptr(control))
         return control
 
+    def expand_lists(self, action_id, lists, out=None):
+        """priority-list ids [N] (int32) -> unnormalised control [N, A] for lists over module instances
+        (``mgx_expand_lists``): ``lists`` int32 device tensor [n_lists, list_len, 3] of (kind, instance, action)."""
+        if action_id.dtype != torch.int32 or tuple(action_id.shape) != (self.N,) or action_id.device != self.device:
+            raise ValueError(f"action_id must be an int32 tensor of shape ({self.N},) on {self.device}")
+        if lists.dtype != torch.int32 or lists.dim() != 3 or lists.shape[2] != 3 or lists.device != self.device \
+                or not lists.is_contiguous():
+            raise ValueError(f"lists must be a contiguous int32 tensor [n_lists, list_len, 3] on {self.device}")
+        control = out if out is not None else self._empty(self.N, self.action_dim)
+        self._call(self._lib.mgx_expand_lists, _ptr(action_id), _ptr(lists), int(lists.shape[0]), int(lists.shape[1]),
+                   _ptr(control))
+        return control
+
     def metrics(self, values, out=None):
         """Column sums over the grids: values [M, N] -> [M] (deterministic LDS + wavefront-shuffle reduction)."""
         if values.dim() == 1:

@@ -21,9 +21,9 @@ Differences that are deliberate:
 import numpy as np
 import torch
 
-from .batch import MicrogridBatch, unpack_status
+from .batch import module_list, MicrogridBatch, unpack_status
 from .engine import StepEngine
-from .priority_list import MODULE_NAMES, get_priority_lists, table_array
+from .priority_list import MODULE_NAMES, get_instance_priority_lists, get_priority_lists, lists_array, table_array
 from .spaces import Box, Discrete
 from .trajectory import check_trajectory_output, shaper_kind
 
@@ -62,7 +62,7 @@ class BatchedMicrogridEnv:
             esz = 4 if obs_dtype == torch.float32 else 8
             while obs_prefetch > 4 and 3 * obs_prefetch * L.n_grids * L.obs_dim * esz > (16 << 30):
                 obs_prefetch //= 2
-        self._prefetch_ok = bool(observations and L.horizon > 0 and L.n_load == 1 and L.n_pv == 1 and not noisy)
+        self._prefetch_ok = bool(observations and L.horizon > 0 and not L.multi and not noisy)
         self._obs_dtype = obs_dtype
         self.obs_prefetch = int(obs_prefetch) if (obs_prefetch and int(obs_prefetch) > 1 and self._prefetch_ok) else 0
         # Three rings of K blocks: while the steps walk ring r, the windows of ring r + 1 (the NEXT K counter values) are
@@ -306,6 +306,13 @@ class BatchedMicrogridEnv:
         def as_col(v):
             v = torch.as_tensor(v, dtype=torch.float64, device=dev)
             return v.expand(self.n_grids) if v.dim() == 0 else v
+        L = self.layout
+        if L.n_genset > 1 or L.n_battery > 1 or L.n_grid > 1:      # one entry per module instance, as Microgrid.run takes them
+            for j in range(L.n_genset):
+                cols += [as_col(control["genset"][j][0]), as_col(control["genset"][j][1])]
+            for name, n in (("battery", L.n_battery), ("grid", L.n_grid)):
+                cols += [as_col(control[name][j]) for j in range(n)]
+            return torch.stack(cols, dim=1).contiguous()
         if self.layout.has_genset:
             g = control["genset"][0] if isinstance(control["genset"], (list, tuple)) and len(control["genset"]) == 1 \
                 else control["genset"]
@@ -327,10 +334,11 @@ class BatchedMicrogridEnv:
             return {}
         stack = torch.stack(self._log_rows)                     # [steps, L, N]
         out = {name: stack[:, j] for j, name in enumerate(self.engine.log_names)}
-        if "genset_status" in out:
-            st = unpack_status(out.pop("genset_status").cpu().numpy())
+        for q in range(self.layout.n_genset):
+            sfx = "" if q == 0 else f"[{q}]"
+            st = unpack_status(out.pop("genset_status" + sfx).cpu().numpy())
             for j, name in enumerate(("current_status", "goal_status", "steps_until_up", "steps_until_down")):
-                out["genset_" + name] = st[..., j]
+                out["genset_" + name + sfx] = st[..., j]
         return {k: (v.cpu().numpy() if as_numpy and torch.is_tensor(v) else v) for k, v in out.items()}
 
     def get_log_frame(self, grid=0):
@@ -350,21 +358,24 @@ class BatchedMicrogridEnv:
                 ("unbalanced_energy", 0, "reward"): col["unbalanced_reward"],
                 ("unbalanced_energy", 0, "loss_load"): col["loss_load"],
                 ("unbalanced_energy", 0, "overgeneration"): col["overgeneration"]}
-        if self.layout.has_genset:
-            data.update({("genset", 0, "reward"): col["genset_reward"],
-                         ("genset", 0, "co2_production"): col["genset_co2_production"],
-                         ("genset", 0, "genset_production"): col["genset_production"]})
+        for q in range(self.layout.n_genset):
+            sfx = "" if q == 0 else f"[{q}]"
+            data.update({("genset", q, "reward"): col["genset_reward" + sfx],
+                         ("genset", q, "co2_production"): col["genset_co2_production" + sfx],
+                         ("genset", q, "genset_production"): col["genset_production" + sfx]})
             for name in ("current_status", "goal_status", "steps_until_up", "steps_until_down"):
-                data[("genset", 0, name)] = col["genset_" + name]
-        if self.layout.has_battery:
-            data.update({("battery", 0, "reward"): col["battery_reward"],
-                         ("battery", 0, "discharge_amount"): col["discharge_amount"],
-                         ("battery", 0, "charge_amount"): col["charge_amount"],
-                         ("battery", 0, "soc"): col["soc_pre"], ("battery", 0, "current_charge"): col["charge_pre"]})
-        if self.layout.has_grid:
-            data.update({("grid", 0, "reward"): col["grid_reward"],
-                         ("grid", 0, "co2_production"): col["grid_co2_production"],
-                         ("grid", 0, "grid_import"): col["grid_import"], ("grid", 0, "grid_export"): col["grid_export"]})
+                data[("genset", q, name)] = col["genset_" + name + sfx]
+        for q in range(self.layout.n_battery):
+            sfx = "" if q == 0 else f"[{q}]"
+            data.update({("battery", q, "reward"): col["battery_reward" + sfx],
+                         ("battery", q, "discharge_amount"): col["discharge_amount" + sfx],
+                         ("battery", q, "charge_amount"): col["charge_amount" + sfx],
+                         ("battery", q, "soc"): col["soc_pre" + sfx], ("battery", q, "current_charge"): col["charge_pre" + sfx]})
+        for q in range(self.layout.n_grid):
+            sfx = "" if q == 0 else f"[{q}]"
+            data.update({("grid", q, "reward"): col["grid_reward" + sfx],
+                         ("grid", q, "co2_production"): col["grid_co2_production" + sfx],
+                         ("grid", q, "grid_import"): col["grid_import" + sfx], ("grid", q, "grid_export"): col["grid_export" + sfx]})
         data.update({("balance", 0, "reward"): col["reward"], ("balance", 0, "shaped_reward"): shaped})
         for a in ("overall", "controllable", "fixed"):
             data[("balance", 0, f"{a}_provided_to_microgrid")] = col[f"{a}_provided"]
@@ -398,17 +409,26 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
                          trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
                          obs_dtype=obs_dtype, obs_prefetch=obs_prefetch)
         L = self.layout
-        redundant = False
+        redundant = []                       # genset instances whose "off" element is redundant (running_min_production == 0)
         if remove_redundant_gensets and L.has_genset:
-            rmin = batch.cols["gen_running_min"]
-            n_zero = int((rmin == 0).sum().item())
-            if 0 < n_zero < L.n_grids:
-                raise ValueError("remove_redundant_gensets: the batch mixes gensets with running_min_production == 0 "
-                                 "and > 0, which have different action spaces in the reference "
-                                 "(priority_list.py:53-67); bucket them or pass remove_redundant_gensets=False")
-            redundant = n_zero == L.n_grids
-        self.actions_list = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, redundant, L.grid_before_battery)
-        self._table = table_array(self.actions_list)
+            rmin = batch.cols["gen_running_min"].reshape(L.n_genset, L.n_grids)
+            for j in range(L.n_genset):
+                n_zero = int((rmin[j] == 0).sum().item())
+                if 0 < n_zero < L.n_grids:
+                    raise ValueError("remove_redundant_gensets: the batch mixes gensets with running_min_production == 0 "
+                                     "and > 0, which have different action spaces in the reference "
+                                     "(priority_list.py:53-67); bucket them or pass remove_redundant_gensets=False")
+                if n_zero == L.n_grids:
+                    redundant.append(j)
+        # several gensets / batteries / grids: priority lists over module instances, (kind, instance, action) elements
+        self._instances = L.n_genset > 1 or L.n_battery > 1 or L.n_grid > 1
+        if self._instances:
+            self.actions_list = get_instance_priority_lists(L.n_genset, L.n_battery, L.n_grid, redundant, L.grid_before_battery)
+            self._table = None
+            self._lists = torch.as_tensor(lists_array(self.actions_list), device=batch.device).contiguous()
+        else:
+            self.actions_list = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, bool(redundant), L.grid_before_battery)
+            self._table = table_array(self.actions_list)
         self.action_space = Discrete(len(self.actions_list))
 
     def get_action(self, action_id):
@@ -416,11 +436,13 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
         if not torch.is_tensor(action_id):
             action_id = torch.as_tensor(np.asarray(action_id), device=self.batch.device)
         action_id = action_id.to(device=self.batch.device, dtype=torch.int32).contiguous()
+        if self._instances:
+            return self.engine.expand_lists(action_id, self._lists)
         return self.engine.expand_discrete(action_id, self._table)
 
     def step(self, action_id):
-        """One fused launch (expand + step); grids with several load / pv modules go through expand + step."""
-        if self.layout.n_load != 1 or self.layout.n_pv != 1:
+        """One fused launch (expand + step); grids with several modules of a kind go through expand + step."""
+        if self.layout.multi:
             return super().step(self.get_action(action_id), normalized=False)
         if not (torch.is_tensor(action_id) and action_id.dtype == torch.int32 and action_id.is_contiguous()
                 and action_id.device == self.batch.device):
@@ -477,12 +499,17 @@ class _SingleMixin:
             raise TypeError("microgrid must be a parameter dict or an N = 1 env of this module")
         params = dict(microgrid._params)
         c = microgrid.batch.cols
-        if microgrid.layout.has_battery:
-            params["battery"] = dict(params["battery"], charge=float(c["charge"][0]), soc=float(c["soc"][0]))
-            params["battery"].pop("init_soc", None); params["battery"].pop("init_charge", None)
-        if microgrid.layout.has_genset:
-            st = unpack_status(c["gen_status"].cpu().numpy().view(np.uint32))[0]
-            params["genset"] = dict(params["genset"], status=[int(v) for v in st])
+        L = microgrid.layout
+        if L.has_battery:
+            ch, soc = c["charge"].reshape(L.n_battery, -1)[:, 0].tolist(), c["soc"].reshape(L.n_battery, -1)[:, 0].tolist()
+            bats = [dict(b, charge=float(ch[j]), soc=float(soc[j])) for j, b in enumerate(module_list(params["battery"]))]
+            for b in bats:
+                b.pop("init_soc", None); b.pop("init_charge", None)
+            params["battery"] = bats if isinstance(params["battery"], (list, tuple)) else bats[0]
+        if L.has_genset:
+            st = unpack_status(c["gen_status"].cpu().numpy().view(np.uint32).reshape(L.n_genset, -1)[:, 0])
+            gens = [dict(q, status=[int(v) for v in st[j]]) for j, q in enumerate(module_list(params["genset"]))]
+            params["genset"] = gens if isinstance(params["genset"], (list, tuple)) else gens[0]
         kwargs = dict(kwargs)
         kwargs.setdefault("reward_shaping_func", microgrid.reward_shaping_func)
         kwargs.setdefault("trajectory_func", microgrid.trajectory_func)
@@ -504,7 +531,7 @@ class _SingleMixin:
 
     def _nested(self, obs_row):
         """flat row -> {'load': [arr], 'pv': [arr], 'genset': [arr], 'battery': [arr], 'grid': [arr]}."""
-        return {name: [obs_row[sl].copy()] for name, sl in self.layout.obs_slices().items()}
+        return {name: [obs_row[sl].copy() for sl in sls] for name, sls in self.layout.obs_instances().items()}
 
     def _obs_out(self, obs):
         row = obs[0].cpu().numpy()
@@ -560,13 +587,13 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
         if action not in self.action_space:
             raise ValueError(f" Action {action} not in action space {self.action_space}")
         c = self.get_action(np.array([action]))[0].cpu().numpy()
-        out, k = {}, 0
-        if self.layout.has_genset:
-            out["genset"] = [np.array([c[k], c[k + 1]])]; k += 2
-        if self.layout.has_battery:
-            out["battery"] = [float(c[k])]; k += 1
-        if self.layout.has_grid:
-            out["grid"] = [float(c[k])]; k += 1
+        out, k, L = {}, 0, self.layout
+        if L.has_genset:
+            out["genset"] = [np.array([c[k + 2 * j], c[k + 2 * j + 1]]) for j in range(L.n_genset)]; k += 2 * L.n_genset
+        if L.has_battery:
+            out["battery"] = [float(c[k + j]) for j in range(L.n_battery)]; k += L.n_battery
+        if L.has_grid:
+            out["grid"] = [float(c[k + j]) for j in range(L.n_grid)]; k += L.n_grid
         return out
 
     def step(self, action):
@@ -580,4 +607,6 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
         return self.action_space.sample()
 
     def priority_list_names(self, action):
+        if self._instances:
+            return [((MODULE_NAMES[m], j), a) for m, j, a in self.actions_list[action]]
         return [(MODULE_NAMES[m], a) for m, a in self.actions_list[action]]

@@ -15,7 +15,7 @@ from .scenario import bucket_by_layout
 
 
 def L_multi(layout):
-    return layout.n_load != 1 or layout.n_pv != 1
+    return layout.multi
 
 
 class BucketedFleet:
@@ -263,8 +263,8 @@ class PerGridWindowEnv:
 
     def __init__(self, full_batch, trajectory_length=None, discrete=False, generator=None, **env_kwargs):
         L = full_batch.layout
-        if L.n_load != 1 or L.n_pv != 1:
-            raise NotImplementedError("per-grid windows need one load and one renewable module per grid")
+        if L.multi:
+            raise NotImplementedError("per-grid windows need one module of every kind per grid")
         self.full = full_batch
         self.length = None if trajectory_length is None else int(trajectory_length)
         if self.length is not None and L.final_step - L.initial_step < self.length:

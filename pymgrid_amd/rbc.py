@@ -7,7 +7,7 @@ the loop and no action stream in HBM (``mgx_rollout_discrete`` with a constant i
 import numpy as np
 import torch
 
-from .priority_list import BATTERY, GENSET, GRID, get_priority_lists, table_array
+from .priority_list import BATTERY, GENSET, GRID, get_instance_priority_lists, get_priority_lists, lists_array, table_array
 
 
 def marginal_costs(cols, layout, t):
@@ -59,6 +59,47 @@ def default_priority_ids(batch, actions_list, remove_redundant_gensets=True, t=N
     return ids
 
 
+def instance_marginal_costs(cols, layout, t):
+    """(kind, instance) -> [N] marginal cost for layouts with several gensets / batteries / grids (columns [n, N])."""
+    N, out = layout.n_grids, {}
+
+    def rows(name, n):
+        return np.asarray(cols[name].cpu(), dtype=np.float64).reshape(n, N)
+    if layout.has_genset:
+        co2 = rows("gen_co2_per_unit", layout.n_genset) * 1.0
+        cost = rows("gen_cost", layout.n_genset) * 1.0 + rows("gen_cost_per_unit_co2", layout.n_genset) * co2
+        for j in range(layout.n_genset):
+            out[(GENSET, j)] = cost[j]
+    if layout.has_battery:
+        c = rows("bat_cost_cycle", layout.n_battery)
+        for j in range(layout.n_battery):
+            out[(BATTERY, j)] = c[j]
+    if layout.has_grid:
+        price = np.asarray(cols["grid_ts"][t].cpu(), dtype=np.float64).reshape(layout.n_grid, 4, N)
+        for j in range(layout.n_grid):
+            out[(GRID, j)] = price[j, 0]
+    return out
+
+
+def default_instance_priority_ids(batch, actions_list, t=None):
+    """Per-grid index (int32 [N]) into ``actions_list`` (lists of (kind, instance, action)) of ``sorted(priority_lists[0])``."""
+    L = batch.layout
+    t = L.initial_step if t is None else t
+    first = actions_list[0]
+    costs = instance_marginal_costs(batch.cols, L, t)
+    cost = np.stack([costs[(k, j)] for k, j, _ in first], axis=1)          # [N, n_el]
+    action = np.array([a for _, _, a in first])
+    order = np.argsort(-action, kind="stable")
+    order = np.broadcast_to(order, (L.n_grids, len(first))).copy()
+    key = np.take_along_axis(cost, order, axis=1)
+    order = np.take_along_axis(order, np.argsort(key, axis=1, kind="stable"), axis=1)
+    index = {pl: j for j, pl in enumerate(actions_list)}
+    ids = np.empty(L.n_grids, dtype=np.int32)
+    for code in np.unique(order, axis=0):
+        ids[(order == code).all(axis=1)] = index[tuple(first[j] for j in code)]
+    return ids
+
+
 class RuleBasedControl:
     """``RuleBasedControl(microgrid).run()`` for a batch.
 
@@ -73,6 +114,31 @@ class RuleBasedControl:
             raise TypeError("env must be a (Discrete)BatchedMicrogridEnv")
         self.env, self.engine, self.batch, self.layout = env, env.engine, env.batch, env.layout
         L = self.layout
+        self._instances = L.n_genset > 1 or L.n_battery > 1 or L.n_grid > 1
+        if self._instances:                  # priority lists over module instances: (kind, instance, action) elements
+            redundant = []
+            if remove_redundant_gensets and L.has_genset:
+                rmin = self.batch.cols["gen_running_min"].reshape(L.n_genset, L.n_grids)
+                for j in range(L.n_genset):
+                    zero = rmin[j] == 0
+                    if bool(zero.any()) and not bool(zero.all()):
+                        raise ValueError("remove_redundant_gensets: mixed running_min_production == 0 / > 0 in one batch")
+                    if bool(zero.all()):
+                        redundant.append(j)
+            self.actions_list = get_instance_priority_lists(L.n_genset, L.n_battery, L.n_grid, redundant, L.grid_before_battery)
+            self._table = None
+            self._lists = torch.as_tensor(lists_array(self.actions_list), device=self.batch.device).contiguous()
+            if priority_list is None:
+                ids = default_instance_priority_ids(self.batch, self.actions_list)
+            else:
+                pl = tuple((int(k), int(j), int(a)) for k, j, a in priority_list)
+                if pl not in self.actions_list:
+                    raise ValueError("Invalid priority list. Use RuleBasedControl.get_priority_lists to view all "
+                                     "valid priority lists.")
+                ids = np.full(L.n_grids, self.actions_list.index(pl), dtype=np.int32)
+            self.priority_ids = ids
+            self._ids_dev = torch.from_numpy(ids).to(self.batch.device)
+            return
         redundant = False
         if remove_redundant_gensets and L.has_genset:
             redundant = bool((self.batch.cols["gen_running_min"] == 0).all().item())
@@ -125,12 +191,13 @@ class RuleBasedControl:
         ret = torch.zeros(L.n_grids, dtype=torch.float64, device=self.batch.device)
         parts = {}
         done = 0
-        if L.n_load != 1 or L.n_pv != 1:
-            # several load / renewable modules per grid: no fused kernel for that layout -- one expand + step per env-step
+        if L.multi:
+            # several modules of a kind per grid: no fused kernel for that layout -- one expand + step per env-step
             ids = self._ids_dev.to(torch.int32)
             rows = {"reward": [], "soc_trace": [], "log": []}
             for _ in range(total):
-                control = self.engine.expand_discrete(ids, self._table)
+                control = self.engine.expand_lists(ids, self._lists) if self._instances \
+                    else self.engine.expand_discrete(ids, self._table)
                 _, r, _, lg = self.engine.step(control, normalized=False, want_obs=False, want_log=log)
                 ret += r
                 if reward:

@@ -22,6 +22,7 @@ warnings.simplefilter("ignore")
 _refenv.import_reference()
 
 from pymgrid import Microgrid  # noqa: E402
+from pymgrid.algos import RuleBasedControl  # noqa: E402
 from pymgrid.envs import DiscreteMicrogridEnv  # noqa: E402
 from pymgrid.modules import (BatteryModule, GensetModule, GridModule, LoadModule,  # noqa: E402
                              RenewableModule, UnbalancedEnergyModule)
@@ -240,6 +241,12 @@ def discrete_case(out, ci, g, n_gen, n_bat, n_grid, A):
         out[f"c{ci}_ids"] = ids.astype(np.int32)
         out[f"c{ci}_control"] = control
         out[f"c{ci}_dreward"] = dreward
+        # RuleBasedControl: the modules sorted by marginal cost (rbc.py:31-50), deployed for the whole series
+        m = Microgrid(build(g), loss_load_cost=g["loss_load_cost"], overgeneration_cost=g["overgeneration_cost"])
+        rbc = RuleBasedControl(m)
+        out[f"c{ci}_rbc_list"] = np.array([(kind_id[el.module[0]], el.module[1], el.action) for el in rbc._priority_list], np.int32)
+        log = rbc.run()
+        out[f"c{ci}_rbc_reward"] = log[("balance", 0, "reward")].values.astype(np.float64)
         return int(env.action_space.n)
 
 

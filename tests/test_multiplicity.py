@@ -36,3 +36,195 @@ def test_multi_instance_oracle_vs_reference(oracle):
                 ctrl = om.populate_action([tuple(int(x) for x in e) for e in table[ids[k]] if e[0] >= 0])
                 assert np.array_equal(ctrl, z[f"c{ci}_control"][k]), (ci, k)
                 assert om.run(ctrl, False).common.reward == z[f"c{ci}_dreward"][k], (ci, k)
+
+
+def _unpack(word):
+    w = int(word)
+    return [w & 0xff, (w >> 8) & 0xff, (w >> 16) & 0xff, w >> 24]
+
+
+def _check_log_row(names, dev_row, ref_names, ref_row, ctx):
+    dev = dict(zip(names, dev_row))
+    for n, r in zip(ref_names, ref_row):
+        base, sfx = (n[:n.index("[")], n[n.index("["):]) if n.endswith("]") else (n, "")
+        if base in ("gen_cur", "gen_goal", "gen_up", "gen_down"):
+            v = _unpack(dev["genset_status" + sfx])[("gen_cur", "gen_goal", "gen_up", "gen_down").index(base)]
+        else:
+            v = dev[n]
+        assert v == r, (*ctx, n, v, r)
+
+
+@pytest.mark.gpu
+def test_multi_instance_device_vs_reference(device):
+    """The general kernels on the reference-made fixtures: two copies of every module mix in one batch; observations (reset
+    and per step), reward, done, every log column of every module instance, final state -- all ==."""
+    import torch
+    from pymgrid_amd import BatchedMicrogridEnv, MicrogridBatch
+    for ci, p, mt, z in multi_cases():
+        ref_names = [str(s) for s in z[f"c{ci}_log_names"]]
+        for tag, normalized in (("n", True), ("r", False)):
+            env = BatchedMicrogridEnv(MicrogridBatch.from_grids([p, p], device=device), log=True)
+            L = env.layout
+            assert (L.n_genset, L.n_battery, L.n_grid) == (len(mt["genset"]), len(mt["battery"]), len(mt["grid"])) and L.multi
+            assert np.array_equal(env.reset().cpu().numpy()[1], z[f"c{ci}_{tag}_obs0"]), (ci, tag)
+            a = z[f"c{ci}_{tag}_actions"]
+            names = env.engine.log_names
+            assert names == L.log_names and len(names) == env.engine.log_dim
+            for k in range(a.shape[0]):
+                act = torch.as_tensor(np.stack([a[k], a[k]]), dtype=torch.float64, device=device)
+                obs, reward, done, info = env.step(act, normalized=normalized)
+                assert reward[0].item() == z[f"c{ci}_{tag}_reward"][k] == reward[1].item(), (ci, tag, k)
+                assert int(done[1]) == z[f"c{ci}_{tag}_done"][k]
+                assert np.array_equal(obs[0].cpu().numpy(), z[f"c{ci}_{tag}_obs"][k]), (ci, tag, k)
+                _check_log_row(names, info["log"][:, 1].cpu().numpy(), ref_names, z[f"c{ci}_{tag}_log"][k], (ci, tag, k))
+            if L.has_battery:
+                assert np.array_equal(env.batch.cols["charge"].reshape(L.n_battery, 2)[:, 0].cpu().numpy(), z[f"c{ci}_{tag}_charge"][-1])
+                assert np.array_equal(env.batch.cols["soc"].reshape(L.n_battery, 2)[:, 1].cpu().numpy(), z[f"c{ci}_{tag}_soc"][-1])
+            if L.has_genset:
+                st = env.batch.cols["gen_status"].reshape(L.n_genset, 2)[:, 0].cpu().numpy().view(np.uint32)
+                assert [_unpack(w) for w in st] == z[f"c{ci}_{tag}_status"][-1].tolist()
+            env.close()
+
+
+@pytest.mark.gpu
+def test_multi_instance_discrete_env_vs_reference(device):
+    """DiscreteBatchedMicrogridEnv on microgrids with several gensets / batteries / grids: the priority lists over module
+    instances are the reference's (same order, so the same action ids), the expanded controls and the rewards are ==; the
+    N = 1 adaptor returns the reference's nested shapes."""
+    import torch
+    from pymgrid_amd import DiscreteBatchedMicrogridEnv, DiscreteMicrogridEnv, MicrogridBatch
+    from pymgrid_amd.priority_list import lists_array
+    for ci, p, mt, z in multi_cases():
+        if not mt["n_lists"]:
+            continue
+        env = DiscreteBatchedMicrogridEnv(MicrogridBatch.from_grids([p, p, p], device=device))
+        assert env.action_space.n == mt["n_lists"]
+        assert np.array_equal(lists_array(env.actions_list), z[f"c{ci}_pl_table"]), ci
+        env.reset()
+        ids = z[f"c{ci}_ids"]
+        for k in range(len(ids)):
+            a = torch.full((3,), int(ids[k]), dtype=torch.int32, device=device)
+            assert np.array_equal(env.get_action(a)[2].cpu().numpy(), z[f"c{ci}_control"][k]), (ci, k)
+            _, reward, _, _ = env.step(a)
+            assert reward[0].item() == z[f"c{ci}_dreward"][k] == reward[2].item(), (ci, k)
+        env.close()
+        one = DiscreteMicrogridEnv(p, device=device, flat_spaces=False)
+        obs = one.reset()
+        L = one.layout
+        assert [len(obs.get(k, [])) for k in ("load", "pv", "genset", "battery", "grid")] == \
+            [L.n_load, L.n_pv, L.n_genset, L.n_battery, L.n_grid]
+        ctrl = one.get_action_dict(int(ids[0]))
+        flat = np.concatenate([np.concatenate(ctrl["genset"]) if L.n_genset else np.zeros(0),
+                               np.array(ctrl.get("battery", [])), np.array(ctrl.get("grid", []))])
+        assert np.array_equal(flat, z[f"c{ci}_control"][0])
+        obs, reward, done, info = one.step(int(ids[0]))
+        assert reward == z[f"c{ci}_dreward"][0] and isinstance(done, bool)
+        # RuleBasedControl: the reference's marginal-cost order of the module instances, and its rewards over the series
+        from pymgrid_amd import RuleBasedControl
+        renv = DiscreteBatchedMicrogridEnv(MicrogridBatch.from_grids([p, p], device=device))
+        rbc = RuleBasedControl(renv)
+        assert np.array_equal(np.array(rbc.priority_list[1]), z[f"c{ci}_rbc_list"]), (ci, rbc.priority_list[1])
+        r = rbc.run()["reward"].cpu().numpy()
+        assert np.array_equal(r[:, 0], z[f"c{ci}_rbc_reward"]) and np.array_equal(r[:, 1], r[:, 0]), ci
+        renv.close()
+        twin = DiscreteMicrogridEnv.from_microgrid(one)           # parameters and state of every instance carry over
+        for name in ("charge", "soc", "gen_status"):
+            if name in one.batch.cols:
+                assert torch.equal(twin.batch.cols[name], one.batch.cols[name])
+        twin.close(); one.close()
+
+
+def _random_multi_grid(rs, T, n_gen, n_bat, n_grid, n_load, n_pv, horizon, grid_first):
+    g = dict(load_ts=80 * rs.rand(T, n_load) + 5, pv_ts=60 * rs.rand(T, n_pv) * (rs.rand(T, n_pv) > 0.3), horizon=horizon,
+             final_step=T, initial_step=0, unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=1.0 + rs.rand()),
+             controllable_order=["genset", "grid", "battery"] if grid_first else ["genset", "battery", "grid"])
+    if n_gen:
+        g["genset"] = [dict(running_min_production=float(rs.choice([0.0, 5.0, 12.0])), running_max_production=40.0 + 40 * rs.rand(),
+                            genset_cost=0.3 + 0.3 * rs.rand(), co2_per_unit=2.0, cost_per_unit_co2=0.1,
+                            start_up_time=int(rs.randint(0, 3)), wind_down_time=int(rs.randint(0, 3)),
+                            init_start_up=bool(rs.randint(0, 2))) for _ in range(n_gen)]
+    if n_bat:
+        g["battery"] = [dict(min_capacity=10.0, max_capacity=60.0 + 80 * rs.rand(), max_charge=20.0 + 10 * rs.rand(),
+                             max_discharge=25.0, efficiency=float(rs.choice([0.9, 0.95, 1.0])), battery_cost_cycle=0.02 * rs.rand(),
+                             init_soc=0.3 + 0.6 * rs.rand()) for _ in range(n_bat)]
+    if n_grid:
+        g["grid"] = [dict(max_import=30.0 + 40 * rs.rand(), max_export=20.0 + 30 * rs.rand(), cost_per_unit_co2=0.1)
+                     for _ in range(n_grid)]
+        g["grid_ts"] = [np.stack([0.1 + rs.rand(T), 0.5 * rs.rand(T), 0.3 * rs.rand(T), (rs.rand(T) > 0.2).astype(float)], axis=1)
+                        for _ in range(n_grid)]
+    return g
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mix", [(2, 2, 2, 2, 1, 2, False), (3, 0, 1, 1, 1, 0, False), (0, 3, 2, 1, 2, 1, True),
+                                 (8, 8, 8, 3, 3, 0, False), (1, 2, 1, 0, 1, 0, True)])
+def test_multi_instance_batches_vs_oracle(mix, device, oracle):
+    """Randomised batches (every grid its own parameters, genset timers, outages): continuous steps with normalised and raw
+    controls, the violations mask of the dry run, discrete steps through the instance priority lists, the rule-based
+    rollout -- log, observations, state against the multi-instance CPU oracle."""
+    import torch
+    from pymgrid_amd import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv, MicrogridBatch, RuleBasedControl
+    n_gen, n_bat, n_grid, n_load, n_pv, H, grid_first = mix
+    rs = np.random.RandomState(hash(mix) % 2 ** 31)
+    T, N, K = 40, 70, 30
+    grids = [_random_multi_grid(rs, T, n_gen, n_bat, n_grid, n_load, n_pv, H, grid_first) for _ in range(N)]
+    env = BatchedMicrogridEnv(MicrogridBatch.from_grids(grids, device=device), log=True)
+    oms = [oracle.OracleMultiMicrogrid(g) for g in grids]
+    names = env.engine.log_names
+    A = env.layout.action_dim
+    obs0 = env.reset().cpu().numpy()
+    for j, om in enumerate(oms):
+        assert np.array_equal(obs0[j], om.reset()), j
+    for k in range(K):
+        normalized = k % 3 != 2
+        a = rs.rand(N, A)
+        if not normalized:
+            a = (a * 2 - 0.7) * 60
+            c = 0
+            for q in range(n_gen):
+                a[:, c] = np.clip(np.round(a[:, c] / 60), 0, 1); a[:, c + 1] = np.abs(a[:, c + 1]); c += 2
+        if k % 5 == 0:
+            a[:, :2 * n_gen:2] = np.round(a[:, :2 * n_gen:2])
+        act = torch.as_tensor(a, dtype=torch.float64, device=device)
+        mask = env.engine.check_step(act, normalized=normalized).cpu().numpy()
+        obs, reward, done, info = env.step(act, normalized=normalized)
+        log, obs = info["log"].cpu().numpy(), obs.cpu().numpy()
+        assert np.array_equal(mask, log[names.index("violations")].astype(mask.dtype)), k
+        for j, om in enumerate(oms):
+            out = om.run(a[j], normalized)
+            for c, (n, v) in enumerate(zip(names, om.log_row(out, names))):
+                if v is not None:
+                    assert log[c, j] == v, (k, j, n, log[c, j], v)
+            assert reward[j].item() == out.common.reward and bool(done[j]) == bool(out.common.done)
+            assert np.array_equal(obs[j], om.observe()), (k, j)
+    env.close()
+    if 2 * n_gen + n_bat + n_grid > 9:
+        return
+    # discrete steps + rule-based rollout on fresh copies
+    denv = DiscreteBatchedMicrogridEnv(MicrogridBatch.from_grids(grids, device=device), remove_redundant_gensets=False)
+    oms = [oracle.OracleMultiMicrogrid(g) for g in grids]
+    denv.reset()
+    for k in range(12):
+        ids = rs.randint(0, denv.action_space.n, size=N)
+        control = denv.get_action(ids).cpu().numpy()
+        _, reward, _, _ = denv.step(ids)
+        for j, om in enumerate(oms):
+            if denv._instances:
+                plist = denv.actions_list[ids[j]]
+            else:
+                plist = [(m, 0, a_) for m, a_ in denv.actions_list[ids[j]]]
+            ctrl = om.populate_action(plist)
+            assert np.array_equal(control[j], ctrl), (k, j)
+            assert reward[j].item() == om.run(ctrl, False).common.reward, (k, j)
+    denv.close()
+    denv = DiscreteBatchedMicrogridEnv(MicrogridBatch.from_grids(grids, device=device), remove_redundant_gensets=False)
+    rbc = RuleBasedControl(denv, remove_redundant_gensets=False)
+    res = rbc.run()
+    r = res["reward"].cpu().numpy()
+    assert r.shape == (T, N)
+    for j, g in enumerate(grids):
+        om = oracle.OracleMultiMicrogrid(g)
+        plist = rbc.priority_list[j] if rbc._instances else [(m, 0, a_) for m, a_ in rbc.priority_list[j]]
+        for k in range(T):
+            assert r[k, j] == om.run(om.populate_action(plist), False).common.reward, (j, k)
+    denv.close()
