@@ -38,7 +38,9 @@ def bucket_by_layout(grids):
     for i, p in enumerate(grids):
         from .batch import grid_first
         load, pv = np.asarray(p["load_ts"]), np.asarray(p["pv_ts"])
-        key = (architecture(p), load.shape[0], int(p.get("horizon", 0)),
+        from .batch import module_list
+        key = (architecture(p), tuple(len(module_list(p.get(k))) for k in ("genset", "battery", "grid")), load.shape[0],
+               int(p.get("horizon", 0)),
                int(p.get("initial_step", 0)), int(p.get("final_step", 0)), grid_first(p),
                1 if load.ndim == 1 else load.shape[1], 1 if pv.ndim == 1 else pv.shape[1])
         buckets.setdefault(key, []).append(i)
@@ -100,16 +102,15 @@ def load_scenario_yaml(path):
         raise ValueError(f"{path}: not a !Microgrid document")
     if doc.get("trajectory_func") is not None or doc.get("reward_shaping_func") is not None:
         raise NotImplementedError("trajectory_func / reward_shaping_func in scenario files are not supported yet")
-    p, seen = {}, set()
+    p = {"load_ts": [], "pv_ts": [], "grid_ts": [], "grid": [], "genset": [], "battery": []}
     ts_meta = []
     order = []                                          # controllable modules in list order (module_container.py:355-413)
     for name, mod in doc["modules"]:
         tag, cp, state = mod["__tag__"], mod["cls_params"], mod.get("state", {})
         if tag in ("!Genset", "!BatteryModule", "!GridModule"):
-            order.append({"!Genset": "genset", "!BatteryModule": "battery", "!GridModule": "grid"}[tag])
-        if tag in seen:
-            raise NotImplementedError(f"more than one {tag} per microgrid is not supported on the device path")
-        seen.add(tag)
+            kind = {"!Genset": "genset", "!BatteryModule": "battery", "!GridModule": "grid"}[tag]
+            if kind not in order:
+                order.append(kind)
         if cp.get("raise_errors"):
             raise NotImplementedError("raise_errors=True is not offered (requests are always clipped)")
         if tag in ("!LoadModule", "!RenewableModule", "!GridModule"):
@@ -130,13 +131,13 @@ def load_scenario_yaml(path):
             init = int(cp.get("initial_step", 0))
             ts_meta.append((horizon, final, init, int(state.get("_current_step", init))))
             if tag == "!LoadModule":
-                p["load_ts"] = -np.abs(ts.reshape(ts.shape[0], -1)[:, 0])
+                p["load_ts"].append(-np.abs(ts.reshape(ts.shape[0], -1)[:, 0]))
             elif tag == "!RenewableModule":
-                p["pv_ts"] = np.abs(ts.reshape(ts.shape[0], -1)[:, 0])
+                p["pv_ts"].append(np.abs(ts.reshape(ts.shape[0], -1)[:, 0]))
             else:
-                p["grid_ts"] = ts
-                p["grid"] = dict(max_import=float(cp["max_import"]), max_export=float(cp["max_export"]),
-                                 cost_per_unit_co2=float(cp.get("cost_per_unit_co2", 0.0)))
+                p["grid_ts"].append(ts)
+                p["grid"].append(dict(max_import=float(cp["max_import"]), max_export=float(cp["max_export"]),
+                                      cost_per_unit_co2=float(cp.get("cost_per_unit_co2", 0.0))))
         elif tag == "!UnbalancedEnergyModule":
             p["unbalanced"] = dict(loss_load_cost=float(cp["loss_load_cost"]),
                                    overgeneration_cost=float(cp["overgeneration_cost"]))
@@ -147,13 +148,13 @@ def load_scenario_yaml(path):
             if "_current_status" in state:
                 status = [int(state["_current_status"]), int(state["_goal_status"]),
                           int(state["_steps_until_up"]), int(state["_steps_until_down"])]
-            p["genset"] = dict(running_min_production=float(cp["running_min_production"]),
-                               running_max_production=float(cp["running_max_production"]),
-                               genset_cost=float(cp["genset_cost"]), co2_per_unit=float(cp.get("co2_per_unit", 0.0)),
-                               cost_per_unit_co2=float(cp.get("cost_per_unit_co2", 0.0)),
-                               start_up_time=su, wind_down_time=wd, status=status)
+            p["genset"].append(dict(running_min_production=float(cp["running_min_production"]),
+                                    running_max_production=float(cp["running_max_production"]),
+                                    genset_cost=float(cp["genset_cost"]), co2_per_unit=float(cp.get("co2_per_unit", 0.0)),
+                                    cost_per_unit_co2=float(cp.get("cost_per_unit_co2", 0.0)),
+                                    start_up_time=su, wind_down_time=wd, status=status))
             if not cp.get("allow_abortion", True):
-                p["genset"]["allow_abortion"] = False
+                p["genset"][-1]["allow_abortion"] = False
         elif tag == "!BatteryModule":
             if cp.get("battery_transition_model") is not None:
                 raise NotImplementedError("custom battery_transition_model is not supported")
@@ -164,11 +165,23 @@ def load_scenario_yaml(path):
                 charge = float(cp["init_charge"])
             else:
                 charge = float(cp["init_soc"]) * cap
-            p["battery"] = dict(min_capacity=float(cp["min_capacity"]), max_capacity=cap,
-                                max_charge=float(cp["max_charge"]), max_discharge=float(cp["max_discharge"]),
-                                efficiency=float(cp["efficiency"]),
-                                battery_cost_cycle=float(cp.get("battery_cost_cycle", 0.0)),
-                                charge=charge, soc=charge / cap)
+            p["battery"].append(dict(min_capacity=float(cp["min_capacity"]), max_capacity=cap,
+                                     max_charge=float(cp["max_charge"]), max_discharge=float(cp["max_discharge"]),
+                                     efficiency=float(cp["efficiency"]),
+                                     battery_cost_cycle=float(cp.get("battery_cost_cycle", 0.0)),
+                                     charge=charge, soc=charge / cap))
+    # one module of a kind: the plain vocabulary (a dict, a [T] series); several: lists / [T, n] (module_container.py:355-413
+    # keeps a list per name)
+    for key in ("load_ts", "pv_ts"):
+        cols = p[key]
+        if not cols:
+            raise NotImplementedError("a microgrid without a LoadModule / RenewableModule is not read from a scenario file")
+        p[key] = cols[0] if len(cols) == 1 else np.stack(cols, axis=1)
+    for key in ("genset", "battery", "grid", "grid_ts"):
+        if not p[key]:
+            del p[key]
+        elif len(p[key]) == 1:
+            p[key] = p[key][0]
     if "unbalanced" not in p:
         raise ValueError("scenario has no UnbalancedEnergyModule")
     if len(set(ts_meta)) != 1:
@@ -183,45 +196,49 @@ def dump_scenario_yaml(p, path):
     ``!Microgrid`` YAML + ``data/cls_params/<Module>/time_series.csv.gz`` next to it, utils/serialize.py:24-83) so that
     ``pymgrid.Microgrid.load(open(path))`` -- and ``load_scenario_yaml(path)`` -- give the same microgrid back: constructor
     arguments under ``cls_params``, the dynamic state (battery charge / SoC, the four genset status fields, the step
-    counter) under ``state``.  One module of each kind; the controllable modules are listed in ``controllable_order``."""
+    counter) under ``state``.  The controllable modules are listed in ``controllable_order``; several modules of a kind are
+    written one after the other (the series of instance j > 0 under ``data/cls_params/<Module>_<j>/``: the reference's own
+    dump writes every instance of a class to the same file, utils/serialize.py:33-41)."""
     import os
 
     import pandas as pd
     import yaml
+    from .batch import grid_series_list, module_list
     load, pv = np.asarray(p["load_ts"], dtype=np.float64), np.asarray(p["pv_ts"], dtype=np.float64)
-    if (load.ndim == 2 and load.shape[1] != 1) or (pv.ndim == 2 and pv.shape[1] != 1):
-        raise NotImplementedError("more than one load / renewable module per microgrid is not supported by the file format here")
+    load, pv = load.reshape(load.shape[0], -1), pv.reshape(pv.shape[0], -1)
     base = os.path.dirname(os.path.abspath(path))
     H, t0, final = int(p.get("horizon", 0)), int(p.get("initial_step", 0)), int(p.get("final_step", 0)) or load.shape[0]
     cur = int(p.get("current_step", t0))               # the saved step counter (state), not the constructor's initial_step
     noise = p.get("forecast_noise")
 
-    def series(tag, arr):
-        rel = os.path.join("data", "cls_params", tag, "time_series.csv.gz")
+    def series(tag, arr, j=0):
+        rel = os.path.join("data", "cls_params", tag if j == 0 else f"{tag}_{j}", "time_series.csv.gz")
         os.makedirs(os.path.dirname(os.path.join(base, rel)), exist_ok=True)
         pd.DataFrame(np.asarray(arr, dtype=np.float64).reshape(arr.shape[0], -1)).to_csv(os.path.join(base, rel))
         return _Tagged("!NDArray", rel)
 
-    def ts_params(tag, arr, extra=None):
+    def ts_params(tag, arr, extra=None, j=0):
         fc = (float(noise["std"]) if noise else "oracle") if H > 0 else None
         d = dict(final_step=final, forecast_horizon=H, forecaster=fc,
                  forecaster_increase_uncertainty=bool(noise and noise.get("increase_uncertainty", False)),
                  forecaster_relative_noise=bool(noise and noise.get("relative_noise", False)),
-                 initial_step=t0, raise_errors=False, time_series=series(tag, arr))
+                 initial_step=t0, raise_errors=False, time_series=series(tag, arr, j))
         d.update(extra or {})
         return d
 
-    def module(name, tag, cls_params, state):
-        return [name, _Tagged(tag, dict(cls_params=cls_params, name=[name, 0], state=dict(state, _current_step=cur)))]
-    mods = [module("load", "!LoadModule", ts_params("LoadModule", np.abs(load)), {}),
-            module("pv", "!RenewableModule", ts_params("RenewableModule", np.abs(pv), dict(provided_energy_name="renewable_used")), {}),
-            module("unbalanced_energy", "!UnbalancedEnergyModule",
-                   dict(initial_step=t0, loss_load_cost=float(p["unbalanced"]["loss_load_cost"]),
-                        overgeneration_cost=float(p["unbalanced"]["overgeneration_cost"]), raise_errors=False), {})]
+    def module(name, tag, cls_params, state, j=0):
+        return [name, _Tagged(tag, dict(cls_params=cls_params, name=[name, j], state=dict(state, _current_step=cur)))]
+    mods = [module("load", "!LoadModule", ts_params("LoadModule", np.abs(load[:, j]), j=j), {}, j) for j in range(load.shape[1])]
+    mods += [module("pv", "!RenewableModule", ts_params("RenewableModule", np.abs(pv[:, j]),
+                                                        dict(provided_energy_name="renewable_used"), j=j), {}, j)
+             for j in range(pv.shape[1])]
+    mods.append(module("unbalanced_energy", "!UnbalancedEnergyModule",
+                       dict(initial_step=t0, loss_load_cost=float(p["unbalanced"]["loss_load_cost"]),
+                            overgeneration_cost=float(p["unbalanced"]["overgeneration_cost"]), raise_errors=False), {}))
     order = [k for k in (p.get("controllable_order") or []) if p.get(k) is not None]
     order += [k for k in ("genset", "battery", "grid") if p.get(k) is not None and k not in order]
-    for kind in order:
-        q = p[kind]
+    grid_series = grid_series_list(p)
+    for kind, j, q in [(kind, j, q) for kind in order for j, q in enumerate(module_list(p[kind]))]:
         if kind == "genset":
             su, wd = int(q.get("start_up_time", 0)), int(q.get("wind_down_time", 0))
             if q.get("status") is not None:
@@ -235,7 +252,7 @@ def dump_scenario_yaml(p, path):
                 init_start_up=bool(st[0]), initial_step=t0, provided_energy_name="genset_production", raise_errors=False,
                 running_max_production=float(q["running_max_production"]),
                 running_min_production=float(q["running_min_production"]), start_up_time=su, wind_down_time=wd),
-                dict(_current_status=st[0], _goal_status=st[1], _steps_until_up=st[2], _steps_until_down=st[3])))
+                dict(_current_status=st[0], _goal_status=st[1], _steps_until_up=st[2], _steps_until_down=st[3]), j))
         elif kind == "battery":
             cap = float(q["max_capacity"])
             if q.get("charge") is not None:
@@ -248,11 +265,11 @@ def dump_scenario_yaml(p, path):
                 battery_cost_cycle=float(q.get("battery_cost_cycle", 0.0)), battery_transition_model=None,
                 efficiency=float(q["efficiency"]), init_charge=None, init_soc=charge / cap, initial_step=t0,
                 max_capacity=cap, max_charge=float(q["max_charge"]), max_discharge=float(q["max_discharge"]),
-                min_capacity=float(q["min_capacity"]), raise_errors=False), dict(current_charge=charge, soc=charge / cap)))
+                min_capacity=float(q["min_capacity"]), raise_errors=False), dict(current_charge=charge, soc=charge / cap), j))
         else:
-            mods.append(module("grid", "!GridModule", ts_params("GridModule", np.asarray(p["grid_ts"], dtype=np.float64), dict(
+            mods.append(module("grid", "!GridModule", ts_params("GridModule", np.asarray(grid_series[j], dtype=np.float64), dict(
                 cost_per_unit_co2=float(q.get("cost_per_unit_co2", 0.0)), max_export=float(q["max_export"]),
-                max_import=float(q["max_import"]))), {}))
+                max_import=float(q["max_import"])), j=j), {}, j))
     doc = _Tagged("!Microgrid", dict(final_step=final, initial_step=t0, modules=mods, trajectory_func=None))
 
     class Dumper(yaml.SafeDumper):

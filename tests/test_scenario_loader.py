@@ -105,3 +105,54 @@ def test_the_reference_loads_what_we_dump(pymgrid25, tmp_path):
                 assert np.array_equal(np.asarray(back[k]).reshape(v.shape), v), (n, k)
             else:
                 assert back[k] == v, (n, k, back[k], v)
+
+
+def test_multi_instance_scenarios_round_trip(tmp_path):
+    """Several gensets / batteries / grids / loads / pvs per microgrid: dump_scenario_yaml -> load_scenario_yaml gives the
+    parameter dict back, and the real reference loads the same file into the same modules (count, order, parameters, state)."""
+    from conftest import multi_cases
+    from pymgrid_amd.batch import module_list
+    from pymgrid_amd.scenario import bucket_by_layout, dump_scenario_yaml, load_scenario_yaml
+    ref_ok = os.path.isdir("/root/reference/src/pymgrid")
+    if ref_ok:
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+        import _refenv
+        _refenv.import_reference()
+        from pymgrid import Microgrid
+    all_p = []
+    for ci, p, mt, z in multi_cases():
+        all_p.append(p)
+        os.makedirs(tmp_path / f"m{ci}", exist_ok=True)
+        path = dump_scenario_yaml(p, str(tmp_path / f"m{ci}" / "microgrid.yaml"))
+        q = load_scenario_yaml(path)
+        # (series go through csv text and pandas' default float parser, as in the reference: the last bit may differ for
+        #  arbitrary doubles -- the pymgrid25 series are short decimals and survive bit for bit, see the tests above)
+        close = lambda a, b: np.allclose(a, b, rtol=1e-14, atol=0.0)
+        assert close(np.asarray(q["load_ts"]).reshape(p["load_ts"].shape), -np.abs(p["load_ts"]))
+        assert close(np.asarray(q["pv_ts"]).reshape(p["pv_ts"].shape), np.abs(p["pv_ts"]))
+        for kind in ("genset", "battery", "grid"):
+            a, b = module_list(p.get(kind)), module_list(q.get(kind))
+            assert len(a) == len(b), (ci, kind)
+            for x, y in zip(a, b):
+                for key in ("running_max_production", "genset_cost", "start_up_time", "max_capacity", "efficiency", "max_import"):
+                    if key in x:
+                        assert y[key] == x[key], (ci, kind, key)
+        for j, ts in enumerate(p["grid_ts"]):
+            got = q["grid_ts"] if len(p["grid_ts"]) == 1 else q["grid_ts"][j]
+            assert close(got, ts), (ci, j)
+        if ref_ok:
+            with open(path) as fh:
+                m = Microgrid.load(fh)
+            for kind in ("genset", "battery", "grid"):
+                mods = m.modules[kind] if module_list(p.get(kind)) else []
+                assert len(mods) == len(module_list(p.get(kind))), (ci, kind)
+            for j, b in enumerate(module_list(p.get("battery"))):
+                assert m.modules["battery"][j].max_capacity == b["max_capacity"]
+                assert abs(m.modules["battery"][j].soc - b["init_soc"]) < 1e-15
+            for j, g in enumerate(module_list(p.get("grid"))):
+                assert m.modules["grid"][j].max_import == g["max_import"]
+                assert close(m.modules["grid"][j].time_series, p["grid_ts"][j])
+            assert len(m.modules["load"]) == p["load_ts"].shape[1]
+            assert close(m.modules["load"][-1].time_series[:, 0], -np.abs(p["load_ts"][:, -1]))
+    assert len(bucket_by_layout(all_p)) == len(all_p)          # every module mix is a layout of its own
