@@ -149,3 +149,85 @@ def test_oracle_equals_reference_on_random_microgrids(seed, oracle):
                 assert om.run(act, normalized=False).reward == r, (seed, case, k)
                 checked += 1
     assert checked > 200
+
+
+@pytest.mark.filterwarnings("ignore")
+@pytest.mark.parametrize("seed", range(6))
+def test_multi_instance_oracle_equals_reference_on_random_microgrids(seed, oracle):
+    """Several gensets / batteries / grids / loads / pvs in a SHUFFLED module list (the container groups them by name in
+    first-seen order, instances in list order): orc_mrun / orc_mobserve / orc_mpopulate_action against the live reference."""
+    import make_multi_goldens as mm
+    from pymgrid import Microgrid
+    from pymgrid.envs import DiscreteMicrogridEnv
+    from pymgrid_amd.priority_list import get_instance_priority_lists
+    rs = np.random.RandomState(4242 + seed)
+    for case in range(8):
+        n_gen, n_bat, n_grid = int(rs.randint(0, 4)), int(rs.randint(0, 4)), int(rs.randint(0, 3))
+        if n_gen + n_bat + n_grid == 0:
+            n_bat = 2
+        n_load, n_pv, H = int(rs.randint(1, 4)), int(rs.randint(1, 4)), int(rs.choice([0, 0, 2, 5]))
+        T = int(rs.randint(20, 50))
+        g = mm.draw_case(rs, T, n_gen, n_bat, n_grid, n_load, n_pv, H, ("load", "pv", "genset", "battery", "grid"))
+
+        def modules():
+            mods = mm.build(g)
+            order = np.random.RandomState(1000 * seed + case).permutation(len(mods))
+            return [mods[j] for j in order]
+        mods = modules()
+        # the parameter dict in this repo's vocabulary: instances in list order per name, names in first-seen order
+        per = {k: [] for k in ("load", "pv", "genset", "battery", "grid")}
+        src = {k: list(range(len(g[k]))) for k in per}
+        flat = [(kind, j) for kind in ("load", "pv", "genset", "battery", "grid") for j in src[kind]]
+        order = np.random.RandomState(1000 * seed + case).permutation(len(flat))
+        seen = []
+        for j in order:
+            kind, inst = flat[j]
+            per[kind].append(inst)
+            if kind in ("genset", "battery", "grid") and kind not in seen:
+                seen.append(kind)
+        p = dict(load_ts=np.stack([g["load"][j] for j in per["load"]], axis=1), pv_ts=np.stack([g["pv"][j] for j in per["pv"]], axis=1),
+                 horizon=H, final_step=T, initial_step=0,
+                 unbalanced=dict(loss_load_cost=g["loss_load_cost"], overgeneration_cost=g["overgeneration_cost"]),
+                 genset=[g["genset"][j] for j in per["genset"]], battery=[g["battery"][j] for j in per["battery"]],
+                 grid=[{k: v for k, v in g["grid"][j].items() if k != "ts"} for j in per["grid"]],
+                 grid_ts=[g["grid"][j]["ts"] for j in per["grid"]], controllable_order=seen)
+        counts = dict(genset=n_gen, battery=n_bat, grid=n_grid)
+        m = Microgrid(mods, loss_load_cost=g["loss_load_cost"], overgeneration_cost=g["overgeneration_cost"])
+        om = oracle.OracleMultiMicrogrid(p)
+        assert np.array_equal(om.reset(), mm.flat_obs(m.reset())), (seed, case)
+        A = 2 * n_gen + n_bat + n_grid
+        K = T - 1
+        for k in range(K):
+            normalized = bool(rs.randint(0, 2))
+            a = rs.rand(A)
+            if not normalized:
+                c = 0
+                for j in range(n_gen):
+                    a[c] = float(rs.randint(0, 2)); a[c + 1] *= 1.2 * p["genset"][j]["running_max_production"]; c += 2
+                for j in range(n_bat):
+                    a[c] = (a[c] * 2 - 1) * 1.5 * p["battery"][j]["max_charge"]; c += 1
+                for j in range(n_grid):
+                    a[c] = (a[c] * 2 - 1) * 1.2 * p["grid"][j]["max_import"]; c += 1
+            obs, r, d, _ = m.run(mm.control_of(m, counts, a), normalized=normalized)
+            out = om.run(a, normalized)
+            assert out.common.reward == r and bool(out.common.done) == bool(d), (seed, case, k)
+            assert np.array_equal(om.observe(), mm.flat_obs(obs)), (seed, case, k)
+        om = oracle.OracleMultiMicrogrid(p)               # fresh state for the discrete part
+        if 0 < 2 * n_gen + n_bat + n_grid <= 6:
+            env = DiscreteMicrogridEnv(modules(), loss_load_cost=g["loss_load_cost"], overgeneration_cost=g["overgeneration_cost"])
+            kind_id = {"genset": 0, "battery": 1, "grid": 2}
+            ref_lists = [tuple((kind_id[el.module[0]], el.module[1], el.action) for el in pl) for pl in env.actions_list]
+            red = [j for j, q in enumerate(p["genset"]) if q["running_min_production"] == 0]
+            gfb = "grid" in seen and "battery" in seen and seen.index("grid") < seen.index("battery")
+            assert get_instance_priority_lists(n_gen, n_bat, n_grid, red, gfb) == ref_lists, (seed, case)
+            env.reset()
+            for k in range(8):
+                i = int(rs.randint(0, env.action_space.n))
+                ctrl = env._get_action(i)
+                flat_ctrl = np.concatenate([np.concatenate([np.asarray(x, dtype=np.float64) for x in ctrl["genset"]]) if n_gen else np.zeros(0),
+                                            np.asarray(ctrl.get("battery", []), dtype=np.float64),
+                                            np.asarray(ctrl.get("grid", []), dtype=np.float64)])
+                mine = om.populate_action(ref_lists[i])
+                assert np.array_equal(mine, flat_ctrl), (seed, case, k, mine, flat_ctrl)
+                _, r, _, _ = env.step(i)
+                assert om.run(mine, False).common.reward == r, (seed, case, k)
