@@ -93,7 +93,8 @@ typedef struct mgx_layout {
      * column of that module kind is [n, N] (instance-major), grid_ts is [T, n_grid, 4, N], grid_lo / grid_hi
      * [n_grid, 4, N]; actions are (goal, energy) per genset, then the batteries, then the grids; the log carries one
      * block per instance; observations one group of state columns / one grid window per instance.  Such layouts run on
-     * the general kernels (as do n_load / n_pv != 1): single steps, observations, priority lists (mgx_expand_lists). */
+     * the general kernels (as do n_load / n_pv != 1): single steps, K-step launches (mgx_step_k, mgx_rollout_lists),
+     * observations, priority lists (mgx_expand_lists). */
     int32_t n_genset, n_battery, n_grid;      /* <= MGX_MAX_INSTANCES */
 } mgx_layout;
 
@@ -255,6 +256,14 @@ int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *
  * 0 genset / 1 battery / 2 grid, kind -1 = padding.  Works for every layout. */
 int mgx_expand_lists(mgx_handle *h, const int32_t *action_id, const int32_t *lists, int32_t n_lists, int32_t list_len,
                      double *control, mgx_stream stream);
+
+/* K fused discrete steps with priority lists over module instances: the general-path counterpart of
+ * mgx_rollout_discrete (`for a in ids: env.step(a)`, discrete.py:109-143, or RuleBasedControl.run with one fixed list
+ * per grid, rbc.py:64-93).  action_id int32 [K, N] (per_step != 0) or [N]; lists as in mgx_expand_lists; outputs as in
+ * mgx_step_k (soc_trace / status_trace report battery 0 / genset 0).  Works for every layout. */
+int mgx_rollout_lists(mgx_handle *h, const int32_t *action_id, int per_step, const int32_t *lists, int32_t n_lists,
+                      int32_t list_len, int32_t K, double *reward, uint8_t *done, double *soc_trace,
+                      uint32_t *status_trace, double *ret_acc, double *log, mgx_stream stream);
 
 /* DiscreteMicrogridEnv.step (discrete.py:109-143) in ONE launch: mgx_expand_discrete + mgx_step(normalized=0) with the
  * control kept in registers.  control [N, A] (optional, may be NULL) receives the expanded control; the other

@@ -931,6 +931,57 @@ __global__ __launch_bounds__(BLOCK_MULTI) void check_multi_kernel(const KArgs a,
     violations[i] = viol;
 }
 
+// K consecutive steps of the general path in ONE launch (mgx_step_k / mgx_rollout_lists on layouts with several modules of a
+// kind): a loop around step_multi_core -- the state columns are re-read every step (cache hits), nothing is kept in
+// registers across steps.  With `lists` the control of every step is expanded on device from the grid's priority list
+// (ids [K, N] with per_step, else one fixed list per grid = RuleBasedControl.run) and applied unnormalised.
+// soc_trace / status_trace report battery 0 / genset 0.
+constexpr int MGX_MAX_ACTIONS_MULTI = 4 * MGX_MAX_INSTANCES;
+
+template <int F>
+__global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a, const void *__restrict__ actions,
+                                                                   const int32_t *__restrict__ lists, int32_t n_lists, int32_t list_len,
+                                                                   const int32_t *__restrict__ ids, int per_step, int32_t t0, int32_t K,
+                                                                   int normalized, const FusedOut out)
+{
+    extern __shared__ double multi_lds[];
+    const int32_t K_launch = K;
+    t0 = resolve_t(a, t0);
+    K = resolve_k(a, t0, K);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
+    if (i < a.g1) {
+        const int64_t N = a.N;
+        const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
+        StepLists L = multi_lists(a, multi_lds);
+        const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
+        double ret = 0.0;
+        for (int32_t k = 0; k < K; k++) {
+            const int64_t off = (int64_t)k * N + i;
+            Outputs o;
+            double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
+            if (lists) {
+                double ctrl[MGX_MAX_ACTIONS_MULTI];
+                int32_t id = per_step ? ids[off] : ids[i];
+                id = (id >= 0 && id < n_lists) ? id : 0;
+                populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t0 + k, ctrl);
+                step_multi_core<F>(a, (const double *)ctrl, i, t0 + k, false, L, log, o);
+            } else if (a.act_f32) {
+                step_multi_core<F>(a, (const float *)actions + off * A, i, t0 + k, normalized != 0, L, log, o);
+            } else {
+                step_multi_core<F>(a, (const double *)actions + off * A, i, t0 + k, normalized != 0, L, log, o);
+            }
+            const double r = shaped_reward<F>(a.shaper, o);
+            if (out.reward) out.reward[off] = r;
+            if (out.done) out.done[off] = (uint8_t)(k >= k_done);
+            if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = a.c.soc[i]; }
+            if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = a.c.gen_status[i]; }
+            ret += r;
+        }
+        if (out.ret_acc) out.ret_acc[i] += ret;
+    }
+    advance_counter_in_kernel(a, K_launch);
+}
+
 // mgx_expand_lists / mgx_expand_discrete on the general path: lists [n_lists, list_len, 3] in device memory
 template <int F>
 __global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a, const int32_t *__restrict__ lists, int32_t n_lists,
@@ -1943,12 +1994,20 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
     g_err[0] = 0;
     if (!h || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_step_k: NULL argument");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_step_k: K must be positive");
-    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: fused steps need exactly one module of every kind "
-                                                    "per grid; use mgx_step");
     if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
         return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, step_limit(h));
     hipStream_t st = (hipStream_t)stream;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
+    if (h->multi) {                                       // general path: the K-step loop around the general step
+        for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+            MGX_DISPATCH_F(h->flags, (step_k_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
+                                          k, actions, nullptr, 0, 0, nullptr, 0, t_arg(h), K, normalized, fo)));
+        });
+        hipError_t em = hipGetLastError();
+        if (em != hipSuccess) return hip_fail(em, "step_k_multi_kernel launch");
+        advance(h, K, st);
+        return MGX_OK;
+    }
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
         const int32_t gpb = fused_grids_per_block(h, k.g1 - k.g0);
         const unsigned blocks = (unsigned)((k.g1 - k.g0 + gpb - 1) / gpb);
@@ -2105,6 +2164,29 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rollout_kernel launch");
+    advance(h, K, st);
+    return MGX_OK;
+}
+
+int mgx_rollout_lists(mgx_handle *h, const int32_t *action_id, int per_step, const int32_t *lists, int32_t n_lists, int32_t list_len,
+                      int32_t K, double *reward, uint8_t *done, double *soc_trace, uint32_t *status_trace, double *ret_acc,
+                      double *log, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !action_id || !lists) return fail(MGX_ERR_INVALID, "mgx_rollout_lists: NULL argument");
+    if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_lists: K must be positive");
+    if (n_lists <= 0 || list_len <= 0 || list_len > 3 * MGX_MAX_INSTANCES)
+        return fail(MGX_ERR_INVALID, "mgx_rollout_lists: need n_lists > 0 and list_len in [1, %d]", 3 * MGX_MAX_INSTANCES);
+    if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
+        return fail(MGX_ERR_RANGE, "mgx_rollout_lists: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, step_limit(h));
+    hipStream_t st = (hipStream_t)stream;
+    const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
+    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+        MGX_DISPATCH_F(h->flags, (step_k_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
+                                      k, nullptr, lists, n_lists, list_len, action_id, per_step, t_arg(h), K, 0, fo)));
+    });
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "step_k_multi_kernel launch");
     advance(h, K, st);
     return MGX_OK;
 }

@@ -372,6 +372,39 @@ class StepEngine:
                    n_lists, K, _ptr(r), _ptr(d), _ptr(s), _ptr(g), _ptr(ret_acc), _ptr(lg))
         return res
 
+    def rollout_lists(self, action_id, lists, K, reward=True, done=False, soc_trace=False, status_trace=False, ret_acc=None,
+                      log=False, out=None):
+        """K fused discrete steps with priority lists over module instances (``mgx_rollout_lists``; every layout).
+        ``action_id`` int32 [K, N] (an id per step) or [N] (one fixed list per grid); ``lists`` as for ``expand_lists``."""
+        out = out or {}
+        K = int(K)
+        if action_id.dtype != torch.int32 or action_id.device != self.device or not action_id.is_contiguous() \
+                or tuple(action_id.shape) not in ((K, self.N), (self.N,)):
+            raise ValueError(f"action_id must be a contiguous int32 tensor [{K}, {self.N}] or [{self.N}] on {self.device}")
+        if lists.dtype != torch.int32 or lists.dim() != 3 or lists.shape[2] != 3 or lists.device != self.device \
+                or not lists.is_contiguous():
+            raise ValueError(f"lists must be a contiguous int32 tensor [n_lists, list_len, 3] on {self.device}")
+        res = {}
+
+        def buf(name, want, *shape, dtype=torch.float64):
+            if not want:
+                return None
+            t = out.get(name)
+            if t is None:
+                t = self._empty(*shape, dtype=dtype)
+            res[name] = t
+            return t
+        r = buf("reward", reward, K, self.N)
+        d = buf("done", done, K, self.N, dtype=torch.uint8)
+        s = buf("soc_trace", soc_trace and self.layout.has_battery, K, self.N)
+        g = buf("status_trace", status_trace and self.layout.has_genset, K, self.N, dtype=torch.int32)
+        lg = buf("log", log, K, self.log_dim, self.N)
+        if ret_acc is not None:
+            res["ret_acc"] = ret_acc
+        self._call(self._lib.mgx_rollout_lists, _ptr(action_id), int(action_id.dim() == 2), _ptr(lists), int(lists.shape[0]),
+                   int(lists.shape[1]), K, _ptr(r), _ptr(d), _ptr(s), _ptr(g), _ptr(ret_acc), _ptr(lg))
+        return res
+
     def expand_discrete(self, action_id, table, out=None):
         """priority-list ids [N] (int32) -> unnormalised control [N, A]; ``table`` int32 [n_actions, 3, 2]."""
         if action_id.dtype != torch.int32 or tuple(action_id.shape) != (self.N,) or action_id.device != self.device:

@@ -9,7 +9,9 @@ streams only pay for many tiny buckets.
 import numpy as np
 import torch
 
+from . import _lib
 from .batch import MicrogridBatch
+from .engine import _raw_stream
 from .envs import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv
 from .scenario import bucket_by_layout
 
@@ -134,7 +136,6 @@ class BucketedFleet:
         observation views the step returns and the ring state after it.  A fleet that walks its rings in lock-step meets
         3 K such situations, so after the first lap a step costs a dictionary look-up instead of ~25 us of bookkeeping."""
         import ctypes as C
-        from . import _lib
         states, slot = key
         n = len(self.envs)
         items = (_lib.FleetItem * n)()
@@ -169,8 +170,6 @@ class BucketedFleet:
         return items, obs_l, next_states, fixed_out
 
     def _step_fused(self, actions, normalized=True):
-        from . import _lib
-        from .engine import _raw_stream
         envs = self.envs
         R = self.reuse_outputs
         if R and self._out_reward is None:

@@ -192,21 +192,19 @@ class RuleBasedControl:
         parts = {}
         done = 0
         if L.multi:
-            # several modules of a kind per grid: no fused kernel for that layout -- one expand + step per env-step
-            ids = self._ids_dev.to(torch.int32)
-            rows = {"reward": [], "soc_trace": [], "log": []}
-            for _ in range(total):
-                control = self.engine.expand_lists(ids, self._lists) if self._instances \
-                    else self.engine.expand_discrete(ids, self._table)
-                _, r, _, lg = self.engine.step(control, normalized=False, want_obs=False, want_log=log)
-                ret += r
-                if reward:
-                    rows["reward"].append(r)
-                if soc_trace and L.has_battery:
-                    rows["soc_trace"].append(self.batch.cols["soc"].clone())
-                if log:
-                    rows["log"].append(lg)
-            res = {name: torch.stack(v) for name, v in rows.items() if v}
+            # several modules of a kind per grid: the general path's K-step kernel with the lists over module instances
+            # (a single-instance table is the same thing with instance 0 everywhere)
+            lists = self._lists if self._instances else torch.as_tensor(
+                lists_array([tuple((m, 0, a) for m, a in pl) for pl in self.actions_list]), device=self.batch.device)
+            ids = self._ids_dev.to(torch.int32).contiguous()
+            while done < total:
+                k = min(chunk, total - done)
+                out = self.engine.rollout_lists(ids, lists, k, reward=reward, soc_trace=soc_trace, log=log, ret_acc=ret)
+                for name, v in out.items():
+                    if name != "ret_acc":
+                        parts.setdefault(name, []).append(v)
+                done += k
+            res = {name: torch.cat(v) for name, v in parts.items()}
             res["episode_return"] = ret
             return res
         while done < total:

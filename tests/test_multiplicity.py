@@ -228,3 +228,53 @@ def test_multi_instance_batches_vs_oracle(mix, device, oracle):
         for k in range(T):
             assert r[k, j] == om.run(om.populate_action(plist), False).common.reward, (j, k)
     denv.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mix", [(2, 2, 1, 1, 1, 0, False), (1, 1, 1, 3, 2, 0, False), (0, 3, 2, 1, 2, 1, True)])
+def test_fused_launches_on_the_general_path(mix, device):
+    """mgx_step_k and mgx_rollout_lists on layouts with several modules of a kind (a K-step loop around the general step)
+    == K single steps / K discrete env steps: rewards, done, log rows, traces, final state; also split over two shards."""
+    import torch
+    from pymgrid_amd import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv, MicrogridBatch
+    from pymgrid_amd.priority_list import lists_array
+    n_gen, n_bat, n_grid, n_load, n_pv, H, grid_first = mix
+    rs = np.random.RandomState(77 + sum(mix))
+    T, N, K = 40, 600, 24
+    grids = [_random_multi_grid(rs, T, n_gen, n_bat, n_grid, n_load, n_pv, H, grid_first) for _ in range(N)]
+    make = lambda: MicrogridBatch.from_grids(grids, device=device)
+    ref, fused, sharded = BatchedMicrogridEnv(make(), log=True), BatchedMicrogridEnv(make()), BatchedMicrogridEnv(make())
+    A = ref.layout.action_dim
+    acts = torch.rand(K, N, A, dtype=torch.float64, device=device)
+    out = fused.engine.step_k(acts, reward=True, done=True, soc_trace=True, status_trace=True, log=True)
+    sharded.engine.set_shards(2)
+    out2 = sharded.engine.step_k(acts, reward=True, log=True)
+    sharded.engine.join(); sharded.engine.set_shards(1)
+    for k in range(K):
+        _, reward, done, info = ref.step(acts[k])
+        assert torch.equal(out["reward"][k], reward) and torch.equal(out2["reward"][k], reward), k
+        assert torch.equal(out["done"][k].view(torch.bool), done)
+        assert torch.equal(out["log"][k], info["log"]) and torch.equal(out2["log"][k], info["log"]), k
+        if n_bat:
+            assert torch.equal(out["soc_trace"][k], ref.batch.cols["soc"].reshape(n_bat, N)[0])
+        if n_gen:
+            assert torch.equal(out["status_trace"][k], ref.batch.cols["gen_status"].reshape(n_gen, N)[0])
+    for name in ("charge", "soc", "gen_status"):
+        if name in ref.batch.cols:
+            assert torch.equal(fused.batch.cols[name], ref.batch.cols[name]) and torch.equal(sharded.batch.cols[name], ref.batch.cols[name])
+    assert fused.engine.current_step == ref.engine.current_step == K
+    for e in (ref, fused, sharded):
+        e.close()
+    # discrete: an id per step and grid through mgx_rollout_lists == the env's expand + step
+    denv, roll = DiscreteBatchedMicrogridEnv(make(), remove_redundant_gensets=False), DiscreteBatchedMicrogridEnv(make(), remove_redundant_gensets=False)
+    lists = denv._lists if denv._instances else torch.as_tensor(
+        lists_array([tuple((m, 0, a) for m, a in pl) for pl in denv.actions_list]), device=device)
+    ids = torch.randint(0, denv.action_space.n, (K, N), dtype=torch.int32, device=device)
+    res = roll.engine.rollout_lists(ids, lists, K, reward=True, done=True)
+    for k in range(K):
+        _, reward, done, _ = denv.step(ids[k])
+        assert torch.equal(res["reward"][k], reward), k
+    for name in ("charge", "soc", "gen_status"):
+        if name in denv.batch.cols:
+            assert torch.equal(roll.batch.cols[name], denv.batch.cols[name])
+    denv.close(); roll.close()
