@@ -240,9 +240,9 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist):
         ach = alg / (gpu / steps) / 1e9
         traffic = None
         try:                                              # PMC bytes of the same fleet shape, if a profile of it is committed
-            tf = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic_fleet.json")))
-            if (tf["grids_per_gpu"], tf["obs_prefetch"], tf["rows"], tf.get("refill")) == \
-                    (3 * per, K_ring, "float64" if dt == torch.float64 else "float32", fleet.refill):
+            rows = "float64" if dt == torch.float64 else "float32"
+            tf = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic_fleet.json" if rows == "float64" else "traffic_fleet_f32.json")))
+            if (tf["grids_per_gpu"], tf["obs_prefetch"], tf["rows"], tf.get("refill")) == (3 * per, K_ring, rows, fleet.refill):
                 traffic = tf["hbm_bytes_per_fleet_step"]
         except (OSError, ValueError, KeyError):
             pass
