@@ -1673,6 +1673,9 @@ static int launch_windows(mgx_handle *h, int32_t ahead, int32_t K, void *ring, h
 int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream)
 {
     g_err[0] = 0;
+    // a prefetch still in flight may be writing this very ring (a reset in the middle of an episode: the ring being refilled
+    // now can be the one the last mgx_observe_windows_ahead targets): its stale rows must not land on top of the new ones
+    if (h && h->prefetch_pending) { if (int rc = mgx_prefetch_wait(h, stream)) return rc; }
     return launch_windows(h, 0, K, ring, (hipStream_t)stream, "mgx_observe_windows");
 }
 

@@ -286,6 +286,32 @@ def test_prefetched_observations_stay_valid_for_k_steps(device):
     ref.close(); pre.close()
 
 
+def test_reset_while_a_prefetch_into_the_same_ring_is_in_flight(device):
+    """After exactly 2 K steps an env sits at the start of ring 2 and the prefetch of ring 0 has just been launched; a reset at
+    that moment refills ring 0 on the caller's stream.  The stale prefetch must not land on top of it (mgx_observe_windows
+    waits for it): every observation of the new episode equals the per-step kernel's."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    from pymgrid_amd.generator import generate
+    N, T, H, K = 60_000, 200, 24, 16
+    make = lambda: generate(N, n_steps=T, seed=9, arch="genset+battery+grid", horizon=H, device=device)
+    ref, pre = BatchedMicrogridEnv(make(), obs_prefetch=0), BatchedMicrogridEnv(make(), obs_prefetch=K)
+    a = torch.rand(N, 4, dtype=torch.float64, device=device)
+    for rep in range(3):
+        ref.reset(); pre.reset()
+        for _ in range(2 * K):
+            pre.step(a)
+        assert (pre._ring_idx, pre._ring_pos) == (2, 0)
+        obs = pre.reset(7 + rep)                            # no synchronisation in between
+        for e in (ref,):
+            e.engine.batch.load_state(pre.batch.state())
+        o_ref = ref.reset(7 + rep)
+        assert torch.equal(obs, o_ref), rep
+        for k in range(K + 2):
+            assert torch.equal(pre.step(a)[0], ref.step(a)[0]), (rep, k)
+        ref.engine.batch.load_state(pre.batch.state())
+    ref.close(); pre.close()
+
+
 def _toy_grid(rs, T, genset, battery, grid, horizon=0):
     g = dict(load_ts=50 * rs.rand(T) + 1, pv_ts=40 * rs.rand(T) * (rs.rand(T) > 0.3), horizon=horizon, final_step=T, initial_step=0,
              unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0))
