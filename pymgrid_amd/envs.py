@@ -187,6 +187,10 @@ class BatchedMicrogridEnv:
             raise RuntimeError("this env belongs to a fused BucketedFleet: its ring depth is fixed")
         self.obs_prefetch = K
         L = self.layout
+        if self._rings is not None:
+            # a prefetch may still be writing the old rings on the engine's prefetch stream, which the caching allocator knows
+            # nothing about: the caller's stream waits for it before the memory can be handed out again
+            self.engine.prefetch_wait()
         self._ring = self._rings = None
         self.engine.set_obs_state_only(bool(K))
         if K:
@@ -395,7 +399,15 @@ class BatchedMicrogridEnv:
         return out
 
     def close(self):
+        # mgx_destroy drains the engine's prefetch stream while the rings it may still be writing are alive
         self.engine.close()
+        self._ring = self._rings = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
