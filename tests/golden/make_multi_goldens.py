@@ -247,6 +247,20 @@ def discrete_case(out, ci, g, n_gen, n_bat, n_grid, A):
         out[f"c{ci}_rbc_list"] = np.array([(kind_id[el.module[0]], el.module[1], el.action) for el in rbc._priority_list], np.int32)
         log = rbc.run()
         out[f"c{ci}_rbc_reward"] = log[("balance", 0, "reward")].values.astype(np.float64)
+        # reward shapers on several batteries / renewables (reward_shaping/*.py sum over the module instances); the balancing
+        # module under the name the scenario files give it ("unbalanced_energy": the name BatteryDischargeShaper looks up)
+        from pymgrid.microgrid.reward_shaping import BatteryDischargeShaper, PVCurtailmentShaper
+        for tag, shaper in (("bat", BatteryDischargeShaper()), ("pv", PVCurtailmentShaper())):
+            mods = build(g) + [("unbalanced_energy", UnbalancedEnergyModule(raise_errors=False, loss_load_cost=g["loss_load_cost"],
+                                                                             overgeneration_cost=g["overgeneration_cost"]))]
+            senv = DiscreteMicrogridEnv(mods, add_unbalanced_module=False, reward_shaping_func=shaper)
+            senv.reset()
+            sids = np.random.RandomState(7400 + ci).randint(0, senv.action_space.n, size=40)
+            shaped = np.zeros(40)
+            for k in range(40):
+                _, shaped[k], _, _ = senv.step(int(sids[k]))
+            out[f"c{ci}_shape_{tag}_ids"] = sids.astype(np.int32)
+            out[f"c{ci}_shape_{tag}"] = shaped
         return int(env.action_space.n)
 
 

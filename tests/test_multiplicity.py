@@ -278,3 +278,26 @@ def test_fused_launches_on_the_general_path(mix, device):
         if name in denv.batch.cols:
             assert torch.equal(roll.batch.cols[name], denv.batch.cols[name])
     denv.close(); roll.close()
+
+
+@pytest.mark.gpu
+def test_reward_shapers_on_several_batteries_and_renewables_vs_reference(device):
+    """BatteryDischargeShaper / PVCurtailmentShaper sum over the module instances (reward_shaping/base.py:10-16; the battery sum
+    falls back to 0 as soon as one battery charged): shaped rewards of 40 discrete steps == the reference's."""
+    import torch
+    from pymgrid_amd import DiscreteBatchedMicrogridEnv, MicrogridBatch
+    from pymgrid_amd.trajectory import BatteryDischargeShaper, PVCurtailmentShaper
+    n = 0
+    for ci, p, mt, z in multi_cases():
+        if f"c{ci}_shape_bat" not in z:
+            continue
+        for tag, shaper in (("bat", BatteryDischargeShaper()), ("pv", PVCurtailmentShaper())):
+            env = DiscreteBatchedMicrogridEnv(MicrogridBatch.from_grids([p, p], device=device), reward_shaping_func=shaper)
+            env.reset()
+            ids = z[f"c{ci}_shape_{tag}_ids"]
+            for k in range(len(ids)):
+                _, reward, _, _ = env.step(torch.full((2,), int(ids[k]), dtype=torch.int32, device=device))
+                assert reward[0].item() == z[f"c{ci}_shape_{tag}"][k] == reward[1].item(), (ci, tag, k)
+            env.close()
+            n += 1
+    assert n >= 8
