@@ -1,10 +1,12 @@
 """Heterogeneous fleets (BASELINE config 5): microgrids with different module sets / horizons cannot share one SoA
 batch (a batch has one layout = one kernel specialisation), so a fleet is bucketed by layout
 (``scenario.bucket_by_layout``) and every bucket gets its own ``MicrogridBatch`` + engine.  Buckets are independent.
-They are issued back to back on the caller's stream by default: at 10^4..10^5 grids per bucket the kernels fill the chip
-and the step is bound by the host's launch rate, where per-bucket HIP streams (``streams=True``: fork / join events
-around every bucket) were measured 2.7x SLOWER (103 vs 39 us per fleet step, 3 buckets of 33k grids, H = 24);
-streams only pay for many tiny buckets.
+
+A fleet step is ONE call of the C ABI (``mgx_fleet_step``) and one ``fleet_step_kernel`` launch for all layouts; the
+observation rings of the buckets are renewed ahead of time on the engines' prefetch streams (``refill="ahead"``, K = 16) or as
+chunks inside the step launches (``refill="chunks"``): 29.5-32 / 33-35 us per 100 000-grid step at H = 24.  Per-bucket HIP
+streams (``streams=True``: fork / join events around every bucket, one ``env.step`` each) were measured 2.7x slower than
+back-to-back launches at 33k grids per bucket (host-bound) and only pay for many tiny buckets.
 """
 import numpy as np
 import torch
