@@ -59,6 +59,7 @@ class StepEngine:
         if obs_dtype != torch.float64:
             self.set_obs_dtype(obs_dtype)
         self.action_dtype = torch.float64
+        self._action_shape = (self.N, self.action_dim)
         if action_dtype != torch.float64:
             self.set_action_dtype(action_dtype)
 

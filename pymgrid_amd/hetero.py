@@ -169,7 +169,15 @@ class BucketedFleet:
                 r, d = self._out_reward[k][slot], self._out_done[k][slot]
                 it.reward, it.done = r.data_ptr(), d.data_ptr()
                 fixed_out.append((r, d.view(torch.bool)))
-        return items, obs_l, next_states, fixed_out
+        # fast path: everything a step returns is known in advance (rotating output buffers, observations out of the rings or
+        # none at all, no log rows): the step only has to hand in the action pointers
+        fast = None
+        if slot is not None and not any(fresh for _, fresh in obs_l) \
+                and not any(env._keep_log or env._obs_index is not None for env in self.envs):
+            sync = [(env, st[0], st[1], env._rings[st[0]]) for env, st in zip(self.envs, next_states) if st is not None]
+            fast = ([o for o, _ in obs_l], [r for r, _ in fixed_out], [d for _, d in fixed_out], sync,
+                    (tuple(next_states), (slot + 1) % self.reuse_outputs))
+        return items, obs_l, next_states, fixed_out, fast
 
     def _step_fused(self, actions, normalized=True):
         envs = self.envs
@@ -182,7 +190,9 @@ class BucketedFleet:
         plan = self._plans.get(key)
         if plan is None:
             plan = self._plans[key] = self._plan(key)
-        items, obs_plan, next_states, fixed_out = plan
+        items, obs_plan, next_states, fixed_out, fast = plan
+        if fast is not None:
+            return self._step_fast(items, fast, actions, normalized)
         obs_l, reward_l, done_l, info_l = [], [], [], []
         for k, (it, env, a) in enumerate(zip(items, envs, actions)):
             e = env.engine
@@ -232,6 +242,37 @@ class BucketedFleet:
                 env._log_rows.append(info_l[k]["log"])
                 env._shaped_rows.append(reward_l[k].clone())
         return obs_l, reward_l, done_l, info_l
+
+    def _step_fast(self, items, fast, actions, normalized):
+        obs_l, reward_l, done_l, sync, _ = fast
+        k, keep = 0, []                           # keep: converted ids stay alive until the launch has been issued
+        for env in self.envs:
+            a = actions[k]
+            it = items[k]
+            if it.table:                          # discrete bucket: priority-list ids
+                if not (torch.is_tensor(a) and a.dtype == torch.int32 and a.is_contiguous() and a.is_cuda and a.shape == (env.n_grids,)):
+                    a = torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a), device=env.batch.device).to(torch.int32).contiguous()
+                    keep.append(a)
+                it.action_id = a.data_ptr()
+            else:
+                e = env.engine
+                if not (a.dtype == e.action_dtype and a.shape == e._action_shape and a.is_contiguous() and a.is_cuda):
+                    a = e._check_actions(a, ())   # raises with the full message
+                it.actions = a.data_ptr()
+            k += 1
+        e0 = self.envs[0].engine
+        idx = e0._dev_index
+        if e0._only_device or torch.cuda.current_device() == idx:
+            rc = e0._lib.mgx_fleet_step(items, k, 1 if normalized else 0, _raw_stream(idx))
+        else:
+            with torch.cuda.device(idx):
+                rc = e0._lib.mgx_fleet_step(items, k, 1 if normalized else 0, _raw_stream(idx))
+        if rc:
+            _lib.check(rc)
+        self._n_steps += 1
+        for env, ring_idx, ring_pos, ring in sync:
+            env._ring_idx, env._ring_pos, env._ring = ring_idx, ring_pos, ring
+        return list(obs_l), list(reward_l), list(done_l), [{} for _ in reward_l]
 
     def sample_action(self, generator=None):
         return [env.sample_action(generator=generator) for env in self.envs]

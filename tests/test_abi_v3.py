@@ -420,3 +420,35 @@ def test_edge_shapes_of_the_new_entry_points(device, oracle):
         env.engine.reset_windows(torch.zeros(5, dtype=torch.int32, device=device), None, 31)     # longer than the env's window
     assert e.value.code == MGX_ERR_INVALID
     env.close()
+
+
+@pytest.mark.parametrize("discrete,refill,K", [(False, "ahead", 4), (False, "chunks", 4), (True, "ahead", 8), (False, "ahead", 0)])
+def test_fleet_fast_path_with_rotating_outputs(discrete, refill, K, pymgrid25, device):
+    """reuse_outputs = R without log rows: the step's returns are prepared per ring position (plan cache) and a step only hands
+    in the action pointers.  Same observations / rewards / done as per-env steps; a returned reward view stays intact for
+    R - 1 further steps; ids given as numpy arrays are converted."""
+    from pymgrid_amd.hetero import BucketedFleet
+    R = 6
+    kw = dict(device=device, observations=True, obs_prefetch=K, discrete=discrete)
+    if discrete:
+        kw["remove_redundant_gensets"] = False
+    fast, plain = BucketedFleet(pymgrid25, refill=refill, reuse_outputs=R, **kw), BucketedFleet(pymgrid25, fused=False, **kw)
+    fast.reset(); plain.reset()
+    g = torch.Generator(device=device); g.manual_seed(3)
+    held = []
+    for k in range(3 * max(K, 4) + 5):
+        acts = fast.sample_action(generator=g)
+        given = [a.cpu().numpy() for a in acts] if (discrete and k % 3 == 0) else acts
+        r1 = fast.step(given)
+        assert fast._plans and all((p[4] is not None) == (K > 0) for p in fast._plans.values())   # fast path unless rows are fresh buffers
+        r2 = [env.step(a) for env, a in zip(plain.envs, acts)]
+        for b in range(len(fast.envs)):
+            assert torch.equal(r1[0][b], r2[b][0]) and torch.equal(r1[1][b], r2[b][1]) and torch.equal(r1[2][b], r2[b][2]), (k, b)
+        held.append((r1[1][0], r1[1][0].clone()))
+        if len(held) >= R:
+            view, snap = held[-(R - 1)]
+            assert torch.equal(view, snap), k
+    for e1, e2 in zip(fast.envs, plain.envs):
+        assert e1.current_step == e2.current_step
+        assert K == 0 or (e1._ring_idx, e1._ring_pos) == (e2._ring_idx, e2._ring_pos)
+    fast.close(); plain.close()
