@@ -357,8 +357,10 @@ def test_error_paths(pymgrid25, device):
     multi = dict(load_ts=z["c1_load_ts"], pv_ts=z["c1_pv_ts"], final_step=100, horizon=0,
                  unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=2.0))
     eng = StepEngine(_batch([multi], device))
-    with pytest.raises(MgxError) as e:                                             # fused path: one load + one pv only
-        eng.step_k(torch.zeros(4, 1, 0, dtype=torch.float64, device=device))
+    out = eng.step_k(torch.zeros(4, 1, 0, dtype=torch.float64, device=device))     # K-step loop of the general path
+    assert out["reward"].shape == (4, 1) and eng.current_step == 4
+    with pytest.raises(MgxError) as e:                                             # window prefetch: one module of every kind only
+        eng.observe_windows(K=4)
     assert e.value.code == 2
     eng.close()
     with pytest.raises(ValueError):
