@@ -10,7 +10,7 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("MGX_LIB") or os.path.join(_PKG, "libmgx.so")   # MGX_LIB: A/B kernel variants
-SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("mgx_kernels.hip", "mgx_core.hpp")] + \
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("mgx_abi.hip", "mgx_kernels.hpp", "mgx_core.hpp")] + \
           [os.path.join(_ROOT, "include", "mgx.h")]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",

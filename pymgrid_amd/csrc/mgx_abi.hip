@@ -1,1193 +1,8 @@
-// mgx_kernels.hip -- HIP kernels of the batched microgrid-step engine, written for gfx950 (MI355X, CDNA4).
-//
-// Execution shape: one lane per microgrid, 64-lane wavefronts, 256-thread workgroups, SoA columns so every
-// global access of a wave is one contiguous 512-byte segment.  The path is element-wise and HBM-bound
-// (~40 useful flops vs 189 B per env-step): no MFMA, no LDS tiling of the physics.
-// LDS + wavefront shuffles are used where data actually crosses lanes: the [N, D] observation tile
-// transpose and the metrics column sums.
-//
-// Block b runs on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch"): because block b always owns grids
-// [256 b, 256 b + 256), the parameter and state columns of a grid stay in the SAME XCD's 4 MiB L2 across
-// the per-step launches -- the blockIdx -> data mapping is deliberately launch-invariant.
-#include "mgx_core.hpp"
+// mgx_abi.hip -- host side of libmgx.so: the C ABI declared in include/mgx.h (handles, argument checks, launch shapes,
+// shard / prefetch streams) over the kernels of mgx_kernels.hpp and the per-grid device arithmetic of mgx_core.hpp.
+// One translation unit: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared mgx_abi.hip -o libmgx.so
+#include "mgx_kernels.hpp"
 
-#include <type_traits>
-
-namespace mgx {
-
-#ifndef MGX_BLOCK
-#define MGX_BLOCK 256
-#endif
-constexpr int BLOCK = MGX_BLOCK;
-#ifndef MGX_RING
-#define MGX_RING 4          // register-ring depth of the fused kernel (steps of loads in flight)
-#endif
-#ifndef MGX_BLOCK_K
-#define MGX_BLOCK_K 256     // workgroup size of the fused kernel
-#endif
-constexpr int BLOCK_K = MGX_BLOCK_K;
-#ifndef MGX_RING_ROLLOUT
-#define MGX_RING_ROLLOUT 8  // ring depth of the discrete rollout kernel for layouts without a GridModule (a slot is two series
-#endif                      // values + an id byte; 58.2 vs 61.3 us per 64 steps against depth 4 once the loop was specialised:
-                            // profiles/r02/exp_rollout_gpb_ring.txt); with a GridModule (six values per slot) the depth stays 4
-
-// ------------------------------------------------------------------------------------------------------
-// Single step: Microgrid.run for N grids (microgrid.py:227-325) + optional obs (base.py:205-209) + log.
-// ------------------------------------------------------------------------------------------------------
-// body of one step of grid i (shared by step_kernel and fleet_step_kernel)
-template <int F>
-__device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict__ actions, int32_t t, int normalized,
-                                          double *__restrict__ reward, uint8_t *__restrict__ done, void *__restrict__ obs,
-                                          double *__restrict__ log, int64_t i)
-{
-    // all loads first (independent, one latency round), then the arithmetic
-    Params p; State s; Inputs in; Outputs o; Derived d;
-    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t, in);
-    else load_inputs<F>(a.c, (const double *)actions, a.N, i, t, in);
-    load_state<F>(a.c, i, log != nullptr, s);
-    load_params<F>(a.c, i, p);
-    derive<F>(p, d);
-    const bool gen_instant = genset_wave_is_instant<F>(p, s);
-
-    step_core<F>(p, d, s, in, normalized != 0, true, gen_instant, o);
-
-    store_state<F>(a.c, i, s);
-    reward[i] = shaped_reward<F>(a.shaper, o);
-    // _done(): t >= final_step - 1, evaluated before the counter moves (base_timeseries_module.py:124-125)
-    if (done) done[i] = done_at(a, i, t);
-    if (log) store_log<F>(log + i, a.N, o, s.status);
-    // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
-    // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
-    if (obs) {
-        if (a.obs_state_only) {                 // the window columns of this row were prefetched (obs_windows_k_kernel)
-            if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
-            else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
-        } else if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
-        else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
-    }
-}
-
-template <int F>
-__global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
-                                                     int normalized, double *__restrict__ reward,
-                                                     uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                     double *__restrict__ log)
-{
-    t = resolve_t(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < a.g1) step_body<F>(a, actions, t, normalized, reward, done, obs, log, i);
-    advance_counter_in_kernel(a, 1);
-}
-
-// Dry run of one step: which requests would the reference refuse with raise_errors=True (base_module.py:79-93,213-224,
-// 265-270)?  The step arithmetic runs on a register copy of the state; only the violations mask leaves the kernel.
-template <int F>
-__global__ __launch_bounds__(BLOCK) void check_kernel(const KArgs a, const void *__restrict__ actions, int32_t t, int normalized,
-                                                      uint32_t *__restrict__ violations)
-{
-    t = resolve_t(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.g1) return;
-    Params p; State s; Inputs in; Outputs o; Derived d;
-    load_state<F>(a.c, i, true, s);
-    load_params<F>(a.c, i, p);
-    derive<F>(p, d);
-    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t, in);
-    else load_inputs<F>(a.c, (const double *)actions, a.N, i, t, in);
-    step_core<F>(p, d, s, in, normalized != 0, false, false, o);
-    violations[i] = o.violations;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// K fused steps: parameters + state live in registers; actions / series rows stream through a U-slot register
-// ring (slot u is refilled with step k+U as soon as step k has been consumed, so U steps of loads are always in
-// flight).  Every [K, N] stream is addressed as base + (k*N + i): one shared 64-bit lane offset, SGPR bases.
-// ------------------------------------------------------------------------------------------------------
-struct FusedOut {
-    double *reward;
-    uint8_t *done;
-    double *soc_trace;
-    uint32_t *status_trace;
-    double *ret_acc;
-    double *log;
-};
-
-// One ring slot: the controls stay in their storage type until the step consumes them (widening a float at load time
-// makes the prefetch wait for its own data: measured 86 instead of 77 us per launch).
-template <typename AT>
-struct RawInputs {
-    AT a_goal, a_gen, a_bat, a_grid;
-    double load, pv, g_pimp, g_pexp, g_co2, g_stat;
-};
-
-template <int F, typename AT>
-__device__ __forceinline__ Inputs widen(const RawInputs<AT> &r)
-{
-    Inputs in;
-    if constexpr (F & F_GENSET) { in.a_goal = (double)r.a_goal; in.a_gen = (double)r.a_gen; }
-    if constexpr (F & F_BATTERY) in.a_bat = (double)r.a_bat;
-    if constexpr (F & F_GRID) {
-        in.a_grid = (double)r.a_grid;
-        in.g_pimp = r.g_pimp; in.g_pexp = r.g_pexp; in.g_co2 = r.g_co2; in.g_stat = r.g_stat;
-    }
-    in.load = r.load; in.pv = r.pv;
-    return in;
-}
-
-template <int F, typename AT>
-__device__ __forceinline__ void load_inputs_at(const AT *__restrict__ act, const double *__restrict__ lts,
-                                               const double *__restrict__ pts, const double *__restrict__ gts,
-                                               int64_t N, int64_t i, int64_t off, RawInputs<AT> &in)
-{
-    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const AT *a = act + off * A;
-    int k = 0;
-    if constexpr (F & F_GENSET) { in.a_goal = a[k]; in.a_gen = a[k + 1]; k += 2; }
-    if constexpr (F & F_BATTERY) { in.a_bat = a[k]; k += 1; }
-    if constexpr (F & F_GRID) { in.a_grid = a[k]; k += 1; }
-    in.load = lts[off];
-    in.pv = pts[off];
-    if constexpr (F & F_GRID) {
-        const double *g = gts + (4 * off - 3 * i);                       // off = k*N + i  ->  (k*4)*N + i
-        in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
-    }
-}
-
-// RICH = false: the launch writes neither log rows nor the status trace -- compiled out, together with every value only
-// they consume (balance sums, co2, the violations mask): the lean form is the hot one (reward / done / SoC streams).
-template <int F, int U, typename AT, bool RICH>
-__global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT *__restrict__ actions, int32_t t0,
-                                                         int32_t K, int normalized, const FusedOut out_rt, int32_t gpb)
-{
-    FusedOut out = out_rt;
-    if constexpr (!RICH) { out.log = nullptr; out.status_trace = nullptr; }
-    const int32_t K_launch = K;          // what the host asked for (the counter always moves by this much)
-    t0 = resolve_t(a, t0);
-    K = resolve_k(a, t0, K);
-    // gpb = grids per workgroup (<= BLOCK_K, multiple of 16 = one 128-B line of doubles): chosen by the host so that
-    // the busiest CU streams as few grids as possible (fused_grids_per_block)
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * gpb + threadIdx.x;
-    if ((int32_t)threadIdx.x >= gpb || i >= a.g1) return;
-    const int64_t N = a.N;
-    Params p; State s; Derived d;
-    load_state<F>(a.c, i, out.log != nullptr, s);
-    load_params<F>(a.c, i, p);
-    derive<F>(p, d);
-    // series bases moved to row t0 once (scalar), so row k of this launch is base + k*N
-    const double *__restrict__ lts = a.c.load_ts + (int64_t)t0 * N;
-    const double *__restrict__ pts = a.c.pv_ts + (int64_t)t0 * N;
-    const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
-    const bool norm = normalized != 0;
-    const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
-    const bool gen_instant = genset_wave_is_instant<F>(p, s);
-    const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;      // done <=> k >= k_done
-    double ret = 0.0;
-
-    RawInputs<AT> ring[U];
-#pragma unroll
-    for (int u = 0; u < U; u++)
-        if (u < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
-
-    int64_t off = i;                                         // k*N + i
-    for (int32_t k0 = 0; k0 < K; k0 += U) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int32_t k = k0 + u;
-            if (k < K) {
-                const Inputs in = widen<F>(ring[u]);
-                if (k + U < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
-                Outputs o;
-                step_core<F>(p, d, s, in, norm, want_soc, gen_instant, o);
-                const double r = shaped_reward<F>(a.shaper, o);
-                if (out.reward) out.reward[off] = r;
-                if (out.done) out.done[off] = (uint8_t)(k >= k_done);
-                if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
-                if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
-                if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
-                ret += r;
-                off += N;
-            }
-        }
-    }
-    if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
-    store_state<F>(a.c, i, s);
-    if (out.ret_acc) out.ret_acc[i] += ret;
-    advance_counter_in_kernel(a, K_launch);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Observation of the current state (reset(), or after step_k).
-// ------------------------------------------------------------------------------------------------------
-template <int F>
-__global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t, void *__restrict__ obs)
-{
-    t = resolve_t_obs(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.g1) return;
-    Params p; State s;
-    load_state<F>(a.c, i, true, s);
-    load_params<F>(a.c, i, p);
-    if (a.obs_state_only) {
-        if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
-        else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
-    } else if (a.obs_f32) observe_row_h0<F>(a, i, t, p, s, (float *)obs + i * a.obs_dim);   // H == 0 only (host dispatches)
-    else observe_row_h0<F>(a, i, t, p, s, (double *)obs + i * a.obs_dim);
-}
-
-// Observation rows for H > 0 (obs_rows_wave_kernel below).  Every cache line of obs is written whole by one wave
-// (partial-line writes from different waves / XCDs cost read-modify-write at the memory side; measured 3x slower).
-struct WindowPlan {
-    int32_t grid_col_base;   // first obs column of the grid window
-    int32_t ld;              // LDS row pitch in doubles (odd: conflict-free column writes)
-    int32_t group;           // grids per wave tile: 16, or 8 / 4 / 2 / 1 when a 16-row tile would not fit the LDS
-};
-
-// Wave-private row tiles: one 64-lane workgroup per G = plan.group (16) grids.  The wave gathers the windows of its
-// grids into an LDS tile [G][LD] (lane = grid x horizon phase), then writes the G rows -- G*D consecutive doubles of
-// obs -- with full-wave 16-byte non-temporal stores (the rows are write-once; keeping them out of the caches leaves
-// the window rows, which the next 24 steps read again, resident in the 256 MB MALL: measured 65 -> 53 us at D = 156).
-// No workgroup is ever waiting for another wave's phase, so load, arithmetic and store phases of different waves
-// overlap on a CU (8 tiles of 20 KB per CU at D = 156).
-template <int F, bool NOISE, typename OT>
-__global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const WindowPlan plan, int32_t t,
-                                                           OT *__restrict__ obs)
-{
-    t = resolve_t_obs(a, t);
-    extern __shared__ double tile_raw[];                // [plan.group][plan.ld] of OT
-    OT *tile = reinterpret_cast<OT *>(tile_raw);
-    const int lane = threadIdx.x;
-    const int32_t G = plan.group, Q = 64 / G;
-    const int32_t g = lane & (G - 1), q = lane / G;
-    const int64_t g0 = (int64_t)blockIdx.x * G;
-    const int64_t N = a.N;
-    const int32_t W = 1 + a.H, D = a.obs_dim, LD = plan.ld;
-    const int64_t i = g0 + g, ic = i < N ? i : g0;
-    OT *row = tile + g * LD;
-    const int32_t slots = OBS_JB * Q;
-    const int32_t W_pad = (W + slots - 1) / slots * slots;
-    // wave-uniform: every slot's row exists, lane offsets fit 32-bit byte offsets
-    const bool fast = t >= 0 && (int64_t)t + W_pad <= a.T && (int64_t)(4 * Q + 4) * N < (int64_t(1) << 28);
-    if (fast) {
-        WinBounds<1> bl, bp;
-        WinBounds<(F & F_GRID) ? 4 : 1> bg;
-        window_bounds<1>(a.c.load_lo, a.c.load_hi, N, ic, bl);
-        window_bounds<1>(a.c.pv_lo, a.c.pv_hi, N, ic, bp);
-        if constexpr (F & F_GRID) window_bounds<4>(a.c.grid_lo, a.c.grid_hi, N, ic, bg);
-        for (int32_t hb = 0; hb < W; hb += slots) {      // one round for the usual 24 / 25-step windows
-            double vl[OBS_JB][1], vp[OBS_JB][1], vg[OBS_JB][(F & F_GRID) ? 4 : 1];
-            window_issue<1>(a.c.load_ts, N, N, t, hb, Q, (uint32_t)(q * N + ic), vl);     // all loads of the round in flight
-            window_issue<1>(a.c.pv_ts, N, N, t, hb, Q, (uint32_t)(q * N + ic), vp);
-            if constexpr (F & F_GRID) window_issue<4>(a.c.grid_ts, N, 4 * N, t, hb, Q, (uint32_t)(q * 4 * N + ic), vg);
-            if (hb == 0) window_bounds_finish<1>(bl);
-            window_finish<1, NOISE, OT>(vl, bl, W, t, hb, i, ic, q, Q, row, a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
-            if (hb == 0) window_bounds_finish<1>(bp);
-            window_finish<1, NOISE, OT>(vp, bp, W, t, hb, i, ic, q, Q, row + W, a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase);
-            if constexpr (F & F_GRID) {
-                if (hb == 0) window_bounds_finish<4>(bg);
-                window_finish<4, NOISE, OT>(vg, bg, W, t, hb, i, ic, q, Q, row + plan.grid_col_base, a.c.grid_noise_std, 2u,
-                                        a.noise_seed, a.noise_increase);
-            }
-        }
-    } else {
-        observe_window_cols<1, NOISE, OT>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row,
-                                      a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
-        observe_window_cols<1, NOISE, OT>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + W,
-                                      a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase);
-        if constexpr (F & F_GRID)
-            observe_window_cols<4, NOISE, OT>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q,
-                                          row + plan.grid_col_base, a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase);
-    }
-    if (q == 0) {                                        // the 6 state columns, by the first lane of each grid
-        Params p; State s;
-        load_state<F>(a.c, ic, true, s);
-        load_params<F>(a.c, ic, p);
-        observe_state_cols<F, OT>(a, p, s, row);
-    }
-    __syncthreads();
-    const int32_t n_valid = (N - g0 < G) ? (int32_t)(N - g0) : G;
-    const int32_t total = n_valid * D;                   // D is even here (one load, one renewable module)
-    OT *out = obs + g0 * D;
-    typedef OT vec2 __attribute__((ext_vector_type(2)));
-    if ((reinterpret_cast<uintptr_t>(out) & (sizeof(vec2) - 1)) == 0) {   // element pair f, f + 1 = 2 lane + 128 j -> (row, column)
-        int32_t r = 2 * lane / D, c = 2 * lane - r * D;
-        for (int32_t f = 2 * lane; f < total; f += 128) {
-            vec2 v2;
-            v2.x = tile[r * LD + c];
-            v2.y = tile[r * LD + c + 1];                 // D even, c even: the pair never straddles two rows
-            __builtin_nontemporal_store(v2, reinterpret_cast<vec2 *>(out + f));
-            c += 128;
-            while (c >= D) { c -= D; r++; }
-        }
-    } else {
-        int32_t r = lane / D, c = lane - r * D;
-        for (int32_t f = lane; f < total; f += 64) {
-            __builtin_nontemporal_store(tile[r * LD + c], out + f);
-            c += 64;
-            while (c >= D) { c -= D; r++; }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Window prefetch: the observation rows of the NEXT K steps in one launch (mgx_observe_windows).
-// The window columns of an observation depend on the series only -- never on the actions -- and the windows of
-// consecutive steps overlap in H of their 1 + H rows.  A per-step kernel therefore re-reads (and re-normalises) every
-// series value 1 + H times, and those reads miss the 4 MiB L2s (per-XCD window working set 15 MB at N = 100k): they are
-// the bound of obs_rows_wave_kernel.  Here a wave reads rows t .. t+K-1+H of its 16 grids ONCE, normalises each value
-// ONCE into LDS (clipped / padded form for forecast positions, unclipped form for the "current value" position), and
-// writes K row blocks ring[k] (k = 0..K-1) as shifted copies -- with 288 GB of HBM the K*N*D ring is cheap (1 GB at
-// K = 8, N = 100k, D = 156).  Block 0 is complete (state columns of the current state); in blocks 1..K-1 the state
-// columns are zero and are filled in by the step that reaches them (obs_state_only mode of the step kernels).
-// Not offered with forecast noise (noise depends on (t, h), not on t + h: nothing to share).
-// ------------------------------------------------------------------------------------------------------
-// Workgroup = 4 waves around ONE LDS image of 16 grids: per grid a block of BP doubles
-//   [NCOMP][RP]  normalised rows t .. t+R-1 in forecast form (clipped to the bounds, padded beyond the series)
-//   [NCOMP][K]   rows t .. t+K-1 in "current value" form (unclipped)
-//   [6][K]       state columns: entry 0 = the current state, entries 1..K-1 = 0
-// so that output element (block k, grid r, column c) = image[r*BP + map[c] + k] for EVERY kind of column (map[c] =
-// offset of the column's k = 0 entry).  Thread (g, q) of the 256 loads rows q, q+16, ... of grid g; wave w then writes
-// blocks w, w+4, ... (each 16*D consecutive elements) with 16-byte non-temporal stores.
-constexpr int OBS_KJ = 2;                               // rows per thread and latency round (x 16 phases = 32 rows)
-constexpr int OBS_K_THREADS = 256;
-
-template <int NC>
-__device__ __forceinline__ void windows_k_module(const double *__restrict__ ts, int64_t N, int64_t row_stride,
-                                                 const double *__restrict__ lo_col, const double *__restrict__ hi_col,
-                                                 int32_t T, int32_t t, int32_t R, int32_t K, int64_t ic, int32_t q, int32_t Q,
-                                                 double *nc /* [NC][RP] of this grid */, double *nu /* [NC][K] */, int32_t RP)
-{
-    double lo[NC], hi[NC], sp[NC], z_lo[NC], z_hi[NC], z_fill[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        lo[c] = lo_col[c * N + ic]; hi[c] = hi_col[c * N + ic];
-        sp[c] = space_spread(lo[c], hi[c]);
-        z_lo[c] = (lo[c] - lo[c]) / sp[c];                               // a forecast clipped to the lower bound
-        z_hi[c] = (hi[c] - lo[c]) / sp[c];                               // ... to the upper bound
-        z_fill[c] = ((hi[c] + lo[c]) / 2 - lo[c]) / sp[c];               // a row beyond the series (forecaster.py:95,120-137)
-    }
-    for (int32_t rb = 0; rb < R; rb += OBS_KJ * Q) {                     // workgroup-uniform trip count
-        double v[OBS_KJ][NC];
-#pragma unroll
-        for (int jj = 0; jj < OBS_KJ; jj++) {                            // unconditional, clamped loads: one latency round
-            const int32_t rr = rb + q + Q * jj;                          // rows past the window re-read its last row (a cache
-            const int32_t r = t + (rr < R ? rr : R - 1);                 // hit) instead of pulling unused rows out of HBM
-            const int32_t rc = r < T ? (r < 0 ? 0 : r) : T - 1;
-#pragma unroll
-            for (int c = 0; c < NC; c++) v[jj][c] = ts[(int64_t)rc * row_stride + c * N + ic];
-        }
-#pragma unroll
-        for (int jj = 0; jj < OBS_KJ; jj++) {
-            const int32_t rr = rb + q + Q * jj;                          // row relative to t
-            if (rr < R) {
-                const bool in = t + rr < T;
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const double x = v[jj][c];
-                    const double n_u = in ? (x - lo[c]) / sp[c] : z_fill[c];                 // unclipped (current value)
-                    const double n_c = in ? (x < lo[c] ? z_lo[c] : (x > hi[c] ? z_hi[c] : n_u)) : z_fill[c];
-                    nc[c * RP + rr] = n_c;
-                    if (rr < K) nu[c * K + rr] = n_u;
-                }
-            }
-        }
-    }
-}
-
-struct WindowsKPlan {
-    int32_t grid_col_base;   // first obs column of the grid window
-    int32_t group;           // grids per workgroup (16)
-    int32_t K;               // steps per launch
-    int32_t rp;              // pitch of one component's rows in the image
-    int32_t bp;              // pitch of one grid's block in the image (odd)
-    int32_t with_state;      // block 0 receives the state columns of the current state (0: a prefetch AHEAD of the counter)
-    int32_t group0;          // first group of this launch (a launch may cover a chunk of the batch's groups)
-};
-
-#ifdef MGX_WIN_PLAIN_STORES
-#define MGX_WIN_STORE(v, p) (*(p) = (v))
-#else
-#define MGX_WIN_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#endif
-// Body shared by obs_windows_k_kernel and the window part of fleet_step_kernel: workgroup `group` (16 grids) of the batch.
-// GRID: the layout has a GridModule (6 instead of 2 series components).  `now` (meaningful in the q == 0 lanes): the state
-// columns of the current state for block 0, or nullptr (a prefetch ahead of the counter: every state column is zero).
-template <bool GRID, typename OT>
-__device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan &plan, int32_t t, OT *__restrict__ ring,
-                                             int64_t group, int32_t nstate, const double *now, double *image)
-{
-    constexpr int NCOMP = 2 + (GRID ? 4 : 0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t G = plan.group, Q = OBS_K_THREADS / G, K = plan.K, RP = plan.rp, BP = plan.bp;
-    const int32_t g = tid & (G - 1), q = tid / G;
-    const int64_t g0 = group * G;
-    const int64_t N = a.N;
-    const int32_t W = 1 + a.H, D = a.obs_dim, R = K + a.H;
-    const int64_t i = g0 + g, ic = i < N ? i : g0;
-    const int32_t NU0 = NCOMP * RP, S0 = NU0 + NCOMP * K;
-    double *blk = image + g * BP;
-    uint32_t *map = reinterpret_cast<uint32_t *>(image + G * BP);       // [D]
-
-    windows_k_module<1>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, R, K, ic, q, Q, blk, blk + NU0, RP);
-    windows_k_module<1>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP);
-    if constexpr (GRID)
-        windows_k_module<4>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, R, K, ic, q, Q, blk + 2 * RP,
-                            blk + NU0 + 2 * K, RP);
-    if (q == 0) {                                        // state columns: the current state for block 0, zeros ahead
-        for (int j = 0; j < nstate; j++) {
-            blk[S0 + j * K] = now ? now[j] : 0.0;
-            for (int32_t k = 1; k < K; k++) blk[S0 + j * K + k] = 0.0;
-        }
-    }
-    for (int32_t col = tid; col < D; col += OBS_K_THREADS) {            // column -> offset of its k = 0 entry in a block
-        uint32_t comp, h;
-        if (col < W) { comp = 0; h = col; }
-        else if (col < 2 * W) { comp = 1; h = col - W; }
-        else if (col < plan.grid_col_base) { comp = 0xffffu; h = col - 2 * W; }
-        else { comp = 2u + ((col - plan.grid_col_base) & 3); h = (col - plan.grid_col_base) >> 2; }
-        map[col] = comp == 0xffffu ? S0 + h * K : (h == 0 ? NU0 + comp * K : comp * RP + h);
-    }
-    __syncthreads();
-    const int32_t n_valid = (N - g0 < G) ? (int32_t)(N - g0) : G;
-    const int32_t total = n_valid * D;                   // D is even (one load, one renewable module)
-    typedef OT vec2 __attribute__((ext_vector_type(2)));
-    const bool wide = (reinterpret_cast<uintptr_t>(ring) & (sizeof(vec2) - 1)) == 0;
-    for (int32_t k = wave; k < K; k += OBS_K_THREADS / 64) {
-        OT *out = ring + ((int64_t)k * N + g0) * D;
-        const double *src = image + k;
-        if (wide) {                                      // element pair f, f + 1 = 2 lane + 128 j -> (row, column)
-            int32_t r = 2 * lane / D, c = 2 * lane - r * D;
-            for (int32_t f = 2 * lane; f < total; f += 128) {
-                vec2 v2;
-                v2.x = (OT)src[r * BP + map[c]];
-                v2.y = (OT)src[r * BP + map[c + 1]];     // D even, c even: the pair never straddles two rows
-                MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out + f));
-                c += 128;
-                while (c >= D) { c -= D; r++; }
-            }
-        } else {
-            int32_t r = lane / D, c = lane - r * D;
-            for (int32_t f = lane; f < total; f += 64) {
-                MGX_WIN_STORE((OT)src[r * BP + map[c]], out + f);
-                c += 64;
-                while (c >= D) { c -= D; r++; }
-            }
-        }
-    }
-}
-
-template <int F, typename OT>
-__global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArgs a, const WindowsKPlan plan, int32_t t,
-                                                                      OT *__restrict__ ring)
-{
-    t = resolve_t_obs(a, t);
-    constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
-    extern __shared__ double image[];
-    const int64_t group = (int64_t)plan.group0 + blockIdx.x;
-    double now[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (plan.with_state && (int)threadIdx.x < plan.group) {           // the q == 0 lanes: one per grid of the group
-        const int64_t i = group * plan.group + threadIdx.x, ic = i < a.N ? i : group * plan.group;
-        Params p; State s;
-        load_state<F>(a.c, ic, true, s);
-        load_params<F>(a.c, ic, p);
-        observe_state_cols<F>(a, p, s, now, 0);
-    }
-    windows_body<(F & F_GRID) != 0, OT>(a, plan, t, ring, group, NSTATE, plan.with_state ? now : nullptr, image);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Discrete action expansion: PriorityListAlgo._populate_action (priority_list.py:69-167).
-// ------------------------------------------------------------------------------------------------------
-template <int F>
-__global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWords tab, const int32_t *__restrict__ action_id,
-                                                       int32_t t, double *__restrict__ control)
-{
-    t = resolve_t(a, t);
-    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.g1) return;
-    const int64_t N = a.N;
-    Params p; State s; Inputs in;
-    load_state<F>(a.c, i, false, s);
-    load_params<F>(a.c, i, p);
-    in.load = a.c.load_ts[(int64_t)t * N + i];
-    in.pv = a.c.pv_ts[(int64_t)t * N + i];
-    in.g_stat = 1.0;
-    if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
-    double q_unused;
-    populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused, 0.0 + -1 * in.load, in.pv);
-    double *c = control + i * A;
-    int k = 0;
-    if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
-    if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
-    if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
-}
-
-template <int F>
-__device__ __forceinline__ void load_series_at(const double *__restrict__ lts, const double *__restrict__ pts,
-                                               const double *__restrict__ gts, int64_t N, int64_t i, int64_t off,
-                                               Inputs &in)
-{
-    in.load = lts[off];
-    in.pv = pts[off];
-    in.g_stat = 1.0;
-    if constexpr (F & F_GRID) {
-        const double *g = gts + (4 * off - 3 * i);
-        in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
-    }
-}
-
-// DiscreteMicrogridEnv.step in ONE launch (discrete.py:109-143): expand the priority list of every grid into its
-// control and run Microgrid.run(control, normalized=False) on it, without the control ever leaving registers.
-// (body shared by step_discrete_kernel and fleet_step_kernel)
-template <int F>
-__device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords &tab, const int32_t *__restrict__ action_id,
-                                                   int32_t t, double *__restrict__ control, double *__restrict__ reward,
-                                                   uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                   double *__restrict__ log, int64_t i)
-{
-    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const int64_t N = a.N;
-    Params p; State s; Inputs in; Outputs o; Derived d;
-    const int32_t id = action_id[i];
-    load_series_at<F>(a.c.load_ts + (int64_t)t * N, a.c.pv_ts + (int64_t)t * N,
-                      (F & F_GRID) ? a.c.grid_ts + (int64_t)t * 4 * N : nullptr, N, i, i, in);
-    load_state<F>(a.c, i, log != nullptr, s);
-    load_params<F>(a.c, i, p);
-    derive<F>(p, d);
-    const bool gen_instant = genset_wave_is_instant<F>(p, s);
-    double bat_q;
-    populate_core<F>(p, s, pl_select(tab, id), in, bat_q, 0.0 + -1 * in.load, in.pv);
-    if (control) {                                   // optional copy of the expanded control (_get_action's value)
-        double *c = control + i * A;
-        int k = 0;
-        if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
-        if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
-        if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
-    }
-    step_core<F, true>(p, d, s, in, false, true, gen_instant, o, bat_q);
-    store_state<F>(a.c, i, s);
-    reward[i] = shaped_reward<F>(a.shaper, o);
-    if (done) done[i] = done_at(a, i, t);
-    if (log) store_log<F>(log + i, N, o, s.status);
-    if (obs) {
-        if (a.obs_state_only) {                 // the window columns of this row were prefetched (obs_windows_k_kernel)
-            if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
-            else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
-        } else if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
-        else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
-    }
-}
-
-template <int F>
-__global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, const PLWords tab,
-                                                              const int32_t *__restrict__ action_id, int32_t t,
-                                                              double *__restrict__ control, double *__restrict__ reward,
-                                                              uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                              double *__restrict__ log)
-{
-    t = resolve_t(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < a.g1) step_discrete_body<F>(a, tab, action_id, t, control, reward, done, obs, log, i);
-    advance_counter_in_kernel(a, 1);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// A heterogeneous fleet in ONE launch (mgx_fleet_step): up to MGX_FLEET_MAX batches of different layouts, each with its own
-// columns / actions / outputs / step counter, laid end to end over the workgroups.  The table travels in the kernarg
-// segment (scalar loads); a workgroup finds its batch with a few scalar compares and jumps -- wave-uniformly -- to that
-// layout's specialisation of the step.  Three 33 000-grid batches cost one ~6 us launch instead of three ~5 us ones.
-// ------------------------------------------------------------------------------------------------------
-constexpr int MGX_FLEET_MAX = 6;
-// What changes from step to step travels by value (small: one scalar-load round at kernel start); the big, rarely changing
-// KArgs of every batch are read from DEVICE memory (the handle's own copy, refreshed by the host when it changes).  A table
-// of whole KArgs in the kernarg segment measured 57 us per launch: the kernarg buffer lives in host memory and the chain
-// of dependent scalar loads (which batch? -> its layout -> its columns) paid a host round trip per link.
-struct FleetArgs {
-    const KArgs *k[MGX_FLEET_MAX];               // device copies (mgx_handle::d_kargs)
-    const PLWords *tab[MGX_FLEET_MAX];           // discrete items: the priority-list table (device copy), else NULL
-    const void *actions[MGX_FLEET_MAX];          // continuous control [N, A] -- or the int32 priority-list ids [N] of a discrete item
-    double *reward[MGX_FLEET_MAX];
-    uint8_t *done[MGX_FLEET_MAX];
-    void *obs[MGX_FLEET_MAX];
-    double *log[MGX_FLEET_MAX];
-    int32_t t[MGX_FLEET_MAX], flags[MGX_FLEET_MAX], block0[MGX_FLEET_MAX];   // block0: first workgroup of the batch
-    int32_t n, normalized;
-};
-
-// Window chunks riding along with a fleet step: workgroups behind the step's own.  While the steps walk an observation
-// ring of K blocks, the ring of the NEXT K counter values is due (obs_windows_k_kernel's job); as one launch per K steps it
-// is a 150 us burst of pure writes between latency-bound step kernels.  Cut into K - 1 chunks of the batch's 16-grid
-// groups, one chunk per step, the same bytes move at a constant rate in the shadow of the step kernels' latency.
-struct FleetWin {
-    const KArgs *k[MGX_FLEET_MAX];
-    void *ring[MGX_FLEET_MAX];
-    WindowsKPlan plan[MGX_FLEET_MAX];            // plan.group0 = first group of the chunk
-    int32_t t[MGX_FLEET_MAX], block0[MGX_FLEET_MAX], kind[MGX_FLEET_MAX], nstate[MGX_FLEET_MAX];   // kind: bit 0 grid, bit 1 float rows
-    int32_t n, first_block;                      // first_block = workgroups of the step part
-};
-
-__global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArgs fa, const FleetWin fw)
-{
-    extern __shared__ double image[];
-    if (fw.n > 0 && (int)blockIdx.x >= fw.first_block) {               // ---- window chunk workgroups
-        const int b = (int)blockIdx.x - fw.first_block;
-        const KArgs *kp = fw.k[0];
-        void *ring = fw.ring[0];
-        WindowsKPlan plan = fw.plan[0];
-        int32_t t = fw.t[0], block0 = 0, kind = fw.kind[0], nstate = fw.nstate[0];
-#pragma unroll
-        for (int q = 1; q < MGX_FLEET_MAX; q++) {
-            const bool mine = q < fw.n && b >= fw.block0[q];
-            kp = mine ? fw.k[q] : kp; ring = mine ? fw.ring[q] : ring;
-            plan.grid_col_base = mine ? fw.plan[q].grid_col_base : plan.grid_col_base;
-            plan.group = mine ? fw.plan[q].group : plan.group; plan.K = mine ? fw.plan[q].K : plan.K;
-            plan.rp = mine ? fw.plan[q].rp : plan.rp; plan.bp = mine ? fw.plan[q].bp : plan.bp;
-            plan.group0 = mine ? fw.plan[q].group0 : plan.group0;
-            t = mine ? fw.t[q] : t; block0 = mine ? fw.block0[q] : block0; kind = mine ? fw.kind[q] : kind;
-            nstate = mine ? fw.nstate[q] : nstate;
-        }
-        const KArgs &a = *kp;
-        const int64_t group = (int64_t)plan.group0 + (b - block0);
-        switch (kind) {
-            case 0: windows_body<false, double>(a, plan, t, (double *)ring, group, nstate, nullptr, image); break;
-            case 1: windows_body<true, double>(a, plan, t, (double *)ring, group, nstate, nullptr, image); break;
-            case 2: windows_body<false, float>(a, plan, t, (float *)ring, group, nstate, nullptr, image); break;
-            default: windows_body<true, float>(a, plan, t, (float *)ring, group, nstate, nullptr, image); break;
-        }
-        return;
-    }
-    // which batch owns this workgroup: selects over the (<= 6) kernarg entries, no run-time indexing (that would send the
-    // struct to scratch)
-    const KArgs *kp = fa.k[0];
-    const PLWords *tp = fa.tab[0];
-    const void *actions = fa.actions[0];
-    double *reward = fa.reward[0]; uint8_t *done = fa.done[0]; void *obs = fa.obs[0]; double *log = fa.log[0];
-    int32_t t = fa.t[0], flags = fa.flags[0], block0 = 0;
-#pragma unroll
-    for (int q = 1; q < MGX_FLEET_MAX; q++) {
-        const bool mine = q < fa.n && (int)blockIdx.x >= fa.block0[q];
-        kp = mine ? fa.k[q] : kp; tp = mine ? fa.tab[q] : tp;
-        actions = mine ? fa.actions[q] : actions; reward = mine ? fa.reward[q] : reward;
-        done = mine ? fa.done[q] : done; obs = mine ? fa.obs[q] : obs; log = mine ? fa.log[q] : log;
-        t = mine ? fa.t[q] : t; flags = mine ? fa.flags[q] : flags; block0 = mine ? fa.block0[q] : block0;
-    }
-    const KArgs &a = *kp;                         // uniform address, read-only: scalar loads from HBM / L2
-    const int64_t i = (int64_t)((int)blockIdx.x - block0) * BLOCK + threadIdx.x;
-    if (i >= a.N) return;
-    if (tp != nullptr) {                          // a DiscreteMicrogridEnv batch: ids -> control -> run, in registers
-        const PLWords &tab = *tp;
-#define MGX_FLEET_CASE(FV) case FV: step_discrete_body<FV>(a, tab, (const int32_t *)actions, t, nullptr, reward, done, obs, log, i); break;
-        switch (flags) {
-            MGX_FLEET_CASE(0) MGX_FLEET_CASE(1) MGX_FLEET_CASE(2) MGX_FLEET_CASE(3) MGX_FLEET_CASE(4)
-            MGX_FLEET_CASE(5) MGX_FLEET_CASE(6) MGX_FLEET_CASE(7) MGX_FLEET_CASE(14)
-            default: step_discrete_body<15>(a, tab, (const int32_t *)actions, t, nullptr, reward, done, obs, log, i); break;
-        }
-#undef MGX_FLEET_CASE
-        return;
-    }
-#define MGX_FLEET_CASE(FV) case FV: step_body<FV>(a, actions, t, fa.normalized, reward, done, obs, log, i); break;
-    switch (flags) {
-        MGX_FLEET_CASE(0) MGX_FLEET_CASE(1) MGX_FLEET_CASE(2) MGX_FLEET_CASE(3) MGX_FLEET_CASE(4)
-        MGX_FLEET_CASE(5) MGX_FLEET_CASE(6) MGX_FLEET_CASE(7) MGX_FLEET_CASE(14)
-        default: step_body<15>(a, actions, t, fa.normalized, reward, done, obs, log, i); break;
-    }
-#undef MGX_FLEET_CASE
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Discrete rollout: K fused steps whose control is expanded ON DEVICE from a priority-list id -- per step
-// (ids [K, N], one byte each: a DiscreteMicrogridEnv roll-out) or constant per grid (ids [N]: RuleBasedControl.run,
-// algos/rbc/rbc.py:64-93).  No action stream at all: per step only the series rows are read.
-// ------------------------------------------------------------------------------------------------------
-template <int F, int U, bool PER_STEP, bool RICH>
-__global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const PLWords tab, const uint8_t *__restrict__ ids,
-                                                          int32_t t0, int32_t K, const FusedOut out_rt, int32_t gpb)
-{
-    FusedOut out = out_rt;
-    if constexpr (!RICH) { out.log = nullptr; out.status_trace = nullptr; }
-    const int32_t K_launch = K;          // what the host asked for (the counter always moves by this much)
-    t0 = resolve_t(a, t0);
-    K = resolve_k(a, t0, K);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * gpb + threadIdx.x;
-    if ((int32_t)threadIdx.x >= gpb || i >= a.g1) return;
-    const int64_t N = a.N;
-    Params p; State s; Derived d;
-    load_state<F>(a.c, i, out.log != nullptr, s);
-    load_params<F>(a.c, i, p);
-    derive<F>(p, d);
-    const double *__restrict__ lts = a.c.load_ts + (int64_t)t0 * N;
-    const double *__restrict__ pts = a.c.pv_ts + (int64_t)t0 * N;
-    const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
-    const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
-    const bool gen_instant = genset_wave_is_instant<F>(p, s);
-    const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
-    // PER_STEP = false (one fixed list per grid: RuleBasedControl): `word` is loop-invariant and the list decoding of
-    // populate_core is hoisted out of the step loop by the compiler
-    uint32_t word = PER_STEP ? 0u : pl_select(tab, ids[i]);
-    double ret = 0.0;
-
-    // The step loop exists twice, specialised at COMPILE time on the wave-uniform `gen_instant`: in the instant form the
-    // genset's status is its goal, its limits under a fixed list are loop-invariant (hoisted), and the FSM is gone.
-    auto run = [&](auto gi_tag) __attribute__((always_inline)) {
-        constexpr bool GI = decltype(gi_tag)::value;
-        Inputs ring[U];
-        uint8_t idr[U];
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (u < K) {
-                load_series_at<F>(lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
-                if constexpr (PER_STEP) idr[u] = ids[(int64_t)u * N + i];
-            }
-
-        int64_t off = i;
-        for (int32_t k0 = 0; k0 < K; k0 += U) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int32_t k = k0 + u;
-                if (k < K) {
-                    Inputs in = ring[u];
-                    if constexpr (PER_STEP) word = pl_select(tab, idr[u]);
-                    if (k + U < K) {
-                        load_series_at<F>(lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
-                        if constexpr (PER_STEP) idr[u] = ids[off + (int64_t)U * N];
-                    }
-                    double bat_q;
-                    populate_core<F>(p, s, word, in, bat_q, 0.0 + -1 * in.load, in.pv, GI);
-                    Outputs o;
-                    step_core<F, true>(p, d, s, in, false, want_soc, GI, o, bat_q);
-                    const double r = shaped_reward<F>(a.shaper, o);
-                    if (out.reward) out.reward[off] = r;
-                    if (out.done) out.done[off] = (uint8_t)(k >= k_done);
-                    if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
-                    if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
-                    if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
-                    ret += r;
-                    off += N;
-                }
-            }
-        }
-    };
-    if constexpr ((F & F_GENSET) != 0) {
-        if (gen_instant) run(std::true_type{}); else run(std::false_type{});
-    } else {
-        run(std::false_type{});
-    }
-    if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
-    store_state<F>(a.c, i, s);
-    if (out.ret_acc) out.ret_acc[i] += ret;
-    advance_counter_in_kernel(a, K_launch);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// General path: any number of modules per kind (n_load / n_pv != 1, or several gensets / batteries / grids: columns
-// [n, N] instance-major, load / pv series [T, n, N], grid series [T, n_grid, 4, N]).  One lane per grid; the lists
-// MicrogridStep sums live in LDS (StepLists).  Parity with the reference's multi-module microgrids, not speed.
-// ------------------------------------------------------------------------------------------------------
-constexpr int BLOCK_MULTI = 64;
-
-__device__ __forceinline__ StepLists multi_lists(const KArgs &a, double *lds)
-{
-    const int cap = multi_list_capacity(a.n_load, a.n_pv, a.n_genset, a.n_battery, a.n_grid);
-    StepLists L;
-    L.stride = BLOCK_MULTI; L.n_prov = 0; L.n_absb = 0;
-    L.prov = lds + threadIdx.x;
-    L.absb = lds + (size_t)cap * BLOCK_MULTI + threadIdx.x;
-    return L;
-}
-
-template <typename OT>
-__device__ inline void observe_series_multi(const double *__restrict__ ts, int64_t row_stride, int32_t T, int32_t t, int32_t H,
-                                            double lo, double hi, OT *__restrict__ obs, int obs_stride = 1)
-{
-    const double fill = (hi + lo) / 2, sp = space_spread(lo, hi);
-    for (int h = 0; h <= H; h++) {
-        const bool in = t < T && t + h < T;
-        const double v = in ? ts[(int64_t)(t + h) * row_stride] : 0.0;
-        obs[h * obs_stride] = (OT)obs_series_value(v, in, h > 0, lo, hi, fill, sp);
-    }
-}
-
-// flat order: load windows, pv windows, gensets (4 columns each), batteries (2 each), grid windows (4 (1 + H) each)
-template <int F, typename OT>
-__device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, OT *__restrict__ obs_row)
-{
-    const int64_t N = a.N;
-    const int W = 1 + a.H;
-    int k = 0;
-    for (int j = 0; j < a.n_load; j++, k += W)
-        observe_series_multi(a.c.load_ts + (int64_t)j * N + i, (int64_t)a.n_load * N, a.T, t, a.H, a.c.load_lo[(int64_t)j * N + i],
-                             a.c.load_hi[(int64_t)j * N + i], obs_row + k);
-    for (int j = 0; j < a.n_pv; j++, k += W)
-        observe_series_multi(a.c.pv_ts + (int64_t)j * N + i, (int64_t)a.n_pv * N, a.T, t, a.H, a.c.pv_lo[(int64_t)j * N + i],
-                             a.c.pv_hi[(int64_t)j * N + i], obs_row + k);
-    if constexpr (F & F_GENSET) {
-        for (int j = 0; j < a.n_genset; j++) {
-            const int64_t c = (int64_t)j * N + i;
-            const uint32_t times = a.c.gen_times[c], st = a.c.gen_status[c];
-            const double su = (double)(times & 0xff), wd = (double)((times >> 16) & 0xff);
-            obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)(st & 0xff));
-            obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)((st >> 8) & 0xff));
-            obs_row[k++] = (OT)space_norm(0.0, su, (double)((st >> 16) & 0xff));
-            obs_row[k++] = (OT)space_norm(0.0, wd, (double)(st >> 24));
-        }
-    }
-    if constexpr (F & F_BATTERY) {
-        for (int j = 0; j < a.n_battery; j++) {
-            const int64_t c = (int64_t)j * N + i;
-            const double cmin = a.c.bat_min_capacity[c], cmax = a.c.bat_max_capacity[c];
-            obs_row[k++] = (OT)space_norm(cmin / cmax, 1.0, a.c.soc[c]);
-            obs_row[k++] = (OT)space_norm(cmin, cmax, a.c.charge[c]);
-        }
-    }
-    if constexpr (F & F_GRID) {
-        for (int j = 0; j < a.n_grid; j++, k += 4 * W)
-            for (int cc = 0; cc < 4; cc++) {
-                const int64_t c = ((int64_t)j * 4 + cc) * N + i;
-                observe_series_multi(a.c.grid_ts + c, (int64_t)a.n_grid * 4 * N, a.T, t, a.H, a.c.grid_lo[c], a.c.grid_hi[c],
-                                     obs_row + k + cc, 4);
-            }
-    }
-}
-
-template <int F>
-__global__ __launch_bounds__(BLOCK_MULTI) void step_multi_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
-                                                                 int normalized, double *__restrict__ reward,
-                                                                 uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                                 double *__restrict__ log)
-{
-    extern __shared__ double multi_lds[];
-    t = resolve_t(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
-    if (i < a.g1) {
-        const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
-        StepLists L = multi_lists(a, multi_lds);
-        Outputs o;
-        if (a.act_f32) step_multi_core<F>(a, (const float *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
-        else step_multi_core<F>(a, (const double *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
-        reward[i] = shaped_reward<F>(a.shaper, o);
-        if (done) done[i] = done_at(a, i, t);
-        if (obs) {
-            if (a.obs_f32) observe_row_multi<F>(a, i, t + 1, (float *)obs + i * a.obs_dim);
-            else observe_row_multi<F>(a, i, t + 1, (double *)obs + i * a.obs_dim);
-        }
-    }
-    advance_counter_in_kernel(a, 1);
-}
-
-template <int F>
-__global__ __launch_bounds__(BLOCK_MULTI) void observe_multi_kernel(const KArgs a, int32_t t, void *__restrict__ obs)
-{
-    t = resolve_t_obs(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
-    if (i >= a.g1) return;
-    if (a.obs_f32) observe_row_multi<F>(a, i, t, (float *)obs + i * a.obs_dim);
-    else observe_row_multi<F>(a, i, t, (double *)obs + i * a.obs_dim);
-}
-
-// dry run (mgx_check_step) on the general path: the violations of the controllable instances depend on their own
-// state and request only, never on the other modules
-template <int F>
-__global__ __launch_bounds__(BLOCK_MULTI) void check_multi_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
-                                                                  int normalized, uint32_t *__restrict__ violations)
-{
-    t = resolve_t(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
-    if (i >= a.g1) return;
-    const int64_t N = a.N;
-    const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid, A = 2 * NG + NB + NR;
-    auto ld = [&](int j) { return a.act_f32 ? (double)((const float *)actions)[i * A + j] : ((const double *)actions)[i * A + j]; };
-    uint32_t viol = 0u;
-    Inputs in; in.load = 0.0; in.pv = 0.0;
-    Outputs oc;
-    if constexpr (F & F_GENSET)
-        for (int j = 0; j < NG; j++) {
-            Params p; Derived d; State s;
-            load_module_params<F_GENSET>(a.c, (int64_t)j * N + i, p); derive<F_GENSET>(p, d);
-            s.status = a.c.gen_status[(int64_t)j * N + i];
-            in.a_goal = ld(2 * j); in.a_gen = ld(2 * j + 1);
-            step_core<F_GENSET>(p, d, s, in, normalized != 0, false, false, oc);
-            viol |= oc.violations;
-        }
-    if constexpr (F & F_BATTERY)
-        for (int j = 0; j < NB; j++) {
-            Params p; Derived d; State s;
-            load_module_params<F_BATTERY>(a.c, (int64_t)j * N + i, p); derive<F_BATTERY>(p, d);
-            s.charge = a.c.charge[(int64_t)j * N + i]; s.soc = 0.0; s.status = 0u;
-            in.a_bat = ld(2 * NG + j);
-            step_core<F_BATTERY>(p, d, s, in, normalized != 0, false, false, oc);
-            viol |= oc.violations;
-        }
-    if constexpr (F & F_GRID)
-        for (int j = 0; j < NR; j++) {
-            Params p; Derived d; State s;
-            load_module_params<F_GRID>(a.c, (int64_t)j * N + i, p); derive<F_GRID>(p, d);
-            s.charge = 0.0; s.soc = 0.0; s.status = 0u;
-            in.g_pimp = 0.0; in.g_pexp = 0.0; in.g_co2 = 0.0;
-            in.g_stat = a.c.grid_ts[(((int64_t)t * NR + j) * 4 + 3) * N + i];
-            in.a_grid = ld(2 * NG + NB + j);
-            step_core<F_GRID>(p, d, s, in, normalized != 0, false, false, oc);
-            viol |= oc.violations;
-        }
-    violations[i] = viol;
-}
-
-// K consecutive steps of the general path in ONE launch (mgx_step_k / mgx_rollout_lists on layouts with several modules of a
-// kind): a loop around step_multi_core -- the state columns are re-read every step (cache hits), nothing is kept in
-// registers across steps.  With `lists` the control of every step is expanded on device from the grid's priority list
-// (ids [K, N] with per_step, else one fixed list per grid = RuleBasedControl.run) and applied unnormalised.
-// soc_trace / status_trace report battery 0 / genset 0.
-constexpr int MGX_MAX_ACTIONS_MULTI = 4 * MGX_MAX_INSTANCES;
-
-template <int F>
-__global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a, const void *__restrict__ actions,
-                                                                   const int32_t *__restrict__ lists, int32_t n_lists, int32_t list_len,
-                                                                   const int32_t *__restrict__ ids, int per_step, int32_t t0, int32_t K,
-                                                                   int normalized, const FusedOut out)
-{
-    extern __shared__ double multi_lds[];
-    const int32_t K_launch = K;
-    t0 = resolve_t(a, t0);
-    K = resolve_k(a, t0, K);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
-    if (i < a.g1) {
-        const int64_t N = a.N;
-        const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
-        StepLists L = multi_lists(a, multi_lds);
-        const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
-        double ret = 0.0;
-        for (int32_t k = 0; k < K; k++) {
-            const int64_t off = (int64_t)k * N + i;
-            Outputs o;
-            double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
-            if (lists) {
-                double ctrl[MGX_MAX_ACTIONS_MULTI];
-                int32_t id = per_step ? ids[off] : ids[i];
-                id = (id >= 0 && id < n_lists) ? id : 0;
-                populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t0 + k, ctrl);
-                step_multi_core<F>(a, (const double *)ctrl, i, t0 + k, false, L, log, o);
-            } else if (a.act_f32) {
-                step_multi_core<F>(a, (const float *)actions + off * A, i, t0 + k, normalized != 0, L, log, o);
-            } else {
-                step_multi_core<F>(a, (const double *)actions + off * A, i, t0 + k, normalized != 0, L, log, o);
-            }
-            const double r = shaped_reward<F>(a.shaper, o);
-            if (out.reward) out.reward[off] = r;
-            if (out.done) out.done[off] = (uint8_t)(k >= k_done);
-            if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = a.c.soc[i]; }
-            if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = a.c.gen_status[i]; }
-            ret += r;
-        }
-        if (out.ret_acc) out.ret_acc[i] += ret;
-    }
-    advance_counter_in_kernel(a, K_launch);
-}
-
-// mgx_expand_lists / mgx_expand_discrete on the general path: lists [n_lists, list_len, 3] in device memory
-template <int F>
-__global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a, const int32_t *__restrict__ lists, int32_t n_lists,
-                                                                   int32_t list_len, const int32_t *__restrict__ action_id,
-                                                                   int32_t t, double *__restrict__ control)
-{
-    t = resolve_t(a, t);
-    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
-    if (i >= a.g1) return;
-    const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
-    int32_t id = action_id[i];
-    id = (id >= 0 && id < n_lists) ? id : 0;              // ids outside [0, n) fall back to list 0 (the reference raises)
-    populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t, control + i * A);
-}
-
-// one wave that idles for `ticks` of the 100 MHz real-time counter: mgx_fork staggers the shard streams with it
-__global__ void stagger_kernel(int64_t ticks)
-{
-    const int64_t t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-
-// device-resident step counter (hipGraph-replayable stepping): counter[0] = t, counter[1] = overrun flag
-__global__ void set_counter_kernel(int32_t *counter, int32_t t) { counter[0] = t; counter[1] = 0; counter[2] = 0; }
-
-// ------------------------------------------------------------------------------------------------------
-// Metrics: deterministic column sums  sums[m] = sum_i values[m, i].
-// Stage 1: every block folds a fixed slice of column m (lane-strided running sums, then a 64-lane
-// wavefront shuffle tree, then the 4 wave results through LDS).  Stage 2: one block per column folds the
-// per-block partials the same way.  No atomics: the order is fixed by (N, grid size) alone.
-// ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-__device__ __forceinline__ double block_sum(double v, double *lds)
-{
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) lds[wave] = v;
-    __syncthreads();
-    double r = 0.0;
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) r += lds[w];
-    }
-    __syncthreads();
-    return r;      // valid in thread 0
-}
-
-__global__ __launch_bounds__(BLOCK) void colsum_stage1(const double *__restrict__ values, int64_t N, int32_t per_block,
-                                                       double *__restrict__ partial)
-{
-    __shared__ double lds[BLOCK / 64];
-    const int m = blockIdx.y;
-    const int64_t begin = (int64_t)blockIdx.x * per_block;
-    int64_t end = begin + per_block; if (end > N) end = N;
-    const double *col = values + (int64_t)m * N;
-    double acc = 0.0;
-    for (int64_t i = begin + threadIdx.x; i < end; i += BLOCK) acc += col[i];
-    const double r = block_sum(acc, lds);
-    if (threadIdx.x == 0) partial[(int64_t)m * gridDim.x + blockIdx.x] = r;
-}
-
-__global__ __launch_bounds__(BLOCK) void colsum_stage2(const double *__restrict__ partial, int32_t n_partial,
-                                                       double *__restrict__ sums)
-{
-    __shared__ double lds[BLOCK / 64];
-    const int m = blockIdx.x;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n_partial; i += BLOCK) acc += partial[(int64_t)m * n_partial + i];
-    const double r = block_sum(acc, lds);
-    if (threadIdx.x == 0) sums[m] = r;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Per-grid episode windows (mgx_reset_windows).  Every reference Microgrid owns its step counter and draws its own
-// trajectory at reset (microgrid.py:205-225, base_module.py:65-77,292-296, trajectory/stochastic.py:15-30).  The batch
-// keeps ONE counter: at reset the rows [start_i, start_i + R) of every grid's series are gathered into window buffers
-// [R, N] that the step kernels then walk from row 0 -- coalesced, like the full series.  Rows beyond the end of the
-// series receive the forecaster's padding value (lo + hi) / 2 (forecaster.py:95,120-137), so the observation kernels
-// need no per-grid series length.  One lane per grid: its reads are one line per row (once per episode), the writes
-// are coalesced.
-// ------------------------------------------------------------------------------------------------------
-struct GatherArgs {
-    const double *load_ts, *pv_ts, *grid_ts;
-    const double *load_lo, *load_hi, *pv_lo, *pv_hi, *grid_lo, *grid_hi;
-    double *load_w, *pv_w, *grid_w;
-    const int32_t *start, *length;
-    int32_t *final_rel;
-    int32_t N, T, rows, max_length, lo, hi;
-};
-
-__global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs g)
-{
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= g.N) return;
-    const int64_t N = g.N;
-    int32_t s = g.start[i];
-    s = s < g.lo ? g.lo : (s > g.hi - 1 ? g.hi - 1 : s);            // a start outside the env's window is clamped into it
-    int32_t len = g.length ? g.length[i] : g.max_length;
-    const int32_t room = g.hi - s;
-    len = len < 1 ? 1 : len;
-    len = len > g.max_length ? g.max_length : len;
-    len = len > room ? room : len;                                     // the episode ends at the env's final step at the latest
-    if (g.final_rel) g.final_rel[i] = len;
-    const double fl = (g.load_lo && g.load_hi) ? (g.load_hi[i] + g.load_lo[i]) / 2 : 0.0;
-    const double fp = (g.pv_lo && g.pv_hi) ? (g.pv_hi[i] + g.pv_lo[i]) / 2 : 0.0;
-    double fg[4] = {0.0, 0.0, 0.0, 0.0};
-    if (g.grid_ts && g.grid_lo && g.grid_hi) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) fg[c] = (g.grid_hi[c * N + i] + g.grid_lo[c * N + i]) / 2;
-    }
-    for (int32_t r = 0; r < g.rows; r++) {
-        const int64_t row = (int64_t)s + r;
-        const bool in = row < g.T;
-        const int64_t src = (in ? row : (int64_t)g.T - 1) * N + i;
-        const double vl = g.load_ts[src], vp = g.pv_ts[src];
-        g.load_w[(int64_t)r * N + i] = in ? vl : fl;
-        g.pv_w[(int64_t)r * N + i] = in ? vp : fp;
-        if (g.grid_ts) {
-            const int64_t sg = (in ? row : (int64_t)g.T - 1) * 4 * N + i;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const double v = g.grid_ts[sg + c * N];
-                g.grid_w[((int64_t)r * 4 + c) * N + i] = in ? v : fg[c];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Series synthesis (mgx_synthesize_series): MicrogridGenerator's time series for N grids, written at HBM speed.
-//   load / pv     base profile x ratio, ratio = size / max(profile)      (_scale_ts 'max', MicrogridGenerator.py:137-147)
-//   import price  tariff pattern 1 / 2 by hour of day                    (_get_electricity_tariff, :253-285)
-//   co2           base co2 profile, verbatim                             (_get_co2_ts, :205-212)
-//   grid status   weak-grid outages: 0 where a uniform draw of rows t .. t+duration-1 falls below outage_per_day / 24;
-//                 the back-fill never reaches row 0                      (_generate_weak_grid_profile, :321-340)
-// One lane per grid walks the rows from the last to the first (the outage back-fill looks forward in time); every row
-// of every output is one coalesced store per wave.  Uniforms: Philox4x32-10 keyed by the seed, counter = (GLOBAL grid
-// index, row), so a shard's draw does not depend on how the batch is split over ranks.
-// ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double synth_uniform(uint64_t seed, int64_t grid, int32_t row)
-{
-    uint32_t r[4];
-    philox4x32_10((uint32_t)grid, (uint32_t)((uint64_t)grid >> 32), (uint32_t)row, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    return (double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) * (1.0 / 9007199254740992.0);      // 53 bits, [0, 1)
-}
-
-// MicrogridGenerator._get_electricity_tariff (:253-285)
-__device__ __forceinline__ double tariff_price(int32_t pattern, int32_t row)
-{
-    const int32_t h = row % 24;
-    if (pattern == 1) return (h >= 12 && h < 18) ? 0.59 : ((h < 8 || h >= 21) ? 0.22 : 0.29);
-    if (pattern == 2) return ((h >= 0 && h < 5) || (h >= 14 && h < 17)) ? 0.08 : 0.11;
-    return 0.0;
-}
-
-__global__ __launch_bounds__(BLOCK) void synthesize_series_kernel(const mgx_synth a)
-{
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.n_grids) return;
-    const int64_t N = a.n_grids;
-    const int32_t T = a.n_steps;
-    const int32_t lp = a.load_profile[i], pp = a.pv_profile[i];
-    const double lr = a.load_ratio[i], pr = a.pv_ratio[i];
-    const bool grid = a.grid_ts != nullptr;
-    int32_t cp = 0, pat = 0, dur = 1;
-    double prob = 0.0;
-    if (grid) {
-        cp = a.co2_profile[i]; pat = a.tariff[i];
-        prob = a.outage_per_day ? a.outage_per_day[i] / 24 : 0.0;           // weak_grid_timeseries[i] < outage_per_day/24 (:332)
-        dur = a.outage_duration ? a.outage_duration[i] : 1;
-    }
-    const bool weak = grid && a.outage_per_day != nullptr && a.weak[i] != 0;
-    const int64_t gi = a.grid_index ? a.grid_index[i] : a.grid_index0 + i;      // the Philox counter: GLOBAL grid index
-    // rows still covered by an outage that starts later: the extra draw of row T (the reference draws T + 1 values) first
-    int32_t cover = 0;
-    if (weak && synth_uniform(a.seed, gi, T) < prob) cover = dur - 1;
-    for (int32_t t = T - 1; t >= 0; t--) {
-        a.load_ts[(int64_t)t * N + i] = -1.0 * fabs(a.base_load[(int64_t)t * a.n_load_profiles + lp] * lr);   // stored sign
-        a.pv_ts[(int64_t)t * N + i] = fabs(a.base_pv[(int64_t)t * a.n_pv_profiles + pp] * pr);
-        if (grid) {
-            double status = 1.0;
-            if (weak) {
-                const bool own = synth_uniform(a.seed, gi, t) < prob;
-                status = (own || (cover > 0 && t > 0)) ? 0.0 : 1.0;             // "if i-j > 0": the back-fill spares row 0
-                cover = own ? dur - 1 : (cover > 0 ? cover - 1 : 0);
-            }
-            double *g = a.grid_ts + (int64_t)t * 4 * N + i;
-            g[0] = tariff_price(pat, t);
-            g[N] = 0.0;                                                       // price_export = zeros (:264)
-            g[2 * N] = a.base_co2[(int64_t)t * a.n_co2_profiles + cp];
-            g[3 * N] = status;
-        }
-    }
-}
-
-}  // namespace mgx
-
-// ======================================================================================================
-// Host side: the C ABI (include/mgx.h)
-// ======================================================================================================
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>

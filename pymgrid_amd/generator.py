@@ -152,7 +152,7 @@ def architecture_of(d):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Philox4x32-10 on the host: the uniforms the synthesis kernel draws (mgx_kernels.hip: synth_uniform)
+# Philox4x32-10 on the host: the uniforms the synthesis kernel draws (mgx_kernels.hpp: synth_uniform)
 # ---------------------------------------------------------------------------------------------------------------------
 def synth_uniform_host(seed, grid, row):
     """U[0, 1) of (seed; GLOBAL grid index, row), bit-identical to the device's synth_uniform (vectorised over arrays)."""
