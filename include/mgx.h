@@ -213,6 +213,11 @@ int mgx_set_action_format(mgx_handle *h, int32_t format);
  * those columns.  Values are identical to mgx_observe's.  MGX_ERR_UNSUPPORTED with forecast noise (it depends on the
  * (step, horizon index) pair) or several load / renewable modules. */
 int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream);
+/* Rows between consecutive blocks of the rings handed to mgx_observe_windows / mgx_observe_windows_ahead / mgx_fleet_step
+ * refills (default: N, i.e. a dense [K, N, D] ring).  With N not a multiple of 16 the blocks of a dense ring are not
+ * 128-byte aligned and every 1-KB wave store of the refill begins and ends in a partial line; a ring [K, P, D] with
+ * P = N rounded up to 16 rows, block k = the first N rows of ring[k], avoids that. */
+int mgx_set_ring_pitch(mgx_handle *h, int32_t rows);
 int mgx_set_obs_mode(mgx_handle *h, int32_t mode);
 
 /* The same prefetch AHEAD of the counter, overlapped with the steps: block k of `ring` = the window columns of counter

@@ -20,6 +20,7 @@ struct mgx_handle {
     mgx_layout layout;
     int32_t window_lo, window_hi;   // episode window given at create: trajectories must stay inside it
     bool multi;             // n_load != 1, n_pv != 1 or several gensets / batteries / grids: general (slow) kernels
+    int32_t ring_pitch;     // rows between the blocks of an observation ring (mgx_set_ring_pitch; default N)
     size_t multi_lds;       // LDS bytes of a general-kernel workgroup (the MicrogridStep lists)
     std::vector<std::string> log_names;
     int32_t *d_lists;       // general path: device copy of the priority lists handed to mgx_expand_discrete as a host table
@@ -286,6 +287,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     add_block(kGridNames, LC_GRID_N, n_grid);
     h->log_names.push_back("violations");
     h->d_lists = nullptr;
+    h->ring_pitch = L->n_grids;
     h->t = L->initial_step;
     h->k.shaper = MGX_SHAPER_NONE;
     h->k.noise_seed = 0; h->k.noise_increase = 0; h->k.obs_f32 = 0; h->k.obs_state_only = 0; h->k.act_f32 = 0;
@@ -442,6 +444,7 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     plan->group = (group_env == 8 || group_env == 4 || group_env == 16) ? group_env : 16;
     plan->with_state = ahead == 0;
     plan->group0 = 0;
+    plan->pitch = h->ring_pitch;
     auto lds_of = [&](int32_t g) { return (size_t)g * plan->bp * sizeof(double) + (size_t)h->k.obs_dim * sizeof(uint32_t); };
     while (plan->group > 1 && lds_of(plan->group) > 160 * 1024) plan->group /= 2;
     const size_t lds = (lds_of(plan->group) + 7) & ~(size_t)7;
@@ -483,6 +486,15 @@ static int launch_windows(mgx_handle *h, int32_t ahead, int32_t K, void *ring, h
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "obs_windows_k_kernel launch");
+}
+
+int mgx_set_ring_pitch(mgx_handle *h, int32_t rows)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_ring_pitch: NULL handle");
+    if (rows < h->k.N) return fail(MGX_ERR_INVALID, "mgx_set_ring_pitch: %d rows per block, the batch has %d grids", rows, h->k.N);
+    h->ring_pitch = rows;
+    return MGX_OK;
 }
 
 int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream)

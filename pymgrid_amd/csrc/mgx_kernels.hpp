@@ -403,6 +403,7 @@ struct WindowsKPlan {
     int32_t bp;              // pitch of one grid's block in the image (odd)
     int32_t with_state;      // block 0 receives the state columns of the current state (0: a prefetch AHEAD of the counter)
     int32_t group0;          // first group of this launch (a launch may cover a chunk of the batch's groups)
+    int32_t pitch;           // rows between consecutive blocks of the ring (>= N; mgx_set_ring_pitch)
 };
 
 #ifdef MGX_WIN_PLAIN_STORES
@@ -411,11 +412,11 @@ struct WindowsKPlan {
 #define MGX_WIN_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #endif
 // Body shared by obs_windows_k_kernel and the window part of fleet_step_kernel: workgroup `group` (16 grids) of the batch.
-// GRID: the layout has a GridModule (6 instead of 2 series components).  `now` (meaningful in the q == 0 lanes): the state
-// columns of the current state for block 0, or nullptr (a prefetch ahead of the counter: every state column is zero).
+// GRID: the layout has a GridModule (6 instead of 2 series components).  `now` (meaningful in the q == 0 lanes, with have_now):
+// the state columns of the current state for block 0; without it (a prefetch ahead of the counter) every state column is zero.
 template <bool GRID, typename OT>
 __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan &plan, int32_t t, OT *__restrict__ ring,
-                                             int64_t group, int32_t nstate, const double *now, double *image)
+                                             int64_t group, int32_t nstate, bool have_now, const double (&now)[6], double *image)
 {
     constexpr int NCOMP = 2 + (GRID ? 4 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -435,9 +436,12 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         windows_k_module<4>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, R, K, ic, q, Q, blk + 2 * RP,
                             blk + NU0 + 2 * K, RP);
     if (q == 0) {                                        // state columns: the current state for block 0, zeros ahead
-        for (int j = 0; j < nstate; j++) {
-            blk[S0 + j * K] = now ? now[j] : 0.0;
-            for (int32_t k = 1; k < K; k++) blk[S0 + j * K + k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {                    // static indices: `now` stays in registers (a dynamic index put it --
+            if (j < nstate) {                            // and 64 B of zero-initialisation per thread -- into scratch memory)
+                blk[S0 + j * K] = have_now ? now[j] : 0.0;
+                for (int32_t k = 1; k < K; k++) blk[S0 + j * K + k] = 0.0;
+            }
         }
     }
     for (int32_t col = tid; col < D; col += OBS_K_THREADS) {            // column -> offset of its k = 0 entry in a block
@@ -454,7 +458,7 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     typedef OT vec2 __attribute__((ext_vector_type(2)));
     const bool wide = (reinterpret_cast<uintptr_t>(ring) & (sizeof(vec2) - 1)) == 0;
     for (int32_t k = wave; k < K; k += OBS_K_THREADS / 64) {
-        OT *out = ring + ((int64_t)k * N + g0) * D;
+        OT *out = ring + ((int64_t)k * plan.pitch + g0) * D;
         const double *src = image + k;
         if (wide) {                                      // element pair f, f + 1 = 2 lane + 128 j -> (row, column)
             int32_t r = 2 * lane / D, c = 2 * lane - r * D;
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArg
     constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
     extern __shared__ double image[];
     const int64_t group = (int64_t)plan.group0 + blockIdx.x;
-    double now[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double now[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (plan.with_state && (int)threadIdx.x < plan.group) {           // the q == 0 lanes: one per grid of the group
         const int64_t i = group * plan.group + threadIdx.x, ic = i < a.N ? i : group * plan.group;
         Params p; State s;
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArg
         load_params<F>(a.c, ic, p);
         observe_state_cols<F>(a, p, s, now, 0);
     }
-    windows_body<(F & F_GRID) != 0, OT>(a, plan, t, ring, group, NSTATE, plan.with_state ? now : nullptr, image);
+    windows_body<(F & F_GRID) != 0, OT>(a, plan, t, ring, group, NSTATE, plan.with_state != 0, now, image);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -644,17 +648,18 @@ __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArgs fa, c
             plan.grid_col_base = mine ? fw.plan[q].grid_col_base : plan.grid_col_base;
             plan.group = mine ? fw.plan[q].group : plan.group; plan.K = mine ? fw.plan[q].K : plan.K;
             plan.rp = mine ? fw.plan[q].rp : plan.rp; plan.bp = mine ? fw.plan[q].bp : plan.bp;
-            plan.group0 = mine ? fw.plan[q].group0 : plan.group0;
+            plan.group0 = mine ? fw.plan[q].group0 : plan.group0; plan.pitch = mine ? fw.plan[q].pitch : plan.pitch;
             t = mine ? fw.t[q] : t; block0 = mine ? fw.block0[q] : block0; kind = mine ? fw.kind[q] : kind;
             nstate = mine ? fw.nstate[q] : nstate;
         }
         const KArgs &a = *kp;
         const int64_t group = (int64_t)plan.group0 + (b - block0);
+        const double none[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // a prefetch ahead of the counter: no state columns yet
         switch (kind) {
-            case 0: windows_body<false, double>(a, plan, t, (double *)ring, group, nstate, nullptr, image); break;
-            case 1: windows_body<true, double>(a, plan, t, (double *)ring, group, nstate, nullptr, image); break;
-            case 2: windows_body<false, float>(a, plan, t, (float *)ring, group, nstate, nullptr, image); break;
-            default: windows_body<true, float>(a, plan, t, (float *)ring, group, nstate, nullptr, image); break;
+            case 0: windows_body<false, double>(a, plan, t, (double *)ring, group, nstate, false, none, image); break;
+            case 1: windows_body<true, double>(a, plan, t, (double *)ring, group, nstate, false, none, image); break;
+            case 2: windows_body<false, float>(a, plan, t, (float *)ring, group, nstate, false, none, image); break;
+            default: windows_body<true, float>(a, plan, t, (float *)ring, group, nstate, false, none, image); break;
         }
         return;
     }

@@ -111,23 +111,32 @@ class StepEngine:
         columns -- the window columns of that row were written ahead of time by ``observe_windows``."""
         check(self._lib.mgx_set_obs_mode(self._h, 1 if flag else 0))
 
+    def set_ring_pitch(self, rows):
+        """Rows between consecutive blocks of the observation rings (``mgx_set_ring_pitch``; default N = dense rings)."""
+        check(self._lib.mgx_set_ring_pitch(self._h, int(rows)))
+        self._ring_pitch = int(rows)
+
+    def _check_ring(self, out):
+        pitch = getattr(self, "_ring_pitch", self.N)
+        if out.dim() != 3 or tuple(out.shape[1:]) != (self.N, self.obs_dim) or out.dtype != self.obs_dtype \
+                or out.device != self.device or out.stride(2) != 1 or out.stride(1) != self.obs_dim \
+                or (out.shape[0] > 1 and out.stride(0) != pitch * self.obs_dim):
+            raise ValueError(f"ring must be a {self.obs_dtype} tensor [K, {self.N}, {self.obs_dim}] on {self.device} whose "
+                             f"blocks are {pitch} rows apart (set_ring_pitch)")
+
     def observe_windows(self, K=None, out=None):
         """Observation rows of the next K steps, ``ring[k]`` = the row of step counter t + k (block 0 complete, blocks
         1..K-1 without the state columns): every series value is read and normalised once instead of 1 + horizon times."""
         if out is None:
             out = torch.empty((int(K), self.N, self.obs_dim), dtype=self.obs_dtype, device=self.device)
-        if out.dim() != 3 or tuple(out.shape[1:]) != (self.N, self.obs_dim) or out.dtype != self.obs_dtype \
-                or not out.is_contiguous() or out.device != self.device:
-            raise ValueError(f"ring must be a contiguous {self.obs_dtype} tensor [K, {self.N}, {self.obs_dim}] on {self.device}")
+        self._check_ring(out)
         self._call(self._lib.mgx_observe_windows, int(out.shape[0]), out.data_ptr())
         return out
 
     def observe_windows_ahead(self, ahead, out):
         """``mgx_observe_windows_ahead``: the window columns of counter values t + ahead .. t + ahead + K - 1 into ``out``
         [K, N, D], written on the engine's prefetch stream behind everything queued on torch's current stream."""
-        if out.dim() != 3 or tuple(out.shape[1:]) != (self.N, self.obs_dim) or out.dtype != self.obs_dtype \
-                or not out.is_contiguous() or out.device != self.device:
-            raise ValueError(f"ring must be a contiguous {self.obs_dtype} tensor [K, {self.N}, {self.obs_dim}] on {self.device}")
+        self._check_ring(out)
         self._call(self._lib.mgx_observe_windows_ahead, int(ahead), int(out.shape[0]), out.data_ptr())
         return out
 

@@ -68,9 +68,9 @@ class BatchedMicrogridEnv:
         # Three rings of K blocks: while the steps walk ring r, the windows of ring r + 1 (the NEXT K counter values) are
         # being written on the engine's prefetch stream (mgx_observe_windows_ahead -- the series rows do not depend on the
         # state, so this overlaps the step kernels), and ring r - 1 is still intact for whoever holds observations from it.
-        self._ring = self._rings = None
+        self._ring = self._rings = self._ring_store = None
         if self.obs_prefetch:
-            self._rings = torch.empty(3, self.obs_prefetch, L.n_grids, L.obs_dim, dtype=obs_dtype, device=batch.device)
+            self._alloc_rings(self.obs_prefetch)
             self._ring_idx, self._ring_pos = 0, 0
             self._ring = self._rings[0]
             self.engine.set_obs_state_only(True)
@@ -191,11 +191,21 @@ class BatchedMicrogridEnv:
             # a prefetch may still be writing the old rings on the engine's prefetch stream, which the caching allocator knows
             # nothing about: the caller's stream waits for it before the memory can be handed out again
             self.engine.prefetch_wait()
-        self._ring = self._rings = None
+        self._ring = self._rings = self._ring_store = None
         self.engine.set_obs_state_only(bool(K))
         if K:
-            self._rings = torch.empty(3, K, L.n_grids, L.obs_dim, dtype=self._obs_dtype, device=self.batch.device)
+            self._alloc_rings(K)
             self._refill()
+
+    def _alloc_rings(self, K):
+        """Three rings of K row blocks.  A block holds N rows; blocks are P = N rounded up to 16 rows apart, so that every block
+        starts on a 128-byte line whatever N is (``mgx_set_ring_pitch``: the 1-KB wave stores of a refill would otherwise begin and
+        end in partial lines).  ``_rings[r][k]`` is the contiguous [N, D] row block the steps return."""
+        L = self.layout
+        pitch = (L.n_grids + 15) // 16 * 16
+        self._ring_store = torch.empty(3, K, pitch, L.obs_dim, dtype=self._obs_dtype, device=self.batch.device)
+        self._rings = self._ring_store[:, :, :L.n_grids]
+        self.engine.set_ring_pitch(pitch)
 
     def _after_external_steps(self):
         """The engine was stepped behind the env's back (fused rollouts: ``RuleBasedControl.run``, ``engine.step_k``): the
@@ -401,7 +411,7 @@ class BatchedMicrogridEnv:
     def close(self):
         # mgx_destroy drains the engine's prefetch stream while the rings it may still be writing are alive
         self.engine.close()
-        self._ring = self._rings = None
+        self._ring = self._rings = self._ring_store = None
 
     def __del__(self):
         try:
