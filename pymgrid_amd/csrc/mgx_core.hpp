@@ -1028,8 +1028,10 @@ __device__ inline void populate_multi(const KArgs &a, const int32_t *__restrict_
     double remaining = total_load - renewable;                         // :74
     uint32_t seen = 0u;
     for (int k = 0; k < list_len; k++) {
-        const int kind = list[3 * k], j = list[3 * k + 1], act = list[3 * k + 2];
-        if (kind < 0) continue;
+        const int kind = list[3 * k], j = list[3 * k + 1], act = list[3 * k + 2] != 0;
+        // padding, or an element that names a module the layout does not have (the lists live in device memory and cannot
+        // be checked by the host: such an element is skipped instead of indexing past the columns)
+        if (kind < 0 || kind > 2 || j < 0 || j >= (kind == 0 ? NG : kind == 1 ? NB : NR)) continue;
         const uint32_t bit = 1u << (kind * MGX_MAX_INSTANCES + j);
         if (seen & bit) continue;                                      // :82-88: a module met again is skipped
         seen |= bit;

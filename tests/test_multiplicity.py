@@ -301,3 +301,23 @@ def test_reward_shapers_on_several_batteries_and_renewables_vs_reference(device)
             env.close()
             n += 1
     assert n >= 8
+
+
+@pytest.mark.gpu
+def test_priority_lists_with_foreign_elements_are_skipped_not_dereferenced(device):
+    """mgx_expand_lists reads its lists from device memory, where the host cannot validate them: an element naming a module
+    the layout does not have (instance out of range, unknown kind) is skipped like padding."""
+    import torch
+    from pymgrid_amd import DiscreteBatchedMicrogridEnv, MicrogridBatch
+    rs = np.random.RandomState(3)
+    grids = [_random_multi_grid(rs, 30, 2, 2, 0, 1, 1, 0, False) for _ in range(50)]
+    env = DiscreteBatchedMicrogridEnv(MicrogridBatch.from_grids(grids, device=device), remove_redundant_gensets=False)
+    env.reset()
+    good = env._lists[:1].clone()                                   # [1, L, 3]
+    junk = torch.tensor([[[0, 7, 1], [5, 0, 0], [2, 0, 0], [1, 9, 0]]], dtype=torch.int32, device=device)   # nothing valid
+    ids = torch.zeros(50, dtype=torch.int32, device=device)
+    both = torch.cat([junk[:, :good.shape[1]] if junk.shape[1] >= good.shape[1] else
+                      torch.cat([junk, -torch.ones(1, good.shape[1] - junk.shape[1], 3, dtype=torch.int32, device=device)], dim=1), good])
+    assert torch.equal(env.engine.expand_lists(ids + 1, both.contiguous()), env.engine.expand_lists(ids, good.contiguous()))
+    assert bool((env.engine.expand_lists(ids, both.contiguous()) == 0).all())          # the junk list deploys nothing
+    env.close()
