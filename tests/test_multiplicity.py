@@ -321,3 +321,30 @@ def test_priority_lists_with_foreign_elements_are_skipped_not_dereferenced(devic
     assert torch.equal(env.engine.expand_lists(ids + 1, both.contiguous()), env.engine.expand_lists(ids, good.contiguous()))
     assert bool((env.engine.expand_lists(ids, both.contiguous()) == 0).all())          # the junk list deploys nothing
     env.close()
+
+
+@pytest.mark.gpu
+def test_general_path_long_run_vs_oracle(device, oracle):
+    """3 000 consecutive steps (fused launches of 500) of grids with 2 gensets + 3 batteries + 2 grids + 2 loads + 2 pvs: every
+    reward and the final state of every module instance == the oracle's (state carried through the cache across launches)."""
+    import torch
+    from pymgrid_amd import BatchedMicrogridEnv, MicrogridBatch
+    rs = np.random.RandomState(11)
+    T, N = 3000, 6
+    grids = [_random_multi_grid(rs, T + 1, 2, 3, 2, 2, 2, 0, False) for j in range(N)]
+    env = BatchedMicrogridEnv(MicrogridBatch.from_grids(grids, device=device), observations=False)
+    A = env.layout.action_dim
+    acts = torch.rand(T, N, A, dtype=torch.float64, device=device)
+    rewards = torch.cat([env.engine.step_k(acts[k:k + 500], reward=True)["reward"] for k in range(0, T, 500)]).cpu().numpy()
+    a = acts.cpu().numpy()
+    for j, g in enumerate(grids):
+        om = oracle.OracleMultiMicrogrid(g)
+        for k in range(T):
+            assert rewards[k, j] == om.run(a[k, j], True).common.reward, (j, k)
+        ch = env.batch.cols["charge"].reshape(3, N)[:, j].cpu().numpy()
+        st = env.batch.cols["gen_status"].reshape(2, N)[:, j].cpu().numpy().view(np.uint32)
+        assert [om.s.battery[q].charge for q in range(3)] == list(ch)
+        for q in range(2):
+            s = om.s.genset[q]
+            assert _unpack(st[q]) == [s.gen_cur, s.gen_goal, s.gen_up, s.gen_down]
+    env.close()
