@@ -466,18 +466,31 @@ def main():
     # the headline first (its launch indices in a rocprofv3 trace are then [prewarm + W, prewarm + W + K) per queue)
     results = {args.mode: measure(args.mode, sharded=(S > 1 and args.mode in ("fused", "rbc")), rounds=args.steps,
                                   warmup=args.warmup)}
+    def guarded(what, fn):
+        """The side legs must not take the headline down with them: on one GPU a failure is reported in the line instead
+        (with several ranks it propagates -- a rank that skipped a leg would leave the others waiting in its barriers)."""
+        if world > 1:
+            return fn()
+        try:
+            return fn()
+        except Exception as e:          # noqa: BLE001
+            print(f"bench.py: {what} failed: {type(e).__name__}: {e}", file=sys.stderr)
+            return {"error": f"{type(e).__name__}: {e}"}
+
     if not args.no_side_modes:
         side = (min(args.steps, SIDE_ROUNDS[0]), min(args.warmup, SIDE_ROUNDS[1]))
         for mode in ("fused", "step", "rbc"):
             if mode != args.mode:
-                results[mode] = measure(mode, sharded=(S > 1 and mode in ("fused", "rbc")), rounds=side[0], warmup=side[1])
+                results[mode] = guarded(mode, lambda mode=mode: measure(mode, sharded=(S > 1 and mode in ("fused", "rbc")),
+                                                                        rounds=side[0], warmup=side[1]))
         if S > 1:    # the same fused kernel as ONE launch sequence over all N grids
-            results["fused_one_stream"] = measure("fused", sharded=False, rounds=side[0], warmup=side[1])
-        results["step_python"] = measure("step_python", sharded=False, rounds=min(side[0], 32), warmup=min(side[1], 8))
+            results["fused_one_stream"] = guarded("fused_one_stream", lambda: measure("fused", sharded=False, rounds=side[0], warmup=side[1]))
+        results["step_python"] = guarded("step_python", lambda: measure("step_python", sharded=False, rounds=min(side[0], 32),
+                                                                        warmup=min(side[1], 8)))
 
     hetero = None
     if args.hetero_steps > 0:
-        hetero = hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist)
+        hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist))
 
     # metrics vector: episode-return sum + mean SoC, all-reduced over ranks (the ONLY collective; RCCL over xGMI)
     sums = eng.metrics(torch.stack([run.outs[0]["reward"][-1], batch.cols["soc"]]))
@@ -486,7 +499,11 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:      # rank 0 only; for N > 1 a shorter sample while the other ranks wait
-        cpu = cpu_baseline(eng, run.pool, args.cpu_seconds if world == 1 else min(args.cpu_seconds, 4.0))
+        try:
+            cpu = cpu_baseline(eng, run.pool, args.cpu_seconds if world == 1 else min(args.cpu_seconds, 4.0))
+        except Exception as e:          # noqa: BLE001  (a host without gcc / OpenMP must not cost the GPU numbers)
+            print(f"bench.py: cpu_baseline failed: {type(e).__name__}: {e}", file=sys.stderr)
+            cpu = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         main_r = results[args.mode]
@@ -507,7 +524,7 @@ def main():
             "roofline": main_r["roofline"],
             "cpu_baseline": cpu,
             "per_rank_env_steps_per_s": main_r["per_rank_env_steps_per_s"],
-            "other": {names[m]: {k: r[k] for k in ("value", "steps", "warmup", "ms_per_step", "roofline")}
+            "other": {names[m]: (r if "error" in r else {k: r[k] for k in ("value", "steps", "warmup", "ms_per_step", "roofline")})
                       for m, r in results.items() if m != args.mode},
             "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total},
             "hetero_h24_gym_steps": hetero,
