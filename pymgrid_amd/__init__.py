@@ -15,4 +15,6 @@ from .rbc import RuleBasedControl  # noqa: F401
 from .trajectory import (BatteryDischargeShaper, DeterministicTrajectory,  # noqa: F401
                          FixedLengthStochasticTrajectory, PVCurtailmentShaper, StochasticTrajectory)
 
+Microgrid = MicrogridEnv      # ``pymgrid.Microgrid``'s stepping surface: run / step / reset / sample_action / get_log / from_scenario
+
 __version__ = "0.1.0"

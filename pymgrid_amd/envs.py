@@ -587,6 +587,26 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
 
     run = step
 
+    def sample_action(self, strict_bound=False, sample_flex_modules=False):
+        """``Microgrid.sample_action`` (microgrid.py:337-362): a random NORMALISED control dict ``{name: [per-module value]}`` (a
+        genset's value is ``array([goal_status, energy])``), uniform in [0, 1) from numpy's global generator.  ``strict_bound``
+        (bounds that depend on the current state) is not offered; flex modules take no action."""
+        if strict_bound:
+            raise NotImplementedError("strict_bound=True is not offered (the reference itself fails on it for gensets, SURVEY Q4)")
+        L, out = self.layout, {}
+        if L.has_genset:
+            out["genset"] = [np.random.rand(2) for _ in range(L.n_genset)]
+        if L.has_battery:
+            out["battery"] = [float(np.random.rand()) for _ in range(L.n_battery)]
+        if L.has_grid:
+            out["grid"] = [float(np.random.rand()) for _ in range(L.n_grid)]
+        return out
+
+    def get_empty_action(self, sample_flex_modules=False):
+        """``Microgrid.get_empty_action`` (microgrid.py:364-381): the control dict's shape with ``None`` entries."""
+        L = self.layout
+        return {name: [None] * n for name, n in (("genset", L.n_genset), ("battery", L.n_battery), ("grid", L.n_grid)) if n}
+
 
 class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
     """One microgrid behind ``DiscreteMicrogridEnv``'s API (envs/discrete/discrete.py:10-152):

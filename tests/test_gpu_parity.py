@@ -330,6 +330,14 @@ def test_gym_adaptors_shapes(pymgrid25, device):
         obs, reward, done, info = env.step(ctrl, normalized=True)
         assert isinstance(reward, float) and len(obs["load"][0]) == 24
         # Env.from_microgrid (envs/base/base.py:253-283): wrap a stepped microgrid -- parameters AND current state carry over
+        # Microgrid.sample_action / get_empty_action / run (microgrid.py:227-381) on the continuous adaptor
+        from pymgrid_amd import Microgrid
+        mg = Microgrid(pymgrid25[n], device=device)
+        ctrl = mg.sample_action()
+        assert set(ctrl) == set(mg.get_empty_action()) == {k for k in ("genset", "battery", "grid") if pymgrid25[n].get(k) is not None}
+        o2, r2, d2, i2 = mg.run(ctrl, normalized=True)
+        assert isinstance(r2, float) and isinstance(d2, bool) and len(o2) == mg.layout.obs_dim
+        mg.close()
         twin = DiscreteMicrogridEnv.from_microgrid(env)
         for name in ("charge", "soc", "gen_status"):
             if name in env.batch.cols:
