@@ -56,4 +56,20 @@ for mix in ((1, 1, 1, 1, 1), (1, 1, 1, 2, 2), (2, 2, 1, 1, 1), (2, 2, 2, 2, 2), 
         kind = "general" if b.layout.multi else "single-instance"
         print(f"gensets {mix[0]} batteries {mix[1]} grids {mix[2]} loads {mix[3]} pvs {mix[4]}  log={int(want_log)}  {kind:15s} "
               f"{us:8.2f} us/step  {N / us / 1e3:6.2f} G env-steps/s  (A = {eng.action_dim}, L = {eng.log_dim})")
+    # the K-step loop of the general path (mgx_step_k on such layouts) / the fused kernel of the single-instance layout
+    K = 64
+    acts = torch.rand(K, N, eng.action_dim, dtype=torch.float64, device=dev)
+    out = dict(reward=torch.empty(K, N, dtype=torch.float64, device=dev))
+    for _ in range(3):
+        eng.reset(0, want_obs=False); eng.step_k(acts, out=out, reward=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    eng.reset(0, want_obs=False)
+    e0.record()
+    for _ in range(8):
+        eng.step_k(acts, out=out, reward=True)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / (8 * K) * 1e3
+    print(f"gensets {mix[0]} batteries {mix[1]} grids {mix[2]} loads {mix[3]} pvs {mix[4]}  fused K={K}      "
+          f"{us:8.2f} us/step  {N / us / 1e3:6.2f} G env-steps/s")
     eng.close()
