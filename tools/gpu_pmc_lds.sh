@@ -1,0 +1,16 @@
+#!/bin/bash
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/pmc_lds; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace -d "$OUT/a" -o b --output-format csv -- python "$REPO/tools/exp_hetero_trace.py" 256 16 float64 ahead > "$OUT/a.log" 2>&1
+python - "$OUT" <<'PY'
+import csv, glob, os, sys
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "obs_windows_k_kernel" in k or "fleet_step_kernel" in k:
+            acc[k.split("mgx::")[1].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in sorted(acc.items()):
+    print(k, {c: round(sum(v) / len(v)) for c, v in d.items()})
+PY
