@@ -184,6 +184,22 @@ int mgx_set_window(mgx_handle *h, int32_t initial_step, int32_t final_step);
 int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length,
                       double *load_w, double *pv_w, double *grid_w, int32_t *final_rel, void *obs, mgx_stream stream);
 
+/* Rolling per-grid windows: N reference microgrids reset one by one, each when ITS episode ends (what a vectorised
+ * Gym env does with auto-reset; microgrid.py:205-225 per microgrid, at different times).  As mgx_reset_windows, but the
+ * window buffers [ring_rows, N] ([ring_rows, 4, N]) are rings addressed by (step counter & (ring_rows - 1)):
+ * ring_rows a power of two >= max_length + horizon + 1.  The shared counter restarts at 0 and never ends; final_abs [N]
+ * (device, required) receives the counter value at which each grid's episode has run its length, done_i =
+ * counter >= final_abs[i] - 1.  Single steps only (mgx_step, mgx_step_discrete, mgx_step_many, mgx_observe, ...);
+ * fused launches, window prefetch, shards and the device counter are refused in this mode.  mgx_reset / mgx_reset_windows
+ * leave it. */
+int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length,
+                              int32_t ring_rows, double *load_w, double *pv_w, double *grid_w, int32_t *final_abs, void *obs,
+                              mgx_stream stream);
+/* Restart the grids with mask[i] != 0 at the current counter value: their rows start[i] .. of the full series are
+ * gathered into the rings from the current row on, final_abs[i] = counter + length[i] (length NULL: max_length).  Dynamic
+ * state is untouched, as in Microgrid.reset.  mask / start / length: device arrays [N]. */
+int mgx_reset_grids(mgx_handle *h, const uint8_t *mask, const int32_t *start, const int32_t *length, mgx_stream stream);
+
 /* Microgrid.reward_shaping_func (microgrid.py:105,130): one of enum mgx_reward_shaper. */
 int mgx_set_reward_shaper(mgx_handle *h, int32_t shaper);
 

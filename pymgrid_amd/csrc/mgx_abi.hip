@@ -52,6 +52,10 @@ struct mgx_handle {
     // per-grid episode windows (mgx_reset_windows): the full series are remembered here while the handle steps over the
     // caller's window buffers
     bool windowed;
+    bool rolling;                            // mgx_reset_windows_rolling: ring buffers, partial resets (mgx_reset_grids)
+    int32_t rolling_max_length;
+    double *roll_load_w, *roll_pv_w, *roll_grid_w;
+    int32_t *roll_final;
     const double *full_load_ts, *full_pv_ts, *full_grid_ts;
     int32_t full_T, full_final, full_initial, full_window_lo, full_window_hi;
 };
@@ -92,7 +96,11 @@ inline int32_t t_arg(const mgx_handle *h) { return h->k.t_dev ? 0 : h->t; }
 inline bool dev_counter(const mgx_handle *h) { return h->k.t_dev != nullptr; }
 // rows a stepping call may consume: the series -- or, during a per-grid-window episode, the longest episode (the window
 // buffers hold horizon + 1 further rows, but those are forecast rows: stepping into them is stepping past the end)
-inline int32_t step_limit(const mgx_handle *h) { return h->windowed ? h->layout.final_step : h->k.T; }
+inline int32_t step_limit(const mgx_handle *h)
+{
+    if (h->rolling) return INT32_MAX / 2;            // rolling windows: every grid ends (and restarts) on its own
+    return h->windowed ? h->layout.final_step : h->k.T;
+}
 inline void advance(mgx_handle *h, int32_t k, hipStream_t st)
 {
     h->counter_stream = st;      // device-counter mode: the stepping kernel itself advanced the counter (on this stream)
@@ -300,7 +308,8 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->d_kargs = nullptr; h->k_uploaded_valid = false;
     h->d_table = nullptr; h->table_uploaded_valid = false;
     h->prefetch_stream = nullptr; h->prefetch_gate = nullptr; h->prefetch_done = nullptr; h->prefetch_pending = false;
-    h->windowed = false;
+    h->windowed = false; h->rolling = false;
+    h->k.row_mask = -1;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
         return hip_fail(e, "hipMalloc(scratch)");
@@ -430,6 +439,7 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "%s: K = %d outside [1, 4096]", who, K);
     if (ahead < 0) return fail(MGX_ERR_INVALID, "%s: ahead = %d is negative", who, ahead);
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "%s: needs exactly one module of every kind per grid", who);
+    if (h->rolling) return fail(MGX_ERR_UNSUPPORTED, "%s: prefetched windows go stale when a grid restarts (rolling windows)", who);
     if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
         return fail(MGX_ERR_UNSUPPORTED, "%s: forecast noise depends on (step, horizon index), windows cannot be shared", who);
     if (int rc = need_obs_bounds(h, who)) return rc;
@@ -611,7 +621,8 @@ static void leave_windows(mgx_handle *h)
     h->k.T = h->full_T; h->k.final_step = h->full_final; h->k.grid_final = nullptr;
     h->layout.n_steps = h->full_T; h->layout.final_step = h->full_final; h->layout.initial_step = h->full_initial;
     h->window_lo = h->full_window_lo; h->window_hi = h->full_window_hi;
-    h->windowed = false;
+    h->windowed = false; h->rolling = false;
+    h->k.row_mask = -1;
 }
 
 int mgx_reset(mgx_handle *h, int32_t initial_step, void *obs, mgx_stream stream)
@@ -655,9 +666,11 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
     g.start = start; g.length = length; g.final_rel = final_rel;
     g.N = h->k.N; g.T = h->full_T; g.rows = rows; g.max_length = max_length;
     g.lo = h->full_window_lo; g.hi = h->full_window_hi;
+    g.mask = nullptr; g.row0 = 0; g.row_mask = -1;
     gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gather_windows_kernel launch");
+    h->rolling = false; h->k.row_mask = -1;
     h->k.c.load_ts = load_w; h->k.c.pv_ts = pv_w; if (h->layout.has_grid) h->k.c.grid_ts = grid_w;
     h->k.T = rows; h->k.final_step = max_length; h->k.grid_final = length ? final_rel : nullptr;
     h->layout.n_steps = rows; h->layout.final_step = max_length; h->layout.initial_step = 0;
@@ -665,6 +678,75 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
     h->windowed = true;
     h->t = 0;
     return obs ? mgx_observe(h, obs, stream) : MGX_OK;
+}
+
+// ---- rolling per-grid windows: every grid restarts on its own ----------------------------------------------------------
+static void rolling_gather_args(const mgx_handle *h, GatherArgs *g)
+{
+    g->load_ts = h->full_load_ts; g->pv_ts = h->full_pv_ts; g->grid_ts = h->layout.has_grid ? h->full_grid_ts : nullptr;
+    g->load_lo = h->k.c.load_lo; g->load_hi = h->k.c.load_hi; g->pv_lo = h->k.c.pv_lo; g->pv_hi = h->k.c.pv_hi;
+    g->grid_lo = h->k.c.grid_lo; g->grid_hi = h->k.c.grid_hi;
+    g->load_w = h->roll_load_w; g->pv_w = h->roll_pv_w; g->grid_w = h->roll_grid_w;
+    g->final_rel = h->roll_final;
+    g->N = h->k.N; g->T = h->full_T; g->rows = h->rolling_max_length + h->k.H + 1; g->max_length = h->rolling_max_length;
+    g->lo = h->full_window_lo; g->hi = h->full_window_hi;
+    g->row_mask = h->k.row_mask;
+}
+
+int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length, int32_t ring_rows,
+                              double *load_w, double *pv_w, double *grid_w, int32_t *final_abs, void *obs, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !start || !load_w || !pv_w || !final_abs) return fail(MGX_ERR_INVALID, "mgx_reset_windows_rolling: NULL argument");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: needs exactly one module of every kind per grid");
+    if (h->layout.has_grid && !grid_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows_rolling: grid_w is NULL but the layout has a GridModule");
+    if (h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: not offered in device-counter mode");
+    if (h->n_shards > 1) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: not offered while the handle steps in shards");
+    if (h->k.obs_state_only) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: prefetched observation windows would "
+                                                               "go stale when a grid restarts; use full observation rows");
+    if (!h->windowed) {
+        h->full_load_ts = h->k.c.load_ts; h->full_pv_ts = h->k.c.pv_ts; h->full_grid_ts = h->k.c.grid_ts;
+        h->full_T = h->k.T; h->full_final = h->layout.final_step; h->full_initial = h->layout.initial_step;
+        h->full_window_lo = h->window_lo; h->full_window_hi = h->window_hi;
+    }
+    if (max_length < 1 || max_length > h->full_window_hi - h->full_window_lo)
+        return fail(MGX_ERR_INVALID, "Cannot create a trajectory of length %d between initial_step (%d) and final_step (%d)",
+                    max_length, h->full_window_lo, h->full_window_hi);
+    if (ring_rows < max_length + h->k.H + 1 || (ring_rows & (ring_rows - 1)) != 0)
+        return fail(MGX_ERR_INVALID, "mgx_reset_windows_rolling: ring_rows = %d must be a power of two >= max_length + horizon + 1 = %d",
+                    ring_rows, max_length + h->k.H + 1);
+    h->rolling_max_length = max_length;
+    h->roll_load_w = load_w; h->roll_pv_w = pv_w; h->roll_grid_w = grid_w; h->roll_final = final_abs;
+    h->k.row_mask = ring_rows - 1;
+    GatherArgs g;
+    rolling_gather_args(h, &g);
+    g.start = start; g.length = length; g.mask = nullptr; g.row0 = 0;
+    hipStream_t st = (hipStream_t)stream;
+    gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gather_windows_kernel launch");
+    h->k.c.load_ts = load_w; h->k.c.pv_ts = pv_w; if (h->layout.has_grid) h->k.c.grid_ts = grid_w;
+    h->k.T = INT32_MAX / 2; h->k.final_step = INT32_MAX / 2; h->k.grid_final = final_abs;
+    h->layout.n_steps = ring_rows; h->layout.final_step = INT32_MAX / 2; h->layout.initial_step = 0;
+    h->window_lo = 0; h->window_hi = INT32_MAX / 2;
+    h->windowed = true; h->rolling = true;
+    h->t = 0;
+    return obs ? mgx_observe(h, obs, stream) : MGX_OK;
+}
+
+int mgx_reset_grids(mgx_handle *h, const uint8_t *mask, const int32_t *start, const int32_t *length, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !mask || !start) return fail(MGX_ERR_INVALID, "mgx_reset_grids: NULL argument");
+    if (!h->rolling) return fail(MGX_ERR_INVALID, "mgx_reset_grids: the handle is not in rolling-window mode (mgx_reset_windows_rolling)");
+    if (h->t > INT32_MAX / 4) return fail(MGX_ERR_RANGE, "mgx_reset_grids: the shared step counter is about to overflow; start over "
+                                                         "with mgx_reset_windows_rolling");
+    GatherArgs g;
+    rolling_gather_args(h, &g);
+    g.start = start; g.length = length; g.mask = mask; g.row0 = h->t;
+    gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, (hipStream_t)stream>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "gather_windows_kernel launch");
 }
 
 // ---- shards -------------------------------------------------------------------------------------------------
@@ -824,6 +906,7 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
     g_err[0] = 0;
     if (!h || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_step_k: NULL argument");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_step_k: K must be positive");
+    if (h->rolling) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: rolling windows take single steps (grids restart between steps)");
     if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
         return fail(MGX_ERR_RANGE, "mgx_step_k: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, step_limit(h));
     hipStream_t st = (hipStream_t)stream;
@@ -973,6 +1056,7 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     g_err[0] = 0;
     if (!h || !action_id || !table) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: NULL argument");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: K must be positive");
+    if (h->rolling) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: rolling windows take single steps");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: needs exactly one module of every kind "
                                                     "per grid; use mgx_expand_discrete / mgx_expand_lists + mgx_step");
     if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
@@ -1048,7 +1132,7 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
     for (int32_t j = 0; j < n && fusable; j++) {
         const mgx_fleet_item &it = items[j];
         const mgx_handle *h = it.handle;
-        fusable = !h->multi && !dev_counter(h) && h->n_shards <= 1 && !(it.obs && h->k.H > 0 && !h->k.obs_state_only);
+        fusable = !h->multi && !h->rolling && !dev_counter(h) && h->n_shards <= 1 && !(it.obs && h->k.H > 0 && !h->k.obs_state_only);
         for (int32_t q = 0; q < j && fusable; q++) fusable = items[q].handle != it.handle;      // a batch steps once per call
     }
     bool chunk_done[64];                                    // window chunks that rode along with the step launch

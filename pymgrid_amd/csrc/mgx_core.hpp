@@ -59,6 +59,9 @@ struct KArgs {
     int32_t g0, g1;
     // Per-grid episode ends (mgx_reset_windows): done_i = t >= grid_final[i] - 1 instead of the batch-wide final_step.
     const int32_t *grid_final;
+    // Rolling per-grid windows (mgx_reset_windows_rolling): the window buffers are rings of 2^p rows addressed by
+    // (step counter & row_mask); -1 (all ones: the identity) everywhere else.
+    int32_t row_mask;
 };
 
 // done flag of grid i at step counter t: _done(), base_timeseries_module.py:124-125 (evaluated before the counter moves)
@@ -656,14 +659,15 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
     const mgx_columns &c = a.c;
     const int64_t N = a.N;
     const bool in = t < a.T;
+    const int64_t tr = t & a.row_mask;                  // row of the series buffers (rolling windows: a ring)
     {
         const double lo = c.load_lo[i], hi = c.load_hi[i];
-        const double v = in ? c.load_ts[(int64_t)t * N + i] : 0.0;
+        const double v = in ? c.load_ts[tr * N + i] : 0.0;
         obs_row[0] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     {
         const double lo = c.pv_lo[i], hi = c.pv_hi[i];
-        const double v = in ? c.pv_ts[(int64_t)t * N + i] : 0.0;
+        const double v = in ? c.pv_ts[tr * N + i] : 0.0;
         obs_row[1] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     observe_state_cols<F, OT>(a, p, s, obs_row);
@@ -672,7 +676,7 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
             const double lo = c.grid_lo[cc * N + i], hi = c.grid_hi[cc * N + i];
-            const double v = in ? c.grid_ts[((int64_t)t * 4 + cc) * N + i] : 0.0;
+            const double v = in ? c.grid_ts[(tr * 4 + cc) * N + i] : 0.0;
             obs_row[k + cc] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
         }
     }
@@ -720,7 +724,7 @@ __device__ __forceinline__ void observe_window_cols(const double *__restrict__ t
                                                     int32_t T, int32_t t, int32_t W, int64_t i, int64_t ic, int32_t q, int32_t Q,
                                                     OT *row /* tile + g*LD + first column of this module */,
                                                     const double *__restrict__ noise_std, uint32_t comp_base,
-                                                    uint64_t noise_seed, int noise_increase)
+                                                    uint64_t noise_seed, int noise_increase, int32_t row_mask = -1)
 {
     double lo[NC], hi[NC], fill[NC], sp[NC];
 #pragma unroll
@@ -735,7 +739,7 @@ __device__ __forceinline__ void observe_window_cols(const double *__restrict__ t
 #pragma unroll
         for (int jj = 0; jj < OBS_JB; jj++) {                         // unconditional, clamped loads (one latency round)
             const int32_t r = t + hb + q + Q * jj;
-            const int32_t rc = r < T ? r : T - 1;
+            const int32_t rc = (r < T ? r : T - 1) & row_mask;
 #pragma unroll
             for (int c = 0; c < NC; c++) v[jj][c] = ts[(int64_t)rc * row_stride + c * N + ic];
         }

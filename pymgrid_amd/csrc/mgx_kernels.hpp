@@ -44,8 +44,8 @@ __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict
 {
     // all loads first (independent, one latency round), then the arithmetic
     Params p; State s; Inputs in; Outputs o; Derived d;
-    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t, in);
-    else load_inputs<F>(a.c, (const double *)actions, a.N, i, t, in);
+    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t & a.row_mask, in);
+    else load_inputs<F>(a.c, (const double *)actions, a.N, i, t & a.row_mask, in);
     load_state<F>(a.c, i, log != nullptr, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(BLOCK) void check_kernel(const KArgs a, const void 
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
-    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t, in);
-    else load_inputs<F>(a.c, (const double *)actions, a.N, i, t, in);
+    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t & a.row_mask, in);
+    else load_inputs<F>(a.c, (const double *)actions, a.N, i, t & a.row_mask, in);
     step_core<F>(p, d, s, in, normalized != 0, false, false, o);
     violations[i] = o.violations;
 }
@@ -268,7 +268,9 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
     const int32_t slots = OBS_JB * Q;
     const int32_t W_pad = (W + slots - 1) / slots * slots;
     // wave-uniform: every slot's row exists, lane offsets fit 32-bit byte offsets
-    const bool fast = t >= 0 && (int64_t)t + W_pad <= a.T && (int64_t)(4 * Q + 4) * N < (int64_t(1) << 28);
+    const int32_t tr = t & a.row_mask;                  // rolling windows: the buffers are rings of row_mask + 1 rows
+    const bool fast = t >= 0 && (int64_t)t + W_pad <= a.T && (int64_t)(4 * Q + 4) * N < (int64_t(1) << 28) &&
+                      (a.row_mask == -1 || tr + W_pad <= a.row_mask + 1);               // ... and this window does not wrap
     if (fast) {
         WinBounds<1> bl, bp;
         WinBounds<(F & F_GRID) ? 4 : 1> bg;
@@ -277,9 +279,9 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
         if constexpr (F & F_GRID) window_bounds<4>(a.c.grid_lo, a.c.grid_hi, N, ic, bg);
         for (int32_t hb = 0; hb < W; hb += slots) {      // one round for the usual 24 / 25-step windows
             double vl[OBS_JB][1], vp[OBS_JB][1], vg[OBS_JB][(F & F_GRID) ? 4 : 1];
-            window_issue<1>(a.c.load_ts, N, N, t, hb, Q, (uint32_t)(q * N + ic), vl);     // all loads of the round in flight
-            window_issue<1>(a.c.pv_ts, N, N, t, hb, Q, (uint32_t)(q * N + ic), vp);
-            if constexpr (F & F_GRID) window_issue<4>(a.c.grid_ts, N, 4 * N, t, hb, Q, (uint32_t)(q * 4 * N + ic), vg);
+            window_issue<1>(a.c.load_ts, N, N, tr, hb, Q, (uint32_t)(q * N + ic), vl);    // all loads of the round in flight
+            window_issue<1>(a.c.pv_ts, N, N, tr, hb, Q, (uint32_t)(q * N + ic), vp);
+            if constexpr (F & F_GRID) window_issue<4>(a.c.grid_ts, N, 4 * N, tr, hb, Q, (uint32_t)(q * 4 * N + ic), vg);
             if (hb == 0) window_bounds_finish<1>(bl);
             window_finish<1, NOISE, OT>(vl, bl, W, t, hb, i, ic, q, Q, row, a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
             if (hb == 0) window_bounds_finish<1>(bp);
@@ -292,12 +294,12 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
         }
     } else {
         observe_window_cols<1, NOISE, OT>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row,
-                                      a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
+                                      a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase, a.row_mask);
         observe_window_cols<1, NOISE, OT>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + W,
-                                      a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase);
+                                      a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase, a.row_mask);
         if constexpr (F & F_GRID)
             observe_window_cols<4, NOISE, OT>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q,
-                                          row + plan.grid_col_base, a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase);
+                                          row + plan.grid_col_base, a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
     }
     if (q == 0) {                                        // the 6 state columns, by the first lane of each grid
         Params p; State s;
@@ -515,10 +517,11 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
     Params p; State s; Inputs in;
     load_state<F>(a.c, i, false, s);
     load_params<F>(a.c, i, p);
-    in.load = a.c.load_ts[(int64_t)t * N + i];
-    in.pv = a.c.pv_ts[(int64_t)t * N + i];
+    const int64_t tr = t & a.row_mask;
+    in.load = a.c.load_ts[tr * N + i];
+    in.pv = a.c.pv_ts[tr * N + i];
     in.g_stat = 1.0;
-    if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[((int64_t)t * 4 + 3) * N + i];
+    if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[(tr * 4 + 3) * N + i];
     double q_unused;
     populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused, 0.0 + -1 * in.load, in.pv);
     double *c = control + i * A;
@@ -555,8 +558,8 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     const int64_t N = a.N;
     Params p; State s; Inputs in; Outputs o; Derived d;
     const int32_t id = action_id[i];
-    load_series_at<F>(a.c.load_ts + (int64_t)t * N, a.c.pv_ts + (int64_t)t * N,
-                      (F & F_GRID) ? a.c.grid_ts + (int64_t)t * 4 * N : nullptr, N, i, i, in);
+    const int64_t tr = t & a.row_mask;
+    load_series_at<F>(a.c.load_ts + tr * N, a.c.pv_ts + tr * N, (F & F_GRID) ? a.c.grid_ts + tr * 4 * N : nullptr, N, i, i, in);
     load_state<F>(a.c, i, log != nullptr, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
@@ -1083,12 +1086,14 @@ struct GatherArgs {
     const int32_t *start, *length;
     int32_t *final_rel;
     int32_t N, T, rows, max_length, lo, hi;
+    const uint8_t *mask;      // NULL = every grid; else only grids with mask[i] != 0 (a partial reset)
+    int32_t row0, row_mask;   // destination row of source row start_i + r: (row0 + r) & row_mask (linear windows: 0, -1)
 };
 
 __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs g)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= g.N) return;
+    if (i >= g.N || (g.mask && !g.mask[i])) return;
     const int64_t N = g.N;
     int32_t s = g.start[i];
     s = s < g.lo ? g.lo : (s > g.hi - 1 ? g.hi - 1 : s);            // a start outside the env's window is clamped into it
@@ -1097,7 +1102,7 @@ __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs 
     len = len < 1 ? 1 : len;
     len = len > g.max_length ? g.max_length : len;
     len = len > room ? room : len;                                     // the episode ends at the env's final step at the latest
-    if (g.final_rel) g.final_rel[i] = len;
+    if (g.final_rel) g.final_rel[i] = g.row0 + len;       // counter value at which the episode has run its length
     const double fl = (g.load_lo && g.load_hi) ? (g.load_hi[i] + g.load_lo[i]) / 2 : 0.0;
     const double fp = (g.pv_lo && g.pv_hi) ? (g.pv_hi[i] + g.pv_lo[i]) / 2 : 0.0;
     double fg[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1110,14 +1115,15 @@ __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs 
         const bool in = row < g.T;
         const int64_t src = (in ? row : (int64_t)g.T - 1) * N + i;
         const double vl = g.load_ts[src], vp = g.pv_ts[src];
-        g.load_w[(int64_t)r * N + i] = in ? vl : fl;
-        g.pv_w[(int64_t)r * N + i] = in ? vp : fp;
+        const int64_t dst = (g.row0 + r) & g.row_mask;
+        g.load_w[dst * N + i] = in ? vl : fl;
+        g.pv_w[dst * N + i] = in ? vp : fp;
         if (g.grid_ts) {
             const int64_t sg = (in ? row : (int64_t)g.T - 1) * 4 * N + i;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const double v = g.grid_ts[sg + c * N];
-                g.grid_w[((int64_t)r * 4 + c) * N + i] = in ? v : fg[c];
+                g.grid_w[(dst * 4 + c) * N + i] = in ? v : fg[c];
             }
         }
     }

@@ -128,7 +128,8 @@ class StepEngine:
         """Observation rows of the next K steps, ``ring[k]`` = the row of step counter t + k (block 0 complete, blocks
         1..K-1 without the state columns): every series value is read and normalised once instead of 1 + horizon times."""
         if out is None:
-            out = torch.empty((int(K), self.N, self.obs_dim), dtype=self.obs_dtype, device=self.device)
+            pitch = getattr(self, "_ring_pitch", self.N)
+            out = torch.empty((int(K), pitch, self.obs_dim), dtype=self.obs_dtype, device=self.device)[:, :self.N]
         self._check_ring(out)
         self._call(self._lib.mgx_observe_windows, int(out.shape[0]), out.data_ptr())
         return out
@@ -194,6 +195,7 @@ class StepEngine:
         self._call(self._lib.mgx_reset, -1 if initial_step is None else int(initial_step), _ptr(obs))
         if getattr(self, "_window_start", None) is not None:       # a per-grid-window episode ends with a plain reset
             self._window_start = None
+            self._window_t0 = None
             self.window = self._full_window
         return obs
 
@@ -222,8 +224,49 @@ class StepEngine:
         self._call(self._lib.mgx_reset_windows, start.data_ptr(), _ptr(length), int(max_length), w["load"].data_ptr(),
                    w["pv"].data_ptr(), _ptr(w["grid"]), w["final"].data_ptr() if length is not None else None, _ptr(obs))
         self._window_start = start
+        self._window_t0 = None
         self.window = (0, int(max_length))
         return obs
+
+    def reset_windows_rolling(self, start, length=None, max_length=None, want_obs=True, out=None):
+        """Rolling per-grid windows (``mgx_reset_windows_rolling``): as ``reset_windows``, but the window buffers are rings
+        (2^p rows >= max_length + horizon + 1), the shared counter never ends, and ``reset_grids`` restarts individual grids
+        at any later step.  Single steps only."""
+        L = self.layout
+        if start.dtype != torch.int32 or tuple(start.shape) != (self.N,) or start.device != self.device:
+            raise ValueError(f"start must be an int32 tensor of shape ({self.N},) on {self.device}")
+        if length is not None and (length.dtype != torch.int32 or tuple(length.shape) != (self.N,) or length.device != self.device):
+            raise ValueError(f"length must be an int32 tensor of shape ({self.N},) on {self.device}")
+        if max_length is None:
+            raise ValueError("max_length is required (the longest episode any later reset_grids may ask for)")
+        need = int(max_length) + L.horizon + 1
+        rows = 1 << (need - 1).bit_length()
+        w = getattr(self, "_rolling", None)
+        if w is None or w["rows"] != rows:
+            w = dict(rows=rows, load=self._empty(rows, self.N), pv=self._empty(rows, self.N),
+                     grid=self._empty(rows, 4, self.N) if L.has_grid else None, final=self._empty(self.N, dtype=torch.int32))
+            self._rolling = w
+        obs = self._obs_buf(out) if want_obs else None
+        self._call(self._lib.mgx_reset_windows_rolling, start.data_ptr(), _ptr(length), int(max_length), rows,
+                   w["load"].data_ptr(), w["pv"].data_ptr(), _ptr(w["grid"]), w["final"].data_ptr(), _ptr(obs))
+        self._window_start = start.clone()                 # per-grid: series row of the episode's first step ...
+        self._window_t0 = torch.zeros_like(start)          # ... and the counter value it started at
+        self.window = (0, int(max_length))
+        self._rolling_max = int(max_length)
+        return obs
+
+    def reset_grids(self, mask, start, length=None):
+        """Restart the grids with ``mask[i] != 0`` at the current step (``mgx_reset_grids``): new start rows / lengths for
+        them, everything else keeps running.  ``mask`` uint8 / bool [N], ``start`` / ``length`` int32 [N] on the device."""
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        for name, t, dt in (("mask", mask, torch.uint8), ("start", start, torch.int32), ("length", length, torch.int32)):
+            if t is not None and (t.dtype != dt or tuple(t.shape) != (self.N,) or t.device != self.device or not t.is_contiguous()):
+                raise ValueError(f"{name} must be a contiguous {dt} tensor of shape ({self.N},) on {self.device}")
+        self._call(self._lib.mgx_reset_grids, mask.data_ptr(), start.data_ptr(), _ptr(length))
+        m = mask.view(torch.bool)
+        self._window_start = torch.where(m, start, self._window_start)
+        self._window_t0 = torch.where(m, torch.full_like(start, self.current_step), self._window_t0)
 
     def set_shards(self, n_shards):
         """Step in ``n_shards`` independent grid ranges, one internal HIP stream each (``mgx_set_shards``).  While

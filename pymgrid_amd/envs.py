@@ -148,11 +148,16 @@ class BatchedMicrogridEnv:
             return self._select_obs(self._refill())
         return self._select_obs(self.engine.reset(initial_step, want_obs=self._observations))
 
-    def reset_windows(self, start, length=None, max_length=None):
+    def reset_windows(self, start, length=None, max_length=None, rolling=False):
         """Per-grid episodes (``mgx_reset_windows``; the reference's per-microgrid trajectories, microgrid.py:205-225,
         trajectory/stochastic.py:9-30): grid i starts at series row ``start[i]`` and is ``done`` after ``length[i]`` steps
         (``length=None``: ``max_length`` steps for every grid).  The batch still advances in lock-step; ``current_steps``
-        gives every grid's own step counter.  A plain ``reset()`` returns to the shared window."""
+        gives every grid's own step counter.  A plain ``reset()`` returns to the shared window.
+
+        ``rolling=True`` (``mgx_reset_windows_rolling``): the shared counter never ends and ``reset_grids(mask, start,
+        length)`` restarts individual grids at any later step -- N microgrids reset one by one, each when its own episode is
+        over.  ``max_length`` is then the longest episode any restart may ask for.  Observation rows are written per step
+        (no window prefetch: a restarted grid's future rows change)."""
         dev = self.batch.device
 
         def as_i32(v):
@@ -162,10 +167,33 @@ class BatchedMicrogridEnv:
         start, length = as_i32(start), as_i32(length)
         self._log_rows = []
         self._shaped_rows = []
+        if rolling:
+            if self._chunked:
+                raise RuntimeError("this env belongs to a fused BucketedFleet: rolling windows are not offered there")
+            if self.obs_prefetch:
+                self.set_obs_prefetch(0)
+            if max_length is None:
+                max_length = int(length.max().item())
+            return self._select_obs(self.engine.reset_windows_rolling(start, length, max_length, want_obs=self._observations))
         if self._ring is not None:
             self.engine.reset_windows(start, length, max_length, want_obs=False)
             return self._select_obs(self._refill())
         return self._select_obs(self.engine.reset_windows(start, length, max_length, want_obs=self._observations))
+
+    def reset_grids(self, mask, start, length=None, want_obs=True):
+        """Restart the grids with ``mask[i]`` set at the current step (rolling windows only; ``mgx_reset_grids``): each gets
+        the episode ``start[i]`` / ``length[i]`` (``Microgrid.reset`` of just those microgrids: counters move, dynamic state
+        stays).  Returns the observation rows of ALL grids at the current step (new episodes for the restarted ones)."""
+        dev = self.batch.device
+
+        def as_t(v, dt):
+            if v is None or (torch.is_tensor(v) and v.dtype in (dt, torch.bool) and v.device == dev and v.is_contiguous()):
+                return v
+            return torch.as_tensor(np.asarray(v.cpu() if torch.is_tensor(v) else v), device=dev).to(dt).contiguous()
+        self.engine.reset_grids(as_t(mask, torch.uint8), as_t(start, torch.int32), as_t(length, torch.int32))
+        if want_obs and self._observations:
+            return self._select_obs(self.engine.observe())
+        return None
 
     @property
     def current_steps(self):
@@ -175,7 +203,8 @@ class BatchedMicrogridEnv:
         st = self.engine._window_start
         if st is None:
             return torch.full((self.n_grids,), t, dtype=torch.int32, device=self.batch.device)
-        return st + t
+        t0 = getattr(self.engine, "_window_t0", None)       # rolling windows: the counter value each episode started at
+        return st + t if t0 is None else st + (t - t0)
 
     def set_obs_prefetch(self, K):
         """Switch the window prefetch on (K > 1 blocks per ring) or off (0) after construction; the next observation comes

@@ -301,9 +301,15 @@ class PerGridWindowEnv:
     ``[start_i, start_i + max length + H]`` of the full series into window buffers the step kernels walk from row 0, and
     ``done`` is per grid.  Observation bounds stay those of the full series, as in the reference.  Draws come from a
     torch generator on the device (the reference draws from numpy's global stream, one microgrid at a time).
+
+    ``auto_reset=True``: every grid restarts ON ITS OWN the moment its episode is over (rolling windows,
+    ``mgx_reset_windows_rolling`` / ``mgx_reset_grids``) -- N reference microgrids that are each reset when they report
+    ``done``, as a vectorised Gym env does.  ``step`` then returns the first observation of the new episode for the grids that
+    just finished (``info["final_observation"]`` holds the rows of the finished episodes) and the batch never needs a global
+    ``reset()`` again.  Observation rows are written per step in this mode.
     """
 
-    def __init__(self, full_batch, trajectory_length=None, discrete=False, generator=None, **env_kwargs):
+    def __init__(self, full_batch, trajectory_length=None, discrete=False, generator=None, auto_reset=False, **env_kwargs):
         L = full_batch.layout
         if L.multi:
             raise NotImplementedError("per-grid windows need one module of every kind per grid")
@@ -314,6 +320,9 @@ class PerGridWindowEnv:
                              f'between initial_step ({L.initial_step}) and final_step ({L.final_step})')
         self.generator = generator
         cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
+        self.auto_reset = bool(auto_reset)
+        if self.auto_reset:
+            env_kwargs = dict(env_kwargs, obs_prefetch=0)
         self.env = cls(full_batch, **env_kwargs)
         self.starts = self.lengths = None
 
@@ -345,10 +354,23 @@ class PerGridWindowEnv:
         max_len = self.length if self.lengths is None else int(self.lengths.max().item())
         if max_len is None:
             raise ValueError("lengths are required when the env was built without a trajectory_length")
+        if self.auto_reset:      # the rings must hold the longest episode any LATER restart can draw
+            L = self.full.layout
+            max_len = self.length if self.length is not None else L.final_step - L.initial_step
+            return self.env.reset_windows(self.starts, self.lengths, max_len, rolling=True)
         return self.env.reset_windows(self.starts, self.lengths, max_len)
 
     def step(self, action, **kw):
-        return self.env.step(action, **kw)
+        if not self.auto_reset:
+            return self.env.step(action, **kw)
+        obs, reward, done, info = self.env.step(action, **kw)
+        starts, lengths = self.draw()                      # a draw per grid; only the finished grids take theirs
+        new_obs = self.env.reset_grids(done, starts, lengths)
+        self.starts = torch.where(done, starts, self.starts)
+        if lengths is not None:
+            self.lengths = torch.where(done, lengths, self.lengths)
+        info = dict(info, final_observation=obs)
+        return (new_obs if new_obs is not None else obs), reward, done, info
 
     def __getattr__(self, name):              # everything else (engine, action_space, sample_action, ...) as the env
         return getattr(self.env, name)
