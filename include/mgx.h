@@ -199,6 +199,14 @@ int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t
  * gathered into the rings from the current row on, final_abs[i] = counter + length[i] (length NULL: max_length).  Dynamic
  * state is untouched, as in Microgrid.reset.  mask / start / length: device arrays [N]. */
 int mgx_reset_grids(mgx_handle *h, const uint8_t *mask, const int32_t *start, const int32_t *length, mgx_stream stream);
+/* The same with the new episodes DRAWN ON DEVICE, one draw per restarted grid as its own trajectory_func would make it:
+ * fixed_length > 0 = FixedLengthStochasticTrajectory(fixed_length) (start = randint(initial, final - length)),
+ * fixed_length == 0 = StochasticTrajectory (start = randint(initial, final - 2), final = randint(start, final));
+ * microgrid/trajectory/stochastic.py:9-30.  Uniforms: Philox4x32-10 of (seed; grid, 2 * counter [+ 1]) -- reproducible and
+ * independent of how often or in which order grids restart.  start_io / length_io / t0_io (device [N], each may be NULL)
+ * receive, for the restarted grids only, the drawn start row, the episode length and the counter value of the restart. */
+int mgx_reset_grids_random(mgx_handle *h, const uint8_t *mask, uint64_t seed, int32_t fixed_length, int32_t *start_io,
+                           int32_t *length_io, int32_t *t0_io, mgx_stream stream);
 
 /* Microgrid.reward_shaping_func (microgrid.py:105,130): one of enum mgx_reward_shaper. */
 int mgx_set_reward_shaper(mgx_handle *h, int32_t shaper);

@@ -667,6 +667,7 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
     g.N = h->k.N; g.T = h->full_T; g.rows = rows; g.max_length = max_length;
     g.lo = h->full_window_lo; g.hi = h->full_window_hi;
     g.mask = nullptr; g.row0 = 0; g.row_mask = -1;
+    g.draw = 0; g.fixed_length = 0; g.seed = 0; g.start_io = nullptr; g.length_io = nullptr; g.t0_io = nullptr;
     gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gather_windows_kernel launch");
@@ -691,6 +692,7 @@ static void rolling_gather_args(const mgx_handle *h, GatherArgs *g)
     g->N = h->k.N; g->T = h->full_T; g->rows = h->rolling_max_length + h->k.H + 1; g->max_length = h->rolling_max_length;
     g->lo = h->full_window_lo; g->hi = h->full_window_hi;
     g->row_mask = h->k.row_mask;
+    g->draw = 0; g->fixed_length = 0; g->seed = 0; g->start_io = nullptr; g->length_io = nullptr; g->t0_io = nullptr;
 }
 
 int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length, int32_t ring_rows,
@@ -732,6 +734,27 @@ int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t
     h->windowed = true; h->rolling = true;
     h->t = 0;
     return obs ? mgx_observe(h, obs, stream) : MGX_OK;
+}
+
+int mgx_reset_grids_random(mgx_handle *h, const uint8_t *mask, uint64_t seed, int32_t fixed_length, int32_t *start_io,
+                           int32_t *length_io, int32_t *t0_io, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !mask) return fail(MGX_ERR_INVALID, "mgx_reset_grids_random: NULL argument");
+    if (!h->rolling) return fail(MGX_ERR_INVALID, "mgx_reset_grids_random: the handle is not in rolling-window mode");
+    if (fixed_length < 0 || fixed_length > h->rolling_max_length)
+        return fail(MGX_ERR_INVALID, "mgx_reset_grids_random: fixed_length %d outside [0, max_length = %d]", fixed_length, h->rolling_max_length);
+    if (fixed_length == 0 && h->rolling_max_length < h->full_window_hi - h->full_window_lo)
+        return fail(MGX_ERR_INVALID, "mgx_reset_grids_random: StochasticTrajectory draws need rings for the whole window "
+                                     "(max_length %d < %d)", h->rolling_max_length, h->full_window_hi - h->full_window_lo);
+    if (h->t > INT32_MAX / 4) return fail(MGX_ERR_RANGE, "mgx_reset_grids_random: the shared step counter is about to overflow");
+    GatherArgs g;
+    rolling_gather_args(h, &g);
+    g.start = nullptr; g.length = nullptr; g.mask = mask; g.row0 = h->t;
+    g.draw = 1; g.fixed_length = fixed_length; g.seed = seed; g.start_io = start_io; g.length_io = length_io; g.t0_io = t0_io;
+    gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, (hipStream_t)stream>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "gather_windows_kernel launch");
 }
 
 int mgx_reset_grids(mgx_handle *h, const uint8_t *mask, const int32_t *start, const int32_t *length, mgx_stream stream)

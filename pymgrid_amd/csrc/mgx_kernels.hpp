@@ -1079,6 +1079,15 @@ __global__ __launch_bounds__(BLOCK) void colsum_stage2(const double *__restrict_
 // need no per-grid series length.  One lane per grid: its reads are one line per row (once per episode), the writes
 // are coalesced.
 // ------------------------------------------------------------------------------------------------------
+// U[0, 1) of (seed; grid, row): Philox4x32-10 as a counter-based generator (the generator's series and the episode draws of
+// mgx_reset_grids_random use it; pymgrid_amd.generator.synth_uniform_host reproduces it bit for bit)
+__device__ __forceinline__ double synth_uniform(uint64_t seed, int64_t grid, int32_t row)
+{
+    uint32_t r[4];
+    philox4x32_10((uint32_t)grid, (uint32_t)((uint64_t)grid >> 32), (uint32_t)row, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return (double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) * (1.0 / 9007199254740992.0);      // 53 bits, [0, 1)
+}
+
 struct GatherArgs {
     const double *load_ts, *pv_ts, *grid_ts;
     const double *load_lo, *load_hi, *pv_lo, *pv_hi, *grid_lo, *grid_hi;
@@ -1088,46 +1097,80 @@ struct GatherArgs {
     int32_t N, T, rows, max_length, lo, hi;
     const uint8_t *mask;      // NULL = every grid; else only grids with mask[i] != 0 (a partial reset)
     int32_t row0, row_mask;   // destination row of source row start_i + r: (row0 + r) & row_mask (linear windows: 0, -1)
+    // mgx_reset_grids_random: start / length are DRAWN here (trajectory/stochastic.py:9-30 per grid) instead of read
+    int32_t draw, fixed_length;
+    uint64_t seed;
+    int32_t *start_io, *length_io, *t0_io;     // optional [N]: what the restarted grids got
 };
 
-__global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs g)
+// the episode of grid i: start row and length (given, or drawn), clamped into the env's window; bookkeeping outputs
+__device__ __forceinline__ void gather_episode(const GatherArgs &g, int64_t i, int32_t &s, int32_t &len)
 {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= g.N || (g.mask && !g.mask[i])) return;
-    const int64_t N = g.N;
-    int32_t s = g.start[i];
+    if (g.draw) {               // np.random.randint(low, high) per grid: low + min(floor(u * (high - low)), high - low - 1)
+        const double u1 = synth_uniform(g.seed, i, 2 * g.row0), u2 = synth_uniform(g.seed, i, 2 * g.row0 + 1);
+        auto randint = [](double u, int32_t low, int32_t high) {
+            const int32_t span = high - low;
+            if (span <= 0) return low;
+            const int32_t k = (int32_t)floor(u * (double)span);
+            return low + (k < span - 1 ? k : span - 1);
+        };
+        if (g.fixed_length > 0) {                                      // FixedLengthStochasticTrajectory (:15-30)
+            s = randint(u1, g.lo, g.hi - g.fixed_length);
+            len = g.fixed_length;
+        } else {                                                       // StochasticTrajectory (:9-12)
+            s = randint(u1, g.lo, g.hi - 2);
+            const int32_t fin = randint(u2, s, g.hi);
+            len = fin - s;
+        }
+    } else {
+        s = g.start[i];
+        len = g.length ? g.length[i] : g.max_length;
+    }
     s = s < g.lo ? g.lo : (s > g.hi - 1 ? g.hi - 1 : s);            // a start outside the env's window is clamped into it
-    int32_t len = g.length ? g.length[i] : g.max_length;
     const int32_t room = g.hi - s;
     len = len < 1 ? 1 : len;
     len = len > g.max_length ? g.max_length : len;
     len = len > room ? room : len;                                     // the episode ends at the env's final step at the latest
-    if (g.final_rel) g.final_rel[i] = g.row0 + len;       // counter value at which the episode has run its length
-    const double fl = (g.load_lo && g.load_hi) ? (g.load_hi[i] + g.load_lo[i]) / 2 : 0.0;
-    const double fp = (g.pv_lo && g.pv_hi) ? (g.pv_hi[i] + g.pv_lo[i]) / 2 : 0.0;
-    double fg[4] = {0.0, 0.0, 0.0, 0.0};
-    if (g.grid_ts && g.grid_lo && g.grid_hi) {
+    if (g.final_rel) g.final_rel[i] = g.row0 + len;                    // counter value at which the episode has run its length
+    if (g.start_io) g.start_io[i] = s;
+    if (g.length_io) g.length_io[i] = len;
+    if (g.t0_io) g.t0_io[i] = g.row0;
+}
+
+// row r of grid i's window: series row s + r (the forecaster's padding value beyond the series) -> window row (row0 + r) & mask
+__device__ __forceinline__ void gather_row(const GatherArgs &g, int64_t i, int32_t s, int32_t r)
+{
+    const int64_t N = g.N;
+    const int64_t row = (int64_t)s + r;
+    const bool in = row < g.T;
+    const int64_t src = (in ? row : (int64_t)g.T - 1) * N + i;
+    const int64_t dst = (g.row0 + r) & g.row_mask;
+    const double vl = g.load_ts[src], vp = g.pv_ts[src];
+    g.load_w[dst * N + i] = in ? vl : ((g.load_lo && g.load_hi) ? (g.load_hi[i] + g.load_lo[i]) / 2 : 0.0);
+    g.pv_w[dst * N + i] = in ? vp : ((g.pv_lo && g.pv_hi) ? (g.pv_hi[i] + g.pv_lo[i]) / 2 : 0.0);
+    if (g.grid_ts) {
+        const int64_t sg = (in ? row : (int64_t)g.T - 1) * 4 * N + i;
 #pragma unroll
-        for (int c = 0; c < 4; c++) fg[c] = (g.grid_hi[c * N + i] + g.grid_lo[c * N + i]) / 2;
-    }
-    for (int32_t r = 0; r < g.rows; r++) {
-        const int64_t row = (int64_t)s + r;
-        const bool in = row < g.T;
-        const int64_t src = (in ? row : (int64_t)g.T - 1) * N + i;
-        const double vl = g.load_ts[src], vp = g.pv_ts[src];
-        const int64_t dst = (g.row0 + r) & g.row_mask;
-        g.load_w[dst * N + i] = in ? vl : fl;
-        g.pv_w[dst * N + i] = in ? vp : fp;
-        if (g.grid_ts) {
-            const int64_t sg = (in ? row : (int64_t)g.T - 1) * 4 * N + i;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const double v = g.grid_ts[sg + c * N];
-                g.grid_w[(dst * 4 + c) * N + i] = in ? v : fg[c];
-            }
+        for (int c = 0; c < 4; c++) {
+            const double v = g.grid_ts[sg + c * N];
+            const double fill = (g.grid_lo && g.grid_hi) ? (g.grid_hi[c * N + i] + g.grid_lo[c * N + i]) / 2 : 0.0;
+            g.grid_w[(dst * 4 + c) * N + i] = in ? v : fill;
         }
     }
 }
+
+// one lane per grid walks its rows (a wave moves 512 contiguous bytes per row when all of its grids take part).  For the
+// sparse restarts of mgx_reset_grids* a variant whose 64 lanes share the rows of each restarting grid was measured SLOWER
+// (36 vs 20 us per step at N = 100 000, one grid in 168 restarting: its accesses are 8 bytes per line)
+__global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs g)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= g.N || (g.mask && !g.mask[i])) return;
+    int32_t s, len;
+    gather_episode(g, i, s, len);
+    for (int32_t r = 0; r < g.rows; r++) gather_row(g, i, s, r);
+}
+
 
 // ------------------------------------------------------------------------------------------------------
 // Series synthesis (mgx_synthesize_series): MicrogridGenerator's time series for N grids, written at HBM speed.
@@ -1140,12 +1183,6 @@ __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs 
 // of every output is one coalesced store per wave.  Uniforms: Philox4x32-10 keyed by the seed, counter = (GLOBAL grid
 // index, row), so a shard's draw does not depend on how the batch is split over ranks.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double synth_uniform(uint64_t seed, int64_t grid, int32_t row)
-{
-    uint32_t r[4];
-    philox4x32_10((uint32_t)grid, (uint32_t)((uint64_t)grid >> 32), (uint32_t)row, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    return (double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) * (1.0 / 9007199254740992.0);      // 53 bits, [0, 1)
-}
 
 // MicrogridGenerator._get_electricity_tariff (:253-285)
 __device__ __forceinline__ double tariff_price(int32_t pattern, int32_t row)

@@ -268,6 +268,20 @@ class StepEngine:
         self._window_start = torch.where(m, start, self._window_start)
         self._window_t0 = torch.where(m, torch.full_like(start, self.current_step), self._window_t0)
 
+    def reset_grids_random(self, mask, seed, fixed_length=0, lengths_out=None):
+        """``mgx_reset_grids_random``: restart the grids with ``mask[i] != 0`` with episodes drawn ON DEVICE (Philox of
+        (seed; grid, counter); ``fixed_length`` > 0: FixedLengthStochasticTrajectory, 0: StochasticTrajectory).  The per-grid
+        start rows / restart counters (``current_steps``) are updated in place by the kernel; ``lengths_out`` (int32 [N])
+        optionally receives the drawn lengths."""
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        if mask.dtype != torch.uint8 or tuple(mask.shape) != (self.N,) or mask.device != self.device or not mask.is_contiguous():
+            raise ValueError(f"mask must be a contiguous uint8 / bool tensor of shape ({self.N},) on {self.device}")
+        if getattr(self, "_window_t0", None) is None:
+            raise _lib.MgxError(_lib.MGX_ERR_INVALID, "reset_grids_random: the engine is not in rolling-window mode")
+        self._call(self._lib.mgx_reset_grids_random, mask.data_ptr(), int(seed) & (2 ** 64 - 1), int(fixed_length),
+                   self._window_start.data_ptr(), _ptr(lengths_out), self._window_t0.data_ptr())
+
     def set_shards(self, n_shards):
         """Step in ``n_shards`` independent grid ranges, one internal HIP stream each (``mgx_set_shards``).  While
         n_shards > 1 the stepping calls ignore torch's current stream: bracket them with ``fork()`` / ``join()``."""

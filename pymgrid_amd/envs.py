@@ -195,6 +195,13 @@ class BatchedMicrogridEnv:
             return self._select_obs(self.engine.observe())
         return None
 
+    def reset_grids_random(self, mask, seed, fixed_length=0, lengths_out=None, want_obs=True):
+        """``reset_grids`` with the new episodes drawn on the device (``mgx_reset_grids_random``): no host work per restart."""
+        self.engine.reset_grids_random(mask, seed, fixed_length, lengths_out)
+        if want_obs and self._observations:
+            return self._select_obs(self.engine.observe())
+        return None
+
     @property
     def current_steps(self):
         """Per-grid step counters [N]: start_i + steps since the reset during a per-grid-window episode, else the shared

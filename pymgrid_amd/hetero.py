@@ -305,11 +305,13 @@ class PerGridWindowEnv:
     ``auto_reset=True``: every grid restarts ON ITS OWN the moment its episode is over (rolling windows,
     ``mgx_reset_windows_rolling`` / ``mgx_reset_grids``) -- N reference microgrids that are each reset when they report
     ``done``, as a vectorised Gym env does.  ``step`` then returns the first observation of the new episode for the grids that
-    just finished (``info["final_observation"]`` holds the rows of the finished episodes) and the batch never needs a global
-    ``reset()`` again.  Observation rows are written per step in this mode.
+    just finished and the batch never needs a global ``reset()`` again.  ``final_observation=True`` also returns the last rows
+    of the finished episodes in ``info["final_observation"]`` (a second observation kernel per step).  Observation rows are
+    written per step in this mode.
     """
 
-    def __init__(self, full_batch, trajectory_length=None, discrete=False, generator=None, auto_reset=False, **env_kwargs):
+    def __init__(self, full_batch, trajectory_length=None, discrete=False, generator=None, auto_reset=False,
+                 final_observation=False, seed=0, **env_kwargs):
         L = full_batch.layout
         if L.multi:
             raise NotImplementedError("per-grid windows need one module of every kind per grid")
@@ -321,6 +323,11 @@ class PerGridWindowEnv:
         self.generator = generator
         cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
         self.auto_reset = bool(auto_reset)
+        self.final_observation = bool(final_observation)
+        # auto_reset without a torch generator: the restarts' episodes are drawn inside the restart kernel (Philox of
+        # (seed; grid, counter)): one launch per step instead of a dozen small torch kernels
+        self.seed = int(seed)
+        self._device_draws = self.auto_reset and generator is None
         if self.auto_reset:
             env_kwargs = dict(env_kwargs, obs_prefetch=0)
         self.env = cls(full_batch, **env_kwargs)
@@ -363,13 +370,27 @@ class PerGridWindowEnv:
     def step(self, action, **kw):
         if not self.auto_reset:
             return self.env.step(action, **kw)
-        obs, reward, done, info = self.env.step(action, **kw)
-        starts, lengths = self.draw()                      # a draw per grid; only the finished grids take theirs
-        new_obs = self.env.reset_grids(done, starts, lengths)
-        self.starts = torch.where(done, starts, self.starts)
-        if lengths is not None:
-            self.lengths = torch.where(done, lengths, self.lengths)
-        info = dict(info, final_observation=obs)
+        env = self.env
+        want_rows = env._observations
+        if want_rows and not self.final_observation:       # the rows come from the observe pass behind the restarts
+            env._observations = False
+        try:
+            obs, reward, done, info = env.step(action, **kw)
+        finally:
+            env._observations = want_rows
+        if self._device_draws:
+            if self.lengths is None:
+                self.lengths = torch.full_like(self.starts, self.length if self.length is not None else 0)
+            new_obs = env.reset_grids_random(done, self.seed, self.length or 0, lengths_out=self.lengths)
+            self.starts = env.engine._window_start          # updated in place by the kernel
+        else:
+            starts, lengths = self.draw()                  # a draw per grid; only the finished grids take theirs
+            new_obs = env.reset_grids(done, starts, lengths)
+            self.starts = torch.where(done, starts, self.starts)
+            if lengths is not None:
+                self.lengths = torch.where(done, lengths, self.lengths)
+        if self.final_observation:
+            info = dict(info, final_observation=obs)
         return (new_obs if new_obs is not None else obs), reward, done, info
 
     def __getattr__(self, name):              # everything else (engine, action_space, sample_action, ...) as the env

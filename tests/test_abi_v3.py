@@ -530,7 +530,8 @@ def test_auto_reset_window_env(pymgrid25, device):
     from pymgrid_amd.hetero import PerGridWindowEnv
     tmpl4 = [pymgrid25[n] for n in (2, 3, 5, 7, 15, 17)] * 20
     gen = torch.Generator(device=device); gen.manual_seed(9)
-    env = PerGridWindowEnv(_batch(tmpl4, device), trajectory_length=12, observations=True, generator=gen, auto_reset=True)
+    env = PerGridWindowEnv(_batch(tmpl4, device), trajectory_length=12, observations=True, generator=gen, auto_reset=True,
+                           final_observation=True)
     ref = PerGridWindowEnv(_batch(tmpl4, device), trajectory_length=12, observations=True)
     obs = env.reset()
     n_done = torch.zeros(len(tmpl4), dtype=torch.int64, device=device)
@@ -547,4 +548,46 @@ def test_auto_reset_window_env(pymgrid25, device):
             assert torch.equal(ref.reset(starts=env.starts), obs)
             assert not torch.equal(info["final_observation"], obs)
     assert bool((n_done == 3).all())
-    env.close(); ref.close()
+    # episodes drawn ON DEVICE (no torch generator): the draws are Philox(seed; grid, counter), reproducible on the host
+    from pymgrid_amd.generator import synth_uniform_host
+    for fixed in (12, None):
+        dd = PerGridWindowEnv(_batch(tmpl4, device), trajectory_length=fixed, observations=True, auto_reset=True, seed=77)
+        assert dd._device_draws
+        dd.reset(starts=np.arange(len(tmpl4)) * 5, lengths=None if fixed else np.full(len(tmpl4), 3) + np.arange(len(tmpl4)) % 4)
+        lo, hi, idx = 0, 8759, np.arange(len(tmpl4))
+        for k in range(20):
+            obs, reward, done, info = dd.step(dd.sample_action())
+            d = done.cpu().numpy()
+            if d.any():
+                c = k + 1                                                # the counter value at the restart
+                u1, u2 = synth_uniform_host(77, idx, 2 * c), synth_uniform_host(77, idx, 2 * c + 1)
+                if fixed:
+                    span = hi - fixed - lo
+                    want_s, want_n = lo + np.minimum(np.floor(u1 * span), span - 1), np.full(len(tmpl4), fixed)
+                else:
+                    span = hi - 2 - lo
+                    want_s = lo + np.minimum(np.floor(u1 * span), span - 1)
+                    sp2 = hi - want_s
+                    want_n = np.maximum(np.minimum(np.floor(u2 * sp2), sp2 - 1), 1)
+                got_s, got_n = dd.starts.cpu().numpy(), dd.lengths.cpu().numpy()
+                assert np.array_equal(got_s[d], want_s[d].astype(np.int64)) and np.array_equal(got_n[d], want_n[d].astype(np.int64)), (fixed, k)
+                ref.env.batch.load_state(dd.env.batch.state())
+                fresh = ref.reset(starts=dd.starts, lengths=None if fixed else dd.lengths) if fixed else None
+                if fixed:
+                    assert torch.equal(fresh[torch.as_tensor(d, device=device)], obs[torch.as_tensor(d, device=device)]), k
+                cur = dd.current_steps.cpu().numpy()
+                assert np.array_equal(cur[d], got_s[d])                  # a restarted grid stands at its new start row
+        dd.close()
+    # without final_observation: one observation pass per step, same rows
+    gen2 = torch.Generator(device=device); gen2.manual_seed(9)
+    lean = PerGridWindowEnv(_batch(tmpl4, device), trajectory_length=12, observations=True, generator=gen2, auto_reset=True)
+    gen3 = torch.Generator(device=device); gen3.manual_seed(9)
+    full = PerGridWindowEnv(_batch(tmpl4, device), trajectory_length=12, observations=True, generator=gen3, auto_reset=True,
+                            final_observation=True)
+    assert torch.equal(lean.reset(), full.reset())
+    for k in range(30):
+        a = lean.sample_action()
+        r1, r2 = lean.step(a), full.step(a)
+        assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1]) and torch.equal(r1[2], r2[2]), k
+        assert "final_observation" not in r1[3] and "final_observation" in r2[3]
+    env.close(); ref.close(); lean.close(); full.close()
