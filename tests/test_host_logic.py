@@ -156,3 +156,13 @@ def test_generator_is_shard_invariant():
     assert g.cols["grid_ts"].shape == (48, 4, 30)
     st = g.cols["grid_ts"][:, 3]
     assert ((st == 0) | (st == 1)).all()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/mgx.h is a C header (the boundary is a C ABI): gcc -std=c99 -pedantic accepts it on its own."""
+    import subprocess
+    src = tmp_path / "chk.c"
+    src.write_text('#include "mgx.h"\nint main(void) { mgx_layout l; l.struct_size = (int)sizeof l; return l.struct_size ? 0 : MGX_ABI_VERSION; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
+                    "-fsyntax-only", str(src)], check=True)
