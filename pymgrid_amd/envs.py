@@ -532,16 +532,20 @@ class _SingleMixin:
     @classmethod
     def from_scenario(cls, microgrid_number=0, root=None, **kwargs):
         """``Env.from_scenario(n)`` (envs/base/base.py:290-296).  ``root`` is the directory that holds ``pymgrid25/``
-        (``<pymgrid>/data/scenario``); with ``root=None`` the scenario is read from an installed ``pymgrid`` package's
-        data directory if there is one."""
-        from .scenario import from_scenario
+        (``<pymgrid>/data/scenario``: the reference's YAML + csv.gz files are read).  With ``root=None`` the scenario comes
+        from an installed ``pymgrid`` package's data directory if there is one, else from the copy of the 25 benchmark
+        microgrids this package carries as data (``pymgrid_amd/data/pymgrid25.npz``: their parameters and series as the
+        reference's loader returns them)."""
+        from .scenario import from_scenario, load_npz_grids
         if root is None:
             import importlib.util
             import os
             spec = importlib.util.find_spec("pymgrid")
             if spec is None or not spec.submodule_search_locations:
-                raise FileNotFoundError("pass root=<.../data/scenario>: no pymgrid installation to take the scenario "
-                                        "files from")
+                grids = load_npz_grids(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "pymgrid25.npz"))
+                if not 0 <= int(microgrid_number) < len(grids):
+                    raise ValueError(f"microgrid_number {microgrid_number} outside [0, {len(grids)})")
+                return cls(grids[int(microgrid_number)], **kwargs)
             root = os.path.join(list(spec.submodule_search_locations)[0], "data", "scenario")
         return cls(from_scenario(microgrid_number, root), **kwargs)
 

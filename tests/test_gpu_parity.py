@@ -330,6 +330,13 @@ def test_gym_adaptors_shapes(pymgrid25, device):
         obs, reward, done, info = env.step(ctrl, normalized=True)
         assert isinstance(reward, float) and len(obs["load"][0]) == 24
         # Env.from_microgrid (envs/base/base.py:253-283): wrap a stepped microgrid -- parameters AND current state carry over
+        # from_scenario(n) without a path: the packaged copy of the benchmark microgrids == the fixture
+        packaged = DiscreteMicrogridEnv.from_scenario(n, device=device)
+        assert packaged.action_space.n == n_expected and packaged.layout == env.layout
+        for name in ("load_ts", "bat_max_capacity", "gen_running_max"):
+            if name in env.batch.cols:
+                assert torch.equal(packaged.batch.cols[name], env.batch.cols[name]), name
+        packaged.close()
         # Microgrid.sample_action / get_empty_action / run (microgrid.py:227-381) on the continuous adaptor
         from pymgrid_amd import Microgrid
         mg = Microgrid(pymgrid25[n], device=device)
