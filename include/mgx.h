@@ -189,8 +189,9 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
  * window buffers [ring_rows, N] ([ring_rows, 4, N]) are rings addressed by (step counter & (ring_rows - 1)):
  * ring_rows a power of two >= max_length + horizon + 1.  The shared counter restarts at 0 and never ends; final_abs [N]
  * (device, required) receives the counter value at which each grid's episode has run its length, done_i =
- * counter >= final_abs[i] - 1.  Single steps only (mgx_step, mgx_step_discrete, mgx_step_many, mgx_observe, ...);
- * fused launches, window prefetch, shards and the device counter are refused in this mode.  mgx_reset / mgx_reset_windows
+ * counter >= final_abs[i] - 1.  Single steps only (mgx_step, mgx_step_discrete, mgx_step_many, mgx_observe,
+ * mgx_observe_windows[_ahead] + mgx_patch_windows, ...); fused launches, shards and the device counter are refused in this
+ * mode.  mgx_reset / mgx_reset_windows
  * leave it. */
 int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length,
                               int32_t ring_rows, double *load_w, double *pv_w, double *grid_w, int32_t *final_abs, void *obs,
@@ -242,6 +243,15 @@ int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream)
  * 128-byte aligned and every 1-KB wave store of the refill begins and ends in a partial line; a ring [K, P, D] with
  * P = N rounded up to 16 rows, block k = the first N rows of ring[k], avoids that. */
 int mgx_set_ring_pitch(mgx_handle *h, int32_t rows);
+/* Rolling windows with prefetched rings: after mgx_reset_grids* has replaced the series rows of the grids with mask[i] != 0,
+ * recompute the window columns of THEIR rows in blocks first_block .. K-1 of `ring` (block first_block = the row of
+ * counter value current + ahead).  State columns are left as they are.  A ring written AHEAD of the counter
+ * (mgx_observe_windows_ahead) may have read a restarting grid's rows before or while they were replaced: once it is complete
+ * (mgx_prefetch_wait), patch into it every grid that restarted since it was launched (first_block = 0 at the moment the
+ * counter reaches its block 0).  `restarted` (device [N], may be NULL, must not be `mask`): restarted[i] = 1 for every masked
+ * grid -- the accumulator of that later patch. */
+int mgx_patch_windows(mgx_handle *h, const uint8_t *mask, int32_t K, void *ring, int32_t first_block, int32_t ahead,
+                      uint8_t *restarted, mgx_stream stream);
 int mgx_set_obs_mode(mgx_handle *h, int32_t mode);
 
 /* The same prefetch AHEAD of the counter, overlapped with the steps: block k of `ring` = the window columns of counter

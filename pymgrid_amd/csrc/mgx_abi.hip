@@ -439,7 +439,6 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "%s: K = %d outside [1, 4096]", who, K);
     if (ahead < 0) return fail(MGX_ERR_INVALID, "%s: ahead = %d is negative", who, ahead);
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "%s: needs exactly one module of every kind per grid", who);
-    if (h->rolling) return fail(MGX_ERR_UNSUPPORTED, "%s: prefetched windows go stale when a grid restarts (rolling windows)", who);
     if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
         return fail(MGX_ERR_UNSUPPORTED, "%s: forecast noise depends on (step, horizon index), windows cannot be shared", who);
     if (int rc = need_obs_bounds(h, who)) return rc;
@@ -496,6 +495,35 @@ static int launch_windows(mgx_handle *h, int32_t ahead, int32_t K, void *ring, h
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "obs_windows_k_kernel launch");
+}
+
+int mgx_patch_windows(mgx_handle *h, const uint8_t *mask, int32_t K, void *ring, int32_t first_block, int32_t ahead,
+                      uint8_t *restarted, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !mask || !ring) return fail(MGX_ERR_INVALID, "mgx_patch_windows: NULL argument");
+    if (K < 1 || first_block < 0 || first_block > K) return fail(MGX_ERR_INVALID, "mgx_patch_windows: first_block %d outside [0, K = %d]", first_block, K);
+    if (ahead < 0) return fail(MGX_ERR_INVALID, "mgx_patch_windows: ahead = %d is negative", ahead);
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: needs exactly one module of every kind per grid");
+    if (dev_counter(h)) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: not offered in device-counter mode");
+    if (int rc = need_obs_bounds(h, "mgx_patch_windows")) return rc;
+    if (first_block == K) return MGX_OK;
+    const int32_t W = 1 + h->k.H;
+    const int32_t grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
+    const unsigned blocks = (unsigned)((h->k.N + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t rows = (K - first_block) + h->k.H;
+    if (rows > PATCH_MAX_ROWS) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: (K - first_block) + horizon = %d rows exceed %d", rows, PATCH_MAX_ROWS);
+    const size_t lds = 2 * (size_t)(h->layout.has_grid ? 6 : 2) * rows * sizeof(double);
+    if (h->layout.has_grid) {
+        if (h->k.obs_f32) patch_windows_kernel<true, float><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, grid_col_base, (float *)ring, restarted);
+        else patch_windows_kernel<true, double><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, grid_col_base, (double *)ring, restarted);
+    } else {
+        if (h->k.obs_f32) patch_windows_kernel<false, float><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, grid_col_base, (float *)ring, restarted);
+        else patch_windows_kernel<false, double><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, grid_col_base, (double *)ring, restarted);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "patch_windows_kernel launch");
 }
 
 int mgx_set_ring_pitch(mgx_handle *h, int32_t rows)
@@ -704,8 +732,6 @@ int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t
     if (h->layout.has_grid && !grid_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows_rolling: grid_w is NULL but the layout has a GridModule");
     if (h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: not offered in device-counter mode");
     if (h->n_shards > 1) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: not offered while the handle steps in shards");
-    if (h->k.obs_state_only) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: prefetched observation windows would "
-                                                               "go stale when a grid restarts; use full observation rows");
     if (!h->windowed) {
         h->full_load_ts = h->k.c.load_ts; h->full_pv_ts = h->k.c.pv_ts; h->full_grid_ts = h->k.c.grid_ts;
         h->full_T = h->k.T; h->full_final = h->layout.final_step; h->full_initial = h->layout.initial_step;

@@ -358,7 +358,8 @@ template <int NC>
 __device__ __forceinline__ void windows_k_module(const double *__restrict__ ts, int64_t N, int64_t row_stride,
                                                  const double *__restrict__ lo_col, const double *__restrict__ hi_col,
                                                  int32_t T, int32_t t, int32_t R, int32_t K, int64_t ic, int32_t q, int32_t Q,
-                                                 double *nc /* [NC][RP] of this grid */, double *nu /* [NC][K] */, int32_t RP)
+                                                 double *nc /* [NC][RP] of this grid */, double *nu /* [NC][K] */, int32_t RP,
+                                                 int32_t row_mask = -1)
 {
     double lo[NC], hi[NC], sp[NC], z_lo[NC], z_hi[NC], z_fill[NC];
 #pragma unroll
@@ -375,7 +376,7 @@ __device__ __forceinline__ void windows_k_module(const double *__restrict__ ts, 
         for (int jj = 0; jj < OBS_KJ; jj++) {                            // unconditional, clamped loads: one latency round
             const int32_t rr = rb + q + Q * jj;                          // rows past the window re-read its last row (a cache
             const int32_t r = t + (rr < R ? rr : R - 1);                 // hit) instead of pulling unused rows out of HBM
-            const int32_t rc = r < T ? (r < 0 ? 0 : r) : T - 1;
+            const int32_t rc = (r < T ? (r < 0 ? 0 : r) : T - 1) & row_mask;      // rolling windows: the series buffers are rings
 #pragma unroll
             for (int c = 0; c < NC; c++) v[jj][c] = ts[(int64_t)rc * row_stride + c * N + ic];
         }
@@ -432,11 +433,11 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     double *blk = image + g * BP;
     uint32_t *map = reinterpret_cast<uint32_t *>(image + G * BP);       // [D]
 
-    windows_k_module<1>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, R, K, ic, q, Q, blk, blk + NU0, RP);
-    windows_k_module<1>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP);
+    windows_k_module<1>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
+    windows_k_module<1>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
     if constexpr (GRID)
         windows_k_module<4>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, R, K, ic, q, Q, blk + 2 * RP,
-                            blk + NU0 + 2 * K, RP);
+                            blk + NU0 + 2 * K, RP, a.row_mask);
     if (q == 0) {                                        // state columns: the current state for block 0, zeros ahead
 #pragma unroll
         for (int j = 0; j < 6; j++) {                    // static indices: `now` stays in registers (a dynamic index put it --
@@ -500,6 +501,63 @@ __global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArg
         observe_state_cols<F>(a, p, s, now, 0);
     }
     windows_body<(F & F_GRID) != 0, OT>(a, plan, t, ring, group, NSTATE, plan.with_state != 0, now, image);
+}
+
+// Restarted grids in a prefetched ring (mgx_patch_windows): the window columns of blocks first..K-1 of `ring` are recomputed
+// for the grids with mask[i] != 0 -- their series rows have just been replaced (mgx_reset_grids*), so the rows the refill
+// wrote for them belong to the old episode.  Block k of the ring is the row of counter value t + (k - first).  A wave takes the
+// masked grids of its 64 one after the other: it reads the grid's rows t .. t + (K - first) + H - 1 ONCE (lanes = (row,
+// component) pairs: scattered 8-byte reads, but each series value only once -- per output column they would be read and
+// normalised K times over), keeps their normalised forms in LDS (unclipped for the "current value" position, clipped for
+// forecast positions, as the refill kernel does), and writes the blocks' rows with lanes = columns (coalesced).  State
+// columns are left alone: the restart does not touch the state, the step has already patched the block it reached.
+constexpr int PATCH_MAX_ROWS = 512;     // (K - first) + H rows the LDS image of one grid can hold
+
+template <bool GRID, typename OT>
+__global__ __launch_bounds__(64) void patch_windows_kernel(const KArgs a, const uint8_t *__restrict__ mask, int32_t t, int32_t K,
+                                                           int32_t first, int32_t pitch, int32_t grid_col_base, OT *__restrict__ ring,
+                                                           uint8_t *__restrict__ acc)
+{
+    constexpr int NCOMP = GRID ? 6 : 2;
+    extern __shared__ double patch_lds[];                  // [2][NCOMP][R]: unclipped, clipped
+    const int lane = threadIdx.x;
+    const int64_t N = a.N;
+    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    const int64_t i = i0 + lane;
+    const bool mine = i < N && mask[i] != 0;
+    if (acc && mine) acc[i] = 1;                           // grids that restarted since the ring ahead was launched
+    unsigned long long todo = __ballot(mine);
+    const int32_t W = 1 + a.H, D = a.obs_dim, R = (K - first) + a.H;
+    double *nu = patch_lds, *nc = patch_lds + NCOMP * R;
+    while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int64_t g = i0 + j;
+        __syncthreads();                                   // the previous grid's image has been consumed
+        for (int32_t idx = lane; idx < NCOMP * R; idx += 64) {
+            const int comp = idx / R, r = idx - comp * R;
+            const double *ts; int64_t row_stride, off; double lo, hi;
+            if (comp == 0) { ts = a.c.load_ts; row_stride = N; off = g; lo = a.c.load_lo[g]; hi = a.c.load_hi[g]; }
+            else if (comp == 1) { ts = a.c.pv_ts; row_stride = N; off = g; lo = a.c.pv_lo[g]; hi = a.c.pv_hi[g]; }
+            else { ts = a.c.grid_ts; row_stride = 4 * N; off = (comp - 2) * N + g; lo = a.c.grid_lo[(comp - 2) * N + g]; hi = a.c.grid_hi[(comp - 2) * N + g]; }
+            const int32_t row = t + r;
+            const bool in = row < a.T;
+            const double v = ts[(int64_t)((in ? row : a.T - 1) & a.row_mask) * row_stride + off];
+            const double fill = (hi + lo) / 2, sp = space_spread(lo, hi);
+            nu[idx] = obs_series_value(v, in, false, lo, hi, fill, sp);
+            nc[idx] = obs_series_value(v, in, true, lo, hi, fill, sp);
+        }
+        __syncthreads();
+        for (int32_t col = lane; col < D; col += 64) {
+            int comp, h;                                   // which series component / horizon step this column shows
+            if (col < W) { comp = 0; h = col; }
+            else if (col < 2 * W) { comp = 1; h = col - W; }
+            else if (col < grid_col_base) continue;        // state columns
+            else { comp = 2 + ((col - grid_col_base) & 3); h = (col - grid_col_base) >> 2; }
+            const double *src = (h == 0 ? nu : nc) + comp * R + h;
+            for (int32_t k = first; k < K; k++) ring[((int64_t)k * pitch + g) * D + col] = (OT)src[k - first];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1137,28 +1195,6 @@ __device__ __forceinline__ void gather_episode(const GatherArgs &g, int64_t i, i
     if (g.t0_io) g.t0_io[i] = g.row0;
 }
 
-// row r of grid i's window: series row s + r (the forecaster's padding value beyond the series) -> window row (row0 + r) & mask
-__device__ __forceinline__ void gather_row(const GatherArgs &g, int64_t i, int32_t s, int32_t r)
-{
-    const int64_t N = g.N;
-    const int64_t row = (int64_t)s + r;
-    const bool in = row < g.T;
-    const int64_t src = (in ? row : (int64_t)g.T - 1) * N + i;
-    const int64_t dst = (g.row0 + r) & g.row_mask;
-    const double vl = g.load_ts[src], vp = g.pv_ts[src];
-    g.load_w[dst * N + i] = in ? vl : ((g.load_lo && g.load_hi) ? (g.load_hi[i] + g.load_lo[i]) / 2 : 0.0);
-    g.pv_w[dst * N + i] = in ? vp : ((g.pv_lo && g.pv_hi) ? (g.pv_hi[i] + g.pv_lo[i]) / 2 : 0.0);
-    if (g.grid_ts) {
-        const int64_t sg = (in ? row : (int64_t)g.T - 1) * 4 * N + i;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const double v = g.grid_ts[sg + c * N];
-            const double fill = (g.grid_lo && g.grid_hi) ? (g.grid_hi[c * N + i] + g.grid_lo[c * N + i]) / 2 : 0.0;
-            g.grid_w[(dst * 4 + c) * N + i] = in ? v : fill;
-        }
-    }
-}
-
 // one lane per grid walks its rows (a wave moves 512 contiguous bytes per row when all of its grids take part).  For the
 // sparse restarts of mgx_reset_grids* a variant whose 64 lanes share the rows of each restarting grid was measured SLOWER
 // (36 vs 20 us per step at N = 100 000, one grid in 168 restarting: its accesses are 8 bytes per line)
@@ -1168,7 +1204,44 @@ __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs 
     if (i >= g.N || (g.mask && !g.mask[i])) return;
     int32_t s, len;
     gather_episode(g, i, s, len);
-    for (int32_t r = 0; r < g.rows; r++) gather_row(g, i, s, r);
+    // 8 rows per round, every load of the round in flight before its first store (the compiler cannot prove that window and
+    // series buffers do not alias: row by row the loop is one memory round trip per row -- 20 us when a few lanes restart)
+    const int64_t N = g.N;
+    const double fl = (g.load_lo && g.load_hi) ? (g.load_hi[i] + g.load_lo[i]) / 2 : 0.0;
+    const double fp = (g.pv_lo && g.pv_hi) ? (g.pv_hi[i] + g.pv_lo[i]) / 2 : 0.0;
+    double fg[4] = {0.0, 0.0, 0.0, 0.0};
+    if (g.grid_ts && g.grid_lo && g.grid_hi) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) fg[c] = (g.grid_hi[c * N + i] + g.grid_lo[c * N + i]) / 2;
+    }
+    constexpr int RB = 8;
+    for (int32_t r0 = 0; r0 < g.rows; r0 += RB) {
+        double vl[RB], vp[RB], vg[RB][4];
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            const int64_t row = (int64_t)s + r0 + u;
+            const int64_t rc = row < g.T ? row : (int64_t)g.T - 1;
+            vl[u] = g.load_ts[rc * N + i]; vp[u] = g.pv_ts[rc * N + i];
+            if (g.grid_ts) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) vg[u][c] = g.grid_ts[(rc * 4 + c) * N + i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            const int32_t r = r0 + u;
+            if (r < g.rows) {
+                const bool in = (int64_t)s + r < g.T;
+                const int64_t dst = (g.row0 + r) & g.row_mask;
+                g.load_w[dst * N + i] = in ? vl[u] : fl;
+                g.pv_w[dst * N + i] = in ? vp[u] : fp;
+                if (g.grid_ts) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) g.grid_w[(dst * 4 + c) * N + i] = in ? vg[u][c] : fg[c];
+                }
+            }
+        }
+    }
 }
 
 

@@ -141,6 +141,16 @@ class StepEngine:
         self._call(self._lib.mgx_observe_windows_ahead, int(ahead), int(out.shape[0]), out.data_ptr())
         return out
 
+    def patch_windows(self, mask, ring, first_block, counter_offset=0, restarted=None):
+        """``mgx_patch_windows``: recompute the window columns of the grids with ``mask[i] != 0`` in blocks first_block..K-1 of
+        ``ring`` (after ``reset_grids*`` replaced their series rows); block first_block = the row of counter value
+        current + counter_offset."""
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        self._check_ring(ring)
+        self._call(self._lib.mgx_patch_windows, mask.data_ptr(), int(ring.shape[0]), ring.data_ptr(), int(first_block),
+                   int(counter_offset), _ptr(restarted))
+
     def prefetch_wait(self):
         """Torch's current stream waits for the last ``observe_windows_ahead``."""
         self._call(self._lib.mgx_prefetch_wait)

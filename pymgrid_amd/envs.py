@@ -77,6 +77,11 @@ class BatchedMicrogridEnv:
         # True inside a fused BucketedFleet: the next ring is written in K - 1 chunks that ride along with the fleet's step
         # launches (mgx_fleet_item.refill_chunk), not by this env's prefetch stream; such an env is stepped by its fleet only
         self._chunked = False
+        # True during rolling per-grid windows: restarted grids are patched into the rings (mgx_patch_windows) -- into the
+        # current ring at once, into a ring prefetched ahead when the counter reaches it (every grid that restarted since that
+        # prefetch was launched: _restart_acc)
+        self._sync_rings = False
+        self._restart_acc = None
         self.reward_shaping_func = reward_shaping_func
         self.engine.set_reward_shaper(shaper_kind(reward_shaping_func))
         self.trajectory_func = trajectory_func
@@ -143,6 +148,7 @@ class BatchedMicrogridEnv:
         self._shaped_rows = []
         if self.trajectory_func is not None and initial_step is None:
             self._draw_window()
+        self._sync_rings = False
         if self._ring is not None:
             self.engine.reset(initial_step, want_obs=False)
             return self._select_obs(self._refill())
@@ -170,11 +176,15 @@ class BatchedMicrogridEnv:
         if rolling:
             if self._chunked:
                 raise RuntimeError("this env belongs to a fused BucketedFleet: rolling windows are not offered there")
-            if self.obs_prefetch:
-                self.set_obs_prefetch(0)
             if max_length is None:
                 max_length = int(length.max().item())
+            if self._ring is not None:               # rings stay: refilled on this stream, restarted grids patched in
+                self.engine.prefetch_wait()
+                self._sync_rings = True
+                self.engine.reset_windows_rolling(start, length, max_length, want_obs=False)
+                return self._select_obs(self._refill())
             return self._select_obs(self.engine.reset_windows_rolling(start, length, max_length, want_obs=self._observations))
+        self._sync_rings = False
         if self._ring is not None:
             self.engine.reset_windows(start, length, max_length, want_obs=False)
             return self._select_obs(self._refill())
@@ -190,16 +200,39 @@ class BatchedMicrogridEnv:
             if v is None or (torch.is_tensor(v) and v.dtype in (dt, torch.bool) and v.device == dev and v.is_contiguous()):
                 return v
             return torch.as_tensor(np.asarray(v.cpu() if torch.is_tensor(v) else v), device=dev).to(dt).contiguous()
-        self.engine.reset_grids(as_t(mask, torch.uint8), as_t(start, torch.int32), as_t(length, torch.int32))
+        mask = as_t(mask, torch.uint8)
+        self.engine.reset_grids(mask, as_t(start, torch.int32), as_t(length, torch.int32))
+        return self._rows_after_restart(mask, want_obs)
+
+    def _rows_after_restart(self, mask, want_obs):
+        if self._ring is not None:                   # the restarted grids' rows in the rest of the ring belong to their old episodes
+            self.engine.patch_windows(mask, self._ring, self._ring_pos, restarted=self._restart_acc)
+            return self._select_obs(self._ring[self._ring_pos]) if want_obs else None
         if want_obs and self._observations:
             return self._select_obs(self.engine.observe())
         return None
 
     def reset_grids_random(self, mask, seed, fixed_length=0, lengths_out=None, want_obs=True):
         """``reset_grids`` with the new episodes drawn on the device (``mgx_reset_grids_random``): no host work per restart."""
-        self.engine.reset_grids_random(mask, seed, fixed_length, lengths_out)
+        e = self.engine
+        if not (torch.is_tensor(mask) and mask.dtype in (torch.bool, torch.uint8) and mask.shape == (self.n_grids,)
+                and mask.is_cuda and mask.is_contiguous()) or e._window_t0 is None:
+            e.reset_grids_random(mask, seed, fixed_length, lengths_out)          # the checked path raises with the full message
+            return self._rows_after_restart(mask, want_obs)
+        # the per-step path of an auto-reset env: two calls of the C ABI, no tensor bookkeeping in between
+        m = mask.data_ptr()
+        e._call(e._lib.mgx_reset_grids_random, m, int(seed) & 0xFFFFFFFFFFFFFFFF, int(fixed_length), e._window_start.data_ptr(),
+                None if lengths_out is None else lengths_out.data_ptr(), e._window_t0.data_ptr())
+        ring = self._ring
+        if ring is not None:
+            pos = self._ring_pos
+            e._call(e._lib.mgx_patch_windows, m, self.obs_prefetch, ring.data_ptr(), pos, 0, self._restart_acc.data_ptr())
+            if not want_obs:
+                return None
+            row = ring[pos]
+            return row if self._obs_index is None else self._select_obs(row)
         if want_obs and self._observations:
-            return self._select_obs(self.engine.observe())
+            return self._select_obs(e.observe())
         return None
 
     @property
@@ -257,6 +290,8 @@ class BatchedMicrogridEnv:
         self.engine.observe_windows(out=self._ring)
         if not self._chunked:
             self.engine.observe_windows_ahead(self.obs_prefetch, out=self._rings[1])
+        if self._sync_rings:
+            self._restart_acc = torch.zeros(self.n_grids, dtype=torch.uint8, device=self.batch.device)
         return self._ring[0]
 
     def _obs_plan(self):
@@ -297,6 +332,10 @@ class BatchedMicrogridEnv:
         want, target, wait = self._obs_plan()
         if wait:
             self.engine.prefetch_wait()
+            if self._sync_rings:                     # the ring we are about to enter was written before / while grids restarted
+                nxt = self._rings[(self._ring_idx + 1) % 3]
+                self.engine.patch_windows(self._restart_acc, nxt, 0, counter_offset=1)
+                self._restart_acc.zero_()
         return want, (None if target is None else dict(obs=target))
 
     def _obs_after(self, obs):

@@ -306,8 +306,9 @@ class PerGridWindowEnv:
     ``mgx_reset_windows_rolling`` / ``mgx_reset_grids``) -- N reference microgrids that are each reset when they report
     ``done``, as a vectorised Gym env does.  ``step`` then returns the first observation of the new episode for the grids that
     just finished and the batch never needs a global ``reset()`` again.  ``final_observation=True`` also returns the last rows
-    of the finished episodes in ``info["final_observation"]`` (a second observation kernel per step).  Observation rows are
-    written per step in this mode.
+    of the finished episodes in ``info["final_observation"]`` (a copy of the rows per step).  With a forecast horizon the
+    observation rings stay in use: they are refilled on the caller's stream and the restarted grids' rows are patched into them
+    (``mgx_patch_windows``).
     """
 
     def __init__(self, full_batch, trajectory_length=None, discrete=False, generator=None, auto_reset=False,
@@ -328,8 +329,6 @@ class PerGridWindowEnv:
         # (seed; grid, counter)): one launch per step instead of a dozen small torch kernels
         self.seed = int(seed)
         self._device_draws = self.auto_reset and generator is None
-        if self.auto_reset:
-            env_kwargs = dict(env_kwargs, obs_prefetch=0)
         self.env = cls(full_batch, **env_kwargs)
         self.starts = self.lengths = None
 
@@ -372,12 +371,13 @@ class PerGridWindowEnv:
             return self.env.step(action, **kw)
         env = self.env
         want_rows = env._observations
-        if want_rows and not self.final_observation:       # the rows come from the observe pass behind the restarts
+        if want_rows and not self.final_observation and env._ring is None:   # the rows come from the observe pass behind the restarts
             env._observations = False
         try:
             obs, reward, done, info = env.step(action, **kw)
         finally:
             env._observations = want_rows
+        final = obs.clone() if (self.final_observation and obs is not None) else None     # (a ring view: patched below)
         if self._device_draws:
             if self.lengths is None:
                 self.lengths = torch.full_like(self.starts, self.length if self.length is not None else 0)
@@ -390,7 +390,7 @@ class PerGridWindowEnv:
             if lengths is not None:
                 self.lengths = torch.where(done, lengths, self.lengths)
         if self.final_observation:
-            info = dict(info, final_observation=obs)
+            info = dict(info, final_observation=final)
         return (new_obs if new_obs is not None else obs), reward, done, info
 
     def __getattr__(self, name):              # everything else (engine, action_space, sample_action, ...) as the env

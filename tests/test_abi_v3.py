@@ -454,8 +454,8 @@ def test_fleet_fast_path_with_rotating_outputs(discrete, refill, K, pymgrid25, d
     fast.close(); plain.close()
 
 
-@pytest.mark.parametrize("discrete", [False, True])
-def test_rolling_windows_with_individual_restarts_vs_oracle(discrete, pymgrid25, device, oracle):
+@pytest.mark.parametrize("discrete,prefetch", [(False, 0), (True, 0), (False, 4), (True, 16), (False, 7)])
+def test_rolling_windows_with_individual_restarts_vs_oracle(discrete, prefetch, pymgrid25, device, oracle):
     """mgx_reset_windows_rolling + mgx_reset_grids: every grid restarts on its own the step after its episode ends (N reference
     microgrids reset one by one), new start rows and lengths each time, for many more steps than the window ring has rows
     (the ring wraps several times, H = 23 forecasts read across the wrap, windows reach the end of the series).  Rewards,
@@ -467,13 +467,14 @@ def test_rolling_windows_with_individual_restarts_vs_oracle(discrete, pymgrid25,
     N = len(grids)
     cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
     kw = dict(remove_redundant_gensets=False) if discrete else {}
-    env = cls(_batch(grids, device), observations=True, **kw)
+    env = cls(_batch(grids, device), observations=True, obs_prefetch=prefetch, **kw)     # prefetch > 0: rings + mgx_patch_windows
     rs = np.random.RandomState(21)
     max_len = 20                                                 # ring: 64 rows >= 20 + 23 + 1
     starts = np.array([0, 100, 4000, 8739, 8735, 37, 8758 - 20, 5555])
     lengths = np.array([20, 3, 7, 20, 11, 1, 20, 17])            # 8739 + 20 = 8759 = final_step
     obs = env.reset_windows(starts, lengths, max_length=max_len, rolling=True).cpu().numpy()
-    assert env.engine._rolling["rows"] == 64 and env.current_step == 0 and env.obs_prefetch == 0
+    assert env.engine._rolling["rows"] == 64 and env.current_step == 0 and env.obs_prefetch == prefetch
+    assert env._sync_rings == (prefetch > 0)
     oms, ends = [], lengths.copy()                               # ends[j]: counter value at which grid j's episode is over
     for p, s, n in zip(grids, starts, lengths):
         q = dict(p); q["initial_step"], q["final_step"] = int(s), int(s) + int(n)
@@ -516,9 +517,8 @@ def test_rolling_windows_with_individual_restarts_vs_oracle(discrete, pymgrid25,
     from pymgrid_amd import MgxError
     with pytest.raises(MgxError):
         env.engine.step_k(torch.rand(4, N, 4, dtype=torch.float64, device=device))
-    with pytest.raises(MgxError):
-        env.engine.observe_windows(K=4)
     env.reset()
+    assert not env._sync_rings
     assert env.final_step == 8759 and env.current_step == 0 and int(env.current_steps[3]) == 0
     env.close()
 
