@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 4
+#define MGX_ABI_VERSION 5
 
 enum mgx_status {
     MGX_OK = 0,
@@ -58,7 +58,9 @@ enum mgx_obs_format { MGX_OBS_F64 = 0, MGX_OBS_F32 = 1 };
 /* element type of the continuous `actions` of mgx_step / mgx_step_k (mgx_set_action_format) */
 enum mgx_action_format { MGX_ACT_F64 = 0, MGX_ACT_F32 = 1 };
 /* what the `obs` argument of mgx_step / mgx_step_discrete / mgx_observe / mgx_reset receives (mgx_set_obs_mode) */
-enum mgx_obs_rows { MGX_OBS_ROWS_FULL = 0, MGX_OBS_ROWS_STATE_ONLY = 1 };
+enum mgx_obs_rows { MGX_OBS_ROWS_FULL = 0, MGX_OBS_ROWS_STATE_ONLY = 1, MGX_OBS_ROWS_STATE_COMPACT = 2 };
+/* what the `done` argument of the fused calls (mgx_step_k, mgx_rollout_discrete) receives (mgx_set_done_format) */
+enum mgx_done_format { MGX_DONE_U8 = 0, MGX_DONE_BITS = 1 };
 
 /* Reward shaping functions of the reference (microgrid/reward_shaping/): what step() RETURNS as reward.
  * The log's "reward" column always keeps the unshaped sum (the balance log's `reward` vs `shaped_reward`). */
@@ -126,7 +128,28 @@ typedef struct mgx_columns {
     /* dynamic state, read and written by every step */
     double *charge, *soc;                 /* BatteryModule._current_charge / _soc */
     uint32_t *gen_status;                 /* current | goal<<8 | steps_until_up<<16 | steps_until_down<<24 */
+    /* FACTORISED series (optional; base_load != NULL switches it on).  Every series MicrogridGenerator builds is one of a
+     * few base profiles times a per-grid scalar (MicrogridGenerator.py:137-147 _scale_ts: ts * (size / ts.max()); :205-212
+     * co2 profile verbatim; :253-285 import tariff by hour of day; :321-340 weak-grid outages), so a generated batch is
+     * fully described by the base tables + a profile id and a ratio per grid.  In this mode load_ts / pv_ts / grid_ts may be
+     * NULL and the kernels FORM the series values as they go, with the same single multiply the generator performs:
+     *     load[t, i] = -|base_load[t, load_profile[i]] * load_ratio[i]|     (sign as stored, base_timeseries_module.py:68-79)
+     *     pv[t, i]   =  |base_pv[t, pv_profile[i]] * pv_ratio[i]|
+     *     grid[t, :, i] = (tariff price of hour t % 24 under pattern tariff[i] (1 or 2), 0, base_co2[t, co2_profile[i]],
+     *                      1 - bit t of grid i's outage words)
+     * -- bit-identical to the arrays mgx_synthesize_series writes.  The [T, N] series (16 of the 57 B a fused env-step of a
+     * Template-4 grid streams; 14 GB per 100 000 grid-years) then never exist; the base tables (<= 560 KB each) stay in
+     * the caches.  Base tables are [n_steps, MGX_PROFILE_PITCH] doubles (one 64-byte row per step, unused columns
+     * arbitrary), profile ids < MGX_PROFILE_PITCH.  outage_bits: [ceil(n_steps / 64), N] words, bit (t & 63) of word
+     * t >> 6 set = grid_status 0 at row t; NULL = no outages.  Offered with one module of every kind per grid (the general
+     * kernels read materialised series only). */
+    const double *base_load, *base_pv, *base_co2;
+    const uint8_t *load_profile, *pv_profile, *co2_profile, *tariff;      /* [N] */
+    const double *load_ratio, *pv_ratio;                                   /* [N] */
+    const uint64_t *outage_bits;
 } mgx_columns;
+
+#define MGX_PROFILE_PITCH 8
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 int mgx_abi_version(void);
@@ -252,7 +275,29 @@ int mgx_set_ring_pitch(mgx_handle *h, int32_t rows);
  * grid -- the accumulator of that later patch. */
 int mgx_patch_windows(mgx_handle *h, const uint8_t *mask, int32_t K, void *ring, int32_t first_block, int32_t ahead,
                       uint8_t *restarted, mgx_stream stream);
+/* MGX_OBS_ROWS_STATE_COMPACT: `obs` receives ONLY the genset / battery state columns, as a dense [N, S] array,
+ * S = 4 * has_genset + 2 * has_battery (the zero-copy observation contract: the window columns are views of the normalised
+ * series written once by mgx_normalise_series). */
 int mgx_set_obs_mode(mgx_handle *h, int32_t mode);
+
+/* `done` of the fused calls.  MGX_DONE_U8 (default): one byte per grid and step, [K, N].  MGX_DONE_BITS: a bit set per step,
+ * [K, W] uint16 words with W = ceil(N / 16), bit (i & 15) of word i >> 4 = done of grid i (little-endian: the row is a
+ * ceil(N / 16) * 2-byte bit array) -- 1/8 byte instead of 1 byte per env-step, written by one lane in 16.
+ * In lock-step (no per-grid episode ends) `done` is the same for every grid, done(k) = (t0 + k >= final_step - 1)
+ * (base_timeseries_module.py:124-125): pass done = NULL and derive it from mgx_current_step / the window. */
+int mgx_set_done_format(mgx_handle *h, int32_t format);
+
+/* The zero-copy observation contract for a forecast horizon H > 0.  With the oracle forecaster the window columns of the
+ * observation at step t are  norm[t .. t + H]  of a series normalised ONCE ((v - lo) / spread, space.py:207-218; rows past
+ * the end of the series = the padding value (lo + hi) / 2, forecaster.py:95,120-137; the forecast clip, forecaster.py:139-149,
+ * is the identity because lo / hi bound the series).  mgx_normalise_series writes that normalised copy GRID-major:
+ *     load_n, pv_n  [N, R]      R = n_steps + horizon
+ *     grid_n        [N, R, 4]   (component-minor: the reference's window order falls out of a flat slice)
+ * as float64 or float32 (the handle's obs format) so that the window of grid i at step t is the contiguous slice
+ * load_n[i, t : t + 1 + H] -- a strided VIEW, no bytes moved per step.  Returns MGX_ERR_UNSUPPORTED when a bound column does
+ * not bound its series (the clip would not be the identity) -- checked on device, reported through `clipped` (device int32[1],
+ * incremented per offending value; may be NULL).  grid_n may be NULL without a GridModule. */
+int mgx_normalise_series(mgx_handle *h, void *load_n, void *pv_n, void *grid_n, int32_t *clipped, mgx_stream stream);
 
 /* The same prefetch AHEAD of the counter, overlapped with the steps: block k of `ring` = the window columns of counter
  * value t + ahead + k (ahead >= 1; the state columns of every block are zero and are filled in by the steps that reach
@@ -409,8 +454,10 @@ typedef struct mgx_synth {
     uint64_t seed;
     int64_t grid_index0;                                    /* global index of grid 0 ... */
     const int64_t *grid_index;                              /* ... or [N] global indices (a scattered selection); NULL: grid_index0 + i */
-    double *load_ts, *pv_ts;                                /* out [T, N] */
+    double *load_ts, *pv_ts;                                /* out [T, N]; both NULL: only the outage words are produced */
     double *grid_ts;                                        /* out [T, 4, N] or NULL */
+    uint64_t *outage_bits;                                  /* out [ceil(T / 64), N] or NULL: the factorised form of grid_status
+                                                             * (mgx_columns.outage_bits), same draws as grid_ts[:, 3] */
 } mgx_synth;
 int mgx_synthesize_series(const mgx_synth *args, mgx_stream stream);
 

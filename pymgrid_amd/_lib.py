@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-fPIC", "-shared"]
 
 MGX_OK, MGX_ERR_INVALID, MGX_ERR_UNSUPPORTED, MGX_ERR_RANGE, MGX_ERR_DEVICE = range(5)
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_INSTANCES = 8          # MGX_MAX_INSTANCES: gensets / batteries / grids per microgrid
 
 
@@ -47,12 +47,20 @@ _F64_COLS2 = ("grid_max_import", "grid_max_export", "grid_cost_per_unit_co2", "l
               "load_noise_std", "pv_noise_std", "grid_noise_std", "charge", "soc")
 
 
+# factorised series (mgx_columns, include/mgx.h): base tables [T, PROFILE_PITCH] f64, profile ids / tariff uint8 [N], ratios f64
+# [N], outage words [ceil(T / 64), N] (stored as int64: torch has no uint64)
+FACTOR_COLUMNS = ("base_load", "base_pv", "base_co2", "load_profile", "pv_profile", "co2_profile", "tariff", "load_ratio",
+                  "pv_ratio", "outage_bits")
+PROFILE_PITCH = 8          # MGX_PROFILE_PITCH
+
+
 class Columns(C.Structure):
     _fields_ = ([("struct_size", C.c_int32), ("reserved", C.c_int32)]
                 + [(n, C.c_void_p) for n in _F64_COLS]
                 + [("gen_times", C.c_void_p)]
                 + [(n, C.c_void_p) for n in _F64_COLS2]
-                + [("gen_status", C.c_void_p)])
+                + [("gen_status", C.c_void_p)]
+                + [(n, C.c_void_p) for n in FACTOR_COLUMNS])
 
 
 COLUMN_NAMES = tuple(n for n, _ in Columns._fields_[2:])
@@ -75,7 +83,7 @@ class Synth(C.Structure):
                                              "load_ratio", "pv_ratio", "tariff", "weak", "outage_per_day",
                                              "outage_duration")]
                 + [("seed", C.c_uint64), ("grid_index0", C.c_int64), ("grid_index", C.c_void_p)]
-                + [(n, C.c_void_p) for n in ("load_ts", "pv_ts", "grid_ts")])
+                + [(n, C.c_void_p) for n in ("load_ts", "pv_ts", "grid_ts", "outage_bits")])
 
 # every symbol include/mgx.h declares: (restype, argtypes)
 SYMBOLS = {
@@ -94,6 +102,8 @@ SYMBOLS = {
     "mgx_set_forecast_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
     "mgx_set_obs_format": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_set_obs_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mgx_set_done_format": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mgx_normalise_series": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_set_action_format": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_observe_windows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgx_observe_windows_ahead": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -145,17 +145,27 @@ class BatchLayout:
             B += 8 * self.obs_dim + 8 * C_ts
         return B
 
-    def bytes_fused(self, K, reward=True, done=True, soc_trace=True, status_trace=False, log=False, action_bytes=8):
+    def bytes_fused(self, K, reward=True, done=True, soc_trace=True, status_trace=False, log=False, action_bytes=8,
+                    factorised=False, done_bits=False):
         """Compulsory HBM bytes of ONE grid for a K-step fused launch: parameters and state move once, the
-        per-step streams (actions, series rows, requested outputs) K times."""
+        per-step streams (actions, series rows, requested outputs) K times.  ``factorised``: the series are formed in the
+        kernel from base profile x ratio -- per launch the grid's factors (two ratios + two profile ids; with a GridModule a
+        co2 profile id, a tariff byte and one 8-byte outage word per 64 steps) instead of 8 * C_ts bytes of rows per step
+        (the base-profile rows are shared by all grids: K * 64 B per table and WORKGROUP, out of the caches, not counted).
+        ``done``: one byte per step, 1/8 with ``done_bits``, none when the caller derives it from the step counter."""
         A = self.action_dim
         P_f = 2 + 6 * int(self.has_battery) + 5 * int(self.has_genset) + 3 * int(self.has_grid)
         C_ts = self.n_load + self.n_pv + 4 * int(self.has_grid)
         # once: float params, packed genset times, charge read + charge/soc write, genset status read + write
         once = 8 * P_f + 4 * int(self.has_genset) + (8 + 16) * int(self.has_battery) + 8 * int(self.has_genset) \
             + 8 * int(log and self.has_battery)      # the log also reads the pre-launch SoC
-        per = action_bytes * A + 8 * C_ts + 8 * int(reward) + int(done) + 8 * int(soc_trace and self.has_battery) \
-            + 4 * int(status_trace and self.has_genset) + 8 * len(self.log_names) * int(log)
+        series = 8 * C_ts
+        if factorised:
+            once += 2 * 8 + 2 + 2 * int(self.has_grid)
+            series = 0.125 * int(self.has_grid)      # the outage word: 8 B per 64 steps
+        per = action_bytes * A + series + 8 * int(reward) + (0.125 if done_bits else 1) * int(done) \
+            + 8 * int(soc_trace and self.has_battery) + 4 * int(status_trace and self.has_genset) \
+            + 8 * len(self.log_names) * int(log)
         return once + K * per
 
 
@@ -196,8 +206,15 @@ class MicrogridBatch:
     # ------------------------------------------------------------------------------------------------
     def _validate(self):
         L, N, T = self.layout, self.layout.n_grids, self.layout.n_steps
-        need = ["loss_load_cost", "overgeneration_cost"] + (["load_ts"] if L.n_load else []) + \
-            (["pv_ts"] if L.n_pv else [])
+        fact = self.factorised
+        need = ["loss_load_cost", "overgeneration_cost"] + (["load_ts"] if L.n_load and not fact else []) + \
+            (["pv_ts"] if L.n_pv and not fact else [])
+        if fact:
+            if L.multi:
+                raise ValueError("factorised series need exactly one module of every kind per grid")
+            need += ["base_load", "base_pv", "load_profile", "pv_profile", "load_ratio", "pv_ratio"]
+            if L.has_grid:
+                need += ["base_co2", "co2_profile", "tariff"]
         if L.has_battery:
             need += ["bat_min_capacity", "bat_max_capacity", "bat_max_charge", "bat_max_discharge", "bat_efficiency",
                      "bat_cost_cycle", "charge", "soc"]
@@ -205,8 +222,12 @@ class MicrogridBatch:
             need += ["gen_running_min", "gen_running_max", "gen_cost", "gen_co2_per_unit", "gen_cost_per_unit_co2",
                      "gen_times", "gen_status"]
         if L.has_grid:
-            need += ["grid_max_import", "grid_max_export", "grid_cost_per_unit_co2", "grid_ts"]
-        shapes = {"load_ts": (T, N), "pv_ts": (T, N), "grid_ts": (T, 4, N), "grid_lo": (4, N), "grid_hi": (4, N)}
+            need += ["grid_max_import", "grid_max_export", "grid_cost_per_unit_co2"] + ([] if fact else ["grid_ts"])
+        PPITCH = _lib.PROFILE_PITCH
+        shapes = {"load_ts": (T, N), "pv_ts": (T, N), "grid_ts": (T, 4, N), "grid_lo": (4, N), "grid_hi": (4, N),
+                  "base_load": (T, PPITCH), "base_pv": (T, PPITCH), "base_co2": (T, PPITCH), "outage_bits": ((T + 63) // 64, N)}
+        dtypes = {"gen_times": torch.int32, "gen_status": torch.int32, "load_profile": torch.uint8, "pv_profile": torch.uint8,
+                  "co2_profile": torch.uint8, "tariff": torch.uint8, "outage_bits": torch.int64}   # (u)int bit patterns
         if L.n_load != 1:            # several (or no) load modules per grid: [T, n_load, N], bounds [n_load, N]
             shapes.update(load_ts=(T, L.n_load, N), load_lo=(L.n_load, N), load_hi=(L.n_load, N))
         if L.n_pv != 1:
@@ -229,7 +250,7 @@ class MicrogridBatch:
         for name, t in self.cols.items():
             if name not in _lib.COLUMN_NAMES:
                 raise ValueError(f"unknown column {name}")
-            want = torch.int32 if name in ("gen_times", "gen_status") else F64   # uint32 bit patterns
+            want = dtypes.get(name, F64)
             if t.dtype != want:
                 raise TypeError(f"column {name}: dtype {t.dtype}, expected {want}")
             if tuple(t.shape) != shapes.get(name, (N,)):
@@ -241,6 +262,23 @@ class MicrogridBatch:
                 raise ValueError("all columns must live on one device")
         self.device = dev
 
+    @property
+    def factorised(self):
+        """True when the batch holds its series as base profile x per-grid ratio (``mgx_columns.base_load``, include/mgx.h)
+        instead of [T, N] arrays: what ``generator.generate(series="factorised")`` builds."""
+        return self.cols.get("base_load") is not None
+
+    def materialise(self):
+        """The materialised twin of a factorised batch: the same columns (the state columns are SHARED, not copied) with the
+        [T, N] series written by ``mgx_synthesize_series``' arithmetic -- one multiply per value, the same the kernels of the
+        factorised form perform, so both step bit-identically."""
+        if not self.factorised:
+            return self
+        from .generator import materialise_series
+        cols = {k: v for k, v in self.cols.items() if k not in _lib.FACTOR_COLUMNS}
+        cols.update(materialise_series(self))
+        return MicrogridBatch(self.layout, cols, forecast_noise=self.forecast_noise)
+
     # ------------------------------------------------------------------------------------------------
     @classmethod
     def from_numpy(cls, layout, arrays, device):
@@ -251,6 +289,10 @@ class MicrogridBatch:
             a = np.ascontiguousarray(a)
             if name in ("gen_times", "gen_status"):
                 t = torch.from_numpy(a.astype(np.uint32).view(np.int32).copy())
+            elif name in ("load_profile", "pv_profile", "co2_profile", "tariff"):
+                t = torch.from_numpy(a.astype(np.uint8).copy())
+            elif name == "outage_bits":
+                t = torch.from_numpy(a.astype(np.uint64).view(np.int64).copy())
             else:
                 t = torch.from_numpy(a.astype(np.float64, copy=False).copy())
             cols[name] = t.to(device)
@@ -273,6 +315,9 @@ class MicrogridBatch:
             self.cols[k].copy_(v)
 
     def numpy_columns(self):
+        """Host copies of the columns (the CPU oracle's input in the tests); a factorised batch is materialised first."""
+        if self.factorised:
+            return self.materialise().numpy_columns()
         out = {}
         for k, v in self.cols.items():
             out[k] = v.cpu().numpy().view(np.uint32) if v.dtype == torch.int32 else v.cpu().numpy()

@@ -57,6 +57,8 @@ struct mgx_handle {
     double *roll_load_w, *roll_pv_w, *roll_grid_w;
     int32_t *roll_final;
     const double *full_load_ts, *full_pv_ts, *full_grid_ts;
+    mgx_columns full_c;                      // the columns as given at create (a factorised batch steps over materialised
+                                             // window buffers during a per-grid-window episode: k.c.base_load is NULL then)
     int32_t full_T, full_final, full_initial, full_window_lo, full_window_hi;
 };
 
@@ -250,7 +252,10 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     if (L->initial_step < 0 || L->initial_step >= final_step)
         return fail(MGX_ERR_INVALID, "mgx_create: final_step value must be greater than initial_step");
 #define NEED(cond, ptr) if ((cond) && !(C->ptr)) return fail(MGX_ERR_INVALID, "mgx_create: column " #ptr " is NULL")
-    NEED(L->n_load > 0, load_ts); NEED(L->n_pv > 0, pv_ts); NEED(true, loss_load_cost); NEED(true, overgeneration_cost);
+    const bool fact = C->base_load != nullptr;           // factorised series: the [T, N] arrays are optional
+    NEED(L->n_load > 0 && !fact, load_ts); NEED(L->n_pv > 0 && !fact, pv_ts); NEED(true, loss_load_cost); NEED(true, overgeneration_cost);
+    NEED(fact, base_pv); NEED(fact, load_profile); NEED(fact, pv_profile); NEED(fact, load_ratio); NEED(fact, pv_ratio);
+    NEED(fact && L->has_grid, base_co2); NEED(fact && L->has_grid, co2_profile); NEED(fact && L->has_grid, tariff);
     NEED(L->has_battery, bat_min_capacity); NEED(L->has_battery, bat_max_capacity); NEED(L->has_battery, bat_max_charge);
     NEED(L->has_battery, bat_max_discharge); NEED(L->has_battery, bat_efficiency); NEED(L->has_battery, bat_cost_cycle);
     NEED(L->has_battery, charge); NEED(L->has_battery, soc);
@@ -258,8 +263,11 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     NEED(L->has_genset, gen_co2_per_unit); NEED(L->has_genset, gen_cost_per_unit_co2); NEED(L->has_genset, gen_times);
     NEED(L->has_genset, gen_status);
     NEED(L->has_grid, grid_max_import); NEED(L->has_grid, grid_max_export); NEED(L->has_grid, grid_cost_per_unit_co2);
-    NEED(L->has_grid, grid_ts);
+    NEED(L->has_grid && !fact, grid_ts);
 #undef NEED
+    if (fact && (L->n_load != 1 || L->n_pv != 1 || n_genset > 1 || n_battery > 1 || n_grid > 1))
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_create: factorised series need exactly one module of every kind per grid (the "
+                                         "general kernels read materialised series)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -299,6 +307,8 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->t = L->initial_step;
     h->k.shaper = MGX_SHAPER_NONE;
     h->k.noise_seed = 0; h->k.noise_increase = 0; h->k.obs_f32 = 0; h->k.obs_state_only = 0; h->k.act_f32 = 0;
+    h->k.done_bits = 0;
+    h->full_c = *C;
     h->window_lo = L->initial_step; h->window_hi = final_step;
     h->k.g0 = 0; h->k.g1 = L->n_grids; h->k.grid_final = nullptr;
     h->n_shards = 1; h->shard_lo[0] = 0; h->shard_lo[1] = L->n_grids;
@@ -367,6 +377,9 @@ int mgx_use_device_counter(mgx_handle *h, int enable, mgx_stream stream)
     hipStream_t st = (hipStream_t)stream;
     if (enable && h->n_shards > 1)
         return fail(MGX_ERR_UNSUPPORTED, "mgx_use_device_counter: not offered while the handle steps in shards (mgx_set_shards)");
+    if (enable && (h->windowed || h->rolling))
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_use_device_counter: not offered during a per-grid-window episode (restarts, ring "
+                                         "patches and episode ends are placed by the host's counter)");
     h->counter_stream = st;
     if (enable) {
         set_counter_kernel<<<1, 1, 0, st>>>(h->d_counter, h->t);
@@ -423,11 +436,23 @@ int mgx_set_obs_mode(mgx_handle *h, int32_t mode)
 {
     g_err[0] = 0;
     if (!h) return fail(MGX_ERR_INVALID, "mgx_set_obs_mode: NULL handle");
-    if (mode != MGX_OBS_ROWS_FULL && mode != MGX_OBS_ROWS_STATE_ONLY)
+    if (mode != MGX_OBS_ROWS_FULL && mode != MGX_OBS_ROWS_STATE_ONLY && mode != MGX_OBS_ROWS_STATE_COMPACT)
         return fail(MGX_ERR_INVALID, "mgx_set_obs_mode: unknown mode %d", mode);
-    if (mode == MGX_OBS_ROWS_STATE_ONLY && h->multi)
+    if (mode != MGX_OBS_ROWS_FULL && h->multi)
         return fail(MGX_ERR_UNSUPPORTED, "mgx_set_obs_mode: state-only rows need exactly one load and one renewable module per grid");
-    h->k.obs_state_only = mode == MGX_OBS_ROWS_STATE_ONLY;
+    h->k.obs_state_only = mode == MGX_OBS_ROWS_STATE_ONLY ? 1 : (mode == MGX_OBS_ROWS_STATE_COMPACT ? 2 : 0);
+    return MGX_OK;
+}
+
+int mgx_set_done_format(mgx_handle *h, int32_t format)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_done_format: NULL handle");
+    if (format != MGX_DONE_U8 && format != MGX_DONE_BITS)
+        return fail(MGX_ERR_INVALID, "mgx_set_done_format: unknown format %d", format);
+    if (format == MGX_DONE_BITS && h->multi)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_set_done_format: bit sets need exactly one module of every kind per grid");
+    h->k.done_bits = format == MGX_DONE_BITS;
     return MGX_OK;
 }
 
@@ -441,6 +466,9 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "%s: needs exactly one module of every kind per grid", who);
     if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
         return fail(MGX_ERR_UNSUPPORTED, "%s: forecast noise depends on (step, horizon index), windows cannot be shared", who);
+    if (h->k.obs_state_only == 2)
+        return fail(MGX_ERR_UNSUPPORTED, "%s: the handle writes compact state rows (MGX_OBS_ROWS_STATE_COMPACT): the windows are "
+                                         "views of mgx_normalise_series' output, there are no rings to fill", who);
     if (int rc = need_obs_bounds(h, who)) return rc;
     if (!dev_counter(h) && ahead == 0 && h->t > h->k.T)
         return fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, h->k.T);
@@ -646,6 +674,7 @@ static void leave_windows(mgx_handle *h)
 {
     if (!h->windowed) return;
     h->k.c.load_ts = h->full_load_ts; h->k.c.pv_ts = h->full_pv_ts; h->k.c.grid_ts = h->full_grid_ts;
+    h->k.c.base_load = h->full_c.base_load;              // a factorised batch is factorised again
     h->k.T = h->full_T; h->k.final_step = h->full_final; h->k.grid_final = nullptr;
     h->layout.n_steps = h->full_T; h->layout.final_step = h->full_final; h->layout.initial_step = h->full_initial;
     h->window_lo = h->full_window_lo; h->window_hi = h->full_window_hi;
@@ -695,11 +724,13 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
     g.N = h->k.N; g.T = h->full_T; g.rows = rows; g.max_length = max_length;
     g.lo = h->full_window_lo; g.hi = h->full_window_hi;
     g.mask = nullptr; g.row0 = 0; g.row_mask = -1;
+    g.fc = h->full_c; g.has_grid = h->layout.has_grid;
     g.draw = 0; g.fixed_length = 0; g.seed = 0; g.start_io = nullptr; g.length_io = nullptr; g.t0_io = nullptr;
     gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gather_windows_kernel launch");
     h->rolling = false; h->k.row_mask = -1;
+    h->k.c.base_load = nullptr;                          // the episode steps over the (materialised) window buffers
     h->k.c.load_ts = load_w; h->k.c.pv_ts = pv_w; if (h->layout.has_grid) h->k.c.grid_ts = grid_w;
     h->k.T = rows; h->k.final_step = max_length; h->k.grid_final = length ? final_rel : nullptr;
     h->layout.n_steps = rows; h->layout.final_step = max_length; h->layout.initial_step = 0;
@@ -720,6 +751,7 @@ static void rolling_gather_args(const mgx_handle *h, GatherArgs *g)
     g->N = h->k.N; g->T = h->full_T; g->rows = h->rolling_max_length + h->k.H + 1; g->max_length = h->rolling_max_length;
     g->lo = h->full_window_lo; g->hi = h->full_window_hi;
     g->row_mask = h->k.row_mask;
+    g->fc = h->full_c; g->has_grid = h->layout.has_grid;
     g->draw = 0; g->fixed_length = 0; g->seed = 0; g->start_io = nullptr; g->length_io = nullptr; g->t0_io = nullptr;
 }
 
@@ -753,6 +785,7 @@ int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t
     gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gather_windows_kernel launch");
+    h->k.c.base_load = nullptr;                          // the episodes step over the (materialised) window rings
     h->k.c.load_ts = load_w; h->k.c.pv_ts = pv_w; if (h->layout.has_grid) h->k.c.grid_ts = grid_w;
     h->k.T = INT32_MAX / 2; h->k.final_step = INT32_MAX / 2; h->k.grid_final = final_abs;
     h->layout.n_steps = ring_rows; h->layout.final_step = INT32_MAX / 2; h->layout.initial_step = 0;
@@ -768,6 +801,7 @@ int mgx_reset_grids_random(mgx_handle *h, const uint8_t *mask, uint64_t seed, in
     g_err[0] = 0;
     if (!h || !mask) return fail(MGX_ERR_INVALID, "mgx_reset_grids_random: NULL argument");
     if (!h->rolling) return fail(MGX_ERR_INVALID, "mgx_reset_grids_random: the handle is not in rolling-window mode");
+    if (dev_counter(h)) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_grids_random: not offered in device-counter mode");
     if (fixed_length < 0 || fixed_length > h->rolling_max_length)
         return fail(MGX_ERR_INVALID, "mgx_reset_grids_random: fixed_length %d outside [0, max_length = %d]", fixed_length, h->rolling_max_length);
     if (fixed_length == 0 && h->rolling_max_length < h->full_window_hi - h->full_window_lo)
@@ -788,6 +822,7 @@ int mgx_reset_grids(mgx_handle *h, const uint8_t *mask, const int32_t *start, co
     g_err[0] = 0;
     if (!h || !mask || !start) return fail(MGX_ERR_INVALID, "mgx_reset_grids: NULL argument");
     if (!h->rolling) return fail(MGX_ERR_INVALID, "mgx_reset_grids: the handle is not in rolling-window mode (mgx_reset_windows_rolling)");
+    if (dev_counter(h)) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_grids: not offered in device-counter mode");
     if (h->t > INT32_MAX / 4) return fail(MGX_ERR_RANGE, "mgx_reset_grids: the shared step counter is about to overflow; start over "
                                                          "with mgx_reset_windows_rolling");
     GatherArgs g;
@@ -961,6 +996,7 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
     hipStream_t st = (hipStream_t)stream;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     if (h->multi) {                                       // general path: the K-step loop around the general step
+        if (h->k.done_bits && done) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: the general kernels write `done` as bytes");
         for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
             MGX_DISPATCH_F(h->flags, (step_k_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
                                           k, actions, nullptr, 0, 0, nullptr, 0, t_arg(h), K, normalized, fo)));
@@ -970,21 +1006,21 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
         advance(h, K, st);
         return MGX_OK;
     }
+    const bool fact = factorised(h->k.c);
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
         const int32_t gpb = fused_grids_per_block(h, k.g1 - k.g0);
         const unsigned blocks = (unsigned)((k.g1 - k.g0 + gpb - 1) / gpb);
         const bool rich = log != nullptr || status_trace != nullptr;
+#define MGX_STEP_K(AT, RC, FC) MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, AT, RC, FC><<<blocks, BLOCK_K, 0, s>>>( \
+                                                            k, (const AT *)actions, t_arg(h), K, normalized, fo, gpb)))
         if (k.act_f32) {
-            if (rich) { MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, float, true><<<blocks, BLOCK_K, 0, s>>>(
-                                                      k, (const float *)actions, t_arg(h), K, normalized, fo, gpb))); }
-            else { MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, float, false><<<blocks, BLOCK_K, 0, s>>>(
-                                                 k, (const float *)actions, t_arg(h), K, normalized, fo, gpb))); }
+            if (fact) { if (rich) { MGX_STEP_K(float, true, true); } else { MGX_STEP_K(float, false, true); } }
+            else { if (rich) { MGX_STEP_K(float, true, false); } else { MGX_STEP_K(float, false, false); } }
         } else {
-            if (rich) { MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, double, true><<<blocks, BLOCK_K, 0, s>>>(
-                                                      k, (const double *)actions, t_arg(h), K, normalized, fo, gpb))); }
-            else { MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, double, false><<<blocks, BLOCK_K, 0, s>>>(
-                                                 k, (const double *)actions, t_arg(h), K, normalized, fo, gpb))); }
+            if (fact) { if (rich) { MGX_STEP_K(double, true, true); } else { MGX_STEP_K(double, false, true); } }
+            else { if (rich) { MGX_STEP_K(double, true, false); } else { MGX_STEP_K(double, false, false); } }
         }
+#undef MGX_STEP_K
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_k_kernel launch");
@@ -1115,14 +1151,20 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     hipStream_t st = (hipStream_t)stream;
     static const int gpb_env = [] { const char *e = getenv("MGX_GPB_ROLLOUT"); return e ? atoi(e) : 0; }();   // experiment knob
+    const bool fact = factorised(h->k.c);
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
         const int32_t gpb = gpb_env > 0 ? gpb_env : fused_grids_per_block(h, k.g1 - k.g0);
         const unsigned blocks = (unsigned)((k.g1 - k.g0 + gpb - 1) / gpb);
         const bool rich = log != nullptr || status_trace != nullptr;
-#define MGX_ROLLOUT(PS, RC) MGX_DISPATCH_F(h->flags, (rollout_kernel<F, (F & F_GRID) ? 4 : MGX_RING_ROLLOUT, PS, RC><<<blocks, BLOCK_K, 0, s>>>( \
-                                                          k, tab, action_id, t_arg(h), K, fo, gpb)))
-        if (per_step) { if (rich) { MGX_ROLLOUT(true, true); } else { MGX_ROLLOUT(true, false); } }
-        else { if (rich) { MGX_ROLLOUT(false, true); } else { MGX_ROLLOUT(false, false); } }
+#define MGX_ROLLOUT(PS, RC, FC) MGX_DISPATCH_F(h->flags, (rollout_kernel<F, (F & F_GRID) ? 4 : MGX_RING_ROLLOUT, PS, RC, FC><<<blocks, BLOCK_K, 0, s>>>( \
+                                                              k, tab, action_id, t_arg(h), K, fo, gpb)))
+        if (fact) {
+            if (per_step) { if (rich) { MGX_ROLLOUT(true, true, true); } else { MGX_ROLLOUT(true, false, true); } }
+            else { if (rich) { MGX_ROLLOUT(false, true, true); } else { MGX_ROLLOUT(false, false, true); } }
+        } else {
+            if (per_step) { if (rich) { MGX_ROLLOUT(true, true, false); } else { MGX_ROLLOUT(true, false, false); } }
+            else { if (rich) { MGX_ROLLOUT(false, true, false); } else { MGX_ROLLOUT(false, false, false); } }
+        }
 #undef MGX_ROLLOUT
     });
     hipError_t e = hipGetLastError();
@@ -1140,6 +1182,10 @@ int mgx_rollout_lists(mgx_handle *h, const int32_t *action_id, int per_step, con
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_lists: K must be positive");
     if (n_lists <= 0 || list_len <= 0 || list_len > 3 * MGX_MAX_INSTANCES)
         return fail(MGX_ERR_INVALID, "mgx_rollout_lists: need n_lists > 0 and list_len in [1, %d]", 3 * MGX_MAX_INSTANCES);
+    if (h->rolling) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_lists: rolling windows take single steps");
+    if (factorised(h->k.c)) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_lists: the general kernels read materialised series; "
+                                                             "use mgx_rollout_discrete on a factorised batch");
+    if (h->k.done_bits && done) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_lists: the general kernels write `done` as bytes");
     if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
         return fail(MGX_ERR_RANGE, "mgx_rollout_lists: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, step_limit(h));
     hipStream_t st = (hipStream_t)stream;
@@ -1277,11 +1323,15 @@ int mgx_synthesize_series(const mgx_synth *a, mgx_stream stream)
         return fail(MGX_ERR_INVALID, "mgx_synthesize_series: struct_size %d vs %zu (ABI %d)", a->struct_size, sizeof(mgx_synth), MGX_ABI_VERSION);
     if (a->n_grids <= 0 || a->n_steps <= 0 || a->n_load_profiles <= 0 || a->n_pv_profiles <= 0)
         return fail(MGX_ERR_INVALID, "mgx_synthesize_series: need n_grids, n_steps, n_load_profiles, n_pv_profiles > 0");
-    if (!a->base_load || !a->base_pv || !a->load_profile || !a->pv_profile || !a->load_ratio || !a->pv_ratio || !a->load_ts || !a->pv_ts)
+    if ((a->load_ts == nullptr) != (a->pv_ts == nullptr))
+        return fail(MGX_ERR_INVALID, "mgx_synthesize_series: load_ts and pv_ts go together");
+    if (!a->load_ts && !a->outage_bits) return fail(MGX_ERR_INVALID, "mgx_synthesize_series: nothing to write");
+    if (!a->load_ts && a->grid_ts) return fail(MGX_ERR_INVALID, "mgx_synthesize_series: grid_ts without load_ts / pv_ts");
+    if (a->load_ts && (!a->base_load || !a->base_pv || !a->load_profile || !a->pv_profile || !a->load_ratio || !a->pv_ratio))
         return fail(MGX_ERR_INVALID, "mgx_synthesize_series: NULL load / pv argument");
     if (a->grid_ts && (!a->base_co2 || !a->co2_profile || !a->tariff || a->n_co2_profiles <= 0))
         return fail(MGX_ERR_INVALID, "mgx_synthesize_series: grid_ts requested without base_co2 / co2_profile / tariff");
-    if (a->grid_ts && a->outage_per_day && (!a->weak || !a->outage_duration))
+    if ((a->grid_ts || a->outage_bits) && a->outage_per_day && (!a->weak || !a->outage_duration))
         return fail(MGX_ERR_INVALID, "mgx_synthesize_series: outage_per_day given without weak / outage_duration");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1290,6 +1340,39 @@ int mgx_synthesize_series(const mgx_synth *a, mgx_stream stream)
     synthesize_series_kernel<<<blocks_for(a->n_grids), BLOCK, 0, (hipStream_t)stream>>>(*a);
     e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "synthesize_series_kernel launch");
+}
+
+int mgx_normalise_series(mgx_handle *h, void *load_n, void *pv_n, void *grid_n, int32_t *clipped, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !load_n || !pv_n) return fail(MGX_ERR_INVALID, "mgx_normalise_series: NULL argument");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_normalise_series: needs exactly one module of every kind per grid");
+    if (h->layout.has_grid && !grid_n) return fail(MGX_ERR_INVALID, "mgx_normalise_series: grid_n is NULL but the layout has a GridModule");
+    if (h->rolling) return fail(MGX_ERR_UNSUPPORTED, "mgx_normalise_series: not offered for rolling windows (restarts rewrite series rows)");
+    if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_normalise_series: forecast noise depends on (step, horizon index): its windows are not "
+                                         "slices of one series");
+    if (int rc = need_obs_bounds(h, "mgx_normalise_series")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t R = h->k.T + h->k.H;
+    const unsigned gx = (unsigned)((h->k.N + 63) / 64);
+    auto launch = [&](int which, void *out, int nc) {
+        const int32_t TR = nc == 1 ? 64 : 16;
+        const dim3 grid(gx, (unsigned)((R + TR - 1) / TR));
+        const size_t lds = (size_t)nc * TR * 65 * sizeof(double);
+        if (nc == 1) {
+            if (h->k.obs_f32) normalise_series_kernel<1, float><<<grid, 256, lds, st>>>(h->k, which, (float *)out, R, TR, clipped);
+            else normalise_series_kernel<1, double><<<grid, 256, lds, st>>>(h->k, which, (double *)out, R, TR, clipped);
+        } else {
+            if (h->k.obs_f32) normalise_series_kernel<4, float><<<grid, 256, lds, st>>>(h->k, which, (float *)out, R, TR, clipped);
+            else normalise_series_kernel<4, double><<<grid, 256, lds, st>>>(h->k, which, (double *)out, R, TR, clipped);
+        }
+    };
+    launch(0, load_n, 1);
+    launch(1, pv_n, 1);
+    if (h->layout.has_grid) launch(2, grid_n, 4);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "normalise_series_kernel launch");
 }
 
 int mgx_metrics(mgx_handle *h, const double *values, int32_t M, double *sums, mgx_stream stream)

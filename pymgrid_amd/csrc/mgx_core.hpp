@@ -46,7 +46,9 @@ struct KArgs {
     int32_t n_genset, n_battery, n_grid;   // controllable module instances per grid (0 / 1 on the fast path, <= MGX_MAX_INSTANCES)
     int32_t obs_f32;         // observation rows are written as float (RN of the fp64 value) instead of double
     int32_t act_f32;         // continuous actions arrive as float (widened to double exactly) instead of double
-    int32_t obs_state_only;  // obs arguments of step / observe receive ONLY the state columns (windows were prefetched)
+    int32_t obs_state_only;  // obs arguments of step / observe receive ONLY the state columns (windows were prefetched):
+                             // 1 = inside full rows [N, D], 2 = as a dense [N, S] array (MGX_OBS_ROWS_STATE_COMPACT)
+    int32_t done_bits;       // fused launches write `done` as bit sets ([K, ceil(N / 16)] uint16) instead of bytes
     int32_t shaper;          // mgx_reward_shaper
     int32_t noise_increase;  // GaussianNoiseForecaster.increase_uncertainty
     uint64_t noise_seed;
@@ -200,6 +202,82 @@ __device__ __forceinline__ void derive(const Params &p, Derived &d)
     }
 }
 
+// ---- factorised series (mgx_columns.base_load != NULL) ------------------------------------------------------
+// MicrogridGenerator's series are base profile x per-grid ratio (MicrogridGenerator.py:137-147), its import tariff a
+// function of the hour of day (:253-285), its co2 series a base profile verbatim (:205-212), its grid status a bit per
+// row (:321-340).  The kernels form the values with the single multiply synthesize_series_kernel performs, so a
+// factorised batch steps bit-identically to its materialised twin.
+constexpr int PP = MGX_PROFILE_PITCH;        // doubles per base-table row (one 64-byte line)
+
+__host__ __device__ __forceinline__ bool factorised(const mgx_columns &c) { return c.base_load != nullptr; }
+
+struct GridFactors {
+    double lr, pr;              // load / pv ratio
+    uint32_t lp, pp, cp, pat;   // load / pv / co2 profile column, tariff pattern
+};
+
+template <int F>
+__device__ __forceinline__ void load_factors(const mgx_columns &c, int64_t i, GridFactors &f)
+{
+    f.lr = c.load_ratio[i]; f.pr = c.pv_ratio[i];
+    f.lp = c.load_profile[i]; f.pp = c.pv_profile[i];
+    f.cp = 0u; f.pat = 0u;
+    if constexpr (F & F_GRID) { f.cp = c.co2_profile[i]; f.pat = c.tariff[i]; }
+}
+
+// stored sign: load <= 0, pv >= 0 (base_timeseries_module.py:68-79); one multiply, as _scale_ts (:137-147)
+__device__ __forceinline__ double fact_load(double base, double ratio) { return -1.0 * fabs(base * ratio); }
+__device__ __forceinline__ double fact_pv(double base, double ratio) { return fabs(base * ratio); }
+
+// MicrogridGenerator._get_electricity_tariff (:253-285): import price by hour of day
+__device__ __forceinline__ double tariff_price(int32_t pattern, int32_t row)
+{
+    const int32_t h = row % 24;
+    if (pattern == 1) return (h >= 12 && h < 18) ? 0.59 : ((h < 8 || h >= 21) ? 0.22 : 0.29);
+    if (pattern == 2) return ((h >= 0 && h < 5) || (h >= 14 && h < 17)) ? 0.08 : 0.11;
+    return 0.0;
+}
+
+// grid_status of grid i at row `row` out of the outage words
+__device__ __forceinline__ double fact_status(const mgx_columns &c, int64_t N, int64_t i, int64_t row)
+{
+    if (c.outage_bits == nullptr) return 1.0;
+    return ((c.outage_bits[(row >> 6) * N + i] >> (row & 63)) & 1ull) ? 0.0 : 1.0;
+}
+
+// the series part of a step's inputs, formed from the factors (global-memory form: base rows out of the caches)
+template <int F>
+__device__ __forceinline__ void fact_series(const mgx_columns &c, int64_t N, int64_t i, int64_t row, const GridFactors &f, Inputs &in)
+{
+    in.load = fact_load(c.base_load[row * PP + f.lp], f.lr);
+    in.pv = fact_pv(c.base_pv[row * PP + f.pp], f.pr);
+    in.g_stat = 1.0;
+    if constexpr (F & F_GRID) {
+        in.g_pimp = tariff_price((int32_t)f.pat, (int32_t)row); in.g_pexp = 0.0;
+        in.g_co2 = c.base_co2[row * PP + f.cp];
+        in.g_stat = fact_status(c, N, i, row);
+    }
+}
+
+// Component `comp` (0 load, 1 pv, 2..5 grid: import price, export price, co2 per kWh, status) of grid i at series row `row`,
+// whichever way the batch holds its series.  For the kernels off the hot path (window patches, episode gathers).
+__device__ __forceinline__ double series_component(const mgx_columns &c, int64_t N, int comp, int64_t row, int64_t i)
+{
+    if (factorised(c)) {
+        switch (comp) {
+            case 0: return fact_load(c.base_load[row * PP + c.load_profile[i]], c.load_ratio[i]);
+            case 1: return fact_pv(c.base_pv[row * PP + c.pv_profile[i]], c.pv_ratio[i]);
+            case 2: return tariff_price((int32_t)c.tariff[i], (int32_t)row);
+            case 3: return 0.0;
+            case 4: return c.base_co2[row * PP + c.co2_profile[i]];
+            default: return fact_status(c, N, i, row);
+        }
+    }
+    if (comp == 0) return c.load_ts[row * N + i];
+    if (comp == 1) return c.pv_ts[row * N + i];
+    return c.grid_ts[(row * 4 + (comp - 2)) * N + i];
+}
+
 // ---- loads ----------------------------------------------------------------------------------------------
 // parameters of the controllable modules at column index i (= instance * N + grid for layouts with several instances)
 template <int F>
@@ -259,6 +337,12 @@ __device__ __forceinline__ void load_inputs(const mgx_columns &c, const AT *__re
     if constexpr (F & F_GENSET) { in.a_goal = a[k]; in.a_gen = a[k + 1]; k += 2; }
     if constexpr (F & F_BATTERY) { in.a_bat = a[k]; k += 1; }
     if constexpr (F & F_GRID) { in.a_grid = a[k]; k += 1; }
+    if (factorised(c)) {                       // uniform over the launch
+        GridFactors f;
+        load_factors<F>(c, i, f);
+        fact_series<F>(c, N, i, t, f, in);
+        return;
+    }
     in.load = c.load_ts[t * N + i];
     in.pv = c.pv_ts[t * N + i];
     if constexpr (F & F_GRID) {
@@ -662,12 +746,12 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
     const int64_t tr = t & a.row_mask;                  // row of the series buffers (rolling windows: a ring)
     {
         const double lo = c.load_lo[i], hi = c.load_hi[i];
-        const double v = in ? c.load_ts[tr * N + i] : 0.0;
+        const double v = in ? series_component(c, N, 0, tr, i) : 0.0;
         obs_row[0] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     {
         const double lo = c.pv_lo[i], hi = c.pv_hi[i];
-        const double v = in ? c.pv_ts[tr * N + i] : 0.0;
+        const double v = in ? series_component(c, N, 1, tr, i) : 0.0;
         obs_row[1] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     observe_state_cols<F, OT>(a, p, s, obs_row);
@@ -676,7 +760,7 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
             const double lo = c.grid_lo[cc * N + i], hi = c.grid_hi[cc * N + i];
-            const double v = in ? c.grid_ts[(tr * 4 + cc) * N + i] : 0.0;
+            const double v = in ? series_component(c, N, 2 + cc, tr, i) : 0.0;
             obs_row[k + cc] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
         }
     }
@@ -718,8 +802,9 @@ __device__ __forceinline__ double forecast_normal(uint64_t seed, int64_t grid, u
 constexpr int OBS_JB = 7;
 
 // General form (any horizon, any t): clamped rows, padding beyond the series.
-template <int NC, bool NOISE, typename OT>
-__device__ __forceinline__ void observe_window_cols(const double *__restrict__ ts, int64_t N, int64_t row_stride,
+// fetch(row, c): component c of this module at series row `row` for the lane's grid
+template <int NC, bool NOISE, typename OT, class Fetch>
+__device__ __forceinline__ void observe_window_cols(Fetch fetch, int64_t N,
                                                     const double *__restrict__ lo_col, const double *__restrict__ hi_col,
                                                     int32_t T, int32_t t, int32_t W, int64_t i, int64_t ic, int32_t q, int32_t Q,
                                                     OT *row /* tile + g*LD + first column of this module */,
@@ -741,7 +826,7 @@ __device__ __forceinline__ void observe_window_cols(const double *__restrict__ t
             const int32_t r = t + hb + q + Q * jj;
             const int32_t rc = (r < T ? r : T - 1) & row_mask;
 #pragma unroll
-            for (int c = 0; c < NC; c++) v[jj][c] = ts[(int64_t)rc * row_stride + c * N + ic];
+            for (int c = 0; c < NC; c++) v[jj][c] = fetch(rc, c);
         }
 #pragma unroll
         for (int jj = 0; jj < OBS_JB; jj++) {

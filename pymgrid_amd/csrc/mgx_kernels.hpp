@@ -36,6 +36,23 @@ constexpr int BLOCK_K = MGX_BLOCK_K;
 // ------------------------------------------------------------------------------------------------------
 // Single step: Microgrid.run for N grids (microgrid.py:227-325) + optional obs (base.py:205-209) + log.
 // ------------------------------------------------------------------------------------------------------
+// the `obs` argument of a single step: state columns only (inside full rows, or as a dense [N, S] array), or -- without a
+// forecaster -- the whole 8..12-value row
+template <int F>
+__device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict__ obs, int64_t i, int32_t t_next, const Params &p,
+                                               const State &s)
+{
+    constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
+    if (a.obs_state_only == 2) {            // MGX_OBS_ROWS_STATE_COMPACT
+        if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * NSTATE, 0);
+        else observe_state_cols<F>(a, p, s, (double *)obs + i * NSTATE, 0);
+    } else if (a.obs_state_only) {          // the window columns of this row were prefetched (obs_windows_k_kernel)
+        if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
+        else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
+    } else if (a.obs_f32) observe_row_h0<F>(a, i, t_next, p, s, (float *)obs + i * a.obs_dim);
+    else observe_row_h0<F>(a, i, t_next, p, s, (double *)obs + i * a.obs_dim);
+}
+
 // body of one step of grid i (shared by step_kernel and fleet_step_kernel)
 template <int F>
 __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict__ actions, int32_t t, int normalized,
@@ -60,13 +77,7 @@ __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict
     if (log) store_log<F>(log + i, a.N, o, s.status);
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
     // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
-    if (obs) {
-        if (a.obs_state_only) {                 // the window columns of this row were prefetched (obs_windows_k_kernel)
-            if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
-            else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
-        } else if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
-        else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
-    }
+    if (obs) store_step_obs<F>(a, obs, i, t + 1, p, s);
 }
 
 template <int F>
@@ -155,9 +166,102 @@ __device__ __forceinline__ void load_inputs_at(const AT *__restrict__ act, const
     }
 }
 
+// ---- factorised series inside the fused kernels ------------------------------------------------------------------
+// The base-profile rows a launch walks are wave-uniform: a workgroup copies rows [t0 + kb, t0 + kb + FACT_ROWS) of the load /
+// pv (/ co2) tables into LDS (64 B per row and table, out of the caches: every workgroup reads the same 8 KB), and a lane
+// picks its profile's column with one ds_read per value and step -- read one step ahead, so the LDS latency never meets a
+// dependent instruction.  The per-grid factors (profile ids, ratios) are loaded once per launch.
+constexpr int FACT_ROWS = 128;                        // rows per LDS chunk (a multiple of every ring depth)
+
+template <int F>
+__device__ __forceinline__ void stage_base_rows(const mgx_columns &c, int64_t row0, int32_t n, double *lds, int nthreads)
+{
+    const int32_t cnt = n * PP;
+    const double *__restrict__ bl = c.base_load + row0 * PP;
+    const double *__restrict__ bp = c.base_pv + row0 * PP;
+    for (int32_t j = threadIdx.x; j < cnt; j += nthreads) {
+        lds[j] = bl[j];
+        lds[FACT_ROWS * PP + j] = bp[j];
+        if constexpr (F & F_GRID) lds[2 * FACT_ROWS * PP + j] = c.base_co2[row0 * PP + j];
+    }
+}
+
+// base values of one row, as read out of the LDS image (this lane's profile columns)
+struct BaseVals { double load, pv, co2; };
+
+template <int F>
+__device__ __forceinline__ BaseVals read_base_row(const double *lds, int32_t r, const GridFactors &f)
+{
+    BaseVals b;
+    b.load = lds[r * PP + f.lp];
+    b.pv = lds[FACT_ROWS * PP + r * PP + f.pp];
+    b.co2 = 0.0;
+    if constexpr (F & F_GRID) b.co2 = lds[2 * FACT_ROWS * PP + r * PP + f.cp];
+    return b;
+}
+
+// grid_status bits of the lane's grid: the word of the current 64-row block + the next one, fetched a block ahead
+struct OutageWords {
+    uint64_t cur, nxt;
+    int64_t wi;
+};
+
+__device__ __forceinline__ void outage_init(const mgx_columns &c, int64_t N, int64_t i, int32_t T, int32_t t0, OutageWords &w)
+{
+    w.wi = t0 >> 6; w.cur = 0; w.nxt = 0;
+    if (c.outage_bits) {
+        w.cur = c.outage_bits[w.wi * N + i];
+        if ((w.wi + 1) * 64 < T) w.nxt = c.outage_bits[(w.wi + 1) * N + i];
+    }
+}
+
+// grid_status at series row `row` (rows are visited in order; `first`: the launch's first row)
+__device__ __forceinline__ double outage_status(const mgx_columns &c, int64_t N, int64_t i, int32_t T, int32_t row, bool first,
+                                                OutageWords &w)
+{
+    if (!first && (row & 63) == 0) {                 // wave-uniform
+        w.cur = w.nxt; w.wi += 1; w.nxt = 0;
+        if (c.outage_bits && (w.wi + 1) * 64 < T) w.nxt = c.outage_bits[(w.wi + 1) * N + i];
+    }
+    return ((w.cur >> (row & 63)) & 1ull) ? 0.0 : 1.0;
+}
+
+template <typename AT>
+struct RawActions {
+    AT a_goal, a_gen, a_bat, a_grid;
+};
+
+template <int F, typename AT>
+__device__ __forceinline__ void load_actions_at(const AT *__restrict__ act, int64_t off, RawActions<AT> &r)
+{
+    constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    const AT *a = act + off * A;
+    int k = 0;
+    if constexpr (F & F_GENSET) { r.a_goal = a[k]; r.a_gen = a[k + 1]; k += 2; }
+    if constexpr (F & F_BATTERY) { r.a_bat = a[k]; k += 1; }
+    if constexpr (F & F_GRID) { r.a_grid = a[k]; k += 1; }
+}
+
+// `done` of one fused step: a byte per grid, or (KArgs.done_bits) a bit per grid in uint16 words -- lane (i & 15) == 0 of every
+// 16-grid group stores the group's word.  Workgroup bases are multiples of 16 grids, so a group never straddles two waves.
+__device__ __forceinline__ void store_done(const KArgs &a, uint8_t *__restrict__ done, int64_t off, int64_t i, int32_t k, bool dn)
+{
+    if (a.done_bits) {
+        const unsigned long long b = __ballot(dn);
+        const int lane = threadIdx.x & 63;
+        if ((lane & 15) == 0) {
+            const int64_t W = ((int64_t)a.N + 15) >> 4;
+            reinterpret_cast<uint16_t *>(done)[(int64_t)k * W + (i >> 4)] = (uint16_t)(b >> (lane & 48));
+        }
+    } else {
+        done[off] = (uint8_t)dn;
+    }
+}
+
 // RICH = false: the launch writes neither log rows nor the status trace -- compiled out, together with every value only
 // they consume (balance sums, co2, the violations mask): the lean form is the hot one (reward / done / SoC streams).
-template <int F, int U, typename AT, bool RICH>
+// FACT: factorised series (mgx_columns.base_load): the ring holds the controls only, the series rows are formed from LDS.
+template <int F, int U, typename AT, bool RICH, bool FACT>
 __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT *__restrict__ actions, int32_t t0,
                                                          int32_t K, int normalized, const FusedOut out_rt, int32_t gpb)
 {
@@ -169,45 +273,108 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT
     // gpb = grids per workgroup (<= BLOCK_K, multiple of 16 = one 128-B line of doubles): chosen by the host so that
     // the busiest CU streams as few grids as possible (fused_grids_per_block)
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * gpb + threadIdx.x;
-    if ((int32_t)threadIdx.x >= gpb || i >= a.g1) return;
+    const bool active = (int32_t)threadIdx.x < gpb && i < a.g1;
+    if constexpr (!FACT) { if (!active) return; }
     const int64_t N = a.N;
     Params p; State s; Derived d;
-    load_state<F>(a.c, i, out.log != nullptr, s);
-    load_params<F>(a.c, i, p);
-    derive<F>(p, d);
-    // series bases moved to row t0 once (scalar), so row k of this launch is base + k*N
-    const double *__restrict__ lts = a.c.load_ts + (int64_t)t0 * N;
-    const double *__restrict__ pts = a.c.pv_ts + (int64_t)t0 * N;
-    const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
     const bool norm = normalized != 0;
     const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
-    const bool gen_instant = genset_wave_is_instant<F>(p, s);
-    const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;      // done <=> k >= k_done
+    bool gen_instant = false;
+    int32_t k_done = 0;
+    if (active) {
+        load_state<F>(a.c, i, out.log != nullptr, s);
+        load_params<F>(a.c, i, p);
+        derive<F>(p, d);
+        gen_instant = genset_wave_is_instant<F>(p, s);
+        k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;      // done <=> k >= k_done
+    }
     double ret = 0.0;
 
-    RawInputs<AT> ring[U];
-#pragma unroll
-    for (int u = 0; u < U; u++)
-        if (u < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
+    // one step of this lane's grid, inputs complete
+    auto consume = [&](const Inputs &in, int32_t k, int64_t off) __attribute__((always_inline)) {
+        Outputs o;
+        step_core<F>(p, d, s, in, norm, want_soc, gen_instant, o);
+        const double r = shaped_reward<F>(a.shaper, o);
+        if (out.reward) out.reward[off] = r;
+        if (out.done) store_done(a, out.done, off, i, k, k >= k_done);
+        if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
+        if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
+        if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
+        ret += r;
+    };
 
-    int64_t off = i;                                         // k*N + i
-    for (int32_t k0 = 0; k0 < K; k0 += U) {
+    if constexpr (FACT) {
+        __shared__ double base_lds[((F & F_GRID) ? 3 : 2) * FACT_ROWS * PP];
+        static_assert(FACT_ROWS % U == 0, "ring slots are addressed by k % U across LDS chunks");
+        GridFactors f;
+        f.lr = 0.0; f.pr = 0.0; f.lp = 0u; f.pp = 0u; f.cp = 0u; f.pat = 0u;
+        OutageWords ow;
+        ow.cur = 0; ow.nxt = 0; ow.wi = 0;
+        RawActions<AT> ring[U];
+        if (active) {
+            load_factors<F>(a.c, i, f);
+            if constexpr (F & F_GRID) outage_init(a.c, N, i, a.T, t0, ow);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int32_t k = k0 + u;
-            if (k < K) {
-                const Inputs in = widen<F>(ring[u]);
-                if (k + U < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
-                Outputs o;
-                step_core<F>(p, d, s, in, norm, want_soc, gen_instant, o);
-                const double r = shaped_reward<F>(a.shaper, o);
-                if (out.reward) out.reward[off] = r;
-                if (out.done) out.done[off] = (uint8_t)(k >= k_done);
-                if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
-                if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
-                if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
-                ret += r;
-                off += N;
+            for (int u = 0; u < U; u++)
+                if (u < K) load_actions_at<F>(actions, (int64_t)u * N + i, ring[u]);
+        }
+        int64_t off = i;                                     // k*N + i
+        for (int32_t kb = 0; kb < K; kb += FACT_ROWS) {      // K is uniform over the launch: the barriers are safe
+            const int32_t n = K - kb < FACT_ROWS ? K - kb : FACT_ROWS;
+            __syncthreads();                                 // the previous chunk's rows have been consumed
+            stage_base_rows<F>(a.c, (int64_t)t0 + kb, n, base_lds, BLOCK_K);
+            __syncthreads();
+            if (active) {
+                BaseVals nb = read_base_row<F>(base_lds, 0, f);
+                for (int32_t k0 = kb; k0 < kb + n; k0 += U) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int32_t k = k0 + u;
+                        if (k < kb + n) {
+                            const RawActions<AT> ra = ring[u];
+                            if (k + U < K) load_actions_at<F>(actions, off + (int64_t)U * N, ring[u]);
+                            Inputs in;
+                            if constexpr (F & F_GENSET) { in.a_goal = (double)ra.a_goal; in.a_gen = (double)ra.a_gen; }
+                            if constexpr (F & F_BATTERY) in.a_bat = (double)ra.a_bat;
+                            in.load = fact_load(nb.load, f.lr);
+                            in.pv = fact_pv(nb.pv, f.pr);
+                            if constexpr (F & F_GRID) {
+                                in.a_grid = (double)ra.a_grid;
+                                in.g_pimp = tariff_price((int32_t)f.pat, t0 + k); in.g_pexp = 0.0;
+                                in.g_co2 = nb.co2;
+                                in.g_stat = outage_status(a.c, N, i, a.T, t0 + k, k == 0, ow);
+                            }
+                            const int32_t rn = (k + 1 - kb < n) ? k + 1 - kb : n - 1;      // next step's row (LDS, one step ahead)
+                            nb = read_base_row<F>(base_lds, rn, f);
+                            consume(in, k, off);
+                            off += N;
+                        }
+                    }
+                }
+            }
+        }
+        if (!active) return;                                 // (no barrier follows: advance_counter_in_kernel's is skipped
+    } else {                                                 //  by returned waves, as in the materialised form)
+        // series bases moved to row t0 once (scalar), so row k of this launch is base + k*N
+        const double *__restrict__ lts = a.c.load_ts + (int64_t)t0 * N;
+        const double *__restrict__ pts = a.c.pv_ts + (int64_t)t0 * N;
+        const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
+        RawInputs<AT> ring[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (u < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
+
+        int64_t off = i;                                         // k*N + i
+        for (int32_t k0 = 0; k0 < K; k0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int32_t k = k0 + u;
+                if (k < K) {
+                    const Inputs in = widen<F>(ring[u]);
+                    if (k + U < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
+                    consume(in, k, off);
+                    off += N;
+                }
             }
         }
     }
@@ -229,11 +396,7 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t
     Params p; State s;
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
-    if (a.obs_state_only) {
-        if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
-        else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
-    } else if (a.obs_f32) observe_row_h0<F>(a, i, t, p, s, (float *)obs + i * a.obs_dim);   // H == 0 only (host dispatches)
-    else observe_row_h0<F>(a, i, t, p, s, (double *)obs + i * a.obs_dim);
+    store_step_obs<F>(a, obs, i, t, p, s);            // whole rows for H == 0 only (the host dispatches)
 }
 
 // Observation rows for H > 0 (obs_rows_wave_kernel below).  Every cache line of obs is written whole by one wave
@@ -269,7 +432,8 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
     const int32_t W_pad = (W + slots - 1) / slots * slots;
     // wave-uniform: every slot's row exists, lane offsets fit 32-bit byte offsets
     const int32_t tr = t & a.row_mask;                  // rolling windows: the buffers are rings of row_mask + 1 rows
-    const bool fast = t >= 0 && (int64_t)t + W_pad <= a.T && (int64_t)(4 * Q + 4) * N < (int64_t(1) << 28) &&
+    const bool fact = factorised(a.c);                  // factorised series: the general form below (rows out of the caches)
+    const bool fast = !fact && t >= 0 && (int64_t)t + W_pad <= a.T && (int64_t)(4 * Q + 4) * N < (int64_t(1) << 28) &&
                       (a.row_mask == -1 || tr + W_pad <= a.row_mask + 1);               // ... and this window does not wrap
     if (fast) {
         WinBounds<1> bl, bp;
@@ -292,14 +456,32 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
                                         a.noise_seed, a.noise_increase);
             }
         }
-    } else {
-        observe_window_cols<1, NOISE, OT>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row,
-                                      a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase, a.row_mask);
-        observe_window_cols<1, NOISE, OT>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + W,
-                                      a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase, a.row_mask);
+    } else if (fact) {
+        GridFactors f;
+        load_factors<F>(a.c, ic, f);
+        const mgx_columns &c = a.c;
+        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return fact_load(c.base_load[(int64_t)r * PP + f.lp], f.lr); }, N,
+                                          a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row, a.c.load_noise_std, 0u,
+                                          a.noise_seed, a.noise_increase, a.row_mask);
+        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return fact_pv(c.base_pv[(int64_t)r * PP + f.pp], f.pr); }, N,
+                                          a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + W, a.c.pv_noise_std, 1u,
+                                          a.noise_seed, a.noise_increase, a.row_mask);
         if constexpr (F & F_GRID)
-            observe_window_cols<4, NOISE, OT>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q,
-                                          row + plan.grid_col_base, a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
+            observe_window_cols<4, NOISE, OT>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic); }, N,
+                                              a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q, row + plan.grid_col_base,
+                                              a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
+    } else {
+        const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
+        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return lts[(int64_t)r * N + ic]; }, N,
+                                          a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row, a.c.load_noise_std, 0u,
+                                          a.noise_seed, a.noise_increase, a.row_mask);
+        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return pts[(int64_t)r * N + ic]; }, N,
+                                          a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + W, a.c.pv_noise_std, 1u,
+                                          a.noise_seed, a.noise_increase, a.row_mask);
+        if constexpr (F & F_GRID)
+            observe_window_cols<4, NOISE, OT>([&](int32_t r, int cc) { return gts[((int64_t)r * 4 + cc) * N + ic]; }, N,
+                                              a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q, row + plan.grid_col_base,
+                                              a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
     }
     if (q == 0) {                                        // the 6 state columns, by the first lane of each grid
         Params p; State s;
@@ -354,8 +536,8 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
 constexpr int OBS_KJ = 2;                               // rows per thread and latency round (x 16 phases = 32 rows)
 constexpr int OBS_K_THREADS = 256;
 
-template <int NC>
-__device__ __forceinline__ void windows_k_module(const double *__restrict__ ts, int64_t N, int64_t row_stride,
+template <int NC, class Fetch>
+__device__ __forceinline__ void windows_k_module(Fetch fetch, int64_t N,
                                                  const double *__restrict__ lo_col, const double *__restrict__ hi_col,
                                                  int32_t T, int32_t t, int32_t R, int32_t K, int64_t ic, int32_t q, int32_t Q,
                                                  double *nc /* [NC][RP] of this grid */, double *nu /* [NC][K] */, int32_t RP,
@@ -378,7 +560,7 @@ __device__ __forceinline__ void windows_k_module(const double *__restrict__ ts, 
             const int32_t r = t + (rr < R ? rr : R - 1);                 // hit) instead of pulling unused rows out of HBM
             const int32_t rc = (r < T ? (r < 0 ? 0 : r) : T - 1) & row_mask;      // rolling windows: the series buffers are rings
 #pragma unroll
-            for (int c = 0; c < NC; c++) v[jj][c] = ts[(int64_t)rc * row_stride + c * N + ic];
+            for (int c = 0; c < NC; c++) v[jj][c] = fetch(rc, c);
         }
 #pragma unroll
         for (int jj = 0; jj < OBS_KJ; jj++) {
@@ -433,11 +615,27 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     double *blk = image + g * BP;
     uint32_t *map = reinterpret_cast<uint32_t *>(image + G * BP);       // [D]
 
-    windows_k_module<1>(a.c.load_ts, N, N, a.c.load_lo, a.c.load_hi, a.T, t, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
-    windows_k_module<1>(a.c.pv_ts, N, N, a.c.pv_lo, a.c.pv_hi, a.T, t, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
-    if constexpr (GRID)
-        windows_k_module<4>(a.c.grid_ts, N, 4 * N, a.c.grid_lo, a.c.grid_hi, a.T, t, R, K, ic, q, Q, blk + 2 * RP,
-                            blk + NU0 + 2 * K, RP, a.row_mask);
+    if (factorised(a.c)) {                               // uniform over the launch: rows formed from the base tables
+        GridFactors f;
+        load_factors<GRID ? F_GRID : 0>(a.c, ic, f);
+        const mgx_columns &c = a.c;
+        windows_k_module<1>([&](int32_t r, int) { return fact_load(c.base_load[(int64_t)r * PP + f.lp], f.lr); }, N,
+                            a.c.load_lo, a.c.load_hi, a.T, t, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
+        windows_k_module<1>([&](int32_t r, int) { return fact_pv(c.base_pv[(int64_t)r * PP + f.pp], f.pr); }, N,
+                            a.c.pv_lo, a.c.pv_hi, a.T, t, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
+        if constexpr (GRID)
+            windows_k_module<4>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic); }, N,
+                                a.c.grid_lo, a.c.grid_hi, a.T, t, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
+    } else {
+        const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
+        windows_k_module<1>([&](int32_t r, int) { return lts[(int64_t)r * N + ic]; }, N,
+                            a.c.load_lo, a.c.load_hi, a.T, t, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
+        windows_k_module<1>([&](int32_t r, int) { return pts[(int64_t)r * N + ic]; }, N,
+                            a.c.pv_lo, a.c.pv_hi, a.T, t, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
+        if constexpr (GRID)
+            windows_k_module<4>([&](int32_t r, int cc) { return gts[((int64_t)r * 4 + cc) * N + ic]; }, N,
+                                a.c.grid_lo, a.c.grid_hi, a.T, t, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
+    }
     if (q == 0) {                                        // state columns: the current state for block 0, zeros ahead
 #pragma unroll
         for (int j = 0; j < 6; j++) {                    // static indices: `now` stays in registers (a dynamic index put it --
@@ -536,13 +734,13 @@ __global__ __launch_bounds__(64) void patch_windows_kernel(const KArgs a, const 
         __syncthreads();                                   // the previous grid's image has been consumed
         for (int32_t idx = lane; idx < NCOMP * R; idx += 64) {
             const int comp = idx / R, r = idx - comp * R;
-            const double *ts; int64_t row_stride, off; double lo, hi;
-            if (comp == 0) { ts = a.c.load_ts; row_stride = N; off = g; lo = a.c.load_lo[g]; hi = a.c.load_hi[g]; }
-            else if (comp == 1) { ts = a.c.pv_ts; row_stride = N; off = g; lo = a.c.pv_lo[g]; hi = a.c.pv_hi[g]; }
-            else { ts = a.c.grid_ts; row_stride = 4 * N; off = (comp - 2) * N + g; lo = a.c.grid_lo[(comp - 2) * N + g]; hi = a.c.grid_hi[(comp - 2) * N + g]; }
+            double lo, hi;
+            if (comp == 0) { lo = a.c.load_lo[g]; hi = a.c.load_hi[g]; }
+            else if (comp == 1) { lo = a.c.pv_lo[g]; hi = a.c.pv_hi[g]; }
+            else { lo = a.c.grid_lo[(comp - 2) * N + g]; hi = a.c.grid_hi[(comp - 2) * N + g]; }
             const int32_t row = t + r;
             const bool in = row < a.T;
-            const double v = ts[(int64_t)((in ? row : a.T - 1) & a.row_mask) * row_stride + off];
+            const double v = series_component(a.c, N, comp, (int64_t)((in ? row : a.T - 1) & a.row_mask), g);
             const double fill = (hi + lo) / 2, sp = space_spread(lo, hi);
             nu[idx] = obs_series_value(v, in, false, lo, hi, fill, sp);
             nc[idx] = obs_series_value(v, in, true, lo, hi, fill, sp);
@@ -576,10 +774,16 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
     load_state<F>(a.c, i, false, s);
     load_params<F>(a.c, i, p);
     const int64_t tr = t & a.row_mask;
-    in.load = a.c.load_ts[tr * N + i];
-    in.pv = a.c.pv_ts[tr * N + i];
-    in.g_stat = 1.0;
-    if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[(tr * 4 + 3) * N + i];
+    if (factorised(a.c)) {
+        GridFactors f;
+        load_factors<F>(a.c, i, f);
+        fact_series<F>(a.c, N, i, tr, f, in);
+    } else {
+        in.load = a.c.load_ts[tr * N + i];
+        in.pv = a.c.pv_ts[tr * N + i];
+        in.g_stat = 1.0;
+        if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[(tr * 4 + 3) * N + i];
+    }
     double q_unused;
     populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused, 0.0 + -1 * in.load, in.pv);
     double *c = control + i * A;
@@ -617,7 +821,13 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     Params p; State s; Inputs in; Outputs o; Derived d;
     const int32_t id = action_id[i];
     const int64_t tr = t & a.row_mask;
-    load_series_at<F>(a.c.load_ts + tr * N, a.c.pv_ts + tr * N, (F & F_GRID) ? a.c.grid_ts + tr * 4 * N : nullptr, N, i, i, in);
+    if (factorised(a.c)) {
+        GridFactors f;
+        load_factors<F>(a.c, i, f);
+        fact_series<F>(a.c, N, i, tr, f, in);
+    } else {
+        load_series_at<F>(a.c.load_ts + tr * N, a.c.pv_ts + tr * N, (F & F_GRID) ? a.c.grid_ts + tr * 4 * N : nullptr, N, i, i, in);
+    }
     load_state<F>(a.c, i, log != nullptr, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
@@ -636,13 +846,7 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     reward[i] = shaped_reward<F>(a.shaper, o);
     if (done) done[i] = done_at(a, i, t);
     if (log) store_log<F>(log + i, N, o, s.status);
-    if (obs) {
-        if (a.obs_state_only) {                 // the window columns of this row were prefetched (obs_windows_k_kernel)
-            if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
-            else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
-        } else if (a.obs_f32) observe_row_h0<F>(a, i, t + 1, p, s, (float *)obs + i * a.obs_dim);
-        else observe_row_h0<F>(a, i, t + 1, p, s, (double *)obs + i * a.obs_dim);
-    }
+    if (obs) store_step_obs<F>(a, obs, i, t + 1, p, s);
 }
 
 template <int F>
@@ -767,7 +971,8 @@ __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArgs fa, c
 // (ids [K, N], one byte each: a DiscreteMicrogridEnv roll-out) or constant per grid (ids [N]: RuleBasedControl.run,
 // algos/rbc/rbc.py:64-93).  No action stream at all: per step only the series rows are read.
 // ------------------------------------------------------------------------------------------------------
-template <int F, int U, bool PER_STEP, bool RICH>
+// FACT: factorised series (mgx_columns.base_load): nothing but the id bytes (PER_STEP) is read per step.
+template <int F, int U, bool PER_STEP, bool RICH, bool FACT>
 __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const PLWords tab, const uint8_t *__restrict__ ids,
                                                           int32_t t0, int32_t K, const FusedOut out_rt, int32_t gpb)
 {
@@ -777,68 +982,142 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
     t0 = resolve_t(a, t0);
     K = resolve_k(a, t0, K);
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * gpb + threadIdx.x;
-    if ((int32_t)threadIdx.x >= gpb || i >= a.g1) return;
+    const bool active = (int32_t)threadIdx.x < gpb && i < a.g1;
+    if constexpr (!FACT) { if (!active) return; }
     const int64_t N = a.N;
     Params p; State s; Derived d;
-    load_state<F>(a.c, i, out.log != nullptr, s);
-    load_params<F>(a.c, i, p);
-    derive<F>(p, d);
-    const double *__restrict__ lts = a.c.load_ts + (int64_t)t0 * N;
-    const double *__restrict__ pts = a.c.pv_ts + (int64_t)t0 * N;
-    const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
     const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
-    const bool gen_instant = genset_wave_is_instant<F>(p, s);
-    const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
+    bool gen_instant = false;
+    int32_t k_done = 0;
     // PER_STEP = false (one fixed list per grid: RuleBasedControl): `word` is loop-invariant and the list decoding of
     // populate_core is hoisted out of the step loop by the compiler
-    uint32_t word = PER_STEP ? 0u : pl_select(tab, ids[i]);
+    uint32_t word = 0u;
+    if (active) {
+        load_state<F>(a.c, i, out.log != nullptr, s);
+        load_params<F>(a.c, i, p);
+        derive<F>(p, d);
+        gen_instant = genset_wave_is_instant<F>(p, s);
+        k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
+        word = PER_STEP ? 0u : pl_select(tab, ids[i]);
+    }
     double ret = 0.0;
 
+    // one step of this lane's grid: series values complete in `in` (GI: compile-time form of the wave-uniform gen_instant)
+    auto consume = [&](auto gi_tag, Inputs &in, int32_t k, int64_t off) __attribute__((always_inline)) {
+        constexpr bool GI = decltype(gi_tag)::value;
+        double bat_q;
+        populate_core<F>(p, s, word, in, bat_q, 0.0 + -1 * in.load, in.pv, GI);
+        Outputs o;
+        step_core<F, true>(p, d, s, in, false, want_soc, GI, o, bat_q);
+        const double r = shaped_reward<F>(a.shaper, o);
+        if (out.reward) out.reward[off] = r;
+        if (out.done) store_done(a, out.done, off, i, k, k >= k_done);
+        if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
+        if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
+        if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
+        ret += r;
+    };
     // The step loop exists twice, specialised at COMPILE time on the wave-uniform `gen_instant`: in the instant form the
     // genset's status is its goal, its limits under a fixed list are loop-invariant (hoisted), and the FSM is gone.
-    auto run = [&](auto gi_tag) __attribute__((always_inline)) {
-        constexpr bool GI = decltype(gi_tag)::value;
-        Inputs ring[U];
+    if constexpr (FACT) {
+        // the barriers of the LDS chunks stay at kernel scope (every wave of the workgroup meets the same ones); only the
+        // loop over a chunk's steps is specialised
+        __shared__ double base_lds[((F & F_GRID) ? 3 : 2) * FACT_ROWS * PP];
+        static_assert(FACT_ROWS % U == 0, "ring slots are addressed by k % U across LDS chunks");
+        GridFactors f;
+        f.lr = 0.0; f.pr = 0.0; f.lp = 0u; f.pp = 0u; f.cp = 0u; f.pat = 0u;
+        OutageWords ow;
+        ow.cur = 0; ow.nxt = 0; ow.wi = 0;
         uint8_t idr[U];
+        if (active) {
+            load_factors<F>(a.c, i, f);
+            if constexpr (F & F_GRID) outage_init(a.c, N, i, a.T, t0, ow);
+            if constexpr (PER_STEP) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            if (u < K) {
-                load_series_at<F>(lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
-                if constexpr (PER_STEP) idr[u] = ids[(int64_t)u * N + i];
+                for (int u = 0; u < U; u++)
+                    if (u < K) idr[u] = ids[(int64_t)u * N + i];
             }
-
+        }
         int64_t off = i;
-        for (int32_t k0 = 0; k0 < K; k0 += U) {
+        auto run_chunk = [&](auto gi_tag, int32_t kb, int32_t n) __attribute__((always_inline)) {
+            BaseVals nb = read_base_row<F>(base_lds, 0, f);
+            for (int32_t k0 = kb; k0 < kb + n; k0 += U) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int32_t k = k0 + u;
-                if (k < K) {
-                    Inputs in = ring[u];
-                    if constexpr (PER_STEP) word = pl_select(tab, idr[u]);
-                    if (k + U < K) {
-                        load_series_at<F>(lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
-                        if constexpr (PER_STEP) idr[u] = ids[off + (int64_t)U * N];
+                for (int u = 0; u < U; u++) {
+                    const int32_t k = k0 + u;
+                    if (k < kb + n) {
+                        if constexpr (PER_STEP) {
+                            word = pl_select(tab, idr[u]);
+                            if (k + U < K) idr[u] = ids[off + (int64_t)U * N];
+                        }
+                        Inputs in;
+                        in.load = fact_load(nb.load, f.lr);
+                        in.pv = fact_pv(nb.pv, f.pr);
+                        in.g_stat = 1.0;
+                        if constexpr (F & F_GRID) {
+                            in.g_pimp = tariff_price((int32_t)f.pat, t0 + k); in.g_pexp = 0.0;
+                            in.g_co2 = nb.co2;
+                            in.g_stat = outage_status(a.c, N, i, a.T, t0 + k, k == 0, ow);
+                        }
+                        const int32_t rn = (k + 1 - kb < n) ? k + 1 - kb : n - 1;      // next step's row (LDS, one step ahead)
+                        nb = read_base_row<F>(base_lds, rn, f);
+                        consume(gi_tag, in, k, off);
+                        off += N;
                     }
-                    double bat_q;
-                    populate_core<F>(p, s, word, in, bat_q, 0.0 + -1 * in.load, in.pv, GI);
-                    Outputs o;
-                    step_core<F, true>(p, d, s, in, false, want_soc, GI, o, bat_q);
-                    const double r = shaped_reward<F>(a.shaper, o);
-                    if (out.reward) out.reward[off] = r;
-                    if (out.done) out.done[off] = (uint8_t)(k >= k_done);
-                    if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
-                    if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
-                    if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
-                    ret += r;
-                    off += N;
+                }
+            }
+        };
+        for (int32_t kb = 0; kb < K; kb += FACT_ROWS) {          // K is uniform over the launch: the barriers are safe
+            const int32_t n = K - kb < FACT_ROWS ? K - kb : FACT_ROWS;
+            __syncthreads();                                     // the previous chunk's rows have been consumed
+            stage_base_rows<F>(a.c, (int64_t)t0 + kb, n, base_lds, BLOCK_K);
+            __syncthreads();
+            if (active) {
+                if constexpr ((F & F_GENSET) != 0) {
+                    if (gen_instant) run_chunk(std::true_type{}, kb, n); else run_chunk(std::false_type{}, kb, n);
+                } else {
+                    run_chunk(std::false_type{}, kb, n);
                 }
             }
         }
-    };
-    if constexpr ((F & F_GENSET) != 0) {
-        if (gen_instant) run(std::true_type{}); else run(std::false_type{});
+        if (!active) return;
     } else {
-        run(std::false_type{});
+        auto run = [&](auto gi_tag) __attribute__((always_inline)) {
+            const double *__restrict__ lts = a.c.load_ts + (int64_t)t0 * N;
+            const double *__restrict__ pts = a.c.pv_ts + (int64_t)t0 * N;
+            const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
+            Inputs ring[U];
+            uint8_t idr[U];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (u < K) {
+                    load_series_at<F>(lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
+                    if constexpr (PER_STEP) idr[u] = ids[(int64_t)u * N + i];
+                }
+
+            int64_t off = i;
+            for (int32_t k0 = 0; k0 < K; k0 += U) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int32_t k = k0 + u;
+                    if (k < K) {
+                        Inputs in = ring[u];
+                        if constexpr (PER_STEP) word = pl_select(tab, idr[u]);
+                        if (k + U < K) {
+                            load_series_at<F>(lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
+                            if constexpr (PER_STEP) idr[u] = ids[off + (int64_t)U * N];
+                        }
+                        consume(gi_tag, in, k, off);
+                        off += N;
+                    }
+                }
+            }
+        };
+        if constexpr ((F & F_GENSET) != 0) {
+            if (gen_instant) run(std::true_type{}); else run(std::false_type{});
+        } else {
+            run(std::false_type{});
+        }
     }
     if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
     store_state<F>(a.c, i, s);
@@ -1155,6 +1434,8 @@ struct GatherArgs {
     int32_t N, T, rows, max_length, lo, hi;
     const uint8_t *mask;      // NULL = every grid; else only grids with mask[i] != 0 (a partial reset)
     int32_t row0, row_mask;   // destination row of source row start_i + r: (row0 + r) & row_mask (linear windows: 0, -1)
+    mgx_columns fc;           // factorised source (fc.base_load != NULL): the rows are formed from the factors
+    int32_t has_grid;
     // mgx_reset_grids_random: start / length are DRAWN here (trajectory/stochastic.py:9-30 per grid) instead of read
     int32_t draw, fixed_length;
     uint64_t seed;
@@ -1209,8 +1490,10 @@ __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs 
     const int64_t N = g.N;
     const double fl = (g.load_lo && g.load_hi) ? (g.load_hi[i] + g.load_lo[i]) / 2 : 0.0;
     const double fp = (g.pv_lo && g.pv_hi) ? (g.pv_hi[i] + g.pv_lo[i]) / 2 : 0.0;
+    const bool fact = factorised(g.fc);
+    const bool has_grid = g.has_grid != 0;
     double fg[4] = {0.0, 0.0, 0.0, 0.0};
-    if (g.grid_ts && g.grid_lo && g.grid_hi) {
+    if (has_grid && g.grid_lo && g.grid_hi) {
 #pragma unroll
         for (int c = 0; c < 4; c++) fg[c] = (g.grid_hi[c * N + i] + g.grid_lo[c * N + i]) / 2;
     }
@@ -1221,10 +1504,18 @@ __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs 
         for (int u = 0; u < RB; u++) {
             const int64_t row = (int64_t)s + r0 + u;
             const int64_t rc = row < g.T ? row : (int64_t)g.T - 1;
-            vl[u] = g.load_ts[rc * N + i]; vp[u] = g.pv_ts[rc * N + i];
-            if (g.grid_ts) {
+            if (fact) {
+                vl[u] = series_component(g.fc, N, 0, rc, i); vp[u] = series_component(g.fc, N, 1, rc, i);
+                if (has_grid) {
 #pragma unroll
-                for (int c = 0; c < 4; c++) vg[u][c] = g.grid_ts[(rc * 4 + c) * N + i];
+                    for (int c = 0; c < 4; c++) vg[u][c] = series_component(g.fc, N, 2 + c, rc, i);
+                }
+            } else {
+                vl[u] = g.load_ts[rc * N + i]; vp[u] = g.pv_ts[rc * N + i];
+                if (has_grid) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) vg[u][c] = g.grid_ts[(rc * 4 + c) * N + i];
+                }
             }
         }
 #pragma unroll
@@ -1235,7 +1526,7 @@ __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs 
                 const int64_t dst = (g.row0 + r) & g.row_mask;
                 g.load_w[dst * N + i] = in ? vl[u] : fl;
                 g.pv_w[dst * N + i] = in ? vp[u] : fp;
-                if (g.grid_ts) {
+                if (has_grid) {
 #pragma unroll
                     for (int c = 0; c < 4; c++) g.grid_w[(dst * 4 + c) * N + i] = in ? vg[u][c] : fg[c];
                 }
@@ -1257,51 +1548,109 @@ __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs 
 // index, row), so a shard's draw does not depend on how the batch is split over ranks.
 // ------------------------------------------------------------------------------------------------------
 
-// MicrogridGenerator._get_electricity_tariff (:253-285)
-__device__ __forceinline__ double tariff_price(int32_t pattern, int32_t row)
-{
-    const int32_t h = row % 24;
-    if (pattern == 1) return (h >= 12 && h < 18) ? 0.59 : ((h < 8 || h >= 21) ? 0.22 : 0.29);
-    if (pattern == 2) return ((h >= 0 && h < 5) || (h >= 14 && h < 17)) ? 0.08 : 0.11;
-    return 0.0;
-}
-
 __global__ __launch_bounds__(BLOCK) void synthesize_series_kernel(const mgx_synth a)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.n_grids) return;
     const int64_t N = a.n_grids;
     const int32_t T = a.n_steps;
-    const int32_t lp = a.load_profile[i], pp = a.pv_profile[i];
-    const double lr = a.load_ratio[i], pr = a.pv_ratio[i];
+    const bool series = a.load_ts != nullptr;              // load / pv rows wanted (else: only the outage words)
+    int32_t lp = 0, pp = 0;
+    double lr = 0.0, pr = 0.0;
+    if (series) { lp = a.load_profile[i]; pp = a.pv_profile[i]; lr = a.load_ratio[i]; pr = a.pv_ratio[i]; }
     const bool grid = a.grid_ts != nullptr;
     int32_t cp = 0, pat = 0, dur = 1;
     double prob = 0.0;
-    if (grid) {
-        cp = a.co2_profile[i]; pat = a.tariff[i];
-        prob = a.outage_per_day ? a.outage_per_day[i] / 24 : 0.0;           // weak_grid_timeseries[i] < outage_per_day/24 (:332)
+    if (grid) { cp = a.co2_profile[i]; pat = a.tariff[i]; }
+    const bool weak = (grid || a.outage_bits != nullptr) && a.outage_per_day != nullptr && a.weak[i] != 0;
+    if (weak) {
+        prob = a.outage_per_day[i] / 24;                                        // weak_grid_timeseries[i] < outage_per_day/24 (:332)
         dur = a.outage_duration ? a.outage_duration[i] : 1;
     }
-    const bool weak = grid && a.outage_per_day != nullptr && a.weak[i] != 0;
     const int64_t gi = a.grid_index ? a.grid_index[i] : a.grid_index0 + i;      // the Philox counter: GLOBAL grid index
     // rows still covered by an outage that starts later: the extra draw of row T (the reference draws T + 1 values) first
     int32_t cover = 0;
     if (weak && synth_uniform(a.seed, gi, T) < prob) cover = dur - 1;
+    uint64_t word = 0;                                                          // outage bits of rows [64 w, 64 w + 64)
     for (int32_t t = T - 1; t >= 0; t--) {
-        a.load_ts[(int64_t)t * N + i] = -1.0 * fabs(a.base_load[(int64_t)t * a.n_load_profiles + lp] * lr);   // stored sign
-        a.pv_ts[(int64_t)t * N + i] = fabs(a.base_pv[(int64_t)t * a.n_pv_profiles + pp] * pr);
+        if (series) {
+            a.load_ts[(int64_t)t * N + i] = -1.0 * fabs(a.base_load[(int64_t)t * a.n_load_profiles + lp] * lr);   // stored sign
+            a.pv_ts[(int64_t)t * N + i] = fabs(a.base_pv[(int64_t)t * a.n_pv_profiles + pp] * pr);
+        }
+        double status = 1.0;
+        if (weak) {
+            const bool own = synth_uniform(a.seed, gi, t) < prob;
+            status = (own || (cover > 0 && t > 0)) ? 0.0 : 1.0;                 // "if i-j > 0": the back-fill spares row 0
+            cover = own ? dur - 1 : (cover > 0 ? cover - 1 : 0);
+        }
         if (grid) {
-            double status = 1.0;
-            if (weak) {
-                const bool own = synth_uniform(a.seed, gi, t) < prob;
-                status = (own || (cover > 0 && t > 0)) ? 0.0 : 1.0;             // "if i-j > 0": the back-fill spares row 0
-                cover = own ? dur - 1 : (cover > 0 ? cover - 1 : 0);
-            }
             double *g = a.grid_ts + (int64_t)t * 4 * N + i;
             g[0] = tariff_price(pat, t);
             g[N] = 0.0;                                                       // price_export = zeros (:264)
             g[2 * N] = a.base_co2[(int64_t)t * a.n_co2_profiles + cp];
             g[3 * N] = status;
+        }
+        if (a.outage_bits) {
+            word |= (status == 0.0 ? 1ull : 0ull) << (t & 63);
+            if ((t & 63) == 0) { a.outage_bits[(int64_t)(t >> 6) * N + i] = word; word = 0; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The zero-copy observation contract (mgx_normalise_series): the series normalised ONCE, grid-major, so that the window
+// columns of grid i at step t are the contiguous slice n[i, t : t + 1 + H] -- a strided view instead of D values rewritten
+// per step.  A [T, N] -> [N, R] transpose: a workgroup owns 64 grids x TR rows; wave w reads rows w, w + 4, ... (lane =
+// grid: one 512-byte segment), the normalised values cross an LDS tile (pitch 65: conflict-free both ways), and the
+// workgroup writes TR * NC consecutive values per grid (lane = position along the row).  Rows >= T hold the forecaster's
+// padding value.  Values outside [lo, hi] (where the reference's forecast clip would bite) are counted in `clipped`.
+// ------------------------------------------------------------------------------------------------------
+template <int NC, typename OT>
+__global__ __launch_bounds__(256) void normalise_series_kernel(const KArgs a, int which /* 0 load, 1 pv, 2 grid */,
+                                                               OT *__restrict__ out, int32_t R, int32_t TR,
+                                                               int32_t *__restrict__ clipped)
+{
+    extern __shared__ double ntile[];                   // [NC][TR][65]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t N = a.N;
+    const int64_t g0 = (int64_t)blockIdx.x * 64;
+    const int32_t r0 = (int32_t)blockIdx.y * TR;
+    const int64_t i = g0 + lane, ic = i < N ? i : N - 1;
+    const double *lo_col = which == 0 ? a.c.load_lo : (which == 1 ? a.c.pv_lo : a.c.grid_lo);
+    const double *hi_col = which == 0 ? a.c.load_hi : (which == 1 ? a.c.pv_hi : a.c.grid_hi);
+    double lo[NC], hi[NC], sp[NC], zf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        lo[c] = lo_col[c * N + ic]; hi[c] = hi_col[c * N + ic];
+        sp[c] = space_spread(lo[c], hi[c]);
+        zf[c] = ((hi[c] + lo[c]) / 2 - lo[c]) / sp[c];                     // a row beyond the series (forecaster.py:95,120-137)
+    }
+    int32_t n_clip = 0;
+    const int comp0 = which == 2 ? 2 : which;
+    for (int32_t rr = wave; rr < TR; rr += 4) {
+        const int32_t row = r0 + rr;
+        if (row >= R) break;
+        const bool in = row < a.T;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            double z = zf[c];
+            if (in) {
+                const double x = series_component(a.c, N, comp0 + c, (int64_t)(row & a.row_mask), ic);
+                n_clip += (x < lo[c] || x > hi[c]) ? 1 : 0;
+                z = (x - lo[c]) / sp[c];
+            }
+            ntile[(c * TR + rr) * 65 + lane] = z;
+        }
+    }
+    if (clipped && n_clip && i < N) atomicAdd(clipped, n_clip);
+    __syncthreads();
+    const int32_t rows = (R - r0 < TR) ? R - r0 : TR;
+    const int32_t per_grid = rows * NC;                  // consecutive output values of one grid in this tile
+    for (int32_t g = wave; g < 64 && g0 + g < N; g += 4) {
+        OT *dst = out + ((g0 + g) * (int64_t)R + r0) * NC;
+        for (int32_t e = lane; e < per_grid; e += 64) {
+            const int32_t rr = e / NC, c = e - rr * NC;
+            dst[e] = (OT)ntile[(c * TR + rr) * 65 + g];
         }
     }
 }

@@ -43,6 +43,10 @@ class StepEngine:
         self.window = (self.layout.initial_step, self.layout.final_step)
         self._full_window = self.window
         self._window_start = None
+        self._window_t0 = None          # rolling windows: counter value each grid's episode started at
+        self._obs_compact = False
+        self._done_bits = False
+        self._dev_counter = False
         self.n_shards = 1
         if batch.forecast_noise is not None:
             self.set_forecast_noise(**batch.forecast_noise)
@@ -110,6 +114,66 @@ class StepEngine:
         """True: the ``obs`` output of step / step_discrete / observe / reset receives only the genset / battery state
         columns -- the window columns of that row were written ahead of time by ``observe_windows``."""
         check(self._lib.mgx_set_obs_mode(self._h, 1 if flag else 0))
+        self._obs_compact = False
+
+    def set_obs_compact(self, flag):
+        """True (``MGX_OBS_ROWS_STATE_COMPACT``): the ``obs`` output of step / step_discrete / observe receives ONLY the
+        genset / battery state columns, as a dense [N, S] array (S = ``state_dim``) -- the zero-copy observation contract:
+        the window columns are views of ``normalise_series()``'s output."""
+        check(self._lib.mgx_set_obs_mode(self._h, 2 if flag else 0))
+        self._obs_compact = bool(flag)
+
+    @property
+    def state_dim(self):
+        return 4 * int(self.layout.has_genset) + 2 * int(self.layout.has_battery)
+
+    def set_done_format(self, bits):
+        """``mgx_set_done_format``: the ``done`` output of the fused calls as bytes [K, N] (default) or, ``bits=True``, as
+        bit sets [K, ceil(N / 16)] uint16 (``unpack_done_bits`` turns them back into [K, N] bools)."""
+        check(self._lib.mgx_set_done_format(self._h, 1 if bits else 0))
+        self._done_bits = bool(bits)
+
+    def unpack_done_bits(self, words):
+        """[K, ceil(N / 16)] int16 words of a fused call with ``set_done_format(True)`` -> [K, N] bool."""
+        K = words.shape[0]
+        sh = torch.arange(16, device=words.device, dtype=torch.int32)
+        bits = (words.to(torch.int32)[:, :, None] >> sh) & 1
+        return bits.reshape(K, -1)[:, :self.N].to(torch.bool)
+
+    def done_steps(self, K):
+        """Lock-step ``done`` of the NEXT K steps without a byte of device traffic: done(k) = (t + k >= final_step - 1) for
+        every grid (base_timeseries_module.py:124-125) -- a [K, N] bool VIEW (stride 0 along the grids) of a K-vector.
+        Not available during per-grid-window episodes (every grid ends on its own: ask the kernel, ``done=True``)."""
+        if getattr(self, "_window_start", None) is not None:
+            raise RuntimeError("per-grid episodes end per grid: request the kernel's done output")
+        t = self.current_step
+        d = torch.arange(t, t + int(K), device=self.device) >= (self.window[1] - 1)
+        return d[:, None].expand(int(K), self.N)
+
+    def normalise_series(self):
+        """``mgx_normalise_series``: the series normalised ONCE, grid-major -- {"load": [N, R], "pv": [N, R],
+        "grid": [N, R, 4]} (R = n_steps + horizon, dtype = the engine's obs dtype) -- so that the window columns of the
+        observation at step t are the slices ``load[:, t : t + 1 + H]`` etc. (views, no bytes moved per step).  Raises if a bound
+        column does not bound its series (the reference's forecast clip would then not be the identity)."""
+        L = self.layout
+        if getattr(self, "_window_t0", None) is not None:
+            raise _lib.MgxError(_lib.MGX_ERR_UNSUPPORTED, "normalise_series: not offered for rolling windows")
+        # rows of the series the handle currently steps over: the window buffers during a per-grid-window episode
+        T = self._windows["rows"] if getattr(self, "_window_start", None) is not None else L.n_steps
+        R = T + L.horizon
+        out = {"load": torch.empty(self.N, R, dtype=self.obs_dtype, device=self.device),
+               "pv": torch.empty(self.N, R, dtype=self.obs_dtype, device=self.device)}
+        if L.has_grid:
+            out["grid"] = torch.empty(self.N, R, 4, dtype=self.obs_dtype, device=self.device)
+        clipped = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._call(self._lib.mgx_normalise_series, out["load"].data_ptr(), out["pv"].data_ptr(), _ptr(out.get("grid")),
+                   clipped.data_ptr())
+        n = int(clipped.item())
+        if n:
+            raise _lib.MgxError(_lib.MGX_ERR_UNSUPPORTED,
+                                f"{n} series values lie outside their observation bounds: the forecast clip "
+                                f"(forecaster.py:139-149) is not the identity and windows are not slices of one normalised series")
+        return out
 
     def set_ring_pitch(self, rows):
         """Rows between consecutive blocks of the observation rings (``mgx_set_ring_pitch``; default N = dense rings)."""
@@ -156,11 +220,12 @@ class StepEngine:
         self._call(self._lib.mgx_prefetch_wait)
 
     def _obs_buf(self, out):
+        D = self.state_dim if getattr(self, "_obs_compact", False) else self.obs_dim
         if out is None:
-            return torch.empty((self.N, self.obs_dim), dtype=self.obs_dtype, device=self.device)
-        if tuple(out.shape) != (self.N, self.obs_dim) or out.dtype != self.obs_dtype or not out.is_contiguous() \
+            return torch.empty((self.N, D), dtype=self.obs_dtype, device=self.device)
+        if tuple(out.shape) != (self.N, D) or out.dtype != self.obs_dtype or not out.is_contiguous() \
                 or out.device != self.device:
-            raise ValueError(f"obs must be a contiguous {self.obs_dtype} tensor of shape ({self.N}, {self.obs_dim}) "
+            raise ValueError(f"obs must be a contiguous {self.obs_dtype} tensor of shape ({self.N}, {D}) "
                              f"on {self.device}")
         return out
 
@@ -185,6 +250,7 @@ class StepEngine:
         """Keep the step counter on the device so that step calls can be captured in a HIP graph
         (``torch.cuda.graph``) and replayed; see ``mgx_use_device_counter`` in include/mgx.h."""
         self._call(self._lib.mgx_use_device_counter, 1 if enable else 0)
+        self._dev_counter = bool(enable)
 
     def set_window(self, initial_step, final_step):
         """Episode window of the next reset (what a trajectory_func returns, microgrid.py:221-225)."""
@@ -209,7 +275,33 @@ class StepEngine:
             self.window = self._full_window
         return obs
 
-    def reset_windows(self, start, length=None, max_length=None, want_obs=True, out=None):
+    def _check_episodes(self, start, length, max_length, mask=None):
+        """The reference refuses a trajectory outside the env's window (Microgrid._check_trajectory_func, microgrid.py:181-203:
+        ValueError); the kernels clamp instead, which would leave ``current_steps`` at odds with the rows actually walked.
+        Validate on the host (one device->host sync per call)."""
+        lo, hi = self._full_window
+        if int(max_length) > hi - lo:
+            return                       # the C ABI refuses this with the reference's own message
+        st = start if mask is None else start[mask.view(torch.bool)]
+        if st.numel() == 0:
+            return
+        s_min, s_max = int(st.min().item()), int(st.max().item())
+        if s_min < lo:
+            raise ValueError(f'trajectory_func returned initial_step value ({s_min}) less than env\'s initial step: ({lo})')
+        if s_max >= hi:
+            raise ValueError(f'trajectory_func returned values ({s_max}, ...) such that initial_step was greater than or equal to '
+                             f'the env\'s final step ({hi}).')
+        ln = None if length is None else (length if mask is None else length[mask.view(torch.bool)])
+        if ln is not None:
+            if int(ln.min().item()) < 1:
+                raise ValueError('trajectory_func returned values such that initial_step was greater than or equal to final_step.')
+            end = int((st.long() + ln.long()).max().item())
+        else:
+            end = s_max + int(max_length)
+        if end > hi:
+            raise ValueError(f'trajectory_func returned final_step value ({end}) greater than env\'s final step: ({hi})')
+
+    def reset_windows(self, start, length=None, max_length=None, want_obs=True, out=None, validate=True):
         """Per-grid episodes (``mgx_reset_windows``): grid i starts at series row ``start[i]`` and reports ``done`` after
         ``length[i]`` steps (``length=None``: ``max_length`` for every grid).  ``start`` / ``length`` are int32 device
         tensors [N].  The window buffers live in the engine and are re-used by the next reset of the same shape."""
@@ -223,6 +315,8 @@ class StepEngine:
                 max_length = int(length.max().item())
         if max_length is None:
             raise ValueError("max_length is required when length is None")
+        if validate:
+            self._check_episodes(start, length, max_length)
         rows = int(max_length) + L.horizon + 1
         w = getattr(self, "_windows", None)
         if w is None or w["rows"] != rows:
@@ -238,7 +332,7 @@ class StepEngine:
         self.window = (0, int(max_length))
         return obs
 
-    def reset_windows_rolling(self, start, length=None, max_length=None, want_obs=True, out=None):
+    def reset_windows_rolling(self, start, length=None, max_length=None, want_obs=True, out=None, validate=True):
         """Rolling per-grid windows (``mgx_reset_windows_rolling``): as ``reset_windows``, but the window buffers are rings
         (2^p rows >= max_length + horizon + 1), the shared counter never ends, and ``reset_grids`` restarts individual grids
         at any later step.  Single steps only."""
@@ -249,6 +343,8 @@ class StepEngine:
             raise ValueError(f"length must be an int32 tensor of shape ({self.N},) on {self.device}")
         if max_length is None:
             raise ValueError("max_length is required (the longest episode any later reset_grids may ask for)")
+        if validate:
+            self._check_episodes(start, length, max_length)
         need = int(max_length) + L.horizon + 1
         rows = 1 << (need - 1).bit_length()
         w = getattr(self, "_rolling", None)
@@ -265,7 +361,7 @@ class StepEngine:
         self._rolling_max = int(max_length)
         return obs
 
-    def reset_grids(self, mask, start, length=None):
+    def reset_grids(self, mask, start, length=None, validate=True):
         """Restart the grids with ``mask[i] != 0`` at the current step (``mgx_reset_grids``): new start rows / lengths for
         them, everything else keeps running.  ``mask`` uint8 / bool [N], ``start`` / ``length`` int32 [N] on the device."""
         if mask.dtype == torch.bool:
@@ -273,6 +369,10 @@ class StepEngine:
         for name, t, dt in (("mask", mask, torch.uint8), ("start", start, torch.int32), ("length", length, torch.int32)):
             if t is not None and (t.dtype != dt or tuple(t.shape) != (self.N,) or t.device != self.device or not t.is_contiguous()):
                 raise ValueError(f"{name} must be a contiguous {dt} tensor of shape ({self.N},) on {self.device}")
+        if self._window_t0 is None:
+            raise _lib.MgxError(_lib.MGX_ERR_INVALID, "reset_grids: the engine is not in rolling-window mode")
+        if validate:
+            self._check_episodes(start, length, self._rolling_max, mask=mask)
         self._call(self._lib.mgx_reset_grids, mask.data_ptr(), start.data_ptr(), _ptr(length))
         m = mask.view(torch.bool)
         self._window_start = torch.where(m, start, self._window_start)
@@ -329,6 +429,8 @@ class StepEngine:
         out = out or {}
         reward = out.get("reward") if out.get("reward") is not None else self._empty(K, self.N)
         d = (out.get("done") if out.get("done") is not None else self._empty(K, self.N, dtype=torch.uint8)) if done else None
+        if want_obs and getattr(self, "_obs_compact", False):
+            raise ValueError("step_many writes whole rows per step: not offered with compact state rows")
         obs = (out.get("obs") if out.get("obs") is not None
                else torch.empty((K, self.N, self.obs_dim), dtype=self.obs_dtype, device=self.device)) if want_obs else None
         log = (out.get("log") if out.get("log") is not None else self._empty(K, self.log_dim, self.N)) if want_log else None
@@ -341,23 +443,26 @@ class StepEngine:
         self._call(self._lib.mgx_observe, _ptr(obs))
         return obs
 
-    def step(self, actions, normalized=True, want_obs=True, want_log=False, out=None):
+    def step(self, actions, normalized=True, want_obs=True, want_log=False, out=None, want_done=True):
         """One Microgrid.run for every grid.  Returns (obs|None, reward, done, log|None); ``out`` may hold
-        preallocated ``obs`` / ``reward`` / ``done`` / ``log`` tensors."""
+        preallocated ``obs`` / ``reward`` / ``done`` / ``log`` tensors.  ``want_done=False``: no per-grid done bytes are
+        written (in lock-step `done` is the same for every grid: ``done_steps``)."""
         actions = self._check_actions(actions, ())
         reward = done = obs = log = None
         if out:
             reward, done, obs, log = out.get("reward"), out.get("done"), out.get("obs"), out.get("log")
         if reward is None:
             reward = self._empty(self.N)
-        if done is None:
+        if not want_done:
+            done = None
+        elif done is None:
             done = self._empty(self.N, dtype=torch.uint8)
         obs = self._obs_buf(obs) if want_obs else None
         if not want_log:
             log = None
         elif log is None:
             log = self._empty(self.log_dim, self.N)
-        self._call(self._lib.mgx_step, _ptr(actions), 1 if normalized else 0, reward.data_ptr(), done.data_ptr(),
+        self._call(self._lib.mgx_step, _ptr(actions), 1 if normalized else 0, reward.data_ptr(), _ptr(done),
                    _ptr(obs), _ptr(log))
         return obs, reward, done, log
 
@@ -378,7 +483,10 @@ class StepEngine:
             res[name] = t
             return t
         r = buf("reward", reward, K, self.N)
-        d = buf("done", done, K, self.N, dtype=torch.uint8)
+        if getattr(self, "_done_bits", False):
+            d = buf("done", done, K, (self.N + 15) // 16, dtype=torch.int16)
+        else:
+            d = buf("done", done, K, self.N, dtype=torch.uint8)
         s = buf("soc_trace", soc_trace and self.layout.has_battery, K, self.N)
         g = buf("status_trace", status_trace and self.layout.has_genset, K, self.N, dtype=torch.int32)
         lg = buf("log", log, K, self.log_dim, self.N)
@@ -400,7 +508,7 @@ class StepEngine:
         self._table_cache = (table, arr, arr.ctypes.data_as(_lib.c_i32_p), arr.shape[0])
         return self._table_cache[2], self._table_cache[3]
 
-    def step_discrete(self, action_id, table, want_obs=True, want_log=False, want_control=False, out=None):
+    def step_discrete(self, action_id, table, want_obs=True, want_log=False, want_control=False, out=None, want_done=True):
         """DiscreteMicrogridEnv.step for every grid in one launch: priority-list ids [N] (int32) are expanded and
         stepped in-kernel.  Returns (obs|None, reward, done, log|None, control|None)."""
         if action_id.dtype != torch.int32 or tuple(action_id.shape) != (self.N,) or action_id.device != self.device:
@@ -408,13 +516,13 @@ class StepEngine:
         tptr, n_lists = self._table_ptr(table)
         out = out or {}
         reward = out.get("reward") if out.get("reward") is not None else self._empty(self.N)
-        done = out.get("done") if out.get("done") is not None else self._empty(self.N, dtype=torch.uint8)
+        done = (out.get("done") if out.get("done") is not None else self._empty(self.N, dtype=torch.uint8)) if want_done else None
         obs = self._obs_buf(out.get("obs")) if want_obs else None
         log = (out.get("log") if out.get("log") is not None else self._empty(self.log_dim, self.N)) if want_log else None
         control = (out.get("control") if out.get("control") is not None
                    else self._empty(self.N, self.action_dim)) if want_control else None
         self._call(self._lib.mgx_step_discrete, _ptr(action_id), tptr, n_lists,
-                   _ptr(control), reward.data_ptr(), done.data_ptr(), _ptr(obs), _ptr(log))
+                   _ptr(control), reward.data_ptr(), _ptr(done), _ptr(obs), _ptr(log))
         return obs, reward, done, log, control
 
     def rollout_discrete(self, action_id, table, K, reward=True, done=False, soc_trace=False, status_trace=False,
@@ -439,7 +547,10 @@ class StepEngine:
             res[name] = t
             return t
         r = buf("reward", reward, K, self.N)
-        d = buf("done", done, K, self.N, dtype=torch.uint8)
+        if getattr(self, "_done_bits", False):
+            d = buf("done", done, K, (self.N + 15) // 16, dtype=torch.int16)
+        else:
+            d = buf("done", done, K, self.N, dtype=torch.uint8)
         s = buf("soc_trace", soc_trace and self.layout.has_battery, K, self.N)
         g = buf("status_trace", status_trace and self.layout.has_genset, K, self.N, dtype=torch.int32)
         lg = buf("log", log, K, self.log_dim, self.N)

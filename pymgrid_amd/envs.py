@@ -28,16 +28,71 @@ from .spaces import Box, Discrete
 from .trajectory import check_trajectory_output, shaper_kind
 
 
+class ObsViews:
+    """The observation of N microgrids at one step as VIEWS (the zero-copy contract of ``obs_views=True``).
+
+    With the oracle forecaster the window columns of the reference's observation at step t are ``norm[t : t + 1 + H]`` of
+    the series normalised once (base_timeseries_module.py:103-140,162-170; forecaster.py:120-149; space.py:207-218), so the
+    env keeps one grid-major normalised copy (``engine.normalise_series``) and an observation is
+
+      ``load`` [N, 1 + H], ``pv`` [N, 1 + H], ``grid`` [N, 4 (1 + H)] (component-minor, the reference's order)
+                                          strided views into that copy -- no bytes move per step;
+      ``state`` [N, S]                    the genset (4) / battery (2) columns the step kernel wrote (48 B per grid).
+
+    ``genset`` / ``battery`` slice ``state``; ``nested()`` is the reference's ``{module: array}`` shape; ``flat()``
+    concatenates everything into the [N, D] row of the rows contract (a copy: for checks, or consumers that insist on rows).
+    Valid until the env has taken ``BatchedMicrogridEnv.VIEW_BUFFERS - 1`` further steps (the state buffers rotate)."""
+    __slots__ = ("_norm", "t", "W", "state", "layout")
+
+    def __init__(self, norm, t, W, state, layout):
+        self._norm, self.t, self.W, self.state, self.layout = norm, t, W, state, layout
+
+    @property
+    def load(self):
+        return self._norm["load"].narrow(1, self.t, self.W)
+
+    @property
+    def pv(self):
+        return self._norm["pv"].narrow(1, self.t, self.W)
+
+    @property
+    def grid(self):
+        g = self._norm.get("grid")
+        return None if g is None else g.narrow(1, self.t, self.W).flatten(1)      # [N, W, 4] slice -> [N, 4 W] view
+
+    @property
+    def genset(self):
+        return self.state[:, :4] if self.layout.has_genset else None
+
+    @property
+    def battery(self):
+        k = 4 * int(self.layout.has_genset)
+        return self.state[:, k:k + 2] if self.layout.has_battery else None
+
+    def nested(self):
+        out = {"load": self.load, "pv": self.pv}
+        for name in ("genset", "battery", "grid"):
+            v = getattr(self, name)
+            if v is not None:
+                out[name] = v
+        return out
+
+    def flat(self):
+        parts = [self.load, self.pv] + [v for v in (self.genset, self.battery, self.grid) if v is not None]
+        return torch.cat(parts, dim=1)
+
+
 class BatchedMicrogridEnv:
     """``BaseMicrogridEnv`` for N microgrids advancing in lock-step (continuous control surface =
     ``Microgrid.run(control, normalized)``; the reference's own ContinuousMicrogridEnv is non-functional in
     v1.2.2)."""
 
     DEFAULT_OBS_PREFETCH = 16
+    VIEW_BUFFERS = 4
 
     def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
                  raise_errors=False, observation_keys=None, obs_dtype=torch.float64, obs_prefetch=None,
-                 action_dtype=torch.float64):
+                 action_dtype=torch.float64, obs_views=False):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
         # raise_errors=True (base_module.py:79-93): every step is preceded by its dry run (mgx_check_step: the violations
@@ -62,6 +117,15 @@ class BatchedMicrogridEnv:
             esz = 4 if obs_dtype == torch.float32 else 8
             while obs_prefetch > 4 and 3 * obs_prefetch * L.n_grids * L.obs_dim * esz > (16 << 30):
                 obs_prefetch //= 2
+        # obs_views=True: the zero-copy observation contract (ObsViews): reset() / step() return views into a normalised copy
+        # of the series written ONCE + the 6 state columns of the step -- instead of D values rewritten per grid and step (at
+        # H = 24 a row repeats 24 / 25 of the previous one).  Same values as the rows (tests/test_factorised.py).
+        self._views = bool(obs_views)
+        if self._views:
+            if not observations or L.multi or noisy or observation_keys:
+                raise ValueError("obs_views needs observations=True, one module of every kind per grid, the oracle forecaster "
+                                 "and no observation_keys")
+            obs_prefetch = 0
         self._prefetch_ok = bool(observations and L.horizon > 0 and not L.multi and not noisy)
         self._obs_dtype = obs_dtype
         self.obs_prefetch = int(obs_prefetch) if (obs_prefetch and int(obs_prefetch) > 1 and self._prefetch_ok) else 0
@@ -76,7 +140,20 @@ class BatchedMicrogridEnv:
             self.engine.set_obs_state_only(True)
         # True inside a fused BucketedFleet: the next ring is written in K - 1 chunks that ride along with the fleet's step
         # launches (mgx_fleet_item.refill_chunk), not by this env's prefetch stream; such an env is stepped by its fleet only
+        self._norm = self._state_bufs = None
+        self._state_pos = 0
+        if self._views:
+            self.engine.set_obs_compact(True)
+            self._norm = self.engine.normalise_series()
+            self._state_bufs = torch.empty(self.VIEW_BUFFERS, L.n_grids, self.engine.state_dim, dtype=obs_dtype,
+                                           device=batch.device)
+        # lock-step `done` is the same for every grid (base_timeseries_module.py:124-125): two constant tensors, no bytes per step
+        self._done_const = (torch.zeros(L.n_grids, dtype=torch.bool, device=batch.device),
+                            torch.ones(L.n_grids, dtype=torch.bool, device=batch.device))
         self._chunked = False
+        # True for every env of a fused BucketedFleet: the fleet's cached step plans hold this env's ring pointers and walk its
+        # rings themselves, so the env refuses what would invalidate them (rolling windows, ring re-allocation)
+        self._fleet_owned = False
         # True during rolling per-grid windows: restarted grids are patched into the rings (mgx_patch_windows) -- into the
         # current ring at once, into a ring prefetched ahead when the counter reaches it (every grid that restarted since that
         # prefetch was launched: _restart_acc)
@@ -149,12 +226,24 @@ class BatchedMicrogridEnv:
         if self.trajectory_func is not None and initial_step is None:
             self._draw_window()
         self._sync_rings = False
+        if self._views:
+            if self.engine._window_start is not None:          # back from a per-grid-window episode: the full series again
+                self.engine.reset(initial_step, want_obs=False)
+                self._norm = None
+                self._norm = self.engine.normalise_series()
+            self._state_pos = 0
+            self.engine.reset(initial_step, want_obs=True, out=self._state_bufs[0])
+            return self._view_now()
         if self._ring is not None:
             self.engine.reset(initial_step, want_obs=False)
             return self._select_obs(self._refill())
         return self._select_obs(self.engine.reset(initial_step, want_obs=self._observations))
 
-    def reset_windows(self, start, length=None, max_length=None, rolling=False):
+    def _view_now(self):
+        return ObsViews(self._norm, self.engine.current_step, 1 + self.layout.horizon, self._state_bufs[self._state_pos],
+                        self.layout)
+
+    def reset_windows(self, start, length=None, max_length=None, rolling=False, validate=True):
         """Per-grid episodes (``mgx_reset_windows``; the reference's per-microgrid trajectories, microgrid.py:205-225,
         trajectory/stochastic.py:9-30): grid i starts at series row ``start[i]`` and is ``done`` after ``length[i]`` steps
         (``length=None``: ``max_length`` steps for every grid).  The batch still advances in lock-step; ``current_steps``
@@ -174,23 +263,34 @@ class BatchedMicrogridEnv:
         self._log_rows = []
         self._shaped_rows = []
         if rolling:
-            if self._chunked:
+            if self._views:
+                raise RuntimeError("obs_views: not offered for rolling windows (restarts rewrite series rows)")
+            if self._chunked or self._fleet_owned:
                 raise RuntimeError("this env belongs to a fused BucketedFleet: rolling windows are not offered there")
             if max_length is None:
+                if length is None:
+                    raise ValueError("rolling windows need max_length (or per-grid lengths to take it from)")
                 max_length = int(length.max().item())
             if self._ring is not None:               # rings stay: refilled on this stream, restarted grids patched in
                 self.engine.prefetch_wait()
                 self._sync_rings = True
-                self.engine.reset_windows_rolling(start, length, max_length, want_obs=False)
+                self.engine.reset_windows_rolling(start, length, max_length, want_obs=False, validate=validate)
                 return self._select_obs(self._refill())
-            return self._select_obs(self.engine.reset_windows_rolling(start, length, max_length, want_obs=self._observations))
+            return self._select_obs(self.engine.reset_windows_rolling(start, length, max_length, want_obs=self._observations,
+                                                                      validate=validate))
         self._sync_rings = False
+        if self._views:                                # the episode's window buffers are the series now: normalise THEM
+            self._state_pos = 0
+            self._norm = None
+            self.engine.reset_windows(start, length, max_length, want_obs=True, out=self._state_bufs[0], validate=validate)
+            self._norm = self.engine.normalise_series()
+            return self._view_now()
         if self._ring is not None:
-            self.engine.reset_windows(start, length, max_length, want_obs=False)
+            self.engine.reset_windows(start, length, max_length, want_obs=False, validate=validate)
             return self._select_obs(self._refill())
-        return self._select_obs(self.engine.reset_windows(start, length, max_length, want_obs=self._observations))
+        return self._select_obs(self.engine.reset_windows(start, length, max_length, want_obs=self._observations, validate=validate))
 
-    def reset_grids(self, mask, start, length=None, want_obs=True):
+    def reset_grids(self, mask, start, length=None, want_obs=True, validate=True):
         """Restart the grids with ``mask[i]`` set at the current step (rolling windows only; ``mgx_reset_grids``): each gets
         the episode ``start[i]`` / ``length[i]`` (``Microgrid.reset`` of just those microgrids: counters move, dynamic state
         stays).  Returns the observation rows of ALL grids at the current step (new episodes for the restarted ones)."""
@@ -201,7 +301,7 @@ class BatchedMicrogridEnv:
                 return v
             return torch.as_tensor(np.asarray(v.cpu() if torch.is_tensor(v) else v), device=dev).to(dt).contiguous()
         mask = as_t(mask, torch.uint8)
-        self.engine.reset_grids(mask, as_t(start, torch.int32), as_t(length, torch.int32))
+        self.engine.reset_grids(mask, as_t(start, torch.int32), as_t(length, torch.int32), validate=validate)
         return self._rows_after_restart(mask, want_obs)
 
     def _rows_after_restart(self, mask, want_obs):
@@ -252,8 +352,9 @@ class BatchedMicrogridEnv:
         K = int(K) if (K and int(K) > 1 and self._prefetch_ok) else 0
         if K == self.obs_prefetch:
             return
-        if self._chunked and K != self.obs_prefetch:
-            raise RuntimeError("this env belongs to a fused BucketedFleet: its ring depth is fixed")
+        if (self._chunked or self._fleet_owned) and K != self.obs_prefetch:
+            raise RuntimeError("this env belongs to a fused BucketedFleet (its step plans hold the ring pointers): the ring "
+                               "depth is fixed; build the fleet with the obs_prefetch you want")
         self.obs_prefetch = K
         L = self.layout
         if self._rings is not None:
@@ -298,6 +399,8 @@ class BatchedMicrogridEnv:
         """Where the coming step's observation goes: (want_obs, target tensor or None, wait for the prefetch first).  With a
         ring the target is the next block (the step adds the state columns): of the current ring, or block 0 of the
         prefetched one."""
+        if self._views:
+            return True, self._state_bufs[(self._state_pos + 1) % self.VIEW_BUFFERS], False
         if self._ring is None:
             return self._observations, None, False
         if self._ring_pos + 1 < self.obs_prefetch:
@@ -307,6 +410,9 @@ class BatchedMicrogridEnv:
     def _obs_commit(self):
         """After the step: advance inside the ring, or move on to the prefetched ring -- then the ring after it is due:
         returns (ring tensor, ahead) for ``observe_windows_ahead``, else None."""
+        if self._views:
+            self._state_pos = (self._state_pos + 1) % self.VIEW_BUFFERS
+            return None
         if self._ring is None:
             return None
         if self._ring_pos + 1 < self.obs_prefetch:
@@ -316,6 +422,23 @@ class BatchedMicrogridEnv:
         self._ring = self._rings[self._ring_idx]
         self._ring_pos = 0
         return None if self._chunked else (self._rings[(self._ring_idx + 1) % 3], self.obs_prefetch)
+
+    def _plan_state(self):
+        """Where the env stands in its observation buffers (hashable; None: nothing cyclic) -- the key of a fleet's step plans."""
+        if self._views:
+            return ("v", self._state_pos)
+        if self._ring is not None:
+            return (self._ring_idx, self._ring_pos)
+        return None
+
+    def _set_plan_state(self, st):
+        if st is None:
+            return
+        if st[0] == "v":
+            self._state_pos = st[1]
+        else:
+            self._ring_idx, self._ring_pos = st
+            self._ring = self._rings[st[0]]
 
     def _chunk_plan(self):
         """Chunked mode: this step's share of the NEXT ring, as (ring tensor, ahead, chunk, n_chunks) -- ahead counted from the
@@ -342,10 +465,18 @@ class BatchedMicrogridEnv:
         refill = self._obs_commit()
         if refill is not None:
             self.engine.observe_windows_ahead(refill[1], out=refill[0])
-        return obs
+        return self._view_now() if self._views else obs
+
+    def _lockstep_done(self):
+        """The coming step's `done` when every grid shares the episode end: one of two constant tensors (no device bytes);
+        None during per-grid-window episodes (the kernel writes the flags)."""
+        e = self.engine
+        if e._window_start is not None or e._dev_counter:       # (device-counter mode: reading the counter would synchronise)
+            return None
+        return self._done_const[int(e.current_step >= e.window[1] - 1)]
 
     def _select_obs(self, obs):
-        if obs is None or self._obs_index is None:
+        if obs is None or self._obs_index is None or self._views:
             return obs
         return obs.index_select(1, self._obs_index)
 
@@ -357,15 +488,17 @@ class BatchedMicrogridEnv:
         if self.raise_errors:             # dry run first (mgx_check_step): a refused request raises BEFORE anything is applied
             self._raise_on_violations(self.engine.check_step(action, normalized=normalized))
         want_obs, out = self._obs_target()
+        dconst = self._lockstep_done()
         obs, reward, done, log = self.engine.step(action, normalized=normalized, want_obs=want_obs,
-                                                  want_log=self._keep_log, out=out)
+                                                  want_log=self._keep_log, out=out, want_done=dconst is None)
         obs = self._obs_after(obs)
         info = {}
         if log is not None:
             self._log_rows.append(log)
             self._shaped_rows.append(reward.clone())
             info["log"] = log
-        return self._select_obs(obs), reward, done.view(torch.bool), info   # 0/1 bytes reinterpreted, no conversion kernel
+        # lock-step: a constant tensor; else 0/1 bytes reinterpreted, no conversion kernel
+        return self._select_obs(obs), reward, (dconst if dconst is not None else done.view(torch.bool)), info
 
     _VIOLATIONS = ((1, "Genset", "supply requested value as a source (outside [min_production, max_production])"),
                    (2, "BatteryModule", "supply / absorb requested value (above max_production / max_consumption)"),
@@ -547,15 +680,16 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
                 action_id = torch.as_tensor(np.asarray(action_id), device=self.batch.device)
             action_id = action_id.to(device=self.batch.device, dtype=torch.int32).contiguous()
         want_obs, out = self._obs_target()
+        dconst = self._lockstep_done()
         obs, reward, done, log, _ = self.engine.step_discrete(action_id, self._table, want_obs=want_obs,
-                                                              want_log=self._keep_log, out=out)
+                                                              want_log=self._keep_log, out=out, want_done=dconst is None)
         obs = self._obs_after(obs)
         info = {}
         if log is not None:
             self._log_rows.append(log)
             self._shaped_rows.append(reward.clone())
             info["log"] = log           # (an expanded priority list never asks a module for more than it can do: nothing to refuse)
-        return self._select_obs(obs), reward, done.view(torch.bool), info
+        return self._select_obs(obs), reward, (dconst if dconst is not None else done.view(torch.bool)), info
 
     def sample_action(self, generator=None):
         return torch.randint(0, self.action_space.n, (self.n_grids,), dtype=torch.int32, device=self.batch.device,

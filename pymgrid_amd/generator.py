@@ -231,11 +231,124 @@ def _synthesize(dev, T, N, gidx, seed, d, r, P, has_grid):
     return load_ts, pv_ts, grid_ts
 
 
+def _pad_table(profile, T):
+    """[T, n] base profile -> [T, PROFILE_PITCH] (one 64-byte row per step; unused columns zero)."""
+    from ._lib import PROFILE_PITCH
+    rows = _tile_rows(profile, T)
+    if rows.shape[1] > PROFILE_PITCH:
+        raise ValueError(f"at most {PROFILE_PITCH} base profiles per table")
+    out = np.zeros((T, PROFILE_PITCH))
+    out[:, :rows.shape[1]] = rows
+    return out
+
+
+def pack_outage_bits(status):
+    """grid_status [T, N] (1 = connected) -> outage words uint64 [ceil(T / 64), N]: bit (t & 63) of word t >> 6 set where
+    the status is 0 (``mgx_columns.outage_bits``)."""
+    T, N = status.shape
+    W = (T + 63) // 64
+    out_b = np.zeros((W * 64, N), dtype=bool)
+    out_b[:T] = np.asarray(status) == 0
+    weights = (np.uint64(1) << np.arange(64, dtype=np.uint64))[None, :, None]
+    return (out_b.reshape(W, 64, N).astype(np.uint64) * weights).sum(axis=1, dtype=np.uint64)
+
+
+def unpack_outage_bits(bits, T):
+    """torch int64 [W, N] outage words -> grid_status float64 [T, N] (1 = connected)."""
+    W, N = bits.shape
+    sh = torch.arange(64, device=bits.device, dtype=torch.int64)[None, :, None]
+    out = (bits[:, None, :] >> sh) & 1                         # arithmetic shift: bit extraction is still exact after & 1
+    return (1 - out.reshape(W * 64, N)[:T]).to(torch.float64)
+
+
+def materialise_series(batch):
+    """{load_ts, pv_ts[, grid_ts]} of a factorised batch (torch, on the batch's device): the single multiply
+    base profile x ratio of ``_scale_ts`` (MicrogridGenerator.py:137-147) with the stored signs
+    (base_timeseries_module.py:68-79) -- what the kernels of the factorised form compute as they go."""
+    c, L = batch.cols, batch.layout
+    T = L.n_steps
+    out = {"load_ts": -(c["base_load"][:, c["load_profile"].long()] * c["load_ratio"][None, :]).abs(),
+           "pv_ts": (c["base_pv"][:, c["pv_profile"].long()] * c["pv_ratio"][None, :]).abs()}
+    if L.has_grid:
+        dev = batch.device
+        g = torch.empty(T, 4, L.n_grids, dtype=torch.float64, device=dev)
+        t1 = torch.as_tensor(electricity_tariff(1, T), device=dev)[:, None]
+        t2 = torch.as_tensor(electricity_tariff(2, T), device=dev)[:, None]
+        pat = c["tariff"][None, :]
+        g[:, 0] = torch.where(pat == 1, t1, torch.where(pat == 2, t2, torch.zeros_like(t1)))
+        g[:, 1] = 0.0
+        g[:, 2] = c["base_co2"][:, c["co2_profile"].long()]
+        g[:, 3] = unpack_outage_bits(c["outage_bits"], T) if c.get("outage_bits") is not None else 1.0
+        out["grid_ts"] = g
+    return {k: v.contiguous() for k, v in out.items()}
+
+
+def _factor_columns(dev, T, N, gidx, seed, d, r, P, has_grid):
+    """The factorised form of the series (``mgx_columns.base_load`` ...): base tables + per-grid profile ids / ratios; for a
+    GridModule the co2 profile id, the tariff pattern and the outage words (device kernel: the same Philox draws as the
+    materialised grid_status column).  Also returns the grid window bounds (min / max over the rows, grid_module.py:125-132)."""
+    f64 = dict(dtype=torch.float64, device=dev)
+    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), **f64)
+    u8 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.uint8), device=dev)
+    cols = dict(base_load=up(_pad_table(P["load"], T)), base_pv=up(_pad_table(P["pv"], T)),
+                load_profile=u8(d["load_file"]), pv_profile=u8(d["pv_file"]),
+                load_ratio=up(r["load_ratio"]), pv_ratio=up(r["pv_ratio"]))
+    if not has_grid:
+        return cols
+    bc = _tile_rows(P["co2"], T)
+    cols.update(base_co2=up(_pad_table(P["co2"], T)), co2_profile=u8(d["co2_file"]), tariff=u8(d["tariff"]))
+    W = (T + 63) // 64
+    if dev.type != "cuda":                                  # host (CPU tests): the same rules in numpy
+        status = np.ones((T, N))
+        rows = np.arange(T + 1)
+        for j in np.nonzero(d["weak"])[0]:
+            status[:, j] = weak_grid_profile(synth_uniform_host(seed, gidx[j], rows), r["outage_per_day"][j], d["outage_dur"][j])
+        bits = torch.from_numpy(pack_outage_bits(status).view(np.int64).copy())
+    else:
+        from . import _lib
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=dev)
+        keep = dict(weak=i32(d["weak"]), outage_per_day=up(r["outage_per_day"]), outage_duration=i32(d["outage_dur"]))
+        bits = torch.zeros(W, N, dtype=torch.int64, device=dev)
+        a = _lib.Synth()
+        a.struct_size = C.sizeof(_lib.Synth)
+        a.n_grids, a.n_steps = N, T
+        a.n_load_profiles = a.n_pv_profiles = a.n_co2_profiles = 1
+        for k, t in keep.items():
+            setattr(a, k, t.data_ptr())
+        contiguous = N == 0 or bool((np.diff(gidx) == 1).all())
+        gi = None if contiguous else torch.as_tensor(np.ascontiguousarray(gidx, dtype=np.int64), device=dev)
+        a.seed, a.grid_index0 = int(seed) & (2 ** 64 - 1), int(gidx[0]) if N else 0
+        a.grid_index = None if gi is None else gi.data_ptr()
+        a.outage_bits = bits.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_synthesize_series(C.byref(a), torch.cuda.current_stream(dev).cuda_stream))
+            torch.cuda.current_stream(dev).synchronize()
+    cols["outage_bits"] = bits
+    # bounds of the four grid components over the T rows
+    tar = np.stack([np.zeros(T), electricity_tariff(1, T), electricity_tariff(2, T)])          # by pattern
+    lo = np.zeros((4, N)); hi = np.zeros((4, N))
+    lo[0], hi[0] = tar.min(axis=1)[d["tariff"]], tar.max(axis=1)[d["tariff"]]
+    lo[2], hi[2] = bc.min(axis=0)[d["co2_file"]], bc.max(axis=0)[d["co2_file"]]
+    full = torch.full((W,), -1, dtype=torch.int64, device=bits.device)
+    if T % 64:
+        full[-1] = (1 << (T % 64)) - 1
+    any_out = (bits != 0).any(dim=0).cpu().numpy()
+    all_out = (bits == full[:, None]).all(dim=0).cpu().numpy()
+    lo[3], hi[3] = np.where(any_out, 0.0, 1.0), np.where(all_out, 0.0, 1.0)
+    cols["grid_lo"], cols["grid_hi"] = up(lo), up(hi)
+    return cols
+
+
 def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, device="cuda", rank=0, world=1,
-             mixed_timers=False, final_step=0, select=None):
+             mixed_timers=False, final_step=0, select=None, series="materialised"):
     """Build the [rank]-th shard of a global batch of ``n_grids`` microgrids of architecture ``arch`` on ``device``.
     ``select``: optional global indices (numpy int array, ascending) -- the grids of the global draw to build instead of
-    the rank's contiguous block (``generate_fleet`` uses it to split one draw by architecture)."""
+    the rank's contiguous block (``generate_fleet`` uses it to split one draw by architecture).
+    ``series``: "materialised" -- [T, N] arrays written by ``mgx_synthesize_series`` -- or "factorised" -- the base
+    profiles + a profile id and a ratio per grid (``mgx_columns.base_load``): the kernels then form every series value with
+    the generator's own multiply, bit-identically, and the [T, N] arrays (14 GB per 100 000 grid-years) never exist."""
+    if series not in ("materialised", "factorised"):
+        raise ValueError("series must be 'materialised' or 'factorised'")
     has_genset, has_battery, has_grid = ARCHS[arch]
     dev = torch.device(device)
     D = draw_scalars(n_grids, seed, mixed_timers)
@@ -253,9 +366,12 @@ def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, d
     f64 = dict(dtype=torch.float64, device=dev)
     up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), **f64)
 
-    load_ts, pv_ts, grid_ts = _synthesize(dev, T, N, idx, seed, d, r, P, has_grid)
-
-    cols = {"load_ts": load_ts, "pv_ts": pv_ts}
+    if series == "factorised":
+        cols = _factor_columns(dev, T, N, idx, seed, d, r, P, has_grid)
+        grid_ts = None
+    else:
+        load_ts, pv_ts, grid_ts = _synthesize(dev, T, N, idx, seed, d, r, P, has_grid)
+        cols = {"load_ts": load_ts, "pv_ts": pv_ts}
     # observation bounds (base_timeseries_module.py:81-88): min / max of the series actually held, with 0
     bl, bp = _tile_rows(P["load"], T), _tile_rows(P["pv"], T)
     cols["load_lo"] = up(-(bl.max(axis=0)[d["load_file"]] * r["load_ratio"])); cols["load_hi"] = torch.zeros(N, **f64)
@@ -279,14 +395,16 @@ def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, d
     if has_grid:                                                        # get_grid_module (:79-97)
         cols["grid_max_import"] = up(r["grid_power"]); cols["grid_max_export"] = up(r["grid_power"])
         cols["grid_cost_per_unit_co2"] = torch.full((N,), 0.1, **f64)
-        cols["grid_ts"] = grid_ts
-        cols["grid_lo"] = grid_ts.amin(dim=0).contiguous(); cols["grid_hi"] = grid_ts.amax(dim=0).contiguous()
+        if grid_ts is not None:
+            cols["grid_ts"] = grid_ts
+            cols["grid_lo"] = grid_ts.amin(dim=0).contiguous(); cols["grid_hi"] = grid_ts.amax(dim=0).contiguous()
     layout = BatchLayout(n_grids=N, n_steps=T, horizon=horizon, initial_step=0, final_step=final_step,
                          has_genset=has_genset, has_battery=has_battery, has_grid=has_grid)
     return MicrogridBatch(layout, {k: v.contiguous() for k, v in cols.items()})
 
 
-def generate_fleet(n_grids, n_steps=YEAR, seed=42, horizon=0, device="cuda", rank=0, world=1, mixed_timers=False):
+def generate_fleet(n_grids, n_steps=YEAR, seed=42, horizon=0, device="cuda", rank=0, world=1, mixed_timers=False,
+                   series="materialised"):
     """A heterogeneous population with MicrogridGenerator's own architecture mix (BASELINE config 5): the rank's block of
     the global draw, split by the architecture each grid drew.  Returns {arch: (MicrogridBatch, global indices)}."""
     if n_grids % world:
@@ -298,5 +416,6 @@ def generate_fleet(n_grids, n_steps=YEAR, seed=42, horizon=0, device="cuda", ran
     for name in ("genset+battery", "battery+grid", "genset+battery+grid"):
         idx = np.nonzero(arch[rank * per:(rank + 1) * per] == name)[0] + rank * per
         if len(idx):
-            out[name] = (generate(n_grids, n_steps, seed, name, horizon, device, mixed_timers=mixed_timers, select=idx), idx)
+            out[name] = (generate(n_grids, n_steps, seed, name, horizon, device, mixed_timers=mixed_timers, select=idx,
+                                  series=series), idx)
     return out

@@ -51,6 +51,7 @@ class BucketedFleet:
                           and not any(isinstance(env, DiscreteBatchedMicrogridEnv) and L_multi(env.layout) for env in self.envs))
         for env in self.envs:
             env._chunked = self.fused and self.refill == "chunks" and not L_multi(env.layout)
+            env._fleet_owned = self.fused
 
     def _init_fused(self, reuse_outputs, fused=True, refill="ahead"):
         # refill: how a fused fleet renews its observation rings -- "ahead" (default): the whole ring after next as one launch
@@ -148,13 +149,11 @@ class BucketedFleet:
             it.handle = e._h.value
             if isinstance(env, DiscreteBatchedMicrogridEnv):
                 it.table, it.n_actions = e._table_ptr(env._table)
-            if st is not None:
-                env._ring_idx, env._ring_pos = st
-                env._ring = env._rings[st[0]]
+            env._set_plan_state(st)
             want_obs, target, wait = env._obs_plan()
             chunk = env._chunk_plan()             # chunked envs: this step's share of the next ring
             refill = env._obs_commit()            # other envs: (ring, ahead) when this step moves on to the prefetched ring
-            next_states.append((env._ring_idx, env._ring_pos) if st is not None else None)
+            next_states.append(env._plan_state())
             obs = target if want_obs else None
             it.obs = None if obs is None else obs.data_ptr()
             it.wait_prefetch = int(wait)
@@ -165,6 +164,8 @@ class BucketedFleet:
                 it.refill_ring = refill[0].data_ptr() if refill else None
                 it.refill_K, it.refill_ahead = (env.obs_prefetch, refill[1]) if refill else (0, 0)
             obs_l.append((obs, want_obs and obs is None))          # (ring view, needs a fresh row buffer per step)
+            env._set_plan_state(st)           # planning must not move the env: the step applies next_states once
+                                              # mgx_fleet_step has succeeded
             if slot is not None:                                     # rotating output buffers: pointers are part of the plan
                 r, d = self._out_reward[k][slot], self._out_done[k][slot]
                 it.reward, it.done = r.data_ptr(), d.data_ptr()
@@ -174,7 +175,7 @@ class BucketedFleet:
         fast = None
         if slot is not None and not any(fresh for _, fresh in obs_l) \
                 and not any(env._keep_log or env._obs_index is not None for env in self.envs):
-            sync = [(env, st[0], st[1], env._rings[st[0]]) for env, st in zip(self.envs, next_states) if st is not None]
+            sync = [(env, st) for env, st in zip(self.envs, next_states) if st is not None]
             fast = ([o for o, _ in obs_l], [r for r, _ in fixed_out], [d for _, d in fixed_out], sync,
                     (tuple(next_states), (slot + 1) % self.reuse_outputs))
         return items, obs_l, next_states, fixed_out, fast
@@ -186,7 +187,7 @@ class BucketedFleet:
             self._out_reward = [e.engine._empty(R, e.engine.N) for e in envs]
             self._out_done = [e.engine._empty(R, e.engine.N, dtype=torch.uint8) for e in envs]
         slot = (self._n_steps % R) if R else None
-        key = (tuple((e._ring_idx, e._ring_pos) if e._ring is not None else None for e in envs), slot)
+        key = (tuple(e._plan_state() for e in envs), slot)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._plans[key] = self._plan(key)
@@ -208,12 +209,21 @@ class BucketedFleet:
             if fresh:
                 obs = e._obs_buf(None)
                 it.obs = obs.data_ptr()
+            dconst = env._lockstep_done()        # lock-step: `done` is a constant tensor, the kernel writes no flags
             if R:
                 reward, done = fixed_out[k]
+                it.done = None if dconst is not None else done.data_ptr()
             else:
-                reward, d8 = e._empty(e.N), e._empty(e.N, dtype=torch.uint8)
-                it.reward, it.done = reward.data_ptr(), d8.data_ptr()
-                done = d8.view(torch.bool)
+                reward = e._empty(e.N)
+                it.reward = reward.data_ptr()
+                if dconst is None:
+                    d8 = e._empty(e.N, dtype=torch.uint8)
+                    it.done = d8.data_ptr()
+                    done = d8.view(torch.bool)
+                else:
+                    it.done = None
+            if dconst is not None:
+                done = dconst
             if env._keep_log:
                 log = e._empty(e.log_dim, e.N)
                 it.log = log.data_ptr()
@@ -232,11 +242,10 @@ class BucketedFleet:
             _lib.check(rc)
         self._n_steps += 1
         for k, env in enumerate(envs):
-            st = next_states[k]
-            if st is not None:
-                env._ring_idx, env._ring_pos = st
-                env._ring = env._rings[st[0]]
-            if env._obs_index is not None:
+            env._set_plan_state(next_states[k])
+            if env._views:
+                obs_l[k] = env._view_now()
+            elif env._obs_index is not None:
                 obs_l[k] = env._select_obs(obs_l[k])
             if env._keep_log:
                 env._log_rows.append(info_l[k]["log"])
@@ -245,10 +254,16 @@ class BucketedFleet:
 
     def _step_fast(self, items, fast, actions, normalized):
         obs_l, reward_l, done_l, sync, _ = fast
+        obs_l, done_l = list(obs_l), list(done_l)
         k, keep = 0, []                           # keep: converted ids stay alive until the launch has been issued
         for env in self.envs:
             a = actions[k]
             it = items[k]
+            dconst = env._lockstep_done()         # lock-step: a constant tensor, the kernel writes no flags
+            if dconst is not None:
+                it.done, done_l[k] = None, dconst
+            else:
+                it.done = done_l[k].data_ptr()
             if it.table:                          # discrete bucket: priority-list ids
                 if not (torch.is_tensor(a) and a.dtype == torch.int32 and a.is_contiguous() and a.is_cuda and a.shape == (env.n_grids,)):
                     a = torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a), device=env.batch.device).to(torch.int32).contiguous()
@@ -270,9 +285,12 @@ class BucketedFleet:
         if rc:
             _lib.check(rc)
         self._n_steps += 1
-        for env, ring_idx, ring_pos, ring in sync:
-            env._ring_idx, env._ring_pos, env._ring = ring_idx, ring_pos, ring
-        return list(obs_l), list(reward_l), list(done_l), [{} for _ in reward_l]
+        for env, st in sync:
+            env._set_plan_state(st)
+        for j, env in enumerate(self.envs):
+            if env._views:
+                obs_l[j] = env._view_now()
+        return obs_l, list(reward_l), done_l, [{} for _ in reward_l]
 
     def sample_action(self, generator=None):
         return [env.sample_action(generator=generator) for env in self.envs]
@@ -351,6 +369,7 @@ class PerGridWindowEnv:
         return starts, lengths
 
     def reset(self, starts=None, lengths=None):
+        validate = starts is not None          # the env's own draws lie inside the window by construction: no host check
         if starts is None:
             starts, lengths = self.draw()
         dev = self.full.device
@@ -363,8 +382,8 @@ class PerGridWindowEnv:
         if self.auto_reset:      # the rings must hold the longest episode any LATER restart can draw
             L = self.full.layout
             max_len = self.length if self.length is not None else L.final_step - L.initial_step
-            return self.env.reset_windows(self.starts, self.lengths, max_len, rolling=True)
-        return self.env.reset_windows(self.starts, self.lengths, max_len)
+            return self.env.reset_windows(self.starts, self.lengths, max_len, rolling=True, validate=validate)
+        return self.env.reset_windows(self.starts, self.lengths, max_len, validate=validate)
 
     def step(self, action, **kw):
         if not self.auto_reset:
@@ -385,7 +404,7 @@ class PerGridWindowEnv:
             self.starts = env.engine._window_start          # updated in place by the kernel
         else:
             starts, lengths = self.draw()                  # a draw per grid; only the finished grids take theirs
-            new_obs = env.reset_grids(done, starts, lengths)
+            new_obs = env.reset_grids(done, starts, lengths, validate=False)
             self.starts = torch.where(done, starts, self.starts)
             if lengths is not None:
                 self.lengths = torch.where(done, lengths, self.lengths)

@@ -1,0 +1,349 @@
+"""Factorised series (mgx_columns.base_load: base profile x per-grid ratio, formed in the kernels) == the materialised [T, N]
+series, bit for bit, on every kernel that reads a series; `done` as bit sets / derived from the counter; the zero-copy
+observation contract (ObsViews) == the rows contract.
+
+Reference being matched: MicrogridGenerator.py:137-147 (_scale_ts), :205-212 (co2), :253-285 (tariff), :321-340 (weak grid);
+base_timeseries_module.py:68-79,103-140,162-170 (stored sign, windows); forecaster.py:120-149 (padding, clip)."""
+import numpy as np
+import pytest
+import torch
+
+ARCHS = ("genset+battery", "battery+grid", "genset+battery+grid")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU: host packing
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arch", ARCHS)
+def test_factorised_batch_materialises_to_the_generated_series_host(arch):
+    """generate(series="factorised") holds base tables + factors; materialise() (the one multiply, torch on the host) gives
+    exactly the arrays the materialised generator builds, bounds included."""
+    from pymgrid_amd.generator import generate
+    bm = generate(48, n_steps=300, seed=5, arch=arch, device="cpu", mixed_timers=True)
+    bf = generate(48, n_steps=300, seed=5, arch=arch, device="cpu", mixed_timers=True, series="factorised")
+    assert bf.factorised and not bm.factorised and "load_ts" not in bf.cols
+    m = bf.materialise()
+    assert set(m.cols) == set(bm.cols)
+    for k, v in bm.cols.items():
+        assert torch.equal(v, m.cols[k]), k
+    assert m.cols["charge"] is bf.cols["charge"]                      # state columns are shared with the twin
+    nc = bf.numpy_columns()                                           # what the oracle is fed in the GPU tests
+    assert np.array_equal(nc["load_ts"], bm.cols["load_ts"].numpy())
+
+
+def test_outage_bits_round_trip():
+    from pymgrid_amd.generator import pack_outage_bits, unpack_outage_bits
+    rs = np.random.RandomState(0)
+    for T in (1, 63, 64, 65, 200):
+        status = (rs.rand(T, 7) > 0.3).astype(np.float64)
+        bits = pack_outage_bits(status)
+        assert bits.shape == ((T + 63) // 64, 7) and bits.dtype == np.uint64
+        back = unpack_outage_bits(torch.from_numpy(bits.view(np.int64).copy()), T)
+        assert np.array_equal(back.numpy(), status)
+
+
+def test_bytes_fused_accounting():
+    from pymgrid_amd import BatchLayout
+    t4 = BatchLayout(n_grids=1, n_steps=10, has_genset=True, has_battery=True, has_grid=False)
+    assert t4.bytes_fused(64) == 140 + 64 * 57
+    # factorised, `done` derived from the counter: 24 B of actions + reward + SoC per step; factors 18 B once
+    assert t4.bytes_fused(64, factorised=True, done=False) == 140 + 18 + 64 * 40
+    assert t4.bytes_fused(64, factorised=True, done=True, done_bits=True) == 140 + 18 + 64 * 40.125
+    t5 = BatchLayout(n_grids=1, n_steps=10, has_genset=True, has_battery=True, has_grid=True)
+    assert t5.bytes_fused(64, factorised=True, done=False) - t5.bytes_fused(64, done=False) == 20 + 64 * (0.125 - 48)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def _pair(n, T, arch, device, horizon=0, seed=9, **kw):
+    """(materialised batch, factorised batch) of the same draw, each with its own state columns."""
+    from pymgrid_amd.generator import generate
+    bm = generate(n, n_steps=T, seed=seed, arch=arch, device=device, horizon=horizon, mixed_timers=True, **kw)
+    bf = generate(n, n_steps=T, seed=seed, arch=arch, device=device, horizon=horizon, mixed_timers=True, series="factorised", **kw)
+    return bm, bf
+
+
+def _same_state(bm, bf):
+    for k in ("charge", "soc", "gen_status"):
+        if k in bm.cols:
+            assert torch.equal(bm.cols[k], bf.cols[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ARCHS)
+def test_device_outage_words_and_twin_equal_the_synthesised_series(arch, device):
+    """The outage words the synthesis kernel packs == the grid_status column it writes; the factorised batch's materialised
+    twin == the materialised batch (same Philox draws), incl. the analytically derived grid bounds."""
+    bm, bf = _pair(3000, 700, arch, device)
+    m = bf.materialise()
+    for k, v in bm.cols.items():
+        assert torch.equal(v, m.cols[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ARCHS)
+@pytest.mark.parametrize("act_dtype", [torch.float64, torch.float32])
+def test_fused_and_single_steps_factorised_vs_materialised(arch, act_dtype, device):
+    """mgx_step_k (lean and rich form, across LDS chunks of 128 rows and 64-row outage words, from an odd start row), mgx_step,
+    mgx_check_step, mgx_step_many: every output and the final state are equal."""
+    from pymgrid_amd import StepEngine
+    N, T = 5000, 700
+    bm, bf = _pair(N, T, arch, device)
+    em, ef = StepEngine(bm, action_dtype=act_dtype), StepEngine(bf, action_dtype=act_dtype)
+    g = torch.Generator(device=device); g.manual_seed(1)
+    A = bm.layout.action_dim
+    for t0, K in ((37, 300), (0, 5), (T - 131, 131)):
+        acts = torch.rand(K, N, A, dtype=act_dtype, device=device, generator=g)
+        for e in (em, ef):
+            e.reset(t0, want_obs=False)
+        om = em.step_k(acts, reward=True, done=True, soc_trace=True)
+        of = ef.step_k(acts, reward=True, done=True, soc_trace=True)
+        for k in om:
+            assert torch.equal(om[k], of[k]), (k, t0)
+        _same_state(bm, bf)
+    for e in (em, ef):
+        e.reset(100, want_obs=False)
+    acts = torch.rand(150, N, A, dtype=act_dtype, device=device, generator=g)
+    om = em.step_k(acts, reward=True, done=True, soc_trace=True, status_trace=True, log=True)
+    of = ef.step_k(acts, reward=True, done=True, soc_trace=True, status_trace=True, log=True)
+    for k in om:
+        assert torch.equal(om[k], of[k]), k
+    _same_state(bm, bf)
+    # single steps, the dry run, K launches by one call
+    vm, vf = em.check_step(acts[0]), ef.check_step(acts[0])
+    assert torch.equal(vm, vf)
+    for k in range(3):
+        rm = em.step(acts[k], want_obs=True, want_log=True)
+        rf = ef.step(acts[k], want_obs=True, want_log=True)
+        for x, y in zip(rm, rf):
+            assert torch.equal(x, y)
+    sm, sf = em.step_many(acts[3:9], want_obs=True), ef.step_many(acts[3:9], want_obs=True)
+    for x, y in zip(sm[:3], sf[:3]):
+        assert torch.equal(x, y)
+    _same_state(bm, bf)
+    em.close(); ef.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ARCHS)
+def test_discrete_paths_factorised_vs_materialised(arch, device):
+    """Priority-list expansion, the one-launch discrete step, per-step and fixed-list rollouts (RuleBasedControl)."""
+    from pymgrid_amd import StepEngine
+    from pymgrid_amd.priority_list import get_priority_lists, table_array
+    N, T = 4000, 520
+    bm, bf = _pair(N, T, arch, device)
+    em, ef = StepEngine(bm), StepEngine(bf)
+    L = bm.layout
+    lists = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, False)
+    table = table_array(lists)
+    g = torch.Generator(device=device); g.manual_seed(2)
+    ids32 = torch.randint(0, len(lists), (N,), dtype=torch.int32, device=device, generator=g)
+    for e in (em, ef):
+        e.reset(11, want_obs=False)
+    assert torch.equal(em.expand_discrete(ids32, table), ef.expand_discrete(ids32, table))
+    rm = em.step_discrete(ids32, table, want_obs=True, want_log=True, want_control=True)
+    rf = ef.step_discrete(ids32, table, want_obs=True, want_log=True, want_control=True)
+    for x, y in zip(rm, rf):
+        assert torch.equal(x, y)
+    K = 400
+    ids = torch.randint(0, len(lists), (K, N), dtype=torch.uint8, device=device, generator=g)
+    om = em.rollout_discrete(ids, table, K, reward=True, done=True, soc_trace=True)
+    of = ef.rollout_discrete(ids, table, K, reward=True, done=True, soc_trace=True)
+    for k in om:
+        assert torch.equal(om[k], of[k]), k
+    _same_state(bm, bf)
+    for e in (em, ef):
+        e.reset(70, want_obs=False)
+    fixed = ids[0].contiguous()
+    om = em.rollout_discrete(fixed, table, K, reward=True, done=True, soc_trace=True, status_trace=True, log=True)
+    of = ef.rollout_discrete(fixed, table, K, reward=True, done=True, soc_trace=True, status_trace=True, log=True)
+    for k in om:
+        assert torch.equal(om[k], of[k]), k
+    _same_state(bm, bf)
+    em.close(); ef.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ARCHS)
+@pytest.mark.parametrize("obs_dtype", [torch.float64, torch.float32])
+def test_observation_rows_and_rings_factorised_vs_materialised(arch, obs_dtype, device):
+    """H = 24 observation rows: per-step rows (obs_rows_wave_kernel), prefetched rings (obs_windows_k_kernel), end-of-series
+    padding; per-grid windows gathered out of the factors (mgx_reset_windows)."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    N, T, H = 3001, 200, 24
+    bm, bf = _pair(N, T, arch, device, horizon=H)
+    g = torch.Generator(device=device); g.manual_seed(3)
+    for prefetch in (0, 8):
+        envm = BatchedMicrogridEnv(bm, obs_dtype=obs_dtype, obs_prefetch=prefetch)
+        envf = BatchedMicrogridEnv(bf, obs_dtype=obs_dtype, obs_prefetch=prefetch)
+        om, of = envm.reset(T - 40), envf.reset(T - 40)
+        assert torch.equal(om, of)
+        for k in range(39):                                      # to the last row: windows run into the padding
+            a = envm.sample_action(generator=g)
+            om, rm, dm, _ = envm.step(a)
+            of, rf, df, _ = envf.step(a)
+            assert torch.equal(om, of) and torch.equal(rm, rf) and torch.equal(dm, df), (prefetch, k)
+        assert bool(dm.all())
+        # per-grid episodes: rows gathered from the factors
+        starts = torch.randint(0, T - 30, (N,), dtype=torch.int32, device=device, generator=g)
+        lengths = torch.randint(1, 30, (N,), dtype=torch.int32, device=device, generator=g)
+        om, of = envm.reset_windows(starts, lengths), envf.reset_windows(starts, lengths)
+        assert torch.equal(om, of)
+        for k in range(int(lengths.max().item())):
+            a = envm.sample_action(generator=g)
+            om, rm, dm, _ = envm.step(a)
+            of, rf, df, _ = envf.step(a)
+            assert torch.equal(om, of) and torch.equal(rm, rf) and torch.equal(dm, df), (prefetch, k)
+        om, of = envm.reset(), envf.reset()                      # back to the full (factorised) series
+        assert torch.equal(om, of) and envf.engine.batch.factorised
+        a = envm.sample_action(generator=g)
+        assert torch.equal(envm.step(a)[0], envf.step(a)[0])
+        envm.close(); envf.close()
+        bm.load_state(bf.state())
+
+
+@pytest.mark.gpu
+def test_done_bit_sets_and_lockstep_done(device):
+    """MGX_DONE_BITS == the byte form (per-grid episode ends, mgx_reset_windows); lock-step `done` derived from the counter
+    (engine.done_steps) == what the kernel writes."""
+    from pymgrid_amd import StepEngine
+    N, T, K = 5003, 300, 90
+    bm, bf = _pair(N, T, "genset+battery", device)
+    g = torch.Generator(device=device); g.manual_seed(4)
+    acts = torch.rand(K, N, 3, dtype=torch.float64, device=device, generator=g)
+    for b in (bm, bf):
+        e = StepEngine(b)
+        e.reset(T - K, want_obs=False)
+        expect = e.done_steps(K)
+        st = b.state()
+        d8 = e.step_k(acts, reward=False, done=True)["done"]
+        assert torch.equal(d8.view(torch.bool), expect) and bool(expect[-1].all()) and not bool(expect[:-1].any())
+        # per-grid episode ends
+        b.load_state(st)
+        starts = torch.randint(0, T - K, (N,), dtype=torch.int32, device=device, generator=g)
+        lengths = torch.randint(1, K + 1, (N,), dtype=torch.int32, device=device, generator=g)
+        e.reset_windows(starts, lengths, want_obs=False)
+        with pytest.raises(RuntimeError):
+            e.done_steps(K)
+        d8 = e.step_k(acts, reward=False, done=True)["done"].view(torch.bool)
+        assert torch.equal(d8, torch.arange(K, device=device)[:, None] >= (lengths[None, :] - 1))
+        b.load_state(st)
+        e.reset_windows(starts, lengths, want_obs=False)
+        e.set_done_format(True)
+        words = e.step_k(acts, reward=False, done=True)["done"]
+        assert words.shape == (K, (N + 15) // 16) and words.dtype == torch.int16
+        assert torch.equal(e.unpack_done_bits(words), d8)
+        e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ARCHS)
+@pytest.mark.parametrize("series", ["materialised", "factorised"])
+@pytest.mark.parametrize("obs_dtype", [torch.float64, torch.float32])
+def test_zero_copy_views_equal_rows(arch, series, obs_dtype, device):
+    """obs_views=True: the strided views into the once-normalised series + the compact state columns == the [N, D] rows of
+    the default contract at every step, through the end-of-series padding and a per-grid-window episode."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    from pymgrid_amd.generator import generate
+    N, T, H = 2500, 160, 24
+    kw = dict(n_steps=T, seed=12, arch=arch, device=device, horizon=H, mixed_timers=True, series=series)
+    br, bv = generate(N, **kw), generate(N, **kw)
+    rows = BatchedMicrogridEnv(br, obs_dtype=obs_dtype)
+    views = BatchedMicrogridEnv(bv, obs_dtype=obs_dtype, obs_views=True)
+    g = torch.Generator(device=device); g.manual_seed(5)
+    o, v = rows.reset(T - 50), views.reset(T - 50)
+    assert torch.equal(o, v.flat()) and v.load.shape == (N, 1 + H) and v.state.shape == (N, views.engine.state_dim)
+    assert v.load.data_ptr() == views._norm["load"].data_ptr() + (T - 50) * v.load.element_size()      # a view, not a copy
+    held = []
+    for k in range(49):
+        a = rows.sample_action(generator=g)
+        o, r, d, _ = rows.step(a)
+        v, r2, d2, _ = views.step(a)
+        assert torch.equal(o, v.flat()) and torch.equal(r, r2) and torch.equal(d, d2), k
+        held.append((o, v))
+        if len(held) >= views.VIEW_BUFFERS - 1:                  # an observation stays valid for VIEW_BUFFERS - 1 more steps
+            o_old, v_old = held.pop(0)
+            assert torch.equal(o_old, v_old.flat())
+    n = v.nested()
+    assert set(n) == {"load", "pv", "battery"} | ({"genset"} if br.layout.has_genset else set()) | ({"grid"} if br.layout.has_grid else set())
+    starts = torch.randint(0, T - 20, (N,), dtype=torch.int32, device=device, generator=g)
+    lengths = torch.randint(1, 20, (N,), dtype=torch.int32, device=device, generator=g)
+    o, v = rows.reset_windows(starts, lengths), views.reset_windows(starts, lengths)
+    assert torch.equal(o, v.flat())
+    for k in range(int(lengths.max().item())):
+        a = rows.sample_action(generator=g)
+        o, r, d, _ = rows.step(a)
+        v, r2, d2, _ = views.step(a)
+        assert torch.equal(o, v.flat()) and torch.equal(r, r2) and torch.equal(d, d2), k
+    o, v = rows.reset(), views.reset()
+    assert torch.equal(o, v.flat())
+    rows.close(); views.close()
+
+
+@pytest.mark.gpu
+def test_views_refuse_bounds_that_do_not_bound(device):
+    """With a bound column tighter than its series the reference's forecast clip bites and windows are no longer slices of
+    one normalised series: normalise_series says so."""
+    from pymgrid_amd import BatchedMicrogridEnv, MgxError
+    from pymgrid_amd.generator import generate
+    b = generate(300, n_steps=60, seed=1, arch="genset+battery", device=device, horizon=4)
+    b.cols["pv_hi"].mul_(0.5)
+    with pytest.raises(MgxError):
+        BatchedMicrogridEnv(b, obs_views=True)
+
+
+@pytest.mark.gpu
+def test_fleet_with_views_and_factorised_series_vs_rows(device):
+    """A heterogeneous fleet (three layouts, H = 24) stepped by mgx_fleet_step: factorised + views == materialised + rows."""
+    from pymgrid_amd.generator import generate_fleet
+    from pymgrid_amd.hetero import BucketedFleet
+    n, T, H = 9000, 100, 24
+    pr = generate_fleet(n, n_steps=T, seed=17, horizon=H, device=device, mixed_timers=True)
+    pv = generate_fleet(n, n_steps=T, seed=17, horizon=H, device=device, mixed_timers=True, series="factorised")
+    names = list(pr)
+    rows = BucketedFleet.from_batches([pr[k][0] for k in names], obs_prefetch=8, reuse_outputs=24)
+    views = BucketedFleet.from_batches([pv[k][0] for k in names], obs_views=True, reuse_outputs=24)
+    assert rows.fused and views.fused
+    o, v = rows.reset(), views.reset()
+    for x, y in zip(o, v):
+        assert torch.equal(x, y.flat())
+    g = torch.Generator(device=device); g.manual_seed(8)
+    for k in range(T - 1):
+        acts = rows.sample_action(generator=g)
+        o, r, d, _ = rows.step(acts)
+        v, r2, d2, _ = views.step(acts)
+        for b in range(len(names)):
+            assert torch.equal(o[b], v[b].flat()) and torch.equal(r[b], r2[b]) and torch.equal(d[b], d2[b]), (k, names[b])
+    assert all(bool(x.all()) for x in d)
+    rows.close(); views.close()
+
+
+@pytest.mark.gpu
+def test_true_shape_config3_factorised_vs_materialised(device):
+    """BASELINE configs[2] at its true shape: 100 000 Template-4 grids x 8 760 rows -- the factorised batch (no [T, N] series:
+    14 GB less) steps bit-identically to the materialised one, in two shards as bench.py steps it, at the start and across
+    the end of the year."""
+    from pymgrid_amd import StepEngine
+    from pymgrid_amd.generator import generate
+    N, T, K = 100_000, 8760, 192
+    bm = generate(N, n_steps=T, seed=42, arch="genset+battery", device=device)
+    bf = generate(N, n_steps=T, seed=42, arch="genset+battery", device=device, series="factorised")
+    assert "load_ts" not in bf.cols and bf.cols["base_load"].shape == (T, 8)
+    em, ef = StepEngine(bm), StepEngine(bf)
+    g = torch.Generator(device=device); g.manual_seed(7)
+    acts = torch.rand(K, N, 3, dtype=torch.float64, device=device, generator=g)
+    for shards in (1, 2):
+        for t0 in (0, T - K):
+            for e in (em, ef):
+                e.set_shards(shards)
+                e.reset(t0, want_obs=False)
+                e.fork()
+            om = em.step_k(acts, reward=True, done=True, soc_trace=True)
+            of = ef.step_k(acts, reward=True, done=True, soc_trace=True)
+            em.join(); ef.join()
+            torch.cuda.synchronize(device)
+            for k in om:
+                assert torch.equal(om[k], of[k]), (k, t0, shards)
+            _same_state(bm, bf)
+    em.close(); ef.close()
