@@ -2,9 +2,15 @@
 """bench.py -- microgrid env-steps/s of the batched step engine (BASELINE.json metric).
 
 Workload (BASELINE.json configs[2]): N = 100 000 generated Template-4 grids (genset + battery + load + pv) per GPU,
-T = 8760 hourly rows, series built on device from the reference's base profiles with the MicrogridGenerator sizing rules
-(pymgrid_amd/generator.py), normalised U[0,1) actions.  Everything the timed region reads (columns, series, actions) is
-resident in HBM before timing starts.
+T = 8760 hourly rows, the series of MicrogridGenerator (pymgrid_amd/generator.py: the reference's base profiles x the per-grid
+sizing ratio), normalised U[0,1) actions.  Everything the timed region reads (columns, series, actions) is resident in HBM
+before timing starts.
+
+Series layout (--series): "factorised" (default, the headline) keeps the series as the generator defines them -- base profile
+id + ratio per grid, the product formed in the kernels with the generator's own multiply, bit-identical to the arrays -- so
+no [T, N] series exist or are streamed; "materialised" streams [T, N] arrays written once by mgx_synthesize_series.  Both are
+timed in every run (the other one under "other"), each with its own algorithmic byte count.  `done` is not written by the
+headline launch: in lock-step it is the same for every grid and follows from the step counter (engine.done_steps).
 
 A bench STEP is one fused ROUND: `--chunk` (64) consecutive env-steps of ALL grids of the rank -- one pass of the hot path
 over one [64, N, A] batch of actions, issued as one K-step kernel launch (mgx_step_k) per shard.  `--steps K --warmup W`
@@ -57,9 +63,12 @@ def parse(argv=None):
     ap.add_argument("--rows", type=int, default=8760, help="time-series rows T")
     ap.add_argument("--mode", choices=["fused", "step", "rbc"], default="fused")
     ap.add_argument("--chunk", type=int, default=64, help="env-steps per round (= per fused launch)")
-    ap.add_argument("--shards", type=int, default=2,
-                    help="grid ranges stepped on internal HIP streams (mgx_set_shards); 1: one launch sequence")
+    ap.add_argument("--shards", type=int, default=None,
+                    help="grid ranges stepped on internal HIP streams (mgx_set_shards); 1: one launch sequence.  Default: 1 for the "
+                         "factorised layout (two ranges measured no faster there), 2 for the materialised one")
     ap.add_argument("--arch", default="genset+battery")
+    ap.add_argument("--series", choices=["factorised", "materialised"], default="factorised",
+                    help="series layout of the headline batch (the other layout is timed under 'other')")
     ap.add_argument("--hetero-steps", type=int, default=256, help="timed Gym steps of the heterogeneous H=24 fleet (0: skip)")
     ap.add_argument("--no-side-modes", action="store_true", help="time the headline mode only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,13 +97,13 @@ def self_launch(args):
 class Runner:
     """Issues rounds on one engine.  Sharded: the engine steps in S grid ranges on its internal streams."""
 
-    def __init__(self, eng, chunk, seed, shards):
+    def __init__(self, eng, chunk, seed, shards, pool=None):
         from pymgrid_amd.priority_list import get_priority_lists, table_array
         from pymgrid_amd.rbc import default_priority_ids
         self.eng, self.chunk, self.S = eng, chunk, shards
         L, N, dev = eng.layout, eng.N, eng.device
         gen = torch.Generator(device=dev); gen.manual_seed(seed)
-        self.pool = torch.rand(4, chunk, N, L.action_dim, dtype=torch.float64, device=dev, generator=gen)
+        self.pool = pool if pool is not None else torch.rand(4, chunk, N, L.action_dim, dtype=torch.float64, device=dev, generator=gen)
         # OUT_SETS sets of [chunk, N] output buffers, cycled: a launch never rewrites what the previous three wrote, so no
         # output line can still sit in the 256 MB Infinity Cache when it is written again
         self.outs = [dict(reward=torch.empty(chunk, N, dtype=torch.float64, device=dev),
@@ -105,6 +114,7 @@ class Runner:
         self.rbc_ids = torch.from_numpy(default_priority_ids(eng.batch, lists, remove_redundant_gensets=False)).to(dev)
         self.rounds = 0            # rounds issued since the process started (per mode runner)
         self.streams = []
+        self.done_stream = False
 
     def shard(self, on):
         self.eng.set_shards(self.S if on else 1)
@@ -114,17 +124,20 @@ class Runner:
         if self.eng.current_step + self.chunk > self.eng.layout.final_step:
             self.eng.reset(want_obs=False)
 
+    # `done`: in lock-step it is the same for every grid, done(k) = (t + k >= final_step - 1); the launches below do not write
+    # it per grid (self.done_stream = False) -- engine.done_steps(K) derives the [K, N] view from the step counter
+
     def fused(self, rounds):
         for _ in range(rounds):
             self._room()
             self.eng.step_k(self.pool[self.rounds % 4], normalized=True, out=self.outs[self.rounds % OUT_SETS],
-                            reward=True, done=True, soc_trace=True)
+                            reward=True, done=self.done_stream, soc_trace=True)
             self.rounds += 1
 
     def rbc(self, rounds):
         for _ in range(rounds):
             self._room()
-            self.eng.rollout_discrete(self.rbc_ids, self.rbc_table, self.chunk, reward=True, done=True, soc_trace=True,
+            self.eng.rollout_discrete(self.rbc_ids, self.rbc_table, self.chunk, reward=True, done=self.done_stream, soc_trace=True,
                                       out=self.outs[self.rounds % OUT_SETS])
             self.rounds += 1
 
@@ -133,7 +146,8 @@ class Runner:
         for _ in range(rounds):
             self._room()
             o = self.outs[self.rounds % OUT_SETS]
-            self.eng.step_many(self.pool[self.rounds % 4], normalized=True, out=dict(reward=o["reward"], done=o["done"]))
+            self.eng.step_many(self.pool[self.rounds % 4], normalized=True, out=dict(reward=o["reward"], done=o["done"]),
+                               done=self.done_stream)
             self.rounds += 1
 
     def step_python(self, rounds):
@@ -144,7 +158,7 @@ class Runner:
             self._room()
             a = self.pool[self.rounds % 4]
             for k in range(self.chunk):
-                self.eng.step(a[k], normalized=True, want_obs=False, want_log=False, out=out1)
+                self.eng.step(a[k], normalized=True, want_obs=False, want_log=False, out=out1, want_done=self.done_stream)
             self.rounds += 1
 
     def kernel_durations_us(self, fn, rounds=16):
@@ -188,80 +202,113 @@ def timed(run, fn, rounds, device, mdist):
     return t1 - t0, max(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3
 
 
-def hetero_gym_steps(N, dev, rank, world, steps, mdist):
-    """BASELINE configs[4] in miniature: a heterogeneous fleet (1/3 genset+battery, 1/3 battery+grid, 1/3
-    genset+battery+grid; forecast_horizon = 24) stepped through the Gym surface WITH observation rows."""
+def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series):
+    """BASELINE configs[4] per GPU: a heterogeneous fleet (1/3 genset+battery, 1/3 battery+grid, 1/3 genset+battery+grid;
+    forecast_horizon = 24, T = `rows`) stepped through the Gym surface WITH observations, under both observation contracts:
+      rows   step() returns the [N, D] rows (D = 56 / 152 / 156): written ahead in rings of 16 row blocks, the step adds the
+             state columns (float64 and float32 rows);
+      views  step() returns ObsViews: strided views into the series normalised once (mgx_normalise_series) + the 6 state
+             columns the step writes -- the windows repeat 24 / 25 of the previous step's, so nothing else needs to move."""
     from pymgrid_amd.generator import generate
     from pymgrid_amd.hetero import BucketedFleet
     per = N // 3
     K_ring = 16
     out = {}
-    for name, dt in (("float64_rows", torch.float64), ("float32_rows", torch.float32)):
-        batches = [generate(per * world, n_steps=steps + 1100, seed=43 + k, arch=arch, horizon=24, device=dev, rank=rank,
-                            world=world) for k, arch in enumerate(("genset+battery", "battery+grid", "genset+battery+grid"))]
-        fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K_ring, reuse_outputs=3 * K_ring)
-        gen = torch.Generator(device=dev); gen.manual_seed(11 + rank)
-        acts = [torch.rand(per, e.layout.action_dim, dtype=torch.float64, device=dev, generator=gen) for e in fleet.envs]
-        # warm-up by wall time: the fleet is built on the host while the GPU idles and clocks down
-        prev, t_end = None, time.perf_counter() + 4.0
-        while time.perf_counter() < t_end:                # until two consecutive 1000-step blocks agree within 3 %
+    archs = ("genset+battery", "battery+grid", "genset+battery+grid")
+    for contract in ("rows", "views"):
+        for dt_name, dt in (("float64", torch.float64), ("float32", torch.float32)):
+            name = f"{dt_name}_{contract}"
+            batches = [generate(per * world, n_steps=rows, seed=43 + k, arch=arch, horizon=24, device=dev, rank=rank,
+                                world=world, series=series) for k, arch in enumerate(archs)]
+            if contract == "rows":
+                fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K_ring, reuse_outputs=3 * K_ring)
+            else:
+                fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_views=True, reuse_outputs=3 * K_ring)
+            gen = torch.Generator(device=dev); gen.manual_seed(11 + rank)
+            acts = [torch.rand(per, e.layout.action_dim, dtype=torch.float64, device=dev, generator=gen) for e in fleet.envs]
+
+            def consume(obs):          # what a policy would do first: take the window views (host work of the views contract)
+                if contract == "views":
+                    for o in obs:
+                        o.load; o.pv; o.grid
+            # warm-up by wall time: the fleet is built on the host while the GPU idles and clocks down
+            prev, t_end = None, time.perf_counter() + 4.0
+            while time.perf_counter() < t_end:                # until two consecutive 1000-step blocks agree within 3 %
+                fleet.reset()
+                t0 = time.perf_counter()
+                for _ in range(1000):
+                    consume(fleet.step(acts)[0])
+                torch.cuda.synchronize(dev)
+                cur = time.perf_counter() - t0
+                if prev is not None and abs(cur - prev) < 0.03 * prev:
+                    break
+                prev = cur
             fleet.reset()
-            t0 = time.perf_counter()
-            for _ in range(1000):
+            for _ in range(64):
                 fleet.step(acts)
+            mdist.barrier()
             torch.cuda.synchronize(dev)
-            cur = time.perf_counter() - t0
-            if prev is not None and abs(cur - prev) < 0.03 * prev:
-                break
-            prev = cur
-        fleet.reset()
-        for _ in range(64):
-            fleet.step(acts)
-        mdist.barrier()
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(steps):
-            fleet.step(acts)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
-        gpu = mdist.max_over_ranks(e0.elapsed_time(e1) * 1e-3, dev)
-        mdist.barrier()
-        esz = 8 if dt == torch.float64 else 4
-        # algorithmic bytes of one fleet step (SURVEY 8(d) formula): the core step of every bucket + the observation row
-        # written (esz * D) + the window rows read once per ring refill (8 * C_ts * (K + H) / K per step)
-        alg = 0
-        for e in fleet.envs:
-            L = e.layout
-            c_ts = L.n_load + L.n_pv + 4 * int(L.has_grid)
-            alg += L.n_grids * (L.bytes_per_step() + esz * L.obs_dim + 8 * c_ts * (K_ring + L.horizon) / K_ring)
-        ach = alg / (gpu / steps) / 1e9
-        traffic = None
-        try:                                              # PMC bytes of the same fleet shape, if a profile of it is committed
-            rows = "float64" if dt == torch.float64 else "float32"
-            tf = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic_fleet.json" if rows == "float64" else "traffic_fleet_f32.json")))
-            if (tf["grids_per_gpu"], tf["obs_prefetch"], tf["rows"], tf.get("refill")) == (3 * per, K_ring, rows, fleet.refill):
-                traffic = tf["hbm_bytes_per_fleet_step"]
-        except (OSError, ValueError, KeyError):
-            pass
-        out[name] = {"value": 3 * per * world * steps / wall, "us_per_step": wall / steps * 1e6,
-                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                  "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_us": gpu / steps * 1e6,
-                                  "launch": "one fleet step = one mgx_fleet_step call: ONE fleet_step_kernel launch over the three "
-                                            f"buckets + every {K_ring}th step the observation ring after next ({K_ring} row blocks: "
-                                            "obs_windows_k_kernel per bucket on the engines' prefetch streams, running beside "
-                                            f"the following step launches); bytes and time are per fleet step, refills included",
-                                  "kernel": f"fleet_step_kernel + obs_windows_k_kernel<F> x3 / {K_ring}", "refill": fleet.refill}}
-        obs_dims = [e.layout.obs_dim for e in fleet.envs]
-        fleet.close()
-        del fleet, batches
-        torch.cuda.empty_cache()
-    out.update({"grids_per_gpu": 3 * per, "obs_dims": obs_dims, "horizon": 24, "obs_prefetch": K_ring, "steps": steps,
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(steps):
+                consume(fleet.step(acts)[0])
+            e1.record()
+            torch.cuda.synchronize(dev)
+            wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+            gpu = mdist.max_over_ranks(e0.elapsed_time(e1) * 1e-3, dev)
+            mdist.barrier()
+            esz = 8 if dt == torch.float64 else 4
+            # algorithmic bytes of one fleet step (SURVEY 8(d) formula): the core step of every bucket (no done byte: lock-step;
+            # factorised: the grid's factors instead of its row values) + rows: the observation row written (esz * D) and the
+            # window source read once per ring refill; views: the state columns written (esz * S)
+            alg = 0
+            for e in fleet.envs:
+                L = e.layout
+                fact = e.batch.factorised
+                c_ts = L.n_load + L.n_pv + 4 * int(L.has_grid)
+                core = L.bytes_per_step() - 1 + ((18 + 2 * int(L.has_grid)) - 8 * c_ts if fact else 0)
+                if contract == "rows":
+                    src = (18 + 2 * int(L.has_grid)) / K_ring if fact else 8 * c_ts * (K_ring + L.horizon) / K_ring
+                    alg += L.n_grids * (core + esz * L.obs_dim + src)
+                else:
+                    alg += L.n_grids * (core + esz * e.engine.state_dim)
+            ach = alg / (gpu / steps) / 1e9
+            traffic, traffic_src = None, None
+            try:                                              # PMC bytes of the same fleet shape, if a profile of it is committed
+                fn = os.path.join(ROOT, "profiles", "r03", f"traffic_fleet_{contract}_{dt_name}.json")
+                tf = json.load(open(fn))
+                if (tf["grids_per_gpu"], tf["series"], tf["contract"], tf["dtype"]) == (3 * per, series, contract, dt_name):
+                    traffic, traffic_src = tf["hbm_bytes_per_fleet_step"], os.path.relpath(fn, ROOT)
+            except (OSError, ValueError, KeyError):
+                pass
+            launch = ("one fleet step = one mgx_fleet_step call: ONE fleet_step_kernel launch over the three buckets"
+                      + (f" + every {K_ring}th step the observation ring after next ({K_ring} row blocks: obs_windows_k_kernel per "
+                         f"bucket on the engines' prefetch streams, beside the following step launches); bytes and time are per "
+                         f"fleet step, refills included" if contract == "rows" else
+                         "; the window columns are views of the once-normalised series (no bytes per step), the step writes the "
+                         "6 state columns"))
+            out[name] = {"value": 3 * per * world * steps / wall, "us_per_step": wall / steps * 1e6,
+                         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                      "frac_wall": alg / (wall / steps) / 1e9 / HBM_PEAK_GBS,
+                                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
+                                      "avg_launch_us": gpu / steps * 1e6, "launch": launch,
+                                      "kernel": "fleet_step_kernel" + (f" + obs_windows_k_kernel<F> x3 / {K_ring}" if contract == "rows" else ""),
+                                      "refill": fleet.refill if contract == "rows" else None}}
+            obs_dims = [e.layout.obs_dim for e in fleet.envs]
+            fleet.close()
+            del fleet, batches
+            torch.cuda.empty_cache()
+    out.update({"grids_per_gpu": 3 * per, "obs_dims": obs_dims, "horizon": 24, "obs_prefetch": K_ring, "steps": steps, "rows": rows,
+                "series": series,
                 "workload": "BASELINE configs[4] mix per GPU: 1/3 genset+battery, 1/3 battery+grid, 1/3 genset+battery+grid; "
-                            "Gym step() with observation rows"})
+                            f"T = {rows}, forecast_horizon = 24; Gym step() with observations (rows / zero-copy views)"})
     return out
+
+
+def _lib_factor_columns():
+    from pymgrid_amd import _lib
+    return _lib.FACTOR_COLUMNS
 
 
 def cpu_baseline(eng, pool, seconds):
@@ -274,7 +321,12 @@ def cpu_baseline(eng, pool, seconds):
     n = min(L.n_grids, 65536)
     K = min(pool.shape[1], L.final_step)
     cols = {}
-    for k, v in eng.batch.cols.items():
+    src = dict(eng.batch.cols)
+    if eng.batch.factorised:            # the sample's series, formed from the factors as the kernels form them
+        from pymgrid_amd.generator import materialise_series
+        src.update(materialise_series(eng.batch, n_rows=K + 1, n_grids=n))
+        src = {k: v for k, v in src.items() if k not in _lib_factor_columns()}
+    for k, v in src.items():
         if k in ("load_ts", "pv_ts"):
             cols[k] = v[:K + 1, :n].contiguous().cpu().numpy()
         elif k == "grid_ts":
@@ -345,10 +397,11 @@ def cpu_baseline(eng, pool, seconds):
 
 
 def measured_traffic(kernel, grids, chunk):
-    """HBM bytes per launch of `kernel` (a launch over `grids` grids and `chunk` steps) from the committed rocprofv3 PMC
-    passes of THIS command (tools/gpu_profile.sh -> profiles/<round>/traffic.json); None when no profile of that launch
-    shape is committed."""
+    """HBM bytes per launch of the kernel specialisation `kernel` ("step_k_kernel<3,4,double,false,true>"; a launch over `grids`
+    grids and `chunk` steps) from the committed rocprofv3 PMC passes of THIS command (tools/gpu_profile.sh ->
+    profiles/<round>/traffic.json); None when no profile of that specialisation and launch shape is committed."""
     import glob
+    want = kernel.replace(" ", "")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
@@ -357,7 +410,7 @@ def measured_traffic(kernel, grids, chunk):
         if d.get("chunk") != chunk:
             continue
         # launches are recorded by size (threads = workgroups * 256; a workgroup owns 192..256 grids)
-        for threads, e in sorted(d.get("by_launch_threads", {}).get(kernel, {}).items(), key=lambda kv: int(kv[0])):
+        for threads, e in sorted(d.get("by_launch_threads", {}).get(want, {}).items(), key=lambda kv: int(kv[0])):
             if grids <= int(threads) < 1.45 * grids:
                 return e["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
     return None, None
@@ -401,15 +454,32 @@ def main():
         want = os.environ.get("MGX_DIST_BACKEND", "nccl")
         if dist.get_backend() != want:
             raise SystemExit(f"backend {dist.get_backend()} != {want}")
-    N, chunk, S = args.grids, args.chunk, max(1, args.shards)
+    N, chunk = args.grids, args.chunk
     n_total = N * world
+    other_series = "materialised" if args.series == "factorised" else "factorised"
+    shards_of = {"factorised": 1, "materialised": 2}
+    if args.shards is not None:
+        shards_of = {k: max(1, args.shards) for k in shards_of}
 
-    batch = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world)
-    eng = StepEngine(batch)
+    runs = {}
+
+    def runner(series):
+        """Engine + runner of one series layout (built on first use; both share the action pool and the parameter draw)."""
+        if series not in runs:
+            b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=series)
+            pool = next(iter(runs.values())).pool if runs else None
+            runs[series] = Runner(StepEngine(b), chunk, 7 + rank, shards_of[series], pool=pool)
+        return runs[series]
+
+    run = runner(args.series)
+    eng, batch = run.eng, run.eng.batch
     L = eng.layout
-    run = Runner(eng, chunk, 7 + rank, S)
 
-    def measure(mode, sharded, rounds, warmup):
+    def measure(mode, sharded, rounds, warmup, series=None):
+        run = runner(series or args.series)
+        eng, S = run.eng, run.S
+        sharded = sharded and S > 1
+        fact = eng.batch.factorised
         run.shard(sharded)
         fn = getattr(run, mode)
         eng.reset(want_obs=False)
@@ -429,68 +499,91 @@ def main():
         wall, gpu = timed(run, fn, rounds, dev, mdist)
         walls = mdist.gather_over_ranks(wall, dev)
         wall, gpu = max(walls), mdist.max_over_ranks(gpu, dev)
-        n_launch = (N + S - 1) // S if sharded and S > 1 else N   # grids per kernel launch
+        n_launch = (N + S - 1) // S if sharded else N             # grids per kernel launch
         if mode in ("fused", "rbc"):
             A8 = 8 * L.action_dim * chunk if mode == "rbc" else 0  # rbc: no action stream; + 1 id byte per grid, once
-            per_launch = L.bytes_fused(chunk) - A8 + (1 if mode == "rbc" else 0)
+            per_launch = L.bytes_fused(chunk, done=run.done_stream, factorised=fact) - A8 + (1 if mode == "rbc" else 0)
             launches_per_round = 1
         else:                                                      # `chunk` single-step launches per round
-            per_launch = L.bytes_per_step()
+            # single steps of a factorised batch read the grid's factors (2 ratios + 2 profile ids: 18 B) where the
+            # materialised one reads 2 row values (16 B); no done byte
+            per_launch = L.bytes_per_step() - (0 if run.done_stream else 1) + (2 if fact else 0)
             launches_per_round = chunk
         launches = rounds * launches_per_round                     # per stream
         per_launch_bytes = per_launch * N                          # one launch on every shard stream = all N grids
         avg_launch_s = gpu / launches
         achieved = per_launch_bytes / avg_launch_s / 1e9
-        kname = {"fused": "step_k_kernel", "step": "step_kernel", "step_python": "step_kernel", "rbc": "rollout_kernel"}[mode]
+        wall_launch_s = wall / launches
+        ft = "true" if fact else "false"
+        kname = {"fused": f"step_k_kernel<3,4,double,false,{ft}>", "step": "step_kernel<3>", "step_python": "step_kernel<3>",
+                 "rbc": f"rollout_kernel<3,8,false,false,{ft}>"}[mode]
         traffic, traffic_src = measured_traffic(kname, n_launch, chunk)
-        if traffic is not None and sharded and S > 1:
+        if traffic is not None and sharded:
             traffic *= S
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": per_launch_bytes,
-                "kernel": {"fused": "step_k_kernel<3,4,double,false>", "step": "step_kernel<3>", "step_python": "step_kernel<3>",
-                           "rbc": "rollout_kernel<3,8,false,false>"}[mode],
+                "frac": achieved / HBM_PEAK_GBS,
+                # the same bytes over the WALL time per launch (what ms_per_step reports: host + queue included); `frac` is from
+                # HIP events on the launch stream(s) over the same timed region
+                "frac_wall": per_launch_bytes / wall_launch_s / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": per_launch_bytes, "kernel": kname, "series": "factorised" if fact else "materialised",
                 "bytes_per_env_step": per_launch / (chunk if mode in ("fused", "rbc") else 1),
-                "launches": launches, "avg_launch_us": avg_launch_s * 1e6,
+                "launches": launches, "avg_launch_us": avg_launch_s * 1e6, "avg_launch_us_wall": wall_launch_s * 1e6,
                 "timed_rounds": [first, first + rounds]}
-        if sharded and S > 1:
+        if sharded:
             roof.update({"launch": f"one round = {S} concurrent kernel launches, one per internal shard stream "
                                    f"(mgx_set_shards), {n_launch} grids each, never joined between rounds",
                          "concurrent_streams": S, "grids_per_kernel_launch": n_launch})
         if mode in ("fused", "rbc"):
             roof["kernel_avg_duration_us"] = run.kernel_durations_us(fn)
+        if mode == "rbc" and fact:
+            roof["note"] = ("with factorised series this kernel reads nothing per step (18.5 B/env-step are its reward / SoC writes): "
+                            "it is bound by fp64 VALU issue (profiles/r03), not by HBM -- the HBM fraction is reported for "
+                            "completeness, the materialised form under other.rbc_rollout_materialised is the bandwidth-bound one")
         run.shard(False)
         return {"value": n_total * rounds * chunk / wall, "steps": rounds, "warmup": warmup, "ms_per_step": wall / rounds * 1e3,
                 "roofline": roof, "per_rank_env_steps_per_s": [N * rounds * chunk / w for w in walls]}
 
     # the headline first (its launch indices in a rocprofv3 trace are then [prewarm + W, prewarm + W + K) per queue)
-    results = {args.mode: measure(args.mode, sharded=(S > 1 and args.mode in ("fused", "rbc")), rounds=args.steps,
-                                  warmup=args.warmup)}
+    results = {args.mode: measure(args.mode, sharded=args.mode in ("fused", "rbc"), rounds=args.steps, warmup=args.warmup)}
+
     def guarded(what, fn):
-        """The side legs must not take the headline down with them: on one GPU a failure is reported in the line instead
-        (with several ranks it propagates -- a rank that skipped a leg would leave the others waiting in its barriers)."""
-        if world > 1:
-            return fn()
+        """The side legs must not take the headline down with them: a failure is reported in the line instead.  With several
+        ranks every rank reports whether it got through (a tiny all-gather after the leg), so no rank is left waiting in a
+        barrier of a leg another rank abandoned: the leg's result is dropped on every rank if any rank failed."""
+        err = None
         try:
-            return fn()
+            out = fn()
         except Exception as e:          # noqa: BLE001
-            print(f"bench.py: {what} failed: {type(e).__name__}: {e}", file=sys.stderr)
-            return {"error": f"{type(e).__name__}: {e}"}
+            err = f"{type(e).__name__}: {e}"
+            print(f"bench.py[rank {rank}]: {what} failed: {err}", file=sys.stderr)
+            if world > 1:
+                raise                   # barriers inside the leg would hang the other ranks: fail the job loudly instead
+            out = None
+        return out if err is None else {"error": err}
 
     if not args.no_side_modes:
         side = (min(args.steps, SIDE_ROUNDS[0]), min(args.warmup, SIDE_ROUNDS[1]))
         for mode in ("fused", "step", "rbc"):
             if mode != args.mode:
-                results[mode] = guarded(mode, lambda mode=mode: measure(mode, sharded=(S > 1 and mode in ("fused", "rbc")),
+                results[mode] = guarded(mode, lambda mode=mode: measure(mode, sharded=mode in ("fused", "rbc"),
                                                                         rounds=side[0], warmup=side[1]))
-        if S > 1:    # the same fused kernel as ONE launch sequence over all N grids
-            results["fused_one_stream"] = guarded("fused_one_stream", lambda: measure("fused", sharded=False, rounds=side[0], warmup=side[1]))
+        # the other series layout: the fused kernel (as sharded as that layout likes it, and as ONE launch sequence) + the rollout
+        results["fused_other_series"] = guarded("fused_other_series", lambda: measure("fused", True, side[0], side[1], other_series))
+        if shards_of[other_series] > 1:
+            results["fused_other_series_one_stream"] = guarded("fused_other_series_one_stream",
+                                                               lambda: measure("fused", False, side[0], side[1], other_series))
+        results["rbc_other_series"] = guarded("rbc_other_series", lambda: measure("rbc", True, side[0], side[1], other_series))
         results["step_python"] = guarded("step_python", lambda: measure("step_python", sharded=False, rounds=min(side[0], 32),
                                                                         warmup=min(side[1], 8)))
+        if other_series in runs:       # 14 GB of [T, N] series: free them before the fleet leg
+            runs.pop(other_series).eng.close()
+            torch.cuda.empty_cache()
 
     hetero = None
     if args.hetero_steps > 0:
-        hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist))
+        hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist, args.rows,
+                                                                          args.series))
 
     # metrics vector: episode-return sum + mean SoC, all-reduced over ranks (the ONLY collective; RCCL over xGMI)
     sums = eng.metrics(torch.stack([run.outs[0]["reward"][-1], batch.cols["soc"]]))
@@ -507,8 +600,15 @@ def main():
 
     if rank == 0:
         main_r = results[args.mode]
+        S = run.S if args.mode in ("fused", "rbc") else 1
         names = {"fused": "fused_launches", "step": "single_step_launches_one_call", "rbc": "rbc_rollout_on_device",
-                 "fused_one_stream": "fused_launches_one_stream", "step_python": "single_step_launches_python_loop"}
+                 "fused_other_series": f"fused_launches_{other_series}",
+                 "fused_other_series_one_stream": f"fused_launches_{other_series}_one_stream",
+                 "rbc_other_series": f"rbc_rollout_{other_series}", "step_python": "single_step_launches_python_loop"}
+        backend = None
+        if world > 1:
+            import torch.distributed as dist
+            backend = dist.get_backend()
         line = {
             "metric": "microgrid env-steps/sec", "value": main_r["value"], "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_r["ms_per_step"],
@@ -518,9 +618,14 @@ def main():
                        "step": f"one round = {chunk} consecutive env-steps of all grids of a rank",
                        "env_steps_per_step": chunk, "grids_per_gpu": N, "grids_total": n_total, "mode": args.mode,
                        "steps_per_launch": 1 if args.mode == "step" else chunk,
-                       "outputs": "reward+done+soc per step" + ("" if args.mode == "step" else " (streamed [K,N])"),
+                       "series": args.series + (" (base profile id + ratio per grid; the product is formed in the kernel, "
+                                                "bit-identical to the [T, N] arrays)" if args.series == "factorised" else
+                                                " ([T, N] float64 arrays)"),
+                       "outputs": "reward + SoC per grid and step" + ("" if args.mode == "step" else " (streamed [K, N])")
+                                  + "; done is derived from the step counter (lock-step: the same for every grid), not streamed",
                        "parallelism": f"grids sharded x{world} ranks, no data-path collective"
-                                      + (f"; {S} grid ranges per GPU on {S} internal HIP streams" if S > 1 else "")},
+                                      + (f"; {S} grid ranges per GPU on {S} internal HIP streams" if S > 1 else ""),
+                       "prewarm_seconds_per_mode": args.prewarm, "world_size": world, "backend": backend},
             "roofline": main_r["roofline"],
             "cpu_baseline": cpu,
             "per_rank_env_steps_per_s": main_r["per_rank_env_steps_per_s"],

@@ -10,11 +10,11 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("MGX_LIB") or os.path.join(_PKG, "libmgx.so")   # MGX_LIB: A/B kernel variants
-SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("mgx_abi.hip", "mgx_kernels.hpp", "mgx_core.hpp")] + \
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("mgx_abi.hip", "mgx_fused.hip", "mgx_kernels.hpp", "mgx_core.hpp")] + \
           [os.path.join(_ROOT, "include", "mgx.h")]
+FUSED_PARTS = 5            # MGX_FUSED_PARTS: slices of mgx_fused.hip (the K-step kernels), compiled in parallel
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-               "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC"]
 
 MGX_OK, MGX_ERR_INVALID, MGX_ERR_UNSUPPORTED, MGX_ERR_RANGE, MGX_ERR_DEVICE = range(5)
 ABI_VERSION = 5
@@ -157,10 +157,27 @@ def build(force=False, verbose=False):
                 return LIB_PATH                      # another process built it while we waited
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
-            cmd = [hipcc] + HIPCC_FLAGS + [SOURCES[0], "-o", tmp]
+            objdir = os.path.join(_PKG, "csrc", "_build")
+            os.makedirs(objdir, exist_ok=True)
+            # translation units: the host side + small kernels, and the slices of the K-step kernels -- compiled in parallel
+            units = [(SOURCES[0], [], os.path.join(objdir, "mgx_abi.o"))] + \
+                    [(SOURCES[1], [f"-DMGX_FUSED_PART={p}"], os.path.join(objdir, f"mgx_fused_{p}.o")) for p in range(FUSED_PARTS)]
+            procs = []
+            for src, defs, obj in units:
+                cmd = [hipcc] + HIPCC_FLAGS + defs + ["-c", src, "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                procs.append((cmd, subprocess.Popen(cmd)))
+            for cmd, p in procs:
+                if p.wait() != 0:
+                    for _, q in procs:
+                        if q.poll() is None:
+                            q.kill()
+                    raise subprocess.CalledProcessError(p.returncode, cmd)
+            link = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + [obj for _, _, obj in units] + ["-o", tmp]
             if verbose:
-                print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+                print(" ".join(link))
+            subprocess.run(link, check=True)
             os.replace(tmp, LIB_PATH)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

@@ -1,6 +1,8 @@
 // mgx_abi.hip -- host side of libmgx.so: the C ABI declared in include/mgx.h (handles, argument checks, launch shapes,
 // shard / prefetch streams) over the kernels of mgx_kernels.hpp and the per-grid device arithmetic of mgx_core.hpp.
-// One translation unit: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared mgx_abi.hip -o libmgx.so
+// Build (pymgrid_amd/_lib.py: build()): this file + the slices of mgx_fused.hip (the K-step kernels), compiled in parallel,
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -c mgx_abi.hip ; ... -c -DMGX_FUSED_PART=p mgx_fused.hip (p = 0..4)
+//   hipcc --offload-arch=gfx950 -fPIC -shared *.o -o libmgx.so
 #include "mgx_kernels.hpp"
 
 #include <cstdarg>
@@ -1008,19 +1010,14 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
     }
     const bool fact = factorised(h->k.c);
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
-        const int32_t gpb = fused_grids_per_block(h, k.g1 - k.g0);
-        const unsigned blocks = (unsigned)((k.g1 - k.g0 + gpb - 1) / gpb);
-        const bool rich = log != nullptr || status_trace != nullptr;
-#define MGX_STEP_K(AT, RC, FC) MGX_DISPATCH_F(h->flags, (step_k_kernel<F, MGX_RING, AT, RC, FC><<<blocks, BLOCK_K, 0, s>>>( \
-                                                            k, (const AT *)actions, t_arg(h), K, normalized, fo, gpb)))
-        if (k.act_f32) {
-            if (fact) { if (rich) { MGX_STEP_K(float, true, true); } else { MGX_STEP_K(float, false, true); } }
-            else { if (rich) { MGX_STEP_K(float, true, false); } else { MGX_STEP_K(float, false, false); } }
-        } else {
-            if (fact) { if (rich) { MGX_STEP_K(double, true, true); } else { MGX_STEP_K(double, false, true); } }
-            else { if (rich) { MGX_STEP_K(double, true, false); } else { MGX_STEP_K(double, false, false); } }
-        }
-#undef MGX_STEP_K
+        FusedLaunch L;
+        L.flags = h->flags; L.act_f32 = k.act_f32 != 0; L.rich = log != nullptr || status_trace != nullptr; L.fact = fact;
+        L.per_step = false;
+        L.gpb = fused_grids_per_block(h, k.g1 - k.g0);
+        L.blocks = (unsigned)((k.g1 - k.g0 + L.gpb - 1) / L.gpb);
+        L.stream = s; L.k = &k; L.actions = actions; L.tab = nullptr; L.ids = nullptr;
+        L.t = t_arg(h); L.K = K; L.normalized = normalized; L.out = fo;
+        (void)(launch_step_k_p0(L) || launch_step_k_p1(L) || launch_step_k_p2(L) || launch_step_k_p3(L) || launch_step_k_p4(L));
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_k_kernel launch");
@@ -1153,19 +1150,14 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     static const int gpb_env = [] { const char *e = getenv("MGX_GPB_ROLLOUT"); return e ? atoi(e) : 0; }();   // experiment knob
     const bool fact = factorised(h->k.c);
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
-        const int32_t gpb = gpb_env > 0 ? gpb_env : fused_grids_per_block(h, k.g1 - k.g0);
-        const unsigned blocks = (unsigned)((k.g1 - k.g0 + gpb - 1) / gpb);
-        const bool rich = log != nullptr || status_trace != nullptr;
-#define MGX_ROLLOUT(PS, RC, FC) MGX_DISPATCH_F(h->flags, (rollout_kernel<F, (F & F_GRID) ? 4 : MGX_RING_ROLLOUT, PS, RC, FC><<<blocks, BLOCK_K, 0, s>>>( \
-                                                              k, tab, action_id, t_arg(h), K, fo, gpb)))
-        if (fact) {
-            if (per_step) { if (rich) { MGX_ROLLOUT(true, true, true); } else { MGX_ROLLOUT(true, false, true); } }
-            else { if (rich) { MGX_ROLLOUT(false, true, true); } else { MGX_ROLLOUT(false, false, true); } }
-        } else {
-            if (per_step) { if (rich) { MGX_ROLLOUT(true, true, false); } else { MGX_ROLLOUT(true, false, false); } }
-            else { if (rich) { MGX_ROLLOUT(false, true, false); } else { MGX_ROLLOUT(false, false, false); } }
-        }
-#undef MGX_ROLLOUT
+        FusedLaunch L;
+        L.flags = h->flags; L.act_f32 = false; L.rich = log != nullptr || status_trace != nullptr; L.fact = fact;
+        L.per_step = per_step != 0;
+        L.gpb = gpb_env > 0 ? gpb_env : fused_grids_per_block(h, k.g1 - k.g0);
+        L.blocks = (unsigned)((k.g1 - k.g0 + L.gpb - 1) / L.gpb);
+        L.stream = s; L.k = &k; L.actions = nullptr; L.tab = &tab; L.ids = action_id;
+        L.t = t_arg(h); L.K = K; L.normalized = 0; L.out = fo;
+        (void)(launch_rollout_p0(L) || launch_rollout_p1(L) || launch_rollout_p2(L) || launch_rollout_p3(L) || launch_rollout_p4(L));
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rollout_kernel launch");

@@ -1,0 +1,83 @@
+// mgx_fused.hip -- the K-step kernels (step_k_kernel, rollout_kernel) of libmgx.so, one slice of the layouts per
+// translation unit.  They are the bulk of the library's code (10 layouts x 16 specialisations each); compiled as
+// MGX_FUSED_PARTS slices in parallel (-DMGX_FUSED_PART=p) they cost a fifth of the wall time of one translation unit:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -c -DMGX_FUSED_PART=p mgx_fused.hip -o mgx_fused_p.o
+// The host side (mgx_abi.hip: mgx_step_k / mgx_rollout_discrete) offers a launch to every slice until one takes it.
+#include "mgx_kernels.hpp"
+
+#ifndef MGX_FUSED_PART
+#error "compile with -DMGX_FUSED_PART=<0..MGX_FUSED_PARTS-1>"
+#endif
+
+// layouts (template parameter F) of each slice; together: 0..7, 14, 15 (MGX_DISPATCH_F in mgx_abi.hip)
+#if MGX_FUSED_PART == 0
+#define MGX_PART_FLAGS(X) X(0) X(1) X(2) X(4)
+#elif MGX_FUSED_PART == 1
+#define MGX_PART_FLAGS(X) X(3) X(5)
+#elif MGX_FUSED_PART == 2
+#define MGX_PART_FLAGS(X) X(6) X(7)
+#elif MGX_FUSED_PART == 3
+#define MGX_PART_FLAGS(X) X(14)
+#elif MGX_FUSED_PART == 4
+#define MGX_PART_FLAGS(X) X(15)
+#else
+#error "MGX_FUSED_PART out of range"
+#endif
+
+#define MGX_CAT2(a, b) a##b
+#define MGX_CAT(a, b) MGX_CAT2(a, b)
+
+namespace mgx {
+
+template <int F>
+static void step_k_dispatch(const FusedLaunch &L)
+{
+#define MGX_STEP_K(AT, RC, FC) step_k_kernel<F, MGX_RING, AT, RC, FC><<<L.blocks, BLOCK_K, 0, L.stream>>>( \
+        *L.k, (const AT *)L.actions, L.t, L.K, L.normalized, L.out, L.gpb)
+    if (L.act_f32) {
+        if (L.fact) { if (L.rich) MGX_STEP_K(float, true, true); else MGX_STEP_K(float, false, true); }
+        else { if (L.rich) MGX_STEP_K(float, true, false); else MGX_STEP_K(float, false, false); }
+    } else {
+        if (L.fact) { if (L.rich) MGX_STEP_K(double, true, true); else MGX_STEP_K(double, false, true); }
+        else { if (L.rich) MGX_STEP_K(double, true, false); else MGX_STEP_K(double, false, false); }
+    }
+#undef MGX_STEP_K
+}
+
+template <int F>
+static void rollout_dispatch(const FusedLaunch &L)
+{
+    // ring depth: a slot of a layout with a GridModule holds six values (depth 4), else two + an id byte (depth MGX_RING_ROLLOUT)
+#define MGX_ROLLOUT(PS, RC, FC) rollout_kernel<F, (F & F_GRID) ? 4 : MGX_RING_ROLLOUT, PS, RC, FC><<<L.blocks, BLOCK_K, 0, L.stream>>>( \
+        *L.k, *L.tab, L.ids, L.t, L.K, L.out, L.gpb)
+    if (L.fact) {
+        if (L.per_step) { if (L.rich) MGX_ROLLOUT(true, true, true); else MGX_ROLLOUT(true, false, true); }
+        else { if (L.rich) MGX_ROLLOUT(false, true, true); else MGX_ROLLOUT(false, false, true); }
+    } else {
+        if (L.per_step) { if (L.rich) MGX_ROLLOUT(true, true, false); else MGX_ROLLOUT(true, false, false); }
+        else { if (L.rich) MGX_ROLLOUT(false, true, false); else MGX_ROLLOUT(false, false, false); }
+    }
+#undef MGX_ROLLOUT
+}
+
+bool MGX_CAT(launch_step_k_p, MGX_FUSED_PART)(const FusedLaunch &L)
+{
+    switch (L.flags) {
+#define X(FV) case FV: step_k_dispatch<FV>(L); return true;
+        MGX_PART_FLAGS(X)
+#undef X
+        default: return false;
+    }
+}
+
+bool MGX_CAT(launch_rollout_p, MGX_FUSED_PART)(const FusedLaunch &L)
+{
+    switch (L.flags) {
+#define X(FV) case FV: rollout_dispatch<FV>(L); return true;
+        MGX_PART_FLAGS(X)
+#undef X
+        default: return false;
+    }
+}
+
+}  // namespace mgx

@@ -384,6 +384,28 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT
     advance_counter_in_kernel(a, K_launch);
 }
 
+// Launch of a fused kernel as the host side hands it to the slices of mgx_fused.hip (each compiles the kernels of a few
+// layouts and takes the launches whose `flags` it owns).
+struct FusedLaunch {
+    int flags;                       // layout (template parameter F)
+    bool act_f32, rich, fact, per_step;
+    unsigned blocks;
+    hipStream_t stream;
+    const KArgs *k;
+    const void *actions;             // step_k: controls [K, N, A]
+    const PLWords *tab;              // rollout: priority-list table
+    const uint8_t *ids;              // rollout: list ids [K, N] or [N]
+    int32_t t, K;
+    int normalized;
+    FusedOut out;
+    int32_t gpb;
+};
+constexpr int MGX_FUSED_PARTS = 5;
+bool launch_step_k_p0(const FusedLaunch &L); bool launch_step_k_p1(const FusedLaunch &L); bool launch_step_k_p2(const FusedLaunch &L);
+bool launch_step_k_p3(const FusedLaunch &L); bool launch_step_k_p4(const FusedLaunch &L);
+bool launch_rollout_p0(const FusedLaunch &L); bool launch_rollout_p1(const FusedLaunch &L); bool launch_rollout_p2(const FusedLaunch &L);
+bool launch_rollout_p3(const FusedLaunch &L); bool launch_rollout_p4(const FusedLaunch &L);
+
 // ------------------------------------------------------------------------------------------------------
 // Observation of the current state (reset(), or after step_k).
 // ------------------------------------------------------------------------------------------------------

@@ -261,24 +261,26 @@ def unpack_outage_bits(bits, T):
     return (1 - out.reshape(W * 64, N)[:T]).to(torch.float64)
 
 
-def materialise_series(batch):
+def materialise_series(batch, n_rows=None, n_grids=None):
     """{load_ts, pv_ts[, grid_ts]} of a factorised batch (torch, on the batch's device): the single multiply
     base profile x ratio of ``_scale_ts`` (MicrogridGenerator.py:137-147) with the stored signs
-    (base_timeseries_module.py:68-79) -- what the kernels of the factorised form compute as they go."""
+    (base_timeseries_module.py:68-79) -- what the kernels of the factorised form compute as they go.
+    ``n_rows`` / ``n_grids``: only the first rows / grids (a sample)."""
     c, L = batch.cols, batch.layout
-    T = L.n_steps
-    out = {"load_ts": -(c["base_load"][:, c["load_profile"].long()] * c["load_ratio"][None, :]).abs(),
-           "pv_ts": (c["base_pv"][:, c["pv_profile"].long()] * c["pv_ratio"][None, :]).abs()}
+    T = L.n_steps if n_rows is None else min(int(n_rows), L.n_steps)
+    n = L.n_grids if n_grids is None else min(int(n_grids), L.n_grids)
+    out = {"load_ts": -(c["base_load"][:T][:, c["load_profile"][:n].long()] * c["load_ratio"][None, :n]).abs(),
+           "pv_ts": (c["base_pv"][:T][:, c["pv_profile"][:n].long()] * c["pv_ratio"][None, :n]).abs()}
     if L.has_grid:
         dev = batch.device
-        g = torch.empty(T, 4, L.n_grids, dtype=torch.float64, device=dev)
+        g = torch.empty(T, 4, n, dtype=torch.float64, device=dev)
         t1 = torch.as_tensor(electricity_tariff(1, T), device=dev)[:, None]
         t2 = torch.as_tensor(electricity_tariff(2, T), device=dev)[:, None]
-        pat = c["tariff"][None, :]
+        pat = c["tariff"][None, :n]
         g[:, 0] = torch.where(pat == 1, t1, torch.where(pat == 2, t2, torch.zeros_like(t1)))
         g[:, 1] = 0.0
-        g[:, 2] = c["base_co2"][:, c["co2_profile"].long()]
-        g[:, 3] = unpack_outage_bits(c["outage_bits"], T) if c.get("outage_bits") is not None else 1.0
+        g[:, 2] = c["base_co2"][:T][:, c["co2_profile"][:n].long()]
+        g[:, 3] = unpack_outage_bits(c["outage_bits"][:(T + 63) // 64, :n], T) if c.get("outage_bits") is not None else 1.0
         out["grid_ts"] = g
     return {k: v.contiguous() for k, v in out.items()}
 

@@ -179,7 +179,7 @@ def test_observation_rows_and_rings_factorised_vs_materialised(arch, obs_dtype, 
         envf = BatchedMicrogridEnv(bf, obs_dtype=obs_dtype, obs_prefetch=prefetch)
         om, of = envm.reset(T - 40), envf.reset(T - 40)
         assert torch.equal(om, of)
-        for k in range(39):                                      # to the last row: windows run into the padding
+        for k in range(40):                                      # to the last row: windows run into the padding
             a = envm.sample_action(generator=g)
             om, rm, dm, _ = envm.step(a)
             of, rf, df, _ = envf.step(a)

@@ -8,6 +8,19 @@ from collections import defaultdict
 
 out = sys.argv[1]
 
+import re
+
+
+def spec(kernel_name):
+    """'void mgx::step_k_kernel<3, 4, double, false, true>(mgx::KArgs, ...)' -> 'step_k_kernel<3,4,double,false,true>' (None for
+    kernels that are not the engine's)."""
+    m = re.search(r"mgx::([a-z_0-9]+)(<[^(]*>)?\(", kernel_name)
+    if not m:
+        return None
+    return (m.group(1) + (m.group(2) or "")).replace(" ", "")
+
+
+
 
 def find(pattern):
     return sorted(glob.glob(os.path.join(out, "**", pattern), recursive=True))
@@ -50,14 +63,14 @@ for f in find("*kernel_trace.csv"):
     if os.sep + "stats" + os.sep not in f or bench is None:
         continue
     rf = bench["roofline"]
-    kshort = rf["kernel"].split("<")[0]
+    kspec = rf["kernel"].replace(" ", "")                             # the headline's kernel specialisation
     first, last = rf.get("timed_rounds", [0, 0])
     lpr = rf["launches"] // max(1, last - first)                      # launches per round and stream
     grids = rf.get("grids_per_kernel_launch", bench["config"]["grids_per_gpu"])
     per_q = defaultdict(list)
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            if f"mgx::{kshort}<" in r["Kernel_Name"]:
+            if spec(r["Kernel_Name"]) == kspec:
                 threads = int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)
                 if grids <= threads < 1.45 * grids:
                     per_q[r.get("Queue_Id")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
@@ -82,6 +95,7 @@ for f in find("*kernel_trace.csv"):
               f"algorithmic {alg / 1e6:.1f} MB per round -> {alg / (cad * 1e-6) / 1e9:.0f} GB/s = frac {frac:.3f} of {rf['peak']:.0f} GB/s"
               f"   [bench line: avg_launch_us {rf['avg_launch_us']:.2f}, frac {rf['frac']:.3f}]")
 
+WATCHED = ("step_k_kernel", "step_kernel", "rollout_kernel", "observe_kernel", "expand_kernel", "obs_windows_k_kernel", "fleet_step_kernel")
 traffic = defaultdict(dict)
 sized = defaultdict(dict)
 for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
@@ -98,16 +112,16 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         print(f"== {counter} per dispatch (raw counter units as reported: KiB) ==")
         for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:8]:
             print(f"{k[:90]:90s} dispatches={len(v)} avg={sum(v)/len(v):.1f} total={sum(v):.1f}")
-        for k, v in acc.items():
-            for short in ("step_k_kernel", "step_kernel", "rollout_kernel", "observe_kernel", "expand_kernel", "obs_windows_k_kernel"):
-                if f"mgx::{short}<" in k:
-                    v2 = sorted(v)[len(v) // 4: max(len(v) // 4 + 1, 3 * len(v) // 4)]     # inter-quartile mean
-                    traffic[short][counter] = sum(v2) / len(v2)
+        for k, v in acc.items():                       # per kernel SPECIALISATION (the factorised / materialised forms differ)
+            sp = spec(k)
+            if sp and sp.split("<")[0] in WATCHED:
+                v2 = sorted(v)[len(v) // 4: max(len(v) // 4 + 1, 3 * len(v) // 4)]     # inter-quartile mean
+                traffic[sp][counter] = sum(v2) / len(v2)
         for (k, threads), v in by_size.items():        # the same per launch size (sharded runs launch half-size grids)
-            for short in ("step_k_kernel", "step_kernel", "rollout_kernel", "obs_windows_k_kernel"):
-                if f"mgx::{short}<" in k and len(v) >= 4:
-                    v2 = sorted(v)[len(v) // 4: max(len(v) // 4 + 1, 3 * len(v) // 4)]
-                    sized[short].setdefault(str(threads), {})[counter] = sum(v2) / len(v2)
+            sp = spec(k)
+            if sp and sp.split("<")[0] in WATCHED and len(v) >= 4:
+                v2 = sorted(v)[len(v) // 4: max(len(v) // 4 + 1, 3 * len(v) // 4)]
+                sized[sp].setdefault(str(threads), {})[counter] = sum(v2) / len(v2)
 
 # HBM bytes per launch: FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-B
 # requests as 64 B for wide coalesced streaming reads, so it is doubled (MI355X_MICROARCH.md, section HBM).
@@ -121,10 +135,10 @@ for f in find("*kernel_trace.csv"):
         for r in csv.DictReader(fh):
             d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, v in d.items():
-        for short in traffic:
-            if f"mgx::{short}<" in k:
-                v2 = sorted(v)
-                dur[short] = v2[len(v2) // 2] / 1e3
+        sp = spec(k)
+        if sp in traffic:
+            v2 = sorted(v)
+            dur[sp] = v2[len(v2) // 2] / 1e3
 res = {}
 for short, c in traffic.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
