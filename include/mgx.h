@@ -30,7 +30,8 @@
  *                                           genset(goal_status, energy), battery, grid = the reference's
  *                                           controllable sweep order (module_container.py:355-413)
  *    obs                         [N, D]     D = mgx_obs_dim(); order load(1+H), pv(1+H), genset(4), battery(2),
- *                                           grid(4*(1+H), component-minor)
+ *                                           grid(4*(1+H), component-minor) -- or, with mgx_layout.flat_order = MGX_FLAT_GYM,
+ *                                           battery, genset, grid, load, pv
  *    log                         [L, N]     L = mgx_log_dim(); names from mgx_log_name()
  */
 #ifndef MGX_H
@@ -98,7 +99,17 @@ typedef struct mgx_layout {
      * the general kernels (as do n_load / n_pv != 1): single steps, K-step launches (mgx_step_k, mgx_rollout_lists),
      * observations, priority lists (mgx_expand_lists). */
     int32_t n_genset, n_battery, n_grid;      /* <= MGX_MAX_INSTANCES */
+    /* Order of the module blocks inside a flat observation row (envs/base/base.py:128-163,211-223: the reference flattens
+     * a gym.spaces.Dict built from a plain dict, and gym sorts the keys of such a Dict):
+     *   MGX_FLAT_MODULE (0)  load, pv, genset, battery, grid   (this library's native order)
+     *   MGX_FLAT_GYM    (1)  battery, genset, grid, load, pv   (alphabetical by module name: what a policy trained against the
+     *                        reference with gym <= 0.26 / gymnasium sees)
+     * Only the column BASES of the blocks move (every kernel writes a block at its base): no cost.  One module of every kind
+     * per grid only. */
+    int32_t flat_order;
 } mgx_layout;
+
+enum mgx_flat_order { MGX_FLAT_MODULE = 0, MGX_FLAT_GYM = 1 };
 
 #define MGX_MAX_INSTANCES 8
 

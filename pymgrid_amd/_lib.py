@@ -36,7 +36,8 @@ c_i32_p = C.POINTER(C.c_int32)
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "n_grids", "n_steps", "horizon", "initial_step", "final_step",
-        "has_genset", "has_battery", "has_grid", "n_load", "n_pv", "grid_before_battery", "n_genset", "n_battery", "n_grid")]
+        "has_genset", "has_battery", "has_grid", "n_load", "n_pv", "grid_before_battery", "n_genset", "n_battery", "n_grid",
+        "flat_order")]
 
 
 _F64_COLS = ("bat_min_capacity", "bat_max_capacity", "bat_max_charge", "bat_max_discharge", "bat_efficiency",
@@ -200,7 +201,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.mgx_abi_version() != ABI_VERSION:
             raise ImportError(f"libmgx.so ABI {L.mgx_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
-        assert C.sizeof(Layout) == 60
+        assert C.sizeof(Layout) == 64
         _lib = L
     return _lib
 

@@ -36,8 +36,14 @@ class BatchLayout:
     n_genset: int = -1
     n_battery: int = -1
     n_grid: int = -1
+    # order of the module blocks in a flat observation row: "module" (load, pv, genset, battery, grid) or "gym" (battery,
+    # genset, grid, load, pv: alphabetical by module name -- what the reference's flat observation is under gym's key-sorting
+    # ``Dict``, envs/base/base.py:128-163,211-223).  Column bases only: no kernel cost.
+    flat_order: str = "module"
 
     def __post_init__(self):
+        if self.flat_order not in ("module", "gym"):
+            raise ValueError("flat_order must be 'module' or 'gym'")
         if self.final_step <= 0:
             object.__setattr__(self, "final_step", self.n_steps)
         for kind in ("genset", "battery", "grid"):
@@ -95,35 +101,38 @@ class BatchLayout:
             for j in range(H):
                 names += [f"{c}_forecast_{j}" for c in components]
             return names
+        per_module = {"load": window(["load"]), "pv": window(["renewable"]),
+                      "genset": ["current_status", "goal_status", "steps_until_up", "steps_until_down"],
+                      "battery": ["soc", "current_charge"],
+                      "grid": window(["import_price", "export_price", "co2_per_kwh", "grid_status"])}
         names = []
-        for _ in range(self.n_load):
-            names += window(["load"])
-        for _ in range(self.n_pv):
-            names += window(["renewable"])
-        for _ in range(self.n_genset):
-            names += ["current_status", "goal_status", "steps_until_up", "steps_until_down"]
-        for _ in range(self.n_battery):
-            names += ["soc", "current_charge"]
-        for _ in range(self.n_grid):
-            names += window(["import_price", "export_price", "co2_per_kwh", "grid_status"])
+        for name, n, _ in self._blocks():
+            names += per_module[name] * n
         return names
 
+    def _blocks(self):
+        """(module name, instances, columns per instance) of the flat observation, in ``flat_order``."""
+        w = 1 + self.horizon
+        blocks = [("load", self.n_load, w), ("pv", self.n_pv, w), ("genset", self.n_genset, 4),
+                  ("battery", self.n_battery, 2), ("grid", self.n_grid, 4 * w)]
+        if self.flat_order == "gym":
+            blocks.sort(key=lambda b: b[0])              # gym.spaces.Dict sorts the keys of a plain dict
+        return blocks
+
     def obs_slices(self):
-        """name -> slice of the flat observation (order load, pv, genset, battery, grid)."""
-        w, k, out = 1 + self.horizon, 0, {}
-        for name, n in (("load", self.n_load * w), ("pv", self.n_pv * w), ("genset", 4 * self.n_genset),
-                        ("battery", 2 * self.n_battery), ("grid", 4 * w * self.n_grid)):
+        """name -> slice of the flat observation (``flat_order``: load, pv, genset, battery, grid -- or alphabetical)."""
+        k, out = 0, {}
+        for name, n, width in self._blocks():
             if n:
-                out[name] = slice(k, k + n)
-                k += n
+                out[name] = slice(k, k + n * width)
+                k += n * width
         return out
 
     def obs_instances(self):
         """module name -> list of slices of the flat observation, one per module instance (the reference's nested
         observation: {name: [array per module]}, microgrid.py:316-319)."""
-        w, k, out = 1 + self.horizon, 0, {}
-        for name, n, width in (("load", self.n_load, w), ("pv", self.n_pv, w), ("genset", self.n_genset, 4),
-                               ("battery", self.n_battery, 2), ("grid", self.n_grid, 4 * w)):
+        k, out = 0, {}
+        for name, n, width in self._blocks():
             if n:
                 out[name] = [slice(k + j * width, k + (j + 1) * width) for j in range(n)]
                 k += n * width
@@ -262,6 +271,12 @@ class MicrogridBatch:
                 raise ValueError("all columns must live on one device")
         self.device = dev
 
+    def with_flat_order(self, flat_order):
+        """The same columns (shared, not copied) under a layout whose flat observation rows are in ``flat_order``
+        ("module" / "gym": BatchLayout.flat_order)."""
+        from dataclasses import replace
+        return MicrogridBatch(replace(self.layout, flat_order=flat_order), self.cols, forecast_noise=self.forecast_noise)
+
     @property
     def factorised(self):
         """True when the batch holds its series as base profile x per-grid ratio (``mgx_columns.base_load``, include/mgx.h)
@@ -299,10 +314,10 @@ class MicrogridBatch:
         return cls(layout, cols, forecast_noise=noise)
 
     @classmethod
-    def from_grids(cls, grids, device="cuda"):
+    def from_grids(cls, grids, device="cuda", flat_order="module"):
         """Pack a list of per-microgrid parameter dicts (the vocabulary of ``scenario.load_fixture`` /
         ``tests/golden/make_goldens.py:extract_params``) that share a layout."""
-        arrays, layout = pack_grids(grids)
+        arrays, layout = pack_grids(grids, flat_order=flat_order)
         return cls.from_numpy(layout, arrays, device)
 
     # ------------------------------------------------------------------------------------------------
@@ -330,6 +345,7 @@ class MicrogridBatch:
     def c_layout(self):
         L = _lib.Layout()
         d = asdict(self.layout)
+        d["flat_order"] = {"module": 0, "gym": 1}[self.layout.flat_order]
         for k, v in d.items():
             setattr(L, k, int(v))
         L.struct_size = _lib.C.sizeof(_lib.Layout)
@@ -375,7 +391,7 @@ def grid_series_list(g):
     return list(ts) if isinstance(ts, (list, tuple)) else [ts]
 
 
-def pack_grids(grids):
+def pack_grids(grids, flat_order="module"):
     """list of parameter dicts -> (numpy column dict, BatchLayout).  ``genset`` / ``battery`` / ``grid`` may be lists of
     dicts (several modules of a kind, ``grid_ts`` then a list of [T, 4] arrays): columns [n, N], instance-major."""
     if not grids:
@@ -409,7 +425,7 @@ def pack_grids(grids):
                          initial_step=int(g0.get("initial_step", 0)), final_step=int(g0.get("final_step", 0)),
                          has_genset=has["genset"], has_battery=has["battery"], has_grid=has["grid"],
                          n_load=n_load, n_pv=n_pv, grid_before_battery=grid_first(g0),
-                         n_genset=count["genset"], n_battery=count["battery"], n_grid=count["grid"])
+                         n_genset=count["genset"], n_battery=count["battery"], n_grid=count["grid"], flat_order=flat_order)
     if any(grid_first(g) != layout.grid_before_battery for g in grids if has["grid"] and has["battery"]):
         raise ValueError("all microgrids of a batch must step battery and grid in the same order (bucket them by layout)")
 

@@ -207,7 +207,7 @@ static int launch_observe(const mgx_handle *h, int32_t t, void *obs, hipStream_t
     }
     const int32_t W = 1 + h->k.H, D = h->k.obs_dim;
     WindowPlan plan;
-    plan.grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
+    plan.grid_col_base = h->k.col_grid;
     plan.ld = D | 1;
     plan.group = 16;                                   // grids per wave tile; halve while a tile would not fit the LDS
     const size_t esz = h->k.obs_f32 ? sizeof(float) : sizeof(double);
@@ -249,6 +249,11 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
                     MGX_MAX_INSTANCES, L->n_genset, L->n_battery, L->n_grid);
     if ((n_genset > 0) != (L->has_genset != 0) || (n_battery > 0) != (L->has_battery != 0) || (n_grid > 0) != (L->has_grid != 0))
         return fail(MGX_ERR_INVALID, "mgx_create: n_genset / n_battery / n_grid contradict has_genset / has_battery / has_grid");
+    if (L->flat_order != MGX_FLAT_MODULE && L->flat_order != MGX_FLAT_GYM)
+        return fail(MGX_ERR_INVALID, "mgx_create: unknown flat_order %d", L->flat_order);
+    if (L->flat_order != MGX_FLAT_MODULE && (L->n_load != 1 || L->n_pv != 1 || n_genset > 1 || n_battery > 1 || n_grid > 1))
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_create: flat_order is offered for one module of every kind per grid (permute the rows "
+                                         "of a multi-module layout on your side)");
     const int32_t final_step = L->final_step <= 0 ? L->n_steps : L->final_step;   // base_timeseries_module.py:321-326
     if (final_step > L->n_steps) return fail(MGX_ERR_INVALID, "mgx_create: final_step %d > n_steps %d", final_step, L->n_steps);
     if (L->initial_step < 0 || L->initial_step >= final_step)
@@ -293,6 +298,15 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->k.n_load = L->n_load; h->k.n_pv = L->n_pv;
     h->k.n_genset = n_genset; h->k.n_battery = n_battery; h->k.n_grid = n_grid;
     h->multi = (L->n_load != 1 || L->n_pv != 1 || n_genset > 1 || n_battery > 1 || n_grid > 1);
+    {   // column bases of the module blocks inside a flat observation row
+        const int32_t g4 = 4 * n_genset, b2 = 2 * n_battery, r4 = 4 * w * n_grid;
+        if (L->flat_order == MGX_FLAT_GYM) {               // battery, genset, grid, load, pv
+            h->k.col_bat = 0; h->k.col_gen = b2; h->k.col_grid = b2 + g4; h->k.col_load = b2 + g4 + r4; h->k.col_pv = h->k.col_load + w * L->n_load;
+        } else {                                            // load, pv, genset, battery, grid
+            h->k.col_load = 0; h->k.col_pv = w * L->n_load; h->k.col_gen = w * (L->n_load + L->n_pv); h->k.col_bat = h->k.col_gen + g4;
+            h->k.col_grid = h->k.col_bat + b2;
+        }
+    }
     h->multi_lds = 2 * (size_t)multi_list_capacity(L->n_load, L->n_pv, n_genset, n_battery, n_grid) * BLOCK_MULTI * sizeof(double);
     h->k.log_dim = LC_COMMON_END + LC_GENSET_N * n_genset + LC_BATTERY_N * n_battery + LC_GRID_N * n_grid + 1;
     for (int c = 0; c < LC_COMMON_END; c++) h->log_names.push_back(kCommonNames[c]);
@@ -475,7 +489,7 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (!dev_counter(h) && ahead == 0 && h->t > h->k.T)
         return fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, h->k.T);
     const int32_t W = 1 + h->k.H, R = K + h->k.H, ncomp = 2 + 4 * h->layout.has_grid;
-    plan->grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
+    plan->grid_col_base = h->k.col_grid;
     plan->K = K;
     plan->rp = R;
     plan->bp = (ncomp * (R + K) + 6 * K) | 1;
@@ -539,7 +553,7 @@ int mgx_patch_windows(mgx_handle *h, const uint8_t *mask, int32_t K, void *ring,
     if (int rc = need_obs_bounds(h, "mgx_patch_windows")) return rc;
     if (first_block == K) return MGX_OK;
     const int32_t W = 1 + h->k.H;
-    const int32_t grid_col_base = 2 * W + 4 * h->layout.has_genset + 2 * h->layout.has_battery;
+    const int32_t grid_col_base = h->k.col_grid;
     const unsigned blocks = (unsigned)((h->k.N + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
     const int32_t rows = (K - first_block) + h->k.H;

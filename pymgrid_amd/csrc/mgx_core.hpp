@@ -49,6 +49,8 @@ struct KArgs {
     int32_t obs_state_only;  // obs arguments of step / observe receive ONLY the state columns (windows were prefetched):
                              // 1 = inside full rows [N, D], 2 = as a dense [N, S] array (MGX_OBS_ROWS_STATE_COMPACT)
     int32_t done_bits;       // fused launches write `done` as bit sets ([K, ceil(N / 16)] uint16) instead of bytes
+    // first column of every module's block inside a flat observation row (mgx_layout.flat_order); fast path only
+    int32_t col_load, col_pv, col_gen, col_bat, col_grid;
     int32_t shaper;          // mgx_reward_shaper
     int32_t noise_increase;  // GaussianNoiseForecaster.increase_uncertainty
     uint64_t noise_seed;
@@ -720,7 +722,8 @@ template <int F, typename OT>
 __device__ __forceinline__ void observe_state_cols(const KArgs &a, const Params &p, const State &s,
                                                    OT *__restrict__ obs_row, int first = -1)
 {
-    int k = first < 0 ? 2 * (1 + a.H) : first;        // the state columns follow the load and pv windows
+    // first < 0: inside a flat row, every block at its column base; else genset (4) then battery (2) from column `first`
+    int k = first < 0 ? a.col_gen : first;
     if constexpr (F & F_GENSET) {
         const double su = (double)(p.gen_times & 0xff), wd = (double)((p.gen_times >> 16) & 0xff);
         obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)(s.status & 0xff));
@@ -729,6 +732,7 @@ __device__ __forceinline__ void observe_state_cols(const KArgs &a, const Params 
         obs_row[k++] = (OT)space_norm(0.0, wd, (double)(s.status >> 24));
     }
     if constexpr (F & F_BATTERY) {
+        if (first < 0) k = a.col_bat;
         const double min_soc = p.bat_cmin / p.bat_cmax;
         obs_row[k++] = (OT)space_norm(min_soc, 1.0, s.soc);
         obs_row[k++] = (OT)space_norm(p.bat_cmin, p.bat_cmax, s.charge);
@@ -747,16 +751,16 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
     {
         const double lo = c.load_lo[i], hi = c.load_hi[i];
         const double v = in ? series_component(c, N, 0, tr, i) : 0.0;
-        obs_row[0] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
+        obs_row[a.col_load] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     {
         const double lo = c.pv_lo[i], hi = c.pv_hi[i];
         const double v = in ? series_component(c, N, 1, tr, i) : 0.0;
-        obs_row[1] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
+        obs_row[a.col_pv] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     observe_state_cols<F, OT>(a, p, s, obs_row);
     if constexpr (F & F_GRID) {
-        const int k = 2 + 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
+        const int k = a.col_grid;
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
             const double lo = c.grid_lo[cc * N + i], hi = c.grid_hi[cc * N + i];
@@ -764,6 +768,18 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
             obs_row[k + cc] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
         }
     }
+}
+
+// Which series component / horizon step -- or which state value -- observation column `col` shows (W = 1 + H):
+// comp 0 load, 1 pv, 2..5 the grid components; 0xffff: a state column, h = its index in (genset 4, battery 2) order.
+__device__ __forceinline__ void decode_obs_col(const KArgs &a, bool grid, int32_t col, int32_t W, uint32_t &comp, uint32_t &h)
+{
+    uint32_t c;
+    if ((c = (uint32_t)(col - a.col_load)) < (uint32_t)W) { comp = 0u; h = c; }
+    else if ((c = (uint32_t)(col - a.col_pv)) < (uint32_t)W) { comp = 1u; h = c; }
+    else if (grid && (c = (uint32_t)(col - a.col_grid)) < (uint32_t)(4 * W)) { comp = 2u + (c & 3u); h = c >> 2; }
+    else if (a.n_genset && (c = (uint32_t)(col - a.col_gen)) < 4u) { comp = 0xffffu; h = c; }
+    else { comp = 0xffffu; h = 4u * (a.n_genset != 0) + (uint32_t)(col - a.col_bat); }
 }
 
 // ---- forecast noise: Philox4x32-10 counter-based generator + Box-Muller ------------------------------------

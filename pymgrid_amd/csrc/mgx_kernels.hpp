@@ -469,12 +469,12 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
             window_issue<1>(a.c.pv_ts, N, N, tr, hb, Q, (uint32_t)(q * N + ic), vp);
             if constexpr (F & F_GRID) window_issue<4>(a.c.grid_ts, N, 4 * N, tr, hb, Q, (uint32_t)(q * 4 * N + ic), vg);
             if (hb == 0) window_bounds_finish<1>(bl);
-            window_finish<1, NOISE, OT>(vl, bl, W, t, hb, i, ic, q, Q, row, a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
+            window_finish<1, NOISE, OT>(vl, bl, W, t, hb, i, ic, q, Q, row + a.col_load, a.c.load_noise_std, 0u, a.noise_seed, a.noise_increase);
             if (hb == 0) window_bounds_finish<1>(bp);
-            window_finish<1, NOISE, OT>(vp, bp, W, t, hb, i, ic, q, Q, row + W, a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase);
+            window_finish<1, NOISE, OT>(vp, bp, W, t, hb, i, ic, q, Q, row + a.col_pv, a.c.pv_noise_std, 1u, a.noise_seed, a.noise_increase);
             if constexpr (F & F_GRID) {
                 if (hb == 0) window_bounds_finish<4>(bg);
-                window_finish<4, NOISE, OT>(vg, bg, W, t, hb, i, ic, q, Q, row + plan.grid_col_base, a.c.grid_noise_std, 2u,
+                window_finish<4, NOISE, OT>(vg, bg, W, t, hb, i, ic, q, Q, row + a.col_grid, a.c.grid_noise_std, 2u,
                                         a.noise_seed, a.noise_increase);
             }
         }
@@ -483,26 +483,26 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
         load_factors<F>(a.c, ic, f);
         const mgx_columns &c = a.c;
         observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return fact_load(c.base_load[(int64_t)r * PP + f.lp], f.lr); }, N,
-                                          a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row, a.c.load_noise_std, 0u,
+                                          a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row + a.col_load, a.c.load_noise_std, 0u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
         observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return fact_pv(c.base_pv[(int64_t)r * PP + f.pp], f.pr); }, N,
-                                          a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + W, a.c.pv_noise_std, 1u,
+                                          a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + a.col_pv, a.c.pv_noise_std, 1u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
         if constexpr (F & F_GRID)
             observe_window_cols<4, NOISE, OT>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic); }, N,
-                                              a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q, row + plan.grid_col_base,
+                                              a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q, row + a.col_grid,
                                               a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
     } else {
         const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
         observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return lts[(int64_t)r * N + ic]; }, N,
-                                          a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row, a.c.load_noise_std, 0u,
+                                          a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row + a.col_load, a.c.load_noise_std, 0u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
         observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return pts[(int64_t)r * N + ic]; }, N,
-                                          a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + W, a.c.pv_noise_std, 1u,
+                                          a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + a.col_pv, a.c.pv_noise_std, 1u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
         if constexpr (F & F_GRID)
             observe_window_cols<4, NOISE, OT>([&](int32_t r, int cc) { return gts[((int64_t)r * 4 + cc) * N + ic]; }, N,
-                                              a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q, row + plan.grid_col_base,
+                                              a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q, row + a.col_grid,
                                               a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
     }
     if (q == 0) {                                        // the 6 state columns, by the first lane of each grid
@@ -669,10 +669,7 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     }
     for (int32_t col = tid; col < D; col += OBS_K_THREADS) {            // column -> offset of its k = 0 entry in a block
         uint32_t comp, h;
-        if (col < W) { comp = 0; h = col; }
-        else if (col < 2 * W) { comp = 1; h = col - W; }
-        else if (col < plan.grid_col_base) { comp = 0xffffu; h = col - 2 * W; }
-        else { comp = 2u + ((col - plan.grid_col_base) & 3); h = (col - plan.grid_col_base) >> 2; }
+        decode_obs_col(a, GRID, col, W, comp, h);
         map[col] = comp == 0xffffu ? S0 + h * K : (h == 0 ? NU0 + comp * K : comp * RP + h);
     }
     __syncthreads();
@@ -769,11 +766,9 @@ __global__ __launch_bounds__(64) void patch_windows_kernel(const KArgs a, const 
         }
         __syncthreads();
         for (int32_t col = lane; col < D; col += 64) {
-            int comp, h;                                   // which series component / horizon step this column shows
-            if (col < W) { comp = 0; h = col; }
-            else if (col < 2 * W) { comp = 1; h = col - W; }
-            else if (col < grid_col_base) continue;        // state columns
-            else { comp = 2 + ((col - grid_col_base) & 3); h = (col - grid_col_base) >> 2; }
+            uint32_t comp, h;                              // which series component / horizon step this column shows
+            decode_obs_col(a, GRID, col, W, comp, h);
+            if (comp == 0xffffu) continue;                 // state columns
             const double *src = (h == 0 ? nu : nc) + comp * R + h;
             for (int32_t k = first; k < K; k++) ring[((int64_t)k * pitch + g) * D + col] = (OT)src[k - first];
         }
@@ -919,7 +914,7 @@ struct FleetWin {
     int32_t n, first_block;                      // first_block = workgroups of the step part
 };
 
-__global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArgs fa, const FleetWin fw)
+static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArgs fa, const FleetWin fw)
 {
     extern __shared__ double image[];
     if (fw.n > 0 && (int)blockIdx.x >= fw.first_block) {               // ---- window chunk workgroups
@@ -1367,14 +1362,14 @@ __global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a
 }
 
 // one wave that idles for `ticks` of the 100 MHz real-time counter: mgx_fork staggers the shard streams with it
-__global__ void stagger_kernel(int64_t ticks)
+static __global__ void stagger_kernel(int64_t ticks)
 {
     const int64_t t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
 // device-resident step counter (hipGraph-replayable stepping): counter[0] = t, counter[1] = overrun flag
-__global__ void set_counter_kernel(int32_t *counter, int32_t t) { counter[0] = t; counter[1] = 0; counter[2] = 0; }
+static __global__ void set_counter_kernel(int32_t *counter, int32_t t) { counter[0] = t; counter[1] = 0; counter[2] = 0; }
 
 // ------------------------------------------------------------------------------------------------------
 // Metrics: deterministic column sums  sums[m] = sum_i values[m, i].
@@ -1404,7 +1399,7 @@ __device__ __forceinline__ double block_sum(double v, double *lds)
     return r;      // valid in thread 0
 }
 
-__global__ __launch_bounds__(BLOCK) void colsum_stage1(const double *__restrict__ values, int64_t N, int32_t per_block,
+static __global__ __launch_bounds__(BLOCK) void colsum_stage1(const double *__restrict__ values, int64_t N, int32_t per_block,
                                                        double *__restrict__ partial)
 {
     __shared__ double lds[BLOCK / 64];
@@ -1418,7 +1413,7 @@ __global__ __launch_bounds__(BLOCK) void colsum_stage1(const double *__restrict_
     if (threadIdx.x == 0) partial[(int64_t)m * gridDim.x + blockIdx.x] = r;
 }
 
-__global__ __launch_bounds__(BLOCK) void colsum_stage2(const double *__restrict__ partial, int32_t n_partial,
+static __global__ __launch_bounds__(BLOCK) void colsum_stage2(const double *__restrict__ partial, int32_t n_partial,
                                                        double *__restrict__ sums)
 {
     __shared__ double lds[BLOCK / 64];
@@ -1501,7 +1496,7 @@ __device__ __forceinline__ void gather_episode(const GatherArgs &g, int64_t i, i
 // one lane per grid walks its rows (a wave moves 512 contiguous bytes per row when all of its grids take part).  For the
 // sparse restarts of mgx_reset_grids* a variant whose 64 lanes share the rows of each restarting grid was measured SLOWER
 // (36 vs 20 us per step at N = 100 000, one grid in 168 restarting: its accesses are 8 bytes per line)
-__global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs g)
+static __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs g)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= g.N || (g.mask && !g.mask[i])) return;
@@ -1570,7 +1565,7 @@ __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const GatherArgs 
 // index, row), so a shard's draw does not depend on how the batch is split over ranks.
 // ------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(BLOCK) void synthesize_series_kernel(const mgx_synth a)
+static __global__ __launch_bounds__(BLOCK) void synthesize_series_kernel(const mgx_synth a)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.n_grids) return;

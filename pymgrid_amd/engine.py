@@ -47,6 +47,7 @@ class StepEngine:
         self._obs_compact = False
         self._done_bits = False
         self._dev_counter = False
+        self._t = self.layout.initial_step
         self.n_shards = 1
         if batch.forecast_noise is not None:
             self.set_forecast_noise(**batch.forecast_noise)
@@ -244,13 +245,17 @@ class StepEngine:
 
     @property
     def current_step(self):
-        return self._lib.mgx_current_step(self._h)
+        # host mirror of the handle's step counter (every call that moves it goes through this class or, for fleets,
+        # hetero._bump): no C call on the per-step paths.  None = the truth lives on the device (device-counter mode).
+        t = self._t
+        return t if t is not None else self._lib.mgx_current_step(self._h)
 
     def use_device_counter(self, enable=True):
         """Keep the step counter on the device so that step calls can be captured in a HIP graph
         (``torch.cuda.graph``) and replayed; see ``mgx_use_device_counter`` in include/mgx.h."""
         self._call(self._lib.mgx_use_device_counter, 1 if enable else 0)
         self._dev_counter = bool(enable)
+        self._t = None if enable else self._lib.mgx_current_step(self._h)
 
     def set_window(self, initial_step, final_step):
         """Episode window of the next reset (what a trajectory_func returns, microgrid.py:221-225)."""
@@ -273,6 +278,8 @@ class StepEngine:
             self._window_start = None
             self._window_t0 = None
             self.window = self._full_window
+        if self._t is not None:
+            self._t = self.window[0] if initial_step is None else int(initial_step)
         return obs
 
     def _check_episodes(self, start, length, max_length, mask=None):
@@ -330,6 +337,7 @@ class StepEngine:
         self._window_start = start
         self._window_t0 = None
         self.window = (0, int(max_length))
+        self._t = 0
         return obs
 
     def reset_windows_rolling(self, start, length=None, max_length=None, want_obs=True, out=None, validate=True):
@@ -359,6 +367,7 @@ class StepEngine:
         self._window_t0 = torch.zeros_like(start)          # ... and the counter value it started at
         self.window = (0, int(max_length))
         self._rolling_max = int(max_length)
+        self._t = 0
         return obs
 
     def reset_grids(self, mask, start, length=None, validate=True):
@@ -436,6 +445,8 @@ class StepEngine:
         log = (out.get("log") if out.get("log") is not None else self._empty(K, self.log_dim, self.N)) if want_log else None
         self._call(self._lib.mgx_step_many, _ptr(actions), K, 1 if normalized else 0, reward.data_ptr(), _ptr(d), _ptr(obs),
                    _ptr(log))
+        if self._t is not None:
+            self._t += K
         return obs, reward, d, log
 
     def observe(self, out=None):
@@ -464,6 +475,8 @@ class StepEngine:
             log = self._empty(self.log_dim, self.N)
         self._call(self._lib.mgx_step, _ptr(actions), 1 if normalized else 0, reward.data_ptr(), _ptr(done),
                    _ptr(obs), _ptr(log))
+        if self._t is not None:
+            self._t += 1
         return obs, reward, done, log
 
     def step_k(self, actions, normalized=True, reward=True, done=False, soc_trace=False, status_trace=False,
@@ -494,6 +507,8 @@ class StepEngine:
             res["ret_acc"] = ret_acc
         self._call(self._lib.mgx_step_k, _ptr(actions), K, 1 if normalized else 0, _ptr(r), _ptr(d), _ptr(s), _ptr(g),
                    _ptr(ret_acc), _ptr(lg))
+        if self._t is not None:
+            self._t += K
         return res
 
     def _table_ptr(self, table):
@@ -523,6 +538,8 @@ class StepEngine:
                    else self._empty(self.N, self.action_dim)) if want_control else None
         self._call(self._lib.mgx_step_discrete, _ptr(action_id), tptr, n_lists,
                    _ptr(control), reward.data_ptr(), _ptr(done), _ptr(obs), _ptr(log))
+        if self._t is not None:
+            self._t += 1
         return obs, reward, done, log, control
 
     def rollout_discrete(self, action_id, table, K, reward=True, done=False, soc_trace=False, status_trace=False,
@@ -558,6 +575,8 @@ class StepEngine:
             res["ret_acc"] = ret_acc
         self._call(self._lib.mgx_rollout_discrete, _ptr(action_id), per_step, tptr,
                    n_lists, K, _ptr(r), _ptr(d), _ptr(s), _ptr(g), _ptr(ret_acc), _ptr(lg))
+        if self._t is not None:
+            self._t += K
         return res
 
     def rollout_lists(self, action_id, lists, K, reward=True, done=False, soc_trace=False, status_trace=False, ret_acc=None,
@@ -591,6 +610,8 @@ class StepEngine:
             res["ret_acc"] = ret_acc
         self._call(self._lib.mgx_rollout_lists, _ptr(action_id), int(action_id.dim() == 2), _ptr(lists), int(lists.shape[0]),
                    int(lists.shape[1]), K, _ptr(r), _ptr(d), _ptr(s), _ptr(g), _ptr(ret_acc), _ptr(lg))
+        if self._t is not None:
+            self._t += K
         return res
 
     def expand_discrete(self, action_id, table, out=None):

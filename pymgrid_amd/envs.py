@@ -78,8 +78,8 @@ class ObsViews:
         return out
 
     def flat(self):
-        parts = [self.load, self.pv] + [v for v in (self.genset, self.battery, self.grid) if v is not None]
-        return torch.cat(parts, dim=1)
+        parts = {"load": self.load, "pv": self.pv, "genset": self.genset, "battery": self.battery, "grid": self.grid}
+        return torch.cat([parts[name] for name, n, _ in self.layout._blocks() if n], dim=1)      # the layout's flat_order
 
 
 class BatchedMicrogridEnv:
@@ -699,6 +699,17 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
 # ---------------------------------------------------------------------------------------------------------
 # N = 1 adaptors with the reference's exact Python return shapes
 # ---------------------------------------------------------------------------------------------------------
+def _n1_order(params, flat_order):
+    """flat_order of an N = 1 adaptor: "gym" (the reference's flat vector under gym's key-sorting Dict) is offered for one
+    module of every kind; microgrids with several modules of a kind keep the module order."""
+    if flat_order == "gym":
+        many = any(len(module_list(params.get(k))) > 1 for k in ("genset", "battery", "grid")) \
+            or any(np.asarray(params[k]).ndim > 1 and np.asarray(params[k]).shape[1] != 1 for k in ("load_ts", "pv_ts"))
+        if many:
+            raise ValueError("flat_order='gym' is offered for microgrids with one module of every kind")
+    return flat_order
+
+
 class _SingleMixin:
     flat_spaces = True
 
@@ -765,18 +776,78 @@ class _SingleMixin:
         return env
 
     def _nested(self, obs_row):
-        """flat row -> {'load': [arr], 'pv': [arr], 'genset': [arr], 'battery': [arr], 'grid': [arr]}."""
-        return {name: [obs_row[sl].copy() for sl in sls] for name, sls in self.layout.obs_instances().items()}
+        """flat row -> the reference's nested observation (MicrogridStep._obs, microgrid/utils/step.py:13-17): every module
+        name of the microgrid in sweep order (fixed, controllable, flex: microgrid.py:255-314) -> [array per module]; the
+        UnbalancedEnergyModule has an empty observation."""
+        inst = self.layout.obs_instances()
+        out = {}
+        for name in ("load", "genset", "battery", "grid", "pv"):
+            if name in inst:
+                out[name] = [obs_row[sl].copy() for sl in inst[name]]
+        out["unbalanced_energy"] = [np.array([])]
+        return out
 
     def _obs_out(self, obs):
         row = obs[0].cpu().numpy()
         return row if (self.flat_spaces or self._obs_index is not None) else self._nested(row)
 
-    def _info_out(self, info):
+    def _request_signs(self, control, normalized):
+        """Sign of the unnormalised battery / grid requests of a control row [A] (numpy): the reference files a module's energy
+        under 'absorbed_energy' exactly when its unnormalised action is negative (base_module.py:161-170) -- also when the clip
+        leaves nothing of it.  De-normalisation as ModuleSpace does it (space.py:224; bounds battery_module.py:332-338,
+        grid_module.py:125-132), in float64 like the kernels."""
+        L, c, k, out = self.layout, self.batch.cols, 0, {}
+        k += 2 * L.n_genset
+        f = lambda name, j: float(c[name].reshape(-1)[j])
+        for j in range(L.n_battery):
+            x = float(control[k]); k += 1
+            if normalized:
+                lo = -f("bat_max_discharge", j) / f("bat_efficiency", j)
+                sp = f("bat_max_charge", j) * f("bat_efficiency", j) - lo
+                x = lo + (sp if sp != 0.0 else 1.0) * x
+            out[("battery", j)] = x < 0
+        for j in range(L.n_grid):
+            x = float(control[k]); k += 1
+            if normalized:
+                lo = -1 * f("grid_max_export", j)
+                sp = f("grid_max_import", j) - lo
+                x = lo + (sp if sp != 0.0 else 1.0) * x
+            out[("grid", j)] = x < 0
+        return out
+
+    def _info_out(self, info, control=None, normalized=True):
+        """The step's ``info`` in the reference's shape (MicrogridStep._output_info, microgrid/utils/step.py:13-31,48-49):
+        ``{module_name: [info dict per module]}`` with the modules' own keys -- 'absorbed_energy' / 'provided_energy'
+        (load_module.py:89, battery_module.py:122, unbalanced_energy_module.py:34), + 'co2_production' (genset_module.py:211,
+        grid_module.py:138), + 'curtailment' (renewable_module.py:90).  The flat log row of the step ({column: float}, the
+        names of ``engine.log_names``) is kept in ``self.last_log``."""
         if "log" not in info:
+            self.last_log = {}
             return {}
         col = info["log"][:, 0].cpu().numpy()
-        return {name: float(col[j]) for j, name in enumerate(self.engine.log_names)}
+        log = {name: float(col[j]) for j, name in enumerate(self.engine.log_names)}
+        self.last_log = log
+        L = self.layout
+        if L.n_load != 1 or L.n_pv != 1:         # several load / renewable modules: the log holds their sums only
+            return {"log": log}
+        sink = self._request_signs(control, normalized) if control is not None else {}
+        sfx = lambda j: "" if j == 0 else f"[{j}]"
+        out = {"load": [{"absorbed_energy": log["load_met"]}]}
+        if L.has_genset:
+            out["genset"] = [{"provided_energy": log["genset_production" + sfx(j)], "co2_production": log["genset_co2_production" + sfx(j)]}
+                             for j in range(L.n_genset)]
+        if L.has_battery:
+            out["battery"] = [({"absorbed_energy": log["charge_amount" + sfx(j)]} if sink.get(("battery", j), log["charge_amount" + sfx(j)] > 0)
+                               else {"provided_energy": log["discharge_amount" + sfx(j)]}) for j in range(L.n_battery)]
+        if L.has_grid:
+            out["grid"] = [dict(({"absorbed_energy": log["grid_export" + sfx(j)]} if sink.get(("grid", j), log["grid_export" + sfx(j)] > 0)
+                                 else {"provided_energy": log["grid_import" + sfx(j)]}), co2_production=log["grid_co2_production" + sfx(j)])
+                           for j in range(L.n_grid)]
+        out["pv"] = [{"provided_energy": log["renewable_used"], "curtailment": log["curtailment"]}]
+        # difference > 0: the flex sinks absorb the excess, else the flex sources fill the need (microgrid.py:286-314)
+        out["unbalanced_energy"] = [{"absorbed_energy": log["overgeneration"]} if log["overgeneration"] > 0
+                                    else {"provided_energy": log["loss_load"]}]
+        return out
 
 
 class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
@@ -784,8 +855,8 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
     ``(obs, float, bool, dict)`` exactly like envs/base/base.py:169-209."""
 
     def __init__(self, params, device="cuda", flat_spaces=True, log=True, reward_shaping_func=None,
-                 trajectory_func=None, raise_errors=False, observation_keys=None):
-        super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
+                 trajectory_func=None, raise_errors=False, observation_keys=None, flat_order="module"):
+        super().__init__(MicrogridBatch.from_grids([params], device=device, flat_order=_n1_order(params, flat_order)), log=log,
                          reward_shaping_func=reward_shaping_func, trajectory_func=trajectory_func,
                          raise_errors=raise_errors, observation_keys=observation_keys, obs_prefetch=0)
         self.flat_spaces = flat_spaces
@@ -795,8 +866,11 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
         return self._obs_out(super().reset(initial_step))
 
     def step(self, action, normalized=True):
+        if isinstance(action, dict):
+            action = self.control_to_tensor(action).to(self.engine.action_dtype)
         obs, reward, done, info = super().step(action, normalized=normalized)
-        return self._obs_out(obs), float(reward.item()), bool(done.item()), self._info_out(info)
+        return self._obs_out(obs), float(reward.item()), bool(done.item()), \
+            self._info_out(info, action[0].double().cpu().numpy(), normalized)
 
     run = step
 
@@ -826,8 +900,8 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
     ``step(action: int) -> (obs, reward: float, done: bool, info: dict)``."""
 
     def __init__(self, params, device="cuda", flat_spaces=True, log=True, remove_redundant_gensets=True,
-                 reward_shaping_func=None, trajectory_func=None, raise_errors=False, observation_keys=None):
-        super().__init__(MicrogridBatch.from_grids([params], device=device), log=log,
+                 reward_shaping_func=None, trajectory_func=None, raise_errors=False, observation_keys=None, flat_order="module"):
+        super().__init__(MicrogridBatch.from_grids([params], device=device, flat_order=_n1_order(params, flat_order)), log=log,
                          remove_redundant_gensets=remove_redundant_gensets, reward_shaping_func=reward_shaping_func,
                          trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
                          obs_prefetch=0)
@@ -854,8 +928,9 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
     def step(self, action):
         if action not in self.action_space:
             raise ValueError(f" Action {action} not in action space {self.action_space}")
+        control = self.get_action(np.array([int(action)]))[0].cpu().numpy() if self._keep_log else None   # for the info's keys
         obs, reward, done, info = super().step(np.array([int(action)]))
-        return self._obs_out(obs), float(reward.item()), bool(done.item()), self._info_out(info)
+        return self._obs_out(obs), float(reward.item()), bool(done.item()), self._info_out(info, control, False)
 
     def sample_action(self, strict_bound=False, sample_flex_modules=False):
         """DiscreteMicrogridEnv.sample_action (discrete.py:145-146): a random priority-list index."""

@@ -342,7 +342,7 @@ def _factor_columns(dev, T, N, gidx, seed, d, r, P, has_grid):
 
 
 def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, device="cuda", rank=0, world=1,
-             mixed_timers=False, final_step=0, select=None, series="materialised"):
+             mixed_timers=False, final_step=0, select=None, series="materialised", flat_order="module"):
     """Build the [rank]-th shard of a global batch of ``n_grids`` microgrids of architecture ``arch`` on ``device``.
     ``select``: optional global indices (numpy int array, ascending) -- the grids of the global draw to build instead of
     the rank's contiguous block (``generate_fleet`` uses it to split one draw by architecture).
@@ -401,7 +401,7 @@ def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, d
             cols["grid_ts"] = grid_ts
             cols["grid_lo"] = grid_ts.amin(dim=0).contiguous(); cols["grid_hi"] = grid_ts.amax(dim=0).contiguous()
     layout = BatchLayout(n_grids=N, n_steps=T, horizon=horizon, initial_step=0, final_step=final_step,
-                         has_genset=has_genset, has_battery=has_battery, has_grid=has_grid)
+                         has_genset=has_genset, has_battery=has_battery, has_grid=has_grid, flat_order=flat_order)
     return MicrogridBatch(layout, {k: v.contiguous() for k, v in cols.items()})
 
 

@@ -242,6 +242,8 @@ class BucketedFleet:
             _lib.check(rc)
         self._n_steps += 1
         for k, env in enumerate(envs):
+            if env.engine._t is not None:
+                env.engine._t += 1                # the host mirror of the handle's counter (mgx_fleet_step moved it)
             env._set_plan_state(next_states[k])
             if env._views:
                 obs_l[k] = env._view_now()
@@ -288,6 +290,9 @@ class BucketedFleet:
         for env, st in sync:
             env._set_plan_state(st)
         for j, env in enumerate(self.envs):
+            e = env.engine
+            if e._t is not None:
+                e._t += 1                         # the host mirror of the handle's counter (mgx_fleet_step moved it)
             if env._views:
                 obs_l[j] = env._view_now()
         return obs_l, list(reward_l), done_l, [{} for _ in reward_l]

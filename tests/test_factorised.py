@@ -309,7 +309,7 @@ def test_fleet_with_views_and_factorised_series_vs_rows(device):
     for x, y in zip(o, v):
         assert torch.equal(x, y.flat())
     g = torch.Generator(device=device); g.manual_seed(8)
-    for k in range(T - 1):
+    for k in range(T):
         acts = rows.sample_action(generator=g)
         o, r, d, _ = rows.step(acts)
         v, r2, d2, _ = views.step(acts)
@@ -347,3 +347,102 @@ def test_true_shape_config3_factorised_vs_materialised(device):
                 assert torch.equal(om[k], of[k]), (k, t0, shards)
             _same_state(bm, bf)
     em.close(); ef.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flat_order="gym": the reference's flat observation under gym's key-sorting Dict
+# ---------------------------------------------------------------------------------------------------------------------
+def test_gym_flat_order_layout():
+    """BatchLayout(flat_order="gym"): blocks in alphabetical module order, names and slices consistent."""
+    from pymgrid_amd import BatchLayout
+    L = BatchLayout(n_grids=1, n_steps=10, horizon=2, has_genset=True, has_battery=True, has_grid=True, flat_order="gym")
+    sl = L.obs_slices()
+    assert list(sl) == ["battery", "genset", "grid", "load", "pv"]
+    assert (sl["battery"], sl["genset"], sl["grid"], sl["load"], sl["pv"]) == \
+        (slice(0, 2), slice(2, 6), slice(6, 18), slice(18, 21), slice(21, 24))
+    assert L.obs_names[:6] == ["soc", "current_charge", "current_status", "goal_status", "steps_until_up", "steps_until_down"]
+    assert L.obs_names[18:] == ["load_current", "load_forecast_0", "load_forecast_1", "renewable_current", "renewable_forecast_0",
+                                "renewable_forecast_1"]
+    M = BatchLayout(n_grids=1, n_steps=10, horizon=2, has_genset=True, has_battery=True, has_grid=True)
+    assert list(M.obs_slices()) == ["load", "pv", "genset", "battery", "grid"] and M.obs_dim == L.obs_dim == 24
+
+
+@pytest.mark.refcheck
+def test_reference_flat_observation_under_a_key_sorting_dict_is_the_gym_order():
+    """The reference builds gym.spaces.Dict(obs_space) from a plain dict (envs/base/base.py:128-163) and flattens observations
+    through it (:211-223); gym <= 0.26 / gymnasium SORT the keys of such a Dict.  With a Dict that does what gym does, the
+    reference's own flat observation == the nested observation concatenated in BatchLayout(flat_order="gym") order."""
+    import _refenv
+    if not _refenv.reference_available():
+        pytest.skip("reference not present")
+    from collections import OrderedDict
+
+    class SortingDict(_refenv.Dict):                       # gym/spaces/dict.py: OrderedDict(sorted(spaces.items())) for a plain dict
+        def __init__(self, spaces=None, seed=None, **kw):
+            super().__init__(spaces, seed, **kw)
+            self.spaces = OrderedDict(sorted(self.spaces.items()))
+    _refenv.import_reference()
+    import gym
+    from pymgrid.envs import DiscreteMicrogridEnv
+    from pymgrid_amd import BatchLayout
+    old = gym.spaces.Dict
+    import pymgrid.envs.base.base as base_mod
+    old_base = base_mod.Dict
+    try:
+        gym.spaces.Dict = base_mod.Dict = SortingDict
+        for n in (0, 1, 2):
+            nested_env = DiscreteMicrogridEnv.from_scenario(n)
+            nested_env._flat_spaces = False
+            flat_env = DiscreteMicrogridEnv.from_scenario(n)
+            np.random.seed(n)
+            o_n, o_f = nested_env.reset(), flat_env.reset()
+            names = {k for k in ("genset", "battery", "grid") if k in o_n}
+            L = BatchLayout(n_grids=1, n_steps=8760, horizon=23, has_genset="genset" in names, has_battery="battery" in names,
+                            has_grid="grid" in names, flat_order="gym")
+            for k in range(5):
+                expect = np.concatenate([np.asarray(o_n[name][0], dtype=np.float64) for name in L.obs_slices()])
+                assert o_f.shape == (L.obs_dim,) and np.array_equal(np.asarray(o_f, dtype=np.float64), expect), (n, k)
+                a = k % flat_env.action_space.n
+                o_n, o_f = nested_env.step(a)[0], flat_env.step(a)[0]
+    finally:
+        gym.spaces.Dict, base_mod.Dict = old, old_base
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ARCHS)
+def test_gym_flat_order_rows_are_the_permuted_module_order_rows(arch, device):
+    """flat_order="gym" moves the column bases of the module blocks, nothing else: every observation kernel (H = 0 rows, per-step
+    rows, prefetched rings, patched rings of rolling windows, float32 rows) == the module-order rows, permuted."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    from pymgrid_amd.generator import generate
+    N, T = 2000, 120
+    g = torch.Generator(device=device); g.manual_seed(6)
+    for H, prefetch, dt in ((0, 0, torch.float64), (24, 0, torch.float64), (24, 8, torch.float64), (24, 8, torch.float32)):
+        bm = generate(N, n_steps=T, seed=4, arch=arch, device=device, horizon=H, mixed_timers=True)
+        bg = generate(N, n_steps=T, seed=4, arch=arch, device=device, horizon=H, mixed_timers=True, flat_order="gym")
+        sm, sg = bm.layout.obs_slices(), bg.layout.obs_slices()
+        perm = torch.cat([torch.arange(sm[name].start, sm[name].stop) for name in sg]).to(device)
+        em = BatchedMicrogridEnv(bm, obs_dtype=dt, obs_prefetch=prefetch)
+        eg = BatchedMicrogridEnv(bg, obs_dtype=dt, obs_prefetch=prefetch)
+        om, og = em.reset(T - 30), eg.reset(T - 30)
+        assert torch.equal(om[:, perm], og)
+        for k in range(30):
+            a = em.sample_action(generator=g)
+            om, og = em.step(a)[0], eg.step(a)[0]
+            assert torch.equal(om[:, perm], og), (H, prefetch, k)
+        if H and prefetch:                                 # rolling windows: restarted grids are patched into the rings
+            starts = torch.randint(0, T - 12, (N,), dtype=torch.int32, device=device, generator=g)
+            lengths = torch.randint(1, 12, (N,), dtype=torch.int32, device=device, generator=g)
+            om, og = em.reset_windows(starts, lengths, max_length=12, rolling=True), eg.reset_windows(starts, lengths, max_length=12, rolling=True)
+            assert torch.equal(om[:, perm], og)
+            for k in range(20):
+                a = em.sample_action(generator=g)
+                om, _, d, _ = em.step(a)
+                og = eg.step(a)[0]
+                assert torch.equal(om[:, perm], og), k
+                if bool(d.any()):
+                    ns = torch.randint(0, T - 12, (N,), dtype=torch.int32, device=device, generator=g)
+                    nl = torch.randint(1, 12, (N,), dtype=torch.int32, device=device, generator=g)
+                    om, og = em.reset_grids(d, ns, nl), eg.reset_grids(d, ns, nl)
+                    assert torch.equal(om[:, perm], og), k
+        em.close(); eg.close()

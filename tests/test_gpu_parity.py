@@ -311,7 +311,7 @@ def test_gym_adaptors_shapes(pymgrid25, device):
             assert set(ctrl) == {k for k in ("genset", "battery", "grid") if p.get(k) is not None}
             obs, reward, done, info = env.step(a)
             assert obs.shape == (env.layout.obs_dim,) and isinstance(reward, float) and isinstance(done, bool)
-            assert info["reward"] == reward
+            assert env.last_log["reward"] == reward and set(info) == set(env._nested(obs)) and "provided_energy" in info["pv"][0]
         assert len(env.get_log()["reward"]) == 10
         df = env.get_log_frame()                          # Microgrid.get_log(as_frame=True) shape
         assert len(df) == 10 and df.columns.nlevels == 3

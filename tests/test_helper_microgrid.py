@@ -81,12 +81,12 @@ def test_device_random_actions_rbc_and_discrete(device):
         assert env.current_step == k + 1
         assert reward == z["rand_reward"][k] and int(done) == z["rand_done"][k], k
         assert np.array_equal(np.asarray(obs, dtype=np.float64), z["rand_obs"][k]), k
-        st = unpack_status(np.array([info["genset_status"]], dtype=np.uint32))[0].tolist()
+        st = unpack_status(np.array([env.last_log["genset_status"]], dtype=np.uint32))[0].tolist()
         assert st == z["rand_status"][k].tolist(), k
         for j, name in enumerate(names):
             ref = z["rand_log"][k, j]
-            if not np.isnan(ref) and name in info:
-                assert info[name] == ref, (k, name)
+            if not np.isnan(ref) and name in env.last_log:
+                assert env.last_log[name] == ref, (k, name)
     env.reset()                                                    # :114-122 (test_current_step_after_reset)
     assert env.current_step == 0
     env.close()

@@ -23,7 +23,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert getattr(L, name) is not None
     lib = _lib.lib()
     assert lib.mgx_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define MGX_ABI_VERSION (\d+)", header).group(1))
-    assert C.sizeof(_lib.Layout) == 15 * 4
+    assert C.sizeof(_lib.Layout) == 16 * 4
     n_ptr = len(_lib.COLUMN_NAMES)
     assert C.sizeof(_lib.Columns) == 8 + 8 * n_ptr
     # every column of the C struct, in order

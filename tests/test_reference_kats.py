@@ -50,9 +50,10 @@ class DeviceBackend:
         from pymgrid_amd import unpack_status
         ctrl = {k: [np.asarray(v)] if k == "genset" else [v] for k, v in action.items()}
         obs, reward, done, info = self.env.step(ctrl, normalized=normalized)
-        out = dict(info); out["reward"], out["done"], out["obs"] = reward, int(done), obs
-        if "genset_status" in info:
-            out["status"] = unpack_status(np.array([info["genset_status"]], dtype=np.uint32))[0].tolist()
+        out = dict(self.env.last_log); out["reward"], out["done"], out["obs"] = reward, int(done), obs
+        out["info"] = info                                   # the reference-shaped {module: [info dict]}
+        if "genset_status" in out:
+            out["status"] = unpack_status(np.array([out["genset_status"]], dtype=np.uint32))[0].tolist()
         return out
 
 
@@ -114,7 +115,7 @@ def test_raise_errors_true_raises_value_error(device):               # :110-122 
     # the refusals came from the dry run (mgx_check_step): nothing was applied -- counter and genset status as before
     assert env.current_step == 1 and env.batch.cols["gen_status"].cpu().numpy().view(np.uint32)[0] & 0xffff == 0x0101
     _, _, _, info = env.step({"genset": [np.array([1.0, 0.25])]})
-    assert env.current_step == 2 and info["violations"] == 0.0
+    assert env.current_step == 2 and env.last_log["violations"] == 0.0
     env.close()
     from pymgrid_amd import BatchedMicrogridEnv, MicrogridBatch
     bat = dict(load_ts=np.full(6, 10.0), pv_ts=np.zeros(6), horizon=0, final_step=6, initial_step=0,
@@ -134,7 +135,7 @@ def test_raise_errors_true_raises_value_error(device):               # :110-122 
     quiet = MicrogridEnv(genset_grid(), device=device)               # raise_errors=False: silently clipped
     quiet.reset()
     _, _, _, info = quiet.step({"genset": [np.array([0.0, 0.5])]})
-    assert info["violations"] == 1.0 and info["genset_production"] == 0
+    assert quiet.last_log["violations"] == 1.0 and info["genset"][0]["provided_energy"] == 0
     quiet.close()
 
 

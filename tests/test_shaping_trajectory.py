@@ -33,13 +33,13 @@ def test_reward_shapers_vs_reference(pymgrid25, device):
         for k in range(300):
             t = torch.as_tensor(a[k:k + 1], dtype=torch.float64, device=device)
             _, r, _, info = env.step(t)
-            assert r == z[f"shape_pv_{n}_shaped"][k] and info["reward"] == z[f"shape_pv_{n}_raw"][k], (n, k)
+            assert r == z[f"shape_pv_{n}_shaped"][k] and env.last_log["reward"] == z[f"shape_pv_{n}_raw"][k], (n, k)
         env.close()
         env = DiscreteMicrogridEnv(p, device=device, reward_shaping_func=BatteryDischargeShaper())
         ids = z[f"shape_bat_{n}_ids"]
         for k in range(300):
             _, r, _, info = env.step(int(ids[k]))
-            assert r == z[f"shape_bat_{n}_shaped"][k] and info["reward"] == z[f"shape_bat_{n}_raw"][k], (n, k)
+            assert r == z[f"shape_bat_{n}_shaped"][k] and env.last_log["reward"] == z[f"shape_bat_{n}_raw"][k], (n, k)
         env.close()
 
 

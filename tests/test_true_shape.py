@@ -82,11 +82,32 @@ def test_full_year_batch_end_of_series_and_wrap_around(n_total, rank, world, dev
     eng.close()
 
 
+def _series_of(batch, j):
+    """(load_ts, pv_ts, grid_ts | None) of grid j as host arrays, stored sign; a factorised batch's are formed from its
+    factors with the generator's multiply (what its kernels do)."""
+    c, L = batch.cols, batch.layout
+    if not batch.factorised:
+        return (c["load_ts"][:, j].cpu().numpy(), c["pv_ts"][:, j].cpu().numpy(),
+                c["grid_ts"][:, :, j].cpu().numpy() if L.has_grid else None)
+    from pymgrid_amd.generator import electricity_tariff, unpack_outage_bits
+    T = L.n_steps
+    load = -np.abs(c["base_load"][:, int(c["load_profile"][j])].cpu().numpy() * float(c["load_ratio"][j]))
+    pv = np.abs(c["base_pv"][:, int(c["pv_profile"][j])].cpu().numpy() * float(c["pv_ratio"][j]))
+    grid = None
+    if L.has_grid:
+        grid = np.zeros((T, 4))
+        grid[:, 0] = electricity_tariff(int(c["tariff"][j]), T)
+        grid[:, 2] = c["base_co2"][:, int(c["co2_profile"][j])].cpu().numpy()
+        grid[:, 3] = unpack_outage_bits(c["outage_bits"][:, j:j + 1], T)[:, 0].cpu().numpy() if "outage_bits" in c else 1.0
+    return load, pv, grid
+
+
 def _grid_params(batch, j):
     """Parameter dict (scenario vocabulary) of grid j of a batch, for oracle.OracleMicrogrid."""
     c, L = batch.cols, batch.layout
     f = lambda k: float(c[k][j])
-    p = dict(load_ts=-c["load_ts"][:, j].cpu().numpy(), pv_ts=c["pv_ts"][:, j].cpu().numpy(), horizon=L.horizon,
+    load_ts, pv_ts, grid_ts = _series_of(batch, j)
+    p = dict(load_ts=-load_ts, pv_ts=pv_ts, horizon=L.horizon,
              initial_step=L.initial_step, final_step=L.final_step,
              unbalanced=dict(loss_load_cost=f("loss_load_cost"), overgeneration_cost=f("overgeneration_cost")))
     if L.has_battery:
@@ -102,7 +123,7 @@ def _grid_params(batch, j):
                            status=[int(x) for x in unpack_status(np.array([c["gen_status"][j].item()]).astype(np.int64) & 0xffffffff)[0]])
     if L.has_grid:
         p["grid"] = dict(max_import=f("grid_max_import"), max_export=f("grid_max_export"), cost_per_unit_co2=f("grid_cost_per_unit_co2"))
-        p["grid_ts"] = c["grid_ts"][:, :, j].cpu().numpy()
+        p["grid_ts"] = grid_ts
     return p
 
 
@@ -145,4 +166,61 @@ def test_heterogeneous_fleet_of_100k_grids_with_forecasts_vs_oracle(device, orac
                 out = om.run(ad, True)
                 assert reward[b][j].item() == out.reward and bool(done[b][j]) == bool(out.done), (names[b], k, j)
                 assert np.array_equal(obs[b][j].cpu().numpy(), om.observe()), (names[b], k, j)
+    fleet.close()
+
+
+@pytest.mark.parametrize("series,contract", [("materialised", "rows"), ("factorised", "rows"), ("factorised", "views")])
+def test_config5_shard_at_its_true_shape_across_the_end_of_the_year(series, contract, device, oracle):
+    """The per-GPU shard of BASELINE configs[4] at its TRUE shape: 125 000 heterogeneous grids (MicrogridGenerator's mix, half of
+    the grid-connected ones weak, genset timers 0..3) x 8 760 rows, forecast_horizon = 24 -- materialised that is 41 GB of
+    series whose [T, 4, N] element offsets pass 2^31 -- stepped through BucketedFleet.step from row 8 700 to the last row of the
+    year: ring refills across the year boundary, the H = 24 windows running into the end-of-series padding, `done` exactly at
+    row 8 759, stepping past the end refused.  Six sampled grids per bucket == per-grid oracle microgrids at every step
+    (observation rows or views, reward, done)."""
+    from pymgrid_amd._lib import MGX_ERR_RANGE, MgxError
+    from pymgrid_amd.generator import generate_fleet
+    from pymgrid_amd.hetero import BucketedFleet
+    n, T, H, t0 = 125_000, 8760, 24, 8700
+    parts = generate_fleet(1_000_000, n_steps=T, seed=42, horizon=H, device=device, rank=5, world=8, mixed_timers=True,
+                           series=series)
+    names = list(parts)
+    assert sum(len(i) for _, i in parts.values()) == n
+    if series == "materialised":
+        big = max(int(b.cols["grid_ts"].numel()) for b, _ in parts.values() if b.layout.has_grid)
+        assert big > 2 ** 31                                  # 64-bit element offsets are really exercised
+    kw = dict(obs_views=True) if contract == "views" else dict(obs_prefetch=16)
+    fleet = BucketedFleet.from_batches([parts[k][0] for k in names], reuse_outputs=8, **kw)
+    assert fleet.fused
+    rs = np.random.RandomState(0)
+    sample = [np.sort(rs.choice(e.n_grids, 6, replace=False)) for e in fleet.envs]
+    oms = [[oracle.OracleMicrogrid(_grid_params(e.batch, int(j))) for j in s] for e, s in zip(fleet.envs, sample)]
+    flat = (lambda o: o.flat()) if contract == "views" else (lambda o: o)
+    obs = [env.reset(t0) for env in fleet.envs]
+    for b, (s, ms) in enumerate(zip(sample, oms)):
+        for j, om in zip(s, ms):
+            assert np.array_equal(flat(obs[b])[j].cpu().numpy(), om.reset(t0)), (names[b], j)
+    g = torch.Generator(device=device); g.manual_seed(3)
+    for k in range(T - t0):
+        acts = fleet.sample_action(generator=g)
+        obs, reward, done, _ = fleet.step(acts)
+        for b, (env, s, ms) in enumerate(zip(fleet.envs, sample, oms)):
+            a = acts[b][torch.as_tensor(s, device=device)].cpu().numpy()
+            L = env.layout
+            rows = flat(obs[b])[torch.as_tensor(s, device=device)].cpu().numpy()
+            for q, (j, om) in enumerate(zip(s, ms)):
+                ad, c = {}, 0
+                if L.has_genset:
+                    ad["genset"] = a[q, c:c + 2]; c += 2
+                if L.has_battery:
+                    ad["battery"] = a[q, c]; c += 1
+                if L.has_grid:
+                    ad["grid"] = a[q, c]
+                out = om.run(ad, True)
+                assert reward[b][j].item() == out.reward and bool(done[b][j]) == bool(out.done) == (k == T - t0 - 1), (names[b], k, j)
+                assert np.array_equal(rows[q], om.observe()), (names[b], k, j)
+        assert all(bool(d.all()) == (k == T - t0 - 1) for d in done)
+    assert all(env.current_step == T for env in fleet.envs)
+    with pytest.raises(MgxError) as e:                         # IndexError in the reference: the series is over
+        fleet.step(fleet.sample_action(generator=g))
+    assert e.value.code == MGX_ERR_RANGE
     fleet.close()

@@ -3,7 +3,7 @@
 import json
 import sys
 
-d = json.load(open(sys.argv[1]))
+d = json.loads([ln for ln in open(sys.argv[1]) if ln.startswith("{")][-1])
 r = d["roofline"]
 print(f"headline {d['value'] / 1e9:.2f} G env-steps/s  {d['ms_per_step'] * 1e3:.2f} us/round  frac {r['frac']:.3f}  "
       f"cadence {r['avg_launch_us']:.2f} us  kernel {r.get('kernel_avg_duration_us')}  traffic {r.get('traffic')}")
@@ -18,8 +18,12 @@ h = d.get("hetero_h24_gym_steps")
 if h and "error" in h:
     print(f"  hetero FAILED: {h['error']}")
 elif h:
-    for k in ("float64_rows", "float32_rows"):
-        print(f"  hetero {k}: {h[k]['us_per_step']:.1f} us/step  {h[k]['value'] / 1e9:.2f} G  frac {h[k]['roofline']['frac']:.3f}")
+    for k in ("float64_rows", "float32_rows", "float64_views", "float32_views"):
+        if k in h:
+            q = h[k]["roofline"]
+            print(f"  hetero {k}: {h[k]['us_per_step']:.1f} us/step wall  {q['avg_launch_us']:.1f} us gpu  {h[k]['value'] / 1e9:.2f} G  "
+                  f"frac {q['frac']:.3f}  isolated {q.get('gpu_us_per_step_isolated', 0):.1f} us (frac {q.get('frac_isolated', 0):.3f})  "
+                  f"traffic {q.get('traffic')}")
 c = d.get("cpu_baseline")
 if c and "error" in c:
     print(f"  cpu baseline FAILED: {c['error']}")
