@@ -16,6 +16,11 @@
  *  - Every pointer in mgx_columns and every data argument is a DEVICE pointer owned by the caller
  *    (e.g. torch tensors); the library allocates only a small scratch buffer in mgx_create.
  *  - All arithmetic is IEEE fp64, unfused (no FMA contraction), in the reference's operation order.
+ *  - Zero signs: every output equals the reference's VALUE bit for bit, except that a result that is zero may carry the other
+ *    sign (+0.0 vs -0.0).  The reference produces -0.0 in places (-1.0 * get_cost(0.0); a flex source asked for `-difference`
+ *    with difference == 0.0, microgrid.py:300-314), its min / max return the first argument on ties where v_min_f64 /
+ *    v_max_f64 order -0 < +0; no operation of the path divides by such a zero or takes its sign, so the difference cannot
+ *    propagate into a non-zero value.  Parity tests compare with `==` (profiles/r03/zero_signs.txt has the census).
  *  - Calls are asynchronous on the given stream and must be issued from one host thread per handle.
  *  - Return value: MGX_OK or an error code; mgx_last_error() gives a thread-local message.
  *
@@ -302,7 +307,7 @@ int mgx_set_done_format(mgx_handle *h, int32_t format);
  * observation at step t are  norm[t .. t + H]  of a series normalised ONCE ((v - lo) / spread, space.py:207-218; rows past
  * the end of the series = the padding value (lo + hi) / 2, forecaster.py:95,120-137; the forecast clip, forecaster.py:139-149,
  * is the identity because lo / hi bound the series).  mgx_normalise_series writes that normalised copy GRID-major:
- *     load_n, pv_n  [N, R]      R = n_steps + horizon
+ *     load_n, pv_n  [N, R]      R = n_steps + horizon + 1 (the observation after the last step, counter = n_steps, is all padding)
  *     grid_n        [N, R, 4]   (component-minor: the reference's window order falls out of a flat slice)
  * as float64 or float32 (the handle's obs format) so that the window of grid i at step t is the contiguous slice
  * load_n[i, t : t + 1 + H] -- a strided VIEW, no bytes moved per step.  Returns MGX_ERR_UNSUPPORTED when a bound column does

@@ -1360,7 +1360,7 @@ int mgx_normalise_series(mgx_handle *h, void *load_n, void *pv_n, void *grid_n, 
                                          "slices of one series");
     if (int rc = need_obs_bounds(h, "mgx_normalise_series")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int32_t R = h->k.T + h->k.H;
+    const int32_t R = h->k.T + h->k.H + 1;               // the window at counter value T (after the last step) is all padding
     const unsigned gx = (unsigned)((h->k.N + 63) / 64);
     auto launch = [&](int which, void *out, int nc) {
         const int32_t TR = nc == 1 ? 64 : 16;

@@ -153,7 +153,7 @@ class StepEngine:
 
     def normalise_series(self):
         """``mgx_normalise_series``: the series normalised ONCE, grid-major -- {"load": [N, R], "pv": [N, R],
-        "grid": [N, R, 4]} (R = n_steps + horizon, dtype = the engine's obs dtype) -- so that the window columns of the
+        "grid": [N, R, 4]} (R = n_steps + horizon + 1, dtype = the engine's obs dtype) -- so that the window columns of the
         observation at step t are the slices ``load[:, t : t + 1 + H]`` etc. (views, no bytes moved per step).  Raises if a bound
         column does not bound its series (the reference's forecast clip would then not be the identity)."""
         L = self.layout
@@ -161,7 +161,7 @@ class StepEngine:
             raise _lib.MgxError(_lib.MGX_ERR_UNSUPPORTED, "normalise_series: not offered for rolling windows")
         # rows of the series the handle currently steps over: the window buffers during a per-grid-window episode
         T = self._windows["rows"] if getattr(self, "_window_start", None) is not None else L.n_steps
-        R = T + L.horizon
+        R = T + L.horizon + 1
         out = {"load": torch.empty(self.N, R, dtype=self.obs_dtype, device=self.device),
                "pv": torch.empty(self.N, R, dtype=self.obs_dtype, device=self.device)}
         if L.has_grid:

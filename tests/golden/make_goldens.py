@@ -148,8 +148,11 @@ def log_matrix(m):
         if name is None:
             continue
         cols = [c for c in log.columns if c[0] == name and c[2] == field]
-        acc = np.zeros(n)
-        for c in cols:
+        if not cols:
+            out[:, j] = np.zeros(n)
+            continue
+        acc = log[cols[0]].values.astype(np.float64).copy()     # (no "0.0 +": a module's -0.0 keeps its sign)
+        for c in cols[1:]:
             acc = acc + log[c].values.astype(np.float64)
         out[:, j] = acc
     return out

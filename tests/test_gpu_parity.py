@@ -323,7 +323,7 @@ def test_gym_adaptors_shapes(pymgrid25, device):
         env.close()
         env = MicrogridEnv(p, device=device, flat_spaces=False)
         obs = env.reset()
-        assert set(obs) == set(env.layout.obs_slices())
+        assert set(obs) == set(env.layout.obs_slices()) | {"unbalanced_energy"} and obs["unbalanced_energy"][0].shape == (0,)
         ctrl = {"battery": [0.5]}
         if p.get("genset") is not None: ctrl["genset"] = [np.array([1.0, 0.5])]
         if p.get("grid") is not None: ctrl["grid"] = [0.5]

@@ -127,6 +127,9 @@ def test_oracle_equals_reference_on_random_microgrids(seed, oracle):
             for j, name in enumerate(mg.LOG_NAMES):
                 if not np.isnan(ref_log[k, j]):
                     assert d[name] == ref_log[k, j], (seed, case, k, name)
+                    # (`==` on VALUES: the sign of a zero result is not part of the contract -- include/mgx.h "Zero signs".  The
+                    #  reference itself produces -0.0 in places, e.g. a renewable asked for `-difference` with difference == 0.0,
+                    #  microgrid.py:300-314, or `-1.0 * get_cost(0.0)`; no later operation can tell +0 from -0.)
         if A:                                                # DiscreteMicrogridEnv: list enumeration, expansion, step
             env = DiscreteMicrogridEnv.from_microgrid(m_disc)
             redundant = "genset" in p and p["genset"]["running_min_production"] == 0
