@@ -142,11 +142,19 @@ SYMBOLS = {
 }
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into pymgrid_amd/libmgx.so (hipcc cross-compiles without a GPU)."""
+def build(force=False, verbose=False, defs=(), lib_path=None):
+    """Compile csrc/*.hip for gfx950 into pymgrid_amd/libmgx.so (hipcc cross-compiles without a GPU).
+    ``defs`` / ``lib_path``: an A/B variant of the kernels (extra -D flags, e.g. ("-DMGX_RING=8",)) built beside the product
+    library; load it with MGX_LIB=<lib_path>."""
+    if lib_path is not None or defs:
+        return _build(lib_path or LIB_PATH, list(defs), verbose, os.path.basename(lib_path or "variant") + ".o")
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in SOURCES)):
         return LIB_PATH
+    return _build(LIB_PATH, [], verbose, "", force)
+
+
+def _build(LIB_PATH, extra_defs, verbose, objtag, force=True):
     # several ranks may get here at once (torchrun): serialise on a lock file, compile to a temporary name and
     # rename atomically so that nobody ever dlopens a half-written library
     import fcntl
@@ -158,14 +166,14 @@ def build(force=False, verbose=False):
                 return LIB_PATH                      # another process built it while we waited
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
-            objdir = os.path.join(_PKG, "csrc", "_build")
+            objdir = os.path.join(_PKG, "csrc", "_build" + ("_" + objtag if objtag else ""))
             os.makedirs(objdir, exist_ok=True)
             # translation units: the host side + small kernels, and the slices of the K-step kernels -- compiled in parallel
             units = [(SOURCES[0], [], os.path.join(objdir, "mgx_abi.o"))] + \
                     [(SOURCES[1], [f"-DMGX_FUSED_PART={p}"], os.path.join(objdir, f"mgx_fused_{p}.o")) for p in range(FUSED_PARTS)]
             procs = []
             for src, defs, obj in units:
-                cmd = [hipcc] + HIPCC_FLAGS + defs + ["-c", src, "-o", obj]
+                cmd = [hipcc] + HIPCC_FLAGS + defs + extra_defs + ["-c", src, "-o", obj]
                 if verbose:
                     print(" ".join(cmd))
                 procs.append((cmd, subprocess.Popen(cmd)))

@@ -231,11 +231,12 @@ struct RawActions {
     AT a_goal, a_gen, a_bat, a_grid;
 };
 
+// `row`: the [N, A] block of one step (wave-uniform: an SGPR base), i32: the lane's grid
 template <int F, typename AT>
-__device__ __forceinline__ void load_actions_at(const AT *__restrict__ act, int64_t off, RawActions<AT> &r)
+__device__ __forceinline__ void load_actions_at(const AT *__restrict__ row, uint32_t i32, RawActions<AT> &r)
 {
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    const AT *a = act + off * A;
+    const AT *a = row + i32 * (uint32_t)A;
     int k = 0;
     if constexpr (F & F_GENSET) { r.a_goal = a[k]; r.a_gen = a[k + 1]; k += 2; }
     if constexpr (F & F_BATTERY) { r.a_bat = a[k]; k += 1; }
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT
     const bool active = (int32_t)threadIdx.x < gpb && i < a.g1;
     if constexpr (!FACT) { if (!active) return; }
     const int64_t N = a.N;
+    constexpr int A_DIM = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
     Params p; State s; Derived d;
     const bool norm = normalized != 0;
     const bool want_soc = (out.soc_trace != nullptr) || (out.log != nullptr);
@@ -290,17 +292,45 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT
     }
     double ret = 0.0;
 
-    // one step of this lane's grid, inputs complete
-    auto consume = [&](const Inputs &in, int32_t k, int64_t off) __attribute__((always_inline)) {
+    // The step loop exists in four forms, picked once per launch by wave-uniform flags and specialised at COMPILE time:
+    //   GI   every genset of the wave is instantaneous (no start-up / wind-down delay, equilibrium status): the status FSM
+    //        (genset_update_status) is not in the loop at all;
+    //   HOT  the launch writes exactly reward + SoC per step (the throughput configuration: lock-step `done` follows from the
+    //        counter, no traces, no log): no per-step tests of the output pointers.
+    // (Without the specialisation the loop body is ~34 basic blocks per step; the scheduler cannot move loads across them.)
+    const bool hot = !RICH && out.reward != nullptr && out.done == nullptr && (!(F & F_BATTERY) || out.soc_trace != nullptr) &&
+                     a.shaper == MGX_SHAPER_NONE;
+    const uint32_t i32 = (uint32_t)i;             // lane offset of every [K, N] stream: row base in SGPRs + this (no 64-bit VALU
+                                                  // address arithmetic per step and stream)
+    auto consume = [&](auto gi_tag, auto hot_tag, const Inputs &in, int32_t k, int64_t off) __attribute__((always_inline)) {
+        constexpr bool GI = decltype(gi_tag)::value, HOT = decltype(hot_tag)::value;
         Outputs o;
-        step_core<F>(p, d, s, in, norm, want_soc, gen_instant, o);
+        step_core<F>(p, d, s, in, norm, HOT ? (F & F_BATTERY) != 0 : want_soc, GI, o);
+        if constexpr (HOT) {
+            const double r = o.reward;
+            (out.reward + (int64_t)k * N)[i32] = r;
+            if constexpr (F & F_BATTERY) (out.soc_trace + (int64_t)k * N)[i32] = s.soc;
+            ret += r;
+            return;
+        }
         const double r = shaped_reward<F>(a.shaper, o);
-        if (out.reward) out.reward[off] = r;
-        if (out.done) store_done(a, out.done, off, i, k, k >= k_done);
-        if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
-        if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
-        if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
+        {
+            if (out.reward) out.reward[off] = r;
+            if (out.done) store_done(a, out.done, off, i, k, k >= k_done);
+            if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
+            if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
+            if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
+        }
         ret += r;
+    };
+    // run fn(gi_tag, hot_tag) in the form the wave's flags select
+    auto specialised = [&](auto fn) __attribute__((always_inline)) {
+        if constexpr ((F & F_GENSET) != 0) {
+            if (gen_instant) { if (hot) fn(std::true_type{}, std::true_type{}); else fn(std::true_type{}, std::false_type{}); }
+            else { if (hot) fn(std::false_type{}, std::true_type{}); else fn(std::false_type{}, std::false_type{}); }
+        } else {
+            if (hot) fn(std::false_type{}, std::true_type{}); else fn(std::false_type{}, std::false_type{});
+        }
     };
 
     if constexpr (FACT) {
@@ -316,42 +346,45 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT
             if constexpr (F & F_GRID) outage_init(a.c, N, i, a.T, t0, ow);
 #pragma unroll
             for (int u = 0; u < U; u++)
-                if (u < K) load_actions_at<F>(actions, (int64_t)u * N + i, ring[u]);
+                if (u < K) load_actions_at<F>(actions + (int64_t)u * N * A_DIM, i32, ring[u]);
         }
         int64_t off = i;                                     // k*N + i
+        // the steps of one LDS chunk (the barriers around a chunk stay at kernel scope: every wave of the workgroup meets
+        // the same ones, whichever form of the loop it runs)
+        auto run_chunk = [&](auto gi_tag, auto hot_tag, int32_t kb, int32_t n) __attribute__((always_inline)) {
+            BaseVals nb = read_base_row<F>(base_lds, 0, f);
+            for (int32_t k0 = kb; k0 < kb + n; k0 += U) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int32_t k = k0 + u;
+                    if (k < kb + n) {
+                        const RawActions<AT> ra = ring[u];
+                        if (k + U < K) load_actions_at<F>(actions + (int64_t)(k + U) * N * A_DIM, i32, ring[u]);
+                        Inputs in;
+                        if constexpr (F & F_GENSET) { in.a_goal = (double)ra.a_goal; in.a_gen = (double)ra.a_gen; }
+                        if constexpr (F & F_BATTERY) in.a_bat = (double)ra.a_bat;
+                        in.load = fact_load(nb.load, f.lr);
+                        in.pv = fact_pv(nb.pv, f.pr);
+                        if constexpr (F & F_GRID) {
+                            in.a_grid = (double)ra.a_grid;
+                            in.g_pimp = tariff_price((int32_t)f.pat, t0 + k); in.g_pexp = 0.0;
+                            in.g_co2 = nb.co2;
+                            in.g_stat = outage_status(a.c, N, i, a.T, t0 + k, k == 0, ow);
+                        }
+                        const int32_t rn = (k + 1 - kb < n) ? k + 1 - kb : n - 1;      // next step's row (LDS, one step ahead)
+                        nb = read_base_row<F>(base_lds, rn, f);
+                        consume(gi_tag, hot_tag, in, k, off);
+                        off += N;
+                    }
+                }
+            }
+        };
         for (int32_t kb = 0; kb < K; kb += FACT_ROWS) {      // K is uniform over the launch: the barriers are safe
             const int32_t n = K - kb < FACT_ROWS ? K - kb : FACT_ROWS;
             __syncthreads();                                 // the previous chunk's rows have been consumed
             stage_base_rows<F>(a.c, (int64_t)t0 + kb, n, base_lds, BLOCK_K);
             __syncthreads();
-            if (active) {
-                BaseVals nb = read_base_row<F>(base_lds, 0, f);
-                for (int32_t k0 = kb; k0 < kb + n; k0 += U) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const int32_t k = k0 + u;
-                        if (k < kb + n) {
-                            const RawActions<AT> ra = ring[u];
-                            if (k + U < K) load_actions_at<F>(actions, off + (int64_t)U * N, ring[u]);
-                            Inputs in;
-                            if constexpr (F & F_GENSET) { in.a_goal = (double)ra.a_goal; in.a_gen = (double)ra.a_gen; }
-                            if constexpr (F & F_BATTERY) in.a_bat = (double)ra.a_bat;
-                            in.load = fact_load(nb.load, f.lr);
-                            in.pv = fact_pv(nb.pv, f.pr);
-                            if constexpr (F & F_GRID) {
-                                in.a_grid = (double)ra.a_grid;
-                                in.g_pimp = tariff_price((int32_t)f.pat, t0 + k); in.g_pexp = 0.0;
-                                in.g_co2 = nb.co2;
-                                in.g_stat = outage_status(a.c, N, i, a.T, t0 + k, k == 0, ow);
-                            }
-                            const int32_t rn = (k + 1 - kb < n) ? k + 1 - kb : n - 1;      // next step's row (LDS, one step ahead)
-                            nb = read_base_row<F>(base_lds, rn, f);
-                            consume(in, k, off);
-                            off += N;
-                        }
-                    }
-                }
-            }
+            if (active) specialised([&](auto gi_tag, auto hot_tag) __attribute__((always_inline)) { run_chunk(gi_tag, hot_tag, kb, n); });
         }
         if (!active) return;                                 // (no barrier follows: advance_counter_in_kernel's is skipped
     } else {                                                 //  by returned waves, as in the materialised form)
@@ -359,24 +392,26 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT
         const double *__restrict__ lts = a.c.load_ts + (int64_t)t0 * N;
         const double *__restrict__ pts = a.c.pv_ts + (int64_t)t0 * N;
         const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
-        RawInputs<AT> ring[U];
+        specialised([&](auto gi_tag, auto hot_tag) __attribute__((always_inline)) {
+            RawInputs<AT> ring[U];
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            if (u < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
+            for (int u = 0; u < U; u++)
+                if (u < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, (int64_t)u * N + i, ring[u]);
 
-        int64_t off = i;                                         // k*N + i
-        for (int32_t k0 = 0; k0 < K; k0 += U) {
+            int64_t off = i;                                         // k*N + i
+            for (int32_t k0 = 0; k0 < K; k0 += U) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int32_t k = k0 + u;
-                if (k < K) {
-                    const Inputs in = widen<F>(ring[u]);
-                    if (k + U < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
-                    consume(in, k, off);
-                    off += N;
+                for (int u = 0; u < U; u++) {
+                    const int32_t k = k0 + u;
+                    if (k < K) {
+                        const Inputs in = widen<F>(ring[u]);
+                        if (k + U < K) load_inputs_at<F>(actions, lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
+                        consume(gi_tag, hot_tag, in, k, off);
+                        off += N;
+                    }
                 }
             }
-        }
+        });
     }
     if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
     store_state<F>(a.c, i, s);
@@ -1019,13 +1054,25 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
     }
     double ret = 0.0;
 
-    // one step of this lane's grid: series values complete in `in` (GI: compile-time form of the wave-uniform gen_instant)
-    auto consume = [&](auto gi_tag, Inputs &in, int32_t k, int64_t off) __attribute__((always_inline)) {
-        constexpr bool GI = decltype(gi_tag)::value;
+    // one step of this lane's grid: series values complete in `in` (GI: compile-time form of the wave-uniform gen_instant;
+    // HOT: the launch writes exactly reward + SoC per step, unshaped -- no per-step tests of the output pointers, row bases in
+    // SGPRs + a 32-bit lane offset)
+    const bool hot = !RICH && out.reward != nullptr && out.done == nullptr && (!(F & F_BATTERY) || out.soc_trace != nullptr) &&
+                     a.shaper == MGX_SHAPER_NONE;
+    const uint32_t i32 = (uint32_t)i;
+    auto consume = [&](auto gi_tag, auto hot_tag, Inputs &in, int32_t k, int64_t off) __attribute__((always_inline)) {
+        constexpr bool GI = decltype(gi_tag)::value, HOT = decltype(hot_tag)::value;
         double bat_q;
         populate_core<F>(p, s, word, in, bat_q, 0.0 + -1 * in.load, in.pv, GI);
         Outputs o;
-        step_core<F, true>(p, d, s, in, false, want_soc, GI, o, bat_q);
+        step_core<F, true>(p, d, s, in, false, HOT ? (F & F_BATTERY) != 0 : want_soc, GI, o, bat_q);
+        if constexpr (HOT) {
+            const double r = o.reward;
+            (out.reward + (int64_t)k * N)[i32] = r;
+            if constexpr (F & F_BATTERY) (out.soc_trace + (int64_t)k * N)[i32] = s.soc;
+            ret += r;
+            return;
+        }
         const double r = shaped_reward<F>(a.shaper, o);
         if (out.reward) out.reward[off] = r;
         if (out.done) store_done(a, out.done, off, i, k, k >= k_done);
@@ -1034,8 +1081,16 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
         if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
         ret += r;
     };
-    // The step loop exists twice, specialised at COMPILE time on the wave-uniform `gen_instant`: in the instant form the
-    // genset's status is its goal, its limits under a fixed list are loop-invariant (hoisted), and the FSM is gone.
+    // The step loop exists in four forms, specialised at COMPILE time on the wave-uniform `gen_instant` (in the instant form the
+    // genset's status is its goal, its limits under a fixed list are loop-invariant (hoisted), and the FSM is gone) and on `hot`.
+    auto specialised = [&](auto fn) __attribute__((always_inline)) {
+        if constexpr ((F & F_GENSET) != 0) {
+            if (gen_instant) { if (hot) fn(std::true_type{}, std::true_type{}); else fn(std::true_type{}, std::false_type{}); }
+            else { if (hot) fn(std::false_type{}, std::true_type{}); else fn(std::false_type{}, std::false_type{}); }
+        } else {
+            if (hot) fn(std::false_type{}, std::true_type{}); else fn(std::false_type{}, std::false_type{});
+        }
+    };
     if constexpr (FACT) {
         // the barriers of the LDS chunks stay at kernel scope (every wave of the workgroup meets the same ones); only the
         // loop over a chunk's steps is specialised
@@ -1045,18 +1100,19 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
         f.lr = 0.0; f.pr = 0.0; f.lp = 0u; f.pp = 0u; f.cp = 0u; f.pat = 0u;
         OutageWords ow;
         ow.cur = 0; ow.nxt = 0; ow.wi = 0;
-        uint8_t idr[U];
+        static_assert(U <= 8, "the id ring is one 64-bit register");
+        uint64_t idq = 0;                 // PER_STEP: the id bytes of the U ring slots (an array would live in scratch memory)
         if (active) {
             load_factors<F>(a.c, i, f);
             if constexpr (F & F_GRID) outage_init(a.c, N, i, a.T, t0, ow);
             if constexpr (PER_STEP) {
 #pragma unroll
                 for (int u = 0; u < U; u++)
-                    if (u < K) idr[u] = ids[(int64_t)u * N + i];
+                    if (u < K) idq |= (uint64_t)(ids + (int64_t)u * N)[i32] << (8 * u);
             }
         }
         int64_t off = i;
-        auto run_chunk = [&](auto gi_tag, int32_t kb, int32_t n) __attribute__((always_inline)) {
+        auto run_chunk = [&](auto gi_tag, auto hot_tag, int32_t kb, int32_t n) __attribute__((always_inline)) {
             BaseVals nb = read_base_row<F>(base_lds, 0, f);
             for (int32_t k0 = kb; k0 < kb + n; k0 += U) {
 #pragma unroll
@@ -1064,8 +1120,9 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
                     const int32_t k = k0 + u;
                     if (k < kb + n) {
                         if constexpr (PER_STEP) {
-                            word = pl_select(tab, idr[u]);
-                            if (k + U < K) idr[u] = ids[off + (int64_t)U * N];
+                            word = pl_select(tab, (int32_t)((idq >> (8 * u)) & 0xffu));
+                            if (k + U < K)
+                                idq = (idq & ~(0xffull << (8 * u))) | ((uint64_t)(ids + (int64_t)(k + U) * N)[i32] << (8 * u));
                         }
                         Inputs in;
                         in.load = fact_load(nb.load, f.lr);
@@ -1078,7 +1135,7 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
                         }
                         const int32_t rn = (k + 1 - kb < n) ? k + 1 - kb : n - 1;      // next step's row (LDS, one step ahead)
                         nb = read_base_row<F>(base_lds, rn, f);
-                        consume(gi_tag, in, k, off);
+                        consume(gi_tag, hot_tag, in, k, off);
                         off += N;
                     }
                 }
@@ -1089,17 +1146,11 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
             __syncthreads();                                     // the previous chunk's rows have been consumed
             stage_base_rows<F>(a.c, (int64_t)t0 + kb, n, base_lds, BLOCK_K);
             __syncthreads();
-            if (active) {
-                if constexpr ((F & F_GENSET) != 0) {
-                    if (gen_instant) run_chunk(std::true_type{}, kb, n); else run_chunk(std::false_type{}, kb, n);
-                } else {
-                    run_chunk(std::false_type{}, kb, n);
-                }
-            }
+            if (active) specialised([&](auto gi_tag, auto hot_tag) __attribute__((always_inline)) { run_chunk(gi_tag, hot_tag, kb, n); });
         }
         if (!active) return;
     } else {
-        auto run = [&](auto gi_tag) __attribute__((always_inline)) {
+        specialised([&](auto gi_tag, auto hot_tag) __attribute__((always_inline)) {
             const double *__restrict__ lts = a.c.load_ts + (int64_t)t0 * N;
             const double *__restrict__ pts = a.c.pv_ts + (int64_t)t0 * N;
             const double *__restrict__ gts = (F & F_GRID) ? a.c.grid_ts + (int64_t)t0 * 4 * N : nullptr;
@@ -1124,17 +1175,12 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
                             load_series_at<F>(lts, pts, gts, N, i, off + (int64_t)U * N, ring[u]);
                             if constexpr (PER_STEP) idr[u] = ids[off + (int64_t)U * N];
                         }
-                        consume(gi_tag, in, k, off);
+                        consume(gi_tag, hot_tag, in, k, off);
                         off += N;
                     }
                 }
             }
-        };
-        if constexpr ((F & F_GENSET) != 0) {
-            if (gen_instant) run(std::true_type{}); else run(std::false_type{});
-        } else {
-            run(std::false_type{});
-        }
+        });
     }
     if constexpr (F & F_BATTERY) { if (!want_soc) s.soc = s.charge / p.bat_cmax; }
     store_state<F>(a.c, i, s);
