@@ -64,8 +64,7 @@ def parse(argv=None):
     ap.add_argument("--mode", choices=["fused", "step", "rbc"], default="fused")
     ap.add_argument("--chunk", type=int, default=64, help="env-steps per round (= per fused launch)")
     ap.add_argument("--shards", type=int, default=None,
-                    help="grid ranges stepped on internal HIP streams (mgx_set_shards); 1: one launch sequence.  Default: 1 for the "
-                         "factorised layout (two ranges measured no faster there), 2 for the materialised one")
+                    help="grid ranges stepped on internal HIP streams (mgx_set_shards); 1: one launch sequence.  Default: 2")
     ap.add_argument("--arch", default="genset+battery")
     ap.add_argument("--series", choices=["factorised", "materialised"], default="factorised",
                     help="series layout of the headline batch (the other layout is timed under 'other')")
@@ -474,7 +473,7 @@ def main():
     N, chunk = args.grids, args.chunk
     n_total = N * world
     other_series = "materialised" if args.series == "factorised" else "factorised"
-    shards_of = {"factorised": 1, "materialised": 2}
+    shards_of = {"factorised": 2, "materialised": 2}
     if args.shards is not None:
         shards_of = {k: max(1, args.shards) for k in shards_of}
 
@@ -586,6 +585,8 @@ def main():
                 results[mode] = guarded(mode, lambda mode=mode: measure(mode, sharded=mode in ("fused", "rbc"),
                                                                         rounds=side[0], warmup=side[1]))
         # the other series layout: the fused kernel (as sharded as that layout likes it, and as ONE launch sequence) + the rollout
+        if shards_of[args.series] > 1 and args.mode == "fused":      # the headline kernel as ONE launch sequence
+            results["fused_one_stream"] = guarded("fused_one_stream", lambda: measure("fused", False, side[0], side[1]))
         results["fused_other_series"] = guarded("fused_other_series", lambda: measure("fused", True, side[0], side[1], other_series))
         if shards_of[other_series] > 1:
             results["fused_other_series_one_stream"] = guarded("fused_other_series_one_stream",
@@ -619,6 +620,7 @@ def main():
         main_r = results[args.mode]
         S = run.S if args.mode in ("fused", "rbc") else 1
         names = {"fused": "fused_launches", "step": "single_step_launches_one_call", "rbc": "rbc_rollout_on_device",
+                 "fused_one_stream": "fused_launches_one_stream",
                  "fused_other_series": f"fused_launches_{other_series}",
                  "fused_other_series_one_stream": f"fused_launches_{other_series}_one_stream",
                  "rbc_other_series": f"rbc_rollout_{other_series}", "step_python": "single_step_launches_python_loop"}

@@ -51,13 +51,14 @@ def test_bench_one_rank_json_line(device):
     assert set(rf) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and rf["bound"] == "hbm"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["launches"] == 6 and rf["series"] == "factorised" and "frac_wall" in rf     # every timed round is one full-K launch
+    assert rf["concurrent_streams"] == 2                                                  # ... per shard stream
     assert rf["kernel"] == "step_k_kernel<3,4,double,false,true>" and abs(rf["bytes_per_env_step"] - (158 / 32 + 40)) < 1e-9
     assert abs(d["value"] - 20000 * 6 * 32 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and d["scaling"] == "weak" and d["higher_is_better"] is True
     for k in ("float64_rows", "float32_rows", "float64_views", "float32_views"):
         assert set(d["hetero_h24_gym_steps"][k]["roofline"]) >= {"bound", "achieved", "peak", "frac", "gpu_us_per_step_isolated"}, k
-    assert {"fused_launches_materialised", "fused_launches_materialised_one_stream", "rbc_rollout_materialised",
+    assert {"fused_launches_one_stream", "fused_launches_materialised", "fused_launches_materialised_one_stream", "rbc_rollout_materialised",
             "single_step_launches_one_call", "rbc_rollout_on_device", "single_step_launches_python_loop"} <= set(d["other"])
     assert all("error" not in v for v in d["other"].values())
     assert d["other"]["fused_launches_materialised"]["roofline"]["concurrent_streams"] == 2

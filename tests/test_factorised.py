@@ -97,11 +97,23 @@ def test_fused_and_single_steps_factorised_vs_materialised(arch, act_dtype, devi
         acts = torch.rand(K, N, A, dtype=act_dtype, device=device, generator=g)
         for e in (em, ef):
             e.reset(t0, want_obs=False)
+        st = bm.state()
         om = em.step_k(acts, reward=True, done=True, soc_trace=True)
         of = ef.step_k(acts, reward=True, done=True, soc_trace=True)
         for k in om:
             assert torch.equal(om[k], of[k]), (k, t0)
         _same_state(bm, bf)
+        # the HOT form of the loop (exactly reward + SoC, `done` derived from the counter) == the general form
+        end = bm.state()
+        for b, e in ((bm, em), (bf, ef)):
+            b.load_state(st)
+            e.reset(t0, want_obs=False)
+            assert torch.equal(e.done_steps(K), om["done"].view(torch.bool))
+            oh = e.step_k(acts, reward=True, done=False, soc_trace=True)
+            assert set(oh) == {"reward", "soc_trace"}
+            assert torch.equal(oh["reward"], om["reward"]) and torch.equal(oh["soc_trace"], om["soc_trace"]), t0
+            for k, v in end.items():
+                assert torch.equal(b.cols[k], v), k
     for e in (em, ef):
         e.reset(100, want_obs=False)
     acts = torch.rand(150, N, A, dtype=act_dtype, device=device, generator=g)
@@ -148,11 +160,27 @@ def test_discrete_paths_factorised_vs_materialised(arch, device):
         assert torch.equal(x, y)
     K = 400
     ids = torch.randint(0, len(lists), (K, N), dtype=torch.uint8, device=device, generator=g)
+    st, t_st = bm.state(), em.current_step
     om = em.rollout_discrete(ids, table, K, reward=True, done=True, soc_trace=True)
     of = ef.rollout_discrete(ids, table, K, reward=True, done=True, soc_trace=True)
     for k in om:
         assert torch.equal(om[k], of[k]), k
     _same_state(bm, bf)
+    end = bm.state()
+    for b, e in ((bm, em), (bf, ef)):                       # the HOT form (reward + SoC only) of both rollouts == the general one
+        for these in (ids, ids[0].contiguous()):
+            b.load_state(st)
+            e.reset(t_st, want_obs=False)
+            ref = e.rollout_discrete(these, table, K, reward=True, done=True, soc_trace=True)
+            b.load_state(st)
+            e.reset(t_st, want_obs=False)
+            oh = e.rollout_discrete(these, table, K, reward=True, done=False, soc_trace=True)
+            assert torch.equal(oh["reward"], ref["reward"]) and torch.equal(oh["soc_trace"], ref["soc_trace"])
+        b.load_state(st)
+        e.reset(t_st, want_obs=False)
+        e.rollout_discrete(ids, table, K, reward=True, done=False, soc_trace=True)
+        for k, v in end.items():
+            assert torch.equal(b.cols[k], v), k
     for e in (em, ef):
         e.reset(70, want_obs=False)
     fixed = ids[0].contiguous()
