@@ -24,6 +24,9 @@ f, a = sys.argv[1], sys.argv[2:]
 def arg(name, default):
     return int(a[a.index(name) + 1]) if name in a else default
 d = json.load(open(f)); d["grids"] = arg("--grids", 100000); d["chunk"] = arg("--chunk", 64); d["bench_args"] = " ".join(a)
+d["series"] = a[a.index("--series") + 1] if "--series" in a else "factorised"
+d["note"] = ("by_launch_threads is keyed by kernel SPECIALISATION: the factorised (…,true>) and materialised (…,false>) forms of the "
+             "fused kernels run in the same bench command (headline and 'other')")
 json.dump(d, open(f, "w"), indent=1)
 PY
 cat "$OUT/summary.txt"
