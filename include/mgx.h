@@ -407,7 +407,9 @@ int mgx_step_many(mgx_handle *h, const void *actions, int32_t K, int normalized,
  *   mgx_join(h, s)  s waits for everything issued to the shard streams so far (outputs are then safe to read on s)
  * Every other entry point still runs on the stream it is given: bracket it with mgx_join / mgx_fork.  Buffers handed to
  * a stepping call must stay alive until the next mgx_join.  mgx_shard_stream returns the hipStream_t of a shard (for
- * timing events), NULL when shards are off.  Not offered in device-counter mode. */
+ * timing events), NULL when shards are off.  Not offered in device-counter mode.  The shard streams are a per-device pool
+ * shared by all handles of the process (the runtime multiplexes streams onto a few hardware queues: private pairs per handle
+ * ended up on one queue): handles that step in shards at the same time are ordered per stream. */
 int mgx_set_shards(mgx_handle *h, int32_t n_shards);
 int mgx_fork(mgx_handle *h, mgx_stream stream);
 int mgx_join(mgx_handle *h, mgx_stream stream);

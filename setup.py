@@ -1,7 +1,7 @@
 """pip install -e .   /   python setup.py build_hip
 
-Builds pymgrid_amd/libmgx.so in-tree with hipcc for gfx950 (the same recipe as __graft_entry__.build(): one translation
-unit, pymgrid_amd/csrc/mgx_abi.hip) and packages it with the Python surface.  hipcc cross-compiles without a GPU."""
+Builds pymgrid_amd/libmgx.so in-tree with hipcc for gfx950 (the same recipe as __graft_entry__.build(): mgx_abi.hip + the
+five slices of mgx_fused.hip compiled in parallel, pymgrid_amd/_lib.py) and packages it with the Python surface.  hipcc cross-compiles without a GPU."""
 import importlib.util
 import os
 

@@ -1,19 +1,19 @@
 #!/bin/bash
-# Run ON THE GPU BOX: HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of config-5 fleet stepping, per fleet step:
-# every mgx kernel dispatched from the first of the last STEPS fleet_step_kernel launches on (step launches + ring refills).
-# usage: gpu_pmc_fleet.sh [K] [chunks|ahead] [float64|float32]
+# Run ON THE GPU BOX: HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of config-5 fleet stepping (99 999 grids, H = 24,
+# T = 8 760, factorised series), per fleet step: every mgx kernel dispatched from the first of the last STEPS fleet_step_kernel
+# launches on (step launches + ring refills).   usage: gpu_pmc_fleet.sh [rows|views] [float64|float32]
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-K=${1:-16}; MODE=${2:-ahead}; ROWS=${3:-float64}; STEPS=256
-OUT=$REPO/gpurun_out/pmc_fleet
+CONTRACT=${1:-rows}; DT=${2:-float64}; STEPS=1024
+OUT=$REPO/gpurun_out/pmc_fleet_${CONTRACT}_${DT}
 mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace -d "$OUT/$c" -o b --output-format csv -- python "$REPO/tools/exp_hetero_trace.py" $STEPS $K $ROWS $MODE > "$OUT/$c.log" 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace -d "$OUT/$c" -o b --output-format csv -- python "$REPO/tools/exp_fleet_prof.py" $CONTRACT $DT 3000 > "$OUT/$c.log" 2>&1
 done
 cd "$REPO"
-python - "$OUT" $STEPS $K $MODE $ROWS <<'PY' | tee "$OUT/summary.txt"
+python - "$OUT" $STEPS $CONTRACT $DT <<'PY' | tee "$OUT/summary.txt"
 import csv, glob, json, os, sys
-out, steps, K, mode, rows_t = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+out, steps, contract, dt = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = []
@@ -32,12 +32,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     tot[c] = sum(v for _, v in by.values())
 # gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads (MI355X_MICROARCH.md)
 per_step = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / steps
-print(f"HBM bytes per fleet step (K = {K}, refill = {mode}, {rows_t} rows): {per_step / 1e6:.1f} MB "
+print(f"HBM bytes per fleet step ({contract}, {dt}): {per_step / 1e6:.1f} MB "
       f"(read {2 * tot['FETCH_SIZE'] * 1024 / steps / 1e6:.1f} + written {tot['WRITE_SIZE'] * 1024 / steps / 1e6:.1f})")
-json.dump({"kernel": "fleet_step_kernel + obs_windows_k_kernel", "grids_per_gpu": 99999, "obs_prefetch": K, "refill": mode,
-           "rows": rows_t, "hbm_bytes_per_fleet_step": per_step,
+json.dump({"kernel": "fleet_step_kernel" + (" + obs_windows_k_kernel" if contract == "rows" else ""), "grids_per_gpu": 99999,
+           "series": "factorised", "contract": contract, "dtype": dt, "obs_prefetch": 16, "hbm_bytes_per_fleet_step": per_step,
            "source": "tools/gpu_pmc_fleet.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + "
                      f"WRITE_SIZE)*1024 summed over every kernel of the last {steps} fleet steps (step launches + ring refills) / {steps}"},
-          open(os.path.join(out, "traffic_fleet.json"), "w"), indent=1)
+          open(os.path.join(out, f"traffic_fleet_{contract}_{dt}.json"), "w"), indent=1)
 PY
 rm -rf "$OUT/FETCH_SIZE" "$OUT/WRITE_SIZE"
