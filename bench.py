@@ -262,17 +262,6 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series):
             wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
             gpu = mdist.max_over_ranks(e0.elapsed_time(e1) * 1e-3, dev)
             mdist.barrier()
-            # GPU time of a fleet step on its own (HIP events around every step of a short extra pass, median): what the step
-            # occupies the device for when the host -- not the GPU -- sets the pace (the views contract from Python)
-            pairs = []
-            for _ in range(128):
-                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                if fleet.envs[0].current_step >= rows - 1:
-                    fleet.reset()
-                a0.record(); fleet.step(acts); a1.record()
-                pairs.append((a0, a1))
-            torch.cuda.synchronize(dev)
-            iso = sorted(a0.elapsed_time(a1) for a0, a1 in pairs)[len(pairs) // 2] * 1e3
             esz = 8 if dt == torch.float64 else 4
             # algorithmic bytes of one fleet step (SURVEY 8(d) formula): the core step of every bucket (no done byte: lock-step;
             # factorised: the grid's factors instead of its row values) + rows: the observation row written (esz * D) and the
@@ -302,13 +291,14 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series):
                          f"bucket on the engines' prefetch streams, beside the following step launches); bytes and time are per "
                          f"fleet step, refills included" if contract == "rows" else
                          "; the window columns are views of the once-normalised series (no bytes per step), the step writes the "
-                         "6 state columns"))
+                         "6 state columns.  From Python this contract is HOST-bound (the GPU idles between launches: the kernel "
+                         "itself takes 8.7 us per fleet step, profiles/r03/fleet_views_kernel_stats.csv), so avg_launch_us here is "
+                         "the host's pace, views taken by the caller every step included"))
             out[name] = {"value": 3 * per * world * steps / wall, "us_per_step": wall / steps * 1e6,
                          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                       "frac_wall": alg / (wall / steps) / 1e9 / HBM_PEAK_GBS,
                                       "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
-                                      "avg_launch_us": gpu / steps * 1e6, "gpu_us_per_step_isolated": iso,
-                                      "frac_isolated": alg / (iso * 1e-6) / 1e9 / HBM_PEAK_GBS, "launch": launch,
+                                      "avg_launch_us": gpu / steps * 1e6, "launch": launch,
                                       "kernel": "fleet_step_kernel" + (f" + obs_windows_k_kernel<F> x3 / {K_ring}" if contract == "rows" else ""),
                                       "refill": fleet.refill if contract == "rows" else None}}
             obs_dims = [e.layout.obs_dim for e in fleet.envs]

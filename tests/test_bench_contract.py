@@ -57,7 +57,7 @@ def test_bench_one_rank_json_line(device):
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and d["scaling"] == "weak" and d["higher_is_better"] is True
     for k in ("float64_rows", "float32_rows", "float64_views", "float32_views"):
-        assert set(d["hetero_h24_gym_steps"][k]["roofline"]) >= {"bound", "achieved", "peak", "frac", "gpu_us_per_step_isolated"}, k
+        assert set(d["hetero_h24_gym_steps"][k]["roofline"]) >= {"bound", "achieved", "peak", "frac", "frac_wall", "traffic"}, k
     assert {"fused_launches_one_stream", "fused_launches_materialised", "fused_launches_materialised_one_stream", "rbc_rollout_materialised",
             "single_step_launches_one_call", "rbc_rollout_on_device", "single_step_launches_python_loop"} <= set(d["other"])
     assert all("error" not in v for v in d["other"].values())

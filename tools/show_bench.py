@@ -22,8 +22,7 @@ elif h:
         if k in h:
             q = h[k]["roofline"]
             print(f"  hetero {k}: {h[k]['us_per_step']:.1f} us/step wall  {q['avg_launch_us']:.1f} us gpu  {h[k]['value'] / 1e9:.2f} G  "
-                  f"frac {q['frac']:.3f}  isolated {q.get('gpu_us_per_step_isolated', 0):.1f} us (frac {q.get('frac_isolated', 0):.3f})  "
-                  f"traffic {q.get('traffic')}")
+                  f"frac {q['frac']:.3f}  traffic {q.get('traffic')}")
 c = d.get("cpu_baseline")
 if c and "error" in c:
     print(f"  cpu baseline FAILED: {c['error']}")
