@@ -640,7 +640,8 @@ def main():
             "per_rank_env_steps_per_s": main_r["per_rank_env_steps_per_s"],
             "other": {names[m]: (r if "error" in r else {k: r[k] for k in ("value", "steps", "warmup", "ms_per_step", "roofline")})
                       for m, r in results.items() if m != args.mode},
-            "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total},
+            "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total,
+                                  "collective_backend": mdist.last_collective["backend"], "collective_error": mdist.last_collective["error"]},
             "hetero_h24_gym_steps": hetero,
             "prewarm_seconds_per_mode": args.prewarm,
         }

@@ -1,10 +1,19 @@
 """Multi-GPU: the grids of a batch are independent (no cross-grid term anywhere in ``Microgrid.run``), so they
 shard contiguously over ranks with NO data-path collective.  The only exchange is an optional all-reduce(sum) of a
 small metrics vector (RCCL over xGMI via ``torch.distributed`` backend "nccl"; "gloo" on CPU in tests)."""
+import datetime
 import os
 
 import torch
 import torch.distributed as dist
+
+# Control plane.  The data path has no collective, so everything a multi-rank run needs besides the final metrics all-reduce --
+# barriers around timed regions, gathering per-rank timings -- goes over a small GLOO group on host tensors: a rank that died
+# shows up as a timeout of ``monitored_barrier`` (naming the missing rank) instead of a hang inside RCCL, and RCCL itself is
+# touched exactly once, by ``all_reduce_metrics`` (with a gloo fallback that is reported, should RCCL refuse to come up).
+_ctrl = None
+CTRL_TIMEOUT_S = float(os.environ.get("MGX_CTRL_TIMEOUT_S", "600"))
+last_collective = {"backend": None, "error": None}
 
 
 def shard_bounds(n_total, rank, world):
@@ -28,33 +37,67 @@ def init_from_env(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        global _ctrl
+        if backend != "gloo":              # every rank gets here: new_group is itself a collective over the default group's store
+            _ctrl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=CTRL_TIMEOUT_S))
     return rank, world, local
 
 
+def _multi():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def all_reduce_metrics(local_sums):
-    """Sum a small metrics vector over all ranks (in place, returns it).  No-op for a single process."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """Sum a small metrics vector over all ranks (in place, returns it): THE collective of the engine (RCCL over xGMI on a GPU
+    node).  Should the default backend fail to come up, the sum is taken over the gloo control group instead and the failure is
+    kept in ``last_collective`` (bench.py prints it) -- the per-rank throughputs do not depend on it.  No-op for one process."""
+    if not _multi():
+        return local_sums
+    last_collective.update(backend=dist.get_backend(), error=None)
+    try:
         dist.all_reduce(local_sums, op=dist.ReduceOp.SUM)
+        if local_sums.is_cuda:
+            torch.cuda.synchronize(local_sums.device)       # surface an asynchronous RCCL failure here, not later
+    except Exception as e:                                   # noqa: BLE001
+        if _ctrl is None:
+            raise
+        host = local_sums.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=_ctrl)
+        local_sums.copy_(host)
+        last_collective.update(backend="gloo (fallback)", error=f"{type(e).__name__}: {e}")
     return local_sums
 
 
-def max_over_ranks(value, device):
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+def max_over_ranks(value, device=None):
+    """max of a host scalar over the ranks (control plane: gloo when the default backend is RCCL)."""
+    if not _multi():
+        return float(value)
+    if _ctrl is not None:
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_ctrl)
+    else:
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def gather_over_ranks(value, device):
+def gather_over_ranks(value, device=None):
     """[value of rank 0, ..., value of rank W-1] on every rank (one small all-gather; a one-element list for one process)."""
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-        dist.all_gather(out, t)
-        return [float(x.item()) for x in out]
-    return [float(value)]
+    if not _multi():
+        return [float(value)]
+    on_host = _ctrl is not None or dist.get_backend() == "gloo"
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if on_host else device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t, group=_ctrl)
+    return [float(x.item()) for x in out]
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """All ranks meet (control plane).  With the gloo control group a missing rank is a RuntimeError that names it after
+    MGX_CTRL_TIMEOUT_S seconds, not a hang."""
+    if not _multi():
+        return
+    if _ctrl is not None:
+        dist.monitored_barrier(group=_ctrl, timeout=datetime.timedelta(seconds=CTRL_TIMEOUT_S))
+    else:
         dist.barrier()

@@ -30,6 +30,25 @@ def _worker(rank, world, port, n_total, out):
     total = mdist.all_reduce_metrics(local.clone())
     tmax = mdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
     mdist.barrier()
+    # the control plane of a GPU run: a gloo group beside the default (RCCL) one carries barriers and timing gathers, and is the
+    # fallback of the metrics all-reduce should the default backend refuse to come up
+    import torch.distributed as dist
+    mdist._ctrl = dist.new_group(backend="gloo")
+    mdist.barrier()                                           # monitored_barrier on the control group
+    assert mdist.gather_over_ranks(10.0 + rank) == [10.0, 11.0] and mdist.max_over_ranks(float(rank)) == 1.0
+    real = dist.all_reduce
+
+    def broken_default(t, op=dist.ReduceOp.SUM, group=None, **kw):
+        if group is None:
+            raise RuntimeError("hipIpcGetMemHandle: invalid argument")      # what RCCL says without dmabuf IPC
+        return real(t, op=op, group=group, **kw)
+    dist.all_reduce = broken_default
+    try:
+        again = mdist.all_reduce_metrics(local.clone())
+    finally:
+        dist.all_reduce = real
+    assert torch.equal(again, total) and mdist.last_collective["backend"] == "gloo (fallback)"
+    assert "hipIpcGetMemHandle" in mdist.last_collective["error"]
     if rank == 0:
         torch.save(dict(total=total, tmax=tmax), out)
     torch.distributed.destroy_process_group()

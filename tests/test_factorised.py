@@ -474,3 +474,44 @@ def test_gym_flat_order_rows_are_the_permuted_module_order_rows(arch, device):
                     om, og = em.reset_grids(d, ns, nl), eg.reset_grids(d, ns, nl)
                     assert torch.equal(om[:, perm], og), k
         em.close(); eg.close()
+
+
+@pytest.mark.gpu
+def test_factorised_with_grid_before_battery_and_reward_shapers(device):
+    """The remaining specialisations of the factorised fused kernels: the grid-before-battery sweep order (F = 14 / 15:
+    module_container.py:355-413) and shaped rewards (reward_shaping/*.py: the non-HOT form of the loop)."""
+    from dataclasses import replace
+    from pymgrid_amd import MicrogridBatch, StepEngine
+    from pymgrid_amd._lib import FACTOR_COLUMNS
+    N, T, K = 3000, 400, 260
+    g = torch.Generator(device=device); g.manual_seed(10)
+    for arch in ("battery+grid", "genset+battery+grid"):
+        bm, bf = _pair(N, T, arch, device)
+        for gfb in (False, True):
+            for shaper in (0, 1, 2):
+                pair = []
+                for b in (bm, bf):
+                    cols = {k: (v.clone() if k in MicrogridBatch.STATE_COLUMNS else v) for k, v in b.cols.items()}
+                    e = StepEngine(MicrogridBatch(replace(b.layout, grid_before_battery=gfb), cols))
+                    e.set_reward_shaper(shaper)
+                    e.reset(13, want_obs=False)
+                    pair.append(e)
+                acts = torch.rand(K, N, bm.layout.action_dim, dtype=torch.float64, device=device, generator=g)
+                om = pair[0].step_k(acts, reward=True, soc_trace=True, status_trace=gfb, log=gfb)
+                of = pair[1].step_k(acts, reward=True, soc_trace=True, status_trace=gfb, log=gfb)
+                for k in om:
+                    assert torch.equal(om[k], of[k]), (arch, gfb, shaper, k)
+                for k in MicrogridBatch.STATE_COLUMNS:
+                    if k in pair[0].batch.cols:
+                        assert torch.equal(pair[0].batch.cols[k], pair[1].batch.cols[k]), (arch, gfb, shaper, k)
+                for e in pair:
+                    e.close()
+    # the sweep order matters (else this test would prove nothing): rewards of the two orders differ somewhere
+    bm, _ = _pair(N, T, "genset+battery+grid", device)
+    outs = []
+    for gfb in (False, True):
+        cols = {k: (v.clone() if k in MicrogridBatch.STATE_COLUMNS else v) for k, v in bm.cols.items()}
+        e = StepEngine(MicrogridBatch(replace(bm.layout, grid_before_battery=gfb), cols))
+        outs.append(e.step_k(acts, reward=True)["reward"])
+        e.close()
+    assert not torch.equal(outs[0], outs[1])
