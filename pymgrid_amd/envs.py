@@ -57,8 +57,8 @@ class ObsViews:
 
     @property
     def grid(self):
-        g = self._norm.get("grid")
-        return None if g is None else g.narrow(1, self.t, self.W).flatten(1)      # [N, W, 4] slice -> [N, 4 W] view
+        g = self._norm.get("grid_flat")                    # [N, R * 4] alias of the [N, R, 4] copy: one narrow, no flatten
+        return None if g is None else g.narrow(1, 4 * self.t, 4 * self.W)
 
     @property
     def genset(self):
@@ -144,7 +144,7 @@ class BatchedMicrogridEnv:
         self._state_pos = 0
         if self._views:
             self.engine.set_obs_compact(True)
-            self._norm = self.engine.normalise_series()
+            self._norm = self._normalised()
             self._state_bufs = torch.empty(self.VIEW_BUFFERS, L.n_grids, self.engine.state_dim, dtype=obs_dtype,
                                            device=batch.device)
         # lock-step `done` is the same for every grid (base_timeseries_module.py:124-125): two constant tensors, no bytes per step
@@ -230,7 +230,7 @@ class BatchedMicrogridEnv:
             if self.engine._window_start is not None:          # back from a per-grid-window episode: the full series again
                 self.engine.reset(initial_step, want_obs=False)
                 self._norm = None
-                self._norm = self.engine.normalise_series()
+                self._norm = self._normalised()
             self._state_pos = 0
             self.engine.reset(initial_step, want_obs=True, out=self._state_bufs[0])
             return self._view_now()
@@ -238,6 +238,12 @@ class BatchedMicrogridEnv:
             self.engine.reset(initial_step, want_obs=False)
             return self._select_obs(self._refill())
         return self._select_obs(self.engine.reset(initial_step, want_obs=self._observations))
+
+    def _normalised(self):
+        norm = self.engine.normalise_series()
+        if "grid" in norm:
+            norm["grid_flat"] = norm["grid"].flatten(1)      # a view: [N, R, 4] -> [N, 4 R]
+        return norm
 
     def _view_now(self):
         return ObsViews(self._norm, self.engine.current_step, 1 + self.layout.horizon, self._state_bufs[self._state_pos],
@@ -283,7 +289,7 @@ class BatchedMicrogridEnv:
             self._state_pos = 0
             self._norm = None
             self.engine.reset_windows(start, length, max_length, want_obs=True, out=self._state_bufs[0], validate=validate)
-            self._norm = self.engine.normalise_series()
+            self._norm = self._normalised()
             return self._view_now()
         if self._ring is not None:
             self.engine.reset_windows(start, length, max_length, want_obs=False, validate=validate)

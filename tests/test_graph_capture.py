@@ -7,19 +7,55 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_captured_steps_replay_like_eager(device):
+@pytest.mark.parametrize("series", ["materialised", "factorised"])
+def test_captured_fused_launches_replay_like_eager(series, device):
+    """A graph of ONE mgx_step_k launch (K = 48 steps, device-resident counter) replayed five times == the same launches issued
+    eagerly; the factorised form stages its base-profile rows from the counter's row."""
+    from pymgrid_amd import StepEngine
+    from pymgrid_amd.generator import generate
+    N, T, K, R = 4000, 300, 48, 5
+    gen = torch.Generator(device=device); gen.manual_seed(3)
+    acts = torch.rand(R, K, N, 4, dtype=torch.float64, device=device, generator=gen)
+    kw = dict(n_steps=T, seed=4, arch="genset+battery+grid", device=device, mixed_timers=True, series=series)
+    eager, eng = StepEngine(generate(N, **kw)), StepEngine(generate(N, **kw))
+    ref = [eager.step_k(acts[r], reward=True, soc_trace=True) for r in range(R)]
+    ref = [{k: v.clone() for k, v in o.items()} for o in ref]
+    eng.use_device_counter(True)
+    static_a = torch.zeros(K, N, 4, dtype=torch.float64, device=device)
+    out = dict(reward=torch.empty(K, N, dtype=torch.float64, device=device), soc_trace=torch.empty(K, N, dtype=torch.float64, device=device))
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            eng.step_k(static_a, reward=True, soc_trace=True, out=out)
+    torch.cuda.current_stream(device).wait_stream(side)
+    for r in range(R):
+        static_a.copy_(acts[r])
+        graph.replay()
+        torch.cuda.synchronize(device)
+        assert torch.equal(out["reward"], ref[r]["reward"]) and torch.equal(out["soc_trace"], ref[r]["soc_trace"]), r
+    eng.use_device_counter(False)
+    assert eng.current_step == R * K == eager.current_step
+    for name in ("charge", "soc", "gen_status"):
+        assert torch.equal(eng.batch.cols[name], eager.batch.cols[name])
+    eng.close(); eager.close()
+
+
+@pytest.mark.parametrize("series", ["materialised", "factorised"])
+def test_captured_steps_replay_like_eager(series, device):
     from pymgrid_amd import StepEngine
     from pymgrid_amd.generator import generate
     N, T, S, R = 5000, 200, 8, 5                 # graph of S steps, replayed R times
     gen = torch.Generator(device=device); gen.manual_seed(1)
     acts = torch.rand(R * S, N, 3, dtype=torch.float64, device=device, generator=gen)
-    eager = StepEngine(generate(N, n_steps=T, seed=4, device=device, mixed_timers=True))
+    eager = StepEngine(generate(N, n_steps=T, seed=4, device=device, mixed_timers=True, series=series))
     ref_r, ref_o = [], []
     for k in range(R * S):
         o, r, d, _ = eager.step(acts[k])
         ref_r.append(r.clone()); ref_o.append(o.clone())
 
-    eng = StepEngine(generate(N, n_steps=T, seed=4, device=device, mixed_timers=True))
+    eng = StepEngine(generate(N, n_steps=T, seed=4, device=device, mixed_timers=True, series=series))
     eng.use_device_counter(True)
     static_a = torch.zeros(S, N, 3, dtype=torch.float64, device=device)
     bufs = [dict(reward=torch.empty(N, dtype=torch.float64, device=device),
