@@ -68,6 +68,10 @@ def parse(argv=None):
     ap.add_argument("--arch", default="genset+battery")
     ap.add_argument("--series", choices=["factorised", "materialised"], default="factorised",
                     help="series layout of the headline batch (the other layout is timed under 'other')")
+    ap.add_argument("--full-columns", action="store_true",
+                    help="hold the parameters MicrogridGenerator gives every microgrid (battery efficiency / cycle cost, genset cost "
+                         "and co2 figures, unbalanced-energy costs, zero genset timers) as [N] columns instead of once "
+                         "(mgx_columns.uniform_mask); the factorised headline batch uses uniform columns by default")
     ap.add_argument("--hetero-steps", type=int, default=256, help="timed Gym steps of the heterogeneous H=24 fleet (0: skip)")
     ap.add_argument("--no-side-modes", action="store_true", help="time the headline mode only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,7 +205,7 @@ def timed(run, fn, rounds, device, mdist):
     return t1 - t0, max(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3
 
 
-def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series):
+def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
     """BASELINE configs[4] per GPU: a heterogeneous fleet (1/3 genset+battery, 1/3 battery+grid, 1/3 genset+battery+grid;
     forecast_horizon = 24, T = `rows`) stepped through the Gym surface WITH observations, under both observation contracts:
       rows   step() returns the [N, D] rows (D = 56 / 152 / 156): written ahead in rings of 16 row blocks, the step adds the
@@ -218,7 +222,7 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series):
         for dt_name, dt in (("float64", torch.float64), ("float32", torch.float32)):
             name = f"{dt_name}_{contract}"
             batches = [generate(per * world, n_steps=rows, seed=43 + k, arch=arch, horizon=24, device=dev, rank=rank,
-                                world=world, series=series) for k, arch in enumerate(archs)]
+                                world=world, series=series, uniform_columns=uniform) for k, arch in enumerate(archs)]
             if contract == "rows":
                 fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K_ring, reuse_outputs=3 * K_ring)
             else:
@@ -271,7 +275,7 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series):
                 L = e.layout
                 fact = e.batch.factorised
                 c_ts = L.n_load + L.n_pv + 4 * int(L.has_grid)
-                core = L.bytes_per_step() - 1 + ((18 + 2 * int(L.has_grid)) - 8 * c_ts if fact else 0)
+                core = L.bytes_per_step() - 1 + ((18 + 2 * int(L.has_grid)) - 8 * c_ts if fact else 0) - e.batch.uniform_param_bytes()
                 if contract == "rows":
                     src = (18 + 2 * int(L.has_grid)) / K_ring if fact else 8 * c_ts * (K_ring + L.horizon) / K_ring
                     alg += L.n_grids * (core + esz * L.obs_dim + src)
@@ -338,7 +342,7 @@ def cpu_baseline(eng, pool, seconds):
         elif k == "grid_ts":
             cols[k] = v[:K + 1, :, :n].contiguous().cpu().numpy()
         elif v.dim() == 1:
-            a = v[:n].cpu().numpy()
+            a = np.ascontiguousarray(v[:n].cpu().numpy())          # (uniform columns are stride-0 views)
             cols[k] = a.view(np.uint32) if v.dtype == torch.int32 else a
     cols["layout"] = dict(N=n, T=K + 1, horizon=0, final_step=K + 1, has_genset=int(L.has_genset),
                           has_battery=int(L.has_battery), has_grid=int(L.has_grid))
@@ -472,7 +476,8 @@ def main():
     def runner(series):
         """Engine + runner of one series layout (built on first use; both share the action pool and the parameter draw)."""
         if series not in runs:
-            b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=series)
+            b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=series,
+                         uniform_columns=(series == "factorised" and not args.full_columns))
             pool = next(iter(runs.values())).pool if runs else None
             runs[series] = Runner(StepEngine(b), chunk, 7 + rank, shards_of[series], pool=pool)
         return runs[series]
@@ -486,6 +491,7 @@ def main():
         eng, S = run.eng, run.S
         sharded = sharded and S > 1
         fact = eng.batch.factorised
+        ub = eng.batch.uniform_param_bytes()         # parameter bytes per grid NOT read: batch-uniform columns are held once
         run.shard(sharded)
         fn = getattr(run, mode)
         eng.reset(want_obs=False)
@@ -508,12 +514,12 @@ def main():
         n_launch = (N + S - 1) // S if sharded else N             # grids per kernel launch
         if mode in ("fused", "rbc"):
             A8 = 8 * L.action_dim * chunk if mode == "rbc" else 0  # rbc: no action stream; + 1 id byte per grid, once
-            per_launch = L.bytes_fused(chunk, done=run.done_stream, factorised=fact) - A8 + (1 if mode == "rbc" else 0)
+            per_launch = L.bytes_fused(chunk, done=run.done_stream, factorised=fact) - A8 + (1 if mode == "rbc" else 0) - ub
             launches_per_round = 1
         else:                                                      # `chunk` single-step launches per round
             # single steps of a factorised batch read the grid's factors (2 ratios + 2 profile ids: 18 B) where the
             # materialised one reads 2 row values (16 B); no done byte
-            per_launch = L.bytes_per_step() - (0 if run.done_stream else 1) + (2 if fact else 0)
+            per_launch = L.bytes_per_step() - (0 if run.done_stream else 1) + (2 if fact else 0) - ub
             launches_per_round = chunk
         launches = rounds * launches_per_round                     # per stream
         per_launch_bytes = per_launch * N                          # one launch on every shard stream = all N grids
@@ -533,6 +539,7 @@ def main():
                 "frac_wall": per_launch_bytes / wall_launch_s / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": per_launch_bytes, "kernel": kname, "series": "factorised" if fact else "materialised",
+                "uniform_parameter_bytes_per_grid": ub,
                 "bytes_per_env_step": per_launch / (chunk if mode in ("fused", "rbc") else 1),
                 "launches": launches, "avg_launch_us": avg_launch_s * 1e6, "avg_launch_us_wall": wall_launch_s * 1e6,
                 "timed_rounds": [first, first + rounds]}
@@ -591,7 +598,7 @@ def main():
     hetero = None
     if args.hetero_steps > 0:
         hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist, args.rows,
-                                                                          args.series))
+                                                                          args.series, args.series == "factorised" and not args.full_columns))
 
     # metrics vector: episode-return sum + mean SoC, all-reduced over ranks (the ONLY collective; RCCL over xGMI)
     sums = eng.metrics(torch.stack([run.outs[0]["reward"][-1], batch.cols["soc"]]))
@@ -627,6 +634,7 @@ def main():
                        "step": f"one round = {chunk} consecutive env-steps of all grids of a rank",
                        "env_steps_per_step": chunk, "grids_per_gpu": N, "grids_total": n_total, "mode": args.mode,
                        "steps_per_launch": 1 if args.mode == "step" else chunk,
+                       "uniform_parameter_columns": batch.uniform_columns(),
                        "series": args.series + (" (base profile id + ratio per grid; the product is formed in the kernel, "
                                                 "bit-identical to the [T, N] arrays)" if args.series == "factorised" else
                                                 " ([T, N] float64 arrays)"),

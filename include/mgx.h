@@ -119,9 +119,21 @@ enum mgx_flat_order { MGX_FLAT_MODULE = 0, MGX_FLAT_GYM = 1 };
 #define MGX_MAX_INSTANCES 8
 
 /* Device columns.  Pointers for absent modules may be NULL. */
+/* Batch-UNIFORM parameter columns (mgx_columns.uniform_mask): bit b set = the parameter column b below holds ONE value that
+ * every grid shares (the pointer addresses a single element; kernels index it with 0).  MicrogridGenerator gives every microgrid
+ * the same battery efficiency / cycle cost, genset cost / co2 figures, unbalanced-energy costs and -- unless drawn -- genset
+ * timers (convert/get_module.py:39-97, MicrogridGenerator.py:472): 60 of the 108 parameter bytes a single step reads per grid.
+ * Values are the same, the loads become same-address (broadcast) loads out of the caches.  One module of every kind only. */
+enum mgx_uniform_bit {
+    MGX_U_BAT_MIN_CAPACITY = 0, MGX_U_BAT_MAX_CAPACITY, MGX_U_BAT_MAX_CHARGE, MGX_U_BAT_MAX_DISCHARGE, MGX_U_BAT_EFFICIENCY,
+    MGX_U_BAT_COST_CYCLE, MGX_U_GEN_RUNNING_MIN, MGX_U_GEN_RUNNING_MAX, MGX_U_GEN_COST, MGX_U_GEN_CO2_PER_UNIT,
+    MGX_U_GEN_COST_PER_UNIT_CO2, MGX_U_GEN_TIMES, MGX_U_GRID_MAX_IMPORT, MGX_U_GRID_MAX_EXPORT, MGX_U_GRID_COST_PER_UNIT_CO2,
+    MGX_U_LOSS_LOAD_COST, MGX_U_OVERGENERATION_COST
+};
+
 typedef struct mgx_columns {
     int32_t struct_size;      /* = sizeof(mgx_columns) */
-    int32_t reserved;
+    uint32_t uniform_mask;    /* bits of enum mgx_uniform_bit; 0 = every column is [N] */
     /* BatteryModule parameters (battery_module.py:66-93) */
     const double *bat_min_capacity, *bat_max_capacity, *bat_max_charge, *bat_max_discharge;
     const double *bat_efficiency, *bat_cost_cycle;

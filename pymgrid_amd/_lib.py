@@ -48,6 +48,11 @@ _F64_COLS2 = ("grid_max_import", "grid_max_export", "grid_cost_per_unit_co2", "l
               "load_noise_std", "pv_noise_std", "grid_noise_std", "charge", "soc")
 
 
+# enum mgx_uniform_bit: parameter columns that may hold ONE value for the whole batch (mgx_columns.uniform_mask)
+UNIFORM_BITS = ("bat_min_capacity", "bat_max_capacity", "bat_max_charge", "bat_max_discharge", "bat_efficiency", "bat_cost_cycle",
+                "gen_running_min", "gen_running_max", "gen_cost", "gen_co2_per_unit", "gen_cost_per_unit_co2", "gen_times",
+                "grid_max_import", "grid_max_export", "grid_cost_per_unit_co2", "loss_load_cost", "overgeneration_cost")
+
 # factorised series (mgx_columns, include/mgx.h): base tables [T, PROFILE_PITCH] f64, profile ids / tariff uint8 [N], ratios f64
 # [N], outage words [ceil(T / 64), N] (stored as int64: torch has no uint64)
 FACTOR_COLUMNS = ("base_load", "base_pv", "base_co2", "load_profile", "pv_profile", "co2_profile", "tariff", "load_ratio",
@@ -56,7 +61,7 @@ PROFILE_PITCH = 8          # MGX_PROFILE_PITCH
 
 
 class Columns(C.Structure):
-    _fields_ = ([("struct_size", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = ([("struct_size", C.c_int32), ("uniform_mask", C.c_uint32)]
                 + [(n, C.c_void_p) for n in _F64_COLS]
                 + [("gen_times", C.c_void_p)]
                 + [(n, C.c_void_p) for n in _F64_COLS2]

@@ -264,7 +264,10 @@ class MicrogridBatch:
                 raise TypeError(f"column {name}: dtype {t.dtype}, expected {want}")
             if tuple(t.shape) != shapes.get(name, (N,)):
                 raise ValueError(f"column {name}: shape {tuple(t.shape)}, expected {shapes.get(name, (N,))}")
-            if not t.is_contiguous():
+            if name in _lib.UNIFORM_BITS and t.dim() == 1 and N > 1 and t.stride(0) == 0:
+                if L.multi:              # a batch-uniform parameter: ONE value, expanded (mgx_columns.uniform_mask)
+                    raise ValueError(f"column {name}: uniform (stride-0) columns need one module of every kind per grid")
+            elif not t.is_contiguous():
                 raise ValueError(f"column {name} must be contiguous")
             dev = dev or t.device
             if t.device != dev:
@@ -335,7 +338,8 @@ class MicrogridBatch:
             return self.materialise().numpy_columns()
         out = {}
         for k, v in self.cols.items():
-            out[k] = v.cpu().numpy().view(np.uint32) if v.dtype == torch.int32 else v.cpu().numpy()
+            a = np.ascontiguousarray(v.cpu().numpy())          # (a uniform column is a stride-0 view: the oracle wants [N])
+            out[k] = a.view(np.uint32) if v.dtype == torch.int32 else a
         out["layout"] = dict(N=self.layout.n_grids, T=self.layout.n_steps, horizon=self.layout.horizon,
                              final_step=self.layout.final_step, has_genset=int(self.layout.has_genset),
                              has_battery=int(self.layout.has_battery), has_grid=int(self.layout.has_grid),
@@ -351,12 +355,26 @@ class MicrogridBatch:
         L.struct_size = _lib.C.sizeof(_lib.Layout)
         return L
 
+    def uniform_columns(self):
+        """Names of the parameter columns that hold ONE value for the whole batch (a stride-0 ``tensor.expand(N)``): the kernels
+        read element 0 for every grid (``mgx_columns.uniform_mask``), nothing per grid moves."""
+        N = self.layout.n_grids
+        return [n for n in _lib.UNIFORM_BITS if n in self.cols and self.cols[n].dim() == 1 and N > 1 and self.cols[n].stride(0) == 0]
+
+    def uniform_param_bytes(self):
+        """Bytes per grid a step does NOT read because these parameters are batch-uniform (8 per fp64 column, 4 for gen_times)."""
+        return sum(4 if n == "gen_times" else 8 for n in self.uniform_columns())
+
     def c_columns(self):
         c = _lib.Columns()
         c.struct_size = _lib.C.sizeof(_lib.Columns)
         for name in _lib.COLUMN_NAMES:
             t = self.cols.get(name)
             setattr(c, name, t.data_ptr() if t is not None else None)
+        mask = 0
+        for name in self.uniform_columns():
+            mask |= 1 << _lib.UNIFORM_BITS.index(name)
+        c.uniform_mask = mask
         return c
 
 

@@ -279,6 +279,10 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     NEED(L->has_grid, grid_max_import); NEED(L->has_grid, grid_max_export); NEED(L->has_grid, grid_cost_per_unit_co2);
     NEED(L->has_grid && !fact, grid_ts);
 #undef NEED
+    if (C->uniform_mask && (L->n_load != 1 || L->n_pv != 1 || n_genset > 1 || n_battery > 1 || n_grid > 1))
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_create: uniform_mask is offered for one module of every kind per grid");
+    if (C->uniform_mask >> (MGX_U_OVERGENERATION_COST + 1))
+        return fail(MGX_ERR_INVALID, "mgx_create: uniform_mask 0x%x has bits beyond MGX_U_OVERGENERATION_COST", C->uniform_mask);
     if (fact && (L->n_load != 1 || L->n_pv != 1 || n_genset > 1 || n_battery > 1 || n_grid > 1))
         return fail(MGX_ERR_UNSUPPORTED, "mgx_create: factorised series need exactly one module of every kind per grid (the "
                                          "general kernels read materialised series)");

@@ -282,23 +282,36 @@ __device__ __forceinline__ double series_component(const mgx_columns &c, int64_t
 
 // ---- loads ----------------------------------------------------------------------------------------------
 // parameters of the controllable modules at column index i (= instance * N + grid for layouts with several instances)
+// A batch-uniform column (mgx_columns.uniform_mask) holds one value: every lane reads element 0 (a same-address load, one
+// cache line for the whole wave) instead of its own element.
+__device__ __forceinline__ int64_t col_index(const mgx_columns &c, int bit, int64_t i)
+{
+    return ((c.uniform_mask >> bit) & 1u) ? (int64_t)0 : i;
+}
+
 template <int F>
 __device__ __forceinline__ void load_module_params(const mgx_columns &c, int64_t i, Params &p)
 {
     if constexpr (F & F_BATTERY) {
-        p.bat_cmin = c.bat_min_capacity[i]; p.bat_cmax = c.bat_max_capacity[i];
-        p.bat_C = c.bat_max_charge[i];      p.bat_D = c.bat_max_discharge[i];
-        p.bat_eta = c.bat_efficiency[i];    p.bat_cost = c.bat_cost_cycle[i];
+        p.bat_cmin = c.bat_min_capacity[col_index(c, MGX_U_BAT_MIN_CAPACITY, i)];
+        p.bat_cmax = c.bat_max_capacity[col_index(c, MGX_U_BAT_MAX_CAPACITY, i)];
+        p.bat_C = c.bat_max_charge[col_index(c, MGX_U_BAT_MAX_CHARGE, i)];
+        p.bat_D = c.bat_max_discharge[col_index(c, MGX_U_BAT_MAX_DISCHARGE, i)];
+        p.bat_eta = c.bat_efficiency[col_index(c, MGX_U_BAT_EFFICIENCY, i)];
+        p.bat_cost = c.bat_cost_cycle[col_index(c, MGX_U_BAT_COST_CYCLE, i)];
     }
     if constexpr (F & F_GENSET) {
-        p.gen_rmin = c.gen_running_min[i];  p.gen_rmax = c.gen_running_max[i];
-        p.gen_cost = c.gen_cost[i];         p.gen_co2 = c.gen_co2_per_unit[i];
-        p.gen_cco2 = c.gen_cost_per_unit_co2[i];
-        p.gen_times = c.gen_times[i];
+        p.gen_rmin = c.gen_running_min[col_index(c, MGX_U_GEN_RUNNING_MIN, i)];
+        p.gen_rmax = c.gen_running_max[col_index(c, MGX_U_GEN_RUNNING_MAX, i)];
+        p.gen_cost = c.gen_cost[col_index(c, MGX_U_GEN_COST, i)];
+        p.gen_co2 = c.gen_co2_per_unit[col_index(c, MGX_U_GEN_CO2_PER_UNIT, i)];
+        p.gen_cco2 = c.gen_cost_per_unit_co2[col_index(c, MGX_U_GEN_COST_PER_UNIT_CO2, i)];
+        p.gen_times = c.gen_times[col_index(c, MGX_U_GEN_TIMES, i)];
     }
     if constexpr (F & F_GRID) {
-        p.grid_imp = c.grid_max_import[i];  p.grid_exp = c.grid_max_export[i];
-        p.grid_cco2 = c.grid_cost_per_unit_co2[i];
+        p.grid_imp = c.grid_max_import[col_index(c, MGX_U_GRID_MAX_IMPORT, i)];
+        p.grid_exp = c.grid_max_export[col_index(c, MGX_U_GRID_MAX_EXPORT, i)];
+        p.grid_cco2 = c.grid_cost_per_unit_co2[col_index(c, MGX_U_GRID_COST_PER_UNIT_CO2, i)];
     }
 }
 
@@ -306,8 +319,8 @@ template <int F>
 __device__ __forceinline__ void load_params(const mgx_columns &c, int64_t i, Params &p)
 {
     load_module_params<F>(c, i, p);
-    p.ll_cost = c.loss_load_cost[i];
-    p.og_cost = c.overgeneration_cost[i];
+    p.ll_cost = c.loss_load_cost[col_index(c, MGX_U_LOSS_LOAD_COST, i)];
+    p.og_cost = c.overgeneration_cost[col_index(c, MGX_U_OVERGENERATION_COST, i)];
 }
 
 template <int F>

@@ -342,7 +342,7 @@ def _factor_columns(dev, T, N, gidx, seed, d, r, P, has_grid):
 
 
 def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, device="cuda", rank=0, world=1,
-             mixed_timers=False, final_step=0, select=None, series="materialised", flat_order="module"):
+             mixed_timers=False, final_step=0, select=None, series="materialised", flat_order="module", uniform_columns=False):
     """Build the [rank]-th shard of a global batch of ``n_grids`` microgrids of architecture ``arch`` on ``device``.
     ``select``: optional global indices (numpy int array, ascending) -- the grids of the global draw to build instead of
     the rank's contiguous block (``generate_fleet`` uses it to split one draw by architecture).
@@ -351,6 +351,9 @@ def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, d
     the generator's own multiply, bit-identically, and the [T, N] arrays (14 GB per 100 000 grid-years) never exist."""
     if series not in ("materialised", "factorised"):
         raise ValueError("series must be 'materialised' or 'factorised'")
+    # uniform_columns: the parameters MicrogridGenerator gives EVERY microgrid (battery efficiency / cycle cost, genset cost and
+    # co2 figures, unbalanced-energy costs; the genset timers unless drawn) are held once (stride-0 columns ->
+    # mgx_columns.uniform_mask) instead of N times: 60 of the 108 parameter bytes a single step reads per grid
     has_genset, has_battery, has_grid = ARCHS[arch]
     dev = torch.device(device)
     D = draw_scalars(n_grids, seed, mixed_timers)
@@ -368,6 +371,9 @@ def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, d
     f64 = dict(dtype=torch.float64, device=dev)
     up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), **f64)
 
+    def const(v):                    # a column every grid shares: one element expanded to [N], or N copies
+        return torch.full((1,), v, **f64).expand(N) if (uniform_columns and N > 1) else torch.full((N,), v, **f64)
+
     if series == "factorised":
         cols = _factor_columns(dev, T, N, idx, seed, d, r, P, has_grid)
         grid_ts = None
@@ -378,35 +384,36 @@ def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, d
     bl, bp = _tile_rows(P["load"], T), _tile_rows(P["pv"], T)
     cols["load_lo"] = up(-(bl.max(axis=0)[d["load_file"]] * r["load_ratio"])); cols["load_hi"] = torch.zeros(N, **f64)
     cols["pv_lo"] = torch.zeros(N, **f64); cols["pv_hi"] = up(bp.max(axis=0)[d["pv_file"]] * r["pv_ratio"])
-    cols["loss_load_cost"] = torch.full((N,), 10.0, **f64)              # df_parameters['cost_loss_load'] (:472)
-    cols["overgeneration_cost"] = torch.full((N,), 1.0, **f64)
+    cols["loss_load_cost"] = const(10.0)              # df_parameters['cost_loss_load'] (:472)
+    cols["overgeneration_cost"] = const(1.0)
     if has_battery:                                                     # get_battery_module (convert/get_module.py:39-57)
         cols["bat_max_capacity"] = up(r["bat_max_capacity"]); cols["bat_min_capacity"] = up(r["bat_min_capacity"])
         cols["bat_max_charge"] = up(r["bat_power"]); cols["bat_max_discharge"] = up(r["bat_power"])
-        cols["bat_efficiency"] = torch.full((N,), 0.9, **f64)
-        cols["bat_cost_cycle"] = torch.full((N,), 0.02, **f64)
+        cols["bat_efficiency"] = const(0.9)
+        cols["bat_cost_cycle"] = const(0.02)
         cols["soc"] = up(r["soc0"]); cols["charge"] = up(r["soc0"] * r["bat_max_capacity"])   # battery_module.py:96-106
     if has_genset:                                                      # get_genset_module (:60-76)
         cols["gen_running_min"] = up(r["gen_running_min"]); cols["gen_running_max"] = up(r["gen_running_max"])
-        cols["gen_cost"] = torch.full((N,), 0.4, **f64)
-        cols["gen_co2_per_unit"] = torch.full((N,), 2.0, **f64)
-        cols["gen_cost_per_unit_co2"] = torch.full((N,), 0.1, **f64)
-        cols["gen_times"] = torch.from_numpy(pack_times(d["su"], d["wd"]).view(np.int32).copy()).to(dev)
+        cols["gen_cost"] = const(0.4)
+        cols["gen_co2_per_unit"] = const(2.0)
+        cols["gen_cost_per_unit_co2"] = const(0.1)
+        times = torch.from_numpy(pack_times(d["su"], d["wd"]).view(np.int32).copy()).to(dev)
+        cols["gen_times"] = times[:1].expand(N) if (uniform_columns and N > 1 and not mixed_timers) else times
         st = pack_status(np.ones(N, np.int64), np.ones(N, np.int64), np.zeros(N, np.int64), d["wd"])   # init on
         cols["gen_status"] = torch.from_numpy(st.view(np.int32).copy()).to(dev)
     if has_grid:                                                        # get_grid_module (:79-97)
         cols["grid_max_import"] = up(r["grid_power"]); cols["grid_max_export"] = up(r["grid_power"])
-        cols["grid_cost_per_unit_co2"] = torch.full((N,), 0.1, **f64)
+        cols["grid_cost_per_unit_co2"] = const(0.1)
         if grid_ts is not None:
             cols["grid_ts"] = grid_ts
             cols["grid_lo"] = grid_ts.amin(dim=0).contiguous(); cols["grid_hi"] = grid_ts.amax(dim=0).contiguous()
     layout = BatchLayout(n_grids=N, n_steps=T, horizon=horizon, initial_step=0, final_step=final_step,
                          has_genset=has_genset, has_battery=has_battery, has_grid=has_grid, flat_order=flat_order)
-    return MicrogridBatch(layout, {k: v.contiguous() for k, v in cols.items()})
+    return MicrogridBatch(layout, {k: (v if (v.dim() == 1 and N > 1 and v.stride(0) == 0) else v.contiguous()) for k, v in cols.items()})
 
 
 def generate_fleet(n_grids, n_steps=YEAR, seed=42, horizon=0, device="cuda", rank=0, world=1, mixed_timers=False,
-                   series="materialised"):
+                   series="materialised", uniform_columns=False):
     """A heterogeneous population with MicrogridGenerator's own architecture mix (BASELINE config 5): the rank's block of
     the global draw, split by the architecture each grid drew.  Returns {arch: (MicrogridBatch, global indices)}."""
     if n_grids % world:
@@ -419,5 +426,5 @@ def generate_fleet(n_grids, n_steps=YEAR, seed=42, horizon=0, device="cuda", ran
         idx = np.nonzero(arch[rank * per:(rank + 1) * per] == name)[0] + rank * per
         if len(idx):
             out[name] = (generate(n_grids, n_steps, seed, name, horizon, device, mixed_timers=mixed_timers, select=idx,
-                                  series=series), idx)
+                                  series=series, uniform_columns=uniform_columns), idx)
     return out

@@ -515,3 +515,81 @@ def test_factorised_with_grid_before_battery_and_reward_shapers(device):
         outs.append(e.step_k(acts, reward=True)["reward"])
         e.close()
     assert not torch.equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batch-uniform parameter columns (mgx_columns.uniform_mask)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_uniform_columns_host():
+    """generate(uniform_columns=True): the parameters MicrogridGenerator gives every microgrid are stride-0 columns (one value),
+    equal to the full columns; the C struct carries their bits; the oracle's copy is contiguous again."""
+    from pymgrid_amd import _lib
+    from pymgrid_amd.generator import generate
+    bu = generate(40, n_steps=50, seed=1, arch="genset+battery+grid", device="cpu", uniform_columns=True)
+    bn = generate(40, n_steps=50, seed=1, arch="genset+battery+grid", device="cpu")
+    assert bn.uniform_columns() == [] and bn.c_columns().uniform_mask == 0
+    names = bu.uniform_columns()
+    assert set(names) == {"bat_efficiency", "bat_cost_cycle", "gen_cost", "gen_co2_per_unit", "gen_cost_per_unit_co2", "gen_times",
+                          "grid_cost_per_unit_co2", "loss_load_cost", "overgeneration_cost"}
+    assert bu.uniform_param_bytes() == 8 * 8 + 4
+    assert bu.c_columns().uniform_mask == sum(1 << _lib.UNIFORM_BITS.index(n) for n in names)
+    for k in bn.cols:
+        assert torch.equal(bu.cols[k], bn.cols[k]), k
+    assert all(a.flags.c_contiguous for a in bu.numpy_columns().values() if isinstance(a, np.ndarray))
+    mixed = generate(40, n_steps=50, seed=1, arch="genset+battery", device="cpu", uniform_columns=True, mixed_timers=True)
+    assert "gen_times" not in mixed.uniform_columns()                  # drawn per grid: a real column
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ARCHS)
+@pytest.mark.parametrize("series", ["materialised", "factorised"])
+def test_uniform_columns_equal_full_columns(arch, series, device):
+    """Every kernel family on a batch with uniform parameter columns == the batch with full [N] columns: single steps (+ log,
+    obs), fused steps (HOT and general form), rollouts, the discrete step, observation rows / rings, views, a fleet step."""
+    from pymgrid_amd import BatchedMicrogridEnv, StepEngine
+    from pymgrid_amd.generator import generate
+    from pymgrid_amd.priority_list import get_priority_lists, table_array
+    N, T, H = 3000, 300, 24
+    kw = dict(n_steps=T, seed=21, arch=arch, device=device, series=series)
+    bn, bu = generate(N, **kw), generate(N, uniform_columns=True, **kw)
+    assert bu.uniform_columns() and not bn.uniform_columns()
+    en, eu = StepEngine(bn), StepEngine(bu)
+    g = torch.Generator(device=device); g.manual_seed(4)
+    A = bn.layout.action_dim
+    acts = torch.rand(140, N, A, dtype=torch.float64, device=device, generator=g)
+    for e in (en, eu):
+        e.reset(5, want_obs=False)
+    for k in range(3):
+        rn, ru = en.step(acts[k], want_obs=True, want_log=True), eu.step(acts[k], want_obs=True, want_log=True)
+        for x, y in zip(rn, ru):
+            assert torch.equal(x, y)
+    for kwargs in (dict(reward=True, soc_trace=True), dict(reward=True, done=True, soc_trace=True, status_trace=True, log=True)):
+        on, ou = en.step_k(acts, **kwargs), eu.step_k(acts, **kwargs)
+        for k in on:
+            assert torch.equal(on[k], ou[k]), k
+    L = bn.layout
+    lists = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, False)
+    table = table_array(lists)
+    ids = torch.randint(0, len(lists), (100, N), dtype=torch.uint8, device=device, generator=g)
+    for these in (ids, ids[0].contiguous()):
+        on, ou = en.rollout_discrete(these, table, 100, reward=True, soc_trace=True), eu.rollout_discrete(these, table, 100, reward=True, soc_trace=True)
+        for k in on:
+            assert torch.equal(on[k], ou[k]), k
+    i32 = ids[1].to(torch.int32)
+    for x, y in zip(en.step_discrete(i32, table, want_log=True, want_control=True), eu.step_discrete(i32, table, want_log=True, want_control=True)):
+        assert torch.equal(x, y)
+    for k in ("charge", "soc", "gen_status"):
+        if k in bn.cols:
+            assert torch.equal(bn.cols[k], bu.cols[k]), k
+    en.close(); eu.close()
+    # observations: rows (per step and rings) and views
+    kw = dict(kw, horizon=H, n_steps=120)
+    for mode in (dict(obs_prefetch=0), dict(obs_prefetch=8), dict(obs_views=True)):
+        vn, vu = BatchedMicrogridEnv(generate(N, **kw), **mode), BatchedMicrogridEnv(generate(N, uniform_columns=True, **kw), **mode)
+        flat = (lambda o: o.flat()) if "obs_views" in mode else (lambda o: o)
+        assert torch.equal(flat(vn.reset(90)), flat(vu.reset(90)))
+        for k in range(30):
+            a = vn.sample_action(generator=g)
+            (o1, r1, d1, _), (o2, r2, d2, _) = vn.step(a), vu.step(a)
+            assert torch.equal(flat(o1), flat(o2)) and torch.equal(r1, r2) and torch.equal(d1, d2), (mode, k)
+        vn.close(); vu.close()
