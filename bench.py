@@ -68,10 +68,11 @@ def parse(argv=None):
     ap.add_argument("--arch", default="genset+battery")
     ap.add_argument("--series", choices=["factorised", "materialised"], default="factorised",
                     help="series layout of the headline batch (the other layout is timed under 'other')")
-    ap.add_argument("--full-columns", action="store_true",
+    ap.add_argument("--uniform-columns", action="store_true",
                     help="hold the parameters MicrogridGenerator gives every microgrid (battery efficiency / cycle cost, genset cost "
-                         "and co2 figures, unbalanced-energy costs, zero genset timers) as [N] columns instead of once "
-                         "(mgx_columns.uniform_mask); the factorised headline batch uses uniform columns by default")
+                         "and co2 figures, unbalanced-energy costs, zero genset timers) once instead of as [N] columns "
+                         "(mgx_columns.uniform_mask).  Off by default: 60 fewer bytes per grid and single step buy no time "
+                         "(profiles/r03/exp_uniform_columns.txt)")
     ap.add_argument("--hetero-steps", type=int, default=256, help="timed Gym steps of the heterogeneous H=24 fleet (0: skip)")
     ap.add_argument("--no-side-modes", action="store_true", help="time the headline mode only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -477,7 +478,7 @@ def main():
         """Engine + runner of one series layout (built on first use; both share the action pool and the parameter draw)."""
         if series not in runs:
             b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=series,
-                         uniform_columns=(series == "factorised" and not args.full_columns))
+                         uniform_columns=(series == "factorised" and args.uniform_columns))
             pool = next(iter(runs.values())).pool if runs else None
             runs[series] = Runner(StepEngine(b), chunk, 7 + rank, shards_of[series], pool=pool)
         return runs[series]
@@ -598,7 +599,7 @@ def main():
     hetero = None
     if args.hetero_steps > 0:
         hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist, args.rows,
-                                                                          args.series, args.series == "factorised" and not args.full_columns))
+                                                                          args.series, args.series == "factorised" and args.uniform_columns))
 
     # metrics vector: episode-return sum + mean SoC, all-reduced over ranks (the ONLY collective; RCCL over xGMI)
     sums = eng.metrics(torch.stack([run.outs[0]["reward"][-1], batch.cols["soc"]]))

@@ -52,7 +52,7 @@ def test_bench_one_rank_json_line(device):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["launches"] == 6 and rf["series"] == "factorised" and "frac_wall" in rf     # every timed round is one full-K launch
     assert rf["concurrent_streams"] == 2                                                  # ... per shard stream
-    assert rf["kernel"] == "step_k_kernel<3,4,double,false,true>" and abs(rf["bytes_per_env_step"] - ((158 - 60) / 32 + 40)) < 1e-9
+    assert rf["kernel"] == "step_k_kernel<3,4,double,false,true>" and abs(rf["bytes_per_env_step"] - (158 / 32 + 40)) < 1e-9
     assert abs(d["value"] - 20000 * 6 * 32 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and d["scaling"] == "weak" and d["higher_is_better"] is True

@@ -549,7 +549,7 @@ def test_uniform_columns_equal_full_columns(arch, series, device):
     from pymgrid_amd import BatchedMicrogridEnv, StepEngine
     from pymgrid_amd.generator import generate
     from pymgrid_amd.priority_list import get_priority_lists, table_array
-    N, T, H = 3000, 300, 24
+    N, T, H = 3000, 700, 24
     kw = dict(n_steps=T, seed=21, arch=arch, device=device, series=series)
     bn, bu = generate(N, **kw), generate(N, uniform_columns=True, **kw)
     assert bu.uniform_columns() and not bn.uniform_columns()
