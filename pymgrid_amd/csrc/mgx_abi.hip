@@ -212,7 +212,7 @@ static int launch_observe(const mgx_handle *h, int32_t t, void *obs, hipStream_t
         MGX_DISPATCH_F(h->flags, (observe_kernel<F><<<blocks_for(h->k.N), BLOCK, 0, st>>>(h->k, t, obs)));
         return MGX_OK;
     }
-    const int32_t W = 1 + h->k.H, D = h->k.obs_dim;
+    const int32_t D = h->k.obs_dim;
     WindowPlan plan;
     plan.grid_col_base = h->k.col_grid;
     plan.ld = D | 1;
@@ -499,7 +499,7 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (int rc = need_obs_bounds(h, who)) return rc;
     if (!dev_counter(h) && ahead == 0 && h->t > h->k.T)
         return fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, h->k.T);
-    const int32_t W = 1 + h->k.H, R = K + h->k.H, ncomp = 2 + 4 * h->layout.has_grid;
+    const int32_t R = K + h->k.H, ncomp = 2 + 4 * h->layout.has_grid;
     plan->grid_col_base = h->k.col_grid;
     plan->K = K;
     plan->rp = R;
@@ -563,19 +563,17 @@ int mgx_patch_windows(mgx_handle *h, const uint8_t *mask, int32_t K, void *ring,
     if (dev_counter(h)) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: not offered in device-counter mode");
     if (int rc = need_obs_bounds(h, "mgx_patch_windows")) return rc;
     if (first_block == K) return MGX_OK;
-    const int32_t W = 1 + h->k.H;
-    const int32_t grid_col_base = h->k.col_grid;
     const unsigned blocks = (unsigned)((h->k.N + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
     const int32_t rows = (K - first_block) + h->k.H;
     if (rows > PATCH_MAX_ROWS) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: (K - first_block) + horizon = %d rows exceed %d", rows, PATCH_MAX_ROWS);
     const size_t lds = 2 * (size_t)(h->layout.has_grid ? 6 : 2) * rows * sizeof(double);
     if (h->layout.has_grid) {
-        if (h->k.obs_f32) patch_windows_kernel<true, float><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, grid_col_base, (float *)ring, restarted);
-        else patch_windows_kernel<true, double><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, grid_col_base, (double *)ring, restarted);
+        if (h->k.obs_f32) patch_windows_kernel<true, float><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, (float *)ring, restarted);
+        else patch_windows_kernel<true, double><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, (double *)ring, restarted);
     } else {
-        if (h->k.obs_f32) patch_windows_kernel<false, float><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, grid_col_base, (float *)ring, restarted);
-        else patch_windows_kernel<false, double><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, grid_col_base, (double *)ring, restarted);
+        if (h->k.obs_f32) patch_windows_kernel<false, float><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, (float *)ring, restarted);
+        else patch_windows_kernel<false, double><<<blocks, 64, lds, st>>>(h->k, mask, h->t + ahead, K, first_block, h->ring_pitch, (double *)ring, restarted);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "patch_windows_kernel launch");

@@ -767,7 +767,7 @@ constexpr int PATCH_MAX_ROWS = 512;     // (K - first) + H rows the LDS image of
 
 template <bool GRID, typename OT>
 __global__ __launch_bounds__(64) void patch_windows_kernel(const KArgs a, const uint8_t *__restrict__ mask, int32_t t, int32_t K,
-                                                           int32_t first, int32_t pitch, int32_t grid_col_base, OT *__restrict__ ring,
+                                                           int32_t first, int32_t pitch, OT *__restrict__ ring,
                                                            uint8_t *__restrict__ acc)
 {
     constexpr int NCOMP = GRID ? 6 : 2;
