@@ -22,7 +22,13 @@ def marginal_costs(cols, layout, t):
     if layout.has_battery:
         out[BATTERY] = cols["bat_cost_cycle"]
     if layout.has_grid:
-        out[GRID] = cols["grid_ts"][t, 0]
+        if cols.get("grid_ts") is not None:
+            out[GRID] = cols["grid_ts"][t, 0]
+        else:                              # factorised series: the import price is the tariff pattern's value at hour t % 24
+            from .generator import electricity_tariff
+            pat = np.asarray(cols["tariff"].cpu())
+            p1, p2 = electricity_tariff(1, t + 1)[t], electricity_tariff(2, t + 1)[t]
+            out[GRID] = np.where(pat == 1, p1, np.where(pat == 2, p2, 0.0))
     return {k: np.asarray(v.cpu() if torch.is_tensor(v) else v, dtype=np.float64) for k, v in out.items()}
 
 

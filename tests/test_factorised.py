@@ -593,3 +593,42 @@ def test_uniform_columns_equal_full_columns(arch, series, device):
             (o1, r1, d1, _), (o2, r2, d2, _) = vn.step(a), vu.step(a)
             assert torch.equal(flat(o1), flat(o2)) and torch.equal(r1, r2) and torch.equal(d1, d2), (mode, k)
         vn.close(); vu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ARCHS)
+def test_factorised_batch_vs_the_oracle_directly(arch, device, oracle):
+    """The factorised kernels against the CPU oracle itself (not only against the materialised kernels): fused steps from an
+    odd row across two LDS chunks, then a rule-based rollout with the marginal-cost priority lists (RuleBasedControl), on the
+    series the factors stand for."""
+    from pymgrid_amd import StepEngine
+    from pymgrid_amd.generator import generate
+    from pymgrid_amd.priority_list import get_priority_lists, table_array
+    from pymgrid_amd.rbc import default_priority_ids
+    N, T, K = 2048, 400, 300
+    bf = generate(N, n_steps=T, seed=33, arch=arch, device=device, mixed_timers=True, series="factorised")
+    bm = generate(N, n_steps=T, seed=33, arch=arch, device=device, mixed_timers=True)
+    cols = bf.numpy_columns()
+    st = {k: cols[k].copy() for k in ("charge", "soc", "gen_status") if k in cols}
+    g = torch.Generator(device=device); g.manual_seed(12)
+    acts = torch.rand(K, N, bf.layout.action_dim, dtype=torch.float64, device=device, generator=g)
+    e = StepEngine(bf)
+    e.reset(41, want_obs=False)
+    out = e.step_k(acts, reward=True, soc_trace=True)
+    ref = oracle.run_batch(cols, st, 41, K, acts.cpu().numpy(), normalized=True, nthreads=8)
+    assert np.array_equal(out["reward"].cpu().numpy(), ref)
+    assert np.array_equal(bf.cols["charge"].cpu().numpy(), st["charge"]) and np.array_equal(out["soc_trace"][-1].cpu().numpy(), st["soc"])
+    if "gen_status" in st:
+        assert np.array_equal(bf.cols["gen_status"].cpu().numpy().view(np.uint32), st["gen_status"])
+    # rule-based control: the priority ids of a factorised batch (tariff prices from the pattern) == the materialised batch's
+    L = bf.layout
+    lists = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, False)
+    ids_f = default_priority_ids(bf, lists, remove_redundant_gensets=False)
+    assert np.array_equal(ids_f, default_priority_ids(bm, lists, remove_redundant_gensets=False))
+    e.reset(0, want_obs=False)
+    st = {k: bf.cols[k].cpu().numpy().view(np.uint32 if k == "gen_status" else np.float64).copy() for k in st}
+    r = e.rollout_discrete(torch.from_numpy(ids_f).to(device), table_array(lists), K, reward=True, soc_trace=True)
+    ref = oracle.rollout_batch(cols, st, 0, K, ids_f, table_array(lists), nthreads=8)
+    assert np.array_equal(r["reward"].cpu().numpy(), ref)
+    assert np.array_equal(bf.cols["charge"].cpu().numpy(), st["charge"])
+    e.close()

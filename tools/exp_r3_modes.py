@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--rows", type=int, default=8760)
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--what", default="fused,rbc,step,graph")
+    ap.add_argument("--series", default="materialised,factorised")
     args = ap.parse_args()
     from pymgrid_amd import StepEngine
     from pymgrid_amd.generator import generate
@@ -40,12 +41,13 @@ def main():
     sync = lambda: torch.cuda.synchronize(dev)
     gen = torch.Generator(device=dev); gen.manual_seed(7)
     pool = torch.rand(4, K, N, 3, dtype=torch.float64, device=dev, generator=gen)
-    bm = generate(N, n_steps=T, seed=42, arch="genset+battery", device=dev)
-    bf = generate(N, n_steps=T, seed=42, arch="genset+battery", device=dev, series="factorised")
     lists = get_priority_lists(True, True, False, False)
     table = table_array(lists)
-    ids = torch.from_numpy(default_priority_ids(bm, lists, remove_redundant_gensets=False)).to(dev)
-    for name, b in (("materialised", bm), ("factorised", bf)):
+    ids = None
+    for name in args.series.split(","):
+        b = generate(N, n_steps=T, seed=42, arch="genset+battery", device=dev, series=name)
+        if ids is None:
+            ids = torch.from_numpy(default_priority_ids(b, lists, remove_redundant_gensets=False)).to(dev)
         eng = StepEngine(b)
         L = eng.layout
         outs = [dict(reward=torch.empty(K, N, dtype=torch.float64, device=dev),
