@@ -608,6 +608,8 @@ int mgx_observe_windows_ahead(mgx_handle *h, int32_t ahead, int32_t K, void *rin
     DeviceGuard on_device(h->device);
     if (!h->prefetch_stream) {
         // (a low- or high-priority prefetch stream is slower: 31.4 / 33.5 vs 29.6 us per config-5 fleet step)
+        // (a CU-masked prefetch stream -- hipExtStreamCreateWithCUMask, 25..75 % of every XCD's CUs -- is 2-3x slower:
+        //  profiles/r03/exp_fleet_cu_mask_reverted.txt)
         e = hipStreamCreateWithFlags(&h->prefetch_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prefetch_gate, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prefetch_done, hipEventDisableTiming);

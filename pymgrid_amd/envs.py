@@ -640,10 +640,10 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
 
     def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
                  trajectory_func=None, raise_errors=False, observation_keys=None, obs_dtype=torch.float64,
-                 obs_prefetch=None):
+                 obs_prefetch=None, obs_views=False):
         super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
                          trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
-                         obs_dtype=obs_dtype, obs_prefetch=obs_prefetch)
+                         obs_dtype=obs_dtype, obs_prefetch=obs_prefetch, obs_views=obs_views)
         L = self.layout
         redundant = []                       # genset instances whose "off" element is redundant (running_min_production == 0)
         if remove_redundant_gensets and L.has_genset:

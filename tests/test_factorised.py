@@ -322,16 +322,19 @@ def test_views_refuse_bounds_that_do_not_bound(device):
 
 
 @pytest.mark.gpu
-def test_fleet_with_views_and_factorised_series_vs_rows(device):
-    """A heterogeneous fleet (three layouts, H = 24) stepped by mgx_fleet_step: factorised + views == materialised + rows."""
+@pytest.mark.parametrize("discrete", [False, True])
+def test_fleet_with_views_and_factorised_series_vs_rows(discrete, device):
+    """A heterogeneous fleet (three layouts, H = 24) stepped by mgx_fleet_step -- continuous controls, or priority-list ids
+    (DiscreteMicrogridEnv.step for every grid) -- factorised + views == materialised + rows."""
     from pymgrid_amd.generator import generate_fleet
     from pymgrid_amd.hetero import BucketedFleet
     n, T, H = 9000, 100, 24
     pr = generate_fleet(n, n_steps=T, seed=17, horizon=H, device=device, mixed_timers=True)
     pv = generate_fleet(n, n_steps=T, seed=17, horizon=H, device=device, mixed_timers=True, series="factorised")
     names = list(pr)
-    rows = BucketedFleet.from_batches([pr[k][0] for k in names], obs_prefetch=8, reuse_outputs=24)
-    views = BucketedFleet.from_batches([pv[k][0] for k in names], obs_views=True, reuse_outputs=24)
+    kw = dict(discrete=True, remove_redundant_gensets=False) if discrete else {}
+    rows = BucketedFleet.from_batches([pr[k][0] for k in names], obs_prefetch=8, reuse_outputs=24, **kw)
+    views = BucketedFleet.from_batches([pv[k][0] for k in names], obs_views=True, reuse_outputs=24, **kw)
     assert rows.fused and views.fused
     o, v = rows.reset(), views.reset()
     for x, y in zip(o, v):
