@@ -635,3 +635,52 @@ def test_factorised_batch_vs_the_oracle_directly(arch, device, oracle):
     assert np.array_equal(r["reward"].cpu().numpy(), ref)
     assert np.array_equal(bf.cols["charge"].cpu().numpy(), st["charge"])
     e.close()
+
+
+@pytest.mark.gpu
+def test_views_and_lockstep_done_through_resets_and_trajectories(device):
+    """The host-side bookkeeping of round 3 under stress: observation views, the lock-step `done` constants and the host mirror
+    of the step counter through mid-episode resets, a FixedLengthStochasticTrajectory (a new window at every reset) and a fused
+    fleet that is reset in the middle of its cached step plans -- always == a rows env driven the same way."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    from pymgrid_amd.generator import generate, generate_fleet
+    from pymgrid_amd.hetero import BucketedFleet
+    from pymgrid_amd.trajectory import FixedLengthStochasticTrajectory
+    N, T, H = 1500, 150, 24
+    kw = dict(n_steps=T, seed=77, arch="genset+battery+grid", device=device, horizon=H, mixed_timers=True)
+    np.random.seed(5)
+    rows = BatchedMicrogridEnv(generate(N, **kw), trajectory_func=FixedLengthStochasticTrajectory(17))
+    np.random.seed(5)
+    views = BatchedMicrogridEnv(generate(N, series="factorised", **kw), trajectory_func=FixedLengthStochasticTrajectory(17), obs_views=True)
+    g = torch.Generator(device=device); g.manual_seed(9)
+    for episode in range(4):
+        np.random.seed(100 + episode); o = rows.reset()
+        np.random.seed(100 + episode); v = views.reset()
+        assert rows.current_step == views.current_step == rows.initial_step and (rows.initial_step, rows.final_step) == (views.initial_step, views.final_step)
+        assert torch.equal(o, v.flat())
+        n_steps = 17 if episode % 2 == 0 else 6                  # every other episode is abandoned mid-way
+        for k in range(n_steps):
+            a = rows.sample_action(generator=g)
+            o, r, d, _ = rows.step(a)
+            v, r2, d2, _ = views.step(a)
+            assert torch.equal(o, v.flat()) and torch.equal(r, r2) and torch.equal(d, d2), (episode, k)
+            assert bool(d.all()) == (k == 16) and rows.current_step == views.current_step == rows.initial_step + k + 1
+    rows.close(); views.close()
+    # a fused fleet: reset in the middle of its rings / cached plans, several times
+    pr = generate_fleet(6000, n_steps=90, seed=3, horizon=H, device=device, mixed_timers=True)
+    pv = generate_fleet(6000, n_steps=90, seed=3, horizon=H, device=device, mixed_timers=True, series="factorised")
+    names = list(pr)
+    fr = BucketedFleet.from_batches([pr[k][0] for k in names], obs_prefetch=8, reuse_outputs=16)
+    fv = BucketedFleet.from_batches([pv[k][0] for k in names], obs_views=True, reuse_outputs=16)
+    for n_steps in (13, 5, 30, 89):
+        o, v = fr.reset(), fv.reset()
+        for x, y in zip(o, v):
+            assert torch.equal(x, y.flat())
+        for k in range(n_steps):
+            acts = fr.sample_action(generator=g)
+            o, r, d, _ = fr.step(acts)
+            v, r2, d2, _ = fv.step(acts)
+            for b in range(len(names)):
+                assert torch.equal(o[b], v[b].flat()) and torch.equal(r[b], r2[b]) and torch.equal(d[b], d2[b]), (n_steps, k, names[b])
+            assert all(e.current_step == k + 1 for e in fr.envs + fv.envs)
+    fr.close(); fv.close()
