@@ -26,8 +26,10 @@ def timed(step, n=300):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+series = sys.argv[1] if len(sys.argv) > 1 else "materialised"
+print(f"series = {series}")
 for arch in ("genset+battery", "genset+battery+grid"):
-    make = lambda: generate(N, n_steps=8760, seed=1, arch=arch, horizon=24, device=dev)
+    make = lambda: generate(N, n_steps=8760, seed=1, arch=arch, horizon=24, device=dev, series=series)
     env = BatchedMicrogridEnv(make())
     a = env.sample_action(); env.reset()
     print(f"{arch:20s} lock-step env, ring prefetch K = 16      {timed(lambda: env.step(a)):7.1f} us/step")
