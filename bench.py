@@ -448,7 +448,7 @@ def main():
             assert ranks == list(range(world)), ranks
             if rank == 0:
                 print(json.dumps({"launch_check": True, "n_gpus": world, "backend": dist.get_backend(), "ranks": ranks}), flush=True)
-            dist.barrier()
+            mdist.barrier()
             dist.destroy_process_group()
         else:
             print(json.dumps({"launch_check": True, "n_gpus": 1, "backend": None, "ranks": [0]}), flush=True)
@@ -658,7 +658,7 @@ def main():
     eng.close()
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
+        mdist.barrier()                 # (control plane: gloo; a dead rank is named after MGX_CTRL_TIMEOUT_S instead of hanging RCCL)
         dist.destroy_process_group()
 
 
