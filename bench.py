@@ -596,6 +596,33 @@ def main():
             runs.pop(other_series).eng.close()
             torch.cuda.empty_cache()
 
+    # an agent IN the loop (the fused modes replay pre-staged actions): obs -> a small on-device policy -> env.step -> obs, from
+    # Python, observation rows written every step (H = 0: 8 values per grid)
+    closed = None
+    if not args.no_side_modes:
+        def closed_loop():
+            from pymgrid_amd import BatchedMicrogridEnv
+            env = BatchedMicrogridEnv(generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world,
+                                               series=args.series))
+            g = torch.Generator(device=dev); g.manual_seed(5)
+            W = torch.randn(env.layout.obs_dim, env.layout.action_dim, dtype=torch.float64, device=dev, generator=g)
+            obs = env.reset()
+            n = min(2000, args.rows - 200)
+            for _ in range(100):
+                obs = env.step(torch.sigmoid(obs @ W))[0]
+            mdist.barrier(); torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                obs, reward, done, _ = env.step(torch.sigmoid(obs @ W))
+            torch.cuda.synchronize(dev)
+            wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+            mdist.barrier()
+            env.close()
+            return {"value": n_total * n / wall, "us_per_step": wall / n * 1e6, "steps": n,
+                    "loop": "obs [N, 8] -> sigmoid(obs @ W) -> BatchedMicrogridEnv.step (one launch) -> obs, issued from Python: "
+                            "three kernels per env-step (matmul, sigmoid, step); host-paced"}
+        closed = guarded("closed_loop_policy_gym_steps", closed_loop)
+
     hetero = None
     if args.hetero_steps > 0:
         hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist, args.rows,
@@ -651,6 +678,7 @@ def main():
                       for m, r in results.items() if m != args.mode},
             "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total,
                                   "collective_backend": mdist.last_collective["backend"], "collective_error": mdist.last_collective["error"]},
+            "closed_loop_policy_gym_steps": closed,
             "hetero_h24_gym_steps": hetero,
             "prewarm_seconds_per_mode": args.prewarm,
         }

@@ -267,6 +267,9 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
         return fail(MGX_ERR_INVALID, "mgx_create: final_step value must be greater than initial_step");
 #define NEED(cond, ptr) if ((cond) && !(C->ptr)) return fail(MGX_ERR_INVALID, "mgx_create: column " #ptr " is NULL")
     const bool fact = C->base_load != nullptr;           // factorised series: the [T, N] arrays are optional
+    if (fact && (L->n_load != 1 || L->n_pv != 1 || n_genset > 1 || n_battery > 1 || n_grid > 1))
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_create: factorised series need exactly one module of every kind per grid (the "
+                                         "general kernels read materialised series)");
     NEED(L->n_load > 0 && !fact, load_ts); NEED(L->n_pv > 0 && !fact, pv_ts); NEED(true, loss_load_cost); NEED(true, overgeneration_cost);
     NEED(fact, base_pv); NEED(fact, load_profile); NEED(fact, pv_profile); NEED(fact, load_ratio); NEED(fact, pv_ratio);
     NEED(fact && L->has_grid, base_co2); NEED(fact && L->has_grid, co2_profile); NEED(fact && L->has_grid, tariff);
@@ -283,9 +286,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
         return fail(MGX_ERR_UNSUPPORTED, "mgx_create: uniform_mask is offered for one module of every kind per grid");
     if (C->uniform_mask >> (MGX_U_OVERGENERATION_COST + 1))
         return fail(MGX_ERR_INVALID, "mgx_create: uniform_mask 0x%x has bits beyond MGX_U_OVERGENERATION_COST", C->uniform_mask);
-    if (fact && (L->n_load != 1 || L->n_pv != 1 || n_genset > 1 || n_battery > 1 || n_grid > 1))
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_create: factorised series need exactly one module of every kind per grid (the "
-                                         "general kernels read materialised series)");
+
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)

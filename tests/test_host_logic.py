@@ -166,3 +166,51 @@ def test_header_is_plain_c(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
                     "-fsyntax-only", str(src)], check=True)
+
+
+def test_create_argument_checks_of_round_3_without_a_gpu(pymgrid25):
+    """mgx_create validates layouts / columns before it looks for a device: the round-3 additions (factorised series, flat_order,
+    uniform columns) refuse inconsistent input with a message -- checked here on a GPU-less host."""
+    from pymgrid_amd import MicrogridBatch, _lib
+    from pymgrid_amd.generator import generate
+    L = _lib.lib()
+
+    def create(batch, edit_layout=None, edit_cols=None):
+        lay, cols = batch.c_layout(), batch.c_columns()
+        if edit_layout:
+            edit_layout(lay)
+        if edit_cols:
+            edit_cols(cols)
+        h = C.c_void_p()
+        rc = L.mgx_create(C.byref(lay), C.byref(cols), C.byref(h))
+        assert not h.value or rc == 0
+        if h.value:
+            L.mgx_destroy(h)
+        return rc, L.mgx_last_error().decode()
+
+    bf = generate(8, n_steps=30, seed=1, arch="genset+battery+grid", device="cpu", series="factorised")
+    rc, msg = create(bf, edit_cols=lambda c: setattr(c, "load_ratio", None))
+    assert rc == _lib.MGX_ERR_INVALID and "load_ratio" in msg
+    rc, msg = create(bf, edit_cols=lambda c: setattr(c, "tariff", None))
+    assert rc == _lib.MGX_ERR_INVALID and "tariff" in msg
+    rc, msg = create(bf, edit_layout=lambda l: setattr(l, "flat_order", 7))
+    assert rc == _lib.MGX_ERR_INVALID and "flat_order" in msg
+    rc, msg = create(bf, edit_cols=lambda c: setattr(c, "uniform_mask", 1 << 20))
+    assert rc == _lib.MGX_ERR_INVALID and "uniform_mask" in msg
+    # several modules of a kind: the general kernels read materialised series, native row order, full columns only
+    two = dict(pymgrid25[2]); two["genset"] = [pymgrid25[2]["genset"]] * 2
+    bm = MicrogridBatch.from_grids([two], device="cpu")
+    for edit_l, edit_c, what in ((lambda l: setattr(l, "flat_order", 1), None, "flat_order"),
+                                 (None, lambda c: setattr(c, "uniform_mask", 1), "uniform_mask"),
+                                 (None, lambda c: setattr(c, "base_load", c.load_ts), "factorised")):
+        rc, msg = create(bm, edit_l, edit_c)
+        assert rc == _lib.MGX_ERR_UNSUPPORTED and what in msg, (rc, msg)
+    if not torch.cuda.is_available():          # everything consistent: only the device is missing
+        rc, msg = create(bf)
+        assert rc == _lib.MGX_ERR_DEVICE and "no HIP device" in msg
+    # the host side refuses the same things earlier
+    with pytest.raises(ValueError):
+        MicrogridBatch(bm.layout, dict(bm.cols, base_load=torch.zeros(8760, 8, dtype=torch.float64)))
+    from dataclasses import replace
+    with pytest.raises(ValueError):
+        replace(bf.layout, flat_order="alphabetical")

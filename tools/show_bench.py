@@ -14,6 +14,10 @@ for k, v in (d.get("other") or {}).items():
     q = v["roofline"]
     print(f"  {k:42s} {v['value'] / 1e9:8.2f} G  {v['ms_per_step'] * 1e3:8.2f} us/round  frac {q['frac']:.3f}  "
           f"launch {q['avg_launch_us']:.2f} us  kernel {q.get('kernel_avg_duration_us')}")
+c = d.get("closed_loop_policy_gym_steps")
+if c:
+    print(f"  closed loop (policy on device, obs rows): " + (f"FAILED {c['error']}" if "error" in c else
+          f"{c['us_per_step']:.1f} us/step  {c['value'] / 1e9:.2f} G env-steps/s"))
 h = d.get("hetero_h24_gym_steps")
 if h and "error" in h:
     print(f"  hetero FAILED: {h['error']}")
