@@ -1,6 +1,7 @@
 // A consumer of the C ABI that is neither Python nor torch: plain HIP runtime calls for memory, include/mgx.h for everything
 // else.  Builds a small genset + battery + load + pv batch on the host, steps it through mgx_step (single steps, normalised
-// random controls) and mgx_step_k (the same steps fused), and checks every reward and the final state bit for bit against the
+// random controls) and mgx_step_k (the same steps fused; then a twin batch whose series are FACTORISED: base profiles + a profile
+// id and ratio per grid, mgx_columns.base_load), and checks every reward and the final state bit for bit against the
 // CPU oracle (oracle/mgx_oracle.h -- TEST INFRASTRUCTURE; this file lives under tests/ and is only built and run by
 // tests/test_c_abi_consumer.py).  Exit code 0 = identical.
 //
@@ -117,6 +118,43 @@ int main()
     MGX_CALL(mgx_step(h, d_actions, 1, d_reward, nullptr, nullptr, nullptr, st));
     if (mgx_step(h, d_actions, 1, d_reward, nullptr, nullptr, nullptr, st) != MGX_ERR_RANGE) { fprintf(stderr, "no MGX_ERR_RANGE\n"); return 5; }
 
+    // (4) the same batch with FACTORISED series (mgx_columns.base_load ...): three base profiles [T, MGX_PROFILE_PITCH], a profile
+    // id and a ratio per grid; no [T, N] arrays on the device.  K fused steps from the initial state, checked against the oracle on
+    // the series the factors stand for (formed here with the same single multiply).
+    std::vector<double> base_l((size_t)T * MGX_PROFILE_PITCH, 0.0), base_p((size_t)T * MGX_PROFILE_PITCH, 0.0), lr(N), pr(N);
+    std::vector<uint8_t> lp(N), pp(N);
+    for (int t = 0; t < T; t++)
+        for (int c = 0; c < 3; c++) {
+            base_l[(size_t)t * MGX_PROFILE_PITCH + c] = 0.2 + uniform();
+            base_p[(size_t)t * MGX_PROFILE_PITCH + c] = uniform() * (uniform() > 0.4);
+        }
+    std::vector<double> load2((size_t)T * N), pv2((size_t)T * N);
+    for (int i = 0; i < N; i++) {
+        lp[i] = (uint8_t)(3 * uniform()); pp[i] = (uint8_t)(3 * uniform());
+        lr[i] = 30 + 90 * uniform(); pr[i] = 50 * uniform();
+        for (int t = 0; t < T; t++) {
+            const double l = base_l[(size_t)t * MGX_PROFILE_PITCH + lp[i]] * lr[i], q = base_p[(size_t)t * MGX_PROFILE_PITCH + pp[i]] * pr[i];
+            load2[(size_t)t * N + i] = -(l < 0 ? -l : l);
+            pv2[(size_t)t * N + i] = q < 0 ? -q : q;
+        }
+    }
+    mgx_columns C2 = C;
+    C2.load_ts = nullptr; C2.pv_ts = nullptr;
+    C2.base_load = to_device(base_l); C2.base_pv = to_device(base_p);
+    C2.load_profile = to_device(lp); C2.pv_profile = to_device(pp);
+    C2.load_ratio = to_device(lr); C2.pv_ratio = to_device(pr);
+    if (!C2.base_load || !C2.base_pv || !C2.load_profile || !C2.pv_profile || !C2.load_ratio || !C2.pv_ratio) return 2;
+    HIP_OK(hipMemcpy(d_charge, charge.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_soc, soc.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_status, status.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    mgx_handle *h2 = nullptr;
+    MGX_CALL(mgx_create(&L, &C2, &h2));
+    MGX_CALL(mgx_step_k(h2, d_actions, K, 1, d_reward, nullptr, nullptr, nullptr, nullptr, nullptr, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::vector<double> r_fact((size_t)K * N);
+    HIP_OK(hipMemcpy(r_fact.data(), d_reward, r_fact.size() * sizeof(double), hipMemcpyDeviceToHost));
+    mgx_destroy(h2);
+
     // the oracle, one microgrid at a time
     long bad = 0;
     for (int i = 0; i < N; i++) {
@@ -145,8 +183,22 @@ int main()
             bad += (o.reward != r_step[j]) + (o.reward != r_fused[j]) + ((uint8_t)o.done != done[j]);
         }
         bad += s.charge != ch_step[i];
+        // ... and on the factorised batch's series
+        g.load_ts = load2.data() + i; g.pv_ts = pv2.data() + i;
+        s.charge = charge[i]; s.soc = soc[i];
+        s.gen_cur = status[i] & 0xff; s.gen_goal = (status[i] >> 8) & 0xff; s.gen_up = (status[i] >> 16) & 0xff; s.gen_down = status[i] >> 24;
+        for (int k = 0; k < K; k++) {
+            orc_action a;
+            memset(&a, 0, sizeof(a));
+            const double *row = actions.data() + ((size_t)k * N + i) * A;
+            a.genset[0] = row[0]; a.genset[1] = row[1]; a.battery = row[2];
+            orc_step_out o;
+            if (orc_run(&g, &s, &a, 1, &o) != 0) { fprintf(stderr, "oracle refused step %d of grid %d (factorised)\n", k, i); return 6; }
+            bad += o.reward != r_fact[(size_t)k * N + i];
+        }
     }
     mgx_destroy(h);
-    printf("c-abi consumer: %d grids x %d steps, single steps and one fused launch vs the CPU oracle: %ld mismatches\n", N, K, bad);
+    printf("c-abi consumer: %d grids x %d steps, single steps, one fused launch and one fused launch on factorised series vs the "
+           "CPU oracle: %ld mismatches\n", N, K, bad);
     return bad == 0 ? 0 : 1;
 }
