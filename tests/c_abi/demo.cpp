@@ -185,6 +185,7 @@ int main()
         bad += s.charge != ch_step[i];
         // ... and on the factorised batch's series
         g.load_ts = load2.data() + i; g.pv_ts = pv2.data() + i;
+        memset(&s, 0, sizeof(s));
         s.charge = charge[i]; s.soc = soc[i];
         s.gen_cur = status[i] & 0xff; s.gen_goal = (status[i] >> 8) & 0xff; s.gen_up = (status[i] >> 16) & 0xff; s.gen_down = status[i] >> 24;
         for (int k = 0; k < K; k++) {
