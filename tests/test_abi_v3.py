@@ -286,6 +286,41 @@ def test_prefetched_observations_stay_valid_for_k_steps(device):
     ref.close(); pre.close()
 
 
+@pytest.mark.parametrize("H,prefetch,discrete,views", [(0, None, False, False), (6, 0, False, False), (6, 4, False, False),
+                                                        (0, None, True, False), (6, 0, False, True)])
+def test_rotating_output_buffers_of_an_env(H, prefetch, discrete, views, device):
+    """reuse_outputs=R: step() hands out reward (and per-step observation rows) as R rotating preallocated buffers -- the same
+    values as fresh tensors, each intact for R - 1 further steps, and no new reward storage after the first R steps."""
+    from pymgrid_amd import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv
+    from pymgrid_amd.generator import generate
+    N, T, R = 2500, 200, 3
+    cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
+    make = lambda: generate(N, n_steps=T, seed=9, arch="genset+battery+grid", horizon=H, device=device, series="factorised")
+    kw = dict(obs_prefetch=prefetch, obs_views=views)
+    ref, rot = cls(make(), **kw), cls(make(), reuse_outputs=R, **kw)
+    flat = (lambda o: o.flat()) if views else (lambda o: o)
+    assert torch.equal(flat(ref.reset()), flat(rot.reset()))
+    g = torch.Generator(device=device); g.manual_seed(4)
+    held, ptrs = [], set()
+    for k in range(4 * R + 1):
+        a = (torch.randint(0, ref.action_space.n, (N,), dtype=torch.int32, device=device, generator=g) if discrete
+             else torch.rand(N, 4, dtype=torch.float64, device=device, generator=g))
+        o0, r0, d0, _ = ref.step(a)
+        o1, r1, d1, _ = rot.step(a)
+        assert torch.equal(flat(o0), flat(o1)) and torch.equal(r0, r1) and torch.equal(d0, d1), k
+        ptrs.add(r1.data_ptr())
+        held.append((r1, r1.clone(), None if views else o1, None if views else o1.clone()))
+        if len(held) >= R:
+            rv, rs, ov, os_ = held[-R]                     # handed out R - 1 steps ago
+            assert torch.equal(rv, rs), k
+            if ov is not None:
+                assert torch.equal(ov, os_), k
+    assert len(ptrs) == R
+    with pytest.raises(ValueError):
+        cls(make(), reuse_outputs=1)
+    ref.close(); rot.close()
+
+
 def test_reset_while_a_prefetch_into_the_same_ring_is_in_flight(device):
     """After exactly 2 K steps an env sits at the start of ring 2 and the prefetch of ring 0 has just been launched; a reset at
     that moment refills ring 0 on the caller's stream.  The stale prefetch must not land on top of it (mgx_observe_windows
