@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 5
+#define MGX_ABI_VERSION 6
 
 enum mgx_status {
     MGX_OK = 0,
@@ -256,9 +256,35 @@ int mgx_reset_grids(mgx_handle *h, const uint8_t *mask, const int32_t *start, co
  * fixed_length == 0 = StochasticTrajectory (start = randint(initial, final - 2), final = randint(start, final));
  * microgrid/trajectory/stochastic.py:9-30.  Uniforms: Philox4x32-10 of (seed; grid, 2 * counter [+ 1]) -- reproducible and
  * independent of how often or in which order grids restart.  start_io / length_io / t0_io (device [N], each may be NULL)
- * receive, for the restarted grids only, the drawn start row, the episode length and the counter value of the restart. */
+ * receive, for the restarted grids only, the drawn start row, the episode length and the counter value of the restart.
+ * Both restart calls also serve in-place episodes (mgx_reset_episodes below): no rows are gathered then. */
 int mgx_reset_grids_random(mgx_handle *h, const uint8_t *mask, uint64_t seed, int32_t fixed_length, int32_t *start_io,
                            int32_t *length_io, int32_t *t0_io, mgx_stream stream);
+
+/* Rolling per-grid episodes IN PLACE -- factorised series only (mgx_columns.base_load ...).  Same model as
+ * mgx_reset_windows_rolling (one shared counter that restarts at 0 and never ends, every grid with its own episode:
+ * microgrid.py:205-225 per microgrid), but nothing is copied: the base tables are small and cached, so grid i simply reads row
+ * counter + row_off[i] of its own series and reports done_i = counter >= final_abs[i] - 1.  row_off / final_abs: caller-owned
+ * DEVICE arrays [N] that the handle keeps reading AND writing until the next mgx_reset*; start / length as for
+ * mgx_reset_windows (length NULL: max_length).  (Re)starts -- mgx_reset_grids, mgx_reset_grids_random -- then rewrite two
+ * words per grid instead of gathering rows.  Observation windows reach beyond an episode's end into the grid's series and
+ * beyond the series' end into the forecaster's padding, exactly as in lock-step.  Single steps only (as for rolling windows);
+ * no observation rings (mgx_observe_windows*, MGX_OBS_ROWS_STATE_ONLY): rows are written per step.
+ * MGX_ERR_UNSUPPORTED for materialised [T, N] series (every lane would read its own row: 8x the traffic). */
+int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length, int32_t *row_off,
+                       int32_t *final_abs, void *obs, mgx_stream stream);
+/* Auto-reset inside the step (in-place episodes only): every single step restarts the grids whose episode it ends -- the
+ * draw mgx_reset_grids_random(mask = done, seed, fixed_length) would make at the counter value after the step, made by the
+ * step kernel itself -- so that the step's `obs` is, for those grids, the first observation of their new episode (what a
+ * vectorised Gym env with auto-reset returns) and no further launch is needed.  start_io / length_io / t0_io as for
+ * mgx_reset_grids_random (device [N], each may be NULL; kept until the mode is switched off or the next mgx_reset*).
+ * enable = 0 switches it off. */
+int mgx_set_auto_reset(mgx_handle *h, int32_t enable, uint64_t seed, int32_t fixed_length, int32_t *start_io, int32_t *length_io,
+                       int32_t *t0_io);
+/* Where the following single steps also write the observation BEFORE any restart ("final_observation" of a vectorised Gym
+ * env): device [N, D] rows in the handle's observation format, for every grid (grids that do not restart get the same row
+ * as `obs`).  NULL (default) = off.  In-place episodes only; the step must write observations. */
+int mgx_set_final_obs(mgx_handle *h, void *final_obs);
 
 /* Microgrid.reward_shaping_func (microgrid.py:105,130): one of enum mgx_reward_shaper. */
 int mgx_set_reward_shaper(mgx_handle *h, int32_t shaper);

@@ -17,7 +17,7 @@ FUSED_PARTS = 5            # MGX_FUSED_PARTS: slices of mgx_fused.hip (the K-ste
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC"]
 
 MGX_OK, MGX_ERR_INVALID, MGX_ERR_UNSUPPORTED, MGX_ERR_RANGE, MGX_ERR_DEVICE = range(5)
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_INSTANCES = 8          # MGX_MAX_INSTANCES: gensets / batteries / grids per microgrid
 
 
@@ -135,6 +135,9 @@ SYMBOLS = {
     "mgx_reset_windows_rolling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6),
     "mgx_reset_grids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_reset_grids_random": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_reset_episodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 4),
+    "mgx_set_auto_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_set_final_obs": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgx_check_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mgx_step_many": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),

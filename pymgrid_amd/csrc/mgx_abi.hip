@@ -55,6 +55,7 @@ struct mgx_handle {
     // caller's window buffers
     bool windowed;
     bool rolling;                            // mgx_reset_windows_rolling: ring buffers, partial resets (mgx_reset_grids)
+    bool inplace;                            // mgx_reset_episodes: rolling episodes on the factorised series themselves (no buffers)
     int32_t rolling_max_length;
     double *roll_load_w, *roll_pv_w, *roll_grid_w;
     int32_t *roll_final;
@@ -348,6 +349,10 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->prefetch_stream = nullptr; h->prefetch_gate = nullptr; h->prefetch_done = nullptr; h->prefetch_pending = false;
     h->windowed = false; h->rolling = false;
     h->k.row_mask = -1;
+    h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.ar_fixed_length = 0; h->k.ar_lo = 0; h->k.ar_hi = 0;
+    h->k.ar_max_length = 0; h->k.ar_seed = 0; h->k.ar_start_io = nullptr; h->k.ar_length_io = nullptr; h->k.ar_t0_io = nullptr;
+    h->k.final_obs = nullptr;
+    h->inplace = false;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
         return hip_fail(e, "hipMalloc(scratch)");
@@ -468,6 +473,8 @@ int mgx_set_obs_mode(mgx_handle *h, int32_t mode)
         return fail(MGX_ERR_INVALID, "mgx_set_obs_mode: unknown mode %d", mode);
     if (mode != MGX_OBS_ROWS_FULL && h->multi)
         return fail(MGX_ERR_UNSUPPORTED, "mgx_set_obs_mode: state-only rows need exactly one load and one renewable module per grid");
+    if (mode == MGX_OBS_ROWS_STATE_ONLY && h->inplace)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_set_obs_mode: prefetched observation rings are not offered with in-place episodes");
     h->k.obs_state_only = mode == MGX_OBS_ROWS_STATE_ONLY ? 1 : (mode == MGX_OBS_ROWS_STATE_COMPACT ? 2 : 0);
     return MGX_OK;
 }
@@ -492,6 +499,7 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "%s: K = %d outside [1, 4096]", who, K);
     if (ahead < 0) return fail(MGX_ERR_INVALID, "%s: ahead = %d is negative", who, ahead);
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "%s: needs exactly one module of every kind per grid", who);
+    if (h->inplace) return fail(MGX_ERR_UNSUPPORTED, "%s: observation rings are not offered with in-place episodes (mgx_reset_episodes)", who);
     if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
         return fail(MGX_ERR_UNSUPPORTED, "%s: forecast noise depends on (step, horizon index), windows cannot be shared", who);
     if (h->k.obs_state_only == 2)
@@ -559,6 +567,7 @@ int mgx_patch_windows(mgx_handle *h, const uint8_t *mask, int32_t K, void *ring,
     g_err[0] = 0;
     if (!h || !mask || !ring) return fail(MGX_ERR_INVALID, "mgx_patch_windows: NULL argument");
     if (K < 1 || first_block < 0 || first_block > K) return fail(MGX_ERR_INVALID, "mgx_patch_windows: first_block %d outside [0, K = %d]", first_block, K);
+    if (h->inplace) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: observation rings are not offered with in-place episodes");
     if (ahead < 0) return fail(MGX_ERR_INVALID, "mgx_patch_windows: ahead = %d is negative", ahead);
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: needs exactly one module of every kind per grid");
     if (dev_counter(h)) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: not offered in device-counter mode");
@@ -706,8 +715,10 @@ static void leave_windows(mgx_handle *h)
     h->k.T = h->full_T; h->k.final_step = h->full_final; h->k.grid_final = nullptr;
     h->layout.n_steps = h->full_T; h->layout.final_step = h->full_final; h->layout.initial_step = h->full_initial;
     h->window_lo = h->full_window_lo; h->window_hi = h->full_window_hi;
-    h->windowed = false; h->rolling = false;
+    h->windowed = false; h->rolling = false; h->inplace = false;
     h->k.row_mask = -1;
+    h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.final_obs = nullptr;
+    h->k.ar_start_io = nullptr; h->k.ar_length_io = nullptr; h->k.ar_t0_io = nullptr;
 }
 
 int mgx_reset(mgx_handle *h, int32_t initial_step, void *obs, mgx_stream stream)
@@ -753,11 +764,12 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
     g.lo = h->full_window_lo; g.hi = h->full_window_hi;
     g.mask = nullptr; g.row0 = 0; g.row_mask = -1;
     g.fc = h->full_c; g.has_grid = h->layout.has_grid;
-    g.draw = 0; g.fixed_length = 0; g.seed = 0; g.start_io = nullptr; g.length_io = nullptr; g.t0_io = nullptr;
+    g.draw = 0; g.fixed_length = 0; g.seed = 0; g.start_io = nullptr; g.length_io = nullptr; g.t0_io = nullptr; g.ep_off = nullptr;
     gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gather_windows_kernel launch");
     h->rolling = false; h->k.row_mask = -1;
+    h->inplace = false; h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.final_obs = nullptr;
     h->k.c.base_load = nullptr;                          // the episode steps over the (materialised) window buffers
     h->k.c.load_ts = load_w; h->k.c.pv_ts = pv_w; if (h->layout.has_grid) h->k.c.grid_ts = grid_w;
     h->k.T = rows; h->k.final_step = max_length; h->k.grid_final = length ? final_rel : nullptr;
@@ -781,6 +793,7 @@ static void rolling_gather_args(const mgx_handle *h, GatherArgs *g)
     g->row_mask = h->k.row_mask;
     g->fc = h->full_c; g->has_grid = h->layout.has_grid;
     g->draw = 0; g->fixed_length = 0; g->seed = 0; g->start_io = nullptr; g->length_io = nullptr; g->t0_io = nullptr;
+    g->ep_off = h->inplace ? h->k.ep_off : nullptr;     // in place: a (re)start writes the grid's row offset and episode end, no rows
 }
 
 int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length, int32_t ring_rows,
@@ -806,6 +819,7 @@ int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t
     h->rolling_max_length = max_length;
     h->roll_load_w = load_w; h->roll_pv_w = pv_w; h->roll_grid_w = grid_w; h->roll_final = final_abs;
     h->k.row_mask = ring_rows - 1;
+    h->inplace = false; h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.final_obs = nullptr;
     GatherArgs g;
     rolling_gather_args(h, &g);
     g.start = start; g.length = length; g.mask = nullptr; g.row0 = 0;
@@ -821,6 +835,82 @@ int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t
     h->windowed = true; h->rolling = true;
     h->t = 0;
     return obs ? mgx_observe(h, obs, stream) : MGX_OK;
+}
+
+int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length, int32_t *row_off,
+                       int32_t *final_abs, void *obs, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !start || !row_off || !final_abs) return fail(MGX_ERR_INVALID, "mgx_reset_episodes: NULL argument");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: needs exactly one module of every kind per grid");
+    if (h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered in device-counter mode");
+    if (h->n_shards > 1) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered while the handle steps in shards");
+    if (!factorised(h->windowed ? h->full_c : h->k.c))
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: in-place episodes need factorised series (every lane reads its own row: "
+                                         "[T, N] arrays would be gathered 8x over); use mgx_reset_windows_rolling");
+    if (h->k.obs_state_only == 1)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: prefetched observation rings are not offered with in-place episodes "
+                                         "(mgx_set_obs_mode(MGX_OBS_ROWS_FULL) first)");
+    if (h->prefetch_pending) { if (int rc = mgx_prefetch_wait(h, stream)) return rc; }
+    leave_windows(h);                                   // back to the full (factorised) series, whatever mode the handle was in
+    h->full_load_ts = h->k.c.load_ts; h->full_pv_ts = h->k.c.pv_ts; h->full_grid_ts = h->k.c.grid_ts;
+    h->full_T = h->k.T; h->full_final = h->layout.final_step; h->full_initial = h->layout.initial_step;
+    h->full_window_lo = h->window_lo; h->full_window_hi = h->window_hi;
+    if (max_length < 1 || max_length > h->full_window_hi - h->full_window_lo)
+        return fail(MGX_ERR_INVALID, "Cannot create a trajectory of length %d between initial_step (%d) and final_step (%d)",
+                    max_length, h->full_window_lo, h->full_window_hi);
+    h->rolling_max_length = max_length;
+    h->roll_load_w = nullptr; h->roll_pv_w = nullptr; h->roll_grid_w = nullptr; h->roll_final = final_abs;
+    h->k.row_mask = -1;
+    h->k.ep_off = row_off; h->k.ep_final = final_abs; h->k.grid_final = final_abs;
+    h->k.ar_mode = 0; h->k.final_obs = nullptr;
+    h->inplace = true;
+    GatherArgs g;
+    rolling_gather_args(h, &g);
+    g.rows = 0;
+    g.start = start; g.length = length; g.mask = nullptr; g.row0 = 0;
+    gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, (hipStream_t)stream>>>(g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->inplace = false; h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.grid_final = nullptr;
+                           return hip_fail(e, "gather_windows_kernel launch"); }
+    // k.T stays the series length (rows beyond it are padding, per grid); the counter itself never ends
+    h->k.final_step = INT32_MAX / 2;
+    h->layout.final_step = INT32_MAX / 2; h->layout.initial_step = 0;
+    h->window_lo = 0; h->window_hi = INT32_MAX / 2;
+    h->windowed = true; h->rolling = true;
+    h->t = 0;
+    return obs ? mgx_observe(h, obs, stream) : MGX_OK;
+}
+
+int mgx_set_auto_reset(mgx_handle *h, int32_t enable, uint64_t seed, int32_t fixed_length, int32_t *start_io, int32_t *length_io,
+                       int32_t *t0_io)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_auto_reset: NULL handle");
+    if (!h->inplace) return fail(MGX_ERR_INVALID, "mgx_set_auto_reset: the handle is not stepping in-place episodes (mgx_reset_episodes)");
+    if (!enable) {
+        h->k.ar_mode = 0; h->k.ar_start_io = nullptr; h->k.ar_length_io = nullptr; h->k.ar_t0_io = nullptr;
+        return MGX_OK;
+    }
+    if (fixed_length < 0 || fixed_length > h->rolling_max_length)
+        return fail(MGX_ERR_INVALID, "mgx_set_auto_reset: fixed_length %d outside [0, max_length = %d]", fixed_length, h->rolling_max_length);
+    if (fixed_length == 0 && h->rolling_max_length < h->full_window_hi - h->full_window_lo)
+        return fail(MGX_ERR_INVALID, "mgx_set_auto_reset: StochasticTrajectory draws need max_length = the whole window (%d < %d)",
+                    h->rolling_max_length, h->full_window_hi - h->full_window_lo);
+    h->k.ar_mode = 1; h->k.ar_seed = seed; h->k.ar_fixed_length = fixed_length;
+    h->k.ar_lo = h->full_window_lo; h->k.ar_hi = h->full_window_hi; h->k.ar_max_length = h->rolling_max_length;
+    h->k.ar_start_io = start_io; h->k.ar_length_io = length_io; h->k.ar_t0_io = t0_io;
+    return MGX_OK;
+}
+
+int mgx_set_final_obs(mgx_handle *h, void *final_obs)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_final_obs: NULL handle");
+    if (final_obs && !h->inplace)
+        return fail(MGX_ERR_INVALID, "mgx_set_final_obs: the handle is not stepping in-place episodes (mgx_reset_episodes)");
+    h->k.final_obs = final_obs;
+    return MGX_OK;
 }
 
 int mgx_reset_grids_random(mgx_handle *h, const uint8_t *mask, uint64_t seed, int32_t fixed_length, int32_t *start_io,
@@ -932,6 +1022,49 @@ void *mgx_shard_stream(mgx_handle *h, int32_t shard)
     return (void *)h->shard_stream[shard];
 }
 
+// ---- a single step during in-place episodes -----------------------------------------------------------------------
+// The step kernel restarts finished grids itself (mgx_set_auto_reset) and writes the observation before the restart
+// (mgx_set_final_obs) -- as long as observation rows are written inline (no forecast horizon, or state columns only).  With
+// a horizon the rows come from obs_rows_wave_kernel behind the step, which reads the offsets the step left: when the
+// pre-restart rows are wanted too, the restart is taken out of the step kernel and issued between the two observation passes.
+struct EpisodeStep {
+    KArgs k;              // what the step kernel gets
+    bool restart_after;   // the restart follows the step as a launch of its own (between the two observation passes)
+};
+
+static int episode_step_begin(mgx_handle *h, const uint8_t *done, void *obs, void *obs_inline, EpisodeStep *ep, const char *who)
+{
+    ep->k = h->k; ep->k.g0 = 0; ep->k.g1 = h->k.N;
+    ep->restart_after = false;
+    const bool rows_behind = obs && !obs_inline;
+    if (ep->k.final_obs && !obs)
+        return fail(MGX_ERR_INVALID, "%s: mgx_set_final_obs is set but the step writes no observation", who);
+    if (rows_behind && ep->k.final_obs) {
+        if (ep->k.ar_mode && !done)
+            return fail(MGX_ERR_INVALID, "%s: with a forecast horizon the observation before an automatic restart needs the `done` flags", who);
+        ep->restart_after = ep->k.ar_mode != 0;
+        ep->k.ar_mode = 0;
+        ep->k.final_obs = nullptr;                        // (written by the first observation pass below)
+    }
+    return MGX_OK;
+}
+
+static int episode_step_end(mgx_handle *h, const EpisodeStep &ep, const uint8_t *done, void *obs, void *obs_inline, hipStream_t st)
+{
+    if (!obs || obs_inline) return MGX_OK;
+    if (h->k.final_obs) { if (int rc = launch_observe(h, h->t + 1, h->k.final_obs, st)) return rc; }
+    if (ep.restart_after) {
+        GatherArgs g;
+        rolling_gather_args(h, &g);
+        g.rows = 0;
+        g.start = nullptr; g.length = nullptr; g.mask = done; g.row0 = h->t + 1;
+        g.draw = 1; g.fixed_length = h->k.ar_fixed_length; g.seed = h->k.ar_seed;
+        g.start_io = h->k.ar_start_io; g.length_io = h->k.ar_length_io; g.t0_io = h->k.ar_t0_io;
+        gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g);
+    }
+    return launch_observe(h, h->t + 1, obs, st);
+}
+
 // ---- single steps ----------------------------------------------------------------------------------------------
 // one Microgrid.run of every grid: the launches of mgx_step without its argument checks
 static int step_once(mgx_handle *h, const void *actions, int normalized, double *reward, uint8_t *done, void *obs, double *log,
@@ -948,6 +1081,17 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
         return MGX_OK;
     }
     void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
+    if (h->inplace) {                                     // in-place episodes: the EP form of the kernel (no shards in this mode)
+        EpisodeStep ep;
+        if (int rc = episode_step_begin(h, done, obs, obs_inline, &ep, "mgx_step")) return rc;
+        MGX_DISPATCH_F(h->flags, (step_kernel<F, true><<<blocks_for(ep.k.N), BLOCK, 0, st>>>(ep.k, actions, h->t, normalized, reward, done,
+                                                                                       obs_inline, log)));
+        if (int rc = episode_step_end(h, ep, done, obs, obs_inline, st)) return rc;
+        hipError_t ee = hipGetLastError();
+        if (ee != hipSuccess) return hip_fail(ee, "step_kernel launch");
+        advance(h, 1, st);
+        return MGX_OK;
+    }
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
         MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, actions, t_arg(h), normalized, reward,
                                                                                        done, obs_inline, log)));
@@ -1151,6 +1295,17 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_step_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
     void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
+    if (h->inplace) {
+        EpisodeStep ep;
+        if (int rc = episode_step_begin(h, done, obs, obs_inline, &ep, "mgx_step_discrete")) return rc;
+        MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F, true><<<blocks_for(ep.k.N), BLOCK, 0, st>>>(ep.k, tab, action_id, h->t, control, reward,
+                                                                                                done, obs_inline, log)));
+        if (int rc = episode_step_end(h, ep, done, obs, obs_inline, st)) return rc;
+        hipError_t ee = hipGetLastError();
+        if (ee != hipSuccess) return hip_fail(ee, "step_discrete_kernel launch");
+        advance(h, 1, st);
+        return MGX_OK;
+    }
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
         MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control,
                                                                                                 reward, done, obs_inline, log)));

@@ -66,6 +66,16 @@ struct KArgs {
     // Rolling per-grid windows (mgx_reset_windows_rolling): the window buffers are rings of 2^p rows addressed by
     // (step counter & row_mask); -1 (all ones: the identity) everywhere else.
     int32_t row_mask;
+    // Per-grid episodes IN PLACE (mgx_reset_episodes; factorised series only): grid i reads row counter + ep_off[i] of its own
+    // series (no window buffers), done_i = counter >= ep_final[i] - 1 (ep_final == grid_final, writable).  NULL everywhere else.
+    int32_t *ep_off, *ep_final;
+    // mgx_set_auto_reset: a single step restarts the grids whose episode it ends -- mgx_reset_grids_random's draw at the counter
+    // value after the step, inside the step kernel -- and its observation is then the first one of the new episode
+    int32_t ar_mode;                        // 0 off, 1 on
+    int32_t ar_fixed_length, ar_lo, ar_hi, ar_max_length;
+    uint64_t ar_seed;
+    int32_t *ar_start_io, *ar_length_io, *ar_t0_io;
+    void *final_obs;                        // mgx_set_final_obs: the observation BEFORE the restart (rows written inline only)
 };
 
 // done flag of grid i at step counter t: _done(), base_timeseries_module.py:124-125 (evaluated before the counter moves)
@@ -73,6 +83,13 @@ __device__ __forceinline__ uint8_t done_at(const KArgs &a, int64_t i, int32_t t)
 {
     const int32_t fin = a.grid_final ? a.grid_final[i] : a.final_step;
     return (uint8_t)(t >= fin - 1);
+}
+
+// series row of grid i at step counter t: the counter itself (rolling window buffers: a ring), or the grid's own row during
+// in-place episodes.  For the kernels off the hot path; step_kernel / step_discrete_kernel have a compile-time form.
+__device__ __forceinline__ int64_t series_row(const KArgs &a, int64_t i, int32_t t)
+{
+    return a.ep_off ? (int64_t)t + a.ep_off[i] : (int64_t)(t & a.row_mask);
 }
 
 __device__ __forceinline__ int32_t resolve_t(const KArgs &a, int32_t t)
@@ -822,6 +839,48 @@ __device__ __forceinline__ double forecast_normal(uint64_t seed, int64_t grid, u
     const double u1 = ((double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) + 1.0) * (1.0 / 9007199254740992.0);
     const double u2 = ((double)r[2] + 0.5) * (1.0 / 4294967296.0);
     return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);     // cospi: no large-argument reduction (no scratch)
+}
+
+// U[0, 1) of (seed; grid, row): Philox4x32-10 as a counter-based generator (the generator's series and the episode draws of
+// mgx_reset_grids_random use it; pymgrid_amd.generator.synth_uniform_host reproduces it bit for bit)
+__device__ __forceinline__ double synth_uniform(uint64_t seed, int64_t grid, int32_t row)
+{
+    uint32_t r[4];
+    philox4x32_10((uint32_t)grid, (uint32_t)((uint64_t)grid >> 32), (uint32_t)row, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return (double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) * (1.0 / 9007199254740992.0);      // 53 bits, [0, 1)
+}
+
+// One grid's trajectory draw at counter value `counter`, as its own trajectory_func would make it
+// (microgrid/trajectory/stochastic.py:9-30): np.random.randint(low, high) = low + min(floor(u * (high - low)), high - low - 1)
+__device__ __forceinline__ void episode_draw(uint64_t seed, int64_t i, int32_t counter, int32_t fixed_length, int32_t lo, int32_t hi,
+                                             int32_t &s, int32_t &len)
+{
+    const double u1 = synth_uniform(seed, i, 2 * counter), u2 = synth_uniform(seed, i, 2 * counter + 1);
+    auto randint = [](double u, int32_t low, int32_t high) {
+        const int32_t span = high - low;
+        if (span <= 0) return low;
+        const int32_t k = (int32_t)floor(u * (double)span);
+        return low + (k < span - 1 ? k : span - 1);
+    };
+    if (fixed_length > 0) {                                            // FixedLengthStochasticTrajectory (:15-30)
+        s = randint(u1, lo, hi - fixed_length);
+        len = fixed_length;
+    } else {                                                           // StochasticTrajectory (:9-12)
+        s = randint(u1, lo, hi - 2);
+        const int32_t fin = randint(u2, s, hi);
+        len = fin - s;
+    }
+}
+
+// a start outside the env's window [lo, hi) is clamped into it; the episode lasts 1 .. max_length steps and ends at the env's
+// final step at the latest
+__device__ __forceinline__ void episode_clamp(int32_t lo, int32_t hi, int32_t max_length, int32_t &s, int32_t &len)
+{
+    s = s < lo ? lo : (s > hi - 1 ? hi - 1 : s);
+    const int32_t room = hi - s;
+    len = len < 1 ? 1 : len;
+    len = len > max_length ? max_length : len;
+    len = len > room ? room : len;
 }
 
 // Window work of a wave: it owns G (= 16) grids and the whole window of one time-series module.  Lane = (g, q):

@@ -53,16 +53,41 @@ __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict_
     else observe_row_h0<F>(a, i, t_next, p, s, (double *)obs + i * a.obs_dim);
 }
 
-// body of one step of grid i (shared by step_kernel and fleet_step_kernel)
+// In-place episodes (KArgs.ep_off): what a step adds once the grid's own step is done -- the observation before a restart
+// (mgx_set_final_obs), the restart itself when this step ended the grid's episode (mgx_set_auto_reset: the draw of
+// mgx_reset_grids_random at the counter value after the step).  Returns the row offset the step's observation is read with.
 template <int F>
+__device__ __forceinline__ int32_t episode_tail(const KArgs &a, int64_t i, int32_t t, int32_t off, bool dn, const Params &p, const State &s)
+{
+    if (a.final_obs) store_step_obs<F>(a, a.final_obs, i, t + 1 + off, p, s);
+    if (a.ar_mode && dn) {
+        int32_t s0, len;
+        episode_draw(a.ar_seed, i, t + 1, a.ar_fixed_length, a.ar_lo, a.ar_hi, s0, len);
+        episode_clamp(a.ar_lo, a.ar_hi, a.ar_max_length, s0, len);
+        off = s0 - (t + 1);
+        a.ep_off[i] = off;
+        a.ep_final[i] = t + 1 + len;
+        if (a.ar_start_io) a.ar_start_io[i] = s0;
+        if (a.ar_length_io) a.ar_length_io[i] = len;
+        if (a.ar_t0_io) a.ar_t0_io[i] = t + 1;
+    }
+    return off;
+}
+
+// body of one step of grid i (shared by step_kernel and fleet_step_kernel).  EP: in-place per-grid episodes (the grid's series
+// row is counter + ep_off[i]; a compile-time form so that the lock-step kernel carries none of it)
+template <int F, bool EP = false>
 __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict__ actions, int32_t t, int normalized,
                                           double *__restrict__ reward, uint8_t *__restrict__ done, void *__restrict__ obs,
                                           double *__restrict__ log, int64_t i)
 {
     // all loads first (independent, one latency round), then the arithmetic
     Params p; State s; Inputs in; Outputs o; Derived d;
-    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t & a.row_mask, in);
-    else load_inputs<F>(a.c, (const double *)actions, a.N, i, t & a.row_mask, in);
+    int32_t off = 0;
+    if constexpr (EP) off = a.ep_off[i];
+    const int64_t row = EP ? (int64_t)t + off : (int64_t)(t & a.row_mask);
+    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, row, in);
+    else load_inputs<F>(a.c, (const double *)actions, a.N, i, row, in);
     load_state<F>(a.c, i, log != nullptr, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
@@ -73,14 +98,16 @@ __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict
     store_state<F>(a.c, i, s);
     reward[i] = shaped_reward<F>(a.shaper, o);
     // _done(): t >= final_step - 1, evaluated before the counter moves (base_timeseries_module.py:124-125)
-    if (done) done[i] = done_at(a, i, t);
+    const uint8_t dn = done_at(a, i, t);
+    if (done) done[i] = dn;
     if (log) store_log<F>(log + i, a.N, o, s.status);
+    if constexpr (EP) off = episode_tail<F>(a, i, t, off, dn != 0, p, s);
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
     // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
-    if (obs) store_step_obs<F>(a, obs, i, t + 1, p, s);
+    if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s);
 }
 
-template <int F>
+template <int F, bool EP = false>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
                                                      int normalized, double *__restrict__ reward,
                                                      uint8_t *__restrict__ done, void *__restrict__ obs,
@@ -88,7 +115,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *
 {
     t = resolve_t(a, t);
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < a.g1) step_body<F>(a, actions, t, normalized, reward, done, obs, log, i);
+    if (i < a.g1) step_body<F, EP>(a, actions, t, normalized, reward, done, obs, log, i);
     advance_counter_in_kernel(a, 1);
 }
 
@@ -105,8 +132,9 @@ __global__ __launch_bounds__(BLOCK) void check_kernel(const KArgs a, const void 
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
-    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, t & a.row_mask, in);
-    else load_inputs<F>(a.c, (const double *)actions, a.N, i, t & a.row_mask, in);
+    const int64_t row = series_row(a, i, t);
+    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, row, in);
+    else load_inputs<F>(a.c, (const double *)actions, a.N, i, row, in);
     step_core<F>(p, d, s, in, normalized != 0, false, false, o);
     violations[i] = o.violations;
 }
@@ -453,7 +481,7 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t
     Params p; State s;
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
-    store_step_obs<F>(a, obs, i, t, p, s);            // whole rows for H == 0 only (the host dispatches)
+    store_step_obs<F>(a, obs, i, t + (a.ep_off ? a.ep_off[i] : 0), p, s);            // whole rows for H == 0 only (the host dispatches)
 }
 
 // Observation rows for H > 0 (obs_rows_wave_kernel below).  Every cache line of obs is written whole by one wave
@@ -517,15 +545,16 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
         GridFactors f;
         load_factors<F>(a.c, ic, f);
         const mgx_columns &c = a.c;
+        const int32_t ti = t + (a.ep_off ? a.ep_off[ic] : 0);         // in-place episodes: the grid's own series row
         observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return fact_load(c.base_load[(int64_t)r * PP + f.lp], f.lr); }, N,
-                                          a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row + a.col_load, a.c.load_noise_std, 0u,
+                                          a.c.load_lo, a.c.load_hi, a.T, ti, W, i, ic, q, Q, row + a.col_load, a.c.load_noise_std, 0u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
         observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return fact_pv(c.base_pv[(int64_t)r * PP + f.pp], f.pr); }, N,
-                                          a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + a.col_pv, a.c.pv_noise_std, 1u,
+                                          a.c.pv_lo, a.c.pv_hi, a.T, ti, W, i, ic, q, Q, row + a.col_pv, a.c.pv_noise_std, 1u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
         if constexpr (F & F_GRID)
             observe_window_cols<4, NOISE, OT>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic); }, N,
-                                              a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q, row + a.col_grid,
+                                              a.c.grid_lo, a.c.grid_hi, a.T, ti, W, i, ic, q, Q, row + a.col_grid,
                                               a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
     } else {
         const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
@@ -825,7 +854,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
     Params p; State s; Inputs in;
     load_state<F>(a.c, i, false, s);
     load_params<F>(a.c, i, p);
-    const int64_t tr = t & a.row_mask;
+    const int64_t tr = series_row(a, i, t);
     if (factorised(a.c)) {
         GridFactors f;
         load_factors<F>(a.c, i, f);
@@ -862,7 +891,7 @@ __device__ __forceinline__ void load_series_at(const double *__restrict__ lts, c
 // DiscreteMicrogridEnv.step in ONE launch (discrete.py:109-143): expand the priority list of every grid into its
 // control and run Microgrid.run(control, normalized=False) on it, without the control ever leaving registers.
 // (body shared by step_discrete_kernel and fleet_step_kernel)
-template <int F>
+template <int F, bool EP = false>
 __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords &tab, const int32_t *__restrict__ action_id,
                                                    int32_t t, double *__restrict__ control, double *__restrict__ reward,
                                                    uint8_t *__restrict__ done, void *__restrict__ obs,
@@ -872,7 +901,9 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     const int64_t N = a.N;
     Params p; State s; Inputs in; Outputs o; Derived d;
     const int32_t id = action_id[i];
-    const int64_t tr = t & a.row_mask;
+    int32_t off = 0;
+    if constexpr (EP) off = a.ep_off[i];
+    const int64_t tr = EP ? (int64_t)t + off : (int64_t)(t & a.row_mask);
     if (factorised(a.c)) {
         GridFactors f;
         load_factors<F>(a.c, i, f);
@@ -896,12 +927,14 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     step_core<F, true>(p, d, s, in, false, true, gen_instant, o, bat_q);
     store_state<F>(a.c, i, s);
     reward[i] = shaped_reward<F>(a.shaper, o);
-    if (done) done[i] = done_at(a, i, t);
+    const uint8_t dn = done_at(a, i, t);
+    if (done) done[i] = dn;
     if (log) store_log<F>(log + i, N, o, s.status);
-    if (obs) store_step_obs<F>(a, obs, i, t + 1, p, s);
+    if constexpr (EP) off = episode_tail<F>(a, i, t, off, dn != 0, p, s);
+    if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s);
 }
 
-template <int F>
+template <int F, bool EP = false>
 __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, const PLWords tab,
                                                               const int32_t *__restrict__ action_id, int32_t t,
                                                               double *__restrict__ control, double *__restrict__ reward,
@@ -910,7 +943,7 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
 {
     t = resolve_t(a, t);
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < a.g1) step_discrete_body<F>(a, tab, action_id, t, control, reward, done, obs, log, i);
+    if (i < a.g1) step_discrete_body<F, EP>(a, tab, action_id, t, control, reward, done, obs, log, i);
     advance_counter_in_kernel(a, 1);
 }
 
@@ -1479,15 +1512,6 @@ static __global__ __launch_bounds__(BLOCK) void colsum_stage2(const double *__re
 // need no per-grid series length.  One lane per grid: its reads are one line per row (once per episode), the writes
 // are coalesced.
 // ------------------------------------------------------------------------------------------------------
-// U[0, 1) of (seed; grid, row): Philox4x32-10 as a counter-based generator (the generator's series and the episode draws of
-// mgx_reset_grids_random use it; pymgrid_amd.generator.synth_uniform_host reproduces it bit for bit)
-__device__ __forceinline__ double synth_uniform(uint64_t seed, int64_t grid, int32_t row)
-{
-    uint32_t r[4];
-    philox4x32_10((uint32_t)grid, (uint32_t)((uint64_t)grid >> 32), (uint32_t)row, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    return (double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) * (1.0 / 9007199254740992.0);      // 53 bits, [0, 1)
-}
-
 struct GatherArgs {
     const double *load_ts, *pv_ts, *grid_ts;
     const double *load_lo, *load_hi, *pv_lo, *pv_hi, *grid_lo, *grid_hi;
@@ -1503,40 +1527,24 @@ struct GatherArgs {
     int32_t draw, fixed_length;
     uint64_t seed;
     int32_t *start_io, *length_io, *t0_io;     // optional [N]: what the restarted grids got
+    int32_t *ep_off;          // in-place episodes (mgx_reset_episodes): the row offset is all a (re)start writes; rows == 0
 };
 
 // the episode of grid i: start row and length (given, or drawn), clamped into the env's window; bookkeeping outputs
 __device__ __forceinline__ void gather_episode(const GatherArgs &g, int64_t i, int32_t &s, int32_t &len)
 {
-    if (g.draw) {               // np.random.randint(low, high) per grid: low + min(floor(u * (high - low)), high - low - 1)
-        const double u1 = synth_uniform(g.seed, i, 2 * g.row0), u2 = synth_uniform(g.seed, i, 2 * g.row0 + 1);
-        auto randint = [](double u, int32_t low, int32_t high) {
-            const int32_t span = high - low;
-            if (span <= 0) return low;
-            const int32_t k = (int32_t)floor(u * (double)span);
-            return low + (k < span - 1 ? k : span - 1);
-        };
-        if (g.fixed_length > 0) {                                      // FixedLengthStochasticTrajectory (:15-30)
-            s = randint(u1, g.lo, g.hi - g.fixed_length);
-            len = g.fixed_length;
-        } else {                                                       // StochasticTrajectory (:9-12)
-            s = randint(u1, g.lo, g.hi - 2);
-            const int32_t fin = randint(u2, s, g.hi);
-            len = fin - s;
-        }
+    if (g.draw) {
+        episode_draw(g.seed, i, g.row0, g.fixed_length, g.lo, g.hi, s, len);
     } else {
         s = g.start[i];
         len = g.length ? g.length[i] : g.max_length;
     }
-    s = s < g.lo ? g.lo : (s > g.hi - 1 ? g.hi - 1 : s);            // a start outside the env's window is clamped into it
-    const int32_t room = g.hi - s;
-    len = len < 1 ? 1 : len;
-    len = len > g.max_length ? g.max_length : len;
-    len = len > room ? room : len;                                     // the episode ends at the env's final step at the latest
+    episode_clamp(g.lo, g.hi, g.max_length, s, len);
     if (g.final_rel) g.final_rel[i] = g.row0 + len;                    // counter value at which the episode has run its length
     if (g.start_io) g.start_io[i] = s;
     if (g.length_io) g.length_io[i] = len;
     if (g.t0_io) g.t0_io[i] = g.row0;
+    if (g.ep_off) g.ep_off[i] = s - g.row0;                            // in-place episodes: no rows to copy
 }
 
 // one lane per grid walks its rows (a wave moves 512 contiguous bytes per row when all of its grids take part).  For the
@@ -1548,6 +1556,7 @@ static __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const Gath
     if (i >= g.N || (g.mask && !g.mask[i])) return;
     int32_t s, len;
     gather_episode(g, i, s, len);
+    if (g.ep_off) return;
     // 8 rows per round, every load of the round in flight before its first store (the compiler cannot prove that window and
     // series buffers do not alias: row by row the loop is one memory round trip per row -- 20 us when a few lanes restart)
     const int64_t N = g.N;

@@ -44,6 +44,8 @@ class StepEngine:
         self._full_window = self.window
         self._window_start = None
         self._window_t0 = None          # rolling windows: counter value each grid's episode started at
+        self._inplace = False           # in-place episodes (reset_episodes)
+        self._final_obs = None
         self._obs_compact = False
         self._done_bits = False
         self._dev_counter = False
@@ -277,6 +279,8 @@ class StepEngine:
         if getattr(self, "_window_start", None) is not None:       # a per-grid-window episode ends with a plain reset
             self._window_start = None
             self._window_t0 = None
+            self._inplace = False
+            self._final_obs = None
             self.window = self._full_window
         if self._t is not None:
             self._t = self.window[0] if initial_step is None else int(initial_step)
@@ -336,6 +340,7 @@ class StepEngine:
                    w["pv"].data_ptr(), _ptr(w["grid"]), w["final"].data_ptr() if length is not None else None, _ptr(obs))
         self._window_start = start
         self._window_t0 = None
+        self._inplace = False
         self.window = (0, int(max_length))
         self._t = 0
         return obs
@@ -367,8 +372,56 @@ class StepEngine:
         self._window_t0 = torch.zeros_like(start)          # ... and the counter value it started at
         self.window = (0, int(max_length))
         self._rolling_max = int(max_length)
+        self._inplace = False
         self._t = 0
         return obs
+
+    def reset_episodes(self, start, length=None, max_length=None, want_obs=True, out=None, validate=True):
+        """Rolling per-grid episodes IN PLACE (``mgx_reset_episodes``; factorised series only): as ``reset_windows_rolling``
+        without window buffers -- grid i reads row ``counter + row_off[i]`` of its own series, a (re)start rewrites two words per
+        grid.  Single steps only, observation rows per step (no rings).  ``set_auto_reset`` makes the steps restart finished
+        grids themselves."""
+        if start.dtype != torch.int32 or tuple(start.shape) != (self.N,) or start.device != self.device:
+            raise ValueError(f"start must be an int32 tensor of shape ({self.N},) on {self.device}")
+        if length is not None and (length.dtype != torch.int32 or tuple(length.shape) != (self.N,) or length.device != self.device):
+            raise ValueError(f"length must be an int32 tensor of shape ({self.N},) on {self.device}")
+        if max_length is None:
+            raise ValueError("max_length is required (the longest episode any later restart may ask for)")
+        if validate:
+            self._check_episodes(start, length, max_length)
+        e = getattr(self, "_episodes", None)
+        if e is None:
+            e = self._episodes = dict(off=self._empty(self.N, dtype=torch.int32), final=self._empty(self.N, dtype=torch.int32))
+        obs = self._obs_buf(out) if want_obs else None
+        self._call(self._lib.mgx_reset_episodes, start.data_ptr(), _ptr(length), int(max_length), e["off"].data_ptr(),
+                   e["final"].data_ptr(), _ptr(obs))
+        self._window_start = start.clone()
+        self._window_t0 = torch.zeros_like(start)
+        self.window = (0, int(max_length))
+        self._rolling_max = int(max_length)
+        self._inplace = True
+        self._final_obs = None
+        self._t = 0
+        return obs
+
+    def set_auto_reset(self, enable=True, seed=0, fixed_length=0, lengths_out=None):
+        """``mgx_set_auto_reset`` (in-place episodes): every single step restarts the grids whose episode it ends with the draw
+        ``reset_grids_random(done, seed, fixed_length)`` would make after the step; the per-grid start rows / restart counters
+        (``current_steps``) and ``lengths_out`` are updated in place by the step kernels."""
+        if not getattr(self, "_inplace", False):
+            raise _lib.MgxError(_lib.MGX_ERR_INVALID, "set_auto_reset: the engine is not stepping in-place episodes (reset_episodes)")
+        check(self._lib.mgx_set_auto_reset(self._h, 1 if enable else 0, int(seed) & (2 ** 64 - 1), int(fixed_length),
+                                           self._window_start.data_ptr() if enable else None, _ptr(lengths_out) if enable else None,
+                                           self._window_t0.data_ptr() if enable else None))
+        self._ar_lengths = lengths_out if enable else None          # (kept alive: the kernels write it)
+
+    def set_final_obs(self, buf):
+        """``mgx_set_final_obs``: the following single steps also write the observation BEFORE any restart into ``buf`` ([N, D]
+        rows in the engine's observation format; None: off)."""
+        if buf is not None:
+            buf = self._obs_buf(buf)
+        check(self._lib.mgx_set_final_obs(self._h, _ptr(buf)))
+        self._final_obs = buf
 
     def reset_grids(self, mask, start, length=None, validate=True):
         """Restart the grids with ``mask[i] != 0`` at the current step (``mgx_reset_grids``): new start rows / lengths for

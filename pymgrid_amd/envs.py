@@ -269,8 +269,9 @@ class BatchedMicrogridEnv:
 
         ``rolling=True`` (``mgx_reset_windows_rolling``): the shared counter never ends and ``reset_grids(mask, start,
         length)`` restarts individual grids at any later step -- N microgrids reset one by one, each when its own episode is
-        over.  ``max_length`` is then the longest episode any restart may ask for.  Observation rows are written per step
-        (no window prefetch: a restarted grid's future rows change)."""
+        over.  ``max_length`` is then the longest episode any restart may ask for.  ``rolling="inplace"``
+        (``mgx_reset_episodes``, factorised series only): the same without window buffers -- every grid reads its own series
+        rows, a restart rewrites two words per grid; observation rows are then written per step (no rings)."""
         dev = self.batch.device
 
         def as_i32(v):
@@ -289,6 +290,14 @@ class BatchedMicrogridEnv:
                 if length is None:
                     raise ValueError("rolling windows need max_length (or per-grid lengths to take it from)")
                 max_length = int(length.max().item())
+            if rolling == "inplace":                 # mgx_reset_episodes: no window buffers, the grids read their own series rows
+                if not self.batch.factorised:
+                    raise ValueError("in-place episodes need a batch with factorised series (generate(..., series='factorised'))")
+                if self._ring is not None:           # no observation rings in this mode: rows per step
+                    self.set_obs_prefetch(0)
+                self._sync_rings = False
+                return self._select_obs(self.engine.reset_episodes(start, length, max_length, want_obs=self._observations,
+                                                                   validate=validate))
             if self._ring is not None:               # rings stay: refilled on this stream, restarted grids patched in
                 self.engine.prefetch_wait()
                 self._sync_rings = True

@@ -1,0 +1,171 @@
+"""In-place per-grid episodes (mgx_reset_episodes / mgx_set_auto_reset / mgx_set_final_obs; ABI v6): factorised batches step per-grid
+episodes on the series themselves -- no window buffers, a restart rewrites two words per grid, and with auto-reset the step kernel
+restarts the grids it finishes.  Pinned three ways: against the CPU oracle on per-grid shifted series, against the rolling window
+buffers (mgx_reset_windows_rolling, itself pinned against per-grid oracle microgrids in test_abi_v3.py) step by step through
+restarts, and PerGridWindowEnv(native=True) against PerGridWindowEnv(native=False) with the same device draws."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ARCHS = ("genset+battery", "battery+grid", "genset+battery+grid")
+
+
+def _gen(n, T, arch, device, H=0, seed=9, **kw):
+    from pymgrid_amd.generator import generate
+    return generate(n, n_steps=T, seed=seed, arch=arch, device=device, horizon=H, mixed_timers=True, series="factorised", **kw)
+
+
+@pytest.mark.parametrize("arch", ARCHS)
+def test_inplace_episodes_vs_the_oracle_on_shifted_series(arch, device, oracle):
+    """Grid i steps L rows from its own start row: the same rewards and final state as the oracle stepping, from row 0, the series
+    whose column i is the grid's series shifted by start_i."""
+    from pymgrid_amd import StepEngine
+    N, T, L = 2051, 400, 37
+    b = _gen(N, T, arch, device, seed=31)
+    cols = b.numpy_columns()
+    st = {k: cols[k].copy() for k in ("charge", "soc", "gen_status") if k in cols}
+    rs = np.random.RandomState(3)
+    starts = rs.randint(0, T - L + 1, size=N).astype(np.int32)
+    starts[:4] = (0, T - L, 1, T - L - 1)
+    rows = starts[None, :] + np.arange(L)[:, None]                                # [L, N]
+    shifted = dict(cols)
+    shifted["layout"] = dict(cols["layout"], T=L, final_step=L)
+    shifted["load_ts"] = np.ascontiguousarray(np.take_along_axis(cols["load_ts"], rows, 0))
+    shifted["pv_ts"] = np.ascontiguousarray(np.take_along_axis(cols["pv_ts"], rows, 0))
+    if "grid_ts" in cols and cols["grid_ts"] is not None:
+        shifted["grid_ts"] = np.ascontiguousarray(np.take_along_axis(cols["grid_ts"], rows[:, None, :].repeat(4, 1), 0))
+    g = torch.Generator(device=device); g.manual_seed(5)
+    acts = torch.rand(L, N, b.layout.action_dim, dtype=torch.float64, device=device, generator=g)
+    e = StepEngine(b)
+    e.reset_episodes(torch.from_numpy(starts).to(device), None, L, want_obs=False)
+    rew = torch.empty(L, N, dtype=torch.float64, device=device)
+    don = torch.empty(L, N, dtype=torch.uint8, device=device)
+    for k in range(L):
+        e.step(acts[k], want_obs=False, out=dict(reward=rew[k], done=don[k]))
+    ref = oracle.run_batch(shifted, st, 0, L, acts.cpu().numpy(), normalized=True, nthreads=8)
+    assert np.array_equal(rew.cpu().numpy(), ref)
+    assert np.array_equal(b.cols["charge"].cpu().numpy(), st["charge"])
+    d = don.cpu().numpy()
+    assert not d[:-1].any() and d[-1].all()
+    e.close()
+
+
+@pytest.mark.parametrize("arch,H,discrete", [("genset+battery", 0, False), ("genset+battery+grid", 0, True), ("battery+grid", 5, False),
+                                            ("genset+battery+grid", 24, False), ("genset+battery", 3, True)])
+def test_inplace_episodes_equal_rolling_windows_through_restarts(arch, H, discrete, device):
+    """The same episodes on window rings (gathered rows) and in place (row offsets): observations, rewards, per-grid done flags
+    and per-grid step counters agree at every step, through individual restarts with new starts and lengths, windows that reach
+    the end of the series, and many more steps than the longest episode."""
+    from pymgrid_amd import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv
+    N, T, max_len = 1500, 300, 14
+    cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
+    kw = dict(remove_redundant_gensets=False) if discrete else {}
+    ring = cls(_gen(N, T, arch, device, H), obs_prefetch=0, **kw)
+    inpl = cls(_gen(N, T, arch, device, H), **kw)                               # (its rings are switched off by the mode)
+    rs = np.random.RandomState(8)
+    lengths = rs.randint(1, max_len + 1, size=N).astype(np.int32)
+    starts = np.array([rs.randint(0, T - n + 1) for n in lengths], dtype=np.int32)
+    starts[:3] = T - lengths[:3]                                                # ... ending at the very end of the series
+    o1 = ring.reset_windows(starts, lengths, max_length=max_len, rolling=True)
+    o2 = inpl.reset_windows(starts, lengths, max_length=max_len, rolling="inplace")
+    assert torch.equal(o1, o2) and inpl.obs_prefetch == 0
+    g = torch.Generator(device=device); g.manual_seed(1)
+    for k in range(3 * max_len + 5):
+        a = (torch.randint(0, ring.action_space.n, (N,), dtype=torch.int32, device=device, generator=g) if discrete
+             else torch.rand(N, ring.layout.action_dim, dtype=torch.float64, device=device, generator=g))
+        o1, r1, d1, _ = ring.step(a)
+        o2, r2, d2, _ = inpl.step(a)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), k
+        assert torch.equal(ring.current_steps, inpl.current_steps), k
+        if bool(d1.any()):
+            new_len = rs.randint(1, max_len + 1, size=N).astype(np.int32)
+            new_start = np.array([rs.randint(0, T - n + 1) for n in new_len], dtype=np.int32)
+            if k % 2:
+                new_start = (T - new_len).astype(np.int32)
+            assert torch.equal(ring.reset_grids(d1, new_start, new_len), inpl.reset_grids(d2, new_start, new_len)), k
+    from pymgrid_amd import MgxError
+    with pytest.raises(MgxError):                           # single steps only, no rings
+        inpl.engine.step_k(torch.rand(4, N, ring.layout.action_dim, dtype=torch.float64, device=device))
+    with pytest.raises(MgxError):
+        inpl.engine.set_obs_state_only(True)
+    assert torch.equal(ring.reset(), inpl.reset())          # a plain reset leaves the mode
+    assert not inpl.engine._inplace
+    a = (torch.zeros(N, dtype=torch.int32, device=device) if discrete
+         else torch.rand(N, ring.layout.action_dim, dtype=torch.float64, device=device, generator=g))
+    o1, r1, d1, _ = ring.step(a); o2, r2, d2, _ = inpl.step(a)
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    ring.close(); inpl.close()
+
+
+@pytest.mark.parametrize("arch,H,discrete,length,final", [("genset+battery", 0, False, 9, False), ("genset+battery", 0, False, 9, True),
+                                                         ("genset+battery+grid", 0, True, None, True),
+                                                         ("battery+grid", 4, False, 7, True), ("genset+battery+grid", 24, False, 11, False),
+                                                         ("genset+battery", 2, True, None, False)])
+def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discrete, length, final, device):
+    """PerGridWindowEnv(auto_reset=True) with device draws: native (one launch per step: the step kernel restarts the grids it
+    finishes, mgx_set_auto_reset; the pre-restart rows through mgx_set_final_obs) against the rolling windows (step, restart
+    gather, observation pass): observations, rewards, done flags, final observations, the drawn starts / lengths and the per-grid
+    counters are identical step by step."""
+    from pymgrid_amd.hetero import PerGridWindowEnv
+    N, T = 1100, 200
+    kw = dict(discrete=discrete, auto_reset=True, final_observation=final, seed=123, trajectory_length=length)
+    if discrete:
+        kw["remove_redundant_gensets"] = False
+    roll = PerGridWindowEnv(_gen(N, T, arch, device, H), native=False, obs_prefetch=0, **kw)
+    nat = PerGridWindowEnv(_gen(N, T, arch, device, H), native=True, **kw)
+    assert nat.native and not roll.native
+    lengths = None
+    rs = np.random.RandomState(2)
+    if length is None:
+        lengths = rs.randint(1, 30, size=N).astype(np.int32)
+        starts = np.array([rs.randint(0, T - n + 1) for n in lengths], dtype=np.int32)
+    else:
+        starts = rs.randint(0, T - length + 1, size=N).astype(np.int32)
+    assert torch.equal(roll.reset(starts, lengths), nat.reset(starts, lengths))
+    g = torch.Generator(device=device); g.manual_seed(1)
+    n_done = 0
+    for k in range(70):
+        a = (torch.randint(0, roll.action_space.n, (N,), dtype=torch.int32, device=device, generator=g) if discrete
+             else torch.rand(N, roll.layout.action_dim, dtype=torch.float64, device=device, generator=g))
+        o1, r1, d1, i1 = roll.step(a)
+        o2, r2, d2, i2 = nat.step(a)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2), k
+        assert torch.equal(o1, o2), k
+        if final:
+            assert torch.equal(i1["final_observation"], i2["final_observation"]), k
+        assert torch.equal(roll.starts, nat.starts) and torch.equal(roll.lengths, nat.lengths), k
+        assert torch.equal(roll.current_steps, nat.current_steps), k
+        n_done += int(d1.sum())
+    assert n_done > N                                       # every grid restarted at least once on average
+    roll.close(); nat.close()
+
+
+def test_inplace_episodes_need_factorised_series_and_refuse_rings(device):
+    from pymgrid_amd import BatchedMicrogridEnv, MgxError, StepEngine
+    from pymgrid_amd.generator import generate
+    from pymgrid_amd.hetero import PerGridWindowEnv
+    N, T = 300, 100
+    bm = generate(N, n_steps=T, seed=1, arch="genset+battery", device=device)
+    e = StepEngine(bm)
+    with pytest.raises(MgxError, match="factorised"):
+        e.reset_episodes(torch.zeros(N, dtype=torch.int32, device=device), None, 10)
+    with pytest.raises(MgxError):
+        e.set_auto_reset(True)
+    e.close()
+    with pytest.raises(ValueError, match="factorised"):
+        PerGridWindowEnv(bm, trajectory_length=5, auto_reset=True, native=True)
+    # defaults: native for factorised series without a forecast horizon, rolling windows (rings) with one
+    assert PerGridWindowEnv(_gen(N, T, "genset+battery", device), trajectory_length=5, auto_reset=True).native
+    assert not PerGridWindowEnv(_gen(N, T, "genset+battery", device, H=6), trajectory_length=5, auto_reset=True).native
+    env = BatchedMicrogridEnv(_gen(N, T, "genset+battery+grid", device, H=6), obs_prefetch=4)
+    env.reset_windows(np.zeros(N, dtype=np.int32), None, max_length=10, rolling="inplace")
+    assert env.obs_prefetch == 0
+    with pytest.raises(MgxError):
+        P = getattr(env.engine, "_ring_pitch", N)
+        env.engine.observe_windows(4, out=torch.empty(4, P, env.layout.obs_dim, dtype=torch.float64, device=device)[:, :N])
+    with pytest.raises(MgxError):
+        env.engine.set_final_obs(torch.empty(N, env.layout.obs_dim, dtype=torch.float64, device=device)) or env.engine.step(
+            env.sample_action(), want_obs=False)            # final rows need a step that writes observations
+    env.close()

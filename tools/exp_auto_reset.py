@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-grid auto-reset (rolling windows): time per Gym step at N = 100 000, H = 24, next to the lock-step env."""
+"""Per-grid auto-reset (rolling windows): time per Gym step at N = 100 000, H = 24 (argv[2]), next to the lock-step env."""
 import os
 import sys
 
@@ -27,9 +27,10 @@ def timed(step, n=300):
 
 
 series = sys.argv[1] if len(sys.argv) > 1 else "materialised"
-print(f"series = {series}")
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+print(f"series = {series}, horizon = {H}")
 for arch in ("genset+battery", "genset+battery+grid"):
-    make = lambda: generate(N, n_steps=8760, seed=1, arch=arch, horizon=24, device=dev, series=series)
+    make = lambda: generate(N, n_steps=8760, seed=1, arch=arch, horizon=H, device=dev, series=series)
     env = BatchedMicrogridEnv(make())
     a = env.sample_action(); env.reset()
     print(f"{arch:20s} lock-step env, ring prefetch K = 16      {timed(lambda: env.step(a)):7.1f} us/step")
@@ -38,8 +39,10 @@ for arch in ("genset+battery", "genset+battery+grid"):
     env.reset()
     print(f"{arch:20s} lock-step env, per-step rows             {timed(lambda: env.step(a)):7.1f} us/step")
     env.close()
-    for fo in (False, True):
-        w = PerGridWindowEnv(make(), trajectory_length=168, auto_reset=True, final_observation=fo)
-        w.reset()
-        print(f"{arch:20s} auto-reset (168-step episodes), final_observation={int(fo)}  {timed(lambda: w.step(a)):7.1f} us/step")
-        w.close()
+    for native in ((False, True) if series == "factorised" else (False,)):
+        for fo in (False, True):
+            w = PerGridWindowEnv(make(), trajectory_length=168, auto_reset=True, final_observation=fo, native=native)
+            w.reset()
+            how = "in place, restart inside the step kernel" if native else "rolling windows (restart gather + observe)"
+            print(f"{arch:20s} auto-reset (168-step episodes), final_observation={int(fo)}, {how:42s} {timed(lambda: w.step(a)):7.1f} us/step")
+            w.close()
