@@ -603,9 +603,14 @@ def main():
         def closed_loop():
             from pymgrid_amd import BatchedMicrogridEnv
 
-            def loop(dtype, reuse, light=False):
-                env = BatchedMicrogridEnv(generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world,
-                                                   series=args.series), obs_dtype=dtype, action_dtype=dtype, reuse_outputs=reuse)
+            def loop(dtype, reuse, light=False, auto_reset=False):
+                b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=args.series)
+                if auto_reset:           # every grid on its own random 168-step episodes, restarted by the step that ends them
+                    from pymgrid_amd.hetero import PerGridWindowEnv
+                    env = PerGridWindowEnv(b, trajectory_length=168, auto_reset=True, seed=3, obs_dtype=dtype, action_dtype=dtype,
+                                           reuse_outputs=reuse)
+                else:
+                    env = BatchedMicrogridEnv(b, obs_dtype=dtype, action_dtype=dtype, reuse_outputs=reuse)
                 g = torch.Generator(device=dev); g.manual_seed(5)
                 A = env.layout.action_dim
                 W = torch.randn(env.layout.obs_dim, A, dtype=dtype, device=dev, generator=g)
@@ -644,12 +649,16 @@ def main():
                 return {"value": n_total * n / wall, "us_per_step": wall / n * 1e6, "steps": n,
                         "policy_kernels_alone_us": policy_us, "env_step_alone_us": env_us}
             out = {"float64": loop(torch.float64, 0), "float32_io_rotating_outputs": loop(torch.float32, 4, light=True)}
+            if args.series == "factorised":
+                out["float32_io_auto_reset_168_step_episodes"] = loop(torch.float32, 4, light=True, auto_reset=True)
             out["loop"] = ("obs [N, 8] -> sigmoid(obs @ W) -> BatchedMicrogridEnv.step (one launch) -> obs, issued from Python: three "
                            "kernels per env-step (matmul, sigmoid, step), each waiting for the one before -- the env's share is "
                            "env_step_alone_us.  float32_io: observations and actions cross the boundary as floats (what a policy "
                            "network consumes / emits; the step itself stays float64), reward and rows in 4 rotating buffers "
                            "(reuse_outputs), and the policy is sigmoid(obs[:, :A] * w): two elementwise kernels instead of torch's "
-                           "GEMM, which takes 23 us (float64) / 84 us (float32) for this [N, 8] x [8, 3] product")
+                           "GEMM, which takes 23 us (float64) / 84 us (float32) for this [N, 8] x [8, 3] product.  auto_reset: PerGridWindowEnv -- "
+                           "every grid walks its own random 168-step episodes and is restarted by the step that ends its episode "
+                           "(in-place episodes, mgx_set_auto_reset: still one launch per env-step)")
             out["value"], out["us_per_step"] = out["float64"]["value"], out["float64"]["us_per_step"]
             return out
         closed = guarded("closed_loop_policy_gym_steps", closed_loop)

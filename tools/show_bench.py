@@ -18,9 +18,9 @@ c = d.get("closed_loop_policy_gym_steps")
 if c:
     print(f"  closed loop (policy on device, obs rows): " + (f"FAILED {c['error']}" if "error" in c else
           f"{c['us_per_step']:.1f} us/step  {c['value'] / 1e9:.2f} G env-steps/s"))
-    for k in ("float64", "float32_io_rotating_outputs"):
+    for k in ("float64", "float32_io_rotating_outputs", "float32_io_auto_reset_168_step_episodes"):
         if k in c and "error" not in c:
-            print(f"    {k:30s} {c[k]['us_per_step']:.1f} us/step = policy kernels {c[k]['policy_kernels_alone_us']:.1f} + env.step "
+            print(f"    {k:40s} {c[k]['us_per_step']:.1f} us/step = policy kernels {c[k]['policy_kernels_alone_us']:.1f} + env.step "
                   f"{c[k]['env_step_alone_us']:.1f} (each alone)")
 h = d.get("hetero_h24_gym_steps")
 if h and "error" in h:
