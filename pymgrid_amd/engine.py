@@ -437,8 +437,9 @@ class StepEngine:
             self._check_episodes(start, length, self._rolling_max, mask=mask)
         self._call(self._lib.mgx_reset_grids, mask.data_ptr(), start.data_ptr(), _ptr(length))
         m = mask.view(torch.bool)
-        self._window_start = torch.where(m, start, self._window_start)
-        self._window_t0 = torch.where(m, torch.full_like(start, self.current_step), self._window_t0)
+        # in place: with set_auto_reset the step kernels hold these two tensors' addresses
+        self._window_start.copy_(torch.where(m, start, self._window_start))
+        self._window_t0.copy_(torch.where(m, torch.full_like(start, self.current_step), self._window_t0))
 
     def reset_grids_random(self, mask, seed, fixed_length=0, lengths_out=None):
         """``mgx_reset_grids_random``: restart the grids with ``mask[i] != 0`` with episodes drawn ON DEVICE (Philox of
