@@ -169,3 +169,33 @@ def test_inplace_episodes_need_factorised_series_and_refuse_rings(device):
         env.engine.set_final_obs(torch.empty(N, env.layout.obs_dim, dtype=torch.float64, device=device)) or env.engine.step(
             env.sample_action(), want_obs=False)            # final rows need a step that writes observations
     env.close()
+
+
+def test_native_auto_reset_at_the_true_shape_of_configs2(device):
+    """BASELINE configs[2] (100 000 generated Template-4 grids x 8 760 rows), every grid on its own random 168-step episodes for
+    400 steps (every grid restarts at least twice): in-place episodes == rolling windows, rewards / done / observations / draws."""
+    from pymgrid_amd.hetero import PerGridWindowEnv
+    N, T = 100_000, 8760
+    kw = dict(auto_reset=True, seed=5, trajectory_length=168)
+    roll = PerGridWindowEnv(_gen(N, T, "genset+battery", device, seed=42), native=False, **kw)
+    nat = PerGridWindowEnv(_gen(N, T, "genset+battery", device, seed=42), **kw)
+    assert nat.native
+    g = torch.Generator(device=device); g.manual_seed(3)
+    st = torch.randint(0, T - 168, (N,), dtype=torch.int32, device=device, generator=g)
+    st[:3] = torch.tensor([0, T - 168, T - 169], dtype=torch.int32)
+    # staggered first episodes, so that restarts happen at every step
+    ln = torch.randint(1, 169, (N,), dtype=torch.int32, device=device, generator=g)
+    assert torch.equal(roll.reset(st, ln), nat.reset(st, ln))
+    bad = torch.zeros((), dtype=torch.int64, device=device)
+    n_done = torch.zeros((), dtype=torch.int64, device=device)
+    for k in range(400):
+        a = torch.rand(N, 3, dtype=torch.float64, device=device, generator=g)
+        o1, r1, d1, _ = roll.step(a)
+        o2, r2, d2, _ = nat.step(a)
+        bad += (o1 != o2).sum() + (r1 != r2).sum() + (d1 != d2).sum()
+        n_done += d1.sum()
+    assert int(bad) == 0
+    assert torch.equal(roll.starts, nat.starts) and torch.equal(roll.lengths, nat.lengths)
+    assert torch.equal(roll.current_steps, nat.current_steps)
+    assert int(n_done) > 2 * N
+    roll.close(); nat.close()
