@@ -269,7 +269,7 @@ int mgx_reset_grids_random(mgx_handle *h, const uint8_t *mask, uint64_t seed, in
  * mgx_reset_windows (length NULL: max_length).  (Re)starts -- mgx_reset_grids, mgx_reset_grids_random -- then rewrite two
  * words per grid instead of gathering rows.  Observation windows reach beyond an episode's end into the grid's series and
  * beyond the series' end into the forecaster's padding, exactly as in lock-step.  Single steps only (as for rolling windows);
- * no observation rings (mgx_observe_windows*, MGX_OBS_ROWS_STATE_ONLY): rows are written per step.
+ * observation rings work as they do there (mgx_observe_windows[_ahead] + mgx_patch_windows for the grids that restarted).
  * MGX_ERR_UNSUPPORTED for materialised [T, N] series (every lane would read its own row: 8x the traffic). */
 int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length, int32_t *row_off,
                        int32_t *final_abs, void *obs, mgx_stream stream);

@@ -473,8 +473,6 @@ int mgx_set_obs_mode(mgx_handle *h, int32_t mode)
         return fail(MGX_ERR_INVALID, "mgx_set_obs_mode: unknown mode %d", mode);
     if (mode != MGX_OBS_ROWS_FULL && h->multi)
         return fail(MGX_ERR_UNSUPPORTED, "mgx_set_obs_mode: state-only rows need exactly one load and one renewable module per grid");
-    if (mode == MGX_OBS_ROWS_STATE_ONLY && h->inplace)
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_set_obs_mode: prefetched observation rings are not offered with in-place episodes");
     h->k.obs_state_only = mode == MGX_OBS_ROWS_STATE_ONLY ? 1 : (mode == MGX_OBS_ROWS_STATE_COMPACT ? 2 : 0);
     return MGX_OK;
 }
@@ -499,14 +497,13 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "%s: K = %d outside [1, 4096]", who, K);
     if (ahead < 0) return fail(MGX_ERR_INVALID, "%s: ahead = %d is negative", who, ahead);
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "%s: needs exactly one module of every kind per grid", who);
-    if (h->inplace) return fail(MGX_ERR_UNSUPPORTED, "%s: observation rings are not offered with in-place episodes (mgx_reset_episodes)", who);
     if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
         return fail(MGX_ERR_UNSUPPORTED, "%s: forecast noise depends on (step, horizon index), windows cannot be shared", who);
     if (h->k.obs_state_only == 2)
         return fail(MGX_ERR_UNSUPPORTED, "%s: the handle writes compact state rows (MGX_OBS_ROWS_STATE_COMPACT): the windows are "
                                          "views of mgx_normalise_series' output, there are no rings to fill", who);
     if (int rc = need_obs_bounds(h, who)) return rc;
-    if (!dev_counter(h) && ahead == 0 && h->t > h->k.T)
+    if (!dev_counter(h) && ahead == 0 && !h->inplace && h->t > h->k.T)       // (in place the counter never ends: per-grid rows)
         return fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, h->k.T);
     const int32_t R = K + h->k.H, ncomp = 2 + 4 * h->layout.has_grid;
     plan->grid_col_base = h->k.col_grid;
@@ -567,7 +564,6 @@ int mgx_patch_windows(mgx_handle *h, const uint8_t *mask, int32_t K, void *ring,
     g_err[0] = 0;
     if (!h || !mask || !ring) return fail(MGX_ERR_INVALID, "mgx_patch_windows: NULL argument");
     if (K < 1 || first_block < 0 || first_block > K) return fail(MGX_ERR_INVALID, "mgx_patch_windows: first_block %d outside [0, K = %d]", first_block, K);
-    if (h->inplace) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: observation rings are not offered with in-place episodes");
     if (ahead < 0) return fail(MGX_ERR_INVALID, "mgx_patch_windows: ahead = %d is negative", ahead);
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: needs exactly one module of every kind per grid");
     if (dev_counter(h)) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: not offered in device-counter mode");
@@ -848,9 +844,6 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
     if (!factorised(h->windowed ? h->full_c : h->k.c))
         return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: in-place episodes need factorised series (every lane reads its own row: "
                                          "[T, N] arrays would be gathered 8x over); use mgx_reset_windows_rolling");
-    if (h->k.obs_state_only == 1)
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: prefetched observation rings are not offered with in-place episodes "
-                                         "(mgx_set_obs_mode(MGX_OBS_ROWS_FULL) first)");
     if (h->prefetch_pending) { if (int rc = mgx_prefetch_wait(h, stream)) return rc; }
     leave_windows(h);                                   // back to the full (factorised) series, whatever mode the handle was in
     h->full_load_ts = h->k.c.load_ts; h->full_pv_ts = h->k.c.pv_ts; h->full_grid_ts = h->k.c.grid_ts;

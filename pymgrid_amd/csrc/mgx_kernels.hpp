@@ -705,13 +705,14 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         GridFactors f;
         load_factors<GRID ? F_GRID : 0>(a.c, ic, f);
         const mgx_columns &c = a.c;
+        const int32_t ti = t + (a.ep_off ? a.ep_off[ic] : 0);          // in-place episodes: the grid's own series row
         windows_k_module<1>([&](int32_t r, int) { return fact_load(c.base_load[(int64_t)r * PP + f.lp], f.lr); }, N,
-                            a.c.load_lo, a.c.load_hi, a.T, t, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
+                            a.c.load_lo, a.c.load_hi, a.T, ti, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
         windows_k_module<1>([&](int32_t r, int) { return fact_pv(c.base_pv[(int64_t)r * PP + f.pp], f.pr); }, N,
-                            a.c.pv_lo, a.c.pv_hi, a.T, t, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
+                            a.c.pv_lo, a.c.pv_hi, a.T, ti, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
         if constexpr (GRID)
             windows_k_module<4>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic); }, N,
-                                a.c.grid_lo, a.c.grid_hi, a.T, t, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
+                                a.c.grid_lo, a.c.grid_hi, a.T, ti, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
     } else {
         const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
         windows_k_module<1>([&](int32_t r, int) { return lts[(int64_t)r * N + ic]; }, N,
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(64) void patch_windows_kernel(const KArgs a, const 
             if (comp == 0) { lo = a.c.load_lo[g]; hi = a.c.load_hi[g]; }
             else if (comp == 1) { lo = a.c.pv_lo[g]; hi = a.c.pv_hi[g]; }
             else { lo = a.c.grid_lo[(comp - 2) * N + g]; hi = a.c.grid_hi[(comp - 2) * N + g]; }
-            const int32_t row = t + r;
+            const int32_t row = t + r + (a.ep_off ? a.ep_off[g] : 0);      // in-place episodes: the grid's own series row
             const bool in = row < a.T;
             const double v = series_component(a.c, N, comp, (int64_t)((in ? row : a.T - 1) & a.row_mask), g);
             const double fill = (hi + lo) / 2, sp = space_spread(lo, hi);

@@ -271,7 +271,7 @@ class BatchedMicrogridEnv:
         length)`` restarts individual grids at any later step -- N microgrids reset one by one, each when its own episode is
         over.  ``max_length`` is then the longest episode any restart may ask for.  ``rolling="inplace"``
         (``mgx_reset_episodes``, factorised series only): the same without window buffers -- every grid reads its own series
-        rows, a restart rewrites two words per grid; observation rows are then written per step (no rings)."""
+        rows, a restart rewrites two words per grid."""
         dev = self.batch.device
 
         def as_i32(v):
@@ -293,8 +293,11 @@ class BatchedMicrogridEnv:
             if rolling == "inplace":                 # mgx_reset_episodes: no window buffers, the grids read their own series rows
                 if not self.batch.factorised:
                     raise ValueError("in-place episodes need a batch with factorised series (generate(..., series='factorised'))")
-                if self._ring is not None:           # no observation rings in this mode: rows per step
-                    self.set_obs_prefetch(0)
+                if self._ring is not None:           # rings stay, as for rolling windows: restarted grids are patched in
+                    self.engine.prefetch_wait()
+                    self._sync_rings = True
+                    self.engine.reset_episodes(start, length, max_length, want_obs=False, validate=validate)
+                    return self._select_obs(self._refill())
                 self._sync_rings = False
                 return self._select_obs(self.engine.reset_episodes(start, length, max_length, want_obs=self._observations,
                                                                    validate=validate))

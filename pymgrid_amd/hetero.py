@@ -356,17 +356,15 @@ class PerGridWindowEnv:
         self._device_draws = self.auto_reset and generator is None
         # native: in-place episodes (mgx_reset_episodes; factorised series).  Nothing is gathered at a (re)start, and with device
         # draws the step kernel restarts finished grids ITSELF (mgx_set_auto_reset): an auto-reset step is ONE launch, as in
-        # lock-step (8 instead of 18-26 us per 100 000-grid step without a forecast horizon).  Observation rows are written per
-        # step in this mode (no rings), so with a forecast horizon the rolling windows + rings stay the default.
+        # lock-step (9.8 instead of 18.4 us per 100 000-grid step without a forecast horizon); with observation rings one more
+        # (the restarted grids' window columns are patched into the ring: 22 / 43 instead of 27 / 50 us at D = 56 / 156).
         if native is None:
-            native = (self.auto_reset and full_batch.factorised and L.horizon == 0 and not env_kwargs.get("obs_views"))
+            native = self.auto_reset and full_batch.factorised and not env_kwargs.get("obs_views")
         if native and not full_batch.factorised:
             raise ValueError("native=True needs a batch with factorised series")
         if native and not self.auto_reset:
             raise ValueError("native=True is the auto_reset=True path (equal-length windows are gathered once per reset)")
         self.native = bool(native)
-        if self.native:
-            env_kwargs = dict(env_kwargs, obs_prefetch=0)
         self.env = cls(full_batch, **env_kwargs)
         self.starts = self.lengths = None
         self._final_bufs = None
@@ -420,6 +418,13 @@ class PerGridWindowEnv:
         if not self.auto_reset:
             return self.env.step(action, **kw)
         env = self.env
+        if self.native and self._device_draws and env._ring is not None:
+            # rings: the step kernel restarts the grids it finishes and adds the state columns to the ring's row; the window columns
+            # of the restarted grids in the rest of the ring are then patched (mgx_patch_windows): two launches
+            obs, reward, done, info = env.step(action, **kw)
+            if self.final_observation:
+                info = dict(info, final_observation=obs.clone())         # (a ring view: patched below)
+            return env._rows_after_restart(done.view(torch.uint8), True), reward, done, info
         if self.native and self._device_draws:            # one launch: the step kernel restarts the grids it finishes
             final = None
             if self.final_observation and env._observations:

@@ -52,9 +52,11 @@ def test_inplace_episodes_vs_the_oracle_on_shifted_series(arch, device, oracle):
     e.close()
 
 
-@pytest.mark.parametrize("arch,H,discrete", [("genset+battery", 0, False), ("genset+battery+grid", 0, True), ("battery+grid", 5, False),
-                                            ("genset+battery+grid", 24, False), ("genset+battery", 3, True)])
-def test_inplace_episodes_equal_rolling_windows_through_restarts(arch, H, discrete, device):
+@pytest.mark.parametrize("arch,H,discrete,prefetch", [("genset+battery", 0, False, 0), ("genset+battery+grid", 0, True, 0),
+                                                     ("battery+grid", 5, False, 0), ("genset+battery+grid", 24, False, 0),
+                                                     ("genset+battery", 3, True, 0), ("genset+battery+grid", 24, False, 4),
+                                                     ("battery+grid", 5, True, 16), ("genset+battery", 7, False, 5)])
+def test_inplace_episodes_equal_rolling_windows_through_restarts(arch, H, discrete, prefetch, device):
     """The same episodes on window rings (gathered rows) and in place (row offsets): observations, rewards, per-grid done flags
     and per-grid step counters agree at every step, through individual restarts with new starts and lengths, windows that reach
     the end of the series, and many more steps than the longest episode."""
@@ -62,15 +64,15 @@ def test_inplace_episodes_equal_rolling_windows_through_restarts(arch, H, discre
     N, T, max_len = 1500, 300, 14
     cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
     kw = dict(remove_redundant_gensets=False) if discrete else {}
-    ring = cls(_gen(N, T, arch, device, H), obs_prefetch=0, **kw)
-    inpl = cls(_gen(N, T, arch, device, H), **kw)                               # (its rings are switched off by the mode)
+    ring = cls(_gen(N, T, arch, device, H), obs_prefetch=0, **kw)               # window buffers, per-step rows: the plain path
+    inpl = cls(_gen(N, T, arch, device, H), obs_prefetch=prefetch, **kw)        # in place; prefetch > 0: rings + mgx_patch_windows
     rs = np.random.RandomState(8)
     lengths = rs.randint(1, max_len + 1, size=N).astype(np.int32)
     starts = np.array([rs.randint(0, T - n + 1) for n in lengths], dtype=np.int32)
     starts[:3] = T - lengths[:3]                                                # ... ending at the very end of the series
     o1 = ring.reset_windows(starts, lengths, max_length=max_len, rolling=True)
     o2 = inpl.reset_windows(starts, lengths, max_length=max_len, rolling="inplace")
-    assert torch.equal(o1, o2) and inpl.obs_prefetch == 0
+    assert torch.equal(o1, o2) and inpl.obs_prefetch == prefetch and inpl._sync_rings == (prefetch > 0)
     g = torch.Generator(device=device); g.manual_seed(1)
     for k in range(3 * max_len + 5):
         a = (torch.randint(0, ring.action_space.n, (N,), dtype=torch.int32, device=device, generator=g) if discrete
@@ -86,10 +88,8 @@ def test_inplace_episodes_equal_rolling_windows_through_restarts(arch, H, discre
                 new_start = (T - new_len).astype(np.int32)
             assert torch.equal(ring.reset_grids(d1, new_start, new_len), inpl.reset_grids(d2, new_start, new_len)), k
     from pymgrid_amd import MgxError
-    with pytest.raises(MgxError):                           # single steps only, no rings
+    with pytest.raises(MgxError):                           # single steps only
         inpl.engine.step_k(torch.rand(4, N, ring.layout.action_dim, dtype=torch.float64, device=device))
-    with pytest.raises(MgxError):
-        inpl.engine.set_obs_state_only(True)
     assert torch.equal(ring.reset(), inpl.reset())          # a plain reset leaves the mode
     assert not inpl.engine._inplace
     a = (torch.zeros(N, dtype=torch.int32, device=device) if discrete
@@ -99,11 +99,13 @@ def test_inplace_episodes_equal_rolling_windows_through_restarts(arch, H, discre
     ring.close(); inpl.close()
 
 
-@pytest.mark.parametrize("arch,H,discrete,length,final", [("genset+battery", 0, False, 9, False), ("genset+battery", 0, False, 9, True),
-                                                         ("genset+battery+grid", 0, True, None, True),
-                                                         ("battery+grid", 4, False, 7, True), ("genset+battery+grid", 24, False, 11, False),
-                                                         ("genset+battery", 2, True, None, False)])
-def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discrete, length, final, device):
+@pytest.mark.parametrize("arch,H,discrete,length,final,prefetch",
+                         [("genset+battery", 0, False, 9, False, 0), ("genset+battery", 0, False, 9, True, 0),
+                          ("genset+battery+grid", 0, True, None, True, 0), ("battery+grid", 4, False, 7, True, 0),
+                          ("genset+battery+grid", 24, False, 11, False, 0), ("genset+battery", 2, True, None, False, 0),
+                          ("genset+battery+grid", 24, False, 11, True, 4), ("battery+grid", 6, True, None, True, 16),
+                          ("genset+battery", 3, False, 5, False, 3)])
+def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discrete, length, final, prefetch, device):
     """PerGridWindowEnv(auto_reset=True) with device draws: native (one launch per step: the step kernel restarts the grids it
     finishes, mgx_set_auto_reset; the pre-restart rows through mgx_set_final_obs) against the rolling windows (step, restart
     gather, observation pass): observations, rewards, done flags, final observations, the drawn starts / lengths and the per-grid
@@ -114,7 +116,7 @@ def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discret
     if discrete:
         kw["remove_redundant_gensets"] = False
     roll = PerGridWindowEnv(_gen(N, T, arch, device, H), native=False, obs_prefetch=0, **kw)
-    nat = PerGridWindowEnv(_gen(N, T, arch, device, H), native=True, **kw)
+    nat = PerGridWindowEnv(_gen(N, T, arch, device, H), native=True, obs_prefetch=prefetch, **kw)   # prefetch > 0: rings + patches
     assert nat.native and not roll.native
     lengths = None
     rs = np.random.RandomState(2)
@@ -142,7 +144,7 @@ def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discret
     roll.close(); nat.close()
 
 
-def test_inplace_episodes_need_factorised_series_and_refuse_rings(device):
+def test_inplace_episodes_need_factorised_series(device):
     from pymgrid_amd import BatchedMicrogridEnv, MgxError, StepEngine
     from pymgrid_amd.generator import generate
     from pymgrid_amd.hetero import PerGridWindowEnv
@@ -156,15 +158,12 @@ def test_inplace_episodes_need_factorised_series_and_refuse_rings(device):
     e.close()
     with pytest.raises(ValueError, match="factorised"):
         PerGridWindowEnv(bm, trajectory_length=5, auto_reset=True, native=True)
-    # defaults: native for factorised series without a forecast horizon, rolling windows (rings) with one
+    # defaults: native for factorised series (rings stay in use with a forecast horizon), rolling windows for materialised ones
     assert PerGridWindowEnv(_gen(N, T, "genset+battery", device), trajectory_length=5, auto_reset=True).native
-    assert not PerGridWindowEnv(_gen(N, T, "genset+battery", device, H=6), trajectory_length=5, auto_reset=True).native
-    env = BatchedMicrogridEnv(_gen(N, T, "genset+battery+grid", device, H=6), obs_prefetch=4)
+    assert PerGridWindowEnv(_gen(N, T, "genset+battery", device, H=6), trajectory_length=5, auto_reset=True).native
+    assert not PerGridWindowEnv(bm, trajectory_length=5, auto_reset=True).native
+    env = BatchedMicrogridEnv(_gen(N, T, "genset+battery+grid", device, H=6), obs_prefetch=0)
     env.reset_windows(np.zeros(N, dtype=np.int32), None, max_length=10, rolling="inplace")
-    assert env.obs_prefetch == 0
-    with pytest.raises(MgxError):
-        P = getattr(env.engine, "_ring_pitch", N)
-        env.engine.observe_windows(4, out=torch.empty(4, P, env.layout.obs_dim, dtype=torch.float64, device=device)[:, :N])
     with pytest.raises(MgxError):
         env.engine.set_final_obs(torch.empty(N, env.layout.obs_dim, dtype=torch.float64, device=device)) or env.engine.step(
             env.sample_action(), want_obs=False)            # final rows need a step that writes observations
