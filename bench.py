@@ -528,7 +528,7 @@ def main():
         achieved = per_launch_bytes / avg_launch_s / 1e9
         wall_launch_s = wall / launches
         ft = "true" if fact else "false"
-        kname = {"fused": f"step_k_kernel<3,4,double,false,{ft}>", "step": "step_kernel<3>", "step_python": "step_kernel<3>",
+        kname = {"fused": f"step_k_kernel<3,4,double,false,{ft}>", "step": "step_kernel<3,false>", "step_python": "step_kernel<3,false>",
                  "rbc": f"rollout_kernel<3,8,false,false,{ft}>"}[mode]
         traffic, traffic_src = measured_traffic(kname, n_launch, chunk)
         if traffic is not None and sharded:
