@@ -700,6 +700,18 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
             self._table = table_array(self.actions_list)
         self.action_space = Discrete(len(self.actions_list))
 
+    def remove_action(self, action_number):
+        """``DiscreteMicrogridEnv.remove_action`` (envs/discrete/discrete.py:90-106): drop one priority list from the action
+        space; the remaining actions are renumbered as ``list.pop`` renumbers them."""
+        if action_number not in self.action_space:
+            raise ValueError('Cannot remove action that is not in the action space!')
+        self.actions_list.pop(int(action_number))
+        if self._instances:
+            self._lists = torch.as_tensor(lists_array(self.actions_list), device=self.batch.device).contiguous()
+        else:
+            self._table = table_array(self.actions_list)
+        self.action_space = Discrete(self.action_space.n - 1)
+
     def get_action(self, action_id):
         """DiscreteMicrogridEnv._get_action: ids [N] -> unnormalised control [N, A]."""
         if not torch.is_tensor(action_id):
@@ -751,6 +763,21 @@ def _n1_order(params, flat_order):
 
 class _SingleMixin:
     flat_spaces = True
+
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def n_modules(self):
+        """``Microgrid.n_modules`` (microgrid.py:810-818): modules in the microgrid, the unbalanced-energy module included."""
+        L = self.layout
+        return L.n_load + L.n_pv + L.n_genset + L.n_battery + L.n_grid + 1
+
+    def get_forecast_horizon(self):
+        """``Microgrid.get_forecast_horizon`` (microgrid.py:553-582): the forecast horizon of the time-series modules (one value
+        per microgrid here: the layout's)."""
+        return self.layout.horizon
 
     @classmethod
     def from_scenario(cls, microgrid_number=0, root=None, **kwargs):

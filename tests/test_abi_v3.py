@@ -321,6 +321,30 @@ def test_rotating_output_buffers_of_an_env(H, prefetch, discrete, views, device)
     ref.close(); rot.close()
 
 
+def test_remove_action_renumbers_the_priority_lists(device):
+    """DiscreteMicrogridEnv.remove_action (discrete.py:90-106): list.pop on the action list; id j of the shortened space is the
+    old id j (j < k) or j + 1."""
+    from pymgrid_amd import DiscreteBatchedMicrogridEnv
+    from pymgrid_amd.generator import generate
+    N, k = 700, 3
+    make = lambda: generate(N, n_steps=50, seed=2, arch="genset+battery+grid", device=device)
+    full, cut = DiscreteBatchedMicrogridEnv(make()), DiscreteBatchedMicrogridEnv(make())
+    n = full.action_space.n
+    removed = cut.actions_list[k]
+    cut.remove_action(k)
+    assert cut.action_space.n == n - 1 and removed not in cut.actions_list and len(cut.actions_list) == n - 1
+    with pytest.raises(ValueError, match="Cannot remove action"):
+        cut.remove_action(n - 1)
+    full.reset(); cut.reset()
+    g = torch.Generator(device=device); g.manual_seed(0)
+    for _ in range(12):
+        j = torch.randint(0, n - 1, (N,), dtype=torch.int32, device=device, generator=g)
+        o1, r1, d1, _ = full.step(j + (j >= k).to(torch.int32))
+        o2, r2, d2, _ = cut.step(j)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    full.close(); cut.close()
+
+
 def test_reset_while_a_prefetch_into_the_same_ring_is_in_flight(device):
     """After exactly 2 K steps an env sits at the start of ring 2 and the prefetch of ring 0 has just been launched; a reset at
     that moment refills ring 0 on the caller's stream.  The stale prefetch must not land on top of it (mgx_observe_windows
