@@ -281,9 +281,11 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
  * enable = 0 switches it off. */
 int mgx_set_auto_reset(mgx_handle *h, int32_t enable, uint64_t seed, int32_t fixed_length, int32_t *start_io, int32_t *length_io,
                        int32_t *t0_io);
-/* Where the following single steps also write the observation BEFORE any restart ("final_observation" of a vectorised Gym
- * env): device [N, D] rows in the handle's observation format, for every grid (grids that do not restart get the same row
- * as `obs`).  NULL (default) = off.  In-place episodes only; the step must write observations. */
+/* Where the observation BEFORE a restart goes ("final_observation" of a vectorised Gym env): device [N, D] rows in the handle's
+ * observation format.  Rows written per step (no ring): the following single steps write every grid's pre-restart row (grids
+ * that do not restart get the same row as `obs`).  Prefetched rings (MGX_OBS_ROWS_STATE_ONLY): mgx_patch_windows saves the
+ * row of block first_block of every MASKED grid here before it rewrites it; the other rows are left as they are.
+ * NULL (default) = off.  In-place episodes only. */
 int mgx_set_final_obs(mgx_handle *h, void *final_obs);
 
 /* Microgrid.reward_shaping_func (microgrid.py:105,130): one of enum mgx_reward_shaper. */

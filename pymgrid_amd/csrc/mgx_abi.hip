@@ -1032,6 +1032,7 @@ static int episode_step_begin(mgx_handle *h, const uint8_t *done, void *obs, voi
     const bool rows_behind = obs && !obs_inline;
     if (ep->k.final_obs && !obs)
         return fail(MGX_ERR_INVALID, "%s: mgx_set_final_obs is set but the step writes no observation", who);
+    if (ep->k.obs_state_only == 1) ep->k.final_obs = nullptr;    // rings: mgx_patch_windows saves the rows of the restarted grids
     if (rows_behind && ep->k.final_obs) {
         if (ep->k.ar_mode && !done)
             return fail(MGX_ERR_INVALID, "%s: with a forecast horizon the observation before an automatic restart needs the `done` flags", who);

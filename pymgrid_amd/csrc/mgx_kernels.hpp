@@ -59,7 +59,7 @@ __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict_
 template <int F>
 __device__ __forceinline__ int32_t episode_tail(const KArgs &a, int64_t i, int32_t t, int32_t off, bool dn, const Params &p, const State &s)
 {
-    if (a.final_obs) store_step_obs<F>(a, a.final_obs, i, t + 1 + off, p, s);
+    if (a.final_obs && a.obs_state_only != 1) store_step_obs<F>(a, a.final_obs, i, t + 1 + off, p, s);   // (rings: mgx_patch_windows saves it)
     if (a.ar_mode && dn) {
         int32_t s0, len;
         episode_draw(a.ar_seed, i, t + 1, a.ar_fixed_length, a.ar_lo, a.ar_hi, s0, len);
@@ -830,9 +830,12 @@ __global__ __launch_bounds__(64) void patch_windows_kernel(const KArgs a, const 
             nc[idx] = obs_series_value(v, in, true, lo, hi, fill, sp);
         }
         __syncthreads();
+        OT *save = a.final_obs ? (OT *)a.final_obs + g * D : nullptr;   // mgx_set_final_obs: the row the restart is about to replace
         for (int32_t col = lane; col < D; col += 64) {
             uint32_t comp, h;                              // which series component / horizon step this column shows
             decode_obs_col(a, GRID, col, W, comp, h);
+            OT *cur = ring + ((int64_t)first * pitch + g) * D + col;
+            if (save) save[col] = *cur;                    // (state columns too: the whole pre-restart observation)
             if (comp == 0xffffu) continue;                 // state columns
             const double *src = (h == 0 ? nu : nc) + comp * R + h;
             for (int32_t k = first; k < K; k++) ring[((int64_t)k * pitch + g) * D + col] = (OT)src[k - first];

@@ -329,7 +329,8 @@ class PerGridWindowEnv:
     ``mgx_reset_windows_rolling`` / ``mgx_reset_grids``) -- N reference microgrids that are each reset when they report
     ``done``, as a vectorised Gym env does.  ``step`` then returns the first observation of the new episode for the grids that
     just finished and the batch never needs a global ``reset()`` again.  ``final_observation=True`` also returns the last rows
-    of the finished episodes in ``info["final_observation"]`` (a copy of the rows per step).  With a forecast horizon the
+    of the finished episodes in ``info["final_observation"]`` ([N, D]; only the rows of the grids with ``done`` set are
+    meaningful -- what a vectorised Gym env reports -- the others may hold older rows).  With a forecast horizon the
     observation rings stay in use: they are refilled on the caller's stream and the restarted grids' rows are patched into them
     (``mgx_patch_windows``).
     """
@@ -421,18 +422,19 @@ class PerGridWindowEnv:
         if self.native and self._device_draws and env._ring is not None:
             # rings: the step kernel restarts the grids it finishes and adds the state columns to the ring's row; the window columns
             # of the restarted grids in the rest of the ring are then patched (mgx_patch_windows): two launches
+            final = None
+            if self.final_observation:       # the patch saves the rows it is about to replace (the finished grids' only)
+                final = self._next_final_buf()
+                env.engine.set_final_obs(final)
             obs, reward, done, info = env.step(action, **kw)
-            if self.final_observation:
-                info = dict(info, final_observation=obs.clone())         # (a ring view: patched below)
-            return env._rows_after_restart(done.view(torch.uint8), True), reward, done, info
+            obs = env._rows_after_restart(done.view(torch.uint8), True)
+            if final is not None:
+                info = dict(info, final_observation=env._select_obs(final))
+            return obs, reward, done, info
         if self.native and self._device_draws:            # one launch: the step kernel restarts the grids it finishes
             final = None
             if self.final_observation and env._observations:
-                if self._final_bufs is None:
-                    e = env.engine
-                    self._final_bufs = torch.empty(self.FINAL_BUFFERS, e.N, e.obs_dim, dtype=e.obs_dtype, device=e.device)
-                self._final_pos = (self._final_pos + 1) % self.FINAL_BUFFERS
-                final = self._final_bufs[self._final_pos]          # (valid for FINAL_BUFFERS - 1 further steps)
+                final = self._next_final_buf()
                 env.engine.set_final_obs(final)
             obs, reward, done, info = env.step(action, **kw)
             if final is not None:
@@ -460,6 +462,14 @@ class PerGridWindowEnv:
         if self.final_observation:
             info = dict(info, final_observation=final)
         return (new_obs if new_obs is not None else obs), reward, done, info
+
+    def _next_final_buf(self):
+        """One of FINAL_BUFFERS rotating [N, D] buffers for ``info["final_observation"]`` (valid for FINAL_BUFFERS - 1 further steps)."""
+        if self._final_bufs is None:
+            e = self.env.engine
+            self._final_bufs = torch.zeros(self.FINAL_BUFFERS, e.N, e.obs_dim, dtype=e.obs_dtype, device=e.device)
+        self._final_pos = (self._final_pos + 1) % self.FINAL_BUFFERS
+        return self._final_bufs[self._final_pos]
 
     def __getattr__(self, name):              # everything else (engine, action_space, sample_action, ...) as the env
         return getattr(self.env, name)
