@@ -670,7 +670,7 @@ def main():
 
     # metrics vector: episode-return sum + mean SoC, all-reduced over ranks (the ONLY collective; RCCL over xGMI)
     sums = eng.metrics(torch.stack([run.outs[0]["reward"][-1], batch.cols["soc"]]))
-    mdist.all_reduce_metrics(sums)
+    sums = mdist.all_reduce_metrics(sums)     # bounded: RCCL raising or hanging ends in a reported gloo fallback, not in a lost line
     mdist.barrier()
 
     cpu = None
@@ -717,16 +717,21 @@ def main():
             "other": {names[m]: (r if "error" in r else {k: r[k] for k in ("value", "steps", "warmup", "ms_per_step", "roofline")})
                       for m, r in results.items() if m != args.mode},
             "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total,
-                                  "collective_backend": mdist.last_collective["backend"], "collective_error": mdist.last_collective["error"]},
+                                  "collective_backend": mdist.last_collective["backend"], "collective_error": mdist.last_collective["error"],
+                                  "collective_hung": mdist.last_collective.get("hung", False)},
             "closed_loop_policy_gym_steps": closed,
             "hetero_h24_gym_steps": hetero,
             "prewarm_seconds_per_mode": args.prewarm,
         }
         print(json.dumps(line), flush=True)
-    eng.close()
     if world > 1:
         import torch.distributed as dist
         mdist.barrier()                 # (control plane: gloo; a dead rank is named after MGX_CTRL_TIMEOUT_S instead of hanging RCCL)
+        if mdist.last_collective.get("hung"):       # a helper thread is still stuck inside RCCL: tearing the group down would hang too
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
+    eng.close()
+    if world > 1:
         dist.destroy_process_group()
 
 

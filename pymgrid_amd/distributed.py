@@ -13,7 +13,7 @@ import torch.distributed as dist
 # touched exactly once, by ``all_reduce_metrics`` (with a gloo fallback that is reported, should RCCL refuse to come up).
 _ctrl = None
 CTRL_TIMEOUT_S = float(os.environ.get("MGX_CTRL_TIMEOUT_S", "600"))
-last_collective = {"backend": None, "error": None}
+last_collective = {"backend": None, "error": None, "hung": False}
 
 
 def shard_bounds(n_total, rank, world):
@@ -47,25 +47,53 @@ def _multi():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def all_reduce_metrics(local_sums):
+def all_reduce_metrics(local_sums, timeout_s=None):
     """Sum a small metrics vector over all ranks (in place, returns it): THE collective of the engine (RCCL over xGMI on a GPU
-    node).  Should the default backend fail to come up, the sum is taken over the gloo control group instead and the failure is
-    kept in ``last_collective`` (bench.py prints it) -- the per-rank throughputs do not depend on it.  No-op for one process."""
+    node).  With a gloo control group beside the default backend the attempt is BOUNDED: the all-reduce runs in a helper thread,
+    every rank waits ``timeout_s`` (MGX_RCCL_TIMEOUT_S, default 120 s) for it, the ranks then agree over the control group whether
+    it came through everywhere, and if it did not -- RCCL raised, or hangs (IPC handles, a missing peer) -- the sum is taken over
+    the control group instead.  The failure is kept in ``last_collective`` (bench.py prints it; ``hung`` tells the caller that a
+    thread is still stuck inside the backend: leave with ``os._exit`` after flushing).  The per-rank throughputs never depend on
+    this call.  No-op for one process."""
     if not _multi():
         return local_sums
-    last_collective.update(backend=dist.get_backend(), error=None)
-    try:
+    last_collective.update(backend=dist.get_backend(), error=None, hung=False)
+    if _ctrl is None:                                        # one backend only (gloo in tests): nothing to fall back to
         dist.all_reduce(local_sums, op=dist.ReduceOp.SUM)
-        if local_sums.is_cuda:
-            torch.cuda.synchronize(local_sums.device)       # surface an asynchronous RCCL failure here, not later
-    except Exception as e:                                   # noqa: BLE001
-        if _ctrl is None:
-            raise
-        host = local_sums.detach().cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=_ctrl)
+        return local_sums
+    import threading
+    timeout_s = float(os.environ.get("MGX_RCCL_TIMEOUT_S", "120")) if timeout_s is None else float(timeout_s)
+    host = local_sums.detach().cpu().clone()                 # what the fallback sums (the attempt may leave garbage behind)
+    res = {}
+
+    def attempt():
+        try:
+            if local_sums.is_cuda:
+                torch.cuda.set_device(local_sums.device)
+            dist.all_reduce(local_sums, op=dist.ReduceOp.SUM)
+            if local_sums.is_cuda:
+                torch.cuda.synchronize(local_sums.device)   # surface an asynchronous RCCL failure here, not later
+            res["ok"] = True
+        except Exception as e:                               # noqa: BLE001
+            res["err"] = f"{type(e).__name__}: {e}"
+    th = threading.Thread(target=attempt, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    ok = torch.tensor([1.0 if res.get("ok") else 0.0], dtype=torch.float64)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=_ctrl)   # a collective comes through everywhere or is not trusted anywhere
+    if float(ok.item()) == 1.0:
+        return local_sums
+    hung = th.is_alive()
+    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=_ctrl)
+    if not hung:
         local_sums.copy_(host)
-        last_collective.update(backend="gloo (fallback)", error=f"{type(e).__name__}: {e}")
-    return local_sums
+        out = local_sums
+    else:                                                    # the stuck thread may still own local_sums: hand out a fresh tensor
+        out = host.to(local_sums.device) if not local_sums.is_cuda else host
+    err = res.get("err") or (f"no answer from the {dist.get_backend()} all-reduce within {timeout_s:g} s" if hung
+                             else "the all-reduce failed on another rank")
+    last_collective.update(backend="gloo (fallback)", error=err, hung=hung)
+    return out
 
 
 def max_over_ranks(value, device=None):

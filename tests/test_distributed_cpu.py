@@ -48,7 +48,26 @@ def _worker(rank, world, port, n_total, out):
     finally:
         dist.all_reduce = real
     assert torch.equal(again, total) and mdist.last_collective["backend"] == "gloo (fallback)"
-    assert "hipIpcGetMemHandle" in mdist.last_collective["error"]
+    assert "hipIpcGetMemHandle" in mdist.last_collective["error"] and not mdist.last_collective["hung"]
+    # ... or hangs (on ONE rank only: the ranks agree over the control group that the collective is not to be trusted)
+    import time
+
+    def hanging_default(t, op=dist.ReduceOp.SUM, group=None, **kw):
+        if group is None:
+            if rank == 1:
+                time.sleep(60)
+            t.fill_(-1.0)                                                    # garbage that must not reach the caller
+            return None
+        return real(t, op=op, group=group, **kw)
+    dist.all_reduce = hanging_default
+    try:
+        t0 = time.time()
+        third = mdist.all_reduce_metrics(local.clone(), timeout_s=1.5)
+    finally:
+        dist.all_reduce = real
+    assert time.time() - t0 < 20 and torch.equal(third, total) and mdist.last_collective["backend"] == "gloo (fallback)"
+    assert mdist.last_collective["hung"] == (rank == 1)
+    assert ("no answer" in mdist.last_collective["error"]) == (rank == 1)
     if rank == 0:
         torch.save(dict(total=total, tmax=tmax), out)
     torch.distributed.destroy_process_group()
