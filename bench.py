@@ -76,6 +76,9 @@ def parse(argv=None):
     ap.add_argument("--hetero-steps", type=int, default=256, help="timed Gym steps of the heterogeneous H=24 fleet (0: skip)")
     ap.add_argument("--no-side-modes", action="store_true", help="time the headline mode only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-closed-loop", action="store_true",
+                    help="skip the closed-loop legs (the PMC passes use it: their single steps WITH observation rows would be "
+                         "averaged into the single-step kernel's counters)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--prewarm", type=float, default=PREWARM_S)
     ap.add_argument("--launch-check", action="store_true",
@@ -599,7 +602,7 @@ def main():
     # an agent IN the loop (the fused modes replay pre-staged actions): obs -> a small on-device policy -> env.step -> obs, from
     # Python, observation rows written every step (H = 0: 8 values per grid)
     closed = None
-    if not args.no_side_modes:
+    if not args.no_side_modes and not args.no_closed_loop:
         def closed_loop():
             from pymgrid_amd import BatchedMicrogridEnv
 

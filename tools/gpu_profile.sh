@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 cd /tmp
 ARGS="${*:---gpus 1 --steps 20 --warmup 5}"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- python "$REPO/bench.py" $ARGS > "$OUT/stats.log" 2> "$OUT/stats.err"
-PMCARGS="$ARGS --no-cpu-baseline --hetero-steps 0"
+PMCARGS="$ARGS --no-cpu-baseline --hetero-steps 0 --no-closed-loop"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o bench --output-format csv -- python "$REPO/bench.py" $PMCARGS > "$OUT/pmc_fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o bench --output-format csv -- python "$REPO/bench.py" $PMCARGS > "$OUT/pmc_write.log" 2>&1
 cd "$REPO"
