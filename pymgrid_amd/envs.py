@@ -155,7 +155,7 @@ class BatchedMicrogridEnv:
         # ~8 us a step costs on the host, tools/exp_closed_loop_host.py) less per step.  0: fresh tensors, as the reference returns
         self._reuse = int(reuse_outputs)
         self._out_pos = 0
-        self._rew_bufs = self._obs_bufs = None
+        self._rew_bufs = self._obs_bufs = self._done_bufs = None
         if self._reuse:
             if self._reuse < 2:
                 raise ValueError("reuse_outputs must be 0 or >= 2")
@@ -493,6 +493,10 @@ class BatchedMicrogridEnv:
             k = self._out_pos
             self._out_pos = k + 1 if k + 1 < self._reuse else 0
             out = {"reward": self._rew_bufs[k]}
+            if self.engine._window_start is not None:      # per-grid episodes: the kernel writes the done flags
+                if self._done_bufs is None:
+                    self._done_bufs = torch.empty(self._reuse, self.n_grids, dtype=torch.uint8, device=self.batch.device)
+                out["done"] = self._done_bufs[k]
             if target is not None:
                 out["obs"] = target
             elif want and self._obs_bufs is not None and self._ring is None:

@@ -116,7 +116,8 @@ def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discret
     if discrete:
         kw["remove_redundant_gensets"] = False
     roll = PerGridWindowEnv(_gen(N, T, arch, device, H), native=False, obs_prefetch=0, **kw)
-    nat = PerGridWindowEnv(_gen(N, T, arch, device, H), native=True, obs_prefetch=prefetch, **kw)   # prefetch > 0: rings + patches
+    nat = PerGridWindowEnv(_gen(N, T, arch, device, H), native=True, obs_prefetch=prefetch,         # prefetch > 0: rings + patches
+                           reuse_outputs=(3 if H in (0, 3) else 0), **kw)                         # (rotating reward / done / row buffers)
     assert nat.native and not roll.native
     lengths = None
     rs = np.random.RandomState(2)
