@@ -192,19 +192,19 @@ def timed(run, fn, rounds, device, mdist):
     """barrier + sync | K rounds | sync + barrier; returns (wall seconds, GPU seconds = the longest launch stream's elapsed
     time between its own start and stop events)."""
     streams = run.streams or [torch.cuda.current_stream(device)]
-    mdist.barrier()
-    torch.cuda.synchronize(device)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
+    mdist.barrier()
+    run.eng.fork()                      # stream ordering only (no GPU work): the shard streams line up behind the caller's stream
+    torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    run.eng.fork()
     for (e0, _), st in zip(ev, streams):
         e0.record(st)
     fn(rounds)
     for (_, e1), st in zip(ev, streams):
         e1.record(st)
-    run.eng.join()
-    torch.cuda.synchronize(device)
+    torch.cuda.synchronize(device)      # the whole device: every shard stream has drained
     t1 = time.perf_counter()
+    run.eng.join()
     mdist.barrier()
     return t1 - t0, max(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3
 
