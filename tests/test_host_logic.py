@@ -214,3 +214,14 @@ def test_create_argument_checks_of_round_3_without_a_gpu(pymgrid25):
     from dataclasses import replace
     with pytest.raises(ValueError):
         replace(bf.layout, flat_order="alphabetical")
+
+
+def test_episode_entry_points_refuse_null_handles_without_a_gpu():
+    """The ABI v6 entry points (in-place episodes) check their arguments before they touch a device."""
+    from pymgrid_amd import _lib
+    L = _lib.lib()
+    assert L.mgx_reset_episodes(None, None, None, 5, None, None, None, None) == _lib.MGX_ERR_INVALID
+    assert b"NULL" in L.mgx_last_error()
+    assert L.mgx_set_auto_reset(None, 1, 0, 0, None, None, None) == _lib.MGX_ERR_INVALID
+    assert L.mgx_set_final_obs(None, None) == _lib.MGX_ERR_INVALID
+    assert b"mgx_set_final_obs" in L.mgx_last_error()
