@@ -742,26 +742,37 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     const int32_t total = n_valid * D;                   // D is even (one load, one renewable module)
     typedef OT vec2 __attribute__((ext_vector_type(2)));
     const bool wide = (reinterpret_cast<uintptr_t>(ring) & (sizeof(vec2) - 1)) == 0;
-    for (int32_t k = wave; k < K; k += OBS_K_THREADS / 64) {
-        OT *out = ring + ((int64_t)k * plan.pitch + g0) * D;
-        const double *src = image + k;
-        if (wide) {                                      // element pair f, f + 1 = 2 lane + 128 j -> (row, column)
-            int32_t r = 2 * lane / D, c = 2 * lane - r * D;
-            for (int32_t f = 2 * lane; f < total; f += 128) {
+    // A lane's element schedule (which (grid, column) its j-th store carries) is the same for every block: the column map is
+    // looked up once per element and reused for the wave's blocks k = wave, wave + 4, ... (image[... + k]: consecutive words)
+    constexpr int KW = OBS_K_THREADS / 64;
+    const int64_t block_stride = (int64_t)plan.pitch * D;
+    OT *out0 = ring + ((int64_t)wave * plan.pitch + g0) * D;
+    if (wide) {                                          // element pair f, f + 1 = 2 lane + 128 j -> (row, column)
+        int32_t r = 2 * lane / D, c = 2 * lane - r * D;
+        for (int32_t f = 2 * lane; f < total; f += 128) {
+            const double *s0 = image + r * BP + map[c] + wave;
+            const double *s1 = image + r * BP + map[c + 1] + wave;     // D even, c even: the pair never straddles two rows
+            OT *out = out0 + f;
+            for (int32_t k = wave; k < K; k += KW) {
                 vec2 v2;
-                v2.x = (OT)src[r * BP + map[c]];
-                v2.y = (OT)src[r * BP + map[c + 1]];     // D even, c even: the pair never straddles two rows
-                MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out + f));
-                c += 128;
-                while (c >= D) { c -= D; r++; }
+                v2.x = (OT)*s0; v2.y = (OT)*s1;
+                MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out));
+                s0 += KW; s1 += KW; out += KW * block_stride;
             }
-        } else {
-            int32_t r = lane / D, c = lane - r * D;
-            for (int32_t f = lane; f < total; f += 64) {
-                MGX_WIN_STORE((OT)src[r * BP + map[c]], out + f);
-                c += 64;
-                while (c >= D) { c -= D; r++; }
+            c += 128;
+            while (c >= D) { c -= D; r++; }
+        }
+    } else {
+        int32_t r = lane / D, c = lane - r * D;
+        for (int32_t f = lane; f < total; f += 64) {
+            const double *s0 = image + r * BP + map[c] + wave;
+            OT *out = out0 + f;
+            for (int32_t k = wave; k < K; k += KW) {
+                MGX_WIN_STORE((OT)*s0, out);
+                s0 += KW; out += KW * block_stride;
             }
+            c += 64;
+            while (c >= D) { c -= D; r++; }
         }
     }
 }
