@@ -684,3 +684,53 @@ def test_views_and_lockstep_done_through_resets_and_trajectories(device):
                 assert torch.equal(o[b], v[b].flat()) and torch.equal(r[b], r2[b]) and torch.equal(d[b], d2[b]), (n_steps, k, names[b])
             assert all(e.current_step == k + 1 for e in fr.envs + fv.envs)
     fr.close(); fv.close()
+
+
+@pytest.mark.gpu
+def test_factorised_edge_shapes_vs_the_oracle(device, oracle):
+    """Series lengths around the 64-row outage words and the 128-row LDS chunks of the fused kernels (T = 2 ... 257), batches of
+    1 ... 257 grids, fused launches that start in the last rows of a chunk and end on the last row, single steps with
+    observations whose windows (H = 0, 3, T + 2) run past the end of the series, the rule-based rollout: == the CPU oracle on the
+    series the factors stand for; observations == the materialised twin's."""
+    from pymgrid_amd import BatchedMicrogridEnv, StepEngine
+    from pymgrid_amd.generator import generate
+    from pymgrid_amd.priority_list import get_priority_lists, table_array
+    from pymgrid_amd.rbc import default_priority_ids
+    rs = np.random.RandomState(0)
+    for T, N in ((2, 1), (3, 65), (63, 257), (64, 63), (65, 64), (127, 130), (128, 1), (129, 257), (257, 66)):
+        arch = ("genset+battery+grid", "battery+grid", "genset+battery")[T % 3]
+        bf = generate(N, n_steps=T, seed=100 + T, arch=arch, device=device, mixed_timers=True, series="factorised")
+        cols = bf.numpy_columns()
+        A = bf.layout.action_dim
+        e = StepEngine(bf)
+        for t0 in sorted({0, max(0, T - 2), max(0, min(T - 1, 126)), rs.randint(0, T)}):
+            K = T - t0
+            st = {k: bf.cols[k].cpu().numpy().view(np.uint32 if k == "gen_status" else np.float64).copy()
+                  for k in ("charge", "soc", "gen_status") if k in bf.cols}
+            acts = torch.rand(K, N, A, dtype=torch.float64, device=device)
+            e.reset(t0, want_obs=False)
+            out = e.step_k(acts, reward=True, soc_trace=True, done=True)
+            ref = oracle.run_batch(cols, st, t0, K, acts.cpu().numpy(), normalized=True)
+            assert np.array_equal(out["reward"].cpu().numpy(), ref), (T, N, t0)
+            assert np.array_equal(bf.cols["charge"].cpu().numpy(), st["charge"]), (T, N, t0)
+            assert bool(out["done"][-1].all()) and (K == 1 or not bool(out["done"][:-1].any()))
+        # rule-based rollout over the whole series
+        lists = get_priority_lists(bf.layout.has_genset, bf.layout.has_battery, bf.layout.has_grid, False)
+        ids = default_priority_ids(bf, lists, remove_redundant_gensets=False)
+        st = {k: bf.cols[k].cpu().numpy().view(np.uint32 if k == "gen_status" else np.float64).copy()
+              for k in ("charge", "soc", "gen_status") if k in bf.cols}
+        e.reset(0, want_obs=False)
+        r = e.rollout_discrete(torch.from_numpy(ids).to(device), table_array(lists), T, reward=True)
+        ref = oracle.rollout_batch(cols, st, 0, T, ids, table_array(lists))
+        assert np.array_equal(r["reward"].cpu().numpy(), ref), (T, N, "rbc")
+        e.close()
+        # observations: single steps to the end of the series, windows past it; factorised == materialised twin
+        for H in (0, 3, T + 2):
+            kw = dict(n_steps=T, seed=100 + T, arch=arch, device=device, mixed_timers=True, horizon=H)
+            em, ef = BatchedMicrogridEnv(generate(N, **kw)), BatchedMicrogridEnv(generate(N, series="factorised", **kw))
+            assert torch.equal(em.reset(), ef.reset()), (T, N, H)
+            for k in range(T - 1):
+                a = torch.rand(N, A, dtype=torch.float64, device=device)
+                (o1, r1, d1, _), (o2, r2, d2, _) = em.step(a), ef.step(a)
+                assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), (T, N, H, k)
+            em.close(); ef.close()
