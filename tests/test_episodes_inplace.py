@@ -281,3 +281,32 @@ def test_mode_changes_leave_nothing_behind(device):
     assert torch.equal(a_env.reset(), b_env.reset())
     steps(4)
     a_env.close(); b_env.close()
+
+
+@pytest.mark.parametrize("length,H,prefetch", [(1, 0, 0), (1, 45, 0), (None, 0, 0), (None, 45, 4), (40, 3, 2), (39, 0, 0)])
+def test_native_auto_reset_at_the_edges(length, H, prefetch, device):
+    """Episodes of one step (every grid restarts at every step), of the whole series (one possible start row), stochastic lengths
+    over the whole window, forecast windows longer than the series: in place == rolling windows."""
+    from pymgrid_amd.hetero import PerGridWindowEnv
+    N, T = 130, 40
+    kw = dict(auto_reset=True, final_observation=True, seed=8, trajectory_length=length)
+    roll = PerGridWindowEnv(_gen(N, T, "genset+battery+grid", device, H), native=False, obs_prefetch=0, **kw)
+    nat = PerGridWindowEnv(_gen(N, T, "genset+battery+grid", device, H), native=True, obs_prefetch=prefetch, **kw)
+    rs = np.random.RandomState(1)
+    if length is None:
+        lengths = rs.randint(1, T + 1, size=N).astype(np.int32)
+        starts = np.array([rs.randint(0, T - n + 1) for n in lengths], dtype=np.int32)
+    else:
+        lengths, starts = None, rs.randint(0, T - length + 1, size=N).astype(np.int32)
+    assert torch.equal(roll.reset(starts, lengths), nat.reset(starts, lengths))
+    g = torch.Generator(device=device); g.manual_seed(2)
+    for k in range(3 * T):
+        a = torch.rand(N, 4, dtype=torch.float64, device=device, generator=g)
+        o1, r1, d1, i1 = roll.step(a)
+        o2, r2, d2, i2 = nat.step(a)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(o1, o2), k
+        assert torch.equal(i1["final_observation"][d1], i2["final_observation"][d2]), k
+        assert torch.equal(roll.starts, nat.starts) and torch.equal(roll.lengths, nat.lengths), k
+        if length == 1:
+            assert bool(d1.all())
+    roll.close(); nat.close()
