@@ -188,6 +188,28 @@ class Runner:
         return sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev) * 1e3
 
 
+def sample_device_state(out, delay_s=0.12):
+    """Clocks / power / temperature of the GPU as rocm-smi reports them, sampled once from a helper thread while the caller keeps
+    the device busy (the untimed pre-warm of the headline): box-to-box differences of the headline show up here or nowhere."""
+    import threading
+
+    def work():
+        time.sleep(delay_s)
+        try:
+            res = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True,
+                                 timeout=10)
+            txt = res.stdout[res.stdout.index("{"):]
+            cards = json.loads(txt)
+            idx = torch.cuda.current_device() if False else 0
+            card = cards.get(f"card{idx}") or next(iter(cards.values()))
+            out.update({k.rstrip(":"): v for k, v in card.items()})
+        except Exception as e:          # noqa: BLE001  (diagnostics only)
+            out["error"] = f"{type(e).__name__}: {e}"
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    return th
+
+
 def timed(run, fn, rounds, device, mdist):
     """barrier + sync | K rounds | sync + barrier; returns (wall seconds, GPU seconds = the longest launch stream's elapsed
     time between its own start and stop events)."""
@@ -490,6 +512,8 @@ def main():
     eng, batch = run.eng, run.eng.batch
     L = eng.layout
 
+    device_state = {}
+
     def measure(mode, sharded, rounds, warmup, series=None):
         run = runner(series or args.series)
         eng, S = run.eng, run.S
@@ -505,11 +529,16 @@ def main():
         # with no idle gap between them
         r0 = run.rounds
         run.eng.fork()
+        sampler = None
+        if mode == args.mode and not device_state and rank == 0:      # the headline's pre-warm: what the device runs at under this load
+            sampler = sample_device_state(device_state)
         t_end = time.perf_counter() + args.prewarm
         while time.perf_counter() < t_end:
             fn(8)
             if run.rounds - r0 > 64:                             # keep the launch queues short: ~64 rounds ahead at most
                 run.eng.join(); torch.cuda.synchronize(dev); run.eng.fork(); r0 = run.rounds
+        if sampler is not None:
+            sampler.join(2.0)
         fn(warmup)
         first = run.rounds
         wall, gpu = timed(run, fn, rounds, dev, mdist)
@@ -725,6 +754,7 @@ def main():
             "closed_loop_policy_gym_steps": closed,
             "hetero_h24_gym_steps": hetero,
             "prewarm_seconds_per_mode": args.prewarm,
+            "device_state_under_load": device_state or None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
