@@ -56,6 +56,8 @@ struct mgx_handle {
     bool windowed;
     bool rolling;                            // mgx_reset_windows_rolling: ring buffers, partial resets (mgx_reset_grids)
     bool inplace;                            // mgx_reset_episodes: rolling episodes on the factorised series themselves (no buffers)
+    double *pm_tables;                       // ... and the profile-major copies of the base tables they read ([3][PP][pm_pitch], lazily)
+    int32_t pm_pitch;
     int32_t rolling_max_length;
     double *roll_load_w, *roll_pv_w, *roll_grid_w;
     int32_t *roll_final;
@@ -351,8 +353,8 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->k.row_mask = -1;
     h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.ar_fixed_length = 0; h->k.ar_lo = 0; h->k.ar_hi = 0;
     h->k.ar_max_length = 0; h->k.ar_seed = 0; h->k.ar_start_io = nullptr; h->k.ar_length_io = nullptr; h->k.ar_t0_io = nullptr;
-    h->k.final_obs = nullptr;
-    h->inplace = false;
+    h->k.final_obs = nullptr; h->k.pm_pitch = 0;
+    h->inplace = false; h->pm_tables = nullptr; h->pm_pitch = 0;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
         return hip_fail(e, "hipMalloc(scratch)");
@@ -376,6 +378,7 @@ void mgx_destroy(mgx_handle *h)
     }
     if (h->fork_event) (void)hipEventDestroy(h->fork_event);
     if (h->prefetch_stream) { (void)hipStreamSynchronize(h->prefetch_stream); (void)hipStreamDestroy(h->prefetch_stream); }
+    if (h->pm_tables) (void)hipFree(h->pm_tables);
     if (h->d_kargs) (void)hipFree(h->d_kargs);
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_lists) (void)hipFree(h->d_lists);
@@ -702,6 +705,18 @@ static int sync_device_kargs(mgx_handle *h, hipStream_t st, const char *who)
     return MGX_OK;
 }
 
+// in-place episode state off: offsets, restart switches, final rows, and the base tables back to the caller's [T, PP] arrays
+static void leave_inplace(mgx_handle *h)
+{
+    h->inplace = false;
+    h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.final_obs = nullptr;
+    h->k.ar_start_io = nullptr; h->k.ar_length_io = nullptr; h->k.ar_t0_io = nullptr;
+    if (h->k.pm_pitch) {
+        h->k.c.base_load = h->full_c.base_load; h->k.c.base_pv = h->full_c.base_pv; h->k.c.base_co2 = h->full_c.base_co2;
+        h->k.pm_pitch = 0;
+    }
+}
+
 // back to the full series after a per-grid-window episode
 static void leave_windows(mgx_handle *h)
 {
@@ -711,10 +726,9 @@ static void leave_windows(mgx_handle *h)
     h->k.T = h->full_T; h->k.final_step = h->full_final; h->k.grid_final = nullptr;
     h->layout.n_steps = h->full_T; h->layout.final_step = h->full_final; h->layout.initial_step = h->full_initial;
     h->window_lo = h->full_window_lo; h->window_hi = h->full_window_hi;
-    h->windowed = false; h->rolling = false; h->inplace = false;
+    h->windowed = false; h->rolling = false;
     h->k.row_mask = -1;
-    h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.final_obs = nullptr;
-    h->k.ar_start_io = nullptr; h->k.ar_length_io = nullptr; h->k.ar_t0_io = nullptr;
+    leave_inplace(h);
 }
 
 int mgx_reset(mgx_handle *h, int32_t initial_step, void *obs, mgx_stream stream)
@@ -765,7 +779,7 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gather_windows_kernel launch");
     h->rolling = false; h->k.row_mask = -1;
-    h->inplace = false; h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.final_obs = nullptr;
+    leave_inplace(h);
     h->k.c.base_load = nullptr;                          // the episode steps over the (materialised) window buffers
     h->k.c.load_ts = load_w; h->k.c.pv_ts = pv_w; if (h->layout.has_grid) h->k.c.grid_ts = grid_w;
     h->k.T = rows; h->k.final_step = max_length; h->k.grid_final = length ? final_rel : nullptr;
@@ -815,7 +829,7 @@ int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t
     h->rolling_max_length = max_length;
     h->roll_load_w = load_w; h->roll_pv_w = pv_w; h->roll_grid_w = grid_w; h->roll_final = final_abs;
     h->k.row_mask = ring_rows - 1;
-    h->inplace = false; h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.final_obs = nullptr;
+    leave_inplace(h);
     GatherArgs g;
     rolling_gather_args(h, &g);
     g.start = start; g.length = length; g.mask = nullptr; g.row0 = 0;
@@ -852,6 +866,30 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
     if (max_length < 1 || max_length > h->full_window_hi - h->full_window_lo)
         return fail(MGX_ERR_INVALID, "Cannot create a trajectory of length %d between initial_step (%d) and final_step (%d)",
                     max_length, h->full_window_lo, h->full_window_hi);
+    // profile-major copies of the base tables (1.7 MB for a year of hourly rows): in this mode every lane reads its own row
+    {
+        const int32_t pitch = h->full_T;
+        const bool co2 = h->full_c.base_co2 != nullptr;
+        DeviceGuard on_device(h->device);
+        hipError_t e = hipSuccess;
+        if (!h->pm_tables || h->pm_pitch != pitch) {
+            if (h->pm_tables) (void)hipFree(h->pm_tables);
+            h->pm_tables = nullptr;
+            e = hipMalloc((void **)&h->pm_tables, (size_t)3 * MGX_PROFILE_PITCH * pitch * sizeof(double));
+            if (e != hipSuccess) return hip_fail(e, "mgx_reset_episodes: allocating the profile-major base tables");
+            h->pm_pitch = pitch;
+        }
+        const size_t one = (size_t)MGX_PROFILE_PITCH * pitch;
+        const unsigned blocks = (unsigned)blocks_for((int64_t)one);
+        profile_major_kernel<<<blocks, BLOCK, 0, (hipStream_t)stream>>>(h->full_c.base_load, h->pm_tables, h->full_T, pitch);
+        profile_major_kernel<<<blocks, BLOCK, 0, (hipStream_t)stream>>>(h->full_c.base_pv, h->pm_tables + one, h->full_T, pitch);
+        if (co2) profile_major_kernel<<<blocks, BLOCK, 0, (hipStream_t)stream>>>(h->full_c.base_co2, h->pm_tables + 2 * one, h->full_T, pitch);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "profile_major_kernel launch");
+        h->k.c.base_load = h->pm_tables; h->k.c.base_pv = h->pm_tables + one;
+        if (co2) h->k.c.base_co2 = h->pm_tables + 2 * one;
+        h->k.pm_pitch = pitch;
+    }
     h->rolling_max_length = max_length;
     h->roll_load_w = nullptr; h->roll_pv_w = nullptr; h->roll_grid_w = nullptr; h->roll_final = final_abs;
     h->k.row_mask = -1;
@@ -864,8 +902,7 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
     g.start = start; g.length = length; g.mask = nullptr; g.row0 = 0;
     gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, (hipStream_t)stream>>>(g);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { h->inplace = false; h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.grid_final = nullptr;
-                           return hip_fail(e, "gather_windows_kernel launch"); }
+    if (e != hipSuccess) { leave_inplace(h); h->k.grid_final = nullptr; return hip_fail(e, "gather_windows_kernel launch"); }
     // k.T stays the series length (rows beyond it are padding, per grid); the counter itself never ends
     h->k.final_step = INT32_MAX / 2;
     h->layout.final_step = INT32_MAX / 2; h->layout.initial_step = 0;

@@ -76,6 +76,10 @@ struct KArgs {
     uint64_t ar_seed;
     int32_t *ar_start_io, *ar_length_io, *ar_t0_io;
     void *final_obs;                        // mgx_set_final_obs: the observation BEFORE the restart (rows written inline only)
+    // In-place episodes read the base tables with one row per LANE: c.base_load / base_pv / base_co2 then point at the handle's
+    // PROFILE-major copies [MGX_PROFILE_PITCH, pm_pitch] (a lane's consecutive rows share a line; the public [T, 8] layout has
+    // a 64-byte line per row, which suits the lock-step kernels where every lane reads the same row).  0 = the public layout.
+    int32_t pm_pitch;
 };
 
 // done flag of grid i at step counter t: _done(), base_timeseries_module.py:124-125 (evaluated before the counter moves)
@@ -244,6 +248,12 @@ __device__ __forceinline__ void load_factors(const mgx_columns &c, int64_t i, Gr
     if constexpr (F & F_GRID) { f.cp = c.co2_profile[i]; f.pat = c.tariff[i]; }
 }
 
+// element (row, profile column p) of a base table: public row-major [T, PP] layout (pm == 0) or the profile-major copy
+__device__ __forceinline__ int64_t base_index(int32_t pm, int64_t row, uint32_t p)
+{
+    return pm ? (int64_t)p * pm + row : row * PP + p;
+}
+
 // stored sign: load <= 0, pv >= 0 (base_timeseries_module.py:68-79); one multiply, as _scale_ts (:137-147)
 __device__ __forceinline__ double fact_load(double base, double ratio) { return -1.0 * fabs(base * ratio); }
 __device__ __forceinline__ double fact_pv(double base, double ratio) { return fabs(base * ratio); }
@@ -266,29 +276,30 @@ __device__ __forceinline__ double fact_status(const mgx_columns &c, int64_t N, i
 
 // the series part of a step's inputs, formed from the factors (global-memory form: base rows out of the caches)
 template <int F>
-__device__ __forceinline__ void fact_series(const mgx_columns &c, int64_t N, int64_t i, int64_t row, const GridFactors &f, Inputs &in)
+__device__ __forceinline__ void fact_series(const mgx_columns &c, int64_t N, int64_t i, int64_t row, const GridFactors &f, Inputs &in,
+                                            int32_t pm = 0)
 {
-    in.load = fact_load(c.base_load[row * PP + f.lp], f.lr);
-    in.pv = fact_pv(c.base_pv[row * PP + f.pp], f.pr);
+    in.load = fact_load(c.base_load[base_index(pm, row, f.lp)], f.lr);
+    in.pv = fact_pv(c.base_pv[base_index(pm, row, f.pp)], f.pr);
     in.g_stat = 1.0;
     if constexpr (F & F_GRID) {
         in.g_pimp = tariff_price((int32_t)f.pat, (int32_t)row); in.g_pexp = 0.0;
-        in.g_co2 = c.base_co2[row * PP + f.cp];
+        in.g_co2 = c.base_co2[base_index(pm, row, f.cp)];
         in.g_stat = fact_status(c, N, i, row);
     }
 }
 
 // Component `comp` (0 load, 1 pv, 2..5 grid: import price, export price, co2 per kWh, status) of grid i at series row `row`,
 // whichever way the batch holds its series.  For the kernels off the hot path (window patches, episode gathers).
-__device__ __forceinline__ double series_component(const mgx_columns &c, int64_t N, int comp, int64_t row, int64_t i)
+__device__ __forceinline__ double series_component(const mgx_columns &c, int64_t N, int comp, int64_t row, int64_t i, int32_t pm = 0)
 {
     if (factorised(c)) {
         switch (comp) {
-            case 0: return fact_load(c.base_load[row * PP + c.load_profile[i]], c.load_ratio[i]);
-            case 1: return fact_pv(c.base_pv[row * PP + c.pv_profile[i]], c.pv_ratio[i]);
+            case 0: return fact_load(c.base_load[base_index(pm, row, c.load_profile[i])], c.load_ratio[i]);
+            case 1: return fact_pv(c.base_pv[base_index(pm, row, c.pv_profile[i])], c.pv_ratio[i]);
             case 2: return tariff_price((int32_t)c.tariff[i], (int32_t)row);
             case 3: return 0.0;
-            case 4: return c.base_co2[row * PP + c.co2_profile[i]];
+            case 4: return c.base_co2[base_index(pm, row, c.co2_profile[i])];
             default: return fact_status(c, N, i, row);
         }
     }
@@ -361,7 +372,7 @@ __device__ __forceinline__ void store_state(const mgx_columns &c, int64_t i, con
 // actions row [A] of grid i at `act` (row-major [N, A]); series rows at time t
 template <int F, typename AT>
 __device__ __forceinline__ void load_inputs(const mgx_columns &c, const AT *__restrict__ act,
-                                            int64_t N, int64_t i, int64_t t, Inputs &in)
+                                            int64_t N, int64_t i, int64_t t, Inputs &in, int32_t pm = 0)
 {
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
     const AT *a = act + i * A;
@@ -372,7 +383,7 @@ __device__ __forceinline__ void load_inputs(const mgx_columns &c, const AT *__re
     if (factorised(c)) {                       // uniform over the launch
         GridFactors f;
         load_factors<F>(c, i, f);
-        fact_series<F>(c, N, i, t, f, in);
+        fact_series<F>(c, N, i, t, f, in, pm);
         return;
     }
     in.load = c.load_ts[t * N + i];
@@ -780,12 +791,12 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
     const int64_t tr = t & a.row_mask;                  // row of the series buffers (rolling windows: a ring)
     {
         const double lo = c.load_lo[i], hi = c.load_hi[i];
-        const double v = in ? series_component(c, N, 0, tr, i) : 0.0;
+        const double v = in ? series_component(c, N, 0, tr, i, a.pm_pitch) : 0.0;
         obs_row[a.col_load] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     {
         const double lo = c.pv_lo[i], hi = c.pv_hi[i];
-        const double v = in ? series_component(c, N, 1, tr, i) : 0.0;
+        const double v = in ? series_component(c, N, 1, tr, i, a.pm_pitch) : 0.0;
         obs_row[a.col_pv] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     observe_state_cols<F, OT>(a, p, s, obs_row);
@@ -794,7 +805,7 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
             const double lo = c.grid_lo[cc * N + i], hi = c.grid_hi[cc * N + i];
-            const double v = in ? series_component(c, N, 2 + cc, tr, i) : 0.0;
+            const double v = in ? series_component(c, N, 2 + cc, tr, i, a.pm_pitch) : 0.0;
             obs_row[k + cc] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
         }
     }

@@ -86,8 +86,9 @@ __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict
     int32_t off = 0;
     if constexpr (EP) off = a.ep_off[i];
     const int64_t row = EP ? (int64_t)t + off : (int64_t)(t & a.row_mask);
-    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, row, in);
-    else load_inputs<F>(a.c, (const double *)actions, a.N, i, row, in);
+    const int32_t pm = EP ? a.pm_pitch : 0;
+    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, row, in, pm);
+    else load_inputs<F>(a.c, (const double *)actions, a.N, i, row, in, pm);
     load_state<F>(a.c, i, log != nullptr, s);
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
@@ -133,8 +134,8 @@ __global__ __launch_bounds__(BLOCK) void check_kernel(const KArgs a, const void 
     load_params<F>(a.c, i, p);
     derive<F>(p, d);
     const int64_t row = series_row(a, i, t);
-    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, row, in);
-    else load_inputs<F>(a.c, (const double *)actions, a.N, i, row, in);
+    if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, row, in, a.pm_pitch);
+    else load_inputs<F>(a.c, (const double *)actions, a.N, i, row, in, a.pm_pitch);
     step_core<F>(p, d, s, in, normalized != 0, false, false, o);
     violations[i] = o.violations;
 }
@@ -546,14 +547,15 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
         load_factors<F>(a.c, ic, f);
         const mgx_columns &c = a.c;
         const int32_t ti = t + (a.ep_off ? a.ep_off[ic] : 0);         // in-place episodes: the grid's own series row
-        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return fact_load(c.base_load[(int64_t)r * PP + f.lp], f.lr); }, N,
+        const int32_t pm = a.pm_pitch;
+        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return fact_load(c.base_load[base_index(pm, r, f.lp)], f.lr); }, N,
                                           a.c.load_lo, a.c.load_hi, a.T, ti, W, i, ic, q, Q, row + a.col_load, a.c.load_noise_std, 0u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
-        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return fact_pv(c.base_pv[(int64_t)r * PP + f.pp], f.pr); }, N,
+        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return fact_pv(c.base_pv[base_index(pm, r, f.pp)], f.pr); }, N,
                                           a.c.pv_lo, a.c.pv_hi, a.T, ti, W, i, ic, q, Q, row + a.col_pv, a.c.pv_noise_std, 1u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
         if constexpr (F & F_GRID)
-            observe_window_cols<4, NOISE, OT>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic); }, N,
+            observe_window_cols<4, NOISE, OT>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic, pm); }, N,
                                               a.c.grid_lo, a.c.grid_hi, a.T, ti, W, i, ic, q, Q, row + a.col_grid,
                                               a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
     } else {
@@ -706,12 +708,13 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         load_factors<GRID ? F_GRID : 0>(a.c, ic, f);
         const mgx_columns &c = a.c;
         const int32_t ti = t + (a.ep_off ? a.ep_off[ic] : 0);          // in-place episodes: the grid's own series row
-        windows_k_module<1>([&](int32_t r, int) { return fact_load(c.base_load[(int64_t)r * PP + f.lp], f.lr); }, N,
+        const int32_t pm = a.pm_pitch;
+        windows_k_module<1>([&](int32_t r, int) { return fact_load(c.base_load[base_index(pm, r, f.lp)], f.lr); }, N,
                             a.c.load_lo, a.c.load_hi, a.T, ti, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
-        windows_k_module<1>([&](int32_t r, int) { return fact_pv(c.base_pv[(int64_t)r * PP + f.pp], f.pr); }, N,
+        windows_k_module<1>([&](int32_t r, int) { return fact_pv(c.base_pv[base_index(pm, r, f.pp)], f.pr); }, N,
                             a.c.pv_lo, a.c.pv_hi, a.T, ti, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
         if constexpr (GRID)
-            windows_k_module<4>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic); }, N,
+            windows_k_module<4>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic, pm); }, N,
                                 a.c.grid_lo, a.c.grid_hi, a.T, ti, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
     } else {
         const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(64) void patch_windows_kernel(const KArgs a, const 
             else { lo = a.c.grid_lo[(comp - 2) * N + g]; hi = a.c.grid_hi[(comp - 2) * N + g]; }
             const int32_t row = t + r + (a.ep_off ? a.ep_off[g] : 0);      // in-place episodes: the grid's own series row
             const bool in = row < a.T;
-            const double v = series_component(a.c, N, comp, (int64_t)((in ? row : a.T - 1) & a.row_mask), g);
+            const double v = series_component(a.c, N, comp, (int64_t)((in ? row : a.T - 1) & a.row_mask), g, a.pm_pitch);
             const double fill = (hi + lo) / 2, sp = space_spread(lo, hi);
             nu[idx] = obs_series_value(v, in, false, lo, hi, fill, sp);
             nc[idx] = obs_series_value(v, in, true, lo, hi, fill, sp);
@@ -873,7 +876,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
     if (factorised(a.c)) {
         GridFactors f;
         load_factors<F>(a.c, i, f);
-        fact_series<F>(a.c, N, i, tr, f, in);
+        fact_series<F>(a.c, N, i, tr, f, in, a.pm_pitch);
     } else {
         in.load = a.c.load_ts[tr * N + i];
         in.pv = a.c.pv_ts[tr * N + i];
@@ -922,7 +925,7 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     if (factorised(a.c)) {
         GridFactors f;
         load_factors<F>(a.c, i, f);
-        fact_series<F>(a.c, N, i, tr, f, in);
+        fact_series<F>(a.c, N, i, tr, f, in, EP ? a.pm_pitch : 0);
     } else {
         load_series_at<F>(a.c.load_ts + tr * N, a.c.pv_ts + tr * N, (F & F_GRID) ? a.c.grid_ts + tr * 4 * N : nullptr, N, i, i, in);
     }
@@ -1527,6 +1530,16 @@ static __global__ __launch_bounds__(BLOCK) void colsum_stage2(const double *__re
 // need no per-grid series length.  One lane per grid: its reads are one line per row (once per episode), the writes
 // are coalesced.
 // ------------------------------------------------------------------------------------------------------
+// [T, PP] base table -> profile-major [PP, pitch] (mgx_reset_episodes: in-place episodes read one row per lane)
+static __global__ __launch_bounds__(BLOCK) void profile_major_kernel(const double *__restrict__ src, double *__restrict__ dst,
+                                                                     int32_t T, int32_t pitch)
+{
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;          // element of the destination
+    if (e >= (int64_t)PP * pitch) return;
+    const int32_t p = (int32_t)(e / pitch), row = (int32_t)(e - (int64_t)p * pitch);
+    dst[e] = row < T ? src[(int64_t)row * PP + p] : 0.0;
+}
+
 struct GatherArgs {
     const double *load_ts, *pv_ts, *grid_ts;
     const double *load_lo, *load_hi, *pv_lo, *pv_hi, *grid_lo, *grid_hi;
