@@ -321,9 +321,9 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
                          f"bucket on the engines' prefetch streams, beside the following step launches); bytes and time are per "
                          f"fleet step, refills included" if contract == "rows" else
                          "; the window columns are views of the once-normalised series (no bytes per step), the step writes the "
-                         "6 state columns.  From Python this contract is HOST-bound (the GPU idles between launches: the kernel "
-                         "itself takes 8.7 us per fleet step, profiles/r03/fleet_views_kernel_stats.csv), so avg_launch_us here is "
-                         "the host's pace, views taken by the caller every step included"))
+                         "6 state columns.  From Python this contract is HOST-paced (the kernel itself takes 8.7 us per fleet step, "
+                         "profiles/r03/fleet_views_kernel_stats.csv): avg_launch_us is the host's pace with the caller taking all "
+                         "window views at every step (memoised per step index: a loop over the same rows builds each view once)"))
             out[name] = {"value": 3 * per * world * steps / wall, "us_per_step": wall / steps * 1e6,
                          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                       "frac_wall": alg / (wall / steps) / 1e9 / HBM_PEAK_GBS,
