@@ -200,8 +200,7 @@ def sample_device_state(out, delay_s=0.12):
                                  timeout=10)
             txt = res.stdout[res.stdout.index("{"):]
             cards = json.loads(txt)
-            idx = torch.cuda.current_device() if False else 0
-            card = cards.get(f"card{idx}") or next(iter(cards.values()))
+            card = next(iter(cards.values()))              # (a rank sees its own GPU only when the launcher isolates devices)
             out.update({k.rstrip(":"): v for k, v in card.items()})
         except Exception as e:          # noqa: BLE001  (diagnostics only)
             out["error"] = f"{type(e).__name__}: {e}"

@@ -395,7 +395,6 @@ class BatchedMicrogridEnv:
             raise RuntimeError("this env belongs to a fused BucketedFleet (its step plans hold the ring pointers): the ring "
                                "depth is fixed; build the fleet with the obs_prefetch you want")
         self.obs_prefetch = K
-        L = self.layout
         if self._rings is not None:
             # a prefetch may still be writing the old rings on the engine's prefetch stream, which the caching allocator knows
             # nothing about: the caller's stream waits for it before the memory can be handed out again

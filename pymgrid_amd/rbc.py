@@ -178,7 +178,6 @@ class RuleBasedControl:
         until ``done`` (the end of the CURRENT episode window) or for ``max_steps`` steps.  The reference works on a deep
         copy of the microgrid; here the batch itself is stepped unless ``restore_state=True`` puts battery charge / SoC and
         genset status back afterwards."""
-        L = self.layout
         self.env.reset()
         lo, hi = self.engine.window                       # the window the reset has just installed
         total = hi - lo                                   # done fires at counter hi - 1: hi - lo steps in all
