@@ -5,6 +5,7 @@ bit-exact (==) on every fp64 output: reward, SoC / charge, genset status, log co
 controls.  (BASELINE.json asks for 1e-6 relative; the engine keeps the reference's operation order and disables
 FMA contraction, so equality is the bar here.)"""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -413,7 +414,7 @@ def test_randomized_differential_degenerate_parameters(arch, device, oracle):
     steps, device == oracle bit for bit."""
     from pymgrid_amd import BatchLayout, MicrogridBatch, StepEngine, pack_status
     from pymgrid_amd.batch import pack_times
-    rs = np.random.RandomState(99)
+    rs = np.random.RandomState(int(os.environ.get("MGX_FUZZ_SEED", "99")))     # (soak runs: for s in ...; MGX_FUZZ_SEED=$s pytest -k degenerate)
     N, T, K = 20_000, 50, 48
     has_grid = "grid" in arch
 
