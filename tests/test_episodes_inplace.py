@@ -3,18 +3,22 @@ episodes on the series themselves -- no window buffers, a restart rewrites two w
 restarts the grids it finishes.  Pinned three ways: against the CPU oracle on per-grid shifted series, against the rolling window
 buffers (mgx_reset_windows_rolling, itself pinned against per-grid oracle microgrids in test_abi_v3.py) step by step through
 restarts, and PerGridWindowEnv(native=True) against PerGridWindowEnv(native=False) with the same device draws."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+SOAK = int(os.environ.get("MGX_FUZZ_SEED", "0"))          # soak runs: another draw of every batch / episode / action sequence
 
 ARCHS = ("genset+battery", "battery+grid", "genset+battery+grid")
 
 
 def _gen(n, T, arch, device, H=0, seed=9, **kw):
     from pymgrid_amd.generator import generate
-    return generate(n, n_steps=T, seed=seed, arch=arch, device=device, horizon=H, mixed_timers=True, series="factorised", **kw)
+    return generate(n, n_steps=T, seed=seed + 1000 * SOAK, arch=arch, device=device, horizon=H, mixed_timers=True,
+                    series="factorised", **kw)
 
 
 @pytest.mark.parametrize("arch", ARCHS)
@@ -26,7 +30,7 @@ def test_inplace_episodes_vs_the_oracle_on_shifted_series(arch, device, oracle):
     b = _gen(N, T, arch, device, seed=31)
     cols = b.numpy_columns()
     st = {k: cols[k].copy() for k in ("charge", "soc", "gen_status") if k in cols}
-    rs = np.random.RandomState(3)
+    rs = np.random.RandomState(3 + SOAK)
     starts = rs.randint(0, T - L + 1, size=N).astype(np.int32)
     starts[:4] = (0, T - L, 1, T - L - 1)
     rows = starts[None, :] + np.arange(L)[:, None]                                # [L, N]
@@ -36,7 +40,7 @@ def test_inplace_episodes_vs_the_oracle_on_shifted_series(arch, device, oracle):
     shifted["pv_ts"] = np.ascontiguousarray(np.take_along_axis(cols["pv_ts"], rows, 0))
     if "grid_ts" in cols and cols["grid_ts"] is not None:
         shifted["grid_ts"] = np.ascontiguousarray(np.take_along_axis(cols["grid_ts"], rows[:, None, :].repeat(4, 1), 0))
-    g = torch.Generator(device=device); g.manual_seed(5)
+    g = torch.Generator(device=device); g.manual_seed(5 + SOAK)
     acts = torch.rand(L, N, b.layout.action_dim, dtype=torch.float64, device=device, generator=g)
     e = StepEngine(b)
     e.reset_episodes(torch.from_numpy(starts).to(device), None, L, want_obs=False)
@@ -66,14 +70,14 @@ def test_inplace_episodes_equal_rolling_windows_through_restarts(arch, H, discre
     kw = dict(remove_redundant_gensets=False) if discrete else {}
     ring = cls(_gen(N, T, arch, device, H), obs_prefetch=0, **kw)               # window buffers, per-step rows: the plain path
     inpl = cls(_gen(N, T, arch, device, H), obs_prefetch=prefetch, **kw)        # in place; prefetch > 0: rings + mgx_patch_windows
-    rs = np.random.RandomState(8)
+    rs = np.random.RandomState(8 + SOAK)
     lengths = rs.randint(1, max_len + 1, size=N).astype(np.int32)
     starts = np.array([rs.randint(0, T - n + 1) for n in lengths], dtype=np.int32)
     starts[:3] = T - lengths[:3]                                                # ... ending at the very end of the series
     o1 = ring.reset_windows(starts, lengths, max_length=max_len, rolling=True)
     o2 = inpl.reset_windows(starts, lengths, max_length=max_len, rolling="inplace")
     assert torch.equal(o1, o2) and inpl.obs_prefetch == prefetch and inpl._sync_rings == (prefetch > 0)
-    g = torch.Generator(device=device); g.manual_seed(1)
+    g = torch.Generator(device=device); g.manual_seed(1 + SOAK)
     for k in range(3 * max_len + 5):
         a = (torch.randint(0, ring.action_space.n, (N,), dtype=torch.int32, device=device, generator=g) if discrete
              else torch.rand(N, ring.layout.action_dim, dtype=torch.float64, device=device, generator=g))
@@ -120,14 +124,14 @@ def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discret
                            reuse_outputs=(3 if H in (0, 3) else 0), **kw)                         # (rotating reward / done / row buffers)
     assert nat.native and not roll.native
     lengths = None
-    rs = np.random.RandomState(2)
+    rs = np.random.RandomState(2 + SOAK)
     if length is None:
         lengths = rs.randint(1, 30, size=N).astype(np.int32)
         starts = np.array([rs.randint(0, T - n + 1) for n in lengths], dtype=np.int32)
     else:
         starts = rs.randint(0, T - length + 1, size=N).astype(np.int32)
     assert torch.equal(roll.reset(starts, lengths), nat.reset(starts, lengths))
-    g = torch.Generator(device=device); g.manual_seed(1)
+    g = torch.Generator(device=device); g.manual_seed(1 + SOAK)
     n_done = 0
     for k in range(70):
         a = (torch.randint(0, roll.action_space.n, (N,), dtype=torch.int32, device=device, generator=g) if discrete
@@ -180,7 +184,7 @@ def test_native_auto_reset_at_the_true_shape_of_configs2(device):
     roll = PerGridWindowEnv(_gen(N, T, "genset+battery", device, seed=42), native=False, **kw)
     nat = PerGridWindowEnv(_gen(N, T, "genset+battery", device, seed=42), **kw)
     assert nat.native
-    g = torch.Generator(device=device); g.manual_seed(3)
+    g = torch.Generator(device=device); g.manual_seed(3 + SOAK)
     st = torch.randint(0, T - 168, (N,), dtype=torch.int32, device=device, generator=g)
     st[:3] = torch.tensor([0, T - 168, T - 169], dtype=torch.int32)
     # staggered first episodes, so that restarts happen at every step
@@ -209,8 +213,8 @@ def test_mode_changes_leave_nothing_behind(device):
     N, T, H = 900, 160, 3
     a_env = BatchedMicrogridEnv(_gen(N, T, "genset+battery+grid", device, H), obs_prefetch=0)
     b_env = BatchedMicrogridEnv(_gen(N, T, "genset+battery+grid", device, H), obs_prefetch=0)
-    rs = np.random.RandomState(4)
-    g = torch.Generator(device=device); g.manual_seed(6)
+    rs = np.random.RandomState(4 + SOAK)
+    g = torch.Generator(device=device); g.manual_seed(6 + SOAK)
 
     def steps(n, restart=None):
         for k in range(n):
@@ -292,14 +296,14 @@ def test_native_auto_reset_at_the_edges(length, H, prefetch, device):
     kw = dict(auto_reset=True, final_observation=True, seed=8, trajectory_length=length)
     roll = PerGridWindowEnv(_gen(N, T, "genset+battery+grid", device, H), native=False, obs_prefetch=0, **kw)
     nat = PerGridWindowEnv(_gen(N, T, "genset+battery+grid", device, H), native=True, obs_prefetch=prefetch, **kw)
-    rs = np.random.RandomState(1)
+    rs = np.random.RandomState(1 + SOAK)
     if length is None:
         lengths = rs.randint(1, T + 1, size=N).astype(np.int32)
         starts = np.array([rs.randint(0, T - n + 1) for n in lengths], dtype=np.int32)
     else:
         lengths, starts = None, rs.randint(0, T - length + 1, size=N).astype(np.int32)
     assert torch.equal(roll.reset(starts, lengths), nat.reset(starts, lengths))
-    g = torch.Generator(device=device); g.manual_seed(2)
+    g = torch.Generator(device=device); g.manual_seed(2 + SOAK)
     for k in range(3 * T):
         a = torch.rand(N, 4, dtype=torch.float64, device=device, generator=g)
         o1, r1, d1, i1 = roll.step(a)
