@@ -170,7 +170,8 @@ class Runner:
 
     def kernel_durations_us(self, fn, rounds=16):
         """Mean start-to-end time of the kernels of a round (HIP events around every launch on its own stream, a short
-        extra pass after the timed region): what rocprofv3 reports as the kernel's duration."""
+        extra pass after the timed region; launches outside [0.5, 2] x the median are left out): what rocprofv3 reports as the
+        kernel's duration."""
         dev = self.eng.device
         streams = self.streams or [torch.cuda.current_stream(dev)]
         ev = []
@@ -185,7 +186,10 @@ class Runner:
             ev += pair
         self.eng.join()
         torch.cuda.synchronize(dev)
-        return sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev) * 1e3
+        d = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+        med = d[len(d) // 2]
+        kept = [x for x in d if 0.5 * med <= x <= 2.0 * med]      # a stalled launch (a 70 ms hiccup was seen once) is not the kernel
+        return sum(kept) / len(kept) * 1e3
 
 
 def sample_device_state(out, delay_s=0.12):

@@ -4,8 +4,11 @@ The HIP library is the only compute path: if it is missing or no GPU is visible 
 no CPU fallback (the CPU oracle under ``oracle/`` is test infrastructure and is never imported from here).
 """
 import ctypes as C
+import json
 import os
+import re
 import subprocess
+import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
@@ -181,16 +184,28 @@ def _build(LIB_PATH, extra_defs, verbose, objtag, force=True):
                     [(SOURCES[1], [f"-DMGX_FUSED_PART={p}"], os.path.join(objdir, f"mgx_fused_{p}.o")) for p in range(FUSED_PARTS)]
             procs = []
             for src, defs, obj in units:
-                cmd = [hipcc] + HIPCC_FLAGS + defs + extra_defs + ["-c", src, "-o", obj]
+                # -Rpass-analysis=kernel-resource-usage: the backend's per-kernel register / scratch figures as remarks (free):
+                # kept in <objdir>/resource_usage.json -- a hot kernel that starts using scratch memory costs launch time
+                # (24 B of private segment in the single-step kernels once cost 0.4-1 us per launch: NOTES.md)
+                cmd = [hipcc] + HIPCC_FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + defs + extra_defs + ["-c", src, "-o", obj]
                 if verbose:
                     print(" ".join(cmd))
-                procs.append((cmd, subprocess.Popen(cmd)))
+                procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+            usage = {}
             for cmd, p in procs:
-                if p.wait() != 0:
+                _, err = p.communicate()
+                if p.returncode != 0:
+                    sys.stderr.write(err)
                     for _, q in procs:
                         if q.poll() is None:
                             q.kill()
                     raise subprocess.CalledProcessError(p.returncode, cmd)
+                usage.update(_parse_resource_usage(err))
+                rest = "\n".join(ln for ln in err.splitlines() if "kernel-resource-usage" not in ln and not _REMARK_ECHO.match(ln))
+                if rest.strip() and verbose:
+                    sys.stderr.write(rest + "\n")
+            with open(os.path.join(objdir, "resource_usage.json"), "w") as fh:
+                json.dump(usage, fh, indent=0, sort_keys=True)
             link = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + [obj for _, _, obj in units] + ["-o", tmp]
             if verbose:
                 print(" ".join(link))
@@ -199,6 +214,44 @@ def _build(LIB_PATH, extra_defs, verbose, objtag, force=True):
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
+
+
+_REMARK_ECHO = re.compile(r"^\s*(\d+ \||\||In file included from)")     # the source echo under each remark
+
+
+def _parse_resource_usage(stderr_text):
+    """{demangled kernel name: {"vgpr", "sgpr", "scratch", "lds"}} out of hipcc's kernel-resource-usage remarks."""
+    out, cur = {}, None
+    for ln in stderr_text.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", ln)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        for key, pat in (("sgpr", r"TotalSGPRs: (\d+)"), ("vgpr", r"remark:\s+VGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+            m = re.search(pat, ln)
+            if m:
+                cur[key] = int(m.group(1))
+    if out:
+        try:
+            names = list(out)
+            dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+            out = {(d.split("(")[0].replace("void ", "") or n): out[n] for n, d in zip(names, dem)}
+        except OSError:
+            pass
+    return out
+
+
+def resource_usage():
+    """The per-kernel resource figures of the last build on this machine (None when the library was built elsewhere)."""
+    f = os.path.join(_PKG, "csrc", "_build", "resource_usage.json")
+    try:
+        with open(f) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
 
 
 _lib = None

@@ -388,6 +388,8 @@ __device__ __forceinline__ void load_inputs(const mgx_columns &c, const AT *__re
     }
     in.load = c.load_ts[t * N + i];
     in.pv = c.pv_ts[t * N + i];
+    in.g_stat = 1.0;       // (the same fields are written on both paths: an asymmetric store was sunk behind a selected ADDRESS by
+                           //  the optimiser once, which kept `in` in scratch memory -- 24 B of private segment, +0.4 us per launch)
     if constexpr (F & F_GRID) {
         const double *g = c.grid_ts + (t * 4) * N + i;
         in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
@@ -783,7 +785,7 @@ __device__ __forceinline__ void observe_state_cols(const KArgs &a, const Params 
 // H == 0 (no forecaster): the whole row is 2 + 6 (+4) values -- the owning lane stores them directly
 template <int F, typename OT>
 __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_t t, const Params &p, const State &s,
-                                               OT *__restrict__ obs_row)
+                                               OT *__restrict__ obs_row, int32_t pm = 0)
 {
     const mgx_columns &c = a.c;
     const int64_t N = a.N;
@@ -791,12 +793,12 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
     const int64_t tr = t & a.row_mask;                  // row of the series buffers (rolling windows: a ring)
     {
         const double lo = c.load_lo[i], hi = c.load_hi[i];
-        const double v = in ? series_component(c, N, 0, tr, i, a.pm_pitch) : 0.0;
+        const double v = in ? series_component(c, N, 0, tr, i, pm) : 0.0;
         obs_row[a.col_load] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     {
         const double lo = c.pv_lo[i], hi = c.pv_hi[i];
-        const double v = in ? series_component(c, N, 1, tr, i, a.pm_pitch) : 0.0;
+        const double v = in ? series_component(c, N, 1, tr, i, pm) : 0.0;
         obs_row[a.col_pv] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
     }
     observe_state_cols<F, OT>(a, p, s, obs_row);
@@ -805,7 +807,7 @@ __device__ __forceinline__ void observe_row_h0(const KArgs &a, int64_t i, int32_
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
             const double lo = c.grid_lo[cc * N + i], hi = c.grid_hi[cc * N + i];
-            const double v = in ? series_component(c, N, 2 + cc, tr, i, a.pm_pitch) : 0.0;
+            const double v = in ? series_component(c, N, 2 + cc, tr, i, pm) : 0.0;
             obs_row[k + cc] = (OT)obs_series_value(v, in, false, lo, hi, (hi + lo) / 2, space_spread(lo, hi));
         }
     }

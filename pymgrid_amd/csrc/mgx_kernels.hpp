@@ -40,7 +40,7 @@ constexpr int BLOCK_K = MGX_BLOCK_K;
 // forecaster -- the whole 8..12-value row
 template <int F>
 __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict__ obs, int64_t i, int32_t t_next, const Params &p,
-                                               const State &s)
+                                               const State &s, int32_t pm = 0)     // pm: KArgs.pm_pitch during in-place episodes
 {
     constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
     if (a.obs_state_only == 2) {            // MGX_OBS_ROWS_STATE_COMPACT
@@ -49,8 +49,8 @@ __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict_
     } else if (a.obs_state_only) {          // the window columns of this row were prefetched (obs_windows_k_kernel)
         if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
         else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
-    } else if (a.obs_f32) observe_row_h0<F>(a, i, t_next, p, s, (float *)obs + i * a.obs_dim);
-    else observe_row_h0<F>(a, i, t_next, p, s, (double *)obs + i * a.obs_dim);
+    } else if (a.obs_f32) observe_row_h0<F>(a, i, t_next, p, s, (float *)obs + i * a.obs_dim, pm);
+    else observe_row_h0<F>(a, i, t_next, p, s, (double *)obs + i * a.obs_dim, pm);
 }
 
 // In-place episodes (KArgs.ep_off): what a step adds once the grid's own step is done -- the observation before a restart
@@ -59,7 +59,7 @@ __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict_
 template <int F>
 __device__ __forceinline__ int32_t episode_tail(const KArgs &a, int64_t i, int32_t t, int32_t off, bool dn, const Params &p, const State &s)
 {
-    if (a.final_obs && a.obs_state_only != 1) store_step_obs<F>(a, a.final_obs, i, t + 1 + off, p, s);   // (rings: mgx_patch_windows saves it)
+    if (a.final_obs && a.obs_state_only != 1) store_step_obs<F>(a, a.final_obs, i, t + 1 + off, p, s, a.pm_pitch);   // (rings: mgx_patch_windows saves it)
     if (a.ar_mode && dn) {
         int32_t s0, len;
         episode_draw(a.ar_seed, i, t + 1, a.ar_fixed_length, a.ar_lo, a.ar_hi, s0, len);
@@ -105,7 +105,7 @@ __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict
     if constexpr (EP) off = episode_tail<F>(a, i, t, off, dn != 0, p, s);
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
     // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
-    if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s);
+    if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, pm);
 }
 
 template <int F, bool EP = false>
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const KArgs a, int32_t t
     Params p; State s;
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
-    store_step_obs<F>(a, obs, i, t + (a.ep_off ? a.ep_off[i] : 0), p, s);            // whole rows for H == 0 only (the host dispatches)
+    store_step_obs<F>(a, obs, i, t + (a.ep_off ? a.ep_off[i] : 0), p, s, a.pm_pitch);   // whole rows for H == 0 only (the host dispatches)
 }
 
 // Observation rows for H > 0 (obs_rows_wave_kernel below).  Every cache line of obs is written whole by one wave
@@ -949,7 +949,7 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     if (done) done[i] = dn;
     if (log) store_log<F>(log + i, N, o, s.status);
     if constexpr (EP) off = episode_tail<F>(a, i, t, off, dn != 0, p, s);
-    if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s);
+    if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, EP ? a.pm_pitch : 0);
 }
 
 template <int F, bool EP = false>

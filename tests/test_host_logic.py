@@ -225,3 +225,24 @@ def test_episode_entry_points_refuse_null_handles_without_a_gpu():
     assert L.mgx_set_auto_reset(None, 1, 0, 0, None, None, None) == _lib.MGX_ERR_INVALID
     assert L.mgx_set_final_obs(None, None) == _lib.MGX_ERR_INVALID
     assert b"mgx_set_final_obs" in L.mgx_last_error()
+
+
+def test_hot_kernels_use_no_scratch_memory():
+    """The backend's per-kernel figures of the build (hipcc -Rpass-analysis=kernel-resource-usage, kept by _lib.build): only the
+    general multi-instance kernels (LDS lists + a per-lane stack) may use scratch memory.  A private segment on a stepping
+    kernel costs launch time: 24 B of it once slowed every single step by 0.4-1 us before anyone noticed."""
+    from pymgrid_amd import _lib
+    _lib.build()
+    usage = _lib.resource_usage()
+    if usage is None:
+        pytest.skip("libmgx.so was not built on this machine (no resource_usage.json beside the objects)")
+    hot = ("step_kernel", "step_discrete_kernel", "step_k_kernel", "rollout_kernel", "fleet_step_kernel", "observe_kernel",
+           "obs_rows_wave_kernel", "obs_windows_k_kernel", "patch_windows_kernel", "expand_kernel", "check_kernel",
+           "normalise_series_kernel", "gather_windows_kernel", "synthesize_series_kernel")
+    seen = 0
+    for name, u in usage.items():
+        base = name.split("<")[0].split("::")[-1]
+        if base in hot:
+            seen += 1
+            assert u.get("scratch", 0) == 0, (name, u)
+    assert seen > 50, seen                                  # every specialisation was looked at
