@@ -230,7 +230,7 @@ def _parse_resource_usage(stderr_text):
         if cur is None:
             continue
         for key, pat in (("sgpr", r"TotalSGPRs: (\d+)"), ("vgpr", r"remark:\s+VGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
-                         ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+                         ("lds", r"LDS Size \[bytes/block\]: (\d+)"), ("sgpr_spill", r"SGPRs Spill: (\d+)"), ("vgpr_spill", r"VGPRs Spill: (\d+)")):
             m = re.search(pat, ln)
             if m:
                 cur[key] = int(m.group(1))

@@ -244,5 +244,5 @@ def test_hot_kernels_use_no_scratch_memory():
         base = name.split("<")[0].split("::")[-1]
         if base in hot:
             seen += 1
-            assert u.get("scratch", 0) == 0, (name, u)
+            assert u.get("scratch", 0) == 0 and u.get("vgpr_spill", 0) == 0, (name, u)
     assert seen > 50, seen                                  # every specialisation was looked at
