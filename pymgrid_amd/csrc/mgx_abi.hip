@@ -858,14 +858,17 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
     if (!factorised(h->windowed ? h->full_c : h->k.c))
         return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: in-place episodes need factorised series (every lane reads its own row: "
                                          "[T, N] arrays would be gathered 8x over); use mgx_reset_windows_rolling");
+    {   // every argument is checked before the handle leaves the mode it is in
+        const int32_t lo = h->windowed ? h->full_window_lo : h->window_lo, hi = h->windowed ? h->full_window_hi : h->window_hi;
+        if (max_length < 1 || max_length > hi - lo)
+            return fail(MGX_ERR_INVALID, "Cannot create a trajectory of length %d between initial_step (%d) and final_step (%d)",
+                        max_length, lo, hi);
+    }
     if (h->prefetch_pending) { if (int rc = mgx_prefetch_wait(h, stream)) return rc; }
     leave_windows(h);                                   // back to the full (factorised) series, whatever mode the handle was in
     h->full_load_ts = h->k.c.load_ts; h->full_pv_ts = h->k.c.pv_ts; h->full_grid_ts = h->k.c.grid_ts;
     h->full_T = h->k.T; h->full_final = h->layout.final_step; h->full_initial = h->layout.initial_step;
     h->full_window_lo = h->window_lo; h->full_window_hi = h->window_hi;
-    if (max_length < 1 || max_length > h->full_window_hi - h->full_window_lo)
-        return fail(MGX_ERR_INVALID, "Cannot create a trajectory of length %d between initial_step (%d) and final_step (%d)",
-                    max_length, h->full_window_lo, h->full_window_hi);
     // profile-major copies of the base tables (1.7 MB for a year of hourly rows): in this mode every lane reads its own row
     {
         const int32_t pitch = h->full_T;
