@@ -153,6 +153,31 @@ int main()
     HIP_OK(hipStreamSynchronize(st));
     std::vector<double> r_fact((size_t)K * N);
     HIP_OK(hipMemcpy(r_fact.data(), d_reward, r_fact.size() * sizeof(double), hipMemcpyDeviceToHost));
+    // (5) per-grid episodes IN PLACE on the factorised batch (mgx_reset_episodes, ABI v6): grid i starts at its own row
+    // start_i = i % (T - KE + 1) and walks KE rows of its own series; single steps from the initial state again
+    const int KE = 6;
+    std::vector<int32_t> ep_start(N);
+    for (int i = 0; i < N; i++) ep_start[i] = i % (T - KE + 1);
+    int32_t *d_start = to_device(ep_start), *d_off = nullptr, *d_fin = nullptr;
+    uint8_t *d_edone = nullptr;
+    HIP_OK(hipMalloc((void **)&d_off, N * sizeof(int32_t)));
+    HIP_OK(hipMalloc((void **)&d_fin, N * sizeof(int32_t)));
+    HIP_OK(hipMalloc((void **)&d_edone, (size_t)KE * N));
+    HIP_OK(hipMemcpy(d_charge, charge.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_soc, soc.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_status, status.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    MGX_CALL(mgx_reset_episodes(h2, d_start, nullptr, KE, d_off, d_fin, nullptr, st));
+    for (int k = 0; k < KE; k++)
+        MGX_CALL(mgx_step(h2, d_actions + (size_t)k * N * A, 1, d_reward + (size_t)k * N, d_edone + (size_t)k * N, nullptr, nullptr, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::vector<double> r_ep((size_t)KE * N);
+    std::vector<uint8_t> done_ep((size_t)KE * N);
+    HIP_OK(hipMemcpy(r_ep.data(), d_reward, r_ep.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(done_ep.data(), d_edone, done_ep.size(), hipMemcpyDeviceToHost));
+    if (mgx_step_k(h2, d_actions, 2, 1, d_reward, nullptr, nullptr, nullptr, nullptr, nullptr, st) != MGX_ERR_UNSUPPORTED) {
+        fprintf(stderr, "fused launches must be refused during rolling episodes\n");
+        return 7;
+    }
     mgx_destroy(h2);
 
     // the oracle, one microgrid at a time
@@ -197,9 +222,24 @@ int main()
             if (orc_run(&g, &s, &a, 1, &o) != 0) { fprintf(stderr, "oracle refused step %d of grid %d (factorised)\n", k, i); return 6; }
             bad += o.reward != r_fact[(size_t)k * N + i];
         }
+        // ... and the in-place episode: the same microgrid started at its own row (the oracle's window = [start, start + KE))
+        g.final_step = ep_start[i] + KE;
+        memset(&s, 0, sizeof(s));
+        s.t = ep_start[i];
+        s.charge = charge[i]; s.soc = soc[i];
+        s.gen_cur = status[i] & 0xff; s.gen_goal = (status[i] >> 8) & 0xff; s.gen_up = (status[i] >> 16) & 0xff; s.gen_down = status[i] >> 24;
+        for (int k = 0; k < KE; k++) {
+            orc_action a;
+            memset(&a, 0, sizeof(a));
+            const double *row = actions.data() + ((size_t)k * N + i) * A;
+            a.genset[0] = row[0]; a.genset[1] = row[1]; a.battery = row[2];
+            orc_step_out o;
+            if (orc_run(&g, &s, &a, 1, &o) != 0) { fprintf(stderr, "oracle refused step %d of grid %d (episode)\n", k, i); return 6; }
+            bad += (o.reward != r_ep[(size_t)k * N + i]) + ((uint8_t)o.done != done_ep[(size_t)k * N + i]);
+        }
     }
     mgx_destroy(h);
-    printf("c-abi consumer: %d grids x %d steps, single steps, one fused launch and one fused launch on factorised series vs the "
-           "CPU oracle: %ld mismatches\n", N, K, bad);
+    printf("c-abi consumer: %d grids x %d steps, single steps, one fused launch, one fused launch on factorised series and in-place "
+           "per-grid episodes vs the CPU oracle: %ld mismatches\n", N, K, bad);
     return bad == 0 ? 0 : 1;
 }
