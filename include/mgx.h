@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 6
+#define MGX_ABI_VERSION 7
 
 enum mgx_status {
     MGX_OK = 0,
@@ -75,6 +75,31 @@ enum mgx_reward_shaper {
     MGX_SHAPER_PV_CURTAILMENT = 1,     /* PVCurtailmentShaper:    -curtailment                       */
     MGX_SHAPER_BATTERY_DISCHARGE = 2   /* BatteryDischargeShaper: (discharge - loss_load) / load     */
 };
+
+/* Bits of a violations mask (mgx_check_step, mgx_check_discrete, the `violations` outputs of mgx_expand_discrete /
+ * mgx_expand_lists, the last log column).  Bits 0-2: requests the reference refuses only with raise_errors=True
+ * (base_module.py:79-93,213-224,265-270).  Bits 3-8: states in which the reference ALWAYS gives up with an AssertionError /
+ * TypeError -- the device goes on with the clipped value (unspecified there); the mask is how a caller finds out. */
+enum mgx_violation_bit {
+    MGX_V_GENSET_RANGE = 1,        /* genset request outside [min_production, max_production] */
+    MGX_V_BATTERY_LIMIT = 2,       /* battery request above max_production / max_consumption */
+    MGX_V_GRID_LIMIT = 4,          /* grid request above max import / export */
+    MGX_V_GENSET_GOAL = 8,         /* genset goal_status outside [0, 1] (`assert`, genset_module.py:146-147) */
+    MGX_V_GENSET_NEGATIVE = 16,    /* negative genset energy: a pure source asked to absorb */
+    MGX_V_NEGATIVE_LIMIT = 32,     /* a battery / grid acting at a NEGATIVE limit: asked to absorb while its max_consumption is
+                                    * negative -- `assert absorbed_energy >= 0` (base_module.py:272), a lossy battery whose charge
+                                    * was rounded one ulp above max_capacity -- or to produce (even 0.0) while its max_production
+                                    * is negative -- `assert internal_energy_change <= 0` (battery_module.py:114), a battery
+                                    * below min_capacity */
+    MGX_V_EXPAND_CONSUME = 64,     /* discrete expansion: `assert module_max_consumption >= 0` (priority_list.py:124), the same
+                                    * battery state met by _consume_in_module with load left to absorb */
+    MGX_V_EXPAND_PRODUCE = 128,    /* discrete expansion: `assert module_production >= 0` (priority_list.py:154): a module whose
+                                    * max_production is negative (a battery below min_capacity) is asked to produce */
+    MGX_V_EXPAND_SIGN = 256        /* discrete expansion: `assert total_load >= 0 and renewable >= 0` / `assert remaining_load
+                                    * <= 0.0` (priority_list.py:73,121): series of the wrong sign, NaN */
+};
+/* The expansion bits are exclusive: the reference stops at the first assert that fails on its way down the priority list,
+ * and the mask names that one. */
 
 typedef struct mgx_handle mgx_handle;
 typedef void *mgx_stream;     /* hipStream_t */
@@ -168,7 +193,8 @@ typedef struct mgx_columns {
      * -- bit-identical to the arrays mgx_synthesize_series writes.  The [T, N] series (16 of the 57 B a fused env-step of a
      * Template-4 grid streams; 14 GB per 100 000 grid-years) then never exist; the base tables (<= 560 KB each) stay in
      * the caches.  Base tables are [n_steps, MGX_PROFILE_PITCH] doubles (one 64-byte row per step, unused columns
-     * arbitrary), profile ids < MGX_PROFILE_PITCH.  outage_bits: [ceil(n_steps / 64), N] words, bit (t & 63) of word
+     * arbitrary), profile ids < MGX_PROFILE_PITCH and tariff in {0, 1, 2} -- a PRECONDITION the library cannot check (device
+     * pointers): an id beyond the pitch reads a neighbouring row / table.  outage_bits: [ceil(n_steps / 64), N] words, bit (t & 63) of word
      * t >> 6 set = grid_status 0 at row t; NULL = no outages.  Offered with one module of every kind per grid (the general
      * kernels read materialised series only). */
     const double *base_load, *base_pv, *base_co2;
@@ -270,7 +296,11 @@ int mgx_reset_grids_random(mgx_handle *h, const uint8_t *mask, uint64_t seed, in
  * words per grid instead of gathering rows.  Observation windows reach beyond an episode's end into the grid's series and
  * beyond the series' end into the forecaster's padding, exactly as in lock-step.  Single steps only (as for rolling windows);
  * observation rings work as they do there (mgx_observe_windows[_ahead] + mgx_patch_windows for the grids that restarted).
- * MGX_ERR_UNSUPPORTED for materialised [T, N] series (every lane would read its own row: 8x the traffic). */
+ * MGX_ERR_UNSUPPORTED for materialised [T, N] series (every lane would read its own row: 8x the traffic).
+ * A grid whose episode is over and that has not been restarted (auto-reset off, or a late mgx_reset_grids) keeps stepping on
+ * its own series; the shared counter has no end in this mode, so nothing refuses the step that would leave the series:
+ * from row n_steps on such a grid re-reads its LAST row (the step stays defined and finite; its observation windows show the
+ * forecaster's padding, as they do at the end of a series in lock-step). */
 int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length, int32_t *row_off,
                        int32_t *final_abs, void *obs, mgx_stream stream);
 /* Auto-reset inside the step (in-place episodes only): every single step restarts the grids whose episode it ends -- the
@@ -350,9 +380,13 @@ int mgx_set_done_format(mgx_handle *h, int32_t format);
  *     load_n, pv_n  [N, R]      R = n_steps + horizon + 1 (the observation after the last step, counter = n_steps, is all padding)
  *     grid_n        [N, R, 4]   (component-minor: the reference's window order falls out of a flat slice)
  * as float64 or float32 (the handle's obs format) so that the window of grid i at step t is the contiguous slice
- * load_n[i, t : t + 1 + H] -- a strided VIEW, no bytes moved per step.  Returns MGX_ERR_UNSUPPORTED when a bound column does
- * not bound its series (the clip would not be the identity) -- checked on device, reported through `clipped` (device int32[1],
- * incremented per offending value; may be NULL).  grid_n may be NULL without a GridModule. */
+ * load_n[i, t : t + 1 + H] -- a strided VIEW, no bytes moved per step.  The contract needs every bound column to bound its
+ * series (else the reference's forecast clip is not the identity and the views differ from its observations).  That is checked
+ * ON DEVICE, asynchronously: the call itself returns MGX_OK; `clipped` (device int32[1], zeroed by the caller) is incremented per
+ * offending value and must be read after the stream has synchronised -- a non-zero count means the views are NOT the
+ * reference's observations (pymgrid_amd refuses such a batch).  Passing NULL skips the check: only for series known to lie
+ * inside their bounds (e.g. bounds computed from the series, base_timeseries_module.py:81-88).  grid_n may be NULL without a
+ * GridModule. */
 int mgx_normalise_series(mgx_handle *h, void *load_n, void *pv_n, void *grid_n, int32_t *clipped, mgx_stream stream);
 
 /* The same prefetch AHEAD of the counter, overlapped with the steps: block k of `ring` = the window columns of counter
@@ -386,16 +420,18 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized,
 /* DiscreteMicrogridEnv._get_action -> PriorityListAlgo._populate_action (discrete.py:82-88,
  * priority_list.py:69-167): expand one priority-list id per grid into an UNNORMALISED control [N, A]
  * (feed it to mgx_step(..., normalized=0)).  `table` is a HOST array [n_actions, 3, 2] of
- * (module, action) pairs, module 0 genset / 1 battery / 2 grid, -1 = padding; n_actions <= 12. */
+ * (module, action) pairs, module 0 genset / 1 battery / 2 grid, -1 = padding; n_actions <= 12.
+ * violations [N] uint32 (device, may be NULL) receives, per grid, the assert the reference's _populate_action would have
+ * failed in this state (MGX_V_EXPAND_*; 0 = none): there the reference raises AssertionError and returns no control. */
 int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions,
-                        double *control, mgx_stream stream);
+                        double *control, uint32_t *violations, mgx_stream stream);
 
 /* The same for priority lists over module INSTANCES (microgrids with several gensets / batteries / grids:
  * get_priority_lists enumerates (module name, module number, action) elements, priority_list.py:15-67, and there can
  * be hundreds of lists): `lists` is a DEVICE array int32 [n_lists, list_len, 3] of (kind, instance, action), kind
  * 0 genset / 1 battery / 2 grid, kind -1 = padding.  Works for every layout. */
 int mgx_expand_lists(mgx_handle *h, const int32_t *action_id, const int32_t *lists, int32_t n_lists, int32_t list_len,
-                     double *control, mgx_stream stream);
+                     double *control, uint32_t *violations /* as in mgx_expand_discrete; may be NULL */, mgx_stream stream);
 
 /* K fused discrete steps with priority lists over module instances: the general-path counterpart of
  * mgx_rollout_discrete (`for a in ids: env.step(a)`, discrete.py:109-143, or RuleBasedControl.run with one fixed list
@@ -424,10 +460,18 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
  * clips; mgx_check_step is its DRY RUN -- the same arithmetic on a register copy of the state, nothing stored, the counter
  * untouched -- and writes per grid the mask of requests the reference would refuse: bit 0 genset request outside
  * [min, max] production, bit 1 battery request above max_production / max_consumption, bit 2 grid request above its
- * limit, bit 3 genset goal outside [0, 1], bit 4 negative genset energy.  A caller that wants raise_errors semantics
+ * limit, bit 3 genset goal outside [0, 1], bit 4 negative genset energy, bit 5 a battery / grid acting at a negative
+ * limit (enum mgx_violation_bit).  A caller that wants raise_errors semantics
  * checks first and steps only when every mask is 0 (the reference has by then already stepped the modules that come
  * before the refusing one in its sweep; here nothing is applied).  violations [N] uint32 (device). */
 int mgx_check_step(mgx_handle *h, const void *actions, int normalized, uint32_t *violations, mgx_stream stream);
+/* The dry run of mgx_step_discrete: DiscreteMicrogridEnv.step asserts its way through _populate_action
+ * (priority_list.py:73,121,124,135,154) and through the step (base_module.py:272) whatever raise_errors says.  violations [N]
+ * receives the expansion's assert bit where the reference would have raised inside _populate_action (MGX_V_EXPAND_*: it never
+ * steps then), else the mask mgx_check_step would give for the expanded control.  Nothing is stored, the counter does not
+ * move.  One module of every kind per grid (layouts with several: mgx_expand_lists with `violations`, then mgx_check_step). */
+int mgx_check_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions, uint32_t *violations,
+                       mgx_stream stream);
 
 /* K consecutive mgx_step calls issued by ONE call: the Gym cadence (`for a in actions: env.step(a)`, one kernel launch
  * per env-step, envs/base/base.py:169-209) without a host round trip per step -- from Python a per-step call costs
@@ -449,7 +493,10 @@ int mgx_step_many(mgx_handle *h, const void *actions, int32_t K, int normalized,
  * a stepping call must stay alive until the next mgx_join.  mgx_shard_stream returns the hipStream_t of a shard (for
  * timing events), NULL when shards are off.  Not offered in device-counter mode.  The shard streams are a per-device pool
  * shared by all handles of the process (the runtime multiplexes streams onto a few hardware queues: private pairs per handle
- * ended up on one queue): handles that step in shards at the same time are ordered per stream. */
+ * ended up on one queue): handles that step in shards at the same time are ordered per stream -- work of two handles on
+ * shard j runs in issue order, and mgx_destroy / mgx_set_shards of one handle synchronise pooled streams that other handles
+ * may still be using (a wait, never a loss).  The pool is created under a lock: handles may live on different host threads
+ * (one thread per handle). */
 int mgx_set_shards(mgx_handle *h, int32_t n_shards);
 int mgx_fork(mgx_handle *h, mgx_stream stream);
 int mgx_join(mgx_handle *h, mgx_stream stream);

@@ -129,6 +129,8 @@ static int battery_step(const orc_grid *g, orc_state *s, double action, int norm
         else if (x < 0.0) e = 0.0;        /* min_production == 0, base_module.py:604-619 */
         else e = x;
         internal = battery_transition(g, -1.0 * e);
+        if (!(internal <= 0)) return -3;  /* `assert internal_energy_change <= 0`, battery_module.py:114: max_production is
+                                           * negative (charge below min_capacity) and the clip handed it on */
         battery_update_state(g, s, internal);
         out->discharge_amount = e;
         out->battery_reward = -1.0 * (fabs(internal) * g->bat_cost_cycle);
@@ -379,9 +381,13 @@ void orc_observe(const orc_grid *g, const orc_state *s, double *obs)
 }
 
 /* ------------------------------------------------------------------------------------------- */
-/* PriorityListAlgo._populate_action, algos/priority_list/priority_list.py:69-167 */
-void orc_populate_action(const orc_grid *g, const orc_state *s,
-                         const orc_pl_element *plist, int32_t n_elements, orc_action *out)
+/* PriorityListAlgo._populate_action, algos/priority_list/priority_list.py:69-167.
+ * Returns 0, or the line of the reference's `assert` that fails in this state (the reference raises AssertionError there and
+ * returns no control): 73 `total_load >= 0 and renewable >= 0`, 121 `remaining_load <= 0.0`, 124 `module_max_consumption >= 0`
+ * (a lossy battery whose charge sits one ulp above max_capacity), 135 `module_consumption <= 0`, 154 `module_production >= 0`
+ * (a battery whose charge sits below min_capacity and is the first to produce).  `out` then holds the control built so far. */
+int orc_populate_action(const orc_grid *g, const orc_state *s,
+                        const orc_pl_element *plist, int32_t n_elements, orc_action *out)
 {
     int32_t t = s->t;
     double total_load = 0.0;                                  /* _get_load :157-164 */
@@ -391,10 +397,11 @@ void orc_populate_action(const orc_grid *g, const orc_state *s,
     for (int32_t j = 0; j < g->n_pv; j++)
         pvs[j] = g->pv_ts[(int64_t)t * g->pv_t_stride + (int64_t)j * g->pv_m_stride];
     double renewable = orc_np_sum(pvs, g->n_pv);
+    memset(out, 0, sizeof(*out));
+    if (!(total_load >= 0 && renewable >= 0)) return 73;      /* :73 */
     double remaining = total_load - renewable;                /* :74 */
 
     int genset_set = 0, battery_set = 0, grid_set = 0;
-    memset(out, 0, sizeof(*out));
     for (int32_t k = 0; k < n_elements; k++) {
         int32_t mod = plist[k].module, act = plist[k].action;
         if (mod == 0) { if (genset_set) continue; genset_set = 1; out->genset[0] = (double)act; }   /* :82-88 */
@@ -416,18 +423,23 @@ void orc_populate_action(const orc_grid *g, const orc_state *s,
             if (mn <= remaining && remaining <= mx) energy = remaining;
             else if (remaining < mn) energy = mn;
             else energy = mx;
+            if (!(energy >= 0)) return 154;                           /* `assert module_production >= 0` :154 */
         } else {                                                      /* _consume_in_module :118-136 */
+            if (!(remaining <= 0.0)) return 121;                      /* `assert remaining_load <= 0.0` :121 (NaN only) */
             if (mod == 0) energy = 0.0;                               /* not a sink */
             else {
                 double mc = (mod == 1) ? battery_max_consumption(g, s) : g->grid_max_export * grid_comp(g, t, 3);
+                if (!(mc >= 0)) return 124;                           /* `assert module_max_consumption >= 0` :124 */
                 energy = (-1 * remaining > mc) ? -1.0 * mc : remaining;
             }
+            if (!(energy <= 0)) return 135;                           /* `assert module_consumption <= 0` :135 */
         }
         if (mod == 0) out->genset[1] = energy;
         else if (mod == 1) out->battery = energy;
         else out->grid = energy;
         remaining -= energy;                                          /* :105 */
     }
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -564,8 +576,8 @@ void orc_mobserve(const orc_mgrid *mg, const orc_mstate *s, double *obs)
 }
 
 /* PriorityListAlgo._populate_action over module instances, priority_list.py:69-116 */
-void orc_mpopulate_action(const orc_mgrid *mg, const orc_mstate *s, const orc_mpl_element *plist, int32_t n_elements,
-                          double *actions)
+int orc_mpopulate_action(const orc_mgrid *mg, const orc_mstate *s, const orc_mpl_element *plist, int32_t n_elements,
+                         double *actions)
 {
     const orc_grid *g = &mg->base;
     int32_t t = s->t;
@@ -575,11 +587,13 @@ void orc_mpopulate_action(const orc_mgrid *mg, const orc_mstate *s, const orc_mp
     double pvs[ORC_MAX_ADDENDS];
     for (int32_t j = 0; j < g->n_pv; j++)
         pvs[j] = g->pv_ts[(int64_t)t * g->pv_t_stride + (int64_t)j * g->pv_m_stride];
-    double remaining = total_load - orc_np_sum(pvs, g->n_pv);
+    double renewable = orc_np_sum(pvs, g->n_pv);
     int set[3][ORC_MAX_INST];
     memset(set, 0, sizeof(set));
     double *a_gen = actions, *a_bat = actions + 2 * mg->n_genset, *a_grid = a_bat + mg->n_battery;
     for (int32_t j = 0; j < 2 * mg->n_genset + mg->n_battery + mg->n_grid; j++) actions[j] = 0.0;
+    if (!(total_load >= 0 && renewable >= 0)) return 73;              /* the asserts: see orc_populate_action */
+    double remaining = total_load - renewable;
     for (int32_t k = 0; k < n_elements; k++) {
         int32_t kind = plist[k].kind, j = plist[k].inst, act = plist[k].action;
         if (set[kind][j]) continue;                                   /* :82-88 */
@@ -606,18 +620,23 @@ void orc_mpopulate_action(const orc_mgrid *mg, const orc_mstate *s, const orc_mp
             if (mn <= remaining && remaining <= mx) energy = remaining;
             else if (remaining < mn) energy = mn;
             else energy = mx;
+            if (!(energy >= 0)) return 154;                           /* :154 */
         } else {
+            if (!(remaining <= 0.0)) return 121;                      /* :121 */
             if (kind == 0) energy = 0.0;
             else {
                 double mc = (kind == 1) ? battery_max_consumption(q, &v) : q->grid_max_export * grid_comp(q, t, 3);
+                if (!(mc >= 0)) return 124;                           /* :124 */
                 energy = (-1 * remaining > mc) ? -1.0 * mc : remaining;
             }
+            if (!(energy <= 0)) return 135;                           /* :135 */
         }
         if (kind == 0) a_gen[2 * j + 1] = energy;
         else if (kind == 1) a_bat[j] = energy;
         else a_grid[j] = energy;
         remaining -= energy;
     }
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -740,8 +759,11 @@ int64_t orc_rollout_batch(const orc_batch *b, int32_t t0, int32_t K, const uint8
                     if (mod >= 0) { pl[n_el].module = mod; pl[n_el].action = act; n_el++; }
                 }
                 orc_action a;
-                orc_populate_action(&g[j], &s[j], pl, n_el, &a);
-                if (orc_run(&g[j], &s[j], &a, 0, &o) != 0) failures++;
+                /* a state where the reference's _populate_action asserts (priority_list.py:73-154): the grid is flagged --
+                 * the reference would have raised there -- and keeps going on the control built so far */
+                int bad = orc_populate_action(&g[j], &s[j], pl, n_el, &a) != 0;
+                if (orc_run(&g[j], &s[j], &a, 0, &o) != 0) { bad = 1; s[j].t = t0 + k + 1; }
+                if (bad) { if (g_failed) g_failed[i] = 1; else failures++; }
                 if (reward) reward[(int64_t)k * N + i] = o.reward;
             }
         }

@@ -124,7 +124,7 @@ void orc_observe(const orc_grid *g, const orc_state *s, double *obs);
 /* One element of a priority list (priority_list_element.py:8-40). module: 0 genset, 1 battery, 2 grid */
 typedef struct orc_pl_element { int32_t module; int32_t action; } orc_pl_element;
 /* PriorityListAlgo._populate_action, priority_list.py:69-116: unnormalised control from a priority list. */
-void orc_populate_action(const orc_grid *g, const orc_state *s,
+int orc_populate_action(const orc_grid *g, const orc_state *s,
                          const orc_pl_element *plist, int32_t n_elements, orc_action *out);
 
 /* ---- microgrids with SEVERAL gensets / batteries / grids -------------------------------------------------------------
@@ -158,7 +158,7 @@ int32_t orc_mobs_dim(const orc_mgrid *g);
 void orc_mobserve(const orc_mgrid *g, const orc_mstate *s, double *obs);
 /* kind: 0 genset, 1 battery, 2 grid */
 typedef struct orc_mpl_element { int32_t kind, inst, action; } orc_mpl_element;
-void orc_mpopulate_action(const orc_mgrid *g, const orc_mstate *s, const orc_mpl_element *plist, int32_t n_elements,
+int orc_mpopulate_action(const orc_mgrid *g, const orc_mstate *s, const orc_mpl_element *plist, int32_t n_elements,
                           double *actions);
 
 /* numpy's float64 add.reduce over a contiguous 1-D array (pairwise_sum, n<=128 path), used by

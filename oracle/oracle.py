@@ -137,7 +137,7 @@ def lib():
         L.orc_run.argtypes = [C.POINTER(Grid), C.POINTER(State), C.POINTER(Action), C.c_int, C.POINTER(StepOut)]
         L.orc_observe.restype = None
         L.orc_observe.argtypes = [C.POINTER(Grid), C.POINTER(State), c_double_p]
-        L.orc_populate_action.restype = None
+        L.orc_populate_action.restype = C.c_int
         L.orc_populate_action.argtypes = [C.POINTER(Grid), C.POINTER(State), C.POINTER(PLElement), C.c_int32,
                                           C.POINTER(Action)]
         L.orc_np_sum.restype = C.c_double
@@ -154,7 +154,7 @@ def lib():
         L.orc_mobs_dim.argtypes = [C.POINTER(MGrid)]
         L.orc_mobserve.restype = None
         L.orc_mobserve.argtypes = [C.POINTER(MGrid), C.POINTER(MState), c_double_p]
-        L.orc_mpopulate_action.restype = None
+        L.orc_mpopulate_action.restype = C.c_int
         L.orc_mpopulate_action.argtypes = [C.POINTER(MGrid), C.POINTER(MState), C.POINTER(MPLElement), C.c_int32, c_double_p]
         _lib = L
     return _lib
@@ -165,6 +165,14 @@ def _dp(a):
 
 
 MODULE_IDS = {"genset": 0, "battery": 1, "grid": 2}
+
+
+class PopulateAssertion(AssertionError):
+    """PriorityListAlgo._populate_action hit one of its asserts (priority_list.py:73,121,124,135,154); ``line`` says which."""
+
+    def __init__(self, line):
+        super().__init__(f"priority_list.py:{line}: the reference asserts in this state")
+        self.line = int(line)
 
 
 class OracleMicrogrid:
@@ -264,7 +272,7 @@ class OracleMicrogrid:
         if rc == -1:
             raise RuntimeError("Microgrid modules unable to balance energy production with consumption.")
         if rc == -3:
-            raise AssertionError("absorbed_energy >= 0 (base_module.py:272)")
+            raise AssertionError("absorbed_energy >= 0 (base_module.py:272) / internal_energy_change <= 0 (battery_module.py:114)")
         if rc != 0:
             raise IndexError("step outside the time series")
         return out
@@ -284,7 +292,9 @@ class OracleMicrogrid:
         arr_t = PLElement * len(plist)
         els = arr_t(*[PLElement(MODULE_IDS[m], int(a)) for m, a in plist])
         out = Action()
-        lib().orc_populate_action(C.byref(self.g), C.byref(self.s), els, len(plist), C.byref(out))
+        rc = lib().orc_populate_action(C.byref(self.g), C.byref(self.s), els, len(plist), C.byref(out))
+        if rc != 0:
+            raise PopulateAssertion(rc)
         d = {}
         if self.g.has_genset: d["genset"] = [out.genset[0], out.genset[1]]
         if self.g.has_battery: d["battery"] = out.battery
@@ -343,7 +353,7 @@ class OracleMultiMicrogrid:
         if rc == -1:
             raise RuntimeError("Microgrid modules unable to balance energy production with consumption.")
         if rc == -3:
-            raise AssertionError("absorbed_energy >= 0 (base_module.py:272)")
+            raise AssertionError("absorbed_energy >= 0 (base_module.py:272) / internal_energy_change <= 0 (battery_module.py:114)")
         if rc != 0:
             raise IndexError("step outside the time series")
         return out
@@ -361,7 +371,9 @@ class OracleMultiMicrogrid:
         """plist: list of (kind id 0/1/2, instance, action id) -> flat unnormalised control."""
         els = (MPLElement * len(plist))(*[MPLElement(int(k), int(j), int(a)) for k, j, a in plist])
         out = np.zeros(self.action_dim, dtype=np.float64)
-        lib().orc_mpopulate_action(C.byref(self.g), C.byref(self.s), els, len(plist), _dp(out))
+        rc = lib().orc_mpopulate_action(C.byref(self.g), C.byref(self.s), els, len(plist), _dp(out))
+        if rc != 0:
+            raise PopulateAssertion(rc)
         return out
 
     def log_row(self, out, names):
@@ -437,8 +449,10 @@ def run_batch(cols, state, t0, K, actions, normalized=True, want_reward=True, nt
     return reward
 
 
-def rollout_batch(cols, state, t0, K, ids, table, want_reward=True, nthreads=1):
-    """K discrete steps (priority-list ids uint8, [K, N] per step or [N] fixed per grid) over an SoA batch."""
+def rollout_batch(cols, state, t0, K, ids, table, want_reward=True, nthreads=1, failed=None):
+    """K discrete steps (priority-list ids uint8, [K, N] per step or [N] fixed per grid) over an SoA batch.
+    ``failed``: optional uint8 [N] array that receives 1 for grids on which the reference would have raised (an assert of
+    _populate_action, priority_list.py:73-154, or of the step); without it such a state raises here."""
     keep = []
     b = _make_batch(cols, state, keep)
     ids = np.ascontiguousarray(ids, dtype=np.uint8)
@@ -446,9 +460,18 @@ def rollout_batch(cols, state, t0, K, ids, table, want_reward=True, nthreads=1):
     assert ids.shape == ((K, b.N) if per_step else (b.N,))
     table = np.ascontiguousarray(table, dtype=np.int32)
     reward = np.empty((K, b.N), dtype=np.float64) if want_reward else None
-    n = lib().orc_rollout_batch(C.byref(b), int(t0), int(K), ids.ctypes.data_as(C.POINTER(C.c_uint8)), per_step,
+    L = lib()
+    L.orc_set_failure_flags.restype = None
+    L.orc_set_failure_flags.argtypes = [C.POINTER(C.c_uint8)]
+    if failed is not None:
+        assert failed.dtype == np.uint8 and failed.shape == (b.N,) and failed.flags.c_contiguous
+        L.orc_set_failure_flags(failed.ctypes.data_as(C.POINTER(C.c_uint8)))
+    try:
+        n = L.orc_rollout_batch(C.byref(b), int(t0), int(K), ids.ctypes.data_as(C.POINTER(C.c_uint8)), per_step,
                                 table.ctypes.data_as(C.POINTER(C.c_int32)), table.shape[0],
                                 _dp(reward) if want_reward else None, int(nthreads))
+    finally:
+        L.orc_set_failure_flags(None)
     if n < 0:
         raise RuntimeError(f"oracle rollout: {-n} step(s) failed")
     return reward

@@ -20,7 +20,12 @@ FUSED_PARTS = 5            # MGX_FUSED_PARTS: slices of mgx_fused.hip (the K-ste
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC"]
 
 MGX_OK, MGX_ERR_INVALID, MGX_ERR_UNSUPPORTED, MGX_ERR_RANGE, MGX_ERR_DEVICE = range(5)
-ABI_VERSION = 6
+# enum mgx_violation_bit
+V_GENSET_RANGE, V_BATTERY_LIMIT, V_GRID_LIMIT, V_GENSET_GOAL, V_GENSET_NEGATIVE, V_NEGATIVE_LIMIT = 1, 2, 4, 8, 16, 32
+V_EXPAND_CONSUME, V_EXPAND_PRODUCE, V_EXPAND_SIGN = 64, 128, 256
+V_EXPAND = V_EXPAND_CONSUME | V_EXPAND_PRODUCE | V_EXPAND_SIGN      # states in which _populate_action asserts
+V_ASSERTS = V_GENSET_GOAL | V_GENSET_NEGATIVE | V_NEGATIVE_LIMIT | V_EXPAND    # the reference raises whatever raise_errors says
+ABI_VERSION = 7
 MAX_INSTANCES = 8          # MGX_MAX_INSTANCES: gensets / batteries / grids per microgrid
 
 
@@ -123,10 +128,11 @@ SYMBOLS = {
                            C.c_void_p]),
     "mgx_step_k": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mgx_expand_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgx_expand_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_check_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgx_set_ring_pitch": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_patch_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "mgx_expand_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgx_expand_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_rollout_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7),
     "mgx_step_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -273,6 +273,16 @@ class MicrogridBatch:
             if t.device != dev:
                 raise ValueError("all columns must live on one device")
         self.device = dev
+        if fact:
+            # Profile ids index the [T, MGX_PROFILE_PITCH] base tables and the tariff selects a price pattern: the C ABI cannot
+            # check device memory (include/mgx.h states the precondition), so it is checked here, once, at construction
+            # (one device -> host read): an id beyond the pitch would read a neighbouring row / table.
+            ids = [k for k in ("load_profile", "pv_profile") + (("co2_profile",) if L.has_grid else ()) if k in self.cols]
+            top = max(int(self.cols[k].max()) for k in ids) if ids and N else 0
+            if top >= PPITCH:
+                raise ValueError(f"profile id {top} >= MGX_PROFILE_PITCH ({PPITCH}): base tables hold {PPITCH} profile columns")
+            if L.has_grid and N and int(self.cols["tariff"].max()) > 2:
+                raise ValueError("tariff pattern must be 0 (no import price), 1 or 2 (MicrogridGenerator.py:253-285)")
 
     def with_flat_order(self, flat_order):
         """The same columns (shared, not copied) under a layout whose flat observation rows are in ``flat_order``

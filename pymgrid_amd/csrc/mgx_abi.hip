@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -80,6 +81,7 @@ thread_local char g_err[512] = "";
 // the second engine of a process).  Handles that step in shards at the same time share these streams (in-order per stream).
 constexpr int MGX_MAX_DEVICES = 16;
 hipStream_t g_shard_streams[MGX_MAX_DEVICES][MGX_MAX_SHARDS] = {};
+std::mutex g_shard_streams_lock;          // handles live on different host threads (one thread per handle): creation is guarded
 
 int fail(int code, const char *fmt, ...)
 {
@@ -1001,6 +1003,7 @@ int mgx_set_shards(mgx_handle *h, int32_t n_shards)
         for (int j = 0; j < n_shards && e == hipSuccess; j++) {
             if (!h->shard_stream[j]) {
                 if (h->device < 0 || h->device >= MGX_MAX_DEVICES) return fail(MGX_ERR_UNSUPPORTED, "mgx_set_shards: device index %d", h->device);
+                std::lock_guard<std::mutex> guard(g_shard_streams_lock);
                 hipStream_t &pooled = g_shard_streams[h->device][j];
                 if (!pooled) e = hipStreamCreateWithFlags(&pooled, hipStreamNonBlocking);
                 h->shard_stream[j] = pooled;
@@ -1257,18 +1260,19 @@ static int encode_table(const mgx_handle *h, const int32_t *table, int32_t n_act
 }
 
 static int launch_expand_lists(mgx_handle *h, const int32_t *action_id, const int32_t *d_lists, int32_t n_lists, int32_t list_len,
-                               double *control, hipStream_t st)
+                               double *control, uint32_t *violations, hipStream_t st)
 {
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
         MGX_DISPATCH_F(h->flags, (expand_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, 0, s>>>(k, d_lists, n_lists, list_len,
-                                                                                                       action_id, t_arg(h), control)));
+                                                                                                       action_id, t_arg(h), control,
+                                                                                                       violations)));
     });
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "expand_multi_kernel launch");
 }
 
 int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions,
-                        double *control, mgx_stream stream)
+                        double *control, uint32_t *violations, mgx_stream stream)
 {
     g_err[0] = 0;
     if (!h || !action_id || !table || !control) return fail(MGX_ERR_INVALID, "mgx_expand_discrete: NULL argument");
@@ -1296,17 +1300,17 @@ int mgx_expand_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *
             if (e != hipSuccess) return hip_fail(e, "mgx_expand_discrete: uploading the priority lists");
             h->lists_uploaded = lists;
         }
-        return launch_expand_lists(h, action_id, h->d_lists, n_actions, 3, control, st);
+        return launch_expand_lists(h, action_id, h->d_lists, n_actions, 3, control, violations, st);
     }
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
-        MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control)));
+        MGX_DISPATCH_F(h->flags, (expand_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control, violations)));
     });
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "expand_kernel launch");
 }
 
 int mgx_expand_lists(mgx_handle *h, const int32_t *action_id, const int32_t *lists, int32_t n_lists, int32_t list_len,
-                     double *control, mgx_stream stream)
+                     double *control, uint32_t *violations, mgx_stream stream)
 {
     g_err[0] = 0;
     if (!h || !action_id || !lists || !control) return fail(MGX_ERR_INVALID, "mgx_expand_lists: NULL argument");
@@ -1314,7 +1318,25 @@ int mgx_expand_lists(mgx_handle *h, const int32_t *action_id, const int32_t *lis
         return fail(MGX_ERR_INVALID, "mgx_expand_lists: need n_lists > 0 and list_len in [1, %d]", 3 * MGX_MAX_INSTANCES);
     if (!dev_counter(h) && (h->t < 0 || h->t >= step_limit(h)))
         return fail(MGX_ERR_RANGE, "mgx_expand_lists: step %d is outside the time series (length %d)", h->t, step_limit(h));
-    return launch_expand_lists(h, action_id, lists, n_lists, list_len, control, (hipStream_t)stream);
+    return launch_expand_lists(h, action_id, lists, n_lists, list_len, control, violations, (hipStream_t)stream);
+}
+
+int mgx_check_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions, uint32_t *violations,
+                       mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !action_id || !table || !violations) return fail(MGX_ERR_INVALID, "mgx_check_discrete: NULL argument");
+    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_check_discrete: needs exactly one module of every kind per grid; use "
+                                                    "mgx_expand_discrete / mgx_expand_lists with `violations`, then mgx_check_step");
+    if (!dev_counter(h) && (h->t < 0 || h->t >= step_limit(h)))
+        return fail(MGX_ERR_RANGE, "mgx_check_discrete: step %d is outside the time series (length %d)", h->t, step_limit(h));
+    PLWords tab;
+    if (int rc = encode_table(h, table, n_actions, &tab, "mgx_check_discrete")) return rc;
+    for_each_shard(h, (hipStream_t)stream, [&](const KArgs &k, hipStream_t s) {
+        MGX_DISPATCH_F(h->flags, (check_discrete_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), violations)));
+    });
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "check_discrete_kernel launch");
 }
 
 int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions, double *control,

@@ -91,9 +91,17 @@ __device__ __forceinline__ uint8_t done_at(const KArgs &a, int64_t i, int32_t t)
 
 // series row of grid i at step counter t: the counter itself (rolling window buffers: a ring), or the grid's own row during
 // in-place episodes.  For the kernels off the hot path; step_kernel / step_discrete_kernel have a compile-time form.
+// In-place episodes: a grid that is done and has not been restarted keeps stepping on its own series; once that would leave
+// the series (row >= T) it re-reads the LAST row -- the counter of this mode never ends, so the row is clamped here rather
+// than refused by the host (include/mgx.h, mgx_reset_episodes).
+__device__ __forceinline__ int64_t episode_row(const KArgs &a, int32_t t, int32_t off)
+{
+    const int64_t row = (int64_t)t + off;
+    return row < a.T ? (row < 0 ? 0 : row) : (int64_t)a.T - 1;
+}
 __device__ __forceinline__ int64_t series_row(const KArgs &a, int64_t i, int32_t t)
 {
-    return a.ep_off ? (int64_t)t + a.ep_off[i] : (int64_t)(t & a.row_mask);
+    return a.ep_off ? episode_row(a, t, a.ep_off[i]) : (int64_t)(t & a.row_mask);
 }
 
 __device__ __forceinline__ int32_t resolve_t(const KArgs &a, int32_t t)
@@ -172,9 +180,12 @@ struct Outputs {
     double discharge_amount, charge_amount, battery_reward, soc_pre, charge_pre;
     double grid_import, grid_export, grid_co2, grid_reward;
     // requests the reference would have refused with raise_errors=True (base_module.py:79-93,213-224,265-270) or
-    // always refuses: bit 0 genset request outside [min, max] production, bit 1 battery request above its limit,
-    // bit 2 grid request above its limit, bit 3 genset goal outside [0, 1] (AssertionError, genset_module.py:147),
-    // bit 4 negative genset energy (a pure source asked to absorb)
+    // always refuses (enum mgx_violation_bit, include/mgx.h): bit 0 genset request outside [min, max] production, bit 1
+    // battery request above its limit, bit 2 grid request above its limit, bit 3 genset goal outside [0, 1] (AssertionError,
+    // genset_module.py:147), bit 4 negative genset energy (a pure source asked to absorb), bit 5 a battery / grid acting at a
+    // NEGATIVE limit (`assert absorbed_energy >= 0`, base_module.py:272: a lossy battery one ulp above max_capacity asked to
+    // absorb; `assert internal_energy_change <= 0`, battery_module.py:114: one below min_capacity asked to produce);
+    // bits 6-8 come from the discrete expansion (populate_core<F, true>)
     uint32_t violations;
 };
 
@@ -519,6 +530,9 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         //  and unspecified here; every valid run has e >= 0 and internal = e * eta.)
         const double e = sink ? e_sink : e_src;
         viol |= (sink ? (ex > q) : (x > mp)) ? 2u : 0u;
+        // `assert absorbed_energy >= 0` (base_module.py:272) / `assert internal_energy_change <= 0` (battery_module.py:114): the
+        // limit the clip hands on is negative (charge above max_capacity / below min_capacity)
+        viol |= !((sink ? e_sink : e_src) >= 0) ? 32u : 0u;
         const double internal = sink ? e * p.bat_eta : ((num < 0) ? q : num * p.bat_eta);
         o.charge_amount = sink ? e : 0.0;
         o.discharge_amount = sink ? 0.0 : e;
@@ -536,6 +550,7 @@ __device__ __forceinline__ void step_core(const Params &p, const Derived &d, Sta
         const double mp = p.grid_imp * in.g_stat;                              // max_production :314-316
         const double e_imp = py_clip(x, 0.0, mp);
         viol |= (sink ? (ex > mc) : (x > mp)) ? 4u : 0u;
+        viol |= !((sink ? e_exp : e_imp) >= 0) ? 32u : 0u;                     // base_module.py:272 (a negative limit)
         const double co2 = sink ? 0.0 : e_imp * in.g_co2;                      // get_co2_production :199-228
         const double cco2 = -1.0 * p.grid_cco2 * co2;                          // get_co2_cost :176-197
         o.grid_export = sink ? e_exp : 0.0;
@@ -614,9 +629,17 @@ __device__ __forceinline__ double pl_energy(double rem, double mn, double mx, do
 
 // gen_instant (wave-uniform, see step_core): next_status(goal) == goal, so the genset's limits under a list element are
 // act * running_{min,max} -- loop-invariant for a fixed list, which lets the compiler hoist them out of a K-step loop.
-template <int F>
+// CHECK: also report, through *xviol, the state in which the reference's _populate_action gives up with an AssertionError
+// instead of returning a control (enum mgx_violation_bit): bit 6 `assert module_max_consumption >= 0` (:124: a sink whose
+// limit is negative is reached with load left to absorb -- a lossy battery whose charge sits one ulp above max_capacity),
+// bit 7 `assert module_production >= 0` (:154: a module whose max_production is negative is asked to produce -- a battery
+// below min_capacity), bit 8 `assert total_load >= 0 and renewable >= 0` / `assert remaining_load <= 0.0` (:73, :121: series
+// of the wrong sign, NaN).  The reference stops at the FIRST failing assert of its walk down the list: so does the mask (one
+// bit).  The control written in such a state is unspecified (the walk goes on with the value the clip ladder gives).
+template <int F, bool CHECK = false>
 __device__ __forceinline__ void populate_core(const Params &p, const State &s, uint32_t word, Inputs &in, double &bat_q,
-                                              double total_load, double renewable, bool gen_instant = false)
+                                              double total_load, double renewable, bool gen_instant = false,
+                                              uint32_t *xviol = nullptr, bool check_sign = true)
 {
     // total_load: sum of the fixed sinks' max_consumption (_get_load :157-164); renewable: np.sum of the flex
     // sources' max_production (_get_renewable :166-167)
@@ -684,11 +707,22 @@ __device__ __forceinline__ void populate_core(const Params &p, const State &s, u
     }
     // pass B: replay the list with the battery's energy known
     double rem = rem0, c_goal = 0.0, c_gen = 0.0, c_grid = 0.0;
+    uint32_t xv = 0u;
+    if constexpr (CHECK) xv = (check_sign && !(total_load >= 0 && renewable >= 0)) ? 256u : 0u;  // :73 (populate_multi: its own test)
 #pragma unroll
     for (int k = 0; k < NSLOT; k++) {
         const bool valid = (el[k] & 8u) != 0;
         const int mod = el[k] & 3u, act = (el[k] >> 2) & 1u;
         const double e = (mod == 1) ? eB : cheap(mod, act, rem);
+        if constexpr (CHECK) {
+            // (at the battery's slot rem == remB, the same running difference: bat_q is then its max_consumption whenever it consumes)
+            const bool close = pl_isclose0(rem), produce = !close && rem > 0, consume = !close && !produce;
+            const double mc = (mod == 1) ? bat_q : r_mc;
+            uint32_t bad = (produce && !(e >= 0)) ? 128u : 0u;                   // :154
+            bad = (consume && !(rem <= 0.0)) ? 256u : bad;                       // :121 (NaN)
+            bad = (consume && rem <= 0.0 && mod != 0 && !(mc >= 0)) ? 64u : bad; // :124 (sinks only: the genset is skipped)
+            xv = (xv == 0u && valid) ? bad : xv;
+        }
         const bool isG = valid && mod == 0, isR = valid && mod == 2;
         c_goal = isG ? (double)act : c_goal;                                    // :82-88
         c_gen = isG ? e : c_gen;
@@ -696,6 +730,7 @@ __device__ __forceinline__ void populate_core(const Params &p, const State &s, u
         rem -= valid ? e : 0.0;                                                 // :105
     }
     in.a_goal = c_goal; in.a_gen = c_gen; in.a_bat = eB; in.a_grid = c_grid;
+    if constexpr (CHECK) { if (xviol) *xviol = xv; }
 }
 
 // ---- reward shaping (microgrid/reward_shaping/*.py; MicrogridStep.shaped_reward, utils/step.py:41-46) ----------
@@ -1064,12 +1099,12 @@ __host__ __device__ inline int multi_list_capacity(int n_load, int n_pv, int n_g
 // load / pv / unbalanced columns, reward, violations; discharge_amount / charge_amount = what BatteryDischargeShaper sums).
 template <int F, typename AT>
 __device__ inline void step_multi_core(const KArgs &a, const AT *__restrict__ act, int64_t i, int32_t t, bool normalized,
-                                       StepLists &L, double *__restrict__ log, Outputs &o)
+                                       StepLists &L, double *__restrict__ log, Outputs &o, uint32_t viol0 = 0u)
 {
     const int64_t N = a.N;
     const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
     double reward = 0.0;
-    uint32_t viol = 0u;
+    uint32_t viol = viol0;                                // (the expansion's assert mask when the control came from a priority list)
     L.n_prov = 0; L.n_absb = 0;
     o.load_met = 0.0;
     for (int j = 0; j < a.n_load; j++) {                  // fixed modules, module order (microgrid.py:255-257)
@@ -1200,9 +1235,10 @@ __device__ inline void step_multi_core(const KArgs &a, const AT *__restrict__ ac
 // PriorityListAlgo._populate_action over module instances (priority_list.py:69-116): `list` holds list_len elements
 // (kind, instance, action), kind < 0 = padding.  Every element runs the single-module form of populate_core on the load
 // that remains when it is reached; control [A] = (goal, energy) per genset, batteries, grids.
+// Returns the assert mask of the expansion (populate_core<F, true>: bits 6-8, the first failing assert of the walk).
 template <int F>
-__device__ inline void populate_multi(const KArgs &a, const int32_t *__restrict__ list, int32_t list_len, int64_t i, int32_t t,
-                                      double *__restrict__ control)
+__device__ inline uint32_t populate_multi(const KArgs &a, const int32_t *__restrict__ list, int32_t list_len, int64_t i, int32_t t,
+                                          double *__restrict__ control)
 {
     const int64_t N = a.N;
     const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
@@ -1217,6 +1253,7 @@ __device__ inline void populate_multi(const KArgs &a, const int32_t *__restrict_
     }
     double remaining = total_load - renewable;                         // :74
     uint32_t seen = 0u;
+    uint32_t xv = !(total_load >= 0 && renewable >= 0) ? 256u : 0u;    // :73
     for (int k = 0; k < list_len; k++) {
         const int kind = list[3 * k], j = list[3 * k + 1], act = list[3 * k + 2] != 0;
         // padding, or an element that names a module the layout does not have (the lists live in device memory and cannot
@@ -1230,28 +1267,31 @@ __device__ inline void populate_multi(const KArgs &a, const int32_t *__restrict_
         Params p; State s; Inputs in; double q_unused;
         s.charge = 0.0; s.soc = 0.0; s.status = 0u; in.g_stat = 1.0;
         double e = 0.0;
+        uint32_t xe = 0u;
         if (kind == 0) {
             if constexpr (F & F_GENSET) {
                 load_module_params<F_GENSET>(a.c, c, p); s.status = a.c.gen_status[c];
-                populate_core<F_GENSET>(p, s, word, in, q_unused, remaining, 0.0);
+                populate_core<F_GENSET, true>(p, s, word, in, q_unused, remaining, 0.0, false, &xe, false);
                 control[2 * j] = in.a_goal; control[2 * j + 1] = in.a_gen; e = in.a_gen;
             }
         } else if (kind == 1) {
             if constexpr (F & F_BATTERY) {
                 load_module_params<F_BATTERY>(a.c, c, p); s.charge = a.c.charge[c];
-                populate_core<F_BATTERY>(p, s, word, in, q_unused, remaining, 0.0);
+                populate_core<F_BATTERY, true>(p, s, word, in, q_unused, remaining, 0.0, false, &xe, false);
                 control[2 * NG + j] = in.a_bat; e = in.a_bat;
             }
         } else {
             if constexpr (F & F_GRID) {
                 load_module_params<F_GRID>(a.c, c, p);
                 in.g_stat = a.c.grid_ts[(((int64_t)t * NR + j) * 4 + 3) * N + i];
-                populate_core<F_GRID>(p, s, word, in, q_unused, remaining, 0.0);
+                populate_core<F_GRID, true>(p, s, word, in, q_unused, remaining, 0.0, false, &xe, false);
                 control[2 * NG + NB + j] = in.a_grid; e = in.a_grid;
             }
         }
+        xv = xv ? xv : xe;                                             // the first assert that fails stops the reference
         remaining -= e;                                                // :105
     }
+    return xv;
 }
 
 }  // namespace mgx

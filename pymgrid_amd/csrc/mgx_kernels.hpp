@@ -85,7 +85,7 @@ __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict
     Params p; State s; Inputs in; Outputs o; Derived d;
     int32_t off = 0;
     if constexpr (EP) off = a.ep_off[i];
-    const int64_t row = EP ? (int64_t)t + off : (int64_t)(t & a.row_mask);
+    const int64_t row = EP ? episode_row(a, t, off) : (int64_t)(t & a.row_mask);
     const int32_t pm = EP ? a.pm_pitch : 0;
     if (a.act_f32) load_inputs<F>(a.c, (const float *)actions, a.N, i, row, in, pm);
     else load_inputs<F>(a.c, (const double *)actions, a.N, i, row, in, pm);
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(64) void patch_windows_kernel(const KArgs a, const 
 // ------------------------------------------------------------------------------------------------------
 template <int F>
 __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWords tab, const int32_t *__restrict__ action_id,
-                                                       int32_t t, double *__restrict__ control)
+                                                       int32_t t, double *__restrict__ control, uint32_t *__restrict__ violations)
 {
     t = resolve_t(a, t);
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
@@ -884,7 +884,9 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
         if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[(tr * 4 + 3) * N + i];
     }
     double q_unused;
-    populate_core<F>(p, s, pl_select(tab, action_id[i]), in, q_unused, 0.0 + -1 * in.load, in.pv);
+    uint32_t xv = 0u;
+    populate_core<F, true>(p, s, pl_select(tab, action_id[i]), in, q_unused, 0.0 + -1 * in.load, in.pv, false, &xv);
+    if (violations) violations[i] = xv;              // where the reference's _populate_action asserts (priority_list.py:73-154)
     double *c = control + i * A;
     int k = 0;
     if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
@@ -921,7 +923,7 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     const int32_t id = action_id[i];
     int32_t off = 0;
     if constexpr (EP) off = a.ep_off[i];
-    const int64_t tr = EP ? (int64_t)t + off : (int64_t)(t & a.row_mask);
+    const int64_t tr = EP ? episode_row(a, t, off) : (int64_t)(t & a.row_mask);
     if (factorised(a.c)) {
         GridFactors f;
         load_factors<F>(a.c, i, f);
@@ -934,7 +936,8 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     derive<F>(p, d);
     const bool gen_instant = genset_wave_is_instant<F>(p, s);
     double bat_q;
-    populate_core<F>(p, s, pl_select(tab, id), in, bat_q, 0.0 + -1 * in.load, in.pv);
+    uint32_t xv = 0u;                                // states in which _populate_action asserts (priority_list.py:73-154): into the
+    populate_core<F, true>(p, s, pl_select(tab, id), in, bat_q, 0.0 + -1 * in.load, in.pv, false, &xv);   // log's violations column
     if (control) {                                   // optional copy of the expanded control (_get_action's value)
         double *c = control + i * A;
         int k = 0;
@@ -943,6 +946,7 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
         if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
     }
     step_core<F, true>(p, d, s, in, false, true, gen_instant, o, bat_q);
+    o.violations |= xv;
     store_state<F>(a.c, i, s);
     reward[i] = shaped_reward<F>(a.shaper, o);
     const uint8_t dn = done_at(a, i, t);
@@ -950,6 +954,35 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     if (log) store_log<F>(log + i, N, o, s.status);
     if constexpr (EP) off = episode_tail<F>(a, i, t, off, dn != 0, p, s);
     if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, EP ? a.pm_pitch : 0);
+}
+
+// Dry run of one discrete step (mgx_check_discrete): the expansion and the step on a register copy of the state; only the mask
+// leaves the kernel -- the expansion's assert bit if it has one (the reference raises there and never steps), else the step's.
+template <int F>
+__global__ __launch_bounds__(BLOCK) void check_discrete_kernel(const KArgs a, const PLWords tab, const int32_t *__restrict__ action_id,
+                                                               int32_t t, uint32_t *__restrict__ violations)
+{
+    t = resolve_t(a, t);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.g1) return;
+    const int64_t N = a.N;
+    Params p; State s; Inputs in; Outputs o; Derived d;
+    const int64_t tr = series_row(a, i, t);
+    if (factorised(a.c)) {
+        GridFactors f;
+        load_factors<F>(a.c, i, f);
+        fact_series<F>(a.c, N, i, tr, f, in, a.pm_pitch);
+    } else {
+        load_series_at<F>(a.c.load_ts + tr * N, a.c.pv_ts + tr * N, (F & F_GRID) ? a.c.grid_ts + tr * 4 * N : nullptr, N, i, i, in);
+    }
+    load_state<F>(a.c, i, true, s);
+    load_params<F>(a.c, i, p);
+    derive<F>(p, d);
+    double bat_q;
+    uint32_t xv = 0u;
+    populate_core<F, true>(p, s, pl_select(tab, action_id[i]), in, bat_q, 0.0 + -1 * in.load, in.pv, false, &xv);
+    step_core<F, true>(p, d, s, in, false, false, false, o, bat_q);
+    violations[i] = xv ? xv : o.violations;
 }
 
 template <int F, bool EP = false>
@@ -1114,9 +1147,11 @@ __global__ __launch_bounds__(BLOCK_K) void rollout_kernel(const KArgs a, const P
     auto consume = [&](auto gi_tag, auto hot_tag, Inputs &in, int32_t k, int64_t off) __attribute__((always_inline)) {
         constexpr bool GI = decltype(gi_tag)::value, HOT = decltype(hot_tag)::value;
         double bat_q;
-        populate_core<F>(p, s, word, in, bat_q, 0.0 + -1 * in.load, in.pv, GI);
+        uint32_t xv = 0u;                // RICH: the expansion's assert mask joins the log's violations column
+        populate_core<F, RICH>(p, s, word, in, bat_q, 0.0 + -1 * in.load, in.pv, GI, &xv);
         Outputs o;
         step_core<F, true>(p, d, s, in, false, HOT ? (F & F_BATTERY) != 0 : want_soc, GI, o, bat_q);
+        if constexpr (RICH) o.violations |= xv;
         if constexpr (HOT) {
             const double r = o.reward;
             (out.reward + (int64_t)k * N)[i32] = r;
@@ -1424,8 +1459,8 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a
                 double ctrl[MGX_MAX_ACTIONS_MULTI];
                 int32_t id = per_step ? ids[off] : ids[i];
                 id = (id >= 0 && id < n_lists) ? id : 0;
-                populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t0 + k, ctrl);
-                step_multi_core<F>(a, (const double *)ctrl, i, t0 + k, false, L, log, o);
+                const uint32_t xv = populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t0 + k, ctrl);
+                step_multi_core<F>(a, (const double *)ctrl, i, t0 + k, false, L, log, o, xv);
             } else if (a.act_f32) {
                 step_multi_core<F>(a, (const float *)actions + off * A, i, t0 + k, normalized != 0, L, log, o);
             } else {
@@ -1447,7 +1482,8 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a
 template <int F>
 __global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a, const int32_t *__restrict__ lists, int32_t n_lists,
                                                                    int32_t list_len, const int32_t *__restrict__ action_id,
-                                                                   int32_t t, double *__restrict__ control)
+                                                                   int32_t t, double *__restrict__ control,
+                                                                   uint32_t *__restrict__ violations)
 {
     t = resolve_t(a, t);
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
@@ -1455,7 +1491,8 @@ __global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a
     const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
     int32_t id = action_id[i];
     id = (id >= 0 && id < n_lists) ? id : 0;              // ids outside [0, n) fall back to list 0 (the reference raises)
-    populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t, control + i * A);
+    const uint32_t xv = populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t, control + i * A);
+    if (violations) violations[i] = xv;
 }
 
 // one wave that idles for `ticks` of the 100 MHz real-time counter: mgx_fork staggers the shard streams with it

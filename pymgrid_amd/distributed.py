@@ -48,8 +48,10 @@ def _multi():
 
 
 def all_reduce_metrics(local_sums, timeout_s=None):
-    """Sum a small metrics vector over all ranks (in place, returns it): THE collective of the engine (RCCL over xGMI on a GPU
-    node).  With a gloo control group beside the default backend the attempt is BOUNDED: the all-reduce runs in a helper thread,
+    """Sum a small metrics vector over all ranks and RETURN the sum -- use the return value: it is ``local_sums`` reduced in place
+    on the normal paths, but when the backend hangs it is a FRESH host tensor (the stuck helper thread may still own
+    ``local_sums``, which is then left as it was -- possibly half reduced -- and must not be read).  THE collective of the engine
+    (RCCL over xGMI on a GPU node).  With a gloo control group beside the default backend the attempt is BOUNDED: the all-reduce runs in a helper thread,
     every rank waits ``timeout_s`` (MGX_RCCL_TIMEOUT_S, default 120 s) for it, the ranks then agree over the control group whether
     it came through everywhere, and if it did not -- RCCL raised, or hangs (IPC handles, a missing peer) -- the sum is taken over
     the control group instead.  The failure is kept in ``last_collective`` (bench.py prints it; ``hung`` tells the caller that a

@@ -668,18 +668,38 @@ class StepEngine:
             self._t += K
         return res
 
-    def expand_discrete(self, action_id, table, out=None):
-        """priority-list ids [N] (int32) -> unnormalised control [N, A]; ``table`` int32 [n_actions, 3, 2]."""
+    def expand_discrete(self, action_id, table, out=None, violations=None):
+        """priority-list ids [N] (int32) -> unnormalised control [N, A]; ``table`` int32 [n_actions, 3, 2].
+        ``violations``: optional int32 [N] tensor that receives the assert the reference's ``_populate_action`` would have failed
+        in this state (``_lib.V_EXPAND_*``, 0 = none; priority_list.py:73-154)."""
         if action_id.dtype != torch.int32 or tuple(action_id.shape) != (self.N,) or action_id.device != self.device:
             raise ValueError(f"action_id must be an int32 tensor of shape ({self.N},) on {self.device}")
         tptr, n_lists = self._table_ptr(table)
         control = out if out is not None else self._empty(self.N, self.action_dim)
-        self._call(self._lib.mgx_expand_discrete, _ptr(action_id), tptr, n_lists, _ptr(control))
+        self._call(self._lib.mgx_expand_discrete, _ptr(action_id), tptr, n_lists, _ptr(control), _ptr(self._mask_arg(violations)))
         return control
 
-    def expand_lists(self, action_id, lists, out=None):
+    def _mask_arg(self, mask):
+        if mask is not None and (mask.dtype != torch.int32 or tuple(mask.shape) != (self.N,) or mask.device != self.device
+                                 or not mask.is_contiguous()):
+            raise ValueError(f"violations must be a contiguous int32 tensor of shape ({self.N},) on {self.device}")
+        return mask
+
+    def check_discrete(self, action_id, table, out=None):
+        """Dry run of ``step_discrete`` (``mgx_check_discrete``): int32 mask [N] -- the assert of ``_populate_action`` the
+        reference would fail in this state (``_lib.V_EXPAND_*``), else the mask ``check_step`` gives for the expanded control;
+        state and step counter are not touched."""
+        if action_id.dtype != torch.int32 or tuple(action_id.shape) != (self.N,) or action_id.device != self.device:
+            raise ValueError(f"action_id must be an int32 tensor of shape ({self.N},) on {self.device}")
+        tptr, n_lists = self._table_ptr(table)
+        mask = self._mask_arg(out) if out is not None else self._empty(self.N, dtype=torch.int32)
+        self._call(self._lib.mgx_check_discrete, _ptr(action_id), tptr, n_lists, mask.data_ptr())
+        return mask
+
+    def expand_lists(self, action_id, lists, out=None, violations=None):
         """priority-list ids [N] (int32) -> unnormalised control [N, A] for lists over module instances
-        (``mgx_expand_lists``): ``lists`` int32 device tensor [n_lists, list_len, 3] of (kind, instance, action)."""
+        (``mgx_expand_lists``): ``lists`` int32 device tensor [n_lists, list_len, 3] of (kind, instance, action).
+        ``violations`` as for ``expand_discrete``."""
         if action_id.dtype != torch.int32 or tuple(action_id.shape) != (self.N,) or action_id.device != self.device:
             raise ValueError(f"action_id must be an int32 tensor of shape ({self.N},) on {self.device}")
         if lists.dtype != torch.int32 or lists.dim() != 3 or lists.shape[2] != 3 or lists.device != self.device \
@@ -687,7 +707,7 @@ class StepEngine:
             raise ValueError(f"lists must be a contiguous int32 tensor [n_lists, list_len, 3] on {self.device}")
         control = out if out is not None else self._empty(self.N, self.action_dim)
         self._call(self._lib.mgx_expand_lists, _ptr(action_id), _ptr(lists), int(lists.shape[0]), int(lists.shape[1]),
-                   _ptr(control))
+                   _ptr(control), _ptr(self._mask_arg(violations)))
         return control
 
     def metrics(self, values, out=None):

@@ -21,11 +21,19 @@ Differences that are deliberate:
 import numpy as np
 import torch
 
+from . import _lib
 from .batch import module_list, MicrogridBatch, unpack_status
 from .engine import StepEngine
 from .priority_list import MODULE_NAMES, get_instance_priority_lists, get_priority_lists, lists_array, table_array
 from .spaces import Box, Discrete
 from .trajectory import check_trajectory_output, shaper_kind
+
+
+class MicrogridAssertion(AssertionError, ValueError):
+    """A state in which the reference gives up with an AssertionError whatever ``raise_errors`` says (genset goal outside
+    [0, 1], genset_module.py:146-147; a sink with a negative limit asked to absorb, base_module.py:272; the asserts of
+    ``_populate_action``, priority_list.py:73-154).  Also a ValueError: the dry run of ``raise_errors=True`` reports every
+    refusal through one exception family."""
 
 
 class ObsViews:
@@ -141,6 +149,11 @@ class BatchedMicrogridEnv:
         # being written on the engine's prefetch stream (mgx_observe_windows_ahead -- the series rows do not depend on the
         # state, so this overlaps the step kernels), and ring r - 1 is still intact for whoever holds observations from it.
         self._ring = self._rings = self._ring_store = None
+        # Position inside ring 0 at which a refill starts the walk (0 <= phase < K): the first ring after a reset is then
+        # K - phase blocks long and every later ring change falls phase steps EARLIER than that of an env with phase 0.  A fleet
+        # gives its buckets different phases so that their ring refills (one burst of K row blocks each) do not all start at the
+        # same step (hetero.BucketedFleet(stagger=True)).
+        self._ring_phase = 0
         if self.obs_prefetch:
             self._alloc_rings(self.obs_prefetch)
             self._ring_idx, self._ring_pos = 0, 0
@@ -424,14 +437,15 @@ class BatchedMicrogridEnv:
     def _refill(self):
         """Fill ring 0 for the counter values t .. t + K - 1 (block 0 complete: current state) and start the prefetch of
         the next K behind it."""
-        self._ring_idx, self._ring_pos = 0, 0
+        p = self._ring_phase if 0 < self._ring_phase < self.obs_prefetch and not self._chunked and not self._sync_rings else 0
+        self._ring_idx, self._ring_pos = 0, p
         self._ring = self._rings[0]
-        self.engine.observe_windows(out=self._ring)
+        self.engine.observe_windows(out=self._ring[p:] if p else self._ring)      # block p = the row of the current counter value
         if not self._chunked:
-            self.engine.observe_windows_ahead(self.obs_prefetch, out=self._rings[1])
+            self.engine.observe_windows_ahead(self.obs_prefetch - p, out=self._rings[1])
         if self._sync_rings:
             self._restart_acc = torch.zeros(self.n_grids, dtype=torch.uint8, device=self.batch.device)
-        return self._ring[0]
+        return self._ring[p]
 
     def _obs_plan(self):
         """Where the coming step's observation goes: (want_obs, target tensor or None, wait for the prefetch first).  With a
@@ -554,15 +568,29 @@ class BatchedMicrogridEnv:
     _VIOLATIONS = ((1, "Genset", "supply requested value as a source (outside [min_production, max_production])"),
                    (2, "BatteryModule", "supply / absorb requested value (above max_production / max_consumption)"),
                    (4, "GridModule", "supply / absorb requested value (above max import / export)"),
-                   (8, "Genset", "goal_status outside [0, 1]"), (16, "Genset", "negative energy request"))
+                   (8, "Genset", "goal_status outside [0, 1]"), (16, "Genset", "negative energy request"),
+                   (32, "BatteryModule / GridModule", "act at a negative limit (assert absorbed_energy >= 0, base_module.py:272: a "
+                                                      "lossy battery one ulp above max_capacity asked to absorb; assert "
+                                                      "internal_energy_change <= 0, battery_module.py:114: one below min_capacity)"),
+                   (64, "priority list", "expand: assert module_max_consumption >= 0 (priority_list.py:124: a lossy battery one "
+                                         "ulp above max_capacity is reached with load left to absorb)"),
+                   (128, "priority list", "expand: assert module_production >= 0 (priority_list.py:154: a module whose "
+                                          "max_production is negative is asked to produce)"),
+                   (256, "priority list", "expand: assert total_load >= 0 and renewable >= 0 / remaining_load <= 0 "
+                                          "(priority_list.py:73,121: series of the wrong sign or NaN)"))
 
-    def _raise_on_violations(self, mask_col):
+    def _raise_on_violations(self, mask_col, asserts_only=False):
+        """ValueError for a request the reference refuses with ``raise_errors=True``; MicrogridAssertion (an AssertionError)
+        for a state in which the reference asserts whatever ``raise_errors`` says.  Nothing has been applied when this raises."""
         mask = mask_col.to(torch.int64)
+        if asserts_only:
+            mask = mask & _lib.V_ASSERTS
         if bool((mask != 0).any()):
             bad = int((mask != 0).nonzero()[0])
             m = int(mask[bad])
             what = "; ".join(f"Module {mod} unable to {msg}" for bit, mod, msg in self._VIOLATIONS if m & bit)
-            raise ValueError(f"{what} [microgrid {bad}; nothing has been applied]")
+            exc = MicrogridAssertion if m & _lib.V_ASSERTS else ValueError
+            raise exc(f"{what} [microgrid {bad}; nothing has been applied]")
 
     run = step      # Microgrid.run has the same signature and return value (microgrid.py:227-325)
 
@@ -685,10 +713,17 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
 
     def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
                  trajectory_func=None, raise_errors=False, observation_keys=None, obs_dtype=torch.float64,
-                 obs_prefetch=None, obs_views=False, reuse_outputs=0):
+                 obs_prefetch=None, obs_views=False, reuse_outputs=0, check_asserts=False):
         super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
                          trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
                          obs_dtype=obs_dtype, obs_prefetch=obs_prefetch, obs_views=obs_views, reuse_outputs=reuse_outputs)
+        # check_asserts=True (implied by raise_errors=True): DiscreteMicrogridEnv.step gives up with an AssertionError in a few
+        # states whatever raise_errors says -- _populate_action's asserts (priority_list.py:73,121,124,135,154: a lossy battery
+        # rounded one ulp above max_capacity with load left to absorb) and the step's (base_module.py:272).  The device goes on
+        # with the clipped value there; with this switch every step is preceded by its dry run (mgx_check_discrete; one
+        # device -> host sync per step) and such a state raises MicrogridAssertion before anything is applied.  Without it
+        # the log's `violations` column (log=True) still carries the bits.
+        self.check_asserts = bool(check_asserts) or self.raise_errors
         L = self.layout
         redundant = []                       # genset instances whose "off" element is redundant (running_min_production == 0)
         if remove_redundant_gensets and L.has_genset:
@@ -724,24 +759,34 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
             self._table = table_array(self.actions_list)
         self.action_space = Discrete(self.action_space.n - 1)
 
-    def get_action(self, action_id):
-        """DiscreteMicrogridEnv._get_action: ids [N] -> unnormalised control [N, A]."""
+    def get_action(self, action_id, violations=None):
+        """DiscreteMicrogridEnv._get_action: ids [N] -> unnormalised control [N, A].  ``violations``: optional int32 [N] tensor
+        for the states in which the reference's ``_populate_action`` asserts (``engine.expand_discrete``)."""
         if not torch.is_tensor(action_id):
             action_id = torch.as_tensor(np.asarray(action_id), device=self.batch.device)
         action_id = action_id.to(device=self.batch.device, dtype=torch.int32).contiguous()
         if self._instances:
-            return self.engine.expand_lists(action_id, self._lists)
-        return self.engine.expand_discrete(action_id, self._table)
+            return self.engine.expand_lists(action_id, self._lists, violations=violations)
+        return self.engine.expand_discrete(action_id, self._table, violations=violations)
 
     def step(self, action_id):
         """One fused launch (expand + step); grids with several modules of a kind go through expand + step."""
         if self.layout.multi:
+            if self.check_asserts:
+                mask = self.engine._empty(self.n_grids, dtype=torch.int32)
+                control = self.get_action(action_id, violations=mask)
+                self._raise_on_violations(mask, asserts_only=True)
+                if not self.raise_errors:                   # (with raise_errors the base class's dry run reports every bit)
+                    self._raise_on_violations(self.engine.check_step(control, normalized=False), asserts_only=True)
+                return super().step(control, normalized=False)
             return super().step(self.get_action(action_id), normalized=False)
         if not (torch.is_tensor(action_id) and action_id.dtype == torch.int32 and action_id.is_contiguous()
                 and action_id.device == self.batch.device):
             if not torch.is_tensor(action_id):
                 action_id = torch.as_tensor(np.asarray(action_id), device=self.batch.device)
             action_id = action_id.to(device=self.batch.device, dtype=torch.int32).contiguous()
+        if self.check_asserts:
+            self._raise_on_violations(self.engine.check_discrete(action_id, self._table), asserts_only=not self.raise_errors)
         want_obs, out = self._obs_target()
         dconst = self._lockstep_done()
         obs, reward, done, log, _ = self.engine.step_discrete(action_id, self._table, want_obs=want_obs,

@@ -8,6 +8,8 @@ chunks inside the step launches (``refill="chunks"``): 29.5-32 / 33-35 us per 10
 streams (``streams=True``: fork / join events around every bucket, one ``env.step`` each) were measured 2.7x slower than
 back-to-back launches at 33k grids per bucket (host-bound) and only pay for many tiny buckets.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -30,8 +32,8 @@ class BucketedFleet:
     """
 
     def __init__(self, grids, device="cuda", discrete=False, streams=False, reuse_outputs=0, fused=True, refill="ahead",
-                 **env_kwargs):
-        self._init_fused(reuse_outputs, fused, refill)
+                 stagger=None, **env_kwargs):
+        self._init_fused(reuse_outputs, fused, refill, stagger)
         self.n_grids = len(grids)
         self.device = torch.device(device)
         self.buckets = list(bucket_by_layout(grids).items())          # [(key, [indices])]
@@ -52,8 +54,13 @@ class BucketedFleet:
         for env in self.envs:
             env._chunked = self.fused and self.refill == "chunks" and not L_multi(env.layout)
             env._fleet_owned = self.fused
+        # stagger: bucket j's rings change j * K / n_buckets steps before bucket 0's, so that the buckets' ring refills -- each a
+        # burst of K row blocks on a prefetch stream -- start at different fleet steps instead of all at once
+        ringed = [env for env in self.envs if env.obs_prefetch]
+        for j, env in enumerate(ringed):
+            env._ring_phase = (j * env.obs_prefetch) // len(ringed) if (self.stagger and self.refill == "ahead") else 0
 
-    def _init_fused(self, reuse_outputs, fused=True, refill="ahead"):
+    def _init_fused(self, reuse_outputs, fused=True, refill="ahead", stagger=None):
         # refill: how a fused fleet renews its observation rings -- "ahead" (default): the whole ring after next as one launch
         # per bucket on the engines' prefetch streams, running beside the following K step launches (what single envs do;
         # 29.5 us per 100k-grid step at K = 16); "chunks": 1/(K-1) of the next ring inside every step launch (33-34 us at
@@ -61,6 +68,7 @@ class BucketedFleet:
         if refill not in ("chunks", "ahead"):
             raise ValueError("refill must be 'chunks' or 'ahead'")
         self.refill = refill
+        self.stagger = bool(int(os.environ.get("MGX_FLEET_STAGGER", "0"))) if stagger is None else bool(stagger)
         # reuse_outputs = R > 0: step() returns reward / done as views into R rotating buffers per bucket (valid for R - 1
         # further steps) instead of fresh tensors -- no allocation on the hot path
         self.reuse_outputs = int(reuse_outputs)
@@ -68,11 +76,12 @@ class BucketedFleet:
         self._plans, self._n_steps, self._out_reward, self._out_done = {}, 0, None, None
 
     @classmethod
-    def from_batches(cls, batches, discrete=False, streams=False, reuse_outputs=0, fused=True, refill="ahead", **env_kwargs):
+    def from_batches(cls, batches, discrete=False, streams=False, reuse_outputs=0, fused=True, refill="ahead", stagger=None,
+                     **env_kwargs):
         """Fleet over ready-made ``MicrogridBatch`` objects (e.g. ``generator.generate`` per architecture): bucket k owns
         fleet positions [sum(n_0..n_{k-1}), ... + n_k)."""
         self = cls.__new__(cls)
-        self._init_fused(reuse_outputs, fused, refill)
+        self._init_fused(reuse_outputs, fused, refill, stagger)
         self.device = batches[0].device
         env_cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
         self.envs, self.index, self.buckets, start = [], [], [], 0

@@ -314,3 +314,48 @@ def test_native_auto_reset_at_the_edges(length, H, prefetch, device):
         if length == 1:
             assert bool(d1.all())
     roll.close(); nat.close()
+
+
+@pytest.mark.parametrize("arch,discrete", [("genset+battery", False), ("genset+battery+grid", False), ("battery+grid", True)])
+def test_done_grids_stepped_past_the_series_stay_defined(arch, discrete, device, oracle):
+    """A grid whose episode is over and that is never restarted keeps stepping on its own series; the shared counter has no end, so
+    nothing refuses the step that leaves the series.  From row T on the kernels re-read the LAST row (clamped: no read beyond the
+    base tables / outage words): rewards and state == the oracle stepping a series whose rows past T repeat row T - 1."""
+    from pymgrid_amd import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv
+    N, T, L, extra = 1027, 70, 6, 150                       # 150 steps past episodes that end at the very end of the series
+    cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
+    kw = dict(remove_redundant_gensets=False) if discrete else {}
+    b = _gen(N, T, arch, device, seed=77)
+    cols = b.numpy_columns()
+    st = {k: cols[k].copy() for k in ("charge", "soc", "gen_status") if k in cols}
+    env = cls(b, obs_prefetch=0, **kw)
+    starts = np.full(N, T - L, dtype=np.int32)
+    starts[::3] = T - L - 5
+    env.reset_windows(starts, None, max_length=L, rolling="inplace")
+    K = L + extra
+    rows = np.minimum(starts[None, :] + np.arange(K)[:, None], T - 1)              # [K, N]: clamped at the last row
+    walked = dict(cols)
+    walked["layout"] = dict(cols["layout"], T=K, final_step=K)
+    walked["load_ts"] = np.ascontiguousarray(np.take_along_axis(cols["load_ts"], rows, 0))
+    walked["pv_ts"] = np.ascontiguousarray(np.take_along_axis(cols["pv_ts"], rows, 0))
+    if cols.get("grid_ts") is not None:
+        walked["grid_ts"] = np.ascontiguousarray(np.take_along_axis(cols["grid_ts"], rows[:, None, :].repeat(4, 1), 0))
+    g = torch.Generator(device=device); g.manual_seed(2 + SOAK)
+    rew = torch.empty(K, N, dtype=torch.float64, device=device)
+    if discrete:
+        ids = torch.randint(0, env.action_space.n, (K, N), dtype=torch.int32, device=device, generator=g)
+        for k in range(K):
+            obs, rew[k], done, _ = env.step(ids[k])
+            assert torch.isfinite(obs).all()
+        from pymgrid_amd.priority_list import table_array
+        ref = oracle.rollout_batch(walked, st, 0, K, ids.cpu().numpy().astype(np.uint8), table_array(env.actions_list), nthreads=8)
+    else:
+        acts = torch.rand(K, N, b.layout.action_dim, dtype=torch.float64, device=device, generator=g)
+        for k in range(K):
+            obs, rew[k], done, _ = env.step(acts[k])
+            assert torch.isfinite(obs).all()
+        ref = oracle.run_batch(walked, st, 0, K, acts.cpu().numpy(), normalized=True, nthreads=8)
+    assert bool(done.all())
+    assert np.array_equal(rew.cpu().numpy(), ref)
+    assert np.array_equal(b.cols["charge"].cpu().numpy(), st["charge"]) and np.isfinite(st["charge"]).all()
+    env.close()
