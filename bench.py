@@ -244,7 +244,7 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
     from pymgrid_amd.generator import generate
     from pymgrid_amd.hetero import BucketedFleet
     per = N // 3
-    K_ring = 16
+    K_ring = 32          # ring depth: 25 vs 27.5 us per fleet step against K = 16 (profiles/r04/exp_fleet_refill_occupancy.txt)
     out = {}
     archs = ("genset+battery", "battery+grid", "genset+battery+grid")
     for contract in ("rows", "views"):

@@ -366,6 +366,15 @@ int mgx_patch_windows(mgx_handle *h, const uint8_t *mask, int32_t K, void *ring,
  * series written once by mgx_normalise_series). */
 int mgx_set_obs_mode(mgx_handle *h, int32_t mode);
 
+/* Step + observation row in ONE launch, for factorised series (enable != 0): with whole rows wanted for a forecast horizon
+ * (MGX_OBS_ROWS_FULL, horizon > 0), mgx_step / mgx_step_discrete / mgx_step_many / mgx_fleet_step form the window values of
+ * every row from the cache-resident base tables inside the stepping launch and write each row once, by whole lines -- no
+ * obs_rows kernel behind the step, no rings.  Lock-step episodes only (per-grid windows keep the two-kernel path).  Same bits.
+ * One launch instead of two is what small batches want; at N = 100 000 the launch is fp64-issue bound (every value of every
+ * row is normalised at every step: one IEEE division each) and the prefetched rings (mgx_observe_windows_ahead) are twice as
+ * fast -- hence off by default.  MGX_ERR_UNSUPPORTED for materialised series or several modules of a kind. */
+int mgx_set_rows_direct(mgx_handle *h, int enable);
+
 /* `done` of the fused calls.  MGX_DONE_U8 (default): one byte per grid and step, [K, N].  MGX_DONE_BITS: a bit set per step,
  * [K, W] uint16 words with W = ceil(N / 16), bit (i & 15) of word i >> 4 = done of grid i (little-endian: the row is a
  * ceil(N / 16) * 2-byte bit array) -- 1/8 byte instead of 1 byte per env-step, written by one lane in 16.
@@ -565,6 +574,59 @@ typedef struct mgx_synth {
                                                              * (mgx_columns.outage_bits), same draws as grid_ts[:, 3] */
 } mgx_synth;
 int mgx_synthesize_series(const mgx_synth *args, mgx_stream stream);
+
+/* MicrogridGenerator's per-microgrid DRAWS and SIZING on device (MicrogridGenerator.py:346-386 _size_mg / _size_genset /
+ * _size_battery, :417-441 _bin_genset_grid / _size_load, :230-243 _get_battery, :288-292 _get_grid, :535-538; module parameters
+ * as convert/get_module.py:39-97 derives them): one lane per grid draws the grid's scalars and sizes its modules.  Every
+ * output is a device array [n_grids] (NULL = not wanted); nothing of size N ever exists on the host, and rank r of W produces
+ * exactly the grids [grid_index0, grid_index0 + n_grids) of the same global batch.
+ *   draws   counter-based: U[0, 1) = Philox4x32-10(seed ^ 0x9E3779B97F4A7C15; global grid index, quantity id) -- the reference
+ *           consumes numpy's global stream one microgrid at a time, which no batch can reproduce; what is reproduced is every
+ *           RULE applied to the draws.  randint(lo, hi) = lo + floor(u (hi - lo)); a standard normal = the sum of 12 uniforms
+ *           minus 6 (Irwin-Hall: additions only, so host and device agree bit for bit without sharing a libm).
+ *   rules   size_load ~ randint(100, 100001), load / pv file ~ randint(0, n_profiles), pv penetration ~ randint(30, 151),
+ *           battery hours ~ randint(3, 6); load_ratio = size_load / max(load profile) (_scale_ts, :137-147); pv size = peak of the
+ *           scaled load x penetration / 100, pv_ratio = pv size / max(pv profile); battery capacity = ceil(hours x mean of the
+ *           scaled load) -- the mean summed in numpy's pairwise order over the n_steps products, divided by n_steps -- power =
+ *           ceil(capacity / 4), min capacity = 0.2 capacity, soc0 = min(max(normal, 0.2), 1), charge = soc0 x capacity; genset
+ *           rating = ceil(peak / 0.9), running min / max = 0.05 / 0.9 of it; grid power = floor(2 peak); weak ~ randint(0, 2),
+ *           tariff ~ randint(1, 3), outages per day = normal x 3 / 4 + 0.25, outage duration ~ randint(1, 8), co2 file ~
+ *           randint(0, n_co2_profiles); genset timers ~ randint(0, 4) when mixed_timers else 0; architecture by
+ *           _bin_genset_grid's uniform (< 0.33 genset only, < 0.66 grid only, else both; a weak grid forces a genset).
+ * base_load: the load table; *_max / *_min: per-profile extrema (host: a few numbers).  Observation bounds come out as the
+ * modules compute them from the series they hold (base_timeseries_module.py:81-88). */
+typedef struct mgx_gen {
+    int32_t struct_size;          /* = sizeof(mgx_gen) */
+    int32_t n_grids, n_steps;
+    int32_t n_load_profiles, n_pv_profiles, n_co2_profiles;
+    int32_t mixed_timers;
+    int32_t n_mean_rows;          /* rows of base_load the sizing rules see: the WHOLE profile (8 760), whatever n_steps is */
+    uint64_t seed;
+    int64_t grid_index0;
+    const int64_t *grid_index;    /* [N] global indices (a scattered selection) or NULL: grid_index0 + i */
+    const double *base_load;      /* [n_mean_rows, n_load_profiles] (the mean of the scaled load) */
+    const double *load_max, *pv_max;                      /* [n_*_profiles]: max over the whole profile (the sizing rules) */
+    const double *load_bound_max, *pv_bound_max;          /* [n_*_profiles]: max over the n_steps rows a module holds (its bounds) */
+    const double *co2_min, *co2_max;                      /* [n_co2_profiles], over the n_steps rows */
+    double tariff_min[3], tariff_max[3];                  /* by pattern (0 unused) */
+    /* outputs, each [N] or NULL */
+    uint8_t *arch;                /* 0 genset+battery, 1 battery+grid, 2 genset+battery+grid */
+    uint8_t *load_profile, *pv_profile, *co2_profile, *tariff;
+    int32_t *weak, *outage_duration;
+    double *outage_per_day;
+    double *load_ratio, *pv_ratio;
+    double *load_lo, *load_hi, *pv_lo, *pv_hi;
+    double *grid_lo, *grid_hi;    /* [4, N]; the status rows (component 3) come out as 1 ("never out"): the caller lowers them where
+                                   * the outage words it synthesises say otherwise */
+    double *bat_min_capacity, *bat_max_capacity, *bat_max_charge, *bat_max_discharge, *charge, *soc;
+    double *gen_running_min, *gen_running_max;
+    uint32_t *gen_times, *gen_status;
+    double *grid_max_import, *grid_max_export;
+    /* the raw draws, for whoever wants to re-apply the rules: [N] each or NULL */
+    double *d_bin_rand, *d_soc0_normal, *d_outage_normal;
+    int32_t *d_size_load, *d_pv_pen, *d_bat_hours, *d_su, *d_wd;
+} mgx_gen;
+int mgx_generate_columns(const mgx_gen *args, mgx_stream stream);
 
 /* Column sums over the grids, sums[m] = sum_i values[m*N + i] (deterministic two-stage wavefront-shuffle +
  * LDS reduction; the "metrics" vector that is all-reduced across GPUs).  M <= 64. */

@@ -99,6 +99,22 @@ class Synth(C.Structure):
                 + [("seed", C.c_uint64), ("grid_index0", C.c_int64), ("grid_index", C.c_void_p)]
                 + [(n, C.c_void_p) for n in ("load_ts", "pv_ts", "grid_ts", "outage_bits")])
 
+class Gen(C.Structure):
+    """mgx_gen (include/mgx.h): arguments of ``mgx_generate_columns``."""
+    _fields_ = ([(n, C.c_int32) for n in ("struct_size", "n_grids", "n_steps", "n_load_profiles", "n_pv_profiles", "n_co2_profiles",
+                                          "mixed_timers", "n_mean_rows")]
+                + [("seed", C.c_uint64), ("grid_index0", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("grid_index", "base_load", "load_max", "pv_max", "load_bound_max", "pv_bound_max",
+                                             "co2_min", "co2_max")]
+                + [("tariff_min", C.c_double * 3), ("tariff_max", C.c_double * 3)]
+                + [(n, C.c_void_p) for n in ("arch", "load_profile", "pv_profile", "co2_profile", "tariff", "weak", "outage_duration",
+                                             "outage_per_day", "load_ratio", "pv_ratio", "load_lo", "load_hi", "pv_lo", "pv_hi",
+                                             "grid_lo", "grid_hi", "bat_min_capacity", "bat_max_capacity", "bat_max_charge",
+                                             "bat_max_discharge", "charge", "soc", "gen_running_min", "gen_running_max", "gen_times",
+                                             "gen_status", "grid_max_import", "grid_max_export", "d_bin_rand", "d_soc0_normal",
+                                             "d_outage_normal", "d_size_load", "d_pv_pen", "d_bat_hours", "d_su", "d_wd")])
+
+
 # every symbol include/mgx.h declares: (restype, argtypes)
 SYMBOLS = {
     "mgx_abi_version": (C.c_int, []),
@@ -117,6 +133,7 @@ SYMBOLS = {
     "mgx_set_obs_format": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_set_obs_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_set_done_format": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mgx_set_rows_direct": (C.c_int, [C.c_void_p, C.c_int]),
     "mgx_normalise_series": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_set_action_format": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_observe_windows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -156,7 +173,37 @@ SYMBOLS = {
     "mgx_shard_stream": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "mgx_fleet_step": (C.c_int, [C.POINTER(FleetItem), C.c_int32, C.c_int, C.c_void_p]),
     "mgx_synthesize_series": (C.c_int, [C.POINTER(Synth), C.c_void_p]),
+    "mgx_generate_columns": (C.c_int, [C.POINTER(Gen), C.c_void_p]),
 }
+
+
+def source_hash(extra=()):
+    """sha256 (16 hex digits) over the contents of every source the library is built from + the compiler flags: what a built
+    libmgx.so is stamped with (``<lib>.srchash``) and what bench.py / the profiles carry to say which kernels they measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES):
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(HIPCC_FLAGS + list(extra)).encode())
+    return h.hexdigest()[:16]
+
+
+def built_hash(lib_path=None):
+    """The source hash the library at ``lib_path`` was built from (None: not built here / no stamp)."""
+    try:
+        with open((lib_path or LIB_PATH) + ".srchash") as fh:
+            return fh.read().strip() or None
+    except OSError:
+        return None
+
+
+def up_to_date(lib_path=None):
+    """The library exists and its stamp equals the hash of the sources as they are now -- file times play no part (a stale
+    .so with a newer mtime than the sources, e.g. after a checkout, does not pass for current)."""
+    path = lib_path or LIB_PATH
+    return os.path.exists(path) and built_hash(path) == source_hash()
 
 
 def build(force=False, verbose=False, defs=(), lib_path=None):
@@ -165,8 +212,7 @@ def build(force=False, verbose=False, defs=(), lib_path=None):
     library; load it with MGX_LIB=<lib_path>."""
     if lib_path is not None or defs:
         return _build(lib_path or LIB_PATH, list(defs), verbose, os.path.basename(lib_path or "variant") + ".o")
-    if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in SOURCES)):
+    if not force and up_to_date(LIB_PATH):
         return LIB_PATH
     return _build(LIB_PATH, [], verbose, "", force)
 
@@ -178,9 +224,9 @@ def _build(LIB_PATH, extra_defs, verbose, objtag, force=True):
     with open(LIB_PATH + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if (not force and os.path.exists(LIB_PATH)
-                    and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in SOURCES)):
+            if not force and not extra_defs and up_to_date(LIB_PATH):
                 return LIB_PATH                      # another process built it while we waited
+            stamp = source_hash(extra_defs)          # (of the sources as they are when the compilers start)
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
             objdir = os.path.join(_PKG, "csrc", "_build" + ("_" + objtag if objtag else ""))
@@ -217,6 +263,9 @@ def _build(LIB_PATH, extra_defs, verbose, objtag, force=True):
                 print(" ".join(link))
             subprocess.run(link, check=True)
             os.replace(tmp, LIB_PATH)
+            with open(LIB_PATH + ".srchash.tmp", "w") as fh:
+                fh.write(stamp + "\n")
+            os.replace(LIB_PATH + ".srchash.tmp", LIB_PATH + ".srchash")
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH

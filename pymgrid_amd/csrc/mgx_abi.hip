@@ -50,6 +50,8 @@ struct mgx_handle {
     PLWords table_uploaded;
     bool table_uploaded_valid;
     hipStream_t prefetch_stream;             // mgx_observe_windows_ahead: the window prefetch overlaps the steps
+    bool prefetch_pooled;                    // ... on the per-device pooled stream (MGX_PREFETCH_POOL): not destroyed with the handle
+    bool rows_direct;                        // mgx_set_rows_direct: step + whole observation row in one launch (fleet_rows_kernel)
     hipEvent_t prefetch_gate, prefetch_done;
     bool prefetch_pending;
     // per-grid episode windows (mgx_reset_windows): the full series are remembered here while the handle steps over the
@@ -82,6 +84,9 @@ thread_local char g_err[512] = "";
 constexpr int MGX_MAX_DEVICES = 16;
 hipStream_t g_shard_streams[MGX_MAX_DEVICES][MGX_MAX_SHARDS] = {};
 std::mutex g_shard_streams_lock;          // handles live on different host threads (one thread per handle): creation is guarded
+// MGX_PREFETCH_POOL=1: one prefetch stream per device shared by every handle -- the ring refills of a fleet's buckets then run one
+// after the other instead of side by side (each alone has the whole memory system; a fleet step orders them with one gate event)
+hipStream_t g_prefetch_streams[MGX_MAX_DEVICES] = {};
 
 int fail(int code, const char *fmt, ...)
 {
@@ -202,6 +207,22 @@ static void launch_obs_rows(const KArgs &k, const WindowPlan &plan, int32_t t, v
         if (k.obs_f32) launch_obs_rows_as<F, false, float>(k, plan, t, obs, blocks, lds, st);
         else launch_obs_rows_as<F, false, double>(k, plan, t, obs, blocks, lds, st);
     }
+}
+
+// the opt-in to more than 64 KB of dynamic LDS is a driver call: made once per kernel and device, not per launch
+template <int F, typename OT>
+static void launch_windows_kernel(const KArgs &k, const WindowsKPlan &plan, int32_t t, void *ring, unsigned blocks, size_t lds, hipStream_t st)
+{
+    static bool opted_in[MGX_MAX_DEVICES] = {};
+    if (lds > 64 * 1024) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= MGX_MAX_DEVICES || !opted_in[dev]) {
+            (void)hipFuncSetAttribute((const void *)obs_windows_k_kernel<F, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (dev >= 0 && dev < MGX_MAX_DEVICES) opted_in[dev] = true;
+        }
+    }
+    obs_windows_k_kernel<F, OT><<<blocks, OBS_K_THREADS, lds, st>>>(k, plan, t, (OT *)ring);
 }
 
 static inline unsigned multi_blocks(int64_t n) { return (unsigned)((n + BLOCK_MULTI - 1) / BLOCK_MULTI); }
@@ -351,6 +372,8 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->d_kargs = nullptr; h->k_uploaded_valid = false;
     h->d_table = nullptr; h->table_uploaded_valid = false;
     h->prefetch_stream = nullptr; h->prefetch_gate = nullptr; h->prefetch_done = nullptr; h->prefetch_pending = false;
+    h->prefetch_pooled = false;
+    h->rows_direct = false;
     h->windowed = false; h->rolling = false;
     h->k.row_mask = -1;
     h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.ar_fixed_length = 0; h->k.ar_lo = 0; h->k.ar_hi = 0;
@@ -379,7 +402,7 @@ void mgx_destroy(mgx_handle *h)
         if (h->shard_event[j]) (void)hipEventDestroy(h->shard_event[j]);
     }
     if (h->fork_event) (void)hipEventDestroy(h->fork_event);
-    if (h->prefetch_stream) { (void)hipStreamSynchronize(h->prefetch_stream); (void)hipStreamDestroy(h->prefetch_stream); }
+    if (h->prefetch_stream) { (void)hipStreamSynchronize(h->prefetch_stream); if (!h->prefetch_pooled) (void)hipStreamDestroy(h->prefetch_stream); }
     if (h->pm_tables) (void)hipFree(h->pm_tables);
     if (h->d_kargs) (void)hipFree(h->d_kargs);
     if (h->d_table) (void)hipFree(h->d_table);
@@ -482,6 +505,17 @@ int mgx_set_obs_mode(mgx_handle *h, int32_t mode)
     return MGX_OK;
 }
 
+int mgx_set_rows_direct(mgx_handle *h, int enable)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_rows_direct: NULL handle");
+    if (enable && (h->multi || !factorised(h->full_c)))
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_set_rows_direct: needs factorised series and one module of every kind per grid (the "
+                                         "window values are formed from cache-resident base tables)");
+    h->rows_direct = enable != 0;
+    return MGX_OK;
+}
+
 int mgx_set_done_format(mgx_handle *h, int32_t format)
 {
     g_err[0] = 0;
@@ -522,7 +556,7 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     plan->pitch = h->ring_pitch;
     auto lds_of = [&](int32_t g) { return (size_t)g * plan->bp * sizeof(double) + (size_t)h->k.obs_dim * sizeof(uint32_t); };
     while (plan->group > 1 && lds_of(plan->group) > 160 * 1024) plan->group /= 2;
-    const size_t lds = (lds_of(plan->group) + 7) & ~(size_t)7;
+    size_t lds = (lds_of(plan->group) + 7) & ~(size_t)7;
     if (lds > 160 * 1024)
         return fail(MGX_ERR_UNSUPPORTED, "%s: K + horizon = %d rows do not fit the 160 KiB LDS", who, R);
     *lds_out = lds;
@@ -550,14 +584,23 @@ static int launch_windows(mgx_handle *h, int32_t ahead, int32_t K, void *ring, h
     chunk_range(n_groups, chunk, n_chunks, &first, &count);
     if (count <= 0) return MGX_OK;
     plan.group0 = first;
+    if (ahead > 0 && n_chunks <= 1) {                 // a whole ring written ahead of the counter, beside the step launches
+        // Refill workgroups per CU.  A refill runs BESIDE the step launches of the rows it is not needed for yet, and how hard it
+        // leans on the memory system decides what those steps cost: with two refill workgroups per CU (K = 16: 55 KB of LDS each)
+        // a 100 000-grid fleet step took 60 us while the refills ran, with one per CU (K = 32: 92 KB) 25 us -- at the same
+        // 5.3 TB/s of row writes (profiles/r04/fleet_timeline_K16.txt, _K32.txt).  Asking for more than half of the 160 KB keeps
+        // it at one workgroup per CU whatever K is.  MGX_WIN_MIN_LDS overrides (bytes; 0 = exactly what the image needs).
+        static const long min_lds_env = [] { const char *e = getenv("MGX_WIN_MIN_LDS"); return e ? atol(e) : -1L; }();
+        const size_t min_lds = min_lds_env >= 0 ? (size_t)min_lds_env : (size_t)(ahead > 0 ? 81 * 1024 : 0);
+        if (lds < min_lds && min_lds <= 160 * 1024) lds = min_lds;
+    }
+
     const unsigned blocks = (unsigned)count;
     const int32_t t = t_arg(h) + ahead;
     if (h->k.obs_f32) {
-        MGX_DISPATCH_F(h->flags, ((lds > 64 * 1024 ? (void)hipFuncSetAttribute((const void *)obs_windows_k_kernel<F, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : (void)0),
-                                  obs_windows_k_kernel<F, float><<<blocks, OBS_K_THREADS, lds, st>>>(h->k, plan, t, (float *)ring)));
+        MGX_DISPATCH_F(h->flags, (launch_windows_kernel<F, float>(h->k, plan, t, ring, blocks, lds, st)));
     } else {
-        MGX_DISPATCH_F(h->flags, ((lds > 64 * 1024 ? (void)hipFuncSetAttribute((const void *)obs_windows_k_kernel<F, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : (void)0),
-                                  obs_windows_k_kernel<F, double><<<blocks, OBS_K_THREADS, lds, st>>>(h->k, plan, t, (double *)ring)));
+        MGX_DISPATCH_F(h->flags, (launch_windows_kernel<F, double>(h->k, plan, t, ring, blocks, lds, st)));
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "obs_windows_k_kernel launch");
@@ -608,32 +651,59 @@ int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream)
     return launch_windows(h, 0, K, ring, (hipStream_t)stream, "mgx_observe_windows");
 }
 
-int mgx_observe_windows_ahead(mgx_handle *h, int32_t ahead, int32_t K, void *ring, mgx_stream stream)
+// the handle's prefetch stream and events, created on first use
+static int ensure_prefetch_stream(mgx_handle *h, const char *who)
 {
-    g_err[0] = 0;
+    if (h->prefetch_stream) return MGX_OK;
+    hipError_t e = hipSuccess;
+    static const bool pool = [] { const char *v = getenv("MGX_PREFETCH_POOL"); return v && atoi(v) != 0; }();
+    if (pool && h->device >= 0 && h->device < MGX_MAX_DEVICES) {
+        std::lock_guard<std::mutex> guard(g_shard_streams_lock);
+        hipStream_t &pooled = g_prefetch_streams[h->device];
+        if (!pooled) e = hipStreamCreateWithFlags(&pooled, hipStreamNonBlocking);
+        h->prefetch_stream = pooled;
+        h->prefetch_pooled = true;
+    } else {
+        // (a low- or high-priority prefetch stream is slower: 31.4 / 33.5 vs 29.6 us per config-5 fleet step)
+        // (a CU-masked prefetch stream -- hipExtStreamCreateWithCUMask, 25..75 % of every XCD's CUs -- is 2-3x slower:
+        //  profiles/r03/exp_fleet_cu_mask_reverted.txt)
+        e = hipStreamCreateWithFlags(&h->prefetch_stream, hipStreamNonBlocking);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prefetch_gate, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prefetch_done, hipEventDisableTiming);
+    return e == hipSuccess ? MGX_OK : hip_fail(e, who);
+}
+
+// gate != nullptr: an event already recorded on the caller's stream (a fleet step records ONE for all of its buckets)
+static int observe_windows_ahead(mgx_handle *h, int32_t ahead, int32_t K, void *ring, hipStream_t stream, hipEvent_t gate,
+                                 hipStream_t *gated_stream)
+{
     if (!h) return fail(MGX_ERR_INVALID, "mgx_observe_windows_ahead: NULL handle");
     if (ahead < 1) return fail(MGX_ERR_INVALID, "mgx_observe_windows_ahead: ahead must be >= 1 (mgx_observe_windows is the ahead = 0 form)");
     if (dev_counter(h)) return fail(MGX_ERR_UNSUPPORTED, "mgx_observe_windows_ahead: not offered in device-counter mode (the prefetch "
                                                          "stream would race with the kernels that move the counter)");
     hipError_t e = hipSuccess;
     DeviceGuard on_device(h->device);
-    if (!h->prefetch_stream) {
-        // (a low- or high-priority prefetch stream is slower: 31.4 / 33.5 vs 29.6 us per config-5 fleet step)
-        // (a CU-masked prefetch stream -- hipExtStreamCreateWithCUMask, 25..75 % of every XCD's CUs -- is 2-3x slower:
-        //  profiles/r03/exp_fleet_cu_mask_reverted.txt)
-        e = hipStreamCreateWithFlags(&h->prefetch_stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prefetch_gate, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->prefetch_done, hipEventDisableTiming);
-        if (e != hipSuccess) return hip_fail(e, "mgx_observe_windows_ahead: creating the prefetch stream");
-    }
+    if (int rc = ensure_prefetch_stream(h, "mgx_observe_windows_ahead: creating the prefetch stream")) return rc;
     // readers of the ring's previous contents were queued on `stream`: the prefetch starts behind them
-    e = hipEventRecord(h->prefetch_gate, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(h->prefetch_stream, h->prefetch_gate, 0);
+    if (!gate) {
+        e = hipEventRecord(h->prefetch_gate, stream);
+        gate = h->prefetch_gate;
+    }
+    if (e == hipSuccess && !(gated_stream && *gated_stream == h->prefetch_stream))     // (a pooled stream is gated once per fleet step)
+        e = hipStreamWaitEvent(h->prefetch_stream, gate, 0);
+    if (gated_stream) *gated_stream = h->prefetch_stream;
     if (e != hipSuccess) return hip_fail(e, "mgx_observe_windows_ahead: ordering behind the caller's stream");
     if (int rc = launch_windows(h, ahead, K, ring, h->prefetch_stream, "mgx_observe_windows_ahead")) return rc;
     e = hipEventRecord(h->prefetch_done, h->prefetch_stream);
     h->prefetch_pending = true;
     return e == hipSuccess ? MGX_OK : hip_fail(e, "mgx_observe_windows_ahead: recording the completion event");
+}
+
+int mgx_observe_windows_ahead(mgx_handle *h, int32_t ahead, int32_t K, void *ring, mgx_stream stream)
+{
+    g_err[0] = 0;
+    return observe_windows_ahead(h, ahead, K, ring, (hipStream_t)stream, nullptr, nullptr);
 }
 
 int mgx_prefetch_wait(mgx_handle *h, mgx_stream stream)
@@ -1102,6 +1172,76 @@ static int episode_step_end(mgx_handle *h, const EpisodeStep &ep, const uint8_t 
     return launch_observe(h, h->t + 1, obs, st);
 }
 
+// ---- step + observation row in one launch (factorised series; fleet_rows_kernel) --------------------------------------
+// Possible when whole rows are wanted for a forecast horizon and every window value can be formed from cache-resident base
+// tables: lock-step stepping of a factorised batch with one module of every kind, no forecast noise.  OFF unless the handle asks
+// for it (mgx_set_rows_direct): bit-identical rows (tests/test_direct_rows.py), one launch instead of two -- but at N = 100 000 it
+// is fp64-VALU bound: every step normalises all D values of every row (one IEEE division each) where the rings normalise a
+// series value once per K steps: 55 us per config-5 fleet step against 26-29 us on rings (profiles/r04/exp_fleet_direct_rows.txt).
+static bool rows_direct_ok(const mgx_handle *h, const void *obs)
+{
+    if (!h->rows_direct || !obs || h->multi || h->k.H <= 0 || h->k.obs_state_only || !factorised(h->k.c)) return false;
+    if (h->windowed || h->rolling || h->inplace || dev_counter(h) || h->n_shards > 1) return false;
+    if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std) return false;
+    return rows_lds_bytes(h->k.obs_dim, h->k.H, h->k.obs_f32 ? sizeof(float) : sizeof(double)) <= 160 * 1024;
+}
+
+struct RowsItem {
+    mgx_handle *h;
+    const void *actions;          // continuous control, or the int32 priority-list ids of a discrete item
+    const PLWords *tab;           // discrete: the encoded table (host); NULL: continuous
+    double *reward; uint8_t *done; void *obs; double *log;
+};
+
+// one fleet_rows_kernel launch per MGX_FLEET_MAX items; the counters are advanced by the caller
+static int launch_rows(const RowsItem *items, int32_t n, int normalized, hipStream_t st, const char *who)
+{
+    size_t lds_max = 0;
+    for (int32_t j = 0; j < n; j++) {
+        mgx_handle *h = items[j].h;
+        if (int rc = sync_device_kargs(h, st, who)) return rc;
+        if (items[j].tab) {                                   // the priority-list table of a discrete item: device copy
+            if (!(h->table_uploaded_valid && memcmp(items[j].tab, &h->table_uploaded, sizeof(PLWords)) == 0)) {
+                hipError_t e = hipSuccess;
+                DeviceGuard on_device(h->device);
+                if (!h->d_table) e = hipMalloc((void **)&h->d_table, sizeof(PLWords));
+                if (e == hipSuccess) e = hipMemcpyAsync(h->d_table, items[j].tab, sizeof(PLWords), hipMemcpyHostToDevice, st);
+                if (e != hipSuccess) return hip_fail(e, who);
+                memcpy(&h->table_uploaded, items[j].tab, sizeof(PLWords));
+                h->table_uploaded_valid = true;
+            }
+        }
+        const size_t lds = rows_lds_bytes(h->k.obs_dim, h->k.H, h->k.obs_f32 ? sizeof(float) : sizeof(double));
+        if (lds > lds_max) lds_max = lds;
+    }
+    static bool opted_in[MGX_MAX_DEVICES] = {};
+    if (lds_max > 64 * 1024) {
+        const int dev = items[0].h->device;
+        if (dev < 0 || dev >= MGX_MAX_DEVICES || !opted_in[dev]) {
+            (void)hipFuncSetAttribute((const void *)fleet_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (dev >= 0 && dev < MGX_MAX_DEVICES) opted_in[dev] = true;
+        }
+    }
+    for (int32_t j0 = 0; j0 < n; j0 += MGX_FLEET_MAX) {
+        FleetRows fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.n = n - j0 < MGX_FLEET_MAX ? n - j0 : MGX_FLEET_MAX;
+        fa.normalized = normalized;
+        int32_t blocks = 0;
+        for (int32_t q = 0; q < fa.n; q++) {
+            const RowsItem &it = items[j0 + q];
+            fa.k[q] = it.h->d_kargs; fa.tab[q] = it.tab ? it.h->d_table : nullptr;
+            fa.actions[q] = it.actions; fa.reward[q] = it.reward; fa.done[q] = it.done; fa.obs[q] = it.obs; fa.log[q] = it.log;
+            fa.t[q] = it.h->t; fa.flags[q] = it.h->flags; fa.block0[q] = blocks;
+            blocks += (int32_t)(((int64_t)it.h->k.N + ROWS_G - 1) / ROWS_G);
+        }
+        fleet_rows_kernel<<<(unsigned)blocks, ROWS_THREADS, lds_max, st>>>(fa);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "fleet_rows_kernel launch");
+    }
+    return MGX_OK;
+}
+
 // ---- single steps ----------------------------------------------------------------------------------------------
 // one Microgrid.run of every grid: the launches of mgx_step without its argument checks
 static int step_once(mgx_handle *h, const void *actions, int normalized, double *reward, uint8_t *done, void *obs, double *log,
@@ -1118,6 +1258,12 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
         return MGX_OK;
     }
     void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
+    if (rows_direct_ok(h, obs)) {                         // factorised series: step + whole observation row in one launch
+        const RowsItem it{h, actions, nullptr, reward, done, obs, log};
+        if (int rc = launch_rows(&it, 1, normalized, st, "mgx_step")) return rc;
+        advance(h, 1, st);
+        return MGX_OK;
+    }
     if (h->inplace) {                                     // in-place episodes: the EP form of the kernel (no shards in this mode)
         EpisodeStep ep;
         if (int rc = episode_step_begin(h, done, obs, obs_inline, &ep, "mgx_step")) return rc;
@@ -1351,6 +1497,12 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_step_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
     void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
+    if (rows_direct_ok(h, obs) && !control) {             // factorised series: expansion + step + whole row in one launch
+        const RowsItem it{h, action_id, &tab, reward, done, obs, log};
+        if (int rc = launch_rows(&it, 1, 0, st, "mgx_step_discrete")) return rc;
+        advance(h, 1, st);
+        return MGX_OK;
+    }
     if (h->inplace) {
         EpisodeStep ep;
         if (int rc = episode_step_begin(h, done, obs, obs_inline, &ep, "mgx_step_discrete")) return rc;
@@ -1456,6 +1608,29 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
             if (int rc = windows_plan(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, "mgx_fleet_step", &plan, &lds, &ng)) return rc;
         }
     }
+    // every batch wants whole rows off factorised series: ONE fleet_rows_kernel (step + row per 16-grid workgroup)
+    {
+        bool all_rows = n <= 64;
+        for (int32_t j = 0; j < n && all_rows; j++) {
+            all_rows = rows_direct_ok(items[j].handle, items[j].obs) && !items[j].refill_ring && !items[j].wait_prefetch;
+            for (int32_t q = 0; q < j && all_rows; q++) all_rows = items[q].handle != items[j].handle;
+        }
+        if (all_rows) {
+            RowsItem ri[64];
+            PLWords tabs[64];
+            for (int32_t j = 0; j < n; j++) {
+                const mgx_fleet_item &it = items[j];
+                ri[j] = RowsItem{it.handle, it.action_id ? (const void *)it.action_id : it.actions, nullptr, it.reward, it.done, it.obs, it.log};
+                if (it.action_id) {
+                    if (int rc = encode_table(it.handle, it.table, it.n_actions, &tabs[j], "mgx_fleet_step")) return rc;
+                    ri[j].tab = &tabs[j];
+                }
+            }
+            if (int rc = launch_rows(ri, n, normalized, st, "mgx_fleet_step")) return rc;
+            for (int32_t j = 0; j < n; j++) advance(items[j].handle, 1, st);
+            return MGX_OK;
+        }
+    }
     // one launch for all batches (continuous and discrete items alike) unless an item needs a kernel of its own
     bool fusable = true;
     for (int32_t j = 0; j < n && fusable; j++) {
@@ -1535,15 +1710,25 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
             rc = step_once(it.handle, it.actions, normalized, it.reward, it.done, it.obs, it.log, st);
         if (rc) return rc;
     }
+    hipEvent_t fleet_gate = nullptr;                        // ONE gate event for every ring refill this fleet step starts
+    hipStream_t gated = nullptr;
     for (int32_t j = 0; j < n; j++) {                       // window prefetch that did not ride along with the step launch
         const mgx_fleet_item &it = items[j];
         if (!it.refill_ring || (j < 64 && chunk_done[j])) continue;
         int rc;
         if (it.refill_chunks > 0)                           // a chunk, on the caller's stream (the counter has advanced: ahead as given)
             rc = launch_windows(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, st, "mgx_fleet_step", it.refill_chunk, it.refill_chunks);
-        else
-            rc = it.refill_ahead > 0 ? mgx_observe_windows_ahead(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, stream)
-                                     : mgx_observe_windows(it.handle, it.refill_K, it.refill_ring, stream);
+        else if (it.refill_ahead > 0) {
+            if (!fleet_gate) {
+                DeviceGuard on_device(it.handle->device);
+                if (int rc0 = ensure_prefetch_stream(it.handle, "mgx_fleet_step: creating the prefetch stream")) return rc0;
+                hipError_t e = hipEventRecord(it.handle->prefetch_gate, st);
+                if (e != hipSuccess) return hip_fail(e, "mgx_fleet_step: recording the refill gate");
+                fleet_gate = it.handle->prefetch_gate;
+            }
+            rc = observe_windows_ahead(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, st, fleet_gate, &gated);
+        } else
+            rc = mgx_observe_windows(it.handle, it.refill_K, it.refill_ring, stream);
         if (rc) return rc;
     }
     return MGX_OK;
@@ -1574,6 +1759,29 @@ int mgx_synthesize_series(const mgx_synth *a, mgx_stream stream)
     synthesize_series_kernel<<<blocks_for(a->n_grids), BLOCK, 0, (hipStream_t)stream>>>(*a);
     e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "synthesize_series_kernel launch");
+}
+
+int mgx_generate_columns(const mgx_gen *a, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!a) return fail(MGX_ERR_INVALID, "mgx_generate_columns: NULL argument");
+    if (a->struct_size != (int32_t)sizeof(mgx_gen))
+        return fail(MGX_ERR_INVALID, "mgx_generate_columns: struct_size %d vs %zu (ABI %d)", a->struct_size, sizeof(mgx_gen), MGX_ABI_VERSION);
+    if (a->n_grids <= 0 || a->n_steps <= 0 || a->n_load_profiles <= 0 || a->n_pv_profiles <= 0 || a->n_co2_profiles < 0)
+        return fail(MGX_ERR_INVALID, "mgx_generate_columns: need n_grids, n_steps, n_load_profiles, n_pv_profiles > 0");
+    if (a->n_load_profiles > 255 || a->n_pv_profiles > 255 || a->n_co2_profiles > 255)
+        return fail(MGX_ERR_INVALID, "mgx_generate_columns: profile ids are bytes");
+    if (!a->base_load || !a->load_max || !a->pv_max || !a->load_bound_max || !a->pv_bound_max || a->n_mean_rows <= 0)
+        return fail(MGX_ERR_INVALID, "mgx_generate_columns: NULL base_load / load_max / pv_max / *_bound_max, or n_mean_rows <= 0");
+    if ((a->grid_lo || a->grid_hi) && a->n_co2_profiles > 0 && (!a->co2_min || !a->co2_max))
+        return fail(MGX_ERR_INVALID, "mgx_generate_columns: grid bounds requested without co2_min / co2_max");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(MGX_ERR_DEVICE, "mgx_generate_columns: no HIP device available -- this engine has no CPU path");
+    generate_columns_kernel<<<blocks_for(a->n_grids), BLOCK, 0, (hipStream_t)stream>>>(*a);
+    e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "generate_columns_kernel launch");
 }
 
 int mgx_normalise_series(mgx_handle *h, void *load_n, void *pv_n, void *grid_n, int32_t *clipped, mgx_stream stream)

@@ -47,6 +47,29 @@ __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict_
         if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * NSTATE, 0);
         else observe_state_cols<F>(a, p, s, (double *)obs + i * NSTATE, 0);
     } else if (a.obs_state_only) {          // the window columns of this row were prefetched (obs_windows_k_kernel)
+#ifdef MGX_EXP_COMPACT_PATCH                // TIMING EXPERIMENT ONLY (wrong rows): what do the partial-line state patches cost?
+        if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * NSTATE, 0);
+        else observe_state_cols<F>(a, p, s, (double *)obs + i * NSTATE, 0);
+        return;
+#endif
+#ifdef MGX_EXP_LINE_PATCH                   // TIMING EXPERIMENT ONLY (junk neighbours): the step writes the WHOLE 128-byte line(s) that
+        if (!a.obs_f32) {                   // hold its state bytes; the ahead refills leave exactly those lines unwritten
+            const int32_t cs = (F & F_GENSET) ? ((F & F_BATTERY) ? (a.col_gen < a.col_bat ? a.col_gen : a.col_bat) : a.col_gen) : a.col_bat;
+            const int64_t g = i * a.obs_dim + cs;
+            const int64_t e0 = (g >> 4) << 4, e1 = ((g + NSTATE - 1) >> 4) << 4;
+            double st[6] = {0, 0, 0, 0, 0, 0};
+            observe_state_cols<F>(a, p, s, st, 0);
+            typedef double vec2 __attribute__((ext_vector_type(2)));
+            double *base = (double *)obs;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { vec2 v; v.x = st[j % NSTATE]; v.y = st[(j + 1) % NSTATE]; *reinterpret_cast<vec2 *>(base + e0 + 2 * j) = v; }
+            if (e1 != e0) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) { vec2 v; v.x = st[j % NSTATE]; v.y = st[(j + 1) % NSTATE]; *reinterpret_cast<vec2 *>(base + e1 + 2 * j) = v; }
+            }
+            return;
+        }
+#endif
         if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
         else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
     } else if (a.obs_f32) observe_row_h0<F>(a, i, t_next, p, s, (float *)obs + i * a.obs_dim, pm);
@@ -76,10 +99,16 @@ __device__ __forceinline__ int32_t episode_tail(const KArgs &a, int64_t i, int32
 
 // body of one step of grid i (shared by step_kernel and fleet_step_kernel).  EP: in-place per-grid episodes (the grid's series
 // row is counter + ep_off[i]; a compile-time form so that the lock-step kernel carries none of it)
+// what a step leaves behind for a caller that goes on to write the grid's observation row itself (rows_body)
+struct StepResult {
+    Params p;
+    State s;
+};
+
 template <int F, bool EP = false>
 __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict__ actions, int32_t t, int normalized,
                                           double *__restrict__ reward, uint8_t *__restrict__ done, void *__restrict__ obs,
-                                          double *__restrict__ log, int64_t i)
+                                          double *__restrict__ log, int64_t i, StepResult *res = nullptr)
 {
     // all loads first (independent, one latency round), then the arithmetic
     Params p; State s; Inputs in; Outputs o; Derived d;
@@ -106,6 +135,7 @@ __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
     // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
     if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, pm);
+    if (res) { res->p = p; res->s = s; }
 }
 
 template <int F, bool EP = false>
@@ -750,17 +780,39 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     constexpr int KW = OBS_K_THREADS / 64;
     const int64_t block_stride = (int64_t)plan.pitch * D;
     OT *out0 = ring + ((int64_t)wave * plan.pitch + g0) * D;
+    // MGX_WIN_SKIP_STATE=1 (experiment, OFF): a ring written ahead of the counter would leave the state columns alone -- the
+    // step that reaches a block writes them, so the zeros here are bytes written twice, 3 % of a config-5 fleet step.  Measured
+    // 10-25 % SLOWER (profiles/r04/exp_fleet_state_holes_ab.txt: 31 -> 34 us per fleet step at K = 16, 29 -> 36 us at K = 32):
+    // a 48-byte hole per row turns 1.25 of its 9.75 lines into partial-line writes, and those cost far more than the bytes
+    // they save.  (The state blocks start on even columns in both flat orders: a 16-byte pair is all state or all window.)
+#ifndef MGX_WIN_SKIP_STATE
+#define MGX_WIN_SKIP_STATE 0
+#endif
+    const bool skip_state = !have_now && MGX_WIN_SKIP_STATE;
     if (wide) {                                          // element pair f, f + 1 = 2 lane + 128 j -> (row, column)
         int32_t r = 2 * lane / D, c = 2 * lane - r * D;
         for (int32_t f = 2 * lane; f < total; f += 128) {
-            const double *s0 = image + r * BP + map[c] + wave;
-            const double *s1 = image + r * BP + map[c + 1] + wave;     // D even, c even: the pair never straddles two rows
-            OT *out = out0 + f;
-            for (int32_t k = wave; k < K; k += KW) {
-                vec2 v2;
-                v2.x = (OT)*s0; v2.y = (OT)*s1;
-                MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out));
-                s0 += KW; s1 += KW; out += KW * block_stride;
+            const uint32_t m0 = map[c], m1 = map[c + 1];               // D even, c even: the pair never straddles two rows
+#ifdef MGX_EXP_LINE_PATCH
+            bool hole = false;
+            if (!have_now && sizeof(OT) == 8) {
+                const int32_t cs = a.n_genset ? (a.n_battery ? (a.col_gen < a.col_bat ? a.col_gen : a.col_bat) : a.col_gen) : a.col_bat;
+                const int64_t gi = (g0 + r) * D + c, l0 = (gi >> 4) << 4;          // first element of this pair's line
+                const int64_t q1 = (l0 + 15 - cs) / D;                             // last row whose state starts at or before the line's end
+                hole = (l0 + 15 - cs) >= 0 && q1 < N && q1 * D + cs + nstate - 1 >= l0;
+            }
+            if (!hole)
+#endif
+            if (!(skip_state && m0 >= (uint32_t)S0)) {
+                const double *s0 = image + r * BP + m0 + wave;
+                const double *s1 = image + r * BP + m1 + wave;
+                OT *out = out0 + f;
+                for (int32_t k = wave; k < K; k += KW) {
+                    vec2 v2;
+                    v2.x = (OT)*s0; v2.y = (OT)*s1;
+                    MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out));
+                    s0 += KW; s1 += KW; out += KW * block_stride;
+                }
             }
             c += 128;
             while (c >= D) { c -= D; r++; }
@@ -768,11 +820,14 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     } else {
         int32_t r = lane / D, c = lane - r * D;
         for (int32_t f = lane; f < total; f += 64) {
-            const double *s0 = image + r * BP + map[c] + wave;
-            OT *out = out0 + f;
-            for (int32_t k = wave; k < K; k += KW) {
-                MGX_WIN_STORE((OT)*s0, out);
-                s0 += KW; out += KW * block_stride;
+            const uint32_t m0 = map[c];
+            if (!(skip_state && m0 >= (uint32_t)S0)) {
+                const double *s0 = image + r * BP + m0 + wave;
+                OT *out = out0 + f;
+                for (int32_t k = wave; k < K; k += KW) {
+                    MGX_WIN_STORE((OT)*s0, out);
+                    s0 += KW; out += KW * block_stride;
+                }
             }
             c += 64;
             while (c >= D) { c -= D; r++; }
@@ -915,7 +970,7 @@ template <int F, bool EP = false>
 __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords &tab, const int32_t *__restrict__ action_id,
                                                    int32_t t, double *__restrict__ control, double *__restrict__ reward,
                                                    uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                   double *__restrict__ log, int64_t i)
+                                                   double *__restrict__ log, int64_t i, StepResult *res = nullptr)
 {
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
     const int64_t N = a.N;
@@ -954,6 +1009,7 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     if (log) store_log<F>(log + i, N, o, s.status);
     if constexpr (EP) off = episode_tail<F>(a, i, t, off, dn != 0, p, s);
     if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, EP ? a.pm_pitch : 0);
+    if (res) { res->p = p; res->s = s; }
 }
 
 // Dry run of one discrete step (mgx_check_discrete): the expansion and the step on a register copy of the state; only the mask
@@ -1100,6 +1156,254 @@ static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArg
         default: step_body<15>(a, actions, t, fa.normalized, reward, done, obs, log, i); break;
     }
 #undef MGX_FLEET_CASE
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Step + observation ROW in one launch, for factorised series (mgx_step / mgx_fleet_step with a forecast horizon and whole
+// rows wanted): DiscreteMicrogridEnv.step / BaseMicrogridEnv.step as the reference returns them -- (obs [N, D], reward, done) --
+// with every byte of the row written ONCE, by whole 128-byte lines.
+//
+// Why not rings here.  With [T, N] series a window value costs an HBM read, so the rows of the next K steps are written ahead
+// from one pass over the series (obs_windows_k_kernel) and the step only adds its state columns -- 48 bytes per row at a
+// 1 248-byte stride: 100 000 scattered line-granular writes per fleet step, measured at 3.5-4 us of a 24-us config-5 step
+// (profiles/r04/exp_fleet_state_patch_cost.txt; leaving holes for them in the refill stream is worse still,
+// exp_fleet_state_holes_ab.txt, and so is a whole-line rewrite from the step, exp_fleet_line_patch_emulation.txt).  With
+// FACTORISED series the window source is a few cache-resident base rows: nothing is gained by sharing them across steps, so
+// the workgroup that steps 16 grids also forms their 16 rows -- state columns included -- in an LDS tile and streams the tile
+// out as one contiguous 16 * D * 8-byte region (16-byte non-temporal stores).  No rings (12 GB at K = 32), no prefetch
+// streams, no second writer per row: HBM traffic == the algorithmic bytes.
+//
+// Workgroup = 256 threads around 64 grids.  Wave 0 runs the step of the 64 grids, one lane each (step_body /
+// step_discrete_body, unchanged: one latency chain per 64 grids) and leaves their 6 state columns in LDS; the rows leave in
+// four tiles of 16 grids: thread (g, q) normalises its share of grid g's 6 (1 + H) window values (component compile-time,
+// horizon steps h = q', q' + Q, ... with q' rotated per component so that the split of a 25-step window over Q threads
+// evens out) -- the first tile by waves 1-3 alone, beside the step.  Base rows t + 1 .. t + 1 + H of the load / pv / co2
+// tables are staged in LDS once per workgroup (64 B per row and table).  Same arithmetic as every other observation kernel
+// (obs_series_value), hence the same bits.
+// ------------------------------------------------------------------------------------------------------
+constexpr int ROWS_G = 64;            // grids per workgroup: one full wave steps them
+constexpr int ROWS_TILE = 16;         // grids per LDS row tile (4 tiles per workgroup, one after the other)
+constexpr int ROWS_THREADS = 256;
+constexpr int ROWS_GP = 14;           // per-grid doubles kept in LDS: lo[6], hi[6], load ratio, pv ratio
+
+// LDS of a rows workgroup: tile [16][ld] of OT | state columns [64][6] of OT | per-grid window parameters [14][64] doubles,
+// outage words [2][64], profile ids [64] | base rows [3][W][PP] doubles
+__host__ __device__ inline size_t rows_lds_bytes(int32_t D, int32_t H, size_t esz)
+{
+    const size_t tile = ((size_t)ROWS_TILE * (size_t)(D | 1) * esz + 15) & ~(size_t)15;
+    const size_t st = ((size_t)ROWS_G * 6 * esz + 15) & ~(size_t)15;
+    const size_t gp = (size_t)(ROWS_GP + 2) * ROWS_G * sizeof(double) + (size_t)ROWS_G * sizeof(uint32_t) * 2;
+    return tile + st + gp + (size_t)3 * (size_t)(1 + H) * PP * sizeof(double);
+}
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global store in flight (vmcnt counts
+// stores on gfx9) -- here that would put the full write latency of a row tile between two tiles
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int F, typename OT>
+__device__ __forceinline__ void rows_body(const KArgs &a, const PLWords *__restrict__ tab, const void *__restrict__ actions, int32_t t,
+                                          int normalized, double *__restrict__ reward, uint8_t *__restrict__ done,
+                                          OT *__restrict__ obs, double *__restrict__ log, int64_t group, double *lds_raw)
+{
+    constexpr bool GRID = (F & F_GRID) != 0;
+    constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
+    constexpr int NC = GRID ? 6 : 2;
+    const int tid = threadIdx.x;
+    const int64_t N = a.N;
+    const int64_t g0 = group * ROWS_G;
+    const int32_t W = 1 + a.H, D = a.obs_dim, LD = D | 1, T = a.T;
+    const int32_t t1 = t + 1;                                      // the observation after the step (base.py:205-209)
+    const size_t tile_b = ((size_t)ROWS_TILE * LD * sizeof(OT) + 15) & ~(size_t)15, st_b = ((size_t)ROWS_G * 6 * sizeof(OT) + 15) & ~(size_t)15;
+    char *lp = reinterpret_cast<char *>(lds_raw);
+    OT *tile = reinterpret_cast<OT *>(lp);
+    OT *st = reinterpret_cast<OT *>(lp + tile_b);                                                  // [64][6]: genset 4, battery 2
+    double *gp = reinterpret_cast<double *>(lp + tile_b + st_b);                                   // [14][64]
+    uint64_t *gw = reinterpret_cast<uint64_t *>(gp + ROWS_GP * ROWS_G);                            // [2][64] outage words
+    uint32_t *gid = reinterpret_cast<uint32_t *>(gw + 2 * ROWS_G);                                 // [64] lp | pp << 8 | cp << 16 | pat << 24
+    double *base = reinterpret_cast<double *>(gid + 2 * ROWS_G);                                   // [3][W][PP]
+    const mgx_columns &c = a.c;
+    const int64_t w0 = (int64_t)(t1 < T ? t1 : T - 1) >> 6;
+
+    // (1) everything the window values need, once per workgroup: base rows t1 .. t1 + H (clamped into the series; rows past its
+    // end are padding and never used) and the 64 grids' bounds / factors / outage words (coalesced along the grids)
+    for (int32_t j = tid; j < W * PP; j += ROWS_THREADS) {
+        const int32_t h = j / PP, pcol = j - h * PP;
+        const int64_t row = (t1 + h < T) ? (int64_t)(t1 + h) : (int64_t)T - 1;
+        base[j] = c.base_load[row * PP + pcol];
+        base[W * PP + j] = c.base_pv[row * PP + pcol];
+        if constexpr (GRID) base[2 * W * PP + j] = c.base_co2[row * PP + pcol];
+    }
+    {
+        const int32_t gi = tid & (ROWS_G - 1), part = tid >> 6;       // 4 threads per grid, each a quarter of its fields
+        const int64_t i = g0 + gi, ic = i < N ? i : N - 1;
+        if (part == 0) {
+            gp[0 * ROWS_G + gi] = c.load_lo[ic]; gp[6 * ROWS_G + gi] = c.load_hi[ic];
+            gp[1 * ROWS_G + gi] = c.pv_lo[ic]; gp[7 * ROWS_G + gi] = c.pv_hi[ic];
+        } else if (part == 1) {
+            gp[12 * ROWS_G + gi] = c.load_ratio[ic]; gp[13 * ROWS_G + gi] = c.pv_ratio[ic];
+            uint32_t ids = (uint32_t)c.load_profile[ic] | ((uint32_t)c.pv_profile[ic] << 8);
+            if constexpr (GRID) ids |= ((uint32_t)c.co2_profile[ic] << 16) | ((uint32_t)c.tariff[ic] << 24);
+            gid[gi] = ids;
+        } else if (part == 2) {
+            if constexpr (GRID) {
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) gp[(2 + cc) * ROWS_G + gi] = c.grid_lo[cc * N + ic];
+            }
+        } else {
+            if constexpr (GRID) {
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) gp[(8 + cc) * ROWS_G + gi] = c.grid_hi[cc * N + ic];
+                uint64_t o0 = 0, o1 = 0;
+                if (c.outage_bits) {
+                    o0 = c.outage_bits[w0 * N + ic];
+                    if ((w0 + 1) * 64 < T) o1 = c.outage_bits[(w0 + 1) * N + ic];
+                }
+                gw[gi] = o0; gw[ROWS_G + gi] = o1;
+            }
+        }
+    }
+    __syncthreads();
+    // (2) wave 0: the step of the 64 grids (one lane each: step_body / step_discrete_body, unchanged), state columns -> LDS
+    if (tid < ROWS_G) {
+        const int64_t i = g0 + tid;
+        if (i < N) {
+            StepResult res;
+            if (tab != nullptr) step_discrete_body<F>(a, *tab, (const int32_t *)actions, t, nullptr, reward, done, nullptr, log, i, &res);
+            else step_body<F>(a, actions, t, normalized, reward, done, nullptr, log, i, &res);
+            observe_state_cols<F, OT>(a, res.p, res.s, st + tid * 6, 0);
+        }
+    }
+    // (3) four row tiles of 16 grids.  Thread (g = u & 15, q = u >> 4) forms grid g's window values at horizon steps h = q', q' + Q,
+    // ... (q' rotated per component).  Tile 0 is formed by waves 1-3 alone (Q = 12) while wave 0 is busy with the step.  Nothing
+    // in this loop reads global memory: the tile's stores stay in flight while the next tile is formed (lds_barrier).
+    for (int32_t s = 0; s < ROWS_G / ROWS_TILE; s++) {
+        const int64_t r0 = g0 + (int64_t)s * ROWS_TILE;             // first grid of the tile
+        if (r0 >= N) break;                                         // (uniform)
+        const bool first = s == 0;
+        const int32_t u = first ? tid - ROWS_G : tid, Q = first ? (ROWS_THREADS - ROWS_G) / ROWS_TILE : ROWS_THREADS / ROWS_TILE;
+        if (u >= 0) {
+            const int32_t g = u & (ROWS_TILE - 1), q = u >> 4, gi = s * ROWS_TILE + g;
+            const uint32_t ids = gid[gi];
+            const double lr = gp[12 * ROWS_G + gi], pr = gp[13 * ROWS_G + gi];
+            OT *row = tile + g * LD;
+            auto window = [&](auto cc_tag) __attribute__((always_inline)) {
+                constexpr int cc = decltype(cc_tag)::value;
+                const double l = gp[cc * ROWS_G + gi], hh = gp[(6 + cc) * ROWS_G + gi];
+                const double fill = (hh + l) / 2, sp = space_spread(l, hh);
+                const int32_t col0 = cc == 0 ? a.col_load : (cc == 1 ? a.col_pv : a.col_grid + (cc - 2));
+                constexpr int stride = cc < 2 ? 1 : 4;
+                int32_t h = q + 9 * cc;
+                while (h >= Q) h -= Q;
+                for (; h < W; h += Q) {
+                    const bool in = t1 + h < T;
+                    double x;
+                    if constexpr (cc == 0) x = fact_load(base[h * PP + (ids & 0xffu)], lr);
+                    else if constexpr (cc == 1) x = fact_pv(base[W * PP + h * PP + ((ids >> 8) & 0xffu)], pr);
+                    else if constexpr (cc == 2) x = tariff_price((int32_t)(ids >> 24), t1 + h);
+                    else if constexpr (cc == 3) x = 0.0;
+                    else if constexpr (cc == 4) x = base[2 * W * PP + h * PP + ((ids >> 16) & 0xffu)];
+                    else {
+                        const int64_t r = in ? (int64_t)(t1 + h) : (int64_t)T - 1;
+                        uint64_t word = ((r >> 6) == w0) ? gw[gi] : gw[ROWS_G + gi];
+                        if ((r >> 6) > w0 + 1) {                       // horizons beyond 64 rows
+                            const int64_t i = r0 + g;
+                            word = c.outage_bits ? c.outage_bits[(r >> 6) * N + (i < N ? i : N - 1)] : 0;
+                        }
+                        x = ((word >> (r & 63)) & 1ull) ? 0.0 : 1.0;
+                    }
+                    row[col0 + stride * h] = (OT)obs_series_value(x, in, h > 0, l, hh, fill, sp);
+                }
+            };
+            window(std::integral_constant<int, 0>{});
+            window(std::integral_constant<int, 1>{});
+            if constexpr (GRID) {
+                window(std::integral_constant<int, 2>{}); window(std::integral_constant<int, 3>{});
+                window(std::integral_constant<int, 4>{}); window(std::integral_constant<int, 5>{});
+            }
+        }
+        lds_barrier();                                              // windows of this tile formed -- and (first tile) the step done
+        if constexpr (NSTATE > 0) {                                 // the state columns of the tile's 16 grids, out of wave 0's LDS copy
+            if (tid < ROWS_TILE * NSTATE) {
+                const int32_t g = tid / NSTATE, j = tid - g * NSTATE;
+                int32_t col;
+                if constexpr ((F & F_GENSET) != 0) col = j < 4 ? a.col_gen + j : a.col_bat + (j - 4);
+                else col = a.col_bat + j;
+                tile[g * LD + col] = st[(s * ROWS_TILE + g) * 6 + j];
+            }
+            lds_barrier();
+        }
+        // the 16 rows are one contiguous region of obs: 16-byte non-temporal stores, whole lines
+        const int32_t n_valid = (N - r0 < ROWS_TILE) ? (int32_t)(N - r0) : ROWS_TILE;
+        const int32_t total = n_valid * D;               // D is even (one load, one renewable module)
+        OT *out = obs + r0 * D;
+        typedef OT vec2 __attribute__((ext_vector_type(2)));
+        if ((reinterpret_cast<uintptr_t>(out) & (sizeof(vec2) - 1)) == 0) {
+            int32_t r = 2 * tid / D, cidx = 2 * tid - r * D;
+            for (int32_t e = 2 * tid; e < total; e += 2 * ROWS_THREADS) {
+                vec2 v2;
+                v2.x = tile[r * LD + cidx];
+                v2.y = tile[r * LD + cidx + 1];
+                __builtin_nontemporal_store(v2, reinterpret_cast<vec2 *>(out + e));
+                cidx += 2 * ROWS_THREADS;
+                while (cidx >= D) { cidx -= D; r++; }
+            }
+        } else {
+            int32_t r = tid / D, cidx = tid - r * D;
+            for (int32_t e = tid; e < total; e += ROWS_THREADS) {
+                __builtin_nontemporal_store(tile[r * LD + cidx], out + e);
+                cidx += ROWS_THREADS;
+                while (cidx >= D) { cidx -= D; r++; }
+            }
+        }
+        lds_barrier();                                              // the tile has been read: free for the next one
+    }
+}
+
+// One launch for every batch of a fleet (or for one batch: mgx_step): block0[q] = first workgroup of batch q.
+struct FleetRows {
+    const KArgs *k[MGX_FLEET_MAX];
+    const PLWords *tab[MGX_FLEET_MAX];
+    const void *actions[MGX_FLEET_MAX];
+    double *reward[MGX_FLEET_MAX];
+    uint8_t *done[MGX_FLEET_MAX];
+    void *obs[MGX_FLEET_MAX];
+    double *log[MGX_FLEET_MAX];
+    int32_t t[MGX_FLEET_MAX], flags[MGX_FLEET_MAX], block0[MGX_FLEET_MAX];
+    int32_t n, normalized;
+};
+
+static __global__ __launch_bounds__(ROWS_THREADS) void fleet_rows_kernel(const FleetRows fa)
+{
+    extern __shared__ double rows_lds[];
+    const KArgs *kp = fa.k[0];
+    const PLWords *tp = fa.tab[0];
+    const void *actions = fa.actions[0];
+    double *reward = fa.reward[0]; uint8_t *done = fa.done[0]; void *obs = fa.obs[0]; double *log = fa.log[0];
+    int32_t t = fa.t[0], flags = fa.flags[0], block0 = 0;
+#pragma unroll
+    for (int q = 1; q < MGX_FLEET_MAX; q++) {
+        const bool mine = q < fa.n && (int)blockIdx.x >= fa.block0[q];
+        kp = mine ? fa.k[q] : kp; tp = mine ? fa.tab[q] : tp;
+        actions = mine ? fa.actions[q] : actions; reward = mine ? fa.reward[q] : reward;
+        done = mine ? fa.done[q] : done; obs = mine ? fa.obs[q] : obs; log = mine ? fa.log[q] : log;
+        t = mine ? fa.t[q] : t; flags = mine ? fa.flags[q] : flags; block0 = mine ? fa.block0[q] : block0;
+    }
+    const KArgs &a = *kp;
+    const int64_t group = (int64_t)((int)blockIdx.x - block0);
+#define MGX_ROWS_CASE(FV)                                                                                                      \
+    case FV:                                                                                                                   \
+        if (a.obs_f32) rows_body<FV, float>(a, tp, actions, t, fa.normalized, reward, done, (float *)obs, log, group, rows_lds); \
+        else rows_body<FV, double>(a, tp, actions, t, fa.normalized, reward, done, (double *)obs, log, group, rows_lds);        \
+        break;
+    switch (flags) {
+        MGX_ROWS_CASE(1) MGX_ROWS_CASE(2) MGX_ROWS_CASE(3) MGX_ROWS_CASE(4) MGX_ROWS_CASE(5) MGX_ROWS_CASE(6) MGX_ROWS_CASE(7)
+        MGX_ROWS_CASE(14) MGX_ROWS_CASE(15)
+        default:
+            if (a.obs_f32) rows_body<0, float>(a, tp, actions, t, fa.normalized, reward, done, (float *)obs, log, group, rows_lds);
+            else rows_body<0, double>(a, tp, actions, t, fa.normalized, reward, done, (double *)obs, log, group, rows_lds);
+            break;
+    }
+#undef MGX_ROWS_CASE
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1732,6 +2036,133 @@ static __global__ __launch_bounds__(BLOCK) void synthesize_series_kernel(const m
             if ((t & 63) == 0) { a.outage_bits[(int64_t)(t >> 6) * N + i] = word; word = 0; }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// MicrogridGenerator's draws and sizing rules (mgx_generate_columns; include/mgx.h has the rule list with the reference lines).
+// One lane per grid.  The only loop is the mean of the scaled load series: T products summed in numpy's pairwise order
+// (DOUBLE_pairwise_sum: blocks of <= 128 with eight interleaved partial sums, halves split at multiples of 8), so that
+// ceil(hours x mean) lands on the integer the reference's pandas / numpy arithmetic gives.
+// ------------------------------------------------------------------------------------------------------
+enum GenQuantity : int32_t {      // Philox counter word 2: one id per drawn quantity (the normals take 12 consecutive ids each)
+    GQ_BIN = 0, GQ_SIZE_LOAD, GQ_LOAD_FILE, GQ_PV_PEN, GQ_BAT_HOURS, GQ_PV_FILE, GQ_WEAK, GQ_TARIFF, GQ_OUTAGE_DUR, GQ_CO2_FILE,
+    GQ_SU, GQ_WD, GQ_SOC0_NORMAL = 16, GQ_OUTAGE_NORMAL = 32
+};
+constexpr uint64_t GEN_SEED_SALT = 0x9E3779B97F4A7C15ull;
+
+__device__ __forceinline__ int32_t gen_randint(uint64_t seed, int64_t gi, int32_t q, int32_t lo, int32_t hi)
+{
+    const int32_t span = hi - lo;
+    const int32_t k = (int32_t)floor(synth_uniform(seed, gi, q) * (double)span);
+    return lo + (k < span - 1 ? k : span - 1);
+}
+
+// sum of 12 uniforms - 6: additions only, left to right
+__device__ __forceinline__ double gen_normal(uint64_t seed, int64_t gi, int32_t q0)
+{
+    double acc = 0.0;
+    for (int j = 0; j < 12; j++) acc += synth_uniform(seed, gi, q0 + j);
+    return acc - 6.0;
+}
+
+// numpy's pairwise sum of col[k * stride] * ratio, k < n
+__device__ inline double gen_pairwise_products(const double *__restrict__ col, int64_t stride, int32_t n, double ratio)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int32_t k = 0; k < n; k++) res += col[(int64_t)k * stride] * ratio;
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = col[(int64_t)j * stride] * ratio;
+        int32_t k;
+        for (k = 8; k < n - (n % 8); k += 8)
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] += col[(int64_t)(k + j) * stride] * ratio;
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; k < n; k++) res += col[(int64_t)k * stride] * ratio;
+        return res;
+    }
+    int32_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return gen_pairwise_products(col, stride, n2, ratio) + gen_pairwise_products(col + (int64_t)n2 * stride, stride, n - n2, ratio);
+}
+
+static __global__ __launch_bounds__(BLOCK) void generate_columns_kernel(const mgx_gen a)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.n_grids) return;
+    const int64_t N = a.n_grids;
+    const int64_t gi = a.grid_index ? a.grid_index[i] : a.grid_index0 + i;
+    const uint64_t seed = a.seed ^ GEN_SEED_SALT;
+    // the draws
+    const double bin = synth_uniform(seed, gi, GQ_BIN);
+    const int32_t size_load = gen_randint(seed, gi, GQ_SIZE_LOAD, 100, 100001);
+    const int32_t lf = gen_randint(seed, gi, GQ_LOAD_FILE, 0, a.n_load_profiles);
+    const int32_t pv_pen = gen_randint(seed, gi, GQ_PV_PEN, 30, 151);
+    const int32_t hours = gen_randint(seed, gi, GQ_BAT_HOURS, 3, 6);
+    const int32_t pf = gen_randint(seed, gi, GQ_PV_FILE, 0, a.n_pv_profiles);
+    const int32_t weak = gen_randint(seed, gi, GQ_WEAK, 0, 2);
+    const int32_t tariff = gen_randint(seed, gi, GQ_TARIFF, 1, 3);
+    const int32_t odur = gen_randint(seed, gi, GQ_OUTAGE_DUR, 1, 8);
+    const int32_t cf = a.n_co2_profiles > 0 ? gen_randint(seed, gi, GQ_CO2_FILE, 0, a.n_co2_profiles) : 0;
+    const int32_t su = a.mixed_timers ? gen_randint(seed, gi, GQ_SU, 0, 4) : 0;
+    const int32_t wd = a.mixed_timers ? gen_randint(seed, gi, GQ_WD, 0, 4) : 0;
+    const double soc_n = gen_normal(seed, gi, GQ_SOC0_NORMAL), out_n = gen_normal(seed, gi, GQ_OUTAGE_NORMAL);
+    // the rules (generator.derive has the same lines in numpy)
+    const double load_ratio = (double)size_load / a.load_max[lf];                 // _scale_ts 'max' (:137-147)
+    const double load_peak = a.load_max[lf] * load_ratio;                         // max of the scaled series
+    const double pv_size = load_peak * ((double)pv_pen / 100);                    // _size_mg (:357)
+    const double pv_ratio = pv_size / a.pv_max[pf];
+    const double mean_load = gen_pairwise_products(a.base_load + lf, a.n_load_profiles, a.n_mean_rows, load_ratio) / (double)a.n_mean_rows;
+    const double cap = ceil((double)hours * mean_load);                          // _size_battery (:382-386)
+    const double power = ceil(cap / 4);                                          // _get_battery (:230-243), duration 4
+    const double soc0 = fmin(fmax(soc_n, 0.2), 1.0);                             // min(max(randn, soc_min), soc_max)
+    const double rated = ceil(load_peak / 0.9);                                  // _size_genset (:372-379)
+    const double grid_power = floor(load_peak * 2);                              // int(max(load.values) * 2) (:364)
+    // architecture (:417-435, :535-538)
+    bool genset = bin < 0.33 || bin >= 0.66;
+    const bool grid = bin >= 0.33;
+    genset = genset || (grid && weak != 0);
+    if (a.arch) a.arch[i] = (uint8_t)(genset && grid ? 2 : (grid ? 1 : 0));
+    if (a.load_profile) a.load_profile[i] = (uint8_t)lf;
+    if (a.pv_profile) a.pv_profile[i] = (uint8_t)pf;
+    if (a.co2_profile) a.co2_profile[i] = (uint8_t)cf;
+    if (a.tariff) a.tariff[i] = (uint8_t)tariff;
+    if (a.weak) a.weak[i] = weak;
+    if (a.outage_duration) a.outage_duration[i] = odur;
+    if (a.outage_per_day) a.outage_per_day[i] = out_n * 3 / 4 + 0.25;            // _get_grid (:291)
+    if (a.load_ratio) a.load_ratio[i] = load_ratio;
+    if (a.pv_ratio) a.pv_ratio[i] = pv_ratio;
+    if (a.load_lo) a.load_lo[i] = -(a.load_bound_max[lf] * load_ratio);          // stored sign: load <= 0 (bounds :81-88)
+    if (a.load_hi) a.load_hi[i] = 0.0;
+    if (a.pv_lo) a.pv_lo[i] = 0.0;
+    if (a.pv_hi) a.pv_hi[i] = a.pv_bound_max[pf] * pv_ratio;
+    // (the status component: 1 = never out; the caller lowers it where the outage words say otherwise)
+    if (a.grid_lo) { a.grid_lo[i] = a.tariff_min[tariff]; a.grid_lo[N + i] = 0.0; a.grid_lo[2 * N + i] = a.co2_min ? a.co2_min[cf] : 0.0; a.grid_lo[3 * N + i] = 1.0; }
+    if (a.grid_hi) { a.grid_hi[i] = a.tariff_max[tariff]; a.grid_hi[N + i] = 0.0; a.grid_hi[2 * N + i] = a.co2_max ? a.co2_max[cf] : 0.0; a.grid_hi[3 * N + i] = 1.0; }
+    if (a.bat_max_capacity) a.bat_max_capacity[i] = cap;
+    if (a.bat_min_capacity) a.bat_min_capacity[i] = cap * 0.2;                   // get_battery_module: capacity * soc_min
+    if (a.bat_max_charge) a.bat_max_charge[i] = power;
+    if (a.bat_max_discharge) a.bat_max_discharge[i] = power;
+    if (a.soc) a.soc[i] = soc0;
+    if (a.charge) a.charge[i] = soc0 * cap;                                      // battery_module.py:96-106
+    if (a.gen_running_min) a.gen_running_min[i] = 0.05 * rated;                  // get_genset_module: p_min * rated_power
+    if (a.gen_running_max) a.gen_running_max[i] = 0.9 * rated;
+    if (a.gen_times) a.gen_times[i] = (uint32_t)su | ((uint32_t)wd << 16);
+    if (a.gen_status) a.gen_status[i] = 1u | (1u << 8) | ((uint32_t)wd << 24);   // initially on: steps_until_down = wind_down_time
+    if (a.grid_max_import) a.grid_max_import[i] = grid_power;
+    if (a.grid_max_export) a.grid_max_export[i] = grid_power;
+    if (a.d_bin_rand) a.d_bin_rand[i] = bin;
+    if (a.d_soc0_normal) a.d_soc0_normal[i] = soc_n;
+    if (a.d_outage_normal) a.d_outage_normal[i] = out_n;
+    if (a.d_size_load) a.d_size_load[i] = size_load;
+    if (a.d_pv_pen) a.d_pv_pen[i] = pv_pen;
+    if (a.d_bat_hours) a.d_bat_hours[i] = hours;
+    if (a.d_su) a.d_su[i] = su;
+    if (a.d_wd) a.d_wd[i] = wd;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -113,6 +113,10 @@ class StepEngine:
         check(self._lib.mgx_set_action_format(self._h, 1 if dtype == torch.float32 else 0))
         self.action_dtype = dtype
 
+    def set_rows_direct(self, flag):
+        """``mgx_set_rows_direct``: step + whole observation row in one launch (factorised series, forecast horizon, no rings)."""
+        check(self._lib.mgx_set_rows_direct(self._h, 1 if flag else 0))
+
     def set_obs_state_only(self, flag):
         """True: the ``obs`` output of step / step_discrete / observe / reset receives only the genset / battery state
         columns -- the window columns of that row were written ahead of time by ``observe_windows``."""

@@ -108,7 +108,7 @@ class BatchedMicrogridEnv:
 
     def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
                  raise_errors=False, observation_keys=None, obs_dtype=torch.float64, obs_prefetch=None,
-                 action_dtype=torch.float64, obs_views=False, reuse_outputs=0):
+                 action_dtype=torch.float64, obs_views=False, reuse_outputs=0, obs_direct=False):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
         # raise_errors=True (base_module.py:79-93): every step is preceded by its dry run (mgx_check_step: the violations
@@ -141,6 +141,14 @@ class BatchedMicrogridEnv:
             if not observations or L.multi or noisy or observation_keys:
                 raise ValueError("obs_views needs observations=True, one module of every kind per grid, the oracle forecaster "
                                  "and no observation_keys")
+            obs_prefetch = 0
+        # obs_direct=True (factorised series, forecast horizon): no rings -- the stepping launch itself forms and writes every
+        # row (mgx_set_rows_direct: one launch per step instead of two; what small batches want, fp64-issue bound at 100 000 grids)
+        if obs_direct:
+            if not batch.factorised or L.multi or noisy or obs_views or not observations:
+                raise ValueError("obs_direct needs factorised series, one module of every kind per grid, the oracle forecaster, "
+                                 "observations=True and no obs_views")
+            self.engine.set_rows_direct(True)
             obs_prefetch = 0
         self._prefetch_ok = bool(observations and L.horizon > 0 and not L.multi and not noisy)
         self._obs_dtype = obs_dtype
@@ -713,10 +721,11 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
 
     def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
                  trajectory_func=None, raise_errors=False, observation_keys=None, obs_dtype=torch.float64,
-                 obs_prefetch=None, obs_views=False, reuse_outputs=0, check_asserts=False):
+                 obs_prefetch=None, obs_views=False, reuse_outputs=0, check_asserts=False, obs_direct=False):
         super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
                          trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
-                         obs_dtype=obs_dtype, obs_prefetch=obs_prefetch, obs_views=obs_views, reuse_outputs=reuse_outputs)
+                         obs_dtype=obs_dtype, obs_prefetch=obs_prefetch, obs_views=obs_views, reuse_outputs=reuse_outputs,
+                         obs_direct=obs_direct)
         # check_asserts=True (implied by raise_errors=True): DiscreteMicrogridEnv.step gives up with an AssertionError in a few
         # states whatever raise_errors says -- _populate_action's asserts (priority_list.py:73,121,124,135,154: a lossy battery
         # rounded one ulp above max_capacity with load left to absorb) and the step's (base_module.py:272).  The device goes on

@@ -117,38 +117,70 @@ def derive(draws, profiles=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Draws: counter-based over the global grid index
+# Draws: counter-based over the GLOBAL grid index (mgx_generate_columns makes the same ones on the device)
 # ---------------------------------------------------------------------------------------------------------------------
-def draw_scalars(n_total, seed=42, mixed_timers=False):
-    """The per-grid random draws of MicrogridGenerator._create_microgrid for the GLOBAL batch (cheap: a few numbers per
-    grid), from one Philox stream per quantity -- not the reference's interleaved global stream."""
-    rs = np.random.Generator(np.random.Philox(key=seed))
+GEN_SEED_SALT = 0x9E3779B97F4A7C15
+# Philox counter word per drawn quantity (enum GenQuantity, csrc/mgx_kernels.hpp); a normal takes 12 consecutive ids
+GQ = dict(bin_rand=0, size_load=1, load_file=2, pv_pen=3, bat_hours=4, pv_file=5, weak=6, tariff=7, outage_dur=8, co2_file=9,
+          su=10, wd=11, soc0_randn=16, outage_randn=32)
+
+
+def draw_scalars(gidx, seed=42, mixed_timers=False, n_load_profiles=5, n_pv_profiles=5, n_co2_profiles=2):
+    """The per-grid random draws of MicrogridGenerator._create_microgrid for the grids with GLOBAL indices ``gidx``: every
+    quantity of every grid is its own Philox4x32-10 counter (seed ^ salt; grid index, quantity id) -- the host mirror of the
+    device kernel behind ``mgx_generate_columns``, bit for bit (tests/test_generator_rules.py), used on CPU devices.  A grid's
+    draws depend on its global index only: shards of any size and order agree.
+    randint(lo, hi) = lo + floor(u (hi - lo)); a standard normal = the sum of 12 uniforms - 6 (Irwin-Hall: additions only, so
+    host and device need not share a libm to agree)."""
+    gidx = np.asarray(gidx, dtype=np.int64)
+    key = (int(seed) ^ GEN_SEED_SALT) & (2 ** 64 - 1)
+
+    def uni(q):
+        return synth_uniform_host(key, gidx, np.full(gidx.shape, q, dtype=np.int64))
+
+    def randint(q, lo, hi):
+        span = hi - lo
+        return lo + np.minimum(np.floor(uni(q) * float(span)).astype(np.int64), span - 1)
+
+    def normal(q0):
+        acc = np.zeros(gidx.shape)
+        for k in range(12):
+            acc = acc + uni(q0 + k)
+        return acc - 6.0
     d = {}
-    d["bin_rand"] = rs.random(n_total)                                         # _bin_genset_grid (:417-435)
-    d["size_load"] = rs.integers(100, 100001, n_total)                         # _size_load (:437-441)
-    d["load_file"] = rs.integers(0, 5, n_total)
-    d["pv_pen"] = rs.integers(30, 151, n_total)                                # _size_mg (:357)
-    d["bat_hours"] = rs.integers(3, 6, n_total)                                # _size_battery (:385)
-    d["pv_file"] = rs.integers(0, 5, n_total)
-    d["soc0_randn"] = rs.standard_normal(n_total)                              # _get_battery (:239)
-    d["weak"] = rs.integers(0, 2, n_total)                                     # rand_weak_grid (:535)
-    d["tariff"] = rs.integers(1, 3, n_total)                                   # price_scenario (:536)
-    d["outage_randn"] = rs.standard_normal(n_total)                            # _get_grid (:291)
-    d["outage_dur"] = rs.integers(1, 8, n_total)                               # (:292)
-    d["co2_file"] = rs.integers(0, 2, n_total)
-    d["su"] = rs.integers(0, 4, n_total) if mixed_timers else np.zeros(n_total, np.int64)
-    d["wd"] = rs.integers(0, 4, n_total) if mixed_timers else np.zeros(n_total, np.int64)
+    d["bin_rand"] = uni(GQ["bin_rand"])                                          # _bin_genset_grid (:417-435)
+    d["size_load"] = randint(GQ["size_load"], 100, 100001)                       # _size_load (:437-441)
+    d["load_file"] = randint(GQ["load_file"], 0, n_load_profiles)
+    d["pv_pen"] = randint(GQ["pv_pen"], 30, 151)                                 # _size_mg (:357)
+    d["bat_hours"] = randint(GQ["bat_hours"], 3, 6)                              # _size_battery (:385)
+    d["pv_file"] = randint(GQ["pv_file"], 0, n_pv_profiles)
+    d["soc0_randn"] = normal(GQ["soc0_randn"])                                   # _get_battery (:239)
+    d["weak"] = randint(GQ["weak"], 0, 2)                                        # rand_weak_grid (:535)
+    d["tariff"] = randint(GQ["tariff"], 1, 3)                                    # price_scenario (:536)
+    d["outage_randn"] = normal(GQ["outage_randn"])                               # _get_grid (:291)
+    d["outage_dur"] = randint(GQ["outage_dur"], 1, 8)                            # (:292)
+    d["co2_file"] = randint(GQ["co2_file"], 0, n_co2_profiles)
+    d["su"] = randint(GQ["su"], 0, 4) if mixed_timers else np.zeros(gidx.shape, np.int64)
+    d["wd"] = randint(GQ["wd"], 0, 4) if mixed_timers else np.zeros(gidx.shape, np.int64)
     return d
 
 
-def architecture_of(d):
+ARCH_NAMES = ("genset+battery", "battery+grid", "genset+battery+grid")       # the codes mgx_generate_columns writes
+
+
+def architecture_code(d):
     """MicrogridGenerator's architecture draw per grid (:417-435,535-538): rand < 0.33 genset only, < 0.66 grid only, else
-    both; a weak grid forces a genset.  Returns an array of ARCHS keys."""
+    both; a weak grid forces a genset.  Returns uint8 codes into ARCH_NAMES."""
     r, weak = d["bin_rand"], d["weak"].astype(bool)
     genset = (r < 0.33) | (r >= 0.66)
     grid = r >= 0.33
     genset = genset | (grid & weak)
-    return np.where(genset & grid, "genset+battery+grid", np.where(grid, "battery+grid", "genset+battery"))
+    return np.where(genset & grid, 2, np.where(grid, 1, 0)).astype(np.uint8)
+
+
+def architecture_of(d):
+    """... as an array of ARCHS keys."""
+    return np.asarray(ARCH_NAMES)[architecture_code(d)]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -181,53 +213,66 @@ def _tile_rows(profile, T):
     return np.concatenate([profile] * reps, axis=0)[:T]
 
 
-def _synthesize(dev, T, N, gidx, seed, d, r, P, has_grid):
-    """load_ts [T, N], pv_ts [T, N], grid_ts [T, 4, N] (or None) for the grids with GLOBAL indices gidx [N]."""
-    f64 = dict(dtype=torch.float64, device=dev)
+def _synthesize_host(T, N, gidx, seed, d, r, P, has_grid):
+    """load_ts [T, N], pv_ts [T, N], grid_ts [T, 4, N] (or None) for the grids with GLOBAL indices gidx [N]: the rules in
+    numpy (CPU devices: the gloo tests)."""
     bl, bp, bc = (_tile_rows(P[k], T) for k in ("load", "pv", "co2"))
-    if dev.type != "cuda":                                  # host synthesis (CPU tests): the same rules in numpy
-        load_ts = -np.abs(bl[:, d["load_file"]] * r["load_ratio"][None, :])
-        pv_ts = np.abs(bp[:, d["pv_file"]] * r["pv_ratio"][None, :])
-        grid_ts = None
-        if has_grid:
-            grid_ts = np.empty((T, 4, N))
-            t1, t2 = electricity_tariff(1, T), electricity_tariff(2, T)
-            grid_ts[:, 0] = np.where(d["tariff"][None, :] == 1, t1[:, None], t2[:, None])
-            grid_ts[:, 1] = 0.0
-            grid_ts[:, 2] = bc[:, d["co2_file"]]
-            grid_ts[:, 3] = 1.0
-            rows = np.arange(T + 1)
-            for j in np.nonzero(d["weak"])[0]:
-                u = synth_uniform_host(seed, gidx[j], rows)
-                grid_ts[:, 3, j] = weak_grid_profile(u, r["outage_per_day"][j], d["outage_dur"][j])
-        as_t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), **f64)
-        return as_t(load_ts), as_t(pv_ts), as_t(grid_ts)
-    from . import _lib
-    lib = _lib.lib()
-    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=dev)
-    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
-    keep = dict(base_load=up(bl), base_pv=up(bp), load_profile=i32(d["load_file"]), pv_profile=i32(d["pv_file"]),
-                load_ratio=up(r["load_ratio"]), pv_ratio=up(r["pv_ratio"]))
-    load_ts, pv_ts = torch.empty(T, N, **f64), torch.empty(T, N, **f64)
-    grid_ts = torch.empty(T, 4, N, **f64) if has_grid else None
+    load_ts = -np.abs(bl[:, d["load_file"]] * r["load_ratio"][None, :])
+    pv_ts = np.abs(bp[:, d["pv_file"]] * r["pv_ratio"][None, :])
+    grid_ts = None
     if has_grid:
-        keep.update(base_co2=up(bc), co2_profile=i32(d["co2_file"]), tariff=i32(d["tariff"]), weak=i32(d["weak"]),
-                    outage_per_day=up(r["outage_per_day"]), outage_duration=i32(d["outage_dur"]))
+        grid_ts = np.empty((T, 4, N))
+        t1, t2 = electricity_tariff(1, T), electricity_tariff(2, T)
+        grid_ts[:, 0] = np.where(d["tariff"][None, :] == 1, t1[:, None], t2[:, None])
+        grid_ts[:, 1] = 0.0
+        grid_ts[:, 2] = bc[:, d["co2_file"]]
+        grid_ts[:, 3] = 1.0
+        rows = np.arange(T + 1)
+        for j in np.nonzero(d["weak"])[0]:
+            u = synth_uniform_host(seed, gidx[j], rows)
+            grid_ts[:, 3, j] = weak_grid_profile(u, r["outage_per_day"][j], d["outage_dur"][j])
+    as_t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64)
+    return as_t(load_ts), as_t(pv_ts), as_t(grid_ts)
+
+
+def _synth_call(dev, a, keep):
+    from . import _lib
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().mgx_synthesize_series(C.byref(a), torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.current_stream(dev).synchronize()        # `keep` may go once the kernel has read it
+    del keep
+
+
+def _synth_args(N, T, seed, g0, gsel):
+    from . import _lib
     a = _lib.Synth()
     a.struct_size = C.sizeof(_lib.Synth)
     a.n_grids, a.n_steps = N, T
+    a.seed, a.grid_index0 = int(seed) & (2 ** 64 - 1), int(g0)
+    a.grid_index = None if gsel is None else gsel.data_ptr()
+    return a
+
+
+def _synthesize_device(dev, T, N, g0, gsel, seed, G, P, has_grid):
+    """The [T, N] series written by ``mgx_synthesize_series`` from the per-grid columns ``G`` (device tensors): nothing of size N
+    crosses the host."""
+    f64 = dict(dtype=torch.float64, device=dev)
+    bl, bp, bc = (_tile_rows(P[k], T) for k in ("load", "pv", "co2"))
+    up = lambda x: torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=dev)
+    keep = dict(base_load=up(bl), base_pv=up(bp), load_profile=G["load_profile"].to(torch.int32), pv_profile=G["pv_profile"].to(torch.int32),
+                load_ratio=G["load_ratio"], pv_ratio=G["pv_ratio"])
+    load_ts, pv_ts = torch.empty(T, N, **f64), torch.empty(T, N, **f64)
+    grid_ts = torch.empty(T, 4, N, **f64) if has_grid else None
+    if has_grid:
+        keep.update(base_co2=up(bc), co2_profile=G["co2_profile"].to(torch.int32), tariff=G["tariff"].to(torch.int32), weak=G["weak"],
+                    outage_per_day=G["outage_per_day"], outage_duration=G["outage_duration"])
+    a = _synth_args(N, T, seed, g0, gsel)
     a.n_load_profiles, a.n_pv_profiles, a.n_co2_profiles = bl.shape[1], bp.shape[1], bc.shape[1]
     for k, t in keep.items():
         setattr(a, k, t.data_ptr())
-    contiguous = N == 0 or bool((np.diff(gidx) == 1).all())
-    gi = None if contiguous else torch.as_tensor(np.ascontiguousarray(gidx, dtype=np.int64), device=dev)
-    a.seed, a.grid_index0 = int(seed) & (2 ** 64 - 1), int(gidx[0]) if N else 0
-    a.grid_index = None if gi is None else gi.data_ptr()
     a.load_ts, a.pv_ts = load_ts.data_ptr(), pv_ts.data_ptr()
     a.grid_ts = grid_ts.data_ptr() if has_grid else None
-    with torch.cuda.device(dev):
-        _lib.check(lib.mgx_synthesize_series(C.byref(a), torch.cuda.current_stream(dev).cuda_stream))
-        torch.cuda.current_stream(dev).synchronize()        # `keep` may go once the kernel has read it
+    _synth_call(dev, a, keep)
     return load_ts, pv_ts, grid_ts
 
 
@@ -285,70 +330,133 @@ def materialise_series(batch, n_rows=None, n_grids=None):
     return {k: v.contiguous() for k, v in out.items()}
 
 
-def _factor_columns(dev, T, N, gidx, seed, d, r, P, has_grid):
-    """The factorised form of the series (``mgx_columns.base_load`` ...): base tables + per-grid profile ids / ratios; for a
-    GridModule the co2 profile id, the tariff pattern and the outage words (device kernel: the same Philox draws as the
-    materialised grid_status column).  Also returns the grid window bounds (min / max over the rows, grid_module.py:125-132)."""
-    f64 = dict(dtype=torch.float64, device=dev)
-    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), **f64)
-    u8 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.uint8), device=dev)
+def _factor_columns(dev, T, N, g0, gsel, seed, G, P, has_grid):
+    """The factorised form of the series (``mgx_columns.base_load`` ...): base tables + per-grid profile ids / ratios (out of
+    ``G``, the per-grid columns on ``dev``); for a GridModule the co2 profile id, the tariff pattern and the outage words (device
+    kernel: the same Philox draws as the materialised grid_status column).  Fills the status row of the grid window bounds
+    (min / max over the rows, grid_module.py:125-132)."""
+    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), dtype=torch.float64, device=dev)
     cols = dict(base_load=up(_pad_table(P["load"], T)), base_pv=up(_pad_table(P["pv"], T)),
-                load_profile=u8(d["load_file"]), pv_profile=u8(d["pv_file"]),
-                load_ratio=up(r["load_ratio"]), pv_ratio=up(r["pv_ratio"]))
+                load_profile=G["load_profile"], pv_profile=G["pv_profile"], load_ratio=G["load_ratio"], pv_ratio=G["pv_ratio"])
     if not has_grid:
         return cols
-    bc = _tile_rows(P["co2"], T)
-    cols.update(base_co2=up(_pad_table(P["co2"], T)), co2_profile=u8(d["co2_file"]), tariff=u8(d["tariff"]))
+    cols.update(base_co2=up(_pad_table(P["co2"], T)), co2_profile=G["co2_profile"], tariff=G["tariff"])
     W = (T + 63) // 64
     if dev.type != "cuda":                                  # host (CPU tests): the same rules in numpy
+        gidx = np.arange(g0, g0 + N) if gsel is None else gsel.numpy()
+        weak, opd, dur = G["weak"].numpy(), G["outage_per_day"].numpy(), G["outage_duration"].numpy()
         status = np.ones((T, N))
         rows = np.arange(T + 1)
-        for j in np.nonzero(d["weak"])[0]:
-            status[:, j] = weak_grid_profile(synth_uniform_host(seed, gidx[j], rows), r["outage_per_day"][j], d["outage_dur"][j])
+        for j in np.nonzero(weak)[0]:
+            status[:, j] = weak_grid_profile(synth_uniform_host(seed, gidx[j], rows), opd[j], dur[j])
         bits = torch.from_numpy(pack_outage_bits(status).view(np.int64).copy())
     else:
-        from . import _lib
-        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=dev)
-        keep = dict(weak=i32(d["weak"]), outage_per_day=up(r["outage_per_day"]), outage_duration=i32(d["outage_dur"]))
+        keep = dict(weak=G["weak"], outage_per_day=G["outage_per_day"], outage_duration=G["outage_duration"])
         bits = torch.zeros(W, N, dtype=torch.int64, device=dev)
-        a = _lib.Synth()
-        a.struct_size = C.sizeof(_lib.Synth)
-        a.n_grids, a.n_steps = N, T
+        a = _synth_args(N, T, seed, g0, gsel)
         a.n_load_profiles = a.n_pv_profiles = a.n_co2_profiles = 1
         for k, t in keep.items():
             setattr(a, k, t.data_ptr())
-        contiguous = N == 0 or bool((np.diff(gidx) == 1).all())
-        gi = None if contiguous else torch.as_tensor(np.ascontiguousarray(gidx, dtype=np.int64), device=dev)
-        a.seed, a.grid_index0 = int(seed) & (2 ** 64 - 1), int(gidx[0]) if N else 0
-        a.grid_index = None if gi is None else gi.data_ptr()
         a.outage_bits = bits.data_ptr()
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgx_synthesize_series(C.byref(a), torch.cuda.current_stream(dev).cuda_stream))
-            torch.cuda.current_stream(dev).synchronize()
+        _synth_call(dev, a, keep)
     cols["outage_bits"] = bits
-    # bounds of the four grid components over the T rows
-    tar = np.stack([np.zeros(T), electricity_tariff(1, T), electricity_tariff(2, T)])          # by pattern
-    lo = np.zeros((4, N)); hi = np.zeros((4, N))
-    lo[0], hi[0] = tar.min(axis=1)[d["tariff"]], tar.max(axis=1)[d["tariff"]]
-    lo[2], hi[2] = bc.min(axis=0)[d["co2_file"]], bc.max(axis=0)[d["co2_file"]]
+    # bounds of the status component over the T rows: 0 wherever a grid has an outage at all, 1 unless it is out all year
     full = torch.full((W,), -1, dtype=torch.int64, device=bits.device)
     if T % 64:
         full[-1] = (1 << (T % 64)) - 1
-    any_out = (bits != 0).any(dim=0).cpu().numpy()
-    all_out = (bits == full[:, None]).all(dim=0).cpu().numpy()
-    lo[3], hi[3] = np.where(any_out, 0.0, 1.0), np.where(all_out, 0.0, 1.0)
-    cols["grid_lo"], cols["grid_hi"] = up(lo), up(hi)
+    any_out = (bits != 0).any(dim=0)
+    all_out = (bits == full[:, None]).all(dim=0)
+    one, zero = torch.ones(N, dtype=torch.float64, device=dev), torch.zeros(N, dtype=torch.float64, device=dev)
+    G["grid_lo"][3] = torch.where(any_out, zero, one)
+    G["grid_hi"][3] = torch.where(all_out, zero, one)
     return cols
+
+
+# what mgx_generate_columns writes per grid: name -> torch dtype ([N]; grid_lo / grid_hi [4, N])
+_GEN_OUT = dict(arch=torch.uint8, load_profile=torch.uint8, pv_profile=torch.uint8, co2_profile=torch.uint8, tariff=torch.uint8,
+                weak=torch.int32, outage_duration=torch.int32, outage_per_day=torch.float64, load_ratio=torch.float64,
+                pv_ratio=torch.float64, load_lo=torch.float64, load_hi=torch.float64, pv_lo=torch.float64, pv_hi=torch.float64,
+                grid_lo=torch.float64, grid_hi=torch.float64, bat_min_capacity=torch.float64, bat_max_capacity=torch.float64,
+                bat_max_charge=torch.float64, bat_max_discharge=torch.float64, charge=torch.float64, soc=torch.float64,
+                gen_running_min=torch.float64, gen_running_max=torch.float64, gen_times=torch.int32, gen_status=torch.int32,
+                grid_max_import=torch.float64, grid_max_export=torch.float64)
+_GEN_DRAWS = dict(d_bin_rand=torch.float64, d_soc0_normal=torch.float64, d_outage_normal=torch.float64, d_size_load=torch.int32,
+                  d_pv_pen=torch.int32, d_bat_hours=torch.int32, d_su=torch.int32, d_wd=torch.int32)
+
+
+def _profile_stats(P, T):
+    bl, bp, bc = (_tile_rows(P[k], T) for k in ("load", "pv", "co2"))
+    tar = np.stack([np.zeros(T), electricity_tariff(1, T), electricity_tariff(2, T)])          # by pattern
+    return dict(load_max=P["load"].max(axis=0), pv_max=P["pv"].max(axis=0), load_bound_max=bl.max(axis=0), pv_bound_max=bp.max(axis=0),
+                co2_min=bc.min(axis=0), co2_max=bc.max(axis=0), tariff_min=tar.min(axis=1), tariff_max=tar.max(axis=1))
+
+
+def generate_columns_device(dev, N, T, seed, mixed_timers, g0=0, gsel=None, P=None, draws=False):
+    """``mgx_generate_columns``: MicrogridGenerator's draws and sizing rules for N grids on the device -- {name: tensor [N]} (see
+    ``_GEN_OUT``; ``draws=True`` adds the raw draws ``d_*``).  No array of size N exists on the host at any point."""
+    from . import _lib
+    P = P or base_profiles()
+    st = _profile_stats(P, T)
+    up = lambda x: torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=dev)
+    keep = {k: up(st[k]) for k in ("load_max", "pv_max", "load_bound_max", "pv_bound_max", "co2_min", "co2_max")}
+    keep["base_load"] = up(P["load"])
+    G = {k: torch.empty((4, N) if k in ("grid_lo", "grid_hi") else (N,), dtype=dt, device=dev) for k, dt in _GEN_OUT.items()}
+    if draws:
+        G.update({k: torch.empty(N, dtype=dt, device=dev) for k, dt in _GEN_DRAWS.items()})
+    a = _lib.Gen()
+    a.struct_size = C.sizeof(_lib.Gen)
+    a.n_grids, a.n_steps = N, T
+    a.n_load_profiles, a.n_pv_profiles, a.n_co2_profiles = P["load"].shape[1], P["pv"].shape[1], P["co2"].shape[1]
+    a.mixed_timers, a.n_mean_rows = int(bool(mixed_timers)), P["load"].shape[0]
+    a.seed, a.grid_index0 = int(seed) & (2 ** 64 - 1), int(g0)
+    a.grid_index = None if gsel is None else gsel.data_ptr()
+    for k, t in keep.items():
+        setattr(a, k, t.data_ptr())
+    for j in range(3):
+        a.tariff_min[j], a.tariff_max[j] = float(st["tariff_min"][j]), float(st["tariff_max"][j])
+    for k, t in G.items():
+        setattr(a, k, t.data_ptr())
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().mgx_generate_columns(C.byref(a), torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.current_stream(dev).synchronize()        # `keep` may go once the kernel has read it
+    return G
+
+
+def generate_columns_host(N, T, seed, mixed_timers, gidx, P=None):
+    """The same columns from the numpy rule functions (``draw_scalars`` + ``derive``): CPU devices, and the reference the
+    device kernel is tested against.  Returns (G, draws, derived)."""
+    P = P or base_profiles()
+    st = _profile_stats(P, T)
+    d = draw_scalars(gidx, seed, mixed_timers, P["load"].shape[1], P["pv"].shape[1], P["co2"].shape[1])
+    r = derive(d, P)
+    arch = architecture_code(d)
+    lf, pf, cf, tar = d["load_file"], d["pv_file"], d["co2_file"], d["tariff"]
+    z = np.zeros(N)
+    host = dict(arch=arch, load_profile=lf, pv_profile=pf, co2_profile=cf, tariff=tar, weak=d["weak"], outage_duration=d["outage_dur"],
+                outage_per_day=r["outage_per_day"], load_ratio=r["load_ratio"], pv_ratio=r["pv_ratio"],
+                load_lo=-(st["load_bound_max"][lf] * r["load_ratio"]), load_hi=z, pv_lo=z, pv_hi=st["pv_bound_max"][pf] * r["pv_ratio"],
+                grid_lo=np.stack([st["tariff_min"][tar], z, st["co2_min"][cf], z + 1.0]),
+                grid_hi=np.stack([st["tariff_max"][tar], z, st["co2_max"][cf], z + 1.0]),
+                bat_min_capacity=r["bat_min_capacity"], bat_max_capacity=r["bat_max_capacity"], bat_max_charge=r["bat_power"],
+                bat_max_discharge=r["bat_power"], charge=r["soc0"] * r["bat_max_capacity"], soc=r["soc0"],
+                gen_running_min=r["gen_running_min"], gen_running_max=r["gen_running_max"],
+                gen_times=pack_times(d["su"], d["wd"]).view(np.int32),
+                gen_status=pack_status(np.ones(N, np.int64), np.ones(N, np.int64), np.zeros(N, np.int64), d["wd"]).view(np.int32),
+                grid_max_import=r["grid_power"], grid_max_export=r["grid_power"])
+    G = {k: torch.as_tensor(np.ascontiguousarray(v)).to(_GEN_OUT[k]).contiguous() for k, v in host.items()}
+    return G, d, r
 
 
 def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, device="cuda", rank=0, world=1,
              mixed_timers=False, final_step=0, select=None, series="materialised", flat_order="module", uniform_columns=False):
     """Build the [rank]-th shard of a global batch of ``n_grids`` microgrids of architecture ``arch`` on ``device``.
-    ``select``: optional global indices (numpy int array, ascending) -- the grids of the global draw to build instead of
-    the rank's contiguous block (``generate_fleet`` uses it to split one draw by architecture).
+    ``select``: optional global indices (ascending; a numpy int array or an int64 tensor on ``device``) -- the grids of the
+    global draw to build instead of the rank's contiguous block (``generate_fleet`` uses it to split one draw by architecture).
     ``series``: "materialised" -- [T, N] arrays written by ``mgx_synthesize_series`` -- or "factorised" -- the base
     profiles + a profile id and a ratio per grid (``mgx_columns.base_load``): the kernels then form every series value with
-    the generator's own multiply, bit-identically, and the [T, N] arrays (14 GB per 100 000 grid-years) never exist."""
+    the generator's own multiply, bit-identically, and the [T, N] arrays (14 GB per 100 000 grid-years) never exist.
+    On a CUDA device every per-grid number is drawn and sized ON the device (``mgx_generate_columns``): no array of size N is
+    ever built on the host, and a rank touches nothing but its own shard."""
     if series not in ("materialised", "factorised"):
         raise ValueError("series must be 'materialised' or 'factorised'")
     # uniform_columns: the parameters MicrogridGenerator gives EVERY microgrid (battery efficiency / cycle cost, genset cost and
@@ -356,57 +464,61 @@ def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, d
     # mgx_columns.uniform_mask) instead of N times: 60 of the 108 parameter bytes a single step reads per grid
     has_genset, has_battery, has_grid = ARCHS[arch]
     dev = torch.device(device)
-    D = draw_scalars(n_grids, seed, mixed_timers)
+    on_dev = dev.type == "cuda"
+    T = int(n_steps)
+    P = base_profiles()
     if select is None:
         if n_grids % world:
             raise ValueError("n_grids must be divisible by the number of ranks")
-        per = n_grids // world
-        idx = np.arange(rank * per, (rank + 1) * per)
+        N = n_grids // world
+        g0, gsel = rank * N, None
     else:
-        idx = np.asarray(select, dtype=np.int64)
-    d = {k: v[idx] for k, v in D.items()}
-    N, T = len(idx), int(n_steps)
-    P = base_profiles()
-    r = derive(d, P)
+        g0 = 0
+        gsel = (select.to(device=dev, dtype=torch.int64) if torch.is_tensor(select)
+                else torch.as_tensor(np.ascontiguousarray(select, dtype=np.int64), device=dev)).contiguous()
+        N = int(gsel.numel())
+    if on_dev:
+        G = generate_columns_device(dev, N, T, seed, mixed_timers, g0, gsel, P)
+    else:
+        gidx = np.arange(g0, g0 + N) if gsel is None else gsel.numpy()
+        G, d, r = generate_columns_host(N, T, seed, mixed_timers, gidx, P)
     f64 = dict(dtype=torch.float64, device=dev)
-    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), **f64)
 
     def const(v):                    # a column every grid shares: one element expanded to [N], or N copies
         return torch.full((1,), v, **f64).expand(N) if (uniform_columns and N > 1) else torch.full((N,), v, **f64)
 
     if series == "factorised":
-        cols = _factor_columns(dev, T, N, idx, seed, d, r, P, has_grid)
+        cols = _factor_columns(dev, T, N, g0, gsel, seed, G, P, has_grid)
         grid_ts = None
     else:
-        load_ts, pv_ts, grid_ts = _synthesize(dev, T, N, idx, seed, d, r, P, has_grid)
+        load_ts, pv_ts, grid_ts = (_synthesize_device(dev, T, N, g0, gsel, seed, G, P, has_grid) if on_dev
+                                   else _synthesize_host(T, N, gidx, seed, d, r, P, has_grid))
         cols = {"load_ts": load_ts, "pv_ts": pv_ts}
     # observation bounds (base_timeseries_module.py:81-88): min / max of the series actually held, with 0
-    bl, bp = _tile_rows(P["load"], T), _tile_rows(P["pv"], T)
-    cols["load_lo"] = up(-(bl.max(axis=0)[d["load_file"]] * r["load_ratio"])); cols["load_hi"] = torch.zeros(N, **f64)
-    cols["pv_lo"] = torch.zeros(N, **f64); cols["pv_hi"] = up(bp.max(axis=0)[d["pv_file"]] * r["pv_ratio"])
+    for k in ("load_lo", "load_hi", "pv_lo", "pv_hi"):
+        cols[k] = G[k]
     cols["loss_load_cost"] = const(10.0)              # df_parameters['cost_loss_load'] (:472)
     cols["overgeneration_cost"] = const(1.0)
     if has_battery:                                                     # get_battery_module (convert/get_module.py:39-57)
-        cols["bat_max_capacity"] = up(r["bat_max_capacity"]); cols["bat_min_capacity"] = up(r["bat_min_capacity"])
-        cols["bat_max_charge"] = up(r["bat_power"]); cols["bat_max_discharge"] = up(r["bat_power"])
+        for k in ("bat_max_capacity", "bat_min_capacity", "bat_max_charge", "bat_max_discharge", "soc", "charge"):
+            cols[k] = G[k]
         cols["bat_efficiency"] = const(0.9)
         cols["bat_cost_cycle"] = const(0.02)
-        cols["soc"] = up(r["soc0"]); cols["charge"] = up(r["soc0"] * r["bat_max_capacity"])   # battery_module.py:96-106
     if has_genset:                                                      # get_genset_module (:60-76)
-        cols["gen_running_min"] = up(r["gen_running_min"]); cols["gen_running_max"] = up(r["gen_running_max"])
+        cols["gen_running_min"], cols["gen_running_max"] = G["gen_running_min"], G["gen_running_max"]
         cols["gen_cost"] = const(0.4)
         cols["gen_co2_per_unit"] = const(2.0)
         cols["gen_cost_per_unit_co2"] = const(0.1)
-        times = torch.from_numpy(pack_times(d["su"], d["wd"]).view(np.int32).copy()).to(dev)
-        cols["gen_times"] = times[:1].expand(N) if (uniform_columns and N > 1 and not mixed_timers) else times
-        st = pack_status(np.ones(N, np.int64), np.ones(N, np.int64), np.zeros(N, np.int64), d["wd"])   # init on
-        cols["gen_status"] = torch.from_numpy(st.view(np.int32).copy()).to(dev)
+        cols["gen_times"] = G["gen_times"][:1].expand(N) if (uniform_columns and N > 1 and not mixed_timers) else G["gen_times"]
+        cols["gen_status"] = G["gen_status"]
     if has_grid:                                                        # get_grid_module (:79-97)
-        cols["grid_max_import"] = up(r["grid_power"]); cols["grid_max_export"] = up(r["grid_power"])
+        cols["grid_max_import"], cols["grid_max_export"] = G["grid_max_import"], G["grid_max_export"]
         cols["grid_cost_per_unit_co2"] = const(0.1)
         if grid_ts is not None:
             cols["grid_ts"] = grid_ts
             cols["grid_lo"] = grid_ts.amin(dim=0).contiguous(); cols["grid_hi"] = grid_ts.amax(dim=0).contiguous()
+        else:
+            cols["grid_lo"], cols["grid_hi"] = G["grid_lo"], G["grid_hi"]
     layout = BatchLayout(n_grids=N, n_steps=T, horizon=horizon, initial_step=0, final_step=final_step,
                          has_genset=has_genset, has_battery=has_battery, has_grid=has_grid, flat_order=flat_order)
     return MicrogridBatch(layout, {k: (v if (v.dim() == 1 and N > 1 and v.stride(0) == 0) else v.contiguous()) for k, v in cols.items()})
@@ -415,16 +527,20 @@ def generate(n_grids, n_steps=YEAR, seed=42, arch="genset+battery", horizon=0, d
 def generate_fleet(n_grids, n_steps=YEAR, seed=42, horizon=0, device="cuda", rank=0, world=1, mixed_timers=False,
                    series="materialised", uniform_columns=False):
     """A heterogeneous population with MicrogridGenerator's own architecture mix (BASELINE config 5): the rank's block of
-    the global draw, split by the architecture each grid drew.  Returns {arch: (MicrogridBatch, global indices)}."""
+    the global draw, split by the architecture each grid drew.  Returns {arch: (MicrogridBatch, global indices)} (the indices a
+    numpy array on a CPU device, an int64 tensor on a CUDA device: the split happens where the draws were made)."""
     if n_grids % world:
         raise ValueError("n_grids must be divisible by the number of ranks")
     per = n_grids // world
-    D = draw_scalars(n_grids, seed, mixed_timers)
-    arch = architecture_of(D)
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        code = generate_columns_device(dev, per, int(n_steps), seed, mixed_timers, rank * per)["arch"]
+    else:
+        code = torch.from_numpy(architecture_code(draw_scalars(np.arange(rank * per, (rank + 1) * per), seed, mixed_timers)))
     out = {}
-    for name in ("genset+battery", "battery+grid", "genset+battery+grid"):
-        idx = np.nonzero(arch[rank * per:(rank + 1) * per] == name)[0] + rank * per
-        if len(idx):
+    for k, name in enumerate(ARCH_NAMES):
+        idx = torch.nonzero(code == k).squeeze(1) + rank * per
+        if idx.numel():
             out[name] = (generate(n_grids, n_steps, seed, name, horizon, device, mixed_timers=mixed_timers, select=idx,
-                                  series=series, uniform_columns=uniform_columns), idx)
+                                  series=series, uniform_columns=uniform_columns), idx if dev.type == "cuda" else idx.numpy())
     return out

@@ -73,7 +73,7 @@ class BucketedFleet:
         # further steps) instead of fresh tensors -- no allocation on the hot path
         self.reuse_outputs = int(reuse_outputs)
         self._want_fused = bool(fused)
-        self._plans, self._n_steps, self._out_reward, self._out_done = {}, 0, None, None
+        self._plans, self._n_steps, self._out_reward, self._out_done, self._out_obs = {}, 0, None, None, None
 
     @classmethod
     def from_batches(cls, batches, discrete=False, streams=False, reuse_outputs=0, fused=True, refill="ahead", stagger=None,
@@ -164,6 +164,8 @@ class BucketedFleet:
             refill = env._obs_commit()            # other envs: (ring, ahead) when this step moves on to the prefetched ring
             next_states.append(env._plan_state())
             obs = target if want_obs else None
+            if obs is None and want_obs and slot is not None and self._out_obs[k] is not None:
+                obs = self._out_obs[k][slot]          # no rings (whole rows written per step): rotating row buffers
             it.obs = None if obs is None else obs.data_ptr()
             it.wait_prefetch = int(wait)
             if chunk:
@@ -195,6 +197,9 @@ class BucketedFleet:
         if R and self._out_reward is None:
             self._out_reward = [e.engine._empty(R, e.engine.N) for e in envs]
             self._out_done = [e.engine._empty(R, e.engine.N, dtype=torch.uint8) for e in envs]
+            # envs that write whole observation rows per step (no rings, no views): R rotating [N, D] buffers per bucket
+            self._out_obs = [torch.empty(R, e.engine.N, e.engine.obs_dim, dtype=e.engine.obs_dtype, device=e.engine.device)
+                             if (e._observations and e._ring is None and not e._views) else None for e in envs]
         slot = (self._n_steps % R) if R else None
         key = (tuple(e._plan_state() for e in envs), slot)
         plan = self._plans.get(key)
@@ -354,8 +359,8 @@ class PerGridWindowEnv:
         self.full = full_batch
         self.length = None if trajectory_length is None else int(trajectory_length)
         if self.length is not None and L.final_step - L.initial_step < self.length:
-            raise ValueError(f'Cannot create a trajectory of length {self.length}'
-                             f'between initial_step ({L.initial_step}) and final_step ({L.final_step})')
+            raise ValueError(f"the batch's window [{L.initial_step}, {L.final_step}) holds {L.final_step - L.initial_step} steps: "
+                             f"too short for episodes of {self.length}")
         self.generator = generator
         cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
         self.auto_reset = bool(auto_reset)

@@ -9,48 +9,60 @@ the step counter).
 import numpy as np
 
 
+def _randint(low, high):
+    """One draw from numpy's GLOBAL stream, as the reference's samplers make it: a seeded run picks the same windows."""
+    return int(np.random.randint(low, high))
+
+
 class DeterministicTrajectory:
-    """trajectory/deterministic.py:4-12"""
+    """The same window at every reset (trajectory/deterministic.py:4-12)."""
 
     def __init__(self, initial_step, final_step):
-        self.initial_step, self.final_step = initial_step, final_step
+        self.window = (initial_step, final_step)
+
+    @property
+    def initial_step(self):
+        return self.window[0]
+
+    @property
+    def final_step(self):
+        return self.window[1]
 
     def __call__(self, initial_step, final_step):
-        return self.initial_step, self.final_step
+        return self.window
 
 
 class StochasticTrajectory:
-    """trajectory/stochastic.py:6-12"""
+    """A random start and a random end behind it: two draws per reset, in the reference's order and with its bounds
+    (trajectory/stochastic.py:6-12: start in [lo, hi - 2), end in [start, hi))."""
 
     def __call__(self, initial_step, final_step):
-        initial = np.random.randint(initial_step, final_step - 2)
-        final = np.random.randint(initial, final_step)
-        return initial, final
+        start = _randint(initial_step, final_step - 2)
+        return start, _randint(start, final_step)
 
 
 class FixedLengthStochasticTrajectory:
-    """trajectory/stochastic.py:15-30"""
+    """A window of ``trajectory_length`` steps at a random start (trajectory/stochastic.py:15-30: one draw per reset, start in
+    [lo, hi - length)); an env window shorter than the length is a ValueError, as in the reference."""
 
     def __init__(self, trajectory_length):
-        self.trajectory_length = trajectory_length
+        self.trajectory_length = int(trajectory_length)
 
     def __call__(self, initial_step, final_step):
-        if final_step - initial_step < self.trajectory_length:
-            raise ValueError(f'Cannot create a trajectory of length {self.trajectory_length}'
-                             f'between initial_step ({initial_step}) and final_step ({final_step})')
-        initial = np.random.randint(initial_step, final_step - self.trajectory_length)
-        return initial, initial + self.trajectory_length
+        room = final_step - initial_step
+        if room < self.trajectory_length:
+            raise ValueError(f"the env's window [{initial_step}, {final_step}) holds {room} steps: too short for episodes of "
+                             f"{self.trajectory_length}")
+        start = _randint(initial_step, final_step - self.trajectory_length)
+        return start, start + self.trajectory_length
 
 
 def check_trajectory_output(output):
-    """Microgrid._check_trajectory_func (microgrid.py:181-203): two Python ints."""
-    try:
-        initial_step, final_step = output
-        if not (isinstance(initial_step, (int, np.integer)) and isinstance(final_step, (int, np.integer))):
-            raise ValueError
-    except (TypeError, ValueError):
-        raise TypeError(f'trajectory func must return two integer values, not {output}')
-    return int(initial_step), int(final_step)
+    """What Microgrid._check_trajectory_func (microgrid.py:181-203) demands of a trajectory function: a pair of integers."""
+    ok = isinstance(output, (tuple, list)) and len(output) == 2 and all(isinstance(v, (int, np.integer)) for v in output)
+    if not ok:
+        raise TypeError(f"a trajectory function returns (initial_step, final_step) as two integers; got {output!r}")
+    return int(output[0]), int(output[1])
 
 
 class PVCurtailmentShaper:

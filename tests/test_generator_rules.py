@@ -116,7 +116,7 @@ def test_generate_on_cpu_follows_the_rules_and_is_shard_invariant():
     halves = [gen.generate(96, n_steps=300, seed=11, arch="genset+battery+grid", device="cpu", rank=r, world=2) for r in (0, 1)]
     for k, v in full.cols.items():
         assert torch.equal(v, torch.cat([h.cols[k] for h in halves], dim=-1)), k
-    D = gen.draw_scalars(96, 11)
+    D = gen.draw_scalars(np.arange(96), 11)
     r = gen.derive(D)
     P = gen.base_profiles()
     c = full.cols
@@ -131,7 +131,7 @@ def test_generate_on_cpu_follows_the_rules_and_is_shard_invariant():
     fleet = gen.generate_fleet(300, n_steps=48, seed=5, device="cpu")
     idx = np.sort(np.concatenate([i for _, i in fleet.values()]))
     assert np.array_equal(idx, np.arange(300)) and set(fleet) == {"genset+battery", "battery+grid", "genset+battery+grid"}
-    arch = gen.architecture_of(gen.draw_scalars(300, 5))
+    arch = gen.architecture_of(gen.draw_scalars(np.arange(300), 5))
     for name, (b, i) in fleet.items():
         assert (arch[i] == name).all() and b.layout.n_grids == len(i)
 
@@ -153,5 +153,51 @@ def test_device_synthesis_equals_the_host_rules(device):
     for k, v in b.cols.items():
         assert torch.equal(a.cols[k].cpu(), v), k
     st = a.cols["grid_ts"][:, 3]
-    weak = gen.draw_scalars(5000, 9)["weak"][sel].astype(bool)
+    weak = gen.draw_scalars(sel, 9)["weak"].astype(bool)
     assert bool(st[:, torch.as_tensor(~weak, device=device)].all()) and float(st[:, torch.as_tensor(weak, device=device)].mean()) < 1.0
+
+
+@pytest.mark.gpu
+def test_device_generator_equals_the_host_rules(device):
+    """mgx_generate_columns (HIP: counter-based Philox draws, randint / Irwin-Hall normal, the sizing rules incl. the mean of the
+    scaled load in numpy's pairwise order, bounds, packed genset words, architecture codes) == draw_scalars + derive in numpy,
+    bit for bit, for contiguous shards at large global offsets and scattered selections."""
+    from pymgrid_amd import generator as gen
+    for N, T, seed, mixed, g0 in ((1029, 300, 11, True, 0), (4097, 8760, 42, False, 875_000), (300, 64, 7, True, (1 << 33) + 5)):
+        G = gen.generate_columns_device(device, N, T, seed, mixed, g0, draws=True)
+        H, d, r = gen.generate_columns_host(N, T, seed, mixed, np.arange(g0, g0 + N))
+        for k, v in H.items():
+            assert torch.equal(G[k].cpu(), v), (N, k)
+        assert np.array_equal(G["d_bin_rand"].cpu().numpy(), d["bin_rand"]) and np.array_equal(G["d_size_load"].cpu().numpy(), d["size_load"])
+        assert np.array_equal(G["d_soc0_normal"].cpu().numpy(), d["soc0_randn"]) and np.array_equal(G["d_outage_normal"].cpu().numpy(), d["outage_randn"])
+        assert np.array_equal(G["d_su"].cpu().numpy(), d["su"]) and np.array_equal(G["d_bat_hours"].cpu().numpy(), d["bat_hours"])
+    sel = np.sort(np.random.RandomState(1).choice(1_000_000, 1500, replace=False))
+    G = gen.generate_columns_device(device, len(sel), 200, 3, True, 0, torch.as_tensor(sel, device=device))
+    H, _, _ = gen.generate_columns_host(len(sel), 200, 3, True, sel)
+    for k, v in H.items():
+        assert torch.equal(G[k].cpu(), v), k
+    # the draws look like what they stand for
+    G = gen.generate_columns_device(device, 200_000, 64, 5, True, 0, draws=True)
+    z = G["d_soc0_normal"].cpu().numpy()
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01 and abs(np.mean(z < -1.0) - 0.1587) < 0.005
+    assert abs(G["d_bin_rand"].mean().item() - 0.5) < 0.005 and set(np.unique(G["d_bat_hours"].cpu().numpy())) == {3, 4, 5}
+    code = G["arch"].cpu().numpy()
+    assert abs(np.mean(code == 0) - 0.33) < 0.01 and abs(np.mean(code == 1) - 0.165) < 0.01      # half of the grid-only draws are weak
+
+
+@pytest.mark.gpu
+def test_generating_a_million_grids_builds_no_host_array_of_that_size(device):
+    """The CUDA path of generate(): draws, sizing, series factors and outage words are all made on the device -- the host holds
+    the base profile tables and a few per-profile numbers, nothing that grows with N."""
+    import tracemalloc
+    from pymgrid_amd import generator as gen
+    gen.base_profiles()                                       # (the package data: loaded once, not part of a generate call)
+    gen.generate(1024, n_steps=64, seed=42, arch="genset+battery+grid", device=device, series="factorised")   # warm-up: lazy imports
+    N = 1_000_000
+    tracemalloc.start()
+    b = gen.generate(N, n_steps=64, seed=42, arch="genset+battery+grid", device=device, series="factorised", mixed_timers=True)
+    f = gen.generate_fleet(N, n_steps=64, seed=42, device=device, rank=3, world=8, series="factorised")
+    _, peak = tracemalloc.get_traced_memory()
+    tracemalloc.stop()
+    assert b.layout.n_grids == N and sum(len(i) for _, i in f.values()) == N // 8
+    assert peak < N, f"host allocations peaked at {peak} bytes: an array of {N} grids was built on the host"

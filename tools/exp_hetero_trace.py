@@ -17,7 +17,8 @@ dt = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "float32") else torc
 refill = sys.argv[4] if len(sys.argv) > 4 else "chunks"
 dev = torch.device("cuda:0")
 per = int(os.environ.get("PER", 33333))
-batches = [generate(per, n_steps=steps + 4000, seed=43 + k, arch=arch, horizon=24, device=dev)
+series = os.environ.get("SERIES", "factorised")
+batches = [generate(per, n_steps=8760, seed=43 + k, arch=arch, horizon=24, device=dev, series=series)
            for k, arch in enumerate(("genset+battery", "battery+grid", "genset+battery+grid"))]
 fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K, reuse_outputs=3 * K, refill=refill)
 gen = torch.Generator(device=dev); gen.manual_seed(11)
@@ -26,7 +27,7 @@ fleet.reset()
 t_end = time.perf_counter() + 1.0
 while time.perf_counter() < t_end:
     fleet.reset()
-    for _ in range(200):
+    for _ in range(1000):
         fleet.step(acts)
     torch.cuda.synchronize()
 fleet.reset()

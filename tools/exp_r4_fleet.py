@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Round 4: config-5 fleet (99 999 mixed grids, H = 24, T = 8 760, factorised series), rows contract -- ring refill scheduling:
-staggered ring phases per bucket (the three refills start at different fleet steps) vs all at once; ring depth K."""
+"""Round 4: config-5 fleet (99 999 mixed grids, H = 24, T = 8 760, factorised series), rows contract -- one variant per process
+(the library reads its experiment knobs from the environment once): ring depth K, refill workgroups per CU (MGX_WIN_MIN_LDS),
+one pooled prefetch stream (MGX_PREFETCH_POOL), staggered ring phases.
+usage: exp_r4_fleet.py K [float64|float32] [stagger]"""
 import os
 import sys
 import time
@@ -14,9 +16,12 @@ from pymgrid_amd.hetero import BucketedFleet  # noqa: E402
 dev = torch.device("cuda:0")
 per = 33333
 archs = ("genset+battery", "battery+grid", "genset+battery+grid")
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 16          # 0: no rings (step + whole row in one launch)
+dt = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "float32") else torch.float64
+stagger = len(sys.argv) > 3 and sys.argv[3] == "stagger"
 
 
-def timeit(fn, n=1600, warm=1200):
+def timeit(fn, n, warm):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -28,18 +33,12 @@ def timeit(fn, n=1600, warm=1200):
     return (time.perf_counter() - t0) / n * 1e6, e0.elapsed_time(e1) / n * 1e3
 
 
-variants = [(torch.float64, 16, False), (torch.float64, 16, True), (torch.float64, 32, False), (torch.float64, 32, True),
-            (torch.float64, 24, True), (torch.float32, 16, False), (torch.float32, 16, True)]
-if len(sys.argv) > 1:
-    variants = variants[:int(sys.argv[1])]
-for rep in range(2):
-    for dt, K, stagger in variants:
-        batches = [generate(per, n_steps=8760, seed=43 + k, arch=a, horizon=24, device=dev, series="factorised") for k, a in enumerate(archs)]
-        fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K, reuse_outputs=3 * K, stagger=stagger)
-        acts = [torch.rand(per, e.layout.action_dim, dtype=torch.float64, device=dev) for e in fleet.envs]
-        fleet.reset()
-        wall, gpu = timeit(lambda: fleet.step(acts))
-        print(f"rep {rep} {str(dt):14s} K={K:2d} stagger={int(stagger)}: {wall:6.1f} us wall  {gpu:6.1f} us gpu per fleet step", flush=True)
-        fleet.close()
-        del fleet, batches
-        torch.cuda.empty_cache()
+batches = [generate(per, n_steps=8760, seed=43 + k, arch=a, horizon=24, device=dev, series="factorised") for k, a in enumerate(archs)]
+fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K, reuse_outputs=3 * K if K else 8, stagger=stagger, obs_direct=(K == 0))
+acts = [torch.rand(per, e.layout.action_dim, dtype=torch.float64, device=dev) for e in fleet.envs]
+fleet.reset()
+res = [timeit(lambda: fleet.step(acts), 2048, 1536 if rep == 0 else 0) for rep in range(3)]
+knobs = " ".join(f"{k}={os.environ[k]}" for k in ("MGX_WIN_MIN_LDS", "MGX_PREFETCH_POOL") if k in os.environ)
+print(f"{str(dt):14s} K={K:2d} stagger={int(stagger)} {knobs:40s}: " + "  ".join(f"{w:5.1f}/{g:5.1f}" for w, g in res) + "  us wall/gpu per fleet step",
+      flush=True)
+fleet.close()
