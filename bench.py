@@ -472,11 +472,27 @@ def main():
         if world > 1:
             import torch.distributed as dist
             assert dist.get_world_size() == args.gpus
-            ranks = mdist.gather_over_ranks(rank, torch.device("cpu") if dist.get_backend() == "gloo" else torch.device("cuda", local))
+            on_gpu = dist.get_backend() != "gloo"
+            if on_gpu:
+                local = int(os.environ.get("MGX_FORCE_LOCAL_RANK", local))
+                torch.cuda.set_device(local)
+            cdev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+            ranks = mdist.gather_over_ranks(rank, cdev)
             assert ranks == list(range(world)), ranks
+            # THE collective of the engine, for real: every rank contributes (rank + 1, 1) over the default backend (RCCL on a GPU
+            # node; bounded, with the gloo fallback reported) -- the sums every rank must see are (W (W + 1) / 2, W)
+            sums = mdist.all_reduce_metrics(torch.tensor([rank + 1.0, 1.0], dtype=torch.float64, device=cdev))
+            ok = sums.cpu().tolist() == [world * (world + 1) / 2, float(world)]
+            oks = mdist.gather_over_ranks(1.0 if ok else 0.0, cdev)
             if rank == 0:
-                print(json.dumps({"launch_check": True, "n_gpus": world, "backend": dist.get_backend(), "ranks": ranks}), flush=True)
+                print(json.dumps({"launch_check": True, "n_gpus": world, "backend": dist.get_backend(), "ranks": ranks,
+                                  "metrics_allreduce": {"sums": sums.cpu().tolist(), "ok_on_every_rank": all(v == 1.0 for v in oks),
+                                                        "collective_backend": mdist.last_collective.get("backend"),
+                                                        "error": mdist.last_collective.get("error")}}), flush=True)
             mdist.barrier()
+            if mdist.last_collective.get("hung"):
+                sys.stdout.flush()
+                os._exit(0 if ok else 1)              # a thread is still stuck inside the backend
             dist.destroy_process_group()
         else:
             print(json.dumps({"launch_check": True, "n_gpus": 1, "backend": None, "ranks": [0]}), flush=True)

@@ -31,7 +31,8 @@ def test_gpus_n_launches_its_own_ranks_cpu():
                        text=True, timeout=300, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _line(r.stdout)
-    assert d == {"launch_check": True, "n_gpus": 2, "backend": "gloo", "ranks": [0, 1]}
+    assert d == {"launch_check": True, "n_gpus": 2, "backend": "gloo", "ranks": [0, 1],
+                 "metrics_allreduce": {"sums": [3.0, 2.0], "ok_on_every_rank": True, "collective_backend": "gloo", "error": None}}
 
 
 def test_gpus_mismatch_fails_loudly():
@@ -85,3 +86,29 @@ def test_bench_two_ranks_under_torchrun(device):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["grids_total"] == 40000 and d["value"] > 0 and d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_two_gpus_first_contact_over_rccl(device):
+    """Fires the first time a box shows two GPUs (skips on the one-GPU boxes of this pool): `python bench.py --gpus 2` launches one
+    rank per GPU over RCCL (backend "nccl"), the ranks see each other, THE collective of the engine -- the metrics all-reduce --
+    comes through on RCCL itself (no gloo fallback), and a short bench line carries two per-rank rates."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the multi-GPU path is covered by the gloo tests; this one needs >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "MGX_DIST_BACKEND", "MGX_FORCE_LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert d["backend"] == "nccl" and d["ranks"] == [0, 1], d
+    m = d["metrics_allreduce"]
+    assert m["sums"] == [3.0, 2.0] and m["ok_on_every_rank"] and m["collective_backend"] == "nccl" and m["error"] is None, m
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-side-modes"] + SMALL, capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["backend"] == "nccl" and len(d["per_rank_env_steps_per_s"]) == 2
+    assert d["metrics_allreduce"]["collective_backend"] == "nccl", d["metrics_allreduce"]

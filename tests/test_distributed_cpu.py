@@ -100,3 +100,42 @@ def test_single_process_is_a_noop():
     assert torch.equal(mdist.all_reduce_metrics(v.clone()), v)
     assert mdist.max_over_ranks(3.5, torch.device("cpu")) == 3.5
     mdist.barrier()
+
+
+def _worker8(rank, world, port, n_total, outdir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from pymgrid_amd import distributed as mdist
+    from pymgrid_amd.generator import generate
+    r, w, _ = mdist.init_from_env(backend="gloo")
+    shard = generate(n_total, n_steps=24, seed=42, arch="genset+battery+grid", device="cpu", rank=r, world=w, series="factorised",
+                     mixed_timers=True)
+    local = torch.stack([shard.cols["charge"].sum(), shard.cols["bat_max_capacity"].sum(), shard.cols["gen_running_max"].sum(),
+                         shard.cols["grid_max_import"].sum(), torch.tensor(float(shard.layout.n_grids), dtype=torch.float64)])
+    total = mdist.all_reduce_metrics(local.clone())
+    torch.save({k: v for k, v in shard.cols.items() if not k.startswith("base_")}, os.path.join(outdir, f"shard{r}.pt"))
+    if r == 0:
+        torch.save(total, os.path.join(outdir, "total.pt"))
+    mdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_eight_shards_are_the_one_batch(tmp_path):
+    """BASELINE configs[3] / [4] in miniature (world 8, gloo): the eight ranks' shards of one global batch -- every per-grid
+    column, profile ids, ratios, outage words -- concatenate bit-equal to the batch one process builds, and the metrics all-reduce
+    over the eight ranks gives the sums of the whole."""
+    from pymgrid_amd.generator import generate
+    n_total, world = 160_000, 8
+    mp.spawn(_worker8, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    full = generate(n_total, n_steps=24, seed=42, arch="genset+battery+grid", device="cpu", series="factorised", mixed_timers=True)
+    shards = [torch.load(str(tmp_path / f"shard{r}.pt")) for r in range(world)]
+    for k, v in full.cols.items():
+        if k.startswith("base_"):
+            continue
+        assert torch.equal(v, torch.cat([s[k] for s in shards], dim=-1)), k
+    total = torch.load(str(tmp_path / "total.pt"))
+    per = n_total // world
+    ref = torch.stack([sum(full.cols[k][r * per:(r + 1) * per].sum() for r in range(world))
+                       for k in ("charge", "bat_max_capacity", "gen_running_max", "grid_max_import")]
+                      + [torch.tensor(float(n_total), dtype=torch.float64)])
+    assert torch.allclose(total, ref, rtol=1e-13) and total[-1].item() == n_total
