@@ -213,25 +213,38 @@ def sample_device_state(out, delay_s=0.12):
     return th
 
 
-def timed(run, fn, rounds, device, mdist):
+def timed(run, fn, rounds, device, mdist, per_round=False):
     """barrier + sync | K rounds | sync + barrier; returns (wall seconds, GPU seconds = the longest launch stream's elapsed
-    time between its own start and stop events)."""
+    time between its own start and stop events, per-round times).  per_round: an event behind every round on every launch stream
+    (a timestamp packet each: no GPU work) -> the K round durations in us (per round the slowest stream's cadence), else None."""
     streams = run.streams or [torch.cuda.current_stream(device)]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
+    marks = [[torch.cuda.Event(enable_timing=True) for _ in range(rounds)] for _ in streams] if per_round else None
     mdist.barrier()
     run.eng.fork()                      # stream ordering only (no GPU work): the shard streams line up behind the caller's stream
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for (e0, _), st in zip(ev, streams):
         e0.record(st)
-    fn(rounds)
+    if per_round:
+        for r in range(rounds):
+            fn(1)
+            for m, st in zip(marks, streams):
+                m[r].record(st)
+    else:
+        fn(rounds)
     for (_, e1), st in zip(ev, streams):
         e1.record(st)
     torch.cuda.synchronize(device)      # the whole device: every shard stream has drained
     t1 = time.perf_counter()
     run.eng.join()
     mdist.barrier()
-    return t1 - t0, max(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3
+    round_us = None
+    if per_round:
+        round_us = []
+        for r in range(rounds):
+            round_us.append(max(((ev[j][0] if r == 0 else marks[j][r - 1]).elapsed_time(marks[j][r])) for j in range(len(streams))) * 1e3)
+    return t1 - t0, max(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3, round_us
 
 
 def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
@@ -311,14 +324,14 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
                 else:
                     alg += L.n_grids * (core + esz * e.engine.state_dim)
             ach = alg / (gpu / steps) / 1e9
-            traffic, traffic_src = None, None
-            try:                                              # PMC bytes of the same fleet shape, if a profile of it is committed
-                fn = os.path.join(ROOT, "profiles", "r03", f"traffic_fleet_{contract}_{dt_name}.json")
-                tf = json.load(open(fn))
-                if (tf["grids_per_gpu"], tf["series"], tf["contract"], tf["dtype"]) == (3 * per, series, contract, dt_name):
-                    traffic, traffic_src = tf["hbm_bytes_per_fleet_step"], os.path.relpath(fn, ROOT)
-            except (OSError, ValueError, KeyError):
-                pass
+            # PMC bytes of the same fleet shape, if a profile of it -- taken on the kernels now running -- is committed
+            traffic = None
+            tf, traffic_src = profile_json(f"traffic_fleet_{contract}_{dt_name}.json")
+            if tf is not None and (tf.get("grids_per_gpu"), tf.get("series"), tf.get("contract"), tf.get("dtype"),
+                                   tf.get("obs_prefetch")) == (3 * per, series, contract, dt_name, K_ring if contract == "rows" else tf.get("obs_prefetch")):
+                traffic = tf["hbm_bytes_per_fleet_step"]
+            elif tf is not None:
+                traffic_src += ": another fleet shape"
             launch = ("one fleet step = one mgx_fleet_step call: ONE fleet_step_kernel launch over the three buckets"
                       + (f" + every {K_ring}th step the observation ring after next ({K_ring} row blocks: obs_windows_k_kernel per "
                          f"bucket on the engines' prefetch streams, beside the following step launches); bytes and time are per "
@@ -441,6 +454,7 @@ def measured_traffic(kernel, grids, chunk):
     profiles/<round>/traffic.json); None when no profile of that specialisation and launch shape is committed."""
     import glob
     want = kernel.replace(" ", "")
+    stale = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
@@ -451,8 +465,29 @@ def measured_traffic(kernel, grids, chunk):
         # launches are recorded by size (threads = workgroups * 256; a workgroup owns 192..256 grids)
         for threads, e in sorted(d.get("by_launch_threads", {}).get(want, {}).items(), key=lambda kv: int(kv[0])):
             if grids <= int(threads) < 1.45 * grids:
+                if d.get("csrc_hash") != CSRC_HASH:      # counters of OTHER kernels say nothing about these: no figure
+                    stale = stale or f"{os.path.relpath(f, ROOT)}: STALE (taken on kernels {d.get('csrc_hash')}, running {CSRC_HASH})"
+                    break
                 return e["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
-    return None, None
+    return None, stale
+
+
+CSRC_HASH = None      # source hash of the libmgx.so this process runs (set in main): profiles are only quoted when they carry it
+
+
+def profile_json(name):
+    """A committed counter summary (profiles/r*/<name>) taken on the kernels that are running, else (None, why not)."""
+    import glob
+    why = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("csrc_hash") == CSRC_HASH:
+            return d, os.path.relpath(f, ROOT)
+        why = why or f"{os.path.relpath(f, ROOT)}: STALE (taken on kernels {d.get('csrc_hash')}, running {CSRC_HASH})"
+    return None, why
 
 
 def main():
@@ -500,6 +535,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     _lib.build()
+    global CSRC_HASH
+    CSRC_HASH = _lib.built_hash(_lib.LIB_PATH) or _lib.source_hash()     # which kernels this run measures (profiles are quoted only if they match)
     local = int(os.environ.get("MGX_FORCE_LOCAL_RANK", local))     # tests: several ranks on one GPU (with a gloo backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -560,7 +597,7 @@ def main():
             sampler.join(2.0)
         fn(warmup)
         first = run.rounds
-        wall, gpu = timed(run, fn, rounds, dev, mdist)
+        wall, gpu, round_us = timed(run, fn, rounds, dev, mdist, per_round=(mode == args.mode))
         walls = mdist.gather_over_ranks(wall, dev)
         wall, gpu = max(walls), mdist.max_over_ranks(gpu, dev)
         n_launch = (N + S - 1) // S if sharded else N             # grids per kernel launch
@@ -595,6 +632,12 @@ def main():
                 "bytes_per_env_step": per_launch / (chunk if mode in ("fused", "rbc") else 1),
                 "launches": launches, "avg_launch_us": avg_launch_s * 1e6, "avg_launch_us_wall": wall_launch_s * 1e6,
                 "timed_rounds": [first, first + rounds]}
+        if round_us:                                               # the spread inside the timed region (the headline only)
+            srt = sorted(round_us)
+            roof["round_us"] = {"n": len(srt), "min": srt[0], "median": srt[len(srt) // 2], "max": srt[-1],
+                                "frac_at_median": per_launch_bytes * launches_per_round / (srt[len(srt) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "what": "stream cadence of each timed round (HIP events behind every round on the launch streams; per "
+                                        "round the slower stream), rank 0"}
         if sharded:
             roof.update({"launch": f"one round = {S} concurrent kernel launches, one per internal shard stream "
                                    f"(mgx_set_shards), {n_launch} grids each, never joined between rounds",
@@ -603,11 +646,32 @@ def main():
             roof["kernel_avg_duration_us"] = run.kernel_durations_us(fn)
         if mode == "rbc" and fact:
             roof["note"] = ("with factorised series this kernel reads nothing per step (18.5 B/env-step are its reward / SoC writes): "
-                            "it is bound by fp64 VALU issue (profiles/r03), not by HBM -- the HBM fraction is reported for "
+                            "it is bound by fp64 VALU issue, not by HBM -- see roofline_valu; the HBM fraction is reported for "
                             "completeness, the materialised form under other.rbc_rollout_materialised is the bandwidth-bound one")
+        if mode in ("fused", "rbc"):
+            # The issue-side ceiling: cycles the kernel's waves spent EXECUTING vector-ALU instructions (SQ_ACTIVE_INST_VALU x 4:
+            # the counter ticks in quad-cycles; summed over the waves of a launch; a committed PMC pass of this command) over the
+            # VALU cycles the chip had in the launch's duration (SIMDs x shader clock x time, measured live).  1.0 = every SIMD
+            # issued a VALU instruction in every cycle.
+            vj, vsrc = profile_json("valu.json")
+            e = (vj or {}).get("kernels", {}).get(kname.replace(" ", ""))
+            if e is not None:
+                props = torch.cuda.get_device_properties(dev)
+                simds = 4 * props.multi_processor_count
+                ghz = float(vj.get("sclk_mhz") or 2400.0) * 1e-3
+                # counters are per KERNEL launch (n_launch grids); a round runs S of them side by side
+                per_round = e["valu_active_cycles_per_launch"] * (S if sharded else 1) * (n_launch / e["grids_per_launch"])
+                ach = per_round / avg_launch_s / 1e9
+                roof_valu = {"bound": "valu", "achieved": ach, "peak": simds * ghz, "unit": "Gcycle/s", "frac": ach / (simds * ghz),
+                             "valu_instructions_per_wave_and_env_step": e.get("valu_insts_per_wave_step"), "source": vsrc,
+                             "what": "wave-cycles spent executing VALU instructions per second over SIMDs x shader clock"}
+            else:
+                roof_valu = {"bound": "valu", "achieved": None, "peak": None, "unit": "Gcycle/s", "frac": None, "source": vsrc}
+        else:
+            roof_valu = None
         run.shard(False)
         return {"value": n_total * rounds * chunk / wall, "steps": rounds, "warmup": warmup, "ms_per_step": wall / rounds * 1e3,
-                "roofline": roof, "per_rank_env_steps_per_s": [N * rounds * chunk / w for w in walls]}
+                "roofline": roof, "roofline_valu": roof_valu, "per_rank_env_steps_per_s": [N * rounds * chunk / w for w in walls]}
 
     # the headline first (its launch indices in a rocprofv3 trace are then [prewarm + W, prewarm + W + K) per queue)
     results = {args.mode: measure(args.mode, sharded=args.mode in ("fused", "rbc"), rounds=args.steps, warmup=args.warmup)}
@@ -763,9 +827,11 @@ def main():
                                       + (f"; {S} grid ranges per GPU on {S} internal HIP streams" if S > 1 else ""),
                        "prewarm_seconds_per_mode": args.prewarm, "world_size": world, "backend": backend},
             "roofline": main_r["roofline"],
+            "roofline_valu": main_r.get("roofline_valu"),
+            "csrc_hash": CSRC_HASH,
             "cpu_baseline": cpu,
             "per_rank_env_steps_per_s": main_r["per_rank_env_steps_per_s"],
-            "other": {names[m]: (r if "error" in r else {k: r[k] for k in ("value", "steps", "warmup", "ms_per_step", "roofline")})
+            "other": {names[m]: (r if "error" in r else {k: r[k] for k in ("value", "steps", "warmup", "ms_per_step", "roofline", "roofline_valu")})
                       for m, r in results.items() if m != args.mode},
             "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total,
                                   "collective_backend": mdist.last_collective["backend"], "collective_error": mdist.last_collective["error"],
