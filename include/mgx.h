@@ -489,6 +489,35 @@ int mgx_check_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *t
 int mgx_step_many(mgx_handle *h, const void *actions, int32_t K, int normalized,
                   double *reward, uint8_t *done, void *obs, double *log, mgx_stream stream);
 
+/* Resident step server: the Gym cadence (one Microgrid.run per call, `while not done: env.step(a)`, README.md:109-111,
+ * envs/base/base.py:169-209) WITHOUT a kernel launch per env-step.  mgx_server_start puts ONE kernel on the device that stays
+ * there for a burst of up to max_steps steps: every grid's parameters and dynamic state live in registers, step k reads its
+ * controls from slot k % n_slots of a ring of caller-owned buffers and leaves reward / done / observation in the same slot.
+ *   mgx_server_post(h, s)   releases the next step once stream s reaches this point: a stream memory operation behind the
+ *                           kernel that wrote the controls (no launch) -- or, started with immediate != 0 (controls already on
+ *                           the device / written by a kernel the caller orders itself), a plain store of the host: free
+ *   mgx_server_wait(h, s)   stream s waits (hipStreamWaitValue32) until every step posted so far has been taken by every grid
+ *   mgx_server_stop(h, &n)  finishes the posted steps, ends the kernel, writes the state columns back, moves the step counter
+ *                           by the n steps taken; MGX_ERR_RANGE when the burst ended early (idle timeout) with posts not served
+ * The caller must not post step k + n_slots before it has consumed slot k % n_slots (the server does not check), and must not
+ * call anything else on the handle -- nor synchronise the whole device -- between start and stop: the kernel ends by itself
+ * idle_timeout_ms after the last activity (and after 60 s at the latest), so a stray hipDeviceSynchronize is a delay, never a
+ * hang.  Observations: whole rows without a forecast horizon, or the state columns (MGX_OBS_ROWS_STATE_ONLY / _COMPACT).
+ * Lock-step episodes, one module of every kind per grid, all workgroups resident (N up to ~400 000): else MGX_ERR_UNSUPPORTED.
+ * Values are those of mgx_step, bit for bit.  (What it buys and what it does not: DESIGN.md section 2, "Resident step server".) */
+typedef struct mgx_server_slot {
+    const void *actions;          /* [N, A] controls (the handle's action format) */
+    double *reward;               /* [N] */
+    uint8_t *done;                /* [N] or NULL */
+    void *obs;                    /* [N, D] rows (horizon 0), [N, S] compact state, or NULL */
+} mgx_server_slot;
+#define MGX_SERVER_MAX_SLOTS 8
+int mgx_server_start(mgx_handle *h, const mgx_server_slot *slots, int32_t n_slots, int normalized, int32_t max_steps,
+                     int32_t idle_timeout_ms, int immediate, mgx_stream stream);
+int mgx_server_post(mgx_handle *h, mgx_stream stream);
+int mgx_server_wait(mgx_handle *h, mgx_stream stream);
+int mgx_server_stop(mgx_handle *h, int32_t *steps_done);
+
 /* Shards.  Grids never interact (no cross-grid term anywhere in Microgrid.run), so the launch sequence of one range of
  * grids owes nothing to another's.  mgx_set_shards(h, S > 1) splits every stepping call (mgx_step, mgx_step_many,
  * mgx_step_k, mgx_step_discrete, mgx_expand_discrete, mgx_rollout_discrete) into S launches over contiguous grid ranges,

@@ -115,6 +115,13 @@ class Gen(C.Structure):
                                              "d_outage_normal", "d_size_load", "d_pv_pen", "d_bat_hours", "d_su", "d_wd")])
 
 
+class ServerSlot(C.Structure):
+    """mgx_server_slot (include/mgx.h): one slot of the resident step server's buffer ring."""
+    _fields_ = [("actions", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("obs", C.c_void_p)]
+
+
+SERVER_MAX_SLOTS = 8       # MGX_SERVER_MAX_SLOTS
+
 # every symbol include/mgx.h declares: (restype, argtypes)
 SYMBOLS = {
     "mgx_abi_version": (C.c_int, []),
@@ -174,6 +181,10 @@ SYMBOLS = {
     "mgx_fleet_step": (C.c_int, [C.POINTER(FleetItem), C.c_int32, C.c_int, C.c_void_p]),
     "mgx_synthesize_series": (C.c_int, [C.POINTER(Synth), C.c_void_p]),
     "mgx_generate_columns": (C.c_int, [C.POINTER(Gen), C.c_void_p]),
+    "mgx_server_start": (C.c_int, [C.c_void_p, C.POINTER(ServerSlot), C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
+    "mgx_server_post": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgx_server_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgx_server_stop": (C.c_int, [C.c_void_p, c_i32_p]),
 }
 
 
@@ -212,6 +223,8 @@ def build(force=False, verbose=False, defs=(), lib_path=None):
     library; load it with MGX_LIB=<lib_path>."""
     if lib_path is not None or defs:
         return _build(lib_path or LIB_PATH, list(defs), verbose, os.path.basename(lib_path or "variant") + ".o")
+    if os.environ.get("MGX_LIB") and os.path.exists(LIB_PATH) and not force:
+        return LIB_PATH                              # an A/B variant named by the caller: loaded as it is, never rebuilt in place
     if not force and up_to_date(LIB_PATH):
         return LIB_PATH
     return _build(LIB_PATH, [], verbose, "", force)

@@ -52,6 +52,15 @@ struct mgx_handle {
     hipStream_t prefetch_stream;             // mgx_observe_windows_ahead: the window prefetch overlaps the steps
     bool prefetch_pooled;                    // ... on the per-device pooled stream (MGX_PREFETCH_POOL): not destroyed with the handle
     bool rows_direct;                        // mgx_set_rows_direct: step + whole observation row in one launch (fleet_rows_kernel)
+    // resident step server (mgx_server_*)
+    bool server_running, server_immediate;
+    ServerCtl *server_ctl;                   // device
+    ServerHostWords *server_host;            // pinned + mapped
+    uint32_t *server_signal;                 // signal memory
+    hipStream_t server_stream;
+    hipEvent_t server_gate;
+    uint32_t server_posted;
+    int32_t server_max_steps;
     hipEvent_t prefetch_gate, prefetch_done;
     bool prefetch_pending;
     // per-grid episode windows (mgx_reset_windows): the full series are remembered here while the handle steps over the
@@ -225,6 +234,17 @@ static void launch_windows_kernel(const KArgs &k, const WindowsKPlan &plan, int3
     obs_windows_k_kernel<F, OT><<<blocks, OBS_K_THREADS, lds, st>>>(k, plan, t, (OT *)ring);
 }
 
+// resident step server: every workgroup must be on the chip at once (occupancy query), then one launch on the server stream
+template <int F>
+static hipError_t launch_server(const mgx_handle *h, const ServerArgs &sv, unsigned blocks, int *resident_per_cu)
+{
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_per_cu, (const void *)step_server_kernel<F>, BLOCK, 0);
+    if (e != hipSuccess) return e;
+    if ((int64_t)*resident_per_cu * (h->n_cu > 0 ? h->n_cu : 1) < (int64_t)blocks) return hipErrorLaunchOutOfResources;
+    step_server_kernel<F><<<blocks, BLOCK, 0, h->server_stream>>>(h->k, sv, h->t);
+    return hipGetLastError();
+}
+
 static inline unsigned multi_blocks(int64_t n) { return (unsigned)((n + BLOCK_MULTI - 1) / BLOCK_MULTI); }
 
 // observation of the state at series index t into obs [N, D]
@@ -374,6 +394,8 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->prefetch_stream = nullptr; h->prefetch_gate = nullptr; h->prefetch_done = nullptr; h->prefetch_pending = false;
     h->prefetch_pooled = false;
     h->rows_direct = false;
+    h->server_running = false; h->server_immediate = false; h->server_ctl = nullptr; h->server_host = nullptr; h->server_signal = nullptr;
+    h->server_stream = nullptr; h->server_gate = nullptr; h->server_posted = 0; h->server_max_steps = 0;
     h->windowed = false; h->rolling = false;
     h->k.row_mask = -1;
     h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.ar_fixed_length = 0; h->k.ar_lo = 0; h->k.ar_hi = 0;
@@ -397,6 +419,12 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
 void mgx_destroy(mgx_handle *h)
 {
     if (!h) return;
+    if (h->server_running) { int32_t n; (void)mgx_server_stop(h, &n); }
+    if (h->server_stream) { (void)hipStreamSynchronize(h->server_stream); (void)hipStreamDestroy(h->server_stream); }
+    if (h->server_gate) (void)hipEventDestroy(h->server_gate);
+    if (h->server_ctl) (void)hipFree(h->server_ctl);
+    if (h->server_signal) (void)hipFree(h->server_signal);
+    if (h->server_host) (void)hipHostFree(h->server_host);
     for (int j = 0; j < MGX_MAX_SHARDS; j++) {
         if (h->shard_stream[j]) (void)hipStreamSynchronize(h->shard_stream[j]);      // (pooled: not destroyed with the handle)
         if (h->shard_event[j]) (void)hipEventDestroy(h->shard_event[j]);
@@ -807,6 +835,7 @@ int mgx_reset(mgx_handle *h, int32_t initial_step, void *obs, mgx_stream stream)
 {
     g_err[0] = 0;
     if (!h) return fail(MGX_ERR_INVALID, "mgx_reset: NULL handle");
+    if (h->server_running) return fail(MGX_ERR_INVALID, "mgx_reset: the resident step server owns the state (mgx_server_stop first)");
     leave_windows(h);
     const int32_t t0 = initial_step >= 0 ? initial_step : h->layout.initial_step;
     if (t0 >= h->layout.final_step)
@@ -1289,6 +1318,7 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
 static int check_step_args(const mgx_handle *h, const void *actions, const double *reward, const void *obs, int32_t K, const char *who)
 {
     if (!h || !reward || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "%s: NULL argument", who);
+    if (h->server_running) return fail(MGX_ERR_INVALID, "%s: the resident step server owns the state (mgx_server_stop first)", who);
     if (K <= 0) return fail(MGX_ERR_INVALID, "%s: K must be positive", who);
     if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
         return K == 1 ? fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, step_limit(h))
@@ -1349,6 +1379,7 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
 {
     g_err[0] = 0;
     if (!h || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_step_k: NULL argument");
+    if (h->server_running) return fail(MGX_ERR_INVALID, "mgx_step_k: the resident step server owns the state (mgx_server_stop first)");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_step_k: K must be positive");
     if (h->rolling) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: rolling windows take single steps (grids restart between steps)");
     if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
@@ -1531,6 +1562,7 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
 {
     g_err[0] = 0;
     if (!h || !action_id || !table) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: NULL argument");
+    if (h->server_running) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: the resident step server owns the state (mgx_server_stop first)");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: K must be positive");
     if (h->rolling) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: rolling windows take single steps");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: needs exactly one module of every kind "
@@ -1565,6 +1597,7 @@ int mgx_rollout_lists(mgx_handle *h, const int32_t *action_id, int per_step, con
 {
     g_err[0] = 0;
     if (!h || !action_id || !lists) return fail(MGX_ERR_INVALID, "mgx_rollout_lists: NULL argument");
+    if (h->server_running) return fail(MGX_ERR_INVALID, "mgx_rollout_lists: the resident step server owns the state (mgx_server_stop first)");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_lists: K must be positive");
     if (n_lists <= 0 || list_len <= 0 || list_len > 3 * MGX_MAX_INSTANCES)
         return fail(MGX_ERR_INVALID, "mgx_rollout_lists: need n_lists > 0 and list_len in [1, %d]", 3 * MGX_MAX_INSTANCES);
@@ -1815,6 +1848,118 @@ int mgx_normalise_series(mgx_handle *h, void *load_n, void *pv_n, void *grid_n, 
     if (h->layout.has_grid) launch(2, grid_n, 4);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "normalise_series_kernel launch");
+}
+
+// ---- resident step server ------------------------------------------------------------------------------------------
+int mgx_server_start(mgx_handle *h, const mgx_server_slot *slots, int32_t n_slots, int normalized, int32_t max_steps,
+                     int32_t idle_timeout_ms, int immediate, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !slots) return fail(MGX_ERR_INVALID, "mgx_server_start: NULL argument");
+    if (h->server_running) return fail(MGX_ERR_INVALID, "mgx_server_start: the server is already running");
+    if (n_slots < 1 || n_slots > MGX_SERVER_MAX_SLOTS) return fail(MGX_ERR_INVALID, "mgx_server_start: n_slots must be in [1, %d]", MGX_SERVER_MAX_SLOTS);
+    if (max_steps < 1) return fail(MGX_ERR_INVALID, "mgx_server_start: max_steps must be positive");
+    if (idle_timeout_ms < 1 || idle_timeout_ms > 60000) return fail(MGX_ERR_INVALID, "mgx_server_start: idle_timeout_ms must be in [1, 60000]");
+    if (h->multi || h->windowed || h->rolling || h->inplace || dev_counter(h) || h->n_shards > 1)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: lock-step stepping of one module of every kind per grid only (no per-grid windows, "
+                                         "device counter or shards)");
+    if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: not offered with forecast noise");
+    if (h->t < 0 || (int64_t)h->t + max_steps > step_limit(h))
+        return fail(MGX_ERR_RANGE, "mgx_server_start: steps [%d, %d) leave the time series (length %d)", h->t, h->t + max_steps, step_limit(h));
+    bool any_obs = false;
+    for (int32_t j = 0; j < n_slots; j++) {
+        if (!slots[j].reward || (h->action_dim > 0 && !slots[j].actions)) return fail(MGX_ERR_INVALID, "mgx_server_start: slot %d: NULL actions / reward", j);
+        any_obs = any_obs || slots[j].obs != nullptr;
+    }
+    if (any_obs) {
+        if (h->k.H > 0 && !h->k.obs_state_only)
+            return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: whole rows need a forecast window per step: use MGX_OBS_ROWS_STATE_ONLY / "
+                                             "_COMPACT (rings / views hold the windows) or horizon 0");
+        if (int rc = need_obs_bounds(h, "mgx_server_start")) return rc;
+    }
+    DeviceGuard on_device(h->device);
+    hipError_t e = hipSuccess;
+    if (!h->server_stream) {
+        e = hipStreamCreateWithFlags(&h->server_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->server_gate, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->server_ctl, sizeof(ServerCtl));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&h->server_host, sizeof(ServerHostWords), hipHostMallocMapped);
+        if (e == hipSuccess) e = hipExtMallocWithFlags((void **)&h->server_signal, 8, hipMallocSignalMemory);
+        if (e != hipSuccess) return hip_fail(e, "mgx_server_start: allocating the mailbox");
+    }
+    ServerCtl init;
+    memset(&init, 0, sizeof(init));
+    for (int32_t j = 0; j < n_slots; j++)
+        init.slot[j] = ServerSlot{slots[j].actions, slots[j].reward, slots[j].done, slots[j].obs};
+    h->server_host->seq = 0; h->server_host->stop = 0;
+    hipStream_t st = (hipStream_t)stream;
+    // the mailbox is written, and everything queued on the caller's stream is done, before the kernel looks at either
+    e = hipMemcpyAsync(h->server_ctl, &init, sizeof(init), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(h->server_signal, 0, 8, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);                 // (`init` is a host temporary; start is not on the per-step path)
+    if (e != hipSuccess) return hip_fail(e, "mgx_server_start: writing the mailbox");
+    ServerArgs sv;
+    sv.ctl = h->server_ctl;
+    void *host_dev = nullptr;
+    e = hipHostGetDevicePointer(&host_dev, h->server_host, 0);
+    if (e != hipSuccess) return hip_fail(e, "mgx_server_start: mapping the host words");
+    sv.host = (const ServerHostWords *)host_dev;
+    sv.done_signal = h->server_signal;
+    sv.n_slots = n_slots; sv.n_workers = (int32_t)blocks_for(h->k.N); sv.max_steps = max_steps; sv.normalized = normalized; sv.immediate = immediate != 0;
+    sv.idle_ticks = (int64_t)idle_timeout_ms * 100000; sv.life_ticks = (int64_t)60000 * 100000;      // 100 MHz
+    int per_cu = 0;
+    MGX_DISPATCH_F(h->flags, (e = launch_server<F>(h, sv, (unsigned)sv.n_workers + 1, &per_cu)));
+    if (e == hipErrorLaunchOutOfResources)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: %d workgroups cannot all be resident (%d per CU x %d CUs): the server needs every "
+                                         "grid on the chip at once", sv.n_workers + 1, per_cu, h->n_cu);
+    if (e != hipSuccess) return hip_fail(e, "step_server_kernel launch");
+    h->server_running = true; h->server_immediate = immediate != 0; h->server_posted = 0; h->server_max_steps = max_steps;
+    return MGX_OK;
+}
+
+int mgx_server_post(mgx_handle *h, mgx_stream stream)
+{
+    if (!h || !h->server_running) { g_err[0] = 0; return fail(MGX_ERR_INVALID, "mgx_server_post: the server is not running"); }
+    if ((int32_t)h->server_posted >= h->server_max_steps) { g_err[0] = 0; return fail(MGX_ERR_RANGE, "mgx_server_post: the burst's %d steps are all posted", h->server_max_steps); }
+    h->server_posted += 1;
+    if (h->server_immediate) {
+        __atomic_store_n(&h->server_host->seq, h->server_posted, __ATOMIC_RELEASE);
+        return MGX_OK;
+    }
+    hipError_t e = hipStreamWriteValue32((hipStream_t)stream, &h->server_ctl->seq, h->server_posted, 0);
+    if (e != hipSuccess) { g_err[0] = 0; h->server_posted -= 1; return hip_fail(e, "mgx_server_post: hipStreamWriteValue32"); }
+    return MGX_OK;
+}
+
+int mgx_server_wait(mgx_handle *h, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !h->server_running) return fail(MGX_ERR_INVALID, "mgx_server_wait: the server is not running");
+    hipError_t e = hipStreamWaitValue32((hipStream_t)stream, h->server_signal, h->server_posted, hipStreamWaitValueGte, 0xffffffffu);
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "mgx_server_wait: hipStreamWaitValue32");
+}
+
+int mgx_server_stop(mgx_handle *h, int32_t *steps_done)
+{
+    g_err[0] = 0;
+    if (steps_done) *steps_done = 0;
+    if (!h || !h->server_running) return fail(MGX_ERR_INVALID, "mgx_server_stop: the server is not running");
+    __atomic_store_n(&h->server_host->stop, h->server_posted + 1, __ATOMIC_RELEASE);
+    hipError_t e = hipStreamSynchronize(h->server_stream);
+    h->server_running = false;
+    if (e != hipSuccess) return hip_fail(e, "mgx_server_stop: waiting for the kernel");
+    uint32_t words[4] = {0, 0, 0, 0};
+    e = hipMemcpy(words, h->server_ctl, sizeof(words), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "mgx_server_stop: reading the mailbox");
+    const uint32_t status = words[2], done = words[3];
+    h->t += (int32_t)done;
+    h->counter_stream = h->server_stream;
+    if (steps_done) *steps_done = (int32_t)done;
+    if (done < h->server_posted)
+        return fail(MGX_ERR_RANGE, "mgx_server_stop: the burst ended after %u of %u posted steps (%s); the counter stands at %d", done,
+                    h->server_posted, status == 2 ? "idle timeout" : (status == 3 ? "lifetime cap" : "stopped"), h->t);
+    return MGX_OK;
 }
 
 int mgx_metrics(mgx_handle *h, const double *values, int32_t M, double *sums, mgx_stream stream)

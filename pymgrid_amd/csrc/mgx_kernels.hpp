@@ -1799,6 +1799,268 @@ __global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a
     if (violations) violations[i] = xv;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Resident step server (mgx_server_start / _post / _wait / _stop): the Gym cadence WITHOUT a launch per env-step.
+// One kernel stays on the chip for a whole burst of steps: every lane keeps its grid's parameters, dynamic state and bounds in
+// registers, step k takes its control from slot k % R of a ring of caller-owned buffers and leaves reward / done / observation
+// in the same slot.  Steps are RELEASED through a mailbox word -- `seq`, the number of steps posted so far: written in stream
+// order behind the kernel that produced the controls (hipStreamWriteValue32: a command-processor packet, no launch) or, when the
+// controls are already on the device, by a plain store of the host into mapped memory -- and COMPLETION comes back through a
+// signal word (`done`: hipStreamWaitValue32 / a polling consumer).
+//
+// Workgroups: ONE decider (block 0) + blocks_for(N) workers.  The decider alone reads the mailbox, the stop word and the
+// clock, and publishes `go` = how many steps are released (| FINAL when nothing more will come): a single decision point, so a
+// burst that ends (stop, idle timeout, lifetime cap: the kernel can never outlive its host) ends at the SAME step for every
+// grid.  Workers poll `go`, run released steps back to back (no barrier between workgroups: grids do not interact) and bump an
+// arrival counter per slot with a no-return atomic; the decider adds the counters up and advances `done`.
+// The series row of step t + 1 is loaded once: it is the "current value" of step t's observation and the input of step t + 1.
+// ------------------------------------------------------------------------------------------------------
+constexpr int SERVER_MAX_SLOTS = 8;
+constexpr int SERVER_LANES = 16;                  // arrival counters per slot (workgroup b bumps counter b % 16)
+constexpr uint32_t SERVER_FINAL = 0x80000000u;
+
+struct ServerSlot {
+    const void *actions;                          // [N, A] controls of the step (action format of the handle)
+    double *reward;                               // [N]
+    uint8_t *done;                                // [N] or NULL
+    void *obs;                                    // [N, D] (H = 0 rows), [N, S] (compact state) or NULL
+};
+
+struct ServerCtl {                                // device memory
+    uint32_t go;                                  // decider -> workers: steps released | SERVER_FINAL
+    uint32_t seq;                                 // host -> decider (stream-ordered posts): steps posted
+    uint32_t status;                              // 0 running, 1 stopped, 2 idle timeout, 3 lifetime cap
+    uint32_t steps_done;                          // steps every grid has taken when the kernel left
+    uint32_t arrive[SERVER_MAX_SLOTS][SERVER_LANES];      // monotonic: arrivals of all laps
+    ServerSlot slot[SERVER_MAX_SLOTS];
+};
+
+struct ServerHostWords {                          // pinned host memory, mapped: the host stores, the decider loads
+    volatile uint32_t seq;                        // immediate posts
+    volatile uint32_t stop;                       // 0 = run; n + 1 = leave once n steps have been taken
+};
+
+struct ServerArgs {
+    ServerCtl *ctl;
+    const ServerHostWords *host;
+    uint32_t *done_signal;                        // signal memory (hipStreamWaitValue32)
+    int32_t n_slots, n_workers, max_steps, normalized, immediate;
+    int64_t idle_ticks, life_ticks;               // 100 MHz ticks
+};
+
+// MGX_SERVER_SC1 (experiment): no L2-wide fences per step -- the controls are loaded and the outputs stored with agent-scope
+// (sc1) accesses instead, element by element
+#ifndef MGX_SERVER_SC1
+#define MGX_SERVER_SC1 0
+#endif
+template <typename T>
+__device__ __forceinline__ T server_load(const T *p)
+{
+    if constexpr (MGX_SERVER_SC1 != 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <typename T>
+__device__ __forceinline__ void server_store(T *p, T v)
+{
+    if constexpr (MGX_SERVER_SC1 != 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <int F>
+__global__ __launch_bounds__(BLOCK) void step_server_kernel(const KArgs a, const ServerArgs sv, int32_t t0)
+{
+    ServerCtl *ctl = sv.ctl;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        // ---- the decider: one wave (block 0: dispatched first)
+        if (tid >= 64) return;
+        const int64_t born = wall_clock64();
+        int64_t last = born;
+        uint32_t released = 0, done = 0, status = 0;
+        bool final_out = false;
+        const uint32_t cap = (uint32_t)sv.max_steps;
+        while (true) {
+            uint32_t posted = 0, stop = 0;
+            if (tid == 0) {
+                posted = sv.immediate ? __hip_atomic_load((const uint32_t *)&sv.host->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                      : __hip_atomic_load(&ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                stop = __hip_atomic_load((const uint32_t *)&sv.host->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            posted = __shfl(posted, 0, 64); stop = __shfl(stop, 0, 64);
+            const int64_t now = wall_clock64();
+            uint32_t want = posted < cap ? posted : cap;
+            if (stop && want > stop - 1) want = stop - 1;
+            if (!final_out && want > released) {
+                released = want; last = now;
+                if (tid == 0) __hip_atomic_store(&ctl->go, released, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // completion: slot s has finished its lap l when its 16 counters add up to n_workers (l + 1)
+            uint32_t nd = done;
+            while (nd < released) {
+                const uint32_t slot = nd % (uint32_t)sv.n_slots, lap = nd / (uint32_t)sv.n_slots;
+                uint32_t c = tid < SERVER_LANES ? __hip_atomic_load(&ctl->arrive[slot][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+                c = __shfl(c, 0, 64);
+                if (c < (uint32_t)sv.n_workers * (lap + 1)) break;
+                nd++;
+            }
+            if (nd != done) {
+                done = nd; last = now;
+                if (tid == 0) __hip_atomic_store(sv.done_signal, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (!final_out) {
+                if (stop && released >= stop - 1) status = 1;
+                else if (released >= cap) status = 1;
+                else if (now - born > sv.life_ticks) status = 3;
+                else if (done == released && now - last > sv.idle_ticks) status = 2;
+                if (status) {
+                    final_out = true;
+                    if (tid == 0) __hip_atomic_store(&ctl->go, released | SERVER_FINAL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (final_out && done == released) break;
+            if (final_out && now - last > sv.life_ticks) break;             // (a worker that never arrives: give up rather than spin forever)
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (tid == 0) {
+            ctl->steps_done = done; ctl->status = status;
+            // whoever waits on the signal for steps that will never be taken is let through (mgx_server_stop reports them)
+            if (status != 1 || (int32_t)done < sv.max_steps)
+                __hip_atomic_store(sv.done_signal, 0x7fffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    // ---- a worker: 256 grids, one lane each
+    __shared__ uint32_t go_lds;
+    const int64_t N = a.N;
+    const uint32_t wb = blockIdx.x - 1;
+    const int64_t i = (int64_t)wb * BLOCK + tid;
+    const bool active = i < N;
+    const int64_t ic = active ? i : N - 1;
+    constexpr int A_DIM = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
+    constexpr bool GRID = (F & F_GRID) != 0;
+    Params p; State s; Derived d;
+    load_state<F>(a.c, ic, true, s);
+    load_params<F>(a.c, ic, p);
+    derive<F>(p, d);
+    const bool fact = factorised(a.c);
+    GridFactors f;
+    f.lr = 0.0; f.pr = 0.0; f.lp = 0u; f.pp = 0u; f.cp = 0u; f.pat = 0u;
+    if (fact) load_factors<F>(a.c, ic, f);
+    // observation bounds (whole H = 0 rows only)
+    const bool rows = a.obs_state_only == 0;
+    double lo[GRID ? 6 : 2], hi[GRID ? 6 : 2];
+#pragma unroll
+    for (int c = 0; c < (GRID ? 6 : 2); c++) { lo[c] = 0.0; hi[c] = 0.0; }
+    if (rows && a.c.load_lo != nullptr) {
+        lo[0] = a.c.load_lo[ic]; hi[0] = a.c.load_hi[ic]; lo[1] = a.c.pv_lo[ic]; hi[1] = a.c.pv_hi[ic];
+        if constexpr (GRID) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) { lo[2 + c] = a.c.grid_lo[c * N + ic]; hi[2 + c] = a.c.grid_hi[c * N + ic]; }
+        }
+    }
+    // the series row of a step: materialised arrays or the factors
+    auto series_at = [&](int32_t row, Inputs &in) __attribute__((always_inline)) {
+        const int64_t r = row < a.T ? row : a.T - 1;
+        if (fact) { fact_series<F>(a.c, N, ic, r, f, in, 0); return; }
+        in.load = a.c.load_ts[r * N + ic];
+        in.pv = a.c.pv_ts[r * N + ic];
+        in.g_stat = 1.0;
+        if constexpr (GRID) {
+            const double *g = a.c.grid_ts + (r * 4) * N + ic;
+            in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
+        }
+    };
+    Inputs cur;
+    series_at(t0, cur);
+    uint32_t k = 0;
+    while (true) {
+        if (tid == 0) {
+            uint32_t g;
+            while (true) {
+                g = __hip_atomic_load(&ctl->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((g & ~SERVER_FINAL) > k || (g & SERVER_FINAL)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            // The controls of this step were written by another kernel: ONE acquire per workgroup (it invalidates the CU's L1 and
+            // the XCD's L2 for every wave that loads behind the barrier) -- one per wave made a step cost 74 us instead of ...
+            if constexpr (MGX_SERVER_SC1 == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            go_lds = g;
+        }
+        __syncthreads();
+        const uint32_t g = go_lds;
+        if ((g & ~SERVER_FINAL) <= k) break;                      // FINAL, and every released step has been taken
+        const uint32_t sl = k % (uint32_t)sv.n_slots;
+        const ServerSlot slot = ctl->slot[sl];
+        const int32_t t = t0 + (int32_t)k;
+        Inputs nxt;
+        if (active) {
+            Inputs in = cur;
+            if (a.act_f32) {
+                const float *ap = (const float *)slot.actions + i * A_DIM;
+                int q = 0;
+                if constexpr (F & F_GENSET) { in.a_goal = (double)server_load(ap + q); in.a_gen = (double)server_load(ap + q + 1); q += 2; }
+                if constexpr (F & F_BATTERY) { in.a_bat = (double)server_load(ap + q); q += 1; }
+                if constexpr (GRID) { in.a_grid = (double)server_load(ap + q); }
+            } else {
+                const double *ap = (const double *)slot.actions + i * A_DIM;
+                int q = 0;
+                if constexpr (F & F_GENSET) { in.a_goal = server_load(ap + q); in.a_gen = server_load(ap + q + 1); q += 2; }
+                if constexpr (F & F_BATTERY) { in.a_bat = server_load(ap + q); q += 1; }
+                if constexpr (GRID) { in.a_grid = server_load(ap + q); }
+            }
+            series_at(t + 1, nxt);                                // the row after: this step's observation, the next step's input
+            Outputs o;
+            step_core<F>(p, d, s, in, sv.normalized != 0, true, false, o);
+            server_store(slot.reward + i, shaped_reward<F>(a.shaper, o));
+            if (slot.done) server_store(slot.done + i, done_at(a, i, t));
+            if (slot.obs) {
+                constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
+                auto put = [&](auto *row) __attribute__((always_inline)) {
+                    typedef typename std::remove_pointer<decltype(row)>::type OT;
+                    OT stc[6] = {0, 0, 0, 0, 0, 0};                      // genset 4, battery 2 (static indices only: registers)
+                    observe_state_cols<F, OT>(a, p, s, stc, 0);
+                    if (!rows) {                                         // state columns: compact [N, S], or inside (ring) rows [N, D]
+                        const bool compact = a.obs_state_only == 2;
+#pragma unroll
+                        for (int j = 0; j < NSTATE; j++) {
+                            const int col = compact ? j : ((F & F_GENSET) != 0 && j < 4 ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0)));
+                            server_store(row + col, stc[j]);
+                        }
+                        return;
+                    }
+                    const bool in_series = t + 1 < a.T;
+                    server_store(row + a.col_load, (OT)obs_series_value(nxt.load, in_series, false, lo[0], hi[0], (hi[0] + lo[0]) / 2, space_spread(lo[0], hi[0])));
+                    server_store(row + a.col_pv, (OT)obs_series_value(nxt.pv, in_series, false, lo[1], hi[1], (hi[1] + lo[1]) / 2, space_spread(lo[1], hi[1])));
+#pragma unroll
+                    for (int j = 0; j < NSTATE; j++)
+                        server_store(row + ((F & F_GENSET) != 0 && j < 4 ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0))), stc[j]);
+                    if constexpr (GRID) {
+                        const double gv[4] = {nxt.g_pimp, nxt.g_pexp, nxt.g_co2, nxt.g_stat};
+#pragma unroll
+                        for (int c = 0; c < 4; c++)
+                            server_store(row + a.col_grid + c, (OT)obs_series_value(gv[c], in_series, false, lo[2 + c], hi[2 + c], (hi[2 + c] + lo[2 + c]) / 2,
+                                                                                     space_spread(lo[2 + c], hi[2 + c])));
+                    }
+                };
+                const int64_t pitch = a.obs_state_only == 2 ? NSTATE : a.obs_dim;
+                if (a.obs_f32) put((float *)slot.obs + i * pitch);
+                else put((double *)slot.obs + i * pitch);
+            }
+            cur = nxt;
+        }
+        __syncthreads();                                          // every wave's stores have been taken by the L2 (vmcnt(0) + barrier; also
+                                                                  // the last reader of go_lds is through)
+        if (tid == 0) {                                           // ... and ONE release per workgroup writes them back before the arrival
+            if constexpr (MGX_SERVER_SC1 != 0) __hip_atomic_fetch_add(&ctl->arrive[sl][wb & (SERVER_LANES - 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(&ctl->arrive[sl][wb & (SERVER_LANES - 1)], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        k++;
+    }
+    if (active) store_state<F>(a.c, i, s);
+}
+
 // one wave that idles for `ticks` of the 100 MHz real-time counter: mgx_fork staggers the shard streams with it
 static __global__ void stagger_kernel(int64_t ticks)
 {
