@@ -260,13 +260,17 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
     K_ring = 32          # ring depth: 25 vs 27.5 us per fleet step against K = 16 (profiles/r04/exp_fleet_refill_occupancy.txt)
     out = {}
     archs = ("genset+battery", "battery+grid", "genset+battery+grid")
-    for contract in ("rows", "views"):
+    #   rows_colmajor   the same [N, D] observation per step, its ring blocks stored column-major (a view with strides (1, pitch)):
+    #                   the state columns a step adds are coalesced runs instead of 48 bytes per row
+    for contract_name in ("rows", "rows_colmajor", "views"):
+        contract = "rows" if contract_name.startswith("rows") else "views"
         for dt_name, dt in (("float64", torch.float64), ("float32", torch.float32)):
-            name = f"{dt_name}_{contract}"
+            name = f"{dt_name}_{contract_name}"
             batches = [generate(per * world, n_steps=rows, seed=43 + k, arch=arch, horizon=24, device=dev, rank=rank,
                                 world=world, series=series, uniform_columns=uniform) for k, arch in enumerate(archs)]
             if contract == "rows":
-                fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K_ring, reuse_outputs=3 * K_ring)
+                fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K_ring, reuse_outputs=3 * K_ring,
+                                                   obs_layout="columns" if contract_name == "rows_colmajor" else "rows")
             else:
                 fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_views=True, reuse_outputs=3 * K_ring)
             gen = torch.Generator(device=dev); gen.manual_seed(11 + rank)
@@ -326,9 +330,9 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
             ach = alg / (gpu / steps) / 1e9
             # PMC bytes of the same fleet shape, if a profile of it -- taken on the kernels now running -- is committed
             traffic = None
-            tf, traffic_src = profile_json(f"traffic_fleet_{contract}_{dt_name}.json")
+            tf, traffic_src = profile_json(f"traffic_fleet_{contract_name}_{dt_name}.json")
             if tf is not None and (tf.get("grids_per_gpu"), tf.get("series"), tf.get("contract"), tf.get("dtype"),
-                                   tf.get("obs_prefetch")) == (3 * per, series, contract, dt_name, K_ring if contract == "rows" else tf.get("obs_prefetch")):
+                                   tf.get("obs_prefetch")) == (3 * per, series, contract_name, dt_name, K_ring if contract == "rows" else tf.get("obs_prefetch")):
                 traffic = tf["hbm_bytes_per_fleet_step"]
             elif tf is not None:
                 traffic_src += ": another fleet shape"
@@ -346,7 +350,9 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
                                       "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
                                       "avg_launch_us": gpu / steps * 1e6, "launch": launch,
                                       "kernel": "fleet_step_kernel" + (f" + obs_windows_k_kernel<F> x3 / {K_ring}" if contract == "rows" else ""),
-                                      "refill": fleet.refill if contract == "rows" else None}}
+                                      "refill": fleet.refill if contract == "rows" else None,
+                                      "ring_blocks": ("column-major [D, pitch]: obs = the [N, D] view with strides (1, pitch)" if contract_name == "rows_colmajor"
+                                                      else ("row-major [N, D]" if contract == "rows" else None))}}
             obs_dims = [e.layout.obs_dim for e in fleet.envs]
             fleet.close()
             del fleet, batches
@@ -778,6 +784,96 @@ def main():
             return out
         closed = guarded("closed_loop_policy_gym_steps", closed_loop)
 
+    # The GENERAL path on the board: 2 gensets + 2 batteries + 1 grid per microgrid (module_container.py:355-413 allows any
+    # multiplicity; such layouts run on the general kernels: columns [n, N], MicrogridStep's lists in LDS).  Single Gym steps and the
+    # K-step launch, each against its own algorithmic bytes (SURVEY 8(d) with per-instance parameter / state counts).
+    general = None
+    if not args.no_side_modes:
+        def general_path():
+            from pymgrid_amd.generator import widen
+            rows_g = min(args.rows, 1200)                   # materialised series [T, n, N]: 1 200 rows are 10 GB at N = 100 000
+            base = generate(n_total, n_steps=rows_g, seed=42, arch="genset+battery+grid", device=dev, rank=rank, world=world)
+            gb = widen(base, n_genset=2, n_battery=2, n_grid=1)
+            del base
+            ge = StepEngine(gb)
+            Lg = ge.layout
+            gen = torch.Generator(device=dev); gen.manual_seed(3 + rank)
+            a1 = torch.rand(N, Lg.action_dim, dtype=torch.float64, device=dev, generator=gen)
+            Kg = min(chunk, 32)
+            aK = torch.rand(Kg, N, Lg.action_dim, dtype=torch.float64, device=dev, generator=gen)
+            out = {}
+            reward1 = torch.empty(N, dtype=torch.float64, device=dev)
+
+            def run(fn, n, per_call_steps):
+                ge.reset(0, want_obs=False)
+                for _ in range(max(8, n // 8)):
+                    fn()
+                ge.reset(0, want_obs=False)
+                mdist.barrier(); torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter(); e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record(); torch.cuda.synchronize(dev)
+                wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+                gpu = mdist.max_over_ranks(e0.elapsed_time(e1) * 1e-3, dev)
+                mdist.barrier()
+                return wall, gpu, n * per_call_steps
+            n1 = min(400, rows_g - 64)
+            wall, gpu, steps1 = run(lambda: ge.step(a1, want_obs=False, want_log=False, out=dict(reward=reward1), want_done=False), n1, 1)
+            b1 = (Lg.bytes_per_step() - 1) * N              # (no done byte: lock-step)
+            out["single_steps"] = {"value": n_total * steps1 / wall, "us_per_step": gpu / steps1 * 1e6,
+                                   "roofline": {"bound": "hbm", "achieved": b1 / (gpu / steps1) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": b1 / (gpu / steps1) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                "algorithmic_bytes_per_launch": b1, "kernel": "step_multi_kernel<7>",
+                                                "bytes_per_env_step": Lg.bytes_per_step() - 1}}
+            nK = max(2, min(12, (rows_g - 64) // Kg))
+            wall, gpu, stepsK = run(lambda: ge.step_k(aK, normalized=True, reward=True, soc_trace=False), nK, Kg)
+            # the K-step loop of the general path keeps nothing in registers: every step re-reads parameters and state
+            bK = (Lg.bytes_per_step() - 1) * N
+            out["k_step_launches"] = {"value": n_total * stepsK / wall, "us_per_step": gpu / stepsK * 1e6, "steps_per_launch": Kg,
+                                      "roofline": {"bound": "hbm", "achieved": bK / (gpu / stepsK) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": bK / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                   "algorithmic_bytes_per_launch": bK * Kg, "kernel": "step_k_multi_kernel<7>",
+                                                   "bytes_per_env_step": Lg.bytes_per_step() - 1,
+                                                   "note": "a K-step loop around the general step: parameters and state are re-read "
+                                                           "every step (cache hits), charged per step like the single launches"}}
+            out["layout"] = "2 gensets + 2 batteries + 1 grid + load + pv per microgrid (general kernels), materialised series"
+            out["grids_per_gpu"], out["rows"] = N, rows_g
+            ge.close()
+            return out
+        general = guarded("general_path_2g2b1grid", general_path)
+        torch.cuda.empty_cache()
+
+    # The resident step server (mgx_server_*): Gym steps WITHOUT a launch per step, controls through a device mailbox.  Reported
+    # because it was asked for and measured; it LOSES to the launches (the per-step cache maintenance of a resident kernel costs
+    # more than the launch it saves: DESIGN.md, profiles/r04/exp_step_server*.txt).
+    server = None
+    if not args.no_side_modes and args.arch == "genset+battery":
+        def step_server():
+            b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=args.series)
+            e = StepEngine(b, obs_dtype=torch.float32, action_dtype=torch.float32)
+            steps, R = min(2000, args.rows - 100), 8
+            slots = e.server_start(n_slots=R, max_steps=steps, want_obs=True, immediate=True, idle_timeout_ms=500)
+            for sl in slots:
+                sl["actions"].uniform_()
+            cs = torch.cuda.current_stream(dev)
+            cs.synchronize()
+            t0 = time.perf_counter()
+            for k0 in range(0, steps, R):
+                for _ in range(min(R, steps - k0)):
+                    e.server_post()
+                e.server_wait()
+            cs.synchronize()
+            wall = time.perf_counter() - t0
+            served = e.server_stop()
+            e.close()
+            return {"value": n_total * served / mdist.max_over_ranks(wall, dev), "us_per_step": wall / max(served, 1) * 1e6, "steps": served,
+                    "what": "env.step ALONE through the resident server: float32 controls already on the device, steps released by host "
+                            "stores in bursts of 8 (one hipStreamWaitValue32 per burst), float32 observation rows + rewards written per step"}
+        server = guarded("resident_step_server", step_server)
+        torch.cuda.empty_cache()
+
     hetero = None
     if args.hetero_steps > 0:
         hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist, args.rows,
@@ -838,6 +934,8 @@ def main():
                                   "collective_hung": mdist.last_collective.get("hung", False)},
             "closed_loop_policy_gym_steps": closed,
             "hetero_h24_gym_steps": hetero,
+            "general_path_2g2b1grid": general,
+            "resident_step_server": server,
             "prewarm_seconds_per_mode": args.prewarm,
             "device_state_under_load": device_state or None,
         }

@@ -352,6 +352,16 @@ int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream)
  * 128-byte aligned and every 1-KB wave store of the refill begins and ends in a partial line; a ring [K, P, D] with
  * P = N rounded up to 16 rows, block k = the first N rows of ring[k], avoids that. */
 int mgx_set_ring_pitch(mgx_handle *h, int32_t rows);
+/* Layout of a ring BLOCK.  MGX_RING_ROWS (default): [P, D] row-major -- a grid's observation is D consecutive values, the
+ * reference's flat vector (envs/base/base.py:211-223).  MGX_RING_COLUMNS: [D, P] -- value (grid i, column c) at c * P + i, P = the
+ * ring pitch (mgx_set_ring_pitch; a multiple of 16): the SAME [N, D] matrix read with strides (1, P), which is what a policy's
+ * first matrix product takes either way.  Why: in a row-major block the step's state columns are 48 bytes at a 8 D-byte stride --
+ * 100 000 scattered partial lines per step, 3.5-4 us of a 24-us config-5 fleet step (profiles/r04/exp_fleet_state_patch_cost.txt) --
+ * in a column-major block they are six coalesced runs of 8 N bytes.  Applies to mgx_observe_windows[_ahead], the fleets' refills and
+ * the state-only `obs` target of the steps (pass the block's base).  Lock-step episodes only (mgx_patch_windows and the in-place /
+ * rolling modes keep row-major rings). */
+enum mgx_ring_layout { MGX_RING_ROWS = 0, MGX_RING_COLUMNS = 1 };
+int mgx_set_ring_layout(mgx_handle *h, int32_t layout);
 /* Rolling windows with prefetched rings: after mgx_reset_grids* has replaced the series rows of the grids with mask[i] != 0,
  * recompute the window columns of THEIR rows in blocks first_block .. K-1 of `ring` (block first_block = the row of
  * counter value current + ahead).  State columns are left as they are.  A ring written AHEAD of the counter

@@ -155,6 +155,7 @@ SYMBOLS = {
     "mgx_expand_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_check_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgx_set_ring_pitch": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mgx_set_ring_layout": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_patch_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgx_expand_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_rollout_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7),

@@ -142,11 +142,12 @@ class BatchLayout:
         """Algorithmic HBM bytes of one env-step of one grid for the single-step kernel:
         B = 8*(A + P_f + C_ts + 2*S_f + 2) + 2*S_i + P_i + 1 [+ 8*L] [+ 8*D + 8*C_ts]."""
         A = self.action_dim
-        P_f = 2 + 6 * int(self.has_battery) + 5 * int(self.has_genset) + 3 * int(self.has_grid)
-        C_ts = self.n_load + self.n_pv + 4 * int(self.has_grid)
-        S_f = int(self.has_battery)
-        S_i = 4 * int(self.has_genset)
-        P_i = 4 * int(self.has_genset)
+        # (per module INSTANCE: a microgrid with two gensets reads two parameter sets, module_container.py:355-413)
+        P_f = 2 + 6 * self.n_battery + 5 * self.n_genset + 3 * self.n_grid
+        C_ts = self.n_load + self.n_pv + 4 * self.n_grid
+        S_f = self.n_battery
+        S_i = 4 * self.n_genset
+        P_i = 4 * self.n_genset
         B = 8 * (A + P_f + C_ts + 2 * S_f + 2) + 2 * S_i + P_i + 1
         if log:
             B += 8 * len(self.log_names) + 8 * S_f     # the log also reads the pre-step SoC

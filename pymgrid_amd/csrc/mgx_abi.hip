@@ -381,7 +381,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->t = L->initial_step;
     h->k.shaper = MGX_SHAPER_NONE;
     h->k.noise_seed = 0; h->k.noise_increase = 0; h->k.obs_f32 = 0; h->k.obs_state_only = 0; h->k.act_f32 = 0;
-    h->k.done_bits = 0;
+    h->k.done_bits = 0; h->k.obs_colpitch = 0;
     h->full_c = *C;
     h->window_lo = L->initial_step; h->window_hi = final_step;
     h->k.g0 = 0; h->k.g1 = L->n_grids; h->k.grid_final = nullptr;
@@ -642,6 +642,7 @@ int mgx_patch_windows(mgx_handle *h, const uint8_t *mask, int32_t K, void *ring,
     if (K < 1 || first_block < 0 || first_block > K) return fail(MGX_ERR_INVALID, "mgx_patch_windows: first_block %d outside [0, K = %d]", first_block, K);
     if (ahead < 0) return fail(MGX_ERR_INVALID, "mgx_patch_windows: ahead = %d is negative", ahead);
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: needs exactly one module of every kind per grid");
+    if (h->k.obs_colpitch) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: not offered with column-major ring blocks");
     if (dev_counter(h)) return fail(MGX_ERR_UNSUPPORTED, "mgx_patch_windows: not offered in device-counter mode");
     if (int rc = need_obs_bounds(h, "mgx_patch_windows")) return rc;
     if (first_block == K) return MGX_OK;
@@ -666,7 +667,24 @@ int mgx_set_ring_pitch(mgx_handle *h, int32_t rows)
     g_err[0] = 0;
     if (!h) return fail(MGX_ERR_INVALID, "mgx_set_ring_pitch: NULL handle");
     if (rows < h->k.N) return fail(MGX_ERR_INVALID, "mgx_set_ring_pitch: %d rows per block, the batch has %d grids", rows, h->k.N);
+    if (h->k.obs_colpitch && rows % 16) return fail(MGX_ERR_INVALID, "mgx_set_ring_pitch: column-major blocks need a pitch that is a multiple of 16");
     h->ring_pitch = rows;
+    if (h->k.obs_colpitch) h->k.obs_colpitch = rows;
+    return MGX_OK;
+}
+
+int mgx_set_ring_layout(mgx_handle *h, int32_t layout)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_ring_layout: NULL handle");
+    if (layout != MGX_RING_ROWS && layout != MGX_RING_COLUMNS) return fail(MGX_ERR_INVALID, "mgx_set_ring_layout: unknown layout %d", layout);
+    if (layout == MGX_RING_COLUMNS) {
+        if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_set_ring_layout: needs exactly one module of every kind per grid");
+        if (h->windowed || h->rolling || h->inplace)
+            return fail(MGX_ERR_UNSUPPORTED, "mgx_set_ring_layout: column-major blocks are offered for lock-step episodes (restarts patch row-major rings)");
+        if (h->ring_pitch % 16) return fail(MGX_ERR_INVALID, "mgx_set_ring_layout: the ring pitch (%d) must be a multiple of 16 first (mgx_set_ring_pitch)", h->ring_pitch);
+    }
+    h->k.obs_colpitch = layout == MGX_RING_COLUMNS ? h->ring_pitch : 0;
     return MGX_OK;
 }
 
@@ -851,6 +869,7 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
     g_err[0] = 0;
     if (!h || !start || !load_w || !pv_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows: NULL argument");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: needs exactly one module of every kind per grid");
+    if (h->k.obs_colpitch) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: not offered with column-major ring blocks (mgx_set_ring_layout)");
     if (h->layout.has_grid && !grid_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows: grid_w is NULL but the layout has a GridModule");
     if (length && !final_rel) return fail(MGX_ERR_INVALID, "mgx_reset_windows: per-grid lengths need the final_rel buffer");
     if (h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: not offered in device-counter mode");
@@ -913,6 +932,7 @@ int mgx_reset_windows_rolling(mgx_handle *h, const int32_t *start, const int32_t
     g_err[0] = 0;
     if (!h || !start || !load_w || !pv_w || !final_abs) return fail(MGX_ERR_INVALID, "mgx_reset_windows_rolling: NULL argument");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: needs exactly one module of every kind per grid");
+    if (h->k.obs_colpitch) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: not offered with column-major ring blocks (mgx_set_ring_layout)");
     if (h->layout.has_grid && !grid_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows_rolling: grid_w is NULL but the layout has a GridModule");
     if (h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: not offered in device-counter mode");
     if (h->n_shards > 1) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows_rolling: not offered while the handle steps in shards");
@@ -954,6 +974,7 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
     g_err[0] = 0;
     if (!h || !start || !row_off || !final_abs) return fail(MGX_ERR_INVALID, "mgx_reset_episodes: NULL argument");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: needs exactly one module of every kind per grid");
+    if (h->k.obs_colpitch) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered with column-major ring blocks (mgx_set_ring_layout)");
     if (h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered in device-counter mode");
     if (h->n_shards > 1) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered while the handle steps in shards");
     if (!factorised(h->windowed ? h->full_c : h->k.c))
@@ -1876,6 +1897,8 @@ int mgx_server_start(mgx_handle *h, const mgx_server_slot *slots, int32_t n_slot
         if (h->k.H > 0 && !h->k.obs_state_only)
             return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: whole rows need a forecast window per step: use MGX_OBS_ROWS_STATE_ONLY / "
                                              "_COMPACT (rings / views hold the windows) or horizon 0");
+        if (h->k.obs_colpitch && h->k.obs_state_only == 1)
+            return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: state columns inside column-major ring blocks are not offered (use compact state rows)");
         if (int rc = need_obs_bounds(h, "mgx_server_start")) return rc;
     }
     DeviceGuard on_device(h->device);

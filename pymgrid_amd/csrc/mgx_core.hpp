@@ -49,6 +49,10 @@ struct KArgs {
     int32_t obs_state_only;  // obs arguments of step / observe receive ONLY the state columns (windows were prefetched):
                              // 1 = inside full rows [N, D], 2 = as a dense [N, S] array (MGX_OBS_ROWS_STATE_COMPACT)
     int32_t done_bits;       // fused launches write `done` as bit sets ([K, ceil(N / 16)] uint16) instead of bytes
+    // mgx_set_ring_layout(MGX_RING_COLUMNS): the blocks of the observation rings are COLUMN-major -- value (grid i, column c) of a
+    // block at c * obs_colpitch + i (obs_colpitch = the ring pitch in grids, >= N): a wave's 64 grids are then 512 consecutive
+    // bytes of every column, for the refill and for the state columns the step adds (0 = row-major blocks [N, D])
+    int32_t obs_colpitch;
     // first column of every module's block inside a flat observation row (mgx_layout.flat_order); fast path only
     int32_t col_load, col_pv, col_gen, col_bat, col_grid;
     int32_t shaper;          // mgx_reward_shaper

@@ -46,6 +46,23 @@ __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict_
     if (a.obs_state_only == 2) {            // MGX_OBS_ROWS_STATE_COMPACT
         if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * NSTATE, 0);
         else observe_state_cols<F>(a, p, s, (double *)obs + i * NSTATE, 0);
+    } else if (a.obs_state_only && a.obs_colpitch) {        // ... into a COLUMN-major ring block: the wave's grids are adjacent in every column
+        const int64_t P = a.obs_colpitch;
+        if (a.obs_f32) {
+            float st[6] = {0, 0, 0, 0, 0, 0};
+            observe_state_cols<F>(a, p, s, st, 0);
+            float *b = (float *)obs + i;
+#pragma unroll
+            for (int j = 0; j < NSTATE; j++)
+                b[(int64_t)(((F & F_GENSET) != 0 && j < 4) ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0))) * P] = st[j];
+        } else {
+            double st[6] = {0, 0, 0, 0, 0, 0};
+            observe_state_cols<F>(a, p, s, st, 0);
+            double *b = (double *)obs + i;
+#pragma unroll
+            for (int j = 0; j < NSTATE; j++)
+                b[(int64_t)(((F & F_GENSET) != 0 && j < 4) ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0))) * P] = st[j];
+        }
     } else if (a.obs_state_only) {          // the window columns of this row were prefetched (obs_windows_k_kernel)
 #ifdef MGX_EXP_COMPACT_PATCH                // TIMING EXPERIMENT ONLY (wrong rows): what do the partial-line state patches cost?
         if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * NSTATE, 0);
@@ -775,9 +792,24 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     const int32_t total = n_valid * D;                   // D is even (one load, one renewable module)
     typedef OT vec2 __attribute__((ext_vector_type(2)));
     const bool wide = (reinterpret_cast<uintptr_t>(ring) & (sizeof(vec2) - 1)) == 0;
+    constexpr int KW = OBS_K_THREADS / 64;
+    if (a.obs_colpitch) {
+        // COLUMN-major blocks: value (block k, column c, grid g0 + g) at (k * D + c) * P + g0 + g.  Thread (g, cq) writes column
+        // c = cq, cq + 16, ... of its grid for the wave's blocks k = wave', ...: the 16 grids of a (k, c) pair are ONE 128-byte line
+        // (P and g0 are multiples of 16), written whole by 16 adjacent lanes.  Nothing else ever writes into such a line's bytes
+        // except the step's state columns -- which are whole coalesced lines of their own here (a wave's 64 grids x 8 B per column).
+        const int64_t P = a.obs_colpitch;
+        const bool in_batch = i < N;
+        OT *outc = ring + g0 + g;
+        for (int32_t c = q; c < D; c += Q) {
+            const double *src = image + g * BP + map[c];
+            for (int32_t k = 0; k < K; k++)
+                if (in_batch) MGX_WIN_STORE((OT)src[k], outc + ((int64_t)k * D + c) * P);
+        }
+        return;
+    }
     // A lane's element schedule (which (grid, column) its j-th store carries) is the same for every block: the column map is
     // looked up once per element and reused for the wave's blocks k = wave, wave + 4, ... (image[... + k]: consecutive words)
-    constexpr int KW = OBS_K_THREADS / 64;
     const int64_t block_stride = (int64_t)plan.pitch * D;
     OT *out0 = ring + ((int64_t)wave * plan.pitch + g0) * D;
     // MGX_WIN_SKIP_STATE=1 (experiment, OFF): a ring written ahead of the counter would leave the state columns alone -- the

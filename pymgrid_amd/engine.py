@@ -187,20 +187,30 @@ class StepEngine:
         check(self._lib.mgx_set_ring_pitch(self._h, int(rows)))
         self._ring_pitch = int(rows)
 
+    def set_ring_layout(self, columns):
+        """``mgx_set_ring_layout``: True = column-major ring blocks -- the [N, D] observation of a block is then a view with
+        strides (1, pitch) (the pitch must be a multiple of 16: ``set_ring_pitch`` first)."""
+        check(self._lib.mgx_set_ring_layout(self._h, 1 if columns else 0))
+        self._ring_columns = bool(columns)
+
     def _check_ring(self, out):
         pitch = getattr(self, "_ring_pitch", self.N)
+        want = (1, pitch) if getattr(self, "_ring_columns", False) else (self.obs_dim, 1)      # strides of a block's [N, D] view
         if out.dim() != 3 or tuple(out.shape[1:]) != (self.N, self.obs_dim) or out.dtype != self.obs_dtype \
-                or out.device != self.device or out.stride(2) != 1 or out.stride(1) != self.obs_dim \
+                or out.device != self.device or (out.stride(1), out.stride(2)) != want \
                 or (out.shape[0] > 1 and out.stride(0) != pitch * self.obs_dim):
             raise ValueError(f"ring must be a {self.obs_dtype} tensor [K, {self.N}, {self.obs_dim}] on {self.device} whose "
-                             f"blocks are {pitch} rows apart (set_ring_pitch)")
+                             f"blocks are {pitch} rows apart (set_ring_pitch) with strides {want} inside a block (set_ring_layout)")
 
     def observe_windows(self, K=None, out=None):
         """Observation rows of the next K steps, ``ring[k]`` = the row of step counter t + k (block 0 complete, blocks
         1..K-1 without the state columns): every series value is read and normalised once instead of 1 + horizon times."""
         if out is None:
             pitch = getattr(self, "_ring_pitch", self.N)
-            out = torch.empty((int(K), pitch, self.obs_dim), dtype=self.obs_dtype, device=self.device)[:, :self.N]
+            if getattr(self, "_ring_columns", False):
+                out = torch.empty((int(K), self.obs_dim, pitch), dtype=self.obs_dtype, device=self.device)[:, :, :self.N].transpose(1, 2)
+            else:
+                out = torch.empty((int(K), pitch, self.obs_dim), dtype=self.obs_dtype, device=self.device)[:, :self.N]
         self._check_ring(out)
         self._call(self._lib.mgx_observe_windows, int(out.shape[0]), out.data_ptr())
         return out
@@ -230,7 +240,9 @@ class StepEngine:
         D = self.state_dim if getattr(self, "_obs_compact", False) else self.obs_dim
         if out is None:
             return torch.empty((self.N, D), dtype=self.obs_dtype, device=self.device)
-        if tuple(out.shape) != (self.N, D) or out.dtype != self.obs_dtype or not out.is_contiguous() \
+        # (a block of a column-major ring is the [N, D] view with strides (1, pitch): the state-only target of a step)
+        columns = getattr(self, "_ring_columns", False) and out.dim() == 2 and out.stride() == (1, getattr(self, "_ring_pitch", self.N))
+        if tuple(out.shape) != (self.N, D) or out.dtype != self.obs_dtype or not (out.is_contiguous() or columns) \
                 or out.device != self.device:
             raise ValueError(f"obs must be a contiguous {self.obs_dtype} tensor of shape ({self.N}, {D}) "
                              f"on {self.device}")

@@ -108,7 +108,7 @@ class BatchedMicrogridEnv:
 
     def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
                  raise_errors=False, observation_keys=None, obs_dtype=torch.float64, obs_prefetch=None,
-                 action_dtype=torch.float64, obs_views=False, reuse_outputs=0, obs_direct=False):
+                 action_dtype=torch.float64, obs_views=False, reuse_outputs=0, obs_direct=False, obs_layout="rows"):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
         # raise_errors=True (base_module.py:79-93): every step is preceded by its dry run (mgx_check_step: the violations
@@ -156,6 +156,13 @@ class BatchedMicrogridEnv:
         # Three rings of K blocks: while the steps walk ring r, the windows of ring r + 1 (the NEXT K counter values) are
         # being written on the engine's prefetch stream (mgx_observe_windows_ahead -- the series rows do not depend on the
         # state, so this overlaps the step kernels), and ring r - 1 is still intact for whoever holds observations from it.
+        # obs_layout="columns": the blocks of the observation rings are stored COLUMN-major ([D, pitch]); step() / reset() still
+        # return [N, D] tensors -- views with strides (1, pitch): the same matrix, what `obs @ W` takes either way -- but the state
+        # columns a step adds are then six coalesced runs instead of 48 bytes per row at a 8 D-byte stride (100 000 scattered
+        # partial lines per step: 3.5-4 us of a config-5 fleet step).  ``obs.contiguous()`` gives the row-major copy.
+        if obs_layout not in ("rows", "columns"):
+            raise ValueError("obs_layout must be 'rows' or 'columns'")
+        self._obs_columns = obs_layout == "columns"
         self._ring = self._rings = self._ring_store = None
         # Position inside ring 0 at which a refill starts the walk (0 <= phase < K): the first ring after a reset is then
         # K - phase blocks long and every later ring change falls phase steps EARLIER than that of an env with phase 0.  A fleet
@@ -432,9 +439,15 @@ class BatchedMicrogridEnv:
         end in partial lines).  ``_rings[r][k]`` is the contiguous [N, D] row block the steps return."""
         L = self.layout
         pitch = (L.n_grids + 15) // 16 * 16
-        self._ring_store = torch.empty(3, K, pitch, L.obs_dim, dtype=self._obs_dtype, device=self.batch.device)
-        self._rings = self._ring_store[:, :, :L.n_grids]
+        self.engine.set_ring_layout(False)
         self.engine.set_ring_pitch(pitch)
+        if self._obs_columns:              # blocks [D, pitch]; a block's observation = the transposed view [N, D], strides (1, pitch)
+            self._ring_store = torch.empty(3, K, L.obs_dim, pitch, dtype=self._obs_dtype, device=self.batch.device)
+            self._rings = self._ring_store[:, :, :, :L.n_grids].transpose(2, 3)
+            self.engine.set_ring_layout(True)
+        else:
+            self._ring_store = torch.empty(3, K, pitch, L.obs_dim, dtype=self._obs_dtype, device=self.batch.device)
+            self._rings = self._ring_store[:, :, :L.n_grids]
 
     def _after_external_steps(self):
         """The engine was stepped behind the env's back (fused rollouts: ``RuleBasedControl.run``, ``engine.step_k``): the
@@ -721,11 +734,11 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
 
     def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
                  trajectory_func=None, raise_errors=False, observation_keys=None, obs_dtype=torch.float64,
-                 obs_prefetch=None, obs_views=False, reuse_outputs=0, check_asserts=False, obs_direct=False):
+                 obs_prefetch=None, obs_views=False, reuse_outputs=0, check_asserts=False, obs_direct=False, obs_layout="rows"):
         super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
                          trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
                          obs_dtype=obs_dtype, obs_prefetch=obs_prefetch, obs_views=obs_views, reuse_outputs=reuse_outputs,
-                         obs_direct=obs_direct)
+                         obs_direct=obs_direct, obs_layout=obs_layout)
         # check_asserts=True (implied by raise_errors=True): DiscreteMicrogridEnv.step gives up with an AssertionError in a few
         # states whatever raise_errors says -- _populate_action's asserts (priority_list.py:73,121,124,135,154: a lossy battery
         # rounded one ulp above max_capacity with load left to absorb) and the step's (base_module.py:272).  The device goes on

@@ -544,3 +544,34 @@ def generate_fleet(n_grids, n_steps=YEAR, seed=42, horizon=0, device="cuda", ran
             out[name] = (generate(n_grids, n_steps, seed, name, horizon, device, mixed_timers=mixed_timers, select=idx,
                                   series=series, uniform_columns=uniform_columns), idx if dev.type == "cuda" else idx.numpy())
     return out
+
+
+def widen(base, n_genset=1, n_battery=1, n_grid=1, n_load=1, n_pv=1):
+    """A batch with SEVERAL modules of a kind per microgrid (module_container.py:355-413: the container holds a list per name)
+    out of a generated single-instance batch with materialised series: instance j of a controllable kind gets the base grid's
+    parameters scaled by (1 + 0.05 j), the load / pv series are split evenly over the load / renewable modules.  Columns become
+    [n, N] (instance-major), series [T, n, N]: such batches run on the general kernels.  For benchmarks and large tests -- parity
+    of those kernels is pinned on reference-made microgrids (tests/golden/multi.npz)."""
+    import dataclasses
+    if base.factorised:
+        raise ValueError("widen needs materialised series (the general kernels read [T, n, N] arrays)")
+    L0 = base.layout
+    n_genset, n_battery, n_grid = (n if has else 0 for n, has in ((n_genset, L0.has_genset), (n_battery, L0.has_battery), (n_grid, L0.has_grid)))
+    L = dataclasses.replace(L0, n_genset=n_genset, n_battery=n_battery, n_grid=n_grid, n_load=n_load, n_pv=n_pv)
+    cols = {}
+    for k, v in base.cols.items():
+        n = n_genset if k.startswith("gen_") else n_battery if (k.startswith("bat_") or k in ("charge", "soc")) else \
+            n_grid if (k.startswith("grid_m") or k.startswith("grid_c")) else 0
+        if k in ("grid_ts", "grid_lo", "grid_hi"):
+            cols[k] = (torch.stack([v] * n_grid, dim=1 if k == "grid_ts" else 0) if n_grid > 1 else v).contiguous()
+        elif k in ("load_ts", "pv_ts"):
+            m = n_load if k == "load_ts" else n_pv
+            cols[k] = (torch.stack([v / m] * m, dim=1) if m > 1 else v).contiguous()
+        elif k in ("load_lo", "load_hi", "pv_lo", "pv_hi"):
+            m = n_load if k.startswith("load") else n_pv
+            cols[k] = (torch.stack([v / m] * m, dim=0) if m > 1 else v).contiguous()
+        elif n > 1:
+            cols[k] = torch.stack([v if v.dtype != torch.float64 else v * (1.0 + 0.05 * j) for j in range(n)], dim=0).contiguous()
+        else:
+            cols[k] = v.clone()
+    return MicrogridBatch(L, cols)

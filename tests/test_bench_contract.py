@@ -57,12 +57,21 @@ def test_bench_one_rank_json_line(device):
     assert abs(d["value"] - 20000 * 6 * 32 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and d["scaling"] == "weak" and d["higher_is_better"] is True
-    for k in ("float64_rows", "float32_rows", "float64_views", "float32_views"):
+    for k in ("float64_rows", "float32_rows", "float64_rows_colmajor", "float32_rows_colmajor", "float64_views", "float32_views"):
         assert set(d["hetero_h24_gym_steps"][k]["roofline"]) >= {"bound", "achieved", "peak", "frac", "frac_wall", "traffic"}, k
     assert {"fused_launches_one_stream", "fused_launches_materialised", "fused_launches_materialised_one_stream", "rbc_rollout_materialised",
             "single_step_launches_one_call", "rbc_rollout_on_device", "single_step_launches_python_loop"} <= set(d["other"])
     assert all("error" not in v for v in d["other"].values())
     assert d["other"]["fused_launches_materialised"]["roofline"]["concurrent_streams"] == 2
+    # round 4: the spread of the timed rounds, which kernels ran, the issue-side roofline block, the general path and the server
+    ru = rf["round_us"]
+    assert ru["n"] == 6 and ru["min"] <= ru["median"] <= ru["max"]
+    from pymgrid_amd import _lib
+    assert d["csrc_hash"] == _lib.source_hash() and d["roofline_valu"]["bound"] == "valu"
+    assert rf["traffic"] is None or "STALE" not in str(rf["traffic_source"])          # a stale counter file is never quoted
+    gp = d["general_path_2g2b1grid"]
+    assert "error" not in gp and gp["single_steps"]["roofline"]["bytes_per_env_step"] == 8 * (7 + 27 + 6 + 2 * 2 + 2) + 2 * 8 + 8
+    assert gp["k_step_launches"]["value"] > 0 and d["resident_step_server"]["steps"] == 600
 
 
 @pytest.mark.gpu
