@@ -802,7 +802,11 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         const bool in_batch = i < N;
         OT *outc = ring + g0 + g;
         for (int32_t c = q; c < D; c += Q) {
-            const double *src = image + g * BP + map[c];
+            const uint32_t m = map[c];
+            // a ring written ahead of the counter leaves the state columns to the steps: here they are lines of their own, so
+            // not writing them costs nothing (in row-major blocks the same holes make partial lines: MGX_WIN_SKIP_STATE)
+            if (!have_now && m >= (uint32_t)S0) continue;
+            const double *src = image + g * BP + m;
             for (int32_t k = 0; k < K; k++)
                 if (in_batch) MGX_WIN_STORE((OT)src[k], outc + ((int64_t)k * D + c) * P);
         }
