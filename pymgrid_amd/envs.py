@@ -50,31 +50,37 @@ class ObsViews:
     ``genset`` / ``battery`` slice ``state``; ``nested()`` is the reference's ``{module: array}`` shape; ``flat()``
     concatenates everything into the [N, D] row of the rows contract (a copy: for checks, or consumers that insist on rows).
     Valid until the env has taken ``BatchedMicrogridEnv.VIEW_BUFFERS - 1`` further steps (the state buffers rotate)."""
-    __slots__ = ("_norm", "t", "W", "state", "layout")
+    __slots__ = ("_norm", "t", "W", "state", "layout", "_w")
 
     def __init__(self, norm, t, W, state, layout):
-        self._norm, self.t, self.W, self.state, self.layout = norm, t, W, state, layout
+        self._norm, self.t, self.W, self.state, self.layout, self._w = norm, t, W, state, layout, None
 
-    # The window views of a step index are memoised beside the normalised copy (a year of hourly steps = 8 760 x 3 small tensor
-    # objects): building a view costs ~1 us of host time, and a training loop walks the same rows epoch after epoch.
-    def _window(self, name, scale):
-        cache = self._norm["_views"][name]
-        v = cache.get(self.t)
-        if v is None:
-            v = cache[self.t] = self._norm[name].narrow(1, scale * self.t, scale * self.W)
-        return v
+    # The window views of a step index are memoised beside the normalised copy, all three under ONE key (a year of hourly steps =
+    # 8 760 small tuples): building a view costs ~1 us of host time, a training loop walks the same rows epoch after epoch, and a
+    # policy that takes load, pv and grid at every step pays one dictionary look-up per observation for them.
+    def _windows(self):
+        w = self._w
+        if w is None:
+            cache = self._norm["_views"]
+            w = cache.get(self.t)
+            if w is None:
+                n, t, W = self._norm, self.t, self.W
+                g = n.get("grid_flat")                     # [N, R * 4] alias of the [N, R, 4] copy: one narrow, no flatten
+                w = cache[t] = (n["load"].narrow(1, t, W), n["pv"].narrow(1, t, W), None if g is None else g.narrow(1, 4 * t, 4 * W))
+            self._w = w
+        return w
 
     @property
     def load(self):
-        return self._window("load", 1)
+        return (self._w or self._windows())[0]
 
     @property
     def pv(self):
-        return self._window("pv", 1)
+        return (self._w or self._windows())[1]
 
     @property
-    def grid(self):                                        # [N, R * 4] alias of the [N, R, 4] copy: one narrow, no flatten
-        return self._window("grid_flat", 4) if "grid_flat" in self._norm else None
+    def grid(self):
+        return (self._w or self._windows())[2]
 
     @property
     def genset(self):
@@ -291,7 +297,7 @@ class BatchedMicrogridEnv:
         norm = self.engine.normalise_series()
         if "grid" in norm:
             norm["grid_flat"] = norm["grid"].flatten(1)      # a view: [N, R, 4] -> [N, 4 R]
-        norm["_views"] = {"load": {}, "pv": {}, "grid_flat": {}}      # ObsViews' memo: step index -> window view
+        norm["_views"] = {}                                  # ObsViews' memo: step index -> (load, pv, grid) window views
         return norm
 
     def _view_now(self):
