@@ -603,7 +603,10 @@ def main():
             sampler.join(2.0)
         fn(warmup)
         first = run.rounds
-        wall, gpu, round_us = timed(run, fn, rounds, dev, mdist, per_round=(mode == args.mode))
+        wall, gpu, _ = timed(run, fn, rounds, dev, mdist)
+        # the spread of a timed region: the SAME number of rounds once more, directly behind it, with an event behind every round on
+        # every launch stream (inside the timed region itself the extra host calls would be part of what is measured)
+        round_us = timed(run, fn, rounds, dev, mdist, per_round=True)[2] if mode == args.mode else None
         walls = mdist.gather_over_ranks(wall, dev)
         wall, gpu = max(walls), mdist.max_over_ranks(gpu, dev)
         n_launch = (N + S - 1) // S if sharded else N             # grids per kernel launch
@@ -642,8 +645,8 @@ def main():
             srt = sorted(round_us)
             roof["round_us"] = {"n": len(srt), "min": srt[0], "median": srt[len(srt) // 2], "max": srt[-1],
                                 "frac_at_median": per_launch_bytes * launches_per_round / (srt[len(srt) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                "what": "stream cadence of each timed round (HIP events behind every round on the launch streams; per "
-                                        "round the slower stream), rank 0"}
+                                "what": "stream cadence of each round of a SECOND pass of the same length directly behind the timed region "
+                                        "(HIP events behind every round on the launch streams; per round the slower stream), rank 0"}
         if sharded:
             roof.update({"launch": f"one round = {S} concurrent kernel launches, one per internal shard stream "
                                    f"(mgx_set_shards), {n_launch} grids each, never joined between rounds",
