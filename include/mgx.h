@@ -380,9 +380,9 @@ int mgx_set_obs_mode(mgx_handle *h, int32_t mode);
  * (MGX_OBS_ROWS_FULL, horizon > 0), mgx_step / mgx_step_discrete / mgx_step_many / mgx_fleet_step form the window values of
  * every row from the cache-resident base tables inside the stepping launch and write each row once, by whole lines -- no
  * obs_rows kernel behind the step, no rings.  Lock-step episodes only (per-grid windows keep the two-kernel path).  Same bits.
- * One launch instead of two is what small batches want; at N = 100 000 the launch is fp64-issue bound (every value of every
- * row is normalised at every step: one IEEE division each) and the prefetched rings (mgx_observe_windows_ahead) are twice as
- * fast -- hence off by default.  MGX_ERR_UNSUPPORTED for materialised series or several modules of a kind. */
+ * One launch instead of two is what small batches want; at N = 100 000 the launch is latency-bound (and normalises every value
+ * of every row at every step, where a ring refill normalises a series value once) and the prefetched rings
+ * (mgx_observe_windows_ahead) are twice as fast -- hence off by default.  MGX_ERR_UNSUPPORTED for materialised series or several modules of a kind. */
 int mgx_set_rows_direct(mgx_handle *h, int enable);
 
 /* `done` of the fused calls.  MGX_DONE_U8 (default): one byte per grid and step, [K, N].  MGX_DONE_BITS: a bit set per step,

@@ -1226,8 +1226,9 @@ static int episode_step_end(mgx_handle *h, const EpisodeStep &ep, const uint8_t 
 // Possible when whole rows are wanted for a forecast horizon and every window value can be formed from cache-resident base
 // tables: lock-step stepping of a factorised batch with one module of every kind, no forecast noise.  OFF unless the handle asks
 // for it (mgx_set_rows_direct): bit-identical rows (tests/test_direct_rows.py), one launch instead of two -- but at N = 100 000 it
-// is fp64-VALU bound: every step normalises all D values of every row (one IEEE division each) where the rings normalise a
-// series value once per K steps: 55 us per config-5 fleet step against 26-29 us on rings (profiles/r04/exp_fleet_direct_rows.txt).
+// takes 55-61 us per config-5 fleet step against 24-28 us on rings: a latency-bound kernel (21 us fixed + 25 us window values +
+// 12 us stores, nothing overlapping: profiles/r04/exp_fleet_direct_rows_parts.txt) that normalises N x D values per step where
+// the rings normalise a series value once per refill.
 static bool rows_direct_ok(const mgx_handle *h, const void *obs)
 {
     if (!h->rows_direct || !obs || h->multi || h->k.H <= 0 || h->k.obs_state_only || !factorised(h->k.c)) return false;

@@ -1207,7 +1207,9 @@ static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArg
 // FACTORISED series the window source is a few cache-resident base rows: nothing is gained by sharing them across steps, so
 // the workgroup that steps 16 grids also forms their 16 rows -- state columns included -- in an LDS tile and streams the tile
 // out as one contiguous 16 * D * 8-byte region (16-byte non-temporal stores).  No rings (12 GB at K = 32), no prefetch
-// streams, no second writer per row: HBM traffic == the algorithmic bytes.
+// streams, no second writer per row: HBM traffic == the algorithmic bytes.  What it costs: N x D normalisations per step where a
+// ring refill normalises a series value once, and a latency-bound workgroup (profiles/r04/exp_fleet_direct_rows_parts.txt:
+// 55-61 us per config-5 fleet step, rings 24-28) -- the option for SMALL batches, where one launch instead of two is what counts.
 //
 // Workgroup = 256 threads around 64 grids.  Wave 0 runs the step of the 64 grids, one lane each (step_body /
 // step_discrete_body, unchanged: one latency chain per 64 grids) and leaves their 6 state columns in LDS; the rows leave in

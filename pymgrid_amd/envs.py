@@ -149,7 +149,7 @@ class BatchedMicrogridEnv:
                                  "and no observation_keys")
             obs_prefetch = 0
         # obs_direct=True (factorised series, forecast horizon): no rings -- the stepping launch itself forms and writes every
-        # row (mgx_set_rows_direct: one launch per step instead of two; what small batches want, fp64-issue bound at 100 000 grids)
+        # row (mgx_set_rows_direct: one launch per step instead of two; what small batches want; latency-bound and twice the rings' time at 100 000 grids)
         if obs_direct:
             if not batch.factorised or L.multi or noisy or obs_views or not observations:
                 raise ValueError("obs_direct needs factorised series, one module of every kind per grid, the oracle forecaster, "
