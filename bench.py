@@ -844,6 +844,36 @@ def main():
             out["layout"] = "2 gensets + 2 batteries + 1 grid + load + pv per microgrid (general kernels), materialised series"
             out["grids_per_gpu"], out["rows"] = N, rows_g
             ge.close()
+            del ge, gb
+            torch.cuda.empty_cache()
+            # Gym steps with whole observation rows (H = 24): rings refilled by the general window kernel (obs_windows_k_multi_kernel;
+            # the step adds its 12 state columns) -- per-step rows by one lane per grid were 261 us (profiles/r04/exp_multi_rings.txt)
+            from pymgrid_amd import BatchedMicrogridEnv
+            rows_o = min(args.rows, 600)
+            base = generate(n_total, n_steps=rows_o, seed=42, arch="genset+battery+grid", horizon=24, device=dev, rank=rank, world=world)
+            env = BatchedMicrogridEnv(widen(base, n_genset=2, n_battery=2, n_grid=1), obs_prefetch=32, reuse_outputs=96)
+            del base
+            Lo = env.layout
+            ao = torch.rand(N, Lo.action_dim, dtype=torch.float64, device=dev, generator=gen)
+            env.reset()
+            for _ in range(40):
+                env.step(ao)
+            mdist.barrier(); torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            no = rows_o - 24 - 40 - 8
+            t0 = time.perf_counter(); e0.record()
+            for _ in range(no):
+                env.step(ao)
+            e1.record(); torch.cuda.synchronize(dev)
+            wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+            gpu = mdist.max_over_ranks(e0.elapsed_time(e1) * 1e-3, dev)
+            bo = (Lo.bytes_per_step() - 1 + 8 * Lo.obs_dim) * N
+            out["gym_steps_rows_h24"] = {"value": n_total * no / wall, "us_per_step": gpu / no * 1e6, "ring_depth": 32, "obs_dim": Lo.obs_dim,
+                                         "roofline": {"bound": "hbm", "achieved": bo / (gpu / no) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                      "frac": bo / (gpu / no) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                      "algorithmic_bytes_per_launch": bo, "kernel": "step_multi_kernel<7> + obs_windows_k_multi_kernel<7, double>",
+                                                      "bytes_per_env_step": bo // N}}
+            env.close()
             return out
         general = guarded("general_path_2g2b1grid", general_path)
         torch.cuda.empty_cache()

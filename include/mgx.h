@@ -345,7 +345,9 @@ int mgx_set_action_format(mgx_handle *h, int32_t format);
  * blocks 1..K-1 the genset / battery state columns are zero: with mgx_set_obs_mode(MGX_OBS_ROWS_STATE_ONLY) the `obs`
  * argument of mgx_step / mgx_step_discrete (pass ring + k*N*D for the step that reaches counter t + k) receives just
  * those columns.  Values are identical to mgx_observe's.  MGX_ERR_UNSUPPORTED with forecast noise (it depends on the
- * (step, horizon index) pair) or several load / renewable modules. */
+ * (step, horizon index) pair).  Microgrids with several modules of a kind (module_container.py:355-413) are served by the
+ * general form of the same kernel -- a window per load / renewable / grid module instance, 4 state columns per genset and
+ * 2 per battery -- for lock-step episodes and row-major blocks (tests/test_multi_windows.py: rows == the per-step rows). */
 int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream);
 /* Rows between consecutive blocks of the rings handed to mgx_observe_windows / mgx_observe_windows_ahead / mgx_fleet_step
  * refills (default: N, i.e. a dense [K, N, D] ring).  With N not a multiple of 16 the blocks of a dense ring are not

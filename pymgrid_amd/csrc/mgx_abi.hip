@@ -234,6 +234,22 @@ static void launch_windows_kernel(const KArgs &k, const WindowsKPlan &plan, int3
     obs_windows_k_kernel<F, OT><<<blocks, OBS_K_THREADS, lds, st>>>(k, plan, t, (OT *)ring);
 }
 
+template <int F, typename OT>
+static void launch_windows_multi_kernel(const KArgs &k, const WindowsKPlan &plan, int32_t t, void *ring, unsigned blocks, size_t lds,
+                                        hipStream_t st)
+{
+    static bool opted_in[MGX_MAX_DEVICES] = {};
+    if (lds > 64 * 1024) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= MGX_MAX_DEVICES || !opted_in[dev]) {
+            (void)hipFuncSetAttribute((const void *)obs_windows_k_multi_kernel<F, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (dev >= 0 && dev < MGX_MAX_DEVICES) opted_in[dev] = true;
+        }
+    }
+    obs_windows_k_multi_kernel<F, OT><<<blocks, OBS_K_THREADS, lds, st>>>(k, plan, t, (OT *)ring);
+}
+
 // resident step server: every workgroup must be on the chip at once (occupancy query), then one launch on the server stream
 template <int F>
 static hipError_t launch_server(const mgx_handle *h, const ServerArgs &sv, unsigned blocks, int *resident_per_cu)
@@ -527,8 +543,8 @@ int mgx_set_obs_mode(mgx_handle *h, int32_t mode)
     if (!h) return fail(MGX_ERR_INVALID, "mgx_set_obs_mode: NULL handle");
     if (mode != MGX_OBS_ROWS_FULL && mode != MGX_OBS_ROWS_STATE_ONLY && mode != MGX_OBS_ROWS_STATE_COMPACT)
         return fail(MGX_ERR_INVALID, "mgx_set_obs_mode: unknown mode %d", mode);
-    if (mode != MGX_OBS_ROWS_FULL && h->multi)
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_set_obs_mode: state-only rows need exactly one load and one renewable module per grid");
+    if (mode == MGX_OBS_ROWS_STATE_COMPACT && h->multi)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_set_obs_mode: compact state rows need exactly one module of every kind per grid");
     h->k.obs_state_only = mode == MGX_OBS_ROWS_STATE_ONLY ? 1 : (mode == MGX_OBS_ROWS_STATE_COMPACT ? 2 : 0);
     return MGX_OK;
 }
@@ -563,7 +579,9 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (!h || !ring) return fail(MGX_ERR_INVALID, "%s: NULL argument", who);
     if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "%s: K = %d outside [1, 4096]", who, K);
     if (ahead < 0) return fail(MGX_ERR_INVALID, "%s: ahead = %d is negative", who, ahead);
-    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "%s: needs exactly one module of every kind per grid", who);
+    if (h->multi && (h->k.obs_colpitch || h->windowed || h->rolling || h->inplace || factorised(h->k.c)))
+        return fail(MGX_ERR_UNSUPPORTED, "%s: with several modules of a kind per grid the window prefetch is offered for lock-step "
+                                         "episodes over [T, n, N] series and row-major ring blocks", who);
     if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
         return fail(MGX_ERR_UNSUPPORTED, "%s: forecast noise depends on (step, horizon index), windows cannot be shared", who);
     if (h->k.obs_state_only == 2)
@@ -572,11 +590,13 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (int rc = need_obs_bounds(h, who)) return rc;
     if (!dev_counter(h) && ahead == 0 && !h->inplace && h->t > h->k.T)       // (in place the counter never ends: per-grid rows)
         return fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, h->k.T);
-    const int32_t R = K + h->k.H, ncomp = 2 + 4 * h->layout.has_grid;
+    // series components and state columns per grid (general path: per module instance, module_container.py:355-413)
+    const int32_t R = K + h->k.H, ncomp = h->multi ? h->k.n_load + h->k.n_pv + 4 * h->k.n_grid : 2 + 4 * h->layout.has_grid;
+    const int32_t nstate = h->multi ? 4 * h->k.n_genset + 2 * h->k.n_battery : 6;
     plan->grid_col_base = h->k.col_grid;
     plan->K = K;
     plan->rp = R;
-    plan->bp = (ncomp * (R + K) + 6 * K) | 1;
+    plan->bp = (ncomp * (R + K) + nstate * K) | 1;
     static const int group_env = [] { const char *e = getenv("MGX_WIN_GROUP"); return e ? atoi(e) : 0; }();   // experiment knob
     plan->group = (group_env == 8 || group_env == 4 || group_env == 16) ? group_env : 16;
     plan->with_state = ahead == 0;
@@ -625,6 +645,15 @@ static int launch_windows(mgx_handle *h, int32_t ahead, int32_t K, void *ring, h
 
     const unsigned blocks = (unsigned)count;
     const int32_t t = t_arg(h) + ahead;
+    if (h->multi) {                                   // general path: run-time component counts (obs_windows_k_multi_kernel)
+        if (h->k.obs_f32) {
+            MGX_DISPATCH_F(h->flags, (launch_windows_multi_kernel<F, float>(h->k, plan, t, ring, blocks, lds, st)));
+        } else {
+            MGX_DISPATCH_F(h->flags, (launch_windows_multi_kernel<F, double>(h->k, plan, t, ring, blocks, lds, st)));
+        }
+        hipError_t em = hipGetLastError();
+        return em == hipSuccess ? MGX_OK : hip_fail(em, "obs_windows_k_multi_kernel launch");
+    }
     if (h->k.obs_f32) {
         MGX_DISPATCH_F(h->flags, (launch_windows_kernel<F, float>(h->k, plan, t, ring, blocks, lds, st)));
     } else {

@@ -1645,38 +1645,52 @@ __device__ inline void observe_series_multi(const double *__restrict__ ts, int64
     }
 }
 
-// flat order: load windows, pv windows, gensets (4 columns each), batteries (2 each), grid windows (4 (1 + H) each)
+// the state columns of grid i as they stand in the columns: 4 per genset, then 2 per battery; value j at dst[j * stride]
 template <int F, typename OT>
-__device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, OT *__restrict__ obs_row)
+__device__ inline void observe_state_multi(const KArgs &a, int64_t i, OT *__restrict__ dst, int64_t stride)
 {
     const int64_t N = a.N;
-    const int W = 1 + a.H;
-    int k = 0;
-    for (int j = 0; j < a.n_load; j++, k += W)
-        observe_series_multi(a.c.load_ts + (int64_t)j * N + i, (int64_t)a.n_load * N, a.T, t, a.H, a.c.load_lo[(int64_t)j * N + i],
-                             a.c.load_hi[(int64_t)j * N + i], obs_row + k);
-    for (int j = 0; j < a.n_pv; j++, k += W)
-        observe_series_multi(a.c.pv_ts + (int64_t)j * N + i, (int64_t)a.n_pv * N, a.T, t, a.H, a.c.pv_lo[(int64_t)j * N + i],
-                             a.c.pv_hi[(int64_t)j * N + i], obs_row + k);
+    int64_t k = 0;
     if constexpr (F & F_GENSET) {
         for (int j = 0; j < a.n_genset; j++) {
             const int64_t c = (int64_t)j * N + i;
             const uint32_t times = a.c.gen_times[c], st = a.c.gen_status[c];
             const double su = (double)(times & 0xff), wd = (double)((times >> 16) & 0xff);
-            obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)(st & 0xff));
-            obs_row[k++] = (OT)space_norm(0.0, 1.0, (double)((st >> 8) & 0xff));
-            obs_row[k++] = (OT)space_norm(0.0, su, (double)((st >> 16) & 0xff));
-            obs_row[k++] = (OT)space_norm(0.0, wd, (double)(st >> 24));
+            dst[(k++) * stride] = (OT)space_norm(0.0, 1.0, (double)(st & 0xff));
+            dst[(k++) * stride] = (OT)space_norm(0.0, 1.0, (double)((st >> 8) & 0xff));
+            dst[(k++) * stride] = (OT)space_norm(0.0, su, (double)((st >> 16) & 0xff));
+            dst[(k++) * stride] = (OT)space_norm(0.0, wd, (double)(st >> 24));
         }
     }
     if constexpr (F & F_BATTERY) {
         for (int j = 0; j < a.n_battery; j++) {
             const int64_t c = (int64_t)j * N + i;
             const double cmin = a.c.bat_min_capacity[c], cmax = a.c.bat_max_capacity[c];
-            obs_row[k++] = (OT)space_norm(cmin / cmax, 1.0, a.c.soc[c]);
-            obs_row[k++] = (OT)space_norm(cmin, cmax, a.c.charge[c]);
+            dst[(k++) * stride] = (OT)space_norm(cmin / cmax, 1.0, a.c.soc[c]);
+            dst[(k++) * stride] = (OT)space_norm(cmin, cmax, a.c.charge[c]);
         }
     }
+}
+
+// flat order: load windows, pv windows, gensets (4 columns each), batteries (2 each), grid windows (4 (1 + H) each).
+// MGX_OBS_ROWS_STATE_ONLY (a.obs_state_only == 1): the row lives in a prefetched ring whose window columns
+// obs_windows_k_multi_kernel has written already -- only the genset / battery columns are stored.
+template <int F, typename OT>
+__device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, OT *__restrict__ obs_row)
+{
+    const int64_t N = a.N;
+    const int W = 1 + a.H;
+    int k = (a.n_load + a.n_pv) * W;
+    observe_state_multi<F, OT>(a, i, obs_row + k, 1);
+    if (a.obs_state_only) return;
+    k = 0;
+    for (int j = 0; j < a.n_load; j++, k += W)
+        observe_series_multi(a.c.load_ts + (int64_t)j * N + i, (int64_t)a.n_load * N, a.T, t, a.H, a.c.load_lo[(int64_t)j * N + i],
+                             a.c.load_hi[(int64_t)j * N + i], obs_row + k);
+    for (int j = 0; j < a.n_pv; j++, k += W)
+        observe_series_multi(a.c.pv_ts + (int64_t)j * N + i, (int64_t)a.n_pv * N, a.T, t, a.H, a.c.pv_lo[(int64_t)j * N + i],
+                             a.c.pv_hi[(int64_t)j * N + i], obs_row + k);
+    k += 4 * a.n_genset + 2 * a.n_battery;
     if constexpr (F & F_GRID) {
         for (int j = 0; j < a.n_grid; j++, k += 4 * W)
             for (int cc = 0; cc < 4; cc++) {
@@ -1720,6 +1734,107 @@ __global__ __launch_bounds__(BLOCK_MULTI) void observe_multi_kernel(const KArgs 
     if (i >= a.g1) return;
     if (a.obs_f32) observe_row_multi<F>(a, i, t, (float *)obs + i * a.obs_dim);
     else observe_row_multi<F>(a, i, t, (double *)obs + i * a.obs_dim);
+}
+
+// Window prefetch on the GENERAL path (any number of load / renewable / genset / battery / grid modules per microgrid,
+// module_container.py:355-413): the LDS image of obs_windows_k_kernel with run-time component counts.  Per grid
+//   [n_series][RP] forecast forms, [n_series][K] current-value forms, [n_state][K] state columns (entry 0 = the current state
+//   for a launch at the counter, zeros ahead of it),  n_series = n_load + n_pv + 4 n_grid,  n_state = 4 n_genset + 2 n_battery,
+// filled by windows_k_module per module instance (every series value read and normalised ONCE per launch) and written out as
+// K row blocks through the same column -> image-offset map.  Row-major blocks only.
+template <int F, typename OT>
+__global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_multi_kernel(const KArgs a, const WindowsKPlan plan, int32_t t,
+                                                                            OT *__restrict__ ring)
+{
+    t = resolve_t_obs(a, t);
+    extern __shared__ double image[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t G = plan.group, Q = OBS_K_THREADS / G, K = plan.K, RP = plan.rp, BP = plan.bp;
+    const int32_t g = tid & (G - 1), q = tid / G;
+    const int64_t group = (int64_t)plan.group0 + blockIdx.x, g0 = group * G, N = a.N;
+    const int32_t W = 1 + a.H, D = a.obs_dim, R = K + a.H;
+    const int32_t n_series = a.n_load + a.n_pv + 4 * a.n_grid, n_state = 4 * a.n_genset + 2 * a.n_battery;
+    const int32_t NU0 = n_series * RP, S0 = NU0 + n_series * K;
+    const int64_t i = g0 + g, ic = i < N ? i : g0;
+    double *blk = image + g * BP;
+    uint32_t *map = reinterpret_cast<uint32_t *>(image + G * BP);       // [D]
+    int32_t e = 0;
+    {
+        const double *ts = a.c.load_ts;
+        const int64_t n = a.n_load;
+        for (int32_t j = 0; j < a.n_load; j++, e++)
+            windows_k_module<1>([&](int32_t r, int) { return ts[((int64_t)r * n + j) * N + ic]; }, N, a.c.load_lo + (int64_t)j * N,
+                                a.c.load_hi + (int64_t)j * N, a.T, t, R, K, ic, q, Q, blk + e * RP, blk + NU0 + e * K, RP, a.row_mask);
+    }
+    {
+        const double *ts = a.c.pv_ts;
+        const int64_t n = a.n_pv;
+        for (int32_t j = 0; j < a.n_pv; j++, e++)
+            windows_k_module<1>([&](int32_t r, int) { return ts[((int64_t)r * n + j) * N + ic]; }, N, a.c.pv_lo + (int64_t)j * N,
+                                a.c.pv_hi + (int64_t)j * N, a.T, t, R, K, ic, q, Q, blk + e * RP, blk + NU0 + e * K, RP, a.row_mask);
+    }
+    if constexpr (F & F_GRID) {
+        const double *ts = a.c.grid_ts;
+        const int64_t n = a.n_grid;
+        for (int32_t j = 0; j < a.n_grid; j++, e += 4)
+            windows_k_module<4>([&](int32_t r, int cc) { return ts[(((int64_t)r * n + j) * 4 + cc) * N + ic]; }, N,
+                                a.c.grid_lo + (int64_t)j * 4 * N, a.c.grid_hi + (int64_t)j * 4 * N, a.T, t, R, K, ic, q, Q,
+                                blk + e * RP, blk + NU0 + e * K, RP, a.row_mask);
+    }
+    if (q == 0) {
+        for (int32_t j = 0; j < n_state * K; j++) blk[S0 + j] = 0.0;
+        if (plan.with_state) observe_state_multi<F, double>(a, ic, blk + S0, K);
+    }
+    const int32_t nw = (a.n_load + a.n_pv) * W;
+    for (int32_t col = tid; col < D; col += OBS_K_THREADS) {            // column -> offset of its k = 0 entry in a block
+        uint32_t m;
+        if (col < nw) {
+            const int32_t s = col / W, h = col - s * W;
+            m = h == 0 ? NU0 + s * K : s * RP + h;
+        } else if (col < nw + n_state) {
+            m = S0 + (col - nw) * K;
+        } else {
+            const int32_t c = col - nw - n_state, j = c / (4 * W), cj = c - j * 4 * W;
+            const int32_t s = a.n_load + a.n_pv + 4 * j + (cj & 3), h = cj >> 2;
+            m = h == 0 ? NU0 + s * K : s * RP + h;
+        }
+        map[col] = m;
+    }
+    __syncthreads();
+    const int32_t n_valid = (N - g0 < G) ? (int32_t)(N - g0) : G;
+    const int32_t total = n_valid * D;
+    typedef OT vec2 __attribute__((ext_vector_type(2)));
+    constexpr int KW = OBS_K_THREADS / 64;
+    const int64_t block_stride = (int64_t)plan.pitch * D;
+    OT *out0 = ring + ((int64_t)wave * plan.pitch + g0) * D;
+    // pairs of elements where they never straddle two rows (D even) and the ring is 16-byte aligned; else element by element
+    if (!(D & 1) && (reinterpret_cast<uintptr_t>(ring) & (sizeof(vec2) - 1)) == 0) {
+        int32_t r = 2 * lane / D, c = 2 * lane - r * D;
+        for (int32_t f = 2 * lane; f < total; f += 128) {
+            const double *s0 = image + r * BP + map[c] + wave, *s1 = image + r * BP + map[c + 1] + wave;
+            OT *out = out0 + f;
+            for (int32_t k = wave; k < K; k += KW) {
+                vec2 v2;
+                v2.x = (OT)*s0; v2.y = (OT)*s1;
+                MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out));
+                s0 += KW; s1 += KW; out += KW * block_stride;
+            }
+            c += 128;
+            while (c >= D) { c -= D; r++; }
+        }
+    } else {
+        int32_t r = lane / D, c = lane - r * D;
+        for (int32_t f = lane; f < total; f += 64) {
+            const double *s0 = image + r * BP + map[c] + wave;
+            OT *out = out0 + f;
+            for (int32_t k = wave; k < K; k += KW) {
+                MGX_WIN_STORE((OT)*s0, out);
+                s0 += KW; out += KW * block_stride;
+            }
+            c += 64;
+            while (c >= D) { c -= D; r++; }
+        }
+    }
 }
 
 // dry run (mgx_check_step) on the general path: the violations of the controllable instances depend on their own

@@ -129,7 +129,7 @@ class BatchedMicrogridEnv:
         # (engine.observe_windows: each series value read and normalised once instead of 1 + horizon times) and a step
         # only adds the genset / battery state columns.  Same values; the returned obs is a view into a ring of K blocks
         # and stays valid for at least K further steps.  Ignored (per-step rows) where there is nothing to share: no
-        # forecast horizon, forecast noise, several load / renewable modules, observations off.
+        # forecast horizon, forecast noise, observations off.
         L = self.layout
         noisy = batch.forecast_noise is not None or any(batch.cols.get(k) is not None
                                                         for k in ("load_noise_std", "pv_noise_std", "grid_noise_std"))
@@ -156,7 +156,8 @@ class BatchedMicrogridEnv:
                                  "observations=True and no obs_views")
             self.engine.set_rows_direct(True)
             obs_prefetch = 0
-        self._prefetch_ok = bool(observations and L.horizon > 0 and not L.multi and not noisy)
+        # (several modules of a kind per grid: the general refill kernel, row-major blocks, lock-step episodes over [T, n, N] series)
+        self._prefetch_ok = bool(observations and L.horizon > 0 and not noisy and not (L.multi and (obs_layout == "columns" or batch.factorised)))
         self._obs_dtype = obs_dtype
         self.obs_prefetch = int(obs_prefetch) if (obs_prefetch and int(obs_prefetch) > 1 and self._prefetch_ok) else 0
         # Three rings of K blocks: while the steps walk ring r, the windows of ring r + 1 (the NEXT K counter values) are

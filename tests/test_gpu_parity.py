@@ -375,9 +375,10 @@ def test_error_paths(pymgrid25, device):
     eng = StepEngine(_batch([multi], device))
     out = eng.step_k(torch.zeros(4, 1, 0, dtype=torch.float64, device=device))     # K-step loop of the general path
     assert out["reward"].shape == (4, 1) and eng.current_step == 4
-    with pytest.raises(MgxError) as e:                                             # window prefetch: one module of every kind only
-        eng.observe_windows(K=4)
-    assert e.value.code == 2
+    ring = eng.observe_windows(K=4)                                                # window prefetch of the general path (no state
+    for k in range(4):                                                             # columns in this layout: block k IS the row of step t + k)
+        assert torch.equal(ring[k], eng.observe())
+        eng.step_k(torch.zeros(1, 1, 0, dtype=torch.float64, device=device))
     eng.close()
     with pytest.raises(ValueError):
         MicrogridBatch(BatchLayout(n_grids=1, n_steps=8760, has_genset=True, has_battery=True, n_load=2), b.cols)

@@ -1,0 +1,70 @@
+"""Window prefetch on the general path: microgrids with SEVERAL modules of a kind (module_container.py:355-413) get their
+forecast windows from the same K-step refill as the single-instance layouts (obs_windows_k_multi_kernel) -- the rows an env
+returns out of its rings must equal, bit for bit, the rows the per-step kernel writes (observe_row_multi, itself pinned to the
+oracle and to the reference-made multi.npz in test_multi_module.py / test_multi_instances.py)."""
+import pytest
+
+torch = pytest.importorskip("torch")
+
+
+def _envs(device, dt, K, **wide):
+    from pymgrid_amd import BatchedMicrogridEnv
+    from pymgrid_amd.generator import generate, widen
+    out = []
+    for k in (K, 0):
+        base = generate(150, n_steps=90, seed=11, arch="genset+battery+grid", horizon=24, device=device)
+        out.append(BatchedMicrogridEnv(widen(base, **wide), obs_prefetch=k, obs_dtype=dt))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["float64", "float32"])
+@pytest.mark.parametrize("wide", [dict(n_genset=2, n_battery=2, n_grid=1), dict(n_genset=1, n_battery=3, n_grid=2, n_load=2),
+                                  dict(n_genset=2, n_battery=1, n_grid=1, n_load=2, n_pv=3)])
+def test_ring_rows_of_multi_instance_grids_are_the_per_step_rows(device, dt, wide):
+    dt = getattr(torch, dt)
+    ring, plain = _envs(device, dt, 4, **wide)
+    assert ring.obs_prefetch == 4 and plain.obs_prefetch == 0 and ring.layout.multi
+    L = ring.layout
+    gen = torch.Generator(device=device); gen.manual_seed(2)
+    o_r, o_p = ring.reset(), plain.reset()
+    assert o_r.shape == (150, L.obs_dim) and torch.equal(o_r, o_p)
+    for k in range(70):                                   # 17 ring changes; rows past the end of the series from step 66 on
+        a = torch.rand(150, L.action_dim, dtype=torch.float64, device=device, generator=gen)
+        o_r, r_r, d_r, _ = ring.step(a)
+        o_p, r_p, d_p, _ = plain.step(a)
+        assert torch.equal(o_r, o_p), (k, (o_r != o_p).nonzero()[:4])
+        assert torch.equal(r_r, r_p) and torch.equal(d_r, d_p)
+        if k == 37:                                       # a reset in the middle of a ring
+            o_r, o_p = ring.reset(), plain.reset()
+            assert torch.equal(o_r, o_p)
+    ring.close(); plain.close()
+
+
+@pytest.mark.gpu
+def test_fleet_with_a_multi_instance_bucket_on_rings(device):
+    """A fleet of a single-instance bucket and a multi-instance one, both on rings: the multi bucket steps through its own
+    launches (not fusable) and refills through the general kernel; rows == the envs stepped alone without rings."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    from pymgrid_amd.generator import generate, widen
+    from pymgrid_amd.hetero import BucketedFleet
+
+    def batches():
+        b0 = generate(100, n_steps=60, seed=3, arch="genset+battery", horizon=24, device=device)
+        b1 = widen(generate(70, n_steps=60, seed=4, arch="genset+battery+grid", horizon=24, device=device), n_genset=2, n_battery=2)
+        return [b0, b1]
+    fleet = BucketedFleet.from_batches(batches(), obs_prefetch=4)
+    alone = [BatchedMicrogridEnv(b, obs_prefetch=0) for b in batches()]
+    gen = torch.Generator(device=device); gen.manual_seed(5)
+    obs = fleet.reset()
+    for o, e in zip(obs, alone):
+        assert torch.equal(o, e.reset())
+    for k in range(30):
+        acts = [torch.rand(e.layout.n_grids, e.layout.action_dim, dtype=torch.float64, device=device, generator=gen) for e in alone]
+        obs, rew, done, _ = fleet.step(acts)
+        for j, e in enumerate(alone):
+            o, r, d, _ = e.step(acts[j])
+            assert torch.equal(obs[j], o) and torch.equal(rew[j], r), (k, j)
+    fleet.close()
+    for e in alone:
+        e.close()
