@@ -73,7 +73,9 @@ def parse(argv=None):
                          "and co2 figures, unbalanced-energy costs, zero genset timers) once instead of as [N] columns "
                          "(mgx_columns.uniform_mask).  Off by default: 60 fewer bytes per grid and single step buy no time "
                          "(profiles/r03/exp_uniform_columns.txt)")
-    ap.add_argument("--hetero-steps", type=int, default=256, help="timed Gym steps of the heterogeneous H=24 fleet (0: skip)")
+    ap.add_argument("--hetero-steps", type=int, default=1024,
+                    help="timed Gym steps of the heterogeneous H=24 fleet (0: skip); the region starts 256 steps after a reset: the "
+                         "first ~100 steps behind a reset + device synchronisation run 2-5 us slower (profiles/r04/exp_fleet_transient2.txt)")
     ap.add_argument("--no-side-modes", action="store_true", help="time the headline mode only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-closed-loop", action="store_true",
@@ -287,10 +289,11 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
                 return fleet.step(acts)
             # warm-up by wall time: the fleet is built on the host while the GPU idles and clocks down
             prev, t_end = None, time.perf_counter() + 4.0
-            while time.perf_counter() < t_end:                # until two consecutive 1000-step blocks agree within 3 %
+            n_warm = max(1000, 256 + steps)                   # (covers the rows of the timed region: their views are built here)
+            while time.perf_counter() < t_end:                # until two consecutive blocks of n_warm steps agree within 3 %
                 fleet.reset()
                 t0 = time.perf_counter()
-                for _ in range(1000):
+                for _ in range(n_warm):
                     consume(fstep()[0])
                 torch.cuda.synchronize(dev)
                 cur = time.perf_counter() - t0
@@ -298,7 +301,7 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
                     break
                 prev = cur
             fleet.reset()
-            for _ in range(64):
+            for _ in range(256):
                 fstep()
             mdist.barrier()
             torch.cuda.synchronize(dev)
