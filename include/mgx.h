@@ -287,16 +287,16 @@ int mgx_reset_grids(mgx_handle *h, const uint8_t *mask, const int32_t *start, co
 int mgx_reset_grids_random(mgx_handle *h, const uint8_t *mask, uint64_t seed, int32_t fixed_length, int32_t *start_io,
                            int32_t *length_io, int32_t *t0_io, mgx_stream stream);
 
-/* Rolling per-grid episodes IN PLACE -- factorised series only (mgx_columns.base_load ...).  Same model as
- * mgx_reset_windows_rolling (one shared counter that restarts at 0 and never ends, every grid with its own episode:
- * microgrid.py:205-225 per microgrid), but nothing is copied: the base tables are small and cached, so grid i simply reads row
- * counter + row_off[i] of its own series and reports done_i = counter >= final_abs[i] - 1.  row_off / final_abs: caller-owned
+/* Rolling per-grid episodes IN PLACE.  Same model as mgx_reset_windows_rolling (one shared counter that restarts at 0 and
+ * never ends, every grid with its own episode: microgrid.py:205-225 per microgrid), but nothing is copied: grid i simply reads
+ * row counter + row_off[i] of its own series and reports done_i = counter >= final_abs[i] - 1.  With factorised series
+ * (mgx_columns.base_load ...) the rows come out of small cached base tables; with [T, N] arrays every lane gathers 8 bytes of
+ * its own row (64 lines per wave and component instead of 4 -- still cheaper than window buffers that restarts copy into).  row_off / final_abs: caller-owned
  * DEVICE arrays [N] that the handle keeps reading AND writing until the next mgx_reset*; start / length as for
  * mgx_reset_windows (length NULL: max_length).  (Re)starts -- mgx_reset_grids, mgx_reset_grids_random -- then rewrite two
  * words per grid instead of gathering rows.  Observation windows reach beyond an episode's end into the grid's series and
  * beyond the series' end into the forecaster's padding, exactly as in lock-step.  Single steps only (as for rolling windows);
  * observation rings work as they do there (mgx_observe_windows[_ahead] + mgx_patch_windows for the grids that restarted).
- * MGX_ERR_UNSUPPORTED for materialised [T, N] series (every lane would read its own row: 8x the traffic).
  * A grid whose episode is over and that has not been restarted (auto-reset off, or a late mgx_reset_grids) keeps stepping on
  * its own series; the shared counter has no end in this mode, so nothing refuses the step that would leave the series:
  * from row n_steps on such a grid re-reads its LAST row (the step stays defined and finite; its observation windows show the

@@ -1006,9 +1006,6 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
     if (h->k.obs_colpitch) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered with column-major ring blocks (mgx_set_ring_layout)");
     if (h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered in device-counter mode");
     if (h->n_shards > 1) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered while the handle steps in shards");
-    if (!factorised(h->windowed ? h->full_c : h->k.c))
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: in-place episodes need factorised series (every lane reads its own row: "
-                                         "[T, N] arrays would be gathered 8x over); use mgx_reset_windows_rolling");
     {   // every argument is checked before the handle leaves the mode it is in
         const int32_t lo = h->windowed ? h->full_window_lo : h->window_lo, hi = h->windowed ? h->full_window_hi : h->window_hi;
         if (max_length < 1 || max_length > hi - lo)
@@ -1020,8 +1017,10 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
     h->full_load_ts = h->k.c.load_ts; h->full_pv_ts = h->k.c.pv_ts; h->full_grid_ts = h->k.c.grid_ts;
     h->full_T = h->k.T; h->full_final = h->layout.final_step; h->full_initial = h->layout.initial_step;
     h->full_window_lo = h->window_lo; h->full_window_hi = h->window_hi;
-    // profile-major copies of the base tables (1.7 MB for a year of hourly rows): in this mode every lane reads its own row
-    {
+    // Factorised series: profile-major copies of the base tables (1.7 MB for a year of hourly rows) -- in this mode every lane reads
+    // its own row.  [T, N] arrays are read where they lie: a lane takes 8 bytes of its own row's line (a gather, 64 lines per wave
+    // and component instead of 4; still no window buffers to copy and restart into).
+    if (factorised(h->k.c)) {
         const int32_t pitch = h->full_T;
         const bool co2 = h->full_c.base_co2 != nullptr;
         DeviceGuard on_device(h->device);

@@ -563,10 +563,10 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
     OT *row = tile + g * LD;
     const int32_t slots = OBS_JB * Q;
     const int32_t W_pad = (W + slots - 1) / slots * slots;
-    // wave-uniform: every slot's row exists, lane offsets fit 32-bit byte offsets
+    // wave-uniform: every slot's row exists, lane offsets fit 32-bit byte offsets (in-place episodes: every grid its own rows)
     const int32_t tr = t & a.row_mask;                  // rolling windows: the buffers are rings of row_mask + 1 rows
     const bool fact = factorised(a.c);                  // factorised series: the general form below (rows out of the caches)
-    const bool fast = !fact && t >= 0 && (int64_t)t + W_pad <= a.T && (int64_t)(4 * Q + 4) * N < (int64_t(1) << 28) &&
+    const bool fast = !fact && !a.ep_off && t >= 0 && (int64_t)t + W_pad <= a.T && (int64_t)(4 * Q + 4) * N < (int64_t(1) << 28) &&
                       (a.row_mask == -1 || tr + W_pad <= a.row_mask + 1);               // ... and this window does not wrap
     if (fast) {
         WinBounds<1> bl, bp;
@@ -607,15 +607,16 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
                                               a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
     } else {
         const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
+        const int32_t ti = t + (a.ep_off ? a.ep_off[ic] : 0);         // in-place episodes: the grid's own series row
         observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return lts[(int64_t)r * N + ic]; }, N,
-                                          a.c.load_lo, a.c.load_hi, a.T, t, W, i, ic, q, Q, row + a.col_load, a.c.load_noise_std, 0u,
+                                          a.c.load_lo, a.c.load_hi, a.T, ti, W, i, ic, q, Q, row + a.col_load, a.c.load_noise_std, 0u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
         observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return pts[(int64_t)r * N + ic]; }, N,
-                                          a.c.pv_lo, a.c.pv_hi, a.T, t, W, i, ic, q, Q, row + a.col_pv, a.c.pv_noise_std, 1u,
+                                          a.c.pv_lo, a.c.pv_hi, a.T, ti, W, i, ic, q, Q, row + a.col_pv, a.c.pv_noise_std, 1u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
         if constexpr (F & F_GRID)
             observe_window_cols<4, NOISE, OT>([&](int32_t r, int cc) { return gts[((int64_t)r * 4 + cc) * N + ic]; }, N,
-                                              a.c.grid_lo, a.c.grid_hi, a.T, t, W, i, ic, q, Q, row + a.col_grid,
+                                              a.c.grid_lo, a.c.grid_hi, a.T, ti, W, i, ic, q, Q, row + a.col_grid,
                                               a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
     }
     if (q == 0) {                                        // the 6 state columns, by the first lane of each grid
@@ -765,13 +766,14 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
                                 a.c.grid_lo, a.c.grid_hi, a.T, ti, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
     } else {
         const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
+        const int32_t ti = t + (a.ep_off ? a.ep_off[ic] : 0);          // in-place episodes: the grid's own series row
         windows_k_module<1>([&](int32_t r, int) { return lts[(int64_t)r * N + ic]; }, N,
-                            a.c.load_lo, a.c.load_hi, a.T, t, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
+                            a.c.load_lo, a.c.load_hi, a.T, ti, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
         windows_k_module<1>([&](int32_t r, int) { return pts[(int64_t)r * N + ic]; }, N,
-                            a.c.pv_lo, a.c.pv_hi, a.T, t, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
+                            a.c.pv_lo, a.c.pv_hi, a.T, ti, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
         if constexpr (GRID)
             windows_k_module<4>([&](int32_t r, int cc) { return gts[((int64_t)r * 4 + cc) * N + ic]; }, N,
-                                a.c.grid_lo, a.c.grid_hi, a.T, t, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
+                                a.c.grid_lo, a.c.grid_hi, a.T, ti, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
     }
     if (q == 0) {                                        // state columns: the current state for block 0, zeros ahead
 #pragma unroll

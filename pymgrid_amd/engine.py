@@ -393,7 +393,7 @@ class StepEngine:
         return obs
 
     def reset_episodes(self, start, length=None, max_length=None, want_obs=True, out=None, validate=True):
-        """Rolling per-grid episodes IN PLACE (``mgx_reset_episodes``; factorised series only): as ``reset_windows_rolling``
+        """Rolling per-grid episodes IN PLACE (``mgx_reset_episodes``): as ``reset_windows_rolling``
         without window buffers -- grid i reads row ``counter + row_off[i]`` of its own series, a (re)start rewrites two words per
         grid.  Single steps only, observation rows per step (no rings).  ``set_auto_reset`` makes the steps restart finished
         grids themselves."""

@@ -314,7 +314,7 @@ class BatchedMicrogridEnv:
         ``rolling=True`` (``mgx_reset_windows_rolling``): the shared counter never ends and ``reset_grids(mask, start,
         length)`` restarts individual grids at any later step -- N microgrids reset one by one, each when its own episode is
         over.  ``max_length`` is then the longest episode any restart may ask for.  ``rolling="inplace"``
-        (``mgx_reset_episodes``, factorised series only): the same without window buffers -- every grid reads its own series
+        (``mgx_reset_episodes``): the same without window buffers -- every grid reads its own series
         rows, a restart rewrites two words per grid."""
         dev = self.batch.device
 
@@ -335,8 +335,6 @@ class BatchedMicrogridEnv:
                     raise ValueError("rolling windows need max_length (or per-grid lengths to take it from)")
                 max_length = int(length.max().item())
             if rolling == "inplace":                 # mgx_reset_episodes: no window buffers, the grids read their own series rows
-                if not self.batch.factorised:
-                    raise ValueError("in-place episodes need a batch with factorised series (generate(..., series='factorised'))")
                 if self._ring is not None:           # rings stay, as for rolling windows: restarted grids are patched in
                     self.engine.prefetch_wait()
                     self._sync_rings = True

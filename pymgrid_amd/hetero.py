@@ -379,14 +379,17 @@ class PerGridWindowEnv:
         # (seed; grid, counter)): one launch per step instead of a dozen small torch kernels
         self.seed = int(seed)
         self._device_draws = self.auto_reset and generator is None
-        # native: in-place episodes (mgx_reset_episodes; factorised series).  Nothing is gathered at a (re)start, and with device
+        # native: in-place episodes (mgx_reset_episodes).  Nothing is gathered at a (re)start, and with device
         # draws the step kernel restarts finished grids ITSELF (mgx_set_auto_reset): an auto-reset step is ONE launch, as in
         # lock-step (9.8 instead of 18.4 us per 100 000-grid step without a forecast horizon); with observation rings one more
         # (the restarted grids' window columns are patched into the ring: 22 / 43 instead of 27 / 50 us at D = 56 / 156).
+        # [T, N] series in place: every lane gathers its own row -- 14.3 against 20.8 us per 100 000-grid step for two series
+        # components without a forecast horizon, but no better than the window buffers with six components (a GridModule) or
+        # with K + H rows per refill (profiles/r04/exp_auto_reset_materialised_in_place.txt): the default follows the measurement
         if native is None:
-            native = self.auto_reset and full_batch.factorised and not env_kwargs.get("obs_views")
-        if native and not full_batch.factorised:
-            raise ValueError("native=True needs a batch with factorised series")
+            L0 = full_batch.layout
+            native = self.auto_reset and not env_kwargs.get("obs_views") and not L0.multi and (
+                full_batch.factorised or (not L0.has_grid and (L0.horizon == 0 or bool(final_observation))))
         if native and not self.auto_reset:
             raise ValueError("native=True is the auto_reset=True path (equal-length windows are gathered once per reset)")
         self.native = bool(native)

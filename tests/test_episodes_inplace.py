@@ -15,10 +15,10 @@ SOAK = int(os.environ.get("MGX_FUZZ_SEED", "0"))          # soak runs: another d
 ARCHS = ("genset+battery", "battery+grid", "genset+battery+grid")
 
 
-def _gen(n, T, arch, device, H=0, seed=9, **kw):
+def _gen(n, T, arch, device, H=0, seed=9, series="factorised", **kw):
     from pymgrid_amd.generator import generate
     return generate(n, n_steps=T, seed=seed + 1000 * SOAK, arch=arch, device=device, horizon=H, mixed_timers=True,
-                    series="factorised", **kw)
+                    series=series, **kw)
 
 
 @pytest.mark.parametrize("arch", ARCHS)
@@ -56,20 +56,22 @@ def test_inplace_episodes_vs_the_oracle_on_shifted_series(arch, device, oracle):
     e.close()
 
 
+@pytest.mark.parametrize("series", ["factorised", "materialised"])
 @pytest.mark.parametrize("arch,H,discrete,prefetch", [("genset+battery", 0, False, 0), ("genset+battery+grid", 0, True, 0),
                                                      ("battery+grid", 5, False, 0), ("genset+battery+grid", 24, False, 0),
                                                      ("genset+battery", 3, True, 0), ("genset+battery+grid", 24, False, 4),
                                                      ("battery+grid", 5, True, 16), ("genset+battery", 7, False, 5)])
-def test_inplace_episodes_equal_rolling_windows_through_restarts(arch, H, discrete, prefetch, device):
+def test_inplace_episodes_equal_rolling_windows_through_restarts(arch, H, discrete, prefetch, series, device):
     """The same episodes on window rings (gathered rows) and in place (row offsets): observations, rewards, per-grid done flags
     and per-grid step counters agree at every step, through individual restarts with new starts and lengths, windows that reach
-    the end of the series, and many more steps than the longest episode."""
+    the end of the series, and many more steps than the longest episode.  Factorised series (the rows formed from the base
+    tables) and [T, N] arrays (every lane gathers its own row)."""
     from pymgrid_amd import BatchedMicrogridEnv, DiscreteBatchedMicrogridEnv
     N, T, max_len = 1500, 300, 14
     cls = DiscreteBatchedMicrogridEnv if discrete else BatchedMicrogridEnv
     kw = dict(remove_redundant_gensets=False) if discrete else {}
-    ring = cls(_gen(N, T, arch, device, H), obs_prefetch=0, **kw)               # window buffers, per-step rows: the plain path
-    inpl = cls(_gen(N, T, arch, device, H), obs_prefetch=prefetch, **kw)        # in place; prefetch > 0: rings + mgx_patch_windows
+    ring = cls(_gen(N, T, arch, device, H, series=series), obs_prefetch=0, **kw)               # window buffers, per-step rows: the plain path
+    inpl = cls(_gen(N, T, arch, device, H, series=series), obs_prefetch=prefetch, **kw)        # in place; prefetch > 0: rings + mgx_patch_windows
     rs = np.random.RandomState(8 + SOAK)
     lengths = rs.randint(1, max_len + 1, size=N).astype(np.int32)
     starts = np.array([rs.randint(0, T - n + 1) for n in lengths], dtype=np.int32)
@@ -109,7 +111,8 @@ def test_inplace_episodes_equal_rolling_windows_through_restarts(arch, H, discre
                           ("genset+battery+grid", 24, False, 11, False, 0), ("genset+battery", 2, True, None, False, 0),
                           ("genset+battery+grid", 24, False, 11, True, 4), ("battery+grid", 6, True, None, True, 16),
                           ("genset+battery", 3, False, 5, False, 3)])
-def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discrete, length, final, prefetch, device):
+@pytest.mark.parametrize("series", ["factorised", "materialised"])
+def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discrete, length, final, prefetch, series, device):
     """PerGridWindowEnv(auto_reset=True) with device draws: native (one launch per step: the step kernel restarts the grids it
     finishes, mgx_set_auto_reset; the pre-restart rows through mgx_set_final_obs) against the rolling windows (step, restart
     gather, observation pass): observations, rewards, done flags, final observations, the drawn starts / lengths and the per-grid
@@ -119,8 +122,8 @@ def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discret
     kw = dict(discrete=discrete, auto_reset=True, final_observation=final, seed=123, trajectory_length=length)
     if discrete:
         kw["remove_redundant_gensets"] = False
-    roll = PerGridWindowEnv(_gen(N, T, arch, device, H), native=False, obs_prefetch=0, **kw)
-    nat = PerGridWindowEnv(_gen(N, T, arch, device, H), native=True, obs_prefetch=prefetch,         # prefetch > 0: rings + patches
+    roll = PerGridWindowEnv(_gen(N, T, arch, device, H, series=series), native=False, obs_prefetch=0, **kw)
+    nat = PerGridWindowEnv(_gen(N, T, arch, device, H, series=series), native=True, obs_prefetch=prefetch,   # prefetch > 0: rings + patches
                            reuse_outputs=(3 if H in (0, 3) else 0), **kw)                         # (rotating reward / done / row buffers)
     assert nat.native and not roll.native
     lengths = None
@@ -149,24 +152,24 @@ def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discret
     roll.close(); nat.close()
 
 
-def test_inplace_episodes_need_factorised_series(device):
+def test_inplace_episodes_defaults_and_refusals(device):
     from pymgrid_amd import BatchedMicrogridEnv, MgxError, StepEngine
-    from pymgrid_amd.generator import generate
     from pymgrid_amd.hetero import PerGridWindowEnv
     N, T = 300, 100
-    bm = generate(N, n_steps=T, seed=1, arch="genset+battery", device=device)
+    bm = _gen(N, T, "genset+battery", device, series="materialised")
     e = StepEngine(bm)
-    with pytest.raises(MgxError, match="factorised"):
-        e.reset_episodes(torch.zeros(N, dtype=torch.int32, device=device), None, 10)
     with pytest.raises(MgxError):
-        e.set_auto_reset(True)
+        e.set_auto_reset(True)                               # not stepping in-place episodes yet
+    e.reset_episodes(torch.zeros(N, dtype=torch.int32, device=device), None, 10)      # [T, N] series: offered since round 4
+    e.set_auto_reset(True, 3, 10)
     e.close()
-    with pytest.raises(ValueError, match="factorised"):
-        PerGridWindowEnv(bm, trajectory_length=5, auto_reset=True, native=True)
-    # defaults: native for factorised series (rings stay in use with a forecast horizon), rolling windows for materialised ones
+    # defaults: native (in place) for factorised series (rings stay in use with a forecast horizon); for [T, N] series where the
+    # per-lane gather beats the window buffers: two series components, no forecast horizon (or final observations wanted)
     assert PerGridWindowEnv(_gen(N, T, "genset+battery", device), trajectory_length=5, auto_reset=True).native
     assert PerGridWindowEnv(_gen(N, T, "genset+battery", device, H=6), trajectory_length=5, auto_reset=True).native
-    assert not PerGridWindowEnv(bm, trajectory_length=5, auto_reset=True).native
+    assert PerGridWindowEnv(bm, trajectory_length=5, auto_reset=True).native
+    assert not PerGridWindowEnv(_gen(N, T, "genset+battery", device, H=6, series="materialised"), trajectory_length=5, auto_reset=True).native
+    assert not PerGridWindowEnv(_gen(N, T, "battery+grid", device, series="materialised"), trajectory_length=5, auto_reset=True).native
     env = BatchedMicrogridEnv(_gen(N, T, "genset+battery+grid", device, H=6), obs_prefetch=0)
     env.reset_windows(np.zeros(N, dtype=np.int32), None, max_length=10, rolling="inplace")
     with pytest.raises(MgxError):

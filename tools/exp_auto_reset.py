@@ -39,7 +39,7 @@ for arch in ("genset+battery", "genset+battery+grid"):
     env.reset()
     print(f"{arch:20s} lock-step env, per-step rows             {timed(lambda: env.step(a)):7.1f} us/step")
     env.close()
-    for native in ((False, True) if series == "factorised" else (False,)):
+    for native in (False, True):
         for fo in (False, True):
             w = PerGridWindowEnv(make(), trajectory_length=168, auto_reset=True, final_observation=fo, native=native)
             w.reset()
