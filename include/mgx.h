@@ -290,8 +290,9 @@ int mgx_reset_grids_random(mgx_handle *h, const uint8_t *mask, uint64_t seed, in
 /* Rolling per-grid episodes IN PLACE.  Same model as mgx_reset_windows_rolling (one shared counter that restarts at 0 and
  * never ends, every grid with its own episode: microgrid.py:205-225 per microgrid), but nothing is copied: grid i simply reads
  * row counter + row_off[i] of its own series and reports done_i = counter >= final_abs[i] - 1.  With factorised series
- * (mgx_columns.base_load ...) the rows come out of small cached base tables; with [T, N] arrays every lane gathers 8 bytes of
- * its own row (64 lines per wave and component instead of 4 -- still cheaper than window buffers that restarts copy into).  row_off / final_abs: caller-owned
+ * (mgx_columns.base_load ...) the rows come out of small cached base tables; for [T, N] arrays the handle makes a grid-major
+ * copy per call ([N, T, 2 or 6]: as much device memory again; a grid's own row is then one 16- or 48-byte read) -- if that
+ * allocation is refused the lanes gather out of the [T, N] arrays instead (same values, slower).  row_off / final_abs: caller-owned
  * DEVICE arrays [N] that the handle keeps reading AND writing until the next mgx_reset*; start / length as for
  * mgx_reset_windows (length NULL: max_length).  (Re)starts -- mgx_reset_grids, mgx_reset_grids_random -- then rewrite two
  * words per grid instead of gathering rows.  Observation windows reach beyond an episode's end into the grid's series and

@@ -69,6 +69,8 @@ struct mgx_handle {
     bool rolling;                            // mgx_reset_windows_rolling: ring buffers, partial resets (mgx_reset_grids)
     bool inplace;                            // mgx_reset_episodes: rolling episodes on the factorised series themselves (no buffers)
     double *pm_tables;                       // ... and the profile-major copies of the base tables they read ([3][PP][pm_pitch], lazily)
+    double *gm_tables;                       // ... or, for [T, N] series, their grid-major copy [N][gm_pitch][2 or 6] (load, pv, grid x 4)
+    int32_t gm_pitch;
     int32_t pm_pitch;
     int32_t rolling_max_length;
     double *roll_load_w, *roll_pv_w, *roll_grid_w;
@@ -417,7 +419,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.ar_fixed_length = 0; h->k.ar_lo = 0; h->k.ar_hi = 0;
     h->k.ar_max_length = 0; h->k.ar_seed = 0; h->k.ar_start_io = nullptr; h->k.ar_length_io = nullptr; h->k.ar_t0_io = nullptr;
     h->k.final_obs = nullptr; h->k.pm_pitch = 0;
-    h->inplace = false; h->pm_tables = nullptr; h->pm_pitch = 0;
+    h->inplace = false; h->pm_tables = nullptr; h->pm_pitch = 0; h->gm_tables = nullptr; h->gm_pitch = 0;
     if ((e = hipMalloc((void **)&h->scratch, sizeof(double) * MAX_METRICS * MAX_PARTIAL)) != hipSuccess) {
         delete h;
         return hip_fail(e, "hipMalloc(scratch)");
@@ -448,6 +450,7 @@ void mgx_destroy(mgx_handle *h)
     if (h->fork_event) (void)hipEventDestroy(h->fork_event);
     if (h->prefetch_stream) { (void)hipStreamSynchronize(h->prefetch_stream); if (!h->prefetch_pooled) (void)hipStreamDestroy(h->prefetch_stream); }
     if (h->pm_tables) (void)hipFree(h->pm_tables);
+    if (h->gm_tables) (void)hipFree(h->gm_tables);
     if (h->d_kargs) (void)hipFree(h->d_kargs);
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_lists) (void)hipFree(h->d_lists);
@@ -859,7 +862,11 @@ static void leave_inplace(mgx_handle *h)
     h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.final_obs = nullptr;
     h->k.ar_start_io = nullptr; h->k.ar_length_io = nullptr; h->k.ar_t0_io = nullptr;
     if (h->k.pm_pitch) {
-        h->k.c.base_load = h->full_c.base_load; h->k.c.base_pv = h->full_c.base_pv; h->k.c.base_co2 = h->full_c.base_co2;
+        if (factorised(h->full_c)) {
+            h->k.c.base_load = h->full_c.base_load; h->k.c.base_pv = h->full_c.base_pv; h->k.c.base_co2 = h->full_c.base_co2;
+        } else {                                          // the caller's [T, N] arrays instead of the grid-major copies
+            h->k.c.load_ts = h->full_load_ts; h->k.c.pv_ts = h->full_pv_ts; h->k.c.grid_ts = h->full_grid_ts;
+        }
         h->k.pm_pitch = 0;
     }
 }
@@ -1042,6 +1049,32 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
         h->k.c.base_load = h->pm_tables; h->k.c.base_pv = h->pm_tables + one;
         if (co2) h->k.c.base_co2 = h->pm_tables + 2 * one;
         h->k.pm_pitch = pitch;
+    } else {
+        // [T, N] series: grid-major copies [N, pitch] (as much memory again as the series; without it -- allocation refused --
+        // the lanes gather their rows out of the [T, N] arrays: 64 lines per wave and component, same values)
+        const int32_t pitch = (h->full_T + 15) & ~15;
+        const int64_t N = h->k.N;
+        const int ncomp = 2 + 4 * h->layout.has_grid;
+        DeviceGuard on_device(h->device);
+        if (!h->gm_tables || h->gm_pitch != pitch) {
+            if (h->gm_tables) (void)hipFree(h->gm_tables);
+            h->gm_tables = nullptr; h->gm_pitch = 0;
+            if (hipMalloc((void **)&h->gm_tables, (size_t)N * ncomp * pitch * sizeof(double)) == hipSuccess) h->gm_pitch = pitch;
+            else { h->gm_tables = nullptr; (void)hipGetLastError(); }
+        }
+        if (h->gm_tables) {
+            const dim3 tiles((unsigned)((N + 31) / 32), (unsigned)((pitch + 31) / 32), 1);
+            hipStream_t s = (hipStream_t)stream;
+            grid_major_kernel<<<tiles, 256, 0, s>>>(h->full_load_ts, h->gm_tables, N, h->full_T, 1, pitch, ncomp, 0);
+            grid_major_kernel<<<tiles, 256, 0, s>>>(h->full_pv_ts, h->gm_tables, N, h->full_T, 1, pitch, ncomp, 1);
+            if (h->layout.has_grid)
+                grid_major_kernel<<<dim3(tiles.x, tiles.y, 4), 256, 0, s>>>(h->full_grid_ts, h->gm_tables, N, h->full_T, 4, pitch, ncomp, 2);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "grid_major_kernel launch");
+            h->k.c.load_ts = h->gm_tables; h->k.c.pv_ts = h->gm_tables + 1;
+            if (h->layout.has_grid) h->k.c.grid_ts = h->gm_tables + 2;
+            h->k.pm_pitch = pitch;
+        }
     }
     h->rolling_max_length = max_length;
     h->roll_load_w = nullptr; h->roll_pv_w = nullptr; h->roll_grid_w = nullptr; h->roll_final = final_abs;

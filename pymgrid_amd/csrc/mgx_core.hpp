@@ -80,9 +80,10 @@ struct KArgs {
     uint64_t ar_seed;
     int32_t *ar_start_io, *ar_length_io, *ar_t0_io;
     void *final_obs;                        // mgx_set_final_obs: the observation BEFORE the restart (rows written inline only)
-    // In-place episodes read the base tables with one row per LANE: c.base_load / base_pv / base_co2 then point at the handle's
-    // PROFILE-major copies [MGX_PROFILE_PITCH, pm_pitch] (a lane's consecutive rows share a line; the public [T, 8] layout has
-    // a 64-byte line per row, which suits the lock-step kernels where every lane reads the same row).  0 = the public layout.
+    // In-place episodes read the series with one row per LANE.  Factorised: c.base_load / base_pv / base_co2 then point at the
+    // handle's PROFILE-major copies [MGX_PROFILE_PITCH, pm_pitch] (a lane's consecutive rows share a line; the public [T, 8] layout
+    // has a 64-byte line per row, which suits the lock-step kernels where every lane reads the same row).  [T, N] series:
+    // c.load_ts / pv_ts / grid_ts point into ONE grid-major copy [N, pm_pitch, 2 or 6] (ts_index).  0 = the public layouts.
     int32_t pm_pitch;
 };
 
@@ -304,6 +305,20 @@ __device__ __forceinline__ void fact_series(const mgx_columns &c, int64_t N, int
     }
 }
 
+// Element (row, grid i) of a [T, N] series -- or, during in-place episodes on such series (pm = KArgs.pm_pitch != 0), of the
+// handle's GRID-major copy [N, pm, C]: every lane reads its own row there, the C = 2 (load, pv) or 6 (+ the four grid components)
+// values of a row are adjacent (one 48-byte read per grid and step) and consecutive rows of a grid share lines.  c.load_ts /
+// pv_ts / grid_ts then point at elements 0 / 1 / 2 of that copy.
+__device__ __forceinline__ int64_t ts_index(int32_t pm, int64_t N, int64_t row, int64_t i, int C)
+{
+    return pm ? (i * pm + row) * C : row * N + i;
+}
+// ... of component cc of the [T, 4, N] grid series
+__device__ __forceinline__ int64_t grid_ts_index(int32_t pm, int64_t N, int64_t row, int cc, int64_t i)
+{
+    return pm ? (i * pm + row) * 6 + cc : (row * 4 + cc) * N + i;
+}
+
 // Component `comp` (0 load, 1 pv, 2..5 grid: import price, export price, co2 per kWh, status) of grid i at series row `row`,
 // whichever way the batch holds its series.  For the kernels off the hot path (window patches, episode gathers).
 __device__ __forceinline__ double series_component(const mgx_columns &c, int64_t N, int comp, int64_t row, int64_t i, int32_t pm = 0)
@@ -318,9 +333,10 @@ __device__ __forceinline__ double series_component(const mgx_columns &c, int64_t
             default: return fact_status(c, N, i, row);
         }
     }
-    if (comp == 0) return c.load_ts[row * N + i];
-    if (comp == 1) return c.pv_ts[row * N + i];
-    return c.grid_ts[(row * 4 + (comp - 2)) * N + i];
+    const int C = c.grid_ts ? 6 : 2;
+    if (comp == 0) return c.load_ts[ts_index(pm, N, row, i, C)];
+    if (comp == 1) return c.pv_ts[ts_index(pm, N, row, i, C)];
+    return c.grid_ts[grid_ts_index(pm, N, row, comp - 2, i)];
 }
 
 // ---- loads ----------------------------------------------------------------------------------------------
@@ -399,6 +415,17 @@ __device__ __forceinline__ void load_inputs(const mgx_columns &c, const AT *__re
         GridFactors f;
         load_factors<F>(c, i, f);
         fact_series<F>(c, N, i, t, f, in, pm);
+        return;
+    }
+    if (pm) {              // in-place episodes on [T, N] series: the grid-major copies (pm is a compile-time 0 in the lock-step kernels)
+        constexpr int C = (F & F_GRID) ? 6 : 2;
+        in.load = c.load_ts[ts_index(pm, N, t, i, C)];
+        in.pv = c.pv_ts[ts_index(pm, N, t, i, C)];
+        in.g_stat = 1.0;
+        if constexpr (F & F_GRID) {
+            const double *g = c.grid_ts + grid_ts_index(pm, N, t, 0, i);
+            in.g_pimp = g[0]; in.g_pexp = g[1]; in.g_co2 = g[2]; in.g_stat = g[3];
+        }
         return;
     }
     in.load = c.load_ts[t * N + i];

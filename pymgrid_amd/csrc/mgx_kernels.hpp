@@ -608,14 +608,16 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
     } else {
         const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
         const int32_t ti = t + (a.ep_off ? a.ep_off[ic] : 0);         // in-place episodes: the grid's own series row
-        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return lts[(int64_t)r * N + ic]; }, N,
+        const int32_t pm = a.pm_pitch;                                // ... out of the grid-major copies
+        constexpr int C = (F & F_GRID) ? 6 : 2;
+        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return lts[ts_index(pm, N, r, ic, C)]; }, N,
                                           a.c.load_lo, a.c.load_hi, a.T, ti, W, i, ic, q, Q, row + a.col_load, a.c.load_noise_std, 0u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
-        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return pts[(int64_t)r * N + ic]; }, N,
+        observe_window_cols<1, NOISE, OT>([&](int32_t r, int) { return pts[ts_index(pm, N, r, ic, C)]; }, N,
                                           a.c.pv_lo, a.c.pv_hi, a.T, ti, W, i, ic, q, Q, row + a.col_pv, a.c.pv_noise_std, 1u,
                                           a.noise_seed, a.noise_increase, a.row_mask);
         if constexpr (F & F_GRID)
-            observe_window_cols<4, NOISE, OT>([&](int32_t r, int cc) { return gts[((int64_t)r * 4 + cc) * N + ic]; }, N,
+            observe_window_cols<4, NOISE, OT>([&](int32_t r, int cc) { return gts[grid_ts_index(pm, N, r, cc, ic)]; }, N,
                                               a.c.grid_lo, a.c.grid_hi, a.T, ti, W, i, ic, q, Q, row + a.col_grid,
                                               a.c.grid_noise_std, 2u, a.noise_seed, a.noise_increase, a.row_mask);
     }
@@ -767,12 +769,14 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     } else {
         const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
         const int32_t ti = t + (a.ep_off ? a.ep_off[ic] : 0);          // in-place episodes: the grid's own series row
-        windows_k_module<1>([&](int32_t r, int) { return lts[(int64_t)r * N + ic]; }, N,
+        const int32_t pm = a.pm_pitch;                                 // ... out of the grid-major copies
+        constexpr int C = GRID ? 6 : 2;
+        windows_k_module<1>([&](int32_t r, int) { return lts[ts_index(pm, N, r, ic, C)]; }, N,
                             a.c.load_lo, a.c.load_hi, a.T, ti, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
-        windows_k_module<1>([&](int32_t r, int) { return pts[(int64_t)r * N + ic]; }, N,
+        windows_k_module<1>([&](int32_t r, int) { return pts[ts_index(pm, N, r, ic, C)]; }, N,
                             a.c.pv_lo, a.c.pv_hi, a.T, ti, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
         if constexpr (GRID)
-            windows_k_module<4>([&](int32_t r, int cc) { return gts[((int64_t)r * 4 + cc) * N + ic]; }, N,
+            windows_k_module<4>([&](int32_t r, int cc) { return gts[grid_ts_index(pm, N, r, cc, ic)]; }, N,
                                 a.c.grid_lo, a.c.grid_hi, a.T, ti, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
     }
     if (q == 0) {                                        // state columns: the current state for block 0, zeros ahead
@@ -971,10 +975,10 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
         load_factors<F>(a.c, i, f);
         fact_series<F>(a.c, N, i, tr, f, in, a.pm_pitch);
     } else {
-        in.load = a.c.load_ts[tr * N + i];
-        in.pv = a.c.pv_ts[tr * N + i];
+        in.load = a.c.load_ts[ts_index(a.pm_pitch, N, tr, i, (F & F_GRID) ? 6 : 2)];
+        in.pv = a.c.pv_ts[ts_index(a.pm_pitch, N, tr, i, (F & F_GRID) ? 6 : 2)];
         in.g_stat = 1.0;
-        if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[(tr * 4 + 3) * N + i];
+        if constexpr (F & F_GRID) in.g_stat = a.c.grid_ts[grid_ts_index(a.pm_pitch, N, tr, 3, i)];
     }
     double q_unused;
     uint32_t xv = 0u;
@@ -985,6 +989,21 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
     if constexpr (F & F_GENSET) { c[k] = in.a_goal; c[k + 1] = in.a_gen; k += 2; }
     if constexpr (F & F_BATTERY) { c[k++] = in.a_bat; }
     if constexpr (F & F_GRID) { c[k++] = in.a_grid; }
+}
+
+// the series part of a step's inputs at series row `row` of grid i (pm: grid-major copies during in-place episodes)
+template <int F>
+__device__ __forceinline__ void load_series_row(const mgx_columns &c, int64_t N, int64_t i, int64_t row, Inputs &in, int32_t pm)
+{
+    constexpr int C = (F & F_GRID) ? 6 : 2;
+    in.load = c.load_ts[ts_index(pm, N, row, i, C)];
+    in.pv = c.pv_ts[ts_index(pm, N, row, i, C)];
+    in.g_stat = 1.0;
+    if constexpr (F & F_GRID) {
+        const int64_t sc = pm ? (int64_t)1 : N;                    // stride between the four components
+        const double *g = c.grid_ts + grid_ts_index(pm, N, row, 0, i);
+        in.g_pimp = g[0]; in.g_pexp = g[sc]; in.g_co2 = g[2 * sc]; in.g_stat = g[3 * sc];
+    }
 }
 
 template <int F>
@@ -1022,7 +1041,7 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
         load_factors<F>(a.c, i, f);
         fact_series<F>(a.c, N, i, tr, f, in, EP ? a.pm_pitch : 0);
     } else {
-        load_series_at<F>(a.c.load_ts + tr * N, a.c.pv_ts + tr * N, (F & F_GRID) ? a.c.grid_ts + tr * 4 * N : nullptr, N, i, i, in);
+        load_series_row<F>(a.c, N, i, tr, in, EP ? a.pm_pitch : 0);
     }
     load_state<F>(a.c, i, log != nullptr, s);
     load_params<F>(a.c, i, p);
@@ -1067,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK) void check_discrete_kernel(const KArgs a, co
         load_factors<F>(a.c, i, f);
         fact_series<F>(a.c, N, i, tr, f, in, a.pm_pitch);
     } else {
-        load_series_at<F>(a.c.load_ts + tr * N, a.c.pv_ts + tr * N, (F & F_GRID) ? a.c.grid_ts + tr * 4 * N : nullptr, N, i, i, in);
+        load_series_row<F>(a.c, N, i, tr, in, a.pm_pitch);
     }
     load_state<F>(a.c, i, true, s);
     load_params<F>(a.c, i, p);
@@ -2296,6 +2315,29 @@ static __global__ __launch_bounds__(BLOCK) void profile_major_kernel(const doubl
     if (e >= (int64_t)PP * pitch) return;
     const int32_t p = (int32_t)(e / pitch), row = (int32_t)(e - (int64_t)p * pitch);
     dst[e] = row < T ? src[(int64_t)row * PP + p] : 0.0;
+}
+
+// [T, Cs, N] series -> the grid-major copy [N, pitch, C] at component offset c0 (mgx_reset_episodes on [T, N] series: every
+// lane reads its own row; the C values of a row are adjacent, consecutive rows of a grid share lines).  One workgroup per
+// 32 x 32 (row, grid) tile of one source component.  A one-off pass per reset: the strided writes do not matter.
+static __global__ __launch_bounds__(256) void grid_major_kernel(const double *__restrict__ src, double *__restrict__ dst, int64_t N,
+                                                                int32_t T, int32_t Cs, int32_t pitch, int32_t C, int32_t c0)
+{
+    __shared__ double tile[32][33];
+    const int32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+    const int64_t i0 = (int64_t)blockIdx.x * 32;
+    const int32_t t0 = (int32_t)blockIdx.y * 32, cs = (int32_t)blockIdx.z;
+    for (int32_t r = ty; r < 32; r += 8) {                             // read: lanes along the grids
+        const int32_t t = t0 + r;
+        const int64_t i = i0 + tx;
+        tile[r][tx] = (t < T && i < N) ? src[((int64_t)t * Cs + cs) * N + i] : 0.0;
+    }
+    __syncthreads();
+    for (int32_t g = ty; g < 32; g += 8) {                             // write: lanes along the rows
+        const int64_t i = i0 + g;
+        const int32_t t = t0 + tx;
+        if (i < N && t < pitch) dst[(i * pitch + t) * C + c0 + cs] = tile[tx][g];
+    }
 }
 
 struct GatherArgs {

@@ -383,13 +383,12 @@ class PerGridWindowEnv:
         # draws the step kernel restarts finished grids ITSELF (mgx_set_auto_reset): an auto-reset step is ONE launch, as in
         # lock-step (9.8 instead of 18.4 us per 100 000-grid step without a forecast horizon); with observation rings one more
         # (the restarted grids' window columns are patched into the ring: 22 / 43 instead of 27 / 50 us at D = 56 / 156).
-        # [T, N] series in place: every lane gathers its own row -- 14.3 against 20.8 us per 100 000-grid step for two series
-        # components without a forecast horizon, but no better than the window buffers with six components (a GridModule) or
-        # with K + H rows per refill (profiles/r04/exp_auto_reset_materialised_in_place.txt): the default follows the measurement
+        # [T, N] series run in place too: the handle keeps a grid-major copy [N, T, 2 or 6] of them (as much memory again) in which a
+        # grid's own row is one 16- or 48-byte read and consecutive rows share lines -- 9.6 / 21.5 us per 100 000-grid auto-reset
+        # step without / with a GridModule against 20.7 / 37.3 us on rolling window buffers, 25 / 48 against 33 / 72 us with 24-hour
+        # observation rows (profiles/r04/exp_auto_reset_materialised_grid_major.txt)
         if native is None:
-            L0 = full_batch.layout
-            native = self.auto_reset and not env_kwargs.get("obs_views") and not L0.multi and (
-                full_batch.factorised or (not L0.has_grid and (L0.horizon == 0 or bool(final_observation))))
+            native = self.auto_reset and not env_kwargs.get("obs_views") and not full_batch.layout.multi
         if native and not self.auto_reset:
             raise ValueError("native=True is the auto_reset=True path (equal-length windows are gathered once per reset)")
         self.native = bool(native)

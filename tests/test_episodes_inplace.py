@@ -163,13 +163,11 @@ def test_inplace_episodes_defaults_and_refusals(device):
     e.reset_episodes(torch.zeros(N, dtype=torch.int32, device=device), None, 10)      # [T, N] series: offered since round 4
     e.set_auto_reset(True, 3, 10)
     e.close()
-    # defaults: native (in place) for factorised series (rings stay in use with a forecast horizon); for [T, N] series where the
-    # per-lane gather beats the window buffers: two series components, no forecast horizon (or final observations wanted)
+    # defaults: native (in place) for either series form; rings stay in use with a forecast horizon
     assert PerGridWindowEnv(_gen(N, T, "genset+battery", device), trajectory_length=5, auto_reset=True).native
     assert PerGridWindowEnv(_gen(N, T, "genset+battery", device, H=6), trajectory_length=5, auto_reset=True).native
     assert PerGridWindowEnv(bm, trajectory_length=5, auto_reset=True).native
-    assert not PerGridWindowEnv(_gen(N, T, "genset+battery", device, H=6, series="materialised"), trajectory_length=5, auto_reset=True).native
-    assert not PerGridWindowEnv(_gen(N, T, "battery+grid", device, series="materialised"), trajectory_length=5, auto_reset=True).native
+    assert PerGridWindowEnv(_gen(N, T, "battery+grid", device, H=6, series="materialised"), trajectory_length=5, auto_reset=True).native
     env = BatchedMicrogridEnv(_gen(N, T, "genset+battery+grid", device, H=6), obs_prefetch=0)
     env.reset_windows(np.zeros(N, dtype=np.int32), None, max_length=10, rolling="inplace")
     with pytest.raises(MgxError):

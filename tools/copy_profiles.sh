@@ -1,0 +1,13 @@
+#!/bin/bash
+# Copy what tools/gpu_profile_r04.sh left under gpurun_out/prof_<tag>/ into profiles/<tag>/ (the tracked, judged place).
+# usage: tools/copy_profiles.sh [tag]
+set -eu
+TAG=${1:-r04}
+P=gpurun_out/prof_$TAG; D=profiles/$TAG
+mkdir -p "$D"
+cp $P/traffic.json $P/valu.json $P/traffic_fleet_*.json $P/csrc_hash.txt "$D"/
+cp $P/summary.txt "$D"/rocprof_summary_$TAG.txt
+cp $P/fleet_summary.txt "$D"/pmc_fleet_step_traffic.txt
+cp $P/stats/bench_kernel_stats.csv "$D"/kernel_stats_$TAG.csv
+tail -n 1 $P/stats.log > "$D"/bench_under_rocprof_driver_cmd.json
+cat "$D"/csrc_hash.txt
