@@ -995,14 +995,25 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(const KArgs a, const PLWo
 template <int F>
 __device__ __forceinline__ void load_series_row(const mgx_columns &c, int64_t N, int64_t i, int64_t row, Inputs &in, int32_t pm)
 {
-    constexpr int C = (F & F_GRID) ? 6 : 2;
-    in.load = c.load_ts[ts_index(pm, N, row, i, C)];
-    in.pv = c.pv_ts[ts_index(pm, N, row, i, C)];
-    in.g_stat = 1.0;
-    if constexpr (F & F_GRID) {
-        const int64_t sc = pm ? (int64_t)1 : N;                    // stride between the four components
-        const double *g = c.grid_ts + grid_ts_index(pm, N, row, 0, i);
-        in.g_pimp = g[0]; in.g_pexp = g[sc]; in.g_co2 = g[2 * sc]; in.g_stat = g[3 * sc];
+    // two explicit forms writing the same fields (a stride selected per launch put `in` into scratch memory: 36 B per lane)
+    if (pm) {
+        constexpr int C = (F & F_GRID) ? 6 : 2;
+        const int64_t e = (i * pm + row) * C;
+        in.load = c.load_ts[e];
+        in.pv = c.pv_ts[e];
+        in.g_stat = 1.0;
+        if constexpr (F & F_GRID) {
+            const double *g = c.grid_ts + e;
+            in.g_pimp = g[0]; in.g_pexp = g[1]; in.g_co2 = g[2]; in.g_stat = g[3];
+        }
+    } else {
+        in.load = c.load_ts[row * N + i];
+        in.pv = c.pv_ts[row * N + i];
+        in.g_stat = 1.0;
+        if constexpr (F & F_GRID) {
+            const double *g = c.grid_ts + (row * 4) * N + i;
+            in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
+        }
     }
 }
 
