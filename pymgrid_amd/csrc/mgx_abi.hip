@@ -67,7 +67,7 @@ struct mgx_handle {
     // caller's window buffers
     bool windowed;
     bool rolling;                            // mgx_reset_windows_rolling: ring buffers, partial resets (mgx_reset_grids)
-    bool inplace;                            // mgx_reset_episodes: rolling episodes on the factorised series themselves (no buffers)
+    bool inplace;                            // mgx_reset_episodes: rolling episodes on the series themselves (no window buffers)
     double *pm_tables;                       // ... and the profile-major copies of the base tables they read ([3][PP][pm_pitch], lazily)
     double *gm_tables;                       // ... or, for [T, N] series, their grid-major copy [N][gm_pitch][2 or 6] (load, pv, grid x 4)
     int32_t gm_pitch;

@@ -70,7 +70,7 @@ struct KArgs {
     // Rolling per-grid windows (mgx_reset_windows_rolling): the window buffers are rings of 2^p rows addressed by
     // (step counter & row_mask); -1 (all ones: the identity) everywhere else.
     int32_t row_mask;
-    // Per-grid episodes IN PLACE (mgx_reset_episodes; factorised series only): grid i reads row counter + ep_off[i] of its own
+    // Per-grid episodes IN PLACE (mgx_reset_episodes): grid i reads row counter + ep_off[i] of its own
     // series (no window buffers), done_i = counter >= ep_final[i] - 1 (ep_final == grid_final, writable).  NULL everywhere else.
     int32_t *ep_off, *ep_final;
     // mgx_set_auto_reset: a single step restarts the grids whose episode it ends -- mgx_reset_grids_random's draw at the counter
