@@ -245,7 +245,8 @@ def timed(run, fn, rounds, device, mdist, per_round=False):
     if per_round:
         round_us = []
         for r in range(rounds):
-            round_us.append(max(((ev[j][0] if r == 0 else marks[j][r - 1]).elapsed_time(marks[j][r])) for j in range(len(streams))) * 1e3)
+            # one sample per (stream, round): a stream's own cadence (the slower stream of a round would bias the level upward)
+            round_us.extend(((ev[j][0] if r == 0 else marks[j][r - 1]).elapsed_time(marks[j][r])) * 1e3 for j in range(len(streams)))
     return t1 - t0, max(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3, round_us
 
 
@@ -646,10 +647,12 @@ def main():
                 "timed_rounds": [first, first + rounds]}
         if round_us:                                               # the spread inside the timed region (the headline only)
             srt = sorted(round_us)
-            roof["round_us"] = {"n": len(srt), "min": srt[0], "median": srt[len(srt) // 2], "max": srt[-1],
+            roof["round_us"] = {"n": len(srt), "min": srt[0], "median": srt[len(srt) // 2], "max": srt[-1], "mean": sum(srt) / len(srt),
                                 "frac_at_median": per_launch_bytes * launches_per_round / (srt[len(srt) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                "what": "stream cadence of each round of a SECOND pass of the same length directly behind the timed region "
-                                        "(HIP events behind every round on the launch streams; per round the slower stream), rank 0"}
+                                "what": "cadence of every launch stream in each round of a SECOND pass of the same length directly behind the "
+                                        "timed region (a HIP event behind every round on each launch stream: n = streams x rounds samples), "
+                                        "rank 0.  The events themselves cost a few us per round (compare `mean` with avg_launch_us of the "
+                                        "timed region, which has none): read this block as the SPREAD of the rounds, not as their level"}
         if sharded:
             roof.update({"launch": f"one round = {S} concurrent kernel launches, one per internal shard stream "
                                    f"(mgx_set_shards), {n_launch} grids each, never joined between rounds",

@@ -22,6 +22,12 @@ def _line(out):
     return json.loads(lines[0])
 
 
+def gp_rows_ok(d):
+    """the general path's Gym step with whole rows off prefetched rings (round 4)"""
+    g = d["general_path_2g2b1grid"].get("gym_steps_rows_h24")
+    return g is not None and g["value"] > 0 and g["roofline"]["frac"] > 0 and g["obs_dim"] == 162
+
+
 def test_gpus_n_launches_its_own_ranks_cpu():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts two ranks itself and they form one process
     group of size 2 (gloo here; nccl = RCCL on a GPU node)."""
@@ -65,7 +71,8 @@ def test_bench_one_rank_json_line(device):
     assert d["other"]["fused_launches_materialised"]["roofline"]["concurrent_streams"] == 2
     # round 4: the spread of the timed rounds, which kernels ran, the issue-side roofline block, the general path and the server
     ru = rf["round_us"]
-    assert ru["n"] == 6 and ru["min"] <= ru["median"] <= ru["max"]
+    assert ru["n"] == 6 * rf["concurrent_streams"] and ru["min"] <= ru["median"] <= ru["max"] and ru["min"] <= ru["mean"] <= ru["max"]
+    assert gp_rows_ok(d)
     from pymgrid_amd import _lib
     assert d["csrc_hash"] == _lib.source_hash() and d["roofline_valu"]["bound"] == "valu"
     assert rf["traffic"] is None or "STALE" not in str(rf["traffic_source"])          # a stale counter file is never quoted
