@@ -179,6 +179,18 @@ int main()
         return 7;
     }
     mgx_destroy(h2);
+    // (6) the same episodes IN PLACE on the first batch's [T, N] arrays (round 4: the handle reads a grid-major copy it makes)
+    HIP_OK(hipMemcpy(d_charge, charge.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_soc, soc.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_status, status.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    MGX_CALL(mgx_reset_episodes(h, d_start, nullptr, KE, d_off, d_fin, nullptr, st));
+    for (int k = 0; k < KE; k++)
+        MGX_CALL(mgx_step(h, d_actions + (size_t)k * N * A, 1, d_reward + (size_t)k * N, d_edone + (size_t)k * N, nullptr, nullptr, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::vector<double> r_epm((size_t)KE * N);
+    std::vector<uint8_t> done_epm((size_t)KE * N);
+    HIP_OK(hipMemcpy(r_epm.data(), d_reward, r_epm.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(done_epm.data(), d_edone, done_epm.size(), hipMemcpyDeviceToHost));
 
     // the oracle, one microgrid at a time
     long bad = 0;
@@ -237,9 +249,24 @@ int main()
             if (orc_run(&g, &s, &a, 1, &o) != 0) { fprintf(stderr, "oracle refused step %d of grid %d (episode)\n", k, i); return 6; }
             bad += (o.reward != r_ep[(size_t)k * N + i]) + ((uint8_t)o.done != done_ep[(size_t)k * N + i]);
         }
+        // ... and the in-place episode on the [T, N] arrays of the first batch
+        g.load_ts = load.data() + i; g.pv_ts = pv.data() + i;
+        memset(&s, 0, sizeof(s));
+        s.t = ep_start[i];
+        s.charge = charge[i]; s.soc = soc[i];
+        s.gen_cur = status[i] & 0xff; s.gen_goal = (status[i] >> 8) & 0xff; s.gen_up = (status[i] >> 16) & 0xff; s.gen_down = status[i] >> 24;
+        for (int k = 0; k < KE; k++) {
+            orc_action a;
+            memset(&a, 0, sizeof(a));
+            const double *row = actions.data() + ((size_t)k * N + i) * A;
+            a.genset[0] = row[0]; a.genset[1] = row[1]; a.battery = row[2];
+            orc_step_out o;
+            if (orc_run(&g, &s, &a, 1, &o) != 0) { fprintf(stderr, "oracle refused step %d of grid %d (episode, [T, N])\n", k, i); return 6; }
+            bad += (o.reward != r_epm[(size_t)k * N + i]) + ((uint8_t)o.done != done_epm[(size_t)k * N + i]);
+        }
     }
     mgx_destroy(h);
     printf("c-abi consumer: %d grids x %d steps, single steps, one fused launch, one fused launch on factorised series and in-place "
-           "per-grid episodes vs the CPU oracle: %ld mismatches\n", N, K, bad);
+           "per-grid episodes (factorised and [T, N] series) vs the CPU oracle: %ld mismatches\n", N, K, bad);
     return bad == 0 ? 0 : 1;
 }
