@@ -318,7 +318,7 @@ class BucketedFleet:
             if e._t is not None:
                 e._t += 1                         # the host mirror of the handle's counter (mgx_fleet_step moved it)
             if env._views:
-                obs_l[k] = ObsViews(env._norm, e.current_step, 1 + env.layout.horizon, env._state_bufs[env._state_pos], env.layout)
+                obs_l[k] = env._view_now()
         return obs_l, list(reward_l), done_l, self._no_info[:n]
 
     def sample_action(self, generator=None):
