@@ -64,29 +64,6 @@ __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict_
                 b[(int64_t)(((F & F_GENSET) != 0 && j < 4) ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0))) * P] = st[j];
         }
     } else if (a.obs_state_only) {          // the window columns of this row were prefetched (obs_windows_k_kernel)
-#ifdef MGX_EXP_COMPACT_PATCH                // TIMING EXPERIMENT ONLY (wrong rows): what do the partial-line state patches cost?
-        if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * NSTATE, 0);
-        else observe_state_cols<F>(a, p, s, (double *)obs + i * NSTATE, 0);
-        return;
-#endif
-#ifdef MGX_EXP_LINE_PATCH                   // TIMING EXPERIMENT ONLY (junk neighbours): the step writes the WHOLE 128-byte line(s) that
-        if (!a.obs_f32) {                   // hold its state bytes; the ahead refills leave exactly those lines unwritten
-            const int32_t cs = (F & F_GENSET) ? ((F & F_BATTERY) ? (a.col_gen < a.col_bat ? a.col_gen : a.col_bat) : a.col_gen) : a.col_bat;
-            const int64_t g = i * a.obs_dim + cs;
-            const int64_t e0 = (g >> 4) << 4, e1 = ((g + NSTATE - 1) >> 4) << 4;
-            double st[6] = {0, 0, 0, 0, 0, 0};
-            observe_state_cols<F>(a, p, s, st, 0);
-            typedef double vec2 __attribute__((ext_vector_type(2)));
-            double *base = (double *)obs;
-#pragma unroll
-            for (int j = 0; j < 8; j++) { vec2 v; v.x = st[j % NSTATE]; v.y = st[(j + 1) % NSTATE]; *reinterpret_cast<vec2 *>(base + e0 + 2 * j) = v; }
-            if (e1 != e0) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) { vec2 v; v.x = st[j % NSTATE]; v.y = st[(j + 1) % NSTATE]; *reinterpret_cast<vec2 *>(base + e1 + 2 * j) = v; }
-            }
-            return;
-        }
-#endif
         if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
         else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
     } else if (a.obs_f32) observe_row_h0<F>(a, i, t_next, p, s, (float *)obs + i * a.obs_dim, pm);
@@ -835,16 +812,6 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         int32_t r = 2 * lane / D, c = 2 * lane - r * D;
         for (int32_t f = 2 * lane; f < total; f += 128) {
             const uint32_t m0 = map[c], m1 = map[c + 1];               // D even, c even: the pair never straddles two rows
-#ifdef MGX_EXP_LINE_PATCH
-            bool hole = false;
-            if (!have_now && sizeof(OT) == 8) {
-                const int32_t cs = a.n_genset ? (a.n_battery ? (a.col_gen < a.col_bat ? a.col_gen : a.col_bat) : a.col_gen) : a.col_bat;
-                const int64_t gi = (g0 + r) * D + c, l0 = (gi >> 4) << 4;          // first element of this pair's line
-                const int64_t q1 = (l0 + 15 - cs) / D;                             // last row whose state starts at or before the line's end
-                hole = (l0 + 15 - cs) >= 0 && q1 < N && q1 * D + cs + nstate - 1 >= l0;
-            }
-            if (!hole)
-#endif
             if (!(skip_state && m0 >= (uint32_t)S0)) {
                 const double *s0 = image + r * BP + m0 + wave;
                 const double *s1 = image + r * BP + m1 + wave;
