@@ -176,14 +176,16 @@ def test_inplace_episodes_defaults_and_refusals(device):
     env.close()
 
 
-def test_native_auto_reset_at_the_true_shape_of_configs2(device):
+@pytest.mark.parametrize("series", ["factorised", "materialised"])
+def test_native_auto_reset_at_the_true_shape_of_configs2(series, device):
     """BASELINE configs[2] (100 000 generated Template-4 grids x 8 760 rows), every grid on its own random 168-step episodes for
-    400 steps (every grid restarts at least twice): in-place episodes == rolling windows, rewards / done / observations / draws."""
+    400 steps (every grid restarts at least twice): in-place episodes == rolling windows, rewards / done / observations / draws.
+    [T, N] series: the in-place env reads the handle's 14 GB grid-major copy of them."""
     from pymgrid_amd.hetero import PerGridWindowEnv
     N, T = 100_000, 8760
     kw = dict(auto_reset=True, seed=5, trajectory_length=168)
-    roll = PerGridWindowEnv(_gen(N, T, "genset+battery", device, seed=42), native=False, **kw)
-    nat = PerGridWindowEnv(_gen(N, T, "genset+battery", device, seed=42), **kw)
+    roll = PerGridWindowEnv(_gen(N, T, "genset+battery", device, seed=42, series=series), native=False, **kw)
+    nat = PerGridWindowEnv(_gen(N, T, "genset+battery", device, seed=42, series=series), **kw)
     assert nat.native
     g = torch.Generator(device=device); g.manual_seed(3 + SOAK)
     st = torch.randint(0, T - 168, (N,), dtype=torch.int32, device=device, generator=g)
