@@ -1056,13 +1056,15 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
         const int64_t N = h->k.N;
         const int ncomp = 2 + 4 * h->layout.has_grid;
         DeviceGuard on_device(h->device);
-        if (!h->gm_tables || h->gm_pitch != pitch) {
+        const char *no_gm = getenv("MGX_NO_GRID_MAJOR");         // tests: take the gather path although the copy would fit
+        const bool want_gm = !(no_gm && no_gm[0] && no_gm[0] != '0');
+        if (want_gm && (!h->gm_tables || h->gm_pitch != pitch)) {
             if (h->gm_tables) (void)hipFree(h->gm_tables);
             h->gm_tables = nullptr; h->gm_pitch = 0;
             if (hipMalloc((void **)&h->gm_tables, (size_t)N * ncomp * pitch * sizeof(double)) == hipSuccess) h->gm_pitch = pitch;
             else { h->gm_tables = nullptr; (void)hipGetLastError(); }
         }
-        if (h->gm_tables) {
+        if (want_gm && h->gm_tables) {
             const dim3 tiles((unsigned)((N + 31) / 32), (unsigned)((pitch + 31) / 32), 1);
             hipStream_t s = (hipStream_t)stream;
             grid_major_kernel<<<tiles, 256, 0, s>>>(h->full_load_ts, h->gm_tables, N, h->full_T, 1, pitch, ncomp, 0);

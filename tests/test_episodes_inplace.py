@@ -152,6 +152,33 @@ def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discret
     roll.close(); nat.close()
 
 
+@pytest.mark.parametrize("arch,H,prefetch", [("genset+battery+grid", 0, 0), ("battery+grid", 5, 0), ("genset+battery+grid", 24, 4)])
+def test_inplace_episodes_without_the_grid_major_copy(arch, H, prefetch, device, monkeypatch):
+    """[T, N] series when the handle cannot have its grid-major copy (allocation refused; here: MGX_NO_GRID_MAJOR=1): the lanes gather
+    their rows out of the [T, N] arrays -- the same values as the window buffers, step by step through restarts."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    monkeypatch.setenv("MGX_NO_GRID_MAJOR", "1")
+    N, T, max_len = 900, 200, 11
+    ring = BatchedMicrogridEnv(_gen(N, T, arch, device, H, series="materialised"), obs_prefetch=0)
+    inpl = BatchedMicrogridEnv(_gen(N, T, arch, device, H, series="materialised"), obs_prefetch=prefetch)
+    rs = np.random.RandomState(4 + SOAK)
+    lengths = rs.randint(1, max_len + 1, size=N).astype(np.int32)
+    starts = np.array([rs.randint(0, T - n + 1) for n in lengths], dtype=np.int32)
+    assert torch.equal(ring.reset_windows(starts, lengths, max_length=max_len, rolling=True),
+                       inpl.reset_windows(starts, lengths, max_length=max_len, rolling="inplace"))
+    g = torch.Generator(device=device); g.manual_seed(6 + SOAK)
+    for k in range(2 * max_len + 3):
+        a = torch.rand(N, ring.layout.action_dim, dtype=torch.float64, device=device, generator=g)
+        o1, r1, d1, _ = ring.step(a)
+        o2, r2, d2, _ = inpl.step(a)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), k
+        if bool(d1.any()):
+            new_len = rs.randint(1, max_len + 1, size=N).astype(np.int32)
+            new_start = np.array([rs.randint(0, T - n + 1) for n in new_len], dtype=np.int32)
+            assert torch.equal(ring.reset_grids(d1, new_start, new_len), inpl.reset_grids(d2, new_start, new_len)), k
+    ring.close(); inpl.close()
+
+
 def test_inplace_episodes_defaults_and_refusals(device):
     from pymgrid_amd import BatchedMicrogridEnv, MgxError, StepEngine
     from pymgrid_amd.hetero import PerGridWindowEnv
