@@ -601,11 +601,15 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     plan->rp = R;
     plan->bp = (ncomp * (R + K) + nstate * K) | 1;
     static const int group_env = [] { const char *e = getenv("MGX_WIN_GROUP"); return e ? atoi(e) : 0; }();   // experiment knob
-    plan->group = (group_env == 8 || group_env == 4 || group_env == 16) ? group_env : 16;
+    // Float rows keep a FLOAT image (windows_body): half the LDS per grid, so a workgroup takes 32 grids where it takes 16 for
+    // double rows -- and 32 grids x 4 bytes are what a whole 128-byte line of a column-major block needs.  (General path: doubles.)
+    const bool float_image = h->k.obs_f32 && !h->multi;
+    plan->group = (group_env == 8 || group_env == 4 || group_env == 16 || group_env == 32) ? group_env : (float_image ? 32 : 16);
     plan->with_state = ahead == 0;
     plan->group0 = 0;
     plan->pitch = h->ring_pitch;
-    auto lds_of = [&](int32_t g) { return (size_t)g * plan->bp * sizeof(double) + (size_t)h->k.obs_dim * sizeof(uint32_t); };
+    const size_t img_esz = float_image ? sizeof(float) : sizeof(double);
+    auto lds_of = [&](int32_t g) { return (size_t)g * plan->bp * img_esz + (size_t)h->k.obs_dim * sizeof(uint32_t); };
     while (plan->group > 1 && lds_of(plan->group) > 160 * 1024) plan->group /= 2;
     size_t lds = (lds_of(plan->group) + 7) & ~(size_t)7;
     if (lds > 160 * 1024)

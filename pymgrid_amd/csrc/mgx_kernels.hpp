@@ -651,11 +651,13 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
 constexpr int OBS_KJ = 2;                               // rows per thread and latency round (x 16 phases = 32 rows)
 constexpr int OBS_K_THREADS = 256;
 
-template <int NC, class Fetch>
+// IT: element type of the LDS image -- double, or float where the rows leave as floats (the value is rounded to float once, here,
+// instead of at every one of its 1 + H stores: the same bits, half the LDS, twice the grids per workgroup)
+template <int NC, typename IT, class Fetch>
 __device__ __forceinline__ void windows_k_module(Fetch fetch, int64_t N,
                                                  const double *__restrict__ lo_col, const double *__restrict__ hi_col,
                                                  int32_t T, int32_t t, int32_t R, int32_t K, int64_t ic, int32_t q, int32_t Q,
-                                                 double *nc /* [NC][RP] of this grid */, double *nu /* [NC][K] */, int32_t RP,
+                                                 IT *nc /* [NC][RP] of this grid */, IT *nu /* [NC][K] */, int32_t RP,
                                                  int32_t row_mask = -1)
 {
     double lo[NC], hi[NC], sp[NC], z_lo[NC], z_hi[NC], z_fill[NC];
@@ -687,8 +689,8 @@ __device__ __forceinline__ void windows_k_module(Fetch fetch, int64_t N,
                     const double x = v[jj][c];
                     const double n_u = in ? (x - lo[c]) / sp[c] : z_fill[c];                 // unclipped (current value)
                     const double n_c = in ? (x < lo[c] ? z_lo[c] : (x > hi[c] ? z_hi[c] : n_u)) : z_fill[c];
-                    nc[c * RP + rr] = n_c;
-                    if (rr < K) nu[c * K + rr] = n_u;
+                    nc[c * RP + rr] = (IT)n_c;
+                    if (rr < K) nu[c * K + rr] = (IT)n_u;
                 }
             }
         }
@@ -716,8 +718,10 @@ struct WindowsKPlan {
 // the state columns of the current state for block 0; without it (a prefetch ahead of the counter) every state column is zero.
 template <bool GRID, typename OT>
 __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan &plan, int32_t t, OT *__restrict__ ring,
-                                             int64_t group, int32_t nstate, bool have_now, const double (&now)[6], double *image)
+                                             int64_t group, int32_t nstate, bool have_now, const double (&now)[6], double *image_raw)
 {
+    typedef typename std::conditional<sizeof(OT) == 4, float, double>::type IT;       // float rows: a float image (windows_k_module)
+    IT *image = reinterpret_cast<IT *>(image_raw);
     constexpr int NCOMP = 2 + (GRID ? 4 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t G = plan.group, Q = OBS_K_THREADS / G, K = plan.K, RP = plan.rp, BP = plan.bp;
@@ -727,7 +731,7 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     const int32_t W = 1 + a.H, D = a.obs_dim, R = K + a.H;
     const int64_t i = g0 + g, ic = i < N ? i : g0;
     const int32_t NU0 = NCOMP * RP, S0 = NU0 + NCOMP * K;
-    double *blk = image + g * BP;
+    IT *blk = image + g * BP;
     uint32_t *map = reinterpret_cast<uint32_t *>(image + G * BP);       // [D]
 
     if (factorised(a.c)) {                               // uniform over the launch: rows formed from the base tables
@@ -736,32 +740,32 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         const mgx_columns &c = a.c;
         const int32_t ti = t + (a.ep_off ? a.ep_off[ic] : 0);          // in-place episodes: the grid's own series row
         const int32_t pm = a.pm_pitch;
-        windows_k_module<1>([&](int32_t r, int) { return fact_load(c.base_load[base_index(pm, r, f.lp)], f.lr); }, N,
+        windows_k_module<1, IT>([&](int32_t r, int) { return fact_load(c.base_load[base_index(pm, r, f.lp)], f.lr); }, N,
                             a.c.load_lo, a.c.load_hi, a.T, ti, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
-        windows_k_module<1>([&](int32_t r, int) { return fact_pv(c.base_pv[base_index(pm, r, f.pp)], f.pr); }, N,
+        windows_k_module<1, IT>([&](int32_t r, int) { return fact_pv(c.base_pv[base_index(pm, r, f.pp)], f.pr); }, N,
                             a.c.pv_lo, a.c.pv_hi, a.T, ti, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
         if constexpr (GRID)
-            windows_k_module<4>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic, pm); }, N,
+            windows_k_module<4, IT>([&](int32_t r, int cc) { return series_component(c, N, 2 + cc, r, ic, pm); }, N,
                                 a.c.grid_lo, a.c.grid_hi, a.T, ti, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
     } else {
         const double *lts = a.c.load_ts, *pts = a.c.pv_ts, *gts = a.c.grid_ts;
         const int32_t ti = t + (a.ep_off ? a.ep_off[ic] : 0);          // in-place episodes: the grid's own series row
         const int32_t pm = a.pm_pitch;                                 // ... out of the grid-major copies
         constexpr int C = GRID ? 6 : 2;
-        windows_k_module<1>([&](int32_t r, int) { return lts[ts_index(pm, N, r, ic, C)]; }, N,
+        windows_k_module<1, IT>([&](int32_t r, int) { return lts[ts_index(pm, N, r, ic, C)]; }, N,
                             a.c.load_lo, a.c.load_hi, a.T, ti, R, K, ic, q, Q, blk, blk + NU0, RP, a.row_mask);
-        windows_k_module<1>([&](int32_t r, int) { return pts[ts_index(pm, N, r, ic, C)]; }, N,
+        windows_k_module<1, IT>([&](int32_t r, int) { return pts[ts_index(pm, N, r, ic, C)]; }, N,
                             a.c.pv_lo, a.c.pv_hi, a.T, ti, R, K, ic, q, Q, blk + RP, blk + NU0 + K, RP, a.row_mask);
         if constexpr (GRID)
-            windows_k_module<4>([&](int32_t r, int cc) { return gts[grid_ts_index(pm, N, r, cc, ic)]; }, N,
+            windows_k_module<4, IT>([&](int32_t r, int cc) { return gts[grid_ts_index(pm, N, r, cc, ic)]; }, N,
                                 a.c.grid_lo, a.c.grid_hi, a.T, ti, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
     }
     if (q == 0) {                                        // state columns: the current state for block 0, zeros ahead
 #pragma unroll
         for (int j = 0; j < 6; j++) {                    // static indices: `now` stays in registers (a dynamic index put it --
             if (j < nstate) {                            // and 64 B of zero-initialisation per thread -- into scratch memory)
-                blk[S0 + j * K] = have_now ? now[j] : 0.0;
-                for (int32_t k = 1; k < K; k++) blk[S0 + j * K + k] = 0.0;
+                blk[S0 + j * K] = (IT)(have_now ? now[j] : 0.0);
+                for (int32_t k = 1; k < K; k++) blk[S0 + j * K + k] = (IT)0.0;
             }
         }
     }
@@ -778,8 +782,8 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     constexpr int KW = OBS_K_THREADS / 64;
     if (a.obs_colpitch) {
         // COLUMN-major blocks: value (block k, column c, grid g0 + g) at (k * D + c) * P + g0 + g.  Thread (g, cq) writes column
-        // c = cq, cq + 16, ... of its grid for the wave's blocks k = wave', ...: the 16 grids of a (k, c) pair are ONE 128-byte line
-        // (P and g0 are multiples of 16), written whole by 16 adjacent lanes.  Nothing else ever writes into such a line's bytes
+        // c = cq, cq + Q, ... of its grid for the wave's blocks k = wave', ...: the G grids of a (k, c) pair -- 16 doubles, or 32
+        // floats out of the float image -- are ONE 128-byte line (P and g0 are multiples of G), written whole by G adjacent lanes.  Nothing else ever writes into such a line's bytes
         // except the step's state columns -- which are whole coalesced lines of their own here (a wave's 64 grids x 8 B per column).
         const int64_t P = a.obs_colpitch;
         const bool in_batch = i < N;
@@ -789,7 +793,7 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
             // a ring written ahead of the counter leaves the state columns to the steps: here they are lines of their own, so
             // not writing them costs nothing (in row-major blocks the same holes make partial lines: MGX_WIN_SKIP_STATE)
             if (!have_now && m >= (uint32_t)S0) continue;
-            const double *src = image + g * BP + m;
+            const IT *src = image + g * BP + m;
             for (int32_t k = 0; k < K; k++)
                 if (in_batch) MGX_WIN_STORE((OT)src[k], outc + ((int64_t)k * D + c) * P);
         }
@@ -813,8 +817,8 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         for (int32_t f = 2 * lane; f < total; f += 128) {
             const uint32_t m0 = map[c], m1 = map[c + 1];               // D even, c even: the pair never straddles two rows
             if (!(skip_state && m0 >= (uint32_t)S0)) {
-                const double *s0 = image + r * BP + m0 + wave;
-                const double *s1 = image + r * BP + m1 + wave;
+                const IT *s0 = image + r * BP + m0 + wave;
+                const IT *s1 = image + r * BP + m1 + wave;
                 OT *out = out0 + f;
                 for (int32_t k = wave; k < K; k += KW) {
                     vec2 v2;
@@ -831,7 +835,7 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         for (int32_t f = lane; f < total; f += 64) {
             const uint32_t m0 = map[c];
             if (!(skip_state && m0 >= (uint32_t)S0)) {
-                const double *s0 = image + r * BP + m0 + wave;
+                const IT *s0 = image + r * BP + m0 + wave;
                 OT *out = out0 + f;
                 for (int32_t k = wave; k < K; k += KW) {
                     MGX_WIN_STORE((OT)*s0, out);
@@ -1762,21 +1766,21 @@ __global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_multi_kernel(cons
         const double *ts = a.c.load_ts;
         const int64_t n = a.n_load;
         for (int32_t j = 0; j < a.n_load; j++, e++)
-            windows_k_module<1>([&](int32_t r, int) { return ts[((int64_t)r * n + j) * N + ic]; }, N, a.c.load_lo + (int64_t)j * N,
+            windows_k_module<1, double>([&](int32_t r, int) { return ts[((int64_t)r * n + j) * N + ic]; }, N, a.c.load_lo + (int64_t)j * N,
                                 a.c.load_hi + (int64_t)j * N, a.T, t, R, K, ic, q, Q, blk + e * RP, blk + NU0 + e * K, RP, a.row_mask);
     }
     {
         const double *ts = a.c.pv_ts;
         const int64_t n = a.n_pv;
         for (int32_t j = 0; j < a.n_pv; j++, e++)
-            windows_k_module<1>([&](int32_t r, int) { return ts[((int64_t)r * n + j) * N + ic]; }, N, a.c.pv_lo + (int64_t)j * N,
+            windows_k_module<1, double>([&](int32_t r, int) { return ts[((int64_t)r * n + j) * N + ic]; }, N, a.c.pv_lo + (int64_t)j * N,
                                 a.c.pv_hi + (int64_t)j * N, a.T, t, R, K, ic, q, Q, blk + e * RP, blk + NU0 + e * K, RP, a.row_mask);
     }
     if constexpr (F & F_GRID) {
         const double *ts = a.c.grid_ts;
         const int64_t n = a.n_grid;
         for (int32_t j = 0; j < a.n_grid; j++, e += 4)
-            windows_k_module<4>([&](int32_t r, int cc) { return ts[(((int64_t)r * n + j) * 4 + cc) * N + ic]; }, N,
+            windows_k_module<4, double>([&](int32_t r, int cc) { return ts[(((int64_t)r * n + j) * 4 + cc) * N + ic]; }, N,
                                 a.c.grid_lo + (int64_t)j * 4 * N, a.c.grid_hi + (int64_t)j * 4 * N, a.T, t, R, K, ic, q, Q,
                                 blk + e * RP, blk + NU0 + e * K, RP, a.row_mask);
     }

@@ -447,11 +447,11 @@ class BatchedMicrogridEnv:
             self._refill()
 
     def _alloc_rings(self, K):
-        """Three rings of K row blocks.  A block holds N rows; blocks are P = N rounded up to 16 rows apart, so that every block
+        """Three rings of K row blocks.  A block holds N rows; blocks are P = N rounded up to 32 rows apart, so that every block
         starts on a 128-byte line whatever N is (``mgx_set_ring_pitch``: the 1-KB wave stores of a refill would otherwise begin and
         end in partial lines).  ``_rings[r][k]`` is the contiguous [N, D] row block the steps return."""
         L = self.layout
-        pitch = (L.n_grids + 15) // 16 * 16
+        pitch = (L.n_grids + 31) // 32 * 32       # (32: a float column of a column-major block is 128 bytes per 32 grids)
         self.engine.set_ring_layout(False)
         self.engine.set_ring_pitch(pitch)
         if self._obs_columns:              # blocks [D, pitch]; a block's observation = the transposed view [N, D], strides (1, pitch)

@@ -24,7 +24,7 @@ def test_column_major_rings_equal_row_major_rings(arch, H, K, dtype, discrete, d
     g = torch.Generator(device=device); g.manual_seed(2)
     for start, n_steps in ((0, 3 * K + 2), (11, K + 1), (T - H - 5, H + 4)):
         o1, o2 = rows.reset(start), cols.reset(start)
-        assert o2.shape == o1.shape and o2.stride() == (1, (N + 15) // 16 * 16) and torch.equal(o1, o2), (start, "reset")
+        assert o2.shape == o1.shape and o2.stride() == (1, (N + 31) // 32 * 32) and torch.equal(o1, o2), (start, "reset")
         for k in range(min(n_steps, T - start - 1)):
             a = rows.sample_action(generator=g)
             (o1, r1, d1, _), (o2, r2, d2, _) = rows.step(a), cols.step(a)
