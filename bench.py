@@ -12,12 +12,18 @@ no [T, N] series exist or are streamed; "materialised" streams [T, N] arrays wri
 timed in every run (the other one under "other"), each with its own algorithmic byte count.  `done` is not written by the
 headline launch: in lock-step it is the same for every grid and follows from the step counter (engine.done_steps).
 
-A bench STEP is one fused ROUND: `--chunk` (64) consecutive env-steps of ALL grids of the rank -- one pass of the hot path
-over one [64, N, A] batch of actions, issued as one K-step kernel launch (mgx_step_k) per shard.  `--steps K --warmup W`
-therefore time exactly K rounds after W untimed ones; `value` = grids x K x chunk / wall time (env-steps/s, whole job),
-`ms_per_step` = wall time per round.
+A bench STEP is one pass of the hot path over one [1024, N, A] batch of actions: `--launches-per-step` (16) fused launches
+(mgx_step_k) of `--chunk` (64) consecutive env-steps of ALL grids of the rank, per shard stream -- 1 024 env-steps of every grid,
+~0.85 ms of GPU time at N = 100 000 (a single 64-step launch is 52 us: twenty of them were a 1-ms timed region and the clock
+noise of the box decided the figure).  `--steps K --warmup W` time exactly K such steps after W untimed ones; `value` = grids x K
+x 1024 / wall time (env-steps/s, whole job), `ms_per_step` = wall time per step.  A roofline "launch" is one 64-step round (one
+kernel per shard stream, all N grids).
 
-Modes (all are timed in every run; --mode picks the headline `value`, the others are reported under "other")
+OUTPUT: stdout carries exactly ONE line -- a compact JSON record (< 4 KB: the headline fields, `roofline`, `cpu_baseline`, and one
+{us, frac} pair per side leg under "legs").  Everything else (full roofline blocks of the legs, clocks, spreads, notes) goes to
+`bench_detail.json` beside this script and to stderr.
+
+Modes (--mode picks the headline `value`; the Gym-cadence legs run by default, the rest with --all-legs)
   fused (default)  parameters and state stay in registers for the 64 steps of a round, actions / series rows / per-step
                    outputs (reward, done, SoC) stream.  The rank's grids are stepped as --shards (2) contiguous ranges on
                    the engine's internal HIP streams (mgx_set_shards): ranges are not joined between rounds, so one range's
@@ -29,7 +35,7 @@ Modes (all are timed in every run; --mode picks the headline `value`, the others
   rbc              rule-based control rolled out on device (mgx_rollout_discrete, one fixed priority list per grid).
 
 Every mode is preceded by PREWARM_S seconds of its own rounds (untimed set-up: code-object load and the ~15 ms the clocks need
-to settle under this load; it runs straight into the W warm-up rounds), then EXACTLY K timed rounds between barrier + synchronize.
+to settle under this load; it runs straight into the W warm-up steps), then EXACTLY K timed steps between barrier + synchronize.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]      N > 1 without WORLD_SIZE in the environment: the script
          re-launches itself under torch.distributed.run, one rank per GPU (RCCL only for the final metrics all-reduce).
@@ -52,22 +58,27 @@ PREWARM_S = 0.3            # seconds of untimed device pre-warm before each mode
 OUT_SETS = 4               # sets of output buffers each runner cycles through (no Infinity-Cache absorption of rewrites)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 SIDE_ROUNDS = (192, 64)    # (timed, warm-up) rounds of the modes that are not the headline
+LAT_FLOOR_US = 1.7         # launch boundary of a kernel that cannot overlap its predecessor (MI355X_MICROARCH.md: 1.5-1.9 us)
+LAT_STREAM_GBS = 6000.0    # ... and the rate at which its one dependent round trip then moves (what the chip sustains)
+MAX_LINE = 4096            # the compact stdout record stays below this (tests/test_bench_contract.py)
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024, help="timed ROUNDS (one round = --chunk env-steps of all grids)")
-    ap.add_argument("--warmup", type=int, default=256, help="untimed rounds before the timed ones")
+    ap.add_argument("--steps", type=int, default=64, help="timed bench STEPS (one step = --launches-per-step rounds of --chunk env-steps of all grids)")
+    ap.add_argument("--warmup", type=int, default=16, help="untimed steps before the timed ones")
     ap.add_argument("--grids", type=int, default=100_000, help="microgrids PER GPU (weak scaling)")
     ap.add_argument("--rows", type=int, default=8760, help="time-series rows T")
     ap.add_argument("--mode", choices=["fused", "step", "rbc"], default="fused")
     ap.add_argument("--chunk", type=int, default=64, help="env-steps per round (= per fused launch)")
+    ap.add_argument("--launches-per-step", type=int, default=16,
+                    help="rounds (fused launches per shard stream) that make up one bench step: 16 x 64 = 1 024 env-steps of every grid")
     ap.add_argument("--shards", type=int, default=None,
                     help="grid ranges stepped on internal HIP streams (mgx_set_shards); 1: one launch sequence.  Default: 2")
     ap.add_argument("--arch", default="genset+battery")
     ap.add_argument("--series", choices=["factorised", "materialised"], default="factorised",
-                    help="series layout of the headline batch (the other layout is timed under 'other')")
+                    help="series layout of the headline batch (the other layout is timed with --all-legs)")
     ap.add_argument("--uniform-columns", action="store_true",
                     help="hold the parameters MicrogridGenerator gives every microgrid (battery efficiency / cycle cost, genset cost "
                          "and co2 figures, unbalanced-energy costs, zero genset timers) once instead of as [N] columns "
@@ -76,15 +87,20 @@ def parse(argv=None):
     ap.add_argument("--hetero-steps", type=int, default=1024,
                     help="timed Gym steps of the heterogeneous H=24 fleet (0: skip); the region starts 256 steps after a reset: the "
                          "first ~100 steps behind a reset + device synchronisation run 2-5 us slower (profiles/r04/exp_fleet_transient2.txt)")
-    ap.add_argument("--no-side-modes", action="store_true", help="time the headline mode only")
+    ap.add_argument("--no-side-modes", action="store_true", help="time the headline mode only (+ the fleet unless --hetero-steps 0)")
+    ap.add_argument("--all-legs", action="store_true",
+                    help="also time the legs that are not part of the default record: the rule-based rollout, the other series layout, "
+                         "one launch sequence, the other ring layout / the views contract of the fleet, the closed policy loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-closed-loop", action="store_true",
-                    help="skip the closed-loop legs (the PMC passes use it: their single steps WITH observation rows would be "
+                    help="skip the Gym legs that write observation rows per step (the PMC passes use it: single steps WITH rows would be "
                          "averaged into the single-step kernel's counters)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the baseline sample")
     ap.add_argument("--prewarm", type=float, default=PREWARM_S)
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (the stdout line is the compact one); '' = nowhere")
     ap.add_argument("--launch-check", action="store_true",
-                    help="only bring the N ranks up, check the process group and print {n_gpus: N} (no GPU work)")
+                    help="only bring the N ranks up, check the process group and the metrics all-reduce, print {n_gpus: N} (no GPU work)")
     return ap.parse_args(argv)
 
 
@@ -106,13 +122,21 @@ def self_launch(args):
 class Runner:
     """Issues rounds on one engine.  Sharded: the engine steps in S grid ranges on its internal streams."""
 
-    def __init__(self, eng, chunk, seed, shards, pool=None):
+    def __init__(self, eng, chunk, seed, shards, pool=None, rank=0, world=1):
         from pymgrid_amd.priority_list import get_priority_lists, table_array
         from pymgrid_amd.rbc import default_priority_ids
         self.eng, self.chunk, self.S = eng, chunk, shards
         L, N, dev = eng.layout, eng.N, eng.device
-        gen = torch.Generator(device=dev); gen.manual_seed(seed)
-        self.pool = pool if pool is not None else torch.rand(4, chunk, N, L.action_dim, dtype=torch.float64, device=dev, generator=gen)
+        if pool is None:
+            # normalised U[0, 1) actions of the GLOBAL batch (seed 7; one [chunk, N x world, A] draw per pool entry, of which this
+            # rank keeps its own grid range): the job's results do not depend on how many GPUs it is spread over
+            gen = torch.Generator(device=dev); gen.manual_seed(seed)
+            pool = torch.empty(4, chunk, N, L.action_dim, dtype=torch.float64, device=dev)
+            for j in range(4):
+                full = torch.rand(chunk, N * world, L.action_dim, dtype=torch.float64, device=dev, generator=gen)
+                pool[j] = full[:, rank * N:(rank + 1) * N]
+                del full
+        self.pool = pool
         # OUT_SETS sets of [chunk, N] output buffers, cycled: a launch never rewrites what the previous three wrote, so no
         # output line can still sit in the 256 MB Infinity Cache when it is written again
         self.outs = [dict(reward=torch.empty(chunk, N, dtype=torch.float64, device=dev),
@@ -122,6 +146,8 @@ class Runner:
         self.rbc_table = table_array(lists)
         self.rbc_ids = torch.from_numpy(default_priority_ids(eng.batch, lists, remove_redundant_gensets=False)).to(dev)
         self.rounds = 0            # rounds issued since the process started (per mode runner)
+        self.env = None            # a BatchedMicrogridEnv around self.eng (the step_env leg)
+        self.act_views = None
         self.streams = []
         self.done_stream = False
 
@@ -129,9 +155,15 @@ class Runner:
         self.eng.set_shards(self.S if on else 1)
         self.streams = self.eng.shard_streams() if on and self.S > 1 else []
 
+    def reset(self):
+        if self.env is not None:
+            self.env.reset()
+        else:
+            self.eng.reset(want_obs=False)
+
     def _room(self):
         if self.eng.current_step + self.chunk > self.eng.layout.final_step:
-            self.eng.reset(want_obs=False)
+            self.reset()
 
     # `done`: in lock-step it is the same for every grid, done(k) = (t + k >= final_step - 1); the launches below do not write
     # it per grid (self.done_stream = False) -- engine.done_steps(K) derives the [K, N] view from the step counter
@@ -159,15 +191,16 @@ class Runner:
                                done=self.done_stream)
             self.rounds += 1
 
-    def step_python(self, rounds):
-        """The same launches from a Python loop around engine.step (what `for a in actions: env.step(a)` costs)."""
-        o = self.outs[0]
-        out1 = dict(reward=o["reward"][0], done=o["done"][0])
+    def step_env(self, rounds):
+        """The Gym surface from a Python loop: `for a in actions: env.step(a)` on a BatchedMicrogridEnv whose step is bound to the
+        handle (mgx_env_bind: one C call per env-step, outputs in rotating buffers)."""
+        if self.act_views is None:                  # the [N, A] views of the pooled actions, built once (a view costs ~1 us)
+            self.act_views = [[self.pool[j][k] for k in range(self.chunk)] for j in range(self.pool.shape[0])]
+        step = self.env.step
         for _ in range(rounds):
             self._room()
-            a = self.pool[self.rounds % 4]
-            for k in range(self.chunk):
-                self.eng.step(a[k], normalized=True, want_obs=False, want_log=False, out=out1, want_done=self.done_stream)
+            for ak in self.act_views[self.rounds % 4]:
+                step(ak)
             self.rounds += 1
 
     def kernel_durations_us(self, fn, rounds=16):
@@ -250,7 +283,7 @@ def timed(run, fn, rounds, device, mdist, per_round=False):
     return t1 - t0, max(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3, round_us
 
 
-def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
+def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform, all_legs=False):
     """BASELINE configs[4] per GPU: a heterogeneous fleet (1/3 genset+battery, 1/3 battery+grid, 1/3 genset+battery+grid;
     forecast_horizon = 24, T = `rows`) stepped through the Gym surface WITH observations, under both observation contracts:
       rows   step() returns the [N, D] rows (D = 56 / 152 / 156): written ahead in rings of 16 row blocks, the step adds the
@@ -263,9 +296,11 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
     K_ring = 32          # ring depth: 25 vs 27.5 us per fleet step against K = 16 (profiles/r04/exp_fleet_refill_occupancy.txt)
     out = {}
     archs = ("genset+battery", "battery+grid", "genset+battery+grid")
-    #   rows_colmajor   the same [N, D] observation per step, its ring blocks stored column-major (a view with strides (1, pitch)):
-    #                   the state columns a step adds are coalesced runs instead of 48 bytes per row
-    for contract_name in ("rows", "rows_colmajor", "views"):
+    #   rows            step() returns the [N, D] observation, the fleet's DEFAULT ring layout: column-major blocks (obs = the view with
+    #                   strides (1, pitch): the state columns a step adds are coalesced runs instead of 48 bytes per row)
+    #   rows_rowmajor   the same with obs_layout="rows": contiguous [N, D] rows              (--all-legs)
+    #   views           the zero-copy contract                                               (--all-legs)
+    for contract_name in (("rows", "rows_rowmajor", "views") if all_legs else ("rows",)):
         contract = "rows" if contract_name.startswith("rows") else "views"
         for dt_name, dt in (("float64", torch.float64), ("float32", torch.float32)):
             name = f"{dt_name}_{contract_name}"
@@ -273,7 +308,7 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
                                 world=world, series=series, uniform_columns=uniform) for k, arch in enumerate(archs)]
             if contract == "rows":
                 fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K_ring, reuse_outputs=3 * K_ring,
-                                                   obs_layout="columns" if contract_name == "rows_colmajor" else "rows")
+                                                   obs_layout="rows" if contract_name == "rows_rowmajor" else None)
             else:
                 fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_views=True, reuse_outputs=3 * K_ring)
             gen = torch.Generator(device=dev); gen.manual_seed(11 + rank)
@@ -355,8 +390,13 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
                                       "avg_launch_us": gpu / steps * 1e6, "launch": launch,
                                       "kernel": "fleet_step_kernel" + (f" + obs_windows_k_kernel<F> x3 / {K_ring}" if contract == "rows" else ""),
                                       "refill": fleet.refill if contract == "rows" else None,
-                                      "ring_blocks": ("column-major [D, pitch]: obs = the [N, D] view with strides (1, pitch)" if contract_name == "rows_colmajor"
+                                      "ring_blocks": ("column-major [D, pitch]: obs = the [N, D] view with strides (1, pitch) (the default)" if contract_name == "rows"
                                                       else ("row-major [N, D]" if contract == "rows" else None))}}
+            if contract == "views":
+                # ONE launch per fleet step that writes 6 state columns: a dependent round trip behind a launch boundary, not a stream
+                rfv = out[name]["roofline"]
+                model_us = LAT_FLOOR_US + alg / (LAT_STREAM_GBS * 1e3)
+                rfv.update({"bound": "latency", "model_us": model_us, "frac_of_latency_model": model_us / (gpu / steps * 1e6)})
             obs_dims = [e.layout.obs_dim for e in fleet.envs]
             fleet.close()
             del fleet, batches
@@ -366,6 +406,247 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform):
                 "workload": "BASELINE configs[4] mix per GPU: 1/3 genset+battery, 1/3 battery+grid, 1/3 genset+battery+grid; "
                             f"T = {rows}, forecast_horizon = 24; Gym step() with observations (rows / zero-copy views)"})
     return out
+
+
+def closed_loop_leg(args, n_total, dev, rank, world, mdist):
+    """An agent IN the loop: obs -> a small on-device policy -> env.step -> obs, from Python (--all-legs)."""
+    from pymgrid_amd.generator import generate
+    from pymgrid_amd import BatchedMicrogridEnv
+
+    def loop(dtype, reuse, light=False, auto_reset=False):
+        b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=args.series)
+        if auto_reset:           # every grid on its own random 168-step episodes, restarted by the step that ends them
+            from pymgrid_amd.hetero import PerGridWindowEnv
+            env = PerGridWindowEnv(b, trajectory_length=168, auto_reset=True, seed=3, obs_dtype=dtype, action_dtype=dtype,
+                                   reuse_outputs=reuse)
+        else:
+            env = BatchedMicrogridEnv(b, obs_dtype=dtype, action_dtype=dtype, reuse_outputs=reuse)
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        A = env.layout.action_dim
+        W = torch.randn(env.layout.obs_dim, A, dtype=dtype, device=dev, generator=g)
+        w = torch.randn(A, dtype=dtype, device=dev, generator=g)
+        # light: a per-feature policy (two elementwise kernels) -- torch's GEMM for a [N, 8] x [8, 3] product takes 23 us in
+        # float64 and 84 us in float32 on this stack, which would hide the env behind the policy
+        policy = (lambda o: torch.sigmoid(o[:, :A] * w)) if light else (lambda o: torch.sigmoid(o @ W))
+        obs = env.reset()
+        n = min(2000, args.rows - 200)
+
+        def timed_loop(fn, sync_ranks):
+            for _ in range(100):
+                fn()
+            if sync_ranks:
+                mdist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize(dev)
+            wall = time.perf_counter() - t0
+            if sync_ranks:
+                wall = mdist.max_over_ranks(wall, dev)
+                mdist.barrier()
+            return wall
+        st = {"obs": obs}
+
+        def both():
+            st["obs"] = env.step(policy(st["obs"]))[0]
+        wall = timed_loop(both, True)
+        policy_us = timed_loop(lambda: policy(obs), False) / n * 1e6                  # the two torch kernels alone
+        env.reset()
+        a = policy(obs)
+        env_us = timed_loop(lambda: env.step(a), False) / n * 1e6                     # env.step alone (host-paced)
+        env.close()
+        return {"value": n_total * n / wall, "us_per_step": wall / n * 1e6, "steps": n,
+                "policy_kernels_alone_us": policy_us, "env_step_alone_us": env_us}
+    out = {"float64": loop(torch.float64, 0), "float32_io_rotating_outputs": loop(torch.float32, 4, light=True)}
+    if args.series == "factorised":
+        out["float32_io_auto_reset_168_step_episodes"] = loop(torch.float32, 4, light=True, auto_reset=True)
+    out["loop"] = ("obs [N, 8] -> sigmoid(obs @ W) -> BatchedMicrogridEnv.step (one launch) -> obs, issued from Python: three "
+                   "kernels per env-step (matmul, sigmoid, step), each waiting for the one before -- the env's share is "
+                   "env_step_alone_us.  float32_io: observations and actions cross the boundary as floats (what a policy "
+                   "network consumes / emits; the step itself stays float64), reward and rows in 4 rotating buffers "
+                   "(reuse_outputs), and the policy is sigmoid(obs[:, :A] * w): two elementwise kernels instead of torch's "
+                   "GEMM, which takes 23 us (float64) / 84 us (float32) for this [N, 8] x [8, 3] product.  auto_reset: PerGridWindowEnv -- "
+                   "every grid walks its own random 168-step episodes and is restarted by the step that ends its episode "
+                   "(in-place episodes, mgx_set_auto_reset: still one launch per env-step)")
+    out["value"], out["us_per_step"] = out["float64"]["value"], out["float64"]["us_per_step"]
+    return out
+
+
+def general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist):
+    """The GENERAL path on the board: 2 gensets + 2 batteries + 1 grid per microgrid (module_container.py:355-413 allows any
+    multiplicity; such layouts run on the general kernels: columns [n, N], MicrogridStep's lists in LDS).  Single Gym steps, the
+    K-step launch and Gym steps with whole 24-hour rows, each against its own algorithmic bytes (SURVEY 8(d) with per-instance
+    parameter / state counts) and, where a counter pass of this hash is committed, its PMC traffic (profiles/r*/traffic_general.json)."""
+    from pymgrid_amd.engine import StepEngine
+    from pymgrid_amd.generator import generate
+    from pymgrid_amd.generator import widen
+    rows_g = min(args.rows, 1200)                   # materialised series [T, n, N]: 1 200 rows are 10 GB at N = 100 000
+    base = generate(n_total, n_steps=rows_g, seed=42, arch="genset+battery+grid", device=dev, rank=rank, world=world)
+    gb = widen(base, n_genset=2, n_battery=2, n_grid=1)
+    del base
+    ge = StepEngine(gb)
+    Lg = ge.layout
+    gen = torch.Generator(device=dev); gen.manual_seed(3 + rank)
+    a1 = torch.rand(N, Lg.action_dim, dtype=torch.float64, device=dev, generator=gen)
+    Kg = min(chunk, 32)
+    aK = torch.rand(Kg, N, Lg.action_dim, dtype=torch.float64, device=dev, generator=gen)
+    out = {}
+    reward1 = torch.empty(N, dtype=torch.float64, device=dev)
+
+    def run(fn, n, per_call_steps):
+        ge.reset(0, want_obs=False)
+        for _ in range(max(8, n // 8)):
+            fn()
+        ge.reset(0, want_obs=False)
+        mdist.barrier(); torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize(dev)
+        wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+        gpu = mdist.max_over_ranks(e0.elapsed_time(e1) * 1e-3, dev)
+        mdist.barrier()
+        return wall, gpu, n * per_call_steps
+    n1 = min(400, rows_g - 64)
+    wall, gpu, steps1 = run(lambda: ge.step(a1, want_obs=False, want_log=False, out=dict(reward=reward1), want_done=False), n1, 1)
+    b1 = (Lg.bytes_per_step() - 1) * N              # (no done byte: lock-step)
+    out["single_steps"] = {"value": n_total * steps1 / wall, "us_per_step": gpu / steps1 * 1e6, "us_per_step_wall": wall / steps1 * 1e6,
+                           "roofline": {"bound": "hbm", "achieved": b1 / (gpu / steps1) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": b1 / (gpu / steps1) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                        "algorithmic_bytes_per_launch": b1, "kernel": "step_multi_kernel<7>",
+                                        "bytes_per_env_step": Lg.bytes_per_step() - 1}}
+    nK = max(2, min(12, (rows_g - 64) // Kg))
+    wall, gpu, stepsK = run(lambda: ge.step_k(aK, normalized=True, reward=True, soc_trace=False), nK, Kg)
+    # the K-step loop of the general path keeps nothing in registers: every step re-reads parameters and state
+    bK = (Lg.bytes_per_step() - 1) * N
+    out["k_step_launches"] = {"value": n_total * stepsK / wall, "us_per_step": gpu / stepsK * 1e6, "steps_per_launch": Kg,
+                              "roofline": {"bound": "hbm", "achieved": bK / (gpu / stepsK) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": bK / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                           "algorithmic_bytes_per_launch": bK * Kg, "kernel": "step_k_multi_kernel<7>",
+                                           "bytes_per_env_step": Lg.bytes_per_step() - 1,
+                                           "note": "a K-step loop around the general step: parameters and state are re-read "
+                                                   "every step (cache hits), charged per step like the single launches"}}
+    out["layout"] = "2 gensets + 2 batteries + 1 grid + load + pv per microgrid (general kernels), materialised series"
+    out["grids_per_gpu"], out["rows"] = N, rows_g
+    ge.close()
+    del ge, gb
+    torch.cuda.empty_cache()
+    # Gym steps with whole observation rows (H = 24): rings refilled by the general window kernel (obs_windows_k_multi_kernel;
+    # the step adds its 12 state columns) -- per-step rows by one lane per grid were 261 us (profiles/r04/exp_multi_rings.txt)
+    from pymgrid_amd import BatchedMicrogridEnv
+    rows_o = min(args.rows, 600)
+    base = generate(n_total, n_steps=rows_o, seed=42, arch="genset+battery+grid", horizon=24, device=dev, rank=rank, world=world)
+    env = BatchedMicrogridEnv(widen(base, n_genset=2, n_battery=2, n_grid=1), obs_prefetch=32, reuse_outputs=96)
+    del base
+    Lo = env.layout
+    ao = torch.rand(N, Lo.action_dim, dtype=torch.float64, device=dev, generator=gen)
+    env.reset()
+    for _ in range(40):
+        env.step(ao)
+    mdist.barrier(); torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    no = rows_o - 24 - 40 - 8
+    t0 = time.perf_counter(); e0.record()
+    for _ in range(no):
+        env.step(ao)
+    e1.record(); torch.cuda.synchronize(dev)
+    wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+    gpu = mdist.max_over_ranks(e0.elapsed_time(e1) * 1e-3, dev)
+    bo = (Lo.bytes_per_step() - 1 + 8 * Lo.obs_dim) * N
+    out["gym_steps_rows_h24"] = {"value": n_total * no / wall, "us_per_step": gpu / no * 1e6, "ring_depth": 32, "obs_dim": Lo.obs_dim,
+                                 "roofline": {"bound": "hbm", "achieved": bo / (gpu / no) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": bo / (gpu / no) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                              "algorithmic_bytes_per_launch": bo, "kernel": "step_multi_kernel<7> + obs_windows_k_multi_kernel<7, double>",
+                                              "bytes_per_env_step": bo // N}}
+    env.close()
+    # PMC traffic of the three legs, where a counter pass taken on the kernels now running is committed (tools/gpu_profile_r05.sh)
+    tg, tsrc = profile_json("traffic_general.json")
+    for key in ("single_steps", "k_step_launches", "gym_steps_rows_h24"):
+        rf = out[key]["roofline"]
+        rf["traffic_source"] = tsrc
+        e = (tg or {}).get(key)
+        if e is not None and e.get("grids_per_gpu") == N:
+            rf["traffic"] = e["hbm_bytes_per_launch"]
+    # a single general step is one dependent round trip behind a launch boundary, like the single-instance one
+    rf = out["single_steps"]["roofline"]
+    model_us = LAT_FLOOR_US + rf["algorithmic_bytes_per_launch"] / (LAT_STREAM_GBS * 1e3)
+    rf.update({"bound": "latency", "model_us": model_us, "frac_of_latency_model": model_us / out["single_steps"]["us_per_step"]})
+    return out
+
+
+def compact_line(detail, mode, detail_name):
+    """The ONE stdout line: the headline fields, the headline's roofline + cpu_baseline, one {us, frac[, lat, t/a]} entry per side leg
+    -- derived from the full record (`detail`, which goes to bench_detail.json / stderr) and kept under MAX_LINE characters: the
+    driver keeps a bounded tail of stdout, and a record it cannot parse is a round without a measurement (round 4)."""
+    def r4(x):
+        return None if x is None else float(f"{x:.4g}")
+
+    def leg(r, us_key=None):
+        """{us per env-step (GPU time per launch or fleet step), HBM-roofline fraction[, fraction of the latency model, traffic / algorithmic]}"""
+        if not r or "error" in r:
+            return {"error": str((r or {}).get("error", "not run"))[:80]}
+        q = r["roofline"]
+        out = {"us": r4(r[us_key] if us_key else q.get("avg_launch_us")), "frac": r4(q["frac"])}
+        if q.get("frac_of_latency_model") is not None:
+            out["lat"] = r4(q["frac_of_latency_model"])
+        if q.get("traffic") is not None and q.get("algorithmic_bytes_per_launch"):
+            out["t/a"] = r4(q["traffic"] / q["algorithmic_bytes_per_launch"])
+        return out
+    legs = {}
+    for name, r in (detail.get("other") or {}).items():
+        legs[name] = leg(r)
+    hetero, general, closed = detail.get("hetero_h24_gym_steps"), detail.get("general_path_2g2b1grid"), detail.get("closed_loop_policy_gym_steps")
+    if isinstance(hetero, dict):
+        for k, v in hetero.items():
+            if isinstance(v, dict) and "roofline" in v:
+                legs["config5_" + k] = leg(v)
+        if "error" in hetero:
+            legs["config5"] = {"error": str(hetero["error"])[:80]}
+    if isinstance(general, dict):
+        for k, short in (("single_steps", "general_single_step"), ("k_step_launches", "general_k_step"), ("gym_steps_rows_h24", "general_gym_rows_h24")):
+            if k in general:
+                legs[short] = leg(general[k], "us_per_step")
+        if "error" in general:
+            legs["general"] = {"error": str(general["error"])[:80]}
+    if isinstance(closed, dict) and "us_per_step" in closed:
+        legs["closed_loop_policy"] = {"us": r4(closed["us_per_step"])}
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: detail[k] for k in keep}
+    cfg = detail["config"]
+    line["config"] = {k: cfg[k] for k in ("workload", "env_steps_per_step", "steps_per_launch", "grids_per_gpu", "grids_total", "mode", "series",
+                                          "parallelism", "backend")}
+    rf = detail["roofline"]
+    line["roofline"] = {"bound": rf["bound"], "achieved": r4(rf["achieved"]), "peak": rf["peak"], "unit": rf["unit"], "frac": r4(rf["frac"]),
+                        "traffic": rf["traffic"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
+                        "kernel": rf["kernel"], "avg_launch_us": r4(rf["avg_launch_us"]), "launches": rf["launches"],
+                        "bytes_per_env_step": r4(rf["bytes_per_env_step"]), "frac_wall": r4(rf["frac_wall"]),
+                        "traffic_source": rf.get("traffic_source")}
+    rv = detail.get("roofline_valu")
+    if rv and rv.get("frac") is not None:
+        line["roofline"]["valu_frac"] = r4(rv["frac"])
+    cpu = detail.get("cpu_baseline")
+    if cpu is not None and "error" not in cpu:
+        line["cpu_baseline"] = {"value": r4(cpu["value"]), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                                "value_1thread": r4(cpu["value_1thread"]), "host_logical_cpus": cpu["host_logical_cpus"],
+                                "sample": cpu["sample_short"]}
+    else:
+        line["cpu_baseline"] = cpu
+    line["csrc_hash"] = detail["csrc_hash"]
+    line["per_rank_env_steps_per_s"] = [r4(v) for v in detail["per_rank_env_steps_per_s"]]
+    ma = detail["metrics_allreduce"]
+    line["metrics"] = {"sum_last_reward": ma["sum_last_reward"], "mean_soc": ma["mean_soc"], "backend": ma["collective_backend"]}
+    line["legs"] = legs
+    line["detail"] = detail_name
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= MAX_LINE:                      # never let the record outgrow what the driver parses: the optional legs go first
+        line["legs"] = {k: v for k, v in legs.items() if "error" not in v and k.startswith(("single_step", "config5", "general"))}
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= MAX_LINE:
+        line["legs"] = {"dropped": "record too long: see " + str(detail_name)}
+        text = json.dumps(line, separators=(",", ":"))
+    return text
 
 
 def _lib_factor_columns():
@@ -452,6 +733,7 @@ def cpu_baseline(eng, pool, seconds):
             "value_1thread": v1, "host_logical_cpus": cores, "cgroup_cpu_quota": quota,
             "per_instance_python_loop_1core": per_instance,
             "thread_probe": {str(c): round(v) for c, v in probe.items()},
+            "sample_short": f"first {n} grids x {K} steps of the bench batch, ~{seconds:.0f} s, oracle/mgx_oracle.c (C restatement, OpenMP)",
             "sample": f"first {n} grids x {K} steps of the benchmark batch, repeated for ~{seconds:.0f} s "
                       f"({n1 + nall} env-steps on 1 and {best} threads): oracle/mgx_oracle.c (scalar C restatement of "
                       f"the reference loop, OpenMP over tiles of 64 grids); the Python reference itself runs ~2e3 "
@@ -571,24 +853,39 @@ def main():
             b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=series,
                          uniform_columns=(series == "factorised" and args.uniform_columns))
             pool = next(iter(runs.values())).pool if runs else None
-            runs[series] = Runner(StepEngine(b), chunk, 7 + rank, shards_of[series], pool=pool)
+            runs[series] = Runner(StepEngine(b), chunk, 7, shards_of[series], pool=pool, rank=rank, world=world)
         return runs[series]
+
+    def env_runner(observations):
+        """The Gym surface itself: BatchedMicrogridEnv.step from a Python loop (the bound step: one mgx_env_step call per env-step),
+        rewards (and rows) in 4 rotating buffers.  Its own batch of the same draw (the env owns an engine)."""
+        key = "env_obs" if observations else "env"
+        if key not in runs:
+            from pymgrid_amd import BatchedMicrogridEnv
+            b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=args.series)
+            env = BatchedMicrogridEnv(b, observations=observations, reuse_outputs=4)
+            assert env._fp is not None, "the env did not bind its step (mgx_env_bind)"
+            r = Runner(env.engine, chunk, 7, 1, pool=runner(args.series).pool)
+            r.env = env
+            runs[key] = r
+        return runs[key]
 
     run = runner(args.series)
     eng, batch = run.eng, run.eng.batch
     L = eng.layout
+    LPS = max(1, args.launches_per_step)             # rounds per bench step
 
     device_state = {}
 
-    def measure(mode, sharded, rounds, warmup, series=None):
-        run = runner(series or args.series)
+    def measure(mode, sharded, rounds, warmup, series=None, run=None, spread=False):
+        run = run or runner(series or args.series)
         eng, S = run.eng, run.S
         sharded = sharded and S > 1
         fact = eng.batch.factorised
         ub = eng.batch.uniform_param_bytes()         # parameter bytes per grid NOT read: batch-uniform columns are held once
         run.shard(sharded)
         fn = getattr(run, mode)
-        eng.reset(want_obs=False)
+        run.reset()
         # device pre-warm (untimed, part of set-up like the data generation): the first launches after start-up or after
         # an idle phase run on a cold device -- code-object load, and ~15 ms until the clocks settle under this load
         # (profiles/r01/exp_transient_cause.txt) -- so PREWARM_S seconds of the same rounds precede the W warm-up rounds,
@@ -608,20 +905,21 @@ def main():
         fn(warmup)
         first = run.rounds
         wall, gpu, _ = timed(run, fn, rounds, dev, mdist)
-        # the spread of a timed region: the SAME number of rounds once more, directly behind it, with an event behind every round on
-        # every launch stream (inside the timed region itself the extra host calls would be part of what is measured)
-        round_us = timed(run, fn, rounds, dev, mdist, per_round=True)[2] if mode == args.mode else None
+        # the spread of a timed region: a second pass directly behind it, with an event behind every round on every launch stream
+        # (inside the timed region itself the extra host calls would be part of what is measured)
+        round_us = timed(run, fn, min(rounds, 256), dev, mdist, per_round=True)[2] if spread else None
         walls = mdist.gather_over_ranks(wall, dev)
         wall, gpu = max(walls), mdist.max_over_ranks(gpu, dev)
         n_launch = (N + S - 1) // S if sharded else N             # grids per kernel launch
+        obs_rows = mode == "step_env" and run.env._observations
         if mode in ("fused", "rbc"):
             A8 = 8 * L.action_dim * chunk if mode == "rbc" else 0  # rbc: no action stream; + 1 id byte per grid, once
             per_launch = L.bytes_fused(chunk, done=run.done_stream, factorised=fact) - A8 + (1 if mode == "rbc" else 0) - ub
             launches_per_round = 1
         else:                                                      # `chunk` single-step launches per round
             # single steps of a factorised batch read the grid's factors (2 ratios + 2 profile ids: 18 B) where the
-            # materialised one reads 2 row values (16 B); no done byte
-            per_launch = L.bytes_per_step() - (0 if run.done_stream else 1) + (2 if fact else 0) - ub
+            # materialised one reads 2 row values (16 B); no done byte.  With observation rows (H = 0): + 8 D written per grid
+            per_launch = L.bytes_per_step() - (0 if run.done_stream else 1) + (2 if fact else 0) - ub + (8 * L.obs_dim if obs_rows else 0)
             launches_per_round = chunk
         launches = rounds * launches_per_round                     # per stream
         per_launch_bytes = per_launch * N                          # one launch on every shard stream = all N grids
@@ -629,9 +927,9 @@ def main():
         achieved = per_launch_bytes / avg_launch_s / 1e9
         wall_launch_s = wall / launches
         ft = "true" if fact else "false"
-        kname = {"fused": f"step_k_kernel<3,4,double,false,{ft}>", "step": "step_kernel<3,false>", "step_python": "step_kernel<3,false>",
+        kname = {"fused": f"step_k_kernel<3,4,double,false,{ft}>", "step": "step_kernel<3,false>", "step_env": "step_kernel<3,false>",
                  "rbc": f"rollout_kernel<3,8,false,false,{ft}>"}[mode]
-        traffic, traffic_src = measured_traffic(kname, n_launch, chunk)
+        traffic, traffic_src = (None, None) if obs_rows else measured_traffic(kname, n_launch, chunk)
         if traffic is not None and sharded:
             traffic *= S
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -645,11 +943,19 @@ def main():
                 "bytes_per_env_step": per_launch / (chunk if mode in ("fused", "rbc") else 1),
                 "launches": launches, "avg_launch_us": avg_launch_s * 1e6, "avg_launch_us_wall": wall_launch_s * 1e6,
                 "timed_rounds": [first, first + rounds]}
+        if mode in ("step", "step_env"):
+            # A single-step launch cannot overlap its predecessor (the next step needs this one's state): it is ONE dependent round
+            # trip behind a launch boundary, not a stream.  Its ceiling is the guide's latency model, not the HBM peak:
+            # t_model = launch boundary (1.5-1.9 us: LAT_FLOOR_US) + bytes / the rate the chip sustains (LAT_STREAM_GBS)
+            model_us = LAT_FLOOR_US + per_launch_bytes / (LAT_STREAM_GBS * 1e3)
+            roof.update({"bound": "latency", "model_us": model_us, "frac_of_latency_model": model_us / (avg_launch_s * 1e6),
+                         "model": f"{LAT_FLOOR_US} us launch boundary + bytes / {LAT_STREAM_GBS / 1e3:.0f} TB/s (MI355X_MICROARCH.md); "
+                                  f"`frac` stays the HBM-peak fraction for comparison with the streaming kernels"})
         if round_us:                                               # the spread inside the timed region (the headline only)
             srt = sorted(round_us)
             roof["round_us"] = {"n": len(srt), "min": srt[0], "median": srt[len(srt) // 2], "max": srt[-1], "mean": sum(srt) / len(srt),
                                 "frac_at_median": per_launch_bytes * launches_per_round / (srt[len(srt) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                "what": "cadence of every launch stream in each round of a SECOND pass of the same length directly behind the "
+                                "what": "cadence of every launch stream in each round of a SECOND pass (<= 256 rounds) directly behind the "
                                         "timed region (a HIP event behind every round on each launch stream: n = streams x rounds samples), "
                                         "rank 0.  The events themselves cost a few us per round (compare `mean` with avg_launch_us of the "
                                         "timed region, which has none): read this block as the SPREAD of the rounds, not as their level"}
@@ -662,7 +968,7 @@ def main():
         if mode == "rbc" and fact:
             roof["note"] = ("with factorised series this kernel reads nothing per step (18.5 B/env-step are its reward / SoC writes): "
                             "it is bound by fp64 VALU issue, not by HBM -- see roofline_valu; the HBM fraction is reported for "
-                            "completeness, the materialised form under other.rbc_rollout_materialised is the bandwidth-bound one")
+                            "completeness, the materialised form is the bandwidth-bound one")
         if mode in ("fused", "rbc"):
             # The issue-side ceiling: cycles the kernel's waves spent EXECUTING vector-ALU instructions (SQ_ACTIVE_INST_VALU x 4:
             # the counter ticks in quad-cycles; summed over the waves of a launch; a committed PMC pass of this command) over the
@@ -685,16 +991,17 @@ def main():
         else:
             roof_valu = None
         run.shard(False)
-        return {"value": n_total * rounds * chunk / wall, "steps": rounds, "warmup": warmup, "ms_per_step": wall / rounds * 1e3,
+        return {"value": n_total * rounds * chunk / wall, "rounds": rounds, "warmup_rounds": warmup, "wall_s": wall,
+                "us_per_env_step": wall / (rounds * chunk) * 1e6, "ms_per_round": wall / rounds * 1e3,
                 "roofline": roof, "roofline_valu": roof_valu, "per_rank_env_steps_per_s": [N * rounds * chunk / w for w in walls]}
 
-    # the headline first (its launch indices in a rocprofv3 trace are then [prewarm + W, prewarm + W + K) per queue)
-    results = {args.mode: measure(args.mode, sharded=args.mode in ("fused", "rbc"), rounds=args.steps, warmup=args.warmup)}
+    # the headline first (its launch indices in a rocprofv3 trace are then [prewarm + W x LPS, prewarm + (W + K) x LPS) per queue)
+    results = {args.mode: measure(args.mode, sharded=args.mode in ("fused", "rbc"), rounds=args.steps * LPS, warmup=args.warmup * LPS,
+                                  spread=True)}
 
     def guarded(what, fn):
-        """The side legs must not take the headline down with them: a failure is reported in the line instead.  With several
-        ranks every rank reports whether it got through (a tiny all-gather after the leg), so no rank is left waiting in a
-        barrier of a leg another rank abandoned: the leg's result is dropped on every rank if any rank failed."""
+        """The side legs must not take the headline down with them: a failure is reported in the record instead.  With several
+        ranks a failure ends the job loudly (barriers inside the leg would hang the other ranks)."""
         err = None
         try:
             out = fn()
@@ -702,16 +1009,26 @@ def main():
             err = f"{type(e).__name__}: {e}"
             print(f"bench.py[rank {rank}]: {what} failed: {err}", file=sys.stderr)
             if world > 1:
-                raise                   # barriers inside the leg would hang the other ranks: fail the job loudly instead
+                raise
             out = None
         return out if err is None else {"error": err}
 
+    side = (min(args.steps * LPS, SIDE_ROUNDS[0]), min(args.warmup * LPS, SIDE_ROUNDS[1]))
     if not args.no_side_modes:
-        side = (min(args.steps, SIDE_ROUNDS[0]), min(args.warmup, SIDE_ROUNDS[1]))
-        for mode in ("fused", "step", "rbc"):
+        # the Gym cadence: single-step launches issued by one C call, and the Gym surface itself from a Python loop
+        if args.mode != "step":
+            results["step"] = guarded("step", lambda: measure("step", False, side[0], side[1]))
+        results["step_env"] = guarded("step_env", lambda: measure("step_env", False, min(side[0], 64), min(side[1], 16), run=env_runner(False)))
+        if not args.no_closed_loop:
+            results["step_env_obs"] = guarded("step_env_obs", lambda: measure("step_env", False, min(side[0], 64), min(side[1], 16),
+                                                                              run=env_runner(True)))
+        for key in ("env", "env_obs"):
+            if key in runs:
+                runs.pop(key).env.close()
+    if not args.no_side_modes and args.all_legs:
+        for mode in ("fused", "rbc"):
             if mode != args.mode:
-                results[mode] = guarded(mode, lambda mode=mode: measure(mode, sharded=mode in ("fused", "rbc"),
-                                                                        rounds=side[0], warmup=side[1]))
+                results[mode] = guarded(mode, lambda mode=mode: measure(mode, True, side[0], side[1]))
         # the other series layout: the fused kernel (as sharded as that layout likes it, and as ONE launch sequence) + the rollout
         if shards_of[args.series] > 1 and args.mode == "fused":      # the headline kernel as ONE launch sequence
             results["fused_one_stream"] = guarded("fused_one_stream", lambda: measure("fused", False, side[0], side[1]))
@@ -720,8 +1037,6 @@ def main():
             results["fused_other_series_one_stream"] = guarded("fused_other_series_one_stream",
                                                                lambda: measure("fused", False, side[0], side[1], other_series))
         results["rbc_other_series"] = guarded("rbc_other_series", lambda: measure("rbc", True, side[0], side[1], other_series))
-        results["step_python"] = guarded("step_python", lambda: measure("step_python", sharded=False, rounds=min(side[0], 32),
-                                                                        warmup=min(side[1], 8)))
         if other_series in runs:       # 14 GB of [T, N] series: free them before the fleet leg
             runs.pop(other_series).eng.close()
             torch.cuda.empty_cache()
@@ -729,198 +1044,25 @@ def main():
     # an agent IN the loop (the fused modes replay pre-staged actions): obs -> a small on-device policy -> env.step -> obs, from
     # Python, observation rows written every step (H = 0: 8 values per grid)
     closed = None
-    if not args.no_side_modes and not args.no_closed_loop:
-        def closed_loop():
-            from pymgrid_amd import BatchedMicrogridEnv
+    if not args.no_side_modes and args.all_legs and not args.no_closed_loop:
+        closed = guarded("closed_loop_policy_gym_steps", lambda: closed_loop_leg(args, n_total, dev, rank, world, mdist))
 
-            def loop(dtype, reuse, light=False, auto_reset=False):
-                b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=args.series)
-                if auto_reset:           # every grid on its own random 168-step episodes, restarted by the step that ends them
-                    from pymgrid_amd.hetero import PerGridWindowEnv
-                    env = PerGridWindowEnv(b, trajectory_length=168, auto_reset=True, seed=3, obs_dtype=dtype, action_dtype=dtype,
-                                           reuse_outputs=reuse)
-                else:
-                    env = BatchedMicrogridEnv(b, obs_dtype=dtype, action_dtype=dtype, reuse_outputs=reuse)
-                g = torch.Generator(device=dev); g.manual_seed(5)
-                A = env.layout.action_dim
-                W = torch.randn(env.layout.obs_dim, A, dtype=dtype, device=dev, generator=g)
-                w = torch.randn(A, dtype=dtype, device=dev, generator=g)
-                # light: a per-feature policy (two elementwise kernels) -- torch's GEMM for a [N, 8] x [8, 3] product takes 23 us in
-                # float64 and 84 us in float32 on this stack, which would hide the env behind the policy
-                policy = (lambda o: torch.sigmoid(o[:, :A] * w)) if light else (lambda o: torch.sigmoid(o @ W))
-                obs = env.reset()
-                n = min(2000, args.rows - 200)
-
-                def timed_loop(fn, sync_ranks):
-                    for _ in range(100):
-                        fn()
-                    if sync_ranks:
-                        mdist.barrier()
-                    torch.cuda.synchronize(dev)
-                    t0 = time.perf_counter()
-                    for _ in range(n):
-                        fn()
-                    torch.cuda.synchronize(dev)
-                    wall = time.perf_counter() - t0
-                    if sync_ranks:
-                        wall = mdist.max_over_ranks(wall, dev)
-                        mdist.barrier()
-                    return wall
-                st = {"obs": obs}
-
-                def both():
-                    st["obs"] = env.step(policy(st["obs"]))[0]
-                wall = timed_loop(both, True)
-                policy_us = timed_loop(lambda: policy(obs), False) / n * 1e6                  # the two torch kernels alone
-                env.reset()
-                a = policy(obs)
-                env_us = timed_loop(lambda: env.step(a), False) / n * 1e6                     # env.step alone (host-paced)
-                env.close()
-                return {"value": n_total * n / wall, "us_per_step": wall / n * 1e6, "steps": n,
-                        "policy_kernels_alone_us": policy_us, "env_step_alone_us": env_us}
-            out = {"float64": loop(torch.float64, 0), "float32_io_rotating_outputs": loop(torch.float32, 4, light=True)}
-            if args.series == "factorised":
-                out["float32_io_auto_reset_168_step_episodes"] = loop(torch.float32, 4, light=True, auto_reset=True)
-            out["loop"] = ("obs [N, 8] -> sigmoid(obs @ W) -> BatchedMicrogridEnv.step (one launch) -> obs, issued from Python: three "
-                           "kernels per env-step (matmul, sigmoid, step), each waiting for the one before -- the env's share is "
-                           "env_step_alone_us.  float32_io: observations and actions cross the boundary as floats (what a policy "
-                           "network consumes / emits; the step itself stays float64), reward and rows in 4 rotating buffers "
-                           "(reuse_outputs), and the policy is sigmoid(obs[:, :A] * w): two elementwise kernels instead of torch's "
-                           "GEMM, which takes 23 us (float64) / 84 us (float32) for this [N, 8] x [8, 3] product.  auto_reset: PerGridWindowEnv -- "
-                           "every grid walks its own random 168-step episodes and is restarted by the step that ends its episode "
-                           "(in-place episodes, mgx_set_auto_reset: still one launch per env-step)")
-            out["value"], out["us_per_step"] = out["float64"]["value"], out["float64"]["us_per_step"]
-            return out
-        closed = guarded("closed_loop_policy_gym_steps", closed_loop)
-
-    # The GENERAL path on the board: 2 gensets + 2 batteries + 1 grid per microgrid (module_container.py:355-413 allows any
-    # multiplicity; such layouts run on the general kernels: columns [n, N], MicrogridStep's lists in LDS).  Single Gym steps and the
-    # K-step launch, each against its own algorithmic bytes (SURVEY 8(d) with per-instance parameter / state counts).
+    # The GENERAL path: 2 gensets + 2 batteries + 1 grid per microgrid (module_container.py:355-413 allows any multiplicity)
     general = None
     if not args.no_side_modes:
-        def general_path():
-            from pymgrid_amd.generator import widen
-            rows_g = min(args.rows, 1200)                   # materialised series [T, n, N]: 1 200 rows are 10 GB at N = 100 000
-            base = generate(n_total, n_steps=rows_g, seed=42, arch="genset+battery+grid", device=dev, rank=rank, world=world)
-            gb = widen(base, n_genset=2, n_battery=2, n_grid=1)
-            del base
-            ge = StepEngine(gb)
-            Lg = ge.layout
-            gen = torch.Generator(device=dev); gen.manual_seed(3 + rank)
-            a1 = torch.rand(N, Lg.action_dim, dtype=torch.float64, device=dev, generator=gen)
-            Kg = min(chunk, 32)
-            aK = torch.rand(Kg, N, Lg.action_dim, dtype=torch.float64, device=dev, generator=gen)
-            out = {}
-            reward1 = torch.empty(N, dtype=torch.float64, device=dev)
-
-            def run(fn, n, per_call_steps):
-                ge.reset(0, want_obs=False)
-                for _ in range(max(8, n // 8)):
-                    fn()
-                ge.reset(0, want_obs=False)
-                mdist.barrier(); torch.cuda.synchronize(dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0 = time.perf_counter(); e0.record()
-                for _ in range(n):
-                    fn()
-                e1.record(); torch.cuda.synchronize(dev)
-                wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
-                gpu = mdist.max_over_ranks(e0.elapsed_time(e1) * 1e-3, dev)
-                mdist.barrier()
-                return wall, gpu, n * per_call_steps
-            n1 = min(400, rows_g - 64)
-            wall, gpu, steps1 = run(lambda: ge.step(a1, want_obs=False, want_log=False, out=dict(reward=reward1), want_done=False), n1, 1)
-            b1 = (Lg.bytes_per_step() - 1) * N              # (no done byte: lock-step)
-            out["single_steps"] = {"value": n_total * steps1 / wall, "us_per_step": gpu / steps1 * 1e6,
-                                   "roofline": {"bound": "hbm", "achieved": b1 / (gpu / steps1) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": b1 / (gpu / steps1) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                                "algorithmic_bytes_per_launch": b1, "kernel": "step_multi_kernel<7>",
-                                                "bytes_per_env_step": Lg.bytes_per_step() - 1}}
-            nK = max(2, min(12, (rows_g - 64) // Kg))
-            wall, gpu, stepsK = run(lambda: ge.step_k(aK, normalized=True, reward=True, soc_trace=False), nK, Kg)
-            # the K-step loop of the general path keeps nothing in registers: every step re-reads parameters and state
-            bK = (Lg.bytes_per_step() - 1) * N
-            out["k_step_launches"] = {"value": n_total * stepsK / wall, "us_per_step": gpu / stepsK * 1e6, "steps_per_launch": Kg,
-                                      "roofline": {"bound": "hbm", "achieved": bK / (gpu / stepsK) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                   "frac": bK / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                                   "algorithmic_bytes_per_launch": bK * Kg, "kernel": "step_k_multi_kernel<7>",
-                                                   "bytes_per_env_step": Lg.bytes_per_step() - 1,
-                                                   "note": "a K-step loop around the general step: parameters and state are re-read "
-                                                           "every step (cache hits), charged per step like the single launches"}}
-            out["layout"] = "2 gensets + 2 batteries + 1 grid + load + pv per microgrid (general kernels), materialised series"
-            out["grids_per_gpu"], out["rows"] = N, rows_g
-            ge.close()
-            del ge, gb
-            torch.cuda.empty_cache()
-            # Gym steps with whole observation rows (H = 24): rings refilled by the general window kernel (obs_windows_k_multi_kernel;
-            # the step adds its 12 state columns) -- per-step rows by one lane per grid were 261 us (profiles/r04/exp_multi_rings.txt)
-            from pymgrid_amd import BatchedMicrogridEnv
-            rows_o = min(args.rows, 600)
-            base = generate(n_total, n_steps=rows_o, seed=42, arch="genset+battery+grid", horizon=24, device=dev, rank=rank, world=world)
-            env = BatchedMicrogridEnv(widen(base, n_genset=2, n_battery=2, n_grid=1), obs_prefetch=32, reuse_outputs=96)
-            del base
-            Lo = env.layout
-            ao = torch.rand(N, Lo.action_dim, dtype=torch.float64, device=dev, generator=gen)
-            env.reset()
-            for _ in range(40):
-                env.step(ao)
-            mdist.barrier(); torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            no = rows_o - 24 - 40 - 8
-            t0 = time.perf_counter(); e0.record()
-            for _ in range(no):
-                env.step(ao)
-            e1.record(); torch.cuda.synchronize(dev)
-            wall = mdist.max_over_ranks(time.perf_counter() - t0, dev)
-            gpu = mdist.max_over_ranks(e0.elapsed_time(e1) * 1e-3, dev)
-            bo = (Lo.bytes_per_step() - 1 + 8 * Lo.obs_dim) * N
-            out["gym_steps_rows_h24"] = {"value": n_total * no / wall, "us_per_step": gpu / no * 1e6, "ring_depth": 32, "obs_dim": Lo.obs_dim,
-                                         "roofline": {"bound": "hbm", "achieved": bo / (gpu / no) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                      "frac": bo / (gpu / no) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                                      "algorithmic_bytes_per_launch": bo, "kernel": "step_multi_kernel<7> + obs_windows_k_multi_kernel<7, double>",
-                                                      "bytes_per_env_step": bo // N}}
-            env.close()
-            return out
-        general = guarded("general_path_2g2b1grid", general_path)
-        torch.cuda.empty_cache()
-
-    # The resident step server (mgx_server_*): Gym steps WITHOUT a launch per step, controls through a device mailbox.  Reported
-    # because it was asked for and measured; it LOSES to the launches (the per-step cache maintenance of a resident kernel costs
-    # more than the launch it saves: DESIGN.md, profiles/r04/exp_step_server*.txt).
-    server = None
-    if not args.no_side_modes and args.arch == "genset+battery":
-        def step_server():
-            b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=args.series)
-            e = StepEngine(b, obs_dtype=torch.float32, action_dtype=torch.float32)
-            steps, R = min(2000, args.rows - 100), 8
-            slots = e.server_start(n_slots=R, max_steps=steps, want_obs=True, immediate=True, idle_timeout_ms=500)
-            for sl in slots:
-                sl["actions"].uniform_()
-            cs = torch.cuda.current_stream(dev)
-            cs.synchronize()
-            t0 = time.perf_counter()
-            for k0 in range(0, steps, R):
-                for _ in range(min(R, steps - k0)):
-                    e.server_post()
-                e.server_wait()
-            cs.synchronize()
-            wall = time.perf_counter() - t0
-            served = e.server_stop()
-            e.close()
-            return {"value": n_total * served / mdist.max_over_ranks(wall, dev), "us_per_step": wall / max(served, 1) * 1e6, "steps": served,
-                    "what": "env.step ALONE through the resident server: float32 controls already on the device, steps released by host "
-                            "stores in bursts of 8 (one hipStreamWaitValue32 per burst), float32 observation rows + rewards written per step"}
-        server = guarded("resident_step_server", step_server)
+        general = guarded("general_path_2g2b1grid", lambda: general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist))
         torch.cuda.empty_cache()
 
     hetero = None
     if args.hetero_steps > 0:
         hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist, args.rows,
-                                                                          args.series, args.series == "factorised" and args.uniform_columns))
+                                                                          args.series, args.series == "factorised" and args.uniform_columns,
+                                                                          all_legs=args.all_legs))
 
     # metrics vector: episode-return sum + mean SoC, all-reduced over ranks (the ONLY collective; RCCL over xGMI)
-    sums = eng.metrics(torch.stack([run.outs[0]["reward"][-1], batch.cols["soc"]]))
-    sums = mdist.all_reduce_metrics(sums)     # bounded: RCCL raising or hanging ends in a reported gloo fallback, not in a lost line
+    local_sums = eng.metrics(torch.stack([run.outs[0]["reward"][-1], batch.cols["soc"]]))
+    per_rank_sums = mdist.gather_over_ranks(float(local_sums[0]), dev)
+    sums = mdist.all_reduce_metrics(local_sums.clone())     # bounded: RCCL raising or hanging ends in a reported gloo fallback, not in a lost line
     mdist.barrier()
 
     cpu = None
@@ -938,47 +1080,57 @@ def main():
                  "fused_one_stream": "fused_launches_one_stream",
                  "fused_other_series": f"fused_launches_{other_series}",
                  "fused_other_series_one_stream": f"fused_launches_{other_series}_one_stream",
-                 "rbc_other_series": f"rbc_rollout_{other_series}", "step_python": "single_step_launches_python_loop"}
+                 "rbc_other_series": f"rbc_rollout_{other_series}", "step_env": "single_step_launches_python_loop",
+                 "step_env_obs": "single_step_launches_python_loop_with_rows"}
         backend = None
         if world > 1:
             import torch.distributed as dist
             backend = dist.get_backend()
-        line = {
+        wall_steps = main_r["wall_s"]
+        rf = main_r["roofline"]
+        head = {
             "metric": "microgrid env-steps/sec", "value": main_r["value"], "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_r["ms_per_step"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_steps / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{N} generated 4-module grids (genset+battery+load+pv) per GPU, T={args.rows}, "
-                                   f"H=0, normalised random actions (BASELINE configs[2])",
-                       "step": f"one round = {chunk} consecutive env-steps of all grids of a rank",
-                       "env_steps_per_step": chunk, "grids_per_gpu": N, "grids_total": n_total, "mode": args.mode,
-                       "steps_per_launch": 1 if args.mode == "step" else chunk,
-                       "uniform_parameter_columns": batch.uniform_columns(),
-                       "series": args.series + (" (base profile id + ratio per grid; the product is formed in the kernel, "
-                                                "bit-identical to the [T, N] arrays)" if args.series == "factorised" else
-                                                " ([T, N] float64 arrays)"),
-                       "outputs": "reward + SoC per grid and step" + ("" if args.mode == "step" else " (streamed [K, N])")
-                                  + "; done is derived from the step counter (lock-step: the same for every grid), not streamed",
+            "config": {"workload": f"{N} generated 4-module grids (genset+battery+load+pv) per GPU, T={args.rows}, H=0, "
+                                   f"normalised random actions (BASELINE configs[2])",
+                       "env_steps_per_step": chunk * LPS, "steps_per_launch": 1 if args.mode == "step" else chunk,
+                       "grids_per_gpu": N, "grids_total": n_total, "mode": args.mode, "series": args.series,
                        "parallelism": f"grids sharded x{world} ranks, no data-path collective"
-                                      + (f"; {S} grid ranges per GPU on {S} internal HIP streams" if S > 1 else ""),
-                       "prewarm_seconds_per_mode": args.prewarm, "world_size": world, "backend": backend},
-            "roofline": main_r["roofline"],
-            "roofline_valu": main_r.get("roofline_valu"),
-            "csrc_hash": CSRC_HASH,
-            "cpu_baseline": cpu,
+                                      + (f"; {S} shard streams per GPU" if S > 1 else ""),
+                       "backend": backend},
+        }
+        detail = dict(head)
+        detail["config"] = dict(head["config"], **{
+            "step": f"one bench step = {LPS} rounds of {chunk} consecutive env-steps of all grids of a rank",
+            "uniform_parameter_columns": batch.uniform_columns(),
+            "series_note": ("base profile id + ratio per grid; the product is formed in the kernel, bit-identical to the [T, N] arrays"
+                            if args.series == "factorised" else "[T, N] float64 arrays"),
+            "outputs": "reward + SoC per grid and step" + ("" if args.mode == "step" else " (streamed [K, N])")
+                       + "; done is derived from the step counter (lock-step: the same for every grid), not streamed",
+            "prewarm_seconds_per_mode": args.prewarm, "world_size": world})
+        detail.update({
+            "roofline": rf, "roofline_valu": main_r.get("roofline_valu"), "csrc_hash": CSRC_HASH, "cpu_baseline": cpu,
             "per_rank_env_steps_per_s": main_r["per_rank_env_steps_per_s"],
-            "other": {names[m]: (r if "error" in r else {k: r[k] for k in ("value", "steps", "warmup", "ms_per_step", "roofline", "roofline_valu")})
-                      for m, r in results.items() if m != args.mode},
+            "other": {names[m]: r for m, r in results.items() if m != args.mode},
             "metrics_allreduce": {"sum_last_reward": float(sums[0]), "mean_soc": float(sums[1]) / n_total,
+                                  "per_rank_sum_last_reward": per_rank_sums,
                                   "collective_backend": mdist.last_collective["backend"], "collective_error": mdist.last_collective["error"],
                                   "collective_hung": mdist.last_collective.get("hung", False)},
-            "closed_loop_policy_gym_steps": closed,
-            "hetero_h24_gym_steps": hetero,
-            "general_path_2g2b1grid": general,
-            "resident_step_server": server,
-            "prewarm_seconds_per_mode": args.prewarm,
-            "device_state_under_load": device_state or None,
-        }
-        print(json.dumps(line), flush=True)
+            "closed_loop_policy_gym_steps": closed, "hetero_h24_gym_steps": hetero, "general_path_2g2b1grid": general,
+            "device_state_under_load": device_state or None})
+
+        detail["leg_names"] = names
+        text = compact_line(detail, args.mode, os.path.basename(args.detail) if args.detail else None)
+        dtext = json.dumps(detail)
+        if args.detail:
+            try:
+                with open(args.detail, "w") as fh:
+                    fh.write(dtext + "\n")
+            except OSError as e:
+                print(f"bench.py: could not write {args.detail}: {e}", file=sys.stderr)
+        print("bench_detail " + dtext, file=sys.stderr, flush=True)
+        print(text, flush=True)
     if world > 1:
         import torch.distributed as dist
         mdist.barrier()                 # (control plane: gloo; a dead rank is named after MGX_CTRL_TIMEOUT_S instead of hanging RCCL)

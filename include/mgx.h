@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 7
+#define MGX_ABI_VERSION 8
 
 enum mgx_status {
     MGX_OK = 0,
@@ -357,7 +357,7 @@ int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream)
 int mgx_set_ring_pitch(mgx_handle *h, int32_t rows);
 /* Layout of a ring BLOCK.  MGX_RING_ROWS (default): [P, D] row-major -- a grid's observation is D consecutive values, the
  * reference's flat vector (envs/base/base.py:211-223).  MGX_RING_COLUMNS: [D, P] -- value (grid i, column c) at c * P + i, P = the
- * ring pitch (mgx_set_ring_pitch; a multiple of 16): the SAME [N, D] matrix read with strides (1, P), which is what a policy's
+ * ring pitch (mgx_set_ring_pitch; a multiple of 32: whole 128-byte lines per 32 float / 16 double grids): the SAME [N, D] matrix read with strides (1, P), which is what a policy's
  * first matrix product takes either way.  Why: in a row-major block the step's state columns are 48 bytes at a 8 D-byte stride --
  * 100 000 scattered partial lines per step, 3.5-4 us of a 24-us config-5 fleet step (profiles/r04/exp_fleet_state_patch_cost.txt) --
  * in a column-major block they are six coalesced runs of 8 N bytes.  Applies to mgx_observe_windows[_ahead], the fleets' refills and
@@ -378,15 +378,6 @@ int mgx_patch_windows(mgx_handle *h, const uint8_t *mask, int32_t K, void *ring,
  * S = 4 * has_genset + 2 * has_battery (the zero-copy observation contract: the window columns are views of the normalised
  * series written once by mgx_normalise_series). */
 int mgx_set_obs_mode(mgx_handle *h, int32_t mode);
-
-/* Step + observation row in ONE launch, for factorised series (enable != 0): with whole rows wanted for a forecast horizon
- * (MGX_OBS_ROWS_FULL, horizon > 0), mgx_step / mgx_step_discrete / mgx_step_many / mgx_fleet_step form the window values of
- * every row from the cache-resident base tables inside the stepping launch and write each row once, by whole lines -- no
- * obs_rows kernel behind the step, no rings.  Lock-step episodes only (per-grid windows keep the two-kernel path).  Same bits.
- * One launch instead of two is what small batches want; at N = 100 000 the launch is latency-bound (and normalises every value
- * of every row at every step, where a ring refill normalises a series value once) and the prefetched rings
- * (mgx_observe_windows_ahead) are twice as fast -- hence off by default.  MGX_ERR_UNSUPPORTED for materialised series or several modules of a kind. */
-int mgx_set_rows_direct(mgx_handle *h, int enable);
 
 /* `done` of the fused calls.  MGX_DONE_U8 (default): one byte per grid and step, [K, N].  MGX_DONE_BITS: a bit set per step,
  * [K, W] uint16 words with W = ceil(N / 16), bit (i & 15) of word i >> 4 = done of grid i (little-endian: the row is a
@@ -502,34 +493,42 @@ int mgx_check_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *t
 int mgx_step_many(mgx_handle *h, const void *actions, int32_t K, int normalized,
                   double *reward, uint8_t *done, void *obs, double *log, mgx_stream stream);
 
-/* Resident step server: the Gym cadence (one Microgrid.run per call, `while not done: env.step(a)`, README.md:109-111,
- * envs/base/base.py:169-209) WITHOUT a kernel launch per env-step.  mgx_server_start puts ONE kernel on the device that stays
- * there for a burst of up to max_steps steps: every grid's parameters and dynamic state live in registers, step k reads its
- * controls from slot k % n_slots of a ring of caller-owned buffers and leaves reward / done / observation in the same slot.
- *   mgx_server_post(h, s)   releases the next step once stream s reaches this point: a stream memory operation behind the
- *                           kernel that wrote the controls (no launch) -- or, started with immediate != 0 (controls already on
- *                           the device / written by a kernel the caller orders itself), a plain store of the host: free
- *   mgx_server_wait(h, s)   stream s waits (hipStreamWaitValue32) until every step posted so far has been taken by every grid
- *   mgx_server_stop(h, &n)  finishes the posted steps, ends the kernel, writes the state columns back, moves the step counter
- *                           by the n steps taken; MGX_ERR_RANGE when the burst ended early (idle timeout) with posts not served
- * The caller must not post step k + n_slots before it has consumed slot k % n_slots (the server does not check), and must not
- * call anything else on the handle -- nor synchronise the whole device -- between start and stop: the kernel ends by itself
- * idle_timeout_ms after the last activity (and after 60 s at the latest), so a stray hipDeviceSynchronize is a delay, never a
- * hang.  Observations: whole rows without a forecast horizon, or the state columns (MGX_OBS_ROWS_STATE_ONLY / _COMPACT).
- * Lock-step episodes, one module of every kind per grid, all workgroups resident (N up to ~400 000): else MGX_ERR_UNSUPPORTED.
- * Values are those of mgx_step, bit for bit.  (What it buys and what it does not: DESIGN.md section 2, "Resident step server".) */
-typedef struct mgx_server_slot {
-    const void *actions;          /* [N, A] controls (the handle's action format) */
+/* The Gym step with NO per-step bookkeeping on the caller's side (`while not done: obs, r, done, info = env.step(a)`,
+ * README.md:109-111, envs/discrete/discrete.py:109-143, envs/base/base.py:169-209).  A single-step kernel takes ~5 us at
+ * N = 100 000, so whatever the host does between two launches -- choosing the output buffers, walking the observation rings,
+ * issuing the next ring's prefetch -- is part of the env-step's time when it is done in an interpreter.  mgx_env_bind hands the
+ * handle everything that rotates, once; mgx_env_step / mgx_env_step_discrete then take the controls and a stream and do the rest:
+ *   outputs   step j (counted from the bind / the last mgx_env_seek) writes reward / done / log -- and, without rings, the
+ *             observation row -- into slots[j % n_slots]: n_slots rotating buffer sets, each valid until the step n_slots later;
+ *   rings     ring_K > 0 (the handle in MGX_OBS_ROWS_STATE_ONLY mode): three rings of ring_K row blocks written ahead by
+ *             mgx_observe_windows[_ahead].  The env stands on block `ring_pos` of ring `ring_idx`; a step adds its state columns to
+ *             the NEXT block (the observation it returns), moves there, and when that enters the following ring it first waits for
+ *             that ring's prefetch (mgx_prefetch_wait) and afterwards starts the prefetch of the ring behind it
+ *             (mgx_observe_windows_ahead(ahead = ring_K)): exactly the sequence pymgrid_amd/envs.py used to issue call by call.
+ * Values are those of mgx_step / mgx_step_discrete, bit for bit (tests/test_env_step.py).  mgx_env_seek tells the handle where
+ * the caller stands after anything that moved the rings or the slot outside these calls (mgx_reset + mgx_observe_windows: block 0
+ * of ring 0); mgx_env_position reports where the LAST step's outputs are.  Slot and ring pointers are caller-owned device memory. */
+typedef struct mgx_env_slot {
     double *reward;               /* [N] */
-    uint8_t *done;                /* [N] or NULL */
-    void *obs;                    /* [N, D] rows (horizon 0), [N, S] compact state, or NULL */
-} mgx_server_slot;
-#define MGX_SERVER_MAX_SLOTS 8
-int mgx_server_start(mgx_handle *h, const mgx_server_slot *slots, int32_t n_slots, int normalized, int32_t max_steps,
-                     int32_t idle_timeout_ms, int immediate, mgx_stream stream);
-int mgx_server_post(mgx_handle *h, mgx_stream stream);
-int mgx_server_wait(mgx_handle *h, mgx_stream stream);
-int mgx_server_stop(mgx_handle *h, int32_t *steps_done);
+    uint8_t *done;                /* [N] or NULL (lock-step: derive it from the counter) */
+    void *obs;                    /* [N, D] row target of the step (NULL with rings, or when no observation is wanted) */
+    double *log;                  /* [L, N] or NULL */
+} mgx_env_slot;
+#define MGX_ENV_MAX_SLOTS 128
+typedef struct mgx_env_plan {
+    int32_t struct_size;          /* = sizeof(mgx_env_plan) */
+    int32_t n_slots;              /* 1 .. MGX_ENV_MAX_SLOTS */
+    const mgx_env_slot *slots;    /* host array [n_slots]; copied */
+    int32_t ring_K;               /* 0: no rings */
+    int32_t n_actions;            /* discrete: rows of `table` (0: continuous steps only) */
+    void *rings[3];               /* ring r = [ring_K] blocks, the handle's ring pitch / layout (mgx_set_ring_pitch / _layout) */
+    const int32_t *table;         /* host [n_actions, 3, 2] (mgx_expand_discrete); copied */
+} mgx_env_plan;
+int mgx_env_bind(mgx_handle *h, const mgx_env_plan *plan);           /* plan == NULL: unbind */
+int mgx_env_seek(mgx_handle *h, int32_t next_slot, int32_t ring_idx, int32_t ring_pos);
+int mgx_env_position(const mgx_handle *h, int32_t *last_slot, int32_t *ring_idx, int32_t *ring_pos);   /* each may be NULL */
+int mgx_env_step(mgx_handle *h, const void *actions, int normalized, mgx_stream stream);
+int mgx_env_step_discrete(mgx_handle *h, const int32_t *action_id, mgx_stream stream);
 
 /* Shards.  Grids never interact (no cross-grid term anywhere in Microgrid.run), so the launch sequence of one range of
  * grids owes nothing to another's.  mgx_set_shards(h, S > 1) splits every stepping call (mgx_step, mgx_step_many,

@@ -25,7 +25,7 @@ V_GENSET_RANGE, V_BATTERY_LIMIT, V_GRID_LIMIT, V_GENSET_GOAL, V_GENSET_NEGATIVE,
 V_EXPAND_CONSUME, V_EXPAND_PRODUCE, V_EXPAND_SIGN = 64, 128, 256
 V_EXPAND = V_EXPAND_CONSUME | V_EXPAND_PRODUCE | V_EXPAND_SIGN      # states in which _populate_action asserts
 V_ASSERTS = V_GENSET_GOAL | V_GENSET_NEGATIVE | V_NEGATIVE_LIMIT | V_EXPAND    # the reference raises whatever raise_errors says
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_INSTANCES = 8          # MGX_MAX_INSTANCES: gensets / batteries / grids per microgrid
 
 
@@ -115,12 +115,19 @@ class Gen(C.Structure):
                                              "d_outage_normal", "d_size_load", "d_pv_pen", "d_bat_hours", "d_su", "d_wd")])
 
 
-class ServerSlot(C.Structure):
-    """mgx_server_slot (include/mgx.h): one slot of the resident step server's buffer ring."""
-    _fields_ = [("actions", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("obs", C.c_void_p)]
+class EnvSlot(C.Structure):
+    """mgx_env_slot (include/mgx.h): one set of rotating output buffers of ``mgx_env_step``."""
+    _fields_ = [("reward", C.c_void_p), ("done", C.c_void_p), ("obs", C.c_void_p), ("log", C.c_void_p)]
 
 
-SERVER_MAX_SLOTS = 8       # MGX_SERVER_MAX_SLOTS
+ENV_MAX_SLOTS = 128        # MGX_ENV_MAX_SLOTS
+
+
+class EnvPlan(C.Structure):
+    """mgx_env_plan (include/mgx.h): what ``mgx_env_bind`` takes."""
+    _fields_ = [("struct_size", C.c_int32), ("n_slots", C.c_int32), ("slots", C.POINTER(EnvSlot)), ("ring_K", C.c_int32),
+                ("n_actions", C.c_int32), ("rings", C.c_void_p * 3), ("table", c_i32_p)]
+
 
 # every symbol include/mgx.h declares: (restype, argtypes)
 SYMBOLS = {
@@ -140,7 +147,6 @@ SYMBOLS = {
     "mgx_set_obs_format": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_set_obs_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_set_done_format": (C.c_int, [C.c_void_p, C.c_int32]),
-    "mgx_set_rows_direct": (C.c_int, [C.c_void_p, C.c_int]),
     "mgx_normalise_series": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_set_action_format": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_observe_windows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -175,6 +181,11 @@ SYMBOLS = {
     "mgx_check_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mgx_step_many": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
+    "mgx_env_bind": (C.c_int, [C.c_void_p, C.POINTER(EnvPlan)]),
+    "mgx_env_seek": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "mgx_env_position": (C.c_int, [C.c_void_p, c_i32_p, c_i32_p, c_i32_p]),
+    "mgx_env_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mgx_env_step_discrete": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_set_shards": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_fork": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgx_join": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -182,10 +193,6 @@ SYMBOLS = {
     "mgx_fleet_step": (C.c_int, [C.POINTER(FleetItem), C.c_int32, C.c_int, C.c_void_p]),
     "mgx_synthesize_series": (C.c_int, [C.POINTER(Synth), C.c_void_p]),
     "mgx_generate_columns": (C.c_int, [C.POINTER(Gen), C.c_void_p]),
-    "mgx_server_start": (C.c_int, [C.c_void_p, C.POINTER(ServerSlot), C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
-    "mgx_server_post": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "mgx_server_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "mgx_server_stop": (C.c_int, [C.c_void_p, c_i32_p]),
 }
 
 
@@ -218,12 +225,14 @@ def up_to_date(lib_path=None):
     return os.path.exists(path) and built_hash(path) == source_hash()
 
 
-def build(force=False, verbose=False, defs=(), lib_path=None):
+def build(force=False, verbose=False, defs=(), lib_path=None, abi_only=False):
     """Compile csrc/*.hip for gfx950 into pymgrid_amd/libmgx.so (hipcc cross-compiles without a GPU).
     ``defs`` / ``lib_path``: an A/B variant of the kernels (extra -D flags, e.g. ("-DMGX_RING=8",)) built beside the product
     library; load it with MGX_LIB=<lib_path>."""
     if lib_path is not None or defs:
-        return _build(lib_path or LIB_PATH, list(defs), verbose, os.path.basename(lib_path or "variant") + ".o")
+        # abi_only: the variant's flags only concern kernels of mgx_abi.hip (everything but the K-step loops): compile that unit
+        # alone and link it with the product build's mgx_fused objects
+        return _build(lib_path or LIB_PATH, list(defs), verbose, os.path.basename(lib_path or "variant") + ".o", abi_only=abi_only)
     if os.environ.get("MGX_LIB") and os.path.exists(LIB_PATH) and not force:
         return LIB_PATH                              # an A/B variant named by the caller: loaded as it is, never rebuilt in place
     if not force and up_to_date(LIB_PATH):
@@ -231,7 +240,7 @@ def build(force=False, verbose=False, defs=(), lib_path=None):
     return _build(LIB_PATH, [], verbose, "", force)
 
 
-def _build(LIB_PATH, extra_defs, verbose, objtag, force=True):
+def _build(LIB_PATH, extra_defs, verbose, objtag, force=True, abi_only=False):
     # several ranks may get here at once (torchrun): serialise on a lock file, compile to a temporary name and
     # rename atomically so that nobody ever dlopens a half-written library
     import fcntl
@@ -248,6 +257,12 @@ def _build(LIB_PATH, extra_defs, verbose, objtag, force=True):
             # translation units: the host side + small kernels, and the slices of the K-step kernels -- compiled in parallel
             units = [(SOURCES[0], [], os.path.join(objdir, "mgx_abi.o"))] + \
                     [(SOURCES[1], [f"-DMGX_FUSED_PART={p}"], os.path.join(objdir, f"mgx_fused_{p}.o")) for p in range(FUSED_PARTS)]
+            if abi_only:
+                base = os.path.join(_PKG, "csrc", "_build")
+                fused = [os.path.join(base, f"mgx_fused_{p}.o") for p in range(FUSED_PARTS)]
+                if not all(os.path.exists(f) for f in fused):
+                    raise FileNotFoundError("abi_only variants link the product build's mgx_fused objects: build() first")
+                units = units[:1]
             procs = []
             for src, defs, obj in units:
                 # -Rpass-analysis=kernel-resource-usage: the backend's per-kernel register / scratch figures as remarks (free):
@@ -272,7 +287,7 @@ def _build(LIB_PATH, extra_defs, verbose, objtag, force=True):
                     sys.stderr.write(rest + "\n")
             with open(os.path.join(objdir, "resource_usage.json"), "w") as fh:
                 json.dump(usage, fh, indent=0, sort_keys=True)
-            link = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + [obj for _, _, obj in units] + ["-o", tmp]
+            link = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + [obj for _, _, obj in units] + (fused if abi_only else []) + ["-o", tmp]
             if verbose:
                 print(" ".join(link))
             subprocess.run(link, check=True)

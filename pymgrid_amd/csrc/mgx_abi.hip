@@ -49,18 +49,14 @@ struct mgx_handle {
     PLWords *d_table;                        // device copy of the priority-list table of a discrete fleet item
     PLWords table_uploaded;
     bool table_uploaded_valid;
+    // mgx_env_bind: the rotating outputs / observation rings of a Gym loop, walked by mgx_env_step itself
+    bool env_bound;
+    int32_t env_n_slots, env_next, env_ring_K, env_ring_idx, env_ring_pos, env_n_actions;
+    mgx_env_slot env_slots[MGX_ENV_MAX_SLOTS];
+    char *env_rings[3];
+    int32_t env_table[12 * 3 * 2];
     hipStream_t prefetch_stream;             // mgx_observe_windows_ahead: the window prefetch overlaps the steps
     bool prefetch_pooled;                    // ... on the per-device pooled stream (MGX_PREFETCH_POOL): not destroyed with the handle
-    bool rows_direct;                        // mgx_set_rows_direct: step + whole observation row in one launch (fleet_rows_kernel)
-    // resident step server (mgx_server_*)
-    bool server_running, server_immediate;
-    ServerCtl *server_ctl;                   // device
-    ServerHostWords *server_host;            // pinned + mapped
-    uint32_t *server_signal;                 // signal memory
-    hipStream_t server_stream;
-    hipEvent_t server_gate;
-    uint32_t server_posted;
-    int32_t server_max_steps;
     hipEvent_t prefetch_gate, prefetch_done;
     bool prefetch_pending;
     // per-grid episode windows (mgx_reset_windows): the full series are remembered here while the handle steps over the
@@ -252,17 +248,6 @@ static void launch_windows_multi_kernel(const KArgs &k, const WindowsKPlan &plan
     obs_windows_k_multi_kernel<F, OT><<<blocks, OBS_K_THREADS, lds, st>>>(k, plan, t, (OT *)ring);
 }
 
-// resident step server: every workgroup must be on the chip at once (occupancy query), then one launch on the server stream
-template <int F>
-static hipError_t launch_server(const mgx_handle *h, const ServerArgs &sv, unsigned blocks, int *resident_per_cu)
-{
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_per_cu, (const void *)step_server_kernel<F>, BLOCK, 0);
-    if (e != hipSuccess) return e;
-    if ((int64_t)*resident_per_cu * (h->n_cu > 0 ? h->n_cu : 1) < (int64_t)blocks) return hipErrorLaunchOutOfResources;
-    step_server_kernel<F><<<blocks, BLOCK, 0, h->server_stream>>>(h->k, sv, h->t);
-    return hipGetLastError();
-}
-
 static inline unsigned multi_blocks(int64_t n) { return (unsigned)((n + BLOCK_MULTI - 1) / BLOCK_MULTI); }
 
 // observation of the state at series index t into obs [N, D]
@@ -409,11 +394,9 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     { const char *e = getenv("MGX_FORK_STAGGER_US"); h->stagger_us = e ? atof(e) : 0.0; }
     h->d_kargs = nullptr; h->k_uploaded_valid = false;
     h->d_table = nullptr; h->table_uploaded_valid = false;
+    h->env_bound = false; h->env_n_slots = 0; h->env_next = 0; h->env_ring_K = 0; h->env_ring_idx = 0; h->env_ring_pos = 0; h->env_n_actions = 0;
     h->prefetch_stream = nullptr; h->prefetch_gate = nullptr; h->prefetch_done = nullptr; h->prefetch_pending = false;
     h->prefetch_pooled = false;
-    h->rows_direct = false;
-    h->server_running = false; h->server_immediate = false; h->server_ctl = nullptr; h->server_host = nullptr; h->server_signal = nullptr;
-    h->server_stream = nullptr; h->server_gate = nullptr; h->server_posted = 0; h->server_max_steps = 0;
     h->windowed = false; h->rolling = false;
     h->k.row_mask = -1;
     h->k.ep_off = nullptr; h->k.ep_final = nullptr; h->k.ar_mode = 0; h->k.ar_fixed_length = 0; h->k.ar_lo = 0; h->k.ar_hi = 0;
@@ -437,12 +420,6 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
 void mgx_destroy(mgx_handle *h)
 {
     if (!h) return;
-    if (h->server_running) { int32_t n; (void)mgx_server_stop(h, &n); }
-    if (h->server_stream) { (void)hipStreamSynchronize(h->server_stream); (void)hipStreamDestroy(h->server_stream); }
-    if (h->server_gate) (void)hipEventDestroy(h->server_gate);
-    if (h->server_ctl) (void)hipFree(h->server_ctl);
-    if (h->server_signal) (void)hipFree(h->server_signal);
-    if (h->server_host) (void)hipHostFree(h->server_host);
     for (int j = 0; j < MGX_MAX_SHARDS; j++) {
         if (h->shard_stream[j]) (void)hipStreamSynchronize(h->shard_stream[j]);      // (pooled: not destroyed with the handle)
         if (h->shard_event[j]) (void)hipEventDestroy(h->shard_event[j]);
@@ -549,17 +526,6 @@ int mgx_set_obs_mode(mgx_handle *h, int32_t mode)
     if (mode == MGX_OBS_ROWS_STATE_COMPACT && h->multi)
         return fail(MGX_ERR_UNSUPPORTED, "mgx_set_obs_mode: compact state rows need exactly one module of every kind per grid");
     h->k.obs_state_only = mode == MGX_OBS_ROWS_STATE_ONLY ? 1 : (mode == MGX_OBS_ROWS_STATE_COMPACT ? 2 : 0);
-    return MGX_OK;
-}
-
-int mgx_set_rows_direct(mgx_handle *h, int enable)
-{
-    g_err[0] = 0;
-    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_rows_direct: NULL handle");
-    if (enable && (h->multi || !factorised(h->full_c)))
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_set_rows_direct: needs factorised series and one module of every kind per grid (the "
-                                         "window values are formed from cache-resident base tables)");
-    h->rows_direct = enable != 0;
     return MGX_OK;
 }
 
@@ -703,7 +669,7 @@ int mgx_set_ring_pitch(mgx_handle *h, int32_t rows)
     g_err[0] = 0;
     if (!h) return fail(MGX_ERR_INVALID, "mgx_set_ring_pitch: NULL handle");
     if (rows < h->k.N) return fail(MGX_ERR_INVALID, "mgx_set_ring_pitch: %d rows per block, the batch has %d grids", rows, h->k.N);
-    if (h->k.obs_colpitch && rows % 16) return fail(MGX_ERR_INVALID, "mgx_set_ring_pitch: column-major blocks need a pitch that is a multiple of 16");
+    if (h->k.obs_colpitch && rows % 32) return fail(MGX_ERR_INVALID, "mgx_set_ring_pitch: column-major blocks need a pitch that is a multiple of 32");
     h->ring_pitch = rows;
     if (h->k.obs_colpitch) h->k.obs_colpitch = rows;
     return MGX_OK;
@@ -718,7 +684,9 @@ int mgx_set_ring_layout(mgx_handle *h, int32_t layout)
         if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_set_ring_layout: needs exactly one module of every kind per grid");
         if (h->windowed || h->rolling || h->inplace)
             return fail(MGX_ERR_UNSUPPORTED, "mgx_set_ring_layout: column-major blocks are offered for lock-step episodes (restarts patch row-major rings)");
-        if (h->ring_pitch % 16) return fail(MGX_ERR_INVALID, "mgx_set_ring_layout: the ring pitch (%d) must be a multiple of 16 first (mgx_set_ring_pitch)", h->ring_pitch);
+        // 32 grids = one 128-byte line of a float column (16 of a double column): every (block, column) run of a refill workgroup is
+        // then whole lines in either observation format
+        if (h->ring_pitch % 32) return fail(MGX_ERR_INVALID, "mgx_set_ring_layout: the ring pitch (%d) must be a multiple of 32 first (mgx_set_ring_pitch)", h->ring_pitch);
     }
     h->k.obs_colpitch = layout == MGX_RING_COLUMNS ? h->ring_pitch : 0;
     return MGX_OK;
@@ -893,7 +861,6 @@ int mgx_reset(mgx_handle *h, int32_t initial_step, void *obs, mgx_stream stream)
 {
     g_err[0] = 0;
     if (!h) return fail(MGX_ERR_INVALID, "mgx_reset: NULL handle");
-    if (h->server_running) return fail(MGX_ERR_INVALID, "mgx_reset: the resident step server owns the state (mgx_server_stop first)");
     leave_windows(h);
     const int32_t t0 = initial_step >= 0 ? initial_step : h->layout.initial_step;
     if (t0 >= h->layout.final_step)
@@ -1289,77 +1256,6 @@ static int episode_step_end(mgx_handle *h, const EpisodeStep &ep, const uint8_t 
     return launch_observe(h, h->t + 1, obs, st);
 }
 
-// ---- step + observation row in one launch (factorised series; fleet_rows_kernel) --------------------------------------
-// Possible when whole rows are wanted for a forecast horizon and every window value can be formed from cache-resident base
-// tables: lock-step stepping of a factorised batch with one module of every kind, no forecast noise.  OFF unless the handle asks
-// for it (mgx_set_rows_direct): bit-identical rows (tests/test_direct_rows.py), one launch instead of two -- but at N = 100 000 it
-// takes 55-61 us per config-5 fleet step against 24-28 us on rings: a latency-bound kernel (21 us fixed + 25 us window values +
-// 12 us stores, nothing overlapping: profiles/r04/exp_fleet_direct_rows_parts.txt) that normalises N x D values per step where
-// the rings normalise a series value once per refill.
-static bool rows_direct_ok(const mgx_handle *h, const void *obs)
-{
-    if (!h->rows_direct || !obs || h->multi || h->k.H <= 0 || h->k.obs_state_only || !factorised(h->k.c)) return false;
-    if (h->windowed || h->rolling || h->inplace || dev_counter(h) || h->n_shards > 1) return false;
-    if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std) return false;
-    return rows_lds_bytes(h->k.obs_dim, h->k.H, h->k.obs_f32 ? sizeof(float) : sizeof(double)) <= 160 * 1024;
-}
-
-struct RowsItem {
-    mgx_handle *h;
-    const void *actions;          // continuous control, or the int32 priority-list ids of a discrete item
-    const PLWords *tab;           // discrete: the encoded table (host); NULL: continuous
-    double *reward; uint8_t *done; void *obs; double *log;
-};
-
-// one fleet_rows_kernel launch per MGX_FLEET_MAX items; the counters are advanced by the caller
-static int launch_rows(const RowsItem *items, int32_t n, int normalized, hipStream_t st, const char *who)
-{
-    size_t lds_max = 0;
-    for (int32_t j = 0; j < n; j++) {
-        mgx_handle *h = items[j].h;
-        if (int rc = sync_device_kargs(h, st, who)) return rc;
-        if (items[j].tab) {                                   // the priority-list table of a discrete item: device copy
-            if (!(h->table_uploaded_valid && memcmp(items[j].tab, &h->table_uploaded, sizeof(PLWords)) == 0)) {
-                hipError_t e = hipSuccess;
-                DeviceGuard on_device(h->device);
-                if (!h->d_table) e = hipMalloc((void **)&h->d_table, sizeof(PLWords));
-                if (e == hipSuccess) e = hipMemcpyAsync(h->d_table, items[j].tab, sizeof(PLWords), hipMemcpyHostToDevice, st);
-                if (e != hipSuccess) return hip_fail(e, who);
-                memcpy(&h->table_uploaded, items[j].tab, sizeof(PLWords));
-                h->table_uploaded_valid = true;
-            }
-        }
-        const size_t lds = rows_lds_bytes(h->k.obs_dim, h->k.H, h->k.obs_f32 ? sizeof(float) : sizeof(double));
-        if (lds > lds_max) lds_max = lds;
-    }
-    static bool opted_in[MGX_MAX_DEVICES] = {};
-    if (lds_max > 64 * 1024) {
-        const int dev = items[0].h->device;
-        if (dev < 0 || dev >= MGX_MAX_DEVICES || !opted_in[dev]) {
-            (void)hipFuncSetAttribute((const void *)fleet_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (dev >= 0 && dev < MGX_MAX_DEVICES) opted_in[dev] = true;
-        }
-    }
-    for (int32_t j0 = 0; j0 < n; j0 += MGX_FLEET_MAX) {
-        FleetRows fa;
-        memset(&fa, 0, sizeof(fa));
-        fa.n = n - j0 < MGX_FLEET_MAX ? n - j0 : MGX_FLEET_MAX;
-        fa.normalized = normalized;
-        int32_t blocks = 0;
-        for (int32_t q = 0; q < fa.n; q++) {
-            const RowsItem &it = items[j0 + q];
-            fa.k[q] = it.h->d_kargs; fa.tab[q] = it.tab ? it.h->d_table : nullptr;
-            fa.actions[q] = it.actions; fa.reward[q] = it.reward; fa.done[q] = it.done; fa.obs[q] = it.obs; fa.log[q] = it.log;
-            fa.t[q] = it.h->t; fa.flags[q] = it.h->flags; fa.block0[q] = blocks;
-            blocks += (int32_t)(((int64_t)it.h->k.N + ROWS_G - 1) / ROWS_G);
-        }
-        fleet_rows_kernel<<<(unsigned)blocks, ROWS_THREADS, lds_max, st>>>(fa);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "fleet_rows_kernel launch");
-    }
-    return MGX_OK;
-}
-
 // ---- single steps ----------------------------------------------------------------------------------------------
 // one Microgrid.run of every grid: the launches of mgx_step without its argument checks
 static int step_once(mgx_handle *h, const void *actions, int normalized, double *reward, uint8_t *done, void *obs, double *log,
@@ -1376,12 +1272,6 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
         return MGX_OK;
     }
     void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
-    if (rows_direct_ok(h, obs)) {                         // factorised series: step + whole observation row in one launch
-        const RowsItem it{h, actions, nullptr, reward, done, obs, log};
-        if (int rc = launch_rows(&it, 1, normalized, st, "mgx_step")) return rc;
-        advance(h, 1, st);
-        return MGX_OK;
-    }
     if (h->inplace) {                                     // in-place episodes: the EP form of the kernel (no shards in this mode)
         EpisodeStep ep;
         if (int rc = episode_step_begin(h, done, obs, obs_inline, &ep, "mgx_step")) return rc;
@@ -1407,7 +1297,6 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
 static int check_step_args(const mgx_handle *h, const void *actions, const double *reward, const void *obs, int32_t K, const char *who)
 {
     if (!h || !reward || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "%s: NULL argument", who);
-    if (h->server_running) return fail(MGX_ERR_INVALID, "%s: the resident step server owns the state (mgx_server_stop first)", who);
     if (K <= 0) return fail(MGX_ERR_INVALID, "%s: K must be positive", who);
     if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
         return K == 1 ? fail(MGX_ERR_RANGE, "%s: step %d is outside the time series (length %d)", who, h->t, step_limit(h))
@@ -1468,7 +1357,6 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
 {
     g_err[0] = 0;
     if (!h || (h->action_dim > 0 && !actions)) return fail(MGX_ERR_INVALID, "mgx_step_k: NULL argument");
-    if (h->server_running) return fail(MGX_ERR_INVALID, "mgx_step_k: the resident step server owns the state (mgx_server_stop first)");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_step_k: K must be positive");
     if (h->rolling) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: rolling windows take single steps (grids restart between steps)");
     if (!dev_counter(h) && (h->t < 0 || (int64_t)h->t + K > step_limit(h)))
@@ -1617,12 +1505,6 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_step_discrete")) return rc;
     hipStream_t st = (hipStream_t)stream;
     void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
-    if (rows_direct_ok(h, obs) && !control) {             // factorised series: expansion + step + whole row in one launch
-        const RowsItem it{h, action_id, &tab, reward, done, obs, log};
-        if (int rc = launch_rows(&it, 1, 0, st, "mgx_step_discrete")) return rc;
-        advance(h, 1, st);
-        return MGX_OK;
-    }
     if (h->inplace) {
         EpisodeStep ep;
         if (int rc = episode_step_begin(h, done, obs, obs_inline, &ep, "mgx_step_discrete")) return rc;
@@ -1645,13 +1527,119 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
     return MGX_OK;
 }
 
+// ---- the Gym step without per-step bookkeeping on the caller's side (mgx_env_*) ---------------------------------
+int mgx_env_bind(mgx_handle *h, const mgx_env_plan *plan)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_env_bind: NULL handle");
+    if (!plan) { h->env_bound = false; return MGX_OK; }
+    if (plan->struct_size != (int32_t)sizeof(mgx_env_plan))
+        return fail(MGX_ERR_INVALID, "mgx_env_bind: struct_size %d vs %zu (ABI %d)", plan->struct_size, sizeof(mgx_env_plan), MGX_ABI_VERSION);
+    if (plan->n_slots < 1 || plan->n_slots > MGX_ENV_MAX_SLOTS || !plan->slots)
+        return fail(MGX_ERR_INVALID, "mgx_env_bind: n_slots must be in [1, %d] with a slot array", MGX_ENV_MAX_SLOTS);
+    for (int32_t j = 0; j < plan->n_slots; j++)
+        if (!plan->slots[j].reward) return fail(MGX_ERR_INVALID, "mgx_env_bind: slot %d has no reward buffer", j);
+    if (plan->ring_K < 0) return fail(MGX_ERR_INVALID, "mgx_env_bind: ring_K must be >= 0");
+    if (plan->ring_K > 0) {
+        if (h->k.obs_state_only != 1)
+            return fail(MGX_ERR_INVALID, "mgx_env_bind: rings need the handle in MGX_OBS_ROWS_STATE_ONLY mode (mgx_set_obs_mode)");
+        if (!plan->rings[0] || !plan->rings[1] || !plan->rings[2]) return fail(MGX_ERR_INVALID, "mgx_env_bind: three rings are required");
+        if (h->rolling || h->windowed || h->inplace)
+            return fail(MGX_ERR_UNSUPPORTED, "mgx_env_bind: rings are walked for lock-step episodes (restarted grids are patched in by the caller)");
+    }
+    if (plan->n_actions < 0 || plan->n_actions > 12 || (plan->n_actions > 0 && !plan->table))
+        return fail(MGX_ERR_INVALID, "mgx_env_bind: a priority-list table holds 1..12 lists");
+    if (plan->n_actions > 0) {
+        PLWords tab;
+        if (int rc = encode_table(h, plan->table, plan->n_actions, &tab, "mgx_env_bind")) return rc;
+        memcpy(h->env_table, plan->table, sizeof(int32_t) * 6 * (size_t)plan->n_actions);
+    }
+    h->env_n_actions = plan->n_actions;
+    h->env_n_slots = plan->n_slots;
+    memcpy(h->env_slots, plan->slots, sizeof(mgx_env_slot) * (size_t)plan->n_slots);
+    h->env_ring_K = plan->ring_K;
+    for (int r = 0; r < 3; r++) h->env_rings[r] = (char *)plan->rings[r];
+    h->env_next = 0; h->env_ring_idx = 0; h->env_ring_pos = 0;
+    h->env_bound = true;
+    return MGX_OK;
+}
+
+int mgx_env_seek(mgx_handle *h, int32_t next_slot, int32_t ring_idx, int32_t ring_pos)
+{
+    g_err[0] = 0;
+    if (!h || !h->env_bound) return fail(MGX_ERR_INVALID, "mgx_env_seek: no plan is bound (mgx_env_bind)");
+    if (next_slot < 0 || next_slot >= h->env_n_slots) return fail(MGX_ERR_INVALID, "mgx_env_seek: slot %d outside [0, %d)", next_slot, h->env_n_slots);
+    if (h->env_ring_K > 0 && (ring_idx < 0 || ring_idx > 2 || ring_pos < 0 || ring_pos >= h->env_ring_K))
+        return fail(MGX_ERR_INVALID, "mgx_env_seek: ring %d block %d outside 3 rings of %d blocks", ring_idx, ring_pos, h->env_ring_K);
+    h->env_next = next_slot;
+    if (h->env_ring_K > 0) { h->env_ring_idx = ring_idx; h->env_ring_pos = ring_pos; }
+    return MGX_OK;
+}
+
+int mgx_env_position(const mgx_handle *h, int32_t *last_slot, int32_t *ring_idx, int32_t *ring_pos)
+{
+    g_err[0] = 0;
+    if (!h || !h->env_bound) return fail(MGX_ERR_INVALID, "mgx_env_position: no plan is bound (mgx_env_bind)");
+    if (last_slot) *last_slot = (h->env_next + h->env_n_slots - 1) % h->env_n_slots;
+    if (ring_idx) *ring_idx = h->env_ring_idx;
+    if (ring_pos) *ring_pos = h->env_ring_pos;
+    return MGX_OK;
+}
+
+namespace {
+// where the coming step's observation goes and what has to happen around it
+struct EnvTarget { void *obs; bool enters_next_ring; };
+inline EnvTarget env_target(const mgx_handle *h, const mgx_env_slot &sl)
+{
+    if (h->env_ring_K <= 0) return EnvTarget{sl.obs, false};
+    const size_t block = (size_t)h->ring_pitch * (size_t)h->k.obs_dim * (h->k.obs_f32 ? sizeof(float) : sizeof(double));
+    if (h->env_ring_pos + 1 < h->env_ring_K)
+        return EnvTarget{h->env_rings[h->env_ring_idx] + (size_t)(h->env_ring_pos + 1) * block, false};
+    return EnvTarget{h->env_rings[(h->env_ring_idx + 1) % 3], true};
+}
+// after a successful step: the slot moves on, the env moves to the block it just completed
+inline int env_commit(mgx_handle *h, bool entered, mgx_stream stream)
+{
+    h->env_next = h->env_next + 1 < h->env_n_slots ? h->env_next + 1 : 0;
+    if (h->env_ring_K <= 0) return MGX_OK;
+    if (!entered) { h->env_ring_pos += 1; return MGX_OK; }
+    h->env_ring_idx = (h->env_ring_idx + 1) % 3;
+    h->env_ring_pos = 0;
+    // the ring behind the one just entered: the windows of counter values t + K .. t + 2K - 1, written beside the next K steps
+    return observe_windows_ahead(h, h->env_ring_K, h->env_ring_K, h->env_rings[(h->env_ring_idx + 1) % 3], (hipStream_t)stream, nullptr, nullptr);
+}
+}  // namespace
+
+int mgx_env_step(mgx_handle *h, const void *actions, int normalized, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !h->env_bound) return fail(MGX_ERR_INVALID, "mgx_env_step: no plan is bound (mgx_env_bind)");
+    const mgx_env_slot &sl = h->env_slots[h->env_next];
+    const EnvTarget tg = env_target(h, sl);
+    if (int rc = check_step_args(h, actions, sl.reward, tg.obs, 1, "mgx_env_step")) return rc;
+    if (tg.enters_next_ring) { if (int rc = mgx_prefetch_wait(h, stream)) return rc; }
+    if (int rc = step_once(h, actions, normalized, sl.reward, sl.done, tg.obs, sl.log, (hipStream_t)stream)) return rc;
+    return env_commit(h, tg.enters_next_ring, stream);
+}
+
+int mgx_env_step_discrete(mgx_handle *h, const int32_t *action_id, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !h->env_bound) return fail(MGX_ERR_INVALID, "mgx_env_step_discrete: no plan is bound (mgx_env_bind)");
+    if (h->env_n_actions <= 0) return fail(MGX_ERR_INVALID, "mgx_env_step_discrete: the bound plan holds no priority-list table");
+    const mgx_env_slot &sl = h->env_slots[h->env_next];
+    const EnvTarget tg = env_target(h, sl);
+    if (tg.enters_next_ring) { if (int rc = mgx_prefetch_wait(h, stream)) return rc; }
+    if (int rc = mgx_step_discrete(h, action_id, h->env_table, h->env_n_actions, nullptr, sl.reward, sl.done, tg.obs, sl.log, stream)) return rc;
+    return env_commit(h, tg.enters_next_ring, stream);
+}
+
 int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, const int32_t *table, int32_t n_actions,
                          int32_t K, double *reward, uint8_t *done, double *soc_trace, uint32_t *status_trace,
                          double *ret_acc, double *log, mgx_stream stream)
 {
     g_err[0] = 0;
     if (!h || !action_id || !table) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: NULL argument");
-    if (h->server_running) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: the resident step server owns the state (mgx_server_stop first)");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_discrete: K must be positive");
     if (h->rolling) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: rolling windows take single steps");
     if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_rollout_discrete: needs exactly one module of every kind "
@@ -1686,7 +1674,6 @@ int mgx_rollout_lists(mgx_handle *h, const int32_t *action_id, int per_step, con
 {
     g_err[0] = 0;
     if (!h || !action_id || !lists) return fail(MGX_ERR_INVALID, "mgx_rollout_lists: NULL argument");
-    if (h->server_running) return fail(MGX_ERR_INVALID, "mgx_rollout_lists: the resident step server owns the state (mgx_server_stop first)");
     if (K <= 0) return fail(MGX_ERR_INVALID, "mgx_rollout_lists: K must be positive");
     if (n_lists <= 0 || list_len <= 0 || list_len > 3 * MGX_MAX_INSTANCES)
         return fail(MGX_ERR_INVALID, "mgx_rollout_lists: need n_lists > 0 and list_len in [1, %d]", 3 * MGX_MAX_INSTANCES);
@@ -1728,29 +1715,6 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
                 return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d: bad refill_K / refill_ahead / refill_chunk(s)", j);
             WindowsKPlan plan; size_t lds; int32_t ng;
             if (int rc = windows_plan(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, "mgx_fleet_step", &plan, &lds, &ng)) return rc;
-        }
-    }
-    // every batch wants whole rows off factorised series: ONE fleet_rows_kernel (step + row per 16-grid workgroup)
-    {
-        bool all_rows = n <= 64;
-        for (int32_t j = 0; j < n && all_rows; j++) {
-            all_rows = rows_direct_ok(items[j].handle, items[j].obs) && !items[j].refill_ring && !items[j].wait_prefetch;
-            for (int32_t q = 0; q < j && all_rows; q++) all_rows = items[q].handle != items[j].handle;
-        }
-        if (all_rows) {
-            RowsItem ri[64];
-            PLWords tabs[64];
-            for (int32_t j = 0; j < n; j++) {
-                const mgx_fleet_item &it = items[j];
-                ri[j] = RowsItem{it.handle, it.action_id ? (const void *)it.action_id : it.actions, nullptr, it.reward, it.done, it.obs, it.log};
-                if (it.action_id) {
-                    if (int rc = encode_table(it.handle, it.table, it.n_actions, &tabs[j], "mgx_fleet_step")) return rc;
-                    ri[j].tab = &tabs[j];
-                }
-            }
-            if (int rc = launch_rows(ri, n, normalized, st, "mgx_fleet_step")) return rc;
-            for (int32_t j = 0; j < n; j++) advance(items[j].handle, 1, st);
-            return MGX_OK;
         }
     }
     // one launch for all batches (continuous and discrete items alike) unless an item needs a kernel of its own
@@ -1937,120 +1901,6 @@ int mgx_normalise_series(mgx_handle *h, void *load_n, void *pv_n, void *grid_n, 
     if (h->layout.has_grid) launch(2, grid_n, 4);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MGX_OK : hip_fail(e, "normalise_series_kernel launch");
-}
-
-// ---- resident step server ------------------------------------------------------------------------------------------
-int mgx_server_start(mgx_handle *h, const mgx_server_slot *slots, int32_t n_slots, int normalized, int32_t max_steps,
-                     int32_t idle_timeout_ms, int immediate, mgx_stream stream)
-{
-    g_err[0] = 0;
-    if (!h || !slots) return fail(MGX_ERR_INVALID, "mgx_server_start: NULL argument");
-    if (h->server_running) return fail(MGX_ERR_INVALID, "mgx_server_start: the server is already running");
-    if (n_slots < 1 || n_slots > MGX_SERVER_MAX_SLOTS) return fail(MGX_ERR_INVALID, "mgx_server_start: n_slots must be in [1, %d]", MGX_SERVER_MAX_SLOTS);
-    if (max_steps < 1) return fail(MGX_ERR_INVALID, "mgx_server_start: max_steps must be positive");
-    if (idle_timeout_ms < 1 || idle_timeout_ms > 60000) return fail(MGX_ERR_INVALID, "mgx_server_start: idle_timeout_ms must be in [1, 60000]");
-    if (h->multi || h->windowed || h->rolling || h->inplace || dev_counter(h) || h->n_shards > 1)
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: lock-step stepping of one module of every kind per grid only (no per-grid windows, "
-                                         "device counter or shards)");
-    if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: not offered with forecast noise");
-    if (h->t < 0 || (int64_t)h->t + max_steps > step_limit(h))
-        return fail(MGX_ERR_RANGE, "mgx_server_start: steps [%d, %d) leave the time series (length %d)", h->t, h->t + max_steps, step_limit(h));
-    bool any_obs = false;
-    for (int32_t j = 0; j < n_slots; j++) {
-        if (!slots[j].reward || (h->action_dim > 0 && !slots[j].actions)) return fail(MGX_ERR_INVALID, "mgx_server_start: slot %d: NULL actions / reward", j);
-        any_obs = any_obs || slots[j].obs != nullptr;
-    }
-    if (any_obs) {
-        if (h->k.H > 0 && !h->k.obs_state_only)
-            return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: whole rows need a forecast window per step: use MGX_OBS_ROWS_STATE_ONLY / "
-                                             "_COMPACT (rings / views hold the windows) or horizon 0");
-        if (h->k.obs_colpitch && h->k.obs_state_only == 1)
-            return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: state columns inside column-major ring blocks are not offered (use compact state rows)");
-        if (int rc = need_obs_bounds(h, "mgx_server_start")) return rc;
-    }
-    DeviceGuard on_device(h->device);
-    hipError_t e = hipSuccess;
-    if (!h->server_stream) {
-        e = hipStreamCreateWithFlags(&h->server_stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->server_gate, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->server_ctl, sizeof(ServerCtl));
-        if (e == hipSuccess) e = hipHostMalloc((void **)&h->server_host, sizeof(ServerHostWords), hipHostMallocMapped);
-        if (e == hipSuccess) e = hipExtMallocWithFlags((void **)&h->server_signal, 8, hipMallocSignalMemory);
-        if (e != hipSuccess) return hip_fail(e, "mgx_server_start: allocating the mailbox");
-    }
-    ServerCtl init;
-    memset(&init, 0, sizeof(init));
-    for (int32_t j = 0; j < n_slots; j++)
-        init.slot[j] = ServerSlot{slots[j].actions, slots[j].reward, slots[j].done, slots[j].obs};
-    h->server_host->seq = 0; h->server_host->stop = 0;
-    hipStream_t st = (hipStream_t)stream;
-    // the mailbox is written, and everything queued on the caller's stream is done, before the kernel looks at either
-    e = hipMemcpyAsync(h->server_ctl, &init, sizeof(init), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(h->server_signal, 0, 8, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);                 // (`init` is a host temporary; start is not on the per-step path)
-    if (e != hipSuccess) return hip_fail(e, "mgx_server_start: writing the mailbox");
-    ServerArgs sv;
-    sv.ctl = h->server_ctl;
-    void *host_dev = nullptr;
-    e = hipHostGetDevicePointer(&host_dev, h->server_host, 0);
-    if (e != hipSuccess) return hip_fail(e, "mgx_server_start: mapping the host words");
-    sv.host = (const ServerHostWords *)host_dev;
-    sv.done_signal = h->server_signal;
-    sv.n_slots = n_slots; sv.n_workers = (int32_t)blocks_for(h->k.N); sv.max_steps = max_steps; sv.normalized = normalized; sv.immediate = immediate != 0;
-    sv.idle_ticks = (int64_t)idle_timeout_ms * 100000; sv.life_ticks = (int64_t)60000 * 100000;      // 100 MHz
-    int per_cu = 0;
-    MGX_DISPATCH_F(h->flags, (e = launch_server<F>(h, sv, (unsigned)sv.n_workers + 1, &per_cu)));
-    if (e == hipErrorLaunchOutOfResources)
-        return fail(MGX_ERR_UNSUPPORTED, "mgx_server_start: %d workgroups cannot all be resident (%d per CU x %d CUs): the server needs every "
-                                         "grid on the chip at once", sv.n_workers + 1, per_cu, h->n_cu);
-    if (e != hipSuccess) return hip_fail(e, "step_server_kernel launch");
-    h->server_running = true; h->server_immediate = immediate != 0; h->server_posted = 0; h->server_max_steps = max_steps;
-    return MGX_OK;
-}
-
-int mgx_server_post(mgx_handle *h, mgx_stream stream)
-{
-    if (!h || !h->server_running) { g_err[0] = 0; return fail(MGX_ERR_INVALID, "mgx_server_post: the server is not running"); }
-    if ((int32_t)h->server_posted >= h->server_max_steps) { g_err[0] = 0; return fail(MGX_ERR_RANGE, "mgx_server_post: the burst's %d steps are all posted", h->server_max_steps); }
-    h->server_posted += 1;
-    if (h->server_immediate) {
-        __atomic_store_n(&h->server_host->seq, h->server_posted, __ATOMIC_RELEASE);
-        return MGX_OK;
-    }
-    hipError_t e = hipStreamWriteValue32((hipStream_t)stream, &h->server_ctl->seq, h->server_posted, 0);
-    if (e != hipSuccess) { g_err[0] = 0; h->server_posted -= 1; return hip_fail(e, "mgx_server_post: hipStreamWriteValue32"); }
-    return MGX_OK;
-}
-
-int mgx_server_wait(mgx_handle *h, mgx_stream stream)
-{
-    g_err[0] = 0;
-    if (!h || !h->server_running) return fail(MGX_ERR_INVALID, "mgx_server_wait: the server is not running");
-    hipError_t e = hipStreamWaitValue32((hipStream_t)stream, h->server_signal, h->server_posted, hipStreamWaitValueGte, 0xffffffffu);
-    return e == hipSuccess ? MGX_OK : hip_fail(e, "mgx_server_wait: hipStreamWaitValue32");
-}
-
-int mgx_server_stop(mgx_handle *h, int32_t *steps_done)
-{
-    g_err[0] = 0;
-    if (steps_done) *steps_done = 0;
-    if (!h || !h->server_running) return fail(MGX_ERR_INVALID, "mgx_server_stop: the server is not running");
-    __atomic_store_n(&h->server_host->stop, h->server_posted + 1, __ATOMIC_RELEASE);
-    hipError_t e = hipStreamSynchronize(h->server_stream);
-    h->server_running = false;
-    if (e != hipSuccess) return hip_fail(e, "mgx_server_stop: waiting for the kernel");
-    uint32_t words[4] = {0, 0, 0, 0};
-    e = hipMemcpy(words, h->server_ctl, sizeof(words), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hip_fail(e, "mgx_server_stop: reading the mailbox");
-    const uint32_t status = words[2], done = words[3];
-    h->t += (int32_t)done;
-    h->counter_stream = h->server_stream;
-    if (steps_done) *steps_done = (int32_t)done;
-    if (done < h->server_posted)
-        return fail(MGX_ERR_RANGE, "mgx_server_stop: the burst ended after %u of %u posted steps (%s); the counter stands at %d", done,
-                    h->server_posted, status == 2 ? "idle timeout" : (status == 3 ? "lifetime cap" : "stopped"), h->t);
-    return MGX_OK;
 }
 
 int mgx_metrics(mgx_handle *h, const double *values, int32_t M, double *sums, mgx_stream stream)

@@ -93,16 +93,10 @@ __device__ __forceinline__ int32_t episode_tail(const KArgs &a, int64_t i, int32
 
 // body of one step of grid i (shared by step_kernel and fleet_step_kernel).  EP: in-place per-grid episodes (the grid's series
 // row is counter + ep_off[i]; a compile-time form so that the lock-step kernel carries none of it)
-// what a step leaves behind for a caller that goes on to write the grid's observation row itself (rows_body)
-struct StepResult {
-    Params p;
-    State s;
-};
-
 template <int F, bool EP = false>
 __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict__ actions, int32_t t, int normalized,
                                           double *__restrict__ reward, uint8_t *__restrict__ done, void *__restrict__ obs,
-                                          double *__restrict__ log, int64_t i, StepResult *res = nullptr)
+                                          double *__restrict__ log, int64_t i)
 {
     // all loads first (independent, one latency round), then the arithmetic
     Params p; State s; Inputs in; Outputs o; Derived d;
@@ -129,7 +123,6 @@ __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
     // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
     if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, pm);
-    if (res) { res->p = p; res->s = s; }
 }
 
 template <int F, bool EP = false>
@@ -648,7 +641,14 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
 // so that output element (block k, grid r, column c) = image[r*BP + map[c] + k] for EVERY kind of column (map[c] =
 // offset of the column's k = 0 entry).  Thread (g, q) of the 256 loads rows q, q+16, ... of grid g; wave w then writes
 // blocks w, w+4, ... (each 16*D consecutive elements) with 16-byte non-temporal stores.
-constexpr int OBS_KJ = 2;                               // rows per thread and latency round (x 16 phases = 32 rows)
+#ifndef MGX_OBS_KJ
+#define MGX_OBS_KJ 2
+#endif
+#ifndef MGX_WIN_UNROLL
+#define MGX_WIN_UNROLL 1
+#endif
+constexpr int OBS_KJ = MGX_OBS_KJ;                      // rows per thread and latency round (x 16 phases = 32 rows)
+constexpr int WIN_U = MGX_WIN_UNROLL;                   // blocks per lane whose image words are read before the first of their stores
 constexpr int OBS_K_THREADS = 256;
 
 // IT: element type of the LDS image -- double, or float where the rows leave as floats (the value is rounded to float once, here,
@@ -734,6 +734,9 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     IT *blk = image + g * BP;
     uint32_t *map = reinterpret_cast<uint32_t *>(image + G * BP);       // [D]
 
+#ifdef MGX_WIN_NO_LOAD
+    if (K < 0)                                           // (diagnostic build: phase 2 -- image -> ring stores -- alone, on whatever the LDS holds)
+#endif
     if (factorised(a.c)) {                               // uniform over the launch: rows formed from the base tables
         GridFactors f;
         load_factors<GRID ? F_GRID : 0>(a.c, ic, f);
@@ -775,6 +778,9 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         map[col] = comp == 0xffffu ? S0 + h * K : (h == 0 ? NU0 + comp * K : comp * RP + h);
     }
     __syncthreads();
+#ifdef MGX_WIN_NO_STORE
+    if (K > 0) return;                                   // (diagnostic build: phase 1 -- the loads and the image -- alone)
+#endif
     const int32_t n_valid = (N - g0 < G) ? (int32_t)(N - g0) : G;
     const int32_t total = n_valid * D;                   // D is even (one load, one renewable module)
     typedef OT vec2 __attribute__((ext_vector_type(2)));
@@ -794,8 +800,21 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
             // not writing them costs nothing (in row-major blocks the same holes make partial lines: MGX_WIN_SKIP_STATE)
             if (!have_now && m >= (uint32_t)S0) continue;
             const IT *src = image + g * BP + m;
-            for (int32_t k = 0; k < K; k++)
-                if (in_batch) MGX_WIN_STORE((OT)src[k], outc + ((int64_t)k * D + c) * P);
+            OT *o = outc + (int64_t)c * P;
+            const int64_t kstride = (int64_t)D * P;
+            int32_t k = 0;
+            if constexpr (WIN_U > 1) {                   // WIN_U image words in flight before the first store of the batch
+                for (; k + WIN_U <= K; k += WIN_U) {
+                    IT v[WIN_U];
+#pragma unroll
+                    for (int u = 0; u < WIN_U; u++) v[u] = src[k + u];
+#pragma unroll
+                    for (int u = 0; u < WIN_U; u++)
+                        if (in_batch) MGX_WIN_STORE((OT)v[u], o + (int64_t)(k + u) * kstride);
+                }
+            }
+            for (; k < K; k++)
+                if (in_batch) MGX_WIN_STORE((OT)src[k], o + (int64_t)k * kstride);
         }
         return;
     }
@@ -820,11 +839,27 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
                 const IT *s0 = image + r * BP + m0 + wave;
                 const IT *s1 = image + r * BP + m1 + wave;
                 OT *out = out0 + f;
-                for (int32_t k = wave; k < K; k += KW) {
+                const int64_t kw_stride = KW * block_stride;
+                int32_t k = wave;
+                if constexpr (WIN_U > 1) {               // WIN_U pairs of image words in flight before the first store of the batch
+                    for (; k + (WIN_U - 1) * KW < K; k += WIN_U * KW) {
+                        IT a0[WIN_U], a1[WIN_U];
+#pragma unroll
+                        for (int u = 0; u < WIN_U; u++) { a0[u] = s0[u * KW]; a1[u] = s1[u * KW]; }
+#pragma unroll
+                        for (int u = 0; u < WIN_U; u++) {
+                            vec2 v2;
+                            v2.x = (OT)a0[u]; v2.y = (OT)a1[u];
+                            MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out + u * kw_stride));
+                        }
+                        s0 += WIN_U * KW; s1 += WIN_U * KW; out += WIN_U * kw_stride;
+                    }
+                }
+                for (; k < K; k += KW) {
                     vec2 v2;
                     v2.x = (OT)*s0; v2.y = (OT)*s1;
                     MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out));
-                    s0 += KW; s1 += KW; out += KW * block_stride;
+                    s0 += KW; s1 += KW; out += kw_stride;
                 }
             }
             c += 128;
@@ -1009,7 +1044,7 @@ template <int F, bool EP = false>
 __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords &tab, const int32_t *__restrict__ action_id,
                                                    int32_t t, double *__restrict__ control, double *__restrict__ reward,
                                                    uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                   double *__restrict__ log, int64_t i, StepResult *res = nullptr)
+                                                   double *__restrict__ log, int64_t i)
 {
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
     const int64_t N = a.N;
@@ -1048,7 +1083,6 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     if (log) store_log<F>(log + i, N, o, s.status);
     if constexpr (EP) off = episode_tail<F>(a, i, t, off, dn != 0, p, s);
     if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, EP ? a.pm_pitch : 0);
-    if (res) { res->p = p; res->s = s; }
 }
 
 // Dry run of one discrete step (mgx_check_discrete): the expansion and the step on a register copy of the state; only the mask
@@ -1195,256 +1229,6 @@ static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArg
         default: step_body<15>(a, actions, t, fa.normalized, reward, done, obs, log, i); break;
     }
 #undef MGX_FLEET_CASE
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Step + observation ROW in one launch, for factorised series (mgx_step / mgx_fleet_step with a forecast horizon and whole
-// rows wanted): DiscreteMicrogridEnv.step / BaseMicrogridEnv.step as the reference returns them -- (obs [N, D], reward, done) --
-// with every byte of the row written ONCE, by whole 128-byte lines.
-//
-// Why not rings here.  With [T, N] series a window value costs an HBM read, so the rows of the next K steps are written ahead
-// from one pass over the series (obs_windows_k_kernel) and the step only adds its state columns -- 48 bytes per row at a
-// 1 248-byte stride: 100 000 scattered line-granular writes per fleet step, measured at 3.5-4 us of a 24-us config-5 step
-// (profiles/r04/exp_fleet_state_patch_cost.txt; leaving holes for them in the refill stream is worse still,
-// exp_fleet_state_holes_ab.txt, and so is a whole-line rewrite from the step, exp_fleet_line_patch_emulation.txt).  With
-// FACTORISED series the window source is a few cache-resident base rows: nothing is gained by sharing them across steps, so
-// the workgroup that steps 16 grids also forms their 16 rows -- state columns included -- in an LDS tile and streams the tile
-// out as one contiguous 16 * D * 8-byte region (16-byte non-temporal stores).  No rings (12 GB at K = 32), no prefetch
-// streams, no second writer per row: HBM traffic == the algorithmic bytes.  What it costs: N x D normalisations per step where a
-// ring refill normalises a series value once, and a latency-bound workgroup (profiles/r04/exp_fleet_direct_rows_parts.txt:
-// 55-61 us per config-5 fleet step, rings 24-28) -- the option for SMALL batches, where one launch instead of two is what counts.
-//
-// Workgroup = 256 threads around 64 grids.  Wave 0 runs the step of the 64 grids, one lane each (step_body /
-// step_discrete_body, unchanged: one latency chain per 64 grids) and leaves their 6 state columns in LDS; the rows leave in
-// four tiles of 16 grids: thread (g, q) normalises its share of grid g's 6 (1 + H) window values (component compile-time,
-// horizon steps h = q', q' + Q, ... with q' rotated per component so that the split of a 25-step window over Q threads
-// evens out) -- the first tile by waves 1-3 alone, beside the step.  Base rows t + 1 .. t + 1 + H of the load / pv / co2
-// tables are staged in LDS once per workgroup (64 B per row and table).  Same arithmetic as every other observation kernel
-// (obs_series_value), hence the same bits.
-// ------------------------------------------------------------------------------------------------------
-constexpr int ROWS_G = 64;            // grids per workgroup: one full wave steps them
-constexpr int ROWS_TILE = 16;         // grids per LDS row tile (4 tiles per workgroup, one after the other)
-constexpr int ROWS_THREADS = 256;
-constexpr int ROWS_GP = 14;           // per-grid doubles kept in LDS: lo[6], hi[6], load ratio, pv ratio
-
-// LDS of a rows workgroup: tile [16][ld] of OT | state columns [64][6] of OT | per-grid window parameters [14][64] doubles,
-// outage words [2][64], profile ids [64] | base rows [3][W][PP] doubles
-__host__ __device__ inline size_t rows_lds_bytes(int32_t D, int32_t H, size_t esz)
-{
-    const size_t tile = ((size_t)ROWS_TILE * (size_t)(D | 1) * esz + 15) & ~(size_t)15;
-    const size_t st = ((size_t)ROWS_G * 6 * esz + 15) & ~(size_t)15;
-    const size_t gp = (size_t)(ROWS_GP + 2) * ROWS_G * sizeof(double) + (size_t)ROWS_G * sizeof(uint32_t) * 2;
-    return tile + st + gp + (size_t)3 * (size_t)(1 + H) * PP * sizeof(double);
-}
-
-// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global store in flight (vmcnt counts
-// stores on gfx9) -- here that would put the full write latency of a row tile between two tiles
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int F, typename OT>
-__device__ __forceinline__ void rows_body(const KArgs &a, const PLWords *__restrict__ tab, const void *__restrict__ actions, int32_t t,
-                                          int normalized, double *__restrict__ reward, uint8_t *__restrict__ done,
-                                          OT *__restrict__ obs, double *__restrict__ log, int64_t group, double *lds_raw)
-{
-    constexpr bool GRID = (F & F_GRID) != 0;
-    constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
-    constexpr int NC = GRID ? 6 : 2;
-    const int tid = threadIdx.x;
-    const int64_t N = a.N;
-    const int64_t g0 = group * ROWS_G;
-    const int32_t W = 1 + a.H, D = a.obs_dim, LD = D | 1, T = a.T;
-    const int32_t t1 = t + 1;                                      // the observation after the step (base.py:205-209)
-    const size_t tile_b = ((size_t)ROWS_TILE * LD * sizeof(OT) + 15) & ~(size_t)15, st_b = ((size_t)ROWS_G * 6 * sizeof(OT) + 15) & ~(size_t)15;
-    char *lp = reinterpret_cast<char *>(lds_raw);
-    OT *tile = reinterpret_cast<OT *>(lp);
-    OT *st = reinterpret_cast<OT *>(lp + tile_b);                                                  // [64][6]: genset 4, battery 2
-    double *gp = reinterpret_cast<double *>(lp + tile_b + st_b);                                   // [14][64]
-    uint64_t *gw = reinterpret_cast<uint64_t *>(gp + ROWS_GP * ROWS_G);                            // [2][64] outage words
-    uint32_t *gid = reinterpret_cast<uint32_t *>(gw + 2 * ROWS_G);                                 // [64] lp | pp << 8 | cp << 16 | pat << 24
-    double *base = reinterpret_cast<double *>(gid + 2 * ROWS_G);                                   // [3][W][PP]
-    const mgx_columns &c = a.c;
-    const int64_t w0 = (int64_t)(t1 < T ? t1 : T - 1) >> 6;
-
-    // (1) everything the window values need, once per workgroup: base rows t1 .. t1 + H (clamped into the series; rows past its
-    // end are padding and never used) and the 64 grids' bounds / factors / outage words (coalesced along the grids)
-    for (int32_t j = tid; j < W * PP; j += ROWS_THREADS) {
-        const int32_t h = j / PP, pcol = j - h * PP;
-        const int64_t row = (t1 + h < T) ? (int64_t)(t1 + h) : (int64_t)T - 1;
-        base[j] = c.base_load[row * PP + pcol];
-        base[W * PP + j] = c.base_pv[row * PP + pcol];
-        if constexpr (GRID) base[2 * W * PP + j] = c.base_co2[row * PP + pcol];
-    }
-    {
-        const int32_t gi = tid & (ROWS_G - 1), part = tid >> 6;       // 4 threads per grid, each a quarter of its fields
-        const int64_t i = g0 + gi, ic = i < N ? i : N - 1;
-        if (part == 0) {
-            gp[0 * ROWS_G + gi] = c.load_lo[ic]; gp[6 * ROWS_G + gi] = c.load_hi[ic];
-            gp[1 * ROWS_G + gi] = c.pv_lo[ic]; gp[7 * ROWS_G + gi] = c.pv_hi[ic];
-        } else if (part == 1) {
-            gp[12 * ROWS_G + gi] = c.load_ratio[ic]; gp[13 * ROWS_G + gi] = c.pv_ratio[ic];
-            uint32_t ids = (uint32_t)c.load_profile[ic] | ((uint32_t)c.pv_profile[ic] << 8);
-            if constexpr (GRID) ids |= ((uint32_t)c.co2_profile[ic] << 16) | ((uint32_t)c.tariff[ic] << 24);
-            gid[gi] = ids;
-        } else if (part == 2) {
-            if constexpr (GRID) {
-#pragma unroll
-                for (int cc = 0; cc < 4; cc++) gp[(2 + cc) * ROWS_G + gi] = c.grid_lo[cc * N + ic];
-            }
-        } else {
-            if constexpr (GRID) {
-#pragma unroll
-                for (int cc = 0; cc < 4; cc++) gp[(8 + cc) * ROWS_G + gi] = c.grid_hi[cc * N + ic];
-                uint64_t o0 = 0, o1 = 0;
-                if (c.outage_bits) {
-                    o0 = c.outage_bits[w0 * N + ic];
-                    if ((w0 + 1) * 64 < T) o1 = c.outage_bits[(w0 + 1) * N + ic];
-                }
-                gw[gi] = o0; gw[ROWS_G + gi] = o1;
-            }
-        }
-    }
-    __syncthreads();
-    // (2) wave 0: the step of the 64 grids (one lane each: step_body / step_discrete_body, unchanged), state columns -> LDS
-    if (tid < ROWS_G) {
-        const int64_t i = g0 + tid;
-        if (i < N) {
-            StepResult res;
-            if (tab != nullptr) step_discrete_body<F>(a, *tab, (const int32_t *)actions, t, nullptr, reward, done, nullptr, log, i, &res);
-            else step_body<F>(a, actions, t, normalized, reward, done, nullptr, log, i, &res);
-            observe_state_cols<F, OT>(a, res.p, res.s, st + tid * 6, 0);
-        }
-    }
-    // (3) four row tiles of 16 grids.  Thread (g = u & 15, q = u >> 4) forms grid g's window values at horizon steps h = q', q' + Q,
-    // ... (q' rotated per component).  Tile 0 is formed by waves 1-3 alone (Q = 12) while wave 0 is busy with the step.  Nothing
-    // in this loop reads global memory: the tile's stores stay in flight while the next tile is formed (lds_barrier).
-    for (int32_t s = 0; s < ROWS_G / ROWS_TILE; s++) {
-        const int64_t r0 = g0 + (int64_t)s * ROWS_TILE;             // first grid of the tile
-        if (r0 >= N) break;                                         // (uniform)
-        const bool first = s == 0;
-        const int32_t u = first ? tid - ROWS_G : tid, Q = first ? (ROWS_THREADS - ROWS_G) / ROWS_TILE : ROWS_THREADS / ROWS_TILE;
-        if (u >= 0) {
-            const int32_t g = u & (ROWS_TILE - 1), q = u >> 4, gi = s * ROWS_TILE + g;
-            const uint32_t ids = gid[gi];
-            const double lr = gp[12 * ROWS_G + gi], pr = gp[13 * ROWS_G + gi];
-            OT *row = tile + g * LD;
-            auto window = [&](auto cc_tag) __attribute__((always_inline)) {
-                constexpr int cc = decltype(cc_tag)::value;
-                const double l = gp[cc * ROWS_G + gi], hh = gp[(6 + cc) * ROWS_G + gi];
-                const double fill = (hh + l) / 2, sp = space_spread(l, hh);
-                const int32_t col0 = cc == 0 ? a.col_load : (cc == 1 ? a.col_pv : a.col_grid + (cc - 2));
-                constexpr int stride = cc < 2 ? 1 : 4;
-                int32_t h = q + 9 * cc;
-                while (h >= Q) h -= Q;
-                for (; h < W; h += Q) {
-                    const bool in = t1 + h < T;
-                    double x;
-                    if constexpr (cc == 0) x = fact_load(base[h * PP + (ids & 0xffu)], lr);
-                    else if constexpr (cc == 1) x = fact_pv(base[W * PP + h * PP + ((ids >> 8) & 0xffu)], pr);
-                    else if constexpr (cc == 2) x = tariff_price((int32_t)(ids >> 24), t1 + h);
-                    else if constexpr (cc == 3) x = 0.0;
-                    else if constexpr (cc == 4) x = base[2 * W * PP + h * PP + ((ids >> 16) & 0xffu)];
-                    else {
-                        const int64_t r = in ? (int64_t)(t1 + h) : (int64_t)T - 1;
-                        uint64_t word = ((r >> 6) == w0) ? gw[gi] : gw[ROWS_G + gi];
-                        if ((r >> 6) > w0 + 1) {                       // horizons beyond 64 rows
-                            const int64_t i = r0 + g;
-                            word = c.outage_bits ? c.outage_bits[(r >> 6) * N + (i < N ? i : N - 1)] : 0;
-                        }
-                        x = ((word >> (r & 63)) & 1ull) ? 0.0 : 1.0;
-                    }
-                    row[col0 + stride * h] = (OT)obs_series_value(x, in, h > 0, l, hh, fill, sp);
-                }
-            };
-            window(std::integral_constant<int, 0>{});
-            window(std::integral_constant<int, 1>{});
-            if constexpr (GRID) {
-                window(std::integral_constant<int, 2>{}); window(std::integral_constant<int, 3>{});
-                window(std::integral_constant<int, 4>{}); window(std::integral_constant<int, 5>{});
-            }
-        }
-        lds_barrier();                                              // windows of this tile formed -- and (first tile) the step done
-        if constexpr (NSTATE > 0) {                                 // the state columns of the tile's 16 grids, out of wave 0's LDS copy
-            if (tid < ROWS_TILE * NSTATE) {
-                const int32_t g = tid / NSTATE, j = tid - g * NSTATE;
-                int32_t col;
-                if constexpr ((F & F_GENSET) != 0) col = j < 4 ? a.col_gen + j : a.col_bat + (j - 4);
-                else col = a.col_bat + j;
-                tile[g * LD + col] = st[(s * ROWS_TILE + g) * 6 + j];
-            }
-            lds_barrier();
-        }
-        // the 16 rows are one contiguous region of obs: 16-byte non-temporal stores, whole lines
-        const int32_t n_valid = (N - r0 < ROWS_TILE) ? (int32_t)(N - r0) : ROWS_TILE;
-        const int32_t total = n_valid * D;               // D is even (one load, one renewable module)
-        OT *out = obs + r0 * D;
-        typedef OT vec2 __attribute__((ext_vector_type(2)));
-        if ((reinterpret_cast<uintptr_t>(out) & (sizeof(vec2) - 1)) == 0) {
-            int32_t r = 2 * tid / D, cidx = 2 * tid - r * D;
-            for (int32_t e = 2 * tid; e < total; e += 2 * ROWS_THREADS) {
-                vec2 v2;
-                v2.x = tile[r * LD + cidx];
-                v2.y = tile[r * LD + cidx + 1];
-                __builtin_nontemporal_store(v2, reinterpret_cast<vec2 *>(out + e));
-                cidx += 2 * ROWS_THREADS;
-                while (cidx >= D) { cidx -= D; r++; }
-            }
-        } else {
-            int32_t r = tid / D, cidx = tid - r * D;
-            for (int32_t e = tid; e < total; e += ROWS_THREADS) {
-                __builtin_nontemporal_store(tile[r * LD + cidx], out + e);
-                cidx += ROWS_THREADS;
-                while (cidx >= D) { cidx -= D; r++; }
-            }
-        }
-        lds_barrier();                                              // the tile has been read: free for the next one
-    }
-}
-
-// One launch for every batch of a fleet (or for one batch: mgx_step): block0[q] = first workgroup of batch q.
-struct FleetRows {
-    const KArgs *k[MGX_FLEET_MAX];
-    const PLWords *tab[MGX_FLEET_MAX];
-    const void *actions[MGX_FLEET_MAX];
-    double *reward[MGX_FLEET_MAX];
-    uint8_t *done[MGX_FLEET_MAX];
-    void *obs[MGX_FLEET_MAX];
-    double *log[MGX_FLEET_MAX];
-    int32_t t[MGX_FLEET_MAX], flags[MGX_FLEET_MAX], block0[MGX_FLEET_MAX];
-    int32_t n, normalized;
-};
-
-static __global__ __launch_bounds__(ROWS_THREADS) void fleet_rows_kernel(const FleetRows fa)
-{
-    extern __shared__ double rows_lds[];
-    const KArgs *kp = fa.k[0];
-    const PLWords *tp = fa.tab[0];
-    const void *actions = fa.actions[0];
-    double *reward = fa.reward[0]; uint8_t *done = fa.done[0]; void *obs = fa.obs[0]; double *log = fa.log[0];
-    int32_t t = fa.t[0], flags = fa.flags[0], block0 = 0;
-#pragma unroll
-    for (int q = 1; q < MGX_FLEET_MAX; q++) {
-        const bool mine = q < fa.n && (int)blockIdx.x >= fa.block0[q];
-        kp = mine ? fa.k[q] : kp; tp = mine ? fa.tab[q] : tp;
-        actions = mine ? fa.actions[q] : actions; reward = mine ? fa.reward[q] : reward;
-        done = mine ? fa.done[q] : done; obs = mine ? fa.obs[q] : obs; log = mine ? fa.log[q] : log;
-        t = mine ? fa.t[q] : t; flags = mine ? fa.flags[q] : flags; block0 = mine ? fa.block0[q] : block0;
-    }
-    const KArgs &a = *kp;
-    const int64_t group = (int64_t)((int)blockIdx.x - block0);
-#define MGX_ROWS_CASE(FV)                                                                                                      \
-    case FV:                                                                                                                   \
-        if (a.obs_f32) rows_body<FV, float>(a, tp, actions, t, fa.normalized, reward, done, (float *)obs, log, group, rows_lds); \
-        else rows_body<FV, double>(a, tp, actions, t, fa.normalized, reward, done, (double *)obs, log, group, rows_lds);        \
-        break;
-    switch (flags) {
-        MGX_ROWS_CASE(1) MGX_ROWS_CASE(2) MGX_ROWS_CASE(3) MGX_ROWS_CASE(4) MGX_ROWS_CASE(5) MGX_ROWS_CASE(6) MGX_ROWS_CASE(7)
-        MGX_ROWS_CASE(14) MGX_ROWS_CASE(15)
-        default:
-            if (a.obs_f32) rows_body<0, float>(a, tp, actions, t, fa.normalized, reward, done, (float *)obs, log, group, rows_lds);
-            else rows_body<0, double>(a, tp, actions, t, fa.normalized, reward, done, (double *)obs, log, group, rows_lds);
-            break;
-    }
-#undef MGX_ROWS_CASE
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1953,268 +1737,6 @@ __global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a
     id = (id >= 0 && id < n_lists) ? id : 0;              // ids outside [0, n) fall back to list 0 (the reference raises)
     const uint32_t xv = populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t, control + i * A);
     if (violations) violations[i] = xv;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Resident step server (mgx_server_start / _post / _wait / _stop): the Gym cadence WITHOUT a launch per env-step.
-// One kernel stays on the chip for a whole burst of steps: every lane keeps its grid's parameters, dynamic state and bounds in
-// registers, step k takes its control from slot k % R of a ring of caller-owned buffers and leaves reward / done / observation
-// in the same slot.  Steps are RELEASED through a mailbox word -- `seq`, the number of steps posted so far: written in stream
-// order behind the kernel that produced the controls (hipStreamWriteValue32: a command-processor packet, no launch) or, when the
-// controls are already on the device, by a plain store of the host into mapped memory -- and COMPLETION comes back through a
-// signal word (`done`: hipStreamWaitValue32 / a polling consumer).
-//
-// Workgroups: ONE decider (block 0) + blocks_for(N) workers.  The decider alone reads the mailbox, the stop word and the
-// clock, and publishes `go` = how many steps are released (| FINAL when nothing more will come): a single decision point, so a
-// burst that ends (stop, idle timeout, lifetime cap: the kernel can never outlive its host) ends at the SAME step for every
-// grid.  Workers poll `go`, run released steps back to back (no barrier between workgroups: grids do not interact) and bump an
-// arrival counter per slot with a no-return atomic; the decider adds the counters up and advances `done`.
-// The series row of step t + 1 is loaded once: it is the "current value" of step t's observation and the input of step t + 1.
-// ------------------------------------------------------------------------------------------------------
-constexpr int SERVER_MAX_SLOTS = 8;
-constexpr int SERVER_LANES = 16;                  // arrival counters per slot (workgroup b bumps counter b % 16)
-constexpr uint32_t SERVER_FINAL = 0x80000000u;
-
-struct ServerSlot {
-    const void *actions;                          // [N, A] controls of the step (action format of the handle)
-    double *reward;                               // [N]
-    uint8_t *done;                                // [N] or NULL
-    void *obs;                                    // [N, D] (H = 0 rows), [N, S] (compact state) or NULL
-};
-
-struct ServerCtl {                                // device memory
-    uint32_t go;                                  // decider -> workers: steps released | SERVER_FINAL
-    uint32_t seq;                                 // host -> decider (stream-ordered posts): steps posted
-    uint32_t status;                              // 0 running, 1 stopped, 2 idle timeout, 3 lifetime cap
-    uint32_t steps_done;                          // steps every grid has taken when the kernel left
-    uint32_t arrive[SERVER_MAX_SLOTS][SERVER_LANES];      // monotonic: arrivals of all laps
-    ServerSlot slot[SERVER_MAX_SLOTS];
-};
-
-struct ServerHostWords {                          // pinned host memory, mapped: the host stores, the decider loads
-    volatile uint32_t seq;                        // immediate posts
-    volatile uint32_t stop;                       // 0 = run; n + 1 = leave once n steps have been taken
-};
-
-struct ServerArgs {
-    ServerCtl *ctl;
-    const ServerHostWords *host;
-    uint32_t *done_signal;                        // signal memory (hipStreamWaitValue32)
-    int32_t n_slots, n_workers, max_steps, normalized, immediate;
-    int64_t idle_ticks, life_ticks;               // 100 MHz ticks
-};
-
-// MGX_SERVER_SC1 (experiment): no L2-wide fences per step -- the controls are loaded and the outputs stored with agent-scope
-// (sc1) accesses instead, element by element
-#ifndef MGX_SERVER_SC1
-#define MGX_SERVER_SC1 0
-#endif
-template <typename T>
-__device__ __forceinline__ T server_load(const T *p)
-{
-    if constexpr (MGX_SERVER_SC1 != 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-template <typename T>
-__device__ __forceinline__ void server_store(T *p, T v)
-{
-    if constexpr (MGX_SERVER_SC1 != 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
-template <int F>
-__global__ __launch_bounds__(BLOCK) void step_server_kernel(const KArgs a, const ServerArgs sv, int32_t t0)
-{
-    ServerCtl *ctl = sv.ctl;
-    const int tid = threadIdx.x;
-    if (blockIdx.x == 0) {
-        // ---- the decider: one wave (block 0: dispatched first)
-        if (tid >= 64) return;
-        const int64_t born = wall_clock64();
-        int64_t last = born;
-        uint32_t released = 0, done = 0, status = 0;
-        bool final_out = false;
-        const uint32_t cap = (uint32_t)sv.max_steps;
-        while (true) {
-            uint32_t posted = 0, stop = 0;
-            if (tid == 0) {
-                posted = sv.immediate ? __hip_atomic_load((const uint32_t *)&sv.host->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                      : __hip_atomic_load(&ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                stop = __hip_atomic_load((const uint32_t *)&sv.host->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            posted = __shfl(posted, 0, 64); stop = __shfl(stop, 0, 64);
-            const int64_t now = wall_clock64();
-            uint32_t want = posted < cap ? posted : cap;
-            if (stop && want > stop - 1) want = stop - 1;
-            if (!final_out && want > released) {
-                released = want; last = now;
-                if (tid == 0) __hip_atomic_store(&ctl->go, released, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            // completion: slot s has finished its lap l when its 16 counters add up to n_workers (l + 1)
-            uint32_t nd = done;
-            while (nd < released) {
-                const uint32_t slot = nd % (uint32_t)sv.n_slots, lap = nd / (uint32_t)sv.n_slots;
-                uint32_t c = tid < SERVER_LANES ? __hip_atomic_load(&ctl->arrive[slot][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-                c = __shfl(c, 0, 64);
-                if (c < (uint32_t)sv.n_workers * (lap + 1)) break;
-                nd++;
-            }
-            if (nd != done) {
-                done = nd; last = now;
-                if (tid == 0) __hip_atomic_store(sv.done_signal, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            if (!final_out) {
-                if (stop && released >= stop - 1) status = 1;
-                else if (released >= cap) status = 1;
-                else if (now - born > sv.life_ticks) status = 3;
-                else if (done == released && now - last > sv.idle_ticks) status = 2;
-                if (status) {
-                    final_out = true;
-                    if (tid == 0) __hip_atomic_store(&ctl->go, released | SERVER_FINAL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            if (final_out && done == released) break;
-            if (final_out && now - last > sv.life_ticks) break;             // (a worker that never arrives: give up rather than spin forever)
-            __builtin_amdgcn_s_sleep(4);
-        }
-        if (tid == 0) {
-            ctl->steps_done = done; ctl->status = status;
-            // whoever waits on the signal for steps that will never be taken is let through (mgx_server_stop reports them)
-            if (status != 1 || (int32_t)done < sv.max_steps)
-                __hip_atomic_store(sv.done_signal, 0x7fffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        return;
-    }
-    // ---- a worker: 256 grids, one lane each
-    __shared__ uint32_t go_lds;
-    const int64_t N = a.N;
-    const uint32_t wb = blockIdx.x - 1;
-    const int64_t i = (int64_t)wb * BLOCK + tid;
-    const bool active = i < N;
-    const int64_t ic = active ? i : N - 1;
-    constexpr int A_DIM = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
-    constexpr bool GRID = (F & F_GRID) != 0;
-    Params p; State s; Derived d;
-    load_state<F>(a.c, ic, true, s);
-    load_params<F>(a.c, ic, p);
-    derive<F>(p, d);
-    const bool fact = factorised(a.c);
-    GridFactors f;
-    f.lr = 0.0; f.pr = 0.0; f.lp = 0u; f.pp = 0u; f.cp = 0u; f.pat = 0u;
-    if (fact) load_factors<F>(a.c, ic, f);
-    // observation bounds (whole H = 0 rows only)
-    const bool rows = a.obs_state_only == 0;
-    double lo[GRID ? 6 : 2], hi[GRID ? 6 : 2];
-#pragma unroll
-    for (int c = 0; c < (GRID ? 6 : 2); c++) { lo[c] = 0.0; hi[c] = 0.0; }
-    if (rows && a.c.load_lo != nullptr) {
-        lo[0] = a.c.load_lo[ic]; hi[0] = a.c.load_hi[ic]; lo[1] = a.c.pv_lo[ic]; hi[1] = a.c.pv_hi[ic];
-        if constexpr (GRID) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) { lo[2 + c] = a.c.grid_lo[c * N + ic]; hi[2 + c] = a.c.grid_hi[c * N + ic]; }
-        }
-    }
-    // the series row of a step: materialised arrays or the factors
-    auto series_at = [&](int32_t row, Inputs &in) __attribute__((always_inline)) {
-        const int64_t r = row < a.T ? row : a.T - 1;
-        if (fact) { fact_series<F>(a.c, N, ic, r, f, in, 0); return; }
-        in.load = a.c.load_ts[r * N + ic];
-        in.pv = a.c.pv_ts[r * N + ic];
-        in.g_stat = 1.0;
-        if constexpr (GRID) {
-            const double *g = a.c.grid_ts + (r * 4) * N + ic;
-            in.g_pimp = g[0]; in.g_pexp = g[N]; in.g_co2 = g[2 * N]; in.g_stat = g[3 * N];
-        }
-    };
-    Inputs cur;
-    series_at(t0, cur);
-    uint32_t k = 0;
-    while (true) {
-        if (tid == 0) {
-            uint32_t g;
-            while (true) {
-                g = __hip_atomic_load(&ctl->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((g & ~SERVER_FINAL) > k || (g & SERVER_FINAL)) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            // The controls of this step were written by another kernel: ONE acquire per workgroup (it invalidates the CU's L1 and
-            // the XCD's L2 for every wave that loads behind the barrier) -- one per wave made a step cost 74 us instead of ...
-            if constexpr (MGX_SERVER_SC1 == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            go_lds = g;
-        }
-        __syncthreads();
-        const uint32_t g = go_lds;
-        if ((g & ~SERVER_FINAL) <= k) break;                      // FINAL, and every released step has been taken
-        const uint32_t sl = k % (uint32_t)sv.n_slots;
-        const ServerSlot slot = ctl->slot[sl];
-        const int32_t t = t0 + (int32_t)k;
-        Inputs nxt;
-        if (active) {
-            Inputs in = cur;
-            if (a.act_f32) {
-                const float *ap = (const float *)slot.actions + i * A_DIM;
-                int q = 0;
-                if constexpr (F & F_GENSET) { in.a_goal = (double)server_load(ap + q); in.a_gen = (double)server_load(ap + q + 1); q += 2; }
-                if constexpr (F & F_BATTERY) { in.a_bat = (double)server_load(ap + q); q += 1; }
-                if constexpr (GRID) { in.a_grid = (double)server_load(ap + q); }
-            } else {
-                const double *ap = (const double *)slot.actions + i * A_DIM;
-                int q = 0;
-                if constexpr (F & F_GENSET) { in.a_goal = server_load(ap + q); in.a_gen = server_load(ap + q + 1); q += 2; }
-                if constexpr (F & F_BATTERY) { in.a_bat = server_load(ap + q); q += 1; }
-                if constexpr (GRID) { in.a_grid = server_load(ap + q); }
-            }
-            series_at(t + 1, nxt);                                // the row after: this step's observation, the next step's input
-            Outputs o;
-            step_core<F>(p, d, s, in, sv.normalized != 0, true, false, o);
-            server_store(slot.reward + i, shaped_reward<F>(a.shaper, o));
-            if (slot.done) server_store(slot.done + i, done_at(a, i, t));
-            if (slot.obs) {
-                constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
-                auto put = [&](auto *row) __attribute__((always_inline)) {
-                    typedef typename std::remove_pointer<decltype(row)>::type OT;
-                    OT stc[6] = {0, 0, 0, 0, 0, 0};                      // genset 4, battery 2 (static indices only: registers)
-                    observe_state_cols<F, OT>(a, p, s, stc, 0);
-                    if (!rows) {                                         // state columns: compact [N, S], or inside (ring) rows [N, D]
-                        const bool compact = a.obs_state_only == 2;
-#pragma unroll
-                        for (int j = 0; j < NSTATE; j++) {
-                            const int col = compact ? j : ((F & F_GENSET) != 0 && j < 4 ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0)));
-                            server_store(row + col, stc[j]);
-                        }
-                        return;
-                    }
-                    const bool in_series = t + 1 < a.T;
-                    server_store(row + a.col_load, (OT)obs_series_value(nxt.load, in_series, false, lo[0], hi[0], (hi[0] + lo[0]) / 2, space_spread(lo[0], hi[0])));
-                    server_store(row + a.col_pv, (OT)obs_series_value(nxt.pv, in_series, false, lo[1], hi[1], (hi[1] + lo[1]) / 2, space_spread(lo[1], hi[1])));
-#pragma unroll
-                    for (int j = 0; j < NSTATE; j++)
-                        server_store(row + ((F & F_GENSET) != 0 && j < 4 ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0))), stc[j]);
-                    if constexpr (GRID) {
-                        const double gv[4] = {nxt.g_pimp, nxt.g_pexp, nxt.g_co2, nxt.g_stat};
-#pragma unroll
-                        for (int c = 0; c < 4; c++)
-                            server_store(row + a.col_grid + c, (OT)obs_series_value(gv[c], in_series, false, lo[2 + c], hi[2 + c], (hi[2 + c] + lo[2 + c]) / 2,
-                                                                                     space_spread(lo[2 + c], hi[2 + c])));
-                    }
-                };
-                const int64_t pitch = a.obs_state_only == 2 ? NSTATE : a.obs_dim;
-                if (a.obs_f32) put((float *)slot.obs + i * pitch);
-                else put((double *)slot.obs + i * pitch);
-            }
-            cur = nxt;
-        }
-        __syncthreads();                                          // every wave's stores have been taken by the L2 (vmcnt(0) + barrier; also
-                                                                  // the last reader of go_lds is through)
-        if (tid == 0) {                                           // ... and ONE release per workgroup writes them back before the arrival
-            if constexpr (MGX_SERVER_SC1 != 0) __hip_atomic_fetch_add(&ctl->arrive[sl][wb & (SERVER_LANES - 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else __hip_atomic_fetch_add(&ctl->arrive[sl][wb & (SERVER_LANES - 1)], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        k++;
-    }
-    if (active) store_state<F>(a.c, i, s);
 }
 
 // one wave that idles for `ticks` of the 100 MHz real-time counter: mgx_fork staggers the shard streams with it

@@ -24,6 +24,23 @@ def shard_bounds(n_total, rank, world):
     return rank * per, (rank + 1) * per
 
 
+class _stdout_to_stderr:
+    """File-descriptor-level redirect of stdout into stderr: gloo announces its connections on stdout ("[Gloo] Rank 0 is connected
+    to ..."), and a bench's stdout is a one-line JSON contract."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -36,10 +53,13 @@ def init_from_env(backend=None):
         backend = backend or os.environ.get("MGX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
         global _ctrl
-        if backend != "gloo":              # every rank gets here: new_group is itself a collective over the default group's store
-            _ctrl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=CTRL_TIMEOUT_S))
+        with _stdout_to_stderr():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend != "gloo":          # every rank gets here: new_group is itself a collective over the default group's store
+                _ctrl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=CTRL_TIMEOUT_S))
+            if backend == "gloo" or _ctrl is not None:     # (gloo connects lazily: bring the control plane up -- and its banner out -- here)
+                dist.barrier(group=_ctrl)
     return rank, world, local
 
 

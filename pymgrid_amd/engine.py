@@ -113,10 +113,6 @@ class StepEngine:
         check(self._lib.mgx_set_action_format(self._h, 1 if dtype == torch.float32 else 0))
         self.action_dtype = dtype
 
-    def set_rows_direct(self, flag):
-        """``mgx_set_rows_direct``: step + whole observation row in one launch (factorised series, forecast horizon, no rings)."""
-        check(self._lib.mgx_set_rows_direct(self._h, 1 if flag else 0))
-
     def set_obs_state_only(self, flag):
         """True: the ``obs`` output of step / step_discrete / observe / reset receives only the genset / battery state
         columns -- the window columns of that row were written ahead of time by ``observe_windows``."""
@@ -189,7 +185,7 @@ class StepEngine:
 
     def set_ring_layout(self, columns):
         """``mgx_set_ring_layout``: True = column-major ring blocks -- the [N, D] observation of a block is then a view with
-        strides (1, pitch) (the pitch must be a multiple of 16: ``set_ring_pitch`` first)."""
+        strides (1, pitch) (the pitch must be a multiple of 32: ``set_ring_pitch`` first)."""
         check(self._lib.mgx_set_ring_layout(self._h, 1 if columns else 0))
         self._ring_columns = bool(columns)
 
@@ -725,56 +721,6 @@ class StepEngine:
         self._call(self._lib.mgx_expand_lists, _ptr(action_id), _ptr(lists), int(lists.shape[0]), int(lists.shape[1]),
                    _ptr(control), _ptr(self._mask_arg(violations)))
         return control
-
-    # ---- resident step server (mgx_server_*): the Gym cadence without a launch per env-step --------------------------------
-    def server_start(self, n_slots=4, max_steps=None, normalized=True, want_obs=True, want_done=False, idle_timeout_ms=200,
-                     immediate=False):
-        """Put the resident step kernel on the device (``mgx_server_start``) for a burst of up to ``max_steps`` steps (default:
-        to the end of the episode window).  Returns the ring of ``n_slots`` buffer sets -- a list of dicts ``actions`` [N, A],
-        ``reward`` [N], ``obs`` ([N, D] rows without a forecast horizon, [N, S] with compact state rows; None) and ``done`` --
-        step k uses slot k % n_slots: write the controls into ``slots[k % n_slots]["actions"]``, ``server_post()``, and read the
-        slot's outputs after ``server_wait()``.  Until ``server_stop()`` nothing else may be called on the engine, and the
-        device must not be synchronised as a whole (a stream's own ``synchronize()`` is fine)."""
-        from ._lib import SERVER_MAX_SLOTS, ServerSlot
-        if not 1 <= n_slots <= SERVER_MAX_SLOTS:
-            raise ValueError(f"n_slots must be in [1, {SERVER_MAX_SLOTS}]")
-        if max_steps is None:
-            max_steps = self.window[1] - self.current_step
-        compact = getattr(self, "_obs_compact", False)
-        D = self.state_dim if compact else self.obs_dim
-        slots = []
-        for _ in range(n_slots):
-            slots.append(dict(actions=torch.zeros(self.N, self.action_dim, dtype=self.action_dtype, device=self.device),
-                              reward=self._empty(self.N),
-                              obs=torch.empty(self.N, D, dtype=self.obs_dtype, device=self.device) if want_obs else None,
-                              done=self._empty(self.N, dtype=torch.uint8) if want_done else None))
-        arr = (ServerSlot * n_slots)()
-        for a, sl in zip(arr, slots):
-            a.actions, a.reward, a.done, a.obs = _ptr(sl["actions"]), _ptr(sl["reward"]), _ptr(sl["done"]), _ptr(sl["obs"])
-        self._call(self._lib.mgx_server_start, arr, n_slots, 1 if normalized else 0, int(max_steps), int(idle_timeout_ms),
-                   1 if immediate else 0)
-        self._server_slots = slots
-        return slots
-
-    def server_post(self):
-        """Release the next step once torch's current stream gets here (behind the kernel that wrote the slot's controls)."""
-        self._call(self._lib.mgx_server_post)
-
-    def server_wait(self):
-        """Torch's current stream waits until every posted step has been taken by every grid."""
-        self._call(self._lib.mgx_server_wait)
-
-    def server_stop(self):
-        """End the burst: posted steps are finished, the state columns written back, the counter moved.  Returns the number of
-        steps taken; raises MgxError(MGX_ERR_RANGE) when the burst had ended early (idle timeout) with posts unserved."""
-        n = C.c_int32(0)
-        rc = self._lib.mgx_server_stop(self._h, C.byref(n))
-        if self._t is not None:
-            self._t += int(n.value)
-        self._server_slots = None
-        if rc:
-            check(rc)
-        return int(n.value)
 
     def metrics(self, values, out=None):
         """Column sums over the grids: values [M, N] -> [M] (deterministic LDS + wavefront-shuffle reduction)."""

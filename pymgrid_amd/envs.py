@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from .batch import module_list, MicrogridBatch, unpack_status
-from .engine import StepEngine
+from .engine import StepEngine, _raw_stream
 from .priority_list import MODULE_NAMES, get_instance_priority_lists, get_priority_lists, lists_array, table_array
 from .spaces import Box, Discrete
 from .trajectory import check_trajectory_output, shaper_kind
@@ -104,6 +104,14 @@ class ObsViews:
         return torch.cat([parts[name] for name, n, _ in self.layout._blocks() if n], dim=1)      # the layout's flat_order
 
 
+class _FastPlan:
+    """What ``BatchedMicrogridEnv.step`` needs once ``mgx_env_bind`` has taken over the per-step bookkeeping: the C entry point and
+    the pre-built tensors a step returns.  The handle walks the rotating output slots and the observation rings itself
+    (include/mgx.h, mgx_env_step); ``k`` / ``p`` mirror its position so that the right views are handed back."""
+    __slots__ = ("fn", "fn_discrete", "h", "dev", "guard", "adt", "ashape", "R", "k", "p", "nring", "obs", "rew", "done", "dconst",
+                 "last", "pergrid", "keep")
+
+
 class BatchedMicrogridEnv:
     """``BaseMicrogridEnv`` for N microgrids advancing in lock-step (continuous control surface =
     ``Microgrid.run(control, normalized)``; the reference's own ContinuousMicrogridEnv is non-functional in
@@ -114,7 +122,7 @@ class BatchedMicrogridEnv:
 
     def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
                  raise_errors=False, observation_keys=None, obs_dtype=torch.float64, obs_prefetch=None,
-                 action_dtype=torch.float64, obs_views=False, reuse_outputs=0, obs_direct=False, obs_layout="rows"):
+                 action_dtype=torch.float64, obs_views=False, reuse_outputs=0, obs_layout=None):
         if not isinstance(batch, MicrogridBatch):
             raise TypeError("batch must be a MicrogridBatch")
         # raise_errors=True (base_module.py:79-93): every step is preceded by its dry run (mgx_check_step: the violations
@@ -148,14 +156,6 @@ class BatchedMicrogridEnv:
                 raise ValueError("obs_views needs observations=True, one module of every kind per grid, the oracle forecaster "
                                  "and no observation_keys")
             obs_prefetch = 0
-        # obs_direct=True (factorised series, forecast horizon): no rings -- the stepping launch itself forms and writes every
-        # row (mgx_set_rows_direct: one launch per step instead of two; what small batches want; latency-bound and twice the rings' time at 100 000 grids)
-        if obs_direct:
-            if not batch.factorised or L.multi or noisy or obs_views or not observations:
-                raise ValueError("obs_direct needs factorised series, one module of every kind per grid, the oracle forecaster, "
-                                 "observations=True and no obs_views")
-            self.engine.set_rows_direct(True)
-            obs_prefetch = 0
         # (several modules of a kind per grid: the general refill kernel, row-major blocks, lock-step episodes over [T, n, N] series)
         self._prefetch_ok = bool(observations and L.horizon > 0 and not noisy and not (L.multi and (obs_layout == "columns" or batch.factorised)))
         self._obs_dtype = obs_dtype
@@ -167,9 +167,14 @@ class BatchedMicrogridEnv:
         # return [N, D] tensors -- views with strides (1, pitch): the same matrix, what `obs @ W` takes either way -- but the state
         # columns a step adds are then six coalesced runs instead of 48 bytes per row at a 8 D-byte stride (100 000 scattered
         # partial lines per step: 3.5-4 us of a config-5 fleet step).  ``obs.contiguous()`` gives the row-major copy.
-        if obs_layout not in ("rows", "columns"):
-            raise ValueError("obs_layout must be 'rows' or 'columns'")
-        self._obs_columns = obs_layout == "columns"
+        # obs_layout=None (default): column-major blocks wherever the rings are walked in lock-step by one module of every kind
+        # per grid (what a config-5 fleet does: 23.6-24 instead of 24.5-27 us per 100 000-grid fleet step, profiles/r04), and the
+        # env switches ITSELF to row-major rings when per-grid episodes begin (restarted grids are patched into row-major rings)
+        # and back at the next lock-step reset.  "rows" / "columns" pin the layout ("columns" then refuses per-grid episodes).
+        if obs_layout not in (None, "rows", "columns"):
+            raise ValueError("obs_layout must be None (automatic), 'rows' or 'columns'")
+        self._obs_layout_auto = obs_layout is None
+        self._obs_columns = (obs_layout == "columns") if obs_layout is not None else not L.multi
         self._ring = self._rings = self._ring_store = None
         # Position inside ring 0 at which a refill starts the walk (0 <= phase < K): the first ring after a reset is then
         # K - phase blocks long and every later ring change falls phase steps EARLIER than that of an env with phase 0.  A fleet
@@ -241,6 +246,113 @@ class BatchedMicrogridEnv:
             self._obs_index = torch.as_tensor(idx, dtype=torch.long, device=batch.device)
         D = len(self._obs_index) if self._obs_index is not None else self.layout.obs_dim
         self.observation_space = Box(0.0, 1.0, shape=(D,))                  # normalised observation
+        # The per-step bookkeeping (which output buffers, which ring block, when to prefetch) moves into the C ABI wherever a step
+        # returns nothing but pre-allocated buffers (reuse_outputs, no log rows, no observation_keys, no views): mgx_env_bind once,
+        # then env.step = one mgx_env_step call (a single-step kernel takes ~5 us at N = 100 000: every microsecond of Python
+        # between two launches is a microsecond per env-step).  _rebind_fast() after everything that moves buffers or counters.
+        self._fp = None
+        self._fast_ok = True           # False: this env belongs to a fused fleet (stepped through mgx_fleet_step)
+        self._rebind_fast()
+
+    # ---- the bound Gym step (mgx_env_bind / mgx_env_step) ---------------------------------------------------
+    def _fast_eligible(self):
+        e = self.engine
+        return bool(self._fast_ok and self._reuse and not self.raise_errors and not self._keep_log and self._obs_index is None
+                    and not self._views and not self._chunked and not self._fleet_owned and not self._sync_rings
+                    and e._t is not None and not e._dev_counter and e.n_shards == 1 and not getattr(self, "check_asserts", False)
+                    and not (isinstance(self, DiscreteBatchedMicrogridEnv) and self.layout.multi)
+                    and not (self._ring is not None and (self._ring_phase or e._window_start is not None)))
+
+    def _unbind_fast(self):
+        """Back to per-call bookkeeping: the Python-side positions take over from where the handle stands."""
+        fp, self._fp = self._fp, None
+        if fp is None:
+            return
+        self._out_pos = fp.k
+        if fp.nring:
+            K = self.obs_prefetch
+            self._ring_idx, self._ring_pos = divmod(fp.p, K)
+            self._ring = self._rings[self._ring_idx]
+        if self.engine._h.value:
+            self.engine._lib.mgx_env_bind(self.engine._h, None)
+
+    def _rebind_fast(self):
+        """(Re)bind the env's rotating buffers to the handle at the env's CURRENT position; called at the end of everything that
+        changes them (construction, resets, set_obs_prefetch).  Leaves ``_fp`` None where a step needs host work."""
+        import ctypes as C
+        self._unbind_fast()
+        if not self._fast_eligible():
+            return
+        e, R = self.engine, self._reuse
+        if R > _lib.ENV_MAX_SLOTS:
+            return
+        pergrid = e._window_start is not None
+        if pergrid and self._done_bufs is None:
+            self._done_bufs = torch.empty(R, self.n_grids, dtype=torch.uint8, device=self.batch.device)
+        slots = (_lib.EnvSlot * R)()
+        for k in range(R):
+            slots[k].reward = self._rew_bufs[k].data_ptr()
+            slots[k].done = self._done_bufs[k].data_ptr() if pergrid else None
+            slots[k].obs = self._obs_bufs[k].data_ptr() if (self._obs_bufs is not None and self._ring is None and self._observations) else None
+        plan = _lib.EnvPlan()
+        plan.struct_size = C.sizeof(_lib.EnvPlan)
+        plan.n_slots, plan.slots = R, slots
+        K = self.obs_prefetch if self._ring is not None else 0
+        plan.ring_K = K
+        if K:
+            for r in range(3):
+                plan.rings[r] = self._rings[r].data_ptr()
+        table = getattr(self, "_table", None)
+        if table is not None:
+            tptr, n_lists = e._table_ptr(table)
+            plan.table, plan.n_actions = tptr, n_lists
+        if e._lib.mgx_env_bind(e._h, C.byref(plan)):
+            return                                 # (a mode the handle walks no rings in: per-call bookkeeping stays)
+        if e._lib.mgx_env_seek(e._h, self._out_pos, self._ring_idx if K else 0, self._ring_pos if K else 0):
+            e._lib.mgx_env_bind(e._h, None)
+            return
+        fp = _FastPlan()
+        fp.fn, fp.fn_discrete, fp.h, fp.dev, fp.guard = e._lib.mgx_env_step, e._lib.mgx_env_step_discrete, e._h, e._dev_index, not e._only_device
+        fp.adt, fp.ashape = e.action_dtype, torch.Size(e._action_shape)
+        fp.R, fp.k = R, self._out_pos
+        fp.nring = 3 * K
+        fp.p = (self._ring_idx * K + self._ring_pos) if K else 0
+        if K:
+            fp.obs = [self._rings[r][k] for r in range(3) for k in range(K)]
+        elif self._obs_bufs is not None and self._observations:
+            fp.obs = [self._obs_bufs[k] for k in range(R)]
+        else:
+            fp.obs = [None] * R
+        fp.rew = [self._rew_bufs[k] for k in range(R)]
+        fp.pergrid = pergrid
+        fp.done = [self._done_bufs[k].view(torch.bool) for k in range(R)] if pergrid else None
+        fp.dconst, fp.last = self._done_const, e.window[1] - 1
+        fp.keep = (slots, plan)
+        self._fp = fp
+
+    def _step_fast(self, fp, fn, action):
+        """One bound step: the controls' address in, the pre-built views of the slot / ring block the handle used out."""
+        e = self.engine
+        t = e._t
+        if fp.guard and torch.cuda.current_device() != fp.dev:
+            with torch.cuda.device(fp.dev):
+                rc = fn(*action, _raw_stream(fp.dev))
+        else:
+            rc = fn(*action, _raw_stream(fp.dev))
+        if rc:
+            _lib.check(rc)
+        e._t = t + 1
+        k = fp.k
+        fp.k = k + 1 if k + 1 < fp.R else 0
+        if fp.nring:
+            p = fp.p + 1
+            if p == fp.nring:
+                p = 0
+            fp.p = p
+            obs = fp.obs[p]
+        else:
+            obs = fp.obs[k]
+        return obs, fp.rew[k], (fp.done[k] if fp.pergrid else fp.dconst[t >= fp.last]), {}
 
     # ---- reference-like properties ------------------------------------------------------------------
     @property
@@ -276,11 +388,21 @@ class BatchedMicrogridEnv:
     # ---- Gym API --------------------------------------------------------------------------------------
     def reset(self, initial_step=None):
         """Microgrid.reset: step counter back to ``initial_step``, logs flushed, state NOT restored."""
+        self._unbind_fast()
+        obs = self._reset(initial_step)
+        self._rebind_fast()
+        return obs
+
+    def _reset(self, initial_step=None):
         self._log_rows = []
         self._shaped_rows = []
         if self.trajectory_func is not None and initial_step is None:
             self._draw_window()
         self._sync_rings = False
+        if self._obs_layout_auto and self._ring is not None and not self._obs_columns and not self.layout.multi \
+                and not self._chunked and not self._fleet_owned:
+            self.engine.reset(initial_step, want_obs=False)    # lock-step again: leave the per-grid mode, then column-major blocks
+            self._set_ring_columns(True)
         if self._views:
             if self.engine._window_start is not None:          # back from a per-grid-window episode: the full series again
                 self.engine.reset(initial_step, want_obs=False)
@@ -314,6 +436,12 @@ class BatchedMicrogridEnv:
         return ov
 
     def reset_windows(self, start, length=None, max_length=None, rolling=False, validate=True):
+        self._unbind_fast()
+        obs = self._reset_windows(start, length, max_length, rolling, validate)
+        self._rebind_fast()
+        return obs
+
+    def _reset_windows(self, start, length=None, max_length=None, rolling=False, validate=True):
         """Per-grid episodes (``mgx_reset_windows``; the reference's per-microgrid trajectories, microgrid.py:205-225,
         trajectory/stochastic.py:9-30): grid i starts at series row ``start[i]`` and is ``done`` after ``length[i]`` steps
         (``length=None``: ``max_length`` steps for every grid).  The batch still advances in lock-step; ``current_steps``
@@ -333,6 +461,8 @@ class BatchedMicrogridEnv:
         start, length = as_i32(start), as_i32(length)
         self._log_rows = []
         self._shaped_rows = []
+        if self._ring is not None and self._obs_columns and self._obs_layout_auto and not self._fleet_owned:
+            self._set_ring_columns(False)            # per-grid episodes patch restarted grids into ROW-major rings
         if rolling:
             if self._views:
                 raise RuntimeError("obs_views: not offered for rolling windows (restarts rewrite series rows)")
@@ -432,6 +562,7 @@ class BatchedMicrogridEnv:
         K = int(K) if (K and int(K) > 1 and self._prefetch_ok) else 0
         if K == self.obs_prefetch:
             return
+        self._unbind_fast()
         if (self._chunked or self._fleet_owned) and K != self.obs_prefetch:
             raise RuntimeError("this env belongs to a fused BucketedFleet (its step plans hold the ring pointers): the ring "
                                "depth is fixed; build the fleet with the obs_prefetch you want")
@@ -445,6 +576,7 @@ class BatchedMicrogridEnv:
         if K:
             self._alloc_rings(K)
             self._refill()
+        self._rebind_fast()
 
     def _alloc_rings(self, K):
         """Three rings of K row blocks.  A block holds N rows; blocks are P = N rounded up to 32 rows apart, so that every block
@@ -462,11 +594,22 @@ class BatchedMicrogridEnv:
             self._ring_store = torch.empty(3, K, pitch, L.obs_dim, dtype=self._obs_dtype, device=self.batch.device)
             self._rings = self._ring_store[:, :, :L.n_grids]
 
+    def _set_ring_columns(self, columns):
+        """Re-allocate the rings in the other block layout (automatic layout only; the caller refills them)."""
+        self.engine.prefetch_wait()                  # the old rings may still be written by a prefetch
+        self._obs_columns = bool(columns)
+        self._ring = self._rings = self._ring_store = None
+        self._alloc_rings(self.obs_prefetch)
+        self._ring_idx, self._ring_pos = 0, 0
+        self._ring = self._rings[0]
+
     def _after_external_steps(self):
         """The engine was stepped behind the env's back (fused rollouts: ``RuleBasedControl.run``, ``engine.step_k``): the
         observation rings no longer match the counter -- refill them at the current step."""
+        self._unbind_fast()
         if self._ring is not None and self.engine.current_step <= self.layout.n_steps:
             self._refill()
+        self._rebind_fast()
 
     def _refill(self):
         """Fill ring 0 for the counter values t .. t + K - 1 (block 0 complete: current state) and start the prefetch of
@@ -584,6 +727,14 @@ class BatchedMicrogridEnv:
         a control dict as taken by ``Microgrid.run``.  Returns (obs [N, D], reward [N], done [N] bool, info)."""
         if isinstance(action, dict):
             action = self.control_to_tensor(action).to(self.engine.action_dtype)
+        fp = self._fp
+        if fp is not None:
+            if self.engine._t is None:    # the counter moved to the device (graph capture): per-call bookkeeping from here on
+                self._unbind_fast()
+            else:
+                if not (action.dtype is fp.adt and action.shape == fp.ashape and action.is_contiguous() and action.is_cuda):
+                    self.engine._check_actions(action, ())           # raises with the full message
+                return self._step_fast(fp, fp.fn, (fp.h, action.data_ptr(), 1 if normalized else 0))
         if self.raise_errors:             # dry run first (mgx_check_step): a refused request raises BEFORE anything is applied
             self._raise_on_violations(self.engine.check_step(action, normalized=normalized))
         want_obs, out = self._obs_target()
@@ -751,11 +902,11 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
 
     def __init__(self, batch, log=False, observations=True, remove_redundant_gensets=True, reward_shaping_func=None,
                  trajectory_func=None, raise_errors=False, observation_keys=None, obs_dtype=torch.float64,
-                 obs_prefetch=None, obs_views=False, reuse_outputs=0, check_asserts=False, obs_direct=False, obs_layout="rows"):
+                 obs_prefetch=None, obs_views=False, reuse_outputs=0, check_asserts=False, obs_layout=None):
         super().__init__(batch, log=log, observations=observations, reward_shaping_func=reward_shaping_func,
                          trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
                          obs_dtype=obs_dtype, obs_prefetch=obs_prefetch, obs_views=obs_views, reuse_outputs=reuse_outputs,
-                         obs_direct=obs_direct, obs_layout=obs_layout)
+                         obs_layout=obs_layout)
         # check_asserts=True (implied by raise_errors=True): DiscreteMicrogridEnv.step gives up with an AssertionError in a few
         # states whatever raise_errors says -- _populate_action's asserts (priority_list.py:73,121,124,135,154: a lossy battery
         # rounded one ulp above max_capacity with load left to absorb) and the step's (base_module.py:272).  The device goes on
@@ -785,6 +936,7 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
             self.actions_list = get_priority_lists(L.has_genset, L.has_battery, L.has_grid, bool(redundant), L.grid_before_battery)
             self._table = table_array(self.actions_list)
         self.action_space = Discrete(len(self.actions_list))
+        self._rebind_fast()                  # (with the priority-list table and check_asserts known)
 
     def remove_action(self, action_number):
         """``DiscreteMicrogridEnv.remove_action`` (envs/discrete/discrete.py:90-106): drop one priority list from the action
@@ -797,6 +949,7 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
         else:
             self._table = table_array(self.actions_list)
         self.action_space = Discrete(self.action_space.n - 1)
+        self._rebind_fast()
 
     def get_action(self, action_id, violations=None):
         """DiscreteMicrogridEnv._get_action: ids [N] -> unnormalised control [N, A].  ``violations``: optional int32 [N] tensor
@@ -826,6 +979,14 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
             action_id = action_id.to(device=self.batch.device, dtype=torch.int32).contiguous()
         if self.check_asserts:
             self._raise_on_violations(self.engine.check_discrete(action_id, self._table), asserts_only=not self.raise_errors)
+        fp = self._fp
+        if fp is not None:
+            if self.engine._t is None:
+                self._unbind_fast()
+            else:
+                if action_id.shape != (self.n_grids,):
+                    raise ValueError(f"action_id must be an int32 tensor of shape ({self.n_grids},) on {self.batch.device}")
+                return self._step_fast(fp, fp.fn_discrete, (fp.h, action_id.data_ptr()))
         want_obs, out = self._obs_target()
         dconst = self._lockstep_done()
         obs, reward, done, log, _ = self.engine.step_discrete(action_id, self._table, want_obs=want_obs,

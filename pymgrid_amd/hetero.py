@@ -54,6 +54,8 @@ class BucketedFleet:
         for env in self.envs:
             env._chunked = self.fused and self.refill == "chunks" and not L_multi(env.layout)
             env._fleet_owned = self.fused
+            env._fast_ok = not self.fused       # a fused fleet steps its envs through mgx_fleet_step: no bound env steps
+            env._rebind_fast()
         # stagger: bucket j's rings change j * K / n_buckets steps before bucket 0's, so that the buckets' ring refills -- each a
         # burst of K row blocks on a prefetch stream -- start at different fleet steps instead of all at once
         ringed = [env for env in self.envs if env.obs_prefetch]
@@ -74,7 +76,6 @@ class BucketedFleet:
         self.reuse_outputs = int(reuse_outputs)
         self._want_fused = bool(fused)
         self._plans, self._n_steps, self._out_reward, self._out_done, self._out_obs = {}, 0, None, None, None
-        self._no_info = [{} for _ in range(64)]                 # the per-bucket `info` of a step without log rows (shared, empty)
 
     @classmethod
     def from_batches(cls, batches, discrete=False, streams=False, reuse_outputs=0, fused=True, refill="ahead", stagger=None,
@@ -319,7 +320,7 @@ class BucketedFleet:
                 e._t += 1                         # the host mirror of the handle's counter (mgx_fleet_step moved it)
             if env._views:
                 obs_l[k] = env._view_now()
-        return obs_l, list(reward_l), done_l, self._no_info[:n]
+        return obs_l, list(reward_l), done_l, [{} for _ in range(n)]      # (fresh dicts: Gym wrappers write into info)
 
     def sample_action(self, generator=None):
         return [env.sample_action(generator=generator) for env in self.envs]
@@ -392,6 +393,7 @@ class PerGridWindowEnv:
         if native and not self.auto_reset:
             raise ValueError("native=True is the auto_reset=True path (equal-length windows are gathered once per reset)")
         self.native = bool(native)
+        env_kwargs.setdefault("obs_layout", "rows")       # restarted grids are patched into row-major rings (mgx_patch_windows)
         self.env = cls(full_batch, **env_kwargs)
         self.starts = self.lengths = None
         self._final_bufs = None

@@ -10,22 +10,71 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--grids", "20000", "--rows", "700", "--steps", "6", "--warmup", "2", "--chunk", "32", "--hetero-steps", "16",
-         "--cpu-seconds", "1", "--prewarm", "0.05"]
+SMALL = ["--grids", "20000", "--rows", "700", "--steps", "3", "--warmup", "1", "--chunk", "32", "--launches-per-step", "2",
+         "--hetero-steps", "16", "--cpu-seconds", "1", "--prewarm", "0.05"]
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
         "dtype", "data", "config", "roofline", "cpu_baseline"}
+MAX_LINE = 4096          # bench.MAX_LINE: the driver keeps a bounded tail of stdout (round 4's 22-KB line did not parse)
 
 
 def _line(out):
-    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    """The contract: stdout is exactly ONE non-empty line, a JSON record shorter than MAX_LINE."""
+    lines = [ln for ln in out.splitlines() if ln.strip()]
     assert len(lines) == 1, out[-2000:]
+    assert len(lines[0]) < MAX_LINE, len(lines[0])
     return json.loads(lines[0])
 
 
-def gp_rows_ok(d):
-    """the general path's Gym step with whole rows off prefetched rings (round 4)"""
-    g = d["general_path_2g2b1grid"].get("gym_steps_rows_h24")
-    return g is not None and g["value"] > 0 and g["roofline"]["frac"] > 0 and g["obs_dim"] == 162
+def _fake_leg(us=5.123456789, frac=0.51234567, lat=None, traffic=1.0e8):
+    rf = {"bound": "hbm", "achieved": 4098.7654321, "peak": 8000.0, "unit": "GB/s", "frac": frac, "frac_wall": frac, "traffic": traffic,
+          "traffic_source": "profiles/r05/traffic.json", "algorithmic_bytes_per_launch": 98765432.1, "kernel": "k" * 60, "avg_launch_us": us,
+          "launches": 1234, "bytes_per_env_step": 42.9375}
+    if lat is not None:
+        rf["frac_of_latency_model"] = lat
+    return {"value": 1.23456789e10, "us_per_step": us, "roofline": rf, "note": "x" * 400}
+
+
+def test_compact_line_stays_parseable_whatever_the_legs_hold():
+    """The stdout record is built from the full record by bench.compact_line: with EVERY leg present (--all-legs, long floats, long
+    notes) it stays under MAX_LINE, keeps the contract's keys, and sheds legs -- never the headline -- if it had to."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.MAX_LINE == MAX_LINE
+    other = {n: _fake_leg(lat=0.61234 if "single" in n else None) for n in (
+        "single_step_launches_one_call", "single_step_launches_python_loop", "single_step_launches_python_loop_with_rows",
+        "rbc_rollout_on_device", "fused_launches_one_stream", "fused_launches_materialised", "fused_launches_materialised_one_stream",
+        "rbc_rollout_materialised")}
+    hetero = {f"{dt}_{c}": _fake_leg() for dt in ("float64", "float32") for c in ("rows", "rows_rowmajor", "views")}
+    hetero.update(grids_per_gpu=99999, workload="w" * 300)
+    general = {k: _fake_leg() for k in ("single_steps", "k_step_launches", "gym_steps_rows_h24")}
+    detail = {"metric": "microgrid env-steps/sec", "value": 1.2345678901234e11, "unit": "env-steps/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+              "ms_per_step": 0.8412345678, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "config": {"workload": "100000 generated 4-module grids (genset+battery+load+pv) per GPU, T=8760, H=0, normalised random actions "
+                                     "(BASELINE configs[2])", "env_steps_per_step": 1024, "steps_per_launch": 64, "grids_per_gpu": 100000,
+                         "grids_total": 800000, "mode": "fused", "series": "factorised", "backend": "nccl",
+                         "parallelism": "grids sharded x8 ranks, no data-path collective; 2 shard streams per GPU", "step": "s" * 200},
+              "roofline": dict(_fake_leg()["roofline"], round_us={"n": 640, "what": "y" * 500}), "roofline_valu": {"frac": 0.4512345},
+              "csrc_hash": "0123456789abcdef", "per_rank_env_steps_per_s": [1.54321098765e10] * 8,
+              "cpu_baseline": {"value": 3.0261e8, "unit": "env-steps/s", "cores": 16, "kind": "port", "value_1thread": 2.12e7,
+                               "host_logical_cpus": 384, "sample": "z" * 400, "sample_short": "first 65536 grids x 64 steps, ~10 s, oracle/mgx_oracle.c"},
+              "other": other, "hetero_h24_gym_steps": hetero, "general_path_2g2b1grid": general,
+              "closed_loop_policy_gym_steps": {"us_per_step": 31.4159, "loop": "l" * 900},
+              "metrics_allreduce": {"sum_last_reward": -1.2345678901234567e9, "mean_soc": 0.61234567890123, "collective_backend": "nccl"}}
+    text = bench.compact_line(detail, "fused", "bench_detail.json")
+    d = json.loads(text)
+    assert len(text) < MAX_LINE and KEYS <= set(d)
+    assert d["value"] == detail["value"] and d["ms_per_step"] == detail["ms_per_step"] and d["n_gpus"] == 8
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel", "avg_launch_us"}
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "value_1thread"}
+    assert len(d["per_rank_env_steps_per_s"]) == 8 and d["csrc_hash"] == "0123456789abcdef"
+    assert {"single_step_launches_python_loop", "config5_float64_rows", "config5_float32_rows", "general_single_step", "general_k_step",
+            "general_gym_rows_h24"} <= set(d["legs"])
+    assert d["legs"]["single_step_launches_python_loop"] == {"us": 5.123, "frac": 0.5123, "lat": 0.6123, "t/a": 1.012}
+    # a record that would not fit sheds legs, never the headline
+    detail["other"].update({f"extra_leg_{j}_{'n' * 40}": _fake_leg() for j in range(60)})
+    text = bench.compact_line(detail, "fused", "bench_detail.json")
+    d = json.loads(text)
+    assert len(text) < MAX_LINE and KEYS <= set(d) and "config5_float64_rows" in d["legs"] and not any(k.startswith("extra") for k in d["legs"])
 
 
 def test_gpus_n_launches_its_own_ranks_cpu():
@@ -49,36 +98,51 @@ def test_gpus_mismatch_fails_loudly():
 
 
 @pytest.mark.gpu
-def test_bench_one_rank_json_line(device):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600)
+def test_bench_one_rank_json_line(device, tmp_path):
+    det = str(tmp_path / "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--detail", det] + SMALL, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
-    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
     rf = d["roofline"]
-    assert set(rf) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and rf["bound"] == "hbm"
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert rf["launches"] == 6 and rf["series"] == "factorised" and "frac_wall" in rf     # every timed round is one full-K launch
-    assert rf["concurrent_streams"] == 2                                                  # ... per shard stream
-    assert rf["kernel"] == "step_k_kernel<3,4,double,false,true>" and abs(rf["bytes_per_env_step"] - (158 / 32 + 40)) < 1e-9
-    assert abs(d["value"] - 20000 * 6 * 32 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
-    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert set(rf) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel", "avg_launch_us"}
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["launches"] == 3 * 2                                    # every timed step is --launches-per-step full-K launches per shard stream
+    assert rf["kernel"] == "step_k_kernel<3,4,double,false,true>" and abs(rf["bytes_per_env_step"] - (158 / 32 + 40)) < 0.01
+    assert d["config"]["env_steps_per_step"] == 64 and d["config"]["series"] == "factorised"
+    assert abs(d["value"] - 20000 * 3 * 64 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "value_1thread"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and d["scaling"] == "weak" and d["higher_is_better"] is True
-    for k in ("float64_rows", "float32_rows", "float64_rows_colmajor", "float32_rows_colmajor", "float64_views", "float32_views"):
-        assert set(d["hetero_h24_gym_steps"][k]["roofline"]) >= {"bound", "achieved", "peak", "frac", "frac_wall", "traffic"}, k
-    assert {"fused_launches_one_stream", "fused_launches_materialised", "fused_launches_materialised_one_stream", "rbc_rollout_materialised",
-            "single_step_launches_one_call", "rbc_rollout_on_device", "single_step_launches_python_loop"} <= set(d["other"])
-    assert all("error" not in v for v in d["other"].values())
-    assert d["other"]["fused_launches_materialised"]["roofline"]["concurrent_streams"] == 2
-    # round 4: the spread of the timed rounds, which kernels ran, the issue-side roofline block, the general path and the server
-    ru = rf["round_us"]
-    assert ru["n"] == 6 * rf["concurrent_streams"] and ru["min"] <= ru["median"] <= ru["max"] and ru["min"] <= ru["mean"] <= ru["max"]
-    assert gp_rows_ok(d)
+    legs = d["legs"]
+    assert {"single_step_launches_one_call", "single_step_launches_python_loop", "single_step_launches_python_loop_with_rows",
+            "config5_float64_rows", "config5_float32_rows", "general_single_step", "general_k_step", "general_gym_rows_h24"} <= set(legs)
+    assert all("error" not in v and v["us"] > 0 and v["frac"] > 0 for v in legs.values()), legs
+    assert legs["single_step_launches_python_loop"]["lat"] > 0 and legs["general_single_step"]["lat"] > 0
     from pymgrid_amd import _lib
-    assert d["csrc_hash"] == _lib.source_hash() and d["roofline_valu"]["bound"] == "valu"
+    assert d["csrc_hash"] == _lib.source_hash()
     assert rf["traffic"] is None or "STALE" not in str(rf["traffic_source"])          # a stale counter file is never quoted
-    gp = d["general_path_2g2b1grid"]
-    assert "error" not in gp and gp["single_steps"]["roofline"]["bytes_per_env_step"] == 8 * (7 + 27 + 6 + 2 * 2 + 2) + 2 * 8 + 8
-    assert gp["k_step_launches"]["value"] > 0 and d["resident_step_server"]["steps"] == 600
+    # the full record beside it
+    full = json.load(open(det))
+    assert full["value"] == d["value"] and full["roofline"]["concurrent_streams"] == 2 and full["roofline"]["series"] == "factorised"
+    ru = full["roofline"]["round_us"]
+    assert ru["n"] == 6 * 2 and ru["min"] <= ru["median"] <= ru["max"]
+    assert full["roofline_valu"]["bound"] == "valu"
+    gp = full["general_path_2g2b1grid"]
+    assert gp["single_steps"]["roofline"]["bytes_per_env_step"] == 8 * (7 + 27 + 6 + 2 * 2 + 2) + 2 * 8 + 8 and gp["gym_steps_rows_h24"]["obs_dim"] == 162
+    assert full["other"]["single_step_launches_python_loop"]["roofline"]["bound"] == "latency"
+    assert "bench_detail " in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_all_legs_still_one_short_line(device, tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--all-legs", "--no-cpu-baseline", "--detail", str(tmp_path / "d.json")] + SMALL,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert {"rbc_rollout_on_device", "fused_launches_one_stream", "fused_launches_materialised", "config5_float64_rows_rowmajor",
+            "config5_float32_views", "closed_loop_policy"} <= set(d["legs"]) and d["cpu_baseline"] is None
+    assert all("error" not in v for v in d["legs"].values()), d["legs"]
+    assert d["legs"]["config5_float64_views"]["lat"] > 0
 
 
 @pytest.mark.gpu
@@ -91,6 +155,32 @@ def test_bench_two_ranks_self_launched(device):
     d = _line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["grids_total"] == 40000 and d["value"] > 0
     assert len(d["per_rank_env_steps_per_s"]) == 2 and d["cpu_baseline"]["kind"] == "port"
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu_equal_one_rank(device):
+    """The 8-GPU launch path without an 8-GPU node: `python bench.py --gpus 8` (self-launching, one rank per "GPU") with every rank
+    pinned to the one device and gloo standing in for RCCL -- 8 ranks x 12 500 grids == BASELINE configs[3]'s sharding at 1/10
+    scale.  The record parses, carries 8 per-rank rates, and -- batch and actions being functions of the GLOBAL grid index -- the
+    all-reduced metrics equal those of ONE rank stepping the same 100 000 grids (to the re-association of a float64 sum)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MGX_DIST_BACKEND="gloo", MGX_FORCE_LOCAL_RANK="0")
+    common = ["--rows", "300", "--steps", "2", "--warmup", "1", "--chunk", "32", "--launches-per-step", "2", "--hetero-steps", "0",
+              "--no-side-modes", "--no-cpu-baseline", "--prewarm", "0", "--detail", ""]
+    r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--grids", "12500"] + common, capture_output=True,
+                        text=True, timeout=1200, env=env)
+    assert r8.returncode == 0, (r8.stdout + r8.stderr)[-3000:]
+    d8 = _line(r8.stdout)
+    assert d8["n_gpus"] == 8 and d8["config"]["grids_total"] == 100000 and d8["config"]["backend"] == "gloo"
+    assert len(d8["per_rank_env_steps_per_s"]) == 8 and all(v > 0 for v in d8["per_rank_env_steps_per_s"]) and d8["value"] > 0
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--grids", "100000"] + common, capture_output=True,
+                        text=True, timeout=600)
+    assert r1.returncode == 0, (r1.stdout + r1.stderr)[-3000:]
+    d1 = _line(r1.stdout)
+    m8, m1 = d8["metrics"], d1["metrics"]
+    assert m8["backend"] == "gloo"
+    assert abs(m8["sum_last_reward"] - m1["sum_last_reward"]) <= 1e-12 * abs(m1["sum_last_reward"]), (m8, m1)
+    assert abs(m8["mean_soc"] - m1["mean_soc"]) <= 1e-12 * abs(m1["mean_soc"]), (m8, m1)
 
 
 @pytest.mark.gpu
@@ -127,4 +217,4 @@ def test_two_gpus_first_contact_over_rccl(device):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["backend"] == "nccl" and len(d["per_rank_env_steps_per_s"]) == 2
-    assert d["metrics_allreduce"]["collective_backend"] == "nccl", d["metrics_allreduce"]
+    assert d["metrics"]["backend"] == "nccl", d["metrics"]

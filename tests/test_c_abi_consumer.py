@@ -10,7 +10,7 @@ SRC = os.path.join(ROOT, "tests", "c_abi", "demo.cpp")
 EXE = os.path.join(ROOT, "tests", "c_abi", "_build", "demo")
 
 
-def build_demo():
+def build_demo(SRC=SRC, EXE=EXE):
     from oracle import oracle as orc
     from pymgrid_amd import _lib
     _lib.build()
@@ -37,3 +37,20 @@ def test_c_abi_consumer_matches_the_oracle():
     res = subprocess.run([build_demo()], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "0 mismatches" in res.stdout
+
+
+# SURVEY 8(b)'s list beyond create / reset / step / step_k: reset with observations, observe, expand_discrete, check_discrete,
+# step_discrete, metrics, the bound Gym step (mgx_env_*), fleet_step, generate_columns -- tests/c_abi/demo2.cpp
+SRC2 = os.path.join(ROOT, "tests", "c_abi", "demo2.cpp")
+EXE2 = os.path.join(ROOT, "tests", "c_abi", "_build", "demo2")
+
+
+def test_c_abi_consumer_2_builds():
+    assert os.path.exists(build_demo(SRC2, EXE2))
+
+
+@pytest.mark.gpu
+def test_c_abi_consumer_2_matches_the_oracle():
+    res = subprocess.run([build_demo(SRC2, EXE2)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert ": 0 mismatches" in res.stdout

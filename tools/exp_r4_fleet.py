@@ -35,7 +35,7 @@ def timeit(fn, n, warm):
 
 
 batches = [generate(per, n_steps=8760, seed=43 + k, arch=a, horizon=24, device=dev, series="factorised") for k, a in enumerate(archs)]
-fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K, reuse_outputs=3 * K if K else 8, stagger=stagger, obs_direct=(K == 0), obs_layout=layout)
+fleet = BucketedFleet.from_batches(batches, obs_dtype=dt, obs_prefetch=K, reuse_outputs=3 * K if K else 8, stagger=stagger, obs_layout=layout)
 acts = [torch.rand(per, e.layout.action_dim, dtype=torch.float64, device=dev) for e in fleet.envs]
 fleet.reset()
 res = [timeit(lambda: fleet.step(acts), 2048, 1536 if rep == 0 else 0) for rep in range(3)]
