@@ -229,7 +229,17 @@ static void launch_windows_kernel(const KArgs &k, const WindowsKPlan &plan, int3
             if (dev >= 0 && dev < MGX_MAX_DEVICES) opted_in[dev] = true;
         }
     }
-    obs_windows_k_kernel<F, OT><<<blocks, OBS_K_THREADS, lds, st>>>(k, plan, t, (OT *)ring);
+    // Threads per refill workgroup (phase 1; phase 2 is always the first 256).  A refill that runs ALONE (the one a reset waits
+    // for: with_state) takes all 1 024 -- 12 % faster (profiles/r05/exp_refill_threads.txt); one written AHEAD, beside the step
+    // launches, stays at 256: the faster it runs the harder it leans on the memory system and the more the steps beside it pay
+    // (config-5 fleet step 16.5 -> 17.2 us with 1 024).  MGX_WIN_THREADS (experiment knob): 256 / 512 / 1024 for both.
+    static const unsigned forced = [] {
+        const char *e = getenv("MGX_WIN_THREADS");
+        const int v = e ? atoi(e) : 0;
+        return (unsigned)((v == 256 || v == 512 || v == 1024) ? v : 0);
+    }();
+    const unsigned threads = forced ? forced : (plan.with_state ? (unsigned)OBS_P1_THREADS : (unsigned)OBS_K_THREADS);
+    obs_windows_k_kernel<F, OT><<<blocks, threads, lds, st>>>(k, plan, t, (OT *)ring);
 }
 
 template <int F, typename OT>

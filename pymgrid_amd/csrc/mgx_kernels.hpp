@@ -38,9 +38,54 @@ constexpr int BLOCK_K = MGX_BLOCK_K;
 // ------------------------------------------------------------------------------------------------------
 // the `obs` argument of a single step: state columns only (inside full rows, or as a dense [N, S] array), or -- without a
 // forecaster -- the whole 8..12-value row
+#ifndef MGX_ROWS_TILE
+#define MGX_ROWS_TILE 1
+#endif
+constexpr int ROW_TILE_MAX_D = 12;                      // H = 0 rows: 2 + 4 + 2 + 4 values at most
+
+// Whole H = 0 rows of a FULL wave through a wave-private LDS tile: every lane leaves its D-value row in the tile (row-major, as
+// the block is in memory), then the wave streams the tile out with 16-byte stores -- 64 lanes x 16 B = 1 KB of consecutive
+// bytes per instruction -- instead of D stores per lane that each touch 64 different lines (a lane's row is 32..96 bytes at a
+// stride of its own length: 100 000 grids x 8 partial-line writes per step).  Same values: the row is built by observe_row_h0.
+template <int F, typename OT>
+__device__ __forceinline__ void observe_row_h0_tiled(const KArgs &a, int64_t i, int32_t t_next, const Params &p, const State &s,
+                                                     OT *__restrict__ obs, int32_t pm, OT *tile)
+{
+    const int lane = threadIdx.x & 63;
+    const int32_t D = a.obs_dim;
+    observe_row_h0<F>(a, i, t_next, p, s, tile + lane * D, pm);
+    __builtin_amdgcn_wave_barrier();                     // (one wave: its LDS traffic is ordered; this keeps the compiler from moving the reads up)
+#ifdef MGX_ROWS_DIAG
+    if (D > 0) return;                                   // (diagnostic build: the rows are formed and never leave the chip)
+#endif
+    typedef OT vec2 __attribute__((ext_vector_type(2)));
+    typedef OT vec4 __attribute__((ext_vector_type(4)));
+    OT *out = obs + (i - lane) * D;                      // the wave's 64 rows are consecutive in memory
+    const int32_t total = 64 * D;
+    if constexpr (sizeof(OT) == 8) {                     // D is even: a 16-byte pair never straddles the tile's end
+        for (int32_t e = 2 * lane; e < total; e += 128) {
+            const vec2 v = *reinterpret_cast<const vec2 *>(tile + e);
+            *reinterpret_cast<vec2 *>(out + e) = v;
+        }
+    } else {
+        if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+            for (int32_t e = 4 * lane; e < total; e += 256) {
+                const vec4 v = *reinterpret_cast<const vec4 *>(tile + e);
+                *reinterpret_cast<vec4 *>(out + e) = v;
+            }
+        } else {
+            for (int32_t e = 2 * lane; e < total; e += 128) {
+                const vec2 v = *reinterpret_cast<const vec2 *>(tile + e);
+                *reinterpret_cast<vec2 *>(out + e) = v;
+            }
+        }
+    }
+}
+
 template <int F>
 __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict__ obs, int64_t i, int32_t t_next, const Params &p,
-                                               const State &s, int32_t pm = 0)     // pm: KArgs.pm_pitch during in-place episodes
+                                               const State &s, int32_t pm = 0,     // pm: KArgs.pm_pitch during in-place episodes
+                                               double *tile = nullptr)             // a wave-private LDS tile for whole H = 0 rows, or NULL
 {
     constexpr int NSTATE = 4 * ((F & F_GENSET) != 0) + 2 * ((F & F_BATTERY) != 0);
     if (a.obs_state_only == 2) {            // MGX_OBS_ROWS_STATE_COMPACT
@@ -66,6 +111,10 @@ __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict_
     } else if (a.obs_state_only) {          // the window columns of this row were prefetched (obs_windows_k_kernel)
         if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
         else observe_state_cols<F>(a, p, s, (double *)obs + i * a.obs_dim);
+    } else if (MGX_ROWS_TILE && tile != nullptr && a.obs_dim <= ROW_TILE_MAX_D && __builtin_amdgcn_read_exec() == ~0ull) {
+        // every lane of the wave owns a grid (uniform): the wave's rows leave together
+        if (a.obs_f32) observe_row_h0_tiled<F>(a, i, t_next, p, s, (float *)obs, pm, reinterpret_cast<float *>(tile));
+        else observe_row_h0_tiled<F>(a, i, t_next, p, s, (double *)obs, pm, tile);
     } else if (a.obs_f32) observe_row_h0<F>(a, i, t_next, p, s, (float *)obs + i * a.obs_dim, pm);
     else observe_row_h0<F>(a, i, t_next, p, s, (double *)obs + i * a.obs_dim, pm);
 }
@@ -96,7 +145,7 @@ __device__ __forceinline__ int32_t episode_tail(const KArgs &a, int64_t i, int32
 template <int F, bool EP = false>
 __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict__ actions, int32_t t, int normalized,
                                           double *__restrict__ reward, uint8_t *__restrict__ done, void *__restrict__ obs,
-                                          double *__restrict__ log, int64_t i)
+                                          double *__restrict__ log, int64_t i, double *tile = nullptr)
 {
     // all loads first (independent, one latency round), then the arithmetic
     Params p; State s; Inputs in; Outputs o; Derived d;
@@ -122,7 +171,7 @@ __device__ __forceinline__ void step_body(const KArgs &a, const void *__restrict
     if constexpr (EP) off = episode_tail<F>(a, i, t, off, dn != 0, p, s);
     // post-step observation (base.py:205-209): without a forecaster the whole 8..12-value row is stored here; with
     // one (H > 0) the host launches obs_rows_wave_kernel behind this kernel and passes obs == nullptr
-    if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, pm);
+    if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, pm, tile);
 }
 
 template <int F, bool EP = false>
@@ -132,8 +181,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *
                                                      double *__restrict__ log)
 {
     t = resolve_t(a, t);
+    __shared__ __attribute__((aligned(16))) double row_tiles[BLOCK / 64][64 * ROW_TILE_MAX_D];   // one tile per wave (store_step_obs: whole H = 0 rows)
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < a.g1) step_body<F, EP>(a, actions, t, normalized, reward, done, obs, log, i);
+    if (i < a.g1) step_body<F, EP>(a, actions, t, normalized, reward, done, obs, log, i, row_tiles[threadIdx.x >> 6]);
     advance_counter_in_kernel(a, 1);
 }
 
@@ -645,11 +695,12 @@ __global__ __launch_bounds__(64) void obs_rows_wave_kernel(const KArgs a, const 
 #define MGX_OBS_KJ 2
 #endif
 #ifndef MGX_WIN_UNROLL
-#define MGX_WIN_UNROLL 1
+#define MGX_WIN_UNROLL 4        // (1 / 4 / 8 measured: 4 is the best of the three for double rows alone, 263 vs 287 us per refill)
 #endif
 constexpr int OBS_KJ = MGX_OBS_KJ;                      // rows per thread and latency round (x 16 phases = 32 rows)
 constexpr int WIN_U = MGX_WIN_UNROLL;                   // blocks per lane whose image words are read before the first of their stores
-constexpr int OBS_K_THREADS = 256;
+constexpr int OBS_K_THREADS = 256;                      // threads that write the ring (phase 2)
+constexpr int OBS_P1_THREADS = 1024;                    // most threads a refill launch may have: all of them build the image (phase 1)
 
 // IT: element type of the LDS image -- double, or float where the rows leave as floats (the value is rounded to float once, here,
 // instead of at every one of its 1 + H stores: the same bits, half the LDS, twice the grids per workgroup)
@@ -724,8 +775,14 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     IT *image = reinterpret_cast<IT *>(image_raw);
     constexpr int NCOMP = 2 + (GRID ? 4 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t G = plan.group, Q = OBS_K_THREADS / G, K = plan.K, RP = plan.rp, BP = plan.bp;
-    const int32_t g = tid & (G - 1), q = tid / G;
+    // Two phases with their own thread counts.  Phase 1 (series rows -> normalised image in LDS) is a chain of dependent loads,
+    // divisions and LDS stores per value: with one wave per SIMD nothing hides its latencies -- it took 84-99 of the 200-290 us of
+    // a refill (profiles/r05/exp_refill_variants.txt: the "nostore" build) -- so ALL blockDim.x threads of the launch share it
+    // (1 024 where the refill runs alone).  Phase 2 (image -> ring stores) stays with the first OBS_K_THREADS threads: how hard a
+    // refill leans on the memory system decides what the step launches beside it cost (one workgroup of four storing waves per CU).
+    const int32_t NT = (int32_t)blockDim.x;
+    const int32_t G = plan.group, K = plan.K, RP = plan.rp, BP = plan.bp;
+    const int32_t g = tid & (G - 1), q = tid / G, Q = NT / G;           // phase 1: thread (g, q) of Q per grid
     const int64_t g0 = group * G;
     const int64_t N = a.N;
     const int32_t W = 1 + a.H, D = a.obs_dim, R = K + a.H;
@@ -772,12 +829,14 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
             }
         }
     }
-    for (int32_t col = tid; col < D; col += OBS_K_THREADS) {            // column -> offset of its k = 0 entry in a block
+    for (int32_t col = tid; col < D; col += NT) {                       // column -> offset of its k = 0 entry in a block
         uint32_t comp, h;
         decode_obs_col(a, GRID, col, W, comp, h);
         map[col] = comp == 0xffffu ? S0 + h * K : (h == 0 ? NU0 + comp * K : comp * RP + h);
     }
     __syncthreads();
+    if (tid >= OBS_K_THREADS) return;                    // phase 2: the first OBS_K_THREADS threads (no barrier follows)
+    const int32_t Q2 = OBS_K_THREADS / G;                // ... thread (g, q) of Q2 per grid (q = tid / G < Q2 here)
 #ifdef MGX_WIN_NO_STORE
     if (K > 0) return;                                   // (diagnostic build: phase 1 -- the loads and the image -- alone)
 #endif
@@ -794,7 +853,7 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         const int64_t P = a.obs_colpitch;
         const bool in_batch = i < N;
         OT *outc = ring + g0 + g;
-        for (int32_t c = q; c < D; c += Q) {
+        for (int32_t c = q; c < D; c += Q2) {
             const uint32_t m = map[c];
             // a ring written ahead of the counter leaves the state columns to the steps: here they are lines of their own, so
             // not writing them costs nothing (in row-major blocks the same holes make partial lines: MGX_WIN_SKIP_STATE)
@@ -884,7 +943,7 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
 }
 
 template <int F, typename OT>
-__global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_kernel(const KArgs a, const WindowsKPlan plan, int32_t t,
+__global__ __launch_bounds__(OBS_P1_THREADS) void obs_windows_k_kernel(const KArgs a, const WindowsKPlan plan, int32_t t,
                                                                       OT *__restrict__ ring)
 {
     t = resolve_t_obs(a, t);
@@ -1044,7 +1103,7 @@ template <int F, bool EP = false>
 __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords &tab, const int32_t *__restrict__ action_id,
                                                    int32_t t, double *__restrict__ control, double *__restrict__ reward,
                                                    uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                   double *__restrict__ log, int64_t i)
+                                                   double *__restrict__ log, int64_t i, double *tile = nullptr)
 {
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
     const int64_t N = a.N;
@@ -1082,7 +1141,7 @@ __device__ __forceinline__ void step_discrete_body(const KArgs &a, const PLWords
     if (done) done[i] = dn;
     if (log) store_log<F>(log + i, N, o, s.status);
     if constexpr (EP) off = episode_tail<F>(a, i, t, off, dn != 0, p, s);
-    if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, EP ? a.pm_pitch : 0);
+    if (obs) store_step_obs<F>(a, obs, i, t + 1 + off, p, s, EP ? a.pm_pitch : 0, tile);
 }
 
 // Dry run of one discrete step (mgx_check_discrete): the expansion and the step on a register copy of the state; only the mask
@@ -1122,8 +1181,9 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
                                                               double *__restrict__ log)
 {
     t = resolve_t(a, t);
+    __shared__ __attribute__((aligned(16))) double row_tiles[BLOCK / 64][64 * ROW_TILE_MAX_D];   // one tile per wave (store_step_obs)
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < a.g1) step_discrete_body<F, EP>(a, tab, action_id, t, control, reward, done, obs, log, i);
+    if (i < a.g1) step_discrete_body<F, EP>(a, tab, action_id, t, control, reward, done, obs, log, i, row_tiles[threadIdx.x >> 6]);
     advance_counter_in_kernel(a, 1);
 }
 

@@ -42,6 +42,7 @@ def test_bound_step_equals_the_per_call_step(arch, H, K, dtype, discrete, layout
     for start, n_steps in ((0, 3 * max(K, 2) + 2), (11, max(K, 2) + 1), (T - H - 5, H + 4)):
         o1, o2 = slow.reset(start), fast.reset(start)
         assert fast._fp is not None and torch.equal(o1, o2), (start, "reset")
+        held = []                               # (a reset refills the rings: what was handed out before is gone)
         for k in range(min(n_steps, T - start - 1)):
             a = slow.sample_action(generator=g)
             (o1, r1, d1, i1), (o2, r2, d2, i2) = slow.step(a), fast.step(a)

@@ -52,13 +52,15 @@ for f in find("*kernel_trace.csv"):
 # first, so on every queue that carries its launches the timed ones are launches [first, last) of that kernel in time order.
 import json
 bench = None
-for name in ("stats.log",):
+for name in ("bench_detail.json", "stats.log"):      # round 5: stdout carries the compact record, the full one sits beside it
     try:
         for ln in open(os.path.join(out, name)):
             if ln.startswith("{"):
                 bench = json.loads(ln)
     except OSError:
         pass
+    if bench is not None and "timed_rounds" in bench.get("roofline", {}):
+        break
 for f in find("*kernel_trace.csv"):
     if os.sep + "stats" + os.sep not in f or bench is None:
         continue
@@ -95,7 +97,8 @@ for f in find("*kernel_trace.csv"):
               f"algorithmic {alg / 1e6:.1f} MB per round -> {alg / (cad * 1e-6) / 1e9:.0f} GB/s = frac {frac:.3f} of {rf['peak']:.0f} GB/s"
               f"   [bench line: avg_launch_us {rf['avg_launch_us']:.2f}, frac {rf['frac']:.3f}]")
 
-WATCHED = ("step_k_kernel", "step_kernel", "rollout_kernel", "observe_kernel", "expand_kernel", "obs_windows_k_kernel", "fleet_step_kernel")
+WATCHED = ("step_k_kernel", "step_kernel", "rollout_kernel", "observe_kernel", "expand_kernel", "obs_windows_k_kernel", "fleet_step_kernel",
+           "step_multi_kernel", "step_k_multi_kernel", "obs_windows_k_multi_kernel")
 traffic = defaultdict(dict)
 sized = defaultdict(dict)
 for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
