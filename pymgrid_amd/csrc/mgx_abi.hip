@@ -25,6 +25,7 @@ struct mgx_handle {
     bool multi;             // n_load != 1, n_pv != 1 or several gensets / batteries / grids: general (slow) kernels
     int32_t ring_pitch;     // rows between the blocks of an observation ring (mgx_set_ring_pitch; default N)
     size_t multi_lds;       // LDS bytes of a general-kernel workgroup (the MicrogridStep lists)
+    int multi_small;        // at most MS modules of every kind per grid: the general steps run their register form (step_multi_small)
     std::vector<std::string> log_names;
     int32_t *d_lists;       // general path: device copy of the priority lists handed to mgx_expand_discrete as a host table
     std::vector<int32_t> lists_uploaded;
@@ -379,6 +380,10 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
         }
     }
     h->multi_lds = 2 * (size_t)multi_list_capacity(L->n_load, L->n_pv, n_genset, n_battery, n_grid) * BLOCK_MULTI * sizeof(double);
+    {   // MGX_MULTI_GENERIC=1 (tests): every general layout on the run-time-count form, whatever its size
+        static const bool generic = [] { const char *e = getenv("MGX_MULTI_GENERIC"); return e && atoi(e) != 0; }();
+        h->multi_small = (!generic && multi_is_small(L->n_load, L->n_pv, n_genset, n_battery, n_grid)) ? 1 : 0;
+    }
     h->k.log_dim = LC_COMMON_END + LC_GENSET_N * n_genset + LC_BATTERY_N * n_battery + LC_GRID_N * n_grid + 1;
     for (int c = 0; c < LC_COMMON_END; c++) h->log_names.push_back(kCommonNames[c]);
     auto add_block = [&](const char *const *names, int n_cols, int n_inst) {       // instance 0: plain names, j > 0: name[j]
@@ -1274,7 +1279,7 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
     if (h->multi) {
         for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
             MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
-                                          k, actions, t_arg(h), normalized, reward, done, obs, log)));
+                                          k, actions, t_arg(h), normalized, reward, done, obs, log, h->multi_small)));
         });
         hipError_t em = hipGetLastError();
         if (em != hipSuccess) return hip_fail(em, "step_multi_kernel launch");
@@ -1377,7 +1382,7 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
         if (h->k.done_bits && done) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: the general kernels write `done` as bytes");
         for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
             MGX_DISPATCH_F(h->flags, (step_k_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
-                                          k, actions, nullptr, 0, 0, nullptr, 0, t_arg(h), K, normalized, fo)));
+                                          k, actions, nullptr, 0, 0, nullptr, 0, t_arg(h), K, normalized, fo, h->multi_small)));
         });
         hipError_t em = hipGetLastError();
         if (em != hipSuccess) return hip_fail(em, "step_k_multi_kernel launch");
@@ -1697,7 +1702,7 @@ int mgx_rollout_lists(mgx_handle *h, const int32_t *action_id, int per_step, con
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
         MGX_DISPATCH_F(h->flags, (step_k_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
-                                      k, nullptr, lists, n_lists, list_len, action_id, per_step, t_arg(h), K, 0, fo)));
+                                      k, nullptr, lists, n_lists, list_len, action_id, per_step, t_arg(h), K, 0, fo, h->multi_small)));
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "step_k_multi_kernel launch");

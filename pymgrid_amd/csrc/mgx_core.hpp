@@ -1263,6 +1263,257 @@ __device__ inline void step_multi_core(const KArgs &a, const AT *__restrict__ ac
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The SMALL form of the general step: at most MS modules of every kind per grid (what "several modules of a kind" means in
+// practice: two gensets, two batteries ...).  step_multi_core walks its module lists with run-time counts, so every instance's
+// parameters, state, control and series values are loaded inside the sweep -- one dependent round trip per instance, 5-7 per
+// step, in a kernel that is nothing but round trips (10 us per 100 000-grid step for 2 gensets + 2 batteries + 1 grid).  Here the
+// counts are bounded at COMPILE time: everything the step reads is requested up front into registers (every load unconditional
+// -- an instance the layout does not have re-reads the last one it has: a cache hit -- so that all are in flight together), the
+// sweep runs on registers with `j < n` guards around its EFFECTS only, and a K-step loop keeps parameters and state there across
+// steps.  Same operations on the same operands in the same order as step_multi_core (the lists and their sums are its), hence
+// the same bits: tests/test_multiplicity.py runs both forms on the same batches.
+// ------------------------------------------------------------------------------------------------------
+constexpr int MS = 2;
+
+struct MultiRegs {                       // parameters + dynamic state of one grid (per instance)
+    double g_rmin[MS], g_rmax[MS], g_cost[MS], g_co2[MS], g_cco2[MS];
+    uint32_t g_times[MS], g_status[MS];
+    double b_cmin[MS], b_cmax[MS], b_C[MS], b_D[MS], b_eta[MS], b_cost[MS], b_charge[MS], b_soc[MS];
+    double r_imp[MS], r_exp[MS], r_cco2[MS];
+    double ll_cost, og_cost;
+    Derived d_gen[MS], d_bat[MS], d_grid[MS];   // the step-invariant values of every instance (derive: once per launch, not per step)
+};
+
+struct MultiStepIn {                     // what one step reads besides: controls and series rows
+    double goal[MS], gen[MS], bat[MS], grd[MS];
+    double load[MS], pv[MS], grid[MS][4];
+};
+
+__host__ __device__ inline bool multi_is_small(int n_load, int n_pv, int n_genset, int n_battery, int n_grid)
+{
+    return n_load >= 1 && n_pv >= 1 && n_load <= MS && n_pv <= MS && n_genset <= MS && n_battery <= MS && n_grid <= MS;
+}
+
+template <int F>
+__device__ __forceinline__ void load_multi_regs(const KArgs &a, int64_t i, MultiRegs &R)
+{
+    const int64_t N = a.N;
+    const mgx_columns &c = a.c;
+#pragma unroll
+    for (int j = 0; j < MS; j++) {
+        if constexpr (F & F_GENSET) {
+            const int64_t q = (int64_t)(j < a.n_genset ? j : a.n_genset - 1) * N + i;
+            R.g_rmin[j] = c.gen_running_min[q]; R.g_rmax[j] = c.gen_running_max[q]; R.g_cost[j] = c.gen_cost[q];
+            R.g_co2[j] = c.gen_co2_per_unit[q]; R.g_cco2[j] = c.gen_cost_per_unit_co2[q];
+            R.g_times[j] = c.gen_times[q]; R.g_status[j] = c.gen_status[q];
+        }
+        if constexpr (F & F_BATTERY) {
+            const int64_t q = (int64_t)(j < a.n_battery ? j : a.n_battery - 1) * N + i;
+            R.b_cmin[j] = c.bat_min_capacity[q]; R.b_cmax[j] = c.bat_max_capacity[q]; R.b_C[j] = c.bat_max_charge[q];
+            R.b_D[j] = c.bat_max_discharge[q]; R.b_eta[j] = c.bat_efficiency[q]; R.b_cost[j] = c.bat_cost_cycle[q];
+            R.b_charge[j] = c.charge[q]; R.b_soc[j] = c.soc[q];
+        }
+        if constexpr (F & F_GRID) {
+            const int64_t q = (int64_t)(j < a.n_grid ? j : a.n_grid - 1) * N + i;
+            R.r_imp[j] = c.grid_max_import[q]; R.r_exp[j] = c.grid_max_export[q]; R.r_cco2[j] = c.grid_cost_per_unit_co2[q];
+        }
+    }
+    R.ll_cost = c.loss_load_cost[i]; R.og_cost = c.overgeneration_cost[i];
+    // the action-space constants of every instance: the same operations on the same operands as a derive per step, hence the same bits
+#pragma unroll
+    for (int j = 0; j < MS; j++) {
+        Params p;
+        if constexpr (F & F_GENSET) { p.gen_rmax = R.g_rmax[j]; derive<F_GENSET>(p, R.d_gen[j]); }
+        if constexpr (F & F_BATTERY) { p.bat_D = R.b_D[j]; p.bat_eta = R.b_eta[j]; p.bat_C = R.b_C[j]; derive<F_BATTERY>(p, R.d_bat[j]); }
+        if constexpr (F & F_GRID) { p.grid_exp = R.r_exp[j]; p.grid_imp = R.r_imp[j]; derive<F_GRID>(p, R.d_grid[j]); }
+    }
+}
+
+// the dynamic state back into the batch's columns
+template <int F>
+__device__ __forceinline__ void store_multi_state(const KArgs &a, int64_t i, const MultiRegs &R)
+{
+    const int64_t N = a.N;
+#pragma unroll
+    for (int j = 0; j < MS; j++) {
+        if constexpr (F & F_GENSET) { if (j < a.n_genset) a.c.gen_status[(int64_t)j * N + i] = R.g_status[j]; }
+        if constexpr (F & F_BATTERY) { if (j < a.n_battery) { a.c.charge[(int64_t)j * N + i] = R.b_charge[j]; a.c.soc[(int64_t)j * N + i] = R.b_soc[j]; } }
+    }
+}
+
+template <int F, typename AT>
+__device__ __forceinline__ void load_multi_step_in(const KArgs &a, const AT *__restrict__ act, int64_t i, int32_t t, MultiStepIn &in)
+{
+    const int64_t N = a.N;
+    const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
+#pragma unroll
+    for (int j = 0; j < MS; j++) {
+        if constexpr (F & F_GENSET) { const int q = j < NG ? j : NG - 1; in.goal[j] = (double)act[2 * q]; in.gen[j] = (double)act[2 * q + 1]; }
+        if constexpr (F & F_BATTERY) { const int q = j < NB ? j : NB - 1; in.bat[j] = (double)act[2 * NG + q]; }
+        if constexpr (F & F_GRID) {
+            const int q = j < NR ? j : NR - 1;
+            in.grd[j] = (double)act[2 * NG + NB + q];
+            const double *g = a.c.grid_ts + (((int64_t)t * NR + q) * 4) * N + i;
+            in.grid[j][0] = g[0]; in.grid[j][1] = g[N]; in.grid[j][2] = g[2 * N]; in.grid[j][3] = g[3 * N];
+        }
+        { const int q = j < a.n_load ? j : a.n_load - 1; in.load[j] = a.c.load_ts[((int64_t)t * a.n_load + q) * N + i]; }
+        { const int q = j < a.n_pv ? j : a.n_pv - 1; in.pv[j] = a.c.pv_ts[((int64_t)t * a.n_pv + q) * N + i]; }
+    }
+}
+
+// One Microgrid.run of grid i out of registers: step_multi_core's sweep, line for line, with compile-time instance indices.
+template <int F>
+__device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, const MultiStepIn &sin, int64_t i, bool normalized,
+                                                 StepLists &L, double *__restrict__ log, Outputs &o)
+{
+    const int64_t N = a.N;
+    const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
+    double reward = 0.0;
+    uint32_t viol = 0u;
+    L.n_prov = 0; L.n_absb = 0;
+    o.load_met = 0.0;
+#pragma unroll
+    for (int j = 0; j < MS; j++) {                        // fixed modules, module order (microgrid.py:255-257)
+        if (j < a.n_load) {
+            const double Lv = -1 * sin.load[j];
+            o.load_met += Lv;
+            L.absorbed(Lv); reward += 0.0;
+        }
+    }
+    o.fixed_provided = np_sum_strided(L.prov, L.stride, L.n_prov);          // :259-260
+    o.fixed_absorbed = np_sum_strided(L.absb, L.stride, L.n_absb);
+
+    const int kg = LC_COMMON_END, kb = kg + LC_GENSET_N * NG, kr = kb + LC_BATTERY_N * NB;    // log blocks
+    Inputs in; in.load = 0.0; in.pv = 0.0;
+    Outputs oc;
+    if constexpr (F & F_GENSET) {
+#pragma unroll
+        for (int j = 0; j < MS; j++) {
+            if (j < NG) {
+                Params p; Derived d; State s;
+                p.gen_rmin = R.g_rmin[j]; p.gen_rmax = R.g_rmax[j]; p.gen_cost = R.g_cost[j]; p.gen_co2 = R.g_co2[j];
+                p.gen_cco2 = R.g_cco2[j]; p.gen_times = R.g_times[j];
+                d = R.d_gen[j];
+                s.status = R.g_status[j];
+                in.a_goal = sin.goal[j]; in.a_gen = sin.gen[j];
+                step_core<F_GENSET>(p, d, s, in, normalized, false, false, oc);
+                R.g_status[j] = s.status;
+                L.provided(oc.genset_production); reward += oc.genset_reward; viol |= oc.violations;
+                if (log) {
+                    double *q = log + (int64_t)(kg + LC_GENSET_N * j) * N;
+                    q[0] = oc.genset_production; q[N] = oc.genset_co2; q[2 * N] = oc.genset_reward; q[3 * N] = (double)s.status;
+                }
+            }
+        }
+    }
+    double discharge_sum = 0.0; bool any_sink = false;   // BatteryDischargeShaper's sum (step_multi_core)
+    auto step_batteries = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < MS; j++) {
+            if (j < NB) {
+                Params p; Derived d; State s;
+                p.bat_cmin = R.b_cmin[j]; p.bat_cmax = R.b_cmax[j]; p.bat_C = R.b_C[j]; p.bat_D = R.b_D[j];
+                p.bat_eta = R.b_eta[j]; p.bat_cost = R.b_cost[j];
+                d = R.d_bat[j];
+                s.charge = R.b_charge[j]; s.soc = R.b_soc[j]; s.status = 0u;
+                in.a_bat = sin.bat[j];
+                step_core<F_BATTERY>(p, d, s, in, normalized, true, false, oc);
+                R.b_charge[j] = s.charge; R.b_soc[j] = s.soc;
+                const double x = normalized ? d.bat_lo + d.bat_sp * in.a_bat : in.a_bat;
+                if (x < 0) { L.absorbed(oc.charge_amount); any_sink = true; }
+                else { L.provided(oc.discharge_amount); discharge_sum += oc.discharge_amount; }
+                reward += oc.battery_reward; viol |= oc.violations;
+                if (log) {
+                    double *q = log + (int64_t)(kb + LC_BATTERY_N * j) * N;
+                    q[0] = oc.discharge_amount; q[N] = oc.charge_amount; q[2 * N] = oc.battery_reward;
+                    q[3 * N] = oc.soc_pre; q[4 * N] = oc.charge_pre;
+                }
+            }
+        }
+    };
+    auto step_grids = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < MS; j++) {
+            if (j < NR) {
+                Params p; Derived d; State s;
+                p.grid_imp = R.r_imp[j]; p.grid_exp = R.r_exp[j]; p.grid_cco2 = R.r_cco2[j];
+                d = R.d_grid[j];
+                s.charge = 0.0; s.soc = 0.0; s.status = 0u;
+                in.g_pimp = sin.grid[j][0]; in.g_pexp = sin.grid[j][1]; in.g_co2 = sin.grid[j][2]; in.g_stat = sin.grid[j][3];
+                in.a_grid = sin.grd[j];
+                step_core<F_GRID>(p, d, s, in, normalized, false, false, oc);
+                const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;
+                if (x < 0) L.absorbed(oc.grid_export); else L.provided(oc.grid_import);
+                reward += oc.grid_reward; viol |= oc.violations;
+                if (log) {
+                    double *q = log + (int64_t)(kr + LC_GRID_N * j) * N;
+                    q[0] = oc.grid_import; q[N] = oc.grid_export; q[2 * N] = oc.grid_co2; q[3 * N] = oc.grid_reward;
+                }
+            }
+        }
+    };
+    if constexpr ((F & F_GRID_FIRST) != 0) {
+        if constexpr (F & F_GRID) step_grids();
+        if constexpr (F & F_BATTERY) step_batteries();
+    } else {
+        if constexpr (F & F_BATTERY) step_batteries();
+        if constexpr (F & F_GRID) step_grids();
+    }
+    o.discharge_amount = any_sink ? 0.0 : discharge_sum;
+    o.charge_amount = 0.0;
+    const double provided = np_sum_strided(L.prov, L.stride, L.n_prov);      // :277
+    const double consumed = np_sum_strided(L.absb, L.stride, L.n_absb);
+    const double difference = provided - consumed;
+    o.ctrl_provided = provided - o.fixed_provided; o.ctrl_absorbed = consumed - o.fixed_absorbed;
+
+    const double ll_cost = R.ll_cost, og_cost = R.og_cost;
+    o.renewable_used = 0.0; o.curtailment = 0.0;
+    if (difference > 0) {                                 // :286-299: renewables idle, the excess is overgeneration
+#pragma unroll
+        for (int j = 0; j < MS; j++) {
+            if (j < a.n_pv) {
+                o.curtailment += sin.pv[j] - 0.0;
+                L.provided(0.0); reward += 0.0;
+            }
+        }
+        const double e = -1.0 * (-1.0 * difference);
+        o.overgeneration = e; o.loss_load = 0.0;
+        o.unbalanced_reward = -1.0 * (og_cost * e);
+        L.absorbed(e);
+    } else {                                              // :301-314: renewables in module order, then loss load
+        double need = -difference;
+#pragma unroll
+        for (int j = 0; j < MS; j++) {
+            if (j < a.n_pv) {
+                const double pv = sin.pv[j];
+                const double amt = (pv < need) ? pv : need;
+                o.renewable_used += amt; o.curtailment += pv - amt;
+                L.provided(amt); reward += 0.0;
+                need -= amt;
+            }
+        }
+        o.loss_load = need; o.overgeneration = 0.0;
+        o.unbalanced_reward = -1.0 * (ll_cost * need);
+        L.provided(need);
+    }
+    reward += o.unbalanced_reward;
+    o.overall_provided = np_sum_strided(L.prov, L.stride, L.n_prov);         // :316-317
+    o.overall_absorbed = np_sum_strided(L.absb, L.stride, L.n_absb);
+    o.reward = reward;
+    o.violations = viol;
+    if (log) {
+        log[0] = o.reward;
+        log[N] = o.fixed_provided;        log[2 * N] = o.fixed_absorbed;
+        log[3 * N] = o.ctrl_provided;     log[4 * N] = o.ctrl_absorbed;
+        log[5 * N] = o.overall_provided;  log[6 * N] = o.overall_absorbed;
+        log[7 * N] = o.load_met;          log[8 * N] = o.renewable_used;
+        log[9 * N] = o.curtailment;       log[10 * N] = o.loss_load;
+        log[11 * N] = o.overgeneration;   log[12 * N] = o.unbalanced_reward;
+        log[(int64_t)(kr + LC_GRID_N * NR) * N] = (double)viol;
+    }
+}
+
 // PriorityListAlgo._populate_action over module instances (priority_list.py:69-116): `list` holds list_len elements
 // (kind, instance, action), kind < 0 = padding.  Every element runs the single-module form of populate_core on the load
 // that remains when it is reached; control [A] = (goal, energy) per genset, batteries, grids.

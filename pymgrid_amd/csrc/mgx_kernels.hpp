@@ -1552,7 +1552,7 @@ template <int F>
 __global__ __launch_bounds__(BLOCK_MULTI) void step_multi_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
                                                                  int normalized, double *__restrict__ reward,
                                                                  uint8_t *__restrict__ done, void *__restrict__ obs,
-                                                                 double *__restrict__ log)
+                                                                 double *__restrict__ log, int small)
 {
     extern __shared__ double multi_lds[];
     t = resolve_t(a, t);
@@ -1561,7 +1561,14 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_multi_kernel(const KArgs a, 
         const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
         StepLists L = multi_lists(a, multi_lds);
         Outputs o;
-        if (a.act_f32) step_multi_core<F>(a, (const float *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
+        if (small) {                                     // at most MS modules of a kind: everything requested up front, the sweep on registers
+            MultiRegs R; MultiStepIn sin;
+            load_multi_regs<F>(a, i, R);
+            if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + i * A, i, t, sin);
+            else load_multi_step_in<F>(a, (const double *)actions + i * A, i, t, sin);
+            step_multi_small<F>(a, R, sin, i, normalized != 0, L, log ? log + i : nullptr, o);
+            store_multi_state<F>(a, i, R);
+        } else if (a.act_f32) step_multi_core<F>(a, (const float *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
         else step_multi_core<F>(a, (const double *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
         reward[i] = shaped_reward<F>(a.shaper, o);
         if (done) done[i] = done_at(a, i, t);
@@ -1742,7 +1749,7 @@ template <int F>
 __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a, const void *__restrict__ actions,
                                                                    const int32_t *__restrict__ lists, int32_t n_lists, int32_t list_len,
                                                                    const int32_t *__restrict__ ids, int per_step, int32_t t0, int32_t K,
-                                                                   int normalized, const FusedOut out)
+                                                                   int normalized, const FusedOut out, int small)
 {
     extern __shared__ double multi_lds[];
     const int32_t K_launch = K;
@@ -1755,6 +1762,35 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a
         StepLists L = multi_lists(a, multi_lds);
         const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
         double ret = 0.0;
+        if (small && !lists) {
+            // At most MS modules of a kind, continuous controls: parameters and state stay in REGISTERS for the K steps (loaded
+            // once, the state written back once); per step only the controls and the series rows are read -- the NEXT step's are
+            // requested before this step's sweep starts -- and the requested outputs written.
+            MultiRegs R; MultiStepIn cur, nxt;
+            load_multi_regs<F>(a, i, R);
+            if (K > 0) {
+                if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + (int64_t)i * A, i, t0, cur);
+                else load_multi_step_in<F>(a, (const double *)actions + (int64_t)i * A, i, t0, cur);
+            }
+            for (int32_t k = 0; k < K; k++) {
+                const int64_t off = (int64_t)k * N + i;
+                const int32_t kn = k + 1 < K ? k + 1 : k;                // (the last step re-reads its own inputs: unconditional loads)
+                const int64_t offn = (int64_t)kn * N + i;
+                if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + offn * A, i, t0 + kn, nxt);
+                else load_multi_step_in<F>(a, (const double *)actions + offn * A, i, t0 + kn, nxt);
+                Outputs o;
+                double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
+                step_multi_small<F>(a, R, cur, i, normalized != 0, L, log, o);
+                const double r = shaped_reward<F>(a.shaper, o);
+                if (out.reward) out.reward[off] = r;
+                if (out.done) out.done[off] = (uint8_t)(k >= k_done);
+                if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = R.b_soc[0]; }
+                if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = R.g_status[0]; }
+                ret += r;
+                cur = nxt;
+            }
+            store_multi_state<F>(a, i, R);
+        } else
         for (int32_t k = 0; k < K; k++) {
             const int64_t off = (int64_t)k * N + i;
             Outputs o;

@@ -1,0 +1,77 @@
+"""The register form of the general step (step_multi_small: at most two modules of every kind per grid -- parameters, state, controls
+and series rows requested up front, the sweep on registers, a K-step loop that keeps parameters and state there) against the run-time
+count form it specialises (step_multi_core, MGX_MULTI_GENERIC=1): the same batches, controls and calls in two processes, every
+reward, log column, observation row and final state `==`.  (Both forms are pinned against the reference-made fixtures of
+tests/golden/multi.npz and the oracle by tests/test_multiplicity.py / test_multi_module.py, which run whichever form the layout
+gets; this test makes sure those pins hold for BOTH.)  Reference: module_container.py:355-413, microgrid.py:255-314."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from pymgrid_amd import BatchedMicrogridEnv, StepEngine
+from pymgrid_amd.generator import generate, widen
+dev = torch.device("cuda:0")
+out = {}
+g = torch.Generator(device=dev); g.manual_seed(11)
+for tag, (ng, nb, nr), arch in (("a", (2, 2, 1), "genset+battery+grid"), ("b", (1, 2, 2), "genset+battery+grid"), ("c", (2, 1, 0), "genset+battery")):
+    N, T, K = 1500, 90, 24
+    def batch():
+        return widen(generate(N, n_steps=T, seed=21, arch=arch, horizon=3, device=dev, mixed_timers=True), n_genset=ng, n_battery=nb, n_grid=nr)
+    env = BatchedMicrogridEnv(batch(), log=True, obs_prefetch=0)
+    A = env.layout.action_dim
+    acts = torch.rand(K + 6, N, A, dtype=torch.float64, device=dev, generator=g)
+    obs0 = env.reset()
+    rows, rew, logs = [obs0], [], []
+    for k in range(6):                                   # single steps with observation rows and log columns
+        o, r, d, info = env.step(acts[k])
+        rows.append(o); rew.append(r.clone()); logs.append(info["log"].clone())
+    e = env.engine
+    res = e.step_k(acts[6:], normalized=True, reward=True, soc_trace=True, status_trace=True, log=True)   # K fused steps
+    out[tag + "_rows"] = torch.stack(rows).cpu().numpy(); out[tag + "_rew"] = torch.stack(rew).cpu().numpy()
+    out[tag + "_log"] = torch.stack(logs).cpu().numpy()
+    for name, v in res.items():
+        out[tag + "_k_" + name] = v.cpu().numpy()
+    for name in ("charge", "soc", "gen_status"):
+        if name in env.batch.cols and env.batch.cols[name] is not None:
+            out[tag + "_" + name] = env.batch.cols[name].cpu().numpy()
+    # float32 controls, unnormalised
+    e32 = StepEngine(batch(), action_dtype=torch.float32)
+    a32 = (acts[:4] * 50).float()
+    rr = torch.empty(4, N, dtype=torch.float64, device=dev)
+    for k in range(4):
+        e32.step(a32[k], normalized=False, want_obs=False, out=dict(reward=rr[k]))
+    out[tag + "_f32_rew"] = rr.cpu().numpy()
+    out[tag + "_f32_k"] = e32.step_k(a32, normalized=False, reward=True)["reward"].cpu().numpy()
+    env.close(); e32.close()
+np.savez(sys.argv[2], **out)
+'''
+
+
+def _run(tmp_path, generic):
+    path = str(tmp_path / ("generic.npz" if generic else "small.npz"))
+    env = dict(os.environ)
+    env.pop("MGX_MULTI_GENERIC", None)
+    if generic:
+        env["MGX_MULTI_GENERIC"] = "1"
+    r = subprocess.run([sys.executable, "-c", SCRIPT, ROOT, path], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    return np.load(path)
+
+
+def test_register_form_equals_the_run_time_count_form(device, tmp_path):
+    small, generic = _run(tmp_path, False), _run(tmp_path, True)
+    assert set(small.files) == set(generic.files) and len(small.files) > 20
+    for k in small.files:
+        a, b = small[k], generic[k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)) or np.array_equal(a, b), k      # == (zeros may differ in sign)
+    assert np.isfinite(small["a_k_reward"]).all() and small["a_k_reward"].std() > 0

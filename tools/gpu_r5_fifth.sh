@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/r05
 mkdir -p "$OUT"
 cd "$REPO"
-timeout 900 python -m pytest tests/test_multiplicity.py tests/test_multi_module.py tests/test_multi_windows.py tests/test_rbc.py tests/test_env_step.py -m gpu -q -p no:cacheprovider > "$OUT/pytest_gpu5.log" 2>&1
+timeout 900 python -m pytest tests/test_multi_small.py tests/test_multiplicity.py tests/test_multi_module.py tests/test_multi_windows.py tests/test_rbc.py tests/test_host_logic.py -m gpu -q -p no:cacheprovider > "$OUT/pytest_gpu5.log" 2>&1
 tail -6 "$OUT/pytest_gpu5.log"
 timeout 600 python bench.py --gpus 1 --steps 2 --warmup 1 --hetero-steps 0 --no-cpu-baseline --detail "$OUT/bench_detail5.json" > "$OUT/bench5.json" 2> "$OUT/bench5.err"
 python - "$OUT/bench5.json" <<'PY'
