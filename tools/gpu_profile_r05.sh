@@ -33,7 +33,7 @@ json.dump(d, open(f, "w"), indent=1)
 PY
 # 3. VALU issue: SQ counters of the two fused kernels (separate pass, kernel-trace only), the headline mode of each run alone
 cd /tmp
-SQARGS="--gpus 1 --steps 4 --warmup 1 --no-cpu-baseline --hetero-steps 0 --no-side-modes --no-closed-loop --detail ''"
+SQARGS="--gpus 1 --steps 4 --warmup 1 --no-cpu-baseline --hetero-steps 0 --no-side-modes --no-closed-loop --detail /dev/null"
 for MODE in fused rbc; do
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d "$OUT/sq_$MODE" -o b --output-format csv -- python "$REPO/bench.py" $SQARGS --mode $MODE > "$OUT/sq_$MODE.log" 2>&1
 done
