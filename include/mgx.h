@@ -348,7 +348,7 @@ int mgx_set_action_format(mgx_handle *h, int32_t format);
  * those columns.  Values are identical to mgx_observe's.  MGX_ERR_UNSUPPORTED with forecast noise (it depends on the
  * (step, horizon index) pair).  Microgrids with several modules of a kind (module_container.py:355-413) are served by the
  * general form of the same kernel -- a window per load / renewable / grid module instance, 4 state columns per genset and
- * 2 per battery -- for lock-step episodes and row-major blocks (tests/test_multi_windows.py: rows == the per-step rows). */
+ * 2 per battery -- for lock-step episodes, row- or column-major blocks (tests/test_multi_windows.py: rows == the per-step rows). */
 int mgx_observe_windows(mgx_handle *h, int32_t K, void *ring, mgx_stream stream);
 /* Rows between consecutive blocks of the rings handed to mgx_observe_windows / mgx_observe_windows_ahead / mgx_fleet_step
  * refills (default: N, i.e. a dense [K, N, D] ring).  With N not a multiple of 16 the blocks of a dense ring are not
@@ -361,8 +361,10 @@ int mgx_set_ring_pitch(mgx_handle *h, int32_t rows);
  * first matrix product takes either way.  Why: in a row-major block the step's state columns are 48 bytes at a 8 D-byte stride --
  * 100 000 scattered partial lines per step, 3.5-4 us of a 24-us config-5 fleet step (profiles/r04/exp_fleet_state_patch_cost.txt) --
  * in a column-major block they are six coalesced runs of 8 N bytes.  Applies to mgx_observe_windows[_ahead], the fleets' refills and
- * the state-only `obs` target of the steps (pass the block's base).  Lock-step episodes only (mgx_patch_windows and the in-place /
- * rolling modes keep row-major rings). */
+ * the state-only `obs` target of the steps (pass the block's base).  A ring written AHEAD of the counter does not touch the state
+ * columns of a column-major block at all (they are lines of their own; the step that reaches the block writes them), where a
+ * row-major one receives zeros.  Layouts with several modules of a kind per grid included (their 4 n_genset + 2 n_battery state
+ * columns).  Lock-step episodes only (mgx_patch_windows and the in-place / rolling modes keep row-major rings). */
 enum mgx_ring_layout { MGX_RING_ROWS = 0, MGX_RING_COLUMNS = 1 };
 int mgx_set_ring_layout(mgx_handle *h, int32_t layout);
 /* Rolling windows with prefetched rings: after mgx_reset_grids* has replaced the series rows of the grids with mask[i] != 0,

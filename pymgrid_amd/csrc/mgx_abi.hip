@@ -256,7 +256,14 @@ static void launch_windows_multi_kernel(const KArgs &k, const WindowsKPlan &plan
             if (dev >= 0 && dev < MGX_MAX_DEVICES) opted_in[dev] = true;
         }
     }
-    obs_windows_k_multi_kernel<F, OT><<<blocks, OBS_K_THREADS, lds, st>>>(k, plan, t, (OT *)ring);
+    // 1 024 threads for phase 1 here, ahead or not: on the general path the refill -- not the chain of step launches -- sets the
+    // pace of a Gym step with rows (1.15 ms per ring of 32 blocks against 0.3 ms of steps).  MGX_WIN_THREADS overrides.
+    static const unsigned forced = [] {
+        const char *e = getenv("MGX_WIN_THREADS");
+        const int v = e ? atoi(e) : 0;
+        return (unsigned)((v == 256 || v == 512 || v == 1024) ? v : 0);
+    }();
+    obs_windows_k_multi_kernel<F, OT><<<blocks, forced ? forced : (unsigned)OBS_P1_THREADS, lds, st>>>(k, plan, t, (OT *)ring);
 }
 
 static inline unsigned multi_blocks(int64_t n) { return (unsigned)((n + BLOCK_MULTI - 1) / BLOCK_MULTI); }
@@ -563,9 +570,9 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (!h || !ring) return fail(MGX_ERR_INVALID, "%s: NULL argument", who);
     if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "%s: K = %d outside [1, 4096]", who, K);
     if (ahead < 0) return fail(MGX_ERR_INVALID, "%s: ahead = %d is negative", who, ahead);
-    if (h->multi && (h->k.obs_colpitch || h->windowed || h->rolling || h->inplace || factorised(h->k.c)))
+    if (h->multi && (h->windowed || h->rolling || h->inplace || factorised(h->k.c)))
         return fail(MGX_ERR_UNSUPPORTED, "%s: with several modules of a kind per grid the window prefetch is offered for lock-step "
-                                         "episodes over [T, n, N] series and row-major ring blocks", who);
+                                         "episodes over [T, n, N] series", who);
     if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
         return fail(MGX_ERR_UNSUPPORTED, "%s: forecast noise depends on (step, horizon index), windows cannot be shared", who);
     if (h->k.obs_state_only == 2)
@@ -580,12 +587,17 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     plan->grid_col_base = h->k.col_grid;
     plan->K = K;
     plan->rp = R;
-    plan->bp = (ncomp * (R + K) + nstate * K) | 1;
+    plan->bp = (ncomp * (R + K) + (ahead == 0 ? nstate : 1) * K) | 1;      // ahead of the counter: ONE strip of zeros for all state columns
     static const int group_env = [] { const char *e = getenv("MGX_WIN_GROUP"); return e ? atoi(e) : 0; }();   // experiment knob
-    // Float rows keep a FLOAT image (windows_body): half the LDS per grid, so a workgroup takes 32 grids where it takes 16 for
-    // double rows -- and 32 grids x 4 bytes are what a whole 128-byte line of a column-major block needs.  (General path: doubles.)
-    const bool float_image = h->k.obs_f32 && !h->multi;
-    plan->group = (group_env == 8 || group_env == 4 || group_env == 16 || group_env == 32) ? group_env : (float_image ? 32 : 16);
+    // Float rows keep a FLOAT image (windows_body): half the LDS per grid.  Column-major blocks and float rows: 32 grids per
+    // workgroup wherever the image fits (halved below while it does not) -- 32 x 4 bytes are what a whole 128-byte line of a
+    // column-major block needs, 32 doubles are two; a refill ahead of the counter, whose image has ONE strip of zeros for the state
+    // columns, fits 32 grids of doubles at K = 32 (144 KB).  Row-major blocks of doubles: 16.  profiles/r05/exp_refill_group32.txt
+    // (us per 100 000-grid Gym step with rows, 16 -> 32 grids): column-major f64 33.0 -> 31.4, f32 23.8 -> 17.9; general path
+    // 40.3 -> 37.9 and 32.9 -> 22.7; row-major f64 32.5 -> 34.5 (hence 16), f32 23.3 -> 22.3.
+    const bool float_image = h->k.obs_f32;
+    plan->group = (group_env == 8 || group_env == 4 || group_env == 16 || group_env == 32 || group_env == 64) ? group_env
+                  : ((h->k.obs_colpitch || float_image) ? 32 : 16);
     plan->with_state = ahead == 0;
     plan->group0 = 0;
     plan->pitch = h->ring_pitch;
@@ -696,7 +708,6 @@ int mgx_set_ring_layout(mgx_handle *h, int32_t layout)
     if (!h) return fail(MGX_ERR_INVALID, "mgx_set_ring_layout: NULL handle");
     if (layout != MGX_RING_ROWS && layout != MGX_RING_COLUMNS) return fail(MGX_ERR_INVALID, "mgx_set_ring_layout: unknown layout %d", layout);
     if (layout == MGX_RING_COLUMNS) {
-        if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_set_ring_layout: needs exactly one module of every kind per grid");
         if (h->windowed || h->rolling || h->inplace)
             return fail(MGX_ERR_UNSUPPORTED, "mgx_set_ring_layout: column-major blocks are offered for lock-step episodes (restarts patch row-major rings)");
         // 32 grids = one 128-byte line of a float column (16 of a double column): every (block, column) run of a refill workgroup is

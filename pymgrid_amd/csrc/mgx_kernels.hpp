@@ -820,19 +820,26 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
             windows_k_module<4, IT>([&](int32_t r, int cc) { return gts[grid_ts_index(pm, N, r, cc, ic)]; }, N,
                                 a.c.grid_lo, a.c.grid_hi, a.T, ti, R, K, ic, q, Q, blk + 2 * RP, blk + NU0 + 2 * K, RP, a.row_mask);
     }
-    if (q == 0) {                                        // state columns: the current state for block 0, zeros ahead
+    // State columns: the current state for block 0 and zeros after it -- nstate strips of K words.  A ring written AHEAD of the
+    // counter has zeros only: ONE strip of K zeros that every state column maps to (windows_plan sizes the image accordingly --
+    // what lets a workgroup take 32 grids of doubles at K = 32: 144 instead of 184 KB).
+    if (q == 0) {
+        if (have_now) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) {                    // static indices: `now` stays in registers (a dynamic index put it --
-            if (j < nstate) {                            // and 64 B of zero-initialisation per thread -- into scratch memory)
-                blk[S0 + j * K] = (IT)(have_now ? now[j] : 0.0);
-                for (int32_t k = 1; k < K; k++) blk[S0 + j * K + k] = (IT)0.0;
+            for (int j = 0; j < 6; j++) {                // static indices: `now` stays in registers (a dynamic index put it --
+                if (j < nstate) {                        // and 64 B of zero-initialisation per thread -- into scratch memory)
+                    blk[S0 + j * K] = (IT)now[j];
+                    for (int32_t k = 1; k < K; k++) blk[S0 + j * K + k] = (IT)0.0;
+                }
             }
+        } else {
+            for (int32_t k = 0; k < K; k++) blk[S0 + k] = (IT)0.0;
         }
     }
     for (int32_t col = tid; col < D; col += NT) {                       // column -> offset of its k = 0 entry in a block
         uint32_t comp, h;
         decode_obs_col(a, GRID, col, W, comp, h);
-        map[col] = comp == 0xffffu ? S0 + h * K : (h == 0 ? NU0 + comp * K : comp * RP + h);
+        map[col] = comp == 0xffffu ? S0 + (have_now ? h * K : 0) : (h == 0 ? NU0 + comp * K : comp * RP + h);
     }
     __syncthreads();
     if (tid >= OBS_K_THREADS) return;                    // phase 2: the first OBS_K_THREADS threads (no barrier follows)
@@ -1573,7 +1580,11 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_multi_kernel(const KArgs a, 
         reward[i] = shaped_reward<F>(a.shaper, o);
         if (done) done[i] = done_at(a, i, t);
         if (obs) {
-            if (a.obs_f32) observe_row_multi<F>(a, i, t + 1, (float *)obs + i * a.obs_dim);
+            if (a.obs_state_only == 1 && a.obs_colpitch) {            // the state columns of a COLUMN-major ring block: coalesced runs
+                const int64_t P = a.obs_colpitch, k0 = (int64_t)(a.n_load + a.n_pv) * (1 + a.H);
+                if (a.obs_f32) observe_state_multi<F>(a, i, (float *)obs + k0 * P + i, P);
+                else observe_state_multi<F>(a, i, (double *)obs + k0 * P + i, P);
+            } else if (a.obs_f32) observe_row_multi<F>(a, i, t + 1, (float *)obs + i * a.obs_dim);
             else observe_row_multi<F>(a, i, t + 1, (double *)obs + i * a.obs_dim);
         }
     }
@@ -1586,6 +1597,12 @@ __global__ __launch_bounds__(BLOCK_MULTI) void observe_multi_kernel(const KArgs 
     t = resolve_t_obs(a, t);
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
     if (i >= a.g1) return;
+    if (a.obs_state_only == 1 && a.obs_colpitch) {                    // state columns of a column-major ring block (step_multi_kernel)
+        const int64_t P = a.obs_colpitch, k0 = (int64_t)(a.n_load + a.n_pv) * (1 + a.H);
+        if (a.obs_f32) observe_state_multi<F>(a, i, (float *)obs + k0 * P + i, P);
+        else observe_state_multi<F>(a, i, (double *)obs + k0 * P + i, P);
+        return;
+    }
     if (a.obs_f32) observe_row_multi<F>(a, i, t, (float *)obs + i * a.obs_dim);
     else observe_row_multi<F>(a, i, t, (double *)obs + i * a.obs_dim);
 }
@@ -1595,58 +1612,62 @@ __global__ __launch_bounds__(BLOCK_MULTI) void observe_multi_kernel(const KArgs 
 //   [n_series][RP] forecast forms, [n_series][K] current-value forms, [n_state][K] state columns (entry 0 = the current state
 //   for a launch at the counter, zeros ahead of it),  n_series = n_load + n_pv + 4 n_grid,  n_state = 4 n_genset + 2 n_battery,
 // filled by windows_k_module per module instance (every series value read and normalised ONCE per launch) and written out as
-// K row blocks through the same column -> image-offset map.  Row-major blocks only.
+// K row blocks through the same column -> image-offset map; row- or column-major blocks (KArgs.obs_colpitch).
 template <int F, typename OT>
-__global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_multi_kernel(const KArgs a, const WindowsKPlan plan, int32_t t,
+__global__ __launch_bounds__(OBS_P1_THREADS) void obs_windows_k_multi_kernel(const KArgs a, const WindowsKPlan plan, int32_t t,
                                                                             OT *__restrict__ ring)
 {
     t = resolve_t_obs(a, t);
-    extern __shared__ double image[];
+    extern __shared__ double image_raw[];
+    typedef typename std::conditional<sizeof(OT) == 4, float, double>::type IT;       // float rows: a float image (windows_body)
+    IT *image = reinterpret_cast<IT *>(image_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t G = plan.group, Q = OBS_K_THREADS / G, K = plan.K, RP = plan.rp, BP = plan.bp;
+    const int32_t NT = (int32_t)blockDim.x;              // phase 1 on every thread of the launch, phase 2 on the first OBS_K_THREADS (windows_body)
+    const int32_t G = plan.group, Q = NT / G, K = plan.K, RP = plan.rp, BP = plan.bp;
     const int32_t g = tid & (G - 1), q = tid / G;
     const int64_t group = (int64_t)plan.group0 + blockIdx.x, g0 = group * G, N = a.N;
     const int32_t W = 1 + a.H, D = a.obs_dim, R = K + a.H;
     const int32_t n_series = a.n_load + a.n_pv + 4 * a.n_grid, n_state = 4 * a.n_genset + 2 * a.n_battery;
     const int32_t NU0 = n_series * RP, S0 = NU0 + n_series * K;
     const int64_t i = g0 + g, ic = i < N ? i : g0;
-    double *blk = image + g * BP;
+    IT *blk = image + g * BP;
     uint32_t *map = reinterpret_cast<uint32_t *>(image + G * BP);       // [D]
     int32_t e = 0;
     {
         const double *ts = a.c.load_ts;
         const int64_t n = a.n_load;
         for (int32_t j = 0; j < a.n_load; j++, e++)
-            windows_k_module<1, double>([&](int32_t r, int) { return ts[((int64_t)r * n + j) * N + ic]; }, N, a.c.load_lo + (int64_t)j * N,
+            windows_k_module<1, IT>([&](int32_t r, int) { return ts[((int64_t)r * n + j) * N + ic]; }, N, a.c.load_lo + (int64_t)j * N,
                                 a.c.load_hi + (int64_t)j * N, a.T, t, R, K, ic, q, Q, blk + e * RP, blk + NU0 + e * K, RP, a.row_mask);
     }
     {
         const double *ts = a.c.pv_ts;
         const int64_t n = a.n_pv;
         for (int32_t j = 0; j < a.n_pv; j++, e++)
-            windows_k_module<1, double>([&](int32_t r, int) { return ts[((int64_t)r * n + j) * N + ic]; }, N, a.c.pv_lo + (int64_t)j * N,
+            windows_k_module<1, IT>([&](int32_t r, int) { return ts[((int64_t)r * n + j) * N + ic]; }, N, a.c.pv_lo + (int64_t)j * N,
                                 a.c.pv_hi + (int64_t)j * N, a.T, t, R, K, ic, q, Q, blk + e * RP, blk + NU0 + e * K, RP, a.row_mask);
     }
     if constexpr (F & F_GRID) {
         const double *ts = a.c.grid_ts;
         const int64_t n = a.n_grid;
         for (int32_t j = 0; j < a.n_grid; j++, e += 4)
-            windows_k_module<4, double>([&](int32_t r, int cc) { return ts[(((int64_t)r * n + j) * 4 + cc) * N + ic]; }, N,
+            windows_k_module<4, IT>([&](int32_t r, int cc) { return ts[(((int64_t)r * n + j) * 4 + cc) * N + ic]; }, N,
                                 a.c.grid_lo + (int64_t)j * 4 * N, a.c.grid_hi + (int64_t)j * 4 * N, a.T, t, R, K, ic, q, Q,
                                 blk + e * RP, blk + NU0 + e * K, RP, a.row_mask);
     }
-    if (q == 0) {
-        for (int32_t j = 0; j < n_state * K; j++) blk[S0 + j] = 0.0;
-        if (plan.with_state) observe_state_multi<F, double>(a, ic, blk + S0, K);
+    if (q == 0) {                                        // state strips (windows_body): one strip of zeros ahead of the counter
+        const int32_t n_zero = plan.with_state ? n_state * K : K;
+        for (int32_t j = 0; j < n_zero; j++) blk[S0 + j] = (IT)0.0;
+        if (plan.with_state) observe_state_multi<F, IT>(a, ic, blk + S0, K);
     }
     const int32_t nw = (a.n_load + a.n_pv) * W;
-    for (int32_t col = tid; col < D; col += OBS_K_THREADS) {            // column -> offset of its k = 0 entry in a block
+    for (int32_t col = tid; col < D; col += NT) {                       // column -> offset of its k = 0 entry in a block
         uint32_t m;
         if (col < nw) {
             const int32_t s = col / W, h = col - s * W;
             m = h == 0 ? NU0 + s * K : s * RP + h;
         } else if (col < nw + n_state) {
-            m = S0 + (col - nw) * K;
+            m = S0 + (plan.with_state ? (col - nw) * K : 0);
         } else {
             const int32_t c = col - nw - n_state, j = c / (4 * W), cj = c - j * 4 * W;
             const int32_t s = a.n_load + a.n_pv + 4 * j + (cj & 3), h = cj >> 2;
@@ -1655,23 +1676,69 @@ __global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_multi_kernel(cons
         map[col] = m;
     }
     __syncthreads();
+    if (tid >= OBS_K_THREADS) return;                    // phase 2: the first OBS_K_THREADS threads (no barrier follows)
     const int32_t n_valid = (N - g0 < G) ? (int32_t)(N - g0) : G;
     const int32_t total = n_valid * D;
     typedef OT vec2 __attribute__((ext_vector_type(2)));
     constexpr int KW = OBS_K_THREADS / 64;
+    if (a.obs_colpitch) {
+        // COLUMN-major blocks (windows_body): value (block k, column c, grid g0 + g) at (k * D + c) * P + g0 + g -- the G grids
+        // of a (k, c) pair are whole 128-byte lines (32 doubles: two, 32 floats: one).  A ring written ahead of the counter leaves the state columns to the
+        // steps: here they are lines of their own, so not writing them costs nothing (7 % of a 162-column row).
+        const int64_t P = a.obs_colpitch, kstride = (int64_t)D * P;
+        const int32_t Q2 = OBS_K_THREADS / G;
+        const bool in_batch = i < N;
+        OT *outc = ring + g0 + g;
+        for (int32_t c = q; c < D; c += Q2) {
+            const uint32_t m = map[c];
+            if (!plan.with_state && m >= (uint32_t)S0) continue;
+            const IT *src = image + g * BP + m;
+            OT *o = outc + (int64_t)c * P;
+            int32_t k = 0;
+            if constexpr (WIN_U > 1) {
+                for (; k + WIN_U <= K; k += WIN_U) {
+                    IT v[WIN_U];
+#pragma unroll
+                    for (int u = 0; u < WIN_U; u++) v[u] = src[k + u];
+#pragma unroll
+                    for (int u = 0; u < WIN_U; u++)
+                        if (in_batch) MGX_WIN_STORE((OT)v[u], o + (int64_t)(k + u) * kstride);
+                }
+            }
+            for (; k < K; k++)
+                if (in_batch) MGX_WIN_STORE((OT)src[k], o + (int64_t)k * kstride);
+        }
+        return;
+    }
     const int64_t block_stride = (int64_t)plan.pitch * D;
     OT *out0 = ring + ((int64_t)wave * plan.pitch + g0) * D;
     // pairs of elements where they never straddle two rows (D even) and the ring is 16-byte aligned; else element by element
     if (!(D & 1) && (reinterpret_cast<uintptr_t>(ring) & (sizeof(vec2) - 1)) == 0) {
         int32_t r = 2 * lane / D, c = 2 * lane - r * D;
         for (int32_t f = 2 * lane; f < total; f += 128) {
-            const double *s0 = image + r * BP + map[c] + wave, *s1 = image + r * BP + map[c + 1] + wave;
+            const IT *s0 = image + r * BP + map[c] + wave, *s1 = image + r * BP + map[c + 1] + wave;
             OT *out = out0 + f;
-            for (int32_t k = wave; k < K; k += KW) {
+            const int64_t kw_stride = KW * block_stride;
+            int32_t k = wave;
+            if constexpr (WIN_U > 1) {                   // WIN_U pairs of image words in flight before the first store of the batch
+                for (; k + (WIN_U - 1) * KW < K; k += WIN_U * KW) {
+                    IT a0[WIN_U], a1[WIN_U];
+#pragma unroll
+                    for (int u = 0; u < WIN_U; u++) { a0[u] = s0[u * KW]; a1[u] = s1[u * KW]; }
+#pragma unroll
+                    for (int u = 0; u < WIN_U; u++) {
+                        vec2 v2;
+                        v2.x = (OT)a0[u]; v2.y = (OT)a1[u];
+                        MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out + u * kw_stride));
+                    }
+                    s0 += WIN_U * KW; s1 += WIN_U * KW; out += WIN_U * kw_stride;
+                }
+            }
+            for (; k < K; k += KW) {
                 vec2 v2;
                 v2.x = (OT)*s0; v2.y = (OT)*s1;
                 MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(out));
-                s0 += KW; s1 += KW; out += KW * block_stride;
+                s0 += KW; s1 += KW; out += kw_stride;
             }
             c += 128;
             while (c >= D) { c -= D; r++; }
@@ -1679,7 +1746,7 @@ __global__ __launch_bounds__(OBS_K_THREADS) void obs_windows_k_multi_kernel(cons
     } else {
         int32_t r = lane / D, c = lane - r * D;
         for (int32_t f = lane; f < total; f += 64) {
-            const double *s0 = image + r * BP + map[c] + wave;
+            const IT *s0 = image + r * BP + map[c] + wave;
             OT *out = out0 + f;
             for (int32_t k = wave; k < K; k += KW) {
                 MGX_WIN_STORE((OT)*s0, out);

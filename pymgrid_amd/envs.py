@@ -156,8 +156,8 @@ class BatchedMicrogridEnv:
                 raise ValueError("obs_views needs observations=True, one module of every kind per grid, the oracle forecaster "
                                  "and no observation_keys")
             obs_prefetch = 0
-        # (several modules of a kind per grid: the general refill kernel, row-major blocks, lock-step episodes over [T, n, N] series)
-        self._prefetch_ok = bool(observations and L.horizon > 0 and not noisy and not (L.multi and (obs_layout == "columns" or batch.factorised)))
+        # (several modules of a kind per grid: the general refill kernel, lock-step episodes over [T, n, N] series)
+        self._prefetch_ok = bool(observations and L.horizon > 0 and not noisy and not (L.multi and batch.factorised))
         self._obs_dtype = obs_dtype
         self.obs_prefetch = int(obs_prefetch) if (obs_prefetch and int(obs_prefetch) > 1 and self._prefetch_ok) else 0
         # Three rings of K blocks: while the steps walk ring r, the windows of ring r + 1 (the NEXT K counter values) are
@@ -174,7 +174,7 @@ class BatchedMicrogridEnv:
         if obs_layout not in (None, "rows", "columns"):
             raise ValueError("obs_layout must be None (automatic), 'rows' or 'columns'")
         self._obs_layout_auto = obs_layout is None
-        self._obs_columns = (obs_layout == "columns") if obs_layout is not None else not L.multi
+        self._obs_columns = (obs_layout == "columns") if obs_layout is not None else True
         self._ring = self._rings = self._ring_store = None
         # Position inside ring 0 at which a refill starts the walk (0 <= phase < K): the first ring after a reset is then
         # K - phase blocks long and every later ring change falls phase steps EARLIER than that of an env with phase 0.  A fleet
@@ -340,7 +340,9 @@ class BatchedMicrogridEnv:
         else:
             rc = fn(*action, _raw_stream(fp.dev))
         if rc:
-            _lib.check(rc)
+            if rc == _lib.MGX_ERR_DEVICE:             # the launch sequence broke off somewhere: the handle's position is not ours any more
+                self._fp = None
+            _lib.check(rc)                            # (range / argument errors are raised before anything moves: still bound)
         e._t = t + 1
         k = fp.k
         fp.k = k + 1 if k + 1 < fp.R else 0
@@ -399,7 +401,7 @@ class BatchedMicrogridEnv:
         if self.trajectory_func is not None and initial_step is None:
             self._draw_window()
         self._sync_rings = False
-        if self._obs_layout_auto and self._ring is not None and not self._obs_columns and not self.layout.multi \
+        if self._obs_layout_auto and self._ring is not None and not self._obs_columns \
                 and not self._chunked and not self._fleet_owned:
             self.engine.reset(initial_step, want_obs=False)    # lock-step again: leave the per-grid mode, then column-major blocks
             self._set_ring_columns(True)
@@ -732,8 +734,9 @@ class BatchedMicrogridEnv:
             if self.engine._t is None:    # the counter moved to the device (graph capture): per-call bookkeeping from here on
                 self._unbind_fast()
             else:
-                if not (action.dtype is fp.adt and action.shape == fp.ashape and action.is_contiguous() and action.is_cuda):
+                if not (action.dtype is fp.adt and action.shape == fp.ashape and action.is_contiguous() and action.get_device() == fp.dev):
                     self.engine._check_actions(action, ())           # raises with the full message
+                    raise ValueError(f"actions must live on {self.batch.device}")
                 return self._step_fast(fp, fp.fn, (fp.h, action.data_ptr(), 1 if normalized else 0))
         if self.raise_errors:             # dry run first (mgx_check_step): a refused request raises BEFORE anything is applied
             self._raise_on_violations(self.engine.check_step(action, normalized=normalized))
@@ -984,7 +987,7 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
             if self.engine._t is None:
                 self._unbind_fast()
             else:
-                if action_id.shape != (self.n_grids,):
+                if action_id.shape != (self.n_grids,) or action_id.get_device() != fp.dev:
                     raise ValueError(f"action_id must be an int32 tensor of shape ({self.n_grids},) on {self.batch.device}")
                 return self._step_fast(fp, fp.fn_discrete, (fp.h, action_id.data_ptr()))
         want_obs, out = self._obs_target()

@@ -7,28 +7,32 @@ import pytest
 torch = pytest.importorskip("torch")
 
 
-def _envs(device, dt, K, **wide):
+def _envs(device, dt, K, layout="rows", **wide):
     from pymgrid_amd import BatchedMicrogridEnv
     from pymgrid_amd.generator import generate, widen
     out = []
     for k in (K, 0):
         base = generate(150, n_steps=90, seed=11, arch="genset+battery+grid", horizon=24, device=device)
-        out.append(BatchedMicrogridEnv(widen(base, **wide), obs_prefetch=k, obs_dtype=dt))
+        out.append(BatchedMicrogridEnv(widen(base, **wide), obs_prefetch=k, obs_dtype=dt, obs_layout=layout if k else "rows"))
     return out
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["rows", "columns", None])
 @pytest.mark.parametrize("dt", ["float64", "float32"])
 @pytest.mark.parametrize("wide", [dict(n_genset=2, n_battery=2, n_grid=1), dict(n_genset=1, n_battery=3, n_grid=2, n_load=2),
                                   dict(n_genset=2, n_battery=1, n_grid=1, n_load=2, n_pv=3)])
-def test_ring_rows_of_multi_instance_grids_are_the_per_step_rows(device, dt, wide):
+def test_ring_rows_of_multi_instance_grids_are_the_per_step_rows(device, dt, wide, layout):
+    """layout: row-major ring blocks, column-major ones ([D, pitch]; the env returns the transposed view), and the default (column-
+    major while the batch walks in lock-step)."""
     dt = getattr(torch, dt)
-    ring, plain = _envs(device, dt, 4, **wide)
+    ring, plain = _envs(device, dt, 4, layout, **wide)
     assert ring.obs_prefetch == 4 and plain.obs_prefetch == 0 and ring.layout.multi
     L = ring.layout
     gen = torch.Generator(device=device); gen.manual_seed(2)
     o_r, o_p = ring.reset(), plain.reset()
     assert o_r.shape == (150, L.obs_dim) and torch.equal(o_r, o_p)
+    assert o_r.stride() == ((L.obs_dim, 1) if layout == "rows" else (1, 160))
     for k in range(70):                                   # 17 ring changes; rows past the end of the series from step 66 on
         a = torch.rand(150, L.action_dim, dtype=torch.float64, device=device, generator=gen)
         o_r, r_r, d_r, _ = ring.step(a)
