@@ -589,15 +589,16 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     plan->rp = R;
     plan->bp = (ncomp * (R + K) + (ahead == 0 ? nstate : 1) * K) | 1;      // ahead of the counter: ONE strip of zeros for all state columns
     static const int group_env = [] { const char *e = getenv("MGX_WIN_GROUP"); return e ? atoi(e) : 0; }();   // experiment knob
-    // Float rows keep a FLOAT image (windows_body): half the LDS per grid.  Column-major blocks and float rows: 32 grids per
-    // workgroup wherever the image fits (halved below while it does not) -- 32 x 4 bytes are what a whole 128-byte line of a
-    // column-major block needs, 32 doubles are two; a refill ahead of the counter, whose image has ONE strip of zeros for the state
-    // columns, fits 32 grids of doubles at K = 32 (144 KB).  Row-major blocks of doubles: 16.  profiles/r05/exp_refill_group32.txt
-    // (us per 100 000-grid Gym step with rows, 16 -> 32 grids): column-major f64 33.0 -> 31.4, f32 23.8 -> 17.9; general path
-    // 40.3 -> 37.9 and 32.9 -> 22.7; row-major f64 32.5 -> 34.5 (hence 16), f32 23.3 -> 22.3.
+    // Float rows keep a FLOAT image (windows_body): half the LDS per grid, and a refill ahead of the counter has ONE strip of zeros
+    // for all state columns.  Grids per workgroup (halved below while the image does not fit): 32 for float rows -- 32 x 4 bytes are
+    // what a whole 128-byte line of a column-major block needs -- and for column-major blocks of doubles on the general path (two
+    // lines per run; 144 KB at K = 32), 16 for everything else in doubles.  us per 100 000-grid Gym step with rows, 16 -> 32 grids
+    // (profiles/r05/exp_refill_group32.txt, exp_fleet_group_ab.txt): general path 40.3 -> 37.9 (f64 columns), 32.9 -> 22.7 (f32
+    // columns); single env f64 columns 33.0 -> 31.4 but the config-5 FLEET 24.5 -> 25.2 (a refill that is faster alone costs the
+    // step launches beside it more: hence 16); f32 columns 23.8 -> 17.9, fleet 22.0 -> 15.5; row-major f64 32.5 -> 34.5.
     const bool float_image = h->k.obs_f32;
     plan->group = (group_env == 8 || group_env == 4 || group_env == 16 || group_env == 32 || group_env == 64) ? group_env
-                  : ((h->k.obs_colpitch || float_image) ? 32 : 16);
+                  : ((float_image || (h->multi && h->k.obs_colpitch)) ? 32 : 16);
     plan->with_state = ahead == 0;
     plan->group0 = 0;
     plan->pitch = h->ring_pitch;
