@@ -257,7 +257,9 @@ int mgx_set_window(mgx_handle *h, int32_t initial_step, int32_t final_step);
  * (device, int32; required with `length`) receives the episode lengths actually used and must stay alive until the
  * next reset.  Observation bounds stay those of the full series.  Stepping past the longest episode (counter >= max_length)
  * is MGX_ERR_RANGE, like stepping past the end of a series.  mgx_reset() returns to the full series.
- * MGX_ERR_UNSUPPORTED with several load / renewable modules, in device-counter mode or while stepping in shards. */
+ * Layouts with several modules of a kind per grid (series [T, n, N]): load_w [R, n_load, N], pv_w [R, n_pv, N], grid_w
+ * [R, n_grid, 4, N]; rings (mgx_observe_windows[_ahead]) work over them as over the full series.
+ * MGX_ERR_UNSUPPORTED in device-counter mode, while stepping in shards, with column-major ring blocks. */
 int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length,
                       double *load_w, double *pv_w, double *grid_w, int32_t *final_rel, void *obs, mgx_stream stream);
 

@@ -570,9 +570,9 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     if (!h || !ring) return fail(MGX_ERR_INVALID, "%s: NULL argument", who);
     if (K < 1 || K > 4096) return fail(MGX_ERR_INVALID, "%s: K = %d outside [1, 4096]", who, K);
     if (ahead < 0) return fail(MGX_ERR_INVALID, "%s: ahead = %d is negative", who, ahead);
-    if (h->multi && (h->windowed || h->rolling || h->inplace || factorised(h->k.c)))
+    if (h->multi && (h->rolling || h->inplace || factorised(h->k.c)))
         return fail(MGX_ERR_UNSUPPORTED, "%s: with several modules of a kind per grid the window prefetch is offered for lock-step "
-                                         "episodes over [T, n, N] series", who);
+                                         "counters (mgx_reset, mgx_reset_windows) over [T, n, N] series", who);
     if (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std)
         return fail(MGX_ERR_UNSUPPORTED, "%s: forecast noise depends on (step, horizon index), windows cannot be shared", who);
     if (h->k.obs_state_only == 2)
@@ -902,7 +902,8 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
 {
     g_err[0] = 0;
     if (!h || !start || !load_w || !pv_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows: NULL argument");
-    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: needs exactly one module of every kind per grid");
+    if (h->multi && factorised(h->windowed ? h->full_c : h->k.c))
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: several modules of a kind per grid need [T, n, N] series arrays");
     if (h->k.obs_colpitch) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_windows: not offered with column-major ring blocks (mgx_set_ring_layout)");
     if (h->layout.has_grid && !grid_w) return fail(MGX_ERR_INVALID, "mgx_reset_windows: grid_w is NULL but the layout has a GridModule");
     if (length && !final_rel) return fail(MGX_ERR_INVALID, "mgx_reset_windows: per-grid lengths need the final_rel buffer");
@@ -929,7 +930,10 @@ int mgx_reset_windows(mgx_handle *h, const int32_t *start, const int32_t *length
     g.mask = nullptr; g.row0 = 0; g.row_mask = -1;
     g.fc = h->full_c; g.has_grid = h->layout.has_grid;
     g.draw = 0; g.fixed_length = 0; g.seed = 0; g.start_io = nullptr; g.length_io = nullptr; g.t0_io = nullptr; g.ep_off = nullptr;
-    gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g);
+    if (h->multi)                                        // [T, n, N] series, window buffers [rows, n, N] ([rows, n_grid, 4, N])
+        gather_windows_multi_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g, h->k.n_load, h->k.n_pv, h->layout.has_grid ? h->k.n_grid : 0);
+    else
+        gather_windows_kernel<<<blocks_for(h->k.N), BLOCK, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gather_windows_kernel launch");
     h->rolling = false; h->k.row_mask = -1;

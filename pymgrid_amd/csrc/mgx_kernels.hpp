@@ -2102,6 +2102,43 @@ static __global__ __launch_bounds__(BLOCK) void gather_windows_kernel(const Gath
     }
 }
 
+// The same for layouts with several modules of a kind (mgx_reset_windows on the general path): series [T, C, N] with
+// C = n_load / n_pv / 4 n_grid components, bounds [C, N], window buffers [rows, C, N].  One lane per grid, component by
+// component, 8 rows in flight; once per episode.
+__device__ __forceinline__ void gather_component_rows(const double *__restrict__ src, const double *__restrict__ lo,
+                                                      const double *__restrict__ hi, double *__restrict__ dst, int32_t C, int64_t N,
+                                                      int32_t T, int32_t rows, int32_t s, int64_t i)
+{
+    constexpr int RB = 8;
+    for (int32_t c = 0; c < C; c++) {
+        const double pad = (lo && hi) ? (hi[(int64_t)c * N + i] + lo[(int64_t)c * N + i]) / 2 : 0.0;   // forecaster.py:95,120-137
+        for (int32_t r0 = 0; r0 < rows; r0 += RB) {
+            double v[RB];
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const int64_t row = (int64_t)s + r0 + u, rc = row < T ? row : (int64_t)T - 1;
+                v[u] = src[(rc * C + c) * N + i];
+            }
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const int32_t r = r0 + u;
+                if (r < rows) dst[((int64_t)r * C + c) * N + i] = ((int64_t)s + r < T) ? v[u] : pad;
+            }
+        }
+    }
+}
+
+static __global__ __launch_bounds__(BLOCK) void gather_windows_multi_kernel(const GatherArgs g, int32_t n_load, int32_t n_pv, int32_t n_grid)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= g.N) return;
+    int32_t s, len;
+    gather_episode(g, i, s, len);
+    gather_component_rows(g.load_ts, g.load_lo, g.load_hi, g.load_w, n_load, g.N, g.T, g.rows, s, i);
+    gather_component_rows(g.pv_ts, g.pv_lo, g.pv_hi, g.pv_w, n_pv, g.N, g.T, g.rows, s, i);
+    if (n_grid > 0) gather_component_rows(g.grid_ts, g.grid_lo, g.grid_hi, g.grid_w, 4 * n_grid, g.N, g.T, g.rows, s, i);
+}
+
 
 // ------------------------------------------------------------------------------------------------------
 // Series synthesis (mgx_synthesize_series): MicrogridGenerator's time series for N grids, written at HBM speed.

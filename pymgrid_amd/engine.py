@@ -343,9 +343,14 @@ class StepEngine:
         rows = int(max_length) + L.horizon + 1
         w = getattr(self, "_windows", None)
         if w is None or w["rows"] != rows:
-            w = dict(rows=rows, load=self._empty(rows, self.N), pv=self._empty(rows, self.N),
-                     grid=self._empty(rows, 4, self.N) if L.has_grid else None,
-                     final=self._empty(self.N, dtype=torch.int32))
+            if L.multi:                 # several modules of a kind: series [T, n, N], window buffers [rows, n, N]
+                w = dict(rows=rows, load=self._empty(rows, max(1, L.n_load), self.N), pv=self._empty(rows, max(1, L.n_pv), self.N),
+                         grid=self._empty(rows, L.n_grid, 4, self.N) if L.has_grid else None,
+                         final=self._empty(self.N, dtype=torch.int32))
+            else:
+                w = dict(rows=rows, load=self._empty(rows, self.N), pv=self._empty(rows, self.N),
+                         grid=self._empty(rows, 4, self.N) if L.has_grid else None,
+                         final=self._empty(self.N, dtype=torch.int32))
             self._windows = w
         obs = self._obs_buf(out) if want_obs else None
         self._call(self._lib.mgx_reset_windows, start.data_ptr(), _ptr(length), int(max_length), w["load"].data_ptr(),

@@ -72,3 +72,49 @@ def test_fleet_with_a_multi_instance_bucket_on_rings(device):
     fleet.close()
     for e in alone:
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [0, 4])
+@pytest.mark.parametrize("wide", [dict(n_genset=2, n_battery=2, n_grid=1), dict(n_genset=1, n_battery=2, n_grid=2, n_load=2, n_pv=3)])
+def test_per_grid_windows_of_multi_instance_grids(device, wide, K):
+    """mgx_reset_windows on the general path (per-microgrid trajectories, microgrid.py:205-225): grid i walks its own rows
+    start[i] + k and is done after length[i] steps -- rows, rewards and log of every grid == those of the lock-step batch reset at
+    that grid's start row (itself pinned to the reference-made multi.npz), forecasts past the end of the series included; with and
+    without rings."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    from pymgrid_amd.generator import generate, widen
+    N, T, H, steps = 150, 90, 24, 30
+
+    def make(k):
+        base = generate(N, n_steps=T, seed=11, arch="genset+battery+grid", horizon=H, device=device)
+        return BatchedMicrogridEnv(widen(base, **wide), obs_prefetch=k)
+    starts_of = (0, 17, 50)                                    # 50 + 30 + 24 > 90: windows that run past the series
+    gen = torch.Generator(device=device); gen.manual_seed(7)
+    pick = torch.randint(0, 3, (N,), device=device, generator=gen)
+    start = torch.tensor(starts_of, device=device, dtype=torch.int32)[pick]
+    length = torch.randint(5, steps + 1, (N,), device=device, generator=gen).to(torch.int32)
+    env = make(K)
+    assert env.layout.multi and env.obs_prefetch == K
+    acts = [torch.rand(N, env.layout.action_dim, dtype=torch.float64, device=device, generator=gen) for _ in range(steps)]
+    obs = [env.reset_windows(start, length, max_length=steps).clone()]
+    rew, done = [], []
+    for a in acts:
+        o, r, d, _ = env.step(a)
+        obs.append(o.clone()); rew.append(r.clone()); done.append(d.clone())
+    assert torch.equal(env.current_steps.to(torch.int32), start + steps)
+    for v, s0 in enumerate(starts_of):
+        ref = make(0)                                          # the same grids, lock-step from row s0
+        mine = pick == v
+        o = ref.reset(s0)
+        assert torch.equal(obs[0][mine], o[mine]), ("reset", s0)
+        for k, a in enumerate(acts):
+            o, r, d, _ = ref.step(a)
+            assert torch.equal(obs[k + 1][mine], o[mine]), (s0, k)
+            assert torch.equal(rew[k][mine], r[mine]), (s0, k)
+        ref.close()
+    for k in range(steps):                                     # done_i from step length_i - 1 on (base_timeseries_module.py:124-125)
+        assert torch.equal(done[k].to(torch.bool), k >= length - 1), k
+    env.reset()                                                # a plain reset returns to the shared window
+    assert int(env.current_steps.max()) == 0
+    env.close()
