@@ -1363,26 +1363,63 @@ __device__ __forceinline__ void load_multi_step_in(const KArgs &a, const AT *__r
 }
 
 // One Microgrid.run of grid i out of registers: step_multi_core's sweep, line for line, with compile-time instance indices.
+// The lists of step_multi_small: slot s of `provided` = gensets [0, MS), then the source-and-sink names in sweep order (batteries and
+// grids, MS slots each), renewables [3 MS, 4 MS), loss load 4 MS; of `absorbed` = loads [0, MS), batteries / grids as above,
+// overgeneration 3 MS.  A slot is an addend iff its bit is set; the list np.sum sees is the set slots in slot order.  The sums follow
+// np_sum_strided: a running sum from 0.0 below 8 addends; with 8 or 9 (only `provided` can: at most ONE of its 9 slots is then unset)
+// the first eight in numpy's pairwise order, the ninth added last.
+constexpr int SMALL_PROV = 4 * MS + 1, SMALL_ABSB = 3 * MS + 1;
+static_assert(MS == 2, "small_sum_prov assumes at most 9 addends: one unset slot at 8");
+
+__device__ __forceinline__ double small_sum_absb(const double (&e)[SMALL_ABSB], uint32_t mask)
+{
+    double res = 0.0;                                     // SMALL_ABSB = 7 < 8 addends: always the running sum
+#pragma unroll
+    for (int s = 0; s < SMALL_ABSB; s++) res = ((mask >> s) & 1u) ? res + e[s] : res;
+    return res;
+}
+
+__device__ __forceinline__ double small_sum_prov(const double (&e)[SMALL_PROV], uint32_t mask)
+{
+    double seq = 0.0;
+#pragma unroll
+    for (int s = 0; s < SMALL_PROV; s++) seq = ((mask >> s) & 1u) ? seq + e[s] : seq;
+    const int n = __popc(mask);
+    if (n < 8) return seq;
+    const uint32_t miss = ~mask & ((1u << SMALL_PROV) - 1u);          // no bit (n = 9) or one (n = 8)
+    const int m = miss ? __ffs((int)miss) - 1 : SMALL_PROV;
+    double r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) r[k] = (k < m) ? e[k] : e[k + 1];     // the first eight addends
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    if (n == 9) res += e[8];
+    return res;
+}
+
 template <int F>
 __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, const MultiStepIn &sin, int64_t i, bool normalized,
-                                                 StepLists &L, double *__restrict__ log, Outputs &o)
+                                                 double *__restrict__ log, Outputs &o)
 {
     const int64_t N = a.N;
     const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
     double reward = 0.0;
     uint32_t viol = 0u;
-    L.n_prov = 0; L.n_absb = 0;
+    // The provided / absorbed lists of MicrogridStep in REGISTERS: one static slot per possible addend in sweep order (SmallLists),
+    // a presence bit each -- the run-time form appends to LDS columns and sums them with a dependent LDS read per addend.
+    constexpr int SB = (F & F_GRID_FIRST) ? 2 * MS : MS, SR = (F & F_GRID_FIRST) ? MS : 2 * MS;     // first battery / grid slot
+    double pe[SMALL_PROV] = {}, ae[SMALL_ABSB] = {};
+    uint32_t pm = 0u, am = 0u;
     o.load_met = 0.0;
 #pragma unroll
     for (int j = 0; j < MS; j++) {                        // fixed modules, module order (microgrid.py:255-257)
         if (j < a.n_load) {
             const double Lv = -1 * sin.load[j];
             o.load_met += Lv;
-            L.absorbed(Lv); reward += 0.0;
+            ae[j] = Lv; am |= 1u << j; reward += 0.0;
         }
     }
-    o.fixed_provided = np_sum_strided(L.prov, L.stride, L.n_prov);          // :259-260
-    o.fixed_absorbed = np_sum_strided(L.absb, L.stride, L.n_absb);
+    o.fixed_provided = small_sum_prov(pe, pm);            // :259-260 (an empty list: 0.0)
+    o.fixed_absorbed = small_sum_absb(ae, am);
 
     const int kg = LC_COMMON_END, kb = kg + LC_GENSET_N * NG, kr = kb + LC_BATTERY_N * NB;    // log blocks
     Inputs in; in.load = 0.0; in.pv = 0.0;
@@ -1399,7 +1436,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 in.a_goal = sin.goal[j]; in.a_gen = sin.gen[j];
                 step_core<F_GENSET>(p, d, s, in, normalized, false, false, oc);
                 R.g_status[j] = s.status;
-                L.provided(oc.genset_production); reward += oc.genset_reward; viol |= oc.violations;
+                pe[j] = oc.genset_production; pm |= 1u << j; reward += oc.genset_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kg + LC_GENSET_N * j) * N;
                     q[0] = oc.genset_production; q[N] = oc.genset_co2; q[2 * N] = oc.genset_reward; q[3 * N] = (double)s.status;
@@ -1421,8 +1458,8 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 step_core<F_BATTERY>(p, d, s, in, normalized, true, false, oc);
                 R.b_charge[j] = s.charge; R.b_soc[j] = s.soc;
                 const double x = normalized ? d.bat_lo + d.bat_sp * in.a_bat : in.a_bat;
-                if (x < 0) { L.absorbed(oc.charge_amount); any_sink = true; }
-                else { L.provided(oc.discharge_amount); discharge_sum += oc.discharge_amount; }
+                if (x < 0) { ae[SB + j] = oc.charge_amount; am |= 1u << (SB + j); any_sink = true; }
+                else { pe[SB + j] = oc.discharge_amount; pm |= 1u << (SB + j); discharge_sum += oc.discharge_amount; }
                 reward += oc.battery_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kb + LC_BATTERY_N * j) * N;
@@ -1444,7 +1481,8 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 in.a_grid = sin.grd[j];
                 step_core<F_GRID>(p, d, s, in, normalized, false, false, oc);
                 const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;
-                if (x < 0) L.absorbed(oc.grid_export); else L.provided(oc.grid_import);
+                if (x < 0) { ae[SR + j] = oc.grid_export; am |= 1u << (SR + j); }
+                else { pe[SR + j] = oc.grid_import; pm |= 1u << (SR + j); }
                 reward += oc.grid_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kr + LC_GRID_N * j) * N;
@@ -1462,8 +1500,8 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     }
     o.discharge_amount = any_sink ? 0.0 : discharge_sum;
     o.charge_amount = 0.0;
-    const double provided = np_sum_strided(L.prov, L.stride, L.n_prov);      // :277
-    const double consumed = np_sum_strided(L.absb, L.stride, L.n_absb);
+    const double provided = small_sum_prov(pe, pm);       // :277
+    const double consumed = small_sum_absb(ae, am);
     const double difference = provided - consumed;
     o.ctrl_provided = provided - o.fixed_provided; o.ctrl_absorbed = consumed - o.fixed_absorbed;
 
@@ -1474,13 +1512,13 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
         for (int j = 0; j < MS; j++) {
             if (j < a.n_pv) {
                 o.curtailment += sin.pv[j] - 0.0;
-                L.provided(0.0); reward += 0.0;
+                pe[3 * MS + j] = 0.0; pm |= 1u << (3 * MS + j); reward += 0.0;
             }
         }
         const double e = -1.0 * (-1.0 * difference);
         o.overgeneration = e; o.loss_load = 0.0;
         o.unbalanced_reward = -1.0 * (og_cost * e);
-        L.absorbed(e);
+        ae[3 * MS] = e; am |= 1u << (3 * MS);
     } else {                                              // :301-314: renewables in module order, then loss load
         double need = -difference;
 #pragma unroll
@@ -1489,17 +1527,17 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 const double pv = sin.pv[j];
                 const double amt = (pv < need) ? pv : need;
                 o.renewable_used += amt; o.curtailment += pv - amt;
-                L.provided(amt); reward += 0.0;
+                pe[3 * MS + j] = amt; pm |= 1u << (3 * MS + j); reward += 0.0;
                 need -= amt;
             }
         }
         o.loss_load = need; o.overgeneration = 0.0;
         o.unbalanced_reward = -1.0 * (ll_cost * need);
-        L.provided(need);
+        pe[4 * MS] = need; pm |= 1u << (4 * MS);
     }
     reward += o.unbalanced_reward;
-    o.overall_provided = np_sum_strided(L.prov, L.stride, L.n_prov);         // :316-317
-    o.overall_absorbed = np_sum_strided(L.absb, L.stride, L.n_absb);
+    o.overall_provided = small_sum_prov(pe, pm);          // :316-317
+    o.overall_absorbed = small_sum_absb(ae, am);
     o.reward = reward;
     o.violations = viol;
     if (log) {

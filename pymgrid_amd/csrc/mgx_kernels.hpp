@@ -1573,7 +1573,7 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_multi_kernel(const KArgs a, 
             load_multi_regs<F>(a, i, R);
             if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + i * A, i, t, sin);
             else load_multi_step_in<F>(a, (const double *)actions + i * A, i, t, sin);
-            step_multi_small<F>(a, R, sin, i, normalized != 0, L, log ? log + i : nullptr, o);
+            step_multi_small<F>(a, R, sin, i, normalized != 0, log ? log + i : nullptr, o);
             store_multi_state<F>(a, i, R);
         } else if (a.act_f32) step_multi_core<F>(a, (const float *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
         else step_multi_core<F>(a, (const double *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
@@ -1847,7 +1847,7 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a
                 else load_multi_step_in<F>(a, (const double *)actions + offn * A, i, t0 + kn, nxt);
                 Outputs o;
                 double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
-                step_multi_small<F>(a, R, cur, i, normalized != 0, L, log, o);
+                step_multi_small<F>(a, R, cur, i, normalized != 0, log, o);
                 const double r = shaped_reward<F>(a.shaper, o);
                 if (out.reward) out.reward[off] = r;
                 if (out.done) out.done[off] = (uint8_t)(k >= k_done);

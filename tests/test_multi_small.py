@@ -22,10 +22,14 @@ from pymgrid_amd.generator import generate, widen
 dev = torch.device("cuda:0")
 out = {}
 g = torch.Generator(device=dev); g.manual_seed(11)
-for tag, (ng, nb, nr), arch in (("a", (2, 2, 1), "genset+battery+grid"), ("b", (1, 2, 2), "genset+battery+grid"), ("c", (2, 1, 0), "genset+battery")):
+# "d": two of EVERYTHING -- up to 9 addends in the provided list (2 gensets, 2 discharging batteries, 2 importing grids, 2 renewables,
+# loss load): the sums with 8 and 9 addends take numpy's pairwise order, which the register form rebuilds from its static slots
+for tag, (ng, nb, nr, nl, npv), arch in (("a", (2, 2, 1, 1, 1), "genset+battery+grid"), ("b", (1, 2, 2, 1, 1), "genset+battery+grid"),
+                                        ("c", (2, 1, 0, 1, 1), "genset+battery"), ("d", (2, 2, 2, 2, 2), "genset+battery+grid")):
     N, T, K = 1500, 90, 24
     def batch():
-        return widen(generate(N, n_steps=T, seed=21, arch=arch, horizon=3, device=dev, mixed_timers=True), n_genset=ng, n_battery=nb, n_grid=nr)
+        return widen(generate(N, n_steps=T, seed=21, arch=arch, horizon=3, device=dev, mixed_timers=True), n_genset=ng, n_battery=nb, n_grid=nr,
+                     n_load=nl, n_pv=npv)
     env = BatchedMicrogridEnv(batch(), log=True, obs_prefetch=0)
     A = env.layout.action_dim
     acts = torch.rand(K + 6, N, A, dtype=torch.float64, device=dev, generator=g)
