@@ -599,6 +599,12 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     const bool float_image = h->k.obs_f32;
     plan->group = (group_env == 8 || group_env == 4 || group_env == 16 || group_env == 32 || group_env == 64) ? group_env
                   : ((float_image || (h->multi && h->k.obs_colpitch)) ? 32 : 16);
+    // Column-major blocks: a lane stores a PAIR of adjacent grids per instruction (16-byte stores of doubles, 8-byte stores of floats:
+    // half the store instructions for the same lines).  us per 100 000-grid Gym step with rows, off -> on
+    // (profiles/r05/exp_refill_col_pairs_matrix.txt): single env f64 31.3 -> 28.8, general path f64 37.9 -> 33.6, config-5 fleet f64
+    // 23.1 -> 21.7, f32 15.5 -> 14.9; float rows of single envs unchanged within the spread.  MGX_WIN_PAIRS=0/1 overrides.
+    static const int pairs_env = [] { const char *e = getenv("MGX_WIN_PAIRS"); return e ? atoi(e) : -1; }();
+    plan->pairs = pairs_env >= 0 ? pairs_env : (h->k.obs_colpitch ? 1 : 0);
     plan->with_state = ahead == 0;
     plan->group0 = 0;
     plan->pitch = h->ring_pitch;

@@ -757,6 +757,7 @@ struct WindowsKPlan {
     int32_t with_state;      // block 0 receives the state columns of the current state (0: a prefetch AHEAD of the counter)
     int32_t group0;          // first group of this launch (a launch may cover a chunk of the batch's groups)
     int32_t pitch;           // rows between consecutive blocks of the ring (>= N; mgx_set_ring_pitch)
+    int32_t pairs;           // column-major blocks: a lane stores a PAIR of adjacent grids per instruction (windows_plan)
 };
 
 #ifdef MGX_WIN_PLAIN_STORES
@@ -858,6 +859,42 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         // floats out of the float image -- are ONE 128-byte line (P and g0 are multiples of G), written whole by G adjacent lanes.  Nothing else ever writes into such a line's bytes
         // except the step's state columns -- which are whole coalesced lines of their own here (a wave's 64 grids x 8 B per column).
         const int64_t P = a.obs_colpitch;
+        const int64_t kstride2 = (int64_t)D * P;
+        if (plan.pairs && wide) {
+            // a lane carries a PAIR of adjacent grids (2 gp, 2 gp + 1: adjacent words of a column): 8-byte stores of floats, 16-byte
+            // stores of doubles -- half the store instructions for the same lines (g0, P even: every pair is aligned)
+            const int32_t GP = G >> 1, gp = tid & (GP - 1), cq = tid / GP, QP = OBS_K_THREADS / GP;
+            const int64_t i0 = g0 + 2 * gp;
+            const bool ok0 = i0 < N, ok1 = i0 + 1 < N;
+            const IT *img0 = image + (2 * gp) * BP, *img1 = img0 + BP;
+            OT *outp = ring + i0;
+            for (int32_t c = cq; c < D; c += QP) {
+                const uint32_t m = map[c];
+                if (!have_now && m >= (uint32_t)S0) continue;
+                const IT *s0 = img0 + m, *s1 = img1 + m;
+                OT *o = outp + (int64_t)c * P;
+                int32_t k = 0;
+                if constexpr (WIN_U > 1) {
+                    for (; k + WIN_U <= K; k += WIN_U) {
+                        IT v0[WIN_U], v1[WIN_U];
+#pragma unroll
+                        for (int u = 0; u < WIN_U; u++) { v0[u] = s0[k + u]; v1[u] = s1[k + u]; }
+#pragma unroll
+                        for (int u = 0; u < WIN_U; u++) {
+                            OT *dst = o + (int64_t)(k + u) * kstride2;
+                            if (ok1) { vec2 v2; v2.x = (OT)v0[u]; v2.y = (OT)v1[u]; MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(dst)); }
+                            else if (ok0) MGX_WIN_STORE((OT)v0[u], dst);
+                        }
+                    }
+                }
+                for (; k < K; k++) {
+                    OT *dst = o + (int64_t)k * kstride2;
+                    if (ok1) { vec2 v2; v2.x = (OT)s0[k]; v2.y = (OT)s1[k]; MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(dst)); }
+                    else if (ok0) MGX_WIN_STORE((OT)s0[k], dst);
+                }
+            }
+            return;
+        }
         const bool in_batch = i < N;
         OT *outc = ring + g0 + g;
         for (int32_t c = q; c < D; c += Q2) {
@@ -1246,6 +1283,7 @@ static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArg
             plan.group = mine ? fw.plan[q].group : plan.group; plan.K = mine ? fw.plan[q].K : plan.K;
             plan.rp = mine ? fw.plan[q].rp : plan.rp; plan.bp = mine ? fw.plan[q].bp : plan.bp;
             plan.group0 = mine ? fw.plan[q].group0 : plan.group0; plan.pitch = mine ? fw.plan[q].pitch : plan.pitch;
+            plan.pairs = mine ? fw.plan[q].pairs : plan.pairs;
             t = mine ? fw.t[q] : t; block0 = mine ? fw.block0[q] : block0; kind = mine ? fw.kind[q] : kind;
             nstate = mine ? fw.nstate[q] : nstate;
         }
@@ -1686,6 +1724,39 @@ __global__ __launch_bounds__(OBS_P1_THREADS) void obs_windows_k_multi_kernel(con
         // of a (k, c) pair are whole 128-byte lines (32 doubles: two, 32 floats: one).  A ring written ahead of the counter leaves the state columns to the
         // steps: here they are lines of their own, so not writing them costs nothing (7 % of a 162-column row).
         const int64_t P = a.obs_colpitch, kstride = (int64_t)D * P;
+        if (plan.pairs && (reinterpret_cast<uintptr_t>(ring) & (sizeof(vec2) - 1)) == 0) {   // a pair of adjacent grids per lane (windows_body)
+            const int32_t GP = G >> 1, gp = tid & (GP - 1), cq = tid / GP, QP = OBS_K_THREADS / GP;
+            const int64_t i0 = g0 + 2 * gp;
+            const bool ok0 = i0 < N, ok1 = i0 + 1 < N;
+            const IT *img0 = image + (2 * gp) * BP, *img1 = img0 + BP;
+            OT *outp = ring + i0;
+            for (int32_t c = cq; c < D; c += QP) {
+                const uint32_t m = map[c];
+                if (!plan.with_state && m >= (uint32_t)S0) continue;
+                const IT *s0 = img0 + m, *s1 = img1 + m;
+                OT *o = outp + (int64_t)c * P;
+                int32_t k = 0;
+                if constexpr (WIN_U > 1) {
+                    for (; k + WIN_U <= K; k += WIN_U) {
+                        IT v0[WIN_U], v1[WIN_U];
+#pragma unroll
+                        for (int u = 0; u < WIN_U; u++) { v0[u] = s0[k + u]; v1[u] = s1[k + u]; }
+#pragma unroll
+                        for (int u = 0; u < WIN_U; u++) {
+                            OT *dst = o + (int64_t)(k + u) * kstride;
+                            if (ok1) { vec2 v2; v2.x = (OT)v0[u]; v2.y = (OT)v1[u]; MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(dst)); }
+                            else if (ok0) MGX_WIN_STORE((OT)v0[u], dst);
+                        }
+                    }
+                }
+                for (; k < K; k++) {
+                    OT *dst = o + (int64_t)k * kstride;
+                    if (ok1) { vec2 v2; v2.x = (OT)s0[k]; v2.y = (OT)s1[k]; MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(dst)); }
+                    else if (ok0) MGX_WIN_STORE((OT)s0[k], dst);
+                }
+            }
+            return;
+        }
         const int32_t Q2 = OBS_K_THREADS / G;
         const bool in_batch = i < N;
         OT *outc = ring + g0 + g;
