@@ -765,6 +765,68 @@ struct WindowsKPlan {
 #else
 #define MGX_WIN_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #endif
+// Phase 2 of a refill into COLUMN-major blocks: a lane carries a PAIR of adjacent grids of one column (adjacent words of the block)
+// through the K blocks -- 16-byte stores of doubles, 8-byte stores of floats: half the store instructions of a word per lane for the
+// same whole lines.  (Four floats per lane, 16-byte stores too, measured no better than two: profiles/r05/exp_refill_col_packs.txt.)
+// map[c] >= skip_from: a state column a ring written ahead leaves to the steps.  Returns false (nothing stored) where the ring is
+// not aligned for the pair.
+template <typename OT, typename IT>
+__device__ __forceinline__ bool store_colmajor_packs(const IT *image, int32_t BP, const uint32_t *map, int32_t D, int32_t skip_from,
+                                                     int32_t K, int32_t G, int64_t g0, int64_t N, int64_t P, OT *__restrict__ ring, int tid)
+{
+    constexpr int NPK = 2;
+    typedef OT vecp __attribute__((ext_vector_type(NPK)));
+    if ((reinterpret_cast<uintptr_t>(ring) & (sizeof(vecp) - 1)) != 0 || G < NPK) return false;
+    const int32_t GP = G / NPK, gp = tid & (GP - 1), cq = tid / GP, QP = OBS_K_THREADS / GP;
+    const int64_t i0 = g0 + (int64_t)NPK * gp, left = N - i0;
+    const int nv = left >= NPK ? NPK : (left > 0 ? (int)left : 0);     // grids of the pack inside the batch (the last group is ragged)
+    const IT *img = image + (NPK * gp) * BP;
+    OT *outp = ring + i0;
+    const int64_t kstride = (int64_t)D * P;
+    for (int32_t c = cq; c < D; c += QP) {
+        const uint32_t m = map[c];
+        if (m >= (uint32_t)skip_from) continue;
+        const IT *src = img + m;
+        OT *o = outp + (int64_t)c * P;
+        int32_t k = 0;
+        if constexpr (WIN_U > 1) {                       // WIN_U packs of image words in flight before the first store of the batch
+            for (; k + WIN_U <= K; k += WIN_U) {
+                IT v[WIN_U][NPK];
+#pragma unroll
+                for (int u = 0; u < WIN_U; u++)
+#pragma unroll
+                    for (int e = 0; e < NPK; e++) v[u][e] = src[e * BP + k + u];
+#pragma unroll
+                for (int u = 0; u < WIN_U; u++) {
+                    OT *dst = o + (int64_t)(k + u) * kstride;
+                    if (nv == NPK) {
+                        vecp vv;
+#pragma unroll
+                        for (int e = 0; e < NPK; e++) vv[e] = (OT)v[u][e];
+                        MGX_WIN_STORE(vv, reinterpret_cast<vecp *>(dst));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < NPK; e++) if (e < nv) MGX_WIN_STORE((OT)v[u][e], dst + e);
+                    }
+                }
+            }
+        }
+        for (; k < K; k++) {
+            OT *dst = o + (int64_t)k * kstride;
+            if (nv == NPK) {
+                vecp vv;
+#pragma unroll
+                for (int e = 0; e < NPK; e++) vv[e] = (OT)src[e * BP + k];
+                MGX_WIN_STORE(vv, reinterpret_cast<vecp *>(dst));
+            } else {
+#pragma unroll
+                for (int e = 0; e < NPK; e++) if (e < nv) MGX_WIN_STORE((OT)src[e * BP + k], dst + e);
+            }
+        }
+    }
+    return true;
+}
+
 // Body shared by obs_windows_k_kernel and the window part of fleet_step_kernel: workgroup `group` (16 grids) of the batch.
 // GRID: the layout has a GridModule (6 instead of 2 series components).  `now` (meaningful in the q == 0 lanes, with have_now):
 // the state columns of the current state for block 0; without it (a prefetch ahead of the counter) every state column is zero.
@@ -859,42 +921,7 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
         // floats out of the float image -- are ONE 128-byte line (P and g0 are multiples of G), written whole by G adjacent lanes.  Nothing else ever writes into such a line's bytes
         // except the step's state columns -- which are whole coalesced lines of their own here (a wave's 64 grids x 8 B per column).
         const int64_t P = a.obs_colpitch;
-        const int64_t kstride2 = (int64_t)D * P;
-        if (plan.pairs && wide) {
-            // a lane carries a PAIR of adjacent grids (2 gp, 2 gp + 1: adjacent words of a column): 8-byte stores of floats, 16-byte
-            // stores of doubles -- half the store instructions for the same lines (g0, P even: every pair is aligned)
-            const int32_t GP = G >> 1, gp = tid & (GP - 1), cq = tid / GP, QP = OBS_K_THREADS / GP;
-            const int64_t i0 = g0 + 2 * gp;
-            const bool ok0 = i0 < N, ok1 = i0 + 1 < N;
-            const IT *img0 = image + (2 * gp) * BP, *img1 = img0 + BP;
-            OT *outp = ring + i0;
-            for (int32_t c = cq; c < D; c += QP) {
-                const uint32_t m = map[c];
-                if (!have_now && m >= (uint32_t)S0) continue;
-                const IT *s0 = img0 + m, *s1 = img1 + m;
-                OT *o = outp + (int64_t)c * P;
-                int32_t k = 0;
-                if constexpr (WIN_U > 1) {
-                    for (; k + WIN_U <= K; k += WIN_U) {
-                        IT v0[WIN_U], v1[WIN_U];
-#pragma unroll
-                        for (int u = 0; u < WIN_U; u++) { v0[u] = s0[k + u]; v1[u] = s1[k + u]; }
-#pragma unroll
-                        for (int u = 0; u < WIN_U; u++) {
-                            OT *dst = o + (int64_t)(k + u) * kstride2;
-                            if (ok1) { vec2 v2; v2.x = (OT)v0[u]; v2.y = (OT)v1[u]; MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(dst)); }
-                            else if (ok0) MGX_WIN_STORE((OT)v0[u], dst);
-                        }
-                    }
-                }
-                for (; k < K; k++) {
-                    OT *dst = o + (int64_t)k * kstride2;
-                    if (ok1) { vec2 v2; v2.x = (OT)s0[k]; v2.y = (OT)s1[k]; MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(dst)); }
-                    else if (ok0) MGX_WIN_STORE((OT)s0[k], dst);
-                }
-            }
-            return;
-        }
+        if (plan.pairs && store_colmajor_packs<OT, IT>(image, BP, map, D, have_now ? 0x7fffffff : S0, K, G, g0, N, P, ring, tid)) return;
         const bool in_batch = i < N;
         OT *outc = ring + g0 + g;
         for (int32_t c = q; c < D; c += Q2) {
@@ -1724,39 +1751,7 @@ __global__ __launch_bounds__(OBS_P1_THREADS) void obs_windows_k_multi_kernel(con
         // of a (k, c) pair are whole 128-byte lines (32 doubles: two, 32 floats: one).  A ring written ahead of the counter leaves the state columns to the
         // steps: here they are lines of their own, so not writing them costs nothing (7 % of a 162-column row).
         const int64_t P = a.obs_colpitch, kstride = (int64_t)D * P;
-        if (plan.pairs && (reinterpret_cast<uintptr_t>(ring) & (sizeof(vec2) - 1)) == 0) {   // a pair of adjacent grids per lane (windows_body)
-            const int32_t GP = G >> 1, gp = tid & (GP - 1), cq = tid / GP, QP = OBS_K_THREADS / GP;
-            const int64_t i0 = g0 + 2 * gp;
-            const bool ok0 = i0 < N, ok1 = i0 + 1 < N;
-            const IT *img0 = image + (2 * gp) * BP, *img1 = img0 + BP;
-            OT *outp = ring + i0;
-            for (int32_t c = cq; c < D; c += QP) {
-                const uint32_t m = map[c];
-                if (!plan.with_state && m >= (uint32_t)S0) continue;
-                const IT *s0 = img0 + m, *s1 = img1 + m;
-                OT *o = outp + (int64_t)c * P;
-                int32_t k = 0;
-                if constexpr (WIN_U > 1) {
-                    for (; k + WIN_U <= K; k += WIN_U) {
-                        IT v0[WIN_U], v1[WIN_U];
-#pragma unroll
-                        for (int u = 0; u < WIN_U; u++) { v0[u] = s0[k + u]; v1[u] = s1[k + u]; }
-#pragma unroll
-                        for (int u = 0; u < WIN_U; u++) {
-                            OT *dst = o + (int64_t)(k + u) * kstride;
-                            if (ok1) { vec2 v2; v2.x = (OT)v0[u]; v2.y = (OT)v1[u]; MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(dst)); }
-                            else if (ok0) MGX_WIN_STORE((OT)v0[u], dst);
-                        }
-                    }
-                }
-                for (; k < K; k++) {
-                    OT *dst = o + (int64_t)k * kstride;
-                    if (ok1) { vec2 v2; v2.x = (OT)s0[k]; v2.y = (OT)s1[k]; MGX_WIN_STORE(v2, reinterpret_cast<vec2 *>(dst)); }
-                    else if (ok0) MGX_WIN_STORE((OT)s0[k], dst);
-                }
-            }
-            return;
-        }
+        if (plan.pairs && store_colmajor_packs<OT, IT>(image, BP, map, D, plan.with_state ? 0x7fffffff : S0, K, G, g0, N, P, ring, tid)) return;
         const int32_t Q2 = OBS_K_THREADS / G;
         const bool in_batch = i < N;
         OT *outc = ring + g0 + g;
