@@ -375,7 +375,7 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform, a
                 traffic = tf["hbm_bytes_per_fleet_step"]
             elif tf is not None:
                 traffic_src += ": another fleet shape"
-            launch = ("one fleet step = one mgx_fleet_step call: ONE fleet_step_kernel launch over the three buckets"
+            launch = ("one fleet step = one mgx_fleet_step call: ONE fleet_step_kernel_v launch over the three buckets (KArgs by value, bucket = blockIdx.y)"
                       + (f" + every {K_ring}th step the observation ring after next ({K_ring} row blocks: obs_windows_k_kernel per "
                          f"bucket on the engines' prefetch streams, beside the following step launches); bytes and time are per "
                          f"fleet step, refills included" if contract == "rows" else
@@ -388,7 +388,7 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform, a
                                       "frac_wall": alg / (wall / steps) / 1e9 / HBM_PEAK_GBS,
                                       "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
                                       "avg_launch_us": gpu / steps * 1e6, "launch": launch,
-                                      "kernel": "fleet_step_kernel" + (f" + obs_windows_k_kernel<F> x3 / {K_ring}" if contract == "rows" else ""),
+                                      "kernel": "fleet_step_kernel_v" + (f" + obs_windows_k_kernel<F> x3 / {K_ring}" if contract == "rows" else ""),
                                       "refill": fleet.refill if contract == "rows" else None,
                                       "ring_blocks": ("column-major [D, pitch]: obs = the [N, D] view with strides (1, pitch) (the default)" if contract_name == "rows"
                                                       else ("row-major [N, D]" if contract == "rows" else None))}}

@@ -1782,12 +1782,39 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
             memcpy(&h->table_uploaded, &tab, sizeof(PLWords));
             h->table_uploaded_valid = true;
         }
+        // MGX_FLEET_BYVALUE=0 keeps the pointer form of the kernel for every launch (A/B)
+        static const bool by_value = [] { const char *e = getenv("MGX_FLEET_BYVALUE"); return !(e && atoi(e) == 0); }();
         for (int32_t j0 = 0; j0 < n; j0 += MGX_FLEET_MAX) {
+            const int32_t nb = n - j0 < MGX_FLEET_MAX ? n - j0 : MGX_FLEET_MAX;
+            bool chunks = !by_value;                       // window chunks riding along with this launch (refill="chunks")?
+            for (int32_t q = 0; q < nb && !chunks; q++) chunks = items[j0 + q].refill_ring && items[j0 + q].refill_chunks > 0;
+            if (!chunks) {
+                // the buckets' KArgs by value, the bucket = blockIdx.y (fleet_step_kernel_v): unused buckets stay unwritten, never read
+                FleetArgsV fv;
+                fv.n = nb; fv.normalized = normalized; fv.pad0 = fv.pad1 = 0;
+                int32_t most = 0;
+                for (int32_t q = 0; q < nb; q++) {
+                    const mgx_fleet_item &it = items[j0 + q];
+                    const mgx_handle *h = it.handle;
+                    FleetBucket &B = fv.b[q];
+                    B.k = h->k;
+                    B.hd.tab = it.action_id ? h->d_table : nullptr; B.hd.n_grids = h->k.N; B.hd.t = h->t; B.hd.flags = h->flags;
+                    B.hd.pad0 = B.hd.pad1 = 0;
+                    B.actions = it.action_id ? (const void *)it.action_id : it.actions;
+                    B.reward = it.reward; B.done = it.done; B.obs = it.obs; B.log = it.log;
+                    const int32_t wg = (int32_t)blocks_for(h->k.N);
+                    if (wg > most) most = wg;
+                }
+                fleet_step_kernel_v<<<dim3((unsigned)most, (unsigned)nb), BLOCK, 0, st>>>(fv);
+                hipError_t ev = hipGetLastError();
+                if (ev != hipSuccess) return hip_fail(ev, "fleet_step_kernel_v launch");
+                continue;
+            }
             FleetArgs fa;
             FleetWin fw;
             memset(&fa, 0, sizeof(fa));
             memset(&fw, 0, sizeof(fw));
-            fa.n = n - j0 < MGX_FLEET_MAX ? n - j0 : MGX_FLEET_MAX;
+            fa.n = nb;
             fa.normalized = normalized;
             int32_t blocks = 0, wblocks = 0;
             size_t lds_max = 0;

@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
 // segment (scalar loads); a workgroup finds its batch with a few scalar compares and jumps -- wave-uniformly -- to that
 // layout's specialisation of the step.  Three 33 000-grid batches cost one ~6 us launch instead of three ~5 us ones.
 // ------------------------------------------------------------------------------------------------------
-constexpr int MGX_FLEET_MAX = 6;
+constexpr int MGX_FLEET_MAX = 5;
 // What changes from step to step travels by value (small: one scalar-load round at kernel start); the big, rarely changing
 // KArgs of every batch are read from DEVICE memory (the handle's own copy, refreshed by the host when it changes).  A table
 // of whole KArgs in the kernarg segment measured 57 us per launch: the kernarg buffer lives in host memory and the chain
@@ -1359,6 +1359,73 @@ static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArg
         MGX_FLEET_CASE(0) MGX_FLEET_CASE(1) MGX_FLEET_CASE(2) MGX_FLEET_CASE(3) MGX_FLEET_CASE(4)
         MGX_FLEET_CASE(5) MGX_FLEET_CASE(6) MGX_FLEET_CASE(7) MGX_FLEET_CASE(14)
         default: step_body<15>(a, actions, t, fa.normalized, reward, done, obs, log, i); break;
+    }
+#undef MGX_FLEET_CASE
+}
+
+// The same step part with every batch's KArgs BY VALUE in the kernarg segment and the batch picked by blockIdx.y -- a wave
+// knows which bucket it serves before any load returns, so the bucket's KArgs, buffers and counter are ONE round of scalar loads
+// at a computed offset of the kernarg segment (what a single batch's step_kernel pays for its by-value KArgs) instead of two
+// dependent ones (the selects over fa.k[], then *kp out of device memory): 8.6 -> 6.4 us for the kernel alone on one
+// 99 999-grid bucket (profiles/r05/exp_fleet_vs_env.txt), and every round trip saved counts double beside a ring refill.
+// (Round 2's table of whole KArgs in the kernarg segment lost because the bucket was FOUND by loads: which batch? -> its
+// layout -> its columns, a chain.)  Launched on a (max workgroups of a bucket, buckets) grid when no window chunks ride along.
+struct FleetHead {                               // what picks the code path: one 32-byte scalar load
+    const PLWords *tab;                          // discrete items: the priority-list table (device copy), else NULL
+    int64_t n_grids;
+    int32_t t, flags, pad0, pad1;
+};
+struct FleetBucket {
+    FleetHead hd;
+    KArgs k;
+    const void *actions;                         // continuous control [N, A] -- or the int32 priority-list ids [N] of a discrete item
+    double *reward; uint8_t *done; void *obs; double *log;
+};
+struct FleetArgsV {
+    int32_t n, normalized, pad0, pad1;
+    FleetBucket b[MGX_FLEET_MAX];
+};
+static_assert(sizeof(FleetArgsV) <= 3840, "the kernarg segment holds 4 KB");
+
+static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel_v(const FleetArgsV fa)
+{
+    typedef const char __attribute__((address_space(4))) *kernarg_bytes;
+    const kernarg_bytes mine = (kernarg_bytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FleetArgsV, b)
+                               + (size_t)blockIdx.y * sizeof(FleetBucket);
+    // Which specialisation: ONE 32-byte scalar load; the bucket's other fields are read THROUGH a reference into the kernarg segment
+    // by the case that uses them (scalar loads of invariant memory the compiler places and re-issues as it likes; a copy of the
+    // whole bucket in front of the switch made it fetch every field any case needs -- 158 dwords through ~100 SGPRs: nine
+    // load-wait-spill rounds before the first vector load -- and a copy inside every case still spilled SGPRs).
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    static_assert(sizeof(FleetHead) == 32 && offsetof(FleetBucket, hd) == 0, "the head is one s_load_dwordx8");
+    const u32x8 h8 = *reinterpret_cast<const u32x8 __attribute__((address_space(4))) *>(mine);
+    FleetHead hd;
+    hd.tab = reinterpret_cast<const PLWords *>((uint64_t)h8[0] | ((uint64_t)h8[1] << 32));
+    hd.n_grids = (int64_t)((uint64_t)h8[2] | ((uint64_t)h8[3] << 32));
+    hd.t = (int32_t)h8[4]; hd.flags = (int32_t)h8[5];
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= hd.n_grids) return;
+    const int normalized = fa.normalized;
+    const FleetBucket &B = *reinterpret_cast<const FleetBucket *>((const char *)mine);
+    if (hd.tab != nullptr) {                      // a DiscreteMicrogridEnv batch: ids -> control -> run, in registers
+#define MGX_FLEET_CASE(FV) case FV: {                                         \
+        step_discrete_body<FV>(B.k, *hd.tab, (const int32_t *)B.actions, hd.t, nullptr, B.reward, B.done, B.obs, B.log, i); } break;
+        switch (hd.flags) {
+            MGX_FLEET_CASE(0) MGX_FLEET_CASE(1) MGX_FLEET_CASE(2) MGX_FLEET_CASE(3) MGX_FLEET_CASE(4)
+            MGX_FLEET_CASE(5) MGX_FLEET_CASE(6) MGX_FLEET_CASE(7) MGX_FLEET_CASE(14)
+            default: {
+                step_discrete_body<15>(B.k, *hd.tab, (const int32_t *)B.actions, hd.t, nullptr, B.reward, B.done, B.obs, B.log, i); } break;
+        }
+#undef MGX_FLEET_CASE
+        return;
+    }
+#define MGX_FLEET_CASE(FV) case FV: {                                             \
+        step_body<FV>(B.k, B.actions, hd.t, normalized, B.reward, B.done, B.obs, B.log, i); } break;
+    switch (hd.flags) {
+        MGX_FLEET_CASE(0) MGX_FLEET_CASE(1) MGX_FLEET_CASE(2) MGX_FLEET_CASE(3) MGX_FLEET_CASE(4)
+        MGX_FLEET_CASE(5) MGX_FLEET_CASE(6) MGX_FLEET_CASE(7) MGX_FLEET_CASE(14)
+        default: {
+            step_body<15>(B.k, B.actions, hd.t, normalized, B.reward, B.done, B.obs, B.log, i); } break;
     }
 #undef MGX_FLEET_CASE
 }

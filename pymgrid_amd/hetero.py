@@ -2,7 +2,7 @@
 batch (a batch has one layout = one kernel specialisation), so a fleet is bucketed by layout
 (``scenario.bucket_by_layout``) and every bucket gets its own ``MicrogridBatch`` + engine.  Buckets are independent.
 
-A fleet step is ONE call of the C ABI (``mgx_fleet_step``) and one ``fleet_step_kernel`` launch for all layouts; the
+A fleet step is ONE call of the C ABI (``mgx_fleet_step``) and one ``fleet_step_kernel_v`` launch for all layouts (up to 5 per launch); the
 observation rings of the buckets are renewed ahead of time on the engines' prefetch streams (``refill="ahead"``, K = 16) or as
 chunks inside the step launches (``refill="chunks"``): 29.5-32 / 33-35 us per 100 000-grid step at H = 24.  Per-bucket HIP
 streams (``streams=True``: fork / join events around every bucket, one ``env.step`` each) were measured 2.7x slower than

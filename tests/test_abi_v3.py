@@ -387,7 +387,7 @@ def _toy_grid(rs, T, genset, battery, grid, horizon=0):
 
 
 def test_fleet_of_all_eight_module_sets_needs_two_launches(device, oracle):
-    """A fleet with every module set (8 buckets > the 6 entries of one fleet_step_kernel launch: two launches per step),
+    """A fleet with every module set (8 buckets > the 5 entries of one fleet_step_kernel launch: two launches per step),
     ragged bucket sizes, H = 3 with ring refills in chunks: every grid == its oracle microgrid (rewards, observations)."""
     from pymgrid_amd.hetero import BucketedFleet
     rs = np.random.RandomState(7)

@@ -107,7 +107,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 per_step = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / steps
 print(f"HBM bytes per fleet step ({contract}, {dt}): {per_step / 1e6:.1f} MB "
       f"(read {2 * tot['FETCH_SIZE'] * 1024 / steps / 1e6:.1f} + written {tot['WRITE_SIZE'] * 1024 / steps / 1e6:.1f})")
-json.dump({"kernel": "fleet_step_kernel" + (" + obs_windows_k_kernel" if contract.startswith("rows") else ""), "grids_per_gpu": 99999,
+json.dump({"kernel": "fleet_step_kernel_v" + (" + obs_windows_k_kernel" if contract.startswith("rows") else ""), "grids_per_gpu": 99999,
            "series": "factorised", "contract": contract, "dtype": dt, "obs_prefetch": 32, "hbm_bytes_per_fleet_step": per_step, "csrc_hash": h,
            "source": "tools/gpu_profile_r05.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + "
                      f"WRITE_SIZE)*1024 summed over every kernel of the last {steps} fleet steps (step launches + ring refills) / {steps}"},

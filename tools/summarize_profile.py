@@ -97,7 +97,7 @@ for f in find("*kernel_trace.csv"):
               f"algorithmic {alg / 1e6:.1f} MB per round -> {alg / (cad * 1e-6) / 1e9:.0f} GB/s = frac {frac:.3f} of {rf['peak']:.0f} GB/s"
               f"   [bench line: avg_launch_us {rf['avg_launch_us']:.2f}, frac {rf['frac']:.3f}]")
 
-WATCHED = ("step_k_kernel", "step_kernel", "rollout_kernel", "observe_kernel", "expand_kernel", "obs_windows_k_kernel", "fleet_step_kernel",
+WATCHED = ("step_k_kernel", "step_kernel", "rollout_kernel", "observe_kernel", "expand_kernel", "obs_windows_k_kernel", "fleet_step_kernel", "fleet_step_kernel_v",
            "step_multi_kernel", "step_k_multi_kernel", "obs_windows_k_multi_kernel")
 traffic = defaultdict(dict)
 sized = defaultdict(dict)
