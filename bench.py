@@ -531,7 +531,7 @@ def general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist):
                               "roofline": {"bound": "hbm", "achieved": bK_launch / Kg / (gpu / stepsK) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": bK_launch / Kg / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                            "frac_charged_per_step": bK / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS,
-                                           "algorithmic_bytes_per_launch": bK_launch, "kernel": "step_k_multi_kernel<7>",
+                                           "algorithmic_bytes_per_launch": bK_launch, "kernel": "step_k_multi_small_kernel<7>",
                                            "bytes_per_env_step": bK_launch / Kg / N, "avg_launch_us": gpu / stepsK * Kg * 1e6,
                                            "note": "parameters and state live in LDS for the launch (round 5): charged once per launch; "
                                                    "per step the controls, the series rows and the reward stream"}}

@@ -1402,9 +1402,15 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     if (h->multi) {                                       // general path: the K-step loop around the general step
         if (h->k.done_bits && done) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: the general kernels write `done` as bytes");
+        static const bool own_kernel = [] { const char *e = getenv("MGX_MULTI_SMALL_OWN"); return !(e && atoi(e) == 0); }();   // (A/B)
         for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
-            MGX_DISPATCH_F(h->flags, (step_k_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
-                                          k, actions, nullptr, 0, 0, nullptr, 0, t_arg(h), K, normalized, fo, h->multi_small)));
+            if (h->multi_small && own_kernel) {           // at most MS modules of a kind: the register loop in a kernel of its own
+                MGX_DISPATCH_F(h->flags, (step_k_multi_small_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, 0, s>>>(
+                                              k, actions, t_arg(h), K, normalized, fo)));
+            } else {
+                MGX_DISPATCH_F(h->flags, (step_k_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
+                                              k, actions, nullptr, 0, 0, nullptr, 0, t_arg(h), K, normalized, fo, h->multi_small)));
+            }
         });
         hipError_t em = hipGetLastError();
         if (em != hipSuccess) return hip_fail(em, "step_k_multi_kernel launch");

@@ -2018,6 +2018,62 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a
     advance_counter_in_kernel(a, K_launch);
 }
 
+// The register form of the K-step launch alone (layouts of at most MS modules of a kind, continuous controls): the same loop as the
+// `small` arm of step_k_multi_kernel in a kernel of its own -- without the run-time-count arm and the priority-list arm beside it the
+// loop keeps its pointers in SGPRs (the shared kernel reloaded ~100 spilled SGPRs per step through v_readlane).
+template <int F>
+__global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_small_kernel(const KArgs a, const void *__restrict__ actions, int32_t t0, int32_t K,
+                                                                         int normalized, const FusedOut out)
+{
+    const int32_t K_launch = K;
+    t0 = resolve_t(a, t0);
+    K = resolve_k(a, t0, K);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
+    if (i < a.g1) {
+        const int64_t N = a.N;
+        const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
+        const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
+        double ret = 0.0;
+        MultiRegs R; MultiStepIn cur, nxt;
+        load_multi_regs<F>(a, i, R);
+        if (K > 0) {
+            if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + (int64_t)i * A, i, t0, cur);
+            else load_multi_step_in<F>(a, (const double *)actions + (int64_t)i * A, i, t0, cur);
+        }
+        // two steps per trip: the inputs of step k + 1 are requested into `nxt` before step k runs on `cur`, those of step k + 2 into
+        // `cur` before step k + 1 runs on `nxt` -- no copy of 26 doubles per step between the two buffers
+        auto fetch = [&](int32_t kk, MultiStepIn &dst) __attribute__((always_inline)) {
+            const int32_t kc = kk < K ? kk : K - 1;                  // (past the end: re-read the last step's inputs, unconditional loads)
+            const int64_t offc = (int64_t)kc * N + i;
+            if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + offc * A, i, t0 + kc, dst);
+            else load_multi_step_in<F>(a, (const double *)actions + offc * A, i, t0 + kc, dst);
+        };
+        auto one_step = [&](int32_t k, const MultiStepIn &in) __attribute__((always_inline)) {
+            const int64_t off = (int64_t)k * N + i;
+            Outputs o;
+            double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
+            step_multi_small<F>(a, R, in, i, normalized != 0, log, o);
+            const double r = shaped_reward<F>(a.shaper, o);
+            if (out.reward) out.reward[off] = r;
+            if (out.done) out.done[off] = (uint8_t)(k >= k_done);
+            if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = R.b_soc[0]; }
+            if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = R.g_status[0]; }
+            ret += r;
+        };
+        int32_t k = 0;
+        for (; k + 1 < K; k += 2) {
+            fetch(k + 1, nxt);
+            one_step(k, cur);
+            fetch(k + 2, cur);
+            one_step(k + 1, nxt);
+        }
+        if (k < K) one_step(k, cur);
+        store_multi_state<F>(a, i, R);
+        if (out.ret_acc) out.ret_acc[i] += ret;
+    }
+    advance_counter_in_kernel(a, K_launch);
+}
+
 // mgx_expand_lists / mgx_expand_discrete on the general path: lists [n_lists, list_len, 3] in device memory
 template <int F>
 __global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a, const int32_t *__restrict__ lists, int32_t n_lists,

@@ -16,7 +16,7 @@ top = sys.argv[1]
 acc = defaultdict(list)
 for f in glob.glob(os.path.join(top, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "step_k_multi_kernel" in r["Kernel_Name"]:
+        if "step_k_multi_" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:24s} launches={len(v)} mean={sum(v)/len(v):.4g}")

@@ -98,7 +98,7 @@ for f in find("*kernel_trace.csv"):
               f"   [bench line: avg_launch_us {rf['avg_launch_us']:.2f}, frac {rf['frac']:.3f}]")
 
 WATCHED = ("step_k_kernel", "step_kernel", "rollout_kernel", "observe_kernel", "expand_kernel", "obs_windows_k_kernel", "fleet_step_kernel", "fleet_step_kernel_v",
-           "step_multi_kernel", "step_k_multi_kernel", "obs_windows_k_multi_kernel")
+           "step_multi_kernel", "step_k_multi_kernel", "step_k_multi_small_kernel", "obs_windows_k_multi_kernel")
 traffic = defaultdict(dict)
 sized = defaultdict(dict)
 for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
