@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 8
+#define MGX_ABI_VERSION 9
 
 enum mgx_status {
     MGX_OK = 0,
@@ -590,6 +590,14 @@ typedef struct mgx_fleet_item {
     int32_t reserved;
 } mgx_fleet_item;
 int mgx_fleet_step(const mgx_fleet_item *items, int32_t n_items, int normalized, mgx_stream stream);
+/* The bound form of a fleet's Gym step: every handle carries an env plan (mgx_env_bind: rotating reward / done / row / log slots,
+ * three observation rings) and the call is mgx_fleet_step over the items those plans produce -- handle j steps with actions[j]
+ * (continuous controls [N, A], or int32 priority-list ids [N] where the plan holds a table) into its next slot and ring block,
+ * waits for its prefetched ring when it enters it and has the ring after that one written ahead -- one launch for the steps of
+ * all layouts, one C call per fleet step, no per-step bookkeeping on the host (`for env in envs: env.step(a)` of N reference
+ * microgrids of different module sets; envs/base/base.py:169-209).  Afterwards every handle's slot and ring position have moved
+ * as by mgx_env_step (mgx_env_position).  Nothing moves when the call fails validation.  n_handles <= 64. */
+int mgx_fleet_env_step(mgx_handle *const *handles, const void *const *actions, int32_t n_handles, int normalized, mgx_stream stream);
 
 /* MicrogridGenerator's time series on device (MicrogridGenerator.py): load / pv = base profile x size / max(profile)
  * (_scale_ts, :137-147; stored with the modules' sign, base_timeseries_module.py:68-79), import price = tariff pattern

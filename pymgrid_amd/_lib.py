@@ -25,7 +25,7 @@ V_GENSET_RANGE, V_BATTERY_LIMIT, V_GRID_LIMIT, V_GENSET_GOAL, V_GENSET_NEGATIVE,
 V_EXPAND_CONSUME, V_EXPAND_PRODUCE, V_EXPAND_SIGN = 64, 128, 256
 V_EXPAND = V_EXPAND_CONSUME | V_EXPAND_PRODUCE | V_EXPAND_SIGN      # states in which _populate_action asserts
 V_ASSERTS = V_GENSET_GOAL | V_GENSET_NEGATIVE | V_NEGATIVE_LIMIT | V_EXPAND    # the reference raises whatever raise_errors says
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_INSTANCES = 8          # MGX_MAX_INSTANCES: gensets / batteries / grids per microgrid
 
 
@@ -191,6 +191,7 @@ SYMBOLS = {
     "mgx_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgx_shard_stream": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "mgx_fleet_step": (C.c_int, [C.POINTER(FleetItem), C.c_int32, C.c_int, C.c_void_p]),
+    "mgx_fleet_env_step": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int, C.c_void_p]),
     "mgx_synthesize_series": (C.c_int, [C.POINTER(Synth), C.c_void_p]),
     "mgx_generate_columns": (C.c_int, [C.POINTER(Gen), C.c_void_p]),
 }

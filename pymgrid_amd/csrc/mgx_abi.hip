@@ -1890,6 +1890,44 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
     return MGX_OK;
 }
 
+int mgx_fleet_env_step(mgx_handle *const *handles, const void *const *actions, int32_t n, int normalized, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!handles || !actions) return fail(MGX_ERR_INVALID, "mgx_fleet_env_step: NULL argument");
+    if (n < 1 || n > 64) return fail(MGX_ERR_INVALID, "mgx_fleet_env_step: n_handles = %d outside [1, 64]", n);
+    mgx_fleet_item items[64];
+    bool enters[64];
+    for (int32_t j = 0; j < n; j++) {
+        mgx_handle *h = handles[j];
+        if (!h || !h->env_bound) return fail(MGX_ERR_INVALID, "mgx_fleet_env_step: handle %d has no plan bound (mgx_env_bind)", j);
+        const mgx_env_slot &sl = h->env_slots[h->env_next];
+        const EnvTarget tg = env_target(h, sl);
+        mgx_fleet_item &it = items[j];
+        memset(&it, 0, sizeof(it));
+        it.struct_size = (int32_t)sizeof(mgx_fleet_item);
+        it.handle = h;
+        if (h->env_n_actions > 0) { it.action_id = (const int32_t *)actions[j]; it.table = h->env_table; it.n_actions = h->env_n_actions; }
+        else it.actions = actions[j];
+        it.reward = sl.reward; it.done = sl.done; it.obs = tg.obs; it.log = sl.log;
+        enters[j] = tg.enters_next_ring;
+        if (tg.enters_next_ring) {                          // the step completes block 0 of the prefetched ring: wait for it, then have
+            it.wait_prefetch = 1;                           // the ring behind it written ahead (env_commit's refill, issued by the fleet step)
+            it.refill_ring = h->env_rings[(h->env_ring_idx + 2) % 3];
+            it.refill_K = h->env_ring_K; it.refill_ahead = h->env_ring_K;
+        }
+    }
+    if (int rc = mgx_fleet_step(items, n, normalized, stream)) return rc;
+    for (int32_t j = 0; j < n; j++) {                       // the slots move on, the envs move to the blocks they just completed
+        mgx_handle *h = handles[j];
+        h->env_next = h->env_next + 1 < h->env_n_slots ? h->env_next + 1 : 0;
+        if (h->env_ring_K <= 0) continue;
+        if (!enters[j]) { h->env_ring_pos += 1; continue; }
+        h->env_ring_idx = (h->env_ring_idx + 1) % 3;
+        h->env_ring_pos = 0;
+    }
+    return MGX_OK;
+}
+
 int mgx_synthesize_series(const mgx_synth *a, mgx_stream stream)
 {
     g_err[0] = 0;

@@ -252,6 +252,7 @@ class BatchedMicrogridEnv:
         # between two launches is a microsecond per env-step).  _rebind_fast() after everything that moves buffers or counters.
         self._fp = None
         self._fast_ok = True           # False: this env belongs to a fused fleet (stepped through mgx_fleet_step)
+        self._fleet_ref = None         # the fused BucketedFleet that owns this env (its bound step may hold the env's handle)
         self._rebind_fast()
 
     # ---- the bound Gym step (mgx_env_bind / mgx_env_step) ---------------------------------------------------
@@ -265,6 +266,8 @@ class BatchedMicrogridEnv:
 
     def _unbind_fast(self):
         """Back to per-call bookkeeping: the Python-side positions take over from where the handle stands."""
+        if self._fleet_ref is not None:            # (a fleet's bound step may hold this env's handle: the fleet hands everything back)
+            self._fleet_ref._invalidate_bound()
         fp, self._fp = self._fp, None
         if fp is None:
             return

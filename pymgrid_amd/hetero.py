@@ -24,6 +24,13 @@ def L_multi(layout):
     return layout.multi
 
 
+class _BoundFleet:
+    """What ``BucketedFleet.step`` needs once every bucket's handle carries an env plan (``mgx_env_bind``) and the fleet steps through
+    ``mgx_fleet_env_step``: the handle / action-pointer arrays of the C call and the pre-built tensors a step returns.  The handles
+    walk the rotating output slots and the observation rings themselves; ``slot`` / ``p`` mirror their positions."""
+    __slots__ = ("fn", "hs", "ptrs", "n", "dev", "guard", "adt", "ashape", "R", "slot", "p", "nring", "obs", "rew", "keep", "VB")
+
+
 class BucketedFleet:
     """N microgrids of mixed layouts behind one step()/reset() surface.
 
@@ -54,6 +61,7 @@ class BucketedFleet:
         for env in self.envs:
             env._chunked = self.fused and self.refill == "chunks" and not L_multi(env.layout)
             env._fleet_owned = self.fused
+            env._fleet_ref = self if self.fused else None
             env._fast_ok = not self.fused       # a fused fleet steps its envs through mgx_fleet_step: no bound env steps
             env._rebind_fast()
         # stagger: bucket j's rings change j * K / n_buckets steps before bucket 0's, so that the buckets' ring refills -- each a
@@ -76,6 +84,7 @@ class BucketedFleet:
         self.reuse_outputs = int(reuse_outputs)
         self._want_fused = bool(fused)
         self._plans, self._n_steps, self._out_reward, self._out_done, self._out_obs = {}, 0, None, None, None
+        self._bound, self._bind_ok = None, True     # the bound step (mgx_fleet_env_step): see _try_bind
 
     @classmethod
     def from_batches(cls, batches, discrete=False, streams=False, reuse_outputs=0, fused=True, refill="ahead", stagger=None,
@@ -202,6 +211,11 @@ class BucketedFleet:
             # envs that write whole observation rows per step (no rings, no views): R rotating [N, D] buffers per bucket
             self._out_obs = [torch.empty(R, e.engine.N, e.engine.obs_dim, dtype=e.engine.obs_dtype, device=e.engine.device)
                              if (e._observations and e._ring is None and not e._views) else None for e in envs]
+        b = self._bound
+        if b is None and R and self._bind_ok:
+            b = self._try_bind()
+        if b is not None:
+            return self._step_bound(b, actions, normalized)
         slot = (self._n_steps % R) if R else None
         key = (tuple(e._plan_state() for e in envs), slot)
         plan = self._plans.get(key)
@@ -322,6 +336,151 @@ class BucketedFleet:
                 obs_l[k] = env._view_now()
         return obs_l, list(reward_l), done_l, [{} for _ in range(n)]      # (fresh dicts: Gym wrappers write into info)
 
+    # ---- the bound step: one C call per fleet step, the handles walk slots and rings -------------------------------------------------
+    def _bind_eligible(self):
+        R = self.reuse_outputs
+        if not (self.fused and R and R <= _lib.ENV_MAX_SLOTS and self.refill == "ahead" and len(self.envs) <= 64):
+            return False
+        for env in self.envs:
+            e = env.engine
+            if env._keep_log or env._obs_index is not None or env.raise_errors or env._chunked or env._sync_rings or env._ring_phase \
+                    or e._t is None or e._dev_counter or e.n_shards != 1 or e._window_start is not None \
+                    or getattr(env, "check_asserts", False) or (env._views and R % env.VIEW_BUFFERS):
+                return False
+        return True
+
+    def _try_bind(self):
+        """Bind every bucket's handle at the fleet's CURRENT position (mgx_env_bind + mgx_env_seek).  Returns the _BoundFleet or None
+        (then the per-step plans of _step_fused stay in charge)."""
+        import ctypes as C
+        if not self._bind_eligible():
+            self._bind_ok = False                         # (until something moves an env: _invalidate_bound)
+            return None
+        R, envs, n = self.reuse_outputs, self.envs, len(self.envs)
+        slot0 = self._n_steps % R
+        b = _BoundFleet()
+        keep, obs_l, nring, p0 = [], [], [], []
+        done_ok = []
+        for k, env in enumerate(envs):
+            e = env.engine
+            K = env.obs_prefetch if env._ring is not None else 0
+            slots = (_lib.EnvSlot * R)()
+            for j in range(R):
+                slots[j].reward = self._out_reward[k][j].data_ptr()
+                slots[j].done = None                      # lock-step: `done` is one of two constant tensors
+                if env._views:                            # the state buffer the step of slot j writes (R is a multiple of VIEW_BUFFERS)
+                    slots[j].obs = env._state_bufs[(env._state_pos + 1 + ((j - slot0) % R)) % env.VIEW_BUFFERS].data_ptr()
+                elif self._out_obs[k] is not None:
+                    slots[j].obs = self._out_obs[k][j].data_ptr()
+                else:
+                    slots[j].obs = None
+            plan = _lib.EnvPlan()
+            plan.struct_size = C.sizeof(_lib.EnvPlan)
+            plan.n_slots, plan.slots, plan.ring_K = R, slots, K
+            if K:
+                for r in range(3):
+                    plan.rings[r] = env._rings[r].data_ptr()
+            table = getattr(env, "_table", None)
+            if table is not None:
+                plan.table, plan.n_actions = e._table_ptr(table)
+            keep.append((slots, plan))
+            if e._lib.mgx_env_bind(e._h, C.byref(plan)) or \
+                    e._lib.mgx_env_seek(e._h, slot0, env._ring_idx if K else 0, env._ring_pos if K else 0):
+                for env2 in envs[:k + 1]:
+                    env2.engine._lib.mgx_env_bind(env2.engine._h, None)
+                self._bind_ok = False                     # (a mode the handles walk no rings in: do not try again every step)
+                return None
+            done_ok.append(True)
+            nring.append(3 * K)
+            p0.append((env._ring_idx * K + env._ring_pos) if K else 0)
+            if K:
+                obs_l.append([env._rings[r][kk] for r in range(3) for kk in range(K)])
+            elif env._views:
+                obs_l.append(None)
+            elif self._out_obs[k] is not None:
+                obs_l.append([self._out_obs[k][j] for j in range(R)])
+            else:
+                obs_l.append([None] * R)
+        e0 = envs[0].engine
+        b.fn, b.n, b.dev, b.guard = e0._lib.mgx_fleet_env_step, n, e0._dev_index, not e0._only_device
+        b.hs = (C.c_void_p * n)(*[env.engine._h.value for env in envs])
+        b.ptrs = (C.c_void_p * n)()
+        b.adt = [torch.int32 if getattr(env, "_table", None) is not None else env.engine.action_dtype for env in envs]
+        b.ashape = [torch.Size((env.n_grids,)) if getattr(env, "_table", None) is not None else torch.Size(env.engine._action_shape)
+                    for env in envs]
+        b.R, b.slot, b.p, b.nring, b.obs = R, slot0, p0, nring, obs_l
+        b.VB = BatchedMicrogridEnv.VIEW_BUFFERS
+        b.rew = [[self._out_reward[k][j] for k in range(n)] for j in range(R)]
+        b.keep = keep
+        self._bound = b
+        return b
+
+    def _invalidate_bound(self):
+        """Something is about to move an env (reset, per-grid episodes, a new ring depth ...): positions back to the envs, and the next
+        fleet step looks again whether it can bind."""
+        self._unbind_bound()
+        self._bind_ok = True
+
+    def _unbind_bound(self):
+        """Hand the positions back to the envs' Python state (called before anything else moves an env: BatchedMicrogridEnv._unbind_fast)."""
+        b, self._bound = self._bound, None
+        if b is None:
+            return
+        for k, env in enumerate(self.envs):
+            if b.nring[k]:
+                K = b.nring[k] // 3
+                env._ring_idx, env._ring_pos = divmod(b.p[k], K)
+                env._ring = env._rings[env._ring_idx]
+            if env.engine._h.value:
+                env.engine._lib.mgx_env_bind(env.engine._h, None)
+
+    def _step_bound(self, b, actions, normalized):
+        """One bound fleet step: the controls' addresses in, the pre-built views of the slots / ring blocks the handles used out."""
+        envs, n = self.envs, b.n
+        ptrs, adt, ashape = b.ptrs, b.adt, b.ashape
+        keep = None
+        for k in range(n):
+            a = actions[k]
+            if not (torch.is_tensor(a) and a.dtype == adt[k] and a.shape == ashape[k] and a.is_contiguous() and a.is_cuda):
+                if adt[k] == torch.int32 and getattr(envs[k], "_table", None) is not None:
+                    a = torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a), device=envs[k].batch.device).to(torch.int32).contiguous()
+                else:
+                    a = envs[k].engine._check_actions(a, ())      # converts, or raises with the full message
+                keep = (keep or []) + [a]
+            ptrs[k] = a.data_ptr()
+        if b.guard and torch.cuda.current_device() != b.dev:
+            with torch.cuda.device(b.dev):
+                rc = b.fn(b.hs, ptrs, n, 1 if normalized else 0, _raw_stream(b.dev))
+        else:
+            rc = b.fn(b.hs, ptrs, n, 1 if normalized else 0, _raw_stream(b.dev))
+        if rc:
+            if rc == _lib.MGX_ERR_DEVICE:             # the launch sequence broke off somewhere: the handles' positions are not ours any more
+                self._bound = None
+            _lib.check(rc)                            # (range / argument errors are raised before anything moves: still bound)
+        self._n_steps += 1
+        slot = b.slot
+        b.slot = slot + 1 if slot + 1 < b.R else 0
+        obs_l, done_l = [None] * n, [None] * n
+        p, nring, obs = b.p, b.nring, b.obs
+        for k in range(n):
+            env = envs[k]
+            e = env.engine
+            t = e._t
+            done_l[k] = env._done_const[t >= e.window[1] - 1]
+            e._t = t + 1
+            if nring[k]:
+                q = p[k] + 1
+                if q == nring[k]:
+                    q = 0
+                p[k] = q
+                obs_l[k] = obs[k][q]
+            elif env._views:
+                env._state_pos = (env._state_pos + 1) % b.VB
+                obs_l[k] = env._view_now()
+            else:
+                obs_l[k] = obs[k][slot]
+        return obs_l, list(b.rew[slot]), done_l, [{} for _ in range(n)]      # (fresh dicts: Gym wrappers write into info)
+
     def sample_action(self, generator=None):
         return [env.sample_action(generator=generator) for env in self.envs]
 
@@ -334,7 +493,9 @@ class BucketedFleet:
         return out
 
     def close(self):
+        self._unbind_bound()
         for env in self.envs:
+            env._fleet_ref = None
             env.close()
 
 

@@ -499,7 +499,9 @@ def test_fleet_fast_path_with_rotating_outputs(discrete, refill, K, pymgrid25, d
         acts = fast.sample_action(generator=g)
         given = [a.cpu().numpy() for a in acts] if (discrete and k % 3 == 0) else acts
         r1 = fast.step(given)
-        assert fast._plans and all(p[4] is not None for p in fast._plans.values())   # fast path (K = 0: rotating row buffers per bucket)
+        # the bound step (mgx_fleet_env_step: the handles walk slots and rings) where the fleet qualifies, else the plan cache's fast path
+        assert (fast._bound is not None) == (refill == "ahead")
+        assert fast._bound is not None or (fast._plans and all(p[4] is not None for p in fast._plans.values()))
         r2 = [env.step(a) for env, a in zip(plain.envs, acts)]
         for b in range(len(fast.envs)):
             assert torch.equal(r1[0][b], r2[b][0]) and torch.equal(r1[1][b], r2[b][1]) and torch.equal(r1[2][b], r2[b][2]), (k, b)
@@ -507,9 +509,14 @@ def test_fleet_fast_path_with_rotating_outputs(discrete, refill, K, pymgrid25, d
         if len(held) >= R:
             view, snap = held[-(R - 1)]
             assert torch.equal(view, snap), k
+    fast._invalidate_bound()                            # (the handles' positions go back to the envs' own bookkeeping)
     for e1, e2 in zip(fast.envs, plain.envs):
         assert e1.current_step == e2.current_step
         assert K == 0 or (e1._ring_idx, e1._ring_pos) == (e2._ring_idx, e2._ring_pos)
+    acts = fast.sample_action(generator=g)              # ... and a step after the hand-back (bound again) still agrees
+    r1, r2 = fast.step(acts), [env.step(a) for env, a in zip(plain.envs, acts)]
+    for b in range(len(fast.envs)):
+        assert torch.equal(r1[0][b], r2[b][0]) and torch.equal(r1[1][b], r2[b][1])
     fast.close(); plain.close()
 
 
