@@ -1,6 +1,6 @@
 // Second C-ABI consumer (no Python, no torch): the rest of SURVEY 8(b)'s list -- mgx_reset with observations, mgx_observe,
 // mgx_expand_discrete, mgx_check_discrete, mgx_step_discrete, mgx_metrics, mgx_env_bind / mgx_env_step (the bound Gym step),
-// mgx_fleet_step over two layouts, mgx_generate_columns -- each checked bit for bit against the CPU oracle
+// mgx_fleet_step / mgx_fleet_env_step over two layouts, mgx_generate_columns -- each checked bit for bit against the CPU oracle
 // (oracle/mgx_oracle.h: TEST INFRASTRUCTURE; this file is built and run only by tests/test_c_abi_consumer.py) or, where the
 // oracle has no counterpart (the generator, the column sums), against the rules / a host sum.  Exit code 0 = identical.
 //
@@ -310,7 +310,25 @@ int main()
         items[0].struct_size = items[1].struct_size = (int32_t)sizeof(mgx_fleet_item);
         items[0].handle = h; items[0].actions = d_acts + (size_t)k * N * A; items[0].reward = d_r1; items[0].obs = d_obs;
         items[1].handle = h2; items[1].actions = d_acts2 + (size_t)k * N2 * A2; items[1].reward = d_r2; items[1].obs = d_o2;
-        MGX_CALL(mgx_fleet_step(items, 2, 1, st));
+        if (k < 2) {
+            MGX_CALL(mgx_fleet_step(items, 2, 1, st));
+        } else {                                   // the same fleet step in its bound form: both handles carry a one-slot env plan
+            mgx_env_slot s1, s2;
+            s1.reward = d_r1; s1.done = nullptr; s1.obs = d_obs; s1.log = nullptr;
+            s2.reward = d_r2; s2.done = nullptr; s2.obs = d_o2; s2.log = nullptr;
+            mgx_env_plan p1, p2;
+            memset(&p1, 0, sizeof(p1)); memset(&p2, 0, sizeof(p2));
+            p1.struct_size = p2.struct_size = (int32_t)sizeof(mgx_env_plan);
+            p1.n_slots = p2.n_slots = 1; p1.slots = &s1; p2.slots = &s2;
+            MGX_CALL(mgx_env_bind(h, &p1));
+            MGX_CALL(mgx_env_bind(h2, &p2));
+            mgx_handle *hs[2] = {h, h2};
+            const void *as[2] = {items[0].actions, items[1].actions};
+            MGX_CALL(mgx_fleet_env_step(hs, as, 2, 1, st));
+            MGX_CALL(mgx_env_bind(h, nullptr));
+            MGX_CALL(mgx_env_bind(h2, nullptr));
+            if (mgx_fleet_env_step(hs, as, 2, 1, st) != MGX_ERR_INVALID) { fprintf(stderr, "unbound handles must refuse mgx_fleet_env_step\n"); return 7; }
+        }
         HIP_OK(hipStreamSynchronize(st));
         std::vector<double> r1 = to_host(d_r1, N), r2 = to_host(d_r2, N2), o1 = to_host(d_obs, (size_t)N * D), o2 = to_host(d_o2, (size_t)N2 * D2);
         std::vector<double> ref2(D2);
