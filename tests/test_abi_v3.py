@@ -509,6 +509,12 @@ def test_fleet_fast_path_with_rotating_outputs(discrete, refill, K, pymgrid25, d
         if len(held) >= R:
             view, snap = held[-(R - 1)]
             assert torch.equal(view, snap), k
+        if k == 6:                                       # a reset in the middle of a ring: the bound fleet hands back, resets, binds again
+            o1, o2 = fast.reset(), [env.reset() for env in plain.envs]
+            assert fast._bound is None
+            for b in range(len(fast.envs)):
+                assert o1[b] is None and o2[b] is None or torch.equal(o1[b], o2[b]), b
+            held = []
     fast._invalidate_bound()                            # (the handles' positions go back to the envs' own bookkeeping)
     for e1, e2 in zip(fast.envs, plain.envs):
         assert e1.current_step == e2.current_step
