@@ -1369,23 +1369,14 @@ __device__ __forceinline__ void load_multi_step_in(const KArgs &a, const AT *__r
 // np_sum_strided: a running sum from 0.0 below 8 addends; with 8 or 9 (only `provided` can: at most ONE of its 9 slots is then unset)
 // the first eight in numpy's pairwise order, the ninth added last.
 constexpr int SMALL_PROV = 4 * MS + 1, SMALL_ABSB = 3 * MS + 1;
-static_assert(MS == 2, "small_sum_prov assumes at most 9 addends: one unset slot at 8");
+static_assert(MS == 2, "small_pairwise_prov assumes at most 9 addends: one unset slot at 8");
 
-__device__ __forceinline__ double small_sum_absb(const double (&e)[SMALL_ABSB], uint32_t mask)
+// `provided` with 8 or 9 addends (n = popcount(mask) >= 8: at most one of the nine slots unset): numpy's pairwise order over the
+// first eight, the ninth added last (np_sum_strided).  Below eight addends -- always for `absorbed`, SMALL_ABSB = 7 -- numpy's sum
+// is the running sum from 0.0 in list order, which the sweep keeps as it appends (the slots are in append order).
+static_assert(SMALL_ABSB < 8, "the absorbed list of the register form is summed as a running sum");
+__device__ __forceinline__ double small_pairwise_prov(const double (&e)[SMALL_PROV], uint32_t mask, int n)
 {
-    double res = 0.0;                                     // SMALL_ABSB = 7 < 8 addends: always the running sum
-#pragma unroll
-    for (int s = 0; s < SMALL_ABSB; s++) res = ((mask >> s) & 1u) ? res + e[s] : res;
-    return res;
-}
-
-__device__ __forceinline__ double small_sum_prov(const double (&e)[SMALL_PROV], uint32_t mask)
-{
-    double seq = 0.0;
-#pragma unroll
-    for (int s = 0; s < SMALL_PROV; s++) seq = ((mask >> s) & 1u) ? seq + e[s] : seq;
-    const int n = __popc(mask);
-    if (n < 8) return seq;
     const uint32_t miss = ~mask & ((1u << SMALL_PROV) - 1u);          // no bit (n = 9) or one (n = 8)
     const int m = miss ? __ffs((int)miss) - 1 : SMALL_PROV;
     double r[8];
@@ -1404,22 +1395,25 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
     double reward = 0.0;
     uint32_t viol = 0u;
-    // The provided / absorbed lists of MicrogridStep in REGISTERS: one static slot per possible addend in sweep order (SmallLists),
-    // a presence bit each -- the run-time form appends to LDS columns and sums them with a dependent LDS read per addend.
+    // The provided / absorbed lists of MicrogridStep in REGISTERS: running sums kept as the sweep appends (numpy's sum of fewer than
+    // eight addends IS the running sum from 0.0 in list order) + one static slot per possible `provided` addend in sweep order with a
+    // presence bit each, for the one sum that can see 8 or 9 addends -- the run-time form appends to LDS columns and sums them with a
+    // dependent LDS read per addend.
     constexpr int SB = (F & F_GRID_FIRST) ? 2 * MS : MS, SR = (F & F_GRID_FIRST) ? MS : 2 * MS;     // first battery / grid slot
-    double pe[SMALL_PROV] = {}, ae[SMALL_ABSB] = {};
-    uint32_t pm = 0u, am = 0u;
+    double pe[SMALL_PROV] = {};                           // (the addends themselves: only the 8-or-9-addend sum needs them again)
+    uint32_t pm = 0u;
+    double psum = 0.0, asum = 0.0;                            // running sums of the two lists, from 0.0 in append order
     o.load_met = 0.0;
 #pragma unroll
     for (int j = 0; j < MS; j++) {                        // fixed modules, module order (microgrid.py:255-257)
         if (j < a.n_load) {
             const double Lv = -1 * sin.load[j];
             o.load_met += Lv;
-            ae[j] = Lv; am |= 1u << j; reward += 0.0;
+            asum += Lv; reward += 0.0;
         }
     }
-    o.fixed_provided = small_sum_prov(pe, pm);            // :259-260 (an empty list: 0.0)
-    o.fixed_absorbed = small_sum_absb(ae, am);
+    o.fixed_provided = psum;                                // :259-260 (an empty list: 0.0)
+    o.fixed_absorbed = asum;
 
     const int kg = LC_COMMON_END, kb = kg + LC_GENSET_N * NG, kr = kb + LC_BATTERY_N * NB;    // log blocks
     Inputs in; in.load = 0.0; in.pv = 0.0;
@@ -1436,7 +1430,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 in.a_goal = sin.goal[j]; in.a_gen = sin.gen[j];
                 step_core<F_GENSET>(p, d, s, in, normalized, false, false, oc);
                 R.g_status[j] = s.status;
-                pe[j] = oc.genset_production; pm |= 1u << j; reward += oc.genset_reward; viol |= oc.violations;
+                pe[j] = oc.genset_production; pm |= 1u << j; psum += oc.genset_production; reward += oc.genset_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kg + LC_GENSET_N * j) * N;
                     q[0] = oc.genset_production; q[N] = oc.genset_co2; q[2 * N] = oc.genset_reward; q[3 * N] = (double)s.status;
@@ -1458,8 +1452,8 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 step_core<F_BATTERY>(p, d, s, in, normalized, true, false, oc);
                 R.b_charge[j] = s.charge; R.b_soc[j] = s.soc;
                 const double x = normalized ? d.bat_lo + d.bat_sp * in.a_bat : in.a_bat;
-                if (x < 0) { ae[SB + j] = oc.charge_amount; am |= 1u << (SB + j); any_sink = true; }
-                else { pe[SB + j] = oc.discharge_amount; pm |= 1u << (SB + j); discharge_sum += oc.discharge_amount; }
+                if (x < 0) { asum += oc.charge_amount; any_sink = true; }
+                else { pe[SB + j] = oc.discharge_amount; pm |= 1u << (SB + j); psum += oc.discharge_amount; discharge_sum += oc.discharge_amount; }
                 reward += oc.battery_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kb + LC_BATTERY_N * j) * N;
@@ -1481,8 +1475,8 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 in.a_grid = sin.grd[j];
                 step_core<F_GRID>(p, d, s, in, normalized, false, false, oc);
                 const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;
-                if (x < 0) { ae[SR + j] = oc.grid_export; am |= 1u << (SR + j); }
-                else { pe[SR + j] = oc.grid_import; pm |= 1u << (SR + j); }
+                if (x < 0) asum += oc.grid_export;
+                else { pe[SR + j] = oc.grid_import; pm |= 1u << (SR + j); psum += oc.grid_import; }
                 reward += oc.grid_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kr + LC_GRID_N * j) * N;
@@ -1500,8 +1494,8 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     }
     o.discharge_amount = any_sink ? 0.0 : discharge_sum;
     o.charge_amount = 0.0;
-    const double provided = small_sum_prov(pe, pm);       // :277
-    const double consumed = small_sum_absb(ae, am);
+    const double provided = psum;                           // :277 (at most 3 MS = 6 addends so far)
+    const double consumed = asum;
     const double difference = provided - consumed;
     o.ctrl_provided = provided - o.fixed_provided; o.ctrl_absorbed = consumed - o.fixed_absorbed;
 
@@ -1512,13 +1506,13 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
         for (int j = 0; j < MS; j++) {
             if (j < a.n_pv) {
                 o.curtailment += sin.pv[j] - 0.0;
-                pe[3 * MS + j] = 0.0; pm |= 1u << (3 * MS + j); reward += 0.0;
+                pe[3 * MS + j] = 0.0; pm |= 1u << (3 * MS + j); psum += 0.0; reward += 0.0;
             }
         }
         const double e = -1.0 * (-1.0 * difference);
         o.overgeneration = e; o.loss_load = 0.0;
         o.unbalanced_reward = -1.0 * (og_cost * e);
-        ae[3 * MS] = e; am |= 1u << (3 * MS);
+        asum += e;
     } else {                                              // :301-314: renewables in module order, then loss load
         double need = -difference;
 #pragma unroll
@@ -1527,17 +1521,18 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 const double pv = sin.pv[j];
                 const double amt = (pv < need) ? pv : need;
                 o.renewable_used += amt; o.curtailment += pv - amt;
-                pe[3 * MS + j] = amt; pm |= 1u << (3 * MS + j); reward += 0.0;
+                pe[3 * MS + j] = amt; pm |= 1u << (3 * MS + j); psum += amt; reward += 0.0;
                 need -= amt;
             }
         }
         o.loss_load = need; o.overgeneration = 0.0;
         o.unbalanced_reward = -1.0 * (ll_cost * need);
-        pe[4 * MS] = need; pm |= 1u << (4 * MS);
+        pe[4 * MS] = need; pm |= 1u << (4 * MS); psum += need;
     }
     reward += o.unbalanced_reward;
-    o.overall_provided = small_sum_prov(pe, pm);          // :316-317
-    o.overall_absorbed = small_sum_absb(ae, am);
+    const int n_prov = __popc(pm);                        // :316-317
+    o.overall_provided = n_prov < 8 ? psum : small_pairwise_prov(pe, pm, n_prov);
+    o.overall_absorbed = asum;
     o.reward = reward;
     o.violations = viol;
     if (log) {
