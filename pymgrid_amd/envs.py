@@ -117,7 +117,8 @@ class BatchedMicrogridEnv:
     ``Microgrid.run(control, normalized)``; the reference's own ContinuousMicrogridEnv is non-functional in
     v1.2.2)."""
 
-    DEFAULT_OBS_PREFETCH = 16
+    DEFAULT_OBS_PREFETCH = 32      # ring depth K: 20.4 / 13.0 us per config-5 fleet step (f64 / f32 rows) against 24.5 / 17.0 at K = 16 and
+                                   # 24.4 / 14.8 at K = 48 (profiles/r05/exp_fleet_ring_depth_v2.txt); halved while three rings exceed 16 GiB
     VIEW_BUFFERS = 4
 
     def __init__(self, batch, log=False, observations=True, reward_shaping_func=None, trajectory_func=None,
@@ -141,7 +142,7 @@ class BatchedMicrogridEnv:
         L = self.layout
         noisy = batch.forecast_noise is not None or any(batch.cols.get(k) is not None
                                                         for k in ("load_noise_std", "pv_noise_std", "grid_noise_std"))
-        if obs_prefetch is None:      # default: on wherever there are forecast windows to share; 0 switches it off.  K = 16
+        if obs_prefetch is None:      # default: on wherever there are forecast windows to share; 0 switches it off.  K = 32
             # (36.7 vs 39.7 us per 100k-grid step at D = 156 with K = 8), halved while the three rings would exceed 16 GiB
             obs_prefetch = self.DEFAULT_OBS_PREFETCH
             esz = 4 if obs_dtype == torch.float32 else 8

@@ -3,7 +3,7 @@ batch (a batch has one layout = one kernel specialisation), so a fleet is bucket
 (``scenario.bucket_by_layout``) and every bucket gets its own ``MicrogridBatch`` + engine.  Buckets are independent.
 
 A fleet step is ONE call of the C ABI (``mgx_fleet_step``) and one ``fleet_step_kernel_v`` launch for all layouts (up to 5 per launch); the
-observation rings of the buckets are renewed ahead of time on the engines' prefetch streams (``refill="ahead"``, K = 16) or as
+observation rings of the buckets are renewed ahead of time on the engines' prefetch streams (``refill="ahead"``, K = 32 by default) or as
 chunks inside the step launches (``refill="chunks"``): 29.5-32 / 33-35 us per 100 000-grid step at H = 24.  Per-bucket HIP
 streams (``streams=True``: fork / join events around every bucket, one ``env.step`` each) were measured 2.7x slower than
 back-to-back launches at 33k grids per bucket (host-bound) and only pay for many tiny buckets.
