@@ -95,6 +95,13 @@ def parse(argv=None):
     ap.add_argument("--no-closed-loop", action="store_true",
                     help="skip the Gym legs that write observation rows per step (the PMC passes use it: single steps WITH rows would be "
                          "averaged into the single-step kernel's counters)")
+    ap.add_argument("--legs", default=None,
+                    help="comma-separated side legs to time INSTEAD of the default set (step, step_env, step_env_obs, step_2chains, "
+                         "step_env_2chains, step_env_obs_2chains, fused_rich, step_full, rbc): the PMC passes of one launch shape")
+    ap.add_argument("--config", type=int, choices=[2, 3, 4], default=2,
+                    help="BASELINE.json configs[] index the job lands on: 2 = 100 000 template-4 grids per GPU (the metric's N = 100k), "
+                         "3 = 1 M template-4 grids over 8 GPUs (125 000 per GPU), 4 = 1 M heterogeneous H = 24 grids over 8 GPUs (the fleet "
+                         "leg at 125 000 per GPU becomes what `value` reports)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the baseline sample")
     ap.add_argument("--prewarm", type=float, default=PREWARM_S)
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
@@ -152,7 +159,10 @@ class Runner:
         self.done_stream = False
 
     def shard(self, on):
-        self.eng.set_shards(self.S if on else 1)
+        if self.env is not None:                   # (the env re-binds its step to the handle around the change)
+            self.env.set_shards(self.S if on else 1)
+        else:
+            self.eng.set_shards(self.S if on else 1)
         self.streams = self.eng.shard_streams() if on and self.S > 1 else []
 
     def reset(self):
@@ -180,6 +190,43 @@ class Runner:
             self._room()
             self.eng.rollout_discrete(self.rbc_ids, self.rbc_table, self.chunk, reward=True, done=self.done_stream, soc_trace=True,
                                       out=self.outs[self.rounds % OUT_SETS])
+            self.rounds += 1
+
+    def _rich_outs(self):
+        """Two sets of the FULL outputs of a fused round (Microgrid.run's per-step returns and log, microgrid.py:305-319,
+        base_module.py:276-290): reward, done, SoC, the packed genset status word and the L log columns [K, L, N]."""
+        if getattr(self, "rich_outs", None) is None:
+            N, dev, Ld = self.eng.N, self.eng.device, self.eng.log_dim
+            self.rich_outs = [dict(reward=torch.empty(self.chunk, N, dtype=torch.float64, device=dev),
+                                   done=torch.empty(self.chunk, N, dtype=torch.uint8, device=dev),
+                                   soc_trace=torch.empty(self.chunk, N, dtype=torch.float64, device=dev),
+                                   status_trace=torch.empty(self.chunk, N, dtype=torch.int32, device=dev),
+                                   log=torch.empty(self.chunk, Ld, N, dtype=torch.float64, device=dev)) for _ in range(2)]
+        return self.rich_outs
+
+    def fused_rich(self, rounds):
+        """The fused launch writing EVERYTHING the reference's step returns and logs: reward, per-grid done, SoC, genset status and
+        the balance / module log columns of every step (SURVEY 8(d) "full total")."""
+        outs = self._rich_outs()
+        for _ in range(rounds):
+            self._room()
+            self.eng.step_k(self.pool[self.rounds % 4], normalized=True, out=outs[self.rounds % 2], reward=True, done=True,
+                            soc_trace=True, status_trace=True, log=True)
+            self.rounds += 1
+
+    def step_full(self, rounds):
+        """Gym cadence with the full outputs: every single-step launch writes reward, per-grid done, the H = 0 observation row and
+        the L log columns."""
+        if getattr(self, "full_outs", None) is None:
+            N, dev, Ld, D = self.eng.N, self.eng.device, self.eng.log_dim, self.eng.obs_dim
+            self.full_outs = [dict(reward=torch.empty(self.chunk, N, dtype=torch.float64, device=dev),
+                                   done=torch.empty(self.chunk, N, dtype=torch.uint8, device=dev),
+                                   obs=torch.empty(self.chunk, N, D, dtype=torch.float64, device=dev),
+                                   log=torch.empty(self.chunk, Ld, N, dtype=torch.float64, device=dev)) for _ in range(2)]
+        for _ in range(rounds):
+            self._room()
+            self.eng.step_many(self.pool[self.rounds % 4], normalized=True, out=self.full_outs[self.rounds % 2], done=True,
+                               want_obs=True, want_log=True)
             self.rounds += 1
 
     def step(self, rounds):
@@ -872,7 +919,7 @@ def main():
             b = generate(n_total, n_steps=args.rows, seed=42, arch=args.arch, device=dev, rank=rank, world=world, series=args.series)
             env = BatchedMicrogridEnv(b, observations=observations, reuse_outputs=4)
             assert env._fp is not None, "the env did not bind its step (mgx_env_bind)"
-            r = Runner(env.engine, chunk, 7, 1, pool=runner(args.series).pool)
+            r = Runner(env.engine, chunk, 7, 2 if args.shards is None else max(1, args.shards), pool=runner(args.series).pool)
             r.env = env
             runs[key] = r
         return runs[key]
@@ -919,14 +966,18 @@ def main():
         wall, gpu = max(walls), mdist.max_over_ranks(gpu, dev)
         n_launch = (N + S - 1) // S if sharded else N             # grids per kernel launch
         obs_rows = mode == "step_env" and run.env._observations
-        if mode in ("fused", "rbc"):
+        rich, full = mode == "fused_rich", mode == "step_full"     # every output of the reference's step: + done, status, log [, row]
+        if mode in ("fused", "rbc", "fused_rich"):
             A8 = 8 * L.action_dim * chunk if mode == "rbc" else 0  # rbc: no action stream; + 1 id byte per grid, once
-            per_launch = L.bytes_fused(chunk, done=run.done_stream, factorised=fact) - A8 + (1 if mode == "rbc" else 0) - ub
+            per_launch = L.bytes_fused(chunk, done=run.done_stream or rich, status_trace=rich, log=rich, factorised=fact) - A8 \
+                + (1 if mode == "rbc" else 0) - ub
             launches_per_round = 1
         else:                                                      # `chunk` single-step launches per round
             # single steps of a factorised batch read the grid's factors (2 ratios + 2 profile ids: 18 B) where the
-            # materialised one reads 2 row values (16 B); no done byte.  With observation rows (H = 0): + 8 D written per grid
-            per_launch = L.bytes_per_step() - (0 if run.done_stream else 1) + (2 if fact else 0) - ub + (8 * L.obs_dim if obs_rows else 0)
+            # materialised one reads 2 row values (16 B); no done byte.  With observation rows (H = 0): + 8 D written per grid;
+            # with the log: + 8 L written and the pre-step SoC read
+            per_launch = L.bytes_per_step(log=full) - (0 if (run.done_stream or full) else 1) + (2 if fact else 0) - ub \
+                + (8 * L.obs_dim if (obs_rows or full) else 0)
             launches_per_round = chunk
         launches = rounds * launches_per_round                     # per stream
         per_launch_bytes = per_launch * N                          # one launch on every shard stream = all N grids
@@ -935,8 +986,10 @@ def main():
         wall_launch_s = wall / launches
         ft = "true" if fact else "false"
         kname = {"fused": f"step_k_kernel<3,4,double,false,{ft}>", "step": "step_kernel<3,false>", "step_env": "step_kernel<3,false>",
-                 "rbc": f"rollout_kernel<3,8,false,false,{ft}>"}[mode]
-        traffic, traffic_src = (None, None) if obs_rows else measured_traffic(kname, n_launch, chunk)
+                 "rbc": f"rollout_kernel<3,8,false,false,{ft}>", "fused_rich": f"step_k_kernel<3,4,double,true,{ft}>",
+                 "step_full": "step_kernel<3,false>"}[mode]
+        tkey = kname + ("+rows" if obs_rows else "") + ("+rows+log" if full else "")     # the key of this launch shape in traffic.json
+        traffic, traffic_src = measured_traffic(tkey, n_launch, chunk)
         if traffic is not None and sharded:
             traffic *= S
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -950,7 +1003,7 @@ def main():
                 "bytes_per_env_step": per_launch / (chunk if mode in ("fused", "rbc") else 1),
                 "launches": launches, "avg_launch_us": avg_launch_s * 1e6, "avg_launch_us_wall": wall_launch_s * 1e6,
                 "timed_rounds": [first, first + rounds]}
-        if mode in ("step", "step_env"):
+        if mode in ("step", "step_env", "step_full") and not sharded:
             # A single-step launch cannot overlap its predecessor (the next step needs this one's state): it is ONE dependent round
             # trip behind a launch boundary, not a stream.  Its ceiling is the guide's latency model, not the HBM peak:
             # t_model = launch boundary (1.5-1.9 us: LAT_FLOOR_US) + bytes / the rate the chip sustains (LAT_STREAM_GBS)
@@ -970,13 +1023,17 @@ def main():
             roof.update({"launch": f"one round = {S} concurrent kernel launches, one per internal shard stream "
                                    f"(mgx_set_shards), {n_launch} grids each, never joined between rounds",
                          "concurrent_streams": S, "grids_per_kernel_launch": n_launch})
-        if mode in ("fused", "rbc"):
+            if mode in ("step", "step_env", "step_full"):
+                roof["launch"] = (f"every env-step = {S} launches of {n_launch} grids, one per shard stream, each shard's dependent chain "
+                                  f"issued by a host thread of its own (mgx_set_launch_threads): a range's step k + 1 waits for its own "
+                                  f"step k only; open loop (actions staged ahead), joined once behind the timed region")
+        if mode in ("fused", "rbc", "fused_rich"):
             roof["kernel_avg_duration_us"] = run.kernel_durations_us(fn)
         if mode == "rbc" and fact:
             roof["note"] = ("with factorised series this kernel reads nothing per step (18.5 B/env-step are its reward / SoC writes): "
                             "it is bound by fp64 VALU issue, not by HBM -- see roofline_valu; the HBM fraction is reported for "
                             "completeness, the materialised form is the bandwidth-bound one")
-        if mode in ("fused", "rbc"):
+        if mode in ("fused", "rbc", "fused_rich"):
             # The issue-side ceiling: cycles the kernel's waves spent EXECUTING vector-ALU instructions (SQ_ACTIVE_INST_VALU x 4:
             # the counter ticks in quad-cycles; summed over the waves of a launch; a committed PMC pass of this command) over the
             # VALU cycles the chip had in the launch's duration (SIMDs x shader clock x time, measured live).  1.0 = every SIMD
@@ -998,6 +1055,10 @@ def main():
         else:
             roof_valu = None
         run.shard(False)
+        if rich:
+            run.rich_outs = None                     # 2 x 1.2 GB of log buffers at N = 100 000
+        if full:
+            run.full_outs = None
         return {"value": n_total * rounds * chunk / wall, "rounds": rounds, "warmup_rounds": warmup, "wall_s": wall,
                 "us_per_env_step": wall / (rounds * chunk) * 1e6, "ms_per_round": wall / rounds * 1e3,
                 "roofline": roof, "roofline_valu": roof_valu, "per_rank_env_steps_per_s": [N * rounds * chunk / w for w in walls]}
@@ -1023,18 +1084,41 @@ def main():
     side = (min(args.steps * LPS, SIDE_ROUNDS[0]), min(args.warmup * LPS, SIDE_ROUNDS[1]))
     if not args.no_side_modes:
         # the Gym cadence: single-step launches issued by one C call, and the Gym surface itself from a Python loop
-        if args.mode != "step":
+        legs_only = [x for x in args.legs.split(",") if x] if args.legs is not None else None
+
+        def want(name, default=True):
+            return (name in legs_only) if legs_only is not None else default
+
+        if args.mode != "step" and want("step"):
             results["step"] = guarded("step", lambda: measure("step", False, side[0], side[1]))
-        results["step_env"] = guarded("step_env", lambda: measure("step_env", False, min(side[0], 64), min(side[1], 16), run=env_runner(False)))
-        if not args.no_closed_loop:
+        if want("step_env"):
+            results["step_env"] = guarded("step_env", lambda: measure("step_env", False, min(side[0], 64), min(side[1], 16), run=env_runner(False)))
+        if want("step_env_obs", not args.no_closed_loop):
             results["step_env_obs"] = guarded("step_env_obs", lambda: measure("step_env", False, min(side[0], 64), min(side[1], 16),
                                                                               run=env_runner(True)))
+        # the same Gym cadence as TWO dependent launch chains (grid ranges on two shard streams, each issued by its own host thread)
+        if want("step_2chains"):
+            results["step_2chains"] = guarded("step_2chains", lambda: measure("step", True, side[0], side[1]))
+        if want("step_env_2chains"):
+            results["step_env_2chains"] = guarded("step_env_2chains", lambda: measure("step_env", True, min(side[0], 64), min(side[1], 16),
+                                                                                      run=env_runner(False)))
+        if want("step_env_obs_2chains", not args.no_closed_loop):
+            results["step_env_obs_2chains"] = guarded("step_env_obs_2chains", lambda: measure("step_env", True, min(side[0], 64), min(side[1], 16),
+                                                                                              run=env_runner(True)))
+        # every output of the reference's step inside the timed region (SURVEY 8(d) "full total"): per-grid done, genset status, the
+        # balance / module log columns of every step -- fused and at the Gym cadence (there with the H = 0 observation row)
+        if args.mode == "fused" and want("fused_rich"):
+            results["fused_rich"] = guarded("fused_rich", lambda: measure("fused_rich", True, min(side[0], 64), min(side[1], 16)))
+        if want("step_full", not args.no_closed_loop):
+            results["step_full"] = guarded("step_full", lambda: measure("step_full", False, min(side[0], 64), min(side[1], 16)))
+        if args.mode != "rbc" and want("rbc"):       # f1: the RuleBasedControl year on device (no host, no action stream)
+            results["rbc"] = guarded("rbc", lambda: measure("rbc", True, side[0], side[1]))
         for key in ("env", "env_obs"):
             if key in runs:
                 runs.pop(key).env.close()
     if not args.no_side_modes and args.all_legs:
         for mode in ("fused", "rbc"):
-            if mode != args.mode:
+            if mode != args.mode and mode not in results:
                 results[mode] = guarded(mode, lambda mode=mode: measure(mode, True, side[0], side[1]))
         # the other series layout: the fused kernel (as sharded as that layout likes it, and as ONE launch sequence) + the rollout
         if shards_of[args.series] > 1 and args.mode == "fused":      # the headline kernel as ONE launch sequence
@@ -1088,7 +1172,10 @@ def main():
                  "fused_other_series": f"fused_launches_{other_series}",
                  "fused_other_series_one_stream": f"fused_launches_{other_series}_one_stream",
                  "rbc_other_series": f"rbc_rollout_{other_series}", "step_env": "single_step_launches_python_loop",
-                 "step_env_obs": "single_step_launches_python_loop_with_rows"}
+                 "step_env_obs": "single_step_launches_python_loop_with_rows",
+                 "step_2chains": "single_step_launches_one_call_2chains", "step_env_2chains": "single_step_launches_python_loop_2chains",
+                 "step_env_obs_2chains": "single_step_launches_python_loop_with_rows_2chains",
+                 "fused_rich": "fused_launches_full_outputs", "step_full": "single_step_launches_full_outputs"}
         backend = None
         if world > 1:
             import torch.distributed as dist

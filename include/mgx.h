@@ -49,7 +49,8 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 9
+#define MGX_ABI_VERSION 9    /* frozen: struct layouts and the meaning of every v9 entry point do not change any more */
+#define MGX_ABI_MINOR 1      /* additions only: 1 = mgx_abi_minor, mgx_set_tunable / mgx_get_tunable, mgx_set_launch_threads */
 
 enum mgx_status {
     MGX_OK = 0,
@@ -207,6 +208,26 @@ typedef struct mgx_columns {
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 int mgx_abi_version(void);
+int mgx_abi_minor(void);
+
+/* Process-wide launch-shape knobs.  The library reads nothing from the environment: this is the only way to change what the
+ * measurements behind DESIGN.md chose, and a consumer can read back what a process runs with.  They change HOW a call is
+ * launched (never a value it computes) and take effect for the calls / handles that follow. */
+enum mgx_tunable {
+    MGX_TUNE_WIN_THREADS = 0,      /* threads of a ring-refill workgroup: 0 = automatic, 256 / 512 / 1024 */
+    MGX_TUNE_WIN_GROUP = 1,        /* grids per refill workgroup: 0 = automatic (16 / 32), else a power of two <= 64 */
+    MGX_TUNE_WIN_PAIRS = 2,        /* column-major refill stores carry a pair of adjacent grids per lane: -1 = automatic, 0, 1 */
+    MGX_TUNE_WIN_MIN_LDS = 3,      /* LDS bytes a refill ahead of the counter asks for at least (occupancy cap): -1 = automatic */
+    MGX_TUNE_PREFETCH_POOL = 4,    /* 1: one prefetch stream per device shared by all handles (default 0: one per handle) */
+    MGX_TUNE_MULTI_GENERIC = 5,    /* 1: handles CREATED afterwards run every general layout on the run-time-count kernels */
+    MGX_TUNE_MULTI_SMALL_OWN = 6,  /* 0: mgx_step_k of small general layouts through the shared kernel (default 1: its own) */
+    MGX_TUNE_GRID_MAJOR_COPY = 7,  /* 0: mgx_reset_episodes on [T, N] series gathers rows instead of making its grid-major copy */
+    MGX_TUNE_FLEET_BYVALUE = 8,    /* 0: mgx_fleet_step launches the pointer form of the fleet kernel (default 1: by value) */
+    MGX_TUNE_LAUNCH_THREADS = 9,   /* default of mgx_set_launch_threads for handles created afterwards (1) */
+    MGX_TUNE_COUNT_ = 10
+};
+int mgx_set_tunable(int32_t id, int64_t value);                                /* MGX_ERR_INVALID: unknown id / value out of range */
+int mgx_get_tunable(int32_t id, int64_t *value, int64_t *default_value);       /* either pointer may be NULL */
 /* thread-local text of the last error returned on this thread ("" if none) */
 const char *mgx_last_error(void);
 
@@ -552,6 +573,14 @@ int mgx_env_step_discrete(mgx_handle *h, const int32_t *action_id, mgx_stream st
  * may still be using (a wait, never a loss).  The pool is created under a lock: handles may live on different host threads
  * (one thread per handle). */
 int mgx_set_shards(mgx_handle *h, int32_t n_shards);
+/* Single-step calls in shards (mgx_step, mgx_step_many, mgx_step_discrete, mgx_env_step*): one host thread issues a launch every
+ * ~4 us, so S launches per env-step from the calling thread made the Gym cadence S times slower than no shards at all.  With
+ * launch threads on (default) shard j >= 1 is issued by a resident host thread of the library (one per device and shard, shared
+ * by all handles, asleep when idle) while the caller issues shard 0: the shards' dependent launch chains advance side by side.
+ * The call still returns only when every shard's launches have been issued, and values do not depend on the setting.
+ * mgx_step_many hands each thread its shard's K launches in one piece.  Fused calls (mgx_step_k, rollouts) are always issued
+ * by the caller. */
+int mgx_set_launch_threads(mgx_handle *h, int32_t enable);
 int mgx_fork(mgx_handle *h, mgx_stream stream);
 int mgx_join(mgx_handle *h, mgx_stream stream);
 void *mgx_shard_stream(mgx_handle *h, int32_t shard);

@@ -26,6 +26,10 @@ V_EXPAND_CONSUME, V_EXPAND_PRODUCE, V_EXPAND_SIGN = 64, 128, 256
 V_EXPAND = V_EXPAND_CONSUME | V_EXPAND_PRODUCE | V_EXPAND_SIGN      # states in which _populate_action asserts
 V_ASSERTS = V_GENSET_GOAL | V_GENSET_NEGATIVE | V_NEGATIVE_LIMIT | V_EXPAND    # the reference raises whatever raise_errors says
 ABI_VERSION = 9
+ABI_MINOR = 1
+# enum mgx_tunable (process-wide launch-shape knobs; set_tunable / get_tunable below)
+TUNABLES = ("win_threads", "win_group", "win_pairs", "win_min_lds", "prefetch_pool", "multi_generic", "multi_small_own",
+            "grid_major_copy", "fleet_byvalue", "launch_threads")
 MAX_INSTANCES = 8          # MGX_MAX_INSTANCES: gensets / batteries / grids per microgrid
 
 
@@ -132,6 +136,10 @@ class EnvPlan(C.Structure):
 # every symbol include/mgx.h declares: (restype, argtypes)
 SYMBOLS = {
     "mgx_abi_version": (C.c_int, []),
+    "mgx_abi_minor": (C.c_int, []),
+    "mgx_set_tunable": (C.c_int, [C.c_int32, C.c_int64]),
+    "mgx_get_tunable": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mgx_set_launch_threads": (C.c_int, [C.c_void_p, C.c_int32]),
     "mgx_last_error": (C.c_char_p, []),
     "mgx_create": (C.c_int, [C.POINTER(Layout), C.POINTER(Columns), C.POINTER(C.c_void_p)]),
     "mgx_destroy": (None, [C.c_void_p]),
@@ -363,3 +371,15 @@ def lib():
 def check(rc):
     if rc != MGX_OK:
         raise MgxError(rc, lib().mgx_last_error().decode())
+
+
+def set_tunable(name, value):
+    """mgx_set_tunable by name (TUNABLES): process-wide launch-shape knobs -- the library reads no environment variables."""
+    check(lib().mgx_set_tunable(TUNABLES.index(name), int(value)))
+
+
+def get_tunable(name):
+    """(current value, default) of a tunable."""
+    v, d = C.c_int64(), C.c_int64()
+    check(lib().mgx_get_tunable(TUNABLES.index(name), C.byref(v), C.byref(d)))
+    return v.value, d.value

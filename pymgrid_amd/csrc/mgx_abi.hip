@@ -9,9 +9,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mgx;
@@ -42,7 +46,7 @@ struct mgx_handle {
     hipStream_t shard_stream[MGX_MAX_SHARDS];
     hipEvent_t shard_event[MGX_MAX_SHARDS];
     hipEvent_t fork_event;
-    double stagger_us;                       // mgx_fork delays shard j by j / S of this (0: off)
+    bool launch_threads;                     // single-step launches of shards 1.. are issued by the device's launch workers
     hipStream_t counter_stream;              // device-counter mode: the stream of the last call that touched the counter
     KArgs *d_kargs;                          // device copy of `k` for fleet_step_kernel, refreshed when `k` changed
     KArgs k_uploaded;
@@ -57,7 +61,7 @@ struct mgx_handle {
     char *env_rings[3];
     int32_t env_table[12 * 3 * 2];
     hipStream_t prefetch_stream;             // mgx_observe_windows_ahead: the window prefetch overlaps the steps
-    bool prefetch_pooled;                    // ... on the per-device pooled stream (MGX_PREFETCH_POOL): not destroyed with the handle
+    bool prefetch_pooled;                    // ... on the per-device pooled stream (MGX_TUNE_PREFETCH_POOL): not destroyed with the handle
     hipEvent_t prefetch_gate, prefetch_done;
     bool prefetch_pending;
     // per-grid episode windows (mgx_reset_windows): the full series are remembered here while the handle steps over the
@@ -92,9 +96,114 @@ thread_local char g_err[512] = "";
 constexpr int MGX_MAX_DEVICES = 16;
 hipStream_t g_shard_streams[MGX_MAX_DEVICES][MGX_MAX_SHARDS] = {};
 std::mutex g_shard_streams_lock;          // handles live on different host threads (one thread per handle): creation is guarded
-// MGX_PREFETCH_POOL=1: one prefetch stream per device shared by every handle -- the ring refills of a fleet's buckets then run one
+// MGX_TUNE_PREFETCH_POOL = 1: one prefetch stream per device shared by every handle -- the ring refills of a fleet's buckets then run one
 // after the other instead of side by side (each alone has the whole memory system; a fleet step orders them with one gate event)
 hipStream_t g_prefetch_streams[MGX_MAX_DEVICES] = {};
+
+// ---- tunables (mgx_set_tunable): process-wide launch-shape knobs, defaults = what the measurements of DESIGN.md chose -------------
+// The library reads NOTHING from the environment: a consumer sees and pins every knob through the ABI.
+std::atomic<int64_t> g_tune[MGX_TUNE_COUNT_];
+const int64_t kTuneDefault[MGX_TUNE_COUNT_] = {
+    /* MGX_TUNE_WIN_THREADS     */ 0,      // 0 = automatic (256 ahead of the counter, 1 024 where a reset waits)
+    /* MGX_TUNE_WIN_GROUP       */ 0,      // 0 = automatic (16 / 32 grids per refill workgroup, windows_plan)
+    /* MGX_TUNE_WIN_PAIRS       */ -1,     // -1 = automatic (pairs of adjacent grids per lane for column-major blocks)
+    /* MGX_TUNE_WIN_MIN_LDS     */ -1,     // -1 = automatic (81 KB ahead of the counter: one refill workgroup per CU)
+    /* MGX_TUNE_PREFETCH_POOL   */ 0,
+    /* MGX_TUNE_MULTI_GENERIC   */ 0,
+    /* MGX_TUNE_MULTI_SMALL_OWN */ 1,
+    /* MGX_TUNE_GRID_MAJOR_COPY */ 1,
+    /* MGX_TUNE_FLEET_BYVALUE   */ 1,
+    /* MGX_TUNE_LAUNCH_THREADS  */ 1,
+};
+struct TuneInit { TuneInit() { for (int j = 0; j < MGX_TUNE_COUNT_; j++) g_tune[j].store(kTuneDefault[j], std::memory_order_relaxed); } } g_tune_init;
+inline int64_t tune(int id) { return g_tune[id].load(std::memory_order_relaxed); }
+
+// ---- launch workers ------------------------------------------------------------------------------------------------------------
+// A single-step launch cannot overlap its predecessor (the next step needs this one's state), and ONE host thread issues a launch
+// every ~4.3 us (profiles/r02/exp_sharded_single_steps.txt): S shard launches per env-step from one thread made the Gym cadence S
+// times slower.  With shards on (mgx_set_shards) shard j >= 1 of a single-step call is therefore issued by a resident host thread
+// of its own -- one per (device, shard), shared by all handles like the shard streams -- while the caller issues shard 0: the
+// two dependent launch chains then advance side by side, one chain's launch boundary under the other's memory round trip.
+// Hand-over by two counters the parties spin on (a worker goes to sleep on a condition variable after SPIN_US idle microseconds);
+// the call returns when every shard's launches have been ISSUED, so "asynchronous on its streams, issued when the call returns" holds.
+struct LaunchWorker {
+    std::atomic<uint64_t> posted{0}, done{0};
+    std::atomic<int> asleep{0};
+    void (*fn)(void *, int) = nullptr;        // fn(ctx, shard)
+    void *ctx = nullptr;
+    int shard = 0, device = 0;
+    hipError_t err = hipSuccess;              // first launch error of the last job (hipGetLastError is per host thread)
+    std::mutex sleep_lock, caller_lock;       // caller_lock: one job at a time (handles on different host threads share a worker)
+    std::condition_variable wake;
+    std::thread th;
+    static constexpr int SPIN_US = 500;
+
+    void run()
+    {
+        (void)hipSetDevice(device);
+        uint64_t seen = 0;
+        for (;;) {
+            auto idle_since = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (posted.load(std::memory_order_acquire) == seen) {
+                __builtin_ia32_pause();
+                if ((++spins & 1023) == 0 &&
+                    std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(SPIN_US)) {
+                    std::unique_lock<std::mutex> lk(sleep_lock);
+                    asleep.store(1, std::memory_order_seq_cst);
+                    wake.wait(lk, [&] { return posted.load(std::memory_order_seq_cst) != seen; });
+                    asleep.store(0, std::memory_order_seq_cst);
+                }
+            }
+            (void)hipGetLastError();
+            fn(ctx, shard);
+            err = hipGetLastError();
+            seen += 1;
+            done.store(seen, std::memory_order_release);
+        }
+    }
+    void post(void (*f)(void *, int), void *c, int j)
+    {
+        fn = f; ctx = c; shard = j;
+        posted.store(posted.load(std::memory_order_relaxed) + 1, std::memory_order_seq_cst);
+        if (asleep.load(std::memory_order_seq_cst)) {
+            std::lock_guard<std::mutex> lk(sleep_lock);
+            wake.notify_one();
+        }
+    }
+    hipError_t wait()
+    {
+        const uint64_t want = posted.load(std::memory_order_relaxed);
+        while (done.load(std::memory_order_acquire) != want) __builtin_ia32_pause();
+        return err;
+    }
+};
+LaunchWorker *g_workers[MGX_MAX_DEVICES][MGX_MAX_SHARDS] = {};     // never destroyed: the threads live until the process ends
+thread_local hipError_t g_worker_err = hipSuccess;                  // a worker's launch error, handed to the calling thread
+
+LaunchWorker *launch_worker(int device, int shard)
+{
+    if (device < 0 || device >= MGX_MAX_DEVICES || shard < 1 || shard >= MGX_MAX_SHARDS) return nullptr;
+    std::lock_guard<std::mutex> guard(g_shard_streams_lock);
+    LaunchWorker *&w = g_workers[device][shard];
+    if (!w) {
+        w = new (std::nothrow) LaunchWorker();
+        if (!w) return nullptr;
+        w->device = device;
+        w->th = std::thread([w] { w->run(); });
+        w->th.detach();
+    }
+    return w;
+}
+
+// the launch error of a stepping call: the calling thread's, or the first one a launch worker met
+inline hipError_t launch_error()
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = g_worker_err;
+    g_worker_err = hipSuccess;
+    return e;
+}
 
 int fail(int code, const char *fmt, ...)
 {
@@ -157,6 +266,37 @@ inline void for_each_shard(const mgx_handle *h, hipStream_t user, Fn fn)
     for (int j = 0; j < h->n_shards; j++) {
         k.g0 = h->shard_lo[j]; k.g1 = h->shard_lo[j + 1];
         if (k.g1 > k.g0) fn(k, h->shard_stream[j]);
+    }
+}
+
+// The same for the single-step calls: with shards on, shard j >= 1 is issued by launch worker j of the device (see LaunchWorker)
+// while the calling thread issues shard 0; returns when all of them are issued.  fn must be safe to run on several threads at once.
+template <class Fn>
+inline void for_each_shard_threaded(const mgx_handle *h, hipStream_t user, Fn fn)
+{
+    if (h->n_shards <= 1 || !h->launch_threads) { for_each_shard(h, user, fn); return; }
+    struct Job { const mgx_handle *h; Fn *fn; };
+    Job job{h, &fn};
+    auto thunk = [](void *ctx, int j) {
+        const Job *jb = (const Job *)ctx;
+        KArgs k = jb->h->k;
+        k.g0 = jb->h->shard_lo[j]; k.g1 = jb->h->shard_lo[j + 1];
+        (*jb->fn)(k, jb->h->shard_stream[j]);
+    };
+    LaunchWorker *ws[MGX_MAX_SHARDS] = {};
+    for (int j = 1; j < h->n_shards; j++) {
+        if (h->shard_lo[j + 1] <= h->shard_lo[j]) continue;
+        ws[j] = launch_worker(h->device, j);
+        if (!ws[j]) { thunk(&job, j); continue; }          // (no worker: this thread issues the shard)
+        ws[j]->caller_lock.lock();
+        ws[j]->post(thunk, &job, j);
+    }
+    if (h->shard_lo[1] > h->shard_lo[0]) thunk(&job, 0);
+    for (int j = 1; j < h->n_shards; j++) {
+        if (!ws[j]) continue;
+        const hipError_t e = ws[j]->wait();
+        ws[j]->caller_lock.unlock();
+        if (e != hipSuccess && g_worker_err == hipSuccess) g_worker_err = e;
     }
 }
 
@@ -233,12 +373,8 @@ static void launch_windows_kernel(const KArgs &k, const WindowsKPlan &plan, int3
     // Threads per refill workgroup (phase 1; phase 2 is always the first 256).  A refill that runs ALONE (the one a reset waits
     // for: with_state) takes all 1 024 -- 12 % faster (profiles/r05/exp_refill_threads.txt); one written AHEAD, beside the step
     // launches, stays at 256: the faster it runs the harder it leans on the memory system and the more the steps beside it pay
-    // (config-5 fleet step 16.5 -> 17.2 us with 1 024).  MGX_WIN_THREADS (experiment knob): 256 / 512 / 1024 for both.
-    static const unsigned forced = [] {
-        const char *e = getenv("MGX_WIN_THREADS");
-        const int v = e ? atoi(e) : 0;
-        return (unsigned)((v == 256 || v == 512 || v == 1024) ? v : 0);
-    }();
+    // (config-5 fleet step 16.5 -> 17.2 us with 1 024).  mgx_set_tunable(MGX_TUNE_WIN_THREADS, 256 / 512 / 1024) pins it for both.
+    const unsigned forced = (unsigned)tune(MGX_TUNE_WIN_THREADS);
     const unsigned threads = forced ? forced : (plan.with_state ? (unsigned)OBS_P1_THREADS : (unsigned)OBS_K_THREADS);
     obs_windows_k_kernel<F, OT><<<blocks, threads, lds, st>>>(k, plan, t, (OT *)ring);
 }
@@ -257,12 +393,8 @@ static void launch_windows_multi_kernel(const KArgs &k, const WindowsKPlan &plan
         }
     }
     // 1 024 threads for phase 1 here, ahead or not: on the general path the refill -- not the chain of step launches -- sets the
-    // pace of a Gym step with rows (1.15 ms per ring of 32 blocks against 0.3 ms of steps).  MGX_WIN_THREADS overrides.
-    static const unsigned forced = [] {
-        const char *e = getenv("MGX_WIN_THREADS");
-        const int v = e ? atoi(e) : 0;
-        return (unsigned)((v == 256 || v == 512 || v == 1024) ? v : 0);
-    }();
+    // pace of a Gym step with rows (1.15 ms per ring of 32 blocks against 0.3 ms of steps).  MGX_TUNE_WIN_THREADS overrides.
+    const unsigned forced = (unsigned)tune(MGX_TUNE_WIN_THREADS);
     obs_windows_k_multi_kernel<F, OT><<<blocks, forced ? forced : (unsigned)OBS_P1_THREADS, lds, st>>>(k, plan, t, (OT *)ring);
 }
 
@@ -297,6 +429,41 @@ static int launch_observe(const mgx_handle *h, int32_t t, void *obs, hipStream_t
 extern "C" {
 
 int mgx_abi_version(void) { return MGX_ABI_VERSION; }
+int mgx_abi_minor(void) { return MGX_ABI_MINOR; }
+
+int mgx_set_tunable(int32_t id, int64_t value)
+{
+    g_err[0] = 0;
+    if (id < 0 || id >= MGX_TUNE_COUNT_) return fail(MGX_ERR_INVALID, "mgx_set_tunable: unknown tunable %d", id);
+    bool ok = true;
+    switch (id) {
+        case MGX_TUNE_WIN_THREADS: ok = value == 0 || value == 256 || value == 512 || value == 1024; break;
+        case MGX_TUNE_WIN_GROUP: ok = value >= 0 && value <= 64; break;
+        case MGX_TUNE_WIN_PAIRS: ok = value >= -1 && value <= 1; break;
+        case MGX_TUNE_WIN_MIN_LDS: ok = value >= -1 && value <= 160 * 1024; break;
+        default: ok = value == 0 || value == 1; break;
+    }
+    if (!ok) return fail(MGX_ERR_INVALID, "mgx_set_tunable: value %lld is not valid for tunable %d", (long long)value, id);
+    g_tune[id].store(value, std::memory_order_relaxed);
+    return MGX_OK;
+}
+
+int mgx_get_tunable(int32_t id, int64_t *value, int64_t *default_value)
+{
+    g_err[0] = 0;
+    if (id < 0 || id >= MGX_TUNE_COUNT_) return fail(MGX_ERR_INVALID, "mgx_get_tunable: unknown tunable %d", id);
+    if (value) *value = tune(id);
+    if (default_value) *default_value = kTuneDefault[id];
+    return MGX_OK;
+}
+
+int mgx_set_launch_threads(mgx_handle *h, int32_t enable)
+{
+    g_err[0] = 0;
+    if (!h) return fail(MGX_ERR_INVALID, "mgx_set_launch_threads: NULL handle");
+    h->launch_threads = enable != 0;
+    return MGX_OK;
+}
 
 const char *mgx_last_error(void) { return g_err; }
 
@@ -387,8 +554,8 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
         }
     }
     h->multi_lds = 2 * (size_t)multi_list_capacity(L->n_load, L->n_pv, n_genset, n_battery, n_grid) * BLOCK_MULTI * sizeof(double);
-    {   // MGX_MULTI_GENERIC=1 (tests): every general layout on the run-time-count form, whatever its size
-        static const bool generic = [] { const char *e = getenv("MGX_MULTI_GENERIC"); return e && atoi(e) != 0; }();
+    {   // MGX_TUNE_MULTI_GENERIC = 1 (tests): every general layout on the run-time-count form, whatever its size
+        const bool generic = tune(MGX_TUNE_MULTI_GENERIC) != 0;
         h->multi_small = (!generic && multi_is_small(L->n_load, L->n_pv, n_genset, n_battery, n_grid)) ? 1 : 0;
     }
     h->k.log_dim = LC_COMMON_END + LC_GENSET_N * n_genset + LC_BATTERY_N * n_battery + LC_GRID_N * n_grid + 1;
@@ -413,7 +580,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->n_shards = 1; h->shard_lo[0] = 0; h->shard_lo[1] = L->n_grids;
     for (int j = 0; j < MGX_MAX_SHARDS; j++) { h->shard_stream[j] = nullptr; h->shard_event[j] = nullptr; }
     h->fork_event = nullptr; h->counter_stream = nullptr;
-    { const char *e = getenv("MGX_FORK_STAGGER_US"); h->stagger_us = e ? atof(e) : 0.0; }
+    h->launch_threads = tune(MGX_TUNE_LAUNCH_THREADS) != 0;
     h->d_kargs = nullptr; h->k_uploaded_valid = false;
     h->d_table = nullptr; h->table_uploaded_valid = false;
     h->env_bound = false; h->env_n_slots = 0; h->env_next = 0; h->env_ring_K = 0; h->env_ring_idx = 0; h->env_ring_pos = 0; h->env_n_actions = 0;
@@ -588,7 +755,7 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     plan->K = K;
     plan->rp = R;
     plan->bp = (ncomp * (R + K) + (ahead == 0 ? nstate : 1) * K) | 1;      // ahead of the counter: ONE strip of zeros for all state columns
-    static const int group_env = [] { const char *e = getenv("MGX_WIN_GROUP"); return e ? atoi(e) : 0; }();   // experiment knob
+    const int group_env = (int)tune(MGX_TUNE_WIN_GROUP);
     // Float rows keep a FLOAT image (windows_body): half the LDS per grid, and a refill ahead of the counter has ONE strip of zeros
     // for all state columns.  Grids per workgroup (halved below while the image does not fit): 32 for float rows -- 32 x 4 bytes are
     // what a whole 128-byte line of a column-major block needs -- and for column-major blocks of doubles on the general path (two
@@ -602,8 +769,8 @@ static int windows_plan(const mgx_handle *h, int32_t ahead, int32_t K, const voi
     // Column-major blocks: a lane stores a PAIR of adjacent grids per instruction (16-byte stores of doubles, 8-byte stores of floats:
     // half the store instructions for the same lines).  us per 100 000-grid Gym step with rows, off -> on
     // (profiles/r05/exp_refill_col_pairs_matrix.txt): single env f64 31.3 -> 28.8, general path f64 37.9 -> 33.6, config-5 fleet f64
-    // 23.1 -> 21.7, f32 15.5 -> 14.9; float rows of single envs unchanged within the spread.  MGX_WIN_PAIRS=0/1 overrides.
-    static const int pairs_env = [] { const char *e = getenv("MGX_WIN_PAIRS"); return e ? atoi(e) : -1; }();
+    // 23.1 -> 21.7, f32 15.5 -> 14.9; float rows of single envs unchanged within the spread.  MGX_TUNE_WIN_PAIRS = 0 / 1 overrides.
+    const int pairs_env = (int)tune(MGX_TUNE_WIN_PAIRS);
     plan->pairs = pairs_env >= 0 ? pairs_env : (h->k.obs_colpitch ? 1 : 0);
     plan->with_state = ahead == 0;
     plan->group0 = 0;
@@ -644,8 +811,8 @@ static int launch_windows(mgx_handle *h, int32_t ahead, int32_t K, void *ring, h
         // leans on the memory system decides what those steps cost: with two refill workgroups per CU (K = 16: 55 KB of LDS each)
         // a 100 000-grid fleet step took 60 us while the refills ran, with one per CU (K = 32: 92 KB) 25 us -- at the same
         // 5.3 TB/s of row writes (profiles/r04/fleet_timeline_K16.txt, _K32.txt).  Asking for more than half of the 160 KB keeps
-        // it at one workgroup per CU whatever K is.  MGX_WIN_MIN_LDS overrides (bytes; 0 = exactly what the image needs).
-        static const long min_lds_env = [] { const char *e = getenv("MGX_WIN_MIN_LDS"); return e ? atol(e) : -1L; }();
+        // it at one workgroup per CU whatever K is.  MGX_TUNE_WIN_MIN_LDS overrides (bytes; 0 = exactly what the image needs).
+        const long min_lds_env = (long)tune(MGX_TUNE_WIN_MIN_LDS);
         const size_t min_lds = min_lds_env >= 0 ? (size_t)min_lds_env : (size_t)(ahead > 0 ? 81 * 1024 : 0);
         if (lds < min_lds && min_lds <= 160 * 1024) lds = min_lds;
     }
@@ -739,7 +906,7 @@ static int ensure_prefetch_stream(mgx_handle *h, const char *who)
 {
     if (h->prefetch_stream) return MGX_OK;
     hipError_t e = hipSuccess;
-    static const bool pool = [] { const char *v = getenv("MGX_PREFETCH_POOL"); return v && atoi(v) != 0; }();
+    const bool pool = tune(MGX_TUNE_PREFETCH_POOL) != 0;
     if (pool && h->device >= 0 && h->device < MGX_MAX_DEVICES) {
         std::lock_guard<std::mutex> guard(g_shard_streams_lock);
         hipStream_t &pooled = g_prefetch_streams[h->device];
@@ -1064,8 +1231,7 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
         const int64_t N = h->k.N;
         const int ncomp = 2 + 4 * h->layout.has_grid;
         DeviceGuard on_device(h->device);
-        const char *no_gm = getenv("MGX_NO_GRID_MAJOR");         // tests: take the gather path although the copy would fit
-        const bool want_gm = !(no_gm && no_gm[0] && no_gm[0] != '0');
+        const bool want_gm = tune(MGX_TUNE_GRID_MAJOR_COPY) != 0;   // (0, tests: take the gather path although the copy would fit)
         if (want_gm && (!h->gm_tables || h->gm_pitch != pitch)) {
             if (h->gm_tables) (void)hipFree(h->gm_tables);
             h->gm_tables = nullptr; h->gm_pitch = 0;
@@ -1219,14 +1385,6 @@ int mgx_fork(mgx_handle *h, mgx_stream stream)
     if (h->n_shards <= 1) return MGX_OK;
     hipError_t e = hipEventRecord(h->fork_event, (hipStream_t)stream);
     for (int j = 0; j < h->n_shards && e == hipSuccess; j++) e = hipStreamWaitEvent(h->shard_stream[j], h->fork_event, 0);
-    // Stagger: shard j starts j / S of `stagger_us` late, so that the launch boundaries of the shards -- which otherwise
-    // all start together after a fork and, their kernels being equally long, STAY together -- interleave: one range's
-    // ramp-up / tail then always falls into the others' steady state (mgx_set_shard_stagger; 0 = off).
-    if (h->stagger_us > 0)
-        for (int j = 1; j < h->n_shards && e == hipSuccess; j++) {
-            stagger_kernel<<<1, 64, 0, h->shard_stream[j]>>>((int64_t)(h->stagger_us * 100.0 * j / h->n_shards));
-            e = hipGetLastError();
-        }
     return e == hipSuccess ? MGX_OK : hip_fail(e, "mgx_fork");
 }
 
@@ -1299,11 +1457,11 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
                      hipStream_t st)
 {
     if (h->multi) {
-        for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+        for_each_shard_threaded(h, st, [&](const KArgs &k, hipStream_t s) {
             MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
                                           k, actions, t_arg(h), normalized, reward, done, obs, log, h->multi_small)));
         });
-        hipError_t em = hipGetLastError();
+        hipError_t em = launch_error();
         if (em != hipSuccess) return hip_fail(em, "step_multi_kernel launch");
         advance(h, 1, st);
         return MGX_OK;
@@ -1320,12 +1478,12 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
         advance(h, 1, st);
         return MGX_OK;
     }
-    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+    for_each_shard_threaded(h, st, [&](const KArgs &k, hipStream_t s) {
         MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, actions, t_arg(h), normalized, reward,
                                                                                        done, obs_inline, log)));
     });
     if (obs && !obs_inline) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_error();
     if (e != hipSuccess) return hip_fail(e, "step_kernel launch");
     advance(h, 1, st);
     return MGX_OK;
@@ -1380,6 +1538,23 @@ int mgx_step_many(mgx_handle *h, const void *actions, int32_t K, int normalized,
     const int64_t N = h->k.N;
     const size_t act_row = (size_t)N * h->action_dim * (h->k.act_f32 ? sizeof(float) : sizeof(double));
     const size_t obs_row = (size_t)N * h->k.obs_dim * (h->k.obs_f32 ? sizeof(float) : sizeof(double));
+    void *obs_inline = (obs && (h->k.H == 0 || h->k.obs_state_only)) ? obs : nullptr;
+    if (h->n_shards > 1 && h->launch_threads && !h->multi && !h->inplace && (!obs || obs_inline)) {
+        // every shard's K dependent launches are issued back to back by a thread of their own: no hand-over between the steps
+        const int32_t t0 = t_arg(h);
+        for_each_shard_threaded(h, (hipStream_t)stream, [&](const KArgs &kk, hipStream_t s) {
+            for (int32_t k = 0; k < K; k++) {
+                MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(kk.g1 - kk.g0), BLOCK, 0, s>>>(
+                                              kk, actions ? (const char *)actions + k * act_row : nullptr, t0 + k, normalized, reward + k * N,
+                                              done ? done + k * N : nullptr, obs_inline ? (char *)obs_inline + k * obs_row : nullptr,
+                                              log ? log + (int64_t)k * h->k.log_dim * N : nullptr)));
+            }
+        });
+        hipError_t e = launch_error();
+        if (e != hipSuccess) return hip_fail(e, "step_kernel launch");
+        advance(h, K, (hipStream_t)stream);
+        return MGX_OK;
+    }
     for (int32_t k = 0; k < K; k++) {
         if (int rc = step_once(h, actions ? (const char *)actions + k * act_row : nullptr, normalized, reward + k * N,
                                done ? done + k * N : nullptr, obs ? (char *)obs + k * obs_row : nullptr,
@@ -1402,7 +1577,7 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     if (h->multi) {                                       // general path: the K-step loop around the general step
         if (h->k.done_bits && done) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: the general kernels write `done` as bytes");
-        static const bool own_kernel = [] { const char *e = getenv("MGX_MULTI_SMALL_OWN"); return !(e && atoi(e) == 0); }();   // (A/B)
+        const bool own_kernel = tune(MGX_TUNE_MULTI_SMALL_OWN) != 0;
         for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
             if (h->multi_small && own_kernel) {           // at most MS modules of a kind: the register loop in a kernel of its own
                 MGX_DISPATCH_F(h->flags, (step_k_multi_small_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, 0, s>>>(
@@ -1559,12 +1734,12 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
         advance(h, 1, st);
         return MGX_OK;
     }
-    for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+    for_each_shard_threaded(h, st, [&](const KArgs &k, hipStream_t s) {
         MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control,
                                                                                                 reward, done, obs_inline, log)));
     });
     if (obs && !obs_inline) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_error();
     if (e != hipSuccess) return hip_fail(e, "step_discrete_kernel launch");
     advance(h, 1, st);
     return MGX_OK;
@@ -1693,13 +1868,12 @@ int mgx_rollout_discrete(mgx_handle *h, const uint8_t *action_id, int per_step, 
     if (int rc = encode_table(h, table, n_actions, &tab, "mgx_rollout_discrete")) return rc;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
     hipStream_t st = (hipStream_t)stream;
-    static const int gpb_env = [] { const char *e = getenv("MGX_GPB_ROLLOUT"); return e ? atoi(e) : 0; }();   // experiment knob
     const bool fact = factorised(h->k.c);
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
         FusedLaunch L;
         L.flags = h->flags; L.act_f32 = false; L.rich = log != nullptr || status_trace != nullptr; L.fact = fact;
         L.per_step = per_step != 0;
-        L.gpb = gpb_env > 0 ? gpb_env : fused_grids_per_block(h, k.g1 - k.g0);
+        L.gpb = fused_grids_per_block(h, k.g1 - k.g0);
         L.blocks = (unsigned)((k.g1 - k.g0 + L.gpb - 1) / L.gpb);
         L.stream = s; L.k = &k; L.actions = nullptr; L.tab = &tab; L.ids = action_id;
         L.t = t_arg(h); L.K = K; L.normalized = 0; L.out = fo;
@@ -1788,8 +1962,8 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
             memcpy(&h->table_uploaded, &tab, sizeof(PLWords));
             h->table_uploaded_valid = true;
         }
-        // MGX_FLEET_BYVALUE=0 keeps the pointer form of the kernel for every launch (A/B)
-        static const bool by_value = [] { const char *e = getenv("MGX_FLEET_BYVALUE"); return !(e && atoi(e) == 0); }();
+        // MGX_TUNE_FLEET_BYVALUE = 0 keeps the pointer form of the kernel for every launch (A/B)
+        const bool by_value = tune(MGX_TUNE_FLEET_BYVALUE) != 0;
         for (int32_t j0 = 0; j0 < n; j0 += MGX_FLEET_MAX) {
             const int32_t nb = n - j0 < MGX_FLEET_MAX ? n - j0 : MGX_FLEET_MAX;
             bool chunks = !by_value;                       // window chunks riding along with this launch (refill="chunks")?

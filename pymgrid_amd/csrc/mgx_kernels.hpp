@@ -55,9 +55,6 @@ __device__ __forceinline__ void observe_row_h0_tiled(const KArgs &a, int64_t i, 
     const int32_t D = a.obs_dim;
     observe_row_h0<F>(a, i, t_next, p, s, tile + lane * D, pm);
     __builtin_amdgcn_wave_barrier();                     // (one wave: its LDS traffic is ordered; this keeps the compiler from moving the reads up)
-#ifdef MGX_ROWS_DIAG
-    if (D > 0) return;                                   // (diagnostic build: the rows are formed and never leave the chip)
-#endif
     typedef OT vec2 __attribute__((ext_vector_type(2)));
     typedef OT vec4 __attribute__((ext_vector_type(4)));
     OT *out = obs + (i - lane) * D;                      // the wave's 64 rows are consecutive in memory
@@ -854,9 +851,6 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     IT *blk = image + g * BP;
     uint32_t *map = reinterpret_cast<uint32_t *>(image + G * BP);       // [D]
 
-#ifdef MGX_WIN_NO_LOAD
-    if (K < 0)                                           // (diagnostic build: phase 2 -- image -> ring stores -- alone, on whatever the LDS holds)
-#endif
     if (factorised(a.c)) {                               // uniform over the launch: rows formed from the base tables
         GridFactors f;
         load_factors<GRID ? F_GRID : 0>(a.c, ic, f);
@@ -907,9 +901,6 @@ __device__ __forceinline__ void windows_body(const KArgs &a, const WindowsKPlan 
     __syncthreads();
     if (tid >= OBS_K_THREADS) return;                    // phase 2: the first OBS_K_THREADS threads (no barrier follows)
     const int32_t Q2 = OBS_K_THREADS / G;                // ... thread (g, q) of Q2 per grid (q = tid / G < Q2 here)
-#ifdef MGX_WIN_NO_STORE
-    if (K > 0) return;                                   // (diagnostic build: phase 1 -- the loads and the image -- alone)
-#endif
     const int32_t n_valid = (N - g0 < G) ? (int32_t)(N - g0) : G;
     const int32_t total = n_valid * D;                   // D is even (one load, one renewable module)
     typedef OT vec2 __attribute__((ext_vector_type(2)));
@@ -2089,13 +2080,6 @@ __global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a
     id = (id >= 0 && id < n_lists) ? id : 0;              // ids outside [0, n) fall back to list 0 (the reference raises)
     const uint32_t xv = populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t, control + i * A);
     if (violations) violations[i] = xv;
-}
-
-// one wave that idles for `ticks` of the 100 MHz real-time counter: mgx_fork staggers the shard streams with it
-static __global__ void stagger_kernel(int64_t ticks)
-{
-    const int64_t t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
 // device-resident step counter (hipGraph-replayable stepping): counter[0] = t, counter[1] = overrun flag

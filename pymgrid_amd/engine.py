@@ -478,6 +478,11 @@ class StepEngine:
         check(self._lib.mgx_set_shards(self._h, int(n_shards)))
         self.n_shards = int(n_shards)
 
+    def set_launch_threads(self, enable=True):
+        """Single-step calls in shards: shard j >= 1 is issued by a resident host thread of the library while the caller issues
+        shard 0 (``mgx_set_launch_threads``; default on).  Off: every shard launch comes from the calling thread."""
+        check(self._lib.mgx_set_launch_threads(self._h, 1 if enable else 0))
+
     def fork(self):
         """The shard streams wait for everything queued on torch's current stream (inputs produced there)."""
         self._call(self._lib.mgx_fork)

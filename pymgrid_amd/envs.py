@@ -261,7 +261,9 @@ class BatchedMicrogridEnv:
         e = self.engine
         return bool(self._fast_ok and self._reuse and not self.raise_errors and not self._keep_log and self._obs_index is None
                     and not self._views and not self._chunked and not self._fleet_owned and not self._sync_rings
-                    and e._t is not None and not e._dev_counter and e.n_shards == 1 and not getattr(self, "check_asserts", False)
+                    and e._t is not None and not e._dev_counter and not getattr(self, "check_asserts", False)
+                    # shards (engine.set_shards; the caller brackets its loop with engine.fork() / join()): rows a step writes itself only
+                    and (e.n_shards == 1 or self._ring is None)
                     and not (isinstance(self, DiscreteBatchedMicrogridEnv) and self.layout.multi)
                     and not (self._ring is not None and (self._ring_phase or e._window_start is not None)))
 
@@ -561,6 +563,24 @@ class BatchedMicrogridEnv:
             return torch.full((self.n_grids,), t, dtype=torch.int32, device=self.batch.device)
         t0 = getattr(self.engine, "_window_t0", None)       # rolling windows: the counter value each episode started at
         return st + t if t0 is None else st + (t - t0)
+
+    def set_shards(self, n_shards):
+        """Step the batch as ``n_shards`` independent grid ranges, each a launch chain on an internal stream of its own
+        (``mgx_set_shards``; with launch threads, include/mgx.h, every chain has a host thread issuing it): grids never interact,
+        so one range's step k + 1 does not wait for another range's step k.  While n_shards > 1 the steps ignore torch's current
+        stream: ``fork()`` before the first step that reads actions produced on it, ``join()`` before reading outputs on it.
+        Observation rows a step writes itself only (no forecast rings)."""
+        if n_shards > 1 and self._ring is not None:
+            raise ValueError("set_shards: observation rings are refilled on the caller's stream; use obs_prefetch=0 or observations=False")
+        self._unbind_fast()
+        self.engine.set_shards(n_shards)
+        self._rebind_fast()
+
+    def fork(self):
+        self.engine.fork()
+
+    def join(self):
+        self.engine.join()
 
     def set_obs_prefetch(self, K):
         """Switch the window prefetch on (K > 1 blocks per ring) or off (0) after construction; the next observation comes

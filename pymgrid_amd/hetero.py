@@ -78,7 +78,7 @@ class BucketedFleet:
         if refill not in ("chunks", "ahead"):
             raise ValueError("refill must be 'chunks' or 'ahead'")
         self.refill = refill
-        self.stagger = bool(int(os.environ.get("MGX_FLEET_STAGGER", "0"))) if stagger is None else bool(stagger)
+        self.stagger = bool(stagger)
         # reuse_outputs = R > 0: step() returns reward / done as views into R rotating buffers per bucket (valid for R - 1
         # further steps) instead of fresh tensors -- no allocation on the hot path
         self.reuse_outputs = int(reuse_outputs)

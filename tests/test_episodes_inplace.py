@@ -152,12 +152,20 @@ def test_native_auto_reset_equals_the_rolling_window_auto_reset(arch, H, discret
     roll.close(); nat.close()
 
 
+@pytest.fixture
+def no_grid_major_copy():
+    """mgx_set_tunable(MGX_TUNE_GRID_MAJOR_COPY, 0) for the test's duration (the tunables are process-wide)."""
+    from pymgrid_amd import _lib
+    _lib.set_tunable("grid_major_copy", 0)
+    yield
+    _lib.set_tunable("grid_major_copy", 1)
+
+
 @pytest.mark.parametrize("arch,H,prefetch", [("genset+battery+grid", 0, 0), ("battery+grid", 5, 0), ("genset+battery+grid", 24, 4)])
-def test_inplace_episodes_without_the_grid_major_copy(arch, H, prefetch, device, monkeypatch):
-    """[T, N] series when the handle cannot have its grid-major copy (allocation refused; here: MGX_NO_GRID_MAJOR=1): the lanes gather
+def test_inplace_episodes_without_the_grid_major_copy(arch, H, prefetch, device, no_grid_major_copy):
+    """[T, N] series when the handle cannot have its grid-major copy (allocation refused; here: the grid_major_copy tunable is 0): the lanes gather
     their rows out of the [T, N] arrays -- the same values as the window buffers, step by step through restarts."""
     from pymgrid_amd import BatchedMicrogridEnv
-    monkeypatch.setenv("MGX_NO_GRID_MAJOR", "1")
     N, T, max_len = 900, 200, 11
     ring = BatchedMicrogridEnv(_gen(N, T, arch, device, H, series="materialised"), obs_prefetch=0)
     inpl = BatchedMicrogridEnv(_gen(N, T, arch, device, H, series="materialised"), obs_prefetch=prefetch)

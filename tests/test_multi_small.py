@@ -1,6 +1,6 @@
 """The register form of the general step (step_multi_small: at most two modules of every kind per grid -- parameters, state, controls
 and series rows requested up front, the sweep on registers, a K-step loop that keeps parameters and state there) against the run-time
-count form it specialises (step_multi_core, MGX_MULTI_GENERIC=1): the same batches, controls and calls in two processes, every
+count form it specialises (step_multi_core, mgx_set_tunable(MGX_TUNE_MULTI_GENERIC, 1)): the same batches, controls and calls in two processes, every
 reward, log column, observation row and final state `==`.  (Both forms are pinned against the reference-made fixtures of
 tests/golden/multi.npz and the oracle by tests/test_multiplicity.py / test_multi_module.py, which run whichever form the layout
 gets; this test makes sure those pins hold for BOTH.)  Reference: module_container.py:355-413, microgrid.py:255-314."""
@@ -17,8 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRIPT = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
-from pymgrid_amd import BatchedMicrogridEnv, StepEngine
+from pymgrid_amd import BatchedMicrogridEnv, StepEngine, _lib
 from pymgrid_amd.generator import generate, widen
+_lib.set_tunable("multi_generic", int(sys.argv[3]))
+assert _lib.get_tunable("multi_generic") == (int(sys.argv[3]), 0)
 dev = torch.device("cuda:0")
 out = {}
 g = torch.Generator(device=dev); g.manual_seed(11)
@@ -62,11 +64,7 @@ np.savez(sys.argv[2], **out)
 
 def _run(tmp_path, generic):
     path = str(tmp_path / ("generic.npz" if generic else "small.npz"))
-    env = dict(os.environ)
-    env.pop("MGX_MULTI_GENERIC", None)
-    if generic:
-        env["MGX_MULTI_GENERIC"] = "1"
-    r = subprocess.run([sys.executable, "-c", SCRIPT, ROOT, path], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, "-c", SCRIPT, ROOT, path, "1" if generic else "0"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     return np.load(path)
 
