@@ -50,7 +50,8 @@ extern "C" {
 #endif
 
 #define MGX_ABI_VERSION 9    /* frozen: struct layouts and the meaning of every v9 entry point do not change any more */
-#define MGX_ABI_MINOR 1      /* additions only: 1 = mgx_abi_minor, mgx_set_tunable / mgx_get_tunable, mgx_set_launch_threads */
+#define MGX_ABI_MINOR 1      /* additions only: 1 = mgx_abi_minor, mgx_set_tunable / mgx_get_tunable, mgx_set_launch_threads,
+                              * mgx_action_bounds */
 
 enum mgx_status {
     MGX_OK = 0,
@@ -223,7 +224,7 @@ enum mgx_tunable {
     MGX_TUNE_MULTI_SMALL_OWN = 6,  /* 0: mgx_step_k of small general layouts through the shared kernel (default 1: its own) */
     MGX_TUNE_GRID_MAJOR_COPY = 7,  /* 0: mgx_reset_episodes on [T, N] series gathers rows instead of making its grid-major copy */
     MGX_TUNE_FLEET_BYVALUE = 8,    /* 0: mgx_fleet_step launches the pointer form of the fleet kernel (default 1: by value) */
-    MGX_TUNE_LAUNCH_THREADS = 9,   /* default of mgx_set_launch_threads for handles created afterwards (1) */
+    MGX_TUNE_LAUNCH_THREADS = 9,   /* mode (0 / 1 / 2) handles created afterwards start with: mgx_set_launch_threads (default 1) */
     MGX_TUNE_COUNT_ = 10
 };
 int mgx_set_tunable(int32_t id, int64_t value);                                /* MGX_ERR_INVALID: unknown id / value out of range */
@@ -555,6 +556,14 @@ int mgx_env_position(const mgx_handle *h, int32_t *last_slot, int32_t *ring_idx,
 int mgx_env_step(mgx_handle *h, const void *actions, int normalized, mgx_stream stream);
 int mgx_env_step_discrete(mgx_handle *h, const int32_t *action_id, mgx_stream stream);
 
+/* BaseMicrogridModule.sample_action(strict_bound=True) (modules/base/base_module.py:326-356, Microgrid.sample_action
+ * microgrid.py:337-362): lo / hi [N, A] (device) receive, per action column, the NORMALISED interval a draw must come from to
+ * respect the module's instantaneous limits at the current state and row: battery and grid columns
+ * [normalize(-max_consumption), normalize(max_production)] (a NaN bound is 0, as there); genset columns [0, 1] (the reference
+ * itself raises on a genset with strict_bound: the Python mirror refuses such layouts).  A strict sample is
+ * lo + u * (hi - lo), u ~ U[0, 1).  Nothing is stepped. */
+int mgx_action_bounds(mgx_handle *h, double *lo, double *hi, mgx_stream stream);
+
 /* Shards.  Grids never interact (no cross-grid term anywhere in Microgrid.run), so the launch sequence of one range of
  * grids owes nothing to another's.  mgx_set_shards(h, S > 1) splits every stepping call (mgx_step, mgx_step_many,
  * mgx_step_k, mgx_step_discrete, mgx_expand_discrete, mgx_rollout_discrete) into S launches over contiguous grid ranges,
@@ -574,13 +583,18 @@ int mgx_env_step_discrete(mgx_handle *h, const int32_t *action_id, mgx_stream st
  * (one thread per handle). */
 int mgx_set_shards(mgx_handle *h, int32_t n_shards);
 /* Single-step calls in shards (mgx_step, mgx_step_many, mgx_step_discrete, mgx_env_step*): one host thread issues a launch every
- * ~4 us, so S launches per env-step from the calling thread made the Gym cadence S times slower than no shards at all.  With
- * launch threads on (default) shard j >= 1 is issued by a resident host thread of the library (one per device and shard, shared
- * by all handles, asleep when idle) while the caller issues shard 0: the shards' dependent launch chains advance side by side.
- * The call still returns only when every shard's launches have been issued, and values do not depend on the setting.
- * mgx_step_many hands each thread its shard's K launches in one piece.  Fused calls (mgx_step_k, rollouts) are always issued
- * by the caller. */
-int mgx_set_launch_threads(mgx_handle *h, int32_t enable);
+ * 3.4-4.3 us, so S launches per env-step from the calling thread make the Gym cadence S times slower than no shards at all.
+ * Launch threads: shard j >= 1 is issued by a resident host thread of the library (one per device and shard, shared by all
+ * handles, asleep when idle) while the caller issues shard 0.  mode 0: never; 1 (default): inside mgx_step_many, where every
+ * thread gets its shard's K launches in one piece; 2: also for every single-step call (one hand-over per call).  A call still
+ * returns only when every shard's launches have been issued, and values do not depend on the mode.  Fused calls (mgx_step_k,
+ * rollouts) are always issued by the caller.
+ * MEASURED (profiles/r06/exp_two_chains.txt, chain_trace_summary.txt; N = 100 000): two chains from two threads run 6.1 us per
+ * env-step against 4.8 us for ONE chain from one thread (7.9 us for two chains from one thread): inside one process two threads
+ * issue at 6 us per launch each, and a 50 000-grid launch lasts as long as a 100 000-grid one (4.2-4.8 us: the step is a latency
+ * chain, not a transfer), so the second chain cannot pay whatever the host does.  Kept because it halves the cost of shards for
+ * single steps; not a way below the one-chain cadence. */
+int mgx_set_launch_threads(mgx_handle *h, int32_t mode);
 int mgx_fork(mgx_handle *h, mgx_stream stream);
 int mgx_join(mgx_handle *h, mgx_stream stream);
 void *mgx_shard_stream(mgx_handle *h, int32_t shard);

@@ -140,6 +140,7 @@ SYMBOLS = {
     "mgx_set_tunable": (C.c_int, [C.c_int32, C.c_int64]),
     "mgx_get_tunable": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mgx_set_launch_threads": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mgx_action_bounds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_last_error": (C.c_char_p, []),
     "mgx_create": (C.c_int, [C.POINTER(Layout), C.POINTER(Columns), C.POINTER(C.c_void_p)]),
     "mgx_destroy": (None, [C.c_void_p]),

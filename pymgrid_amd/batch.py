@@ -211,6 +211,9 @@ class MicrogridBatch:
         self.cols = cols
         # GaussianNoiseForecaster switches: dict(seed=int, increase_uncertainty=bool) or None (oracle forecaster)
         self.forecast_noise = forecast_noise
+        # time-series modules with forecast horizons of their own (``horizons`` of the parameter dicts): the columns of the
+        # H = max row the microgrids really have, or None (all share ``layout.horizon``); the envs return these columns only
+        self.obs_keep = None
         self._validate()
 
     # ------------------------------------------------------------------------------------------------
@@ -332,7 +335,12 @@ class MicrogridBatch:
         """Pack a list of per-microgrid parameter dicts (the vocabulary of ``scenario.load_fixture`` /
         ``tests/golden/make_goldens.py:extract_params``) that share a layout."""
         arrays, layout = pack_grids(grids, flat_order=flat_order)
-        return cls.from_numpy(layout, arrays, device)
+        b = cls.from_numpy(layout, arrays, device)
+        hz = grids[0].get("horizons")
+        if any(g.get("horizons") != hz for g in grids):
+            raise ValueError("all microgrids of a batch must share the per-module forecast horizons (bucket them by layout)")
+        b.obs_keep = obs_keep_columns(layout, hz)
+        return b
 
     # ------------------------------------------------------------------------------------------------
     def state(self):
@@ -387,6 +395,31 @@ class MicrogridBatch:
             mask |= 1 << _lib.UNIFORM_BITS.index(name)
         c.uniform_mask = mask
         return c
+
+
+def obs_keep_columns(layout, horizons):
+    """Columns of the flat observation row (built for H = ``layout.horizon``, the LONGEST forecast horizon) that a microgrid
+    whose time-series modules have horizons of their own really has: ``horizons`` = {"load": [h per module], "pv": [...],
+    "grid": [...]} (forecast_horizon is a per-module argument, base_timeseries_module.py:30-45; a module without a forecaster
+    observes its current value only).  A window block is [current x C, forecast_0 x C, ...] (C = 1, or the 4 grid components):
+    module j keeps its first C * (1 + h_j) columns -- the normalisation of a column does not depend on the horizon.  None when
+    every module has the layout's horizon."""
+    if not horizons:
+        return None
+    H, keep, k = layout.horizon, [], 0
+    for name, n, width in layout._blocks():
+        hs = horizons.get(name)
+        for j in range(n):
+            if name in ("load", "pv", "grid"):
+                C = 4 if name == "grid" else 1
+                h = int(hs[j]) if hs is not None else H
+                if not 0 <= h <= H:
+                    raise ValueError(f"horizons[{name!r}][{j}] = {h} outside [0, {H}]")
+                keep += list(range(k, k + C * (1 + h)))
+            else:
+                keep += list(range(k, k + width))
+            k += width
+    return None if len(keep) == layout.obs_dim else keep
 
 
 def series_bounds(ts):

@@ -46,7 +46,7 @@ struct mgx_handle {
     hipStream_t shard_stream[MGX_MAX_SHARDS];
     hipEvent_t shard_event[MGX_MAX_SHARDS];
     hipEvent_t fork_event;
-    bool launch_threads;                     // single-step launches of shards 1.. are issued by the device's launch workers
+    int32_t launch_threads;                  // shards 1.. issued by the device's launch workers: 0 never, 1 inside mgx_step_many, 2 every single step
     hipStream_t counter_stream;              // device-counter mode: the stream of the last call that touched the counter
     KArgs *d_kargs;                          // device copy of `k` for fleet_step_kernel, refreshed when `k` changed
     KArgs k_uploaded;
@@ -113,7 +113,7 @@ const int64_t kTuneDefault[MGX_TUNE_COUNT_] = {
     /* MGX_TUNE_MULTI_SMALL_OWN */ 1,
     /* MGX_TUNE_GRID_MAJOR_COPY */ 1,
     /* MGX_TUNE_FLEET_BYVALUE   */ 1,
-    /* MGX_TUNE_LAUNCH_THREADS  */ 1,
+    /* MGX_TUNE_LAUNCH_THREADS  */ 1,      // 0 / 1 / 2: see mgx_set_launch_threads
 };
 struct TuneInit { TuneInit() { for (int j = 0; j < MGX_TUNE_COUNT_; j++) g_tune[j].store(kTuneDefault[j], std::memory_order_relaxed); } } g_tune_init;
 inline int64_t tune(int id) { return g_tune[id].load(std::memory_order_relaxed); }
@@ -272,9 +272,9 @@ inline void for_each_shard(const mgx_handle *h, hipStream_t user, Fn fn)
 // The same for the single-step calls: with shards on, shard j >= 1 is issued by launch worker j of the device (see LaunchWorker)
 // while the calling thread issues shard 0; returns when all of them are issued.  fn must be safe to run on several threads at once.
 template <class Fn>
-inline void for_each_shard_threaded(const mgx_handle *h, hipStream_t user, Fn fn)
+inline void for_each_shard_threaded(const mgx_handle *h, hipStream_t user, Fn fn, int32_t min_mode = 2)
 {
-    if (h->n_shards <= 1 || !h->launch_threads) { for_each_shard(h, user, fn); return; }
+    if (h->n_shards <= 1 || h->launch_threads < min_mode) { for_each_shard(h, user, fn); return; }
     struct Job { const mgx_handle *h; Fn *fn; };
     Job job{h, &fn};
     auto thunk = [](void *ctx, int j) {
@@ -441,6 +441,7 @@ int mgx_set_tunable(int32_t id, int64_t value)
         case MGX_TUNE_WIN_GROUP: ok = value >= 0 && value <= 64; break;
         case MGX_TUNE_WIN_PAIRS: ok = value >= -1 && value <= 1; break;
         case MGX_TUNE_WIN_MIN_LDS: ok = value >= -1 && value <= 160 * 1024; break;
+        case MGX_TUNE_LAUNCH_THREADS: ok = value >= 0 && value <= 2; break;
         default: ok = value == 0 || value == 1; break;
     }
     if (!ok) return fail(MGX_ERR_INVALID, "mgx_set_tunable: value %lld is not valid for tunable %d", (long long)value, id);
@@ -461,7 +462,8 @@ int mgx_set_launch_threads(mgx_handle *h, int32_t enable)
 {
     g_err[0] = 0;
     if (!h) return fail(MGX_ERR_INVALID, "mgx_set_launch_threads: NULL handle");
-    h->launch_threads = enable != 0;
+    if (enable < 0 || enable > 2) return fail(MGX_ERR_INVALID, "mgx_set_launch_threads: mode must be 0, 1 or 2");
+    h->launch_threads = enable;
     return MGX_OK;
 }
 
@@ -580,7 +582,7 @@ int mgx_create(const mgx_layout *L, const mgx_columns *C, mgx_handle **out)
     h->n_shards = 1; h->shard_lo[0] = 0; h->shard_lo[1] = L->n_grids;
     for (int j = 0; j < MGX_MAX_SHARDS; j++) { h->shard_stream[j] = nullptr; h->shard_event[j] = nullptr; }
     h->fork_event = nullptr; h->counter_stream = nullptr;
-    h->launch_threads = tune(MGX_TUNE_LAUNCH_THREADS) != 0;
+    h->launch_threads = (int32_t)tune(MGX_TUNE_LAUNCH_THREADS);
     h->d_kargs = nullptr; h->k_uploaded_valid = false;
     h->d_table = nullptr; h->table_uploaded_valid = false;
     h->env_bound = false; h->env_n_slots = 0; h->env_next = 0; h->env_ring_K = 0; h->env_ring_idx = 0; h->env_ring_pos = 0; h->env_n_actions = 0;
@@ -1451,6 +1453,13 @@ static int episode_step_end(mgx_handle *h, const EpisodeStep &ep, const uint8_t 
     return launch_observe(h, h->t + 1, obs, st);
 }
 
+// LDS of a step_kernel / step_discrete_kernel launch: the wave-private row tiles (store_step_obs) -- only launches that write whole
+// H = 0 rows ask for them; state-only rows, no rows and the final-observation rows of in-place episodes leave occupancy alone
+static inline size_t row_tile_lds(const KArgs &k, const void *obs_inline)
+{
+    return step_rows_tiled(k, obs_inline) ? sizeof(double) * (BLOCK / 64) * 64 * ROW_TILE_MAX_D : 0;
+}
+
 // ---- single steps ----------------------------------------------------------------------------------------------
 // one Microgrid.run of every grid: the launches of mgx_step without its argument checks
 static int step_once(mgx_handle *h, const void *actions, int normalized, double *reward, uint8_t *done, void *obs, double *log,
@@ -1470,7 +1479,7 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
     if (h->inplace) {                                     // in-place episodes: the EP form of the kernel (no shards in this mode)
         EpisodeStep ep;
         if (int rc = episode_step_begin(h, done, obs, obs_inline, &ep, "mgx_step")) return rc;
-        MGX_DISPATCH_F(h->flags, (step_kernel<F, true><<<blocks_for(ep.k.N), BLOCK, 0, st>>>(ep.k, actions, h->t, normalized, reward, done,
+        MGX_DISPATCH_F(h->flags, (step_kernel<F, true><<<blocks_for(ep.k.N), BLOCK, row_tile_lds(ep.k, obs_inline), st>>>(ep.k, actions, h->t, normalized, reward, done,
                                                                                        obs_inline, log)));
         if (int rc = episode_step_end(h, ep, done, obs, obs_inline, st)) return rc;
         hipError_t ee = hipGetLastError();
@@ -1479,7 +1488,7 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
         return MGX_OK;
     }
     for_each_shard_threaded(h, st, [&](const KArgs &k, hipStream_t s) {
-        MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, actions, t_arg(h), normalized, reward,
+        MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, row_tile_lds(k, obs_inline), s>>>(k, actions, t_arg(h), normalized, reward,
                                                                                        done, obs_inline, log)));
     });
     if (obs && !obs_inline) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
@@ -1530,6 +1539,18 @@ int mgx_check_step(mgx_handle *h, const void *actions, int normalized, uint32_t 
     return e == hipSuccess ? MGX_OK : hip_fail(e, "check_kernel launch");
 }
 
+int mgx_action_bounds(mgx_handle *h, double *lo, double *hi, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !lo || !hi) return fail(MGX_ERR_INVALID, "mgx_action_bounds: NULL argument");
+    if (!dev_counter(h) && (h->t < 0 || h->t >= step_limit(h)))
+        return fail(MGX_ERR_RANGE, "mgx_action_bounds: step %d is outside the time series (length %d)", h->t, step_limit(h));
+    KArgs k = h->k; k.g0 = 0; k.g1 = k.N;
+    MGX_DISPATCH_F(h->flags, (action_bounds_kernel<F><<<multi_blocks(k.N), BLOCK_MULTI, 0, (hipStream_t)stream>>>(k, t_arg(h), lo, hi)));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MGX_OK : hip_fail(e, "action_bounds_kernel launch");
+}
+
 int mgx_step_many(mgx_handle *h, const void *actions, int32_t K, int normalized, double *reward, uint8_t *done, void *obs,
                   double *log, mgx_stream stream)
 {
@@ -1544,12 +1565,12 @@ int mgx_step_many(mgx_handle *h, const void *actions, int32_t K, int normalized,
         const int32_t t0 = t_arg(h);
         for_each_shard_threaded(h, (hipStream_t)stream, [&](const KArgs &kk, hipStream_t s) {
             for (int32_t k = 0; k < K; k++) {
-                MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(kk.g1 - kk.g0), BLOCK, 0, s>>>(
+                MGX_DISPATCH_F(h->flags, (step_kernel<F><<<blocks_for(kk.g1 - kk.g0), BLOCK, row_tile_lds(kk, obs_inline), s>>>(
                                               kk, actions ? (const char *)actions + k * act_row : nullptr, t0 + k, normalized, reward + k * N,
                                               done ? done + k * N : nullptr, obs_inline ? (char *)obs_inline + k * obs_row : nullptr,
                                               log ? log + (int64_t)k * h->k.log_dim * N : nullptr)));
             }
-        });
+        }, 1);
         hipError_t e = launch_error();
         if (e != hipSuccess) return hip_fail(e, "step_kernel launch");
         advance(h, K, (hipStream_t)stream);
@@ -1726,7 +1747,7 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
     if (h->inplace) {
         EpisodeStep ep;
         if (int rc = episode_step_begin(h, done, obs, obs_inline, &ep, "mgx_step_discrete")) return rc;
-        MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F, true><<<blocks_for(ep.k.N), BLOCK, 0, st>>>(ep.k, tab, action_id, h->t, control, reward,
+        MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F, true><<<blocks_for(ep.k.N), BLOCK, row_tile_lds(ep.k, obs_inline), st>>>(ep.k, tab, action_id, h->t, control, reward,
                                                                                                 done, obs_inline, log)));
         if (int rc = episode_step_end(h, ep, done, obs, obs_inline, st)) return rc;
         hipError_t ee = hipGetLastError();
@@ -1735,7 +1756,7 @@ int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *ta
         return MGX_OK;
     }
     for_each_shard_threaded(h, st, [&](const KArgs &k, hipStream_t s) {
-        MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, 0, s>>>(k, tab, action_id, t_arg(h), control,
+        MGX_DISPATCH_F(h->flags, (step_discrete_kernel<F><<<blocks_for(k.g1 - k.g0), BLOCK, row_tile_lds(k, obs_inline), s>>>(k, tab, action_id, t_arg(h), control,
                                                                                                 reward, done, obs_inline, log)));
     });
     if (obs && !obs_inline) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs, st)) return rc; }
@@ -1755,8 +1776,11 @@ int mgx_env_bind(mgx_handle *h, const mgx_env_plan *plan)
         return fail(MGX_ERR_INVALID, "mgx_env_bind: struct_size %d vs %zu (ABI %d)", plan->struct_size, sizeof(mgx_env_plan), MGX_ABI_VERSION);
     if (plan->n_slots < 1 || plan->n_slots > MGX_ENV_MAX_SLOTS || !plan->slots)
         return fail(MGX_ERR_INVALID, "mgx_env_bind: n_slots must be in [1, %d] with a slot array", MGX_ENV_MAX_SLOTS);
-    for (int32_t j = 0; j < plan->n_slots; j++)
+    for (int32_t j = 0; j < plan->n_slots; j++) {
         if (!plan->slots[j].reward) return fail(MGX_ERR_INVALID, "mgx_env_bind: slot %d has no reward buffer", j);
+        if ((h->windowed || h->inplace) && !plan->slots[j].done)      // per-grid episodes end per grid: the flags must go somewhere
+            return fail(MGX_ERR_INVALID, "mgx_env_bind: slot %d has no done buffer (the handle steps per-grid episodes)", j);
+    }
     if (plan->ring_K < 0) return fail(MGX_ERR_INVALID, "mgx_env_bind: ring_K must be >= 0");
     if (plan->ring_K > 0) {
         if (h->k.obs_state_only != 1)
@@ -1847,6 +1871,8 @@ int mgx_env_step_discrete(mgx_handle *h, const int32_t *action_id, mgx_stream st
     if (h->env_n_actions <= 0) return fail(MGX_ERR_INVALID, "mgx_env_step_discrete: the bound plan holds no priority-list table");
     const mgx_env_slot &sl = h->env_slots[h->env_next];
     const EnvTarget tg = env_target(h, sl);
+    if (!action_id) return fail(MGX_ERR_INVALID, "mgx_env_step_discrete: NULL argument");       // (nothing has moved yet, as in mgx_env_step)
+    if (int rc = check_step_args(h, action_id, sl.reward, tg.obs, 1, "mgx_env_step_discrete")) return rc;
     if (tg.enters_next_ring) { if (int rc = mgx_prefetch_wait(h, stream)) return rc; }
     if (int rc = mgx_step_discrete(h, action_id, h->env_table, h->env_n_actions, nullptr, sl.reward, sl.done, tg.obs, sl.log, stream)) return rc;
     return env_commit(h, tg.enters_next_ring, stream);
@@ -2074,6 +2100,8 @@ int mgx_fleet_env_step(mgx_handle *const *handles, const void *const *actions, i
     for (int32_t j = 0; j < n; j++) {
         mgx_handle *h = handles[j];
         if (!h || !h->env_bound) return fail(MGX_ERR_INVALID, "mgx_fleet_env_step: handle %d has no plan bound (mgx_env_bind)", j);
+        for (int32_t q = 0; q < j; q++)                     // one slot and one ring position per handle and step
+            if (handles[q] == h) return fail(MGX_ERR_INVALID, "mgx_fleet_env_step: handle %d is handle %d again", j, q);
         const mgx_env_slot &sl = h->env_slots[h->env_next];
         const EnvTarget tg = env_target(h, sl);
         mgx_fleet_item &it = items[j];

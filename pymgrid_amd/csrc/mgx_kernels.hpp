@@ -42,6 +42,12 @@ constexpr int BLOCK_K = MGX_BLOCK_K;
 #define MGX_ROWS_TILE 1
 #endif
 constexpr int ROW_TILE_MAX_D = 12;                      // H = 0 rows: 2 + 4 + 2 + 4 values at most
+// does a single-step launch write whole H = 0 rows through the wave-private LDS tiles?  (host: how much dynamic LDS to ask for;
+// kernel: whether there is a tile) -- the same predicate on both sides
+__host__ __device__ inline bool step_rows_tiled(const KArgs &a, const void *obs)
+{
+    return MGX_ROWS_TILE && obs != nullptr && a.H == 0 && !a.obs_state_only && a.obs_dim <= ROW_TILE_MAX_D;
+}
 
 // Whole H = 0 rows of a FULL wave through a wave-private LDS tile: every lane leaves its D-value row in the tile (row-major, as
 // the block is in memory), then the wave streams the tile out with 16-byte stores -- 64 lanes x 16 B = 1 KB of consecutive
@@ -60,9 +66,13 @@ __device__ __forceinline__ void observe_row_h0_tiled(const KArgs &a, int64_t i, 
     OT *out = obs + (i - lane) * D;                      // the wave's 64 rows are consecutive in memory
     const int32_t total = 64 * D;
     if constexpr (sizeof(OT) == 8) {                     // D is even: a 16-byte pair never straddles the tile's end
-        for (int32_t e = 2 * lane; e < total; e += 128) {
-            const vec2 v = *reinterpret_cast<const vec2 *>(tile + e);
-            *reinterpret_cast<vec2 *>(out + e) = v;
+        if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+            for (int32_t e = 2 * lane; e < total; e += 128) {
+                const vec2 v = *reinterpret_cast<const vec2 *>(tile + e);
+                *reinterpret_cast<vec2 *>(out + e) = v;
+            }
+        } else {                                         // a caller's buffer at an odd 8-byte offset: word stores, same bytes
+            for (int32_t e = lane; e < total; e += 64) out[e] = tile[e];
         }
     } else {
         if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
@@ -178,9 +188,12 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs a, const void *
                                                      double *__restrict__ log)
 {
     t = resolve_t(a, t);
-    __shared__ __attribute__((aligned(16))) double row_tiles[BLOCK / 64][64 * ROW_TILE_MAX_D];   // one tile per wave (store_step_obs: whole H = 0 rows)
+    // one wave-private tile per wave for whole H = 0 rows (store_step_obs): DYNAMIC LDS, asked for by the launches that write such
+    // rows only (mgx_abi.hip row_tile_lds) -- every other launch of this kernel keeps its full occupancy
+    extern __shared__ __attribute__((aligned(16))) double row_tiles[];
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < a.g1) step_body<F, EP>(a, actions, t, normalized, reward, done, obs, log, i, row_tiles[threadIdx.x >> 6]);
+    // (the pointer is formed whatever the launch asked for: store_step_obs dereferences it exactly when step_rows_tiled() holds)
+    if (i < a.g1) step_body<F, EP>(a, actions, t, normalized, reward, done, obs, log, i, row_tiles + (threadIdx.x >> 6) * (64 * ROW_TILE_MAX_D));
     advance_counter_in_kernel(a, 1);
 }
 
@@ -1243,9 +1256,10 @@ __global__ __launch_bounds__(BLOCK) void step_discrete_kernel(const KArgs a, con
                                                               double *__restrict__ log)
 {
     t = resolve_t(a, t);
-    __shared__ __attribute__((aligned(16))) double row_tiles[BLOCK / 64][64 * ROW_TILE_MAX_D];   // one tile per wave (store_step_obs)
+    extern __shared__ __attribute__((aligned(16))) double row_tiles[];      // (dynamic: see step_kernel)
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < a.g1) step_discrete_body<F, EP>(a, tab, action_id, t, control, reward, done, obs, log, i, row_tiles[threadIdx.x >> 6]);
+    if (i < a.g1) step_discrete_body<F, EP>(a, tab, action_id, t, control, reward, done, obs, log, i,
+                                            row_tiles + (threadIdx.x >> 6) * (64 * ROW_TILE_MAX_D));
     advance_counter_in_kernel(a, 1);
 }
 
@@ -1927,6 +1941,42 @@ __global__ __launch_bounds__(BLOCK_MULTI) void check_multi_kernel(const KArgs a,
             viol |= oc.violations;
         }
     violations[i] = viol;
+}
+
+// BaseMicrogridModule.sample_action(strict_bound=True) (base_module.py:326-356): the NORMALISED interval a module's action may be
+// drawn from so that it satisfies the instantaneous bounds -- [normalize(-max_consumption), normalize(max_production)] of the
+// battery (battery_module.py:283-291,332-338) and the grid (grid_module.py:125-132,314-320: limits x grid_status[t]) at the
+// CURRENT state and row; a NaN bound is 0 (:349-355).  Genset columns get [0, 1] (the reference itself fails on them, SURVEY Q4:
+// the host refuses such layouts before it gets here).  lo / hi: [N, A], the action layout.  Any multiplicity (columns [n, N]).
+template <int F>
+__global__ __launch_bounds__(BLOCK_MULTI) void action_bounds_kernel(const KArgs a, int32_t t, double *__restrict__ lo, double *__restrict__ hi)
+{
+    t = resolve_t(a, t);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
+    if (i >= a.g1) return;
+    const int64_t N = a.N;
+    const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid, A = 2 * NG + NB + NR;
+    double *l = lo + i * A, *h = hi + i * A;
+    auto unit = [](double v) { return v != v ? 0.0 : v; };                   // np.isnan(bound) -> 0
+    for (int j = 0; j < 2 * NG; j++) { l[j] = 0.0; h[j] = 1.0; }
+    if constexpr (F & F_BATTERY)
+        for (int j = 0; j < NB; j++) {
+            Params p; Derived d;
+            load_module_params<F_BATTERY>(a.c, (int64_t)j * N + i, p); derive<F_BATTERY>(p, d);
+            const double c = a.c.charge[(int64_t)j * N + i];
+            l[2 * NG + j] = unit((-1 * battery_max_consumption(p, c) - d.bat_lo) / d.bat_sp);      // space.py:207-218
+            h[2 * NG + j] = unit((battery_max_production(p, c) - d.bat_lo) / d.bat_sp);
+        }
+    if constexpr (F & F_GRID)
+        for (int j = 0; j < NR; j++) {
+            Params p; Derived d;
+            load_module_params<F_GRID>(a.c, (int64_t)j * N + i, p); derive<F_GRID>(p, d);
+            // one GridModule: whichever way the batch holds its series; several: [T, n_grid, 4, N] arrays
+            const int64_t row = series_row(a, i, t);
+            const double stat = NR == 1 ? series_component(a.c, N, 5, row, i, a.pm_pitch) : a.c.grid_ts[((row * NR + j) * 4 + 3) * N + i];
+            l[2 * NG + NB + j] = unit((-1 * (p.grid_exp * stat) - d.grid_lo) / d.grid_sp);
+            h[2 * NG + NB + j] = unit((p.grid_imp * stat - d.grid_lo) / d.grid_sp);
+        }
 }
 
 // K consecutive steps of the general path in ONE launch (mgx_step_k / mgx_rollout_lists on layouts with several modules of a

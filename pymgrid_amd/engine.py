@@ -478,10 +478,11 @@ class StepEngine:
         check(self._lib.mgx_set_shards(self._h, int(n_shards)))
         self.n_shards = int(n_shards)
 
-    def set_launch_threads(self, enable=True):
-        """Single-step calls in shards: shard j >= 1 is issued by a resident host thread of the library while the caller issues
-        shard 0 (``mgx_set_launch_threads``; default on).  Off: every shard launch comes from the calling thread."""
-        check(self._lib.mgx_set_launch_threads(self._h, 1 if enable else 0))
+    def set_launch_threads(self, mode=1):
+        """Single-step calls in shards: shard j >= 1 issued by a resident host thread of the library while the caller issues shard
+        0 (``mgx_set_launch_threads``): 0 never, 1 (default) inside ``step_many``, 2 / True also for every single-step call."""
+        mode = 2 if mode is True else int(mode)
+        check(self._lib.mgx_set_launch_threads(self._h, mode))
 
     def fork(self):
         """The shard streams wait for everything queued on torch's current stream (inputs produced there)."""
@@ -505,6 +506,14 @@ class StepEngine:
         mask = out if out is not None else self._empty(self.N, dtype=torch.int32)
         self._call(self._lib.mgx_check_step, _ptr(actions), 1 if normalized else 0, mask.data_ptr())
         return mask
+
+    def action_bounds(self, out=None):
+        """``mgx_action_bounds``: (lo, hi) [N, A] float64 -- the normalised interval ``sample_action(strict_bound=True)`` draws
+        every action column from at the CURRENT state and row (base_module.py:326-356)."""
+        A = self.layout.action_dim
+        lo, hi = out if out is not None else (self._empty(self.N, A), self._empty(self.N, A))
+        self._call(self._lib.mgx_action_bounds, lo.data_ptr(), hi.data_ptr())
+        return lo, hi
 
     def step_many(self, actions, normalized=True, want_obs=False, want_log=False, done=True, out=None):
         """K single-step launches issued by one call (``mgx_step_many``): actions [K, N, A] -> reward [K, N], done [K, N],

@@ -238,13 +238,21 @@ class BatchedMicrogridEnv:
         # order of the list; unknown keys are a NameError as in _validate_observation_keys
         self.observation_keys = list(observation_keys) if observation_keys else None
         self._obs_index = None
+        # modules with forecast horizons of their own (batch.obs_keep): the row is built for the longest one and the columns a
+        # module does not have are dropped here -- the same gather observation_keys uses
+        keep = getattr(batch, "obs_keep", None)
+        if keep is not None and self._views:
+            raise ValueError("obs_views needs one forecast horizon for all time-series modules")
         if self.observation_keys:
             names = self.layout.obs_names
-            bad = [k for k in self.observation_keys if k not in names]
+            have = range(len(names)) if keep is None else keep
+            bad = [k for k in self.observation_keys if k not in [names[j] for j in have]]
             if bad:
                 raise NameError(f'Keys {bad} not found in state.')
-            idx = [j for k in self.observation_keys for j, n in enumerate(names) if n == k]
+            idx = [j for k in self.observation_keys for j in have if names[j] == k]
             self._obs_index = torch.as_tensor(idx, dtype=torch.long, device=batch.device)
+        elif keep is not None:
+            self._obs_index = torch.as_tensor(keep, dtype=torch.long, device=batch.device)
         D = len(self._obs_index) if self._obs_index is not None else self.layout.obs_dim
         self.observation_space = Box(0.0, 1.0, shape=(D,))                  # normalised observation
         # The per-step bookkeeping (which output buffers, which ring block, when to prefetch) moves into the C ABI wherever a step
@@ -336,6 +344,19 @@ class BatchedMicrogridEnv:
         fp.keep = (slots, plan)
         self._fp = fp
 
+    def _resync_fast(self, fp):
+        """The Python mirror of the bound step's position, re-read from the handle (mgx_env_position, mgx_current_step)."""
+        import ctypes as C
+        e = self.engine
+        s_, r_, p_ = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        if e._lib.mgx_env_position(e._h, C.byref(s_), C.byref(r_), C.byref(p_)):
+            self._fp = None                        # (no plan bound any more: per-call bookkeeping from the Python-side positions)
+            return
+        fp.k = (s_.value + 1) % fp.R
+        if fp.nring:
+            fp.p = r_.value * (fp.nring // 3) + p_.value
+        e._t = int(e._lib.mgx_current_step(e._h))
+
     def _step_fast(self, fp, fn, action):
         """One bound step: the controls' address in, the pre-built views of the slot / ring block the handle used out."""
         e = self.engine
@@ -346,9 +367,11 @@ class BatchedMicrogridEnv:
         else:
             rc = fn(*action, _raw_stream(fp.dev))
         if rc:
-            if rc == _lib.MGX_ERR_DEVICE:             # the launch sequence broke off somewhere: the handle's position is not ours any more
-                self._fp = None
-            _lib.check(rc)                            # (range / argument errors are raised before anything moves: still bound)
+            # Argument / range errors are raised before anything moves; a device error (or a failed ring refill behind a step that
+            # did happen) leaves the handle wherever the launch sequence broke off: take slot, ring position and counter from IT
+            msg = _lib.lib().mgx_last_error()
+            self._resync_fast(fp)
+            raise _lib.MgxError(rc, msg.decode() if msg else "")
         e._t = t + 1
         k = fp.k
         fp.k = k + 1 if k + 1 < fp.R else 0
@@ -469,7 +492,11 @@ class BatchedMicrogridEnv:
         start, length = as_i32(start), as_i32(length)
         self._log_rows = []
         self._shaped_rows = []
-        if self._ring is not None and self._obs_columns and self._obs_layout_auto and not self._fleet_owned:
+        if self._ring is not None and self._obs_columns and self._fleet_owned:
+            # (the fleet's cached step plans hold this env's ring pointers: the env cannot swap its rings for row-major ones itself)
+            raise RuntimeError("per-grid episodes patch restarted grids into ROW-major rings and this env's rings are column-major "
+                               "blocks owned by a fused BucketedFleet: build the fleet with obs_layout='rows'")
+        if self._ring is not None and self._obs_columns and self._obs_layout_auto:
             self._set_ring_columns(False)            # per-grid episodes patch restarted grids into ROW-major rings
         if rolling:
             if self._views:
@@ -613,11 +640,11 @@ class BatchedMicrogridEnv:
         self.engine.set_ring_layout(False)
         self.engine.set_ring_pitch(pitch)
         if self._obs_columns:              # blocks [D, pitch]; a block's observation = the transposed view [N, D], strides (1, pitch)
-            self._ring_store = torch.empty(3, K, L.obs_dim, pitch, dtype=self._obs_dtype, device=self.batch.device)
+            self._ring_store = torch.zeros(3, K, L.obs_dim, pitch, dtype=self._obs_dtype, device=self.batch.device)
             self._rings = self._ring_store[:, :, :, :L.n_grids].transpose(2, 3)
             self.engine.set_ring_layout(True)
         else:
-            self._ring_store = torch.empty(3, K, pitch, L.obs_dim, dtype=self._obs_dtype, device=self.batch.device)
+            self._ring_store = torch.zeros(3, K, pitch, L.obs_dim, dtype=self._obs_dtype, device=self.batch.device)
             self._rings = self._ring_store[:, :, :L.n_grids]
 
     def _set_ring_columns(self, columns):
@@ -806,10 +833,21 @@ class BatchedMicrogridEnv:
 
     run = step      # Microgrid.run has the same signature and return value (microgrid.py:227-325)
 
-    def sample_action(self, generator=None):
-        """Microgrid.sample_action(strict_bound=False): uniform normalised control (microgrid.py:337-362)."""
-        return torch.rand(self.n_grids, self.layout.action_dim, dtype=self.engine.action_dtype, device=self.batch.device,
-                          generator=generator)
+    def sample_action(self, generator=None, strict_bound=False):
+        """Microgrid.sample_action (microgrid.py:337-362): a uniform normalised control [N, A].  ``strict_bound=True``
+        (base_module.py:326-356): every battery / grid column is drawn from [normalize(-max_consumption), normalize(max_production)]
+        at the grid's CURRENT state and row (``mgx_action_bounds``; u * (hi - lo) + lo with the same u), so that the request never
+        exceeds an instantaneous limit.  As in the reference, a layout with a GensetModule raises TypeError for strict bounds (its
+        2-dim action space cannot normalise the scalar limit, genset_module.py:348-349 -> space.py:207-218)."""
+        u = torch.rand(self.n_grids, self.layout.action_dim, dtype=torch.float64 if strict_bound else self.engine.action_dtype,
+                       device=self.batch.device, generator=generator)
+        if not strict_bound:
+            return u
+        if self.layout.has_genset:
+            raise TypeError("sample_action(strict_bound=True): the reference fails on a GensetModule (only size-1 arrays can be "
+                            "converted to Python scalars); battery / grid layouts only")
+        lo, hi = self.engine.action_bounds()
+        return (u * (hi - lo) + lo).to(self.engine.action_dtype)
 
     def control_to_tensor(self, control):
         """{'genset': [[goal, energy]], 'battery': [x], 'grid': [x]} (values scalars or [N] tensors) -> [N, A]."""
@@ -1058,6 +1096,36 @@ class _SingleMixin:
         L = self.layout
         return L.n_load + L.n_pv + L.n_genset + L.n_battery + L.n_grid + 1
 
+    def _make_spaces(self):
+        """``BaseMicrogridEnv._get_observation_space`` (envs/base/base.py:128-163): the nested space -- module name -> ``Tuple`` of one
+        normalised ``Box`` per module (the UnbalancedEnergyModule's is empty), with ``observation_keys`` the listed keys a module
+        has -- kept as ``_nested_observation_space``; ``observation_space`` is that ``Dict`` when ``flat_spaces=False`` and its
+        flattening (a ``Box`` of the row's length) otherwise."""
+        from .spaces import Dict, Tuple
+        L = self.layout
+        inst, names = L.obs_instances(), L.obs_names
+        keep = getattr(self.batch, "obs_keep", None)
+        have = set(range(len(names)) if keep is None else keep)
+        nested = {}
+        for name in ("load", "pv", "unbalanced_energy", "genset", "battery", "grid"):       # modules.iterdict() order of a scenario file
+            boxes = []
+            if name == "unbalanced_energy":
+                if not self.observation_keys:
+                    boxes.append(Box(0.0, 1.0, shape=(0,)))
+            else:
+                for sl in inst.get(name, []):
+                    cols = [j for j in range(sl.start, sl.stop) if j in have]
+                    if self.observation_keys:
+                        cols = [j for k in self.observation_keys for j in cols if names[j] == k]
+                        if not cols:
+                            continue
+                    boxes.append(Box(0.0, 1.0, shape=(len(cols),)))
+            if boxes:
+                nested[name] = Tuple(boxes)
+        self._nested_observation_space = Dict(nested)
+        if not self.flat_spaces:
+            self.observation_space = self._nested_observation_space
+
     def get_forecast_horizon(self):
         """``Microgrid.get_forecast_horizon`` (microgrid.py:553-582): the forecast horizon of the time-series modules (one value
         per microgrid here: the layout's)."""
@@ -1130,16 +1198,20 @@ class _SingleMixin:
         name of the microgrid in sweep order (fixed, controllable, flex: microgrid.py:255-314) -> [array per module]; the
         UnbalancedEnergyModule has an empty observation."""
         inst = self.layout.obs_instances()
+        keep = getattr(self.batch, "obs_keep", None)
         out = {}
         for name in ("load", "genset", "battery", "grid", "pv"):
             if name in inst:
-                out[name] = [obs_row[sl].copy() for sl in inst[name]]
+                if keep is None:
+                    out[name] = [obs_row[sl].copy() for sl in inst[name]]
+                else:          # per-module horizons: the row holds the kept columns only; a module's are those inside its block
+                    out[name] = [obs_row[[q for q, col in enumerate(keep) if sl.start <= col < sl.stop]] for sl in inst[name]]
         out["unbalanced_energy"] = [np.array([])]
         return out
 
     def _obs_out(self, obs):
         row = obs[0].cpu().numpy()
-        return row if (self.flat_spaces or self._obs_index is not None) else self._nested(row)
+        return row if (self.flat_spaces or self.observation_keys) else self._nested(row)
 
     def _request_signs(self, control, normalized):
         """Sign of the unnormalised battery / grid requests of a control row [A] (numpy): the reference files a module's energy
@@ -1206,11 +1278,15 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
 
     def __init__(self, params, device="cuda", flat_spaces=True, log=True, reward_shaping_func=None,
                  trajectory_func=None, raise_errors=False, observation_keys=None, flat_order="module"):
+        # (a parameter dict read from a serialised microgrid may carry its trajectory_func / raise_errors: the defaults here)
         super().__init__(MicrogridBatch.from_grids([params], device=device, flat_order=_n1_order(params, flat_order)), log=log,
-                         reward_shaping_func=reward_shaping_func, trajectory_func=trajectory_func,
-                         raise_errors=raise_errors, observation_keys=observation_keys, obs_prefetch=0)
+                         reward_shaping_func=reward_shaping_func if reward_shaping_func is not None else params.get("reward_shaping_func"),
+                         trajectory_func=trajectory_func if trajectory_func is not None else params.get("trajectory_func"),
+                         raise_errors=raise_errors or bool(params.get("raise_errors", False)), observation_keys=observation_keys,
+                         obs_prefetch=0)
         self.flat_spaces = flat_spaces
         self._params = params
+        self._make_spaces()
 
     def reset(self, initial_step=None):
         return self._obs_out(super().reset(initial_step))
@@ -1226,17 +1302,30 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
 
     def sample_action(self, strict_bound=False, sample_flex_modules=False):
         """``Microgrid.sample_action`` (microgrid.py:337-362): a random NORMALISED control dict ``{name: [per-module value]}`` (a
-        genset's value is ``array([goal_status, energy])``), uniform in [0, 1) from numpy's global generator.  ``strict_bound``
-        (bounds that depend on the current state) is not offered; flex modules take no action."""
-        if strict_bound:
-            raise NotImplementedError("strict_bound=True is not offered (the reference itself fails on it for gensets, SURVEY Q4)")
+        genset's value is ``array([goal_status, energy])``), drawn from numpy's GLOBAL generator in the reference's order (genset,
+        battery, grid: the controllable container's order) with its arithmetic -- ``rand() * (max_bound - min_bound) + min_bound``,
+        bounds (0, 1) or, with ``strict_bound``, [normalize(-max_consumption), normalize(max_production)] of the module's current
+        state (base_module.py:326-356; read back from ``mgx_action_bounds``): a seeded run draws the same controls.  A GensetModule
+        with ``strict_bound`` raises TypeError as the reference does (App. C Q4); flex modules take no action."""
         L, out = self.layout, {}
+        if strict_bound and L.has_genset:
+            raise TypeError("only size-1 arrays can be converted to Python scalars")      # genset_module.py:348-349 -> space.py:207-218
+        lo = hi = None
+        if strict_bound and L.action_dim:
+            lo, hi = (v[0].cpu().numpy() for v in self.engine.action_bounds())
+
+        def draw(col):
+            if lo is None:
+                return np.random.rand() * (1 - 0) + 0
+            return np.random.rand() * (float(hi[col]) - float(lo[col])) + float(lo[col])
         if L.has_genset:
-            out["genset"] = [np.random.rand(2) for _ in range(L.n_genset)]
-        if L.has_battery:
-            out["battery"] = [float(np.random.rand()) for _ in range(L.n_battery)]
-        if L.has_grid:
-            out["grid"] = [float(np.random.rand()) for _ in range(L.n_grid)]
+            out["genset"] = [np.array([np.random.rand(), draw(2 * j + 1)]) for j in range(L.n_genset)]
+        # sources-and-sinks in module-list order (module_container.py:355-413): the draws come in that order
+        for kind in (("grid", "battery") if L.grid_before_battery else ("battery", "grid")):
+            if kind == "battery" and L.has_battery:
+                out["battery"] = [float(draw(2 * L.n_genset + j)) for j in range(L.n_battery)]
+            if kind == "grid" and L.has_grid:
+                out["grid"] = [float(draw(2 * L.n_genset + L.n_battery + j)) for j in range(L.n_grid)]
         return out
 
     def get_empty_action(self, sample_flex_modules=False):
@@ -1252,11 +1341,14 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
     def __init__(self, params, device="cuda", flat_spaces=True, log=True, remove_redundant_gensets=True,
                  reward_shaping_func=None, trajectory_func=None, raise_errors=False, observation_keys=None, flat_order="module"):
         super().__init__(MicrogridBatch.from_grids([params], device=device, flat_order=_n1_order(params, flat_order)), log=log,
-                         remove_redundant_gensets=remove_redundant_gensets, reward_shaping_func=reward_shaping_func,
-                         trajectory_func=trajectory_func, raise_errors=raise_errors, observation_keys=observation_keys,
+                         remove_redundant_gensets=remove_redundant_gensets,
+                         reward_shaping_func=reward_shaping_func if reward_shaping_func is not None else params.get("reward_shaping_func"),
+                         trajectory_func=trajectory_func if trajectory_func is not None else params.get("trajectory_func"),
+                         raise_errors=raise_errors or bool(params.get("raise_errors", False)), observation_keys=observation_keys,
                          obs_prefetch=0)
         self.flat_spaces = flat_spaces
         self._params = params
+        self._make_spaces()
 
     def reset(self, initial_step=None):
         return self._obs_out(super().reset(initial_step))

@@ -39,8 +39,9 @@ def bucket_by_layout(grids):
         from .batch import grid_first
         load, pv = np.asarray(p["load_ts"]), np.asarray(p["pv_ts"])
         from .batch import module_list
+        hz = p.get("horizons") or {}
         key = (architecture(p), tuple(len(module_list(p.get(k))) for k in ("genset", "battery", "grid")), load.shape[0],
-               int(p.get("horizon", 0)),
+               int(p.get("horizon", 0)), tuple((k, tuple(v)) for k, v in sorted(hz.items())),
                int(p.get("initial_step", 0)), int(p.get("final_step", 0)), grid_first(p),
                1 if load.ndim == 1 else load.shape[1], 1 if pv.ndim == 1 else pv.shape[1])
         buckets.setdefault(key, []).append(i)
@@ -84,6 +85,21 @@ def _make_loader(base_dir):
     Loader.add_constructor("!NDArray", ndarray)
     for tag in _MODULE_TAGS + ("!Microgrid", "!DiscreteMicrogridEnv"):
         Loader.add_constructor(tag, tagged(tag))
+
+    # trajectory functions / reward shapers (yaml.YAMLObject subclasses in the reference: the mapping holds the instance's
+    # attributes, microgrid/trajectory/*.py, microgrid/reward_shaping/*.py) -> this package's mirrors of those classes
+    from . import trajectory as tj
+
+    def obj(cls, *fields):
+        def construct(loader, node):
+            d = loader.construct_mapping(node, deep=True) if isinstance(node, yaml.MappingNode) else {}
+            return cls(*[d[f] for f in fields])
+        return construct
+    Loader.add_constructor("!DeterministicTrajectory", obj(tj.DeterministicTrajectory, "initial_step", "final_step"))
+    Loader.add_constructor("!StochasticTrajectory", obj(tj.StochasticTrajectory))
+    Loader.add_constructor("!FixedLengthStochasticTrajectory", obj(tj.FixedLengthStochasticTrajectory, "trajectory_length"))
+    Loader.add_constructor("!PVCurtailmentShaper", obj(tj.PVCurtailmentShaper))
+    Loader.add_constructor("!BatteryDischargeShaper", obj(tj.BatteryDischargeShaper))
     return Loader
 
 
@@ -92,7 +108,12 @@ def load_scenario_yaml(path):
     microgrid_3.yaml) into a parameter dict, applying the reference's deserialisation rules: constructor arguments
     from ``cls_params``, then the state attributes (battery: ``soc`` then ``current_charge`` setters,
     battery_module.py:356-362 -> charge = current_charge, soc = charge / max_capacity; genset: the four private
-    status fields, genset_module.py:426-427)."""
+    status fields, genset_module.py:426-427).
+
+    Beyond the plain vocabulary the dict may carry: ``trajectory_func`` / ``reward_shaping_func`` (instances of this package's
+    mirrors of the reference's classes; the N = 1 envs take them as defaults), ``raise_errors`` (True when any module was built
+    with it: the envs' default), ``horizons`` ({"load": [h per module], "pv": [...], "grid": [...]} when the time-series modules do
+    not share one forecast horizon: ``horizon`` is then their maximum and the envs drop the columns a module does not have)."""
     import os
 
     import yaml
@@ -100,10 +121,14 @@ def load_scenario_yaml(path):
         doc = yaml.load(fh, Loader=_make_loader(os.path.dirname(os.path.abspath(path))))
     if doc.get("__tag__") not in ("!Microgrid", "!DiscreteMicrogridEnv"):
         raise ValueError(f"{path}: not a !Microgrid document")
-    if doc.get("trajectory_func") is not None or doc.get("reward_shaping_func") is not None:
-        raise NotImplementedError("trajectory_func / reward_shaping_func in scenario files are not supported yet")
     p = {"load_ts": [], "pv_ts": [], "grid_ts": [], "grid": [], "genset": [], "battery": []}
-    ts_meta = []
+    for key in ("trajectory_func", "reward_shaping_func"):           # (Microgrid._serialization_data writes the former only)
+        if doc.get(key) is not None:
+            if isinstance(doc[key], dict):
+                raise ValueError(f"{path}: {key} {doc[key].get('__tag__')!r} is not one of the reference's classes")
+            p[key] = doc[key]
+    ts_meta, horizons = [], {"load": [], "pv": [], "grid": []}
+    raise_errors = False
     order = []                                          # controllable modules in list order (module_container.py:355-413)
     for name, mod in doc["modules"]:
         tag, cp, state = mod["__tag__"], mod["cls_params"], mod.get("state", {})
@@ -111,8 +136,7 @@ def load_scenario_yaml(path):
             kind = {"!Genset": "genset", "!BatteryModule": "battery", "!GridModule": "grid"}[tag]
             if kind not in order:
                 order.append(kind)
-        if cp.get("raise_errors"):
-            raise NotImplementedError("raise_errors=True is not offered (requests are always clipped)")
+        raise_errors = raise_errors or bool(cp.get("raise_errors"))     # base_module.py:79-93: the envs' dry-run check (mgx_check_step)
         if tag in ("!LoadModule", "!RenewableModule", "!GridModule"):
             fc = cp.get("forecaster")
             if isinstance(fc, (int, float)) and not isinstance(fc, bool):         # GaussianNoiseForecaster
@@ -129,7 +153,8 @@ def load_scenario_yaml(path):
             # the constructor's initial_step and the saved step counter are two things (Microgrid.from_yaml builds the module
             # from cls_params and only then restores _current_step, base_module.py:771-957): reset() goes back to the former
             init = int(cp.get("initial_step", 0))
-            ts_meta.append((horizon, final, init, int(state.get("_current_step", init))))
+            ts_meta.append((final, init, int(state.get("_current_step", init)), ts.shape[0]))
+            horizons[{"!LoadModule": "load", "!RenewableModule": "pv", "!GridModule": "grid"}[tag]].append(horizon)
             if tag == "!LoadModule":
                 p["load_ts"].append(-np.abs(ts.reshape(ts.shape[0], -1)[:, 0]))
             elif tag == "!RenewableModule":
@@ -172,11 +197,16 @@ def load_scenario_yaml(path):
                                      charge=charge, soc=charge / cap))
     # one module of a kind: the plain vocabulary (a dict, a [T] series); several: lists / [T, n] (module_container.py:355-413
     # keeps a list per name)
-    for key in ("load_ts", "pv_ts"):
+    if not ts_meta:         # (the reference cannot build such a microgrid either: Microgrid.__init__ -> get_attrs('final_step') finds no value)
+        raise ValueError(f"{path}: no time-series module (No values found for key(s) ['final_step'])")
+    # the reference refuses modules that disagree about the window (Microgrid.__init__ -> get_attrs(..., unique=True):
+    # module_container.py:97-180 raises ValueError); a saved microgrid's modules all stand at the same counter (Microgrid.run steps them together)
+    if len(set(ts_meta)) != 1:
+        raise ValueError(f"{path}: the time-series modules disagree about (final_step, initial_step, current step, length): {sorted(set(ts_meta))}")
+    T = ts_meta[0][3]
+    for key in ("load_ts", "pv_ts"):            # a microgrid without a LoadModule / RenewableModule: a [T, 0] series (the general kernels)
         cols = p[key]
-        if not cols:
-            raise NotImplementedError("a microgrid without a LoadModule / RenewableModule is not read from a scenario file")
-        p[key] = cols[0] if len(cols) == 1 else np.stack(cols, axis=1)
+        p[key] = cols[0] if len(cols) == 1 else (np.stack(cols, axis=1) if cols else np.zeros((T, 0)))
     for key in ("genset", "battery", "grid", "grid_ts"):
         if not p[key]:
             del p[key]
@@ -184,9 +214,13 @@ def load_scenario_yaml(path):
             p[key] = p[key][0]
     if "unbalanced" not in p:
         raise ValueError("scenario has no UnbalancedEnergyModule")
-    if len(set(ts_meta)) != 1:
-        raise NotImplementedError("time-series modules with different horizon / final_step / current step")
-    p["horizon"], p["final_step"], p["initial_step"], p["current_step"] = ts_meta[0]
+    p["final_step"], p["initial_step"], p["current_step"] = ts_meta[0][:3]
+    hs = [h for v in horizons.values() for h in v]
+    p["horizon"] = max(hs) if hs else 0
+    if len(set(hs)) > 1:                        # forecast_horizon is per module (base_timeseries_module.py:40): keep who has what
+        p["horizons"] = {k: list(v) for k, v in horizons.items() if v}
+    if raise_errors:
+        p["raise_errors"] = True
     p["controllable_order"] = order
     return p
 
@@ -217,12 +251,16 @@ def dump_scenario_yaml(p, path):
         pd.DataFrame(np.asarray(arr, dtype=np.float64).reshape(arr.shape[0], -1)).to_csv(os.path.join(base, rel))
         return _Tagged("!NDArray", rel)
 
+    hz, rerr = p.get("horizons") or {}, bool(p.get("raise_errors", False))
+
     def ts_params(tag, arr, extra=None, j=0):
-        fc = (float(noise["std"]) if noise else "oracle") if H > 0 else None
-        d = dict(final_step=final, forecast_horizon=H, forecaster=fc,
+        kind = {"LoadModule": "load", "RenewableModule": "pv", "GridModule": "grid"}[tag]
+        h = int(hz[kind][j]) if kind in hz else H           # forecast_horizon is per module (base_timeseries_module.py:40)
+        fc = (float(noise["std"]) if noise else "oracle") if h > 0 else None
+        d = dict(final_step=final, forecast_horizon=h, forecaster=fc,
                  forecaster_increase_uncertainty=bool(noise and noise.get("increase_uncertainty", False)),
                  forecaster_relative_noise=bool(noise and noise.get("relative_noise", False)),
-                 initial_step=t0, raise_errors=False, time_series=series(tag, arr, j))
+                 initial_step=t0, raise_errors=rerr, time_series=series(tag, arr, j))
         d.update(extra or {})
         return d
 
@@ -234,7 +272,7 @@ def dump_scenario_yaml(p, path):
              for j in range(pv.shape[1])]
     mods.append(module("unbalanced_energy", "!UnbalancedEnergyModule",
                        dict(initial_step=t0, loss_load_cost=float(p["unbalanced"]["loss_load_cost"]),
-                            overgeneration_cost=float(p["unbalanced"]["overgeneration_cost"]), raise_errors=False), {}))
+                            overgeneration_cost=float(p["unbalanced"]["overgeneration_cost"]), raise_errors=rerr), {}))
     order = [k for k in (p.get("controllable_order") or []) if p.get(k) is not None]
     order += [k for k in ("genset", "battery", "grid") if p.get(k) is not None and k not in order]
     grid_series = grid_series_list(p)
@@ -249,7 +287,7 @@ def dump_scenario_yaml(p, path):
             mods.append(module("genset", "!Genset", dict(
                 allow_abortion=bool(q.get("allow_abortion", True)), co2_per_unit=float(q.get("co2_per_unit", 0.0)),
                 cost_per_unit_co2=float(q.get("cost_per_unit_co2", 0.0)), genset_cost=float(q["genset_cost"]),
-                init_start_up=bool(st[0]), initial_step=t0, provided_energy_name="genset_production", raise_errors=False,
+                init_start_up=bool(st[0]), initial_step=t0, provided_energy_name="genset_production", raise_errors=rerr,
                 running_max_production=float(q["running_max_production"]),
                 running_min_production=float(q["running_min_production"]), start_up_time=su, wind_down_time=wd),
                 dict(_current_status=st[0], _goal_status=st[1], _steps_until_up=st[2], _steps_until_down=st[3]), j))
@@ -265,12 +303,22 @@ def dump_scenario_yaml(p, path):
                 battery_cost_cycle=float(q.get("battery_cost_cycle", 0.0)), battery_transition_model=None,
                 efficiency=float(q["efficiency"]), init_charge=None, init_soc=charge / cap, initial_step=t0,
                 max_capacity=cap, max_charge=float(q["max_charge"]), max_discharge=float(q["max_discharge"]),
-                min_capacity=float(q["min_capacity"]), raise_errors=False), dict(current_charge=charge, soc=charge / cap), j))
+                min_capacity=float(q["min_capacity"]), raise_errors=rerr), dict(current_charge=charge, soc=charge / cap), j))
         else:
             mods.append(module("grid", "!GridModule", ts_params("GridModule", np.asarray(grid_series[j], dtype=np.float64), dict(
                 cost_per_unit_co2=float(q.get("cost_per_unit_co2", 0.0)), max_export=float(q["max_export"]),
                 max_import=float(q["max_import"])), j=j), {}, j))
-    doc = _Tagged("!Microgrid", dict(final_step=final, initial_step=t0, modules=mods, trajectory_func=None))
+    from . import trajectory as tj
+    tf = p.get("trajectory_func")
+    if isinstance(tf, tj.DeterministicTrajectory):
+        tf = _Tagged("!DeterministicTrajectory", dict(initial_step=int(tf.initial_step), final_step=int(tf.final_step)))
+    elif isinstance(tf, tj.FixedLengthStochasticTrajectory):
+        tf = _Tagged("!FixedLengthStochasticTrajectory", dict(trajectory_length=int(tf.trajectory_length)))
+    elif isinstance(tf, tj.StochasticTrajectory):
+        tf = _Tagged("!StochasticTrajectory", {})
+    elif tf is not None:
+        raise TypeError(f"trajectory_func {tf!r}: only the reference's three trajectory classes have a YAML form")
+    doc = _Tagged("!Microgrid", dict(final_step=final, initial_step=t0, modules=mods, trajectory_func=tf))
 
     class Dumper(yaml.SafeDumper):
         pass

@@ -42,3 +42,68 @@ class Discrete:
 
     def __repr__(self):
         return f"Discrete({self.n})"
+
+
+class Tuple:
+    """``gym.spaces.Tuple``: one space per module of a name (envs/base/base.py:141-160)."""
+
+    def __init__(self, spaces):
+        self.spaces = tuple(spaces)
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def __getitem__(self, j):
+        return self.spaces[j]
+
+    def __iter__(self):
+        return iter(self.spaces)
+
+    def contains(self, x):
+        return isinstance(x, (tuple, list)) and len(x) == len(self.spaces) and all(s.contains(v) for s, v in zip(self.spaces, x))
+
+    __contains__ = contains
+
+    def sample(self, rng=None):
+        return tuple(s.sample(rng) for s in self.spaces)
+
+    def __repr__(self):
+        return "Tuple(" + ", ".join(repr(s) for s in self.spaces) + ")"
+
+
+class Dict:
+    """``gym.spaces.Dict`` over module names -> ``Tuple`` of per-module ``Box``es: the nested observation space a
+    ``flat_spaces=False`` env exposes (envs/base/base.py:128-163).  Keys keep the order given (the reference builds it in
+    ``modules.iterdict()`` order; gym itself sorts the keys of a plain dict -- ``sorted_keys()`` gives that order)."""
+
+    def __init__(self, spaces):
+        self.spaces = dict(spaces)
+
+    def keys(self):
+        return self.spaces.keys()
+
+    def items(self):
+        return self.spaces.items()
+
+    def sorted_keys(self):
+        return sorted(self.spaces)
+
+    def __getitem__(self, k):
+        return self.spaces[k]
+
+    def __iter__(self):
+        return iter(self.spaces)
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def contains(self, x):
+        return isinstance(x, dict) and set(x) == set(self.spaces) and all(self.spaces[k].contains(v) for k, v in x.items())
+
+    __contains__ = contains
+
+    def sample(self, rng=None):
+        return {k: s.sample(rng) for k, s in self.spaces.items()}
+
+    def __repr__(self):
+        return "Dict(" + ", ".join(f"{k}: {s!r}" for k, s in self.spaces.items()) + ")"

@@ -134,3 +134,74 @@ def test_bind_refuses_what_it_cannot_walk(device):
                                      for a in ("genset+battery", "battery+grid")], obs_prefetch=4, reuse_outputs=12)
     assert fl.fused and all(env._fp is None for env in fl.envs)
     fl.close()
+
+
+@pytest.mark.parametrize("rows", [False, True])
+def test_two_launch_chains_equal_the_one_stream_step(rows, device):
+    """mgx_set_shards(2) + launch threads (include/mgx.h mgx_set_launch_threads): the Gym step as two dependent launch chains, shard 1
+    issued by the library's resident host thread -- through env.step (bound, one hand-over per call: mode 2), through step_many
+    (each thread its shard's K launches) and with the threads off: rewards, rows and the final state `==` the one-stream env."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    from pymgrid_amd.generator import generate
+    N, T, K = 3001, 200, 48
+
+    def make():
+        b = generate(N, n_steps=T, seed=8, arch="genset+battery+grid", device=device, mixed_timers=True, series="factorised")
+        return BatchedMicrogridEnv(b, observations=rows, reuse_outputs=4)
+    g = torch.Generator(device=device); g.manual_seed(3)
+    one = make()
+    acts = torch.rand(3 * K, N, one.layout.action_dim, dtype=torch.float64, device=device, generator=g)
+    one.reset()
+    ref_rew, ref_obs = [], []
+    for a in acts:
+        o, r, d, _ = one.step(a)
+        ref_rew.append(r.clone()); ref_obs.append(o.clone() if rows else None)
+    for mode in (2, 0):
+        two = make()
+        two.reset()
+        two.set_shards(2)
+        two.engine.set_launch_threads(mode)
+        assert two._fp is not None and two.engine.n_shards == 2
+        two.fork()
+        got_rew, got_obs = [], []
+        for k in range(K):                                     # the bound step, one C call per env-step
+            o, r, d, _ = two.step(acts[k])
+            two.join()
+            got_rew.append(r.clone()); got_obs.append(o.clone() if rows else None)
+            two.fork()
+        out = dict(reward=torch.empty(K, N, dtype=torch.float64, device=device))
+        if rows:
+            out["obs"] = torch.empty(K, N, two.layout.obs_dim, dtype=torch.float64, device=device)
+        two._unbind_fast()
+        two.engine.set_launch_threads(1 if mode else 0)
+        o2, r2, _, _ = two.engine.step_many(acts[K:2 * K], normalized=True, out=out, done=False, want_obs=rows)   # K launches per shard and call
+        two.join()
+        got_rew += list(r2); got_obs += (list(o2) if rows else [None] * K)
+        two.set_shards(1)                                      # (re-binds at the counter the sharded calls left)
+        assert two.current_step == 2 * K
+        for k in range(2 * K, 3 * K):
+            o, r, d, _ = two.step(acts[k])
+            got_rew.append(r.clone()); got_obs.append(o.clone() if rows else None)
+        for k in range(3 * K):
+            assert torch.equal(got_rew[k], ref_rew[k]), (mode, k)
+            assert not rows or torch.equal(got_obs[k], ref_obs[k]), (mode, k)
+        for name in ("charge", "soc", "gen_status"):
+            assert torch.equal(two.batch.cols[name], one.batch.cols[name]), (mode, name)
+        two.close()
+    one.close()
+
+
+def test_tunables_are_read_back_and_validated(device):
+    """mgx_set_tunable / mgx_get_tunable: the library's launch-shape knobs (it reads no environment variables)."""
+    from pymgrid_amd import MgxError, _lib
+    for name in _lib.TUNABLES:
+        cur, dflt = _lib.get_tunable(name)
+        assert cur == dflt, name
+    _lib.set_tunable("win_threads", 512)
+    assert _lib.get_tunable("win_threads") == (512, 0)
+    _lib.set_tunable("win_threads", 0)
+    for name, bad in (("win_threads", 300), ("win_pairs", 2), ("launch_threads", 3), ("fleet_byvalue", -1)):
+        with pytest.raises(MgxError):
+            _lib.set_tunable(name, bad)
+    assert _lib.lib().mgx_set_tunable(99, 0) == _lib.MGX_ERR_INVALID
+    assert _lib.lib().mgx_abi_minor() == _lib.ABI_MINOR

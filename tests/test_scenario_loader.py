@@ -156,3 +156,85 @@ def test_multi_instance_scenarios_round_trip(tmp_path):
             assert len(m.modules["load"]) == p["load_ts"].shape[1]
             assert close(m.modules["load"][-1].time_series[:, 0], -np.abs(p["load_ts"][:, -1]))
     assert len(bucket_by_layout(all_p)) == len(all_p)          # every module mix is a layout of its own
+
+
+def test_scenario_features_the_reference_serialises(tmp_path):
+    """What round 5's loader refused and Microgrid.load (microgrid.py:848-908) accepts, both directions against the REAL reference:
+    a trajectory function, modules built with raise_errors=True, time-series modules with forecast horizons of their own, a
+    microgrid without a LoadModule -- the reference dumps, this loader reads; this dump writes, the reference loads."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import _refenv
+    _refenv.import_reference()
+    from pymgrid import Microgrid
+    from pymgrid.microgrid.trajectory import DeterministicTrajectory as RefDet, FixedLengthStochasticTrajectory as RefFixed, \
+        StochasticTrajectory as RefStoch
+    from pymgrid.modules import BatteryModule, GridModule, LoadModule, RenewableModule
+    from pymgrid_amd import trajectory as tj
+    from pymgrid_amd.scenario import dump_scenario_yaml, load_scenario_yaml
+    rs = np.random.RandomState(3)
+    T = 60
+    load, pv = 40 + 30 * rs.rand(T), 50 * rs.rand(T)
+    grid = np.stack([0.2 + rs.rand(T), 0.1 * rs.rand(T), 0.3 * rs.rand(T), (rs.rand(T) > 0.2).astype(float)], axis=1)
+
+    def bat():
+        return BatteryModule(min_capacity=20.0, max_capacity=100.0, max_charge=25.0, max_discharge=30.0, efficiency=0.9, init_soc=0.5,
+                             raise_errors=True)
+    cases = {
+        "fixed": (RefFixed(24), tj.FixedLengthStochasticTrajectory), "det": (RefDet(5, 40), tj.DeterministicTrajectory),
+        "stoch": (RefStoch(), tj.StochasticTrajectory)}
+    for name, (ref_tf, mirror) in cases.items():
+        m = Microgrid([("load", LoadModule(time_series=load, forecaster="oracle", forecast_horizon=5, raise_errors=True)),
+                       ("pv", RenewableModule(time_series=pv, raise_errors=True)), ("battery", bat()),
+                       ("grid", GridModule(max_import=90.0, max_export=50.0, time_series=grid, forecaster="oracle", forecast_horizon=3,
+                                           raise_errors=True))], trajectory_func=ref_tf)
+        d = tmp_path / f"ref_{name}"
+        os.makedirs(d)
+        with open(d / "microgrid.yaml", "w") as fh:
+            m.dump(fh)
+        p = load_scenario_yaml(str(d / "microgrid.yaml"))
+        assert isinstance(p["trajectory_func"], mirror), name
+        if name == "fixed":
+            assert p["trajectory_func"].trajectory_length == 24
+        if name == "det":
+            assert (p["trajectory_func"].initial_step, p["trajectory_func"].final_step) == (5, 40)
+        assert p["raise_errors"] is True
+        assert p["horizon"] == 5 and p["horizons"] == {"load": [5], "pv": [0], "grid": [3]}
+        # ... and back: the reference loads this repo's dump of that dict into the same microgrid
+        d2 = tmp_path / f"ours_{name}"
+        os.makedirs(d2)
+        with open(dump_scenario_yaml(p, str(d2 / "microgrid.yaml"))) as fh:
+            m2 = Microgrid.load(fh)
+        assert type(m2.trajectory_func) is type(ref_tf) and vars(m2.trajectory_func) == vars(ref_tf)
+        assert m2.modules["load"][0].forecast_horizon == 5 and m2.modules["grid"][0].forecast_horizon == 3
+        assert m2.modules["pv"][0].forecast_horizon == 0 and type(m2.modules["pv"][0].forecaster).__name__ == "NoForecaster"
+        assert all(mod.raise_errors for mod in m2.modules.to_list() if hasattr(mod, "raise_errors"))
+        assert m2.modules["battery"][0].soc == 0.5
+    # no LoadModule
+    m = Microgrid([("pv", RenewableModule(time_series=pv)), ("battery", bat())])
+    d = tmp_path / "ref_noload"
+    os.makedirs(d)
+    with open(d / "microgrid.yaml", "w") as fh:
+        m.dump(fh)
+    p = load_scenario_yaml(str(d / "microgrid.yaml"))
+    # (series go through csv text and pandas' default float parser, as in the reference: the last bit of an arbitrary double may differ)
+    assert np.asarray(p["load_ts"]).shape == (T, 0) and np.allclose(p["pv_ts"], pv, rtol=1e-14, atol=0.0)
+    d2 = tmp_path / "ours_noload"
+    os.makedirs(d2)
+    with open(dump_scenario_yaml(p, str(d2 / "microgrid.yaml"))) as fh:
+        m2 = Microgrid.load(fh)
+    assert "load" not in m2.modules.to_dict() and np.allclose(m2.modules["pv"][0].time_series[:, 0], pv, rtol=1e-14, atol=0.0)
+    # modules that disagree about the window: a ValueError in the reference's constructor (get_attrs(unique=True)) and here
+    with pytest.raises(ValueError):
+        Microgrid([("load", LoadModule(time_series=load, final_step=50)), ("pv", RenewableModule(time_series=pv))])
+    good = load_scenario_yaml(str(tmp_path / "ours_det" / "microgrid.yaml"))
+    text = open(tmp_path / "ours_det" / "microgrid.yaml").read()
+    assert good["final_step"] == T
+    bad = text.replace("      final_step: 60", "      final_step: 50", 1)  # the first module's only
+    with open(tmp_path / "ours_det" / "bad.yaml", "w") as fh:
+        fh.write(bad)
+    with pytest.raises(ValueError):
+        load_scenario_yaml(str(tmp_path / "ours_det" / "bad.yaml"))
+    # no time-series module at all: the reference cannot build such a microgrid (get_attrs: "No values found for key(s) ['final_step']")
+    with pytest.raises(AttributeError):
+        Microgrid([("battery", bat())])
