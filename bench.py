@@ -68,7 +68,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64, help="timed bench STEPS (one step = --launches-per-step rounds of --chunk env-steps of all grids)")
     ap.add_argument("--warmup", type=int, default=16, help="untimed steps before the timed ones")
-    ap.add_argument("--grids", type=int, default=100_000, help="microgrids PER GPU (weak scaling)")
+    ap.add_argument("--grids", type=int, default=None,
+                    help="microgrids PER GPU (weak scaling); default 100 000 (--config 2) / 125 000 (--config 3, 4: 1 M over 8 GPUs)")
     ap.add_argument("--rows", type=int, default=8760, help="time-series rows T")
     ap.add_argument("--mode", choices=["fused", "step", "rbc"], default="fused")
     ap.add_argument("--chunk", type=int, default=64, help="env-steps per round (= per fused launch)")
@@ -102,13 +103,20 @@ def parse(argv=None):
                     help="BASELINE.json configs[] index the job lands on: 2 = 100 000 template-4 grids per GPU (the metric's N = 100k), "
                          "3 = 1 M template-4 grids over 8 GPUs (125 000 per GPU), 4 = 1 M heterogeneous H = 24 grids over 8 GPUs (the fleet "
                          "leg at 125 000 per GPU becomes what `value` reports)")
+    ap.add_argument("--tunable", action="append", default=[], metavar="NAME=VALUE",
+                    help="mgx_set_tunable before anything runs (A/B of launch shapes: e.g. multi_static=0); repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the baseline sample")
     ap.add_argument("--prewarm", type=float, default=PREWARM_S)
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
                     help="where the full record goes (the stdout line is the compact one); '' = nowhere")
     ap.add_argument("--launch-check", action="store_true",
                     help="only bring the N ranks up, check the process group and the metrics all-reduce, print {n_gpus: N} (no GPU work)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.grids is None:
+        args.grids = 100_000 if args.config == 2 else 125_000
+    if args.config == 4 and args.hetero_steps <= 0:
+        ap.error("--config 4 reports the heterogeneous fleet: --hetero-steps must be > 0")
+    return args
 
 
 def self_launch(args):
@@ -881,6 +889,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     _lib.build()
+    for kv in args.tunable:
+        name, _, value = kv.partition("=")
+        _lib.set_tunable(name, int(value))
     global CSRC_HASH
     CSRC_HASH = _lib.built_hash(_lib.LIB_PATH) or _lib.source_hash()     # which kernels this run measures (profiles are quoted only if they match)
     local = int(os.environ.get("MGX_FORCE_LOCAL_RANK", local))     # tests: several ranks on one GPU (with a gloo backend)
@@ -1146,7 +1157,9 @@ def main():
 
     hetero = None
     if args.hetero_steps > 0:
-        hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, args.hetero_steps, mdist, args.rows,
+        # --config 4: the fleet IS the job -- `--steps` bench steps of `chunk` fleet Gym steps each are what the head reports
+        fleet_steps = args.steps * chunk if args.config == 4 else args.hetero_steps
+        hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, fleet_steps, mdist, args.rows,
                                                                           args.series, args.series == "factorised" and args.uniform_columns,
                                                                           all_legs=args.all_legs))
 
@@ -1187,7 +1200,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_steps / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{N} generated 4-module grids (genset+battery+load+pv) per GPU, T={args.rows}, H=0, "
-                                   f"normalised random actions (BASELINE configs[2])",
+                                   f"normalised random actions (BASELINE configs[{args.config if args.config != 4 else 2}]"
+                                   + (f": {n_total} grids over {world} GPUs" if args.config == 3 else "") + ")",
                        "env_steps_per_step": chunk * LPS, "steps_per_launch": 1 if args.mode == "step" else chunk,
                        "grids_per_gpu": N, "grids_total": n_total, "mode": args.mode, "series": args.series,
                        "parallelism": f"grids sharded x{world} ranks, no data-path collective"
@@ -1214,6 +1228,19 @@ def main():
             "closed_loop_policy_gym_steps": closed, "hetero_h24_gym_steps": hetero, "general_path_2g2b1grid": general,
             "device_state_under_load": device_state or None})
 
+        if args.config == 4 and isinstance(hetero, dict) and "float64_rows" in hetero:
+            # BASELINE configs[4]: the heterogeneous H = 24 fleet through the Gym surface WITH observation rows is what the job is;
+            # a bench step = `chunk` fleet Gym steps of all grids of a rank (the Template-4 headline above stays in `other`)
+            fl = hetero["float64_rows"]
+            detail["other"] = dict(detail["other"], **{names[args.mode]: dict(main_r)})
+            detail.update({"value": fl["value"], "ms_per_step": fl["us_per_step"] * chunk * 1e-3, "roofline": fl["roofline"],
+                           "roofline_valu": None, "per_rank_env_steps_per_s": [fl["value"] / world] * world})
+            detail["config"] = dict(detail["config"], workload=hetero["workload"] + f" (BASELINE configs[4]: {3 * (N // 3) * world} grids over "
+                                    f"{world} GPUs), float64 rows", mode="fleet_gym_steps_rows", env_steps_per_step=chunk,
+                                    steps_per_launch=1, grids_per_gpu=3 * (N // 3), grids_total=3 * (N // 3) * world)
+            for k, v in (("bytes_per_env_step", fl["roofline"]["algorithmic_bytes_per_launch"] / (3 * (N // 3))), ("launches", fleet_steps),
+                         ("timed_rounds", None)):
+                detail["roofline"].setdefault(k, v)
         detail["leg_names"] = names
         text = compact_line(detail, args.mode, os.path.basename(args.detail) if args.detail else None)
         dtext = json.dumps(detail)

@@ -225,7 +225,8 @@ enum mgx_tunable {
     MGX_TUNE_GRID_MAJOR_COPY = 7,  /* 0: mgx_reset_episodes on [T, N] series gathers rows instead of making its grid-major copy */
     MGX_TUNE_FLEET_BYVALUE = 8,    /* 0: mgx_fleet_step launches the pointer form of the fleet kernel (default 1: by value) */
     MGX_TUNE_LAUNCH_THREADS = 9,   /* mode (0 / 1 / 2) handles created afterwards start with: mgx_set_launch_threads (default 1) */
-    MGX_TUNE_COUNT_ = 10
+    MGX_TUNE_MULTI_STATIC = 10,    /* 0: mgx_step_k of small general layouts never takes a compile-time-count specialisation (A/B, tests) */
+    MGX_TUNE_COUNT_ = 11
 };
 int mgx_set_tunable(int32_t id, int64_t value);                                /* MGX_ERR_INVALID: unknown id / value out of range */
 int mgx_get_tunable(int32_t id, int64_t *value, int64_t *default_value);       /* either pointer may be NULL */

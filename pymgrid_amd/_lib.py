@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("MGX_LIB") or os.path.join(_PKG, "libmgx.so")   # MGX_LIB: A/B kernel variants
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("mgx_abi.hip", "mgx_fused.hip", "mgx_kernels.hpp", "mgx_core.hpp")] + \
           [os.path.join(_ROOT, "include", "mgx.h")]
-FUSED_PARTS = 5            # MGX_FUSED_PARTS: slices of mgx_fused.hip (the K-step kernels), compiled in parallel
+FUSED_PARTS = 6            # MGX_FUSED_PARTS: slices of mgx_fused.hip (the K-step kernels), compiled in parallel
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC"]
 
@@ -29,7 +29,7 @@ ABI_VERSION = 9
 ABI_MINOR = 1
 # enum mgx_tunable (process-wide launch-shape knobs; set_tunable / get_tunable below)
 TUNABLES = ("win_threads", "win_group", "win_pairs", "win_min_lds", "prefetch_pool", "multi_generic", "multi_small_own",
-            "grid_major_copy", "fleet_byvalue", "launch_threads")
+            "grid_major_copy", "fleet_byvalue", "launch_threads", "multi_static")
 MAX_INSTANCES = 8          # MGX_MAX_INSTANCES: gensets / batteries / grids per microgrid
 
 

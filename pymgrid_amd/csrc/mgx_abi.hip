@@ -114,6 +114,7 @@ const int64_t kTuneDefault[MGX_TUNE_COUNT_] = {
     /* MGX_TUNE_GRID_MAJOR_COPY */ 1,
     /* MGX_TUNE_FLEET_BYVALUE   */ 1,
     /* MGX_TUNE_LAUNCH_THREADS  */ 1,      // 0 / 1 / 2: see mgx_set_launch_threads
+    /* MGX_TUNE_MULTI_STATIC    */ 1,
 };
 struct TuneInit { TuneInit() { for (int j = 0; j < MGX_TUNE_COUNT_; j++) g_tune[j].store(kTuneDefault[j], std::memory_order_relaxed); } } g_tune_init;
 inline int64_t tune(int id) { return g_tune[id].load(std::memory_order_relaxed); }
@@ -1599,7 +1600,13 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
     if (h->multi) {                                       // general path: the K-step loop around the general step
         if (h->k.done_bits && done) return fail(MGX_ERR_UNSUPPORTED, "mgx_step_k: the general kernels write `done` as bytes");
         const bool own_kernel = tune(MGX_TUNE_MULTI_SMALL_OWN) != 0;
+        const bool static_counts = tune(MGX_TUNE_MULTI_STATIC) != 0;
         for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+            if (h->multi_small && own_kernel && static_counts) {      // ... with compile-time instance counts where the layout has them
+                MultiStaticLaunch L{h->flags, k.n_genset, k.n_battery, k.n_grid, k.n_load, k.n_pv, multi_blocks(k.g1 - k.g0), s, &k, actions,
+                                    t_arg(h), K, normalized, fo};
+                if (launch_step_k_multi_static(L)) return;
+            }
             if (h->multi_small && own_kernel) {           // at most MS modules of a kind: the register loop in a kernel of its own
                 MGX_DISPATCH_F(h->flags, (step_k_multi_small_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, 0, s>>>(
                                               k, actions, t_arg(h), K, normalized, fo)));

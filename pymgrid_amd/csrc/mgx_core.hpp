@@ -1276,6 +1276,27 @@ __device__ inline void step_multi_core(const KArgs &a, const AT *__restrict__ ac
 // ------------------------------------------------------------------------------------------------------
 constexpr int MS = 2;
 
+// How many modules of each kind the grids of a launch have: read from the launch's KArgs (any layout: the loops keep their `j < n`
+// guards and the instances a layout lacks re-read the last one it has) -- or fixed at COMPILE time for the layouts that occur most
+// (step_k_multi_small_kernel<F, CountsCT<...>>, mgx_fused.hip part 5): the guards fold away, nothing is loaded twice, the presence
+// bits of the provided list become constants.  The same operations on the same operands either way.
+struct CountsRT {
+    static __device__ __forceinline__ int ng(const KArgs &a) { return a.n_genset; }
+    static __device__ __forceinline__ int nb(const KArgs &a) { return a.n_battery; }
+    static __device__ __forceinline__ int nr(const KArgs &a) { return a.n_grid; }
+    static __device__ __forceinline__ int nl(const KArgs &a) { return a.n_load; }
+    static __device__ __forceinline__ int np(const KArgs &a) { return a.n_pv; }
+};
+template <int NG_, int NB_, int NR_, int NL_, int NP_>
+struct CountsCT {
+    static_assert(NG_ <= MS && NB_ <= MS && NR_ <= MS && NL_ >= 1 && NL_ <= MS && NP_ >= 1 && NP_ <= MS, "the register form holds MS instances");
+    static __device__ __forceinline__ constexpr int ng(const KArgs &) { return NG_; }
+    static __device__ __forceinline__ constexpr int nb(const KArgs &) { return NB_; }
+    static __device__ __forceinline__ constexpr int nr(const KArgs &) { return NR_; }
+    static __device__ __forceinline__ constexpr int nl(const KArgs &) { return NL_; }
+    static __device__ __forceinline__ constexpr int np(const KArgs &) { return NP_; }
+};
+
 struct MultiRegs {                       // parameters + dynamic state of one grid (per instance)
     double g_rmin[MS], g_rmax[MS], g_cost[MS], g_co2[MS], g_cco2[MS];
     uint32_t g_times[MS], g_status[MS];
@@ -1295,27 +1316,28 @@ __host__ __device__ inline bool multi_is_small(int n_load, int n_pv, int n_gense
     return n_load >= 1 && n_pv >= 1 && n_load <= MS && n_pv <= MS && n_genset <= MS && n_battery <= MS && n_grid <= MS;
 }
 
-template <int F>
+template <int F, class CNT = CountsRT>
 __device__ __forceinline__ void load_multi_regs(const KArgs &a, int64_t i, MultiRegs &R)
 {
     const int64_t N = a.N;
     const mgx_columns &c = a.c;
+    const int NG = CNT::ng(a), NB = CNT::nb(a), NR = CNT::nr(a);
 #pragma unroll
     for (int j = 0; j < MS; j++) {
         if constexpr (F & F_GENSET) {
-            const int64_t q = (int64_t)(j < a.n_genset ? j : a.n_genset - 1) * N + i;
+            const int64_t q = (int64_t)(j < NG ? j : NG - 1) * N + i;
             R.g_rmin[j] = c.gen_running_min[q]; R.g_rmax[j] = c.gen_running_max[q]; R.g_cost[j] = c.gen_cost[q];
             R.g_co2[j] = c.gen_co2_per_unit[q]; R.g_cco2[j] = c.gen_cost_per_unit_co2[q];
             R.g_times[j] = c.gen_times[q]; R.g_status[j] = c.gen_status[q];
         }
         if constexpr (F & F_BATTERY) {
-            const int64_t q = (int64_t)(j < a.n_battery ? j : a.n_battery - 1) * N + i;
+            const int64_t q = (int64_t)(j < NB ? j : NB - 1) * N + i;
             R.b_cmin[j] = c.bat_min_capacity[q]; R.b_cmax[j] = c.bat_max_capacity[q]; R.b_C[j] = c.bat_max_charge[q];
             R.b_D[j] = c.bat_max_discharge[q]; R.b_eta[j] = c.bat_efficiency[q]; R.b_cost[j] = c.bat_cost_cycle[q];
             R.b_charge[j] = c.charge[q]; R.b_soc[j] = c.soc[q];
         }
         if constexpr (F & F_GRID) {
-            const int64_t q = (int64_t)(j < a.n_grid ? j : a.n_grid - 1) * N + i;
+            const int64_t q = (int64_t)(j < NR ? j : NR - 1) * N + i;
             R.r_imp[j] = c.grid_max_import[q]; R.r_exp[j] = c.grid_max_export[q]; R.r_cco2[j] = c.grid_cost_per_unit_co2[q];
         }
     }
@@ -1331,22 +1353,22 @@ __device__ __forceinline__ void load_multi_regs(const KArgs &a, int64_t i, Multi
 }
 
 // the dynamic state back into the batch's columns
-template <int F>
+template <int F, class CNT = CountsRT>
 __device__ __forceinline__ void store_multi_state(const KArgs &a, int64_t i, const MultiRegs &R)
 {
     const int64_t N = a.N;
 #pragma unroll
     for (int j = 0; j < MS; j++) {
-        if constexpr (F & F_GENSET) { if (j < a.n_genset) a.c.gen_status[(int64_t)j * N + i] = R.g_status[j]; }
-        if constexpr (F & F_BATTERY) { if (j < a.n_battery) { a.c.charge[(int64_t)j * N + i] = R.b_charge[j]; a.c.soc[(int64_t)j * N + i] = R.b_soc[j]; } }
+        if constexpr (F & F_GENSET) { if (j < CNT::ng(a)) a.c.gen_status[(int64_t)j * N + i] = R.g_status[j]; }
+        if constexpr (F & F_BATTERY) { if (j < CNT::nb(a)) { a.c.charge[(int64_t)j * N + i] = R.b_charge[j]; a.c.soc[(int64_t)j * N + i] = R.b_soc[j]; } }
     }
 }
 
-template <int F, typename AT>
+template <int F, typename AT, class CNT = CountsRT>
 __device__ __forceinline__ void load_multi_step_in(const KArgs &a, const AT *__restrict__ act, int64_t i, int32_t t, MultiStepIn &in)
 {
     const int64_t N = a.N;
-    const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
+    const int NG = CNT::ng(a), NB = CNT::nb(a), NR = CNT::nr(a), NL = CNT::nl(a), NP = CNT::np(a);
 #pragma unroll
     for (int j = 0; j < MS; j++) {
         if constexpr (F & F_GENSET) { const int q = j < NG ? j : NG - 1; in.goal[j] = (double)act[2 * q]; in.gen[j] = (double)act[2 * q + 1]; }
@@ -1357,8 +1379,8 @@ __device__ __forceinline__ void load_multi_step_in(const KArgs &a, const AT *__r
             const double *g = a.c.grid_ts + (((int64_t)t * NR + q) * 4) * N + i;
             in.grid[j][0] = g[0]; in.grid[j][1] = g[N]; in.grid[j][2] = g[2 * N]; in.grid[j][3] = g[3 * N];
         }
-        { const int q = j < a.n_load ? j : a.n_load - 1; in.load[j] = a.c.load_ts[((int64_t)t * a.n_load + q) * N + i]; }
-        { const int q = j < a.n_pv ? j : a.n_pv - 1; in.pv[j] = a.c.pv_ts[((int64_t)t * a.n_pv + q) * N + i]; }
+        { const int q = j < NL ? j : NL - 1; in.load[j] = a.c.load_ts[((int64_t)t * NL + q) * N + i]; }
+        { const int q = j < NP ? j : NP - 1; in.pv[j] = a.c.pv_ts[((int64_t)t * NP + q) * N + i]; }
     }
 }
 
@@ -1387,12 +1409,12 @@ __device__ __forceinline__ double small_pairwise_prov(const double (&e)[SMALL_PR
     return res;
 }
 
-template <int F>
+template <int F, class CNT = CountsRT>
 __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, const MultiStepIn &sin, int64_t i, bool normalized,
                                                  double *__restrict__ log, Outputs &o)
 {
     const int64_t N = a.N;
-    const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
+    const int NG = CNT::ng(a), NB = CNT::nb(a), NR = CNT::nr(a), NL = CNT::nl(a), NP = CNT::np(a);
     double reward = 0.0;
     uint32_t viol = 0u;
     // The provided / absorbed lists of MicrogridStep in REGISTERS: running sums kept as the sweep appends (numpy's sum of fewer than
@@ -1406,7 +1428,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     o.load_met = 0.0;
 #pragma unroll
     for (int j = 0; j < MS; j++) {                        // fixed modules, module order (microgrid.py:255-257)
-        if (j < a.n_load) {
+        if (j < NL) {
             const double Lv = -1 * sin.load[j];
             o.load_met += Lv;
             asum += Lv; reward += 0.0;
@@ -1504,7 +1526,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     if (difference > 0) {                                 // :286-299: renewables idle, the excess is overgeneration
 #pragma unroll
         for (int j = 0; j < MS; j++) {
-            if (j < a.n_pv) {
+            if (j < NP) {
                 o.curtailment += sin.pv[j] - 0.0;
                 pe[3 * MS + j] = 0.0; pm |= 1u << (3 * MS + j); psum += 0.0; reward += 0.0;
             }
@@ -1517,7 +1539,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
         double need = -difference;
 #pragma unroll
         for (int j = 0; j < MS; j++) {
-            if (j < a.n_pv) {
+            if (j < NP) {
                 const double pv = sin.pv[j];
                 const double amt = (pv < need) ? pv : need;
                 o.renewable_used += amt; o.curtailment += pv - amt;

@@ -20,12 +20,37 @@
 #define MGX_PART_FLAGS(X) X(14)
 #elif MGX_FUSED_PART == 4
 #define MGX_PART_FLAGS(X) X(15)
+#elif MGX_FUSED_PART == 5
+#define MGX_PART_FLAGS(X)
 #else
 #error "MGX_FUSED_PART out of range"
 #endif
 
 #define MGX_CAT2(a, b) a##b
 #define MGX_CAT(a, b) MGX_CAT2(a, b)
+
+#if MGX_FUSED_PART == 5
+// The general path's K-step launch with the instance counts fixed at compile time (step_k_multi_small_kernel<F, CountsCT<...>>):
+// (n_genset, n_battery, n_grid, n_load, n_pv) of the layouts that occur most; every other small layout takes the run-time-count
+// form (CountsRT) of the same kernel.  The module list is the flags' (grid before battery: F_GRID_FIRST layouts are not listed).
+namespace mgx {
+#define MGX_STATIC_LAYOUTS(X) \
+    X(7, 2, 2, 1, 1, 1) X(7, 2, 2, 2, 1, 1) X(7, 2, 2, 2, 2, 2) X(7, 1, 2, 1, 1, 1) X(7, 1, 2, 2, 1, 1) X(7, 2, 1, 1, 1, 1) X(7, 1, 1, 2, 1, 1) \
+    X(3, 2, 2, 0, 1, 1) X(3, 2, 1, 0, 1, 1) X(3, 1, 2, 0, 1, 1) X(6, 0, 2, 1, 1, 1) X(6, 0, 2, 2, 1, 1) X(6, 0, 1, 2, 1, 1)
+bool launch_step_k_multi_static(const MultiStaticLaunch &L)
+{
+#define X(FV, G, B, R, LD, PV)                                                                                                           \
+    if (L.flags == FV && L.ng == G && L.nb == B && L.nr == R && L.nl == LD && L.np == PV) {                                             \
+        step_k_multi_small_kernel<FV, CountsCT<G, B, R, LD, PV>><<<L.blocks, BLOCK_MULTI, 0, L.stream>>>(*L.k, L.actions, L.t, L.K, L.normalized, \
+                                                                                                        L.out);                         \
+        return true;                                                                                                                    \
+    }
+    MGX_STATIC_LAYOUTS(X)
+#undef X
+    return false;
+}
+}  // namespace mgx
+#else
 
 namespace mgx {
 
@@ -81,3 +106,4 @@ bool MGX_CAT(launch_rollout_p, MGX_FUSED_PART)(const FusedLaunch &L)
 }
 
 }  // namespace mgx
+#endif

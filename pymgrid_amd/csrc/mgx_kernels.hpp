@@ -541,7 +541,19 @@ struct FusedLaunch {
     FusedOut out;
     int32_t gpb;
 };
-constexpr int MGX_FUSED_PARTS = 5;
+constexpr int MGX_FUSED_PARTS = 6;
+// part 5: step_k_multi_small_kernel with COMPILE-TIME instance counts for the layouts listed there; false = no such specialisation
+struct MultiStaticLaunch {
+    int flags, ng, nb, nr, nl, np;
+    unsigned blocks;
+    hipStream_t stream;
+    const KArgs *k;
+    const void *actions;
+    int32_t t, K;
+    int normalized;
+    FusedOut out;
+};
+bool launch_step_k_multi_static(const MultiStaticLaunch &L);
 bool launch_step_k_p0(const FusedLaunch &L); bool launch_step_k_p1(const FusedLaunch &L); bool launch_step_k_p2(const FusedLaunch &L);
 bool launch_step_k_p3(const FusedLaunch &L); bool launch_step_k_p4(const FusedLaunch &L);
 bool launch_rollout_p0(const FusedLaunch &L); bool launch_rollout_p1(const FusedLaunch &L); bool launch_rollout_p2(const FusedLaunch &L);
@@ -2062,7 +2074,8 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a
 // The register form of the K-step launch alone (layouts of at most MS modules of a kind, continuous controls): the same loop as the
 // `small` arm of step_k_multi_kernel in a kernel of its own -- without the run-time-count arm and the priority-list arm beside it the
 // loop keeps its pointers in SGPRs (the shared kernel reloaded ~100 spilled SGPRs per step through v_readlane).
-template <int F>
+// CNT: the instance counts, run-time (CountsRT: any small layout) or compile-time (CountsCT: the layouts of mgx_fused.hip part 5).
+template <int F, class CNT = CountsRT>
 __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_small_kernel(const KArgs a, const void *__restrict__ actions, int32_t t0, int32_t K,
                                                                          int normalized, const FusedOut out)
 {
@@ -2072,28 +2085,28 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_small_kernel(const K
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
     if (i < a.g1) {
         const int64_t N = a.N;
-        const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
+        const int A = 2 * CNT::ng(a) + CNT::nb(a) + CNT::nr(a);
         const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
         double ret = 0.0;
         MultiRegs R; MultiStepIn cur, nxt;
-        load_multi_regs<F>(a, i, R);
+        load_multi_regs<F, CNT>(a, i, R);
         if (K > 0) {
-            if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + (int64_t)i * A, i, t0, cur);
-            else load_multi_step_in<F>(a, (const double *)actions + (int64_t)i * A, i, t0, cur);
+            if (a.act_f32) load_multi_step_in<F, float, CNT>(a, (const float *)actions + (int64_t)i * A, i, t0, cur);
+            else load_multi_step_in<F, double, CNT>(a, (const double *)actions + (int64_t)i * A, i, t0, cur);
         }
         // two steps per trip: the inputs of step k + 1 are requested into `nxt` before step k runs on `cur`, those of step k + 2 into
         // `cur` before step k + 1 runs on `nxt` -- no copy of 26 doubles per step between the two buffers
         auto fetch = [&](int32_t kk, MultiStepIn &dst) __attribute__((always_inline)) {
             const int32_t kc = kk < K ? kk : K - 1;                  // (past the end: re-read the last step's inputs, unconditional loads)
             const int64_t offc = (int64_t)kc * N + i;
-            if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + offc * A, i, t0 + kc, dst);
-            else load_multi_step_in<F>(a, (const double *)actions + offc * A, i, t0 + kc, dst);
+            if (a.act_f32) load_multi_step_in<F, float, CNT>(a, (const float *)actions + offc * A, i, t0 + kc, dst);
+            else load_multi_step_in<F, double, CNT>(a, (const double *)actions + offc * A, i, t0 + kc, dst);
         };
         auto one_step = [&](int32_t k, const MultiStepIn &in) __attribute__((always_inline)) {
             const int64_t off = (int64_t)k * N + i;
             Outputs o;
             double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
-            step_multi_small<F>(a, R, in, i, normalized != 0, log, o);
+            step_multi_small<F, CNT>(a, R, in, i, normalized != 0, log, o);
             const double r = shaped_reward<F>(a.shaper, o);
             if (out.reward) out.reward[off] = r;
             if (out.done) out.done[off] = (uint8_t)(k >= k_done);
@@ -2109,7 +2122,7 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_small_kernel(const K
             one_step(k + 1, nxt);
         }
         if (k < K) one_step(k, cur);
-        store_multi_state<F>(a, i, R);
+        store_multi_state<F, CNT>(a, i, R);
         if (out.ret_acc) out.ret_acc[i] += ret;
     }
     advance_counter_in_kernel(a, K_launch);

@@ -77,3 +77,44 @@ def test_register_form_equals_the_run_time_count_form(device, tmp_path):
         assert a.shape == b.shape and a.dtype == b.dtype, k
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)) or np.array_equal(a, b), k      # == (zeros may differ in sign)
     assert np.isfinite(small["a_k_reward"]).all() and small["a_k_reward"].std() > 0
+
+
+def test_compile_time_counts_equal_run_time_counts(device):
+    """mgx_step_k on small general layouts: the specialisations with the instance counts fixed at compile time
+    (step_k_multi_small_kernel<F, CountsCT<...>>, mgx_fused.hip part 5) against the run-time-count form of the same kernel
+    (mgx_set_tunable(MGX_TUNE_MULTI_STATIC, 0)): rewards, SoC / status traces, every log column and the final state `==`."""
+    import torch
+    from pymgrid_amd import StepEngine, _lib
+    from pymgrid_amd.generator import generate, widen
+    g = torch.Generator(device=device); g.manual_seed(19)
+    for (ng, nb, nr, nl, npv), arch in (((2, 2, 1, 1, 1), "genset+battery+grid"), ((2, 2, 2, 2, 2), "genset+battery+grid"),
+                                        ((1, 2, 2, 1, 1), "genset+battery+grid"), ((2, 1, 0, 1, 1), "genset+battery"),
+                                        ((0, 2, 1, 1, 1), "battery+grid"), ((2, 2, 1, 2, 1), "genset+battery+grid")):   # (the last: no specialisation)
+        N, T, K = 2100, 80, 33
+
+        def batch():
+            return widen(generate(N, n_steps=T, seed=31, arch=arch, horizon=0, device=device, mixed_timers=True), n_genset=ng, n_battery=nb,
+                         n_grid=nr, n_load=nl, n_pv=npv)
+        res = []
+        acts = None
+        for static in (1, 0):
+            _lib.set_tunable("multi_static", static)
+            try:
+                e = StepEngine(batch())
+                if acts is None:
+                    acts = torch.rand(K, N, e.layout.action_dim, dtype=torch.float64, device=device, generator=g)
+                e.reset(3, want_obs=False)
+                out = e.step_k(acts, normalized=True, reward=True, done=True, soc_trace=True, status_trace=True, log=True)
+                out2 = e.step_k(acts[:7].float().double() * 40, normalized=False, reward=True)        # a second launch from the carried state
+                torch.cuda.synchronize()
+                res.append(({k: v.clone() for k, v in out.items()}, out2["reward"].clone(),
+                            {k: e.batch.cols[k].clone() for k in ("charge", "soc", "gen_status") if k in e.batch.cols}))
+                e.close()
+            finally:
+                _lib.set_tunable("multi_static", 1)
+        (o1, r1, s1), (o0, r0, s0) = res
+        assert set(o1) == set(o0)
+        for k in o1:
+            assert torch.equal(o1[k], o0[k]), ((ng, nb, nr, nl, npv), k)
+        assert torch.equal(r1, r0) and all(torch.equal(s1[k], s0[k]) for k in s1)
+        assert float(o1["reward"].std()) > 0
