@@ -539,6 +539,7 @@ def general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist):
     rows_g = min(args.rows, 1200)                   # materialised series [T, n, N]: 1 200 rows are 10 GB at N = 100 000
     base = generate(n_total, n_steps=rows_g, seed=42, arch="genset+battery+grid", device=dev, rank=rank, world=world)
     gb = widen(base, n_genset=2, n_battery=2, n_grid=1)
+    gb3 = widen(base, n_genset=3, n_battery=3, n_grid=1)     # THREE of a kind: beyond the register form (MS = 2), the run-time-count kernels
     del base
     ge = StepEngine(gb)
     Lg = ge.layout
@@ -586,14 +587,35 @@ def general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist):
                               "roofline": {"bound": "hbm", "achieved": bK_launch / Kg / (gpu / stepsK) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": bK_launch / Kg / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                            "frac_charged_per_step": bK / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS,
-                                           "algorithmic_bytes_per_launch": bK_launch, "kernel": "step_k_multi_small_kernel<7>",
+                                           "algorithmic_bytes_per_launch": bK_launch, "kernel": "step_k_multi_small_kernel<7, CountsCT<2,2,1,1,1>>",
                                            "bytes_per_env_step": bK_launch / Kg / N, "avg_launch_us": gpu / stepsK * Kg * 1e6,
                                            "note": "parameters and state live in LDS for the launch (round 5): charged once per launch; "
                                                    "per step the controls, the series rows and the reward stream"}}
+    out["k_step_launches"]["roofline_valu"] = valu_roofline("step_k_multi_small_kernel<7,mgx::CountsCT<2,2,1,1,1>>", gpu / stepsK * Kg, N, 1, dev)
     out["layout"] = "2 gensets + 2 batteries + 1 grid + load + pv per microgrid (general kernels), materialised series"
     out["grids_per_gpu"], out["rows"] = N, rows_g
     ge.close()
     del ge, gb
+    # three gensets + three batteries + a grid: the K-step launch of the run-time-count form (MicrogridStep's lists in LDS)
+    ge = StepEngine(gb3)
+    L3 = ge.layout
+    aK3 = torch.rand(Kg, N, L3.action_dim, dtype=torch.float64, device=dev, generator=gen)
+    wall, gpu, stepsK = run(lambda: ge.step_k(aK3, normalized=True, reward=True, soc_trace=False), nK, Kg)
+    c_ts3 = L3.n_load + L3.n_pv + 4 * L3.n_grid
+    stream3 = 8 * (L3.action_dim + c_ts3) + 8
+    b3_step = (L3.bytes_per_step() - 1) * N              # this form re-reads parameters and state every step (through the caches)
+    b3_launch = (stream3 * Kg + (L3.bytes_per_step() - 1 - stream3)) * N
+    out["k_step_3_of_a_kind"] = {"value": n_total * stepsK / wall, "us_per_step": gpu / stepsK * 1e6, "steps_per_launch": Kg,
+                                 "roofline": {"bound": "hbm", "achieved": b3_launch / Kg / (gpu / stepsK) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": b3_launch / Kg / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                              "frac_charged_per_step": b3_step / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS,
+                                              "algorithmic_bytes_per_launch": b3_launch, "kernel": "step_k_multi_kernel<7>",
+                                              "bytes_per_env_step": b3_launch / Kg / N, "avg_launch_us": gpu / stepsK * Kg * 1e6,
+                                              "layout": "3 gensets + 3 batteries + 1 grid + load + pv per microgrid",
+                                              "note": "run-time instance counts: MicrogridStep's provided / absorbed lists in LDS, parameters and "
+                                                      "state re-read every step (cache hits); compulsory bytes charged as for the register form"}}
+    ge.close()
+    del ge, gb3
     torch.cuda.empty_cache()
     # Gym steps with whole observation rows (H = 24): rings refilled by the general window kernel (obs_windows_k_multi_kernel;
     # the step adds its 12 state columns) -- per-step rows by one lane per grid were 261 us (profiles/r04/exp_multi_rings.txt)
@@ -625,7 +647,7 @@ def general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist):
     env.close()
     # PMC traffic of the three legs, where a counter pass taken on the kernels now running is committed (tools/gpu_profile_r05.sh)
     tg, tsrc = profile_json("traffic_general.json")
-    for key in ("single_steps", "k_step_launches", "gym_steps_rows_h24"):
+    for key in ("single_steps", "k_step_launches", "gym_steps_rows_h24", "k_step_3_of_a_kind"):
         rf = out[key]["roofline"]
         rf["traffic_source"] = tsrc
         e = (tg or {}).get(key)
@@ -655,6 +677,10 @@ def compact_line(detail, mode, detail_name):
             out["lat"] = r4(q["frac_of_latency_model"])
         if q.get("traffic") is not None and q.get("algorithmic_bytes_per_launch"):
             out["t/a"] = r4(q["traffic"] / q["algorithmic_bytes_per_launch"])
+        rv = r.get("roofline_valu")
+        if rv and rv.get("frac") is not None:       # the issue-side fraction; the leg is bound by whichever ceiling it is closer to
+            out["valu"] = r4(rv["frac"])
+            out["bound"] = "valu" if rv["frac"] > q["frac"] else "hbm"
         return out
     legs = {}
     for name, r in (detail.get("other") or {}).items():
@@ -667,7 +693,8 @@ def compact_line(detail, mode, detail_name):
         if "error" in hetero:
             legs["config5"] = {"error": str(hetero["error"])[:80]}
     if isinstance(general, dict):
-        for k, short in (("single_steps", "general_single_step"), ("k_step_launches", "general_k_step"), ("gym_steps_rows_h24", "general_gym_rows_h24")):
+        for k, short in (("single_steps", "general_single_step"), ("k_step_launches", "general_k_step"), ("gym_steps_rows_h24", "general_gym_rows_h24"),
+                         ("k_step_3_of_a_kind", "general_k_step_3_of_a_kind")):
             if k in general:
                 legs[short] = leg(general[k], "us_per_step")
         if "error" in general:
@@ -800,6 +827,25 @@ def cpu_baseline(eng, pool, seconds):
                       f"({n1 + nall} env-steps on 1 and {best} threads): oracle/mgx_oracle.c (scalar C restatement of "
                       f"the reference loop, OpenMP over tiles of 64 grids); the Python reference itself runs ~2e3 "
                       f"env-steps/s/core (BASELINE.md)"}
+
+
+def valu_roofline(kname, launch_s, grids_per_launch, concurrent, dev):
+    """The issue-side ceiling of a kernel: cycles its waves spent EXECUTING vector-ALU instructions (SQ_ACTIVE_INST_VALU x 4: the
+    counter ticks in quad-cycles; summed over the waves of a launch; a committed PMC pass of this command, profiles/r*/valu.json,
+    taken on the kernels now running) over the VALU cycles the chip had in the launch's duration (SIMDs x shader clock x time,
+    measured live).  1.0 = every SIMD issued a VALU instruction in every cycle.  `concurrent`: launches running side by side."""
+    vj, vsrc = profile_json("valu.json")
+    e = (vj or {}).get("kernels", {}).get(kname.replace(" ", ""))
+    if e is None:
+        return {"bound": "valu", "achieved": None, "peak": None, "unit": "Gcycle/s", "frac": None, "source": vsrc}
+    props = torch.cuda.get_device_properties(dev)
+    simds = 4 * props.multi_processor_count
+    ghz = float(vj.get("sclk_mhz") or 2400.0) * 1e-3
+    per_round = e["valu_active_cycles_per_launch"] * concurrent * (grids_per_launch / e["grids_per_launch"])
+    ach = per_round / launch_s / 1e9
+    return {"bound": "valu", "achieved": ach, "peak": simds * ghz, "unit": "Gcycle/s", "frac": ach / (simds * ghz),
+            "valu_instructions_per_wave_and_env_step": e.get("valu_insts_per_wave_step"), "source": vsrc,
+            "what": "wave-cycles spent executing VALU instructions per second over SIMDs x shader clock"}
 
 
 def measured_traffic(kernel, grids, chunk):
@@ -1011,7 +1057,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": per_launch_bytes, "kernel": kname, "series": "factorised" if fact else "materialised",
                 "uniform_parameter_bytes_per_grid": ub,
-                "bytes_per_env_step": per_launch / (chunk if mode in ("fused", "rbc") else 1),
+                "bytes_per_env_step": per_launch / (chunk if mode in ("fused", "rbc", "fused_rich") else 1),
                 "launches": launches, "avg_launch_us": avg_launch_s * 1e6, "avg_launch_us_wall": wall_launch_s * 1e6,
                 "timed_rounds": [first, first + rounds]}
         if mode in ("step", "step_env", "step_full") and not sharded:
@@ -1045,24 +1091,8 @@ def main():
                             "it is bound by fp64 VALU issue, not by HBM -- see roofline_valu; the HBM fraction is reported for "
                             "completeness, the materialised form is the bandwidth-bound one")
         if mode in ("fused", "rbc", "fused_rich"):
-            # The issue-side ceiling: cycles the kernel's waves spent EXECUTING vector-ALU instructions (SQ_ACTIVE_INST_VALU x 4:
-            # the counter ticks in quad-cycles; summed over the waves of a launch; a committed PMC pass of this command) over the
-            # VALU cycles the chip had in the launch's duration (SIMDs x shader clock x time, measured live).  1.0 = every SIMD
-            # issued a VALU instruction in every cycle.
-            vj, vsrc = profile_json("valu.json")
-            e = (vj or {}).get("kernels", {}).get(kname.replace(" ", ""))
-            if e is not None:
-                props = torch.cuda.get_device_properties(dev)
-                simds = 4 * props.multi_processor_count
-                ghz = float(vj.get("sclk_mhz") or 2400.0) * 1e-3
-                # counters are per KERNEL launch (n_launch grids); a round runs S of them side by side
-                per_round = e["valu_active_cycles_per_launch"] * (S if sharded else 1) * (n_launch / e["grids_per_launch"])
-                ach = per_round / avg_launch_s / 1e9
-                roof_valu = {"bound": "valu", "achieved": ach, "peak": simds * ghz, "unit": "Gcycle/s", "frac": ach / (simds * ghz),
-                             "valu_instructions_per_wave_and_env_step": e.get("valu_insts_per_wave_step"), "source": vsrc,
-                             "what": "wave-cycles spent executing VALU instructions per second over SIMDs x shader clock"}
-            else:
-                roof_valu = {"bound": "valu", "achieved": None, "peak": None, "unit": "Gcycle/s", "frac": None, "source": vsrc}
+            # the issue-side ceiling (counters are per KERNEL launch of n_launch grids; a round runs S of them side by side)
+            roof_valu = valu_roofline(kname, avg_launch_s, n_launch, S if sharded else 1, dev)
         else:
             roof_valu = None
         run.shard(False)
@@ -1151,7 +1181,7 @@ def main():
 
     # The GENERAL path: 2 gensets + 2 batteries + 1 grid per microgrid (module_container.py:355-413 allows any multiplicity)
     general = None
-    if not args.no_side_modes:
+    if not args.no_side_modes and (args.legs is None or "general" in args.legs.split(",")):
         general = guarded("general_path_2g2b1grid", lambda: general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist))
         torch.cuda.empty_cache()
 

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Copy what tools/gpu_profile_r05.sh left under gpurun_out/prof_<tag>/ into profiles/<tag>/ (the tracked, judged place).
+# Copy what tools/gpu_profile_r06.sh left under gpurun_out/prof_<tag>/ into profiles/<tag>/ (the tracked, judged place).
 # usage: tools/copy_profiles.sh [tag]
 set -eu
-TAG=${1:-r05}
+TAG=${1:-r06}
 P=gpurun_out/prof_$TAG; D=profiles/$TAG
 mkdir -p "$D"
 cp $P/traffic.json $P/valu.json $P/traffic_fleet_*.json $P/traffic_general.json $P/csrc_hash.txt "$D"/

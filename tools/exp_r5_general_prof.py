@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The general path (2 gensets + 2 batteries + 1 grid per microgrid, 100 000 grids) one leg at a time -- for rocprofv3 counter passes:
-   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -- python tools/exp_r5_general_prof.py single|kstep|gymrows [steps]
+   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -- python tools/exp_r5_general_prof.py single|kstep|kstep3|gymrows [steps]
 The same shapes as bench.py's general_path_leg: single Gym steps (step_multi_kernel), K = 32 fused steps per launch
 (step_k_multi_kernel), Gym steps with 24-hour rows off rings of 32 blocks (step_multi_kernel + obs_windows_k_multi_kernel)."""
 import os
@@ -17,8 +17,9 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 dev = torch.device("cuda:0")
 N = 100_000
 gen = torch.Generator(device=dev); gen.manual_seed(3)
-if leg in ("single", "kstep"):
-    gb = widen(generate(N, n_steps=1200, seed=42, arch="genset+battery+grid", device=dev), n_genset=2, n_battery=2, n_grid=1)
+if leg in ("single", "kstep", "kstep3"):
+    n_kind = 3 if leg == "kstep3" else 2            # kstep3: three gensets + three batteries (the run-time-count K-step kernel)
+    gb = widen(generate(N, n_steps=1200, seed=42, arch="genset+battery+grid", device=dev), n_genset=n_kind, n_battery=n_kind, n_grid=1)
     ge = StepEngine(gb)
     A = ge.layout.action_dim
     if leg == "single":
