@@ -645,7 +645,7 @@ def general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist):
                                               "algorithmic_bytes_per_launch": bo, "kernel": "step_multi_kernel<7> + obs_windows_k_multi_kernel<7, double>",
                                               "bytes_per_env_step": bo // N}}
     env.close()
-    # PMC traffic of the three legs, where a counter pass taken on the kernels now running is committed (tools/gpu_profile_r05.sh)
+    # PMC traffic of the three legs, where a counter pass taken on the kernels now running is committed (tools/gpu_profile_r06.sh)
     tg, tsrc = profile_json("traffic_general.json")
     for key in ("single_steps", "k_step_launches", "gym_steps_rows_h24", "k_step_3_of_a_kind"):
         rf = out[key]["roofline"]
@@ -850,7 +850,7 @@ def valu_roofline(kname, launch_s, grids_per_launch, concurrent, dev):
 
 def measured_traffic(kernel, grids, chunk):
     """HBM bytes per launch of the kernel specialisation `kernel` ("step_k_kernel<3,4,double,false,true>"; a launch over `grids`
-    grids and `chunk` steps) from the committed rocprofv3 PMC passes of THIS command (tools/gpu_profile.sh ->
+    grids and `chunk` steps) from the committed rocprofv3 PMC passes of THIS command (tools/gpu_profile_r06.sh ->
     profiles/<round>/traffic.json); None when no profile of that specialisation and launch shape is committed."""
     import glob
     want = kernel.replace(" ", "")

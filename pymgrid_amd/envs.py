@@ -201,7 +201,7 @@ class BatchedMicrogridEnv:
                             torch.ones(L.n_grids, dtype=torch.bool, device=batch.device))
         # reuse_outputs = R > 0: step() returns reward (and, without rings / views, the observation rows) as R rotating
         # preallocated buffers -- valid for R - 1 further steps -- instead of fresh tensors: two allocator calls (~2.5 us of the
-        # ~8 us a step costs on the host, tools/exp_closed_loop_host.py) less per step.  0: fresh tensors, as the reference returns
+        # ~8 us a step costs on the host, tools/archive/exp_closed_loop_host.py) less per step.  0: fresh tensors, as the reference returns
         self._reuse = int(reuse_outputs)
         self._out_pos = 0
         self._rew_bufs = self._obs_bufs = self._done_bufs = None
