@@ -1602,7 +1602,8 @@ int mgx_step_k(mgx_handle *h, const void *actions, int32_t K, int normalized, do
         const bool own_kernel = tune(MGX_TUNE_MULTI_SMALL_OWN) != 0;
         const bool static_counts = tune(MGX_TUNE_MULTI_STATIC) != 0;
         for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
-            if (h->multi_small && own_kernel && static_counts) {      // ... with compile-time instance counts where the layout has them
+            if (own_kernel && static_counts && k.n_load >= 1 && k.n_pv >= 1) {   // ... with compile-time instance counts where the layout has them
+                // (also layouts with THREE modules of a kind: beyond the run-time-count register form, h->multi_small == 0)
                 MultiStaticLaunch L{h->flags, k.n_genset, k.n_battery, k.n_grid, k.n_load, k.n_pv, multi_blocks(k.g1 - k.g0), s, &k, actions,
                                     t_arg(h), K, normalized, fo};
                 if (launch_step_k_multi_static(L)) return;
@@ -1967,20 +1968,27 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
             if (int rc = windows_plan(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, "mgx_fleet_step", &plan, &lds, &ng)) return rc;
         }
     }
-    // one launch for all batches (continuous and discrete items alike) unless an item needs a kernel of its own
-    bool fusable = true;
-    for (int32_t j = 0; j < n && fusable; j++) {
+    // One launch for all batches (continuous and discrete items alike) that can share it; an item that needs kernels of its own
+    // (several modules of a kind, rolling windows, a device counter, shards, per-step rows with a horizon) is stepped beside it --
+    // the others still share their launch (round 6: one such bucket used to send EVERY bucket of the fleet to its own launch).
+    if (n > 64) return fail(MGX_ERR_INVALID, "mgx_fleet_step: at most 64 items per call");
+    bool fuse[64];
+    int32_t fz[64], nf = 0;                                 // the items that share the launch, in item order
+    for (int32_t j = 0; j < n; j++) {
         const mgx_fleet_item &it = items[j];
         const mgx_handle *h = it.handle;
-        fusable = !h->multi && !h->rolling && !dev_counter(h) && h->n_shards <= 1 && !(it.obs && h->k.H > 0 && !h->k.obs_state_only);
-        for (int32_t q = 0; q < j && fusable; q++) fusable = items[q].handle != it.handle;      // a batch steps once per call
+        fuse[j] = !h->multi && !h->rolling && !dev_counter(h) && h->n_shards <= 1 && !(it.obs && h->k.H > 0 && !h->k.obs_state_only);
+        for (int32_t q = 0; q < j; q++)
+            if (items[q].handle == it.handle) return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d steps the batch of item %d again", j, q);
+        if (fuse[j]) fz[nf++] = j;
     }
     bool chunk_done[64];                                    // window chunks that rode along with the step launch
-    for (int32_t j = 0; j < n && j < 64; j++) chunk_done[j] = false;
+    for (int32_t j = 0; j < n; j++) chunk_done[j] = false;
     for (int32_t j = 0; j < n; j++)
         if (items[j].wait_prefetch) { if (int rc = mgx_prefetch_wait(items[j].handle, stream)) return rc; }
-    if (fusable) {
-        for (int32_t j = 0; j < n; j++) {                 // device copies of the batches' KArgs: uploaded when they changed
+    if (nf > 0) {
+        for (int32_t z = 0; z < nf; z++) {                // device copies of the batches' KArgs: uploaded when they changed
+            const int32_t j = fz[z];
             if (int rc = sync_device_kargs(items[j].handle, st, "mgx_fleet_step: uploading the layout table")) return rc;
             if (!items[j].action_id) continue;            // discrete item: its priority-list table, too
             mgx_handle *h = items[j].handle;
@@ -1997,17 +2005,17 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
         }
         // MGX_TUNE_FLEET_BYVALUE = 0 keeps the pointer form of the kernel for every launch (A/B)
         const bool by_value = tune(MGX_TUNE_FLEET_BYVALUE) != 0;
-        for (int32_t j0 = 0; j0 < n; j0 += MGX_FLEET_MAX) {
-            const int32_t nb = n - j0 < MGX_FLEET_MAX ? n - j0 : MGX_FLEET_MAX;
+        for (int32_t z0 = 0; z0 < nf; z0 += MGX_FLEET_MAX) {
+            const int32_t nb = nf - z0 < MGX_FLEET_MAX ? nf - z0 : MGX_FLEET_MAX;
             bool chunks = !by_value;                       // window chunks riding along with this launch (refill="chunks")?
-            for (int32_t q = 0; q < nb && !chunks; q++) chunks = items[j0 + q].refill_ring && items[j0 + q].refill_chunks > 0;
+            for (int32_t q = 0; q < nb && !chunks; q++) chunks = items[fz[z0 + q]].refill_ring && items[fz[z0 + q]].refill_chunks > 0;
             if (!chunks) {
                 // the buckets' KArgs by value, the bucket = blockIdx.y (fleet_step_kernel_v): unused buckets stay unwritten, never read
                 FleetArgsV fv;
                 fv.n = nb; fv.normalized = normalized; fv.pad0 = fv.pad1 = 0;
                 int32_t most = 0;
                 for (int32_t q = 0; q < nb; q++) {
-                    const mgx_fleet_item &it = items[j0 + q];
+                    const mgx_fleet_item &it = items[fz[z0 + q]];
                     const mgx_handle *h = it.handle;
                     FleetBucket &B = fv.b[q];
                     B.k = h->k;
@@ -2032,19 +2040,20 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
             int32_t blocks = 0, wblocks = 0;
             size_t lds_max = 0;
             for (int32_t q = 0; q < fa.n; q++) {
-                const mgx_fleet_item &it = items[j0 + q];
+                const int32_t j = fz[z0 + q];
+                const mgx_fleet_item &it = items[j];
                 mgx_handle *h = it.handle;
                 fa.k[q] = h->d_kargs;
                 fa.tab[q] = it.action_id ? h->d_table : nullptr;
                 fa.actions[q] = it.action_id ? (const void *)it.action_id : it.actions; fa.reward[q] = it.reward; fa.done[q] = it.done; fa.obs[q] = it.obs; fa.log[q] = it.log;
                 fa.t[q] = h->t; fa.flags[q] = h->flags; fa.block0[q] = blocks;
                 blocks += (int32_t)blocks_for(h->k.N);
-                if (it.refill_ring && it.refill_chunks > 0 && j0 + q < 64) {        // this step's share of the next ring
+                if (it.refill_ring && it.refill_chunks > 0) {                        // this step's share of the next ring
                     WindowsKPlan plan; size_t lds; int32_t ng, first, count;
                     (void)windows_plan(h, it.refill_ahead, it.refill_K, it.refill_ring, "mgx_fleet_step", &plan, &lds, &ng);
                     if (lds > 64 * 1024) continue;                                   // launched on its own below
                     chunk_range(ng, it.refill_chunk, it.refill_chunks, &first, &count);
-                    chunk_done[j0 + q] = true;
+                    chunk_done[j] = true;
                     if (count <= 0) continue;
                     const int w = fw.n++;
                     plan.group0 = first;
@@ -2062,9 +2071,10 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hip_fail(e, "fleet_step_kernel launch");
         }
-        for (int32_t j = 0; j < n; j++) advance(items[j].handle, 1, st);
+        for (int32_t z = 0; z < nf; z++) advance(items[fz[z]].handle, 1, st);
     }
-    for (int32_t j = 0; j < n && !fusable; j++) {
+    for (int32_t j = 0; j < n; j++) {                     // the items with kernels of their own
+        if (fuse[j]) continue;
         const mgx_fleet_item &it = items[j];
         int rc;
         if (it.action_id)
@@ -2077,7 +2087,7 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
     hipStream_t gated = nullptr;
     for (int32_t j = 0; j < n; j++) {                       // window prefetch that did not ride along with the step launch
         const mgx_fleet_item &it = items[j];
-        if (!it.refill_ring || (j < 64 && chunk_done[j])) continue;
+        if (!it.refill_ring || chunk_done[j]) continue;
         int rc;
         if (it.refill_chunks > 0)                           // a chunk, on the caller's stream (the counter has advanced: ahead as given)
             rc = launch_windows(it.handle, it.refill_ahead, it.refill_K, it.refill_ring, st, "mgx_fleet_step", it.refill_chunk, it.refill_chunks);

@@ -782,31 +782,41 @@ __device__ __forceinline__ double shaped_reward(int32_t shaper, const Outputs &o
 
 // ---- log row ------------------------------------------------------------------------------------------
 // log points at column 0 of grid i; consecutive columns are N apart.
+// the log's column stores: write-once streams, non-temporal (full-output fused launch 334 -> 321 us per 64 steps, single step with
+// rows + log 11.8 -> 10.8 us: profiles/r06/exp_log_nt_stores.txt; -DMGX_LOG_NT=0 for plain stores)
+#ifndef MGX_LOG_NT
+#define MGX_LOG_NT 1
+#endif
+#if MGX_LOG_NT
+#define MGX_LOG_ST(ptr, v) __builtin_nontemporal_store((double)(v), (ptr))
+#else
+#define MGX_LOG_ST(ptr, v) (*(ptr) = (v))
+#endif
 template <int F>
 __device__ __forceinline__ void store_log(double *__restrict__ log, int64_t N, const Outputs &o, uint32_t status)
 {
     int k = 0;
-    log[(k++) * N] = o.reward;
-    log[(k++) * N] = o.fixed_provided;   log[(k++) * N] = o.fixed_absorbed;
-    log[(k++) * N] = o.ctrl_provided;    log[(k++) * N] = o.ctrl_absorbed;
-    log[(k++) * N] = o.overall_provided; log[(k++) * N] = o.overall_absorbed;
-    log[(k++) * N] = o.load_met;         log[(k++) * N] = o.renewable_used;
-    log[(k++) * N] = o.curtailment;      log[(k++) * N] = o.loss_load;
-    log[(k++) * N] = o.overgeneration;   log[(k++) * N] = o.unbalanced_reward;
+    MGX_LOG_ST(log + (k++) * N, o.reward);
+    MGX_LOG_ST(log + (k++) * N, o.fixed_provided);   MGX_LOG_ST(log + (k++) * N, o.fixed_absorbed);
+    MGX_LOG_ST(log + (k++) * N, o.ctrl_provided);    MGX_LOG_ST(log + (k++) * N, o.ctrl_absorbed);
+    MGX_LOG_ST(log + (k++) * N, o.overall_provided); MGX_LOG_ST(log + (k++) * N, o.overall_absorbed);
+    MGX_LOG_ST(log + (k++) * N, o.load_met);         MGX_LOG_ST(log + (k++) * N, o.renewable_used);
+    MGX_LOG_ST(log + (k++) * N, o.curtailment);      MGX_LOG_ST(log + (k++) * N, o.loss_load);
+    MGX_LOG_ST(log + (k++) * N, o.overgeneration);   MGX_LOG_ST(log + (k++) * N, o.unbalanced_reward);
     if constexpr (F & F_GENSET) {
-        log[(k++) * N] = o.genset_production; log[(k++) * N] = o.genset_co2;
-        log[(k++) * N] = o.genset_reward;     log[(k++) * N] = (double)status;   // packed word, exact in fp64
+        MGX_LOG_ST(log + (k++) * N, o.genset_production); MGX_LOG_ST(log + (k++) * N, o.genset_co2);
+        MGX_LOG_ST(log + (k++) * N, o.genset_reward);     MGX_LOG_ST(log + (k++) * N, (double)status);   // packed word, exact in fp64
     }
     if constexpr (F & F_BATTERY) {
-        log[(k++) * N] = o.discharge_amount;  log[(k++) * N] = o.charge_amount;
-        log[(k++) * N] = o.battery_reward;    log[(k++) * N] = o.soc_pre;
-        log[(k++) * N] = o.charge_pre;
+        MGX_LOG_ST(log + (k++) * N, o.discharge_amount);  MGX_LOG_ST(log + (k++) * N, o.charge_amount);
+        MGX_LOG_ST(log + (k++) * N, o.battery_reward);    MGX_LOG_ST(log + (k++) * N, o.soc_pre);
+        MGX_LOG_ST(log + (k++) * N, o.charge_pre);
     }
     if constexpr (F & F_GRID) {
-        log[(k++) * N] = o.grid_import;       log[(k++) * N] = o.grid_export;
-        log[(k++) * N] = o.grid_co2;          log[(k++) * N] = o.grid_reward;
+        MGX_LOG_ST(log + (k++) * N, o.grid_import);       MGX_LOG_ST(log + (k++) * N, o.grid_export);
+        MGX_LOG_ST(log + (k++) * N, o.grid_co2);          MGX_LOG_ST(log + (k++) * N, o.grid_reward);
     }
-    log[(k++) * N] = (double)o.violations;
+    MGX_LOG_ST(log + (k++) * N, (double)o.violations);
 }
 
 // ---- observation (post-step state, series index t = current step) --------------------------------------
@@ -1286,10 +1296,19 @@ struct CountsRT {
     static __device__ __forceinline__ int nr(const KArgs &a) { return a.n_grid; }
     static __device__ __forceinline__ int nl(const KArgs &a) { return a.n_load; }
     static __device__ __forceinline__ int np(const KArgs &a) { return a.n_pv; }
+    static constexpr bool is_static = false;
+    static constexpr int max_prov = 0, max_absb = 0, max_mid_prov = 0, max_mid_absb = 0;   // (unused: the slot counts decide)
 };
+constexpr int MS_CT = 3;     // most instance slots a compile-time-count specialisation may hold
 template <int NG_, int NB_, int NR_, int NL_, int NP_>
 struct CountsCT {
-    static_assert(NG_ <= MS && NB_ <= MS && NR_ <= MS && NL_ >= 1 && NL_ <= MS && NP_ >= 1 && NP_ <= MS, "the register form holds MS instances");
+    static_assert(NG_ <= MS_CT && NB_ <= MS_CT && NR_ <= MS_CT && NL_ >= 1 && NL_ <= MS_CT && NP_ >= 1 && NP_ <= MS_CT, "the register form holds M instances");
+    static constexpr int slots = (NG_ > MS || NB_ > MS || NR_ > MS || NL_ > MS || NP_ > MS) ? MS_CT : MS;     // M of the kernel
+    static constexpr bool is_static = true;
+    // most addends MicrogridStep's lists can hold: at the end of the sweep (gensets / discharging batteries / importing grids / renewables /
+    // loss load; loads / charging batteries / exporting grids / overgeneration) and after the controllable modules (:277)
+    static constexpr int max_prov = NG_ + NB_ + NR_ + NP_ + 1, max_absb = NL_ + NB_ + NR_ + 1, max_mid_prov = NG_ + NB_ + NR_,
+                         max_mid_absb = NL_ + NB_ + NR_;
     static __device__ __forceinline__ constexpr int ng(const KArgs &) { return NG_; }
     static __device__ __forceinline__ constexpr int nb(const KArgs &) { return NB_; }
     static __device__ __forceinline__ constexpr int nr(const KArgs &) { return NR_; }
@@ -1297,33 +1316,39 @@ struct CountsCT {
     static __device__ __forceinline__ constexpr int np(const KArgs &) { return NP_; }
 };
 
-struct MultiRegs {                       // parameters + dynamic state of one grid (per instance)
-    double g_rmin[MS], g_rmax[MS], g_cost[MS], g_co2[MS], g_cco2[MS];
-    uint32_t g_times[MS], g_status[MS];
-    double b_cmin[MS], b_cmax[MS], b_C[MS], b_D[MS], b_eta[MS], b_cost[MS], b_charge[MS], b_soc[MS];
-    double r_imp[MS], r_exp[MS], r_cco2[MS];
+// M: instance slots per kind the register form holds (MS for the run-time-count form; the compile-time-count specialisations of
+// layouts with three modules of a kind use 3 -- slots a layout does not have cost nothing there)
+template <int M>
+struct MultiRegsT {                      // parameters + dynamic state of one grid (per instance)
+    double g_rmin[M], g_rmax[M], g_cost[M], g_co2[M], g_cco2[M];
+    uint32_t g_times[M], g_status[M];
+    double b_cmin[M], b_cmax[M], b_C[M], b_D[M], b_eta[M], b_cost[M], b_charge[M], b_soc[M];
+    double r_imp[M], r_exp[M], r_cco2[M];
     double ll_cost, og_cost;
-    Derived d_gen[MS], d_bat[MS], d_grid[MS];   // the step-invariant values of every instance (derive: once per launch, not per step)
+    Derived d_gen[M], d_bat[M], d_grid[M];      // the step-invariant values of every instance (derive: once per launch, not per step)
 };
+using MultiRegs = MultiRegsT<MS>;
 
-struct MultiStepIn {                     // what one step reads besides: controls and series rows
-    double goal[MS], gen[MS], bat[MS], grd[MS];
-    double load[MS], pv[MS], grid[MS][4];
+template <int M>
+struct MultiStepInT {                    // what one step reads besides: controls and series rows
+    double goal[M], gen[M], bat[M], grd[M];
+    double load[M], pv[M], grid[M][4];
 };
+using MultiStepIn = MultiStepInT<MS>;
 
 __host__ __device__ inline bool multi_is_small(int n_load, int n_pv, int n_genset, int n_battery, int n_grid)
 {
     return n_load >= 1 && n_pv >= 1 && n_load <= MS && n_pv <= MS && n_genset <= MS && n_battery <= MS && n_grid <= MS;
 }
 
-template <int F, class CNT = CountsRT>
-__device__ __forceinline__ void load_multi_regs(const KArgs &a, int64_t i, MultiRegs &R)
+template <int F, class CNT = CountsRT, int M = MS>
+__device__ __forceinline__ void load_multi_regs(const KArgs &a, int64_t i, MultiRegsT<M> &R)
 {
     const int64_t N = a.N;
     const mgx_columns &c = a.c;
     const int NG = CNT::ng(a), NB = CNT::nb(a), NR = CNT::nr(a);
 #pragma unroll
-    for (int j = 0; j < MS; j++) {
+    for (int j = 0; j < M; j++) {
         if constexpr (F & F_GENSET) {
             const int64_t q = (int64_t)(j < NG ? j : NG - 1) * N + i;
             R.g_rmin[j] = c.gen_running_min[q]; R.g_rmax[j] = c.gen_running_max[q]; R.g_cost[j] = c.gen_cost[q];
@@ -1344,7 +1369,7 @@ __device__ __forceinline__ void load_multi_regs(const KArgs &a, int64_t i, Multi
     R.ll_cost = c.loss_load_cost[i]; R.og_cost = c.overgeneration_cost[i];
     // the action-space constants of every instance: the same operations on the same operands as a derive per step, hence the same bits
 #pragma unroll
-    for (int j = 0; j < MS; j++) {
+    for (int j = 0; j < M; j++) {
         Params p;
         if constexpr (F & F_GENSET) { p.gen_rmax = R.g_rmax[j]; derive<F_GENSET>(p, R.d_gen[j]); }
         if constexpr (F & F_BATTERY) { p.bat_D = R.b_D[j]; p.bat_eta = R.b_eta[j]; p.bat_C = R.b_C[j]; derive<F_BATTERY>(p, R.d_bat[j]); }
@@ -1353,24 +1378,24 @@ __device__ __forceinline__ void load_multi_regs(const KArgs &a, int64_t i, Multi
 }
 
 // the dynamic state back into the batch's columns
-template <int F, class CNT = CountsRT>
-__device__ __forceinline__ void store_multi_state(const KArgs &a, int64_t i, const MultiRegs &R)
+template <int F, class CNT = CountsRT, int M = MS>
+__device__ __forceinline__ void store_multi_state(const KArgs &a, int64_t i, const MultiRegsT<M> &R)
 {
     const int64_t N = a.N;
 #pragma unroll
-    for (int j = 0; j < MS; j++) {
+    for (int j = 0; j < M; j++) {
         if constexpr (F & F_GENSET) { if (j < CNT::ng(a)) a.c.gen_status[(int64_t)j * N + i] = R.g_status[j]; }
         if constexpr (F & F_BATTERY) { if (j < CNT::nb(a)) { a.c.charge[(int64_t)j * N + i] = R.b_charge[j]; a.c.soc[(int64_t)j * N + i] = R.b_soc[j]; } }
     }
 }
 
-template <int F, typename AT, class CNT = CountsRT>
-__device__ __forceinline__ void load_multi_step_in(const KArgs &a, const AT *__restrict__ act, int64_t i, int32_t t, MultiStepIn &in)
+template <int F, typename AT, class CNT = CountsRT, int M = MS>
+__device__ __forceinline__ void load_multi_step_in(const KArgs &a, const AT *__restrict__ act, int64_t i, int32_t t, MultiStepInT<M> &in)
 {
     const int64_t N = a.N;
     const int NG = CNT::ng(a), NB = CNT::nb(a), NR = CNT::nr(a), NL = CNT::nl(a), NP = CNT::np(a);
 #pragma unroll
-    for (int j = 0; j < MS; j++) {
+    for (int j = 0; j < M; j++) {
         if constexpr (F & F_GENSET) { const int q = j < NG ? j : NG - 1; in.goal[j] = (double)act[2 * q]; in.gen[j] = (double)act[2 * q + 1]; }
         if constexpr (F & F_BATTERY) { const int q = j < NB ? j : NB - 1; in.bat[j] = (double)act[2 * NG + q]; }
         if constexpr (F & F_GRID) {
@@ -1393,6 +1418,31 @@ __device__ __forceinline__ void load_multi_step_in(const KArgs &a, const AT *__r
 constexpr int SMALL_PROV = 4 * MS + 1, SMALL_ABSB = 3 * MS + 1;
 static_assert(MS == 2, "small_pairwise_prov assumes at most 9 addends: one unset slot at 8");
 
+// The same for ANY number of slots (M = 3: 13 provided slots, 10 absorbed ones): the set slots in slot order are the list np.sum sees;
+// with n >= 8 addends numpy sums the first eight pairwise and adds the rest one by one (np_sum_strided, n < 16).  The addends are
+// compacted into registers with compile-time-unrolled selects on a running count (no indexed register arrays: they would live in scratch).
+template <int NSLOT>
+__device__ __forceinline__ double slots_pairwise_sum(const double (&e)[NSLOT], uint32_t mask, int n)
+{
+    static_assert(NSLOT <= 15, "one pairwise block of eight + a tail of at most seven addends");
+    constexpr int NT = NSLOT > 8 ? NSLOT - 8 : 1;
+    double r[8] = {}, tail[NT] = {};
+    int c = 0;
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; sl++) {
+        const bool on = (mask >> sl) & 1u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) r[q] = (on && c == q) ? e[sl] : r[q];
+#pragma unroll
+        for (int q = 0; q < NT; q++) tail[q] = (on && c == 8 + q) ? e[sl] : tail[q];
+        c += on ? 1 : 0;
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int q = 0; q < NT; q++) if (8 + q < n) res += tail[q];
+    return res;
+}
+
 // `provided` with 8 or 9 addends (n = popcount(mask) >= 8: at most one of the nine slots unset): numpy's pairwise order over the
 // first eight, the ninth added last (np_sum_strided).  Below eight addends -- always for `absorbed`, SMALL_ABSB = 7 -- numpy's sum
 // is the running sum from 0.0 in list order, which the sweep keeps as it appends (the slots are in append order).
@@ -1409,8 +1459,8 @@ __device__ __forceinline__ double small_pairwise_prov(const double (&e)[SMALL_PR
     return res;
 }
 
-template <int F, class CNT = CountsRT>
-__device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, const MultiStepIn &sin, int64_t i, bool normalized,
+template <int F, class CNT = CountsRT, int M = MS>
+__device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &R, const MultiStepInT<M> &sin, int64_t i, bool normalized,
                                                  double *__restrict__ log, Outputs &o)
 {
     const int64_t N = a.N;
@@ -1421,17 +1471,26 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     // eight addends IS the running sum from 0.0 in list order) + one static slot per possible `provided` addend in sweep order with a
     // presence bit each, for the one sum that can see 8 or 9 addends -- the run-time form appends to LDS columns and sums them with a
     // dependent LDS read per addend.
-    constexpr int SB = (F & F_GRID_FIRST) ? 2 * MS : MS, SR = (F & F_GRID_FIRST) ? MS : 2 * MS;     // first battery / grid slot
-    double pe[SMALL_PROV] = {};                           // (the addends themselves: only the 8-or-9-addend sum needs them again)
+    constexpr int SB = (F & F_GRID_FIRST) ? 2 * M : M, SR = (F & F_GRID_FIRST) ? M : 2 * M;     // first battery / grid slot
+    constexpr int NPROV = 4 * M + 1, NABSB = 3 * M + 1;   // slots of the provided / absorbed lists
+    // The addends themselves are kept only where a list CAN reach the eight addends from which numpy sums pairwise: by the slot counts
+    // with run-time instance counts, by the layout's own maxima with compile-time ones (2 g + 2 b + 1 grid: 7 provided addends at
+    // most -- no slots at all, every sum is the running sum)
+    constexpr bool TRACK_P = CNT::is_static ? CNT::max_prov >= 8 : NPROV >= 8, TRACK_A = CNT::is_static ? CNT::max_absb >= 8 : NABSB >= 8;
+    constexpr bool MID_P = CNT::is_static ? CNT::max_mid_prov >= 8 : 3 * M >= 8, MID_A = CNT::is_static ? CNT::max_mid_absb >= 8 : 3 * M >= 8;
+    double pe[TRACK_P ? NPROV : 1] = {};
+    double ae[TRACK_A ? NABSB : 1] = {};
+    uint32_t am = 0u;
     uint32_t pm = 0u;
     double psum = 0.0, asum = 0.0;                            // running sums of the two lists, from 0.0 in append order
     o.load_met = 0.0;
 #pragma unroll
-    for (int j = 0; j < MS; j++) {                        // fixed modules, module order (microgrid.py:255-257)
+    for (int j = 0; j < M; j++) {                        // fixed modules, module order (microgrid.py:255-257)
         if (j < NL) {
             const double Lv = -1 * sin.load[j];
             o.load_met += Lv;
             asum += Lv; reward += 0.0;
+            if constexpr (TRACK_A) { ae[j] = Lv; am |= 1u << j; }
         }
     }
     o.fixed_provided = psum;                                // :259-260 (an empty list: 0.0)
@@ -1442,7 +1501,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     Outputs oc;
     if constexpr (F & F_GENSET) {
 #pragma unroll
-        for (int j = 0; j < MS; j++) {
+        for (int j = 0; j < M; j++) {
             if (j < NG) {
                 Params p; Derived d; State s;
                 p.gen_rmin = R.g_rmin[j]; p.gen_rmax = R.g_rmax[j]; p.gen_cost = R.g_cost[j]; p.gen_co2 = R.g_co2[j];
@@ -1452,7 +1511,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 in.a_goal = sin.goal[j]; in.a_gen = sin.gen[j];
                 step_core<F_GENSET>(p, d, s, in, normalized, false, false, oc);
                 R.g_status[j] = s.status;
-                pe[j] = oc.genset_production; pm |= 1u << j; psum += oc.genset_production; reward += oc.genset_reward; viol |= oc.violations;
+                if constexpr (TRACK_P) { pe[j] = oc.genset_production; pm |= 1u << j; } psum += oc.genset_production; reward += oc.genset_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kg + LC_GENSET_N * j) * N;
                     q[0] = oc.genset_production; q[N] = oc.genset_co2; q[2 * N] = oc.genset_reward; q[3 * N] = (double)s.status;
@@ -1463,7 +1522,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     double discharge_sum = 0.0; bool any_sink = false;   // BatteryDischargeShaper's sum (step_multi_core)
     auto step_batteries = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < MS; j++) {
+        for (int j = 0; j < M; j++) {
             if (j < NB) {
                 Params p; Derived d; State s;
                 p.bat_cmin = R.b_cmin[j]; p.bat_cmax = R.b_cmax[j]; p.bat_C = R.b_C[j]; p.bat_D = R.b_D[j];
@@ -1474,8 +1533,11 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 step_core<F_BATTERY>(p, d, s, in, normalized, true, false, oc);
                 R.b_charge[j] = s.charge; R.b_soc[j] = s.soc;
                 const double x = normalized ? d.bat_lo + d.bat_sp * in.a_bat : in.a_bat;
-                if (x < 0) { asum += oc.charge_amount; any_sink = true; }
-                else { pe[SB + j] = oc.discharge_amount; pm |= 1u << (SB + j); psum += oc.discharge_amount; discharge_sum += oc.discharge_amount; }
+                if (x < 0) {
+                    asum += oc.charge_amount; any_sink = true;
+                    if constexpr (TRACK_A) { ae[SB + j] = oc.charge_amount; am |= 1u << (SB + j); }
+                }
+                else { if constexpr (TRACK_P) { pe[SB + j] = oc.discharge_amount; pm |= 1u << (SB + j); } psum += oc.discharge_amount; discharge_sum += oc.discharge_amount; }
                 reward += oc.battery_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kb + LC_BATTERY_N * j) * N;
@@ -1487,7 +1549,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     };
     auto step_grids = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < MS; j++) {
+        for (int j = 0; j < M; j++) {
             if (j < NR) {
                 Params p; Derived d; State s;
                 p.grid_imp = R.r_imp[j]; p.grid_exp = R.r_exp[j]; p.grid_cco2 = R.r_cco2[j];
@@ -1497,8 +1559,11 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
                 in.a_grid = sin.grd[j];
                 step_core<F_GRID>(p, d, s, in, normalized, false, false, oc);
                 const double x = normalized ? d.grid_lo + d.grid_sp * in.a_grid : in.a_grid;
-                if (x < 0) asum += oc.grid_export;
-                else { pe[SR + j] = oc.grid_import; pm |= 1u << (SR + j); psum += oc.grid_import; }
+                if (x < 0) {
+                    asum += oc.grid_export;
+                    if constexpr (TRACK_A) { ae[SR + j] = oc.grid_export; am |= 1u << (SR + j); }
+                }
+                else { if constexpr (TRACK_P) { pe[SR + j] = oc.grid_import; pm |= 1u << (SR + j); } psum += oc.grid_import; }
                 reward += oc.grid_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kr + LC_GRID_N * j) * N;
@@ -1516,8 +1581,10 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     }
     o.discharge_amount = any_sink ? 0.0 : discharge_sum;
     o.charge_amount = 0.0;
-    const double provided = psum;                           // :277 (at most 3 MS = 6 addends so far)
-    const double consumed = asum;
+    // :277: np.sum of the lists so far -- a running sum below eight addends (always with M = 2: at most 6 so far), numpy's pairwise order from eight on
+    double provided = psum, consumed = asum;
+    if constexpr (MID_P) { const int np_mid = __popc(pm); if (np_mid >= 8) provided = slots_pairwise_sum(pe, pm, np_mid); }
+    if constexpr (MID_A) { const int na_mid = __popc(am); if (na_mid >= 8) consumed = slots_pairwise_sum(ae, am, na_mid); }
     const double difference = provided - consumed;
     o.ctrl_provided = provided - o.fixed_provided; o.ctrl_absorbed = consumed - o.fixed_absorbed;
 
@@ -1525,36 +1592,42 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegs &R, c
     o.renewable_used = 0.0; o.curtailment = 0.0;
     if (difference > 0) {                                 // :286-299: renewables idle, the excess is overgeneration
 #pragma unroll
-        for (int j = 0; j < MS; j++) {
+        for (int j = 0; j < M; j++) {
             if (j < NP) {
                 o.curtailment += sin.pv[j] - 0.0;
-                pe[3 * MS + j] = 0.0; pm |= 1u << (3 * MS + j); psum += 0.0; reward += 0.0;
+                if constexpr (TRACK_P) { pe[3 * M + j] = 0.0; pm |= 1u << (3 * M + j); } psum += 0.0; reward += 0.0;
             }
         }
         const double e = -1.0 * (-1.0 * difference);
         o.overgeneration = e; o.loss_load = 0.0;
         o.unbalanced_reward = -1.0 * (og_cost * e);
         asum += e;
+        if constexpr (TRACK_A) { ae[3 * M] = e; am |= 1u << (3 * M); }
     } else {                                              // :301-314: renewables in module order, then loss load
         double need = -difference;
 #pragma unroll
-        for (int j = 0; j < MS; j++) {
+        for (int j = 0; j < M; j++) {
             if (j < NP) {
                 const double pv = sin.pv[j];
                 const double amt = (pv < need) ? pv : need;
                 o.renewable_used += amt; o.curtailment += pv - amt;
-                pe[3 * MS + j] = amt; pm |= 1u << (3 * MS + j); psum += amt; reward += 0.0;
+                if constexpr (TRACK_P) { pe[3 * M + j] = amt; pm |= 1u << (3 * M + j); } psum += amt; reward += 0.0;
                 need -= amt;
             }
         }
         o.loss_load = need; o.overgeneration = 0.0;
         o.unbalanced_reward = -1.0 * (ll_cost * need);
-        pe[4 * MS] = need; pm |= 1u << (4 * MS); psum += need;
+        if constexpr (TRACK_P) { pe[4 * M] = need; pm |= 1u << (4 * M); } psum += need;
     }
     reward += o.unbalanced_reward;
-    const int n_prov = __popc(pm);                        // :316-317
-    o.overall_provided = n_prov < 8 ? psum : small_pairwise_prov(pe, pm, n_prov);
+    o.overall_provided = psum;                            // :316-317
+    if constexpr (TRACK_P) {
+        const int n_prov = __popc(pm);
+        if constexpr (M == MS) { if (n_prov >= 8) o.overall_provided = small_pairwise_prov(pe, pm, n_prov); }
+        else { if (n_prov >= 8) o.overall_provided = slots_pairwise_sum(pe, pm, n_prov); }
+    }
     o.overall_absorbed = asum;
+    if constexpr (TRACK_A) { const int n_absb = __popc(am); if (n_absb >= 8) o.overall_absorbed = slots_pairwise_sum(ae, am, n_absb); }
     o.reward = reward;
     o.violations = viol;
     if (log) {

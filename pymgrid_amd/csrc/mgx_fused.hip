@@ -36,13 +36,15 @@
 namespace mgx {
 #define MGX_STATIC_LAYOUTS(X) \
     X(7, 2, 2, 1, 1, 1) X(7, 2, 2, 2, 1, 1) X(7, 2, 2, 2, 2, 2) X(7, 1, 2, 1, 1, 1) X(7, 1, 2, 2, 1, 1) X(7, 2, 1, 1, 1, 1) X(7, 1, 1, 2, 1, 1) \
-    X(3, 2, 2, 0, 1, 1) X(3, 2, 1, 0, 1, 1) X(3, 1, 2, 0, 1, 1) X(6, 0, 2, 1, 1, 1) X(6, 0, 2, 2, 1, 1) X(6, 0, 1, 2, 1, 1)
+    X(3, 2, 2, 0, 1, 1) X(3, 2, 1, 0, 1, 1) X(3, 1, 2, 0, 1, 1) X(6, 0, 2, 1, 1, 1) X(6, 0, 2, 2, 1, 1) X(6, 0, 1, 2, 1, 1) \
+    /* three modules of a kind (M = 3 instance slots; beyond the run-time-count register form, which holds two) */                       \
+    X(7, 3, 3, 1, 1, 1) X(7, 3, 2, 1, 1, 1) X(7, 2, 3, 1, 1, 1) X(3, 3, 3, 0, 1, 1) X(6, 0, 3, 1, 1, 1)
 bool launch_step_k_multi_static(const MultiStaticLaunch &L)
 {
 #define X(FV, G, B, R, LD, PV)                                                                                                           \
     if (L.flags == FV && L.ng == G && L.nb == B && L.nr == R && L.nl == LD && L.np == PV) {                                             \
-        step_k_multi_small_kernel<FV, CountsCT<G, B, R, LD, PV>><<<L.blocks, BLOCK_MULTI, 0, L.stream>>>(*L.k, L.actions, L.t, L.K, L.normalized, \
-                                                                                                        L.out);                         \
+        using CT = CountsCT<G, B, R, LD, PV>;                                                                                          \
+        step_k_multi_small_kernel<FV, CT, CT::slots><<<L.blocks, BLOCK_MULTI, 0, L.stream>>>(*L.k, L.actions, L.t, L.K, L.normalized, L.out); \
         return true;                                                                                                                    \
     }
     MGX_STATIC_LAYOUTS(X)

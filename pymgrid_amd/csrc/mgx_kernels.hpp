@@ -38,6 +38,18 @@ constexpr int BLOCK_K = MGX_BLOCK_K;
 // ------------------------------------------------------------------------------------------------------
 // the `obs` argument of a single step: state columns only (inside full rows, or as a dense [N, S] array), or -- without a
 // forecaster -- the whole 8..12-value row
+// Non-temporal stores for the fused kernels' [K, N] output streams.  HOT = the headline's reward + SoC: 0.692 -> 0.709 and 0.695 -> 0.7145
+// of peak in alternating runs on one box (profiles/r06/exp_out_nt_stores.txt); OUT = the general form's reward / done / SoC / status:
+// inside the noise (283-297 vs 292-298 us per full-output launch), left plain.  ACT = non-temporal loads of the action stream (A/B).
+#ifndef MGX_HOT_NT
+#define MGX_HOT_NT 1
+#endif
+#ifndef MGX_ACT_NT
+#define MGX_ACT_NT 0
+#endif
+#ifndef MGX_OUT_NT
+#define MGX_OUT_NT 0
+#endif
 #ifndef MGX_ROWS_TILE
 #define MGX_ROWS_TILE 1
 #endif
@@ -344,9 +356,15 @@ __device__ __forceinline__ void load_actions_at(const AT *__restrict__ row, uint
     constexpr int A = 2 * ((F & F_GENSET) != 0) + ((F & F_BATTERY) != 0) + ((F & F_GRID) != 0);
     const AT *a = row + i32 * (uint32_t)A;
     int k = 0;
+#if MGX_ACT_NT
+    if constexpr (F & F_GENSET) { r.a_goal = __builtin_nontemporal_load(a + k); r.a_gen = __builtin_nontemporal_load(a + k + 1); k += 2; }
+    if constexpr (F & F_BATTERY) { r.a_bat = __builtin_nontemporal_load(a + k); k += 1; }
+    if constexpr (F & F_GRID) { r.a_grid = __builtin_nontemporal_load(a + k); k += 1; }
+#else
     if constexpr (F & F_GENSET) { r.a_goal = a[k]; r.a_gen = a[k + 1]; k += 2; }
     if constexpr (F & F_BATTERY) { r.a_bat = a[k]; k += 1; }
     if constexpr (F & F_GRID) { r.a_grid = a[k]; k += 1; }
+#endif
 }
 
 // `done` of one fused step: a byte per grid, or (KArgs.done_bits) a bit per grid in uint16 words -- lane (i & 15) == 0 of every
@@ -414,17 +432,29 @@ __global__ __launch_bounds__(BLOCK_K) void step_k_kernel(const KArgs a, const AT
         step_core<F>(p, d, s, in, norm, HOT ? (F & F_BATTERY) != 0 : want_soc, GI, o);
         if constexpr (HOT) {
             const double r = o.reward;
+#if MGX_HOT_NT
+            __builtin_nontemporal_store(r, (out.reward + (int64_t)k * N) + i32);
+            if constexpr (F & F_BATTERY) __builtin_nontemporal_store(s.soc, (out.soc_trace + (int64_t)k * N) + i32);
+#else
             (out.reward + (int64_t)k * N)[i32] = r;
             if constexpr (F & F_BATTERY) (out.soc_trace + (int64_t)k * N)[i32] = s.soc;
+#endif
             ret += r;
             return;
         }
         const double r = shaped_reward<F>(a.shaper, o);
         {
+#if MGX_OUT_NT
+            if (out.reward) __builtin_nontemporal_store(r, out.reward + off);
+            if (out.done) store_done(a, out.done, off, i, k, k >= k_done);
+            if constexpr (F & F_BATTERY) { if (out.soc_trace) __builtin_nontemporal_store(s.soc, out.soc_trace + off); }
+            if constexpr (F & F_GENSET) { if (out.status_trace) __builtin_nontemporal_store(s.status, out.status_trace + off); }
+#else
             if (out.reward) out.reward[off] = r;
             if (out.done) store_done(a, out.done, off, i, k, k >= k_done);
             if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = s.soc; }
             if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = s.status; }
+#endif
             if (out.log) store_log<F>(out.log + (off - i) * a.log_dim + i, N, o, s.status);
         }
         ret += r;
@@ -2075,7 +2105,7 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a
 // `small` arm of step_k_multi_kernel in a kernel of its own -- without the run-time-count arm and the priority-list arm beside it the
 // loop keeps its pointers in SGPRs (the shared kernel reloaded ~100 spilled SGPRs per step through v_readlane).
 // CNT: the instance counts, run-time (CountsRT: any small layout) or compile-time (CountsCT: the layouts of mgx_fused.hip part 5).
-template <int F, class CNT = CountsRT>
+template <int F, class CNT = CountsRT, int M = MS>
 __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_small_kernel(const KArgs a, const void *__restrict__ actions, int32_t t0, int32_t K,
                                                                          int normalized, const FusedOut out)
 {
@@ -2088,25 +2118,25 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_small_kernel(const K
         const int A = 2 * CNT::ng(a) + CNT::nb(a) + CNT::nr(a);
         const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
         double ret = 0.0;
-        MultiRegs R; MultiStepIn cur, nxt;
-        load_multi_regs<F, CNT>(a, i, R);
+        MultiRegsT<M> R; MultiStepInT<M> cur, nxt;
+        load_multi_regs<F, CNT, M>(a, i, R);
         if (K > 0) {
-            if (a.act_f32) load_multi_step_in<F, float, CNT>(a, (const float *)actions + (int64_t)i * A, i, t0, cur);
-            else load_multi_step_in<F, double, CNT>(a, (const double *)actions + (int64_t)i * A, i, t0, cur);
+            if (a.act_f32) load_multi_step_in<F, float, CNT, M>(a, (const float *)actions + (int64_t)i * A, i, t0, cur);
+            else load_multi_step_in<F, double, CNT, M>(a, (const double *)actions + (int64_t)i * A, i, t0, cur);
         }
         // two steps per trip: the inputs of step k + 1 are requested into `nxt` before step k runs on `cur`, those of step k + 2 into
         // `cur` before step k + 1 runs on `nxt` -- no copy of 26 doubles per step between the two buffers
-        auto fetch = [&](int32_t kk, MultiStepIn &dst) __attribute__((always_inline)) {
+        auto fetch = [&](int32_t kk, MultiStepInT<M> &dst) __attribute__((always_inline)) {
             const int32_t kc = kk < K ? kk : K - 1;                  // (past the end: re-read the last step's inputs, unconditional loads)
             const int64_t offc = (int64_t)kc * N + i;
-            if (a.act_f32) load_multi_step_in<F, float, CNT>(a, (const float *)actions + offc * A, i, t0 + kc, dst);
-            else load_multi_step_in<F, double, CNT>(a, (const double *)actions + offc * A, i, t0 + kc, dst);
+            if (a.act_f32) load_multi_step_in<F, float, CNT, M>(a, (const float *)actions + offc * A, i, t0 + kc, dst);
+            else load_multi_step_in<F, double, CNT, M>(a, (const double *)actions + offc * A, i, t0 + kc, dst);
         };
-        auto one_step = [&](int32_t k, const MultiStepIn &in) __attribute__((always_inline)) {
+        auto one_step = [&](int32_t k, const MultiStepInT<M> &in) __attribute__((always_inline)) {
             const int64_t off = (int64_t)k * N + i;
             Outputs o;
             double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
-            step_multi_small<F, CNT>(a, R, in, i, normalized != 0, log, o);
+            step_multi_small<F, CNT, M>(a, R, in, i, normalized != 0, log, o);
             const double r = shaped_reward<F>(a.shaper, o);
             if (out.reward) out.reward[off] = r;
             if (out.done) out.done[off] = (uint8_t)(k >= k_done);
@@ -2122,7 +2152,7 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_small_kernel(const K
             one_step(k + 1, nxt);
         }
         if (k < K) one_step(k, cur);
-        store_multi_state<F, CNT>(a, i, R);
+        store_multi_state<F, CNT, M>(a, i, R);
         if (out.ret_acc) out.ret_acc[i] += ret;
     }
     advance_counter_in_kernel(a, K_launch);

@@ -89,7 +89,12 @@ def test_compile_time_counts_equal_run_time_counts(device):
     g = torch.Generator(device=device); g.manual_seed(19)
     for (ng, nb, nr, nl, npv), arch in (((2, 2, 1, 1, 1), "genset+battery+grid"), ((2, 2, 2, 2, 2), "genset+battery+grid"),
                                         ((1, 2, 2, 1, 1), "genset+battery+grid"), ((2, 1, 0, 1, 1), "genset+battery"),
-                                        ((0, 2, 1, 1, 1), "battery+grid"), ((2, 2, 1, 2, 1), "genset+battery+grid")):   # (the last: no specialisation)
+                                        ((0, 2, 1, 1, 1), "battery+grid"), ((2, 2, 1, 2, 1), "genset+battery+grid"),   # (no specialisation)
+                                        # THREE of a kind (M = 3 slots; up to 9 addends in the mid-sweep sums, 10 / 11 in the final ones:
+                                        # numpy's pairwise order rebuilt from the slots) against the run-time-count kernel with its LDS lists
+                                        ((3, 3, 1, 1, 1), "genset+battery+grid"), ((3, 2, 1, 1, 1), "genset+battery+grid"),
+                                        ((2, 3, 1, 1, 1), "genset+battery+grid"), ((3, 3, 0, 1, 1), "genset+battery"),
+                                        ((0, 3, 1, 1, 1), "battery+grid")):
         N, T, K = 2100, 80, 33
 
         def batch():

@@ -170,7 +170,7 @@ top, h = sys.argv[1], sys.argv[2]
 res = {}
 # what "one launch" of bench.py's leg is, which kernel marks it, and over how many of them (the tail of the run) the bytes are averaged
 legs = {"single": ("single_steps", "step_multi_kernel", 256, 1), "kstep": ("k_step_launches", "step_k_multi_small_kernel", 8, 1),
-        "kstep3": ("k_step_3_of_a_kind", "step_k_multi_kernel", 8, 1),
+        "kstep3": ("k_step_3_of_a_kind", "step_k_multi_small_kernel", 8, 1),
         "gymrows": ("gym_steps_rows_h24", "step_multi_kernel", 256, 1)}
 for leg, (key, marker, n_tail, _) in legs.items():
     tot, per = {}, {}
