@@ -849,7 +849,7 @@ def valu_roofline(kname, launch_s, grids_per_launch, concurrent, dev):
 
 
 def measured_traffic(kernel, grids, chunk):
-    """HBM bytes per launch of the kernel specialisation `kernel` ("step_k_kernel<3,4,double,false,true>"; a launch over `grids`
+    """HBM bytes per launch of the kernel specialisation `kernel` ("step_k_kernel<3,8,double,false,true>"; a launch over `grids`
     grids and `chunk` steps) from the committed rocprofv3 PMC passes of THIS command (tools/gpu_profile_r06.sh ->
     profiles/<round>/traffic.json); None when no profile of that specialisation and launch shape is committed."""
     import glob
@@ -1042,8 +1042,8 @@ def main():
         achieved = per_launch_bytes / avg_launch_s / 1e9
         wall_launch_s = wall / launches
         ft = "true" if fact else "false"
-        kname = {"fused": f"step_k_kernel<3,4,double,false,{ft}>", "step": "step_kernel<3,false>", "step_env": "step_kernel<3,false>",
-                 "rbc": f"rollout_kernel<3,8,false,false,{ft}>", "fused_rich": f"step_k_kernel<3,4,double,true,{ft}>",
+        kname = {"fused": f"step_k_kernel<3,8,double,false,{ft}>", "step": "step_kernel<3,false>", "step_env": "step_kernel<3,false>",
+                 "rbc": f"rollout_kernel<3,8,false,false,{ft}>", "fused_rich": f"step_k_kernel<3,16,double,true,{ft}>",
                  "step_full": "step_kernel<3,false>"}[mode]
         tkey = kname + ("+rows" if obs_rows else "") + ("+rows+log" if full else "")     # the key of this launch shape in traffic.json
         traffic, traffic_src = measured_traffic(tkey, n_launch, chunk)

@@ -56,10 +56,20 @@ bool launch_step_k_multi_static(const MultiStaticLaunch &L)
 
 namespace mgx {
 
+// Register-ring depth of a specialisation: what a slot holds decides how deep the ring may be before it costs occupancy or spills --
+// factorised series: the controls only (depth MGX_RING = 8; the write-bound full-output form MGX_RING_RICH = 16 without a GridModule);
+// materialised series: + 2 series values per slot (8 for the hot form), + 6 with a GridModule (4, as before round 6)
+template <int F, bool RC, bool FC>
+constexpr int ring_depth()
+{
+    if (FC) return RC ? ((F & F_GRID) ? 8 : MGX_RING_RICH) : MGX_RING;
+    return (F & F_GRID) ? 4 : (RC ? 4 : MGX_RING);
+}
+
 template <int F>
 static void step_k_dispatch(const FusedLaunch &L)
 {
-#define MGX_STEP_K(AT, RC, FC) step_k_kernel<F, MGX_RING, AT, RC, FC><<<L.blocks, BLOCK_K, 0, L.stream>>>( \
+#define MGX_STEP_K(AT, RC, FC) step_k_kernel<F, ring_depth<F, RC, FC>(), AT, RC, FC><<<L.blocks, BLOCK_K, 0, L.stream>>>( \
         *L.k, (const AT *)L.actions, L.t, L.K, L.normalized, L.out, L.gpb)
     if (L.act_f32) {
         if (L.fact) { if (L.rich) MGX_STEP_K(float, true, true); else MGX_STEP_K(float, false, true); }

@@ -21,8 +21,14 @@ namespace mgx {
 #define MGX_BLOCK 256
 #endif
 constexpr int BLOCK = MGX_BLOCK;
+// Register-ring depth of the fused kernel (steps of loads in flight).  Re-swept in round 6 (profiles/r06/exp_ring_depth8.txt, _16.txt): the
+// headline form 0.698 -> 0.7145 of peak at depth 8 against 4 (0.754 -> 0.773 at 125 000 grids) and 0.558 at 16 (the ring then costs occupancy);
+// the full-output form (RICH: it is write-bound, its waves wait on stores) gains up to 16: 314 -> 305 -> 297 us per 64-step launch.
 #ifndef MGX_RING
-#define MGX_RING 4          // register-ring depth of the fused kernel (steps of loads in flight)
+#define MGX_RING 8
+#endif
+#ifndef MGX_RING_RICH
+#define MGX_RING_RICH 16
 #endif
 #ifndef MGX_BLOCK_K
 #define MGX_BLOCK_K 256     // workgroup size of the fused kernel

@@ -108,7 +108,7 @@ def test_bench_one_rank_json_line(device, tmp_path):
     assert set(rf) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel", "avg_launch_us"}
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["launches"] == 3 * 2                                    # every timed step is --launches-per-step full-K launches per shard stream
-    assert rf["kernel"] == "step_k_kernel<3,4,double,false,true>" and abs(rf["bytes_per_env_step"] - (158 / 32 + 40)) < 0.01
+    assert rf["kernel"] == "step_k_kernel<3,8,double,false,true>" and abs(rf["bytes_per_env_step"] - (158 / 32 + 40)) < 0.01
     assert d["config"]["env_steps_per_step"] == 64 and d["config"]["series"] == "factorised"
     assert abs(d["value"] - 20000 * 3 * 64 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "value_1thread"} and d["cpu_baseline"]["kind"] == "port"
