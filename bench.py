@@ -587,11 +587,11 @@ def general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist):
                               "roofline": {"bound": "hbm", "achieved": bK_launch / Kg / (gpu / stepsK) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": bK_launch / Kg / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                            "frac_charged_per_step": bK / (gpu / stepsK) / 1e9 / HBM_PEAK_GBS,
-                                           "algorithmic_bytes_per_launch": bK_launch, "kernel": "step_k_multi_small_kernel<7, CountsCT<2,2,1,1,1>>",
+                                           "algorithmic_bytes_per_launch": bK_launch, "kernel": "step_k_multi_small_kernel<7, CountsCT<2,2,1,1,1>, 2>",
                                            "bytes_per_env_step": bK_launch / Kg / N, "avg_launch_us": gpu / stepsK * Kg * 1e6,
                                            "note": "parameters and state live in LDS for the launch (round 5): charged once per launch; "
                                                    "per step the controls, the series rows and the reward stream"}}
-    out["k_step_launches"]["roofline_valu"] = valu_roofline("step_k_multi_small_kernel<7,mgx::CountsCT<2,2,1,1,1>>", gpu / stepsK * Kg, N, 1, dev)
+    out["k_step_launches"]["roofline_valu"] = valu_roofline("step_k_multi_small_kernel<7,mgx::CountsCT<2,2,1,1,1>,2>", gpu / stepsK * Kg, N, 1, dev)
     out["layout"] = "2 gensets + 2 batteries + 1 grid + load + pv per microgrid (general kernels), materialised series"
     out["grids_per_gpu"], out["rows"] = N, rows_g
     ge.close()
