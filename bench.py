@@ -1033,8 +1033,11 @@ def main():
             # single steps of a factorised batch read the grid's factors (2 ratios + 2 profile ids: 18 B) where the
             # materialised one reads 2 row values (16 B); no done byte.  With observation rows (H = 0): + 8 D written per grid;
             # with the log: + 8 L written and the pre-step SoC read
+            # (rows: + the series' observation bounds the normalisation reads, lo and hi per component: 16 C_ts -- parameters like
+            #  the module columns; until round 6 they were left out of the count and showed up as t/a = 1.14)
+            c_ts = L.n_load + L.n_pv + 4 * int(L.has_grid)
             per_launch = L.bytes_per_step(log=full) - (0 if (run.done_stream or full) else 1) + (2 if fact else 0) - ub \
-                + (8 * L.obs_dim if (obs_rows or full) else 0)
+                + ((8 * L.obs_dim + 16 * c_ts) if (obs_rows or full) else 0)
             launches_per_round = chunk
         launches = rounds * launches_per_round                     # per stream
         per_launch_bytes = per_launch * N                          # one launch on every shard stream = all N grids
