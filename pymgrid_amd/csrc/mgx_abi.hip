@@ -1187,7 +1187,11 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
 {
     g_err[0] = 0;
     if (!h || !start || !row_off || !final_abs) return fail(MGX_ERR_INVALID, "mgx_reset_episodes: NULL argument");
-    if (h->multi) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: needs exactly one module of every kind per grid");
+    // several modules of a kind (round 6): single steps of the general kernels read the grid's own rows of the [T, n, N] series (a per-lane
+    // gather: no grid-major copy); rows per step only -- the ring patches (mgx_patch_windows) are single-instance
+    if (h->multi && h->k.obs_state_only == 1)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: with several modules of a kind the observation rows are written per step "
+                                         "(no rings: mgx_set_obs_mode(MGX_OBS_ROWS_FULL))");
     if (h->k.obs_colpitch) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered with column-major ring blocks (mgx_set_ring_layout)");
     if (h->k.t_dev) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered in device-counter mode");
     if (h->n_shards > 1) return fail(MGX_ERR_UNSUPPORTED, "mgx_reset_episodes: not offered while the handle steps in shards");
@@ -1234,7 +1238,7 @@ int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *lengt
         const int64_t N = h->k.N;
         const int ncomp = 2 + 4 * h->layout.has_grid;
         DeviceGuard on_device(h->device);
-        const bool want_gm = tune(MGX_TUNE_GRID_MAJOR_COPY) != 0;   // (0, tests: take the gather path although the copy would fit)
+        const bool want_gm = tune(MGX_TUNE_GRID_MAJOR_COPY) != 0 && !h->multi;   // (0, tests: take the gather path although the copy would fit)
         if (want_gm && (!h->gm_tables || h->gm_pitch != pitch)) {
             if (h->gm_tables) (void)hipFree(h->gm_tables);
             h->gm_tables = nullptr; h->gm_pitch = 0;
@@ -1304,6 +1308,8 @@ int mgx_set_final_obs(mgx_handle *h, void *final_obs)
     if (!h) return fail(MGX_ERR_INVALID, "mgx_set_final_obs: NULL handle");
     if (final_obs && !h->inplace)
         return fail(MGX_ERR_INVALID, "mgx_set_final_obs: the handle is not stepping in-place episodes (mgx_reset_episodes)");
+    if (final_obs && h->multi)
+        return fail(MGX_ERR_UNSUPPORTED, "mgx_set_final_obs: needs exactly one module of every kind per grid");
     h->k.final_obs = final_obs;
     return MGX_OK;
 }

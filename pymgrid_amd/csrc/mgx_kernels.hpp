@@ -144,13 +144,10 @@ __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict_
     else observe_row_h0<F>(a, i, t_next, p, s, (double *)obs + i * a.obs_dim, pm);
 }
 
-// In-place episodes (KArgs.ep_off): what a step adds once the grid's own step is done -- the observation before a restart
-// (mgx_set_final_obs), the restart itself when this step ended the grid's episode (mgx_set_auto_reset: the draw of
-// mgx_reset_grids_random at the counter value after the step).  Returns the row offset the step's observation is read with.
-template <int F>
-__device__ __forceinline__ int32_t episode_tail(const KArgs &a, int64_t i, int32_t t, int32_t off, bool dn, const Params &p, const State &s)
+// mgx_set_auto_reset: the grid whose episode this step ended (dn) restarts at once -- the draw of mgx_reset_grids_random at the counter
+// value after the step.  Returns the row offset the step's observation is read with (the new episode's when the grid restarted).
+__device__ __forceinline__ int32_t episode_auto_restart(const KArgs &a, int64_t i, int32_t t, int32_t off, bool dn)
 {
-    if (a.final_obs && a.obs_state_only != 1) store_step_obs<F>(a, a.final_obs, i, t + 1 + off, p, s, a.pm_pitch);   // (rings: mgx_patch_windows saves it)
     if (a.ar_mode && dn) {
         int32_t s0, len;
         episode_draw(a.ar_seed, i, t + 1, a.ar_fixed_length, a.ar_lo, a.ar_hi, s0, len);
@@ -163,6 +160,16 @@ __device__ __forceinline__ int32_t episode_tail(const KArgs &a, int64_t i, int32
         if (a.ar_t0_io) a.ar_t0_io[i] = t + 1;
     }
     return off;
+}
+
+// In-place episodes (KArgs.ep_off): what a step adds once the grid's own step is done -- the observation before a restart
+// (mgx_set_final_obs), the restart itself when this step ended the grid's episode (mgx_set_auto_reset: the draw of
+// mgx_reset_grids_random at the counter value after the step).  Returns the row offset the step's observation is read with.
+template <int F>
+__device__ __forceinline__ int32_t episode_tail(const KArgs &a, int64_t i, int32_t t, int32_t off, bool dn, const Params &p, const State &s)
+{
+    if (a.final_obs && a.obs_state_only != 1) store_step_obs<F>(a, a.final_obs, i, t + 1 + off, p, s, a.pm_pitch);   // (rings: mgx_patch_windows saves it)
+    return episode_auto_restart(a, i, t, off, dn);
 }
 
 // body of one step of grid i (shared by step_kernel and fleet_step_kernel).  EP: in-place per-grid episodes (the grid's series
@@ -1753,17 +1760,23 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_multi_kernel(const KArgs a, 
         const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
         StepLists L = multi_lists(a, multi_lds);
         Outputs o;
+        // in-place per-grid episodes (mgx_reset_episodes on the general path, round 6): the grid reads row counter + ep_off[i] of its
+        // own [T, n, N] series (a per-lane gather); `tr` is the counter itself otherwise
+        int32_t off = a.ep_off ? a.ep_off[i] : 0;
+        const int32_t tr = a.ep_off ? (int32_t)episode_row(a, t, off) : t;
         if (small) {                                     // at most MS modules of a kind: everything requested up front, the sweep on registers
             MultiRegs R; MultiStepIn sin;
             load_multi_regs<F>(a, i, R);
-            if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + i * A, i, t, sin);
-            else load_multi_step_in<F>(a, (const double *)actions + i * A, i, t, sin);
+            if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + i * A, i, tr, sin);
+            else load_multi_step_in<F>(a, (const double *)actions + i * A, i, tr, sin);
             step_multi_small<F>(a, R, sin, i, normalized != 0, log ? log + i : nullptr, o);
             store_multi_state<F>(a, i, R);
-        } else if (a.act_f32) step_multi_core<F>(a, (const float *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
-        else step_multi_core<F>(a, (const double *)actions + i * A, i, t, normalized != 0, L, log ? log + i : nullptr, o);
+        } else if (a.act_f32) step_multi_core<F>(a, (const float *)actions + i * A, i, tr, normalized != 0, L, log ? log + i : nullptr, o);
+        else step_multi_core<F>(a, (const double *)actions + i * A, i, tr, normalized != 0, L, log ? log + i : nullptr, o);
         reward[i] = shaped_reward<F>(a.shaper, o);
-        if (done) done[i] = done_at(a, i, t);
+        const uint8_t dn = done_at(a, i, t);
+        if (done) done[i] = dn;
+        if (a.ep_off) { off = episode_auto_restart(a, i, t, off, dn != 0); t += off; }      // (the observation: row counter + 1 + offset)
         if (obs) {
             if (a.obs_state_only == 1 && a.obs_colpitch) {            // the state columns of a COLUMN-major ring block: coalesced runs
                 const int64_t P = a.obs_colpitch, k0 = (int64_t)(a.n_load + a.n_pv) * (1 + a.H);
@@ -1782,6 +1795,7 @@ __global__ __launch_bounds__(BLOCK_MULTI) void observe_multi_kernel(const KArgs 
     t = resolve_t_obs(a, t);
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
     if (i >= a.g1) return;
+    if (a.ep_off) t += a.ep_off[i];                                   // in-place episodes: the grid's own row
     if (a.obs_state_only == 1 && a.obs_colpitch) {                    // state columns of a column-major ring block (step_multi_kernel)
         const int64_t P = a.obs_colpitch, k0 = (int64_t)(a.n_load + a.n_pv) * (1 + a.H);
         if (a.obs_f32) observe_state_multi<F>(a, i, (float *)obs + k0 * P + i, P);
@@ -1953,6 +1967,7 @@ __global__ __launch_bounds__(BLOCK_MULTI) void check_multi_kernel(const KArgs a,
     t = resolve_t(a, t);
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
     if (i >= a.g1) return;
+    if (a.ep_off) t = (int32_t)episode_row(a, t, a.ep_off[i]);        // in-place episodes: the grid's own row
     const int64_t N = a.N;
     const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid, A = 2 * NG + NB + NR;
     auto ld = [&](int j) { return a.act_f32 ? (double)((const float *)actions)[i * A + j] : ((const double *)actions)[i * A + j]; };
@@ -2175,6 +2190,7 @@ __global__ __launch_bounds__(BLOCK_MULTI) void expand_multi_kernel(const KArgs a
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
     if (i >= a.g1) return;
     const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
+    if (a.ep_off) t = (int32_t)episode_row(a, t, a.ep_off[i]);        // in-place episodes: the grid's own row
     int32_t id = action_id[i];
     id = (id >= 0 && id < n_lists) ? id : 0;              // ids outside [0, n) fall back to list 0 (the reference raises)
     const uint32_t xv = populate_multi<F>(a, lists + (int64_t)id * list_len * 3, list_len, i, t, control + i * A);

@@ -526,8 +526,16 @@ class PerGridWindowEnv:
     def __init__(self, full_batch, trajectory_length=None, discrete=False, generator=None, auto_reset=False,
                  final_observation=False, seed=0, native=None, **env_kwargs):
         L = full_batch.layout
+        # Several modules of a kind per grid (round 6): equal-length windows are gathered per reset (mgx_reset_windows on the general
+        # path); auto_reset runs IN PLACE only (mgx_reset_episodes: the grid reads its own rows of the [T, n, N] series, the step kernel
+        # restarts it) with device draws and rows per step -- the rolling window buffers and the ring patches are single-instance
         if L.multi:
-            raise NotImplementedError("per-grid windows need one module of every kind per grid")
+            if auto_reset and (generator is not None or final_observation or native is False or discrete):
+                raise NotImplementedError("several modules of a kind per grid: auto_reset runs in place with device draws "
+                                          "(generator=None, native, continuous controls, no final_observation)")
+            if auto_reset:
+                env_kwargs = dict(env_kwargs, obs_prefetch=0)
+                native = True
         self.full = full_batch
         self.length = None if trajectory_length is None else int(trajectory_length)
         if self.length is not None and L.final_step - L.initial_step < self.length:

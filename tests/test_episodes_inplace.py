@@ -397,3 +397,64 @@ def test_done_grids_stepped_past_the_series_stay_defined(arch, discrete, device,
     assert np.array_equal(rew.cpu().numpy(), ref)
     assert np.array_equal(b.cols["charge"].cpu().numpy(), st["charge"]) and np.isfinite(st["charge"]).all()
     env.close()
+
+
+@pytest.mark.parametrize("counts,H", [((2, 2, 1, 1, 1), 0), ((2, 2, 1, 1, 1), 3), ((3, 1, 2, 2, 1), 2)])
+def test_inplace_episodes_with_several_modules_of_a_kind(counts, H, device):
+    """Round 6: per-grid episodes IN PLACE on the general path (several gensets / batteries / grids per microgrid; the register form
+    and the run-time-count form): grid i reads its own rows of the [T, n, N] series -- against the gathered window buffers
+    (mgx_reset_windows on the general path, pinned in tests/test_multi_windows.py) step by step: first episode, a restart of every
+    grid with new starts (mgx_reset_grids), and PerGridWindowEnv(auto_reset=True) whose step kernel restarts the grids it finishes
+    with device draws (the draws are read back and replayed on the gathered windows)."""
+    from pymgrid_amd import BatchedMicrogridEnv
+    from pymgrid_amd.generator import widen
+    from pymgrid_amd.hetero import PerGridWindowEnv
+    ng, nb, nr, nl, npv = counts
+    N, T, Lg = 700, 160, 9
+
+    def batch():
+        return widen(_gen(N, T, "genset+battery+grid", device, H=H, seed=41, series="materialised"), n_genset=ng, n_battery=nb, n_grid=nr,
+                     n_load=nl, n_pv=npv)
+    inpl, gath = BatchedMicrogridEnv(batch(), obs_prefetch=0), BatchedMicrogridEnv(batch(), obs_prefetch=0)
+    rs = np.random.RandomState(8 + SOAK)
+    g = torch.Generator(device=device); g.manual_seed(2 + SOAK)
+    A = inpl.layout.action_dim
+
+    def episode(starts, first_a, first_b):
+        assert torch.equal(first_a, first_b)
+        for k in range(Lg):
+            a = torch.rand(N, A, dtype=torch.float64, device=device, generator=g)
+            (o1, r1, d1, _), (o2, r2, d2, _) = inpl.step(a), gath.step(a)
+            assert torch.equal(r1, r2) and torch.equal(d1, d2), k
+            assert torch.equal(o1, o2), k
+            assert bool(d1.all()) == (k == Lg - 1) and bool(d1.any()) == (k == Lg - 1)
+    starts = rs.randint(0, T - Lg + 1, size=N).astype(np.int32)
+    starts[:3] = (0, T - Lg, 1)
+    episode(starts, inpl.reset_windows(starts, None, max_length=Lg, rolling="inplace"), gath.reset_windows(starts, None, max_length=Lg))
+    starts2 = rs.randint(0, T - Lg + 1, size=N).astype(np.int32)
+    every = torch.ones(N, dtype=torch.uint8, device=device)
+    episode(starts2, inpl.reset_grids(every, starts2, None), gath.reset_windows(starts2, None, max_length=Lg))
+    for name in ("charge", "soc", "gen_status"):
+        assert torch.equal(inpl.batch.cols[name], gath.batch.cols[name]), name
+    inpl.close()
+    # auto-reset: the step kernel restarts every grid at the end of its episode with its own draw
+    auto = PerGridWindowEnv(batch(), trajectory_length=Lg, auto_reset=True, seed=13 + SOAK)
+    assert auto.native and auto.env._ring is None
+    for name in ("charge", "soc", "gen_status"):                   # carry on from the state the gathered env stands at
+        auto.env.batch.cols[name].copy_(gath.batch.cols[name])
+    starts3 = rs.randint(0, T - Lg + 1, size=N).astype(np.int32)
+    o_a, o_g = auto.reset(starts3), gath.reset_windows(starts3, None, max_length=Lg)
+    for episode_no in range(3):
+        assert torch.equal(o_a, o_g), episode_no
+        for k in range(Lg):
+            a = torch.rand(N, A, dtype=torch.float64, device=device, generator=g)
+            (o_a, r1, d1, _), (o_g, r2, d2, _) = auto.step(a), gath.step(a)
+            assert torch.equal(r1, r2) and torch.equal(d1, d2), (episode_no, k)
+            if k < Lg - 1:
+                assert torch.equal(o_a, o_g), (episode_no, k)
+        new_starts = auto.starts.clone()                           # what the kernel drew for the grids it restarted (all of them)
+        assert int(new_starts.min()) >= 0 and int(new_starts.max()) <= T - Lg and not torch.equal(new_starts.cpu(), torch.as_tensor(starts3))
+        o_g = gath.reset_windows(new_starts, None, max_length=Lg)  # the gathered windows replay the draw: o_a is the new episode's first row
+    with pytest.raises(NotImplementedError):
+        PerGridWindowEnv(batch(), trajectory_length=Lg, auto_reset=True, final_observation=True)
+    auto.env.close(); gath.close()
