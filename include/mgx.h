@@ -326,7 +326,10 @@ int mgx_reset_grids_random(mgx_handle *h, const uint8_t *mask, uint64_t seed, in
  * A grid whose episode is over and that has not been restarted (auto-reset off, or a late mgx_reset_grids) keeps stepping on
  * its own series; the shared counter has no end in this mode, so nothing refuses the step that would leave the series:
  * from row n_steps on such a grid re-reads its LAST row (the step stays defined and finite; its observation windows show the
- * forecaster's padding, as they do at the end of a series in lock-step). */
+ * forecaster's padding, as they do at the end of a series in lock-step).
+ * Layouts with several modules of a kind (ABI minor 1): single steps of the general kernels, every grid reading its own rows of the
+ * [T, n, N] series (a per-lane gather; no grid-major copy), restarts and mgx_set_auto_reset as above; observation rows per step
+ * only (MGX_OBS_ROWS_FULL: the ring patches are single-instance) and no mgx_set_final_obs. */
 int mgx_reset_episodes(mgx_handle *h, const int32_t *start, const int32_t *length, int32_t max_length, int32_t *row_off,
                        int32_t *final_abs, void *obs, mgx_stream stream);
 /* Auto-reset inside the step (in-place episodes only): every single step restarts the grids whose episode it ends -- the
@@ -349,7 +352,8 @@ int mgx_set_reward_shaper(mgx_handle *h, int32_t shaper);
 
 /* GaussianNoiseForecaster switches: Philox seed of the forecast noise and `increase_uncertainty`
  * (std_j = std * (1 + log(1 + j)) for forecast_j, forecaster.py:243-249).  Noise is drawn per (grid, module
- * component, step, horizon index); statistical -- not bit -- parity with the reference's np.random.normal. */
+ * component, step, horizon index); statistical -- not bit -- parity with the reference's np.random.normal.
+ * With several modules of a kind the *_noise_std columns are [n, N]: one std per module instance, independent streams. */
 int mgx_set_forecast_noise(mgx_handle *h, uint64_t seed, int increase_uncertainty);
 
 /* Element type of every `obs` argument below: MGX_OBS_F64 (default; the reference's float64 arrays) or MGX_OBS_F32

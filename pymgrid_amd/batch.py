@@ -242,9 +242,9 @@ class MicrogridBatch:
         dtypes = {"gen_times": torch.int32, "gen_status": torch.int32, "load_profile": torch.uint8, "pv_profile": torch.uint8,
                   "co2_profile": torch.uint8, "tariff": torch.uint8, "outage_bits": torch.int64}   # (u)int bit patterns
         if L.n_load != 1:            # several (or no) load modules per grid: [T, n_load, N], bounds [n_load, N]
-            shapes.update(load_ts=(T, L.n_load, N), load_lo=(L.n_load, N), load_hi=(L.n_load, N))
+            shapes.update(load_ts=(T, L.n_load, N), load_lo=(L.n_load, N), load_hi=(L.n_load, N), load_noise_std=(L.n_load, N))
         if L.n_pv != 1:
-            shapes.update(pv_ts=(T, L.n_pv, N), pv_lo=(L.n_pv, N), pv_hi=(L.n_pv, N))
+            shapes.update(pv_ts=(T, L.n_pv, N), pv_lo=(L.n_pv, N), pv_hi=(L.n_pv, N), pv_noise_std=(L.n_pv, N))
         # several modules of a controllable kind: instance-major columns
         per_kind = {"bat_": L.n_battery, "gen_": L.n_genset, "grid_m": L.n_grid, "grid_c": L.n_grid}
         for name in _lib.COLUMN_NAMES:
@@ -591,8 +591,6 @@ def pack_grids(grids, flat_order="module"):
     if fn0 is not None:
         if layout.horizon == 0:
             raise ValueError("forecast_noise needs a forecast horizon > 0")
-        if layout.multi:
-            raise ValueError("forecast_noise is offered for microgrids with one module of every kind only")
         lo_, hi_ = layout.initial_step, layout.final_step
         for g in grids:
             f = g["forecast_noise"]
@@ -608,10 +606,16 @@ def pack_grids(grids, flat_order="module"):
                     sd *= abs(float(series_of(j)[lo_:hi_].mean()))
                 out.append(sd)
             return np.array(out)
-        A["load_noise_std"] = stds(lambda j: A["load_ts"][:, j])
-        A["pv_noise_std"] = stds(lambda j: A["pv_ts"][:, j])
-        if has["grid"]:
-            A["grid_noise_std"] = stds(lambda j: A["grid_ts"][:, :, j])
+        def inst_stds(key, n):    # one std per module INSTANCE: a column [N], or [n, N] with several modules of the kind
+            if n == 0:
+                return None
+            per = [stds(lambda j, q=q: (A[key] if n == 1 else A[key][:, q])[..., j]) for q in range(n)]
+            return per[0] if n == 1 else np.stack(per)
+        for key, name, n in (("load_ts", "load_noise_std", layout.n_load), ("pv_ts", "pv_noise_std", layout.n_pv),
+                             ("grid_ts", "grid_noise_std", layout.n_grid)):
+            col_ = inst_stds(key, n)
+            if col_ is not None:
+                A[name] = col_
         A["__forecast_noise__"] = dict(seed=int(fn0.get("seed", 0)),
                                        increase_uncertainty=bool(fn0.get("increase_uncertainty", False)))
     return A, layout

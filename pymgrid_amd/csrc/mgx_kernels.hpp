@@ -1679,14 +1679,24 @@ __device__ __forceinline__ StepLists multi_lists(const KArgs &a, double *lds)
     return L;
 }
 
+// noise: GaussianNoiseForecaster on the general path (round 6; forecaster.py:220-275): forecast value h > 0 of the window gets
+// std * N(0, 1) -- std x (1 + log(1 + (h - 1))) with increase_uncertainty -- from the counter-based generator (seed; grid, component id,
+// series row, h), BEFORE the clip to the bounds, as in window_finish<NOISE>; statistical parity only.
+struct SeriesNoise { double std; uint64_t seed; int increase; int64_t grid; uint32_t comp; };
+
 template <typename OT>
 __device__ inline void observe_series_multi(const double *__restrict__ ts, int64_t row_stride, int32_t T, int32_t t, int32_t H,
-                                            double lo, double hi, OT *__restrict__ obs, int obs_stride = 1)
+                                            double lo, double hi, OT *__restrict__ obs, int obs_stride = 1,
+                                            const SeriesNoise *noise = nullptr)
 {
     const double fill = (hi + lo) / 2, sp = space_spread(lo, hi);
     for (int h = 0; h <= H; h++) {
         const bool in = t < T && t + h < T;
-        const double v = in ? ts[(int64_t)(t + h) * row_stride] : 0.0;
+        double v = in ? ts[(int64_t)(t + h) * row_stride] : 0.0;
+        if (noise && in && h > 0) {
+            const double sd = noise->increase ? noise->std * (1.0 + log(1.0 + (double)(h - 1))) : noise->std;
+            v += sd * forecast_normal(noise->seed, noise->grid, noise->comp, t, h);
+        }
         obs[h * obs_stride] = (OT)obs_series_value(v, in, h > 0, lo, hi, fill, sp);
     }
 }
@@ -1730,19 +1740,29 @@ __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, O
     observe_state_multi<F, OT>(a, i, obs_row + k, 1);
     if (a.obs_state_only) return;
     k = 0;
-    for (int j = 0; j < a.n_load; j++, k += W)
+    // noisy forecasters: one std per module instance ([n, N] columns), a component id per (kind, instance, component) for the generator
+    SeriesNoise nz{0.0, a.noise_seed, a.noise_increase, i, 0u};
+    for (int j = 0; j < a.n_load; j++, k += W) {
+        const bool noisy = a.c.load_noise_std != nullptr;
+        if (noisy) { nz.std = a.c.load_noise_std[(int64_t)j * N + i]; nz.comp = (uint32_t)j; }
         observe_series_multi(a.c.load_ts + (int64_t)j * N + i, (int64_t)a.n_load * N, a.T, t, a.H, a.c.load_lo[(int64_t)j * N + i],
-                             a.c.load_hi[(int64_t)j * N + i], obs_row + k);
-    for (int j = 0; j < a.n_pv; j++, k += W)
+                             a.c.load_hi[(int64_t)j * N + i], obs_row + k, 1, noisy ? &nz : nullptr);
+    }
+    for (int j = 0; j < a.n_pv; j++, k += W) {
+        const bool noisy = a.c.pv_noise_std != nullptr;
+        if (noisy) { nz.std = a.c.pv_noise_std[(int64_t)j * N + i]; nz.comp = (uint32_t)(MGX_MAX_MODULES + j); }
         observe_series_multi(a.c.pv_ts + (int64_t)j * N + i, (int64_t)a.n_pv * N, a.T, t, a.H, a.c.pv_lo[(int64_t)j * N + i],
-                             a.c.pv_hi[(int64_t)j * N + i], obs_row + k);
+                             a.c.pv_hi[(int64_t)j * N + i], obs_row + k, 1, noisy ? &nz : nullptr);
+    }
     k += 4 * a.n_genset + 2 * a.n_battery;
     if constexpr (F & F_GRID) {
         for (int j = 0; j < a.n_grid; j++, k += 4 * W)
             for (int cc = 0; cc < 4; cc++) {
                 const int64_t c = ((int64_t)j * 4 + cc) * N + i;
+                const bool noisy = a.c.grid_noise_std != nullptr;
+                if (noisy) { nz.std = a.c.grid_noise_std[(int64_t)j * N + i]; nz.comp = (uint32_t)(2 * MGX_MAX_MODULES + 4 * j + cc); }
                 observe_series_multi(a.c.grid_ts + c, (int64_t)a.n_grid * 4 * N, a.T, t, a.H, a.c.grid_lo[c], a.c.grid_hi[c],
-                                     obs_row + k + cc, 4);
+                                     obs_row + k + cc, 4, noisy ? &nz : nullptr);
             }
     }
 }

@@ -82,6 +82,17 @@ def test_forecast_noise_columns_follow_the_reference_rule(pymgrid25):
     assert A["__forecast_noise__"] == dict(seed=5, increase_uncertainty=True)
     q = dict(pymgrid25[1], forecast_noise=dict(std=0.3))
     assert pack_grids([q])[0]["pv_noise_std"][0] == 0.3
+    # several modules of a kind: a std per module INSTANCE ([n, N] columns), each from its own series
+    rs = np.random.RandomState(2)
+    T = 40
+    g = dict(load_ts=np.stack([40 + rs.rand(T), 20 + rs.rand(T)], axis=1), pv_ts=30 * rs.rand(T), horizon=4, final_step=T, initial_step=0,
+             unbalanced=dict(loss_load_cost=10.0, overgeneration_cost=1.0),
+             battery=[dict(min_capacity=10.0, max_capacity=80.0, max_charge=20.0, max_discharge=25.0, efficiency=0.9, battery_cost_cycle=0.02,
+                           init_soc=0.5)] * 2,
+             forecast_noise=dict(std=0.1, relative_noise=True))
+    A, L = pack_grids([g, g])
+    assert L.multi and A["load_noise_std"].shape == (2, 2) and A["pv_noise_std"].shape == (2,)
+    assert A["load_noise_std"][1, 0] == 0.1 * abs(-np.abs(g["load_ts"][:, 1]).mean())
 
 
 @pytest.mark.gpu
@@ -131,3 +142,60 @@ def test_gaussian_noise_forecaster_statistics(device):
     d2 = (n1 - o_next)[:, sl["load"]][:, 1] * spread
     assert not torch.equal(d2, d[:, 1]) and abs((d2 / cols["load_noise_std"]).std().item() - 1.0) < 0.05
     oracle_eng.close(); noisy.close()
+
+
+@pytest.mark.gpu
+def test_gaussian_noise_forecaster_on_the_general_path(device):
+    """Round 6: noisy forecasters for microgrids with several modules of a kind (two loads, two renewables, two grids: a std per
+    module instance, [n, N] columns): current values untouched, forecast_j of EVERY instance = truth + N(0, std_instance x
+    (1 + log(1 + j))), independent streams per instance, clipped to the bounds, reproducible per seed, redrawn every step."""
+    from pymgrid_amd import MicrogridBatch, StepEngine
+    from pymgrid_amd.generator import generate, widen
+    N, H = 8192, 6
+    base = widen(generate(N, n_steps=60, seed=4, arch="genset+battery+grid", horizon=H, device=device), n_genset=2, n_battery=2, n_grid=2,
+                 n_load=2, n_pv=2)
+    L = base.layout
+    cols = dict(base.cols)
+    cols["load_noise_std"] = 0.02 * base.cols["load_ts"].mean(0).abs() * torch.tensor([[1.0], [3.0]], dtype=torch.float64, device=device)
+    cols["pv_noise_std"] = 0.03 * base.cols["pv_ts"].mean(0).abs()
+    cols["grid_noise_std"] = torch.full((2, N), 0.01, dtype=torch.float64, device=device)
+    plain = StepEngine(MicrogridBatch(L, dict(base.cols)))
+    noisy = StepEngine(MicrogridBatch(L, cols, forecast_noise=dict(seed=11, increase_uncertainty=True)))
+    plain.reset(initial_step=7, want_obs=False); noisy.reset(initial_step=7, want_obs=False)
+    o0, o1 = plain.observe(), noisy.observe()
+    assert torch.equal(noisy.observe(), o1)
+    W = H + 1
+    inst = L.obs_instances()
+    zs = []
+    for q, sl in enumerate(inst["load"]):
+        spread = base.cols["load_hi"][q] - base.cols["load_lo"][q]
+        d = (o1 - o0)[:, sl] * spread[:, None]
+        assert torch.equal(d[:, 0], torch.zeros(N, dtype=torch.float64, device=device))
+        z = d[:, 1:] / cols["load_noise_std"][q][:, None]
+        inside = (o0[:, sl][:, 1:] > 0.1) & (o0[:, sl][:, 1:] < 0.9)
+        for j in (0, 2, 5):
+            zz = z[:, j][inside[:, j]]
+            expect = 1.0 + np.log(1.0 + j)
+            assert abs(zz.mean().item()) < 5 * expect / np.sqrt(zz.numel())
+            assert abs(zz.std().item() / expect - 1.0) < 0.04, (q, j, zz.std().item(), expect)
+        zs.append(z[:, 0])
+    both = inside[:, 0]
+    corr = torch.corrcoef(torch.stack([zs[0][both], zs[1][both]]))[0, 1].item()
+    assert abs(corr) < 0.05                                        # the two load modules draw from streams of their own
+    for q, sl in enumerate(inst["grid"]):                         # component-minor windows, absolute std 0.01 on every component
+        g = (o1 - o0)[:, sl].reshape(N, W, 4)
+        assert torch.equal(g[:, 0], torch.zeros(N, 4, dtype=torch.float64, device=device))
+        price_spread = base.cols["grid_hi"][q, 0] - base.cols["grid_lo"][q, 0]
+        ref = o0[:, sl].reshape(N, W, 4)[:, 1, 0]
+        ok = (ref > 0.2) & (ref < 0.8)
+        if ok.sum() > 1000:
+            assert abs((g[:, 1, 0] * price_spread / 0.01)[ok].std().item() - 1.0) < 0.06, q
+    for name in ("load", "pv", "grid"):
+        for sl in inst[name]:
+            assert (o1[:, sl] >= 0).all() and (o1[:, sl] <= 1).all()
+    a = torch.rand(N, L.action_dim, dtype=torch.float64, device=device)
+    n1 = noisy.step(a)[0]; p1 = plain.step(a)[0]
+    sl = inst["load"][0]
+    d2 = (n1 - p1)[:, sl][:, 1] * (base.cols["load_hi"][0] - base.cols["load_lo"][0])
+    assert not torch.equal(d2, ((o1 - o0)[:, sl] * (base.cols["load_hi"][0] - base.cols["load_lo"][0])[:, None])[:, 1])
+    plain.close(); noisy.close()
