@@ -103,6 +103,7 @@ def parse(argv=None):
                     help="BASELINE.json configs[] index the job lands on: 2 = 100 000 template-4 grids per GPU (the metric's N = 100k), "
                          "3 = 1 M template-4 grids over 8 GPUs (125 000 per GPU), 4 = 1 M heterogeneous H = 24 grids over 8 GPUs (the fleet "
                          "leg at 125 000 per GPU becomes what `value` reports)")
+    ap.add_argument("--fleet-ring", type=int, default=32, help="observation-ring depth K of the config-5 fleet leg (experiments; default 32)")
     ap.add_argument("--tunable", action="append", default=[], metavar="NAME=VALUE",
                     help="mgx_set_tunable before anything runs (A/B of launch shapes: e.g. multi_static=0); repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the baseline sample")
@@ -338,7 +339,7 @@ def timed(run, fn, rounds, device, mdist, per_round=False):
     return t1 - t0, max(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3, round_us
 
 
-def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform, all_legs=False):
+def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform, all_legs=False, K_ring=32):
     """BASELINE configs[4] per GPU: a heterogeneous fleet (1/3 genset+battery, 1/3 battery+grid, 1/3 genset+battery+grid;
     forecast_horizon = 24, T = `rows`) stepped through the Gym surface WITH observations, under both observation contracts:
       rows   step() returns the [N, D] rows (D = 56 / 152 / 156): written ahead in rings of 16 row blocks, the step adds the
@@ -348,7 +349,7 @@ def hetero_gym_steps(N, dev, rank, world, steps, mdist, rows, series, uniform, a
     from pymgrid_amd.generator import generate
     from pymgrid_amd.hetero import BucketedFleet
     per = N // 3
-    K_ring = 32          # ring depth: 25 vs 27.5 us per fleet step against K = 16 (profiles/r04/exp_fleet_refill_occupancy.txt)
+    # K_ring: ring depth, 32 by default: 25 vs 27.5 us per fleet step against K = 16 (profiles/r04/exp_fleet_refill_occupancy.txt)
     out = {}
     archs = ("genset+battery", "battery+grid", "genset+battery+grid")
     #   rows            step() returns the [N, D] observation, the fleet's DEFAULT ring layout: column-major blocks (obs = the view with
@@ -1194,7 +1195,7 @@ def main():
         fleet_steps = args.steps * chunk if args.config == 4 else args.hetero_steps
         hetero = guarded("hetero_h24_gym_steps", lambda: hetero_gym_steps(N, dev, rank, world, fleet_steps, mdist, args.rows,
                                                                           args.series, args.series == "factorised" and args.uniform_columns,
-                                                                          all_legs=args.all_legs))
+                                                                          all_legs=args.all_legs, K_ring=args.fleet_ring))
 
     # metrics vector: episode-return sum + mean SoC, all-reduced over ranks (the ONLY collective; RCCL over xGMI)
     local_sums = eng.metrics(torch.stack([run.outs[0]["reward"][-1], batch.cols["soc"]]))

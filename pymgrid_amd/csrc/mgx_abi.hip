@@ -2053,7 +2053,7 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
                 fa.tab[q] = it.action_id ? h->d_table : nullptr;
                 fa.actions[q] = it.action_id ? (const void *)it.action_id : it.actions; fa.reward[q] = it.reward; fa.done[q] = it.done; fa.obs[q] = it.obs; fa.log[q] = it.log;
                 fa.t[q] = h->t; fa.flags[q] = h->flags; fa.block0[q] = blocks;
-                blocks += (int32_t)blocks_for(h->k.N);
+                blocks += (int32_t)((h->k.N + BLOCK_FLEET - 1) / BLOCK_FLEET);
                 if (it.refill_ring && it.refill_chunks > 0) {                        // this step's share of the next ring
                     WindowsKPlan plan; size_t lds; int32_t ng, first, count;
                     (void)windows_plan(h, it.refill_ahead, it.refill_K, it.refill_ring, "mgx_fleet_step", &plan, &lds, &ng);
@@ -2073,7 +2073,7 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
                 }
             }
             fw.first_block = blocks;
-            fleet_step_kernel<<<(unsigned)(blocks + wblocks), BLOCK, lds_max, st>>>(fa, fw);
+            fleet_step_kernel<<<(unsigned)(blocks + wblocks), BLOCK_FLEET, lds_max, st>>>(fa, fw);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hip_fail(e, "fleet_step_kernel launch");
         }

@@ -17,8 +17,10 @@
 
 namespace mgx {
 
+// Workgroup size of the single-step / observation / fleet kernels.  128 since round 6 (profiles/r06/exp_block_size.txt, alternating runs:
+// single step 4.94 -> 4.78 us, with row + log + done 10.85 -> 10.25, config-5 float64 fleet step 22.1 -> 21.5 against 256; 64 = 128; 512 = 256).
 #ifndef MGX_BLOCK
-#define MGX_BLOCK 256
+#define MGX_BLOCK 128
 #endif
 constexpr int BLOCK = MGX_BLOCK;
 // Register-ring depth of the fused kernel (steps of loads in flight).  Re-swept in round 6 (profiles/r06/exp_ring_depth8.txt, _16.txt): the
@@ -1353,7 +1355,9 @@ struct FleetWin {
     int32_t n, first_block;                      // first_block = workgroups of the step part
 };
 
-static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArgs fa, const FleetWin fw)
+// (its workgroups are BLOCK_FLEET = OBS_K_THREADS threads whatever BLOCK is: the window chunks' phase 2 needs that many)
+constexpr int BLOCK_FLEET = OBS_K_THREADS;
+static __global__ __launch_bounds__(BLOCK_FLEET) void fleet_step_kernel(const FleetArgs fa, const FleetWin fw)
 {
     extern __shared__ double image[];
     if (fw.n > 0 && (int)blockIdx.x >= fw.first_block) {               // ---- window chunk workgroups
@@ -1401,7 +1405,7 @@ static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel(const FleetArg
         t = mine ? fa.t[q] : t; flags = mine ? fa.flags[q] : flags; block0 = mine ? fa.block0[q] : block0;
     }
     const KArgs &a = *kp;                         // uniform address, read-only: scalar loads from HBM / L2
-    const int64_t i = (int64_t)((int)blockIdx.x - block0) * BLOCK + threadIdx.x;
+    const int64_t i = (int64_t)((int)blockIdx.x - block0) * BLOCK_FLEET + threadIdx.x;
     if (i >= a.N) return;
     if (tp != nullptr) {                          // a DiscreteMicrogridEnv batch: ids -> control -> run, in registers
         const PLWords &tab = *tp;
