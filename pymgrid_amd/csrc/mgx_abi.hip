@@ -328,7 +328,7 @@ static int32_t fused_grids_per_block(const mgx_handle *h, int64_t N)
     const int cus = h->n_cu > 0 ? h->n_cu : 256;
     int32_t best = BLOCK_K;
     int64_t best_cost = -1;
-    for (int32_t g = BLOCK_K; g >= 192 && g >= BLOCK_K - 64; g -= 16) {
+    for (int32_t g = BLOCK_K; g >= BLOCK_K * 3 / 4; g -= 16) {
         const int64_t blocks = (N + g - 1) / g;
         const int64_t cost = ((blocks + cus - 1) / cus) * g;          // grids streamed by the busiest CU
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = g; }

@@ -58,6 +58,15 @@ constexpr int BLOCK_K = MGX_BLOCK_K;
 #ifndef MGX_OUT_NT
 #define MGX_OUT_NT 0
 #endif
+// Non-temporal stores of the H = 0 row tiles: Gym step with rows 7.25 -> 6.79 us, with row + log + done 10.25 -> 9.55 us in alternating
+// runs (profiles/r06/exp_rows_nt.txt).  MGX_STATE_NT: the same for the state columns a step adds to a column-major ring block: config-5
+// fleet step 20.7 -> 20.15 us (float64 rows), 13.55 -> 12.9 us (float32), profiles/r06/exp_state_nt.txt.
+#ifndef MGX_ROWS_NT
+#define MGX_ROWS_NT 1
+#endif
+#ifndef MGX_STATE_NT
+#define MGX_STATE_NT 1
+#endif
 #ifndef MGX_ROWS_TILE
 #define MGX_ROWS_TILE 1
 #endif
@@ -89,7 +98,11 @@ __device__ __forceinline__ void observe_row_h0_tiled(const KArgs &a, int64_t i, 
         if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
             for (int32_t e = 2 * lane; e < total; e += 128) {
                 const vec2 v = *reinterpret_cast<const vec2 *>(tile + e);
+#if MGX_ROWS_NT
+                __builtin_nontemporal_store(v, reinterpret_cast<vec2 *>(out + e));
+#else
                 *reinterpret_cast<vec2 *>(out + e) = v;
+#endif
             }
         } else {                                         // a caller's buffer at an odd 8-byte offset: word stores, same bytes
             for (int32_t e = lane; e < total; e += 64) out[e] = tile[e];
@@ -98,7 +111,11 @@ __device__ __forceinline__ void observe_row_h0_tiled(const KArgs &a, int64_t i, 
         if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
             for (int32_t e = 4 * lane; e < total; e += 256) {
                 const vec4 v = *reinterpret_cast<const vec4 *>(tile + e);
+#if MGX_ROWS_NT
+                __builtin_nontemporal_store(v, reinterpret_cast<vec4 *>(out + e));
+#else
                 *reinterpret_cast<vec4 *>(out + e) = v;
+#endif
             }
         } else {
             for (int32_t e = 2 * lane; e < total; e += 128) {
@@ -125,15 +142,27 @@ __device__ __forceinline__ void store_step_obs(const KArgs &a, void *__restrict_
             observe_state_cols<F>(a, p, s, st, 0);
             float *b = (float *)obs + i;
 #pragma unroll
-            for (int j = 0; j < NSTATE; j++)
-                b[(int64_t)(((F & F_GENSET) != 0 && j < 4) ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0))) * P] = st[j];
+            for (int j = 0; j < NSTATE; j++) {
+                float *q = b + (int64_t)(((F & F_GENSET) != 0 && j < 4) ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0))) * P;
+#if MGX_STATE_NT
+                __builtin_nontemporal_store(st[j], q);
+#else
+                *q = st[j];
+#endif
+            }
         } else {
             double st[6] = {0, 0, 0, 0, 0, 0};
             observe_state_cols<F>(a, p, s, st, 0);
             double *b = (double *)obs + i;
 #pragma unroll
-            for (int j = 0; j < NSTATE; j++)
-                b[(int64_t)(((F & F_GENSET) != 0 && j < 4) ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0))) * P] = st[j];
+            for (int j = 0; j < NSTATE; j++) {
+                double *q = b + (int64_t)(((F & F_GENSET) != 0 && j < 4) ? a.col_gen + j : a.col_bat + (j - ((F & F_GENSET) ? 4 : 0))) * P;
+#if MGX_STATE_NT
+                __builtin_nontemporal_store(st[j], q);
+#else
+                *q = st[j];
+#endif
+            }
         }
     } else if (a.obs_state_only) {          // the window columns of this row were prefetched (obs_windows_k_kernel)
         if (a.obs_f32) observe_state_cols<F>(a, p, s, (float *)obs + i * a.obs_dim);
