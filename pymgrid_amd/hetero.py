@@ -64,6 +64,8 @@ class BucketedFleet:
             env._fleet_ref = self if self.fused else None
             env._fast_ok = not self.fused       # a fused fleet steps its envs through mgx_fleet_step: no bound env steps
             env._rebind_fast()
+        # (stagger=True keeps the fleet on its per-step plans: the bound step, mgx_fleet_env_step, walks rings from phase 0 only --
+        #  _bind_eligible -- which costs ~3 us of host time per fleet step; staggering measured no gain, it is off by default)
         # stagger: bucket j's rings change j * K / n_buckets steps before bucket 0's, so that the buckets' ring refills -- each a
         # burst of K row blocks on a prefetch stream -- start at different fleet steps instead of all at once
         ringed = [env for env in self.envs if env.obs_prefetch]
