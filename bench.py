@@ -1144,10 +1144,11 @@ def main():
         # the same Gym cadence as TWO dependent launch chains (grid ranges on two shard streams, each issued by its own host thread)
         if want("step_2chains"):
             results["step_2chains"] = guarded("step_2chains", lambda: measure("step", True, side[0], side[1]))
-        if want("step_env_2chains"):
+        if want("step_env_2chains", args.all_legs):     # (the Python-loop forms of the two-chain step: --all-legs; the one-call form above stays
+                                                        #  in the default line as the record of the negative result)
             results["step_env_2chains"] = guarded("step_env_2chains", lambda: measure("step_env", True, min(side[0], 64), min(side[1], 16),
                                                                                       run=env_runner(False)))
-        if want("step_env_obs_2chains", not args.no_closed_loop):
+        if want("step_env_obs_2chains", args.all_legs and not args.no_closed_loop):
             results["step_env_obs_2chains"] = guarded("step_env_obs_2chains", lambda: measure("step_env", True, min(side[0], 64), min(side[1], 16),
                                                                                               run=env_runner(True)))
         # every output of the reference's step inside the timed region (SURVEY 8(d) "full total"): per-grid done, genset status, the

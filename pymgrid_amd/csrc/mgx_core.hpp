@@ -1514,7 +1514,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &
                 if constexpr (TRACK_P) { pe[j] = oc.genset_production; pm |= 1u << j; } psum += oc.genset_production; reward += oc.genset_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kg + LC_GENSET_N * j) * N;
-                    q[0] = oc.genset_production; q[N] = oc.genset_co2; q[2 * N] = oc.genset_reward; q[3 * N] = (double)s.status;
+                    MGX_LOG_ST(q + 0, oc.genset_production); MGX_LOG_ST(q + N, oc.genset_co2); MGX_LOG_ST(q + 2 * N, oc.genset_reward); MGX_LOG_ST(q + 3 * N, (double)s.status);
                 }
             }
         }
@@ -1541,8 +1541,8 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &
                 reward += oc.battery_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kb + LC_BATTERY_N * j) * N;
-                    q[0] = oc.discharge_amount; q[N] = oc.charge_amount; q[2 * N] = oc.battery_reward;
-                    q[3 * N] = oc.soc_pre; q[4 * N] = oc.charge_pre;
+                    MGX_LOG_ST(q + 0, oc.discharge_amount); MGX_LOG_ST(q + N, oc.charge_amount); MGX_LOG_ST(q + 2 * N, oc.battery_reward);
+                    MGX_LOG_ST(q + 3 * N, oc.soc_pre); MGX_LOG_ST(q + 4 * N, oc.charge_pre);
                 }
             }
         }
@@ -1567,7 +1567,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &
                 reward += oc.grid_reward; viol |= oc.violations;
                 if (log) {
                     double *q = log + (int64_t)(kr + LC_GRID_N * j) * N;
-                    q[0] = oc.grid_import; q[N] = oc.grid_export; q[2 * N] = oc.grid_co2; q[3 * N] = oc.grid_reward;
+                    MGX_LOG_ST(q + 0, oc.grid_import); MGX_LOG_ST(q + N, oc.grid_export); MGX_LOG_ST(q + 2 * N, oc.grid_co2); MGX_LOG_ST(q + 3 * N, oc.grid_reward);
                 }
             }
         }
@@ -1631,14 +1631,14 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &
     o.reward = reward;
     o.violations = viol;
     if (log) {
-        log[0] = o.reward;
-        log[N] = o.fixed_provided;        log[2 * N] = o.fixed_absorbed;
-        log[3 * N] = o.ctrl_provided;     log[4 * N] = o.ctrl_absorbed;
-        log[5 * N] = o.overall_provided;  log[6 * N] = o.overall_absorbed;
-        log[7 * N] = o.load_met;          log[8 * N] = o.renewable_used;
-        log[9 * N] = o.curtailment;       log[10 * N] = o.loss_load;
-        log[11 * N] = o.overgeneration;   log[12 * N] = o.unbalanced_reward;
-        log[(int64_t)(kr + LC_GRID_N * NR) * N] = (double)viol;
+        MGX_LOG_ST(log + 0, o.reward);
+        MGX_LOG_ST(log + N, o.fixed_provided);        MGX_LOG_ST(log + 2 * N, o.fixed_absorbed);
+        MGX_LOG_ST(log + 3 * N, o.ctrl_provided);     MGX_LOG_ST(log + 4 * N, o.ctrl_absorbed);
+        MGX_LOG_ST(log + 5 * N, o.overall_provided);  MGX_LOG_ST(log + 6 * N, o.overall_absorbed);
+        MGX_LOG_ST(log + 7 * N, o.load_met);          MGX_LOG_ST(log + 8 * N, o.renewable_used);
+        MGX_LOG_ST(log + 9 * N, o.curtailment);       MGX_LOG_ST(log + 10 * N, o.loss_load);
+        MGX_LOG_ST(log + 11 * N, o.overgeneration);   MGX_LOG_ST(log + 12 * N, o.unbalanced_reward);
+        MGX_LOG_ST(log + (int64_t)(kr + LC_GRID_N * NR) * N, (double)viol);
     }
 }
 

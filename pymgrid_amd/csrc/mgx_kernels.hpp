@@ -333,7 +333,10 @@ __device__ __forceinline__ void load_inputs_at(const AT *__restrict__ act, const
 // pv (/ co2) tables into LDS (64 B per row and table, out of the caches: every workgroup reads the same 8 KB), and a lane
 // picks its profile's column with one ds_read per value and step -- read one step ahead, so the LDS latency never meets a
 // dependent instruction.  The per-grid factors (profile ids, ratios) are loaded once per launch.
-constexpr int FACT_ROWS = 128;                        // rows per LDS chunk (a multiple of every ring depth)
+#ifndef MGX_FACT_ROWS
+#define MGX_FACT_ROWS 128
+#endif
+constexpr int FACT_ROWS = MGX_FACT_ROWS;              // rows per LDS chunk (a multiple of every ring depth)
 
 template <int F>
 __device__ __forceinline__ void stage_base_rows(const mgx_columns &c, int64_t row0, int32_t n, double *lds, int nthreads)
@@ -2212,10 +2215,11 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_small_kernel(const K
             double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
             step_multi_small<F, CNT, M>(a, R, in, i, normalized != 0, log, o);
             const double r = shaped_reward<F>(a.shaper, o);
-            if (out.reward) out.reward[off] = r;
+            // (write-once [K, N] streams: non-temporal stores, as in the single-instance fused kernels)
+            if (out.reward) __builtin_nontemporal_store(r, out.reward + off);
             if (out.done) out.done[off] = (uint8_t)(k >= k_done);
-            if constexpr (F & F_BATTERY) { if (out.soc_trace) out.soc_trace[off] = R.b_soc[0]; }
-            if constexpr (F & F_GENSET) { if (out.status_trace) out.status_trace[off] = R.g_status[0]; }
+            if constexpr (F & F_BATTERY) { if (out.soc_trace) __builtin_nontemporal_store(R.b_soc[0], out.soc_trace + off); }
+            if constexpr (F & F_GENSET) { if (out.status_trace) __builtin_nontemporal_store(R.g_status[0], out.status_trace + off); }
             ret += r;
         };
         int32_t k = 0;
