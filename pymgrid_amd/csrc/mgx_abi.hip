@@ -1473,10 +1473,23 @@ static int step_once(mgx_handle *h, const void *actions, int normalized, double 
                      hipStream_t st)
 {
     if (h->multi) {
+        // noisy forecasters: the rows come from observe_multi_kernel behind the step (the step kernel carries no noise code)
+        const bool rows_behind = obs && !h->k.obs_state_only && (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std);
+        void *obs_rows = obs;
+        if (rows_behind) {
+            if (h->n_shards > 1) return fail(MGX_ERR_UNSUPPORTED, "mgx_step: noisy observation rows are not written per shard");
+            obs = nullptr;
+        }
         for_each_shard_threaded(h, st, [&](const KArgs &k, hipStream_t s) {
-            MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
-                                          k, actions, t_arg(h), normalized, reward, done, obs, log, h->multi_small)));
+            if (h->inplace && k.ep_off) {                 // in-place episodes: the EP form (the grid's own rows, restarts in the kernel)
+                MGX_DISPATCH_F(h->flags, (step_multi_kernel<F, true><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
+                                              k, actions, t_arg(h), normalized, reward, done, obs, log, h->multi_small)));
+            } else {
+                MGX_DISPATCH_F(h->flags, (step_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
+                                              k, actions, t_arg(h), normalized, reward, done, obs, log, h->multi_small)));
+            }
         });
+        if (rows_behind) { if (int rc = launch_observe(h, dev_counter(h) ? 0 : h->t + 1, obs_rows, st)) return rc; }
         hipError_t em = launch_error();
         if (em != hipSuccess) return hip_fail(em, "step_multi_kernel launch");
         advance(h, 1, st);

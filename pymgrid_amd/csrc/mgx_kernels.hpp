@@ -1718,20 +1718,21 @@ __device__ __forceinline__ StepLists multi_lists(const KArgs &a, double *lds)
 // noise: GaussianNoiseForecaster on the general path (round 6; forecaster.py:220-275): forecast value h > 0 of the window gets
 // std * N(0, 1) -- std x (1 + log(1 + (h - 1))) with increase_uncertainty -- from the counter-based generator (seed; grid, component id,
 // series row, h), BEFORE the clip to the bounds, as in window_finish<NOISE>; statistical parity only.
-struct SeriesNoise { double std; uint64_t seed; int increase; int64_t grid; uint32_t comp; };
-
+// (the noise arguments travel BY VALUE: a struct handed over by address lived in the private segment -- 48 B of scratch per lane, which
+//  slowed every launch of step_multi_kernel by 7 %: tests/test_host_logic.py now refuses scratch on the general single-step kernels too)
 template <typename OT>
-__device__ inline void observe_series_multi(const double *__restrict__ ts, int64_t row_stride, int32_t T, int32_t t, int32_t H,
-                                            double lo, double hi, OT *__restrict__ obs, int obs_stride = 1,
-                                            const SeriesNoise *noise = nullptr)
+__device__ __forceinline__ void observe_series_multi(const double *__restrict__ ts, int64_t row_stride, int32_t T, int32_t t, int32_t H,
+                                                     double lo, double hi, OT *__restrict__ obs, int obs_stride = 1, bool noisy = false,
+                                                     double noise_std = 0.0, uint64_t noise_seed = 0, int noise_increase = 0,
+                                                     int64_t grid = 0, uint32_t comp = 0)
 {
     const double fill = (hi + lo) / 2, sp = space_spread(lo, hi);
     for (int h = 0; h <= H; h++) {
         const bool in = t < T && t + h < T;
         double v = in ? ts[(int64_t)(t + h) * row_stride] : 0.0;
-        if (noise && in && h > 0) {
-            const double sd = noise->increase ? noise->std * (1.0 + log(1.0 + (double)(h - 1))) : noise->std;
-            v += sd * forecast_normal(noise->seed, noise->grid, noise->comp, t, h);
+        if (noisy && in && h > 0) {
+            const double sd = noise_increase ? noise_std * (1.0 + log(1.0 + (double)(h - 1))) : noise_std;
+            v += sd * forecast_normal(noise_seed, grid, comp, t, h);
         }
         obs[h * obs_stride] = (OT)obs_series_value(v, in, h > 0, lo, hi, fill, sp);
     }
@@ -1767,7 +1768,9 @@ __device__ inline void observe_state_multi(const KArgs &a, int64_t i, OT *__rest
 // flat order: load windows, pv windows, gensets (4 columns each), batteries (2 each), grid windows (4 (1 + H) each).
 // MGX_OBS_ROWS_STATE_ONLY (a.obs_state_only == 1): the row lives in a prefetched ring whose window columns
 // obs_windows_k_multi_kernel has written already -- only the genset / battery columns are stored.
-template <int F, typename OT>
+// NOISE: the noisy-forecaster form -- only observe_multi_kernel carries it (a noisy batch's step launches write no rows themselves, the host
+// sends the rows' launch behind them: with the noise code inlined step_multi_kernel spilled 90 more SGPRs and ran 7 % slower for everyone)
+template <int F, typename OT, bool NOISE = false>
 __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, OT *__restrict__ obs_row)
 {
     const int64_t N = a.N;
@@ -1777,33 +1780,35 @@ __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, O
     if (a.obs_state_only) return;
     k = 0;
     // noisy forecasters: one std per module instance ([n, N] columns), a component id per (kind, instance, component) for the generator
-    SeriesNoise nz{0.0, a.noise_seed, a.noise_increase, i, 0u};
+    const uint64_t nseed = a.noise_seed;
+    const int ninc = a.noise_increase;
     for (int j = 0; j < a.n_load; j++, k += W) {
-        const bool noisy = a.c.load_noise_std != nullptr;
-        if (noisy) { nz.std = a.c.load_noise_std[(int64_t)j * N + i]; nz.comp = (uint32_t)j; }
+        const bool noisy = NOISE && a.c.load_noise_std != nullptr;
+        const double sd = noisy ? a.c.load_noise_std[(int64_t)j * N + i] : 0.0;
         observe_series_multi(a.c.load_ts + (int64_t)j * N + i, (int64_t)a.n_load * N, a.T, t, a.H, a.c.load_lo[(int64_t)j * N + i],
-                             a.c.load_hi[(int64_t)j * N + i], obs_row + k, 1, noisy ? &nz : nullptr);
+                             a.c.load_hi[(int64_t)j * N + i], obs_row + k, 1, noisy, sd, nseed, ninc, i, (uint32_t)j);
     }
     for (int j = 0; j < a.n_pv; j++, k += W) {
-        const bool noisy = a.c.pv_noise_std != nullptr;
-        if (noisy) { nz.std = a.c.pv_noise_std[(int64_t)j * N + i]; nz.comp = (uint32_t)(MGX_MAX_MODULES + j); }
+        const bool noisy = NOISE && a.c.pv_noise_std != nullptr;
+        const double sd = noisy ? a.c.pv_noise_std[(int64_t)j * N + i] : 0.0;
         observe_series_multi(a.c.pv_ts + (int64_t)j * N + i, (int64_t)a.n_pv * N, a.T, t, a.H, a.c.pv_lo[(int64_t)j * N + i],
-                             a.c.pv_hi[(int64_t)j * N + i], obs_row + k, 1, noisy ? &nz : nullptr);
+                             a.c.pv_hi[(int64_t)j * N + i], obs_row + k, 1, noisy, sd, nseed, ninc, i, (uint32_t)(MGX_MAX_MODULES + j));
     }
     k += 4 * a.n_genset + 2 * a.n_battery;
     if constexpr (F & F_GRID) {
         for (int j = 0; j < a.n_grid; j++, k += 4 * W)
             for (int cc = 0; cc < 4; cc++) {
                 const int64_t c = ((int64_t)j * 4 + cc) * N + i;
-                const bool noisy = a.c.grid_noise_std != nullptr;
-                if (noisy) { nz.std = a.c.grid_noise_std[(int64_t)j * N + i]; nz.comp = (uint32_t)(2 * MGX_MAX_MODULES + 4 * j + cc); }
+                const bool noisy = NOISE && a.c.grid_noise_std != nullptr;
+                const double sd = noisy ? a.c.grid_noise_std[(int64_t)j * N + i] : 0.0;
                 observe_series_multi(a.c.grid_ts + c, (int64_t)a.n_grid * 4 * N, a.T, t, a.H, a.c.grid_lo[c], a.c.grid_hi[c],
-                                     obs_row + k + cc, 4, noisy ? &nz : nullptr);
+                                     obs_row + k + cc, 4, noisy, sd, nseed, ninc, i, (uint32_t)(2 * MGX_MAX_MODULES + 4 * j + cc));
             }
     }
 }
 
-template <int F>
+// EP: in-place per-grid episodes (the lock-step form carries none of it, as step_kernel<F, EP>)
+template <int F, bool EP = false>
 __global__ __launch_bounds__(BLOCK_MULTI) void step_multi_kernel(const KArgs a, const void *__restrict__ actions, int32_t t,
                                                                  int normalized, double *__restrict__ reward,
                                                                  uint8_t *__restrict__ done, void *__restrict__ obs,
@@ -1818,8 +1823,8 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_multi_kernel(const KArgs a, 
         Outputs o;
         // in-place per-grid episodes (mgx_reset_episodes on the general path, round 6): the grid reads row counter + ep_off[i] of its
         // own [T, n, N] series (a per-lane gather); `tr` is the counter itself otherwise
-        int32_t off = a.ep_off ? a.ep_off[i] : 0;
-        const int32_t tr = a.ep_off ? (int32_t)episode_row(a, t, off) : t;
+        int32_t off = 0, tr = t;
+        if constexpr (EP) { off = a.ep_off[i]; tr = (int32_t)episode_row(a, t, off); }
         if (small) {                                     // at most MS modules of a kind: everything requested up front, the sweep on registers
             MultiRegs R; MultiStepIn sin;
             load_multi_regs<F>(a, i, R);
@@ -1832,7 +1837,7 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_multi_kernel(const KArgs a, 
         reward[i] = shaped_reward<F>(a.shaper, o);
         const uint8_t dn = done_at(a, i, t);
         if (done) done[i] = dn;
-        if (a.ep_off) { off = episode_auto_restart(a, i, t, off, dn != 0); t += off; }      // (the observation: row counter + 1 + offset)
+        if constexpr (EP) { off = episode_auto_restart(a, i, t, off, dn != 0); t += off; }  // (the observation: row counter + 1 + offset)
         if (obs) {
             if (a.obs_state_only == 1 && a.obs_colpitch) {            // the state columns of a COLUMN-major ring block: coalesced runs
                 const int64_t P = a.obs_colpitch, k0 = (int64_t)(a.n_load + a.n_pv) * (1 + a.H);
@@ -1858,7 +1863,11 @@ __global__ __launch_bounds__(BLOCK_MULTI) void observe_multi_kernel(const KArgs 
         else observe_state_multi<F>(a, i, (double *)obs + k0 * P + i, P);
         return;
     }
-    if (a.obs_f32) observe_row_multi<F>(a, i, t, (float *)obs + i * a.obs_dim);
+    const bool noisy = a.c.load_noise_std || a.c.pv_noise_std || a.c.grid_noise_std;
+    if (noisy) {
+        if (a.obs_f32) observe_row_multi<F, float, true>(a, i, t, (float *)obs + i * a.obs_dim);
+        else observe_row_multi<F, double, true>(a, i, t, (double *)obs + i * a.obs_dim);
+    } else if (a.obs_f32) observe_row_multi<F>(a, i, t, (float *)obs + i * a.obs_dim);
     else observe_row_multi<F>(a, i, t, (double *)obs + i * a.obs_dim);
 }
 
@@ -2182,8 +2191,11 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a
 // `small` arm of step_k_multi_kernel in a kernel of its own -- without the run-time-count arm and the priority-list arm beside it the
 // loop keeps its pointers in SGPRs (the shared kernel reloaded ~100 spilled SGPRs per step through v_readlane).
 // CNT: the instance counts, run-time (CountsRT: any small layout) or compile-time (CountsCT: the layouts of mgx_fused.hip part 5).
+#ifndef MGX_M3_WAVES
+#define MGX_M3_WAVES 1
+#endif
 template <int F, class CNT = CountsRT, int M = MS>
-__global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_small_kernel(const KArgs a, const void *__restrict__ actions, int32_t t0, int32_t K,
+__global__ __launch_bounds__(BLOCK_MULTI, (M >= 3 ? MGX_M3_WAVES : 1)) void step_k_multi_small_kernel(const KArgs a, const void *__restrict__ actions, int32_t t0, int32_t K,
                                                                          int normalized, const FusedOut out)
 {
     const int32_t K_launch = K;
