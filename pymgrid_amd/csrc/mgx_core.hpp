@@ -1297,6 +1297,7 @@ struct CountsRT {
     static __device__ __forceinline__ int nl(const KArgs &a) { return a.n_load; }
     static __device__ __forceinline__ int np(const KArgs &a) { return a.n_pv; }
     static constexpr bool is_static = false;
+    static constexpr int kNG = 0, kNB = 0;
     static constexpr int max_prov = 0, max_absb = 0, max_mid_prov = 0, max_mid_absb = 0;   // (unused: the slot counts decide)
 };
 constexpr int MS_CT = 3;     // most instance slots a compile-time-count specialisation may hold
@@ -1305,6 +1306,7 @@ struct CountsCT {
     static_assert(NG_ <= MS_CT && NB_ <= MS_CT && NR_ <= MS_CT && NL_ >= 1 && NL_ <= MS_CT && NP_ >= 1 && NP_ <= MS_CT, "the register form holds M instances");
     static constexpr int slots = (NG_ > MS || NB_ > MS || NR_ > MS || NL_ > MS || NP_ > MS) ? MS_CT : MS;     // M of the kernel
     static constexpr bool is_static = true;
+    static constexpr int kNG = NG_, kNB = NB_;
     // most addends MicrogridStep's lists can hold: at the end of the sweep (gensets / discharging batteries / importing grids / renewables /
     // loss load; loads / charging batteries / exporting grids / overgeneration) and after the controllable modules (:277)
     static constexpr int max_prov = NG_ + NB_ + NR_ + NP_ + 1, max_absb = NL_ + NB_ + NR_ + 1, max_mid_prov = NG_ + NB_ + NR_,
@@ -1335,6 +1337,48 @@ struct MultiStepInT {                    // what one step reads besides: control
     double load[M], pv[M], grid[M][4];
 };
 using MultiStepIn = MultiStepInT<MS>;
+
+// LDS PARKING of step-invariant parameters (round 6, the three-of-a-kind forms): 3 gensets + 3 batteries + 1 grid keep 330 registers
+// per lane live across the K-step loop -- one wave per SIMD, so a 100 000-grid launch runs in two rounds of waves.  The parameters a
+// step reads ONCE (cost terms, capacity limits, the action-space constants) wait in a per-lane LDS column instead (slot-major,
+// PARK_STRIDE lanes per slot: lane-consecutive 8-byte reads, conflict-free) and are read where the sweep needs them; the dynamic state and
+// the power limits stay in registers.  The reads are `volatile` so that the compiler does not hoist them back out of the loop into
+// registers.  Same operands, same operations: the bits cannot differ.  At most 38 doubles per lane (3 gensets + 3 batteries) = 19 456 B per wave: 8 waves per CU.
+constexpr int PARK_STRIDE = 64;
+template <class CNT, int M>
+struct ParkSlots {                                          // slot rows: per genset 4, per battery 8, loss-load / overgeneration cost
+    static constexpr int NG = CNT::is_static ? CNT::kNG : M, NB = CNT::is_static ? CNT::kNB : M;
+    static constexpr int G_RMIN = 0, G_COST = NG, G_CO2 = 2 * NG, G_CCO2 = 3 * NG, B0 = 4 * NG, B_CMIN = B0, B_CMAX = B0 + NB, B_ETA = B0 + 2 * NB,
+                         B_COST = B0 + 3 * NB, B_C = B0 + 4 * NB, B_D = B0 + 5 * NB, B_LO = B0 + 6 * NB, B_SP = B0 + 7 * NB, LL = B0 + 8 * NB, OG = LL + 1,
+                         COUNT = OG + 1;
+};
+// (an LDS-address-space pointer: a volatile access through a generic pointer stays a flat_load with a 64-bit address and system scope)
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __forceinline__ double park_ld(const lds_double *pk, int slot) { return *(const volatile lds_double *)(pk + slot * PARK_STRIDE); }
+
+template <int F, class CNT, int M>
+__device__ __forceinline__ void park_multi_regs(const KArgs &a, const MultiRegsT<M> &R, lds_double *pk)
+{
+    using PS = ParkSlots<CNT, M>;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        if constexpr (F & F_GENSET) {
+            if (j < CNT::ng(a)) {
+                pk[(PS::G_RMIN + j) * PARK_STRIDE] = R.g_rmin[j]; pk[(PS::G_COST + j) * PARK_STRIDE] = R.g_cost[j];
+                pk[(PS::G_CO2 + j) * PARK_STRIDE] = R.g_co2[j]; pk[(PS::G_CCO2 + j) * PARK_STRIDE] = R.g_cco2[j];
+            }
+        }
+        if constexpr (F & F_BATTERY) {
+            if (j < CNT::nb(a)) {
+                pk[(PS::B_CMIN + j) * PARK_STRIDE] = R.b_cmin[j]; pk[(PS::B_CMAX + j) * PARK_STRIDE] = R.b_cmax[j];
+                pk[(PS::B_ETA + j) * PARK_STRIDE] = R.b_eta[j]; pk[(PS::B_COST + j) * PARK_STRIDE] = R.b_cost[j];
+                pk[(PS::B_C + j) * PARK_STRIDE] = R.b_C[j]; pk[(PS::B_D + j) * PARK_STRIDE] = R.b_D[j];
+                pk[(PS::B_LO + j) * PARK_STRIDE] = R.d_bat[j].bat_lo; pk[(PS::B_SP + j) * PARK_STRIDE] = R.d_bat[j].bat_sp;
+            }
+        }
+    }
+    pk[PS::LL * PARK_STRIDE] = R.ll_cost; pk[PS::OG * PARK_STRIDE] = R.og_cost;
+}
 
 __host__ __device__ inline bool multi_is_small(int n_load, int n_pv, int n_genset, int n_battery, int n_grid)
 {
@@ -1459,11 +1503,14 @@ __device__ __forceinline__ double small_pairwise_prov(const double (&e)[SMALL_PR
     return res;
 }
 
-template <int F, class CNT = CountsRT, int M = MS>
+template <int F, class CNT = CountsRT, int M = MS, bool PARK = false>
 __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &R, const MultiStepInT<M> &sin, int64_t i, bool normalized,
-                                                 double *__restrict__ log, Outputs &o)
+                                                 double *__restrict__ log, Outputs &o, const lds_double *pk = nullptr)
 {
     const int64_t N = a.N;
+    using PS = ParkSlots<CNT, M>;
+    // a parked parameter comes from its LDS slot (park_multi_regs), any other from the register copy
+    auto cold = [&](int slot, double reg) __attribute__((always_inline)) { if constexpr (PARK) return park_ld(pk, slot); else return reg; };
     const int NG = CNT::ng(a), NB = CNT::nb(a), NR = CNT::nr(a), NL = CNT::nl(a), NP = CNT::np(a);
     double reward = 0.0;
     uint32_t viol = 0u;
@@ -1504,9 +1551,10 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &
         for (int j = 0; j < M; j++) {
             if (j < NG) {
                 Params p; Derived d; State s;
-                p.gen_rmin = R.g_rmin[j]; p.gen_rmax = R.g_rmax[j]; p.gen_cost = R.g_cost[j]; p.gen_co2 = R.g_co2[j];
-                p.gen_cco2 = R.g_cco2[j]; p.gen_times = R.g_times[j];
+                p.gen_rmin = cold(PS::G_RMIN + j, R.g_rmin[j]); p.gen_rmax = R.g_rmax[j]; p.gen_cost = cold(PS::G_COST + j, R.g_cost[j]);
+                p.gen_co2 = cold(PS::G_CO2 + j, R.g_co2[j]); p.gen_cco2 = cold(PS::G_CCO2 + j, R.g_cco2[j]); p.gen_times = R.g_times[j];
                 d = R.d_gen[j];
+                if constexpr (PARK) derive<F_GENSET>(p, d);          // (formed again from running_max, which stays in a register: a compare and a select)
                 s.status = R.g_status[j];
                 in.a_goal = sin.goal[j]; in.a_gen = sin.gen[j];
                 step_core<F_GENSET>(p, d, s, in, normalized, false, false, oc);
@@ -1525,9 +1573,10 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &
         for (int j = 0; j < M; j++) {
             if (j < NB) {
                 Params p; Derived d; State s;
-                p.bat_cmin = R.b_cmin[j]; p.bat_cmax = R.b_cmax[j]; p.bat_C = R.b_C[j]; p.bat_D = R.b_D[j];
-                p.bat_eta = R.b_eta[j]; p.bat_cost = R.b_cost[j];
+                p.bat_cmin = cold(PS::B_CMIN + j, R.b_cmin[j]); p.bat_cmax = cold(PS::B_CMAX + j, R.b_cmax[j]); p.bat_C = cold(PS::B_C + j, R.b_C[j]);
+                p.bat_D = cold(PS::B_D + j, R.b_D[j]); p.bat_eta = cold(PS::B_ETA + j, R.b_eta[j]); p.bat_cost = cold(PS::B_COST + j, R.b_cost[j]);
                 d = R.d_bat[j];
+                if constexpr (PARK) { d.bat_lo = park_ld(pk, PS::B_LO + j); d.bat_sp = park_ld(pk, PS::B_SP + j); }
                 s.charge = R.b_charge[j]; s.soc = R.b_soc[j]; s.status = 0u;
                 in.a_bat = sin.bat[j];
                 step_core<F_BATTERY>(p, d, s, in, normalized, true, false, oc);
@@ -1588,7 +1637,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &
     const double difference = provided - consumed;
     o.ctrl_provided = provided - o.fixed_provided; o.ctrl_absorbed = consumed - o.fixed_absorbed;
 
-    const double ll_cost = R.ll_cost, og_cost = R.og_cost;
+    const double ll_cost = cold(PS::LL, R.ll_cost), og_cost = cold(PS::OG, R.og_cost);
     o.renewable_used = 0.0; o.curtailment = 0.0;
     if (difference > 0) {                                 // :286-299: renewables idle, the excess is overgeneration
 #pragma unroll

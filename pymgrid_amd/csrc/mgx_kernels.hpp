@@ -2192,7 +2192,10 @@ __global__ __launch_bounds__(BLOCK_MULTI) void step_k_multi_kernel(const KArgs a
 // loop keeps its pointers in SGPRs (the shared kernel reloaded ~100 spilled SGPRs per step through v_readlane).
 // CNT: the instance counts, run-time (CountsRT: any small layout) or compile-time (CountsCT: the layouts of mgx_fused.hip part 5).
 #ifndef MGX_M3_WAVES
-#define MGX_M3_WAVES 1
+#define MGX_M3_WAVES 2
+#endif
+#ifndef MGX_M3_PARK
+#define MGX_M3_PARK 1
 #endif
 template <int F, class CNT = CountsRT, int M = MS>
 __global__ __launch_bounds__(BLOCK_MULTI, (M >= 3 ? MGX_M3_WAVES : 1)) void step_k_multi_small_kernel(const KArgs a, const void *__restrict__ actions, int32_t t0, int32_t K,
@@ -2202,6 +2205,11 @@ __global__ __launch_bounds__(BLOCK_MULTI, (M >= 3 ? MGX_M3_WAVES : 1)) void step
     t0 = resolve_t(a, t0);
     K = resolve_k(a, t0, K);
     const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
+    // M = 3: the once-per-step parameters wait in LDS (park_multi_regs, mgx_core.hpp) -- two waves per SIMD instead of one
+    constexpr bool PARK = M >= 3 && MGX_M3_PARK;
+    static_assert(BLOCK_MULTI == PARK_STRIDE, "one LDS slot row per workgroup lane");
+    __shared__ double park[PARK ? ParkSlots<CNT, M>::COUNT * PARK_STRIDE : 1];
+    lds_double *pk = (lds_double *)park + threadIdx.x;
     if (i < a.g1) {
         const int64_t N = a.N;
         const int A = 2 * CNT::ng(a) + CNT::nb(a) + CNT::nr(a);
@@ -2209,6 +2217,7 @@ __global__ __launch_bounds__(BLOCK_MULTI, (M >= 3 ? MGX_M3_WAVES : 1)) void step
         double ret = 0.0;
         MultiRegsT<M> R; MultiStepInT<M> cur, nxt;
         load_multi_regs<F, CNT, M>(a, i, R);
+        if constexpr (PARK) park_multi_regs<F, CNT, M>(a, R, pk);
         if (K > 0) {
             if (a.act_f32) load_multi_step_in<F, float, CNT, M>(a, (const float *)actions + (int64_t)i * A, i, t0, cur);
             else load_multi_step_in<F, double, CNT, M>(a, (const double *)actions + (int64_t)i * A, i, t0, cur);
@@ -2225,7 +2234,7 @@ __global__ __launch_bounds__(BLOCK_MULTI, (M >= 3 ? MGX_M3_WAVES : 1)) void step
             const int64_t off = (int64_t)k * N + i;
             Outputs o;
             double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
-            step_multi_small<F, CNT, M>(a, R, in, i, normalized != 0, log, o);
+            step_multi_small<F, CNT, M, PARK>(a, R, in, i, normalized != 0, log, o, pk);
             const double r = shaped_reward<F>(a.shaper, o);
             // (write-once [K, N] streams: non-temporal stores, as in the single-instance fused kernels)
             if (out.reward) __builtin_nontemporal_store(r, out.reward + off);
@@ -2242,7 +2251,11 @@ __global__ __launch_bounds__(BLOCK_MULTI, (M >= 3 ? MGX_M3_WAVES : 1)) void step
             one_step(k + 1, nxt);
         }
         if (k < K) one_step(k, cur);
-        store_multi_state<F, CNT, M>(a, i, R);
+        // (the state columns' addresses are formed again here from an index the compiler cannot see through: held across the loop since the
+        //  prologue's loads they were the registers the three-of-a-kind form spilled)
+        int64_t i_out = i;
+        asm volatile("" : "+v"(i_out));
+        store_multi_state<F, CNT, M>(a, i_out, R);
         if (out.ret_acc) out.ret_acc[i] += ret;
     }
     advance_counter_in_kernel(a, K_launch);
