@@ -1151,16 +1151,9 @@ class _SingleMixin:
             root = os.path.join(list(spec.submodule_search_locations)[0], "data", "scenario")
         return cls(from_scenario(microgrid_number, root), **kwargs)
 
-    @classmethod
-    def from_microgrid(cls, microgrid, **kwargs):
-        """``Env.from_microgrid(microgrid)`` (envs/base/base.py:253-283): wrap an existing microgrid with the environment
-        API.  ``microgrid`` is a parameter dict or one of this module's N = 1 envs -- its parameters WITH its current
-        dynamic state (battery charge / SoC, genset status; logs are not carried over, as in the reference), its reward
-        shaper and trajectory function unless overridden."""
-        if isinstance(microgrid, dict):
-            return cls(microgrid, **kwargs)
-        if not isinstance(microgrid, BatchedMicrogridEnv) or microgrid.n_grids != 1:
-            raise TypeError("microgrid must be a parameter dict or an N = 1 env of this module")
+    def _params_now(self):
+        """The parameter dict of this microgrid WITH its current dynamic state (battery charge / SoC, genset status)."""
+        microgrid = self
         params = dict(microgrid._params)
         c = microgrid.batch.cols
         L = microgrid.layout
@@ -1174,6 +1167,19 @@ class _SingleMixin:
             st = unpack_status(c["gen_status"].cpu().numpy().view(np.uint32).reshape(L.n_genset, -1)[:, 0])
             gens = [dict(q, status=[int(v) for v in st[j]]) for j, q in enumerate(module_list(params["genset"]))]
             params["genset"] = gens if isinstance(params["genset"], (list, tuple)) else gens[0]
+        return params
+
+    @classmethod
+    def from_microgrid(cls, microgrid, **kwargs):
+        """``Env.from_microgrid(microgrid)`` (envs/base/base.py:253-283): wrap an existing microgrid with the environment
+        API.  ``microgrid`` is a parameter dict or one of this module's N = 1 envs -- its parameters WITH its current
+        dynamic state (battery charge / SoC, genset status; logs are not carried over, as in the reference), its reward
+        shaper and trajectory function unless overridden."""
+        if isinstance(microgrid, dict):
+            return cls(microgrid, **kwargs)
+        if not isinstance(microgrid, BatchedMicrogridEnv) or microgrid.n_grids != 1:
+            raise TypeError("microgrid must be a parameter dict or an N = 1 env of this module")
+        params = microgrid._params_now()
         kwargs = dict(kwargs)
         kwargs.setdefault("reward_shaping_func", microgrid.reward_shaping_func)
         kwargs.setdefault("trajectory_func", microgrid.trajectory_func)
@@ -1272,6 +1278,240 @@ class _SingleMixin:
         return out
 
 
+    # ---- Microgrid's methods beside `run` (microgrid.py:334-335, 388-431, 699-759): state, cost info, (de)normalisation ----
+    def run(self, control, normalized=True):
+        """``Microgrid.run`` (microgrid.py:227-325): one step under a control dict ``{name: [value per module]}``; returns
+        ``(observation, reward, done, info)`` with the NESTED observation ``{name: [array per module]}`` whatever ``flat_spaces``
+        says (flattening is ``BaseMicrogridEnv.step``'s, envs/base/base.py:169-209).  A control that lacks a controllable module
+        raises ValueError like the reference (:266-267)."""
+        for name, n in (("genset", self.layout.n_genset), ("battery", self.layout.n_battery), ("grid", self.layout.n_grid)):
+            if n and name not in control:
+                raise ValueError(f'Control for module "{name}" not found. Available controls:\n\t{control.keys()}')
+        action = self.control_to_tensor(control).to(self.engine.action_dtype)
+        obs, reward, done, info = BatchedMicrogridEnv.step(self, action, normalized=normalized)
+        return self._nested(obs[0].cpu().numpy()), float(reward.item()), bool(done.item()), \
+            self._info_out(info, action[0].double().cpu().numpy(), normalized)
+
+    def _container_order(self):
+        """(name, instances) in the module container's order: fixed, flex, controllable (module_container.py:355-413)."""
+        L = self.layout
+        sas = [("battery", L.n_battery), ("grid", L.n_grid)]
+        if L.grid_before_battery:
+            sas.reverse()
+        return [(n, k) for n, k in [("load", L.n_load), ("pv", L.n_pv), ("unbalanced_energy", 1), ("genset", L.n_genset)] + sas if k]
+
+    def _col(self, name, *shape):
+        return self.batch.cols[name].detach().reshape(*shape, -1)[..., 0].cpu().numpy()
+
+    def _state_blocks(self):
+        """Per module instance in container order: (name, j, keys, raw values, low, high) -- the module's ``_state_dict`` and the
+        bounds of its observation space: time-series modules base_timeseries_module.py:81-97,103-122 (values past the end of the
+        series are the middle of the bounds: forecaster.py:120-135), battery battery_module.py:280-281,323-330, genset
+        genset_module.py:426-431,503-509.  Read from the batch's columns (the values the kernels normalise)."""
+        from .batch import unpack_status
+        L, c = self.layout, self.batch.cols
+        if "load_ts" not in c and L.n_load:
+            raise RuntimeError("state_dict reads the series columns: materialise a factorised batch first")
+        H, T, t = L.horizon, L.n_steps, int(self.current_step)
+        W = 1 + H
+        names, inst = L.obs_names, L.obs_instances()
+        keep = getattr(self.batch, "obs_keep", None)
+        rows = np.arange(t, t + W)
+        inside = rows < T
+        rr = np.minimum(rows, T - 1)
+
+        def window(ts, lo, hi):                 # rows t .. t + H of a series [W, C] -> [W * C] in the row's order (component-minor), padded
+            v = np.where(inside[:, None], ts, ((hi + lo) / 2)[None, :])
+            return v.reshape(-1), np.tile(lo, W), np.tile(hi, W)
+        out = []
+        for name, n in self._container_order():
+            for j in range(n):
+                if name == "unbalanced_energy":
+                    out.append((name, 0, [], np.zeros(0), np.zeros(0), np.zeros(0)))
+                    continue
+                sl = inst[name][j]
+                keys = names[sl]
+                if name in ("load", "pv"):
+                    ts = self._series_rows(name + "_ts", (T, n), rr)[:, j:j + 1]
+                    lo, hi = self._col(name + "_lo", n)[j:j + 1], self._col(name + "_hi", n)[j:j + 1]
+                    v, lo, hi = window(ts, lo, hi)
+                elif name == "grid":
+                    ts = self._series_rows("grid_ts", (T, n, 4), rr)[:, j, :]
+                    lo, hi = self._col("grid_lo", n, 4)[j], self._col("grid_hi", n, 4)[j]
+                    v, lo, hi = window(ts, lo, hi)
+                elif name == "battery":
+                    cmin, cmax = float(self._col("bat_min_capacity", n)[j]), float(self._col("bat_max_capacity", n)[j])
+                    v = np.array([self._col("soc", n)[j], self._col("charge", n)[j]], dtype=np.float64)
+                    lo, hi = np.array([cmin / cmax, cmin]), np.array([1.0, cmax])
+                else:
+                    st = unpack_status(self._col("gen_status", n)[j])
+                    tm = int(self._col("gen_times", n)[j])
+                    v = st.astype(np.int64)
+                    lo, hi = np.zeros(4), np.array([1.0, 1.0, float(tm & 0xff), float((tm >> 16) & 0xff)])
+                if keep is not None and name in ("load", "pv", "grid"):       # per-module horizons: the columns this module has
+                    sel = [q - sl.start for q in keep if sl.start <= q < sl.stop]
+                    keys, v, lo, hi = [keys[q] for q in sel], v[sel], lo[sel], hi[sel]
+                out.append((name, j, list(keys), v, lo, hi))
+        return out
+
+    def _series_rows(self, name, shape, rr):
+        """rows `rr` of a series column [T, ..., N] of this one microgrid -> numpy [len(rr), ...]"""
+        ts = self.batch.cols[name].detach().reshape(*shape, -1)
+        return ts[torch.as_tensor(rr, device=ts.device)][..., 0].cpu().numpy().reshape(len(rr), *shape[1:])
+
+    def state_dict(self, normalized=False):
+        """``Microgrid.state_dict`` (microgrid.py:699-717): ``{name: [state dict per module]}`` in the container's order.  Raw values
+        come from the batch's columns; normalised ones are ``(value - low) / spread`` as ModuleSpace.normalize forms them
+        (space.py:207-218, spread 0 -> 1) -- the arithmetic of the observation kernels.  (With no forecaster the reference's own
+        normalised state_dict raises TypeError -- a one-value state normalises to a float, base_module.py:488 --; here it works.)"""
+        out = {}
+        for name, j, keys, v, lo, hi in self._state_blocks():
+            if normalized and len(keys):
+                sp = hi - lo
+                sp = np.where(sp == 0, 1.0, sp)
+                vals = ((v.astype(np.float64) - lo) / sp).tolist()
+            else:
+                vals = v.tolist()
+            out.setdefault(name, []).append(dict(zip(keys, vals)))
+        return out
+
+    def state_series(self, normalized=False):
+        """``Microgrid.state_series`` (microgrid.py:736-759): the state as a pandas Series indexed (module name, number, key)."""
+        import pandas as pd
+        return pd.Series({(name, num, key): value for name, lst in self.state_dict(normalized=normalized).items()
+                          for num, sd in enumerate(lst) for key, value in sd.items()})
+
+    def get_cost_info(self):
+        """``Microgrid.get_cost_info`` (microgrid.py:334-335): production / absorption marginal cost of every module at the current
+        step -- genset ``get_cost(1.0)`` (genset_module.py:188-205,519-521), battery ``battery_cost_cycle`` both ways
+        (battery_module.py:340-346), grid the current import / export price (grid_module.py:322-328), the unbalanced-energy module
+        its loss-load / overgeneration cost (unbalanced_energy_module.py:111-117), 0.0 for load and renewable modules."""
+        L = self.layout
+        t = min(int(self.current_step), L.n_steps - 1)
+        out = {}
+        for name, n in self._container_order():
+            lst = []
+            for j in range(n):
+                prod = absb = 0.0
+                if name == "unbalanced_energy":
+                    prod, absb = float(self._col("loss_load_cost")), float(self._col("overgeneration_cost"))
+                elif name == "genset":
+                    production = 1.0
+                    co2 = float(self._col("gen_co2_per_unit", n)[j]) * production
+                    prod = float(self._col("gen_cost", n)[j]) * production + float(self._col("gen_cost_per_unit_co2", n)[j]) * co2
+                elif name == "battery":
+                    prod = absb = float(self._col("bat_cost_cycle", n)[j])
+                elif name == "grid":
+                    row = self._series_rows("grid_ts", (L.n_steps, n, 4), np.array([t]))[0, j]
+                    prod, absb = float(row[0]), float(row[1])
+                lst.append({"production_marginal_cost": prod, "absorption_marginal_cost": absb})
+            out[name] = lst
+        return out
+
+    def _action_bounds_static(self, name, j):
+        """(low, high) of a module's action space: genset_module.py:511-517, battery_module.py:332-338, grid_module.py:125-132"""
+        L = self.layout
+        if name == "genset":
+            return np.array([0.0, 0.0]), np.array([1.0, float(self._col("gen_running_max", L.n_genset)[j])])
+        if name == "battery":
+            n = L.n_battery
+            eta = float(self._col("bat_efficiency", n)[j])
+            return -float(self._col("bat_max_discharge", n)[j]) / eta, float(self._col("bat_max_charge", n)[j]) * eta
+        if name == "grid":
+            n = L.n_grid
+            return -1 * float(self._col("grid_max_export", n)[j]), float(self._col("grid_max_import", n)[j])
+        raise KeyError(name)
+
+    def _normalise_dict(self, data_dict, act, obs, forward):
+        assert act + obs == 1, "One of act or obs must be True but not both."
+        blocks = {(name, j): (lo, hi) for name, j, _, _, lo, hi in self._state_blocks()} if obs else None
+        out = {}
+        for name, n in self._container_order():
+            if name not in data_dict:
+                continue
+            lst = []
+            for j, value in zip(range(n), data_dict[name]):
+                lo, hi = blocks[(name, j)] if obs else self._action_bounds_static(name, j)
+                sp = np.asarray(hi - lo, dtype=np.float64)
+                sp = np.where(sp == 0, 1.0, sp)
+                res = (value - lo) / sp if forward else lo + sp * value
+                try:
+                    res = res.item()                          # ModuleSpace hands scalars back for one-value spaces (space.py:215-218)
+                except (AttributeError, ValueError):
+                    pass
+                lst.append(res)
+            out[name] = lst
+        return out
+
+    def to_normalized(self, data_dict, act=False, obs=False):
+        """``Microgrid.to_normalized`` (microgrid.py:388-409): ``{name: [value per module]}`` of actions (``act=True``) or state arrays
+        (``obs=True``) -> ``(value - low) / spread`` per module (ModuleSpace.normalize, space.py:207-218)."""
+        return self._normalise_dict(data_dict, act, obs, True)
+
+    def from_normalized(self, data_dict, act=False, obs=False):
+        """``Microgrid.from_normalized`` (microgrid.py:411-431): ``low + spread * value`` per module (ModuleSpace.denormalize)."""
+        return self._normalise_dict(data_dict, act, obs, False)
+
+    @property
+    def modules(self):
+        """``Microgrid.modules`` (microgrid.py:688-697): name -> list of module views (read-only, modules.py)."""
+        from .modules import ModuleContainerView
+        return ModuleContainerView(self)
+
+    @property
+    def fixed(self):
+        return self.modules.fixed
+
+    @property
+    def flex(self):
+        return self.modules.flex
+
+    @property
+    def controllable(self):
+        return self.modules.controllable
+
+    @property
+    def module_list(self):
+        return self.modules.to_list()
+
+    def set_module_attr(self, attr_name, value):
+        """``Microgrid.set_module_attr`` (microgrid.py:583-610) for the attributes the device path can change in place: the step
+        window (``initial_step`` / ``final_step``: ``microgrid.initial_step = t`` in the reference, :612-680; takes effect like
+        there -- the counter moves at the next ``reset``).  An attribute no module has raises AttributeError as the reference does;
+        a module PARAMETER (costs, capacities ...) lives in the batch's columns and is set when the batch is built."""
+        lo, hi = self.engine.window
+        if attr_name == "initial_step":
+            self.engine.set_window(int(value), hi)
+        elif attr_name == "final_step":
+            self.engine.set_window(lo, int(value))
+        else:
+            from .modules import _PARAMS
+            if any(attr_name in cols for cols in _PARAMS.values()):
+                raise NotImplementedError(f"'{attr_name}' is a column of the device batch: build the batch with the new value")
+            raise AttributeError(f"No module has attribute '{attr_name}'.")
+
+    def dump(self, stream):
+        """``Microgrid.dump(stream)`` (microgrid.py:820-846) to a path or an open file: the ``!Microgrid`` YAML with the dynamic state
+        and the step counter, the series as ``csv.gz`` files next to it (scenario.dump_scenario_yaml) -- a file the reference's
+        ``Microgrid.load`` and this package's ``load`` both read.  (The inline form the reference returns for ``stream=None`` is not
+        offered.)"""
+        from .scenario import dump_scenario_yaml
+        if stream is None:
+            raise NotImplementedError("dump(None): pass a path (the series are written as csv.gz files next to the YAML)")
+        path = stream if isinstance(stream, (str, bytes)) or hasattr(stream, "__fspath__") else stream.name
+        params = dict(self._params_now(), current_step=self.current_step)
+        dump_scenario_yaml(params, str(path))
+
+    @property
+    def log(self):
+        """``Microgrid.log`` (microgrid.py:719-734): the log as a DataFrame (= ``get_log()``)."""
+        return self.get_log_frame()
+
+    def render(self, mode="human"):
+        """``BaseMicrogridEnv.render`` (envs/base/base.py:225-227)."""
+        raise NotImplementedError
+
+
 class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
     """One microgrid behind ``BaseMicrogridEnv``'s API: ``step(control_dict, normalized=True)`` returns
     ``(obs, float, bool, dict)`` exactly like envs/base/base.py:169-209."""
@@ -1298,7 +1538,6 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
         return self._obs_out(obs), float(reward.item()), bool(done.item()), \
             self._info_out(info, action[0].double().cpu().numpy(), normalized)
 
-    run = step
 
     def sample_action(self, strict_bound=False, sample_flex_modules=False):
         """``Microgrid.sample_action`` (microgrid.py:337-362): a random NORMALISED control dict ``{name: [per-module value]}`` (a
