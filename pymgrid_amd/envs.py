@@ -1292,6 +1292,11 @@ class _SingleMixin:
         return self._nested(obs[0].cpu().numpy()), float(reward.item()), bool(done.item()), \
             self._info_out(info, action[0].double().cpu().numpy(), normalized)
 
+    def get_empty_action(self, sample_flex_modules=False):
+        """``Microgrid.get_empty_action`` (microgrid.py:364-381): the control dict's shape with ``None`` entries."""
+        L = self.layout
+        return {name: [None] * n for name, n in (("genset", L.n_genset), ("battery", L.n_battery), ("grid", L.n_grid)) if n}
+
     def _container_order(self):
         """(name, instances) in the module container's order: fixed, flex, controllable (module_container.py:355-413)."""
         L = self.layout
@@ -1566,11 +1571,6 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
             if kind == "grid" and L.has_grid:
                 out["grid"] = [float(draw(2 * L.n_genset + L.n_battery + j)) for j in range(L.n_grid)]
         return out
-
-    def get_empty_action(self, sample_flex_modules=False):
-        """``Microgrid.get_empty_action`` (microgrid.py:364-381): the control dict's shape with ``None`` entries."""
-        L = self.layout
-        return {name: [None] * n for name, n in (("genset", L.n_genset), ("battery", L.n_battery), ("grid", L.n_grid)) if n}
 
 
 class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):

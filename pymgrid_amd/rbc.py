@@ -111,7 +111,9 @@ class RuleBasedControl:
 
     Parameters mirror the reference: ``priority_list`` None -> marginal-cost order per grid; or one list of
     ``(module, action)`` pairs applied to every grid.  ``run`` returns ``{"reward": [K, N], ...}`` (the balance
-    log's reward column; pass ``log=True`` for every log column) and leaves the engine at the end of the episode.
+    log's reward column; pass ``log=True`` for every log column) and leaves the engine at the end of the episode.  On an N = 1
+    adaptor (``MicrogridEnv`` / ``DiscreteMicrogridEnv`` with ``log=True``) ``run()`` returns what the reference's does (rbc.py:64-93):
+    the microgrid's log as a DataFrame (``as_frame=False`` for the tensors).
     """
 
     def __init__(self, env, priority_list=None, remove_redundant_gensets=True):
@@ -172,12 +174,37 @@ class RuleBasedControl:
     def reset(self):
         return self.env.reset()
 
-    def run(self, max_steps=None, chunk=512, log=False, soc_trace=False, reward=True, restore_state=False):
+    @property
+    def microgrid(self):
+        """``PriorityListAlgo.microgrid`` (priority_list.py:169-180): the microgrid(s) under control -- the env."""
+        return self.env
+
+    @property
+    def modules(self):
+        return self.env.modules
+
+    @property
+    def fixed(self):
+        return self.env.fixed
+
+    @property
+    def flex(self):
+        return self.env.flex
+
+    def get_empty_action(self):
+        return self.env.get_empty_action()
+
+    def run(self, max_steps=None, chunk=512, log=False, soc_trace=False, reward=True, restore_state=False, as_frame=None, verbose=False):
         """``RuleBasedControl.run`` (rbc.py:64-93): reset the microgrids -- through the env, so a ``trajectory_func``
         redraws the episode window as ``Microgrid.reset`` does (microgrid.py:205-225) -- then deploy the priority lists
         until ``done`` (the end of the CURRENT episode window) or for ``max_steps`` steps.  The reference works on a deep
         copy of the microgrid; here the batch itself is stepped unless ``restore_state=True`` puts battery charge / SoC and
         genset status back afterwards."""
+        from .envs import _SingleMixin
+        if as_frame is None:                              # the reference returns the microgrid's log (rbc.py:93): so does an N = 1 adaptor
+            as_frame = isinstance(self.env, _SingleMixin) and getattr(self.env, "_keep_log", False) and not (log or soc_trace)
+        if as_frame:
+            log = True
         self.env.reset()
         lo, hi = self.engine.window                       # the window the reset has just installed
         total = hi - lo                                   # done fires at counter hi - 1: hi - lo steps in all
@@ -185,7 +212,12 @@ class RuleBasedControl:
             total = min(total, int(max_steps))
         saved = self.batch.state() if restore_state else None
         try:
-            return self._run(total, chunk, log, soc_trace, reward)
+            res = self._run(total, chunk, log, soc_trace, reward)
+            if as_frame:                                  # the steps' log rows become the env's log, as if it had been stepped: get_log() works after
+                self.env._log_rows = list(res["log"])
+                self.env._shaped_rows = list(res["reward"])
+                return self.env.get_log_frame()
+            return res
         finally:
             if saved is not None:
                 self.batch.load_state(saved)
