@@ -1072,6 +1072,15 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
 # ---------------------------------------------------------------------------------------------------------
 # N = 1 adaptors with the reference's exact Python return shapes
 # ---------------------------------------------------------------------------------------------------------
+def _as_params(params, add_unbalanced_module=True, loss_load_cost=10.0, overgeneration_cost=2.0):
+    """A parameter dict as it is; a list of module descriptions (``Microgrid([...])``, microgrid.py:100-173) through
+    modules.params_from_modules."""
+    if isinstance(params, dict):
+        return params
+    from .modules import params_from_modules
+    return params_from_modules(list(params), add_unbalanced_module, loss_load_cost, overgeneration_cost)
+
+
 def _n1_order(params, flat_order):
     """flat_order of an N = 1 adaptor: "gym" (the reference's flat vector under gym's key-sorting Dict) is offered for one
     module of every kind; microgrids with several modules of a kind keep the module order."""
@@ -1522,8 +1531,12 @@ class MicrogridEnv(_SingleMixin, BatchedMicrogridEnv):
     ``(obs, float, bool, dict)`` exactly like envs/base/base.py:169-209."""
 
     def __init__(self, params, device="cuda", flat_spaces=True, log=True, reward_shaping_func=None,
-                 trajectory_func=None, raise_errors=False, observation_keys=None, flat_order="module"):
+                 trajectory_func=None, raise_errors=False, observation_keys=None, flat_order="module",
+                 add_unbalanced_module=True, loss_load_cost=10.0, overgeneration_cost=2.0):
+        # ``params``: a parameter dict, or the reference's own form -- a list of modules (modules.py; Microgrid.__init__,
+        # microgrid.py:100-173, with its add_unbalanced_module / loss_load_cost / overgeneration_cost arguments)
         # (a parameter dict read from a serialised microgrid may carry its trajectory_func / raise_errors: the defaults here)
+        params = _as_params(params, add_unbalanced_module, loss_load_cost, overgeneration_cost)
         super().__init__(MicrogridBatch.from_grids([params], device=device, flat_order=_n1_order(params, flat_order)), log=log,
                          reward_shaping_func=reward_shaping_func if reward_shaping_func is not None else params.get("reward_shaping_func"),
                          trajectory_func=trajectory_func if trajectory_func is not None else params.get("trajectory_func"),
@@ -1578,7 +1591,9 @@ class DiscreteMicrogridEnv(_SingleMixin, DiscreteBatchedMicrogridEnv):
     ``step(action: int) -> (obs, reward: float, done: bool, info: dict)``."""
 
     def __init__(self, params, device="cuda", flat_spaces=True, log=True, remove_redundant_gensets=True,
-                 reward_shaping_func=None, trajectory_func=None, raise_errors=False, observation_keys=None, flat_order="module"):
+                 reward_shaping_func=None, trajectory_func=None, raise_errors=False, observation_keys=None, flat_order="module",
+                 add_unbalanced_module=True, loss_load_cost=10.0, overgeneration_cost=2.0):
+        params = _as_params(params, add_unbalanced_module, loss_load_cost, overgeneration_cost)
         super().__init__(MicrogridBatch.from_grids([params], device=device, flat_order=_n1_order(params, flat_order)), log=log,
                          remove_redundant_gensets=remove_redundant_gensets,
                          reward_shaping_func=reward_shaping_func if reward_shaping_func is not None else params.get("reward_shaping_func"),

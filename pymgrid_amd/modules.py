@@ -1,12 +1,156 @@
-"""Read-only views of ONE microgrid's modules in the reference's vocabulary: ``microgrid.modules`` / ``.fixed`` / ``.flex`` /
-``.controllable`` / ``.module_list`` (microgrid.py:761-818, modules/module_container.py:355-413) over the columns of an N = 1
-batch.  A view holds no data: every attribute is read from the batch when it is asked for, so it shows the state the kernels
-left.  Parameters are those of the modules' constructors (battery_module.py:60-106, genset_module.py:61-98, grid_module.py:58-96,
-load_module.py:45-70, renewable_module.py:45-70, unbalanced_energy_module.py:9-26); writing is not offered (the device path has
-no per-module Python objects to write to -- ``set_module_attr`` covers the step window)."""
+"""The reference's modules as this package sees them, in two halves.
+
+Descriptions: ``BatteryModule`` / ``GensetModule`` / ``GridModule`` / ``LoadModule`` / ``RenewableModule`` / ``UnbalancedEnergyModule``
+take the reference constructors' arguments (battery_module.py:66-106, genset_module.py:61-98, grid_module.py:73-123,
+load_module.py:58-80, renewable_module.py:61-84, unbalanced_energy_module.py:13-26), check what those check, and keep them as data:
+``Microgrid([("load", LoadModule(...)), BatteryModule(...), ...], loss_load_cost=..)`` (microgrid.py:100-173) builds the N = 1 batch
+from them.  They do not step -- the microgrid steps on the device.
+
+Views: ``microgrid.modules`` / ``.fixed`` / ``.flex`` / ``.controllable`` / ``.module_list`` (microgrid.py:761-818,
+modules/module_container.py:355-413) are read-only views over the batch's columns: every attribute is read from the batch when it
+is asked for, so it shows the state the kernels left (``microgrid.modules.battery[0].soc``).  Writing is not offered (the device
+path has no per-module Python objects to write to -- ``set_module_attr`` covers the step window)."""
 import numpy as np
 
 from .batch import unpack_status
+
+DEFAULT_HORIZON = 23          # microgrid/__init__.py:1
+
+
+class _ModuleSpec:
+    """The constructor arguments of one of the reference's modules, kept as data: ``Microgrid([...])`` turns a list of these into
+    the columns of an N = 1 batch (scenario.params_from_module_docs: the rules of the modules' constructors).  Not a stepping
+    object -- the microgrid steps on the device; read a module's live state through ``microgrid.modules``."""
+    tag, default_name = None, None
+
+    def __init__(self, **cls_params):
+        self.cls_params = cls_params
+
+    def doc(self):
+        return {"__tag__": self.tag, "cls_params": dict(self.cls_params), "state": {}}
+
+    def __repr__(self):
+        args = ", ".join(f"{k}={type(v).__name__ if isinstance(v, np.ndarray) else v!r}" for k, v in self.cls_params.items())
+        return f"{type(self).__name__}({args})"
+
+
+class BatteryModule(_ModuleSpec):
+    """``pymgrid.modules.BatteryModule`` (battery_module.py:66-106)."""
+    tag, default_name = "!BatteryModule", "battery"
+
+    def __init__(self, min_capacity, max_capacity, max_charge, max_discharge, efficiency, battery_cost_cycle=0.0,
+                 battery_transition_model=None, init_charge=None, init_soc=None, initial_step=0, raise_errors=False):
+        assert 0 < efficiency <= 1
+        if init_charge is None and init_soc is None:
+            raise ValueError("Must set one of init_charge and init_soc.")                      # battery_module.py:96-106
+        if init_charge is not None and init_soc is not None:
+            import warnings
+            warnings.warn("Passed both init_capa and init_soc. Using init_charge and ignoring init_soc")
+            init_soc = None
+        super().__init__(min_capacity=min_capacity, max_capacity=max_capacity, max_charge=max_charge, max_discharge=max_discharge,
+                         efficiency=efficiency, battery_cost_cycle=battery_cost_cycle, battery_transition_model=battery_transition_model,
+                         init_charge=init_charge, init_soc=init_soc, initial_step=initial_step, raise_errors=raise_errors)
+
+
+class GensetModule(_ModuleSpec):
+    """``pymgrid.modules.GensetModule`` (genset_module.py:61-98)."""
+    tag, default_name = "!Genset", "genset"
+
+    def __init__(self, running_min_production, running_max_production, genset_cost, co2_per_unit=0.0, cost_per_unit_co2=0.0,
+                 start_up_time=0, wind_down_time=0, allow_abortion=True, init_start_up=True, initial_step=0, raise_errors=False,
+                 provided_energy_name="genset_production"):
+        if running_min_production > running_max_production:
+            raise ValueError("parameter min_production must not be greater than parameter max_production.")
+        if callable(genset_cost):
+            raise NotImplementedError("a callable genset_cost is not offered on the device path")
+        super().__init__(running_min_production=running_min_production, running_max_production=running_max_production,
+                         genset_cost=genset_cost, co2_per_unit=co2_per_unit, cost_per_unit_co2=cost_per_unit_co2,
+                         start_up_time=start_up_time, wind_down_time=wind_down_time, allow_abortion=allow_abortion,
+                         init_start_up=init_start_up, initial_step=initial_step, raise_errors=raise_errors)
+
+
+class _SeriesSpec(_ModuleSpec):
+    def __init__(self, time_series, forecaster, forecast_horizon, forecaster_increase_uncertainty, forecaster_relative_noise,
+                 initial_step, final_step, raise_errors, **more):
+        if callable(forecaster):
+            raise NotImplementedError("user-defined forecasters (callables) are not offered on the device path")
+        super().__init__(time_series=np.asarray(time_series, dtype=np.float64), forecaster=forecaster, forecast_horizon=forecast_horizon,
+                         forecaster_increase_uncertainty=forecaster_increase_uncertainty,
+                         forecaster_relative_noise=forecaster_relative_noise, initial_step=initial_step, final_step=final_step,
+                         raise_errors=raise_errors, **more)
+
+
+class LoadModule(_SeriesSpec):
+    """``pymgrid.modules.LoadModule`` (load_module.py:58-80)."""
+    tag, default_name = "!LoadModule", "load"
+
+    def __init__(self, time_series, forecaster=None, forecast_horizon=DEFAULT_HORIZON, forecaster_increase_uncertainty=False,
+                 forecaster_relative_noise=False, initial_step=0, final_step=-1, raise_errors=False):
+        super().__init__(time_series, forecaster, forecast_horizon, forecaster_increase_uncertainty, forecaster_relative_noise,
+                         initial_step, final_step, raise_errors)
+
+
+class RenewableModule(_SeriesSpec):
+    """``pymgrid.modules.RenewableModule`` (renewable_module.py:61-84)."""
+    tag, default_name = "!RenewableModule", "pv"
+
+    def __init__(self, time_series, raise_errors=False, forecaster=None, forecast_horizon=DEFAULT_HORIZON,
+                 forecaster_increase_uncertainty=False, forecaster_relative_noise=False, initial_step=0, final_step=-1,
+                 provided_energy_name="renewable_used"):
+        super().__init__(time_series, forecaster, forecast_horizon, forecaster_increase_uncertainty, forecaster_relative_noise,
+                         initial_step, final_step, raise_errors)
+
+
+class GridModule(_SeriesSpec):
+    """``pymgrid.modules.GridModule`` (grid_module.py:73-123): ``time_series`` [T, 3] (import price, export price, co2 per kWh:
+    the grid is always up) or [T, 4] (+ grid status)."""
+    tag, default_name = "!GridModule", "grid"
+
+    def __init__(self, max_import, max_export, time_series, forecaster=None, forecast_horizon=DEFAULT_HORIZON,
+                 forecaster_increase_uncertainty=False, forecaster_relative_noise=False, initial_step=0, final_step=-1,
+                 cost_per_unit_co2=0.0, raise_errors=False):
+        ts = np.asarray(time_series, dtype=np.float64)
+        if max_import < 0 or max_export < 0:                                              # grid_module.py:98-104
+            raise ValueError("parameter max_import / max_export must be non-negative.")
+        if ts.ndim != 2 or ts.shape[1] not in (3, 4):
+            raise ValueError("Time series must be two dimensional with three or four columns."
+                             "See docstring for details.")
+        if ts.shape[1] == 3:                                                              # :106-109: the status column is all ones
+            ts = np.concatenate([ts, np.ones((ts.shape[0], 1))], axis=1)
+        if (ts < 0).any():
+            raise ValueError("Time series must be non-negative.")
+        if not ((ts[:, 3] == 0) | (ts[:, 3] == 1)).all():
+            raise ValueError("Last column (grid status) must contain binary values.")
+        super().__init__(ts, forecaster, forecast_horizon, forecaster_increase_uncertainty, forecaster_relative_noise,
+                         initial_step, final_step, raise_errors, max_import=max_import, max_export=max_export,
+                         cost_per_unit_co2=cost_per_unit_co2)
+
+
+class UnbalancedEnergyModule(_ModuleSpec):
+    """``pymgrid.modules.UnbalancedEnergyModule`` (unbalanced_energy_module.py:13-26)."""
+    tag, default_name = "!UnbalancedEnergyModule", "unbalanced_energy"
+
+    def __init__(self, raise_errors, initial_step=0, loss_load_cost=10, overgeneration_cost=2.0):
+        super().__init__(raise_errors=raise_errors, initial_step=initial_step, loss_load_cost=loss_load_cost,
+                         overgeneration_cost=overgeneration_cost)
+
+
+def params_from_modules(modules, add_unbalanced_module=True, loss_load_cost=10.0, overgeneration_cost=2.0,
+                        reward_shaping_func=None, trajectory_func=None):
+    """``Microgrid(modules, add_unbalanced_module, loss_load_cost, overgeneration_cost, ...)`` (microgrid.py:100-173): a list of
+    module descriptions -- bare or ``(name, module)`` tuples; the names are this package's fixed ones whatever the tuple says --
+    to the parameter dict the N = 1 adaptors are built from."""
+    from .scenario import params_from_module_docs
+    docs = []
+    for item in modules:
+        mod = item[1] if isinstance(item, tuple) else item
+        if not isinstance(mod, _ModuleSpec):
+            raise TypeError(f"modules must be list-like of modules, not {type(mod).__name__}")
+        docs.append((mod.default_name, mod.doc()))
+    if add_unbalanced_module:
+        docs.append(("unbalanced_energy", UnbalancedEnergyModule(False, loss_load_cost=loss_load_cost,
+                                                                 overgeneration_cost=overgeneration_cost).doc()))
+    return params_from_module_docs({"modules": docs, "trajectory_func": trajectory_func, "reward_shaping_func": reward_shaping_func})
 
 # reference attribute -> batch column, per kind
 _PARAMS = {

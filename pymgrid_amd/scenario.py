@@ -121,6 +121,13 @@ def load_scenario_yaml(path):
         doc = yaml.load(fh, Loader=_make_loader(os.path.dirname(os.path.abspath(path))))
     if doc.get("__tag__") not in ("!Microgrid", "!DiscreteMicrogridEnv"):
         raise ValueError(f"{path}: not a !Microgrid document")
+    return params_from_module_docs(doc, path)
+
+
+def params_from_module_docs(doc, path="<modules>"):
+    """The parameter dict of a microgrid described as ``{"modules": [(name, {"__tag__", "cls_params", "state"}), ...],
+    "trajectory_func": .., "reward_shaping_func": ..}`` -- what a serialised ``!Microgrid`` document holds (load_scenario_yaml) and
+    what a list of this package's module descriptions (modules.py: ``Microgrid([BatteryModule(...), ...])``) turns into."""
     p = {"load_ts": [], "pv_ts": [], "grid_ts": [], "grid": [], "genset": [], "battery": []}
     for key in ("trajectory_func", "reward_shaping_func"):           # (Microgrid._serialization_data writes the former only)
         if doc.get(key) is not None:
@@ -184,17 +191,20 @@ def load_scenario_yaml(path):
             if cp.get("battery_transition_model") is not None:
                 raise NotImplementedError("custom battery_transition_model is not supported")
             cap = float(cp["max_capacity"])
-            if "current_charge" in state:
+            if "current_charge" in state:                # the setters of a restored state: soc = charge / max_capacity
                 charge = float(state["current_charge"])
-            elif cp.get("init_charge") is not None:
+                soc = charge / cap
+            elif cp.get("init_charge") is not None:      # the constructor's rules (battery_module.py:96-106)
                 charge = float(cp["init_charge"])
+                soc = charge / cap
             else:
-                charge = float(cp["init_soc"]) * cap
+                soc = float(cp["init_soc"])
+                charge = soc * cap
             p["battery"].append(dict(min_capacity=float(cp["min_capacity"]), max_capacity=cap,
                                      max_charge=float(cp["max_charge"]), max_discharge=float(cp["max_discharge"]),
                                      efficiency=float(cp["efficiency"]),
                                      battery_cost_cycle=float(cp.get("battery_cost_cycle", 0.0)),
-                                     charge=charge, soc=charge / cap))
+                                     charge=charge, soc=soc))
     # one module of a kind: the plain vocabulary (a dict, a [T] series); several: lists / [T, n] (module_container.py:355-413
     # keeps a list per name)
     if not ts_meta:         # (the reference cannot build such a microgrid either: Microgrid.__init__ -> get_attrs('final_step') finds no value)
