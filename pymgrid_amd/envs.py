@@ -897,7 +897,7 @@ class BatchedMicrogridEnv:
         columns (module_name, module_number, field) (microgrid.py:434-475).  Columns that are verbatim copies of the
         input series (``*_current``, ``*_forecast_j``) are not materialised."""
         import pandas as pd
-        log = self.get_log()
+        log = BatchedMicrogridEnv.get_log(self)
         if not log:
             return pd.DataFrame()
         col = {k: np.asarray(v)[:, grid] for k, v in log.items()}
@@ -1516,10 +1516,26 @@ class _SingleMixin:
         params = dict(self._params_now(), current_step=self.current_step)
         dump_scenario_yaml(params, str(path))
 
+    def get_log(self, as_frame=True, drop_singleton_key=False):
+        """``Microgrid.get_log`` (microgrid.py:434-475): the log as a DataFrame with (module_name, module_number, field) columns,
+        indexed by step from ``initial_step`` -- or, ``as_frame=False``, that frame's ``to_dict()``.  (The batched envs' plain
+        ``{column: [steps, N]}`` form is ``get_log_columns()``.)"""
+        df = self.get_log_frame()
+        if len(df):
+            import pandas as pd
+            df.index = pd.RangeIndex(start=self.current_step - len(df), stop=self.current_step)
+            if drop_singleton_key:
+                df.columns = df.columns.remove_unused_levels()
+        return df if as_frame else df.to_dict()
+
+    def get_log_columns(self, as_numpy=True):
+        """The batched form of the log: ``{column: [steps, 1]}`` (BatchedMicrogridEnv.get_log)."""
+        return BatchedMicrogridEnv.get_log(self, as_numpy=as_numpy)
+
     @property
     def log(self):
         """``Microgrid.log`` (microgrid.py:719-734): the log as a DataFrame (= ``get_log()``)."""
-        return self.get_log_frame()
+        return self.get_log()
 
     def render(self, mode="human"):
         """``BaseMicrogridEnv.render`` (envs/base/base.py:225-227)."""

@@ -216,7 +216,7 @@ class RuleBasedControl:
             if as_frame:                                  # the steps' log rows become the env's log, as if it had been stepped: get_log() works after
                 self.env._log_rows = list(res["log"])
                 self.env._shaped_rows = list(res["reward"])
-                return self.env.get_log_frame()
+                return self.env.get_log()
             return res
         finally:
             if saved is not None:

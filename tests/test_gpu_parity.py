@@ -313,12 +313,13 @@ def test_gym_adaptors_shapes(pymgrid25, device):
             obs, reward, done, info = env.step(a)
             assert obs.shape == (env.layout.obs_dim,) and isinstance(reward, float) and isinstance(done, bool)
             assert env.last_log["reward"] == reward and set(info) == set(env._nested(obs)) and "provided_energy" in info["pv"][0]
-        assert len(env.get_log()["reward"]) == 10
-        df = env.get_log_frame()                          # Microgrid.get_log(as_frame=True) shape
-        assert len(df) == 10 and df.columns.nlevels == 3
-        assert np.array_equal(df[("balance", 0, "reward")].values, env.get_log()["reward"][:, 0])
+        assert len(env.get_log_columns()["reward"]) == 10
+        df = env.get_log()                                # Microgrid.get_log(as_frame=True) shape, indexed by step
+        assert len(df) == 10 and df.columns.nlevels == 3 and list(df.index) == list(range(env.current_step - 10, env.current_step))
+        assert np.array_equal(df[("balance", 0, "reward")].values, env.get_log_columns()["reward"][:, 0])
         assert ("battery", 0, "soc") in df.columns and ("unbalanced_energy", 0, "loss_load") in df.columns
-        env.reset(); assert env.current_step == 0 and env.get_log() == {}
+        assert env.get_log(as_frame=False)[("balance", 0, "reward")][env.current_step - 1] == df[("balance", 0, "reward")].iloc[-1]
+        env.reset(); assert env.current_step == 0 and len(env.get_log()) == 0 and env.get_log_columns() == {}
         with pytest.raises(ValueError):
             env.step(env.action_space.n)
         env.close()
@@ -344,7 +345,9 @@ def test_gym_adaptors_shapes(pymgrid25, device):
         ctrl = mg.sample_action()
         assert set(ctrl) == set(mg.get_empty_action()) == {k for k in ("genset", "battery", "grid") if pymgrid25[n].get(k) is not None}
         o2, r2, d2, i2 = mg.run(ctrl, normalized=True)
-        assert isinstance(r2, float) and isinstance(d2, bool) and len(o2) == mg.layout.obs_dim
+        assert isinstance(r2, float) and isinstance(d2, bool)
+        # (run returns MicrogridStep's NESTED observation whatever flat_spaces says: microgrid.py:325; the flattening is env.step's)
+        assert isinstance(o2, dict) and sum(len(a) for v in o2.values() for a in v) == mg.layout.obs_dim
         mg.close()
         twin = DiscreteMicrogridEnv.from_microgrid(env)
         for name in ("charge", "soc", "gen_status"):
