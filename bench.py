@@ -593,6 +593,24 @@ def general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist):
                                            "note": "parameters and state live in LDS for the launch (round 5): charged once per launch; "
                                                    "per step the controls, the series rows and the reward stream"}}
     out["k_step_launches"]["roofline_valu"] = valu_roofline("step_k_multi_small_kernel<7,mgx::CountsCT<2,2,1,1,1>,2>", gpu / stepsK * Kg, N, 1, dev)
+    # RuleBasedControl on the same layout (f1 on the general path, round 6): one fixed priority list per grid (sorted by marginal cost,
+    # rbc.py:26-62), the controls expanded in registers (rollout_multi_small_kernel); per step only the series rows are read
+    from pymgrid_amd.priority_list import get_instance_priority_lists, lists_array
+    from pymgrid_amd.rbc import default_instance_priority_ids
+    pls = get_instance_priority_lists(Lg.n_genset, Lg.n_battery, Lg.n_grid, (), Lg.grid_before_battery)
+    pl_tab = torch.as_tensor(lists_array(pls), device=dev).contiguous()
+    pl_ids = torch.from_numpy(default_instance_priority_ids(gb, pls)).to(dev).to(torch.int32).contiguous()
+    rbc_out = {"reward": torch.empty(Kg, N, dtype=torch.float64, device=dev)}
+    wall, gpu, stepsR = run(lambda: ge.rollout_lists(pl_ids, pl_tab, Kg, reward=True, out=rbc_out), nK, Kg)
+    streamR = 8 * c_ts + 8
+    bR_launch = (streamR * Kg + (Lg.bytes_per_step() - 1 - stream_b)) * N
+    out["rbc_rollout"] = {"value": n_total * stepsR / wall, "us_per_step": gpu / stepsR * 1e6, "steps_per_launch": Kg,
+                          "roofline": {"bound": "hbm", "achieved": bR_launch / Kg / (gpu / stepsR) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": bR_launch / Kg / (gpu / stepsR) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                       "algorithmic_bytes_per_launch": bR_launch, "kernel": "rollout_multi_small_kernel<7, CountsCT<2,2,1,1,1>, 2>",
+                                       "bytes_per_env_step": bR_launch / Kg / N, "avg_launch_us": gpu / stepsR * Kg * 1e6,
+                                       "note": "no action stream: the priority-list walk (5 modules) and the step are arithmetic -- VALU / latency bound; "
+                                               "the run-time-count kernel with its walk over the batch's columns took 14.8 us per env-step"}}
     out["layout"] = "2 gensets + 2 batteries + 1 grid + load + pv per microgrid (general kernels), materialised series"
     out["grids_per_gpu"], out["rows"] = N, rows_g
     ge.close()
@@ -695,7 +713,7 @@ def compact_line(detail, mode, detail_name):
             legs["config5"] = {"error": str(hetero["error"])[:80]}
     if isinstance(general, dict):
         for k, short in (("single_steps", "general_single_step"), ("k_step_launches", "general_k_step"), ("gym_steps_rows_h24", "general_gym_rows_h24"),
-                         ("k_step_3_of_a_kind", "general_k_step_3_of_a_kind")):
+                         ("k_step_3_of_a_kind", "general_k_step_3_of_a_kind"), ("rbc_rollout", "general_rbc_rollout")):
             if k in general:
                 legs[short] = leg(general[k], "us_per_step")
         if "error" in general:

@@ -1955,7 +1955,13 @@ int mgx_rollout_lists(mgx_handle *h, const int32_t *action_id, int per_step, con
         return fail(MGX_ERR_RANGE, "mgx_rollout_lists: steps [%d, %d) leave the time series (length %d)", h->t, h->t + K, step_limit(h));
     hipStream_t st = (hipStream_t)stream;
     const FusedOut fo{reward, done, soc_trace, status_trace, ret_acc, log};
+    const bool static_counts = tune(MGX_TUNE_MULTI_STATIC) != 0 && tune(MGX_TUNE_MULTI_SMALL_OWN) != 0;
     for_each_shard(h, st, [&](const KArgs &k, hipStream_t s) {
+        if (static_counts && k.n_load >= 1 && k.n_pv >= 1) {     // the register form where the layout has a compile-time-count specialisation
+            MultiStaticRollout L{h->flags, k.n_genset, k.n_battery, k.n_grid, k.n_load, k.n_pv, multi_blocks(k.g1 - k.g0), s, &k, lists,
+                                 n_lists, list_len, action_id, per_step, t_arg(h), K, fo};
+            if (launch_rollout_multi_static(L)) return;
+        }
         MGX_DISPATCH_F(h->flags, (step_k_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
                                       k, nullptr, lists, n_lists, list_len, action_id, per_step, t_arg(h), K, 0, fo, h->multi_small)));
     });

@@ -1297,7 +1297,7 @@ struct CountsRT {
     static __device__ __forceinline__ int nl(const KArgs &a) { return a.n_load; }
     static __device__ __forceinline__ int np(const KArgs &a) { return a.n_pv; }
     static constexpr bool is_static = false;
-    static constexpr int kNG = 0, kNB = 0;
+    static constexpr int kNG = 0, kNB = 0, kNR_ = 0;
     static constexpr int max_prov = 0, max_absb = 0, max_mid_prov = 0, max_mid_absb = 0;   // (unused: the slot counts decide)
 };
 constexpr int MS_CT = 3;     // most instance slots a compile-time-count specialisation may hold
@@ -1306,7 +1306,7 @@ struct CountsCT {
     static_assert(NG_ <= MS_CT && NB_ <= MS_CT && NR_ <= MS_CT && NL_ >= 1 && NL_ <= MS_CT && NP_ >= 1 && NP_ <= MS_CT, "the register form holds M instances");
     static constexpr int slots = (NG_ > MS || NB_ > MS || NR_ > MS || NL_ > MS || NP_ > MS) ? MS_CT : MS;     // M of the kernel
     static constexpr bool is_static = true;
-    static constexpr int kNG = NG_, kNB = NB_;
+    static constexpr int kNG = NG_, kNB = NB_, kNR_ = NR_;
     // most addends MicrogridStep's lists can hold: at the end of the sweep (gensets / discharging batteries / importing grids / renewables /
     // loss load; loads / charging batteries / exporting grids / overgeneration) and after the controllable modules (:277)
     static constexpr int max_prov = NG_ + NB_ + NR_ + NP_ + 1, max_absb = NL_ + NB_ + NR_ + 1, max_mid_prov = NG_ + NB_ + NR_,
@@ -1505,7 +1505,7 @@ __device__ __forceinline__ double small_pairwise_prov(const double (&e)[SMALL_PR
 
 template <int F, class CNT = CountsRT, int M = MS, bool PARK = false>
 __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &R, const MultiStepInT<M> &sin, int64_t i, bool normalized,
-                                                 double *__restrict__ log, Outputs &o, const lds_double *pk = nullptr)
+                                                 double *__restrict__ log, Outputs &o, const lds_double *pk = nullptr, uint32_t viol0 = 0u)
 {
     const int64_t N = a.N;
     using PS = ParkSlots<CNT, M>;
@@ -1513,7 +1513,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &
     auto cold = [&](int slot, double reg) __attribute__((always_inline)) { if constexpr (PARK) return park_ld(pk, slot); else return reg; };
     const int NG = CNT::ng(a), NB = CNT::nb(a), NR = CNT::nr(a), NL = CNT::nl(a), NP = CNT::np(a);
     double reward = 0.0;
-    uint32_t viol = 0u;
+    uint32_t viol = viol0;                                // (the expansion's assert mask when the control came from a priority list)
     // The provided / absorbed lists of MicrogridStep in REGISTERS: running sums kept as the sweep appends (numpy's sum of fewer than
     // eight addends IS the running sum from 0.0 in list order) + one static slot per possible `provided` addend in sweep order with a
     // presence bit each, for the one sum that can see 8 or 9 addends -- the run-time form appends to LDS columns and sums them with a
@@ -1689,6 +1689,159 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &
         MGX_LOG_ST(log + 11 * N, o.overgeneration);   MGX_LOG_ST(log + 12 * N, o.unbalanced_reward);
         MGX_LOG_ST(log + (int64_t)(kr + LC_GRID_N * NR) * N, (double)viol);
     }
+}
+
+// ---- priority lists over module instances, register form (round 6: RuleBasedControl on layouts with several modules of a kind) ----
+// The series rows of one step without the controls (load_multi_step_in reads both): what a list rollout reads per step.
+template <int F, class CNT = CountsRT, int M = MS>
+__device__ __forceinline__ void load_multi_series(const KArgs &a, int64_t i, int32_t t, MultiStepInT<M> &in)
+{
+    const int64_t N = a.N;
+    const int NR = CNT::nr(a), NL = CNT::nl(a), NP = CNT::np(a);
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        if constexpr (F & F_GRID) {
+            const int q = j < NR ? j : NR - 1;
+            const double *g = a.c.grid_ts + (((int64_t)t * NR + q) * 4) * N + i;
+            in.grid[j][0] = g[0]; in.grid[j][1] = g[N]; in.grid[j][2] = g[2 * N]; in.grid[j][3] = g[3 * N];
+        }
+        { const int q = j < NL ? j : NL - 1; in.load[j] = a.c.load_ts[((int64_t)t * NL + q) * N + i]; }
+        { const int q = j < NP ? j : NP - 1; in.pv[j] = a.c.pv_ts[((int64_t)t * NP + q) * N + i]; }
+    }
+}
+
+// One priority list [list_len, 3] = (kind, instance, action) packed into a 64-bit word, a byte per element that COUNTS: kind |
+// instance << 2 | action << 5 | 0x80.  What populate_multi decides per element at walk time is decided here: padding, a kind outside
+// 0..2, an instance the layout does not have and a module met before in this list (priority_list.py:82-88) are dropped, the others
+// move up -- a list names every module at most once after that, so the word holds the whole list whenever the layout has at most
+// PL_PACK_MAX controllable modules (any list_len).
+constexpr int PL_PACK_MAX = 8;
+__device__ __forceinline__ uint64_t pack_priority_list(const int32_t *__restrict__ list, int32_t list_len, int NG, int NB, int NR)
+{
+    uint64_t w = 0;
+    uint32_t seen = 0u;
+    int n = 0;
+    for (int k = 0; k < list_len; k++) {
+        const int kind = list[3 * k], j = list[3 * k + 1], act = list[3 * k + 2] != 0;
+        bool valid = !(kind < 0 || kind > 2 || j < 0 || j >= (kind == 0 ? NG : kind == 1 ? NB : NR));
+        const uint32_t bit = valid ? 1u << (kind * MGX_MAX_INSTANCES + j) : 0u;
+        valid = valid && !(seen & bit) && n < PL_PACK_MAX;
+        seen |= bit;
+        const uint32_t el = (uint32_t)kind | ((uint32_t)j << 2) | ((uint32_t)act << 5) | 0x80u;
+        w |= valid ? (uint64_t)el << (8 * n) : 0ull;
+        n += valid ? 1 : 0;
+    }
+    return w;
+}
+
+// PriorityListAlgo._populate_action (priority_list.py:69-116) for grid i out of registers: populate_multi's walk -- every element the
+// single-module form of populate_core on the load that remains when it is reached -- with the modules' parameters and state taken
+// from the register copy R (the state of a K-step loop lives there, not in the batch's columns) by compile-time-unrolled selects on the
+// element's instance, and the controls written into `sin` the same way.  Lanes hold different lists: an element is a battery in one
+// lane and a genset in the next, so both forms run under their lanes' masks.  Returns the expansion's assert mask like populate_multi.
+template <int F, class CNT, int M, bool PARK = false>
+__device__ __forceinline__ uint32_t populate_multi_small(const KArgs &a, const MultiRegsT<M> &R, uint64_t plw, MultiStepInT<M> &sin,
+                                                         const lds_double *pk = nullptr)
+{
+    constexpr bool parked = PARK;
+    const int NG = CNT::ng(a), NB = CNT::nb(a), NR = CNT::nr(a), NL = CNT::nl(a), NP = CNT::np(a);
+    using PS = ParkSlots<CNT, M>;
+    // (the candidates pass through an empty asm: hipcc re-forms a chain of selects between elements of one array into ONE load at a
+    //  selected address -- a dynamically indexed array, which lives in scratch memory; the same for the select-stores below)
+    auto opaque = [](double x) __attribute__((always_inline)) { asm("" : "+v"(x)); return x; };
+    auto pick = [&](const double (&arr)[M], int j) __attribute__((always_inline)) {
+        double v = opaque(arr[0]);
+#pragma unroll
+        for (int q = 1; q < M; q++) v = (j == q) ? opaque(arr[q]) : v;
+        return v;
+    };
+    auto put = [&](double (&arr)[M], int j, double e) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < M; q++) { const double old = opaque(arr[q]); arr[q] = (j == q) ? e : old; }
+    };
+#pragma unroll
+    for (int j = 0; j < M; j++) { sin.goal[j] = 0.0; sin.gen[j] = 0.0; sin.bat[j] = 0.0; sin.grd[j] = 0.0; }
+    double total_load = 0.0;                                           // _get_load: running sum (:157-164)
+#pragma unroll
+    for (int j = 0; j < M; j++) if (j < NL) total_load += -1 * sin.load[j];
+    double renewable = 0.0;                                            // _get_renewable: np.sum of fewer than eight values (:166-167)
+#pragma unroll
+    for (int j = 0; j < M; j++) if (j < NP) renewable += sin.pv[j];
+    double remaining = total_load - renewable;                         // :74
+    uint32_t xv = !(total_load >= 0 && renewable >= 0) ? 256u : 0u;    // :73
+    // the gensets' next_max / next_min production for either goal (genset_module.py:392-424) and the grids' limits, once per step
+    double g_mx[M][2], g_mn[M][2], r_mx[M], r_mc[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        if constexpr (F & F_GENSET) {
+#pragma unroll
+            for (int act = 0; act < 2; act++) {
+                const double ns = (double)genset_next_status(R.g_status[j], act);
+                double rmin;
+                if constexpr (parked) rmin = park_ld(pk, PS::G_RMIN + (j < NG ? j : 0)); else rmin = R.g_rmin[j];
+                g_mx[j][act] = ns * R.g_rmax[j]; g_mn[j][act] = ns * rmin;
+            }
+        }
+        if constexpr (F & F_GRID) { r_mx[j] = R.r_imp[j] * sin.grid[j][3]; r_mc[j] = R.r_exp[j] * sin.grid[j][3]; }
+    }
+    constexpr int LMAX = CNT::is_static ? (CNT::kNG + CNT::kNB + CNT::kNR_) : PL_PACK_MAX;
+#pragma unroll
+    for (int k = 0; k < (LMAX < PL_PACK_MAX ? LMAX : PL_PACK_MAX); k++) {
+        const uint32_t el = (uint32_t)(plw >> (8 * k)) & 0xffu;
+        const bool valid = (el & 0x80u) != 0;
+        const int kind = el & 3u, j = (el >> 2) & 7u, act = (el >> 5) & 1u;
+        const bool close = pl_isclose0(remaining), produce = !close && remaining > 0, consume = !close && !produce;
+        double e = 0.0, mc = 0.0;
+        if (valid) {
+            if (kind == 1) {
+                if constexpr (F & F_BATTERY) {                          // populate_core<F_BATTERY>: one division
+                    double cmin, cmax, C, D, eta;
+                    if constexpr (parked) {
+                        const int q = j < NB ? j : 0;
+                        cmin = park_ld(pk, PS::B_CMIN + q); cmax = park_ld(pk, PS::B_CMAX + q); C = park_ld(pk, PS::B_C + q);
+                        D = park_ld(pk, PS::B_D + q); eta = park_ld(pk, PS::B_ETA + q);
+                    } else {
+                        cmin = pick(R.b_cmin, j); cmax = pick(R.b_cmax, j); C = pick(R.b_C, j); D = pick(R.b_D, j); eta = pick(R.b_eta, j);
+                    }
+                    const double charge = pick(R.b_charge, j);
+                    Params p; p.bat_cmin = cmin; p.bat_D = D; p.bat_eta = eta;
+                    const double mp = battery_max_production(p, charge);                  // battery_module.py:283-286
+                    const double room = cmax - charge;
+                    const double num_sink = py_min(C, room);
+                    const double e_src = py_clip(remaining, 0.0, mp);
+                    const double num = (close || produce) ? -1.0 * (produce ? e_src : 0.0) : num_sink;
+                    const double q = num / eta;
+                    const double e_snk = py_max(remaining, -1.0 * q);
+                    e = close ? 0.0 : (produce ? e_src : e_snk);
+                    mc = q;
+                    put(sin.bat, j, e);
+                }
+            } else if (kind == 0) {
+                if constexpr (F & F_GENSET) {
+                    double mn = g_mn[0][0], mx = g_mx[0][0];
+#pragma unroll
+                    for (int q = 0; q < M; q++)
+#pragma unroll
+                        for (int c = 0; c < 2; c++) { const bool hit = (j == q) && (act == c); mn = hit ? opaque(g_mn[q][c]) : mn; mx = hit ? opaque(g_mx[q][c]) : mx; }
+                    e = pl_energy(remaining, mn, mx, 0.0, false);
+                    put(sin.goal, j, (double)act); put(sin.gen, j, e);
+                }
+            } else {
+                if constexpr (F & F_GRID) {
+                    const double mx = pick(r_mx, j);
+                    mc = pick(r_mc, j);
+                    e = pl_energy(remaining, 0.0, mx, mc, true);
+                    put(sin.grd, j, e);
+                }
+            }
+            uint32_t bad = (produce && !(e >= 0)) ? 128u : 0u;                   // priority_list.py:154
+            bad = (consume && !(remaining <= 0.0)) ? 256u : bad;                 // :121 (NaN)
+            bad = (consume && remaining <= 0.0 && kind != 0 && !(mc >= 0)) ? 64u : bad;     // :124 (sinks only)
+            xv = xv ? xv : bad;                                                  // the first assert that fails stops the reference
+            remaining -= e;                                                      // :105
+        }
+    }
+    return xv;
 }
 
 // PriorityListAlgo._populate_action over module instances (priority_list.py:69-116): `list` holds list_len elements

@@ -51,6 +51,19 @@ bool launch_step_k_multi_static(const MultiStaticLaunch &L)
 #undef X
     return false;
 }
+bool launch_rollout_multi_static(const MultiStaticRollout &L)
+{
+#define X(FV, G, B, R, LD, PV)                                                                                                           \
+    if (L.flags == FV && L.ng == G && L.nb == B && L.nr == R && L.nl == LD && L.np == PV) {                                             \
+        using CT = CountsCT<G, B, R, LD, PV>;                                                                                          \
+        rollout_multi_small_kernel<FV, CT, CT::slots><<<L.blocks, BLOCK_MULTI, 0, L.stream>>>(*L.k, L.lists, L.n_lists, L.list_len,     \
+                                                                                             L.ids, L.per_step, L.t, L.K, L.out);      \
+        return true;                                                                                                                    \
+    }
+    MGX_STATIC_LAYOUTS(X)
+#undef X
+    return false;
+}
 }  // namespace mgx
 #else
 

@@ -631,6 +631,20 @@ struct MultiStaticLaunch {
     FusedOut out;
 };
 bool launch_step_k_multi_static(const MultiStaticLaunch &L);
+// ... and mgx_rollout_lists on the same specialisations (rollout_multi_small_kernel)
+struct MultiStaticRollout {
+    int flags, ng, nb, nr, nl, np;
+    unsigned blocks;
+    hipStream_t stream;
+    const KArgs *k;
+    const int32_t *lists;
+    int32_t n_lists, list_len;
+    const int32_t *ids;
+    int per_step;
+    int32_t t, K;
+    FusedOut out;
+};
+bool launch_rollout_multi_static(const MultiStaticRollout &L);
 bool launch_step_k_p0(const FusedLaunch &L); bool launch_step_k_p1(const FusedLaunch &L); bool launch_step_k_p2(const FusedLaunch &L);
 bool launch_step_k_p3(const FusedLaunch &L); bool launch_step_k_p4(const FusedLaunch &L);
 bool launch_rollout_p0(const FusedLaunch &L); bool launch_rollout_p1(const FusedLaunch &L); bool launch_rollout_p2(const FusedLaunch &L);
@@ -2253,6 +2267,70 @@ __global__ __launch_bounds__(BLOCK_MULTI, (M >= 3 ? MGX_M3_WAVES : 1)) void step
         if (k < K) one_step(k, cur);
         // (the state columns' addresses are formed again here from an index the compiler cannot see through: held across the loop since the
         //  prologue's loads they were the registers the three-of-a-kind form spilled)
+        int64_t i_out = i;
+        asm volatile("" : "+v"(i_out));
+        store_multi_state<F, CNT, M>(a, i_out, R);
+        if (out.ret_acc) out.ret_acc[i] += ret;
+    }
+    advance_counter_in_kernel(a, K_launch);
+}
+
+// mgx_rollout_lists on the register form (round 6): K fused steps whose controls come from a priority list over module instances --
+// RuleBasedControl on a layout with several modules of a kind (rbc.py:64-93; ids [N]: one fixed list per grid) or a discrete roll-out
+// (ids [K, N]).  The loop of step_k_multi_small_kernel with populate_multi_small in place of the action stream: per step only the
+// series rows are read.  The list is packed into one 64-bit word (pack_priority_list): once per launch for fixed lists.
+template <int F, class CNT, int M>
+__global__ __launch_bounds__(BLOCK_MULTI, (M >= 3 ? MGX_M3_WAVES : 1)) void rollout_multi_small_kernel(
+    const KArgs a, const int32_t *__restrict__ lists, int32_t n_lists, int32_t list_len, const int32_t *__restrict__ ids, int per_step,
+    int32_t t0, int32_t K, const FusedOut out)
+{
+    static_assert(CNT::kNG + CNT::kNB + CNT::kNR_ <= PL_PACK_MAX, "a packed list holds every controllable module of the layout");
+    const int32_t K_launch = K;
+    t0 = resolve_t(a, t0);
+    K = resolve_k(a, t0, K);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
+    constexpr bool PARK = M >= 3 && MGX_M3_PARK;
+    __shared__ double park[PARK ? ParkSlots<CNT, M>::COUNT * PARK_STRIDE : 1];
+    lds_double *pk = (lds_double *)park + threadIdx.x;
+    if (i < a.g1) {
+        const int64_t N = a.N;
+        const int32_t k_done = (a.grid_final ? a.grid_final[i] : a.final_step) - 1 - t0;
+        double ret = 0.0;
+        MultiRegsT<M> R; MultiStepInT<M> cur, nxt;
+        load_multi_regs<F, CNT, M>(a, i, R);
+        if constexpr (PARK) park_multi_regs<F, CNT, M>(a, R, pk);
+        auto list_word = [&](int32_t id) __attribute__((always_inline)) {
+            id = (id >= 0 && id < n_lists) ? id : 0;            // ids outside [0, n) fall back to list 0 (the reference raises)
+            return pack_priority_list(lists + (int64_t)id * list_len * 3, list_len, CNT::ng(a), CNT::nb(a), CNT::nr(a));
+        };
+        uint64_t plw = per_step ? 0ull : list_word(ids[i]);
+        if (K > 0) load_multi_series<F, CNT, M>(a, i, t0, cur);
+        auto fetch = [&](int32_t kk, MultiStepInT<M> &dst) __attribute__((always_inline)) {
+            const int32_t kc = kk < K ? kk : K - 1;                  // (past the end: re-read the last step's rows, unconditional loads)
+            load_multi_series<F, CNT, M>(a, i, t0 + kc, dst);
+        };
+        auto one_step = [&](int32_t k, MultiStepInT<M> &in) __attribute__((always_inline)) {
+            const int64_t off = (int64_t)k * N + i;
+            if (per_step) plw = list_word(ids[off]);
+            const uint32_t xv = populate_multi_small<F, CNT, M, PARK>(a, R, plw, in, pk);
+            Outputs o;
+            double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
+            step_multi_small<F, CNT, M, PARK>(a, R, in, i, false, log, o, pk, xv);
+            const double r = shaped_reward<F>(a.shaper, o);
+            if (out.reward) __builtin_nontemporal_store(r, out.reward + off);
+            if (out.done) out.done[off] = (uint8_t)(k >= k_done);
+            if constexpr (F & F_BATTERY) { if (out.soc_trace) __builtin_nontemporal_store(R.b_soc[0], out.soc_trace + off); }
+            if constexpr (F & F_GENSET) { if (out.status_trace) __builtin_nontemporal_store(R.g_status[0], out.status_trace + off); }
+            ret += r;
+        };
+        int32_t k = 0;
+        for (; k + 1 < K; k += 2) {
+            fetch(k + 1, nxt);
+            one_step(k, cur);
+            fetch(k + 2, cur);
+            one_step(k + 1, nxt);
+        }
+        if (k < K) one_step(k, cur);
         int64_t i_out = i;
         asm volatile("" : "+v"(i_out));
         store_multi_state<F, CNT, M>(a, i_out, R);

@@ -123,3 +123,63 @@ def test_compile_time_counts_equal_run_time_counts(device):
             assert torch.equal(o1[k], o0[k]), ((ng, nb, nr, nl, npv), k)
         assert torch.equal(r1, r0) and all(torch.equal(s1[k], s0[k]) for k in s1)
         assert float(o1["reward"].std()) > 0
+
+
+@pytest.mark.gpu
+def test_list_rollouts_on_the_register_form_equal_the_run_time_form(device):
+    """mgx_rollout_lists on the compile-time-count specialisations (rollout_multi_small_kernel: the priority-list walk out of registers,
+    the list packed into a 64-bit word) against the run-time-count kernel with its walk over the batch's columns
+    (mgx_set_tunable(MGX_TUNE_MULTI_STATIC, 0)): one fixed list per grid (RuleBasedControl) and an id per step (a discrete roll-out),
+    rewards, done, traces, every log column (the expansion's assert mask in it) and the final state `==` -- two and three of a kind."""
+    import torch
+    from pymgrid_amd import StepEngine, _lib
+    from pymgrid_amd.generator import generate, widen
+    g = torch.Generator(device=device); g.manual_seed(23)
+    for (ng, nb, nr, nl, npv), arch in (((2, 2, 1, 1, 1), "genset+battery+grid"), ((2, 2, 2, 2, 2), "genset+battery+grid"),
+                                        ((1, 2, 1, 1, 1), "genset+battery+grid"), ((2, 1, 0, 1, 1), "genset+battery"),
+                                        ((0, 2, 1, 1, 1), "battery+grid"), ((3, 3, 1, 1, 1), "genset+battery+grid"),
+                                        ((2, 3, 1, 1, 1), "genset+battery+grid"), ((0, 3, 1, 1, 1), "battery+grid")):
+        N, T, K = 1500, 70, 21
+        # 24 lists drawn by hand (the reference's enumeration is factorial in the elements): every module somewhere, genset goals 0 / 1,
+        # modules named twice (the second is skipped, priority_list.py:82-88), padding and elements the layout does not have in between
+        rs = np.random.RandomState(100 * ng + 10 * nb + nr)
+        mods = [(0, j) for j in range(ng)] + [(1, j) for j in range(nb)] + [(2, j) for j in range(nr)]
+        rows = []
+        for _ in range(24):
+            order = [mods[q] for q in rs.permutation(len(mods))]
+            els = [(k, j, int(rs.randint(0, 2)) if k == 0 else 0) for k, j in order]
+            els.insert(int(rs.randint(0, len(els) + 1)), (-1, -1, -1))
+            els.insert(int(rs.randint(0, len(els) + 1)), (int(rs.randint(0, 3)), 5, 0))
+            els.insert(int(rs.randint(1, len(els) + 1)), els[0])
+            rows.append(els[: len(mods) + 3] if rs.rand() < 0.8 else els[: max(1, len(mods) - 1)])
+        width = max(len(r) for r in rows)
+        tab = -np.ones((len(rows), width, 3), dtype=np.int32)
+        for q, r in enumerate(rows):
+            tab[q, :len(r)] = r
+        lists = torch.as_tensor(tab, device=device).contiguous()
+
+        def batch():
+            return widen(generate(N, n_steps=T, seed=47, arch=arch, horizon=0, device=device, mixed_timers=True), n_genset=ng, n_battery=nb,
+                         n_grid=nr, n_load=nl, n_pv=npv)
+        ids_fixed = torch.randint(0, lists.shape[0], (N,), dtype=torch.int32, device=device, generator=g)
+        ids_step = torch.randint(-1, lists.shape[0] + 1, (K, N), dtype=torch.int32, device=device, generator=g)   # (ids outside: list 0)
+        res = []
+        for static in (1, 0):
+            _lib.set_tunable("multi_static", static)
+            try:
+                e = StepEngine(batch())
+                e.reset(2, want_obs=False)
+                o1 = e.rollout_lists(ids_fixed, lists, K, reward=True, done=True, soc_trace=True, status_trace=True, log=True)
+                o2 = e.rollout_lists(ids_step, lists, K, reward=True, log=True)          # a second launch from the carried state
+                torch.cuda.synchronize()
+                res.append(({k: v.clone() for k, v in o1.items()}, {k: v.clone() for k, v in o2.items()},
+                            {k: e.batch.cols[k].clone() for k in ("charge", "soc", "gen_status") if k in e.batch.cols}))
+                e.close()
+            finally:
+                _lib.set_tunable("multi_static", 1)
+        (a1, a2, s1), (b1, b2, s0) = res
+        for x, y in ((a1, b1), (a2, b2), (s1, s0)):
+            assert set(x) == set(y)
+            for k in x:
+                assert torch.equal(x[k], y[k]), ((ng, nb, nr, nl, npv), k)
+        assert float(a1["reward"].std()) > 0
