@@ -1962,6 +1962,11 @@ int mgx_rollout_lists(mgx_handle *h, const int32_t *action_id, int per_step, con
                                  n_lists, list_len, action_id, per_step, t_arg(h), K, fo};
             if (launch_rollout_multi_static(L)) return;
         }
+        if (h->multi_small && tune(MGX_TUNE_MULTI_SMALL_OWN) != 0) {     // any other layout of at most MS modules of a kind: run-time counts, same walk
+            MGX_DISPATCH_F(h->flags, (rollout_multi_small_kernel<F, CountsRT, MS><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, 0, s>>>(
+                                          k, lists, n_lists, list_len, action_id, per_step, t_arg(h), K, fo)));
+            return;
+        }
         MGX_DISPATCH_F(h->flags, (step_k_multi_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, h->multi_lds, s>>>(
                                       k, nullptr, lists, n_lists, list_len, action_id, per_step, t_arg(h), K, 0, fo, h->multi_small)));
     });

@@ -137,7 +137,8 @@ def test_list_rollouts_on_the_register_form_equal_the_run_time_form(device):
     g = torch.Generator(device=device); g.manual_seed(23)
     for (ng, nb, nr, nl, npv), arch in (((2, 2, 1, 1, 1), "genset+battery+grid"), ((2, 2, 2, 2, 2), "genset+battery+grid"),
                                         ((1, 2, 1, 1, 1), "genset+battery+grid"), ((2, 1, 0, 1, 1), "genset+battery"),
-                                        ((0, 2, 1, 1, 1), "battery+grid"), ((3, 3, 1, 1, 1), "genset+battery+grid"),
+                                        ((0, 2, 1, 1, 1), "battery+grid"), ((2, 2, 1, 2, 1), "genset+battery+grid"),      # (no compile-time specialisation)
+                                        ((3, 3, 1, 1, 1), "genset+battery+grid"),
                                         ((2, 3, 1, 1, 1), "genset+battery+grid"), ((0, 3, 1, 1, 1), "battery+grid")):
         N, T, K = 1500, 70, 21
         # 24 lists drawn by hand (the reference's enumeration is factorial in the elements): every module somewhere, genset goals 0 / 1,
@@ -164,8 +165,9 @@ def test_list_rollouts_on_the_register_form_equal_the_run_time_form(device):
         ids_fixed = torch.randint(0, lists.shape[0], (N,), dtype=torch.int32, device=device, generator=g)
         ids_step = torch.randint(-1, lists.shape[0] + 1, (K, N), dtype=torch.int32, device=device, generator=g)   # (ids outside: list 0)
         res = []
-        for static in (1, 0):
+        for static, generic in ((1, 0), (0, 0), (0, 1)):     # compile-time counts / run-time counts in registers / the walk over the columns
             _lib.set_tunable("multi_static", static)
+            _lib.set_tunable("multi_generic", generic)
             try:
                 e = StepEngine(batch())
                 e.reset(2, want_obs=False)
@@ -177,9 +179,11 @@ def test_list_rollouts_on_the_register_form_equal_the_run_time_form(device):
                 e.close()
             finally:
                 _lib.set_tunable("multi_static", 1)
-        (a1, a2, s1), (b1, b2, s0) = res
-        for x, y in ((a1, b1), (a2, b2), (s1, s0)):
-            assert set(x) == set(y)
-            for k in x:
-                assert torch.equal(x[k], y[k]), ((ng, nb, nr, nl, npv), k)
+                _lib.set_tunable("multi_generic", 0)
+        (a1, a2, s1) = res[0]
+        for (b1, b2, s0) in res[1:]:
+            for x, y in ((a1, b1), (a2, b2), (s1, s0)):
+                assert set(x) == set(y)
+                for k in x:
+                    assert torch.equal(x[k], y[k]), ((ng, nb, nr, nl, npv), k)
         assert float(a1["reward"].std()) > 0
