@@ -611,6 +611,7 @@ def general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist):
                                        "bytes_per_env_step": bR_launch / Kg / N, "avg_launch_us": gpu / stepsR * Kg * 1e6,
                                        "note": "no action stream: the priority-list walk (5 modules) and the step are arithmetic -- VALU / latency bound; "
                                                "the run-time-count kernel with its walk over the batch's columns took 14.8 us per env-step"}}
+    out["rbc_rollout"]["roofline_valu"] = valu_roofline("rollout_multi_small_kernel<7,mgx::CountsCT<2,2,1,1,1>,2>", gpu / stepsR * Kg, N, 1, dev)
     out["layout"] = "2 gensets + 2 batteries + 1 grid + load + pv per microgrid (general kernels), materialised series"
     out["grids_per_gpu"], out["rows"] = N, rows_g
     ge.close()
@@ -633,6 +634,7 @@ def general_path_leg(args, N, n_total, chunk, dev, rank, world, mdist):
                                               "layout": "3 gensets + 3 batteries + 1 grid + load + pv per microgrid",
                                               "note": "three instance slots per kind in registers, counts at compile time (round 6; the run-time-count "
                                                       "kernel with its LDS lists took 11.5 us per env-step: 0.16)"}}
+    out["k_step_3_of_a_kind"]["roofline_valu"] = valu_roofline("step_k_multi_small_kernel<7,mgx::CountsCT<3,3,1,1,1>,3>", gpu / stepsK * Kg, N, 1, dev)
     ge.close()
     del ge, gb3
     torch.cuda.empty_cache()

@@ -1297,7 +1297,7 @@ struct CountsRT {
     static __device__ __forceinline__ int nl(const KArgs &a) { return a.n_load; }
     static __device__ __forceinline__ int np(const KArgs &a) { return a.n_pv; }
     static constexpr bool is_static = false;
-    static constexpr int kNG = 0, kNB = 0, kNR_ = 0;
+    static constexpr int kNG = 0, kNB = 0, kNR_ = 0, kNP_ = 0;
     static constexpr int max_prov = 0, max_absb = 0, max_mid_prov = 0, max_mid_absb = 0;   // (unused: the slot counts decide)
 };
 constexpr int MS_CT = 3;     // most instance slots a compile-time-count specialisation may hold
@@ -1306,7 +1306,7 @@ struct CountsCT {
     static_assert(NG_ <= MS_CT && NB_ <= MS_CT && NR_ <= MS_CT && NL_ >= 1 && NL_ <= MS_CT && NP_ >= 1 && NP_ <= MS_CT, "the register form holds M instances");
     static constexpr int slots = (NG_ > MS || NB_ > MS || NR_ > MS || NL_ > MS || NP_ > MS) ? MS_CT : MS;     // M of the kernel
     static constexpr bool is_static = true;
-    static constexpr int kNG = NG_, kNB = NB_, kNR_ = NR_;
+    static constexpr int kNG = NG_, kNB = NB_, kNR_ = NR_, kNP_ = NP_;
     // most addends MicrogridStep's lists can hold: at the end of the sweep (gensets / discharging batteries / importing grids / renewables /
     // loss load; loads / charging batteries / exporting grids / overgeneration) and after the controllable modules (:277)
     static constexpr int max_prov = NG_ + NB_ + NR_ + NP_ + 1, max_absb = NL_ + NB_ + NR_ + 1, max_mid_prov = NG_ + NB_ + NR_,
@@ -1503,6 +1503,53 @@ __device__ __forceinline__ double small_pairwise_prov(const double (&e)[SMALL_PR
     return res;
 }
 
+// The provided list's sum for a COMPILE-TIME layout whose list can hold at most nine addends (3 gensets + 3 batteries + 1 grid + 1
+// renewable + loss load): the slots the layout can fill at all are known at compile time, and with eight or nine addends at most ONE
+// of them is unset -- small_pairwise_prov's rule on that compile-time slot list instead of slots_pairwise_sum's run-time compaction of
+// all 13 slots (13 x 13 selects of doubles per step: half of the three-of-a-kind kernel's 688 VALU instructions per wave-step).
+template <int F, class CNT, int M>
+struct ProvSlotList {
+    int idx[4 * M + 1];
+    int n;
+    constexpr ProvSlotList() : idx{}, n(0)
+    {
+        constexpr int SB = (F & F_GRID_FIRST) ? 2 * M : M, SR = (F & F_GRID_FIRST) ? M : 2 * M;
+        for (int j = 0; j < CNT::kNG; j++) idx[n++] = j;
+        if (SB < SR) { for (int j = 0; j < CNT::kNB; j++) idx[n++] = SB + j; for (int j = 0; j < CNT::kNR_; j++) idx[n++] = SR + j; }
+        else { for (int j = 0; j < CNT::kNR_; j++) idx[n++] = SR + j; for (int j = 0; j < CNT::kNB; j++) idx[n++] = SB + j; }
+        for (int j = 0; j < CNT::kNP_; j++) idx[n++] = 3 * M + j;
+        idx[n++] = 4 * M;
+    }
+};
+
+template <int F, class CNT, int M>
+__device__ __forceinline__ double ct_pairwise_prov(const double (&pe)[4 * M + 1], uint32_t pm, int n)
+{
+    constexpr ProvSlotList<F, CNT, M> SL{};
+    static_assert(SL.n == CNT::max_prov && SL.n >= 8 && SL.n <= 9, "eight or nine possible addends");
+    double r[8];
+    if constexpr (SL.n == 8) {                       // eight addends: every possible slot is set
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = pe[SL.idx[k]];
+        return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    } else {
+        uint32_t mask9 = 0u;
+#pragma unroll
+        for (int k = 0; k < 9; k++) mask9 |= ((pm >> SL.idx[k]) & 1u) << k;
+        const uint32_t miss = ~mask9 & 0x1ffu;                                // no bit (n = 9) or one (n = 8)
+        const int m = miss ? __ffs((int)miss) - 1 : 9;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {                 // (through an empty asm: a select between two elements of one array becomes an indexed load = scratch)
+            double lo = pe[SL.idx[k]], hi = pe[SL.idx[k + 1]];
+            asm("" : "+v"(lo)); asm("" : "+v"(hi));
+            r[k] = (k < m) ? lo : hi;
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        if (n == 9) res += pe[SL.idx[8]];
+        return res;
+    }
+}
+
 template <int F, class CNT = CountsRT, int M = MS, bool PARK = false>
 __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &R, const MultiStepInT<M> &sin, int64_t i, bool normalized,
                                                  double *__restrict__ log, Outputs &o, const lds_double *pk = nullptr, uint32_t viol0 = 0u)
@@ -1673,6 +1720,7 @@ __device__ __forceinline__ void step_multi_small(const KArgs &a, MultiRegsT<M> &
     if constexpr (TRACK_P) {
         const int n_prov = __popc(pm);
         if constexpr (M == MS) { if (n_prov >= 8) o.overall_provided = small_pairwise_prov(pe, pm, n_prov); }
+        else if constexpr (CNT::is_static && CNT::max_prov <= 9) { if (n_prov >= 8) o.overall_provided = ct_pairwise_prov<F, CNT, M>(pe, pm, n_prov); }
         else { if (n_prov >= 8) o.overall_provided = slots_pairwise_sum(pe, pm, n_prov); }
     }
     o.overall_absorbed = asum;

@@ -74,6 +74,10 @@ done
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d "$OUT/sq_rich" -o b --output-format csv -- python "$REPO/bench.py" --gpus 1 --steps 4 --warmup 1 --no-cpu-baseline --hetero-steps 0 --no-closed-loop --legs fused_rich --detail /dev/null > "$OUT/sq_rich.log" 2>&1
 # (the general path's K-step launch: 100 000 grids, 32 steps per launch)
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d "$OUT/sq_kstep" -o b --output-format csv -- python "$REPO/tools/exp_r5_general_prof.py" kstep 512 > "$OUT/sq_kstep.log" 2>&1
+# (three of a kind, and RuleBasedControl's list roll-out on the general path: 100 000 grids, 32 steps per launch)
+for GL in kstep3 rbc; do
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d "$OUT/sq_g$GL" -o b --output-format csv -- python "$REPO/tools/exp_r5_general_prof.py" $GL 512 > "$OUT/sq_g$GL.log" 2>&1
+done
 cd "$REPO"
 python - "$OUT" "$HASH" <<'PY'
 import csv, glob, json, os, re, subprocess, sys
@@ -83,12 +87,12 @@ def spec(k):
     m = re.search(r"mgx::([a-z_0-9]+)(<[^(]*>)?\(", k)
     return (m.group(1) + (m.group(2) or "")).replace(" ", "") if m else None
 kern = {}
-for mode in ("fused", "rbc", "rich", "kstep"):
+for mode in ("fused", "rbc", "rich", "kstep", "gkstep3", "grbc"):
     acc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(out, f"sq_{mode}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             sp = spec(r["Kernel_Name"])
-            if sp and sp.split("<")[0] in ("step_k_kernel", "rollout_kernel", "step_k_multi_small_kernel"):
+            if sp and sp.split("<")[0] in ("step_k_kernel", "rollout_kernel", "step_k_multi_small_kernel", "rollout_multi_small_kernel"):
                 acc[sp][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for sp, d in acc.items():
         if mode == "rich" and sp in kern:           # (the headline's kernel runs in this pass too: its own pass above is the one kept)
@@ -98,8 +102,8 @@ for mode in ("fused", "rbc", "rich", "kstep"):
         # launches of 50 000 grids (two shards): 64 grids per wave, 192..256 grids per workgroup of 4 waves
         kern[sp] = {"valu_active_cycles_per_launch": 4.0 * mean.get("SQ_ACTIVE_INST_VALU", 0.0), "valu_insts_per_launch": mean.get("SQ_INSTS_VALU"),
                     "waves_per_launch": waves, "wave_cycles_per_launch": 4.0 * mean.get("SQ_WAVE_CYCLES", 0.0),
-                    "grids_per_launch": 100000 if mode == "kstep" else 50000, "steps_per_launch": 32 if mode == "kstep" else 64,
-                    "valu_insts_per_wave_step": (mean.get("SQ_INSTS_VALU", 0.0) / waves / (32 if mode == "kstep" else 64)) if waves else None,
+                    "grids_per_launch": 100000 if "kstep" in mode or mode == "grbc" else 50000, "steps_per_launch": 32 if "kstep" in mode or mode == "grbc" else 64,
+                    "valu_insts_per_wave_step": (mean.get("SQ_INSTS_VALU", 0.0) / waves / (32 if "kstep" in mode or mode == "grbc" else 64)) if waves else None,
                     "launches_averaged": len(next(iter(d.values())))}
 sclk = None
 try:
