@@ -2004,10 +2004,16 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
     if (n > 64) return fail(MGX_ERR_INVALID, "mgx_fleet_step: at most 64 items per call");
     bool fuse[64];
     int32_t fz[64], nf = 0;                                 // the items that share the launch, in item order
+    bool any_chunks = tune(MGX_TUNE_FLEET_BYVALUE) == 0;    // window chunks ride with the POINTER form of the kernel: single-instance layouts only
+    for (int32_t j = 0; j < n; j++) any_chunks = any_chunks || (items[j].refill_ring && items[j].refill_chunks > 0);
     for (int32_t j = 0; j < n; j++) {
         const mgx_fleet_item &it = items[j];
         const mgx_handle *h = it.handle;
-        fuse[j] = !h->multi && !h->rolling && !dev_counter(h) && h->n_shards <= 1 && !(it.obs && h->k.H > 0 && !h->k.obs_state_only);
+        // (a bucket with several modules of a kind shares the launch on the register form -- fleet_step_kernel_vm, round 6 -- when it
+        //  holds at most MS of a kind, takes continuous controls, walks the series in lock-step and its rows carry no forecast noise)
+        const bool multi_ok = h->multi && h->multi_small && !any_chunks && !it.action_id && !h->inplace && !h->windowed &&
+                              !(it.obs && (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std));
+        fuse[j] = (!h->multi || multi_ok) && !h->rolling && !dev_counter(h) && h->n_shards <= 1 && !(it.obs && h->k.H > 0 && !h->k.obs_state_only);
         for (int32_t q = 0; q < j; q++)
             if (items[q].handle == it.handle) return fail(MGX_ERR_INVALID, "mgx_fleet_step: item %d steps the batch of item %d again", j, q);
         if (fuse[j]) fz[nf++] = j;
@@ -2039,6 +2045,8 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
             const int32_t nb = nf - z0 < MGX_FLEET_MAX ? nf - z0 : MGX_FLEET_MAX;
             bool chunks = !by_value;                       // window chunks riding along with this launch (refill="chunks")?
             for (int32_t q = 0; q < nb && !chunks; q++) chunks = items[fz[z0 + q]].refill_ring && items[fz[z0 + q]].refill_chunks > 0;
+            bool any_multi = false;                        // (never with chunks: see multi_ok above)
+            for (int32_t q = 0; q < nb; q++) any_multi = any_multi || items[fz[z0 + q]].handle->multi;
             if (!chunks) {
                 // the buckets' KArgs by value, the bucket = blockIdx.y (fleet_step_kernel_v): unused buckets stay unwritten, never read
                 FleetArgsV fv;
@@ -2050,13 +2058,14 @@ int mgx_fleet_step(const mgx_fleet_item *items, int32_t n, int normalized, mgx_s
                     FleetBucket &B = fv.b[q];
                     B.k = h->k;
                     B.hd.tab = it.action_id ? h->d_table : nullptr; B.hd.n_grids = h->k.N; B.hd.t = h->t; B.hd.flags = h->flags;
-                    B.hd.pad0 = B.hd.pad1 = 0;
+                    B.hd.pad0 = h->multi ? 1 : 0; B.hd.pad1 = 0;          // pad0: a bucket of the general path (fleet_step_kernel_vm)
                     B.actions = it.action_id ? (const void *)it.action_id : it.actions;
                     B.reward = it.reward; B.done = it.done; B.obs = it.obs; B.log = it.log;
                     const int32_t wg = (int32_t)blocks_for(h->k.N);
                     if (wg > most) most = wg;
                 }
-                fleet_step_kernel_v<<<dim3((unsigned)most, (unsigned)nb), BLOCK, 0, st>>>(fv);
+                if (any_multi) fleet_step_kernel_vm<<<dim3((unsigned)most, (unsigned)nb), BLOCK, 0, st>>>(fv);
+                else fleet_step_kernel_v<<<dim3((unsigned)most, (unsigned)nb), BLOCK, 0, st>>>(fv);
                 hipError_t ev = hipGetLastError();
                 if (ev != hipSuccess) return hip_fail(ev, "fleet_step_kernel_v launch");
                 continue;

@@ -1497,47 +1497,49 @@ struct FleetArgsV {
 };
 static_assert(sizeof(FleetArgsV) <= 3840, "the kernarg segment holds 4 KB");
 
+// (the kernel's head -- which bucket, which specialisation -- and its two switches are shared by the plain form and the form that also
+//  serves buckets with several modules of a kind, fleet_step_kernel_vm below the general kernels)
+// Which specialisation: ONE 32-byte scalar load; the bucket's other fields are read THROUGH a reference into the kernarg segment
+// by the case that uses them (scalar loads of invariant memory the compiler places and re-issues as it likes; a copy of the
+// whole bucket in front of the switch made it fetch every field any case needs -- 158 dwords through ~100 SGPRs: nine
+// load-wait-spill rounds before the first vector load -- and a copy inside every case still spilled SGPRs).
+#define MGX_FLEET_V_HEAD \
+    typedef const char __attribute__((address_space(4))) *kernarg_bytes; \
+    const kernarg_bytes mine = (kernarg_bytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FleetArgsV, b) \
+                               + (size_t)blockIdx.y * sizeof(FleetBucket); \
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8))); \
+    static_assert(sizeof(FleetHead) == 32 && offsetof(FleetBucket, hd) == 0, "the head is one s_load_dwordx8"); \
+    const u32x8 h8 = *reinterpret_cast<const u32x8 __attribute__((address_space(4))) *>(mine); \
+    FleetHead hd; \
+    hd.tab = reinterpret_cast<const PLWords *>((uint64_t)h8[0] | ((uint64_t)h8[1] << 32)); \
+    hd.n_grids = (int64_t)((uint64_t)h8[2] | ((uint64_t)h8[3] << 32)); \
+    hd.t = (int32_t)h8[4]; hd.flags = (int32_t)h8[5]; \
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; \
+    if (i >= hd.n_grids) return; \
+    const int normalized = fa.normalized; \
+    const FleetBucket &B = *reinterpret_cast<const FleetBucket *>((const char *)mine);
+
+#define MGX_FLEET_V_DISCRETE(FV) case FV: { step_discrete_body<FV>(B.k, *hd.tab, (const int32_t *)B.actions, hd.t, nullptr, B.reward, B.done, B.obs, B.log, i); } break;
+#define MGX_FLEET_V_STEP(FV) case FV: { step_body<FV>(B.k, B.actions, hd.t, normalized, B.reward, B.done, B.obs, B.log, i); } break;
+#define MGX_FLEET_V_SWITCHES                                                                                                          \
+    if (hd.tab != nullptr) {                      /* a DiscreteMicrogridEnv batch: ids -> control -> run, in registers */            \
+        switch (hd.flags) {                                                                                                           \
+            MGX_FLEET_V_DISCRETE(0) MGX_FLEET_V_DISCRETE(1) MGX_FLEET_V_DISCRETE(2) MGX_FLEET_V_DISCRETE(3) MGX_FLEET_V_DISCRETE(4)   \
+            MGX_FLEET_V_DISCRETE(5) MGX_FLEET_V_DISCRETE(6) MGX_FLEET_V_DISCRETE(7) MGX_FLEET_V_DISCRETE(14)                          \
+            default: { step_discrete_body<15>(B.k, *hd.tab, (const int32_t *)B.actions, hd.t, nullptr, B.reward, B.done, B.obs, B.log, i); } break; \
+        }                                                                                                                             \
+        return;                                                                                                                       \
+    }                                                                                                                                 \
+    switch (hd.flags) {                                                                                                               \
+        MGX_FLEET_V_STEP(0) MGX_FLEET_V_STEP(1) MGX_FLEET_V_STEP(2) MGX_FLEET_V_STEP(3) MGX_FLEET_V_STEP(4)                           \
+        MGX_FLEET_V_STEP(5) MGX_FLEET_V_STEP(6) MGX_FLEET_V_STEP(7) MGX_FLEET_V_STEP(14)                                              \
+        default: { step_body<15>(B.k, B.actions, hd.t, normalized, B.reward, B.done, B.obs, B.log, i); } break;                       \
+    }
+
 static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel_v(const FleetArgsV fa)
 {
-    typedef const char __attribute__((address_space(4))) *kernarg_bytes;
-    const kernarg_bytes mine = (kernarg_bytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FleetArgsV, b)
-                               + (size_t)blockIdx.y * sizeof(FleetBucket);
-    // Which specialisation: ONE 32-byte scalar load; the bucket's other fields are read THROUGH a reference into the kernarg segment
-    // by the case that uses them (scalar loads of invariant memory the compiler places and re-issues as it likes; a copy of the
-    // whole bucket in front of the switch made it fetch every field any case needs -- 158 dwords through ~100 SGPRs: nine
-    // load-wait-spill rounds before the first vector load -- and a copy inside every case still spilled SGPRs).
-    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-    static_assert(sizeof(FleetHead) == 32 && offsetof(FleetBucket, hd) == 0, "the head is one s_load_dwordx8");
-    const u32x8 h8 = *reinterpret_cast<const u32x8 __attribute__((address_space(4))) *>(mine);
-    FleetHead hd;
-    hd.tab = reinterpret_cast<const PLWords *>((uint64_t)h8[0] | ((uint64_t)h8[1] << 32));
-    hd.n_grids = (int64_t)((uint64_t)h8[2] | ((uint64_t)h8[3] << 32));
-    hd.t = (int32_t)h8[4]; hd.flags = (int32_t)h8[5];
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= hd.n_grids) return;
-    const int normalized = fa.normalized;
-    const FleetBucket &B = *reinterpret_cast<const FleetBucket *>((const char *)mine);
-    if (hd.tab != nullptr) {                      // a DiscreteMicrogridEnv batch: ids -> control -> run, in registers
-#define MGX_FLEET_CASE(FV) case FV: {                                         \
-        step_discrete_body<FV>(B.k, *hd.tab, (const int32_t *)B.actions, hd.t, nullptr, B.reward, B.done, B.obs, B.log, i); } break;
-        switch (hd.flags) {
-            MGX_FLEET_CASE(0) MGX_FLEET_CASE(1) MGX_FLEET_CASE(2) MGX_FLEET_CASE(3) MGX_FLEET_CASE(4)
-            MGX_FLEET_CASE(5) MGX_FLEET_CASE(6) MGX_FLEET_CASE(7) MGX_FLEET_CASE(14)
-            default: {
-                step_discrete_body<15>(B.k, *hd.tab, (const int32_t *)B.actions, hd.t, nullptr, B.reward, B.done, B.obs, B.log, i); } break;
-        }
-#undef MGX_FLEET_CASE
-        return;
-    }
-#define MGX_FLEET_CASE(FV) case FV: {                                             \
-        step_body<FV>(B.k, B.actions, hd.t, normalized, B.reward, B.done, B.obs, B.log, i); } break;
-    switch (hd.flags) {
-        MGX_FLEET_CASE(0) MGX_FLEET_CASE(1) MGX_FLEET_CASE(2) MGX_FLEET_CASE(3) MGX_FLEET_CASE(4)
-        MGX_FLEET_CASE(5) MGX_FLEET_CASE(6) MGX_FLEET_CASE(7) MGX_FLEET_CASE(14)
-        default: {
-            step_body<15>(B.k, B.actions, hd.t, normalized, B.reward, B.done, B.obs, B.log, i); } break;
-    }
-#undef MGX_FLEET_CASE
+    MGX_FLEET_V_HEAD
+    MGX_FLEET_V_SWITCHES
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1819,6 +1821,53 @@ __device__ inline void observe_row_multi(const KArgs &a, int64_t i, int32_t t, O
                                      obs_row + k + cc, 4, noisy, sd, nseed, ninc, i, (uint32_t)(2 * MGX_MAX_MODULES + 4 * j + cc));
             }
     }
+}
+
+// One general-path step of grid i on the register form (at most MS modules of a kind), lock-step: what a bucket with several
+// modules of a kind runs inside the fleet's launch (fleet_step_kernel_v<true>, round 6) -- the `small` arm of step_multi_kernel
+// without per-grid episodes.
+template <int F>
+__device__ __forceinline__ void step_multi_small_body(const KArgs &a, const void *__restrict__ actions, int32_t t, int normalized,
+                                                      double *__restrict__ reward, uint8_t *__restrict__ done, void *__restrict__ obs,
+                                                      double *__restrict__ log, int64_t i)
+{
+    const int A = 2 * a.n_genset + a.n_battery + a.n_grid;
+    Outputs o;
+    MultiRegs R; MultiStepIn sin;
+    load_multi_regs<F>(a, i, R);
+    if (a.act_f32) load_multi_step_in<F>(a, (const float *)actions + i * A, i, t, sin);
+    else load_multi_step_in<F>(a, (const double *)actions + i * A, i, t, sin);
+    step_multi_small<F>(a, R, sin, i, normalized != 0, log ? log + i : nullptr, o);
+    store_multi_state<F>(a, i, R);
+    reward[i] = shaped_reward<F>(a.shaper, o);
+    if (done) done[i] = done_at(a, i, t);
+    if (obs) {
+        if (a.obs_state_only == 1 && a.obs_colpitch) {            // the state columns of a COLUMN-major ring block: coalesced runs
+            const int64_t P = a.obs_colpitch, k0 = (int64_t)(a.n_load + a.n_pv) * (1 + a.H);
+            if (a.obs_f32) observe_state_multi<F>(a, i, (float *)obs + k0 * P + i, P);
+            else observe_state_multi<F>(a, i, (double *)obs + k0 * P + i, P);
+        } else if (a.obs_f32) observe_row_multi<F>(a, i, t + 1, (float *)obs + i * a.obs_dim);
+        else observe_row_multi<F>(a, i, t + 1, (double *)obs + i * a.obs_dim);
+    }
+}
+
+// fleet_step_kernel_v for a fleet that holds buckets with several modules of a kind (round 6): such a bucket (head.pad0 = 1; at most
+// MS modules of a kind, continuous controls, lock-step) steps on the register form inside the SAME launch instead of in launches of
+// its own beside it.  A kernel of its own: the general bodies would cost the plain fleet launch registers it does not need.
+static __global__ __launch_bounds__(BLOCK) void fleet_step_kernel_vm(const FleetArgsV fa)
+{
+    MGX_FLEET_V_HEAD
+    if (h8[6]) {
+#define MGX_FLEET_V_MULTI(FV) case FV: { step_multi_small_body<FV>(B.k, B.actions, hd.t, normalized, B.reward, B.done, B.obs, B.log, i); } break;
+        switch (hd.flags) {
+            MGX_FLEET_V_MULTI(0) MGX_FLEET_V_MULTI(1) MGX_FLEET_V_MULTI(2) MGX_FLEET_V_MULTI(3) MGX_FLEET_V_MULTI(4)
+            MGX_FLEET_V_MULTI(5) MGX_FLEET_V_MULTI(6) MGX_FLEET_V_MULTI(7) MGX_FLEET_V_MULTI(14)
+            default: { step_multi_small_body<15>(B.k, B.actions, hd.t, normalized, B.reward, B.done, B.obs, B.log, i); } break;
+        }
+#undef MGX_FLEET_V_MULTI
+        return;
+    }
+    MGX_FLEET_V_SWITCHES
 }
 
 // EP: in-place per-grid episodes (the lock-step form carries none of it, as step_kernel<F, EP>)

@@ -47,8 +47,9 @@ def test_ring_rows_of_multi_instance_grids_are_the_per_step_rows(device, dt, wid
 
 @pytest.mark.gpu
 def test_fleet_with_a_multi_instance_bucket_on_rings(device):
-    """A fleet of a single-instance bucket and a multi-instance one, both on rings: the multi bucket steps through its own
-    launches (not fusable) and refills through the general kernel; rows == the envs stepped alone without rings."""
+    """A fleet of a single-instance bucket and a multi-instance one, both on rings: since round 6 the multi bucket (two of a kind:
+    the register form) steps INSIDE the fleet's one launch (fleet_step_kernel_vm) and refills through the general window kernel;
+    rows == the envs stepped alone without rings."""
     from pymgrid_amd import BatchedMicrogridEnv
     from pymgrid_amd.generator import generate, widen
     from pymgrid_amd.hetero import BucketedFleet
