@@ -1789,7 +1789,7 @@ __device__ __forceinline__ uint64_t pack_priority_list(const int32_t *__restrict
 // lane and a genset in the next, so both forms run under their lanes' masks.  Returns the expansion's assert mask like populate_multi.
 template <int F, class CNT, int M, bool PARK = false>
 __device__ __forceinline__ uint32_t populate_multi_small(const KArgs &a, const MultiRegsT<M> &R, uint64_t plw, MultiStepInT<M> &sin,
-                                                         const lds_double *pk = nullptr)
+                                                         const lds_double *pk = nullptr, bool check = true)
 {
     constexpr bool parked = PARK;
     const int NG = CNT::ng(a), NB = CNT::nb(a), NR = CNT::nr(a), NL = CNT::nl(a), NP = CNT::np(a);
@@ -1882,10 +1882,12 @@ __device__ __forceinline__ uint32_t populate_multi_small(const KArgs &a, const M
                     put(sin.grd, j, e);
                 }
             }
-            uint32_t bad = (produce && !(e >= 0)) ? 128u : 0u;                   // priority_list.py:154
-            bad = (consume && !(remaining <= 0.0)) ? 256u : bad;                 // :121 (NaN)
-            bad = (consume && remaining <= 0.0 && kind != 0 && !(mc >= 0)) ? 64u : bad;     // :124 (sinks only)
-            xv = xv ? xv : bad;                                                  // the first assert that fails stops the reference
+            if (check) {                                                         // (wave-uniform: the mask lands in the log's violations column only)
+                uint32_t bad = (produce && !(e >= 0)) ? 128u : 0u;               // priority_list.py:154
+                bad = (consume && !(remaining <= 0.0)) ? 256u : bad;             // :121 (NaN)
+                bad = (consume && remaining <= 0.0 && kind != 0 && !(mc >= 0)) ? 64u : bad;     // :124 (sinks only)
+                xv = xv ? xv : bad;                                              // the first assert that fails stops the reference
+            }
             remaining -= e;                                                      // :105
         }
     }

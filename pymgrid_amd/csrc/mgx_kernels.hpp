@@ -2361,7 +2361,7 @@ __global__ __launch_bounds__(BLOCK_MULTI, (M >= 3 ? MGX_M3_WAVES : 1)) void roll
         auto one_step = [&](int32_t k, MultiStepInT<M> &in) __attribute__((always_inline)) {
             const int64_t off = (int64_t)k * N + i;
             if (per_step) plw = list_word(ids[off]);
-            const uint32_t xv = populate_multi_small<F, CNT, M, PARK>(a, R, plw, in, pk);
+            const uint32_t xv = populate_multi_small<F, CNT, M, PARK>(a, R, plw, in, pk, out.log != nullptr);
             Outputs o;
             double *log = out.log ? out.log + (int64_t)k * a.log_dim * N + i : nullptr;
             step_multi_small<F, CNT, M, PARK>(a, R, in, i, false, log, o, pk, xv);
