@@ -50,8 +50,8 @@ extern "C" {
 #endif
 
 #define MGX_ABI_VERSION 9    /* frozen: struct layouts and the meaning of every v9 entry point do not change any more */
-#define MGX_ABI_MINOR 1      /* additions only: 1 = mgx_abi_minor, mgx_set_tunable / mgx_get_tunable, mgx_set_launch_threads,
-                              * mgx_action_bounds */
+#define MGX_ABI_MINOR 2      /* additions only: 1 = mgx_abi_minor, mgx_set_tunable / mgx_get_tunable, mgx_set_launch_threads,
+                              * mgx_action_bounds; 2 = mgx_step_lists */
 
 enum mgx_status {
     MGX_OK = 0,
@@ -490,6 +490,14 @@ int mgx_rollout_lists(mgx_handle *h, const int32_t *action_id, int per_step, con
  * outputs are those of mgx_step. */
 int mgx_step_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions, double *control,
                       double *reward, uint8_t *done, void *obs, double *log, mgx_stream stream);
+
+/* (minor 2) DiscreteMicrogridEnv.step (discrete.py:109-143) for priority lists over module INSTANCES: mgx_expand_lists +
+ * mgx_step(normalized=0).  ONE launch -- the list walked and the control kept in registers -- where the layout holds at most two
+ * modules of a kind and steps in lock-step or per-grid windows; two launches through `control` otherwise.  control [N, A]: optional
+ * where one launch is taken (it receives the expanded control when given), REQUIRED (the buffer between the two launches) for any
+ * other layout -- MGX_ERR_INVALID without it.  lists as in mgx_expand_lists; the other outputs are those of mgx_step. */
+int mgx_step_lists(mgx_handle *h, const int32_t *action_id, const int32_t *lists, int32_t n_lists, int32_t list_len,
+                   double *control, double *reward, uint8_t *done, void *obs, double *log, mgx_stream stream);
 
 /* K fused DiscreteMicrogridEnv steps with the control expanded ON DEVICE: action_id holds priority-list ids as
  * bytes, either [K, N] (per_step != 0: `for a in ids: env.step(a)`, discrete.py:109-143) or [N] (per_step == 0: one

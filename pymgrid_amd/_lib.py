@@ -26,7 +26,7 @@ V_EXPAND_CONSUME, V_EXPAND_PRODUCE, V_EXPAND_SIGN = 64, 128, 256
 V_EXPAND = V_EXPAND_CONSUME | V_EXPAND_PRODUCE | V_EXPAND_SIGN      # states in which _populate_action asserts
 V_ASSERTS = V_GENSET_GOAL | V_GENSET_NEGATIVE | V_NEGATIVE_LIMIT | V_EXPAND    # the reference raises whatever raise_errors says
 ABI_VERSION = 9
-ABI_MINOR = 1
+ABI_MINOR = 2
 # enum mgx_tunable (process-wide launch-shape knobs; set_tunable / get_tunable below)
 TUNABLES = ("win_threads", "win_group", "win_pairs", "win_min_lds", "prefetch_pool", "multi_generic", "multi_small_own",
             "grid_major_copy", "fleet_byvalue", "launch_threads", "multi_static")
@@ -174,6 +174,7 @@ SYMBOLS = {
     "mgx_patch_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgx_expand_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_rollout_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7),
+    "mgx_step_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6),
     "mgx_step_discrete": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_rollout_discrete": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_i32_p, C.c_int32, C.c_int32, C.c_void_p,

@@ -1741,6 +1741,33 @@ int mgx_expand_lists(mgx_handle *h, const int32_t *action_id, const int32_t *lis
     return launch_expand_lists(h, action_id, lists, n_lists, list_len, control, violations, (hipStream_t)stream);
 }
 
+int mgx_step_lists(mgx_handle *h, const int32_t *action_id, const int32_t *lists, int32_t n_lists, int32_t list_len,
+                   double *control, double *reward, uint8_t *done, void *obs, double *log, mgx_stream stream)
+{
+    g_err[0] = 0;
+    if (!h || !action_id || !lists) return fail(MGX_ERR_INVALID, "mgx_step_lists: NULL argument");
+    if (n_lists <= 0 || list_len <= 0 || list_len > 3 * MGX_MAX_INSTANCES)
+        return fail(MGX_ERR_INVALID, "mgx_step_lists: need n_lists > 0 and list_len in [1, %d]", 3 * MGX_MAX_INSTANCES);
+    if (int rc = check_step_args(h, action_id, reward, obs, 1, "mgx_step_lists")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool noisy_rows = obs && !h->k.obs_state_only && (h->k.c.load_noise_std || h->k.c.pv_noise_std || h->k.c.grid_noise_std);
+    const bool one_launch = h->multi && h->multi_small && !h->inplace && !h->rolling && !noisy_rows && tune(MGX_TUNE_MULTI_SMALL_OWN) != 0 &&
+                            h->k.n_load >= 1 && h->k.n_pv >= 1;
+    if (!one_launch) {                                    // any other layout: the control passes through the caller's buffer
+        if (!control) return fail(MGX_ERR_INVALID, "mgx_step_lists: this layout steps in two launches and needs the control buffer [N, A]");
+        if (int rc = launch_expand_lists(h, action_id, lists, n_lists, list_len, control, nullptr, st)) return rc;
+        return step_once(h, control, 0, reward, done, obs, log, st);
+    }
+    for_each_shard_threaded(h, st, [&](const KArgs &k, hipStream_t s) {
+        MGX_DISPATCH_F(h->flags, (step_lists_small_kernel<F><<<multi_blocks(k.g1 - k.g0), BLOCK_MULTI, 0, s>>>(
+                                      k, action_id, lists, n_lists, list_len, t_arg(h), control, reward, done, obs, log)));
+    });
+    hipError_t e = launch_error();
+    if (e != hipSuccess) return hip_fail(e, "step_lists_small_kernel launch");
+    advance(h, 1, st);
+    return MGX_OK;
+}
+
 int mgx_check_discrete(mgx_handle *h, const int32_t *action_id, const int32_t *table, int32_t n_actions, uint32_t *violations,
                        mgx_stream stream)
 {

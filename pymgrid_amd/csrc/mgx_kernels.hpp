@@ -2324,6 +2324,53 @@ __global__ __launch_bounds__(BLOCK_MULTI, (M >= 3 ? MGX_M3_WAVES : 1)) void step
     advance_counter_in_kernel(a, K_launch);
 }
 
+// mgx_step_lists on the register form (round 6, ABI minor 2): ONE discrete Gym step of a layout with at most MS modules of a kind --
+// the grid's priority list packed into a word, walked out of registers (populate_multi_small), the step, the observation.  What
+// DiscreteMicrogridEnv.step was as two launches (expand_multi_kernel -> control [N, A] -> step_multi_kernel).
+template <int F>
+__global__ __launch_bounds__(BLOCK_MULTI) void step_lists_small_kernel(const KArgs a, const int32_t *__restrict__ ids,
+                                                                       const int32_t *__restrict__ lists, int32_t n_lists, int32_t list_len,
+                                                                       int32_t t, double *__restrict__ control, double *__restrict__ reward,
+                                                                       uint8_t *__restrict__ done, void *__restrict__ obs,
+                                                                       double *__restrict__ log)
+{
+    t = resolve_t(a, t);
+    const int64_t i = (int64_t)a.g0 + (int64_t)blockIdx.x * BLOCK_MULTI + threadIdx.x;
+    if (i < a.g1) {
+        const int NG = a.n_genset, NB = a.n_battery, NR = a.n_grid;
+        Outputs o;
+        MultiRegs R; MultiStepIn sin;
+        load_multi_regs<F>(a, i, R);
+        load_multi_series<F>(a, i, t, sin);
+        int32_t id = ids[i];
+        id = (id >= 0 && id < n_lists) ? id : 0;              // ids outside [0, n) fall back to list 0 (the reference raises)
+        const uint64_t plw = pack_priority_list(lists + (int64_t)id * list_len * 3, list_len, NG, NB, NR);
+        const uint32_t xv = populate_multi_small<F, CountsRT, MS>(a, R, plw, sin, nullptr, log != nullptr);
+        if (control) {                                         // the expanded control, in mgx_expand_lists' column order
+            double *c = control + i * (2 * NG + NB + NR);
+#pragma unroll
+            for (int j = 0; j < MS; j++) {
+                if (j < NG) { c[2 * j] = sin.goal[j]; c[2 * j + 1] = sin.gen[j]; }
+                if (j < NB) c[2 * NG + j] = sin.bat[j];
+                if (j < NR) c[2 * NG + NB + j] = sin.grd[j];
+            }
+        }
+        step_multi_small<F>(a, R, sin, i, false, log ? log + i : nullptr, o, nullptr, xv);
+        store_multi_state<F>(a, i, R);
+        reward[i] = shaped_reward<F>(a.shaper, o);
+        if (done) done[i] = done_at(a, i, t);
+        if (obs) {
+            if (a.obs_state_only == 1 && a.obs_colpitch) {
+                const int64_t P = a.obs_colpitch, k0 = (int64_t)(a.n_load + a.n_pv) * (1 + a.H);
+                if (a.obs_f32) observe_state_multi<F>(a, i, (float *)obs + k0 * P + i, P);
+                else observe_state_multi<F>(a, i, (double *)obs + k0 * P + i, P);
+            } else if (a.obs_f32) observe_row_multi<F>(a, i, t + 1, (float *)obs + i * a.obs_dim);
+            else observe_row_multi<F>(a, i, t + 1, (double *)obs + i * a.obs_dim);
+        }
+    }
+    advance_counter_in_kernel(a, 1);
+}
+
 // mgx_rollout_lists on the register form (round 6): K fused steps whose controls come from a priority list over module instances --
 // RuleBasedControl on a layout with several modules of a kind (rbc.py:64-93; ids [N]: one fixed list per grid) or a discrete roll-out
 // (ids [K, N]).  The loop of step_k_multi_small_kernel with populate_multi_small in place of the action stream: per step only the

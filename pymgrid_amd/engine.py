@@ -627,6 +627,41 @@ class StepEngine:
             self._t += 1
         return obs, reward, done, log, control
 
+    def step_lists(self, action_id, lists, want_obs=True, want_log=False, out=None, want_done=True):
+        """DiscreteMicrogridEnv.step with priority lists over module instances (``mgx_step_lists``): one launch where the layout holds
+        at most two modules of a kind, expand + step through a control buffer otherwise.  ``lists`` as for ``expand_lists``.
+        Returns (obs|None, reward, done, log|None)."""
+        if action_id.dtype != torch.int32 or tuple(action_id.shape) != (self.N,) or action_id.device != self.device or not action_id.is_contiguous():
+            raise ValueError(f"action_id must be a contiguous int32 tensor of shape ({self.N},) on {self.device}")
+        if lists.dtype != torch.int32 or lists.dim() != 3 or lists.shape[2] != 3 or lists.device != self.device or not lists.is_contiguous():
+            raise ValueError(f"lists must be a contiguous int32 tensor [n_lists, list_len, 3] on {self.device}")
+        out = out or {}
+        reward = out.get("reward") if out.get("reward") is not None else self._empty(self.N)
+        done = (out.get("done") if out.get("done") is not None else self._empty(self.N, dtype=torch.uint8)) if want_done else None
+        obs = self._obs_buf(out.get("obs")) if want_obs else None
+        log = (out.get("log") if out.get("log") is not None else self._empty(self.log_dim, self.N)) if want_log else None
+        L = self.layout
+        one_launch = L.multi and max(L.n_genset, L.n_battery, L.n_grid, L.n_load, L.n_pv) <= 2 and min(L.n_load, L.n_pv) >= 1
+        control = None
+        if not one_launch or out.get("control") is not None:       # (the buffer between the two launches; kept on the engine)
+            control = out.get("control")
+            if control is None:
+                control = getattr(self, "_lists_control", None)
+                if control is None:
+                    control = self._lists_control = self._empty(self.N, self.action_dim)
+        try:
+            self._call(self._lib.mgx_step_lists, _ptr(action_id), _ptr(lists), int(lists.shape[0]), int(lists.shape[1]), _ptr(control),
+                       reward.data_ptr(), _ptr(done), _ptr(obs), _ptr(log))
+        except Exception:
+            if control is not None:
+                raise
+            control = self._lists_control = self._empty(self.N, self.action_dim)      # (in-place episodes, noisy rows: two launches after all)
+            self._call(self._lib.mgx_step_lists, _ptr(action_id), _ptr(lists), int(lists.shape[0]), int(lists.shape[1]), _ptr(control),
+                       reward.data_ptr(), _ptr(done), _ptr(obs), _ptr(log))
+        if self._t is not None:
+            self._t += 1
+        return obs, reward, done, log
+
     def rollout_discrete(self, action_id, table, K, reward=True, done=False, soc_trace=False, status_trace=False,
                          ret_acc=None, log=False, out=None):
         """K fused discrete steps with on-device action expansion.  ``action_id`` uint8: [K, N] (an id per step) or

@@ -1036,7 +1036,26 @@ class DiscreteBatchedMicrogridEnv(BatchedMicrogridEnv):
                 if not self.raise_errors:                   # (with raise_errors the base class's dry run reports every bit)
                     self._raise_on_violations(self.engine.check_step(control, normalized=False), asserts_only=True)
                 return super().step(control, normalized=False)
-            return super().step(self.get_action(action_id), normalized=False)
+            if not self._instances or self.raise_errors or self._views or self._fleet_owned or self._fp is not None:
+                return super().step(self.get_action(action_id), normalized=False)
+            # priority lists over module instances: expansion and step in one call (mgx_step_lists: one launch for two of a kind)
+            if not (torch.is_tensor(action_id) and action_id.dtype == torch.int32 and action_id.is_contiguous()
+                    and action_id.device == self.batch.device):
+                action_id = torch.as_tensor(np.asarray(action_id.cpu() if torch.is_tensor(action_id) else action_id),
+                                            device=self.batch.device).to(torch.int32).contiguous()
+            if action_id.shape != (self.n_grids,):
+                raise ValueError(f"action_id must be an int32 tensor of shape ({self.n_grids},) on {self.batch.device}")
+            want_obs, out = self._obs_target()
+            dconst = self._lockstep_done()
+            obs, reward, done, log = self.engine.step_lists(action_id, self._lists, want_obs=want_obs, want_log=self._keep_log, out=out,
+                                                            want_done=dconst is None)
+            obs = self._obs_after(obs)
+            info = {}
+            if log is not None:
+                self._log_rows.append(log)
+                self._shaped_rows.append(reward.clone())
+                info["log"] = log
+            return self._select_obs(obs), reward, (dconst if dconst is not None else done.view(torch.bool)), info
         if not (torch.is_tensor(action_id) and action_id.dtype == torch.int32 and action_id.is_contiguous()
                 and action_id.device == self.batch.device):
             if not torch.is_tensor(action_id):

@@ -187,3 +187,61 @@ def test_list_rollouts_on_the_register_form_equal_the_run_time_form(device):
                 for k in x:
                     assert torch.equal(x[k], y[k]), ((ng, nb, nr, nl, npv), k)
         assert float(a1["reward"].std()) > 0
+
+
+@pytest.mark.gpu
+def test_discrete_step_over_instance_lists_in_one_call(device):
+    """mgx_step_lists (ABI minor 2): DiscreteMicrogridEnv.step over priority lists of module instances -- one launch for layouts of at
+    most two of a kind (the walk in registers), expand + step through the control buffer for three of a kind -- against the two calls
+    it replaces (mgx_expand_lists -> control -> mgx_step(normalized=0)): control, reward, done, observation rows (H = 0 and H = 6, float64
+    and float32), every log column and the state, step after step; the discrete env takes the call."""
+    import torch
+    from pymgrid_amd import DiscreteBatchedMicrogridEnv, StepEngine
+    from pymgrid_amd.generator import generate, widen
+    g = torch.Generator(device=device); g.manual_seed(31)
+    for (ng, nb, nr, nl, npv), arch, H in (((2, 2, 1, 1, 1), "genset+battery+grid", 0), ((2, 2, 2, 2, 1), "genset+battery+grid", 6),
+                                           ((1, 2, 0, 1, 1), "genset+battery", 6), ((0, 2, 2, 1, 2), "battery+grid", 0),
+                                           ((3, 2, 1, 1, 1), "genset+battery+grid", 0)):
+        N, T, K = 900, 50, 14
+        rs = np.random.RandomState(7 + 10 * ng + nb)
+        mods = [(0, j) for j in range(ng)] + [(1, j) for j in range(nb)] + [(2, j) for j in range(nr)]
+        tab = -np.ones((16, len(mods) + 2, 3), dtype=np.int32)
+        for q in range(16):
+            els = [(k, j, int(rs.randint(0, 2)) if k == 0 else 0) for k, j in (mods[p] for p in rs.permutation(len(mods)))]
+            els.insert(int(rs.randint(0, len(els) + 1)), (-1, -1, -1))
+            els.insert(int(rs.randint(1, len(els) + 1)), els[0])
+            tab[q, :len(els)] = els
+        lists = torch.as_tensor(tab, device=device).contiguous()
+
+        def batch():
+            return widen(generate(N, n_steps=T, seed=5, arch=arch, horizon=H, device=device, mixed_timers=True), n_genset=ng, n_battery=nb,
+                         n_grid=nr, n_load=nl, n_pv=npv)
+        for f32 in (False, True):
+            one, two = StepEngine(batch()), StepEngine(batch())
+            if f32:
+                one.set_obs_dtype(torch.float32); two.set_obs_dtype(torch.float32)
+            one.reset(1, want_obs=False); two.reset(1, want_obs=False)
+            for k in range(K):
+                ids = torch.randint(-1, 17, (N,), dtype=torch.int32, device=device, generator=g)
+                ctrl1 = torch.empty(N, one.action_dim, dtype=torch.float64, device=device)
+                o1, r1, d1, l1 = one.step_lists(ids, lists, want_obs=True, want_log=True, out=dict(control=ctrl1))
+                ctrl2 = two.expand_lists(ids, lists)
+                o2, r2, d2, l2 = two.step(ctrl2, normalized=False, want_obs=True, want_log=True)
+                assert torch.equal(ctrl1, ctrl2), ((ng, nb, nr), k, "control")
+                assert torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(l1, l2), ((ng, nb, nr), k)
+                assert torch.equal(o1, o2), ((ng, nb, nr), k, "obs")
+            for name in ("charge", "soc", "gen_status"):
+                if name in one.batch.cols:
+                    assert torch.equal(one.batch.cols[name], two.batch.cols[name])
+            assert one.current_step == two.current_step == 1 + K
+            one.close(); two.close()
+    # the env: ids -> (obs, reward, done, info) through the one call == expansion + continuous step
+    a, b = DiscreteBatchedMicrogridEnv(batch(), log=True), DiscreteBatchedMicrogridEnv(batch(), log=True)
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    for k in range(10):
+        ids = a.sample_action(generator=g)
+        oa, ra, da, ia = a.step(ids)
+        ob, rb, db, ib = super(DiscreteBatchedMicrogridEnv, b).step(b.get_action(ids), normalized=False)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ia["log"], ib["log"]), k
+    a.close(); b.close()
