@@ -237,7 +237,7 @@ def test_hot_kernels_use_no_scratch_memory():
     if usage is None:
         pytest.skip("libmgx.so was not built on this machine (no resource_usage.json beside the objects)")
     hot = ("step_kernel", "step_discrete_kernel", "step_k_kernel", "rollout_kernel", "fleet_step_kernel", "fleet_step_kernel_v", "fleet_step_kernel_vm", "observe_kernel",
-           "step_multi_kernel", "step_k_multi_small_kernel", "rollout_multi_small_kernel",
+           "step_multi_kernel", "step_k_multi_small_kernel", "rollout_multi_small_kernel", "step_lists_small_kernel",
            "obs_rows_wave_kernel", "obs_windows_k_kernel", "patch_windows_kernel", "expand_kernel", "check_kernel",
            "normalise_series_kernel", "gather_windows_kernel", "synthesize_series_kernel")
     seen = 0
