@@ -54,3 +54,20 @@ def test_c_abi_consumer_2_matches_the_oracle():
     res = subprocess.run([build_demo(SRC2, EXE2)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert ": 0 mismatches" in res.stdout
+
+
+# the general path (several modules of a kind) from C++: mgx_step, mgx_step_k, mgx_expand_lists, mgx_step_lists (ABI minor 2),
+# mgx_rollout_lists against the oracle's multi-instance restatement -- tests/c_abi/demo3.cpp
+SRC3 = os.path.join(ROOT, "tests", "c_abi", "demo3.cpp")
+EXE3 = os.path.join(ROOT, "tests", "c_abi", "_build", "demo3")
+
+
+def test_c_abi_consumer_3_builds():
+    assert os.path.exists(build_demo(SRC3, EXE3))
+
+
+@pytest.mark.gpu
+def test_c_abi_consumer_3_matches_the_oracle():
+    res = subprocess.run([build_demo(SRC3, EXE3)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert ": 0 mismatches" in res.stdout
