@@ -119,3 +119,41 @@ def test_per_grid_windows_of_multi_instance_grids(device, wide, K):
     env.reset()                                                # a plain reset returns to the shared window
     assert int(env.current_steps.max()) == 0
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("windows, shards", [(True, 1), (False, 2)])
+def test_discrete_steps_of_multi_instance_grids_in_per_grid_windows(device, windows, shards):
+    """mgx_step_lists (the one-launch discrete step of the general path) on a handle in per-grid windows (mgx_reset_windows: gathered
+    window buffers, `done` per grid) -- and, in lock-step, over two shards (shards are not offered during per-grid windows) -- ==
+    expansion + continuous step of a twin env, step by step."""
+    from pymgrid_amd import DiscreteBatchedMicrogridEnv
+    from pymgrid_amd.generator import generate, widen
+    N, T, steps = 300, 80, 20
+
+    def make():
+        base = generate(N, n_steps=T, seed=21, arch="genset+battery+grid", horizon=4, device=device)
+        return DiscreteBatchedMicrogridEnv(widen(base, n_genset=2, n_battery=2, n_grid=1), obs_prefetch=0, remove_redundant_gensets=False)
+    gen = torch.Generator(device=device); gen.manual_seed(9)
+    start = torch.randint(0, 40, (N,), device=device, generator=gen).to(torch.int32)
+    length = torch.randint(5, steps + 1, (N,), device=device, generator=gen).to(torch.int32)
+    a, b = make(), make()
+    if windows:
+        oa, ob = a.reset_windows(start, length, max_length=steps), b.reset_windows(start, length, max_length=steps)
+    else:
+        oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    if shards > 1:
+        a.engine.set_shards(shards); a.engine.fork()
+    for k in range(steps):
+        ids = a.sample_action(generator=gen)
+        oa, ra, da, _ = a.step(ids)
+        ob, rb, db, _ = super(DiscreteBatchedMicrogridEnv, b).step(b.get_action(ids), normalized=False)
+        if shards > 1:
+            a.engine.join(); a.engine.fork()
+        assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(oa, ob), k
+    if shards > 1:
+        a.engine.join(); a.engine.set_shards(1)
+    for name in ("charge", "soc", "gen_status"):
+        assert torch.equal(a.batch.cols[name], b.batch.cols[name])
+    a.close(); b.close()
